@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — filtered scan of a 1e9-row Int64 column at 10 % selectivity on MI355X (BASELINE.json config 2).
+
+One "step" = the whole hot path over the resident column: predicate scan `x > 899999` -> selection bitmap
++ tile counts (K1), exclusive scan of the counts, compaction to ascending 1-based Int64 row indices (K2),
+count left on the device (and all-reduced over ranks when --gpus > 1).  The column is generated in HBM
+(splitmix64) before the timed region; outputs stay in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU: contiguous block-range shards (rank r owns rows [r*rows, (r+1)*rows)), no data-path collective,
+one RCCL all-reduce of the 8-byte count per step ("scaling": "weak").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SEED = 0x9E3779B97F4A7C15
+THRESHOLD = 899_999          # x > c over h mod 1e6  ->  10 % selectivity
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def cpu_baseline(rows: int, repeats: int):
+    """The oracle (C restatement of the reference's block_streams path) on ONE host core over a bounded
+    sample of the same workload: LZ4 block decode -> mask -> LogicalIndex -> row indices."""
+    import numpy as np
+    from oracle import oracle as O
+    from dfdb import ir
+    x = O.gen_i64(SEED, 0, rows)
+    t = O.Table(block_size=65536)
+    t.add_column("x", x)
+    del x
+    v = t.view().add_predicate((ir.col(0) > THRESHOLD).to_ir())
+    best = None
+    nsel = 0
+    for _ in range(repeats):
+        nsel, sec, _ = v.bench_scan(0)
+        best = sec if best is None else min(best, sec)
+    st = t.column_stats(0)
+    return dict(value=rows / best, unit="rows/s", cores=1, kind="port",
+                sample=f"{rows} rows ({st['blocks']} LZ4 blocks of 65536, ratio {st['uncompressed'] / st['compressed']:.2f}), "
+                       f"best of {repeats}, {nsel} selected; count-only pass of select_indices (decode + mask + index)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--cpu-rows", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    import dfdb
+    from dfdb import ir
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = dfdb.Context(local, stream=stream)
+    info = ctx.device_info()
+
+    rows = args.rows
+    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+    t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
+    t.set_row_base(rank * rows)
+    v = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]
+    q = v._query()
+    nsel = q.count()                                   # exact selected count from the first (untimed) execution
+    cap = nsel
+    out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        q.execute()                                    # K1 + count scan
+        q.indices_device(out.data_ptr(), cap)          # K2
+        q.count_device(cnt.data_ptr())
+        if world > 1:
+            dist.all_reduce(cnt)                       # the only exchange: 8 bytes
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    total_sel = int(cnt.item())
+
+    # ---- roofline leg: HIP events around each launch of the dominant kernel, on the launch stream
+    ctx.profile(True)
+    prof_steps = max(3, min(args.steps, 10))
+    for _ in range(prof_steps):
+        q.execute()
+        q.indices_device(out.data_ptr(), cap)
+    torch.cuda.synchronize()
+    kernels = {}
+    for k in ("scan_cmp", "scan_counts", "compact_indices"):
+        n, ms = ctx.profile_get(k)
+        if n:
+            kernels[k] = dict(launches=n, avg_ms=ms / n)
+    ctx.profile(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * rows * args.steps / elapsed
+        sigma = nsel / rows
+        # algorithmic bytes of ONE scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
+        scan_bytes = rows * (8 + 1 / 8 + 4 / 1024)
+        scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
+        job_bytes = rows * (8 + 8 * sigma)             # 8 + 8*sigma B/row for the whole job
+        res = {
+            "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "Int64 column, selection(x -> x > 899999) -> ascending 1-based Int64 row indices + count",
+                       "rows_per_gpu": rows, "selected_per_gpu": nsel, "selectivity": sigma, "block_size": 65536,
+                       "sharding": f"contiguous block ranges x{world}, all-reduce(count) per step" if world > 1 else "single GPU",
+                       "device": info["name"], "global_selected": total_sel},
+            "job_hbm_gbps": job_bytes * world / (elapsed / args.steps) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_scan_cmp<int64,GT>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
+        }
+        if not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

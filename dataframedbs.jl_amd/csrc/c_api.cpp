@@ -1,0 +1,242 @@
+// c_api.cpp — the extern "C" boundary of libdfdb_hip.so (include/dfdb.h).  Every entry point converts
+// engine exceptions to status codes; nothing else crosses the ABI.
+#include "engine.hpp"
+#include <cstdio>
+
+using namespace dfdb;
+
+static thread_local std::string g_last_error;
+
+template <class F>
+static int32_t guard(F&& f) noexcept {
+  try { f(); return DFDB_OK; }
+  catch (const Error& e) { g_last_error = e.what(); return e.code; }
+  catch (const std::bad_alloc&) { g_last_error = "out of host memory"; return DFDB_ERR_NOMEM; }
+  catch (const std::exception& e) { g_last_error = e.what(); return DFDB_ERR_DEVICE; }
+  catch (...) { g_last_error = "unknown error"; return DFDB_ERR_DEVICE; }
+}
+#define NEED(p) do { if (!(p)) fail(DFDB_ERR_ARGUMENT, "null argument: " #p); } while (0)
+
+namespace dfdb {
+LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n) : ctx(c), name(n) {
+  if (ctx->profiling) (void)hipEventRecord(ctx->pev0, ctx->stream);
+}
+LaunchTimer::~LaunchTimer() {
+  if (!ctx->profiling) return;
+  (void)hipEventRecord(ctx->pev1, ctx->stream);
+  (void)hipEventSynchronize(ctx->pev1);
+  float ms = 0; (void)hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1);
+  auto& e = ctx->prof[name]; e.launches++; e.ms += ms;
+}
+}  // namespace dfdb
+
+extern "C" {
+
+int32_t dfdb_version(void) { return DFDB_ABI_VERSION; }
+
+int32_t dfdb_last_error(char* buf, size_t cap) {
+  if (buf && cap) { snprintf(buf, cap, "%s", g_last_error.c_str()); }
+  return (int32_t)g_last_error.size();
+}
+
+// ------------------------------------------------------------------ context
+int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out) {
+  return guard([&] {
+    NEED(out);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) fail(DFDB_ERR_DEVICE, "no HIP device visible (%s): libdfdb_hip has no CPU fallback", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) fail(DFDB_ERR_ARGUMENT, "device %d out of range (have %d)", device_id, ndev);
+    auto c = std::make_unique<dfdb_ctx>();
+    c->device = device_id;
+    HIP_CHECK(hipSetDevice(device_id));
+    HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
+    if (std::string(c->prop.gcnArchName).rfind("gfx950", 0) != 0)
+      fail(DFDB_ERR_DEVICE, "libdfdb_hip is built for gfx950 (MI355X); device %d is %s", device_id, c->prop.gcnArchName);
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
+    HIP_CHECK(hipEventCreate(&c->pev0)); HIP_CHECK(hipEventCreate(&c->pev1));
+    HIP_CHECK(hipHostMalloc((void**)&c->pinned_scalar, 64, hipHostMallocDefault));
+    *out = c.release();
+  });
+}
+int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
+  return guard([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); (void)hipEventDestroy(ctx->pev0); (void)hipEventDestroy(ctx->pev1);
+    if (ctx->pinned_scalar) (void)hipHostFree(ctx->pinned_scalar);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx) { return guard([&] { NEED(ctx); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out) {
+  return guard([&] {
+    NEED(ctx); NEED(out);
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    // memoryClockRate is kHz; HBM is double data rate
+    out->peak_hbm_gbps = 2.0 * (double)ctx->prop.memoryClockRate * 1e3 * ((double)ctx->prop.memoryBusWidth / 8.0) / 1e9;
+  });
+}
+int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx) { return guard([&] { NEED(ctx); HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream)); }); }
+int32_t dfdb_ctx_timer_stop(dfdb_ctx* ctx, double* elapsed_ms) {
+  return guard([&] {
+    NEED(ctx); NEED(elapsed_ms);
+    HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = ms;
+  });
+}
+int32_t dfdb_ctx_profile_enable(dfdb_ctx* ctx, int32_t on) { return guard([&] { NEED(ctx); ctx->profiling = on != 0; if (on) ctx->prof.clear(); }); }
+int32_t dfdb_ctx_profile_get(dfdb_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms) {
+  return guard([&] {
+    NEED(ctx); NEED(kernel);
+    auto it = ctx->prof.find(kernel);
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+  });
+}
+
+// ------------------------------------------------------------------ tables
+int32_t dfdb_table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out) { return guard([&] { NEED(ctx); NEED(path); NEED(out); table_open(ctx, path, out); }); }
+int32_t dfdb_table_new(dfdb_ctx* ctx, int64_t block_size, dfdb_table** out) {
+  return guard([&] {
+    NEED(ctx); NEED(out);
+    auto t = std::make_unique<dfdb_table>();
+    t->ctx = ctx; t->block_size = block_size > 0 ? block_size : 65536;
+    *out = t.release();
+  });
+}
+int32_t dfdb_table_close(dfdb_table* t) { return guard([&] { if (t) { (void)hipStreamSynchronize(t->ctx->stream); delete t; } }); }
+int32_t dfdb_table_ncols(dfdb_table* t, int32_t* n) { return guard([&] { NEED(t); NEED(n); *n = (int32_t)t->cols.size(); }); }
+int32_t dfdb_table_nrows(dfdb_table* t, int64_t* n) { return guard([&] { NEED(t); NEED(n); *n = t->nrows < 0 ? 0 : t->nrows; }); }
+int32_t dfdb_table_block_size(dfdb_table* t, int64_t* bs) { return guard([&] { NEED(t); NEED(bs); *bs = t->block_size; }); }
+int32_t dfdb_table_colinfo(dfdb_table* t, int32_t ordinal, dfdb_colinfo* out) {
+  return guard([&] {
+    NEED(t); NEED(out);
+    if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
+    const Column& c = t->cols[(size_t)ordinal];
+    memset(out, 0, sizeof *out);
+    out->id = c.id; snprintf(out->name, sizeof out->name, "%s", c.name.c_str()); out->dtype = c.dtype; out->resident = c.resident ? 1 : 0;
+  });
+}
+int32_t dfdb_table_find_column(dfdb_table* t, const char* name, int32_t* ordinal) {
+  return guard([&] {
+    NEED(t); NEED(name); NEED(ordinal);
+    for (size_t i = 0; i < t->cols.size(); i++) if (t->cols[i].name == name) { *ordinal = (int32_t)i; return; }
+    fail(DFDB_ERR_KEY, "KeyError: key :%s not found", name);   // getmeta: table.jl:52-56
+  });
+}
+int32_t dfdb_table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {
+  return guard([&] { NEED(t); table_load(t, ordinals, ncols, block_first, block_last, stats); });
+}
+int32_t dfdb_table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,
+                              dfdb_sizestats* stats) {
+  return guard([&] { NEED(t); NEED(image); table_load_image(t, ordinal, image, nbytes, block_first, block_last, stats); });
+}
+int32_t dfdb_table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nrows, const void* data, const uint8_t* bytes,
+                              int64_t nbytes, const uint8_t* missing) {
+  return guard([&] { NEED(t); NEED(name); if (nrows > 0) NEED(data); table_add_column(t, name, dtype, nrows, data, bytes, nbytes, missing); });
+}
+int32_t dfdb_table_add_generated(dfdb_table* t, const char* name, int32_t generator, uint64_t seed, int64_t row_first, int64_t nrows) {
+  return guard([&] { NEED(t); NEED(name); table_add_generated(t, name, generator, seed, row_first, nrows); });
+}
+int32_t dfdb_table_set_row_base(dfdb_table* t, int64_t row_base) { return guard([&] { NEED(t); t->row_base = row_base; }); }
+
+// ------------------------------------------------------------------ queries
+int32_t dfdb_query_new(dfdb_table* t, dfdb_query** out) {
+  return guard([&] {
+    NEED(t); NEED(out);
+    auto q = std::make_unique<dfdb_query>();
+    q->t = t;
+    for (size_t i = 0; i < t->cols.size(); i++) {   // full_table_projection: view.jl:43-48
+      auto n = std::make_unique<Node>(); n->op = DFIR_COL; n->col = (int)i; n->dtype = t->cols[i].dtype;
+      q->proj.push_back(ProjCol{t->cols[i].name, std::move(n)});
+    }
+    *out = q.release();
+  });
+}
+int32_t dfdb_query_free(dfdb_query* q) { return guard([&] { if (q) { (void)hipStreamSynchronize(q->t->ctx->stream); delete q; } }); }
+int32_t dfdb_query_add_range(dfdb_query* q, int64_t start, int64_t step, int64_t stop) {
+  return guard([&] { NEED(q); Stage s; s.kind = ST_RANGE; s.start = start; s.step = step; s.stop = stop; query_add_stage(q, std::move(s)); });
+}
+int32_t dfdb_query_add_indices(dfdb_query* q, const int64_t* idx, int64_t n) {
+  return guard([&] {
+    NEED(q); if (n > 0) NEED(idx);
+    if (n < 0) fail(DFDB_ERR_ARGUMENT, "negative index count");
+    Stage s; s.kind = ST_INDICES; s.idx.assign(idx, idx + n);
+    query_add_stage(q, std::move(s));
+  });
+}
+int32_t dfdb_query_add_integer(dfdb_query* q, int64_t i) {
+  return guard([&] { NEED(q); Stage s; s.kind = ST_INTEGER; s.idx = {i}; query_add_stage(q, std::move(s)); });
+}
+int32_t dfdb_query_add_predicate(dfdb_query* q, const uint8_t* ir, size_t len) {
+  return guard([&] {
+    NEED(q); NEED(ir);
+    Stage s; s.kind = ST_PRED; s.pred = parse_ir(*q->t, ir, len);
+    if (s.pred->dtype != DFDB_BOOL) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Function for selection must have Bool result type");   // selection.jl:52-55
+    query_add_stage(q, std::move(s));
+  });
+}
+int32_t dfdb_query_nstages(dfdb_query* q, int32_t* n) { return guard([&] { NEED(q); NEED(n); *n = (int32_t)q->stages.size(); }); }
+int32_t dfdb_query_set_projection(dfdb_query* q, int32_t n, const char* const* names, const uint8_t* const* irs, const size_t* lens) {
+  return guard([&] {
+    NEED(q); if (n > 0) { NEED(names); NEED(irs); NEED(lens); }
+    std::vector<ProjCol> np;
+    for (int32_t i = 0; i < n; i++) {
+      for (int32_t j = 0; j < i; j++) if (std::string(names[j]) == names[i]) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", names[i]);   // projection.jl:25-28
+      np.push_back(ProjCol{names[i], parse_ir(*q->t, irs[i], lens[i])});
+    }
+    q->proj = std::move(np);
+  });
+}
+int32_t dfdb_query_ncols(dfdb_query* q, int32_t* n) { return guard([&] { NEED(q); NEED(n); *n = (int32_t)q->proj.size(); }); }
+int32_t dfdb_query_coltype(dfdb_query* q, int32_t i, int32_t* dtype) {
+  return guard([&] {
+    NEED(q); NEED(dtype);
+    if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
+    *dtype = q->proj[(size_t)i].expr->dtype;
+  });
+}
+int32_t dfdb_expr_result_type(dfdb_table* t, const uint8_t* ir, size_t len, int32_t* dtype) {
+  return guard([&] { NEED(t); NEED(ir); NEED(dtype); *dtype = parse_ir(*t, ir, len)->dtype; });
+}
+int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivors_before) {
+  return guard([&] {
+    NEED(q);
+    if (stage < 0 || (size_t)stage >= q->stages.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: stage %d", stage);
+    q->stages[(size_t)stage].stage_base = survivors_before; q->executed_stages = -1; q->count = -1;
+  });
+}
+int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEED(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
+
+// ------------------------------------------------------------------ execution
+int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEED(q); query_execute(q, -1); }); }
+int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEED(q); NEED(n); *n = query_count(q, -1); }); }
+int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind) {
+  return guard([&] {
+    NEED(q); NEED(out);
+    if (memkind != DFDB_MEM_DEVICE) { *out = query_count(q, -1); return; }
+    if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
+    const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
+    HIP_CHECK(hipMemcpyAsync(out, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
+  });
+}
+int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEED(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
+int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
+  return guard([&] { NEED(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
+}
+int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEED(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
+int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEED(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
+int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEED(q); query_aggregate(q, op, i, out_i, out_f); }); }
+
+}  // extern "C"

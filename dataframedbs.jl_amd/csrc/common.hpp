@@ -1,0 +1,95 @@
+// common.hpp — shared host-side declarations of libdfdb_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/dfdb.h"
+
+namespace dfdb {
+
+// ---- errors: thrown inside the engine, turned into status codes at the C ABI --------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] void fail(int code, const char* fmt, ...);
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) ::dfdb::fail(DFDB_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- dtypes -------------------------------------------------------------------------------------
+inline int dt_base(int32_t dt) { return dt & DFDB_DTYPE_MASK; }
+inline bool dt_nullable(int32_t dt) { return (dt & DFDB_NULLABLE) != 0; }
+inline bool dt_isint(int32_t dt) { int b = dt_base(dt); return b >= DFDB_I8 && b <= DFDB_U64; }
+inline bool dt_issigned(int32_t dt) { int b = dt_base(dt); return b >= DFDB_I8 && b <= DFDB_I64; }
+inline bool dt_isfloat(int32_t dt) { int b = dt_base(dt); return b == DFDB_F32 || b == DFDB_F64; }
+inline bool dt_isnum(int32_t dt) { return dt_isint(dt) || dt_isfloat(dt) || dt_base(dt) == DFDB_BOOL; }
+int dt_width(int32_t dt);
+std::string dt_name(int32_t dt);
+int32_t dt_parse(const std::string& s);
+
+// ---- geometry -----------------------------------------------------------------------------------
+// A "tile" is the unit one wavefront scans: 1024 rows = 16 bitmap words = one 128-B line of bitmap.
+// A "ctile" (compaction tile) is 4096 rows = 64 bitmap words = one word per lane.
+constexpr int64_t kTileRows = 1024;
+constexpr int64_t kTileWords = 16;
+constexpr int64_t kCTileRows = 4096;
+constexpr int64_t kStrTileRows = 1024;  // string byte offsets are kept per 1024 rows
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---- device buffer ------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+  ~DevBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  void ensure(size_t n) {  // grow-only
+    if (n <= bytes && p) return;
+    release();
+    if (n == 0) n = 256;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; fail(DFDB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+    bytes = n;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace dfdb
+
+// ---- context ------------------------------------------------------------------------------------
+struct dfdb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // dfdb_ctx_timer_*
+  bool profiling = false;
+  struct ProfEntry { int64_t launches = 0; double ms = 0; };
+  std::map<std::string, ProfEntry> prof;
+  hipEvent_t pev0 = nullptr, pev1 = nullptr; // per-launch profiling
+  hipDeviceProp_t prop{};
+  int64_t* pinned_scalar = nullptr;          // 64 B of pinned host memory for small readbacks
+};
+
+namespace dfdb {
+// RAII per-launch profiler: when ctx->profiling, brackets a launch with events on the engine stream
+struct LaunchTimer {
+  dfdb_ctx* ctx; const char* name;
+  LaunchTimer(dfdb_ctx* c, const char* n);
+  ~LaunchTimer();
+};
+}  // namespace dfdb

@@ -1,0 +1,85 @@
+// engine.hpp — host-side objects behind the opaque C-ABI handles.
+#pragma once
+#include "common.hpp"
+#include "expr.hpp"
+
+namespace dfdb {
+
+// one column of a table, decoded and resident in HBM as ONE contiguous array over all resident blocks
+// (every block holds block_size rows except the last, so block b starts at row b*block_size)
+struct Column {
+  std::string name;
+  int64_t id = 0;
+  int32_t dtype = 0;
+  bool resident = false;
+  int64_t nrows = 0;
+  DevBuf data;       // fixed width: nrows*width bytes (+ pad); String: int32 sizes[nrows] (-1 = missing)
+  DevBuf bytes;      // String: byte arena (+16 B pad so 8-byte probes never fault)
+  int64_t nbytes = 0;
+  DevBuf tile_off;   // String: u64[nstrtiles+1] byte offset of each 1024-row tile (K4)
+  DevBuf missing;    // nullable fixed width: bitmap, 1 = missing, padded like the selection bitmap
+  // on-disk source (tables opened from files)
+  std::string file;
+  size_t data_off = 0;  // first block inside the file
+};
+
+enum StageKind { ST_RANGE = 0, ST_INTEGER = 1, ST_INDICES = 2, ST_PRED = 3 };
+
+struct Stage {
+  int kind = ST_RANGE;
+  int64_t start = 0, step = 1, stop = 0, n = 0;  // ST_RANGE (stop normalised to the last element)
+  std::vector<int64_t> idx;                      // ST_INDICES / ST_INTEGER, caller order
+  NodePtr pred;                                  // ST_PRED
+  int64_t stage_base = 0;                        // survivors on lower ranks (multi-GPU)
+  int64_t first() const;                         // minimum (RangeToProcess.first)
+  int64_t last() const;                          // maximum (RangeToProcess.last)
+  int64_t elem(int64_t k) const;                 // 1-based element with Julia bounds checking
+};
+
+struct ProjCol { std::string name; NodePtr expr; };
+
+}  // namespace dfdb
+
+struct dfdb_table {
+  dfdb_ctx* ctx = nullptr;
+  std::string path;            // empty for in-memory tables
+  int64_t block_size = 65536;
+  int64_t format_version = 1;
+  std::vector<dfdb::Column> cols;
+  int64_t nrows = -1;          // rows resident (all resident columns agree); -1 = nothing resident yet
+  int64_t row_base = 0;        // global 0-based row of local row 0 (block-range shard)
+  int64_t block_first = 0;     // first resident block
+};
+
+struct dfdb_query {
+  dfdb_table* t = nullptr;
+  std::vector<dfdb::Stage> stages;
+  std::vector<dfdb::ProjCol> proj;
+  // device state of the last execution
+  dfdb::DevBuf bitmap, tile_counts, prefix, scan_scratch, idx_sorted, red_scratch, red_result, tmp_a, tmp_b, tmp_c;
+  int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
+  int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
+  bool prefix_valid = false;
+  int64_t count = -1;          // host copy of the total (valid when >= 0)
+};
+
+namespace dfdb {
+// engine entry points used by c_api.cpp
+void table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out);
+void table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nrows, const void* data, const uint8_t* bytes,
+                      int64_t nbytes, const uint8_t* missing);
+void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t seed, int64_t row_first, int64_t nrows);
+void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t block_first, int64_t block_last, dfdb_sizestats* stats);
+void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,
+                      dfdb_sizestats* stats);
+
+void query_add_stage(dfdb_query* q, Stage&& s);   // composition rules of selection.jl:39-49
+void query_execute(dfdb_query* q, int nstages);   // evaluate stages [0, nstages) -> bitmap + counts + prefix
+int64_t query_count(dfdb_query* q, int nstages);
+void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind);
+void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n);
+int64_t query_string_bytes(dfdb_query* q, int i);
+void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
+void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
+void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
+}  // namespace dfdb

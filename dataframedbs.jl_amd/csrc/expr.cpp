@@ -1,0 +1,287 @@
+// expr.cpp — IR parsing, Julia result typing and kernel routing (see expr.hpp).
+#include "expr.hpp"
+#include "engine.hpp"
+#include <cmath>
+#include <cstdarg>
+
+namespace dfdb {
+
+void fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  throw Error(code, buf);
+}
+
+static const char* kNames[] = {nullptr, "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64",
+                               "Float32", "Float64", "Bool", "String"};
+static const int kWidth[] = {0, 1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 1, 0};
+int dt_width(int32_t dt) { int b = dt_base(dt); return (b >= 1 && b <= 12) ? kWidth[b] : 0; }
+std::string dt_name(int32_t dt) {  // ColumnTypes.typestring: columntypes/base.jl:78-126, complex.jl:1-8
+  int b = dt_base(dt);
+  if (b < 1 || b > 12) return "?";
+  return dt_nullable(dt) ? std::string("Missing(") + kNames[b] + ")" : std::string(kNames[b]);
+}
+int32_t dt_parse(const std::string& s0) {
+  std::string s = s0; int32_t flag = 0;
+  if (s.size() > 9 && s.compare(0, 8, "Missing(") == 0 && s.back() == ')') { flag = DFDB_NULLABLE; s = s.substr(8, s.size() - 9); }
+  for (int b = 1; b <= 12; b++) if (s == kNames[b]) return b | flag;
+  fail(DFDB_ERR_UNSUPPORTED, "UndefinedType: column type '%s' is outside the engine's dtype set", s0.c_str());
+}
+
+int promote_num(int a, int b) {   // Julia promote_type restricted to the column dtypes
+  a = dt_base(a); b = dt_base(b);
+  if (a == DFDB_BOOL && b == DFDB_BOOL) return DFDB_BOOL;
+  if (a == DFDB_BOOL) return b;
+  if (b == DFDB_BOOL) return a;
+  if (a == DFDB_F64 || b == DFDB_F64) return DFDB_F64;
+  if (a == DFDB_F32 || b == DFDB_F32) return DFDB_F32;
+  const int sa = dt_width(a), sb = dt_width(b);
+  if (dt_issigned(a) == dt_issigned(b)) return sa >= sb ? a : b;
+  if (sa != sb) return sa > sb ? a : b;
+  return dt_issigned(a) ? b : a;
+}
+
+// result dtype; throws ArgumentError for Missing-propagating expressions, UNSUPPORTED for absent methods
+static int infer(int op, int ta, int tb) {
+  if (op == DFIR_ISMISSING) return DFDB_BOOL;
+  if (dt_nullable(ta) || (tb && dt_nullable(tb)))
+    fail(DFDB_ERR_ARGUMENT, "ArgumentError: expression over a Union{T,Missing} column yields Missing (wrap it in ismissing)");
+  const int a = dt_base(ta), b = tb ? dt_base(tb) : 0;
+  auto nomethod = [&]() -> int { fail(DFDB_ERR_UNSUPPORTED, "no method for IR op 0x%02x on (%s, %s)", op, dt_name(ta).c_str(), tb ? dt_name(tb).c_str() : "-"); };
+  switch (op) {
+    case DFIR_ADD: case DFIR_SUB:
+      if (!dt_isnum(a) || !dt_isnum(b)) return nomethod();
+      if (a == DFDB_BOOL && b == DFDB_BOOL) return DFDB_I64;
+      return promote_num(a, b);
+    case DFIR_MUL: case DFIR_MIN: case DFIR_MAX:
+      if (!dt_isnum(a) || !dt_isnum(b)) return nomethod();
+      return promote_num(a, b);
+    case DFIR_DIV: {
+      if (!dt_isnum(a) || !dt_isnum(b)) return nomethod();
+      const int p = promote_num(a, b);
+      return dt_isfloat(p) ? p : DFDB_F64;
+    }
+    case DFIR_IDIV: case DFIR_REM: case DFIR_MOD: {
+      if (!dt_isnum(a) || !dt_isnum(b)) return nomethod();
+      const int p = promote_num(a, b);
+      if (p == DFDB_BOOL) return nomethod();
+      return p;
+    }
+    case DFIR_NEG: if (!dt_isnum(a)) return nomethod(); return a == DFDB_BOOL ? DFDB_I64 : a;
+    case DFIR_ABS: if (!dt_isnum(a)) return nomethod(); return a;
+    case DFIR_EQ: case DFIR_NE: case DFIR_LT: case DFIR_LE: case DFIR_GT: case DFIR_GE:
+      if (dt_isnum(a) && dt_isnum(b)) return DFDB_BOOL;
+      if (a == DFDB_STRING && b == DFDB_STRING) return DFDB_BOOL;
+      return nomethod();
+    case DFIR_AND: case DFIR_OR: case DFIR_XOR:
+      if (a == DFDB_BOOL && b == DFDB_BOOL) return DFDB_BOOL;
+      if ((dt_isint(a) || a == DFDB_BOOL) && (dt_isint(b) || b == DFDB_BOOL)) return promote_num(a, b);
+      return nomethod();
+    case DFIR_NOT: if (a != DFDB_BOOL) return nomethod(); return DFDB_BOOL;
+    case DFIR_IN_SET: if (!dt_isnum(a)) return nomethod(); return DFDB_BOOL;
+    case DFIR_STARTSWITH: case DFIR_ENDSWITH: if (a != DFDB_STRING || b != DFDB_STRING) return nomethod(); return DFDB_BOOL;
+    case DFIR_SIZEOF: if (a != DFDB_STRING) return nomethod(); return DFDB_I64;
+  }
+  return nomethod();
+}
+
+NodePtr Node::clone() const {
+  auto n = std::make_unique<Node>();
+  n->op = op; n->dtype = dtype; n->col = col; n->cbits = cbits; n->str = str; n->set = set; n->set_dtype = set_dtype; n->cast_to = cast_to;
+  if (a) n->a = a->clone();
+  if (b) n->b = b->clone();
+  return n;
+}
+NodePtr make_and(NodePtr a, NodePtr b) {
+  auto n = std::make_unique<Node>();
+  n->op = DFIR_AND; n->dtype = DFDB_BOOL; n->a = std::move(a); n->b = std::move(b);
+  return n;
+}
+void required_columns(const Node& n, std::vector<int>& out) {
+  if (n.op == DFIR_COL) { for (int c : out) if (c == n.col) return; out.push_back(n.col); return; }
+  if (n.a) required_columns(*n.a, out);
+  if (n.b) required_columns(*n.b, out);
+}
+void flatten_and(const Node& n, std::vector<const Node*>& out) {
+  if (n.op == DFIR_AND && dt_base(n.dtype) == DFDB_BOOL && n.a && n.b && dt_base(n.a->dtype) == DFDB_BOOL && dt_base(n.b->dtype) == DFDB_BOOL) {
+    flatten_and(*n.a, out); flatten_and(*n.b, out);
+  } else out.push_back(&n);
+}
+
+NodePtr parse_ir(const dfdb_table& t, const uint8_t* ir, size_t len) {
+  std::vector<NodePtr> st;
+  size_t pos = 0;
+  auto need = [&](size_t n) { if (pos + n > len) fail(DFDB_ERR_ARGUMENT, "truncated IR"); };
+  auto pop = [&]() -> NodePtr { if (st.empty()) fail(DFDB_ERR_ARGUMENT, "IR stack underflow"); NodePtr n = std::move(st.back()); st.pop_back(); return n; };
+  while (pos < len) {
+    const int op = ir[pos++];
+    auto n = std::make_unique<Node>();
+    n->op = op;
+    if (st.size() > 60) fail(DFDB_ERR_ARGUMENT, "IR stack overflow");
+    switch (op) {
+      case DFIR_COL: {
+        need(4); uint32_t c; memcpy(&c, ir + pos, 4); pos += 4;
+        if (c >= t.cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %u out of range", c);
+        n->col = (int)c; n->dtype = t.cols[c].dtype; break;
+      }
+      case DFIR_CONST: {
+        need(9); n->dtype = ir[pos]; memcpy(&n->cbits, ir + pos + 1, 8); pos += 9;
+        if (!dt_isnum(n->dtype) || dt_nullable(n->dtype)) fail(DFDB_ERR_ARGUMENT, "bad constant dtype %d", n->dtype);
+        break;
+      }
+      case DFIR_CONST_STR: {
+        need(4); uint32_t l; memcpy(&l, ir + pos, 4); pos += 4; need(l);
+        n->str.assign((const char*)ir + pos, l); pos += l; n->dtype = DFDB_STRING; break;
+      }
+      case DFIR_CONST_SET: {
+        need(5); n->set_dtype = ir[pos]; uint32_t cnt; memcpy(&cnt, ir + pos + 1, 4); pos += 5; need(8ull * cnt);
+        if (!dt_isnum(n->set_dtype)) fail(DFDB_ERR_ARGUMENT, "bad set dtype");
+        n->set.resize(cnt); if (cnt) memcpy(n->set.data(), ir + pos, 8ull * cnt); pos += 8ull * cnt; n->dtype = 0; break;
+      }
+      case DFIR_NEG: case DFIR_ABS: case DFIR_NOT: case DFIR_ISMISSING: case DFIR_SIZEOF: case DFIR_CAST: {
+        if (op == DFIR_CAST) { need(1); n->cast_to = ir[pos++]; }
+        n->a = pop();
+        if (n->a->op == DFIR_CONST_SET) fail(DFDB_ERR_ARGUMENT, "a set is only valid as the second argument of in");
+        if (op == DFIR_CAST) {
+          if (!dt_isnum(n->a->dtype) || dt_nullable(n->a->dtype) || !dt_isnum(n->cast_to) || dt_nullable(n->cast_to))
+            fail(DFDB_ERR_UNSUPPORTED, "unsupported conversion %s -> %s", dt_name(n->a->dtype).c_str(), dt_name(n->cast_to).c_str());
+          n->dtype = n->cast_to;
+        } else {
+          if (op == DFIR_ISMISSING && n->a->op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "ismissing is supported on columns only");
+          n->dtype = infer(op, n->a->dtype, 0);
+        }
+        break;
+      }
+      default: {
+        const bool known = (op >= DFIR_ADD && op <= DFIR_MAX) || (op >= DFIR_EQ && op <= DFIR_GE) || (op >= DFIR_AND && op <= DFIR_XOR) ||
+                           op == DFIR_IN_SET || op == DFIR_STARTSWITH || op == DFIR_ENDSWITH;
+        if (!known) fail(DFDB_ERR_UNSUPPORTED, "unknown IR opcode 0x%02x", op);
+        n->b = pop(); n->a = pop();
+        if (op == DFIR_IN_SET) {
+          if (n->b->op != DFIR_CONST_SET || n->a->op == DFIR_CONST_SET) fail(DFDB_ERR_ARGUMENT, "in needs (value, set)");
+          n->dtype = infer(op, n->a->dtype, 0);
+        } else {
+          if (n->a->op == DFIR_CONST_SET || n->b->op == DFIR_CONST_SET) fail(DFDB_ERR_ARGUMENT, "a set is only valid as the second argument of in");
+          if ((op == DFIR_STARTSWITH || op == DFIR_ENDSWITH) && n->b->op != DFIR_CONST_STR) fail(DFDB_ERR_UNSUPPORTED, "startswith/endswith need a constant pattern");
+          n->dtype = infer(op, n->a->dtype, n->b->dtype);
+        }
+        break;
+      }
+    }
+    st.push_back(std::move(n));
+  }
+  if (st.size() != 1) fail(DFDB_ERR_ARGUMENT, "IR must leave exactly one value (left %zu)", st.size());
+  if (st[0]->op == DFIR_CONST_SET) fail(DFDB_ERR_ARGUMENT, "IR result cannot be a set");
+  return std::move(st[0]);
+}
+
+// ---------------------------------------------------------------- routing to specialised kernels
+static int cmp_from_ir(int op) {
+  switch (op) { case DFIR_EQ: return CMP_EQ; case DFIR_NE: return CMP_NE; case DFIR_LT: return CMP_LT; case DFIR_LE: return CMP_LE;
+                case DFIR_GT: return CMP_GT; case DFIR_GE: return CMP_GE; }
+  return -1;
+}
+static int flip(int op) {  // c OP x  ==  x flip(OP) c
+  switch (op) { case CMP_LT: return CMP_GT; case CMP_LE: return CMP_GE; case CMP_GT: return CMP_LT; case CMP_GE: return CMP_LE; }
+  return op;
+}
+
+struct IntRange { __int128 lo, hi; };
+static IntRange int_range(int dt) {
+  switch (dt_base(dt)) {
+    case DFDB_I8: return {-128, 127}; case DFDB_I16: return {-32768, 32767};
+    case DFDB_I32: return {-(__int128)2147483648LL, 2147483647}; case DFDB_I64: return {(__int128)INT64_MIN, (__int128)INT64_MAX};
+    case DFDB_U8: return {0, 255}; case DFDB_U16: return {0, 65535}; case DFDB_U32: return {0, 4294967295LL};
+    case DFDB_BOOL: return {0, 1};
+    default: return {0, (__int128)UINT64_MAX};
+  }
+}
+static uint64_t int_bits(__int128 v) { return (uint64_t)v; }
+
+// make the term constant-true / constant-false for every value of an integer column type
+static void const_term(ScanTerm& term, int coldt, bool value) {
+  IntRange r = int_range(coldt);
+  term.op = value ? CMP_GE : CMP_LT;   // x >= Tmin is always true, x < Tmin always false
+  term.cbits = int_bits(r.lo);
+}
+
+// integer column vs integer constant c (as int128)
+static void int_vs_int(ScanTerm& term, int coldt, int op, __int128 c) {
+  IntRange r = int_range(coldt);
+  if (c > r.hi) { const_term(term, coldt, op == CMP_LT || op == CMP_LE || op == CMP_NE); return; }
+  if (c < r.lo) { const_term(term, coldt, op == CMP_GT || op == CMP_GE || op == CMP_NE); return; }
+  term.op = op; term.cbits = int_bits(c);
+}
+
+bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& ordinal) {
+  int op = cmp_from_ir(n.op);
+  if (op < 0 || !n.a || !n.b) return false;
+  const Node *coln = nullptr, *cn = nullptr;
+  if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST) { coln = n.a.get(); cn = n.b.get(); }
+  else if (n.a->op == DFIR_CONST && n.b->op == DFIR_COL) { coln = n.b.get(); cn = n.a.get(); op = flip(op); }
+  else return false;
+  const int ct = dt_base(coln->dtype), kt = dt_base(cn->dtype);
+  if (dt_nullable(coln->dtype) || !dt_isnum(ct) || ct == DFDB_BOOL) return false;
+  (void)t;
+  term.col = nullptr; term.dtype = ct; ordinal = coln->col;
+  if (dt_isint(ct)) {
+    if (dt_isint(kt) || kt == DFDB_BOOL) {
+      __int128 c = (kt == DFDB_U64) ? (__int128)(uint64_t)cn->cbits : (__int128)(int64_t)cn->cbits;
+      if (kt == DFDB_BOOL) c = cn->cbits ? 1 : 0;
+      int_vs_int(term, ct, op, c); return true;
+    }
+    // Int column vs Float constant: Julia compares exactly -> move to an equivalent integer threshold
+    double d; if (kt == DFDB_F32) { float f; memcpy(&f, &cn->cbits, 4); d = f; } else memcpy(&d, &cn->cbits, 8);
+    if (d != d) { const_term(term, ct, op == CMP_NE); return true; }
+    if (d >= 1.8446744073709552e19) { const_term(term, ct, op == CMP_LT || op == CMP_LE || op == CMP_NE); return true; }
+    if (d < -9.2233720368547758e18) { const_term(term, ct, op == CMP_GT || op == CMP_GE || op == CMP_NE); return true; }
+    const double fl = std::floor(d);
+    const __int128 fi = (__int128)fl;
+    if (fl == d) { int_vs_int(term, ct, op, fi); return true; }
+    switch (op) {   // d strictly between fi and fi+1
+      case CMP_EQ: const_term(term, ct, false); return true;
+      case CMP_NE: const_term(term, ct, true); return true;
+      case CMP_LT: case CMP_LE: int_vs_int(term, ct, CMP_LE, fi); return true;
+      default: int_vs_int(term, ct, CMP_GE, fi + 1); return true;
+    }
+  }
+  // float column
+  if (ct == DFDB_F64) {
+    double d;
+    if (kt == DFDB_F64) memcpy(&d, &cn->cbits, 8);
+    else if (kt == DFDB_F32) { float f; memcpy(&f, &cn->cbits, 4); d = f; }
+    else if (kt == DFDB_BOOL) d = cn->cbits ? 1.0 : 0.0;
+    else {
+      if (kt == DFDB_U64) { uint64_t u = cn->cbits; if (u > (1ull << 53)) return false; d = (double)u; }
+      else { int64_t i = (int64_t)cn->cbits; if (i > (1ll << 53) || i < -(1ll << 53)) return false; d = (double)i; }
+    }
+    term.op = op; memcpy(&term.cbits, &d, 8); return true;
+  }
+  if (ct == DFDB_F32) {
+    float f;
+    if (kt == DFDB_F32) memcpy(&f, &cn->cbits, 4);
+    else if (kt == DFDB_F64) { double d; memcpy(&d, &cn->cbits, 8); f = (float)d; if ((double)f != d && d == d) return false; }
+    else if (kt == DFDB_BOOL) f = cn->cbits ? 1.f : 0.f;
+    else { int64_t i = (int64_t)cn->cbits; if (kt == DFDB_U64 || i > (1 << 24) || i < -(1 << 24)) return false; f = (float)i; }
+    term.op = op; term.cbits = 0; memcpy(&term.cbits, &f, 4); return true;
+  }
+  return false;
+}
+
+bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat) {
+  (void)t;
+  if (!n.a || !n.b) return false;
+  const Node *coln = nullptr, *cn = nullptr;
+  if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST_STR) { coln = n.a.get(); cn = n.b.get(); }
+  else if (n.a->op == DFIR_CONST_STR && n.b->op == DFIR_COL && (n.op == DFIR_EQ || n.op == DFIR_NE)) { coln = n.b.get(); cn = n.a.get(); }
+  else return false;
+  if (dt_base(coln->dtype) != DFDB_STRING || dt_nullable(coln->dtype)) return false;
+  switch (n.op) {
+    case DFIR_EQ: mode = 0; break; case DFIR_NE: mode = 1; break;
+    case DFIR_STARTSWITH: mode = 2; break; case DFIR_ENDSWITH: mode = 3; break;
+    default: return false;
+  }
+  ordinal = coln->col; pat = cn->str; return true;
+}
+
+}  // namespace dfdb

@@ -1,0 +1,254 @@
+// k_compact.hip — K2/K3: selection bitmap -> row indices / gathered projection columns (gfx950).
+//
+// Replaces Base.LogicalIndex iteration + the gather loops of the reference
+// (src/tables/selection.jl:166, src/tables/broadcast.jl:106-110, src/tables/projection.jl:128-133) and the
+// per-block append! of materialize (src/tables/materialization.jl:33-37).
+//
+// One wave owns a 4096-row compaction tile = 64 bitmap words, one word per lane.  Each lane expands the
+// set bits of its word into a per-wave LDS staging buffer of 16-bit in-tile positions at its exclusive
+// prefix (wave prefix-sum of popcounts), so the expensive part is O(max popcount in the wave) instead of
+// O(64) ballots; the wave then streams the staged positions out as fully coalesced 512-B stores at the
+// tile's global offset (exclusive scan of the per-1024-row counts produced by K1).  Output order is
+// table order (stable), as the reference guarantees.
+//   algorithmic bytes / row: 1/8 (bitmap) + sigma * 8 (index)  |  gather: 1/8 + sigma * 2 * width
+#include "device_utils.hpp"
+#include "kernels.hpp"
+#include "../../include/dfdb_ir.h"
+
+namespace dfdb {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int64_t kCTile = 4096;
+
+static inline int grid_for_ctiles(int64_t n) {
+  int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+// expand this lane's word into pos[excl ...]; returns the tile's selected count
+__device__ __forceinline__ uint32_t stage_positions(uint64_t w, uint16_t* pos, int lane) {
+  const uint32_t c = (uint32_t)__popcll(w);
+  const uint32_t incl = wave_incl_scan(c);
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t o = incl - c;
+  const uint32_t lbase = (uint32_t)lane << 6;
+  while (w) {
+    const int b = __builtin_ctzll(w);
+    w &= w - 1;
+    pos[o++] = (uint16_t)(lbase + (uint32_t)b);
+  }
+  wave_lds_fence();
+  return total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact_indices(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                            int64_t* __restrict__ out, int64_t nctiles, int64_t row_base, int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
+    const uint64_t w = bitmap[ct * 64 + lane];
+    const uint32_t total = stage_positions(w, pos, lane);
+    const int64_t obase = (int64_t)prefix[ct * 4];
+    const int64_t row1 = row_base + ct * kCTile + 1;   // 1-based table row of in-tile position 0
+    for (uint32_t k = lane; k < total; k += 64) {
+      const int64_t o = obase + k;
+      if (o < out_cap) out[o] = row1 + pos[k];
+    }
+    wave_lds_fence();
+  }
+}
+
+void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows, int64_t row_base,
+                            int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile;
+  if (nct == 0) return;
+  hipLaunchKernelGGL(k_compact_indices, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                   const T* __restrict__ src, T* __restrict__ dst, int64_t nctiles, int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
+    const uint64_t w = bitmap[ct * 64 + lane];
+    const uint32_t total = stage_positions(w, pos, lane);
+    const int64_t obase = (int64_t)prefix[ct * 4];
+    const T* tsrc = src + ct * kCTile;
+    for (uint32_t k = lane; k < total; k += 64) {
+      const int64_t o = obase + k;
+      if (o < out_cap) dst[o] = tsrc[pos[k]];
+    }
+    wave_lds_fence();
+  }
+}
+
+void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, void* dst, int width, int64_t nrows,
+                   int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile;
+  if (nct == 0) return;
+  const dim3 g(grid_for_ctiles(nct)), b(kBlock);
+  switch (width) {
+    case 1: hipLaunchKernelGGL((k_gather<uint8_t>), g, b, 0, s, bitmap, prefix, (const uint8_t*)src, (uint8_t*)dst, nct, out_cap); break;
+    case 2: hipLaunchKernelGGL((k_gather<uint16_t>), g, b, 0, s, bitmap, prefix, (const uint16_t*)src, (uint16_t*)dst, nct, out_cap); break;
+    case 4: hipLaunchKernelGGL((k_gather<uint32_t>), g, b, 0, s, bitmap, prefix, (const uint32_t*)src, (uint32_t*)dst, nct, out_cap); break;
+    default: hipLaunchKernelGGL((k_gather<uint64_t>), g, b, 0, s, bitmap, prefix, (const uint64_t*)src, (uint64_t*)dst, nct, out_cap); break;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_bits(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                        const uint64_t* __restrict__ srcbits, uint8_t* __restrict__ dst, int64_t nctiles,
+                                                        int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
+    const uint64_t w = bitmap[ct * 64 + lane];
+    const uint32_t total = stage_positions(w, pos, lane);
+    const int64_t obase = (int64_t)prefix[ct * 4];
+    const uint64_t* tb = srcbits + ct * 64;
+    for (uint32_t k = lane; k < total; k += 64) {
+      const int64_t o = obase + k;
+      const uint32_t p = pos[k];
+      if (o < out_cap) dst[o] = (uint8_t)((tb[p >> 6] >> (p & 63)) & 1ull);
+    }
+    wave_lds_fence();
+  }
+}
+void launch_gather_bits(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const uint64_t* srcbits, uint8_t* dst, int64_t nrows,
+                        int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile;
+  if (nct == 0) return;
+  hipLaunchKernelGGL(k_gather_bits, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, srcbits, dst, nct, out_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions over the selected rows (sum / min / max); integer results exact, Float64 sums pairwise
+// per lane -> wave -> block -> final block (deterministic for a fixed grid)
+// ------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+
+template <typename T> struct Acc;   // accumulator type
+template <> struct Acc<int8_t> { using type = int64_t; };   template <> struct Acc<int16_t> { using type = int64_t; };
+template <> struct Acc<int32_t> { using type = int64_t; };  template <> struct Acc<int64_t> { using type = int64_t; };
+template <> struct Acc<uint8_t> { using type = uint64_t; }; template <> struct Acc<uint16_t> { using type = uint64_t; };
+template <> struct Acc<uint32_t> { using type = uint64_t; }; template <> struct Acc<uint64_t> { using type = uint64_t; };
+template <> struct Acc<float> { using type = double; };     template <> struct Acc<double> { using type = double; };
+
+template <typename A> __device__ __forceinline__ A red_identity(int op);
+template <> __device__ __forceinline__ int64_t red_identity<int64_t>(int op) { return op == DFDB_AGG_MIN ? INT64_MAX : (op == DFDB_AGG_MAX ? INT64_MIN : 0); }
+template <> __device__ __forceinline__ uint64_t red_identity<uint64_t>(int op) { return op == DFDB_AGG_MIN ? ~0ull : 0ull; }
+template <> __device__ __forceinline__ double red_identity<double>(int op) { return op == DFDB_AGG_MIN ? __builtin_inf() : (op == DFDB_AGG_MAX ? -__builtin_inf() : 0.0); }
+
+template <typename A> __device__ __forceinline__ A red_combine(A a, A b, int op) {
+  if (op == DFDB_AGG_SUM) return a + b;
+  if (op == DFDB_AGG_MIN) return b < a ? b : a;
+  return b > a ? b : a;
+}
+__device__ __forceinline__ double red_combine_f(double a, double b, int op) {   // Julia min/max propagate NaN
+  if (op == DFDB_AGG_SUM) return a + b;
+  if (a != a) return a;
+  if (b != b) return b;
+  if (op == DFDB_AGG_MIN) return b < a ? b : a;
+  return b > a ? b : a;
+}
+template <typename A> __device__ __forceinline__ A comb(A a, A b, int op) { return red_combine<A>(a, b, op); }
+template <> __device__ __forceinline__ double comb<double>(double a, double b, int op) { return red_combine_f(a, b, op); }
+
+template <typename A> __device__ __forceinline__ A wave_reduce(A v, int op) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { A t = __shfl_xor(v, d, 64); v = comb<A>(v, t, op); }
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reduce_partial(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, int op,
+                                                           int64_t nwords, typename Acc<T>::type* __restrict__ partials,
+                                                           uint64_t* __restrict__ pcounts) {
+  using A = typename Acc<T>::type;
+  __shared__ A sh[kWavesPerBlock];
+  __shared__ uint64_t shc[kWavesPerBlock];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  A acc = red_identity<A>(op);
+  uint64_t cnt = 0;
+  for (int64_t wi = wave; wi < nwords; wi += nwaves) {   // one bitmap word (64 rows) per wave step
+    const uint64_t w = bitmap[wi];
+    if (w == 0) continue;                                  // wave-uniform: skip dead words without touching the column
+    if ((w >> lane) & 1ull) { acc = comb<A>(acc, (A)col[wi * 64 + lane], op); cnt++; }
+  }
+  acc = wave_reduce<A>(acc, op);
+  cnt = wave_sum64(cnt);
+  if (lane == 0) { sh[wib] = acc; shc[wib] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A r = sh[0]; uint64_t c = shc[0];
+    for (int i = 1; i < kWavesPerBlock; i++) { r = comb<A>(r, sh[i], op); c += shc[i]; }
+    partials[blockIdx.x] = r; pcounts[blockIdx.x] = c;
+  }
+}
+template <typename A>
+__global__ __launch_bounds__(kBlock) void k_reduce_final(const A* __restrict__ partials, const uint64_t* __restrict__ pcounts, int n, int op,
+                                                         A* __restrict__ result, uint64_t* __restrict__ rcount) {
+  __shared__ A sh[kWavesPerBlock];
+  __shared__ uint64_t shc[kWavesPerBlock];
+  A acc = red_identity<A>(op); uint64_t cnt = 0;
+  // fixed association: thread t folds partials t, t+256, ... then a fixed tree
+  for (int i = threadIdx.x; i < n; i += kBlock) { acc = comb<A>(acc, partials[i], op); cnt += pcounts[i]; }
+  acc = wave_reduce<A>(acc, op); cnt = wave_sum64(cnt);
+  if (lane_id() == 0) { sh[threadIdx.x >> 6] = acc; shc[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A r = sh[0]; uint64_t c = shc[0];
+    for (int i = 1; i < kWavesPerBlock; i++) { r = comb<A>(r, sh[i], op); c += shc[i]; }
+    *result = r; *rcount = c;
+  }
+}
+
+size_t reduce_scratch_bytes() { return (size_t)kRedBlocks * 16 + 64; }
+
+template <typename T>
+static void launch_reduce_t(hipStream_t s, const uint64_t* bitmap, const void* col, int op, int64_t nrows, void* partials, void* result) {
+  using A = typename Acc<T>::type;
+  const int64_t nwords = (nrows + 63) / 64;
+  int grid = (int)((nwords + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (grid > kRedBlocks) grid = kRedBlocks;
+  if (grid < 1) grid = 1;
+  A* pv = (A*)partials; uint64_t* pc = (uint64_t*)((char*)partials + (size_t)kRedBlocks * 8);
+  hipLaunchKernelGGL((k_reduce_partial<T>), dim3(grid), dim3(kBlock), 0, s, bitmap, (const T*)col, op, nwords, pv, pc);
+  hipLaunchKernelGGL((k_reduce_final<A>), dim3(1), dim3(kBlock), 0, s, (const A*)pv, (const uint64_t*)pc, grid, op, (A*)result,
+                     (uint64_t*)((char*)result + 8));
+}
+
+void launch_reduce(hipStream_t s, const uint64_t* bitmap, const void* col, int32_t dtype, int op, int64_t nrows, void* partials, void* result) {
+  switch (dtype) {
+    case DFDB_I8:  launch_reduce_t<int8_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_I16: launch_reduce_t<int16_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_I32: launch_reduce_t<int32_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_I64: launch_reduce_t<int64_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_U8: case DFDB_BOOL: launch_reduce_t<uint8_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_U16: launch_reduce_t<uint16_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_U32: launch_reduce_t<uint32_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_U64: launch_reduce_t<uint64_t>(s, bitmap, col, op, nrows, partials, result); break;
+    case DFDB_F32: launch_reduce_t<float>(s, bitmap, col, op, nrows, partials, result); break;
+    default:       launch_reduce_t<double>(s, bitmap, col, op, nrows, partials, result); break;
+  }
+}
+
+}  // namespace dfdb

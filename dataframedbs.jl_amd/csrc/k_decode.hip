@@ -1,0 +1,128 @@
+// k_decode.hip — K7: LZ4 block decode on gfx950, K8: Union{T,Missing} bodies, String bodies.
+//
+// Replaces LZ4_decompress_safe as called per (column, block) by BlockStream.read_block
+// (src/io/BlockStreams.jl:101-119) and read_block_body! for nullable and String columns
+// (src/io/blocks.jl:46-71).  The LZ4 *block* format is serial inside a block, so parallelism comes from
+// the blocks: one wavefront decodes one block (15 259 blocks per 1e9-row column), all lanes parse the same
+// token (wave-uniform control flow) and the literal / match copies are spread over the 64 lanes.
+// A match whose source overlaps its destination (offset < length) is a periodic pattern: byte k of the
+// match equals source byte k mod offset, all of which precede the write pointer, so it is also copied in
+// parallel.  Reads of bytes this wave wrote earlier are ordered by a workgroup-scope fence (same CU, same
+// L1) before every match copy.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace dfdb {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+
+// a byte every lane reads from the same address, pinned to a scalar register so the token parse stays
+// wave-uniform (scalar branches, no exec masking)
+__device__ __forceinline__ uint32_t ubyte(const uint8_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*p); }
+
+__global__ __launch_bounds__(kBlock) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    const uint32_t in_len = (uint32_t)blk.src_len, out_len = (uint32_t)blk.dst_len;
+    uint32_t ip = 0, op = 0;
+    int err = 0;
+    while (ip < in_len) {                       // every quantity below is wave-uniform
+      const uint32_t token = ubyte(in + ip); ip++;
+      uint32_t lit = token >> 4;
+      if (lit == 15) {
+        uint32_t bb;
+        do { if (ip >= in_len) { err = 1; break; } bb = ubyte(in + ip); ip++; lit += bb; } while (bb == 255);
+        if (err) break;
+      }
+      if (lit > in_len - ip || lit > out_len - op) { err = 2; break; }
+      for (uint32_t k = lane; k < lit; k += 64) out[op + k] = in[ip + k];      // literal run
+      ip += lit; op += lit;
+      if (ip >= in_len) break;                  // the last sequence is literals only
+      if (ip + 2 > in_len) { err = 3; break; }
+      const uint32_t offset = ubyte(in + ip) | (ubyte(in + ip + 1) << 8);
+      ip += 2;
+      uint32_t ml = token & 15u;
+      if (ml == 15) {
+        uint32_t bb;
+        do { if (ip >= in_len) { err = 4; break; } bb = ubyte(in + ip); ip++; ml += bb; } while (bb == 255);
+        if (err) break;
+      }
+      ml += 4;
+      if (offset == 0 || offset > op || ml > out_len - op) { err = 5; break; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // this wave's earlier stores are visible to its loads
+      const uint8_t* m = out + op - offset;
+      if (offset >= ml) { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k]; }
+      else              { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k % offset]; }
+      op += ml;
+    }
+    if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
+    if (lane == 0) status[b] = err;
+  }
+}
+
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
+  if (nblocks <= 0) return;
+  // latency-bound: give every block its own wave and let the CUs hold as many as they can
+  int64_t grid = ((int64_t)nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > 65535) grid = 65535;
+  hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
+}
+
+// ---------------------------------------------------------------- K8: Union{T,Missing} bodies
+// body = cld(rows,64) UInt64 chunks (bit i = row i missing) then rows*width values (blocks.jl:9-18,46-60).
+// One workgroup per block: values are copied to the column at the block's row offset; the bits are
+// re-packed at the block's global bit position (blocks need not start on a word boundary).
+__global__ __launch_bounds__(kBlock) void k_unpack_nullable(const uint8_t* __restrict__ bodies, const int64_t* __restrict__ body_off,
+                                                            const int64_t* __restrict__ row_off, int width, uint8_t* __restrict__ values,
+                                                            uint64_t* __restrict__ missing_bits) {
+  const int b = blockIdx.x;
+  const int64_t r0 = row_off[b], rows = row_off[b + 1] - r0;
+  const uint8_t* body = bodies + body_off[b];
+  const int64_t nchunks = (rows + 63) / 64;
+  const uint64_t* chunks = (const uint64_t*)body;
+  const uint8_t* vals = body + nchunks * 8;
+  const int64_t nbytes = rows * width;
+  uint8_t* vdst = values + r0 * width;
+  for (int64_t k = threadIdx.x; k < nbytes; k += kBlock) vdst[k] = vals[k];
+  for (int64_t i = threadIdx.x; i < rows; i += kBlock) {
+    if ((chunks[i >> 6] >> (i & 63)) & 1ull) {
+      const int64_t g = r0 + i;
+      atomicOr((unsigned long long*)&missing_bits[g >> 6], 1ull << (g & 63));
+    }
+  }
+}
+void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, int32_t nblocks, int width,
+                            uint8_t* values, uint64_t* missing_bits) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(k_unpack_nullable, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, width, values, missing_bits);
+}
+
+// ---------------------------------------------------------------- String bodies
+// body = Int32 datasize, rows x Int32 sizes, datasize bytes (blocks.jl:21-33,62-71)
+__global__ __launch_bounds__(kBlock) void k_unpack_strings(const uint8_t* __restrict__ bodies, const int64_t* __restrict__ body_off,
+                                                           const int64_t* __restrict__ row_off, const int64_t* __restrict__ byte_off,
+                                                           int32_t* __restrict__ sizes, uint8_t* __restrict__ bytes) {
+  const int b = blockIdx.x;
+  const int64_t r0 = row_off[b], rows = row_off[b + 1] - r0;
+  const int64_t nb = byte_off[b + 1] - byte_off[b];
+  const uint8_t* body = bodies + body_off[b];
+  const int32_t* bs = (const int32_t*)(body + 4);
+  const uint8_t* bd = body + 4 + rows * 4;
+  for (int64_t i = threadIdx.x; i < rows; i += kBlock) sizes[r0 + i] = bs[i];
+  uint8_t* d = bytes + byte_off[b];
+  for (int64_t k = threadIdx.x; k < nb; k += kBlock) d[k] = bd[k];
+}
+void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* byte_off,
+                           int32_t nblocks, int32_t* sizes, uint8_t* bytes) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(k_unpack_strings, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, byte_off, sizes, bytes);
+}
+
+}  // namespace dfdb

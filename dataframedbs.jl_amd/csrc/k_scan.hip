@@ -1,0 +1,361 @@
+// k_scan.hip — K1: predicate scan kernels for gfx950 (MI355X).
+//
+// Replaces, per 65 536-row block of the reference: _extract_for_eval! + materialize! + mask write-back
+// (src/tables/broadcast.jl:96-133, src/tables/selection.jl:133-157) and the LogicalIndex count
+// (selection.jl:166).  HBM-bound: every row of every referenced column is read exactly once with fully
+// coalesced wave loads (lane l reads row base+l: one 512-B request per wave instruction for 8-byte
+// types), the predicate result is a wavefront ballot (= one 64-bit word of the selection bitmap, LSB =
+// lowest row), and a wave emits one 128-B line of bitmap + one tile count per 1024 rows.
+//   algorithmic bytes / row: sum of referenced column widths + 1/8 (bitmap) + 4/1024 (count)
+#include "device_utils.hpp"
+#include "kernels.hpp"
+#include "../../include/dfdb_ir.h"
+
+namespace dfdb {
+
+constexpr int kBlock = 256;           // 4 waves
+constexpr int kWavesPerBlock = 4;
+constexpr int64_t kTile = 1024;       // rows per wave step
+constexpr int kWordsPerTile = 16;
+
+static inline int grid_for_tiles(int64_t ntiles) {
+  // memory-bound streaming: 256 CUs x 8 blocks, grid-stride over tiles (cdna guide G11)
+  int64_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <int OP, typename T>
+__device__ __forceinline__ bool cmp_op(T x, T c) {
+  if constexpr (OP == CMP_EQ) return x == c;
+  else if constexpr (OP == CMP_NE) return x != c;
+  else if constexpr (OP == CMP_LT) return x < c;
+  else if constexpr (OP == CMP_LE) return x <= c;
+  else if constexpr (OP == CMP_GT) return x > c;
+  else return x >= c;
+}
+
+// sum of popcounts held by lanes 0..15
+__device__ __forceinline__ uint32_t tile_popcount(uint64_t myword, int lane) {
+  uint32_t c = lane < kWordsPerTile ? (uint32_t)__popcll(myword) : 0u;
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  return c;  // valid in lanes 0..15 (each 16-lane group reduced separately; group 0 holds the tile)
+}
+
+// ------------------------------------------------------------------------------------------------
+// single column  x OP c
+// ------------------------------------------------------------------------------------------------
+template <typename T, int OP, bool AND_EXISTING>
+__global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
+                                                     uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * kTile;
+    const T* p = col + base + lane;
+    uint64_t myword = 0;
+    if (base + kTile <= nrows) {
+      T v[kWordsPerTile];
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) v[j] = p[j * 64];   // 16 independent coalesced loads in flight
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) {
+        uint64_t m = __ballot(cmp_op<OP, T>(v[j], c));
+        if (lane == j) myword = m;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) {
+        const int64_t row = base + j * 64 + lane;
+        bool r = false;
+        if (row < nrows) r = cmp_op<OP, T>(p[j * 64], c);
+        uint64_t m = __ballot(r);
+        if (lane == j) myword = m;
+      }
+    }
+    if (AND_EXISTING) { if (lane < kWordsPerTile) myword &= bitmap[tile * kWordsPerTile + lane]; }
+    const uint32_t cnt = tile_popcount(myword, lane);
+    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = myword;   // one 128-B line
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+
+template <typename T, int OP>
+static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing) {
+  const T c = from_bits<T>(cbits);
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  if (ntiles == 0) return;
+  const int grid = grid_for_tiles(ntiles);
+  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
+  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
+}
+template <typename T>
+static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae) {
+  switch (op) {
+    case CMP_EQ: launch_cmp_t<T, CMP_EQ>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    case CMP_NE: launch_cmp_t<T, CMP_NE>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    case CMP_LT: launch_cmp_t<T, CMP_LT>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    case CMP_LE: launch_cmp_t<T, CMP_LE>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    case CMP_GT: launch_cmp_t<T, CMP_GT>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    default:     launch_cmp_t<T, CMP_GE>(s, col, cbits, bitmap, tc, nrows, ae); break;
+  }
+}
+
+void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tile_counts,
+                     int64_t nrows, bool and_existing) {
+  switch (dtype) {
+    case DFDB_I8:  launch_cmp_op<int8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_I16: launch_cmp_op<int16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_I32: launch_cmp_op<int32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_I64: launch_cmp_op<int64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_U8: case DFDB_BOOL: launch_cmp_op<uint8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_U16: launch_cmp_op<uint16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_U32: launch_cmp_op<uint32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_U64: launch_cmp_op<uint64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_F32: launch_cmp_op<float>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    default:       launch_cmp_op<double>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conjunction / disjunction of simple terms over several columns (config 3: (a > c1) & (x < c2))
+// ------------------------------------------------------------------------------------------------
+// op -> which of {lt, eq, gt, unordered} satisfy it
+__device__ __forceinline__ uint32_t op_sel(int op) {
+  switch (op) {
+    case CMP_EQ: return 2u; case CMP_NE: return 1u | 4u | 8u; case CMP_LT: return 1u;
+    case CMP_LE: return 1u | 2u; case CMP_GT: return 4u; default: return 4u | 2u;
+  }
+}
+template <typename T>
+__device__ __forceinline__ bool cmp_sel(T x, T c, uint32_t sel) {
+  const bool lt = x < c, eq = x == c, gt = x > c;
+  return ((sel & 1u) && lt) || ((sel & 2u) && eq) || ((sel & 4u) && gt) || ((sel & 8u) && !(lt || eq || gt));
+}
+template <typename T>
+__device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane) {
+  const T* p = (const T*)colv + base + lane;
+  const T c = from_bits<T>(cbits);
+  uint64_t myword = 0;
+  if (base + kTile <= nrows) {
+    T v[kWordsPerTile];
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) v[j] = p[j * 64];
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == j) myword = m; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) {
+      bool r = false;
+      if (base + j * 64 + lane < nrows) r = cmp_sel<T>(p[j * 64], c, sel);
+      uint64_t m = __ballot(r); if (lane == j) myword = m;
+    }
+  }
+  return myword;
+}
+
+template <bool AND_EXISTING>
+__global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
+                                                       int64_t nrows, int64_t ntiles) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t base = tile * kTile;
+    uint64_t acc = terms.combine_or ? 0ull : ~0ull;
+    for (int t = 0; t < terms.n; t++) {
+      const ScanTerm& tm = terms.t[t];
+      const uint32_t sel = op_sel(tm.op);
+      uint64_t w;
+      switch (tm.dtype) {   // wave-uniform
+        case DFDB_I8:  w = term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_I16: w = term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_I32: w = term_word<int32_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_I64: w = term_word<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_U8: case DFDB_BOOL: w = term_word<uint8_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_U16: w = term_word<uint16_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_U32: w = term_word<uint32_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_U64: w = term_word<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        case DFDB_F32: w = term_word<float>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+        default:       w = term_word<double>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+      }
+      acc = terms.combine_or ? (acc | w) : (acc & w);
+    }
+    // rows past nrows never set: every term's tail ballot is false (AND) — for OR also false
+    if (AND_EXISTING) { if (lane < kWordsPerTile) acc &= bitmap[tile * kWordsPerTile + lane]; }
+    const uint32_t cnt = tile_popcount(acc, lane);
+    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = acc;
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+
+void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows, bool and_existing) {
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  if (ntiles == 0) return;
+  const int grid = grid_for_tiles(ntiles);
+  if (and_existing) hipLaunchKernelGGL((k_scan_terms<true>), dim3(grid), dim3(kBlock), 0, s, terms, bitmap, tile_counts, nrows, ntiles);
+  else hipLaunchKernelGGL((k_scan_terms<false>), dim3(grid), dim3(kBlock), 0, s, terms, bitmap, tile_counts, nrows, ntiles);
+}
+
+// ------------------------------------------------------------------------------------------------
+// all-ones mask (fill!(range_buffer, 1): selection.jl:163) for an empty SelectionQueue
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ones_word(int64_t word_row0, int64_t nrows) {
+  if (word_row0 + 64 <= nrows) return ~0ull;
+  if (word_row0 >= nrows) return 0ull;
+  return (1ull << (nrows - word_row0)) - 1ull;
+}
+__global__ __launch_bounds__(kBlock) void k_fill_ones(uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    uint64_t w = lane < kWordsPerTile ? ones_word(tile * kTile + lane * 64, nrows) : 0ull;
+    const uint32_t cnt = tile_popcount(w, lane);
+    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = w;
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows) {
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  if (ntiles == 0) return;
+  hipLaunchKernelGGL(k_fill_ones, dim3(grid_for_tiles(ntiles)), dim3(kBlock), 0, s, bitmap, tile_counts, nrows, ntiles);
+}
+
+// ------------------------------------------------------------------------------------------------
+// range stage (selection.jl:94-111): survivor number offset+i is kept iff it is in the range.
+// The cross-block `offset` of RangeToProcess is the global exclusive prefix of the mask popcounts.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool range_contains(const RangeSpec& r, int64_t rank) {
+  if (r.kind == 0) {
+    if (rank < r.first || rank > r.last) return false;
+    return r.step == 1 || ((rank - r.first) % r.step) == 0;
+  }
+  int64_t lo = 0, hi = r.nsorted;
+  while (lo < hi) { int64_t m = (lo + hi) >> 1; if (r.sorted[m] < rank) lo = m + 1; else hi = m; }
+  return lo < r.nsorted && r.sorted[lo] == rank;
+}
+
+__global__ __launch_bounds__(kBlock) void k_range_stage(RangeSpec r, uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                        uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles,
+                                                        int64_t rank_base, int implicit_ones) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    uint64_t w = 0;
+    if (lane < kWordsPerTile) w = implicit_ones ? ones_word(tile * kTile + lane * 64, nrows) : bitmap[tile * kWordsPerTile + lane];
+    const uint32_t c = (uint32_t)__popcll(w);
+    const uint32_t incl = wave_incl_scan(c);
+    const int64_t tile_rank0 = rank_base + (implicit_ones ? tile * kTile : (int64_t)prefix[tile]);
+    int64_t rank = tile_rank0 + (int64_t)(incl - c) + 1;   // rank of this word's first survivor
+    uint64_t nw = 0;
+    if (c) {
+      const int64_t rlast = rank + c - 1;
+      if (rlast < r.first || rank > r.last) nw = 0;
+      else if (r.kind == 0 && r.step == 1 && rank >= r.first && rlast <= r.last) nw = w;
+      else {
+        uint64_t ww = w;
+        while (ww) {
+          const uint64_t bit = ww & (0 - ww);
+          if (range_contains(r, rank)) nw |= bit;
+          ww ^= bit; rank++;
+        }
+      }
+    }
+    const uint32_t cnt = tile_popcount(nw, lane);
+    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = nw;
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+void launch_range_stage(hipStream_t s, const RangeSpec& r, uint64_t* bitmap, const uint64_t* prefix, uint32_t* tile_counts, int64_t nrows,
+                        int64_t rank_base, bool implicit_ones) {
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  if (ntiles == 0) return;
+  hipLaunchKernelGGL(k_range_stage, dim3(grid_for_tiles(ntiles)), dim3(kBlock), 0, s, r, bitmap, prefix, tile_counts, nrows, ntiles,
+                     rank_base, implicit_ones ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of the per-tile counts: u32[ntiles] -> u64[ntiles+1]
+// ------------------------------------------------------------------------------------------------
+constexpr int kScChunk = 4096;       // counts per workgroup
+constexpr int kScPerThread = kScChunk / kBlock;  // 16
+
+__device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t* sh /*4*/) {
+  v = wave_sum64(v);
+  if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint64_t t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sc_reduce(const uint32_t* __restrict__ counts, uint64_t* __restrict__ chunk_sums, int64_t ntiles) {
+  __shared__ uint64_t sh[4];
+  const int64_t base = (int64_t)blockIdx.x * kScChunk;
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScPerThread; k++) {
+    const int64_t i = base + k * kBlock + threadIdx.x;
+    if (i < ntiles) s += counts[i];
+  }
+  s = block_sum64(s, sh);
+  if (threadIdx.x == 0) chunk_sums[blockIdx.x] = s;
+}
+
+// single workgroup: in-place exclusive scan of chunk_sums[0..nchunks), total -> chunk_sums[nchunks]
+__global__ __launch_bounds__(kBlock) void k_sc_scan_chunks(uint64_t* __restrict__ chunk_sums, int64_t nchunks) {
+  __shared__ uint64_t wave_tot[4];
+  __shared__ uint64_t carry_sh;
+  if (threadIdx.x == 0) carry_sh = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nchunks; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const uint64_t v = i < nchunks ? chunk_sums[i] : 0;
+    const uint64_t incl = wave_incl_scan64(v);
+    if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += wave_tot[w];
+    const uint64_t carry = carry_sh;
+    if (i < nchunks) chunk_sums[i] = carry + wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry_sh = carry + wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) chunk_sums[nchunks] = carry_sh;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sc_down(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ chunk_sums,
+                                                    uint64_t* __restrict__ prefix, int64_t ntiles, int64_t nchunks) {
+  __shared__ uint64_t wave_tot[4];
+  const int64_t base = (int64_t)blockIdx.x * kScChunk + (int64_t)threadIdx.x * kScPerThread;
+  uint32_t v[kScPerThread];
+  uint64_t tsum = 0;
+#pragma unroll
+  for (int k = 0; k < kScPerThread; k++) { const int64_t i = base + k; v[k] = i < ntiles ? counts[i] : 0u; tsum += v[k]; }
+  const uint64_t incl = wave_incl_scan64(tsum);
+  if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint64_t run = chunk_sums[blockIdx.x] + incl - tsum;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kScPerThread; k++) { const int64_t i = base + k; if (i < ntiles) prefix[i] = run; run += v[k]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) prefix[ntiles] = chunk_sums[nchunks];
+}
+
+size_t scan_counts_scratch_bytes(int64_t ntiles) { return (size_t)((ntiles + kScChunk - 1) / kScChunk + 2) * 8; }
+
+void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch) {
+  if (ntiles <= 0) { (void)hipMemsetAsync(prefix, 0, 8, s); return; }
+  const int64_t nchunks = (ntiles + kScChunk - 1) / kScChunk;
+  hipLaunchKernelGGL(k_sc_reduce, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, ntiles);
+  hipLaunchKernelGGL(k_sc_scan_chunks, dim3(1), dim3(kBlock), 0, s, scratch, nchunks);
+  hipLaunchKernelGGL(k_sc_down, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, prefix, ntiles, nchunks);
+}
+
+}  // namespace dfdb

@@ -1,0 +1,98 @@
+// kernels.hpp — host-callable launchers of the gfx950 kernels (definitions in k_*.hip).
+// Every launcher enqueues on `s` and returns immediately; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/dfdb.h"
+
+namespace dfdb {
+
+enum CmpOp : int { CMP_EQ = 0, CMP_NE = 1, CMP_LT = 2, CMP_LE = 3, CMP_GT = 4, CMP_GE = 5 };
+
+// one simple term `col OP const` of a conjunction/disjunction (K1 multi-column form)
+struct ScanTerm {
+  const void* col;
+  int32_t dtype;     // DFDB_* base dtype of the column
+  int32_t op;        // CmpOp
+  uint64_t cbits;    // constant already converted to the column's own type (bit pattern)
+};
+constexpr int kMaxTerms = 6;
+struct ScanTerms {
+  ScanTerm t[kMaxTerms];
+  int32_t n;
+  int32_t combine_or;  // 0 = AND of all terms, 1 = OR
+};
+
+// ---- K1: predicate scan -> bitmap (+ per-1024-row tile counts) ----------------------------------
+// single column `x OP c`; and_existing: bitmap &= result (a predicate stage after a range stage)
+void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap,
+                     uint32_t* tile_counts, int64_t nrows, bool and_existing);
+void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
+                       bool and_existing);
+
+// ---- tile-count scan: u32 counts[ntiles] -> u64 prefix[ntiles+1] (prefix[ntiles] = total) -------
+// scratch: >= (ceil(ntiles/4096)+1) * 8 bytes
+void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch);
+size_t scan_counts_scratch_bytes(int64_t ntiles);
+
+// ---- range stages (selection.jl:94-111 on the packed mask) --------------------------------------
+struct RangeSpec {
+  int32_t kind;        // 0 = a:s:b (first/last/step normalised ascending), 1 = sorted unique index list
+  int64_t first, last, step;
+  const int64_t* sorted; int64_t nsorted;
+};
+// implicit_ones: the incoming mask is all ones and rank = rank_base + local row + 1 (a leading range stage);
+// otherwise rank = rank_base + prefix[tile] + position among the survivors.
+void launch_range_stage(hipStream_t s, const RangeSpec& r, uint64_t* bitmap, const uint64_t* prefix, uint32_t* tile_counts,
+                        int64_t nrows, int64_t rank_base, bool implicit_ones);
+// all-ones mask (empty SelectionQueue): bitmap + counts
+void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
+
+// ---- K2: bitmap -> ascending 1-based row numbers -------------------------------------------------
+void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows,
+                            int64_t row_base, int64_t out_cap);
+// ---- K3: projection gather of a fixed-width column (width 1,2,4,8 bytes) -------------------------
+void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, void* dst, int width,
+                   int64_t nrows, int64_t out_cap);
+// bitmap (1 = missing) of the source gathered into one byte per selected row
+void launch_gather_bits(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const uint64_t* srcbits, uint8_t* dst,
+                        int64_t nrows, int64_t out_cap);
+
+// ---- synthetic generators --------------------------------------------------------
+void launch_gen_i64_mod1m(hipStream_t s, int64_t* out, uint64_t seed, int64_t row_first, int64_t n);
+void launch_gen_i64_iota(hipStream_t s, int64_t* out, int64_t row_first, int64_t n);
+void launch_gen_f64_u2000(hipStream_t s, double* out, uint64_t seed, int64_t row_first, int64_t n);
+void launch_gen_brand_sizes(hipStream_t s, int32_t* sizes, uint64_t seed, int64_t row_first, int64_t n);
+void launch_gen_brand_bytes(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, uint8_t* bytes, uint64_t seed,
+                            int64_t row_first, int64_t n);
+
+// ---- strings (K4-K6) -------------------------------------------------------------------------------
+// per-1024-row byte totals of max(size,0)  (first half of unsafe_remake_offsets!)
+void launch_str_tile_bytes(hipStream_t s, const int32_t* sizes, uint32_t* tile_bytes, int64_t nrows);
+// K5: s OP "const" (EQ / NE / STARTSWITH / ENDSWITH) -> bitmap + counts.  mode: 0 EQ, 1 NE, 2 STARTSWITH, 3 ENDSWITH
+// pat_host: the pattern in host memory (<= 64 bytes travel as kernel arguments); pat_dev: device copy for longer ones
+void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
+                      const uint8_t* pat_dev, int32_t patlen, int mode, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
+                      bool and_existing);
+// K6: selected sizes -> out sizes (+ per-ctile selected byte totals); then bytes
+void launch_str_gather_sizes(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const int32_t* sizes, int32_t* out_sizes,
+                             uint32_t* sel_tile_bytes, int64_t nrows, int64_t out_cap);
+void launch_str_gather_bytes(hipStream_t s, const uint64_t* bitmap, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes,
+                             const uint64_t* out_tile_off, uint8_t* out_bytes, int64_t nrows, int64_t out_bytes_cap);
+
+// ---- reductions ------------------------------------------------------------------------------------
+// sum/min/max of a fixed-width column over the selected rows -> partials then final (2 launches)
+void launch_reduce(hipStream_t s, const uint64_t* bitmap, const void* col, int32_t dtype, int op, int64_t nrows, void* partials,
+                   void* result /* 16 bytes: i64/u64 or f64 result + count */);
+size_t reduce_scratch_bytes();
+
+// ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------
+struct Lz4Block {      // one (column, block) unit of work
+  int64_t src_off;     // offset of the compressed bytes inside the staged image
+  int32_t src_len;     // compressed bytes
+  int32_t dst_len;     // expected uncompressed bytes (origin)
+  int64_t dst_off;     // where the decoded body goes inside the body arena
+};
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status);
+
+}  // namespace dfdb

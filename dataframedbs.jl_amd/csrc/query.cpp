@@ -1,0 +1,368 @@
+// query.cpp — DFView on the device: SelectionQueue composition, stage execution, count, indices,
+// materialize, aggregates.
+//
+// Replaces (paths under /root/reference): SelectionQueue add/_new_queue src/tables/selection.jl:37-60,
+// SelectionExecutor.apply :161-167 with its range :94-111 and predicate :133-157 stages, the block loop of
+// src/io/blocksiterator.jl:98-145, nrow src/tables/view.jl:192-206, ProjectionExecutor.eval_on_range
+// src/tables/projection.jl:128-154 and materialize src/tables/materialization.jl:27-52.
+//
+// The reference walks blocks serially and carries a per-stage `offset`; here every stage is ONE pass over
+// the whole resident column range, the mask is a packed bitmap in HBM, and the cross-block offset becomes
+// an exclusive scan of per-tile popcounts.  The selection is evaluated once (no count pre-pass, quirk Q8):
+// dfdb_count reads the scan total, dfdb_materialize reuses the same bitmap.
+#include "engine.hpp"
+#include <algorithm>
+
+namespace dfdb {
+
+// launchers living in k_interp.hip / k_strings.hip that take engine-level descriptions
+void run_interp_predicate(dfdb_query* q, const Node& pred, bool and_existing);
+void run_interp_project(dfdb_query* q, const Node& expr, void* dst, int64_t cap);
+
+// ---------------------------------------------------------------- ranges
+static int64_t range_len(int64_t a, int64_t s, int64_t b) {
+  if (s > 0) return b < a ? 0 : (b - a) / s + 1;
+  return b > a ? 0 : (a - b) / (-s) + 1;
+}
+int64_t Stage::first() const {
+  if (kind == ST_RANGE) return n == 0 ? INT64_MAX : (step > 0 ? start : stop);
+  return idx.empty() ? INT64_MAX : *std::min_element(idx.begin(), idx.end());
+}
+int64_t Stage::last() const {
+  if (kind == ST_RANGE) return n == 0 ? INT64_MIN : (step > 0 ? stop : start);
+  return idx.empty() ? INT64_MIN : *std::max_element(idx.begin(), idx.end());
+}
+int64_t Stage::elem(int64_t k) const {
+  if (k < 1 || k > n) fail(DFDB_ERR_BOUNDS, "BoundsError: attempt to access %lld-element selection at index [%lld]", (long long)n, (long long)k);
+  return kind == ST_RANGE ? start + (k - 1) * step : idx[(size_t)k - 1];
+}
+static void normalise(Stage& s) {
+  if (s.kind == ST_RANGE) {
+    if (s.step == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: step cannot be zero");
+    s.n = range_len(s.start, s.step, s.stop);
+    if (s.n > 0) s.stop = s.start + (s.n - 1) * s.step;
+  } else if (s.kind != ST_PRED) s.n = (int64_t)s.idx.size();
+}
+
+// add(q, elem) with _new_queue's rules (selection.jl:39-49)
+void query_add_stage(dfdb_query* q, Stage&& ns) {
+  normalise(ns);
+  q->executed_stages = -1; q->count = -1; q->prefix_valid = false;
+  Stage* last = q->stages.empty() ? nullptr : &q->stages.back();
+  const bool new_is_range = ns.kind != ST_PRED;
+  if (last && last->kind != ST_PRED && new_is_range) {   // range∘range collapses to old[elem] (:40)
+    Stage r;
+    if (last->kind == ST_INTEGER) {                       // Number indexing: only x[1]
+      if (!(ns.kind == ST_INTEGER && ns.idx[0] == 1)) fail(DFDB_ERR_BOUNDS, "BoundsError: indexing a scalar selection");
+      return;
+    }
+    if (ns.kind == ST_INTEGER) { r.kind = ST_INTEGER; r.idx = {last->elem(ns.idx[0])}; }
+    else if (last->kind == ST_RANGE && ns.kind == ST_RANGE) {
+      r.kind = ST_RANGE; r.step = last->step * ns.step;
+      if (ns.n == 0) { r.start = last->start; r.stop = r.start - r.step; }
+      else { r.start = last->elem(ns.start); r.stop = last->elem(ns.stop); }
+    } else {
+      r.kind = ST_INDICES; r.idx.resize((size_t)ns.n);
+      for (int64_t k = 0; k < ns.n; k++) r.idx[(size_t)k] = last->elem(ns.kind == ST_RANGE ? ns.start + k * ns.step : ns.idx[(size_t)k]);
+    }
+    normalise(r);
+    *last = std::move(r);
+    return;
+  }
+  if (last && last->kind == ST_PRED && !new_is_range) {   // predicate∘predicate fuses with & (:44-47)
+    last->pred = make_and(std::move(last->pred), std::move(ns.pred));
+    return;
+  }
+  q->stages.push_back(std::move(ns));
+}
+
+// ---------------------------------------------------------------- device state
+static size_t padded_words(int64_t nrows) { return (size_t)(round_up(nrows > 0 ? nrows : 1, kCTileRows) / 64 + 64); }
+
+static void ensure_state(dfdb_query* q) {
+  dfdb_table* t = q->t;
+  if (t->nrows < 0) fail(DFDB_ERR_ARGUMENT, "table has no resident columns: call dfdb_table_load / add_column first");
+  const int64_t nrows = t->nrows;
+  if (q->bitmap_rows != nrows) {
+    const size_t nw = padded_words(nrows);
+    const int64_t ntiles = ceil_div(nrows, kTileRows);
+    q->bitmap.ensure(nw * 8);
+    HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, nw * 8, t->ctx->stream));   // pad words stay zero forever
+    q->tile_counts.ensure((size_t)(ntiles + 8) * 4);
+    q->prefix.ensure((size_t)(ntiles + 8) * 8);
+    HIP_CHECK(hipMemsetAsync(q->prefix.p, 0, (size_t)(ntiles + 8) * 8, t->ctx->stream));
+    q->scan_scratch.ensure(scan_counts_scratch_bytes(ntiles));
+    q->bitmap_rows = nrows;
+    q->executed_stages = -1;
+  }
+}
+
+static const Column& need_resident(const dfdb_table* t, int ordinal) {
+  const Column& c = t->cols[(size_t)ordinal];
+  if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  return c;
+}
+
+static void scan_prefix(dfdb_query* q) {
+  dfdb_ctx* ctx = q->t->ctx;
+  LaunchTimer lt(ctx, "scan_counts");
+  launch_scan_counts(ctx->stream, q->tile_counts.as<uint32_t>(), q->prefix.as<uint64_t>(), ceil_div(q->t->nrows, kTileRows), q->scan_scratch.as<uint64_t>());
+  q->prefix_valid = true;
+}
+
+// predicate stage = AND of its conjuncts, each routed to the cheapest kernel that is exact for it
+static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int64_t nrows = t->nrows;
+  std::vector<const Node*> conj; flatten_and(pred, conj);
+  std::vector<const Node*> generic, strs; ScanTerms terms{}; terms.n = 0; terms.combine_or = 0;
+  std::vector<ScanTerms> term_batches;
+  for (const Node* c : conj) {
+    ScanTerm tm; int ord; int mode; std::string pat;
+    if (match_simple_term(*c, *t, tm, ord)) {
+      tm.col = need_resident(t, ord).data.p;
+      if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }
+      terms.t[terms.n++] = tm;
+    } else if (match_string_term(*c, *t, ord, mode, pat)) strs.push_back(c);
+    else generic.push_back(c);
+  }
+  if (terms.n) term_batches.push_back(terms);
+  bool have = !first_stage;   // does the bitmap already hold a mask to AND with?
+  // generic conjuncts first: their DivideError check sees exactly the rows that reached this stage
+  for (const Node* c : generic) { run_interp_predicate(q, *c, have); have = true; }
+  for (const Node* c : strs) {
+    int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
+    const Column& col = need_resident(t, ord);
+    DevBuf& pb = q->tmp_a; pb.ensure(pat.size() + 64);
+    if (pat.size() > 64) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+    LaunchTimer lt(ctx, "str_match");
+    launch_str_match(s, col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(), (const uint8_t*)pat.data(),
+                     pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+    have = true;
+  }
+  for (const ScanTerms& tb : term_batches) {
+    if (tb.n == 1) {
+      LaunchTimer lt(ctx, "scan_cmp");
+      launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+    } else {
+      LaunchTimer lt(ctx, "scan_terms");
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+    }
+    have = true;
+  }
+}
+
+static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  RangeSpec r{};
+  if (st.kind == ST_RANGE) {
+    r.kind = 0; r.first = st.first(); r.last = st.last(); r.step = st.step > 0 ? st.step : -st.step;
+    if (st.n == 0) { r.first = 1; r.last = 0; r.step = 1; }
+  } else {   // index vectors keep table order and collapse duplicates (quirk Q3): membership in the sorted unique list
+    std::vector<int64_t> sorted(st.idx);
+    std::sort(sorted.begin(), sorted.end());
+    sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+    q->idx_sorted.ensure(sorted.size() * 8 + 64);
+    if (!sorted.empty()) HIP_CHECK(hipMemcpyAsync(q->idx_sorted.p, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));   // `sorted` is pageable host memory
+    r.kind = 1; r.sorted = q->idx_sorted.as<int64_t>(); r.nsorted = (int64_t)sorted.size();
+    r.first = sorted.empty() ? 1 : sorted.front(); r.last = sorted.empty() ? 0 : sorted.back(); r.step = 1;
+  }
+  if (!first_stage && !q->prefix_valid) scan_prefix(q);
+  // a leading range stage numbers TABLE rows (row_base makes that global on a shard); later stages number
+  // the survivors, continuing after the survivors that live on lower ranks (stage_base)
+  const int64_t rank_base = first_stage ? t->row_base : st.stage_base;
+  LaunchTimer lt(ctx, "range_stage");
+  launch_range_stage(s, r, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows, rank_base, first_stage);
+  q->prefix_valid = false;
+}
+
+void query_execute(dfdb_query* q, int nstages) {
+  ensure_state(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
+  if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1;
+  if (nstages == 0) {
+    LaunchTimer lt(ctx, "fill_ones");
+    launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
+  }
+  for (int i = 0; i < nstages; i++) {
+    const Stage& st = q->stages[(size_t)i];
+    if (st.kind == ST_PRED) { run_predicate(q, *st.pred, i == 0); q->prefix_valid = false; }
+    else run_range(q, st, i == 0);
+  }
+  scan_prefix(q);
+  q->executed_stages = nstages;
+}
+
+static void ensure_executed(dfdb_query* q) {
+  if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
+}
+
+int64_t query_count(dfdb_query* q, int nstages) {
+  if (nstages < 0) { ensure_executed(q); if (q->count >= 0) return q->count; }
+  else query_execute(q, nstages);
+  dfdb_ctx* ctx = q->t->ctx;
+  const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
+  HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const int64_t n = ctx->pinned_scalar[0];
+  if (nstages < 0) q->count = n;
+  return n;
+}
+
+void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
+  ensure_executed(q);
+  hipStream_t s = q->t->ctx->stream;
+  const size_t bytes = (size_t)ceil_div(q->t->nrows, 64) * 8;
+  if (!bytes) return;
+  HIP_CHECK(hipMemcpyAsync(out, q->bitmap.p, bytes, memkind == DFDB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  if (memkind != DFDB_MEM_DEVICE) HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
+  ensure_executed(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (memkind == DFDB_MEM_DEVICE) {
+    { LaunchTimer lt(ctx, "compact_indices");
+      launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap); }
+    if (n) *n = query_count(q, -1);
+    return;
+  }
+  const int64_t cnt = query_count(q, -1);
+  if (n) *n = cnt;
+  const int64_t m = std::min(cnt, cap);
+  if (m <= 0) return;
+  q->tmp_b.ensure((size_t)m * 8);
+  { LaunchTimer lt(ctx, "compact_indices");
+    launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m); }
+  HIP_CHECK(hipMemcpyAsync(out, q->tmp_b.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ---------------------------------------------------------------- materialize
+// selected string bytes per 4096-row ctile -> exclusive scan (output arena offsets); returns total
+static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_sizes_tmp, int32_t* out_sizes, int64_t cap, DevBuf& tile_off_out) {
+  dfdb_ctx* ctx = q->t->ctx; hipStream_t s = ctx->stream;
+  const int64_t nct = ceil_div(q->t->nrows, kCTileRows);
+  DevBuf& tb = q->tmp_c; tb.ensure((size_t)(nct + 8) * 4);
+  tile_off_out.ensure((size_t)(nct + 8) * 8);
+  DevBuf scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
+  int32_t* dst_sizes = out_sizes;
+  if (!dst_sizes) { out_sizes_tmp.ensure((size_t)std::max<int64_t>(cap, 1) * 4); dst_sizes = out_sizes_tmp.as<int32_t>(); }
+  { LaunchTimer lt(ctx, "str_gather_sizes");
+    launch_str_gather_sizes(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.as<int32_t>(), dst_sizes, tb.as<uint32_t>(), q->t->nrows, cap); }
+  launch_scan_counts(s, tb.as<uint32_t>(), tile_off_out.as<uint64_t>(), nct, scratch.as<uint64_t>());
+  HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 1, tile_off_out.as<uint64_t>() + nct, 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  return ctx->pinned_scalar[1];
+}
+
+int64_t query_string_bytes(dfdb_query* q, int i) {
+  ensure_executed(q);
+  if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
+  const Node& e = *q->proj[(size_t)i].expr;
+  if (dt_base(e.dtype) != DFDB_STRING) return 0;
+  if (e.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
+  const Column& col = need_resident(q->t, e.col);
+  const int64_t cnt = query_count(q, -1);
+  DevBuf tmp_sizes, toff;
+  return string_out_offsets(q, col, tmp_sizes, nullptr, cnt, toff);
+}
+
+void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
+  ensure_executed(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (ncols != (int32_t)q->proj.size()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: view has %zu columns, %d outputs given", q->proj.size(), ncols);
+  const int64_t cnt = query_count(q, -1);
+  for (int32_t p = 0; p < ncols; p++) {
+    const Node& e = *q->proj[(size_t)p].expr; dfdb_outcol& o = outs[p];
+    o.dtype = e.dtype; o.count = cnt; o.nbytes = 0;
+    const bool dev = o.memkind == DFDB_MEM_DEVICE;
+    const int w = dt_width(e.dtype);
+    if (cnt == 0) continue;
+    if (!o.data) fail(DFDB_ERR_ARGUMENT, "output column %d has no data buffer", p);
+    if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
+      const Column& col = need_resident(t, e.col);
+      if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
+        DevBuf dsz, toff, dbytes;
+        int32_t* d_sizes = dev ? (int32_t*)o.data : nullptr;
+        const int64_t total = string_out_offsets(q, col, dsz, d_sizes, cnt, toff);
+        if (!d_sizes) d_sizes = dsz.as<int32_t>();
+        o.nbytes = total;
+        if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
+        uint8_t* d_bytes = dev ? o.bytes : nullptr;
+        if (!dev) { dbytes.ensure((size_t)total + 64); d_bytes = dbytes.as<uint8_t>(); }
+        if (total > 0) {
+          LaunchTimer lt(ctx, "str_gather_bytes");
+          launch_str_gather_bytes(s, q->bitmap.as<uint64_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                                  toff.as<uint64_t>(), d_bytes, t->nrows, total);
+        }
+        if (!dev) {
+          HIP_CHECK(hipMemcpyAsync(o.data, d_sizes, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+          if (total > 0) HIP_CHECK(hipMemcpyAsync(o.bytes, d_bytes, (size_t)total, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        continue;
+      }
+      DevBuf stage; void* dst = o.data;
+      if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
+      { LaunchTimer lt(ctx, "gather");
+        launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt); }
+      if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
+      if (dt_nullable(e.dtype) && o.missing) {
+        DevBuf ms; uint8_t* md = o.missing;
+        if (!dev) { ms.ensure((size_t)cnt); md = ms.as<uint8_t>(); }
+        launch_gather_bits(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.missing.as<uint64_t>(), md, t->nrows, cnt);
+        if (!dev) HIP_CHECK(hipMemcpyAsync(o.missing, md, (size_t)cnt, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      }
+      HIP_CHECK(hipStreamSynchronize(s));
+    } else {                  // BroadcastExecutor: computed column (projection.jl:128-129)
+      if (dt_base(e.dtype) == DFDB_STRING) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
+      DevBuf stage; void* dst = o.data;
+      if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
+      run_interp_project(q, e, dst, cnt);
+      if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  }
+}
+
+void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
+  ensure_executed(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (op == DFDB_AGG_COUNT) { const int64_t n = query_count(q, -1); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
+  if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
+  const Node& e = *q->proj[(size_t)i].expr;
+  if (!dt_isnum(e.dtype) || dt_nullable(e.dtype)) fail(DFDB_ERR_UNSUPPORTED, "aggregate over %s is not supported", dt_name(e.dtype).c_str());
+  const void* src; DevBuf full; int dt = dt_base(e.dtype);
+  const uint64_t* mask = q->bitmap.as<uint64_t>();
+  DevBuf ones;
+  if (e.op == DFIR_COL) src = need_resident(t, e.col).data.p;
+  else {   // computed column: materialise the selected values, then reduce them all
+    const int64_t cnt = query_count(q, -1);
+    full.ensure((size_t)std::max<int64_t>(cnt, 1) * dt_width(dt) + 256);
+    if (cnt) run_interp_project(q, e, full.p, cnt);
+    const size_t nw = padded_words(cnt);
+    ones.ensure(nw * 8);
+    HIP_CHECK(hipMemsetAsync(ones.p, 0xff, (size_t)(cnt / 64) * 8, s));
+    uint64_t tail = (cnt & 63) ? ((1ull << (cnt & 63)) - 1ull) : 0ull;
+    HIP_CHECK(hipMemcpyAsync((uint64_t*)ones.p + cnt / 64, &tail, 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    src = full.p; mask = ones.as<uint64_t>();
+    q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
+    { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, cnt, q->red_scratch.p, q->red_result.p); }
+    goto readback;
+  }
+  q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
+  { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, t->nrows, q->red_scratch.p, q->red_result.p); }
+readback:
+  HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->red_result.p, 16, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (ctx->pinned_scalar[1] == 0 && op != DFDB_AGG_SUM) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
+  if (dt_isfloat(dt)) { double d; memcpy(&d, &ctx->pinned_scalar[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
+  else { const int64_t v = ctx->pinned_scalar[0]; if (out_i) *out_i = v; if (out_f) *out_f = dt == DFDB_U64 ? (double)(uint64_t)v : (double)v; }
+}
+
+}  // namespace dfdb

@@ -1,0 +1,319 @@
+// table.cpp — DFTable on the device: metadata parsing, column residency, block loading.
+//
+// Replaces (paths under /root/reference): open_table src/tables/creators.jl:7-16, read_table_meta
+// src/io/table_io.jl:21-33, check_column_head src/io/filesystem.jl:47-54, and — for the data — the
+// per-block BlockStream.read_block + read_block_body! loop of src/io/BlockStreams.jl:101-119 and
+// src/io/blocks.jl:37-71, which here becomes: stage the compressed file bytes in HBM once, LZ4-decode all
+// blocks of a column in ONE launch (K7, a wave per block), and leave the decoded column contiguous in HBM.
+#include "engine.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <sys/stat.h>
+
+namespace dfdb {
+
+// ---------------------------------------------------------------- little-endian readers
+struct Rd {
+  const uint8_t* p; size_t n, pos;
+  bool i32(int32_t& v) { if (pos + 4 > n) return false; memcpy(&v, p + pos, 4); pos += 4; return true; }
+  bool i64(int64_t& v) { if (pos + 8 > n) return false; memcpy(&v, p + pos, 8); pos += 8; return true; }
+  bool str(std::string& s) {  // read_string: common_io.jl:5-8 (Int32 nbytes + bytes)
+    int32_t l; if (!i32(l) || l < 0 || pos + (size_t)l > n) return false;
+    s.assign((const char*)p + pos, (size_t)l); pos += (size_t)l; return true;
+  }
+};
+
+static std::vector<uint8_t> slurp(const std::string& fn, bool& ok, size_t max_bytes = SIZE_MAX) {
+  std::vector<uint8_t> v; ok = false;
+  FILE* f = fopen(fn.c_str(), "rb"); if (!f) return v;
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  size_t want = (size_t)n < max_bytes ? (size_t)n : max_bytes;
+  v.resize(want);
+  ok = fread(v.data(), 1, want, f) == want;
+  fclose(f); return v;
+}
+
+void table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out) {
+  const std::string dir(path);
+  bool ok;
+  std::vector<uint8_t> m = slurp(dir + "/meta.bin", ok);   // metapath: filesystem.jl:8
+  if (!ok) fail(DFDB_ERR_IO, "table %s don't exists", path);
+  auto t = std::make_unique<dfdb_table>();
+  t->ctx = ctx; t->path = dir;
+  Rd r{m.data(), m.size(), 0};
+  int64_t ncols = 0;
+  if (!r.i64(t->format_version) || !r.i64(t->block_size) || !r.i64(ncols) || ncols < 0 || ncols > 1000000 || t->block_size <= 0)
+    fail(DFDB_ERR_FORMAT, "bad meta.bin in %s", path);
+  for (int64_t i = 0; i < ncols; i++) {
+    Column c; std::string ty;
+    if (!r.i64(c.id) || !r.str(c.name) || !r.str(ty)) fail(DFDB_ERR_FORMAT, "bad meta.bin in %s", path);
+    c.dtype = dt_parse(ty);
+    c.file = dir + "/" + std::to_string(c.id) + ".bin";   // columnpath: filesystem.jl:11
+    t->cols.push_back(std::move(c));
+  }
+  for (auto& c : t->cols) {   // check_column_file / check_column_head: filesystem.jl:47-61
+    std::vector<uint8_t> h = slurp(c.file, ok, 4096);
+    if (!ok) fail(DFDB_ERR_IO, "column file '%s' for column %s don't exists", c.file.c_str(), c.name.c_str());
+    Rd hr{h.data(), h.size(), 0};
+    int64_t bs; std::string ty;
+    if (!hr.i64(bs) || !hr.str(ty)) fail(DFDB_ERR_FORMAT, "bad column header in %s", c.file.c_str());
+    if (bs != t->block_size) fail(DFDB_ERR_FORMAT, "column %s has blocksize %lld, but table has blocksize %lld", c.name.c_str(), (long long)bs, (long long)t->block_size);
+    if (dt_parse(ty) != c.dtype) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_name(c.dtype).c_str());
+    c.data_off = hr.pos;
+  }
+  *out = t.release();
+}
+
+static void set_table_rows(dfdb_table* t, int64_t nrows) {
+  if (t->nrows >= 0 && t->nrows != nrows)
+    fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table holds %lld resident rows", (long long)nrows, (long long)t->nrows);
+  t->nrows = nrows;
+}
+
+static Column& new_column(dfdb_table* t, const char* name, int32_t dtype) {
+  for (auto& c : t->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
+  if (dt_base(dtype) < 1 || dt_base(dtype) > 12) fail(DFDB_ERR_UNSUPPORTED, "unsupported dtype %d", dtype);
+  Column c; c.name = name; c.dtype = dtype; c.id = (int64_t)t->cols.size() + 1;
+  t->cols.push_back(std::move(c));
+  return t->cols.back();
+}
+
+// bitmap words for n rows, padded so that K2's 64-word (4096-row) reads stay in bounds
+static size_t padded_words(int64_t nrows) { return (size_t)(round_up(nrows > 0 ? nrows : 1, kCTileRows) / 64 + 64); }
+
+// K4: byte offset of every 1024-row string tile = exclusive scan of the per-tile sums of max(size,0)
+// (the parallel form of unsafe_remake_offsets!: FlatStringsVectors.jl:61-70)
+void set_string_tile_offsets(dfdb_ctx* ctx, Column& c) {
+  const int64_t ntiles = ceil_div(c.nrows, kStrTileRows);
+  DevBuf tb, scratch;
+  tb.ensure((size_t)(ntiles + 1) * 4);
+  scratch.ensure(scan_counts_scratch_bytes(ntiles));
+  c.tile_off.ensure((size_t)(ntiles + 2) * 8);
+  launch_str_tile_bytes(ctx->stream, c.data.as<int32_t>(), tb.as<uint32_t>(), c.nrows);
+  launch_scan_counts(ctx->stream, tb.as<uint32_t>(), c.tile_off.as<uint64_t>(), ntiles, scratch.as<uint64_t>());
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));   // tb/scratch die here
+}
+
+void table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nrows, const void* data, const uint8_t* bytes,
+                      int64_t nbytes, const uint8_t* missing) {
+  if (nrows < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
+  set_table_rows(t, nrows);
+  Column& c = new_column(t, name, dtype);
+  hipStream_t s = t->ctx->stream;
+  c.nrows = nrows;
+  if (dt_base(dtype) == DFDB_STRING) {
+    c.data.ensure((size_t)nrows * 4 + 256);
+    if (nrows) HIP_CHECK(hipMemcpyAsync(c.data.p, data, (size_t)nrows * 4, hipMemcpyHostToDevice, s));
+    c.nbytes = nbytes;
+    c.bytes.ensure((size_t)nbytes + 64);
+    if (nbytes) HIP_CHECK(hipMemcpyAsync(c.bytes.p, bytes, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + nbytes, 0, 64, s));
+    set_string_tile_offsets(t->ctx, c);
+  } else {
+    const int w = dt_width(dtype);
+    c.data.ensure((size_t)nrows * w + 256);
+    if (nrows) HIP_CHECK(hipMemcpyAsync(c.data.p, data, (size_t)nrows * w, hipMemcpyHostToDevice, s));
+    if (dt_nullable(dtype)) {   // pack the caller's byte flags into the 1-bit/row device layout
+      const size_t nw = padded_words(nrows);
+      std::vector<uint64_t> bits(nw, 0);
+      if (missing) for (int64_t i = 0; i < nrows; i++) if (missing[i]) bits[(size_t)i >> 6] |= 1ull << (i & 63);
+      c.missing.ensure(nw * 8);
+      HIP_CHECK(hipMemcpyAsync(c.missing.p, bits.data(), nw * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  c.resident = true;
+}
+
+void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t seed, int64_t row_first, int64_t nrows) {
+  if (nrows < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
+  set_table_rows(t, nrows);
+  hipStream_t s = t->ctx->stream;
+  switch (gen) {
+    case DFDB_GEN_I64_MOD1M: case DFDB_GEN_I64_IOTA: {
+      Column& c = new_column(t, name, DFDB_I64); c.nrows = nrows;
+      c.data.ensure((size_t)nrows * 8 + 256);
+      if (gen == DFDB_GEN_I64_MOD1M) launch_gen_i64_mod1m(s, c.data.as<int64_t>(), seed, row_first, nrows);
+      else launch_gen_i64_iota(s, c.data.as<int64_t>(), row_first, nrows);
+      c.resident = true; break;
+    }
+    case DFDB_GEN_F64_U2000: {
+      Column& c = new_column(t, name, DFDB_F64); c.nrows = nrows;
+      c.data.ensure((size_t)nrows * 8 + 256);
+      launch_gen_f64_u2000(s, c.data.as<double>(), seed, row_first, nrows);
+      c.resident = true; break;
+    }
+    case DFDB_GEN_STR_BRANDS10: {
+      Column& c = new_column(t, name, DFDB_STRING); c.nrows = nrows;
+      c.data.ensure((size_t)nrows * 4 + 256);
+      launch_gen_brand_sizes(s, c.data.as<int32_t>(), seed, row_first, nrows);
+      set_string_tile_offsets(t->ctx, c);
+      const int64_t ntiles = ceil_div(nrows, kStrTileRows);
+      uint64_t total = 0;
+      HIP_CHECK(hipMemcpy(&total, c.tile_off.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost));
+      c.nbytes = (int64_t)total;
+      c.bytes.ensure((size_t)total + 64);
+      HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + total, 0, 64, s));
+      launch_gen_brand_bytes(s, c.data.as<int32_t>(), (const int64_t*)c.tile_off.p, c.bytes.as<uint8_t>(), seed, row_first, nrows);
+      c.resident = true; break;
+    }
+    default: fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ---------------------------------------------------------------- block loading (D1-D6)
+struct BlockHdr { int32_t rows; int64_t origin, compressed; size_t body_off; };
+
+// read_sizes over the whole image (BlockStreams.jl:68-72): host walks the 20-byte headers only
+static std::vector<BlockHdr> walk_blocks(const uint8_t* img, size_t n, size_t pos) {
+  std::vector<BlockHdr> v;
+  while (pos < n) {
+    if (pos + 20 > n) fail(DFDB_ERR_FORMAT, "truncated block header");
+    BlockHdr h; memcpy(&h.rows, img + pos, 4); memcpy(&h.origin, img + pos + 4, 8); memcpy(&h.compressed, img + pos + 12, 8);
+    if (h.rows < 0 || h.origin < 0 || h.compressed < 0 || (uint64_t)h.compressed > n - pos - 20) fail(DFDB_ERR_FORMAT, "corrupt block header");
+    h.body_off = pos + 20;
+    pos += 20 + (size_t)h.compressed;
+    v.push_back(h);
+  }
+  return v;
+}
+
+// K8 + block bodies on the device (k_decode.hip)
+void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, int32_t nblocks, int width,
+                            uint8_t* values, uint64_t* missing_bits);
+void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* byte_off,
+                           int32_t nblocks, int32_t* sizes, uint8_t* bytes);
+
+static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t nbytes, size_t data_off, int64_t block_first,
+                            int64_t block_last, dfdb_sizestats* stats) {
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  std::vector<BlockHdr> all = walk_blocks(img, nbytes, data_off);
+  const int64_t nb_total = (int64_t)all.size();
+  if (block_last < 0 || block_last > nb_total) block_last = nb_total;
+  if (block_first < 0) block_first = 0;
+  if (block_first > block_last) block_first = block_last;
+  const int64_t nb = block_last - block_first;
+  for (int64_t b = 0; b + 1 < nb_total; b++)
+    if (all[b].rows != t->block_size) fail(DFDB_ERR_FORMAT, "block %lld of column %s holds %d rows, expected block_size %lld", (long long)b, c.name.c_str(), all[b].rows, (long long)t->block_size);
+  int64_t nrows = 0, comp_lo = 0, comp_hi = 0, origin_total = 0;
+  for (int64_t b = block_first; b < block_last; b++) { nrows += all[b].rows; origin_total += all[b].origin; }
+  if (nb) { comp_lo = (int64_t)all[block_first].body_off; comp_hi = (int64_t)(all[block_last - 1].body_off + all[block_last - 1].compressed); }
+  if (t->nrows >= 0 && t->nrows != nrows)
+    fail(DFDB_ERR_ARGUMENT, "column %s would load %lld rows but the table holds %lld resident rows", c.name.c_str(), (long long)nrows, (long long)t->nrows);
+  if (t->nrows >= 0 && t->block_first != block_first) fail(DFDB_ERR_ARGUMENT, "all columns of a table must load the same block range");
+  const int w = dt_width(c.dtype);
+  const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
+
+  // stage the compressed byte range in HBM
+  DevBuf staged, bodies, dblocks, dstatus, d_aux;
+  staged.ensure((size_t)(comp_hi - comp_lo) + 64);
+  if (comp_hi > comp_lo) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
+
+  std::vector<Lz4Block> blocks((size_t)nb);
+  std::vector<int64_t> body_off((size_t)nb + 1), row_off((size_t)nb + 1), byte_off((size_t)nb + 1);
+  int64_t bo = 0, ro = 0, so = 0;
+  for (int64_t i = 0; i < nb; i++) {
+    const BlockHdr& h = all[block_first + i];
+    if (h.origin > 0x7fffffffLL || h.compressed > 0x7fffffffLL) fail(DFDB_ERR_FORMAT, "block larger than the LZ4 block limit");
+    int64_t expect_min = is_str ? 4 + 4ll * h.rows : (is_null ? 8 * ceil_div(h.rows, 64) + (int64_t)w * h.rows : (int64_t)w * h.rows);
+    if (is_str ? h.origin < expect_min : h.origin != expect_min)
+      fail(DFDB_ERR_FORMAT, "block %lld of column %s has body of %lld bytes, expected %lld", (long long)(block_first + i), c.name.c_str(), (long long)h.origin, (long long)expect_min);
+    blocks[i].src_off = (int64_t)h.body_off - comp_lo; blocks[i].src_len = (int32_t)h.compressed; blocks[i].dst_len = (int32_t)h.origin;
+    blocks[i].dst_off = bo;
+    body_off[i] = bo; row_off[i] = ro; byte_off[i] = so;
+    bo += round_up(h.origin, 16); ro += h.rows; if (is_str) so += h.origin - 4 - 4ll * h.rows;
+  }
+  body_off[nb] = bo; row_off[nb] = ro; byte_off[nb] = so;
+
+  c.nrows = nrows;
+  uint8_t* decode_dst;
+  if (!is_str && !is_null) {   // plain fixed width: decode straight into the column (no read!(io, v) copy: blocks.jl:43)
+    c.data.ensure((size_t)nrows * w + 256);
+    decode_dst = c.data.as<uint8_t>();
+    int64_t off = 0;
+    for (int64_t i = 0; i < nb; i++) { blocks[i].dst_off = off; off += (int64_t)w * all[block_first + i].rows; }
+  } else {
+    bodies.ensure((size_t)bo + 64);
+    decode_dst = bodies.as<uint8_t>();
+  }
+  if (nb) {
+    dblocks.ensure(sizeof(Lz4Block) * (size_t)nb);
+    dstatus.ensure(4 * (size_t)nb);
+    HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)nb, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4 * (size_t)nb, s));
+    { LaunchTimer lt(ctx, "lz4_decode"); launch_lz4_decode(s, staged.as<uint8_t>(), decode_dst, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>()); }
+    std::vector<int32_t> st((size_t)nb);
+    HIP_CHECK(hipMemcpyAsync(st.data(), dstatus.p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < nb; i++) if (st[i] != 0) fail(DFDB_ERR_FORMAT, "decompression error in block %lld of column %s", (long long)(block_first + i), c.name.c_str());
+  }
+  if (is_str || is_null) {
+    d_aux.ensure(8 * 3 * ((size_t)nb + 1));
+    int64_t* d_body = d_aux.as<int64_t>(); int64_t* d_row = d_body + nb + 1; int64_t* d_byte = d_row + nb + 1;
+    HIP_CHECK(hipMemcpyAsync(d_body, body_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_byte, byte_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
+    if (is_str) {
+      c.data.ensure((size_t)nrows * 4 + 256);
+      c.nbytes = so; c.bytes.ensure((size_t)so + 64);
+      HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + so, 0, 64, s));
+      if (nb) launch_unpack_strings(s, bodies.as<uint8_t>(), d_body, d_row, d_byte, (int32_t)nb, c.data.as<int32_t>(), c.bytes.as<uint8_t>());
+      set_string_tile_offsets(ctx, c);
+      // datasize must equal the sum of the positive sizes (unsafe_remake_offsets!: FlatStringsVectors.jl:69)
+      uint64_t total = 0;
+      HIP_CHECK(hipMemcpy(&total, c.tile_off.as<uint64_t>() + ceil_div(nrows, kStrTileRows), 8, hipMemcpyDeviceToHost));
+      if ((int64_t)total != so) fail(DFDB_ERR_FORMAT, "string column %s: sizes sum to %llu bytes but blocks hold %lld", c.name.c_str(), (unsigned long long)total, (long long)so);
+    } else {
+      c.data.ensure((size_t)nrows * w + 256);
+      const size_t nw = padded_words(nrows);
+      c.missing.ensure(nw * 8);
+      HIP_CHECK(hipMemsetAsync(c.missing.p, 0, nw * 8, s));
+      if (nb) launch_unpack_nullable(s, bodies.as<uint8_t>(), d_body, d_row, (int32_t)nb, w, c.data.as<uint8_t>(), c.missing.as<uint64_t>());
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  if (t->nrows < 0) { t->nrows = nrows; t->block_first = block_first; t->row_base = block_first * t->block_size; }
+  c.resident = true;
+  if (stats) {   // SizeStats incl. the 24-byte header quirk (BlockStreams.jl:7,23)
+    stats->rows = nrows;
+    for (int64_t b = block_first; b < block_last; b++) { stats->compressed += all[b].compressed + 24; stats->uncompressed += all[b].origin; }
+  }
+  (void)origin_total;
+}
+
+void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,
+                      dfdb_sizestats* stats) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  // validate the header like check_column_head does
+  Rd hr{image, nbytes, 0}; int64_t bs; std::string ty;
+  if (!hr.i64(bs) || !hr.str(ty)) fail(DFDB_ERR_FORMAT, "bad column header");
+  if (bs != t->block_size) fail(DFDB_ERR_FORMAT, "column %s has blocksize %lld, but table has blocksize %lld", c.name.c_str(), (long long)bs, (long long)t->block_size);
+  if (dt_parse(ty) != c.dtype) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_name(c.dtype).c_str());
+  dfdb_sizestats st{0, 0, 0};
+  load_from_image(t, c, image, nbytes, hr.pos, block_first, block_last, &st);
+  if (stats) *stats = st;
+}
+
+void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {
+  dfdb_sizestats tot{0, 0, 0};
+  std::vector<int32_t> all;
+  if (!ordinals) { for (size_t i = 0; i < t->cols.size(); i++) all.push_back((int32_t)i); ordinals = all.data(); ncols = (int32_t)all.size(); }
+  for (int32_t k = 0; k < ncols; k++) {
+    const int32_t o = ordinals[k];
+    if (o < 0 || (size_t)o >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", o);
+    Column& c = t->cols[(size_t)o];
+    if (c.resident) continue;
+    if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
+    bool ok; std::vector<uint8_t> img = slurp(c.file, ok);
+    if (!ok) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
+    dfdb_sizestats st{0, 0, 0};
+    load_from_image(t, c, img.data(), img.size(), c.data_off, block_first, block_last, &st);
+    tot.rows = st.rows; tot.compressed += st.compressed; tot.uncompressed += st.uncompressed;
+  }
+  if (stats) *stats = tot;
+}
+
+}  // namespace dfdb

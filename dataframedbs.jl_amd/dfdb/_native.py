@@ -1,0 +1,102 @@
+"""ctypes binding of libdfdb_hip.so (include/dfdb.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is visible, loading or
+creating a context raises.  The same symbols are what the Julia `ccall` shim binds.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "libdfdb_hip.so")
+
+# status codes -> the Python exception standing in for the Julia one (include/dfdb.h)
+OK, ERR_ARGUMENT, ERR_IO, ERR_FORMAT, ERR_KEY, ERR_BOUNDS, ERR_DIVIDE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = range(10)
+MEM_HOST, MEM_DEVICE = 0, 1
+GEN_I64_MOD1M, GEN_F64_U2000, GEN_STR_BRANDS10, GEN_I64_IOTA = 1, 2, 3, 4
+AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2, 3
+
+
+class DfdbError(RuntimeError):
+    """ErrorException (bad/missing file, header mismatch, decompression error, device failure)."""
+
+
+_EXC = {ERR_ARGUMENT: ValueError, ERR_IO: DfdbError, ERR_FORMAT: DfdbError, ERR_KEY: KeyError, ERR_BOUNDS: IndexError,
+        ERR_DIVIDE: ZeroDivisionError, ERR_UNSUPPORTED: NotImplementedError, ERR_DEVICE: DfdbError, ERR_NOMEM: MemoryError}
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("compute_units", C.c_int32), ("wavefront_size", C.c_int32),
+                ("hbm_bytes", C.c_int64), ("peak_hbm_gbps", C.c_double)]
+
+
+class ColInfo(C.Structure):
+    _fields_ = [("id", C.c_int64), ("name", C.c_char * 128), ("dtype", C.c_int32), ("resident", C.c_int32)]
+
+
+class SizeStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("compressed", C.c_int64), ("uncompressed", C.c_int64)]
+
+
+class OutCol(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes", C.c_void_p), ("missing", C.c_void_p), ("bytes_cap", C.c_int64),
+                ("memkind", C.c_int32), ("dtype", C.c_int32), ("count", C.c_int64), ("nbytes", C.c_int64)]
+
+
+# every exported symbol of include/dfdb.h: (restype is always int32 status)
+SYMBOLS = [
+    "dfdb_version", "dfdb_last_error",
+    "dfdb_ctx_create", "dfdb_ctx_destroy", "dfdb_ctx_synchronize", "dfdb_ctx_device_info", "dfdb_ctx_timer_start",
+    "dfdb_ctx_timer_stop", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
+    "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",
+    "dfdb_table_colinfo", "dfdb_table_find_column", "dfdb_table_load", "dfdb_table_load_image", "dfdb_table_add_column",
+    "dfdb_table_add_generated", "dfdb_table_set_row_base",
+    "dfdb_query_new", "dfdb_query_free", "dfdb_query_add_range", "dfdb_query_add_indices", "dfdb_query_add_integer",
+    "dfdb_query_add_predicate", "dfdb_query_nstages", "dfdb_query_set_projection", "dfdb_query_ncols", "dfdb_query_coltype",
+    "dfdb_expr_result_type", "dfdb_query_set_stage_base", "dfdb_query_count_prefix",
+    "dfdb_query_execute", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
+    "dfdb_materialize", "dfdb_aggregate",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree HIP library; loud failure if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C dataframedbs.jl_amd/csrc` "
+                              "(__graft_entry__.build()).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(lib, s).restype = C.c_int32
+        lib.dfdb_table_add_generated.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int64]
+        lib.dfdb_table_add_column.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dfdb_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+        lib.dfdb_table_load_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p]
+        lib.dfdb_table_set_row_base.argtypes = [C.c_void_p, C.c_int64]
+        lib.dfdb_query_add_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+        lib.dfdb_query_add_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        lib.dfdb_query_add_integer.argtypes = [C.c_void_p, C.c_int64]
+        lib.dfdb_query_add_predicate.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.dfdb_expr_result_type.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        lib.dfdb_query_set_stage_base.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        lib.dfdb_select_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        lib.dfdb_count_to.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_select_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_ctx_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    load().dfdb_last_error(buf, C.c_size_t(1024))
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int):
+    if rc != OK:
+        raise _EXC.get(rc, DfdbError)(last_error())

@@ -1,0 +1,200 @@
+/* dfdb.h — C ABI of libdfdb_hip.so, the MI355X (gfx950) scan/filter engine that
+ * replaces DataFrameDBs.jl's block-streamed decode + selection + projection +
+ * materialize hot path.
+ *
+ * The reference has no FFI seam of its own (it is pure Julia; its only ccalls are
+ * the three liblz4 entry points in src/io/BlockStreams.jl:39,42,110).  Each entry
+ * point below therefore names the Julia method it stands in for (paths relative
+ * to /root/reference).  A Julia `ccall` shim and the Python ctypes mirror bind
+ * exactly these symbols; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int32 status (0 = DFDB_OK); no exception crosses the ABI
+ *   - dfdb_last_error() gives the thread-local message of the last failure
+ *   - handles are opaque; one host thread per handle at a time (the reference's
+ *     iterator/executors are not thread-safe either: selection.jl:68-75)
+ *   - row numbers are 1-based like Julia; column ordinals are 0-based positions
+ *   - the engine is HIP-only: there is no CPU fallback behind any entry point
+ */
+#ifndef DFDB_H
+#define DFDB_H
+#include <stddef.h>
+#include <stdint.h>
+#include "dfdb_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFDB_ABI_VERSION 1
+
+/* status codes; the Julia exception each maps to */
+enum {
+  DFDB_OK = 0,
+  DFDB_ERR_ARGUMENT = 1,   /* ArgumentError  (selection.jl:54, projection.jl:27, columnbroadcast.jl:22) */
+  DFDB_ERR_IO = 2,         /* ErrorException (filesystem.jl:16,31,50-57,70) */
+  DFDB_ERR_FORMAT = 3,     /* header mismatch / "decompression error" (BlockStreams.jl:112) */
+  DFDB_ERR_KEY = 4,        /* KeyError       (table.jl:54) */
+  DFDB_ERR_BOUNDS = 5,     /* BoundsError    (view.jl:134, column.jl:97, selection.jl:40 range[range]) */
+  DFDB_ERR_DIVIDE = 6,     /* DivideError raised by `%` / `÷` inside a predicate */
+  DFDB_ERR_UNSUPPORTED = 7,/* outside the IR op set: caller falls back to the Julia path */
+  DFDB_ERR_DEVICE = 8,     /* HIP runtime failure (message carries hipGetErrorString) */
+  DFDB_ERR_NOMEM = 9
+};
+
+/* where a caller-provided output buffer lives */
+enum { DFDB_MEM_HOST = 0, DFDB_MEM_DEVICE = 1 };
+
+/* synthetic generators (SURVEY.md §8d "Data generation"): value of 0-based row i is a
+ * function of h = splitmix64(seed + i) */
+enum {
+  DFDB_GEN_I64_MOD1M = 1,   /* Int64   : h mod 1 000 000 */
+  DFDB_GEN_F64_U2000 = 2,   /* Float64 : (h >> 11) * 2^-53 * 2000.0 */
+  DFDB_GEN_STR_BRANDS10 = 3,/* String  : brands10[h mod 10] */
+  DFDB_GEN_I64_IOTA = 4     /* Int64   : i + 1  (the reference tests' 1:N columns) */
+};
+
+/* aggregates over a filtered view (Base.iterate(::DFColumn) column.jl:102-126) */
+enum { DFDB_AGG_COUNT = 0, DFDB_AGG_SUM = 1, DFDB_AGG_MIN = 2, DFDB_AGG_MAX = 3 };
+
+typedef struct dfdb_ctx dfdb_ctx;     /* device + stream + workspace */
+typedef struct dfdb_table dfdb_table; /* DFTable whose columns are decoded and resident in HBM */
+typedef struct dfdb_query dfdb_query; /* DFView: projection + SelectionQueue over one table */
+
+typedef struct dfdb_device_info {
+  char name[128];
+  int32_t compute_units;
+  int32_t wavefront_size;
+  int64_t hbm_bytes;
+  double  peak_hbm_gbps;   /* memoryClockRate * busWidth as reported by hipDeviceProp */
+} dfdb_device_info;
+
+typedef struct dfdb_colinfo {   /* ColumnMeta(id,name,type): src/tables/meta.jl:2-10 */
+  int64_t id;
+  char    name[128];
+  int32_t dtype;      /* DFDB_* | DFDB_NULLABLE */
+  int32_t resident;   /* 1 once decoded blocks are in HBM */
+} dfdb_colinfo;
+
+typedef struct dfdb_sizestats { /* SizeStats: src/io/sizestats.jl:2-10 (compressed adds 24 B/block, quirk Q10) */
+  int64_t rows, compressed, uncompressed;
+} dfdb_sizestats;
+
+/* one output column of materialize(); the caller allocates after dfdb_count()/dfdb_result_layout() */
+typedef struct dfdb_outcol {
+  void*    data;      /* fixed width: count*width bytes ; String: count * int32 sizes (-1 = missing) */
+  uint8_t* bytes;     /* String only: concatenated UTF-8 of the selected rows */
+  uint8_t* missing;   /* nullable only: count bytes, 1 = missing (may be NULL for non-nullable) */
+  int64_t  bytes_cap; /* capacity of `bytes` */
+  int32_t  memkind;   /* DFDB_MEM_HOST | DFDB_MEM_DEVICE */
+  int32_t  dtype;     /* filled by the engine */
+  int64_t  count;     /* filled: rows written */
+  int64_t  nbytes;    /* filled: string bytes written */
+} dfdb_outcol;
+
+/* ------------------------------------------------------------------ misc */
+int32_t dfdb_version(void);
+int32_t dfdb_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------ context */
+/* hip_stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one */
+int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out);
+int32_t dfdb_ctx_destroy(dfdb_ctx* ctx);
+int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx);
+int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
+/* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
+int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);
+int32_t dfdb_ctx_timer_stop(dfdb_ctx* ctx, double* elapsed_ms);
+/* per-kernel-family accumulated device time since the last reset (HIP events around each launch
+ * when profiling is on): name -> (launches, total_ms) */
+int32_t dfdb_ctx_profile_enable(dfdb_ctx* ctx, int32_t on);
+int32_t dfdb_ctx_profile_get(dfdb_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);
+
+/* ------------------------------------------------------------------ tables */
+/* open_table(path): creators.jl:7-16 -> read_table_meta table_io.jl:21-33 + check_column_head filesystem.jl:47-54 */
+int32_t dfdb_table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out);
+/* in-memory table for synthetic / caller-supplied columns (no files) */
+int32_t dfdb_table_new(dfdb_ctx* ctx, int64_t block_size, dfdb_table** out);
+int32_t dfdb_table_close(dfdb_table* t);
+int32_t dfdb_table_ncols(dfdb_table* t, int32_t* n);
+int32_t dfdb_table_nrows(dfdb_table* t, int64_t* n);      /* rows resident on this device */
+int32_t dfdb_table_block_size(dfdb_table* t, int64_t* bs); /* blocksize(t): table.jl:47 */
+int32_t dfdb_table_colinfo(dfdb_table* t, int32_t ordinal, dfdb_colinfo* out); /* getmeta: table.jl:52-56 */
+int32_t dfdb_table_find_column(dfdb_table* t, const char* name, int32_t* ordinal); /* KeyError if absent */
+
+/* BlockStream.read_block + read_block_body! for every block in [block_first, block_last) of the
+ * listed columns (BlockStreams.jl:101-119, blocks.jl:37-71): file -> compressed bytes -> HBM ->
+ * device LZ4 decode -> decoded column resident.  block_last < 0 means "to EOF".  This is the
+ * block-range shard of SURVEY.md §8e: rank g loads only its blocks. */
+int32_t dfdb_table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols,
+                        int64_t block_first, int64_t block_last, dfdb_sizestats* stats);
+/* same from a caller-held image of one column file (header + blocks), e.g. an mmap */
+int32_t dfdb_table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes,
+                              int64_t block_first, int64_t block_last, dfdb_sizestats* stats);
+
+/* caller-supplied decoded column (host memory).  Fixed width: data = nrows*width bytes.
+ * String: data = nrows int32 sizes (-1 = missing), bytes = arena (FlatStringsVector: FlatStringsVectors.jl:5-52).
+ * missing = nrows bytes (1 = missing) or NULL. */
+int32_t dfdb_table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nrows,
+                              const void* data, const uint8_t* bytes, int64_t nbytes,
+                              const uint8_t* missing);
+/* device-side synthetic fill (no PCIe): rows [row_first, row_first+nrows) of the global column */
+int32_t dfdb_table_add_generated(dfdb_table* t, const char* name, int32_t generator,
+                                 uint64_t seed, int64_t row_first, int64_t nrows);
+/* global row number (0-based) of this shard's first row, so that selection indices and leading
+ * range stages refer to table rows when a table is block-range sharded over ranks */
+int32_t dfdb_table_set_row_base(dfdb_table* t, int64_t row_base);
+
+/* ------------------------------------------------------------------ queries (DFView) */
+/* DFView(table): full projection, empty SelectionQueue (view.jl:50) */
+int32_t dfdb_query_new(dfdb_table* t, dfdb_query** out);
+int32_t dfdb_query_free(dfdb_query* q);
+/* selection(v, range): stages are appended with the composition rules of selection.jl:37-60
+ * (range∘range collapses, predicate∘predicate fuses with &). */
+int32_t dfdb_query_add_range(dfdb_query* q, int64_t start, int64_t step, int64_t stop);
+int32_t dfdb_query_add_indices(dfdb_query* q, const int64_t* idx, int64_t n);
+/* selection(v, i::Integer) (view.jl:125,130; column.jl:93-99): a one-element selector that composes like a Number */
+int32_t dfdb_query_add_integer(dfdb_query* q, int64_t i);
+/* selection(v, cols => f) / selection(v, ::DFColumn{Bool}): IR must type to Bool else ArgumentError */
+int32_t dfdb_query_add_predicate(dfdb_query* q, const uint8_t* ir, size_t len);
+int32_t dfdb_query_nstages(dfdb_query* q, int32_t* n);
+/* projection(v, …): replaces the projection by `n` named expressions (plain column = IR "COL k") */
+int32_t dfdb_query_set_projection(dfdb_query* q, int32_t n, const char* const* names,
+                                  const uint8_t* const* irs, const size_t* lens);
+int32_t dfdb_query_ncols(dfdb_query* q, int32_t* n);                 /* ncol(v): view.jl:207-209 */
+int32_t dfdb_query_coltype(dfdb_query* q, int32_t i, int32_t* dtype); /* coltype: projection.jl:80-81 */
+/* result dtype of an expression over the table's columns: Base._return_type in BlockBroadcasting (broadcast.jl:13) */
+int32_t dfdb_expr_result_type(dfdb_table* t, const uint8_t* ir, size_t len, int32_t* dtype);
+
+/* multi-GPU: survivors of the stages before range stage `stage` that live on lower ranks
+ * (exclusive scan of per-shard counts); default 0 */
+int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivors_before);
+/* evaluate the queue only up to (not including) stage `nstages` and count: lets the host run the
+ * all-gather between a predicate stage and a following range stage */
+int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n);
+
+/* ------------------------------------------------------------------ execution */
+/* SelectionExecutor.apply over every resident block (selection.jl:161-167, blocksiterator.jl:98-145):
+ * leaves the selection bitmap + per-tile counts + their prefix in HBM.  Asynchronous. */
+int32_t dfdb_query_execute(dfdb_query* q);
+/* nrow(v) / size(v,1) / length(col): view.jl:192-206, column.jl:46-52 */
+int32_t dfdb_count(dfdb_query* q, int64_t* n);
+/* same total written to a caller buffer without a host sync when memkind == DFDB_MEM_DEVICE (the operand of
+ * the multi-GPU all-reduce) */
+int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind);
+/* 1 bit per resident row, LSB-first in uint64 words (the mask `apply` returns, packed) */
+int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind);
+/* ascending 1-based table row numbers of the selected rows; n may be NULL (no host sync) */
+int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n);
+/* string bytes the i-th projection column will need (0 for fixed width) */
+int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes);
+/* materialize(v): materialization.jl:27-40 (projection gather projection.jl:128-154 + append) */
+int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
+/* sum/min/max/count of projection column i over the selected rows; Float64 sums are pairwise
+ * (tolerance documented in DESIGN.md), integer results exact */
+int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

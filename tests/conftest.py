@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "dataframedbs.jl_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement of the reference (test infrastructure)."""
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def dfdb_mod():
+    import dfdb
+    return dfdb
+
+
+@pytest.fixture(scope="session")
+def ctx(dfdb_mod):
+    """One engine context on cuda:0 for the whole GPU session.  Fails loudly without the HIP library / a GPU."""
+    return dfdb_mod.default_context(0)

@@ -1,0 +1,92 @@
+"""Shared test plumbing: build the same table for the CPU oracle and for the HIP engine and compare
+every observable of a view (count, bitmap, 1-based row indices, materialized columns) bit for bit."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def is_str_col(v) -> bool:
+    return isinstance(v, (list, tuple)) and (len(v) == 0 or isinstance(v[0], (str, type(None))))
+
+
+class Pair:
+    """One logical table held twice: `o` (oracle.Table) and `d` (dfdb.DFTable)."""
+
+    def __init__(self, O, dfdb, columns: Dict[str, Any], block_size: int = 65536, via_files: Optional[str] = None):
+        self.O, self.dfdb = O, dfdb
+        self.names = list(columns.keys())
+        self.nrows = len(next(iter(columns.values()))) if columns else 0
+        self.o = O.Table(block_size=block_size)
+        for k, v in columns.items():
+            if isinstance(v, np.ma.MaskedArray):
+                self.o.add_column(k, np.ascontiguousarray(v.filled(0)), missing=np.ma.getmaskarray(v))
+            else:
+                self.o.add_column(k, v)
+        if via_files:
+            # the product reads what the oracle's writer (liblz4) wrote: file format + device LZ4 decode parity
+            self.o.save(via_files)
+            self.d = dfdb.open_table(via_files)
+        else:
+            self.d = dfdb.DFTable.from_columns(columns, block_size=block_size)
+
+    def ord(self, name: str) -> int:
+        return self.names.index(name)
+
+
+def apply_stages(pair: Pair, stages: Sequence[Tuple], proj: Optional[Sequence[Tuple[str, Any]]] = None):
+    """stages: ('range', a, s, b) | ('int', i) | ('idx', [..]) | ('pred', Expr).
+    proj: list of (name, Expr) or None for the full table.  Returns (oracle.View, dfdb.DFView)."""
+    from dfdb import ir
+    dfdb = pair.dfdb
+    ov = pair.o.view()
+    dv = dfdb.DFView(pair.d)
+    for st in stages:
+        if st[0] == "range":
+            ov.add_range(st[1], st[2], st[3])
+            dv = dfdb.selection(dv, dfdb.jr(st[1], st[2], st[3]))
+        elif st[0] == "int":
+            ov.add_integer(st[1])
+            dv = dfdb.selection(dv, st[1])
+        elif st[0] == "idx":
+            ov.add_indices(st[1])
+            dv = dfdb.selection(dv, list(st[1]))
+        else:
+            ov.add_predicate(st[1].to_ir())
+            dv = dfdb.selection(dv, st[1])
+    if proj is not None:
+        ov.set_projection([(n, e.to_ir()) for n, e in proj])
+        dv = dfdb.DFView(dv.table, dfdb.Projection({n: e for n, e in proj}), dv.selection)
+    return ov, dv
+
+
+def assert_same(pair: Pair, ov, dv, check_indices: bool = True, float_exact: bool = True):
+    dfdb = pair.dfdb
+    q = dv._query()
+    want_n = ov.nrow()
+    assert q.count() == want_n, f"count {q.count()} != oracle {want_n}"
+    if check_indices:
+        want_idx = ov.select_indices()
+        got_idx = q.indices()
+        assert np.array_equal(got_idx, want_idx), f"indices differ: got {got_idx[:8]}… want {want_idx[:8]}…"
+        want_bm = ov.select_bitmap(pair.nrows)
+        got_bm = q.bitmap()
+        assert np.array_equal(got_bm, want_bm), "bitmap differs"
+    want = ov.materialize()
+    got = q.materialize()
+    assert len(want) == len(got)
+    for i, (w, g) in enumerate(zip(want, got)):
+        if isinstance(w, tuple):
+            assert isinstance(g, tuple), f"column {i}: expected flat strings"
+            assert np.array_equal(w[0], g[0]), f"column {i}: string sizes differ"
+            assert np.array_equal(w[1], g[1]), f"column {i}: string bytes differ"
+        elif isinstance(w, np.ma.MaskedArray):
+            assert np.array_equal(np.ma.getmaskarray(w), np.ma.getmaskarray(g)), f"column {i}: missing flags differ"
+            assert np.array_equal(w.compressed(), g.compressed()), f"column {i}: values differ"   # bytes under a missing bit are garbage (Q11)
+        else:
+            assert w.dtype == g.dtype, f"column {i}: dtype {g.dtype} != {w.dtype}"
+            if float_exact or w.dtype.kind != "f":
+                assert np.array_equal(w.view(np.uint8), g.view(np.uint8)), f"column {i}: values differ: {g[:5]} vs {w[:5]}"
+            else:
+                assert np.allclose(w, g, rtol=1e-12, atol=0)

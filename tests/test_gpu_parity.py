@@ -1,0 +1,237 @@
+"""GPU parity: the HIP engine (through the C ABI / Python mirror) against the CPU oracle on the same
+seeded inputs.  Integer, byte and index results must be bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import Pair, apply_stages, assert_same
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x9E3779B97F4A7C15
+
+
+def col_seed(k):  # column k uses seed * (k+1)
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------ generators
+def test_generators_match_oracle(oracle, dfdb_mod, ctx):
+    n = 200_001
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, col_seed(0), n, row_first=12345)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, col_seed(1), n, row_first=12345)
+    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, col_seed(2), n, row_first=12345)
+    t.add_generated("i", dfdb_mod.GEN_I64_IOTA, 0, n, row_first=12345)
+    a, x, s, i = t.view()._query().materialize()
+    assert np.array_equal(a, oracle.gen_i64(col_seed(0), 12345, n))
+    assert np.array_equal(x.view(np.uint64), oracle.gen_f64(col_seed(1), 12345, n).view(np.uint64))
+    sz, by = oracle.gen_str(col_seed(2), 12345, n)
+    assert np.array_equal(s[0], sz) and np.array_equal(s[1], by)
+    assert np.array_equal(i, np.arange(12346, 12346 + n, dtype=np.int64))
+
+
+# ------------------------------------------------------------------ config 2 shape: x > c
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 65536, 65537, 300_001])
+def test_int64_gt_sizes(oracle, dfdb_mod, ctx, n):
+    from dfdb import ir
+    x = oracle.gen_i64(col_seed(0), 0, n)
+    p = Pair(oracle, dfdb_mod, {"x": x}, block_size=65536)
+    ov, dv = apply_stages(p, [("pred", ir.col(0) > 899_999)])
+    assert_same(p, ov, dv)
+
+
+@pytest.mark.parametrize("op", ["==", "!=", "<", "<=", ">", ">="])
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64, np.float32, np.float64])
+def test_cmp_ops_all_dtypes(oracle, dfdb_mod, ctx, op, dtype):
+    from dfdb import ir
+    import operator
+    rng = np.random.default_rng(7)
+    n = 10_007
+    if np.dtype(dtype).kind == "f":
+        x = rng.integers(-50, 50, n).astype(dtype) / dtype(4)
+        x[::97] = np.nan
+        c = dtype(3.25)
+    elif np.dtype(dtype).kind == "u":
+        x = rng.integers(0, 100, n).astype(dtype); c = 40
+    else:
+        x = rng.integers(-60, 60, n).astype(dtype); c = -7
+    f = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}[op]
+    p = Pair(oracle, dfdb_mod, {"x": x}, block_size=4096)
+    ov, dv = apply_stages(p, [("pred", f(ir.col(0), ir.const(c)))])
+    assert_same(p, ov, dv)
+    # third opinion: numpy
+    want = np.nonzero(f(x, c))[0] + 1
+    assert np.array_equal(dv._query().indices(), want)
+
+
+def test_int_column_vs_float_constant_is_exact(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    x = np.array([-3, -2, 2, 3, 4, 2**53, 2**53 + 1, -(2**63), 2**63 - 1], np.int64)
+    p = Pair(oracle, dfdb_mod, {"x": x}, block_size=4)
+    for c in [3.5, -2.5, 3.0, float(2**53), 9.3e18, -9.3e18, float("nan"), float("inf")]:
+        for mk in (lambda e, c: e > c, lambda e, c: e <= c, lambda e, c: e == c, lambda e, c: e != c, lambda e, c: c > e):
+            ov, dv = apply_stages(p, [("pred", mk(ir.col(0), c))])
+            assert_same(p, ov, dv)
+            want = [i + 1 for i, v in enumerate(x.tolist()) if bool(mk(v, c))]   # Python int-vs-float comparison is exact too
+            assert dv._query().indices().tolist() == want, (c, want)
+
+
+# ------------------------------------------------------------------ selection executor known answers (test/selection.jl)
+def test_selection_known_answers(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    a = np.arange(1, 101, dtype=np.int64)
+    for bs in (100, 50, 7):
+        p = Pair(oracle, dfdb_mod, {"a": a, "b": a * 5}, block_size=bs)
+        # (5:20)∘(3:4) -> 7:8   (test/selection.jl:40-49)
+        ov, dv = apply_stages(p, [("range", 5, 1, 20), ("range", 3, 1, 4)])
+        assert_same(p, ov, dv); assert dv._query().indices().tolist() == [7, 8]
+        # (10:60, 65>a>34, 15:18) -> 49:52   (:51-72)
+        ov, dv = apply_stages(p, [("range", 10, 1, 60), ("pred", (65 > ir.col(0)) & (ir.col(0) > 34)), ("range", 15, 1, 18)])
+        assert_same(p, ov, dv); assert dv._query().indices().tolist() == [49, 50, 51, 52]
+        # (65>a>34) & (b%10==0), fused into one stage (:74-106)
+        ov, dv = apply_stages(p, [("pred", (65 > ir.col(0)) & (ir.col(0) > 34)), ("pred", ir.col(1) % 10 == 0)])
+        assert len(dv.selection) == 1
+        assert_same(p, ov, dv)
+        assert dv._query().indices().tolist() == [i for i in range(35, 65) if (i * 5) % 10 == 0]
+
+
+def test_range_stage_forms(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    n = 10_000
+    a = np.arange(1, n + 1, dtype=np.int64)
+    p = Pair(oracle, dfdb_mod, {"a": a}, block_size=1000)
+    cases = [
+        [("range", 5, 300, 10_000)], [("range", 9990, 1, 10_000)], [("idx", [1, 200, 20])], [("idx", [7, 7, 3, 9999])], [("int", 4242)],
+        [("range", 1, 10, n), ("pred", ir.col(0) % 3 == 1)], [("pred", ir.col(0) % 3 == 1), ("range", 1, 7, 3000)],
+        [("pred", ir.col(0) > 5000), ("idx", [5, 1, 4000])], [("range", 100, -3, 10)], [("range", 20, 1, 10)],
+        [("pred", ir.col(0) % 2 == 0), ("range", 10, 1, 4000), ("pred", ir.col(0) % 3 == 0), ("range", 2, 2, 600)],
+    ]
+    for st in cases:
+        ov, dv = apply_stages(p, st)
+        assert_same(p, ov, dv)
+
+
+# ------------------------------------------------------------------ config 3 shape
+def test_conjunction_and_projection(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    n = 150_003
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "b": oracle.gen_i64(col_seed(1), 0, n), "x": oracle.gen_f64(col_seed(2), 0, n)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    pred = (ir.col(0) > 683_771) & (ir.col(2) < 632.456)
+    ov, dv = apply_stages(p, [("pred", pred)], proj=[("b", ir.col(1)), ("x", ir.col(2))])
+    assert_same(p, ov, dv)
+    ov, dv = apply_stages(p, [("pred", pred)], proj=[("b", ir.col(1)), ("x2", ir.col(2) * 2)])
+    assert_same(p, ov, dv)
+
+
+# ------------------------------------------------------------------ config 4 shape
+def test_string_equality_and_gather(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    n = 120_001
+    sizes, data = oracle.gen_str(col_seed(0), 0, n)
+    strs = oracle.flat_to_strings(sizes, data)
+    cols = {"s": strs, "a": oracle.gen_i64(col_seed(1), 0, n)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    for pred in (ir.col(0) == "sony", ir.col(0) != "sony", ir.startswith(ir.col(0), "s"), ir.endswith(ir.col(0), "l"),
+                 (ir.col(0) == "dell") & (ir.col(1) > 500_000), ir.col(0) == "", ir.col(0) < "dell", ir.sizeof(ir.col(0)) == 4):
+        ov, dv = apply_stages(p, [("pred", pred)])
+        assert_same(p, ov, dv)
+
+
+# ------------------------------------------------------------------ generic expressions (interpreter)
+def test_generic_expressions(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    n = 20_011
+    rng = np.random.default_rng(3)
+    cols = {"a": rng.integers(-1000, 1000, n).astype(np.int64), "c": (rng.integers(1, 50, n)).astype(np.int64),
+            "x": rng.normal(0, 100, n), "i32": rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), "f": rng.normal(0, 3, n).astype(np.float32),
+            "u8": rng.integers(0, 255, n).astype(np.uint8), "flag": rng.integers(0, 2, n).astype(bool)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=4096)
+    a, c, x, i32, f, u8, flag = (ir.col(k) for k in range(7))
+    preds = [a % c == 0, (a * 2 + c) > x, a / c > 1.5, ir.mod(a, c) == 3, ir.div(a, c) == -2, (a + i32) < 0, (i32 + i32) > 0, f * 2 > x,
+             u8 + u8 > 300, flag & (a > 0), ~flag | (x < 0), ir.isin(a, [1, 11, 21, -5]), abs(a) < 10, -a > 990, ir.maximum(a, c) == c,
+             (a ^ c) & 1 == 1, ir.float64(a) * 0.5 == x, a == x, (u8 - u8) == 0, ir.minimum(x, f) < -3, (f + 1) > 1]
+    for pred in preds:
+        ov, dv = apply_stages(p, [("pred", pred)])
+        assert_same(p, ov, dv)
+    projs = [[("k", a / 50)], [("k", a * 2 + c), ("m", x - f)], [("k", i32 * i32)], [("k", u8 + u8), ("z", a % c)], [("k", f * f)],
+             [("k", flag), ("n", ~flag)], [("k", a > c)]]
+    for pr in projs:
+        ov, dv = apply_stages(p, [("pred", a % 7 == 0)], proj=pr)
+        assert_same(p, ov, dv)
+
+
+def test_divide_error_and_bad_predicates(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    a = np.arange(-5, 6, dtype=np.int64)
+    p = Pair(oracle, dfdb_mod, {"a": a, "z": np.zeros(11, np.int64)}, block_size=4)
+    ov, dv = apply_stages(p, [("pred", ir.col(0) % ir.col(1) == 0)])
+    with pytest.raises(ZeroDivisionError):
+        ov.nrow()
+    with pytest.raises(ZeroDivisionError):
+        dfdb_mod.nrow(dv)
+    with pytest.raises(ValueError):      # non-Bool predicate: selection.jl:52-55
+        dfdb_mod.selection(dfdb_mod.DFView(p.d), ir.col(0) * 3)
+    with pytest.raises(ValueError):
+        p.o.view().add_predicate((ir.col(0) * 3).to_ir())
+
+
+# ------------------------------------------------------------------ files: oracle writer (liblz4) -> device LZ4 decode
+def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
+    from dfdb import ir
+    n = 200_003
+    rng = np.random.default_rng(11)
+    sizes, data = oracle.gen_str(col_seed(3), 0, n)
+    strs = oracle.flat_to_strings(sizes, data)
+    strs_m = [None if i % 13 == 0 else s for i, s in enumerate(strs)]
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": strs, "sm": strs_m,
+            "iota": np.arange(1, n + 1, dtype=np.int64), "i16": rng.integers(-300, 300, n).astype(np.int16),
+            "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.2),
+            "b": rng.integers(0, 2, n).astype(bool), "rnd": rng.integers(-2**62, 2**62, n).astype(np.int64)}
+    for bs in (65536, 1000):
+        p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"tb{bs}"))
+        ov, dv = apply_stages(p, [])
+        assert_same(p, ov, dv)
+        ov, dv = apply_stages(p, [("pred", (ir.col(0) > 500_000) & (ir.col(2) == "sony"))])
+        assert_same(p, ov, dv)
+        ov, dv = apply_stages(p, [("pred", ir.ismissing(ir.col(6)) | ir.ismissing(ir.col(3)))])
+        assert_same(p, ov, dv)
+
+
+def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
+    with pytest.raises(dfdb_mod.DfdbError):
+        dfdb_mod.open_table(str(tmp_path / "nope"))
+    t = oracle.Table(block_size=10)
+    t.add_column("a", np.arange(25, dtype=np.int64))
+    t.save(str(tmp_path / "tb"))
+    # corrupt header: wrong block size (test/tables.jl:52-58)
+    import struct
+    f = tmp_path / "tb" / "1.bin"
+    raw = f.read_bytes()
+    f.write_bytes(struct.pack("<q", 11) + raw[8:])
+    with pytest.raises(dfdb_mod.DfdbError):
+        dfdb_mod.open_table(str(tmp_path / "tb"))
+    # corrupt LZ4 payload -> "decompression error"
+    f.write_bytes(raw[:len(raw) - 6] + b"\xff" * 6)
+    with pytest.raises(dfdb_mod.DfdbError):
+        dfdb_mod.open_table(str(tmp_path / "tb"))
+
+
+# ------------------------------------------------------------------ aggregates
+def test_aggregates(oracle, dfdb_mod, ctx):
+    from dfdb import ir
+    n = 250_000
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    ov, dv = apply_stages(p, [("pred", ir.col(0) > 899_999)])
+    sel = cols["a"] > 899_999
+    ca, cx = dv[dfdb_mod.ALL, "a"], dv[dfdb_mod.ALL, "x"]
+    assert ca.sum() == int(cols["a"][sel].sum()) == ov.sum_i64(0)
+    assert ca.min() == int(cols["a"][sel].min()) and ca.max() == int(cols["a"][sel].max())
+    # Float64 sum: the reference adds left to right (column.jl:102-126); the device sums pairwise.
+    # tolerance: |err| <= n * eps * sum|x|  (stated in DESIGN.md)
+    want = ov.sum_f64(1)
+    tol = len(cols["x"][sel]) * np.finfo(np.float64).eps * float(np.abs(cols["x"][sel]).sum())
+    assert abs(cx.sum() - want) <= tol
+    assert cx.min() == float(cols["x"][sel].min()) and cx.max() == float(cols["x"][sel].max())
+    assert abs(cx.mean() - want / sel.sum()) <= tol
