@@ -1,7 +1,7 @@
 // k_gen.hip — device-side synthetic column fill (SURVEY.md §8d "Data generation"), so benchmark columns
 // are born in HBM with no PCIe copy.  Row i (0-based, global) is a pure function of
-// h = splitmix64(seed + i); the CPU oracle uses the same formula (oracle/orc_codec.c) and the tests
-// compare the two bit for bit.
+// h = splitmix64(seed + i); the tests compare these columns bit for bit with the same formula evaluated
+// on the CPU.
 #include "device_utils.hpp"
 #include "kernels.hpp"
 

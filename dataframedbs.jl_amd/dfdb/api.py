@@ -387,7 +387,7 @@ class DFTable:
             raise AttributeError(name)
         try:
             return DFView(self)[ALL, name]
-        except KeyError:
+        except (KeyError, ValueError):
             raise AttributeError(name) from None
 
     def __repr__(self): return f"DFTable({self.path!r}, {self.columns_meta()})"

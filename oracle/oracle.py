@@ -245,8 +245,8 @@ class View:
     def set_projection(self, items: Sequence[Tuple[str, bytes]]) -> "View":
         n = len(items)
         names = (C.c_char_p * n)(*[nm.encode() for nm, _ in items])
-        irs = (C.c_char_p * n)(*[ir for _, ir in items])
-        irp = (C.c_void_p * n)(*[C.cast(irs[i], C.c_void_p) for i in range(n)])
+        irs = [C.create_string_buffer(ir, len(ir)) for _, ir in items]   # IR bytes contain NULs: keep real buffers alive
+        irp = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in irs])
         lens = (C.c_size_t * n)(*[len(ir) for _, ir in items])
         self._keep = (names, irs, irp, lens)
         _check(lib().orc_view_set_projection(self._h, n, names, irp, lens))

@@ -211,10 +211,15 @@ def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
     f.write_bytes(struct.pack("<q", 11) + raw[8:])
     with pytest.raises(dfdb_mod.DfdbError):
         dfdb_mod.open_table(str(tmp_path / "tb"))
-    # corrupt LZ4 payload -> "decompression error"
-    f.write_bytes(raw[:len(raw) - 6] + b"\xff" * 6)
-    with pytest.raises(dfdb_mod.DfdbError):
+    # corrupt LZ4 payload (first token claims an endless literal run) -> "decompression error" (BlockStreams.jl:112)
+    hdr = 8 + 4 + len("Int64")
+    bad = bytearray(raw)
+    bad[hdr + 20: hdr + 24] = b"\xff\xff\xff\xff"
+    f.write_bytes(bytes(bad))
+    with pytest.raises(dfdb_mod.DfdbError, match="decompression error"):
         dfdb_mod.open_table(str(tmp_path / "tb"))
+    with pytest.raises(OSError):
+        oracle.Table.open(str(tmp_path / "tb")).view().nrow()
 
 
 # ------------------------------------------------------------------ aggregates

@@ -1,0 +1,215 @@
+"""CPU tests (no GPU): the oracle against the reference's known answers (golden file), against numpy, and
+the codec round-trip properties of test/block_streams.jl."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from helpers import is_str_col
+
+CASES = G.load_cases()
+
+
+def make_oracle_table(O, cols, block_size):
+    t = O.Table(block_size=block_size)
+    for k, v in cols.items():
+        if isinstance(v, np.ma.MaskedArray):
+            t.add_column(k, np.ascontiguousarray(v.filled(0)), missing=np.ma.getmaskarray(v))
+        else:
+            t.add_column(k, v)
+    return t
+
+
+def oracle_view(O, t, stages, proj):
+    v = t.view()
+    for st in stages:
+        if st[0] == "range":
+            v.add_range(st[1], st[2], st[3])
+        elif st[0] == "int":
+            v.add_integer(st[1])
+        elif st[0] == "idx":
+            v.add_indices(st[1])
+        else:
+            v.add_predicate(st[1].to_ir())
+    if proj is not None:
+        v.set_projection([(n, e.to_ir()) for n, e in proj])
+    return v
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_known_answers(oracle, case):
+    cols = G.build_columns(case["table"])
+    names = list(cols.keys())
+    for bs in case["block_sizes"]:
+        t = make_oracle_table(oracle, cols, bs)
+        v = oracle_view(oracle, t, G.stages_for(case, names), G.proj_for(case, names))
+        assert v.select_indices().tolist() == case["expect_rows"], f"{case['name']} ({case['ref']}) block_size={bs}"
+        assert v.nrow() == len(case["expect_rows"])
+        G.check_columns(case, names, v.materialize(), oracle.flat_to_strings)
+        G.check_columns(case, names, v.materialize(count_pass=False), oracle.flat_to_strings)
+
+
+def test_queue_composition_rules(oracle):
+    """test/selection.jl:5-37."""
+    from dfdb import ir
+    t = make_oracle_table(oracle, {"a": np.arange(1, 101, dtype=np.int64)}, 50)
+    v = t.view()
+    assert v.nstages == 0
+    v.add_range(5, 1, 20)
+    assert v.nstages == 1
+    v.add_range(1, 1, 5)                       # (5:20)[1:5] == 5:9
+    assert v.nstages == 1 and v.stage(0) == dict(kind="range", start=5, step=1, stop=9, n=5)
+    tb = (ir.col(0) == 1).to_ir()
+    v.add_predicate(tb)
+    assert v.nstages == 2 and v.stage(1)["kind"] == "predicate"
+    v2 = t.view().add_predicate(tb).add_predicate(tb)   # two predicates fuse
+    assert v2.nstages == 1
+    v2.add_range(1, 1, 3)
+    assert v2.nstages == 2
+    with pytest.raises(ValueError):            # non-Bool result: ArgumentError
+        v2.add_predicate((ir.col(0) * 3).to_ir())
+    with pytest.raises(IndexError):            # (5:20)[1:30] is a BoundsError
+        t.view().add_range(5, 1, 20).add_range(1, 1, 30)
+    # range[vector], vector[range], strided collapse
+    v3 = t.view().add_range(10, 2, 30).add_range(2, 2, 6)
+    assert v3.stage(0) == dict(kind="range", start=12, step=4, stop=20, n=3)
+    v4 = t.view().add_range(10, 2, 30).add_indices([3, 1]).add_range(2, 1, 2)
+    assert v4.nstages == 1 and v4.stage(0)["kind"] == "indices" and v4.select_indices().tolist() == [10]
+
+
+def test_executor_state_across_blocks(oracle):
+    """test/selection.jl:62-72: offsets carry over blocks, is_finished flips after the last needed row."""
+    from dfdb import ir
+    a = np.arange(1, 101, dtype=np.int64)
+    t = make_oracle_table(oracle, {"a": a}, 50)
+    v = t.view().add_range(10, 1, 60).add_predicate(((65 > ir.col(0)) & (ir.col(0) > 34)).to_ir()).add_range(15, 1, 18)
+    e = oracle.SelExec(v)
+    res = []
+    for blk in range(2):
+        assert not e.is_finished()
+        part = a[blk * 50:(blk + 1) * 50]
+        res += part[e.apply(50, {0: part})].tolist()
+    assert res == [49, 50, 51, 52] and e.is_finished()
+    # skip_if_can: only the first stage, nominal block size (selection.jl:177-190)
+    e2 = oracle.SelExec(t.view().add_range(120, 1, 130))
+    assert e2.skip_if_can(50) and e2.skip_if_can(50) and not e2.skip_if_can(50)
+
+
+def test_required_columns_and_types(oracle):
+    """test/broadcast.jl:15-44."""
+    from dfdb import ir
+    t = make_oracle_table(oracle, {"a": np.arange(1, 101, dtype=np.int64), "b": [str(i) for i in range(100)], "c": 0.5 * np.arange(1, 101)}, 100)
+    a, c = ir.col(0), ir.col(2)
+    assert oracle.expr_result_type(t, (a * 2).to_ir()) == oracle.I64
+    assert oracle.expr_result_type(t, (a + c).to_ir()) == oracle.F64
+    assert oracle.expr_result_type(t, (a + (a + c)).to_ir()) == oracle.F64
+    assert oracle.expr_required_columns(t, (a + (a + c)).to_ir()) == [0, 2]
+    assert oracle.expr_result_type(t, (a / 50).to_ir()) == oracle.F64
+    assert oracle.expr_result_type(t, (a > c).to_ir()) == oracle.BOOL
+    with pytest.raises(ValueError):            # arrays are rejected (test/broadcast.jl:73-81)
+        ir.isin(a, [1]) + [1, 2, 3]
+    with pytest.raises(ValueError):
+        a + np.array([1, 2, 3])
+
+
+@pytest.mark.parametrize("n", [64000, 74000])
+def test_block_codec_roundtrip(oracle, n):
+    """test/block_streams.jl:11-67: header + LZ4 round trip, skip_block."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(1, 100000, n).astype(np.int64)
+    blk = oracle.block_encode(a.tobytes(), n)
+    rows, body, used = oracle.block_decode(blk)
+    assert rows == n and used == len(blk) and np.array_equal(np.frombuffer(body, np.int64), a)
+    b = rng.integers(1, 100000, 1000).astype(np.int64)
+    two = blk + oracle.block_encode(b.tobytes(), 1000)
+    rows2, body2, used2 = oracle.block_decode(two, offset=used)      # skip the first, read the second
+    assert rows2 == 1000 and used + used2 == len(two) and np.array_equal(np.frombuffer(body2, np.int64), b)
+
+
+def test_docs_compression_ratios(oracle):
+    """docs/src/index.md:53,56: LZ4 ratio 2.0 for 1:3e6 and 2.55 for rand(1:1000) (COMPRESSION_LEVEL = 2)."""
+    t = oracle.Table()
+    t.add_column("a", np.arange(1, 3_000_001, dtype=np.int64))
+    st = t.column_stats(0)
+    assert st["uncompressed"] == 3_000_000 * 8 and round(st["uncompressed"] / st["compressed"], 2) == 2.0
+    t.add_column("r", np.random.default_rng(1).integers(1, 1001, 3_000_000).astype(np.int64))
+    st = t.column_stats(1)
+    assert abs(st["uncompressed"] / st["compressed"] - 2.55) < 0.03
+    assert st["blocks"] == 46 and st["rows"] == 3_000_000
+
+
+def test_table_files_and_header_validation(oracle, tmp_path):
+    """test/tables.jl:36-70, test/table_io.jl:4-9."""
+    t = oracle.Table(block_size=1223)
+    t.add_column("a", np.arange(10, dtype=np.int32))
+    t.add_column("b", ["x", "yy", ""] + ["z"] * 7)
+    t.add_column("c", np.arange(10, dtype=np.int64))
+    p = str(tmp_path / "test_tb")
+    t.save(p)
+    assert sorted(os.listdir(p)) == ["1.bin", "2.bin", "3.bin", "meta.bin"]
+    t2 = oracle.Table.open(p)
+    assert [t2.colinfo(i) for i in range(3)] == [(1, "a", oracle.I32), (2, "b", oracle.STRING), (3, "c", oracle.I64)]
+    assert t2.block_size == 1223
+    got = t2.view().materialize()
+    assert got[0].tolist() == list(range(10)) and oracle.flat_to_strings(*got[1]) == ["x", "yy", ""] + ["z"] * 7
+    with pytest.raises(OSError):
+        oracle.Table.open(str(tmp_path / "missing"))
+    import struct
+    raw = open(os.path.join(p, "3.bin"), "rb").read()
+    open(os.path.join(p, "3.bin"), "wb").write(struct.pack("<q", 10) + raw[8:])          # wrong block size
+    with pytest.raises(OSError):
+        oracle.Table.open(p)
+    open(os.path.join(p, "3.bin"), "wb").write(struct.pack("<qi", 1223, 5) + b"Int32")   # wrong type
+    with pytest.raises(OSError):
+        oracle.Table.open(p)
+
+
+def test_oracle_vs_numpy_random_queries(oracle):
+    """Third opinion: numpy boolean indexing (what DataFrames.jl does for the reference's own tests)."""
+    from dfdb import ir
+    rng = np.random.default_rng(5)
+    n = 30_011
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    c = rng.integers(1, 50, n).astype(np.int64)
+    x = rng.normal(0, 100, n)
+    t = make_oracle_table(oracle, {"a": a, "c": c, "x": x}, 4096)
+    A, Cc, X = ir.col(0), ir.col(1), ir.col(2)
+    # Julia rem: sign of the dividend == numpy fmod
+    checks = [(A % Cc == 0, np.fmod(a, c) == 0), ((A * 2 + Cc) > X, (a * 2 + c) > x), (A / Cc > 1.5, a / c > 1.5),
+              (ir.mod(A, Cc) == 3, np.mod(a, c) == 3), (ir.div(A, Cc) == -2, np.trunc(a / c) == -2), (abs(A) < 10, np.abs(a) < 10),
+              (ir.isin(A, [1, 11, 21, -5]), np.isin(a, [1, 11, 21, -5])), ((A > 0) & ~(X < 0), (a > 0) & ~(x < 0)), (A == X, a == x)]
+    for e, m in checks:
+        v = t.view().add_predicate(e.to_ir())
+        assert np.array_equal(v.select_indices(), np.nonzero(m)[0] + 1)
+    # range after predicate indexes the survivor stream (quirk Q1)
+    v = t.view().add_predicate((A > 0).to_ir()).add_range(5, 3, 400)
+    assert np.array_equal(v.select_indices(), (np.nonzero(a > 0)[0] + 1)[4:400:3])
+    # float sum is strictly left to right
+    v = t.view().add_predicate((A > 0).to_ir()).set_projection([("x", X.to_ir())])
+    acc = 0.0
+    for val in x[a > 0]:
+        acc += val
+    assert v.sum_f64(0) == acc
+
+
+def test_generator_formulas(oracle):
+    """splitmix64-based columns; spot values computed by hand in Python ints."""
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+    seed = 0x9E3779B97F4A7C15
+    assert oracle.splitmix64(0) == sm(0) and oracle.splitmix64(seed + 5) == sm(seed + 5)
+    a = oracle.gen_i64(seed, 100, 50)
+    assert a.tolist() == [sm((seed + 100 + i) & M) % 1_000_000 for i in range(50)]
+    x = oracle.gen_f64(seed, 0, 50)
+    assert x.tolist() == [(sm((seed + i) & M) >> 11) * 2.0 ** -53 * 2000.0 for i in range(50)]
+    brands = ["apple", "samsung", "huawei", "microsoft", "dell", "xbox", "sony", "intel", "lenovo", "asus"]
+    sz, by = oracle.gen_str(seed, 7, 40)
+    assert oracle.flat_to_strings(sz, by) == [brands[sm((seed + 7 + i) & M) % 10] for i in range(40)]
+    big = oracle.gen_i64(seed, 0, 1_000_000)
+    assert abs((big > 899_999).mean() - 0.1) < 0.002
