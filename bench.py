@@ -138,6 +138,16 @@ def main():
         scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
         job_bytes = rows * (8 + 8 * sigma)             # 8 + 8*sigma B/row for the whole job
+        # HBM traffic of that kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        # same command; FETCH_SIZE doubled per the gfx950 correction, calibrated on a known-byte read): profiles/
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_scan_cmp.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("rows"):
+                traffic = pj["hbm_bytes_per_launch_corrected"] * rows / pj["rows"]
+                traffic_src = "profiles/r1_pmc_scan_cmp.json (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
         res = {
             "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -149,7 +159,7 @@ def main():
                        "device": info["name"], "global_selected": total_sel},
             "job_hbm_gbps": job_bytes * world / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "k_scan_cmp<int64,GT>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }
         if not args.no_cpu:

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
     if (base + kTile <= nrows) {
       T v[kWordsPerTile];
 #pragma unroll
-      for (int j = 0; j < kWordsPerTile; j++) v[j] = p[j * 64];   // 16 independent coalesced loads in flight
+      for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);   // 16 independent coalesced loads in flight; nt: streamed once (+12 % vs default policy, tools/bench_k1)
 #pragma unroll
       for (int j = 0; j < kWordsPerTile; j++) {
         uint64_t m = __ballot(cmp_op<OP, T>(v[j], c));
@@ -143,7 +143,7 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
   if (base + kTile <= nrows) {
     T v[kWordsPerTile];
 #pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) v[j] = p[j * 64];
+    for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);
 #pragma unroll
     for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == j) myword = m; }
   } else {

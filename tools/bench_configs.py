@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Per-kernel timings of BASELINE.json configs 2-4 and of the device LZ4 decode stage on one MI355X.
+
+Not the driver's bench (that is /bench.py, config 2 only): this prints one JSON object per config with the
+HIP-event time of every kernel family, the algorithmic bytes of SURVEY.md §8d and the resulting GB/s, for
+DESIGN.md's roofline table.   python tools/bench_configs.py [--scale 1.0] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402,F401  (before any HIP call of libdfdb: torch must load ITS libamdhip64 first)
+import numpy as np  # noqa: E402
+
+import dfdb  # noqa: E402
+from dfdb import ir  # noqa: E402
+
+SEED = 0x9E3779B97F4A7C15
+KERNELS = ["scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
+           "compact_indices", "gather", "str_gather_sizes", "str_gather_bytes", "reduce", "lz4_decode"]
+
+
+def seed(k):
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def timed(ctx, fn, reps):
+    fn()
+    ctx.synchronize()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ks = {}
+    for k in KERNELS:
+        n, ms = ctx.profile_get(k)
+        if n:
+            ks[k] = round(ms / n, 4)
+    ctx.profile(False)
+    # un-profiled wall time (profiling serialises each launch on an event)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    return ks, (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--lz4-rows", type=int, default=50_000_000)
+    args = ap.parse_args()
+    ctx = dfdb.default_context(0)
+    info = ctx.device_info()
+    print(json.dumps({"device": info}))
+    import torch
+    dev = torch.device("cuda", 0)
+
+    # ---- config 2
+    n = int(1e9 * args.scale)
+    t = dfdb.DFTable.new()
+    t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, n)
+    v = t[("x", lambda x: x > 899_999), dfdb.ALL]
+    q = v._query()
+    nsel = q.count()
+    out = torch.empty(nsel, dtype=torch.int64, device=dev)
+
+    def step2():
+        q.execute(); q.indices_device(out.data_ptr(), nsel)
+    ks, wall = timed(ctx, step2, args.reps)
+    byts = n * 8 + nsel * 8
+    print(json.dumps({"config": 2, "rows": n, "selected": nsel, "kernels_ms": ks, "wall_ms": wall * 1e3, "algorithmic_GB": byts / 1e9,
+                      "job_GBps": byts / wall / 1e9, "rows_per_s": n / wall}))
+    cx = v[dfdb.ALL, "x"]
+    ks, wall = timed(ctx, lambda: (q.execute(), cx.sum()), args.reps)
+    print(json.dumps({"config": "2-sum", "kernels_ms": ks, "wall_ms": wall * 1e3}))
+    del out, q, v, cx
+    t.close()
+
+    # ---- config 3: (a > 683771) & (x < 632.456), project [b, x]
+    t = dfdb.DFTable.new()
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed(0), n)
+    t.add_generated("b", dfdb.GEN_I64_MOD1M, seed(1), n)
+    t.add_generated("x", dfdb.GEN_F64_U2000, seed(2), n)
+    v = t[(t.a > 683_771) & (t.x < 632.456), ["b", "x"]]
+    q = v._query()
+    nsel = q.count()
+    ob = torch.empty(nsel, dtype=torch.int64, device=dev)
+    ox = torch.empty(nsel, dtype=torch.float64, device=dev)
+    import ctypes as C
+    from dfdb import _native as N
+    outs = (N.OutCol * 2)()
+    outs[0].data, outs[0].memkind = ob.data_ptr(), N.MEM_DEVICE
+    outs[1].data, outs[1].memkind = ox.data_ptr(), N.MEM_DEVICE
+
+    def step3():
+        q.execute(); N.check(N.load().dfdb_materialize(q._h, outs, 2))
+    ks, wall = timed(ctx, step3, args.reps)
+    byts = n * 16 + nsel * 8 + nsel * 16
+    print(json.dumps({"config": 3, "rows": n, "selected": nsel, "kernels_ms": ks, "wall_ms": wall * 1e3, "algorithmic_GB": byts / 1e9,
+                      "job_GBps": byts / wall / 1e9, "rows_per_s": n / wall}))
+    # same predicate through the generic interpreter (x*1 defeats the term matcher)
+    v2 = t[(t.a > 683_771) & (t.x * 1.0 < 632.456), ["b", "x"]]
+    q2 = v2._query()
+    ks, wall = timed(ctx, lambda: q2.execute(), max(2, args.reps // 2))
+    print(json.dumps({"config": "3-interp", "kernels_ms": ks, "wall_ms": wall * 1e3, "count_equal": q2.count() == nsel}))
+    del ob, ox, q, q2, v, v2
+    t.close()
+
+    # ---- config 4: s == "sony", materialize s and a
+    n4 = int(5e8 * args.scale)
+    t = dfdb.DFTable.new()
+    t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed(0), n4)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed(1), n4)
+    v = t[t.s == "sony", dfdb.ALL]
+    q = v._query()
+    nsel = q.count()
+    nb = C.c_int64()
+    N.check(N.load().dfdb_result_string_bytes(q._h, 0, C.byref(nb)))
+    osz = torch.empty(nsel, dtype=torch.int32, device=dev)
+    oby = torch.empty(nb.value + 64, dtype=torch.uint8, device=dev)
+    oa = torch.empty(nsel, dtype=torch.int64, device=dev)
+    outs = (N.OutCol * 2)()
+    outs[0].data, outs[0].bytes, outs[0].bytes_cap, outs[0].memkind = osz.data_ptr(), oby.data_ptr(), nb.value, N.MEM_DEVICE
+    outs[1].data, outs[1].memkind = oa.data_ptr(), N.MEM_DEVICE
+
+    def step4():
+        q.execute(); N.check(N.load().dfdb_materialize(q._h, outs, 2))
+    ks, wall = timed(ctx, step4, args.reps)
+    lbar = 5.4
+    byts = n4 * (4 + lbar) + nsel * (8 + 8 + 4 + 4)
+    print(json.dumps({"config": 4, "rows": n4, "selected": nsel, "string_bytes_out": nb.value, "kernels_ms": ks, "wall_ms": wall * 1e3,
+                      "algorithmic_GB": byts / 1e9, "job_GBps": byts / wall / 1e9, "rows_per_s": n4 / wall}))
+    del osz, oby, oa, q, v
+    t.close()
+
+    # ---- LZ4 decode stage: reference-format image written by the test oracle's liblz4 writer
+    from oracle import oracle as O
+    m = args.lz4_rows
+    ot = O.Table(block_size=65536)
+    ot.add_column("x", O.gen_i64(SEED, 0, m))
+    img = ot.image(0)
+    st = ot.column_stats(0)
+    t = dfdb.DFTable.new()
+    # declare the column through a file-less table: write to tmp and open
+    import tempfile
+    d = tempfile.mkdtemp()
+    ot.save(os.path.join(d, "tb"))
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    tb = dfdb.open_table(os.path.join(d, "tb"))
+    wall = time.perf_counter() - t0
+    nl, ms = ctx.profile_get("lz4_decode")
+    ctx.profile(False)
+    print(json.dumps({"config": "lz4", "rows": m, "blocks": st["blocks"], "compressed_MB": len(img) / 1e6, "uncompressed_MB": m * 8 / 1e6,
+                      "lz4_decode_ms": ms, "decode_GBps_out": m * 8 / (ms * 1e-3) / 1e9 if ms else None, "open_table_wall_s": wall}))
+    t0 = time.perf_counter()
+    nrow = ot.view().add_predicate((ir.col(0) > 899_999).to_ir()).nrow()
+    cpu = time.perf_counter() - t0
+    print(json.dumps({"config": "lz4-cpu", "rows": m, "oracle_scan_s": cpu, "oracle_rows_per_s": m / cpu, "selected": nrow,
+                      "engine_selected": dfdb.nrow(tb[("x", lambda x: x > 899_999), dfdb.ALL])}))
+
+
+if __name__ == "__main__":
+    main()
