@@ -28,6 +28,19 @@ LaunchTimer::~LaunchTimer() {
   float ms = 0; (void)hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1);
   auto& e = ctx->prof[name]; e.launches++; e.ms += ms;
 }
+void stream_wait(dfdb_ctx* ctx) {
+  HIP_CHECK(hipEventRecord(ctx->sync_ev, ctx->stream));
+  for (;;) {
+    const hipError_t e = hipEventQuery(ctx->sync_ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) fail(DFDB_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+    __builtin_ia32_pause();
+  }
+}
+int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt) {
+  auto it = ctx->options.find(key);
+  return it == ctx->options.end() ? dflt : it->second;
+}
 }  // namespace dfdb
 
 extern "C" {
@@ -57,6 +70,7 @@ int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out) {
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
     HIP_CHECK(hipEventCreate(&c->pev0)); HIP_CHECK(hipEventCreate(&c->pev1));
+    HIP_CHECK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc((void**)&c->pinned_scalar, 64, hipHostMallocDefault));
     *out = c.release();
   });
@@ -85,6 +99,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out) {
     out->peak_hbm_gbps = 2.0 * (double)ctx->prop.memoryClockRate * 1e3 * ((double)ctx->prop.memoryBusWidth / 8.0) / 1e9;
   });
 }
+int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value) { return guard([&] { NEED(ctx); NEED(key); ctx->options[key] = value; }); }
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx) { return guard([&] { NEED(ctx); HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream)); }); }
 int32_t dfdb_ctx_timer_stop(dfdb_ctx* ctx, double* elapsed_ms) {
   return guard([&] {

@@ -83,6 +83,8 @@ struct dfdb_ctx {
   hipEvent_t pev0 = nullptr, pev1 = nullptr; // per-launch profiling
   hipDeviceProp_t prop{};
   int64_t* pinned_scalar = nullptr;          // 64 B of pinned host memory for small readbacks
+  hipEvent_t sync_ev = nullptr;              // stream_wait()
+  std::map<std::string, int64_t> options;    // dfdb_ctx_set_option
 };
 
 namespace dfdb {
@@ -92,4 +94,12 @@ struct LaunchTimer {
   LaunchTimer(dfdb_ctx* c, const char* n);
   ~LaunchTimer();
 };
+}  // namespace dfdb
+
+namespace dfdb {
+// low-latency wait for everything enqueued on the engine stream: event + spin on hipEventQuery
+// (hipStreamSynchronize's blocking wait costs ~0.5 ms per call on this stack; a step must not pay that)
+void stream_wait(dfdb_ctx* ctx);
+// runtime tuning knobs (dfdb_ctx_set_option)
+int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt);
 }  // namespace dfdb

@@ -140,7 +140,7 @@ void launch_gather_bits(hipStream_t s, const uint64_t* bitmap, const uint64_t* p
 // reductions over the selected rows (sum / min / max); integer results exact, Float64 sums pairwise
 // per lane -> wave -> block -> final block (deterministic for a fixed grid)
 // ------------------------------------------------------------------------------------------------
-constexpr int kRedBlocks = 1024;
+constexpr int kRedBlocks = 2048;
 
 template <typename T> struct Acc;   // accumulator type
 template <> struct Acc<int8_t> { using type = int64_t; };   template <> struct Acc<int16_t> { using type = int64_t; };
@@ -188,10 +188,23 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partial(const uint64_t* __res
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   A acc = red_identity<A>(op);
   uint64_t cnt = 0;
-  for (int64_t wi = wave; wi < nwords; wi += nwaves) {   // one bitmap word (64 rows) per wave step
-    const uint64_t w = bitmap[wi];
-    if (w == 0) continue;                                  // wave-uniform: skip dead words without touching the column
-    if ((w >> lane) & 1ull) { acc = comb<A>(acc, (A)col[wi * 64 + lane], op); cnt++; }
+  const int64_t ntiles = (nwords + 15) / 16;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {   // 1024 rows per wave step, 16 column loads in flight
+    const int64_t wi = tile * 16 + lane;
+    const uint64_t myw = (lane < 16 && wi < nwords) ? bitmap[wi] : 0ull;
+    if (__ballot(myw != 0) == 0) continue;                     // wave-uniform: dead tiles never touch the column
+    const T* p = col + tile * 1024 + lane;
+    T v[16];
+    uint64_t w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      w[j] = __shfl(myw, j, 64);                               // word j, broadcast
+      v[j] = T(0);
+      if (w[j] != 0 && ((w[j] >> lane) & 1ull)) v[j] = __builtin_nontemporal_load(p + j * 64);   // selected rows only (never past nrows)
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if ((w[j] >> lane) & 1ull) { acc = comb<A>(acc, (A)v[j], op); cnt++; }
   }
   acc = wave_reduce<A>(acc, op);
   cnt = wave_sum64(cnt);

@@ -399,7 +399,7 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   memcpy(img.data(), &c.prog, sizeof(IProgram));
   if (!c.pool.empty()) memcpy(img.data() + pool_off, c.pool.data(), c.pool.size());
   HIP_CHECK(hipMemcpyAsync(db.p, img.data(), img.size(), hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(q->t->ctx);
   const int64_t ntiles = ceil_div(t->nrows, kTile);
   if (ntiles == 0) return;
   int64_t grid = ceil_div(ntiles, kWavesPerBlock); if (grid > 2048) grid = 2048;
@@ -413,7 +413,7 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   }
   int herr = 0;
   HIP_CHECK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(q->t->ctx);
   if (herr & 1) fail(DFDB_ERR_DIVIDE, "DivideError: integer division error");
   if (herr & 2) fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t tile_popcount(uint64_t myword, int lane) {
 // ------------------------------------------------------------------------------------------------
 // single column  x OP c
 // ------------------------------------------------------------------------------------------------
-template <typename T, int OP, bool AND_EXISTING>
+template <typename T, int OP, bool AND_EXISTING, bool NT>
 __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
                                                      uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles) {
   const int lane = lane_id();
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
     if (base + kTile <= nrows) {
       T v[kWordsPerTile];
 #pragma unroll
-      for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);   // 16 independent coalesced loads in flight; nt: streamed once (+12 % vs default policy, tools/bench_k1)
+      for (int j = 0; j < kWordsPerTile; j++) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];   // 16 independent coalesced loads in flight; NT: streamed once
 #pragma unroll
       for (int j = 0; j < kWordsPerTile; j++) {
         uint64_t m = __ballot(cmp_op<OP, T>(v[j], c));
@@ -84,39 +84,40 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
 }
 
 template <typename T, int OP>
-static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing) {
+static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing, bool nt) {
   const T c = from_bits<T>(cbits);
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   const int grid = grid_for_tiles(ntiles);
-  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
-  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
+  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
+  else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
+  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles);
 }
 template <typename T>
-static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae) {
+static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae, bool nt) {
   switch (op) {
-    case CMP_EQ: launch_cmp_t<T, CMP_EQ>(s, col, cbits, bitmap, tc, nrows, ae); break;
-    case CMP_NE: launch_cmp_t<T, CMP_NE>(s, col, cbits, bitmap, tc, nrows, ae); break;
-    case CMP_LT: launch_cmp_t<T, CMP_LT>(s, col, cbits, bitmap, tc, nrows, ae); break;
-    case CMP_LE: launch_cmp_t<T, CMP_LE>(s, col, cbits, bitmap, tc, nrows, ae); break;
-    case CMP_GT: launch_cmp_t<T, CMP_GT>(s, col, cbits, bitmap, tc, nrows, ae); break;
-    default:     launch_cmp_t<T, CMP_GE>(s, col, cbits, bitmap, tc, nrows, ae); break;
+    case CMP_EQ: launch_cmp_t<T, CMP_EQ>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
+    case CMP_NE: launch_cmp_t<T, CMP_NE>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
+    case CMP_LT: launch_cmp_t<T, CMP_LT>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
+    case CMP_LE: launch_cmp_t<T, CMP_LE>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
+    case CMP_GT: launch_cmp_t<T, CMP_GT>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
+    default:     launch_cmp_t<T, CMP_GE>(s, col, cbits, bitmap, tc, nrows, ae, nt); break;
   }
 }
 
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tile_counts,
-                     int64_t nrows, bool and_existing) {
+                     int64_t nrows, bool and_existing, bool nt) {
   switch (dtype) {
-    case DFDB_I8:  launch_cmp_op<int8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_I16: launch_cmp_op<int16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_I32: launch_cmp_op<int32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_I64: launch_cmp_op<int64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_U8: case DFDB_BOOL: launch_cmp_op<uint8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_U16: launch_cmp_op<uint16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_U32: launch_cmp_op<uint32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_U64: launch_cmp_op<uint64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    case DFDB_F32: launch_cmp_op<float>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
-    default:       launch_cmp_op<double>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing); break;
+    case DFDB_I8:  launch_cmp_op<int8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_I16: launch_cmp_op<int16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_I32: launch_cmp_op<int32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_I64: launch_cmp_op<int64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_U8: case DFDB_BOOL: launch_cmp_op<uint8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_U16: launch_cmp_op<uint16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_U32: launch_cmp_op<uint32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_U64: launch_cmp_op<uint64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    case DFDB_F32: launch_cmp_op<float>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
+    default:       launch_cmp_op<double>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt); break;
   }
 }
 

@@ -134,7 +134,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
     int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
     const Column& col = need_resident(t, ord);
     DevBuf& pb = q->tmp_a; pb.ensure(pat.size() + 64);
-    if (pat.size() > 64) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+    if (pat.size() > 64) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); stream_wait(q->t->ctx); }
     LaunchTimer lt(ctx, "str_match");
     launch_str_match(s, col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(), (const uint8_t*)pat.data(),
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
@@ -143,7 +143,8 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
   for (const ScanTerms& tb : term_batches) {
     if (tb.n == 1) {
       LaunchTimer lt(ctx, "scan_cmp");
-      launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+      launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
+                      ctx_option(ctx, "scan_nt", 1) != 0);
     } else {
       LaunchTimer lt(ctx, "scan_terms");
       launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
@@ -164,7 +165,7 @@ static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
     sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
     q->idx_sorted.ensure(sorted.size() * 8 + 64);
     if (!sorted.empty()) HIP_CHECK(hipMemcpyAsync(q->idx_sorted.p, sorted.data(), sorted.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));   // `sorted` is pageable host memory
+    stream_wait(q->t->ctx);   // `sorted` is pageable host memory
     r.kind = 1; r.sorted = q->idx_sorted.as<int64_t>(); r.nsorted = (int64_t)sorted.size();
     r.first = sorted.empty() ? 1 : sorted.front(); r.last = sorted.empty() ? 0 : sorted.back(); r.step = 1;
   }
@@ -205,7 +206,7 @@ int64_t query_count(dfdb_query* q, int nstages) {
   dfdb_ctx* ctx = q->t->ctx;
   const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  stream_wait(ctx);
   const int64_t n = ctx->pinned_scalar[0];
   if (nstages < 0) q->count = n;
   return n;
@@ -217,7 +218,7 @@ void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
   const size_t bytes = (size_t)ceil_div(q->t->nrows, 64) * 8;
   if (!bytes) return;
   HIP_CHECK(hipMemcpyAsync(out, q->bitmap.p, bytes, memkind == DFDB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-  if (memkind != DFDB_MEM_DEVICE) HIP_CHECK(hipStreamSynchronize(s));
+  if (memkind != DFDB_MEM_DEVICE) stream_wait(q->t->ctx);
 }
 
 void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
@@ -237,7 +238,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   { LaunchTimer lt(ctx, "compact_indices");
     launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m); }
   HIP_CHECK(hipMemcpyAsync(out, q->tmp_b.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(q->t->ctx);
 }
 
 // ---------------------------------------------------------------- materialize
@@ -247,14 +248,14 @@ static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_
   const int64_t nct = ceil_div(q->t->nrows, kCTileRows);
   DevBuf& tb = q->tmp_c; tb.ensure((size_t)(nct + 8) * 4);
   tile_off_out.ensure((size_t)(nct + 8) * 8);
-  DevBuf scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
+  DevBuf& scratch = q->str_scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
   int32_t* dst_sizes = out_sizes;
   if (!dst_sizes) { out_sizes_tmp.ensure((size_t)std::max<int64_t>(cap, 1) * 4); dst_sizes = out_sizes_tmp.as<int32_t>(); }
   { LaunchTimer lt(ctx, "str_gather_sizes");
     launch_str_gather_sizes(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.as<int32_t>(), dst_sizes, tb.as<uint32_t>(), q->t->nrows, cap); }
   launch_scan_counts(s, tb.as<uint32_t>(), tile_off_out.as<uint64_t>(), nct, scratch.as<uint64_t>());
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 1, tile_off_out.as<uint64_t>() + nct, 8, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(q->t->ctx);
   return ctx->pinned_scalar[1];
 }
 
@@ -266,8 +267,7 @@ int64_t query_string_bytes(dfdb_query* q, int i) {
   if (e.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
   const Column& col = need_resident(q->t, e.col);
   const int64_t cnt = query_count(q, -1);
-  DevBuf tmp_sizes, toff;
-  return string_out_offsets(q, col, tmp_sizes, nullptr, cnt, toff);
+  return string_out_offsets(q, col, q->str_sizes, nullptr, cnt, q->str_toff);
 }
 
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
@@ -285,7 +285,7 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
     if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
       const Column& col = need_resident(t, e.col);
       if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
-        DevBuf dsz, toff, dbytes;
+        DevBuf &dsz = q->str_sizes, &toff = q->str_toff, &dbytes = q->str_bytes;   // reused across calls (hipFree would sync the device)
         int32_t* d_sizes = dev ? (int32_t*)o.data : nullptr;
         const int64_t total = string_out_offsets(q, col, dsz, d_sizes, cnt, toff);
         if (!d_sizes) d_sizes = dsz.as<int32_t>();
@@ -301,8 +301,8 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
         if (!dev) {
           HIP_CHECK(hipMemcpyAsync(o.data, d_sizes, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
           if (total > 0) HIP_CHECK(hipMemcpyAsync(o.bytes, d_bytes, (size_t)total, hipMemcpyDeviceToHost, s));
+          stream_wait(ctx);
         }
-        HIP_CHECK(hipStreamSynchronize(s));
         continue;
       }
       DevBuf stage; void* dst = o.data;
@@ -314,17 +314,15 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
         DevBuf ms; uint8_t* md = o.missing;
         if (!dev) { ms.ensure((size_t)cnt); md = ms.as<uint8_t>(); }
         launch_gather_bits(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.missing.as<uint64_t>(), md, t->nrows, cnt);
-        if (!dev) HIP_CHECK(hipMemcpyAsync(o.missing, md, (size_t)cnt, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        if (!dev) { HIP_CHECK(hipMemcpyAsync(o.missing, md, (size_t)cnt, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
       }
-      HIP_CHECK(hipStreamSynchronize(s));
+      if (!dev) stream_wait(ctx);   // staging buffers die at scope exit; device outputs stay stream-ordered, no host wait
     } else {                  // BroadcastExecutor: computed column (projection.jl:128-129)
       if (dt_base(e.dtype) == DFDB_STRING) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
       DevBuf stage; void* dst = o.data;
       if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
       run_interp_project(q, e, dst, cnt);
-      if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
+      if (!dev) { HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
     }
   }
 }
@@ -349,7 +347,7 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
     HIP_CHECK(hipMemsetAsync(ones.p, 0xff, (size_t)(cnt / 64) * 8, s));
     uint64_t tail = (cnt & 63) ? ((1ull << (cnt & 63)) - 1ull) : 0ull;
     HIP_CHECK(hipMemcpyAsync((uint64_t*)ones.p + cnt / 64, &tail, 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    stream_wait(q->t->ctx);
     src = full.p; mask = ones.as<uint64_t>();
     q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
     { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, cnt, q->red_scratch.p, q->red_result.p); }
@@ -359,7 +357,7 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
   { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, t->nrows, q->red_scratch.p, q->red_result.p); }
 readback:
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->red_result.p, 16, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(q->t->ctx);
   if (ctx->pinned_scalar[1] == 0 && op != DFDB_AGG_SUM) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
   if (dt_isfloat(dt)) { double d; memcpy(&d, &ctx->pinned_scalar[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
   else { const int64_t v = ctx->pinned_scalar[0]; if (out_i) *out_i = v; if (out_f) *out_f = dt == DFDB_U64 ? (double)(uint64_t)v : (double)v; }

@@ -48,7 +48,7 @@ class OutCol(C.Structure):
 SYMBOLS = [
     "dfdb_version", "dfdb_last_error",
     "dfdb_ctx_create", "dfdb_ctx_destroy", "dfdb_ctx_synchronize", "dfdb_ctx_device_info", "dfdb_ctx_timer_start",
-    "dfdb_ctx_timer_stop", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
+    "dfdb_ctx_timer_stop", "dfdb_ctx_set_option", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
     "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",
     "dfdb_table_colinfo", "dfdb_table_find_column", "dfdb_table_load", "dfdb_table_load_image", "dfdb_table_add_column",
     "dfdb_table_add_generated", "dfdb_table_set_row_base",
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
         lib.dfdb_select_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.dfdb_count_to.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         lib.dfdb_select_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dfdb_ctx_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib

@@ -223,6 +223,8 @@ class Context:
         return dict(name=d.name.decode(), compute_units=d.compute_units, wavefront_size=d.wavefront_size, hbm_bytes=d.hbm_bytes,
                     peak_hbm_gbps=d.peak_hbm_gbps)
 
+    def set_option(self, key: str, value: int): N.check(N.load().dfdb_ctx_set_option(self._h, key.encode(), value))
+
     def timer_start(self): N.check(N.load().dfdb_ctx_timer_start(self._h))
 
     def timer_stop(self) -> float:
@@ -606,7 +608,8 @@ class _Query:
 
     def __del__(self):
         try:
-            if self._h:
+            import sys
+            if self._h and not sys.is_finalizing():    # never call into HIP while the interpreter tears down
                 N.load().dfdb_query_free(self._h)
         except Exception:
             pass

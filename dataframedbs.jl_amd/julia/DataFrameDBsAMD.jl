@@ -1,0 +1,272 @@
+# DataFrameDBsAMD.jl — the reference-side binding of libdfdb_hip.so: a thin `ccall` shim that keeps
+# DataFrameDBs.jl's DFTable / DFView API (selection(), projection(), materialize(), nrow/size) and sends the
+# block-streamed decode + selection + projection + materialize hot path to the MI355X engine.
+#
+# NOT EXECUTED IN THE BUILD IMAGE (julia is not installed there: SURVEY.md "Facts").  It is the binding a
+# DataFrameDBs.jl maintainer would add; INTEGRATION.md walks through it.  Every ccall below targets a symbol
+# declared in include/dfdb.h, whose comments name the Julia method each one stands in for.
+#
+#   using DataFrameDBs, DataFrameDBsAMD
+#   DataFrameDBsAMD.enable!()                 # route materialize/nrow of DFView through the GPU
+#   t = open_table("ecommerce")
+#   materialize(t[(t.price .> 100) .& (t.brand .== "apple"), [:user_id, :price]])
+#
+# Lowering: a `BlockBroadcasting{RT,F,Args}` tree (src/tables/broadcast.jl:6-17) becomes the postfix IR of
+# include/dfdb_ir.h.  Named Base functions map 1:1; closures (`:a => x -> x > c`) are traced by calling
+# them on a symbolic `Tr` value.  Anything outside the IR op set makes the engine answer
+# DFDB_ERR_UNSUPPORTED (or the tracer throw), and the call falls back to the stock Julia path.
+module DataFrameDBsAMD
+
+using DataFrameDBs
+using DataFrameDBs: DFTable, DFView, DFColumn, ColRef, BlockBroadcasting, SelectionQueue, Projection
+import DataFrames
+
+const LIB = joinpath(@__DIR__, "..", "libdfdb_hip.so")
+
+# ---------------------------------------------------------------- status codes (include/dfdb.h)
+const OK = Int32(0)
+struct Unsupported <: Exception
+    msg::String
+end
+
+function last_error()
+    buf = Vector{UInt8}(undef, 1024)
+    ccall((:dfdb_last_error, LIB), Int32, (Ptr{UInt8}, Csize_t), buf, 1024)
+    unsafe_string(pointer(buf))
+end
+
+function check(rc::Int32)
+    rc == OK && return
+    msg = last_error()
+    rc == 1 && throw(ArgumentError(msg))
+    rc == 4 && throw(KeyError(msg))
+    rc == 5 && throw(BoundsError(msg))
+    rc == 6 && throw(DivideError())
+    rc == 7 && throw(Unsupported(msg))
+    error(msg)                       # IO / FORMAT / DEVICE / NOMEM -> ErrorException, like filesystem.jl:50-57
+end
+
+# ---------------------------------------------------------------- dtypes (include/dfdb_ir.h)
+const DT = Dict{DataType,UInt8}(Int8 => 1, Int16 => 2, Int32 => 3, Int64 => 4, UInt8 => 5, UInt16 => 6, UInt32 => 7,
+                                UInt64 => 8, Float32 => 9, Float64 => 10, Bool => 11, String => 12)
+const JT = Dict(v => k for (k, v) in DT)
+const NULLABLE = 0x80
+dtype(::Type{Union{T,Missing}}) where {T} = DT[T] | NULLABLE
+dtype(::Type{T}) where {T} = DT[T]
+jltype(dt::Integer) = (dt & NULLABLE) != 0 ? Union{JT[UInt8(dt & 0x3f)],Missing} : JT[UInt8(dt & 0x3f)]
+
+# ---------------------------------------------------------------- IR emission
+const OPS = Dict{Any,UInt8}(
+    (+) => 0x10, (-) => 0x11, (*) => 0x12, (/) => 0x13, div => 0x14, (÷) => 0x14, rem => 0x15, (%) => 0x15, mod => 0x16,
+    min => 0x19, max => 0x1a,
+    (==) => 0x20, (!=) => 0x21, (<) => 0x22, (<=) => 0x23, (>) => 0x24, (>=) => 0x25,
+    (&) => 0x30, (|) => 0x31, xor => 0x32,
+    startswith => 0x41, endswith => 0x42)
+const UNARY = Dict{Any,UInt8}((-) => 0x17, abs => 0x18, (!) => 0x33, ismissing => 0x43, sizeof => 0x44)
+
+emit_col(io, ord::Integer) = (write(io, 0x01); write(io, UInt32(ord)))
+function emit_const(io, v::T) where {T<:Union{Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64,Float32,Float64,Bool}}
+    write(io, 0x02); write(io, DT[T])
+    T == Float64 ? write(io, v) : T == Float32 ? (write(io, v); write(io, UInt32(0))) : write(io, Int64(v) % Int64)
+end
+emit_const(io, s::AbstractString) = (write(io, 0x03); write(io, UInt32(sizeof(s))); write(io, String(s)))
+emit_const(io, r::Base.RefValue) = emit_const(io, r[])
+function emit_const(io, v::AbstractVector{T}) where {T<:Union{Integer,AbstractFloat}}     # Ref([1,11,21]) for in.()
+    E = T <: AbstractFloat ? Float64 : Int64
+    write(io, 0x04); write(io, DT[E]); write(io, UInt32(length(v))); foreach(x -> write(io, E(x)), v)
+end
+emit_const(io, v) = throw(Unsupported("constant of type $(typeof(v)) is outside the IR"))
+
+# symbolic value used to trace closures: every operation appends postfix IR
+struct Tr
+    code::Vector{UInt8}
+end
+leaf(f) = (io = IOBuffer(); f(io); Tr(take!(io)))
+tr(x::Tr) = x
+tr(x) = leaf(io -> emit_const(io, x))
+cat2(a, b, op::UInt8) = Tr(vcat(tr(a).code, tr(b).code, op))
+for (f, op) in OPS
+    fn = f
+    @eval Base.$(nameof(fn))(a::Tr, b::Tr) = cat2(a, b, $op)
+    @eval Base.$(nameof(fn))(a::Tr, b::Union{Number,AbstractString}) = cat2(a, b, $op)
+    @eval Base.$(nameof(fn))(a::Union{Number,AbstractString}, b::Tr) = cat2(a, b, $op)
+end
+for (f, op) in UNARY
+    @eval Base.$(nameof(f))(a::Tr) = Tr(vcat(a.code, $op))
+end
+Base.in(a::Tr, s::AbstractVector) = Tr(vcat(a.code, tr(s).code, 0x40))
+Base.Float64(a::Tr) = Tr(vcat(a.code, 0x50, DT[Float64]))
+Base.convert(::Type{Float64}, a::Tr) = Float64(a)
+
+# BlockBroadcasting / ColRef -> Tr.  `ord` maps a column Symbol to its 0-based table ordinal.
+lower(c::ColRef, ord) = leaf(io -> emit_col(io, ord[c.name]))
+lower(x, ord) = tr(x)
+function lower(b::BlockBroadcasting, ord)
+    args = map(a -> lower(a, ord), b.args)
+    f = b.f
+    if f === in && length(args) == 2
+        return Tr(vcat(args[1].code, args[2].code, 0x40))
+    elseif haskey(OPS, f) && length(args) == 2
+        return cat2(args[1], args[2], OPS[f])
+    elseif haskey(UNARY, f) && length(args) == 1
+        return Tr(vcat(args[1].code, UNARY[f]))
+    end
+    try
+        r = f(args...)                       # closure: trace it
+        r isa Tr || throw(Unsupported("closure did not reduce to IR (returned $(typeof(r)))"))
+        return r
+    catch e
+        e isa Unsupported && rethrow()
+        throw(Unsupported("cannot trace $(f): $(e)"))
+    end
+end
+
+# ---------------------------------------------------------------- device tables (one per opened DFTable path)
+mutable struct Device
+    ctx::Ptr{Cvoid}
+    tables::Dict{String,Ptr{Cvoid}}
+end
+const DEV = Ref{Union{Nothing,Device}}(nothing)
+
+function device()
+    if DEV[] === nothing
+        ctx = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dfdb_ctx_create, LIB), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), 0, C_NULL, ctx))
+        DEV[] = Device(ctx[], Dict{String,Ptr{Cvoid}}())
+    end
+    DEV[]
+end
+
+# open_table + read_block! of every block, once: decoded columns stay resident in HBM
+function device_table(t::DFTable)
+    d = device()
+    get!(d.tables, t.path) do
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dfdb_table_open, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Ptr{Cvoid}}), d.ctx, t.path, h))
+        check(ccall((:dfdb_table_load, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Int64, Int64, Ptr{Cvoid}), h[], C_NULL, 0, 0, -1, C_NULL))
+        h[]
+    end
+end
+
+ordinals(t::DFTable) = Dict(m.name => i - 1 for (i, m) in enumerate(t.meta.columns))
+
+# ---------------------------------------------------------------- DFView -> dfdb_query
+function with_query(f, v::DFView)
+    th = device_table(v.table)
+    ord = ordinals(v.table)
+    q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dfdb_query_new, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), th, q))
+    try
+        for el in v.selection.queue           # SelectionQueue stages, already composed by DataFrameDBs.add
+            if el isa BlockBroadcasting
+                code = lower(el, ord).code
+                GC.@preserve code check(ccall((:dfdb_query_add_predicate, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), q[], code, length(code)))
+            elseif el isa AbstractRange
+                check(ccall((:dfdb_query_add_range, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64), q[], first(el), step(el), last(el)))
+            elseif el isa Integer
+                check(ccall((:dfdb_query_add_integer, LIB), Int32, (Ptr{Cvoid}, Int64), q[], el))
+            else
+                idx = collect(Int64, el)
+                GC.@preserve idx check(ccall((:dfdb_query_add_indices, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64), q[], idx, length(idx)))
+            end
+        end
+        names = [string(k) for k in keys(v.projection)]
+        codes = [lower(c, ord).code for c in values(v.projection.cols)]
+        lens = Csize_t[length(c) for c in codes]
+        GC.@preserve names codes begin
+            np = [pointer(n) for n in names]; cp = [pointer(c) for c in codes]
+            check(ccall((:dfdb_query_set_projection, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Ptr{UInt8}}, Ptr{Csize_t}),
+                        q[], length(names), np, cp, lens))
+        end
+        return f(q[])
+    finally
+        ccall((:dfdb_query_free, LIB), Int32, (Ptr{Cvoid},), q[])
+    end
+end
+
+# struct dfdb_outcol (include/dfdb.h)
+struct OutCol
+    data::Ptr{Cvoid}; bytes::Ptr{UInt8}; missing::Ptr{UInt8}; bytes_cap::Int64
+    memkind::Int32; dtype::Int32; count::Int64; nbytes::Int64
+end
+
+"nrow(v) on the device (view.jl:192-206): one predicate scan, no block loop."
+function gpu_nrow(v::DFView)
+    with_query(v) do q
+        n = Ref{Int64}(0)
+        check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        n[]
+    end
+end
+
+"materialize(v) on the device (materialization.jl:27-40): the selection is evaluated once, outputs are caller-owned Julia vectors."
+function gpu_materialize(v::DFView)
+    with_query(v) do q
+        n = Ref{Int64}(0)
+        check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        ncols = length(v.projection)
+        outs = Vector{OutCol}(undef, ncols)
+        bufs = Any[]
+        for i in 1:ncols
+            dt = Ref{Int32}(0)
+            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, i - 1, dt))
+            T = jltype(dt[])
+            if (dt[] & 0x3f) == 12                                   # String: sizes + byte arena
+                nb = Ref{Int64}(0)
+                check(ccall((:dfdb_result_string_bytes, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), q, i - 1, nb))
+                sizes = Vector{Int32}(undef, n[]); arena = Vector{UInt8}(undef, nb[])
+                push!(bufs, (T, sizes, arena, nothing))
+                outs[i] = OutCol(pointer(sizes), pointer(arena), C_NULL, nb[], 0, 0, 0, 0)
+            else
+                B = Base.nonmissingtype(T)
+                vals = Vector{B}(undef, n[]); miss = T === B ? nothing : Vector{UInt8}(undef, n[])
+                push!(bufs, (T, vals, nothing, miss))
+                outs[i] = OutCol(pointer(vals), C_NULL, miss === nothing ? C_NULL : pointer(miss), 0, 0, 0, 0, 0)
+            end
+        end
+        GC.@preserve bufs outs check(ccall((:dfdb_materialize, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Int32), q, outs, ncols))
+        cols = map(bufs) do (T, a, arena, miss)
+            if arena !== nothing                                     # FlatStrings -> Vector{String} like projection.jl:99-100
+                res = Vector{T}(undef, length(a)); o = 0
+                for (k, s) in enumerate(a)
+                    res[k] = s < 0 ? missing : (str = unsafe_string(pointer(arena) + o, s); o += s; str)
+                end
+                res
+            elseif miss !== nothing
+                T[m != 0 ? missing : x for (x, m) in zip(a, miss)]
+            else
+                a
+            end
+        end
+        DataFrames.DataFrame(collect(cols), collect(keys(v.projection)), copycols = false)
+    end
+end
+
+# ---------------------------------------------------------------- drop-in switch
+"Route materialize(::DFView) / nrow(::DFView) through the MI355X engine, falling back to the stock path
+when a predicate is outside the IR op set."
+function enable!()
+    @eval DataFrameDBs begin
+        const _cpu_materialize = materialize
+        const _cpu_nrow = nrow
+    end
+    @eval function DataFrameDBs.materialize(v::DFView)
+        try
+            return DataFrameDBsAMD.gpu_materialize(v)
+        catch e
+            e isa DataFrameDBsAMD.Unsupported || rethrow()
+            return invoke(DataFrameDBs._cpu_materialize, Tuple{DFView}, v)
+        end
+    end
+    @eval function DataFrameDBs.nrow(v::DFView)
+        try
+            return DataFrameDBsAMD.gpu_nrow(v)
+        catch e
+            e isa DataFrameDBsAMD.Unsupported || rethrow()
+            return invoke(DataFrameDBs._cpu_nrow, Tuple{DFView}, v)
+        end
+    end
+    nothing
+end
+
+end # module

@@ -102,6 +102,8 @@ int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out);
 int32_t dfdb_ctx_destroy(dfdb_ctx* ctx);
 int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx);
 int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
+/* tuning knobs, e.g. "scan_nt" (1 = nontemporal column loads in the scan kernels, default 1) */
+int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);
 int32_t dfdb_ctx_timer_stop(dfdb_ctx* ctx, double* elapsed_ms);
