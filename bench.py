@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="three-kernel pipeline (K1, count scan, K2) instead of the fused one-pass kernel")
     args = ap.parse_args()
 
     import torch
@@ -90,10 +91,12 @@ def main():
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    ctx.set_option("fused", 0 if args.unfused else 1)
+
     def step():
-        q.execute()                                    # K1 + count scan
-        q.indices_device(out.data_ptr(), cap)          # K2
-        q.count_device(cnt.data_ptr())
+        q.reset()                                      # a fresh evaluation every step (nothing cached)
+        q.indices_device(out.data_ptr(), cap)          # fused: scan + look-back + compaction in one launch
+        q.count_device(cnt.data_ptr())                 # (unfused: K1, count scan, K2)
         if world > 1:
             dist.all_reduce(cnt)                       # the only exchange: 8 bytes
 
@@ -119,11 +122,11 @@ def main():
     ctx.profile(True)
     prof_steps = max(3, min(args.steps, 10))
     for _ in range(prof_steps):
-        q.execute()
+        q.reset()
         q.indices_device(out.data_ptr(), cap)
     torch.cuda.synchronize()
     kernels = {}
-    for k in ("scan_cmp", "scan_counts", "compact_indices"):
+    for k in ("scan_compact", "scan_cmp", "scan_counts", "compact_indices"):
         n, ms = ctx.profile_get(k)
         if n:
             kernels[k] = dict(launches=n, avg_ms=ms / n)
@@ -133,21 +136,28 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * rows * args.steps / elapsed
         sigma = nsel / rows
-        # algorithmic bytes of ONE scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
-        scan_bytes = rows * (8 + 1 / 8 + 4 / 1024)
-        scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
+        if "scan_compact" in kernels:
+            # ONE k_scan_compact launch: 8 B/row column + 1/8 bitmap + 12 B per 1024-row tile (count + prefix) + 8*sigma index
+            kname, pmc_name = "k_scan_compact<int64,GT>", "r1_pmc_scan_compact.json"
+            scan_bytes = rows * (8 + 1 / 8 + 12 / 1024 + 8 * sigma)
+            scan_ms = kernels["scan_compact"]["avg_ms"]
+        else:
+            # ONE k_scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
+            kname, pmc_name = "k_scan_cmp<int64,GT>", "r1_pmc_scan_cmp.json"
+            scan_bytes = rows * (8 + 1 / 8 + 4 / 1024)
+            scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
         job_bytes = rows * (8 + 8 * sigma)             # 8 + 8*sigma B/row for the whole job
         # HBM traffic of that kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command; FETCH_SIZE doubled per the gfx950 correction, calibrated on a known-byte read): profiles/
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_scan_cmp.json")
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("rows"):
                 traffic = pj["hbm_bytes_per_launch_corrected"] * rows / pj["rows"]
-                traffic_src = "profiles/r1_pmc_scan_cmp.json (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
+                traffic_src = f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
         res = {
             "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,10 +165,11 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "Int64 column, selection(x -> x > 899999) -> ascending 1-based Int64 row indices + count",
                        "rows_per_gpu": rows, "selected_per_gpu": nsel, "selectivity": sigma, "block_size": 65536,
+                       "pipeline": "unfused: k_scan_cmp + count scan + k_compact_indices" if args.unfused else "fused: k_scan_compact (one pass, decoupled look-back)",
                        "sharding": f"contiguous block ranges x{world}, all-reduce(count) per step" if world > 1 else "single GPU",
                        "device": info["name"], "global_selected": total_sel},
             "job_hbm_gbps": job_bytes * world / (elapsed / args.steps) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_scan_cmp<int64,GT>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }

@@ -57,7 +57,8 @@ struct dfdb_query {
   std::vector<dfdb::ProjCol> proj;
   // device state of the last execution
   dfdb::DevBuf bitmap, tile_counts, prefix, scan_scratch, idx_sorted, red_scratch, red_result, tmp_a, tmp_b, tmp_c,
-      str_sizes, str_toff, str_bytes, str_scratch;
+      str_sizes, str_toff, str_bytes, str_scratch, fused_scratch;
+  bool fused_pending = false;  // a fused launch whose spin-overrun flag has not been checked yet
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
   bool prefix_valid = false;

@@ -206,10 +206,31 @@ int64_t query_count(dfdb_query* q, int nstages) {
   dfdb_ctx* ctx = q->t->ctx;
   const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (q->fused_pending) HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 2, q->fused_scratch.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   stream_wait(ctx);
+  if (q->fused_pending) {
+    q->fused_pending = false;
+    if (((const uint32_t*)(ctx->pinned_scalar + 2))[1] != 0) {
+      q->executed_stages = -1;
+      fail(DFDB_ERR_DEVICE, "fused scan: look-back spin overrun (a predecessor chunk never published)");
+    }
+  }
   const int64_t n = ctx->pinned_scalar[0];
   if (nstages < 0) q->count = n;
   return n;
+}
+
+// single stage, single `col OP const` term over a dtype the fused kernel is instantiated for
+static bool fused_plan(dfdb_query* q, ScanTerm& tm) {
+  dfdb_table* t = q->t;
+  if (ctx_option(t->ctx, "fused", 1) == 0) return false;
+  if (q->stages.size() != 1 || q->stages[0].kind != ST_PRED) return false;
+  std::vector<const Node*> conj; flatten_and(*q->stages[0].pred, conj);
+  int ord;
+  if (conj.size() != 1 || !match_simple_term(*conj[0], *t, tm, ord)) return false;
+  if (!fused_supported(tm.dtype)) return false;
+  tm.col = need_resident(t, ord).data.p;
+  return true;
 }
 
 void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
@@ -222,8 +243,22 @@ void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
 }
 
 void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
-  ensure_executed(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  ScanTerm tm;
+  const bool need_exec = q->executed_stages != (int)q->stages.size() || q->bitmap_rows != t->nrows;
+  if (memkind == DFDB_MEM_DEVICE && need_exec && t->nrows > 0 && fused_plan(q, tm)) {
+    // one pass: bitmap + tile counts + per-tile prefix + total + indices (k_fused.hip)
+    ensure_state(q);
+    q->fused_scratch.ensure(fused_scratch_bytes(t->nrows));
+    q->count = -1;
+    { LaunchTimer lt(ctx, "scan_compact");
+      launch_scan_compact(s, tm.col, tm.dtype, tm.op, tm.cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), q->prefix.as<uint64_t>(),
+                          out, cap, t->nrows, t->row_base, q->fused_scratch.p); }
+    q->prefix_valid = true; q->executed_stages = 1; q->fused_pending = true;
+    if (n) *n = query_count(q, -1);
+    return;
+  }
+  ensure_executed(q);
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");
       launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap); }

@@ -55,7 +55,7 @@ SYMBOLS = [
     "dfdb_query_new", "dfdb_query_free", "dfdb_query_add_range", "dfdb_query_add_indices", "dfdb_query_add_integer",
     "dfdb_query_add_predicate", "dfdb_query_nstages", "dfdb_query_set_projection", "dfdb_query_ncols", "dfdb_query_coltype",
     "dfdb_expr_result_type", "dfdb_query_set_stage_base", "dfdb_query_count_prefix",
-    "dfdb_query_execute", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
+    "dfdb_query_execute", "dfdb_query_reset", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
     "dfdb_materialize", "dfdb_aggregate",
 ]
 

@@ -616,6 +616,8 @@ class _Query:
 
     def execute(self): N.check(N.load().dfdb_query_execute(self._h))
 
+    def reset(self): N.check(N.load().dfdb_query_reset(self._h))
+
     def count(self) -> int:
         n = C.c_int64()
         N.check(N.load().dfdb_count(self._h, C.byref(n)))

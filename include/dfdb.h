@@ -179,6 +179,10 @@ int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n);
 /* SelectionExecutor.apply over every resident block (selection.jl:161-167, blocksiterator.jl:98-145):
  * leaves the selection bitmap + per-tile counts + their prefix in HBM.  Asynchronous. */
 int32_t dfdb_query_execute(dfdb_query* q);
+/* forget the cached execution so the next count/indices/materialize re-evaluates the selection (a new
+ * BlocksIterator in the reference: blocksiterator.jl:20-44).  dfdb_select_indices on a reset single-predicate
+ * query with a device output runs the fused one-pass kernel (scan + look-back + compaction). */
+int32_t dfdb_query_reset(dfdb_query* q);
 /* nrow(v) / size(v,1) / length(col): view.jl:192-206, column.jl:46-52 */
 int32_t dfdb_count(dfdb_query* q, int64_t* n);
 /* same total written to a caller buffer without a host sync when memkind == DFDB_MEM_DEVICE (the operand of

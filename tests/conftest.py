@@ -31,4 +31,5 @@ def dfdb_mod():
 @pytest.fixture(scope="session")
 def ctx(dfdb_mod):
     """One engine context on cuda:0 for the whole GPU session.  Fails loudly without the HIP library / a GPU."""
+    import torch  # noqa: F401  torch's bundled HIP runtime must be the one loaded first when both live in a process
     return dfdb_mod.default_context(0)

@@ -242,3 +242,45 @@ def test_aggregates(oracle, dfdb_mod, ctx):
     assert abs(cx.sum() - want) <= tol
     assert cx.min() == float(cols["x"][sel].min()) and cx.max() == float(cols["x"][sel].max())
     assert abs(cx.mean() - want / sel.sum()) <= tol
+
+
+# ------------------------------------------------------------------ fused one-pass kernel (scan + look-back + compaction)
+@pytest.mark.parametrize("n", [1, 1023, 65535, 65536, 65537, 131072, 1_000_003, 5_000_011])
+@pytest.mark.parametrize("dtype", [np.int64, np.float64, np.int32])
+def test_fused_scan_compact(oracle, dfdb_mod, ctx, n, dtype):
+    """dfdb_select_indices on a reset single-predicate query with a device output takes k_scan_compact; it must give
+    the same indices, bitmap, count and per-tile prefix (checked through a later gather) as the oracle."""
+    import torch
+    from dfdb import ir
+    if n > 1_100_000 and dtype is not np.int64:
+        pytest.skip("large size once")
+    x = oracle.gen_i64(col_seed(0), 0, n).astype(dtype)
+    thr = 899_999
+    p = Pair(oracle, dfdb_mod, {"x": x, "y": oracle.gen_i64(col_seed(1), 0, n)}, block_size=65536)
+    ov, dv = apply_stages(p, [("pred", ir.col(0) > thr)])
+    want = ov.select_indices()
+    q = dv._query()
+    out = torch.full((max(len(want), 1) + 8,), -7, dtype=torch.int64, device="cuda:0")
+    for fused in (1, 0, 1):
+        ctx.set_option("fused", fused)
+        out.fill_(-7)
+        q.reset()
+        got_n = q.indices_device(out.data_ptr(), len(want), want_count=True)
+        torch.cuda.synchronize()
+        assert got_n == len(want)
+        assert np.array_equal(out[:len(want)].cpu().numpy(), want), f"fused={fused}"
+        assert (out[len(want):] == -7).all()            # never writes past cap
+        assert np.array_equal(q.bitmap(), ov.select_bitmap(n))
+        got = q.materialize()                            # gathers use the prefix the fused kernel wrote
+        wantm = ov.materialize()
+        assert np.array_equal(got[0], wantm[0]) and np.array_equal(got[1], wantm[1])
+    ctx.set_option("fused", 1)
+    # every chunk publishes through the look-back: all rows selected / none selected
+    for pred, cnt in ((ir.col(0) >= 0, n), (ir.col(0) < 0, 0)):
+        ov2, dv2 = apply_stages(p, [("pred", pred)])
+        q2 = dv2._query()
+        out2 = torch.empty(max(cnt, 1), dtype=torch.int64, device="cuda:0")
+        assert q2.indices_device(out2.data_ptr(), cnt, want_count=True) == cnt
+        torch.cuda.synchronize()
+        if cnt:
+            assert np.array_equal(out2.cpu().numpy(), np.arange(1, n + 1))

@@ -81,6 +81,20 @@ def main():
     byts = n * 8 + nsel * 8
     print(json.dumps({"config": 2, "rows": n, "selected": nsel, "kernels_ms": ks, "wall_ms": wall * 1e3, "algorithmic_GB": byts / 1e9,
                       "job_GBps": byts / wall / 1e9, "rows_per_s": n / wall}))
+    # A/B in ONE process on ONE device (boxes differ by several %): default-policy vs nontemporal column loads
+    ab = {0: [], 1: []}
+    ctx.profile(True)
+    for r in range(6):
+        for nt in (0, 1):
+            ctx.set_option("scan_nt", nt)
+            n0, ms0 = ctx.profile_get("scan_cmp")
+            q.execute()
+            n1, ms1 = ctx.profile_get("scan_cmp")
+            if r:
+                ab[nt].append(ms1 - ms0)
+    ctx.profile(False)
+    ctx.set_option("scan_nt", 1)
+    print(json.dumps({"config": "2-nt-ab", "scan_cmp_ms_default": sorted(ab[0]), "scan_cmp_ms_nt": sorted(ab[1])}))
     cx = v[dfdb.ALL, "x"]
     ks, wall = timed(ctx, lambda: (q.execute(), cx.sum()), args.reps)
     print(json.dumps({"config": "2-sum", "kernels_ms": ks, "wall_ms": wall * 1e3}))
