@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — filtered scan of a 1e9-row Int64 column at 10 % selectivity on MI355X (BASELINE.json config 2).
 
-One "step" = the whole hot path over the resident column: predicate scan `x > 899999` -> selection bitmap
-+ tile counts (K1), exclusive scan of the counts, compaction to ascending 1-based Int64 row indices (K2),
-count left on the device (and all-reduced over ranks when --gpus > 1).  The column is generated in HBM
+One "step" = the whole hot path over the resident column, re-evaluated from scratch (dfdb_query_reset): predicate
+scan `x > 899999` -> selection bitmap + tile counts (K1), exclusive scan of the counts, compaction to ascending
+1-based Int64 row indices (K2), count left on the device (and all-reduced over ranks when --gpus > 1).  The column is generated in HBM
 (splitmix64) before the timed region; outputs stay in HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="three-kernel pipeline (K1, count scan, K2) instead of the fused one-pass kernel")
+    ap.add_argument("--fused", action="store_true", help="one-pass k_scan_compact (decoupled look-back) instead of K1 + count scan + K2; "
+                    "measured 8-10 %% slower than the three-kernel pipeline on MI355X (DESIGN.md §4), kept as an option")
     args = ap.parse_args()
 
     import torch
@@ -91,12 +92,12 @@ def main():
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    ctx.set_option("fused", 0 if args.unfused else 1)
+    ctx.set_option("fused", 1 if args.fused else 0)
 
     def step():
         q.reset()                                      # a fresh evaluation every step (nothing cached)
-        q.indices_device(out.data_ptr(), cap)          # fused: scan + look-back + compaction in one launch
-        q.count_device(cnt.data_ptr())                 # (unfused: K1, count scan, K2)
+        q.indices_device(out.data_ptr(), cap)          # K1 scan -> bitmap + tile counts, count scan, K2 compaction
+        q.count_device(cnt.data_ptr())                 # (--fused: all three in one launch)
         if world > 1:
             dist.all_reduce(cnt)                       # the only exchange: 8 bytes
 
@@ -165,7 +166,7 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "Int64 column, selection(x -> x > 899999) -> ascending 1-based Int64 row indices + count",
                        "rows_per_gpu": rows, "selected_per_gpu": nsel, "selectivity": sigma, "block_size": 65536,
-                       "pipeline": "unfused: k_scan_cmp + count scan + k_compact_indices" if args.unfused else "fused: k_scan_compact (one pass, decoupled look-back)",
+                       "pipeline": "fused: k_scan_compact (one pass, decoupled look-back)" if args.fused else "k_scan_cmp + count scan + k_compact_indices",
                        "sharding": f"contiguous block ranges x{world}, all-reduce(count) per step" if world > 1 else "single GPU",
                        "device": info["name"], "global_selected": total_sel},
             "job_hbm_gbps": job_bytes * world / (elapsed / args.steps) / 1e9,

@@ -2,7 +2,7 @@
 //
 // For the headline query `selection(x -> x OP c)` -> ascending row indices, the three-kernel pipeline reads
 // the bitmap back, pays two extra launches, and serialises index stores behind column loads.  Here one
-// workgroup claims a 65 536-row chunk (= one block of the reference's DEFAULT_BLOCK_SIZE) with a ticket,
+// workgroup (16 waves) claims a 262 144-row chunk (= four blocks of the reference's DEFAULT_BLOCK_SIZE) with a ticket,
 //   1. scans it exactly like K1 (coalesced nontemporal loads, ballot = bitmap word), keeping the chunk's
 //      bitmap (8 KB) and 64 tile counts in LDS while also writing them to HBM for later gathers,
 //   2. publishes the chunk's survivor count and obtains its global output offset by DECOUPLED LOOK-BACK
@@ -21,9 +21,11 @@
 
 namespace dfdb {
 
-constexpr int kBlock = 256;
-constexpr int kChunkTiles = 64;                 // 64 x 1024 rows = 65 536 rows per chunk
-constexpr int kTilesPerWave = kChunkTiles / 4;  // 16
+constexpr int kWaves = 16;                      // 1024-thread workgroups: few chunks in flight -> short look-backs
+constexpr int kBlock = 64 * kWaves;
+constexpr int kTilesPerWave = 16;
+constexpr int kChunkTiles = kTilesPerWave * kWaves;   // 256 x 1024 rows = 262 144 rows (4 reference blocks) per chunk
+constexpr int kTPL = kChunkTiles / 64;          // tile counts per lane in the chunk-level scan
 constexpr uint64_t kStAgg = 1ull << 62, kStPrefix = 2ull << 62, kValMask = (1ull << 62) - 1;
 
 template <int OP, typename T>
@@ -37,15 +39,15 @@ __device__ __forceinline__ bool fcmp(T x, T c) {
 }
 
 template <typename T, int OP>
-__global__ __launch_bounds__(kBlock) void k_scan_compact(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
+__global__ __launch_bounds__(kBlock, 8) void k_scan_compact(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
                                                          uint32_t* __restrict__ tile_counts, uint64_t* __restrict__ prefix,
                                                          int64_t* __restrict__ out, int64_t out_cap, int64_t nrows, int64_t ntiles,
                                                          int64_t nchunks, int64_t row_base, uint64_t* __restrict__ desc,
-                                                         uint32_t* __restrict__ ticket /* [0] ticket, [1] overrun flag */) {
+                                                         uint32_t* __restrict__ ticket /* [0] ticket, [1] overrun flag */, int diag) {
   __shared__ uint64_t words[kChunkTiles * 16];      // the chunk's bitmap
   __shared__ uint32_t tcount[kChunkTiles];
   __shared__ uint32_t tpre[kChunkTiles];
-  __shared__ uint16_t pos_sh[4][4096];
+  __shared__ uint16_t pos_sh[kWaves][1024];
   __shared__ int64_t chunk_sh;
   __shared__ uint64_t base_sh;
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -93,13 +95,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_compact(const T* __restrict__ c
 
     // ---- 2. chunk aggregate, publish, look back
     if (wib == 0) {
-      const uint32_t cnt = tcount[lane];
+      uint32_t c4[kTPL], cnt = 0;
+#pragma unroll
+      for (int i = 0; i < kTPL; i++) { c4[i] = tcount[lane * kTPL + i]; cnt += c4[i]; }
       const uint32_t incl = wave_incl_scan(cnt);
-      tpre[lane] = incl - cnt;
+      uint32_t run = incl - cnt;
+#pragma unroll
+      for (int i = 0; i < kTPL; i++) { tpre[lane * kTPL + i] = run; run += c4[i]; }
       const uint64_t agg = __shfl(incl, 63, 64);
       if (lane == 0) __hip_atomic_store(&desc[chunk], (chunk == 0 ? kStPrefix : kStAgg) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint64_t base = 0;
-      if (chunk > 0) {
+      if (chunk > 0 && !(diag & 2)) {
         int64_t look = chunk - 1;
         uint32_t spins = 0;
         for (;;) {
@@ -128,20 +134,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_compact(const T* __restrict__ c
     const uint64_t base = base_sh;
     if (tid < kChunkTiles) { const int64_t tile = chunk * kChunkTiles + tid; if (tile < ntiles) prefix[tile] = base + tpre[tid]; }
 
-    // ---- 3. compaction of this wave's four 4096-row ctiles out of LDS
-    for (int k = 0; k < 4; k++) {
-      const int ct = wib * 4 + k;                          // ctile inside the chunk = tiles 4ct .. 4ct+3
-      uint64_t w = words[ct * 64 + lane];
-      const uint32_t pc = (uint32_t)__popcll(w);
+    // ---- 3. compaction of the 16 tiles this wave scanned, out of LDS: lane l owns 16 bits (rows 16l..16l+15 of
+    //         the tile), expands them at its wave-prefix into a 2-KB staging buffer, then coalesced stores
+    for (int k = 0; k < kTilesPerWave; k++) {
+      const int lt = wib * kTilesPerWave + k;
+      if (tcount[lt] == 0 || (diag & 1)) continue;         // wave-uniform
+      uint32_t w = (uint32_t)(words[lt * 16 + (lane >> 2)] >> ((lane & 3) * 16)) & 0xffffu;
+      const uint32_t pc = (uint32_t)__popc(w);
       const uint32_t incl = wave_incl_scan(pc);
       const uint32_t total = __shfl(incl, 63, 64);
-      if (total == 0) continue;
       uint32_t o = incl - pc;
-      const uint32_t lbase = (uint32_t)lane << 6;
-      while (w) { const int b = __builtin_ctzll(w); w &= w - 1; pos[o++] = (uint16_t)(lbase + (uint32_t)b); }
+      const uint32_t lbase = (uint32_t)lane << 4;
+      while (w) { const int b = __builtin_ctz(w); w &= w - 1; pos[o++] = (uint16_t)(lbase + (uint32_t)b); }
       wave_lds_fence();
-      const int64_t obase = (int64_t)(base + tpre[ct * 4]);
-      const int64_t row1 = row_base + (chunk * kChunkTiles + ct * 4) * 1024 + 1;
+      const int64_t obase = (int64_t)(base + tpre[lt]);
+      const int64_t row1 = row_base + (chunk * kChunkTiles + lt) * 1024 + 1;
       for (uint32_t i = lane; i < total; i += 64) { const int64_t oo = obase + i; if (oo < out_cap) out[oo] = row1 + pos[i]; }
       wave_lds_fence();
     }
@@ -149,7 +156,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_compact(const T* __restrict__ c
   }
 }
 
-size_t fused_scratch_bytes(int64_t nrows) { return (size_t)((nrows + 65535) / 65536 + 8) * 8 + 64; }
+int g_fused_diag = 0;   // diagnostics only: 1 = skip index stores, 2 = skip look-back (wrong results, timing only)
+void set_fused_diag(int d) { g_fused_diag = d; }
+size_t fused_scratch_bytes(int64_t nrows) { return (size_t)((nrows + 65535) / 65536 + 8) * 8 + 64; }   // >= one descriptor per chunk
 
 template <typename T, int OP>
 static void launch_fused_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, uint64_t* prefix, int64_t* out,
@@ -158,10 +167,10 @@ static void launch_fused_t(hipStream_t s, const void* col, uint64_t cbits, uint6
   uint32_t* ticket = (uint32_t*)scratch;
   uint64_t* desc = (uint64_t*)((char*)scratch + 64);
   (void)hipMemsetAsync(scratch, 0, fused_scratch_bytes(nrows), s);
-  int64_t grid = nchunks < 768 ? nchunks : 768;   // 3 workgroups per CU (41 KB LDS each)
+  int64_t grid = nchunks < 512 ? nchunks : 512;   // 2 workgroups of 16 waves per CU (67 KB LDS each)
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_scan_compact<T, OP>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const T*)col, from_bits<T>(cbits), bitmap, tc, prefix, out,
-                     out_cap, nrows, ntiles, nchunks, row_base, desc, ticket);
+                     out_cap, nrows, ntiles, nchunks, row_base, desc, ticket, g_fused_diag);
 }
 template <typename T>
 static void launch_fused_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, uint64_t* prefix, int64_t* out,

@@ -33,6 +33,7 @@ void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, 
 // ---- fused single pass: K1 + count scan + K2 (decoupled look-back) for `x OP c` -> indices (k_fused.hip) ----
 // scratch: fused_scratch_bytes(nrows), zeroed by the launcher; ((uint32_t*)scratch)[1] != 0 afterwards = spin overrun
 bool fused_supported(int32_t dtype);
+void set_fused_diag(int d);
 size_t fused_scratch_bytes(int64_t nrows);
 void launch_scan_compact(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tile_counts,
                          uint64_t* prefix, int64_t* out, int64_t out_cap, int64_t nrows, int64_t row_base, void* scratch);

@@ -223,7 +223,7 @@ int64_t query_count(dfdb_query* q, int nstages) {
 // single stage, single `col OP const` term over a dtype the fused kernel is instantiated for
 static bool fused_plan(dfdb_query* q, ScanTerm& tm) {
   dfdb_table* t = q->t;
-  if (ctx_option(t->ctx, "fused", 1) == 0) return false;
+  if (ctx_option(t->ctx, "fused", 0) == 0) return false;   // opt-in: measured slower than K1 + scan + K2
   if (q->stages.size() != 1 || q->stages[0].kind != ST_PRED) return false;
   std::vector<const Node*> conj; flatten_and(*q->stages[0].pred, conj);
   int ord;
@@ -249,6 +249,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   if (memkind == DFDB_MEM_DEVICE && need_exec && t->nrows > 0 && fused_plan(q, tm)) {
     // one pass: bitmap + tile counts + per-tile prefix + total + indices (k_fused.hip)
     ensure_state(q);
+    set_fused_diag((int)ctx_option(ctx, "fused_diag", 0));
     q->fused_scratch.ensure(fused_scratch_bytes(t->nrows));
     q->count = -1;
     { LaunchTimer lt(ctx, "scan_compact");

@@ -284,3 +284,4 @@ def test_fused_scan_compact(oracle, dfdb_mod, ctx, n, dtype):
         torch.cuda.synchronize()
         if cnt:
             assert np.array_equal(out2.cpu().numpy(), np.arange(1, n + 1))
+    ctx.set_option("fused", 0)
