@@ -7,8 +7,22 @@ namespace dfdb {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-// inclusive prefix sum across the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+// inclusive prefix sum across the 64 lanes of a wave, in-register DPP form (no LDS crossbar): three row_shr
+// on the input, row_shr 4/8 on the partials (bank-masked), then row_bcast15 / row_bcast31 to carry across the
+// four 16-lane rows.  7 v_add_u32 with DPP modifiers instead of 6 x (ds_bpermute + select + add).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t r = x;
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return r;
+}
+// reference form (cross-checked against the DPP form by tests/test_gpu_parity.py through every compaction)
+__device__ __forceinline__ uint32_t wave_incl_scan_shfl(uint32_t v) {
   const int lane = lane_id();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
