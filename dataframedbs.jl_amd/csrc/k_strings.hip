@@ -117,6 +117,71 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
   }
 }
 
+// Short patterns (<= 8 bytes: the common case of brand / event-type equality): three phases per 8 steps so that
+// the byte probes of 8 x 64 rows are all in flight together instead of one dependent round trip per 64 rows:
+//   A  wave prefix-sums of the sizes -> per-row byte offsets       (ALU only)
+//   B  one unaligned 8-byte probe per candidate row (size matches) (8 loads in flight per lane)
+//   C  masked compare + ballot = bitmap word
+template <bool AND_EXISTING, int MODE>
+__global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
+                                                            const uint8_t* __restrict__ bytes, uint64_t patw, int plen,
+                                                            uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows,
+                                                            int64_t ntiles) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const uint64_t mask = plen >= 8 ? ~0ull : ((1ull << (8 * plen)) - 1ull);
+  const uint64_t want = patw & mask;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const uint8_t* tb = bytes + tile_off[tile];
+    const int64_t base = tile * kTile;
+    int32_t sz[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int64_t i = base + j * 64 + lane; sz[j] = i < nrows ? __builtin_nontemporal_load(sizes + i) : -2; }
+    uint64_t myword = 0;
+    uint32_t run = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t rel[8]; uint64_t v[8]; bool cand[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {                                   // A
+        const uint32_t c = clamp_size(sz[h * 8 + j]);
+        const uint32_t incl = wave_incl_scan(c);
+        rel[j] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {                                   // B
+        const int32_t s0 = sz[h * 8 + j];
+        const int len = s0 > 0 ? s0 : 0;
+        cand[j] = s0 != -2 && (MODE <= 1 ? len == plen : len >= plen);
+        v[j] = 0;
+        if (cand[j] && plen > 0) v[j] = load_u64_unaligned(tb + rel[j] + (MODE == 3 ? len - plen : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {                                   // C
+        const bool eq = cand[j] && ((v[j] & mask) == want);
+        const bool r = MODE == 1 ? (sz[h * 8 + j] != -2 && !eq) : eq;
+        const uint64_t m = __ballot(r);
+        if (lane == h * 8 + j) myword = m;
+      }
+    }
+    if (AND_EXISTING) { if (lane < 16) myword &= bitmap[tile * 16 + lane]; }
+    uint32_t cnt = lane < 16 ? (uint32_t)__popcll(myword) : 0u;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane < 16) bitmap[tile * 16 + lane] = myword;
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+
+template <int MODE>
+static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, uint64_t patw, int plen,
+                         uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles) {
+  if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles);
+  else hipLaunchKernelGGL((k_str_match_short<false, MODE>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles);
+}
+
 void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
                       const uint8_t* pat_dev, int32_t patlen, int mode, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
                       bool and_existing) {
@@ -125,33 +190,51 @@ void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_o
   Pattern pat; memset(&pat, 0, sizeof pat); pat.len = patlen;
   if (patlen > 0 && patlen <= 64) memcpy(pat.w, pat_host, (size_t)patlen);   // short patterns ride in the kernel arguments
   const int grid = grid_for(ntiles, 2048);
+  if (patlen <= 8) {
+    switch (mode) {
+      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
+      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
+      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
+      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
+    }
+    return;
+  }
   if (and_existing) hipLaunchKernelGGL((k_str_match<true>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, pat, pat_dev, mode, bitmap, tile_counts, nrows, ntiles);
   else hipLaunchKernelGGL((k_str_match<false>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, pat, pat_dev, mode, bitmap, tile_counts, nrows, ntiles);
 }
 
 // ---------------------------------------------------------------- K6
-constexpr int64_t kCTile = 4096;
+// Both passes work on 1024-row tiles, one wave per tile.  Lane l owns a 16-bit slice of the tile's bitmap
+// (rows 16l..16l+15) and expands it into a 2-KB LDS list of selected in-tile positions (wave prefix-sum of
+// popcounts), so everything after that is proportional to the SELECTED rows.
 
-// selected sizes -> out_sizes at the tile's output offset, plus the selected byte total per 4096-row ctile
+// stage the selected positions of `tile`; returns how many
+__device__ __forceinline__ uint32_t stage_tile_positions(const uint64_t* __restrict__ bitmap, int64_t tile, uint16_t* pos, int lane) {
+  uint32_t w = (uint32_t)(bitmap[tile * 16 + (lane >> 2)] >> ((lane & 3) * 16)) & 0xffffu;
+  const uint32_t pc = (uint32_t)__popc(w);
+  const uint32_t incl = wave_incl_scan(pc);
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t o = incl - pc;
+  const uint32_t lbase = (uint32_t)lane << 4;
+  while (w) { const int b = __builtin_ctz(w); w &= w - 1; pos[o++] = (uint16_t)(lbase + (uint32_t)b); }
+  wave_lds_fence();
+  return total;
+}
+
+// pass 1: selected sizes -> out_sizes at the tile's row offset, plus the selected byte total of the tile
 __global__ __launch_bounds__(kBlock) void k_str_gather_sizes(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
                                                              const int32_t* __restrict__ sizes, int32_t* __restrict__ out_sizes,
-                                                             uint32_t* __restrict__ sel_tile_bytes, int64_t nctiles, int64_t out_cap) {
-  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+                                                             uint32_t* __restrict__ sel_tile_bytes, int64_t ntiles, int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][1024];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   uint16_t* pos = pos_sh[wib];
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
-    uint64_t w = bitmap[ct * 64 + lane];
-    const uint32_t c = (uint32_t)__popcll(w);
-    const uint32_t incl = wave_incl_scan(c);
-    const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t o = incl - c;
-    while (w) { const int b = __builtin_ctzll(w); w &= w - 1; pos[o++] = (uint16_t)((lane << 6) + b); }
-    wave_lds_fence();
-    const int64_t obase = (int64_t)prefix[ct * 4];
-    const int32_t* ts = sizes + ct * kCTile;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const uint32_t total = stage_tile_positions(bitmap, tile, pos, lane);
+    const int64_t obase = (int64_t)prefix[tile];
+    const int32_t* ts = sizes + tile * kTile;
     uint32_t bsum = 0;
     for (uint32_t k = lane; k < total; k += 64) {
       const int32_t sz = ts[pos[k]];
@@ -159,64 +242,81 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_sizes(const uint64_t* __r
       if (obase + k < out_cap) out_sizes[obase + k] = sz;
     }
     bsum = wave_sum(bsum);
-    if (lane == 0) sel_tile_bytes[ct] = bsum;
+    if (lane == 0) sel_tile_bytes[tile] = bsum;
     wave_lds_fence();
   }
 }
 void launch_str_gather_sizes(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const int32_t* sizes, int32_t* out_sizes,
                              uint32_t* sel_tile_bytes, int64_t nrows, int64_t out_cap) {
-  const int64_t nct = (nrows + kCTile - 1) / kCTile;
-  if (nct == 0) return;
-  hipLaunchKernelGGL(k_str_gather_sizes, dim3(grid_for(nct)), dim3(kBlock), 0, s, bitmap, prefix, sizes, out_sizes, sel_tile_bytes, nct, out_cap);
+  const int64_t nt = (nrows + kTile - 1) / kTile;
+  if (nt == 0) return;
+  hipLaunchKernelGGL(k_str_gather_sizes, dim3(grid_for(nt)), dim3(kBlock), 0, s, bitmap, prefix, sizes, out_sizes, sel_tile_bytes, nt, out_cap);
 }
 
-// bytes: walk the ctile 64 rows at a time carrying the source offset (all rows) and the destination offset
-// (selected rows); a selected lane copies its string
+// pass 2: bytes.  The tile's per-row source offsets (exclusive prefix of the sizes of ALL rows) go to LDS once
+// (16 coalesced size loads + 16 in-register scans); then 64 selected rows at a time: destination offsets by a
+// wave prefix-sum of the selected sizes, and every lane copies its own string.
 __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __restrict__ bitmap, const int32_t* __restrict__ sizes,
                                                              const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes,
                                                              const uint64_t* __restrict__ out_tile_off, uint8_t* __restrict__ out_bytes,
-                                                             int64_t nrows, int64_t nctiles, int64_t out_cap) {
+                                                             int64_t nrows, int64_t ntiles, int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][1024];
+  __shared__ uint32_t pre_sh[kWavesPerBlock][1024];
   const int lane = lane_id();
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  uint32_t* pre = pre_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
-    const uint64_t myw = bitmap[ct * 64 + lane];
-    if (__ballot(myw != 0) == 0) continue;           // nothing selected in this ctile
-    int64_t src = tile_off[ct * 4];
-    int64_t dst = (int64_t)out_tile_off[ct];
-    for (int j = 0; j < 64; j++) {
-      if (ct * kCTile + j * 64 >= nrows) break;      // wave-uniform: past the last row
-      const uint64_t w = __shfl(myw, j, 64);         // word j, broadcast
-      const int64_t i = ct * kCTile + j * 64 + lane;
-      if (w == 0) {
-        // still advance the source offset past these 64 rows; use the next tile offset when we cross a
-        // 1024-row boundary instead of summing sizes
-        if ((j & 15) == 15) { src = tile_off[ct * 4 + (j >> 4) + 1]; continue; }
-        const uint32_t c = i < nrows ? clamp_size(sizes[i]) : 0u;
-        src += (int64_t)wave_sum(c);
-        continue;
-      }
-      const uint32_t c = i < nrows ? clamp_size(sizes[i]) : 0u;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const uint32_t total = stage_tile_positions(bitmap, tile, pos, lane);
+    if (total == 0) { wave_lds_fence(); continue; }        // wave-uniform: late materialization of the arena
+    const int64_t base = tile * kTile;
+    int32_t sz[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int64_t i = base + j * 64 + lane; sz[j] = i < nrows ? sizes[i] : 0; }
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t c = clamp_size(sz[j]);
       const uint32_t incl = wave_incl_scan(c);
-      const bool sel = (w >> lane) & 1ull;
-      const uint32_t cs = sel ? c : 0u;
-      const uint32_t incls = wave_incl_scan(cs);
-      if (sel && cs) {
-        const uint8_t* sp = bytes + src + (int64_t)(incl - c);
-        const int64_t d0 = dst + (int64_t)(incls - cs);
-        if (d0 + cs <= out_cap) { uint8_t* dp = out_bytes + d0; for (uint32_t k = 0; k < cs; k++) dp[k] = sp[k]; }
-      }
-      src += (int64_t)__shfl(incl, 63, 64);
-      dst += (int64_t)__shfl(incls, 63, 64);
+      pre[j * 64 + lane] = run + incl - c;
+      run += __shfl(incl, 63, 64);
     }
+    wave_lds_fence();
+    const uint8_t* sb = bytes + tile_off[tile];
+    int64_t drun = (int64_t)out_tile_off[tile];
+    const int32_t* ts = sizes + base;
+    for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool valid = k < total;
+      const uint32_t p = valid ? pos[k] : 0u;
+      const uint32_t cs = valid ? clamp_size(ts[p]) : 0u;
+      const uint32_t incl = wave_incl_scan(cs);
+      if (cs) {
+        const uint8_t* sp = sb + pre[p];
+        const int64_t d0 = drun + (int64_t)(incl - cs);
+        if (d0 + cs <= out_cap) {
+          uint8_t* dp = out_bytes + d0;
+          uint32_t b = 0;
+          for (; b + 8 <= cs; b += 8) {                      // unaligned 8-byte moves stay inside this row's bytes
+            typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+            *(u64u*)(dp + b) = *(const u64u*)(sp + b);
+          }
+          for (; b < cs; b++) dp[b] = sp[b];
+        }
+      }
+      drun += (int64_t)__shfl(incl, 63, 64);
+    }
+    wave_lds_fence();
   }
 }
 void launch_str_gather_bytes(hipStream_t s, const uint64_t* bitmap, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes,
                              const uint64_t* out_tile_off, uint8_t* out_bytes, int64_t nrows, int64_t out_bytes_cap) {
-  const int64_t nct = (nrows + kCTile - 1) / kCTile;
-  if (nct == 0) return;
-  hipLaunchKernelGGL(k_str_gather_bytes, dim3(grid_for(nct)), dim3(kBlock), 0, s, bitmap, sizes, tile_off, bytes, out_tile_off, out_bytes, nrows,
-                     nct, out_bytes_cap);
+  const int64_t nt = (nrows + kTile - 1) / kTile;
+  if (nt == 0) return;
+  hipLaunchKernelGGL(k_str_gather_bytes, dim3(grid_for(nt)), dim3(kBlock), 0, s, bitmap, sizes, tile_off, bytes, out_tile_off, out_bytes, nrows,
+                     nt, out_bytes_cap);
 }
 
 }  // namespace dfdb

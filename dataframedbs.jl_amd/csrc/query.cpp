@@ -278,10 +278,10 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
 }
 
 // ---------------------------------------------------------------- materialize
-// selected string bytes per 4096-row ctile -> exclusive scan (output arena offsets); returns total
+// selected string bytes per 1024-row tile -> exclusive scan (output arena offsets); returns total
 static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_sizes_tmp, int32_t* out_sizes, int64_t cap, DevBuf& tile_off_out) {
   dfdb_ctx* ctx = q->t->ctx; hipStream_t s = ctx->stream;
-  const int64_t nct = ceil_div(q->t->nrows, kCTileRows);
+  const int64_t nct = ceil_div(q->t->nrows, kTileRows);
   DevBuf& tb = q->tmp_c; tb.ensure((size_t)(nct + 8) * 4);
   tile_off_out.ensure((size_t)(nct + 8) * 8);
   DevBuf& scratch = q->str_scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
