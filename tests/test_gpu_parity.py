@@ -187,15 +187,22 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
     cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": strs, "sm": strs_m,
             "iota": np.arange(1, n + 1, dtype=np.int64), "i16": rng.integers(-300, 300, n).astype(np.int16),
             "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.2),
-            "b": rng.integers(0, 2, n).astype(bool), "rnd": rng.integers(-2**62, 2**62, n).astype(np.int64)}
-    for bs in (65536, 1000):
-        p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"tb{bs}"))
+            "b": rng.integers(0, 2, n).astype(bool), "rnd": rng.integers(-2**62, 2**62, n).astype(np.int64),
+            # LZ4 corner cases for the device decoder: one endless RLE match (far beyond the 8-KB LDS ring), a period-24 pattern,
+            # long literal runs followed by far matches (offset > 8 KB)
+            "zeros": np.zeros(n, np.int64), "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n],
+            "far": np.concatenate([rng.integers(-2**62, 2**62, 3000), np.zeros(10, np.int64)] * (n // 3010 + 1))[:n].astype(np.int64)}
+    cols["far"][6000:9000] = cols["far"][0:3000]          # a 24-KB repeat at distance 48 KB
+    for bs, variant in ((65536, 1), (1000, 1), (65536, 0)):
+        ctx.set_option("lz4_variant", variant)
+        p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"tb{bs}_{variant}"))
         ov, dv = apply_stages(p, [])
         assert_same(p, ov, dv)
         ov, dv = apply_stages(p, [("pred", (ir.col(0) > 500_000) & (ir.col(2) == "sony"))])
         assert_same(p, ov, dv)
         ov, dv = apply_stages(p, [("pred", ir.ismissing(ir.col(6)) | ir.ismissing(ir.col(3)))])
         assert_same(p, ov, dv)
+    ctx.set_option("lz4_variant", 1)
 
 
 def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
