@@ -16,6 +16,7 @@ static int32_t guard(F&& f) noexcept {
   catch (...) { g_last_error = "unknown error"; return DFDB_ERR_DEVICE; }
 }
 #define NEED(p) do { if (!(p)) fail(DFDB_ERR_ARGUMENT, "null argument: " #p); } while (0)
+#define NEEDQ(q) do { NEED(q); if (!(q)->t) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); } while (0)
 
 namespace dfdb {
 LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n) : ctx(c), name(n) {
@@ -130,7 +131,14 @@ int32_t dfdb_table_new(dfdb_ctx* ctx, int64_t block_size, dfdb_table** out) {
     *out = t.release();
   });
 }
-int32_t dfdb_table_close(dfdb_table* t) { return guard([&] { if (t) { (void)hipStreamSynchronize(t->ctx->stream); delete t; } }); }
+int32_t dfdb_table_close(dfdb_table* t) {
+  return guard([&] {
+    if (!t) return;
+    (void)hipStreamSynchronize(t->ctx->stream);
+    for (dfdb_query* q : t->queries) q->t = nullptr;   // orphan live queries: they may be freed later, never used
+    delete t;
+  });
+}
 int32_t dfdb_table_ncols(dfdb_table* t, int32_t* n) { return guard([&] { NEED(t); NEED(n); *n = (int32_t)t->cols.size(); }); }
 int32_t dfdb_table_nrows(dfdb_table* t, int64_t* n) { return guard([&] { NEED(t); NEED(n); *n = t->nrows < 0 ? 0 : t->nrows; }); }
 int32_t dfdb_table_block_size(dfdb_table* t, int64_t* bs) { return guard([&] { NEED(t); NEED(bs); *bs = t->block_size; }); }
@@ -176,36 +184,47 @@ int32_t dfdb_query_new(dfdb_table* t, dfdb_query** out) {
       auto n = std::make_unique<Node>(); n->op = DFIR_COL; n->col = (int)i; n->dtype = t->cols[i].dtype;
       q->proj.push_back(ProjCol{t->cols[i].name, std::move(n)});
     }
+    t->queries.push_back(q.get());
     *out = q.release();
   });
 }
-int32_t dfdb_query_free(dfdb_query* q) { return guard([&] { if (q) { (void)hipStreamSynchronize(q->t->ctx->stream); delete q; } }); }
+int32_t dfdb_query_free(dfdb_query* q) {
+  return guard([&] {
+    if (!q) return;
+    if (q->t) {
+      (void)hipStreamSynchronize(q->t->ctx->stream);
+      auto& v = q->t->queries;
+      for (size_t i = 0; i < v.size(); i++) if (v[i] == q) { v[i] = v.back(); v.pop_back(); break; }
+    } else (void)hipDeviceSynchronize();
+    delete q;
+  });
+}
 int32_t dfdb_query_add_range(dfdb_query* q, int64_t start, int64_t step, int64_t stop) {
-  return guard([&] { NEED(q); Stage s; s.kind = ST_RANGE; s.start = start; s.step = step; s.stop = stop; query_add_stage(q, std::move(s)); });
+  return guard([&] { NEEDQ(q); Stage s; s.kind = ST_RANGE; s.start = start; s.step = step; s.stop = stop; query_add_stage(q, std::move(s)); });
 }
 int32_t dfdb_query_add_indices(dfdb_query* q, const int64_t* idx, int64_t n) {
   return guard([&] {
-    NEED(q); if (n > 0) NEED(idx);
+    NEEDQ(q); if (n > 0) NEED(idx);
     if (n < 0) fail(DFDB_ERR_ARGUMENT, "negative index count");
     Stage s; s.kind = ST_INDICES; s.idx.assign(idx, idx + n);
     query_add_stage(q, std::move(s));
   });
 }
 int32_t dfdb_query_add_integer(dfdb_query* q, int64_t i) {
-  return guard([&] { NEED(q); Stage s; s.kind = ST_INTEGER; s.idx = {i}; query_add_stage(q, std::move(s)); });
+  return guard([&] { NEEDQ(q); Stage s; s.kind = ST_INTEGER; s.idx = {i}; query_add_stage(q, std::move(s)); });
 }
 int32_t dfdb_query_add_predicate(dfdb_query* q, const uint8_t* ir, size_t len) {
   return guard([&] {
-    NEED(q); NEED(ir);
+    NEEDQ(q); NEED(ir);
     Stage s; s.kind = ST_PRED; s.pred = parse_ir(*q->t, ir, len);
     if (s.pred->dtype != DFDB_BOOL) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Function for selection must have Bool result type");   // selection.jl:52-55
     query_add_stage(q, std::move(s));
   });
 }
-int32_t dfdb_query_nstages(dfdb_query* q, int32_t* n) { return guard([&] { NEED(q); NEED(n); *n = (int32_t)q->stages.size(); }); }
+int32_t dfdb_query_nstages(dfdb_query* q, int32_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = (int32_t)q->stages.size(); }); }
 int32_t dfdb_query_set_projection(dfdb_query* q, int32_t n, const char* const* names, const uint8_t* const* irs, const size_t* lens) {
   return guard([&] {
-    NEED(q); if (n > 0) { NEED(names); NEED(irs); NEED(lens); }
+    NEEDQ(q); if (n > 0) { NEED(names); NEED(irs); NEED(lens); }
     std::vector<ProjCol> np;
     for (int32_t i = 0; i < n; i++) {
       for (int32_t j = 0; j < i; j++) if (std::string(names[j]) == names[i]) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", names[i]);   // projection.jl:25-28
@@ -214,10 +233,10 @@ int32_t dfdb_query_set_projection(dfdb_query* q, int32_t n, const char* const* n
     q->proj = std::move(np);
   });
 }
-int32_t dfdb_query_ncols(dfdb_query* q, int32_t* n) { return guard([&] { NEED(q); NEED(n); *n = (int32_t)q->proj.size(); }); }
+int32_t dfdb_query_ncols(dfdb_query* q, int32_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = (int32_t)q->proj.size(); }); }
 int32_t dfdb_query_coltype(dfdb_query* q, int32_t i, int32_t* dtype) {
   return guard([&] {
-    NEED(q); NEED(dtype);
+    NEEDQ(q); NEED(dtype);
     if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
     *dtype = q->proj[(size_t)i].expr->dtype;
   });
@@ -227,32 +246,32 @@ int32_t dfdb_expr_result_type(dfdb_table* t, const uint8_t* ir, size_t len, int3
 }
 int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivors_before) {
   return guard([&] {
-    NEED(q);
+    NEEDQ(q);
     if (stage < 0 || (size_t)stage >= q->stages.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: stage %d", stage);
     q->stages[(size_t)stage].stage_base = survivors_before; q->executed_stages = -1; q->count = -1;
   });
 }
-int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEED(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
+int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
 
 // ------------------------------------------------------------------ execution
-int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEED(q); query_execute(q, -1); }); }
-int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEED(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }); }
-int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEED(q); NEED(n); *n = query_count(q, -1); }); }
+int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQ(q); query_execute(q, -1); }); }
+int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }); }
+int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = query_count(q, -1); }); }
 int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind) {
   return guard([&] {
-    NEED(q); NEED(out);
+    NEEDQ(q); NEED(out);
     if (memkind != DFDB_MEM_DEVICE) { *out = query_count(q, -1); return; }
     if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
     const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
     HIP_CHECK(hipMemcpyAsync(out, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
   });
 }
-int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEED(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
+int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEEDQ(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
 int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
-  return guard([&] { NEED(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
+  return guard([&] { NEEDQ(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
 }
-int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEED(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
-int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEED(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
-int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEED(q); query_aggregate(q, op, i, out_i, out_f); }); }
+int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEEDQ(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
+int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEEDQ(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
+int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQ(q); query_aggregate(q, op, i, out_i, out_f); }); }
 
 }  // extern "C"

@@ -40,6 +40,7 @@ struct ProjCol { std::string name; NodePtr expr; };
 
 }  // namespace dfdb
 
+struct dfdb_query;
 struct dfdb_table {
   dfdb_ctx* ctx = nullptr;
   std::string path;            // empty for in-memory tables
@@ -49,6 +50,7 @@ struct dfdb_table {
   int64_t nrows = -1;          // rows resident (all resident columns agree); -1 = nothing resident yet
   int64_t row_base = 0;        // global 0-based row of local row 0 (block-range shard)
   int64_t block_first = 0;     // first resident block
+  std::vector<dfdb_query*> queries;   // live queries over this table (orphaned, not dangling, when the table closes)
 };
 
 struct dfdb_query {

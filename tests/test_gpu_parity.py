@@ -292,3 +292,16 @@ def test_fused_scan_compact(oracle, dfdb_mod, ctx, n, dtype):
         if cnt:
             assert np.array_equal(out2.cpu().numpy(), np.arange(1, n + 1))
     ctx.set_option("fused", 0)
+
+
+def test_query_outlives_closed_table(oracle, dfdb_mod, ctx):
+    """Handles may be released in any order: a query whose table was closed is orphaned (errors, never dangles)."""
+    from dfdb import ir
+    t = dfdb_mod.DFTable.from_columns({"a": np.arange(100, dtype=np.int64)})
+    v = t[("a", lambda a: a > 50), dfdb_mod.ALL]
+    q = v._query()
+    assert q.count() == 49
+    t.close()
+    with pytest.raises(ValueError, match="closed"):
+        q.reset(); q.count()
+    del q, v
