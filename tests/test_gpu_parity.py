@@ -305,3 +305,70 @@ def test_query_outlives_closed_table(oracle, dfdb_mod, ctx):
     with pytest.raises(ValueError, match="closed"):
         q.reset(); q.count()
     del q, v
+
+
+# ------------------------------------------------------------------ block-range shards on one GPU
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_range_shards_concatenate_to_table_order(oracle, dfdb_mod, ctx, tmp_path, world):
+    """Each 'rank' loads only its contiguous block range of every column (dfdb_table_load), leading range stages and row
+    numbers stay global through row_base, a range stage after a predicate gets the survivors of lower ranks through
+    dfdb_query_count_prefix / dfdb_query_set_stage_base; rank-order concatenation must equal the oracle's single table."""
+    import ctypes as C
+    from dfdb import ir, _native as N
+    from dfdb.sharding import block_range
+    n, bs = 300_007, 4096
+    sizes, data = oracle.gen_str(col_seed(2), 0, n)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": oracle.flat_to_strings(sizes, data)}
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    nblocks = -(-n // bs)
+    shards = []
+    for r in range(world):
+        b0, b1 = block_range(nblocks, r, world)
+        t = dfdb_mod.open_table(path, load=False)
+        t.load(None, b0, b1)
+        shards.append(t)
+    a, x, s = ir.col(0), ir.col(1), ir.col(2)
+    queries = {
+        "pred": [("pred", (a > 700_000) & (s != "sony"))],
+        "lead_range": [("range", 5, 7, 250_000), ("pred", x < 1000.0)],
+        "range_after_pred": [("pred", a > 500_000), ("range", 11, 3, 90_000)],
+        "two_exchanges": [("pred", a % 2 == 0), ("range", 10, 1, 100_000), ("pred", s == "dell"), ("idx", [1, 5, 400, 4999, 10**9])],
+        "count_all": [],
+    }
+    for name, stages in queries.items():
+        ov = ot.view()
+        views = [dfdb_mod.DFView(t) for t in shards]
+        for st in stages:
+            if st[0] == "pred":
+                ov.add_predicate(st[1].to_ir()); views = [dfdb_mod.selection(v, st[1]) for v in views]
+            elif st[0] == "range":
+                ov.add_range(st[1], st[2], st[3]); views = [dfdb_mod.selection(v, dfdb_mod.jr(st[1], st[2], st[3])) for v in views]
+            else:
+                ov.add_indices(st[1]); views = [dfdb_mod.selection(v, list(st[1])) for v in views]
+        qs = [v._query() for v in views]
+        for k, st in enumerate(stages):                      # the all-gather + exclusive scan, done by hand
+            if k == 0 or st[0] == "pred":
+                continue
+            counts = []
+            for q in qs:
+                c = C.c_int64()
+                N.check(N.load().dfdb_query_count_prefix(q._h, k, C.byref(c)))
+                counts.append(c.value)
+            for r, q in enumerate(qs):
+                N.check(N.load().dfdb_query_set_stage_base(q._h, k, sum(counts[:r])))
+        want_idx = ov.select_indices()
+        got_idx = np.concatenate([q.indices() for q in qs])
+        assert np.array_equal(got_idx, want_idx), name
+        assert sum(q.count() for q in qs) == ov.nrow()
+        want = ov.materialize()
+        got = [q.materialize() for q in qs]
+        assert np.array_equal(np.concatenate([g[0] for g in got]), want[0]), name
+        assert np.array_equal(np.concatenate([g[1] for g in got]).view(np.uint64), want[1].view(np.uint64)), name
+        assert np.array_equal(np.concatenate([g[2][0] for g in got]), want[2][0]) and np.array_equal(np.concatenate([g[2][1] for g in got]), want[2][1]), name
+    # sum(x) over shards: one all-reduce of a scalar; tolerance n*eps*sum|x| (DESIGN.md §5)
+    tot = sum(v[dfdb_mod.ALL, "x"].sum() for v in [dfdb_mod.DFView(t) for t in shards])
+    assert abs(tot - float(np.sum(cols["x"]))) <= n * np.finfo(float).eps * float(np.abs(cols["x"]).sum())
