@@ -57,6 +57,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
     const int64_t base = tile * kTile;
     const T* p = col + base + lane;
     uint64_t myword = 0;
+    uint64_t existing = ~0ull;
+    if (AND_EXISTING) {   // late materialization: a tile no earlier stage left a survivor in is never read
+      existing = lane < kWordsPerTile ? bitmap[tile * kWordsPerTile + lane] : 0ull;
+      if (__ballot(existing != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+    }
     if (base + kTile <= nrows) {
       T v[kWordsPerTile];
 #pragma unroll
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
         if (lane == j) myword = m;
       }
     }
-    if (AND_EXISTING) { if (lane < kWordsPerTile) myword &= bitmap[tile * kWordsPerTile + lane]; }
+    if (AND_EXISTING) myword &= existing;
     const uint32_t cnt = tile_popcount(myword, lane);
     if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = myword;   // one 128-B line
     if (lane == 0) tile_counts[tile] = cnt;
@@ -166,6 +171,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kTile;
+    uint64_t existing = ~0ull;
+    if (AND_EXISTING) {
+      existing = lane < kWordsPerTile ? bitmap[tile * kWordsPerTile + lane] : 0ull;
+      if (__ballot(existing != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+    }
     uint64_t acc = terms.combine_or ? 0ull : ~0ull;
     for (int t = 0; t < terms.n; t++) {
       const ScanTerm& tm = terms.t[t];
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       acc = terms.combine_or ? (acc | w) : (acc & w);
     }
     // rows past nrows never set: every term's tail ballot is false (AND) — for OR also false
-    if (AND_EXISTING) { if (lane < kWordsPerTile) acc &= bitmap[tile * kWordsPerTile + lane]; }
+    if (AND_EXISTING) acc &= existing;
     const uint32_t cnt = tile_popcount(acc, lane);
     if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = acc;
     if (lane == 0) tile_counts[tile] = cnt;

@@ -80,6 +80,11 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const int plen = pat.len;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    uint64_t existing = ~0ull;
+    if (AND_EXISTING) {
+      existing = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
+      if (__ballot(existing != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+    }
     int64_t run = tile_off[tile];
     const int64_t base = tile * kTile;
     int32_t sz[16];
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
       const uint64_t m = __ballot(r);
       if (lane == j) myword = m;
     }
-    if (AND_EXISTING) { if (lane < 16) myword &= bitmap[tile * 16 + lane]; }
+    if (AND_EXISTING) myword &= existing;
     uint32_t cnt = lane < 16 ? (uint32_t)__popcll(myword) : 0u;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
@@ -133,6 +138,11 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
   const uint64_t mask = plen >= 8 ? ~0ull : ((1ull << (8 * plen)) - 1ull);
   const uint64_t want = patw & mask;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    uint64_t existing = ~0ull;
+    if (AND_EXISTING) {
+      existing = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
+      if (__ballot(existing != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+    }
     const uint8_t* tb = bytes + tile_off[tile];
     const int64_t base = tile * kTile;
     int32_t sz[16];
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
         if (lane == h * 8 + j) myword = m;
       }
     }
-    if (AND_EXISTING) { if (lane < 16) myword &= bitmap[tile * 16 + lane]; }
+    if (AND_EXISTING) myword &= existing;
     uint32_t cnt = lane < 16 ? (uint32_t)__popcll(myword) : 0u;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);

@@ -98,7 +98,12 @@ def main():
     cx = v[dfdb.ALL, "x"]
     ks, wall = timed(ctx, lambda: (q.execute(), cx.sum()), args.reps)
     print(json.dumps({"config": "2-sum", "kernels_ms": ks, "wall_ms": wall * 1e3}))
-    del out, q, v, cx
+    # leading range stage then predicate: t[1:100000, :][x -> x > c, :] -- later stages skip tiles without survivors
+    vh = t[dfdb.jr(1, 100_000), dfdb.ALL][("x", lambda x: x > 899_999), dfdb.ALL]
+    qh = vh._query()
+    ks, wall = timed(ctx, lambda: (qh.reset(), qh.execute()), args.reps)
+    print(json.dumps({"config": "2-head", "rows": n, "selected": qh.count(), "kernels_ms": ks, "wall_ms": wall * 1e3}))
+    del out, q, v, cx, qh, vh
     t.close()
 
     # ---- config 3: (a > 683771) & (x < 632.456), project [b, x]
