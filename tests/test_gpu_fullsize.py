@@ -1,0 +1,142 @@
+"""GPU: BASELINE.json's full sizes, checked through size-independent properties (the oracle cannot finish 1e9 rows in
+seconds): sortedness, count == popcount(bitmap) == torch's own count, every gathered value satisfies the predicate,
+idempotence, and bit-exact agreement with the oracle on SAMPLED 65 536-row blocks of the same seeded column."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x9E3779B97F4A7C15
+THR = 899_999
+
+
+def _dev_outcol(N, tensor, bytes_t=None):
+    o = N.OutCol()
+    o.data, o.memkind = tensor.data_ptr(), N.MEM_DEVICE
+    if bytes_t is not None:
+        o.bytes, o.bytes_cap = bytes_t.data_ptr(), bytes_t.numel()
+    return o
+
+
+@pytest.mark.parametrize("n", [1_000_000_000])
+def test_config2_full_size_properties(oracle, dfdb_mod, ctx, n):
+    import torch
+    from dfdb import _native as N
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30e9:
+        pytest.skip("needs ~20 GB of HBM")
+    dev = torch.device("cuda", 0)
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("x", dfdb_mod.GEN_I64_MOD1M, SEED, n)
+    v = t[("x", lambda x: x > THR), dfdb_mod.ALL]
+    q = v._query()
+    nsel = q.count()
+    assert abs(nsel / n - 0.1) < 1e-3
+    idx = torch.empty(nsel, dtype=torch.int64, device=dev)
+    assert q.indices_device(idx.data_ptr(), nsel, want_count=True) == nsel
+    torch.cuda.synchronize()
+    # sortedness / range
+    assert bool((idx[1:] > idx[:-1]).all()) and int(idx[0]) >= 1 and int(idx[-1]) <= n
+    # the whole column, materialized to the device through the ABI, is torch's third opinion
+    full = torch.empty(n, dtype=torch.int64, device=dev)
+    qa = dfdb_mod.DFView(t)._query()
+    outs = (N.OutCol * 1)(_dev_outcol(N, full))
+    N.check(N.load().dfdb_materialize(qa._h, outs, 1))
+    torch.cuda.synchronize()
+    mask = full > THR
+    assert int(mask.sum()) == nsel
+    assert bool(mask[idx - 1].all())                                   # every selected row satisfies the predicate
+    assert int(idx.sum()) == int((torch.nonzero(mask).flatten() + 1).sum())   # checksum of the index list
+    del mask
+    # gathered values == column[idx]
+    xs = torch.empty(nsel, dtype=torch.int64, device=dev)
+    outs = (N.OutCol * 1)(_dev_outcol(N, xs))
+    N.check(N.load().dfdb_materialize(q._h, outs, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(xs, full[idx - 1])
+    # bitmap popcount and sampled blocks against the oracle's generator + predicate
+    bm = q.bitmap()
+    assert int(np.unpackbits(bm.view(np.uint8)).sum()) == nsel
+    rng = np.random.default_rng(1)
+    nblocks = -(-n // 65536)
+    for b in [0, 1, nblocks - 1, nblocks - 2] + rng.integers(0, nblocks, 12).tolist():
+        r0 = b * 65536
+        rows = min(65536, n - r0)
+        want = oracle.gen_i64(SEED, r0, rows) > THR
+        got = np.unpackbits(bm[r0 // 64:(r0 + rows + 63) // 64].view(np.uint8), bitorder="little")[:rows].astype(bool)
+        assert np.array_equal(got, want), f"block {b}"
+        lo, hi = int(torch.searchsorted(idx, r0 + 1)), int(torch.searchsorted(idx, r0 + rows + 1))
+        assert np.array_equal(idx[lo:hi].cpu().numpy(), np.nonzero(want)[0] + r0 + 1), f"block {b}"
+    # idempotence: a fresh evaluation gives the same bytes
+    idx2 = torch.empty_like(idx)
+    q.reset()
+    q.indices_device(idx2.data_ptr(), nsel)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2)
+    # sum over the filtered column == torch's exact integer sum
+    assert v[dfdb_mod.ALL, "x"].sum() == int(xs.sum())
+    t.close()
+
+
+def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
+    """3-column conjunction + projection and string equality + materialize at 2e8 / 1e8 rows."""
+    import torch
+    from dfdb import _native as N
+    dev = torch.device("cuda", 0)
+
+    def seed(k):
+        return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+    n = 200_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(0), n)
+    t.add_generated("b", dfdb_mod.GEN_I64_MOD1M, seed(1), n)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, seed(2), n)
+    v = t[(t.a > 683_771) & (t.x < 632.456), ["b", "x"]]
+    q = v._query()
+    nsel = q.count()
+    assert abs(nsel / n - 0.1) < 2e-3
+    ob = torch.empty(nsel, dtype=torch.int64, device=dev)
+    ox = torch.empty(nsel, dtype=torch.float64, device=dev)
+    outs = (N.OutCol * 2)(_dev_outcol(N, ob), _dev_outcol(N, ox))
+    N.check(N.load().dfdb_materialize(q._h, outs, 2))
+    torch.cuda.synchronize()
+    assert bool((ox < 632.456).all())
+    idx = q.indices()
+    for r0 in (0, 65536 * 1000, n - 65536):                             # sampled blocks vs the oracle's generators
+        a = oracle.gen_i64(seed(0), r0, 65536); b = oracle.gen_i64(seed(1), r0, 65536); x = oracle.gen_f64(seed(2), r0, 65536)
+        m = (a > 683_771) & (x < 632.456)
+        lo, hi = np.searchsorted(idx, r0 + 1), np.searchsorted(idx, r0 + 65536 + 1)
+        assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
+        assert np.array_equal(ob[lo:hi].cpu().numpy(), b[m]) and np.array_equal(ox[lo:hi].cpu().numpy().view(np.uint64), x[m].view(np.uint64))
+    t.close()
+
+    n = 100_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, seed(0), n)
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(1), n)
+    v = t[t.s == "sony", dfdb_mod.ALL]
+    q = v._query()
+    nsel = q.count()
+    assert abs(nsel / n - 0.1) < 2e-3
+    nb = C.c_int64()
+    N.check(N.load().dfdb_result_string_bytes(q._h, 0, C.byref(nb)))
+    assert nb.value == 4 * nsel                                          # every selected string is "sony"
+    osz = torch.empty(nsel, dtype=torch.int32, device=dev)
+    oby = torch.empty(nb.value + 64, dtype=torch.uint8, device=dev)
+    oa = torch.empty(nsel, dtype=torch.int64, device=dev)
+    outs = (N.OutCol * 2)(_dev_outcol(N, osz, oby), _dev_outcol(N, oa))
+    N.check(N.load().dfdb_materialize(q._h, outs, 2))
+    torch.cuda.synchronize()
+    assert bool((osz == 4).all())
+    assert bytes(oby[:nb.value].view(nsel, 4)[:: max(1, nsel // 1000)].cpu().numpy().tobytes()) == b"sony" * len(range(0, nsel, max(1, nsel // 1000)))
+    assert bool((oby[:nb.value].view(nsel, 4) == torch.tensor(list(b"sony"), dtype=torch.uint8, device=dev)).all())
+    idx = q.indices()
+    for r0 in (0, 65536 * 700, n - 65536):
+        sz, by = oracle.gen_str(seed(0), r0, 65536)
+        strs = oracle.flat_to_strings(sz, by)
+        m = np.array([s == "sony" for s in strs])
+        lo, hi = np.searchsorted(idx, r0 + 1), np.searchsorted(idx, r0 + 65536 + 1)
+        assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
+        assert np.array_equal(oa[lo:hi].cpu().numpy(), oracle.gen_i64(seed(1), r0, 65536)[m])
+    t.close()
