@@ -43,12 +43,12 @@ def cpu_baseline(rows: int, repeats: int):
     best = None
     nsel = 0
     for _ in range(repeats):
-        nsel, sec, _ = v.bench_scan(0)
+        nsel, sec, _ = v.bench_scan(rows // 5)           # indices are written, like the GPU job
         best = sec if best is None else min(best, sec)
     st = t.column_stats(0)
     return dict(value=rows / best, unit="rows/s", cores=1, kind="port",
                 sample=f"{rows} rows ({st['blocks']} LZ4 blocks of 65536, ratio {st['uncompressed'] / st['compressed']:.2f}), "
-                       f"best of {repeats}, {nsel} selected; count-only pass of select_indices (decode + mask + index)")
+                       f"best of {repeats}, {nsel} selected; LZ4 decode -> mask -> LogicalIndex -> 1-based Int64 row indices written")
 
 
 def main():
@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
+    ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--fused", action="store_true", help="one-pass k_scan_compact (decoupled look-back) instead of K1 + count scan + K2; "
                     "measured 8-10 %% slower than the three-kernel pipeline on MI355X (DESIGN.md §4), kept as an option")
     args = ap.parse_args()
@@ -70,15 +72,33 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+    if args.all_on_device0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
+
+    def all_reduce(tensor, op=None):
+        """the only exchange of a step: 8 bytes.  RCCL reduces the device tensor in place on the engine's stream."""
+        op = op or dist.ReduceOp.SUM
+        if args.backend == "nccl":
+            dist.all_reduce(tensor, op=op)
+        else:                                             # gloo functional path: through the host
+            h = tensor.cpu()
+            dist.all_reduce(h, op=op)
+            tensor.copy_(h)
 
     import dfdb
     from dfdb import ir
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = dfdb.Context(local, stream=stream)
+    # ONE stream for the engine's kernels, torch's tensors and the collective: a non-default torch stream made current
+    # (the default stream's handle is 0, which the C ABI reads as "create a private stream")
+    stream_obj = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream_obj)
+    ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
     info = ctx.device_info()
 
     rows = args.rows
@@ -99,7 +119,7 @@ def main():
         q.indices_device(out.data_ptr(), cap)          # K1 scan -> bitmap + tile counts, count scan, K2 compaction
         q.count_device(cnt.data_ptr())                 # (--fused: all three in one launch)
         if world > 1:
-            dist.all_reduce(cnt)                       # the only exchange: 8 bytes
+            all_reduce(cnt)
 
     for _ in range(args.warmup):
         step()
@@ -115,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        all_reduce(el, dist.ReduceOp.MAX)
         elapsed = float(el.item())
     total_sel = int(cnt.item())
 
