@@ -169,7 +169,225 @@ __global__ __launch_bounds__(kBlock) void k_lz4_decode_lds(const uint8_t* __rest
   }
 }
 
-static int g_lz4_variant = 0;   // v1 wins once there are enough blocks to fill the CUs (26 vs 18 GB/s at 3815 blocks): v2 trades occupancy for latency
+
+// ---- K7 v3: register-window parse + one LDS round trip per sequence ------------------------------------------
+// v1 measured 26 GB/s on 8-byte integer columns (one sequence per ~8 output bytes): ~2800 cycles per sequence, all of
+// it dependent L2/HBM round trips (token, literals, offset, a fence, the match source).  v3 keeps the whole
+// per-sequence dependency chain on chip:
+//   * the compressed stream is staged through a 4 KB per-wave LDS buffer in 2 KB chunks; the NEXT chunk is always in
+//     flight in registers (global loads issued one chunk ahead), so staging never waits on memory in steady state;
+//   * the parser reads tokens / lengths / offsets from a 512-byte REGISTER window (8 bytes per lane, refreshed from the
+//     staging buffer every ~400 consumed bytes) with v_readlane: scalar work, no memory latency;
+//   * the last 8 KB of output live in a per-wave LDS ring.  For a sequence with literals + match <= 64 bytes every
+//     lane produces ONE output byte with ONE ds_read_u8 whose address points either into the staging buffer (a literal,
+//     or a match byte that falls inside this sequence's own literals) or into the ring (earlier output), then ONE
+//     ds_write_b8.  The LDS queue is in order per wave, so consecutive sequences need no fence;
+//   * the ring is flushed to HBM in coalesced dword stores every 2 KB; nothing in the chain waits for a store.
+// Longer runs take the same steps 64 bytes at a time; a match that reaches further back than the ring is copied from
+// HBM behind a fence (rare on columnar data; costs what every v1 sequence cost).
+constexpr int kStage = 4096;      // two 2 KB chunks
+constexpr int kChunk = 2048;
+constexpr int kRing = 8192;
+constexpr int kV3Waves = 4;
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+__global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                  const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage_sh[kV3Waves][kStage];
+  __shared__ __attribute__((aligned(16))) uint8_t ring_sh[kV3Waves][kRing];
+  const uint32_t lane = (uint32_t)lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* stage = stage_sh[wib];
+  uint8_t* ring = ring_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kV3Waves + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kV3Waves;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    const uint32_t in_len = (uint32_t)blk.src_len, out_len = (uint32_t)blk.dst_len;
+    uint32_t ip = 0, op = 0, flushed = 0;
+    uint32_t cb = 0;                   // staged: input bytes [cb, cb + 4096); invariant cb <= ip < cb + 2048
+    uint32_t wbase = 0, wlo = 0, whi = 0;
+    int err = 0;
+    uint64_t f[4];                     // the chunk in flight: input bytes [cb + 4096, cb + 6144), 32 per lane
+
+    auto chunk_load = [&](uint32_t pos) {          // global -> registers (bytes past in_len are never consumed)
+      const uint32_t g = pos + lane * 32;
+#pragma unroll
+      for (int i = 0; i < 4; i++) f[i] = g + 8 * i < in_len ? ld_u64_unaligned(in + g + 8 * i) : 0ull;
+    };
+    auto chunk_store = [&](uint32_t pos) {         // registers -> staging slot of input position pos (a multiple of 2048)
+      uint64_t* d = (uint64_t*)(stage + (pos & (kStage - 1)) + lane * 32);
+#pragma unroll
+      for (int i = 0; i < 4; i++) d[i] = f[i];
+    };
+    auto window_load = [&](uint32_t pos8) {        // 512 input bytes from pos8 (multiple of 8), 8 per lane
+      wbase = pos8;
+      const uint2 w = *(const uint2*)(stage + ((pos8 + lane * 8) & (kStage - 1)));
+      wlo = w.x; whi = w.y;
+    };
+    // make input bytes [p, p + 72) parseable: advance the staging buffer and refresh the register window as needed
+    auto ensure = [&](uint32_t p) {
+      while (p >= cb + kChunk) {                   // p left the first staged chunk: recycle its slot for the chunk in flight
+        chunk_store(cb + kStage);                  // (waits for those loads: issued a whole chunk ago)
+        cb += kChunk;
+        chunk_load(cb + kStage);
+        if (wbase < cb) { wbase = 0xffffffffu; }   // window no longer backed: force a reload below
+      }
+      if (p < wbase || p - wbase > 432u) window_load(p & ~7u);
+    };
+    // the same without recycling staging slots: used while the literals of the current sequence still sit in the staging
+    // buffer (every position a <= 64-literal sequence can touch is < sequence start + 400 < cb + 4096)
+    auto window_only = [&](uint32_t p) {
+      if (p < wbase || p - wbase > 432u) window_load(p & ~7u);
+    };
+    // 8 input bytes at p (wave-uniform), little-endian; requires wbase <= p, p - wbase <= 496
+    auto fetch64 = [&](uint32_t p) -> uint64_t {
+      const uint32_t d = p - wbase, q = d >> 3, sh = (d & 7u) * 8u;
+      const uint64_t lo = (uint64_t)rl(whi, q) << 32 | rl(wlo, q);
+      const uint64_t hi = (uint64_t)rl(whi, q + 1) << 32 | rl(wlo, q + 1);
+      return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    };
+    auto byte_at = [&](uint32_t p) -> uint32_t {
+      const uint32_t d = p - wbase, q = d >> 3, sh = (d & 7u) * 8u;
+      const uint64_t lo = (uint64_t)rl(whi, q) << 32 | rl(wlo, q);
+      return (uint32_t)(lo >> sh) & 255u;
+    };
+    // ring -> HBM, bytes [flushed, upto)
+    auto flush_to = [&](uint32_t upto) {
+      if ((flushed & 3u) == 0 && (((uintptr_t)out) & 3u) == 0) {
+        const uint32_t n4 = (upto - flushed) & ~3u;
+        for (uint32_t o = lane * 4; o < n4; o += 256) {
+          const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1)));
+          *(uint32_t*)(out + flushed + o) = v;
+        }
+        flushed += n4;
+      }
+      for (uint32_t o = flushed + lane; o < upto; o += 64) out[o] = ring[o & (kRing - 1)];
+      flushed = upto;
+    };
+
+    // prime the staging buffer: chunks 0 and 1 in LDS, chunk 2 in flight
+    chunk_load(0); chunk_store(0);
+    chunk_load(kChunk); chunk_store(kChunk);
+    chunk_load(kStage);
+    window_load(0);
+
+    while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
+      ensure(ip);
+      const uint64_t t64 = fetch64(ip);
+      const uint32_t token = (uint32_t)t64 & 255u;
+      ip++;
+      uint32_t lit = token >> 4;
+      if (lit == 15) {
+        uint32_t bb;
+        do { if (ip >= in_len) { err = 1; break; } ensure(ip); bb = byte_at(ip); ip++; lit += bb; } while (bb == 255);
+        if (err) break;
+      }
+      if (lit > in_len - ip || lit > out_len - op) { err = 2; break; }
+      const uint32_t lit_ip = ip;                  // the literals are input bytes [lit_ip, lit_ip + lit)
+      const bool last = ip + lit >= in_len;        // the last sequence is literals only
+      uint32_t offset = 0, ml = 0;
+      if (!last) {
+        uint32_t mp = ip + lit;                    // position of the 2-byte offset
+        if (mp + 2 > in_len) { err = 3; break; }
+        if (lit <= 5) offset = (uint32_t)(t64 >> (8u * (1u + lit))) & 0xffffu;   // still inside the 8 bytes already fetched
+        else if (lit <= 64) { window_only(mp); offset = (uint32_t)fetch64(mp) & 0xffffu; }
+        mp += 2;
+        ml = token & 15u;
+        if (lit <= 64) {
+          if (ml == 15) {
+            uint32_t bb;
+            do { if (mp >= in_len) { err = 4; break; } window_only(mp); bb = byte_at(mp); mp++; ml += bb; } while (bb == 255);
+            if (err) break;
+          }
+          ml += 4;
+          if (offset == 0 || offset > op + lit || ml > out_len - op - lit) { err = 5; break; }
+        }
+        ip = mp;                                   // (for lit > 64 the match fields are parsed after the literal copy)
+      } else ip += lit;
+
+      if (lit + ml <= 64u && lit <= 64u && offset + 64u <= (uint32_t)kRing) {
+        // ---- fast path: the whole sequence is <= 64 bytes; lane k makes output byte op + k
+        const uint32_t total = lit + ml, mbase = op + lit;
+        if (total) {
+          const uint32_t k = lane;
+          uint32_t j = k - lit;                                          // index inside the match
+          if (offset < 64u && offset != 0) j = j % offset;               // periodic source (overlapping match)
+          const uint32_t s = mbase - offset + j;                         // absolute output position of the source byte
+          const bool from_in = k < lit || s >= op;                       // a literal, or a match byte inside this sequence's literals
+          const uint32_t in_pos = k < lit ? lit_ip + k : lit_ip + (s - op);
+          const uint8_t* a = from_in ? stage + (in_pos & (kStage - 1)) : ring + (s & (kRing - 1));
+          if (k < total) { const uint8_t v = *a; ring[(op + k) & (kRing - 1)] = v; }
+          op += total;
+        }
+      } else {
+        // ---- general path: 64 bytes at a time
+        uint32_t rem = lit, lp = lit_ip;
+        while (rem) {                                                    // literals: staging buffer -> ring
+          ensure(lp);
+          const uint32_t n = rem < 64u ? rem : 64u;
+          if (lane < n) ring[(op + lane) & (kRing - 1)] = stage[(lp + lane) & (kStage - 1)];
+          lp += n; op += n; rem -= n;
+          if (op - flushed >= 2048u) flush_to(op & ~255u);
+        }
+        if (!last) {
+          if (lit > 64) {                                                // match fields of a long-literal sequence
+            uint32_t mp = lp;
+            ensure(mp); offset = (uint32_t)fetch64(mp) & 0xffffu; mp += 2;
+            ml = token & 15u;
+            if (ml == 15) {
+              uint32_t bb;
+              do { if (mp >= in_len) { err = 4; break; } ensure(mp); bb = byte_at(mp); mp++; ml += bb; } while (bb == 255);
+              if (err) break;
+            }
+            ml += 4;
+            if (offset == 0 || offset > op || ml > out_len - op) { err = 5; break; }
+            ip = mp;
+          }
+          if (offset + 64u <= (uint32_t)kRing) {                         // source inside the ring
+            uint32_t done = 0;
+            while (done < ml) {
+              const uint32_t n = ml - done < 64u ? ml - done : 64u;
+              const uint32_t j = offset < 64u ? lane % offset : lane;    // chunk start - offset + (i mod offset): always already written
+              const uint32_t s = op - offset + j;
+              if (lane < n) { const uint8_t v = ring[s & (kRing - 1)]; ring[(op + lane) & (kRing - 1)] = v; }
+              op += n; done += n;
+              if (op - flushed >= 2048u) flush_to(op & ~255u);
+            }
+          } else {                                                       // far match: through HBM, v1 style
+            flush_to(op);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint8_t* m = out + op - offset;                        // offset > 8128 > any 64-byte step: never overlaps a step
+            for (uint32_t k = lane; k < ml; k += 64) {
+              const uint8_t v = __builtin_nontemporal_load(m + k);
+              out[op + k] = v;
+              if (ml - (k - lane) <= (uint32_t)kRing) ring[(op + k) & (kRing - 1)] = v;   // keep the ring current (its last 8 KB)
+            }
+            if (ml >= (uint32_t)kRing - 64u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+            op += ml; flushed = op;
+          }
+        }
+      }
+      if (op - flushed >= 2048u) flush_to(op & ~255u);
+      if (last) break;
+    }
+    if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
+    if (!err) flush_to(op);
+    if (lane == 0) status[b] = err;
+    wave_lds_fence();
+  }
+}
+
+// Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format), GB/s of
+// decoded output: v1 26 (3815 blocks) / 30 (7630 blocks); v2 18; v3 22 / 26.  v3 removes every memory round trip from the
+// per-sequence chain (SQ_WAIT_INST_ANY 7 % of wave cycles) but spends 110 SALU + 45 VALU + 2.3 LDS instructions per
+// sequence at 12 waves/CU (LDS), and one wave retires an instruction of this branchy scalar code only every ~12 cycles:
+// it is instruction-issue bound, where v1 hides its L2 round trips behind 2.7x the waves.  v1 stays the default.
+static int g_lz4_variant = 0;
 void set_lz4_variant(int v) { g_lz4_variant = v; }
 
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
@@ -178,7 +396,8 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   int64_t grid = ((int64_t)nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 65535) grid = 65535;
   if (g_lz4_variant == 0) hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
-  else hipLaunchKernelGGL(k_lz4_decode_lds, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
+  else if (g_lz4_variant == 1) hipLaunchKernelGGL(k_lz4_decode_lds, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
+  else hipLaunchKernelGGL(k_lz4_decode_v3, dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -193,7 +193,7 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
             "zeros": np.zeros(n, np.int64), "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n],
             "far": np.concatenate([rng.integers(-2**62, 2**62, 3000), np.zeros(10, np.int64)] * (n // 3010 + 1))[:n].astype(np.int64)}
     cols["far"][6000:9000] = cols["far"][0:3000]          # a 24-KB repeat at distance 48 KB
-    for bs, variant in ((65536, 1), (1000, 1), (65536, 0)):
+    for bs, variant in ((65536, 1), (1000, 1), (65536, 0), (65536, 2), (1000, 2)):
         ctx.set_option("lz4_variant", variant)
         p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"tb{bs}_{variant}"))
         ov, dv = apply_stages(p, [])
@@ -202,7 +202,41 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
         assert_same(p, ov, dv)
         ov, dv = apply_stages(p, [("pred", ir.ismissing(ir.col(6)) | ir.ismissing(ir.col(3)))])
         assert_same(p, ov, dv)
-    ctx.set_option("lz4_variant", 1)
+    ctx.set_option("lz4_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
+    """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
+    matches with offset < 64, = 64, > 64), literal runs of 0..400 bytes between matches (length-byte chains), matches at
+    distances beyond the 8-KB LDS ring, incompressible blocks (one 64-KB literal run), sequences that straddle the 2-KB
+    staging chunks, and blocks that end right after a match / with a 5-byte literal tail."""
+    rng = np.random.default_rng(5 + variant)
+    n = 300_000
+    periodic = np.concatenate([np.tile(rng.integers(0, 256, per).astype(np.uint8), 2300 // per + 1)[:2300] for per in range(1, 131)])
+    pieces = []
+    base = rng.integers(0, 256, 20_000).astype(np.uint8)
+    pos = 0
+    while sum(len(x) for x in pieces) < n:
+        lit = int(rng.integers(0, 401))
+        pieces.append(rng.integers(0, 256, lit).astype(np.uint8))                    # literal run
+        ln = int(rng.choice([4, 5, 18, 19, 20, 64, 65, 270, 271, 300, 1000, 9000]))
+        start = int(rng.integers(0, len(base) - ln))
+        pieces.append(base[start:start + ln])                                        # match somewhere in the first 20 KB of output
+        if not pos:
+            pieces.insert(0, base); pos = 1
+    mixed = np.concatenate(pieces)[:n]
+    cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "noise": rng.integers(0, 256, n).astype(np.uint8),
+            "runs": np.repeat(rng.integers(0, 4, n // 50 + 1).astype(np.uint8), rng.integers(1, 100, n // 50 + 1))[:n]}
+    cols["runs"] = np.resize(cols["runs"], n)
+    ctx.set_option("lz4_variant", variant)
+    try:
+        for bs in (65536, 50_000, 4099):
+            p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"c{bs}"))
+            ov, dv = apply_stages(p, [])
+            assert_same(p, ov, dv)
+    finally:
+        ctx.set_option("lz4_variant", 0)
 
 
 def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
