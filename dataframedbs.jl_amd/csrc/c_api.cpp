@@ -172,6 +172,13 @@ int32_t dfdb_table_add_column(dfdb_table* t, const char* name, int32_t dtype, in
 int32_t dfdb_table_add_generated(dfdb_table* t, const char* name, int32_t generator, uint64_t seed, int64_t row_first, int64_t nrows) {
   return guard([&] { NEED(t); NEED(name); table_add_generated(t, name, generator, seed, row_first, nrows); });
 }
+int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t proj_col) {
+  return guard([&] { NEED(dst); NEED(name); NEEDQ(q); table_add_from_query(dst, name, q, proj_col); });
+}
+int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(path); table_save(t, path, stats); }); }
+int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
+  return guard([&] { NEED(t); NEED(file); table_save_column(t, ordinal, file, stats); });
+}
 int32_t dfdb_table_set_row_base(dfdb_table* t, int64_t row_base) { return guard([&] { NEED(t); t->row_base = row_base; }); }
 
 // ------------------------------------------------------------------ queries

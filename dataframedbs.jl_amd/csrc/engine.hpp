@@ -86,4 +86,7 @@ int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
+void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp
+void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
+void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p);       // add_column!(t, name, lazy column)
 }  // namespace dfdb

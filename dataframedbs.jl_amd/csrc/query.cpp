@@ -306,61 +306,106 @@ int64_t query_string_bytes(dfdb_query* q, int i) {
   return string_out_offsets(q, col, q->str_sizes, nullptr, cnt, q->str_toff);
 }
 
+// one output column of the projection (ProjectionExecutor.eval_on_range for column p: projection.jl:128-154)
+static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cnt) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const Node& e = *q->proj[(size_t)p].expr;
+  o.dtype = e.dtype; o.count = cnt; o.nbytes = 0;
+  const bool dev = o.memkind == DFDB_MEM_DEVICE;
+  const int w = dt_width(e.dtype);
+  if (cnt == 0) return;
+  if (!o.data) fail(DFDB_ERR_ARGUMENT, "output column %d has no data buffer", p);
+  if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
+    const Column& col = need_resident(t, e.col);
+    if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
+      DevBuf &dsz = q->str_sizes, &toff = q->str_toff, &dbytes = q->str_bytes;   // reused across calls (hipFree would sync the device)
+      int32_t* d_sizes = dev ? (int32_t*)o.data : nullptr;
+      const int64_t total = string_out_offsets(q, col, dsz, d_sizes, cnt, toff);
+      if (!d_sizes) d_sizes = dsz.as<int32_t>();
+      o.nbytes = total;
+      if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
+      uint8_t* d_bytes = dev ? o.bytes : nullptr;
+      if (!dev) { dbytes.ensure((size_t)total + 64); d_bytes = dbytes.as<uint8_t>(); }
+      if (total > 0) {
+        LaunchTimer lt(ctx, "str_gather_bytes");
+        launch_str_gather_bytes(s, q->bitmap.as<uint64_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                                toff.as<uint64_t>(), d_bytes, t->nrows, total);
+      }
+      if (!dev) {
+        HIP_CHECK(hipMemcpyAsync(o.data, d_sizes, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        if (total > 0) HIP_CHECK(hipMemcpyAsync(o.bytes, d_bytes, (size_t)total, hipMemcpyDeviceToHost, s));
+        stream_wait(ctx);
+      }
+      return;
+    }
+    DevBuf stage; void* dst = o.data;
+    if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
+    { LaunchTimer lt(ctx, "gather");
+      launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt); }
+    if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
+    if (dt_nullable(e.dtype) && o.missing) {
+      DevBuf ms; uint8_t* md = o.missing;
+      if (!dev) { ms.ensure((size_t)cnt); md = ms.as<uint8_t>(); }
+      launch_gather_bits(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.missing.as<uint64_t>(), md, t->nrows, cnt);
+      if (!dev) { HIP_CHECK(hipMemcpyAsync(o.missing, md, (size_t)cnt, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
+    }
+    if (!dev) stream_wait(ctx);   // staging buffers die at scope exit; device outputs stay stream-ordered, no host wait
+  } else {                  // BroadcastExecutor: computed column (projection.jl:128-129)
+    if (dt_base(e.dtype) == DFDB_STRING) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
+    DevBuf stage; void* dst = o.data;
+    if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
+    run_interp_project(q, e, dst, cnt);
+    if (!dev) { HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
+  }
+}
+
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
   ensure_executed(q);
-  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   if (ncols != (int32_t)q->proj.size()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: view has %zu columns, %d outputs given", q->proj.size(), ncols);
   const int64_t cnt = query_count(q, -1);
-  for (int32_t p = 0; p < ncols; p++) {
-    const Node& e = *q->proj[(size_t)p].expr; dfdb_outcol& o = outs[p];
-    o.dtype = e.dtype; o.count = cnt; o.nbytes = 0;
-    const bool dev = o.memkind == DFDB_MEM_DEVICE;
-    const int w = dt_width(e.dtype);
-    if (cnt == 0) continue;
-    if (!o.data) fail(DFDB_ERR_ARGUMENT, "output column %d has no data buffer", p);
-    if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
-      const Column& col = need_resident(t, e.col);
-      if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
-        DevBuf &dsz = q->str_sizes, &toff = q->str_toff, &dbytes = q->str_bytes;   // reused across calls (hipFree would sync the device)
-        int32_t* d_sizes = dev ? (int32_t*)o.data : nullptr;
-        const int64_t total = string_out_offsets(q, col, dsz, d_sizes, cnt, toff);
-        if (!d_sizes) d_sizes = dsz.as<int32_t>();
-        o.nbytes = total;
-        if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
-        uint8_t* d_bytes = dev ? o.bytes : nullptr;
-        if (!dev) { dbytes.ensure((size_t)total + 64); d_bytes = dbytes.as<uint8_t>(); }
-        if (total > 0) {
-          LaunchTimer lt(ctx, "str_gather_bytes");
-          launch_str_gather_bytes(s, q->bitmap.as<uint64_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
-                                  toff.as<uint64_t>(), d_bytes, t->nrows, total);
-        }
-        if (!dev) {
-          HIP_CHECK(hipMemcpyAsync(o.data, d_sizes, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
-          if (total > 0) HIP_CHECK(hipMemcpyAsync(o.bytes, d_bytes, (size_t)total, hipMemcpyDeviceToHost, s));
-          stream_wait(ctx);
-        }
-        continue;
-      }
-      DevBuf stage; void* dst = o.data;
-      if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
-      { LaunchTimer lt(ctx, "gather");
-        launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt); }
-      if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
-      if (dt_nullable(e.dtype) && o.missing) {
-        DevBuf ms; uint8_t* md = o.missing;
-        if (!dev) { ms.ensure((size_t)cnt); md = ms.as<uint8_t>(); }
-        launch_gather_bits(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.missing.as<uint64_t>(), md, t->nrows, cnt);
-        if (!dev) { HIP_CHECK(hipMemcpyAsync(o.missing, md, (size_t)cnt, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
-      }
-      if (!dev) stream_wait(ctx);   // staging buffers die at scope exit; device outputs stay stream-ordered, no host wait
-    } else {                  // BroadcastExecutor: computed column (projection.jl:128-129)
-      if (dt_base(e.dtype) == DFDB_STRING) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
-      DevBuf stage; void* dst = o.data;
-      if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
-      run_interp_project(q, e, dst, cnt);
-      if (!dev) { HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
-    }
+  for (int32_t p = 0; p < ncols; p++) materialize_col(q, p, outs[p], cnt);
+}
+
+// add_column!(table, name, lazy_col) (src/tables/table.jl:96-124): the p-th column of the view materialised into a new
+// RESIDENT column of dst without leaving the device.  dst may be the view's own table (then every row must be selected).
+void launch_pack_flags(hipStream_t s, const uint8_t* flags, uint64_t* bits, int64_t n);
+void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p) {
+  ensure_executed(q);
+  if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
+  if (dst->ctx != q->t->ctx) fail(DFDB_ERR_ARGUMENT, "the destination table lives on another context");
+  for (auto& c : dst->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
+  const Node& e = *q->proj[(size_t)p].expr;
+  const int64_t cnt = query_count(q, -1);
+  if (dst->nrows >= 0 && dst->nrows != cnt)
+    fail(DFDB_ERR_ARGUMENT, "ArgumentError: column has %lld rows but the table has %lld", (long long)cnt, (long long)dst->nrows);
+  dfdb_ctx* ctx = dst->ctx; hipStream_t s = ctx->stream;
+  Column c; c.name = name; c.dtype = e.dtype; c.id = 1; c.nrows = cnt;
+  for (auto& o : dst->cols) c.id = std::max(c.id, o.id + 1);
+  dfdb_outcol o{}; o.memkind = DFDB_MEM_DEVICE;
+  DevBuf flags;
+  if (dt_base(e.dtype) == DFDB_STRING) {
+    const int64_t total = query_string_bytes(q, p);
+    c.data.ensure((size_t)cnt * 4 + 256);
+    c.nbytes = total; c.bytes.ensure((size_t)total + 64);
+    HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + total, 0, 64, s));
+    o.data = c.data.p; o.bytes = c.bytes.as<uint8_t>(); o.bytes_cap = total;
+  } else {
+    c.data.ensure((size_t)cnt * dt_width(e.dtype) + 256);
+    o.data = c.data.p;
+    if (dt_nullable(e.dtype)) { flags.ensure((size_t)cnt + 64); HIP_CHECK(hipMemsetAsync(flags.p, 0, (size_t)cnt + 64, s)); o.missing = flags.as<uint8_t>(); }
   }
+  materialize_col(q, p, o, cnt);
+  if (dt_base(e.dtype) == DFDB_STRING) set_string_tile_offsets(ctx, c);
+  else if (dt_nullable(e.dtype)) {
+    const size_t nw = (size_t)(round_up(cnt > 0 ? cnt : 1, kCTileRows) / 64 + 64);
+    c.missing.ensure(nw * 8);
+    HIP_CHECK(hipMemsetAsync(c.missing.p, 0, nw * 8, s));
+    if (cnt) launch_pack_flags(s, flags.as<uint8_t>(), c.missing.as<uint64_t>(), cnt);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  c.resident = true;
+  if (dst->nrows < 0) dst->nrows = cnt;
+  dst->cols.push_back(std::move(c));
 }
 
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {

@@ -1,0 +1,165 @@
+// writer.cpp — resident columns -> table directory in the reference's on-disk format.
+//
+// Replaces (paths under /root/reference): write_table_meta src/io/table_io.jl:9-19, write_column_head
+// src/io/filesystem.jl:14-23, the write_column block loop src/tables/columns.jl:39-53, write_block_body
+// src/io/blocks.jl:2-33 and commit_block_write! src/io/BlockStreams.jl:36-60 (LZ4_compress + the 20-byte
+// block header: Int32 rows, Int64 origin, Int64 compressed).  The column never leaves HBM decoded: block
+// bodies are packed (nullable / String) and LZ4-compressed on the device, a wave per block (k_encode.hip);
+// only compressed bytes cross PCIe.  Blocks are processed in batches so the staging arenas stay bounded.
+#include "engine.hpp"
+#include <cerrno>
+#include <cstring>
+#include <cstdio>
+#include <sys/stat.h>
+
+namespace dfdb {
+
+void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* out_len);
+void launch_pack_nullable(hipStream_t s, const uint8_t* values, const uint64_t* missing_bits, const int64_t* row_off, const int64_t* body_off,
+                          int32_t nblocks, int width, uint8_t* bodies);
+void launch_pack_strings(hipStream_t s, const int32_t* sizes, const uint8_t* bytes, const int64_t* row_off, const int64_t* byte_off,
+                         const int64_t* body_off, int32_t nblocks, uint8_t* bodies);
+void launch_row_byte_offsets(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const int64_t* rows, int32_t n, int64_t nrows, int64_t* out);
+
+namespace {
+
+struct Wr {   // little-endian writer (native Julia `write`)
+  std::vector<uint8_t> b;
+  void i32(int32_t v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + 4); }
+  void i64(int64_t v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + 8); }
+  void str(const std::string& s) { i32((int32_t)s.size()); b.insert(b.end(), s.begin(), s.end()); }   // write_string: common_io.jl:1-4
+};
+
+struct File {
+  FILE* f = nullptr; std::string name;
+  File(const std::string& fn) : name(fn) { f = fopen(fn.c_str(), "wb"); if (!f) fail(DFDB_ERR_IO, "cannot create %s: %s", fn.c_str(), strerror(errno)); }
+  ~File() { if (f) fclose(f); }
+  void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) fail(DFDB_ERR_IO, "short write to %s", name.c_str()); }
+  void close() { if (f && fclose(f) != 0) { f = nullptr; fail(DFDB_ERR_IO, "cannot close %s", name.c_str()); } f = nullptr; }
+};
+
+inline int64_t lz4_bound(int64_t n) { return n + n / 255 + 16; }   // LZ4_COMPRESSBOUND
+
+constexpr int64_t kBatchBodyBytes = 512ll << 20;   // uncompressed bytes encoded per batch
+
+}  // namespace
+
+// one column file: header, then every block of the RESIDENT rows
+void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  if (t->block_first != 0) fail(DFDB_ERR_UNSUPPORTED, "a block-range shard cannot be saved as a whole column");
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int64_t B = t->block_size, nrows = c.nrows, nb = ceil_div(nrows, B);
+  const int w = dt_width(c.dtype);
+  const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
+
+  File f(file);
+  { Wr h; h.i64(B); h.str(dt_name(c.dtype)); f.put(h.b.data(), h.b.size()); }   // write_column_head: filesystem.jl:14-23
+  dfdb_sizestats st{0, 0, 0};
+  st.rows = nrows;
+
+  // String columns: arena offset of the first row of every block
+  std::vector<int64_t> blk_byte((size_t)nb + 1, 0);
+  if (is_str && nb) {
+    std::vector<int64_t> rows((size_t)nb + 1);
+    for (int64_t b = 0; b <= nb; b++) rows[(size_t)b] = std::min(b * B, nrows);
+    DevBuf d; d.ensure(16 * ((size_t)nb + 1));
+    HIP_CHECK(hipMemcpyAsync(d.p, rows.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
+    launch_row_byte_offsets(s, c.data.as<int32_t>(), (const int64_t*)c.tile_off.p, d.as<int64_t>(), (int32_t)(nb + 1), nrows, d.as<int64_t>() + nb + 1);
+    HIP_CHECK(hipMemcpyAsync(blk_byte.data(), d.as<int64_t>() + nb + 1, 8 * ((size_t)nb + 1), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  auto body_bytes = [&](int64_t b) -> int64_t {   // blocks.jl:2-33
+    const int64_t rows = std::min(B, nrows - b * B);
+    if (is_str) return 4 + 4 * rows + (blk_byte[(size_t)b + 1] - blk_byte[(size_t)b]);
+    if (is_null) return 8 * ceil_div(rows, 64) + (int64_t)w * rows;
+    return (int64_t)w * rows;
+  };
+
+  DevBuf bodies, comp, dblocks, dlens, daux;
+  std::vector<uint8_t> hcomp;
+  int64_t b0 = 0;
+  while (b0 < nb) {
+    // batch [b0, b1): bounded by kBatchBodyBytes of bodies
+    int64_t b1 = b0, tot = 0;
+    while (b1 < nb && (b1 == b0 || tot + body_bytes(b1) <= kBatchBodyBytes)) { tot += round_up(body_bytes(b1), 16); b1++; }
+    const int64_t n = b1 - b0;
+    std::vector<Lz4Block> blocks((size_t)n);
+    std::vector<int64_t> body_off((size_t)n + 1), row_off((size_t)n + 1), byte_off((size_t)n + 1);
+    int64_t bo = 0, co = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const int64_t b = b0 + i, len = body_bytes(b);
+      if (len > 0x7e000000LL) fail(DFDB_ERR_UNSUPPORTED, "block body larger than the LZ4 block limit");
+      body_off[(size_t)i] = bo; row_off[(size_t)i] = b * B; byte_off[(size_t)i] = blk_byte[(size_t)b];
+      blocks[(size_t)i].src_off = (is_str || is_null) ? bo : b * B * w;   // plain columns are compressed straight out of the column
+      blocks[(size_t)i].src_len = (int32_t)len; blocks[(size_t)i].dst_len = (int32_t)lz4_bound(len);
+      blocks[(size_t)i].dst_off = co;
+      bo += round_up(len, 16); co += round_up(lz4_bound(len), 16);
+    }
+    body_off[(size_t)n] = bo; row_off[(size_t)n] = std::min(b1 * B, nrows); byte_off[(size_t)n] = blk_byte[(size_t)b1];
+
+    const uint8_t* csrc = c.data.as<uint8_t>();
+    if (is_str || is_null) {
+      bodies.ensure((size_t)bo + 64);
+      daux.ensure(8 * 3 * ((size_t)n + 1));
+      int64_t* d_body = daux.as<int64_t>(); int64_t* d_row = d_body + n + 1; int64_t* d_byte = d_row + n + 1;
+      HIP_CHECK(hipMemcpyAsync(d_body, body_off.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(d_byte, byte_off.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+      if (is_str) launch_pack_strings(s, c.data.as<int32_t>(), c.bytes.as<uint8_t>(), d_row, d_byte, d_body, (int32_t)n, bodies.as<uint8_t>());
+      else launch_pack_nullable(s, c.data.as<uint8_t>(), c.missing.as<uint64_t>(), d_row, d_body, (int32_t)n, w, bodies.as<uint8_t>());
+      csrc = bodies.as<uint8_t>();
+    }
+    comp.ensure((size_t)co + 64);
+    dblocks.ensure(sizeof(Lz4Block) * (size_t)n);
+    dlens.ensure(4 * (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)n, hipMemcpyHostToDevice, s));
+    { LaunchTimer lt(ctx, "lz4_compress"); launch_lz4_compress(s, csrc, comp.as<uint8_t>(), dblocks.as<Lz4Block>(), (int32_t)n, dlens.as<int32_t>()); }
+    std::vector<int32_t> lens((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(lens.data(), dlens.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    // compressed bytes: one D2H copy per run of blocks (the arena is sparse: every slot is sized for the worst case)
+    hcomp.resize((size_t)co);
+    for (int64_t i = 0; i < n; i++) {
+      if (lens[(size_t)i] <= 0 || lens[(size_t)i] > blocks[(size_t)i].dst_len) fail(DFDB_ERR_DEVICE, "LZ4 compression failed in block %lld of column %s", (long long)(b0 + i), c.name.c_str());
+      HIP_CHECK(hipMemcpyAsync(hcomp.data() + blocks[(size_t)i].dst_off, comp.as<uint8_t>() + blocks[(size_t)i].dst_off, (size_t)lens[(size_t)i], hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; i++) {   // commit_block_write!: BlockStreams.jl:50-53
+      const int64_t b = b0 + i;
+      const int32_t rows = (int32_t)std::min(B, nrows - b * B);
+      Wr h; h.i32(rows); h.i64(blocks[(size_t)i].src_len); h.i64(lens[(size_t)i]);
+      f.put(h.b.data(), h.b.size());
+      f.put(hcomp.data() + blocks[(size_t)i].dst_off, (size_t)lens[(size_t)i]);
+      st.compressed += lens[(size_t)i] + 24; st.uncompressed += blocks[(size_t)i].src_len;   // SizeStats incl. the 24-byte header quirk (:7,23)
+    }
+    b0 = b1;
+  }
+  f.close();
+  if (stats) *stats = st;
+}
+
+// make_table / create_table: meta.bin + one file per column (creators.jl:18-60, table_io.jl:9-19)
+void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) {
+  const std::string dir(path);
+  struct stat sb;
+  if (stat((dir + "/meta.bin").c_str(), &sb) == 0) fail(DFDB_ERR_IO, "table %s already exists", path);
+  if (mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) fail(DFDB_ERR_IO, "cannot create directory %s: %s", path, strerror(errno));
+  for (auto& c : t->cols) if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  dfdb_sizestats tot{0, 0, 0};
+  for (size_t i = 0; i < t->cols.size(); i++) {
+    dfdb_sizestats st{0, 0, 0};
+    table_save_column(t, (int32_t)i, (dir + "/" + std::to_string(t->cols[i].id) + ".bin").c_str(), &st);   // columnpath: filesystem.jl:11
+    tot.rows = st.rows; tot.compressed += st.compressed; tot.uncompressed += st.uncompressed;
+  }
+  Wr m; m.i64(t->format_version); m.i64(t->block_size); m.i64((int64_t)t->cols.size());
+  for (auto& c : t->cols) { m.i64(c.id); m.str(c.name); m.str(dt_name(c.dtype)); }
+  File f(dir + "/meta.bin");   // written last: a table without meta.bin "don't exists" (creators.jl:9)
+  f.put(m.b.data(), m.b.size());
+  f.close();
+  if (stats) *stats = tot;
+}
+
+}  // namespace dfdb

@@ -25,6 +25,7 @@ Everything data-parallel runs in libdfdb_hip.so; this module only builds queries
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -332,6 +333,27 @@ class DFTable:
         return dict(rows=st.rows, compressed=st.compressed, uncompressed=st.uncompressed)
 
     def set_row_base(self, row_base: int): N.check(N.load().dfdb_table_set_row_base(self._h, row_base))
+
+    def add_column_from(self, name: str, col) -> None:
+        """add_column!(table, name, lazy_col) (table.jl:96-124): a DFColumn (or one-column DFView), plain or computed,
+        filtered or not, becomes a new resident column of this table without leaving the device."""
+        v = col.view if isinstance(col, DFColumn) else col
+        if not isinstance(v, DFView) or len(v.projection) != 1:
+            raise ValueError("ArgumentError: add_column_from needs a DFColumn or a one-column DFView")
+        q = v._query()
+        N.check(N.load().dfdb_table_add_from_query(self._h, name.encode(), q._h, 0))
+
+    def save(self, path: str) -> dict:
+        """create_table(path; from=table) (creators.jl:18-60): every resident column to `<path>/<id>.bin` in the reference's
+        block format (bodies packed + LZ4-compressed on the device) and `<path>/meta.bin`.  Returns the SizeStats."""
+        st = N.SizeStats()
+        N.check(N.load().dfdb_table_save(self._h, os.fsencode(path), C.byref(st)))
+        return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
+
+    def save_column(self, name: str, file: str) -> dict:
+        st = N.SizeStats()
+        N.check(N.load().dfdb_table_save_column(self._h, self.ordinal(name), os.fsencode(file), C.byref(st)))
+        return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
 
     def close(self):
         if self._h:
@@ -891,6 +913,23 @@ def view_from_columns(**cols: DFColumn) -> DFView:
     if first is None:
         raise ValueError("ArgumentError: no columns")
     return DFView(first.view.table, Projection({k: c.expr for k, c in cols.items()}), first.view.selection)
+
+
+def create_table(path: str, from_=None, block_size: int = 65536, ctx: Optional[Context] = None, **columns) -> "DFTable":
+    """create_table(path; from=..., block_size=...) (creators.jl:18-60).  `from_`: a dict of host columns, a DFTable, or a
+    DFView / DFColumn(s) to materialise (on the device) first.  Writes the table directory and returns the opened table."""
+    src = from_ if from_ is not None else columns
+    if isinstance(src, DFTable):
+        t = src
+    elif isinstance(src, (DFView, DFColumn)):
+        v = src.view if isinstance(src, DFColumn) else src
+        t = DFTable.new(block_size=block_size, ctx=v.table.ctx)
+        for name in v.names():
+            t.add_column_from(name, v[ALL, name])
+    else:
+        t = DFTable.from_columns(dict(src), block_size=block_size, ctx=ctx)
+    t.save(path)
+    return open_table(path, ctx=t.ctx)
 
 
 def map_to_column(f: Callable, v: Union[DFView, DFTable]) -> DFColumn:   # view.jl:160-164

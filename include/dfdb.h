@@ -143,6 +143,20 @@ int32_t dfdb_table_add_column(dfdb_table* t, const char* name, int32_t dtype, in
 /* device-side synthetic fill (no PCIe): rows [row_first, row_first+nrows) of the global column */
 int32_t dfdb_table_add_generated(dfdb_table* t, const char* name, int32_t generator,
                                  uint64_t seed, int64_t row_first, int64_t nrows);
+/* add_column!(table, name, lazy_col) (src/tables/table.jl:96-124, src/tables/columns.jl:65-84): column `proj_col` of the
+ * view behind `q` is materialised into a new RESIDENT column of `dst` without leaving the device.  dst may be the view's
+ * own table; the column must have exactly as many rows as dst (ArgumentError otherwise). */
+int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t proj_col);
+
+/* create_table(path; from=...) / write_column (src/tables/creators.jl:18-60, src/tables/columns.jl:39-53): every resident
+ * column -> `<path>/<id>.bin` in the reference's block format (write_column_head filesystem.jl:14-23, write_block_body
+ * blocks.jl:2-33, commit_block_write! BlockStreams.jl:36-60) + `<path>/meta.bin` (write_table_meta table_io.jl:9-19).
+ * Block bodies are packed and LZ4-compressed on the device; only compressed bytes cross PCIe.  The files open with the
+ * reference's open_table and with dfdb_table_open.  ErrorException (DFDB_ERR_IO) if the table already exists. */
+int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);
+/* one column file (header + blocks) */
+int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
+
 /* global row number (0-based) of this shard's first row, so that selection indices and leading
  * range stages refer to table rows when a table is block-range sharded over ranks */
 int32_t dfdb_table_set_row_base(dfdb_table* t, int64_t row_base);

@@ -1,0 +1,188 @@
+"""Write side of the block format: columns resident in HBM -> table directory in the reference's
+on-disk format, bodies packed and LZ4-compressed ON THE DEVICE.  The parity statement is the one SURVEY.md §8c allows:
+the compressed BYTES are not a target (liblz4 versions differ), the frozen LZ4 block format is — so every file the
+engine writes is read back (a) by the CPU oracle, whose decoder is the system liblz4 and whose reader follows
+BlockStreams.jl / blocks.jl, and (b) by the engine's own loaders, and must give the original columns bit for bit."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import Pair, apply_stages, assert_same
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x9E3779B97F4A7C15
+
+
+def col_seed(k):
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+class Reopened:
+    """What assert_same needs: the oracle's view of the files the ENGINE wrote, and the engine's own re-read."""
+
+    def __init__(self, O, dfdb, path, names, nrows):
+        self.O, self.dfdb, self.names, self.nrows = O, dfdb, names, nrows
+        self.o = O.Table.open(path)
+        self.d = dfdb.open_table(path)
+
+    def ord(self, name):
+        return self.names.index(name)
+
+
+def sample_columns(oracle, n, rng):
+    sizes, data = oracle.gen_str(col_seed(3), 0, n)
+    strs = oracle.flat_to_strings(sizes, data)
+    return {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": strs,
+            "sm": [None if i % 13 == 0 else s + "é" * (i % 3) for i, s in enumerate(strs)],
+            "iota": np.arange(1, n + 1, dtype=np.int64), "i16": rng.integers(-300, 300, n).astype(np.int16),
+            "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.2),
+            "mf": np.ma.masked_array(rng.random(n).astype(np.float32), mask=rng.random(n) < 0.5),
+            "b": rng.integers(0, 2, n).astype(bool), "rnd": rng.integers(-2**62, 2**62, n).astype(np.int64),
+            "zeros": np.zeros(n, np.int64), "u8": np.repeat(rng.integers(0, 7, n // 40 + 1).astype(np.uint8), 40)[:n],
+            "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n]}
+
+
+@pytest.mark.parametrize("n,bs", [(200_003, 65536), (200_003, 1000), (70_001, 999), (5, 65536), (12, 3), (0, 65536)])
+def test_saved_table_reads_back_everywhere(oracle, dfdb_mod, ctx, tmp_path, n, bs):
+    from dfdb import ir
+    rng = np.random.default_rng(3)
+    cols = sample_columns(oracle, n, rng)
+    t = dfdb_mod.DFTable.from_columns(cols, block_size=bs)
+    path = str(tmp_path / "tb")
+    st = t.save(path)
+    assert st["rows"] == n
+    assert sorted(os.listdir(path)) == sorted(["meta.bin"] + [f"{i + 1}.bin" for i in range(len(cols))])   # test/tables.jl:36-44
+    # the oracle (liblz4 + the reference's reader logic) and the engine's decoders agree with the source on every observable
+    for variant in (0, 2):
+        ctx.set_option("lz4_variant", variant)
+        try:
+            p = Reopened(oracle, dfdb_mod, path, list(cols), n)
+        finally:
+            ctx.set_option("lz4_variant", 0)
+        assert p.d.names() == list(cols) and p.d.blocksize == bs
+        ov, dv = apply_stages(p, [])
+        assert_same(p, ov, dv)
+        if n > 100:
+            ov, dv = apply_stages(p, [("pred", (ir.col(0) > 500_000) & (ir.col(2) == "sony"))])
+            assert_same(p, ov, dv)
+            ov, dv = apply_stages(p, [("pred", ir.ismissing(ir.col(6)) | ir.ismissing(ir.col(3)))])
+            assert_same(p, ov, dv)
+    # and with the data the files were made from (not only with each other)
+    if n == 0:
+        return                      # (an empty Python list carries no element type: nothing to compare)
+    src = Pair(oracle, dfdb_mod, cols, block_size=bs)
+    want = src.o.view().materialize()
+    got = p.o.view().materialize()
+    for w, g in zip(want, got):
+        if isinstance(w, tuple):
+            assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1])
+        elif isinstance(w, np.ma.MaskedArray):
+            assert np.array_equal(np.ma.getmaskarray(w), np.ma.getmaskarray(g)) and np.array_equal(w.compressed(), g.compressed())
+        else:
+            assert np.array_equal(w.view(np.uint8), g.view(np.uint8))
+
+
+def read_blocks(fn):
+    """(block_size, type string, [(rows, origin, compressed)]) of one column file: Appendix A."""
+    raw = open(fn, "rb").read()
+    bs, = struct.unpack_from("<q", raw, 0)
+    tl, = struct.unpack_from("<i", raw, 8)
+    ty = raw[12:12 + tl].decode()
+    pos, out = 12 + tl, []
+    while pos < len(raw):
+        rows, origin, comp = struct.unpack_from("<iqq", raw, pos)
+        out.append((rows, origin, comp))
+        pos += 20 + comp
+    assert pos == len(raw)
+    return bs, ty, out
+
+
+def test_file_layout_and_compression(oracle, dfdb_mod, ctx, tmp_path):
+    n, bs = 300_000, 65536
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "iota": np.arange(1, n + 1, dtype=np.int64), "zeros": np.zeros(n, np.int64),
+            "m": np.ma.masked_array(np.arange(n, dtype=np.int32), mask=np.arange(n) % 7 == 0), "s": ["ab", None, "xyz"] * (n // 3)}
+    t = dfdb_mod.DFTable.from_columns(cols, block_size=bs)
+    st = t.save(str(tmp_path / "tb"))
+    meta = open(tmp_path / "tb" / "meta.bin", "rb").read()
+    assert struct.unpack_from("<qqq", meta, 0) == (1, bs, len(cols))               # table_io.jl:9-19
+    tot_c = tot_u = 0
+    for i, (name, ty, width) in enumerate([("a", "Int64", 8), ("iota", "Int64", 8), ("zeros", "Int64", 8), ("m", "Missing(Int32)", 4), ("s", "Missing(String)", 0)]):
+        fbs, fty, blocks = read_blocks(tmp_path / "tb" / f"{i + 1}.bin")
+        assert fbs == bs and fty == ty
+        assert [b[0] for b in blocks] == [bs] * (n // bs) + [n % bs]                # columns.jl:16-26: full blocks, then the rest
+        for bi, (rows, origin, comp) in enumerate(blocks):
+            if name == "m":
+                assert origin == 8 * ((rows + 63) // 64) + 4 * rows                 # blocks.jl:9-18
+            elif name == "s":
+                datasize = sum(len(x) for x in cols["s"][bi * bs: bi * bs + rows] if x is not None)
+                assert origin == 4 + 4 * rows + datasize                            # blocks.jl:21-33: datasize, sizes, bytes
+            else:
+                assert origin == width * rows
+            assert 0 < comp <= origin + origin // 255 + 16
+        tot_c += sum(b[2] + 24 for b in blocks); tot_u += sum(b[1] for b in blocks)
+        ratio = sum(b[1] for b in blocks) / sum(b[2] for b in blocks)
+        if name == "zeros":
+            assert ratio > 200
+        if name == "iota":
+            assert ratio > 1.9                                                     # docs/src/index.md:53 quotes 2.0 for 1:3e6
+        if name == "a":
+            assert ratio > 1.25                                                    # 20 random bits per 8 bytes
+    assert (st["compressed"], st["uncompressed"]) == (tot_c, tot_u)                 # SizeStats with the 24-byte quirk (Q10)
+
+
+def test_add_column_from_lazy_column_and_create_table(oracle, dfdb_mod, ctx, tmp_path):
+    """add_column!(t, :k, lazy) and create_table(path; from=view): computed and filtered columns go device -> device -> disk."""
+    from dfdb import ir
+    n = 150_000
+    rng = np.random.default_rng(9)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "c": rng.integers(1, 50, n).astype(np.int64),
+            "s": oracle.flat_to_strings(*oracle.gen_str(col_seed(3), 0, n)),
+            "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.3)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=4096)
+    t = p.d
+    t.add_column_from("k", t.a * 2 + t.c)                 # same table, every row
+    t.add_column_from("r", t.a / t.c)
+    got = dfdb_mod.materialize(t[dfdb_mod.ALL, ["k", "r"]])
+    assert np.array_equal(np.asarray(got["k"]), cols["a"] * 2 + cols["c"])
+    assert np.array_equal(np.asarray(got["r"]), cols["a"] / cols["c"])
+    with pytest.raises(ValueError):                       # wrong length: add_column! rejects it
+        t.add_column_from("bad", t[("a", lambda a: a > 500_000), dfdb_mod.ALL].a)
+    with pytest.raises(ValueError):                       # duplicate name
+        t.add_column_from("k", t.a)
+    # a filtered, projected view -> new table on disk; the oracle evaluates the same view on the source data
+    pred = (ir.col(0) > 600_000) & (ir.col(2) != "sony")
+    v = t[pred, ["a", "s", "m", "k"]]
+    path = str(tmp_path / "sub")
+    sub = dfdb_mod.create_table(path, from_=v, block_size=1000)
+    ov, _ = apply_stages(p, [("pred", pred)], proj=[("a", ir.col(0)), ("s", ir.col(2)), ("m", ir.col(3)), ("k", ir.col(0) * 2 + ir.col(1))])
+    want = ov.materialize()
+    ot = oracle.Table.open(path)
+    got = ot.view().materialize()
+    assert dfdb_mod.nrow(sub) == ov.nrow() == len(got[0])
+    for w, g in zip(want, got):
+        if isinstance(w, tuple):
+            assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1])
+        elif isinstance(w, np.ma.MaskedArray):
+            assert np.array_equal(np.ma.getmaskarray(w), np.ma.getmaskarray(g)) and np.array_equal(w.compressed(), g.compressed())
+        else:
+            assert np.array_equal(w, g)
+    with pytest.raises(dfdb_mod.DfdbError):               # create_table refuses an existing table
+        sub.save(path)
+
+
+def test_incompressible_and_degenerate_blocks(oracle, dfdb_mod, ctx, tmp_path):
+    """Bodies of 0..40 bytes (below the 13-byte minimum the format needs for a match), pure noise, a 1-row table."""
+    rng = np.random.default_rng(17)
+    for k, (n, bs, dt) in enumerate([(1, 65536, np.int8), (5, 2, np.int8), (40, 13, np.uint8), (13, 65536, np.int8), (100_000, 65536, np.int64)]):
+        cols = {"v": rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, n).astype(dt), "z": np.zeros(n, dt)}
+        t = dfdb_mod.DFTable.from_columns(cols, block_size=bs)
+        path = str(tmp_path / f"t{k}")
+        t.save(path)
+        ot = oracle.Table.open(path)
+        got = ot.view().materialize()
+        assert np.array_equal(got[0], cols["v"]) and np.array_equal(got[1], cols["z"])
+        back = dfdb_mod.materialize(dfdb_mod.open_table(path))
+        assert np.array_equal(np.asarray(back["v"]), cols["v"])

@@ -23,7 +23,7 @@ import dfdb  # noqa: E402
 from dfdb import ir  # noqa: E402
 
 SEED = 0x9E3779B97F4A7C15
-KERNELS = ["scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
+KERNELS = ["lz4_compress", "scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
            "compact_indices", "gather", "str_gather_sizes", "str_gather_bytes", "reduce", "lz4_decode"]
 
 
@@ -187,6 +187,17 @@ def main():
                           "open_table_wall_s": wall}))
     print(json.dumps({"config": "lz4", "rows": m, "blocks": st["blocks"], "compressed_MB": len(img) / 1e6, "uncompressed_MB": m * 8 / 1e6,
                       "lz4_decode_ms": ms, "decode_GBps_out": m * 8 / (ms * 1e-3) / 1e9 if ms else None, "open_table_wall_s": wall}))
+    # write side: the decoded column back to disk (device LZ4 compression, k_encode.hip)
+    import shutil
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    st = tb.save(os.path.join(d, "tb_out"))
+    wall = time.perf_counter() - t0
+    nl, ms = ctx.profile_get("lz4_compress")
+    ctx.profile(False)
+    print(json.dumps({"config": "lz4-write", "rows": m, "lz4_compress_ms": ms, "compress_GBps_in": m * 8 / (ms * 1e-3) / 1e9 if ms else None,
+                      "ratio": st["uncompressed"] / max(1, st["compressed"]), "liblz4_ratio": m * 8 / len(img), "save_wall_s": wall}))
+    shutil.rmtree(os.path.join(d, "tb_out"), ignore_errors=True)
     t0 = time.perf_counter()
     nrow = ot.view().add_predicate((ir.col(0) > 899_999).to_ir()).nrow()
     cpu = time.perf_counter() - t0
