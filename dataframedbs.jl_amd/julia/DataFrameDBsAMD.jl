@@ -242,6 +242,48 @@ function gpu_materialize(v::DFView)
     end
 end
 
+# ---------------------------------------------------------------- write side (create_table / add_column!)
+struct SizeStatsC; rows::Int64; compressed::Int64; uncompressed::Int64; end
+
+"create_table(path; from = v) on the device (creators.jl:18-60): the view is materialised column by column into a
+device-resident table (dfdb_table_add_from_query: no host round trip), block bodies are packed and LZ4-compressed
+on the GPU and written in the reference's format; the result opens with the stock `open_table`."
+function gpu_create_table(path::AbstractString, v::DFView; block_size::Integer = DataFrameDBs.DEFAULT_BLOCK_SIZE)
+    d = device()
+    dst = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dfdb_table_new, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), d.ctx, block_size, dst))
+    try
+        for name in keys(v.projection)
+            with_query(v[:, [name]]) do q                              # a one-column view: projection column 0
+                check(ccall((:dfdb_table_add_from_query, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Cvoid}, Int32), dst[], String(name), q, 0))
+            end
+        end
+        st = Ref(SizeStatsC(0, 0, 0))
+        check(ccall((:dfdb_table_save, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{SizeStatsC}), dst[], path, st))
+    finally
+        ccall((:dfdb_table_close, LIB), Int32, (Ptr{Cvoid},), dst[])
+    end
+    DataFrameDBs.open_table(path)
+end
+
+"add_column!(t, name, col::DFColumn) (table.jl:96-124): the lazy column is evaluated on the device and the new
+`<id>.bin` is written next to the table's other column files; the caller then re-reads meta like the stock method."
+function gpu_write_column(file::AbstractString, col::DFColumn)
+    with_query(col.view) do q
+        d = device()
+        tmp = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dfdb_table_new, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), d.ctx, DataFrameDBs.blocksize(col.view.table), tmp))
+        try
+            check(ccall((:dfdb_table_add_from_query, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Cvoid}, Int32), tmp[], "col", q, 0))
+            st = Ref(SizeStatsC(0, 0, 0))
+            check(ccall((:dfdb_table_save_column, LIB), Int32, (Ptr{Cvoid}, Int32, Cstring, Ptr{SizeStatsC}), tmp[], 0, file, st))
+            return st[]
+        finally
+            ccall((:dfdb_table_close, LIB), Int32, (Ptr{Cvoid},), tmp[])
+        end
+    end
+end
+
 # ---------------------------------------------------------------- drop-in switch
 "Route materialize(::DFView) / nrow(::DFView) through the MI355X engine, falling back to the stock path
 when a predicate is outside the IR op set."
