@@ -46,9 +46,33 @@ def cpu_baseline(rows: int, repeats: int):
         nsel, sec, _ = v.bench_scan(rows // 5)           # indices are written, like the GPU job
         best = sec if best is None else min(best, sec)
     st = t.column_stats(0)
-    return dict(value=rows / best, unit="rows/s", cores=1, kind="port",
-                sample=f"{rows} rows ({st['blocks']} LZ4 blocks of 65536, ratio {st['uncompressed'] / st['compressed']:.2f}), "
-                       f"best of {repeats}, {nsel} selected; LZ4 decode -> mask -> LogicalIndex -> 1-based Int64 row indices written")
+    res = dict(value=rows / best, unit="rows/s", cores=1, kind="port",
+               sample=f"{rows} rows ({st['blocks']} LZ4 blocks of 65536, ratio {st['uncompressed'] / st['compressed']:.2f}), "
+                      f"best of {repeats}, {nsel} selected; LZ4 decode -> mask -> LogicalIndex -> 1-based Int64 row indices written")
+    # context only (SURVEY.md §8d "CPU_MT"): the same scan with the blocks split over every host core, one oracle table per
+    # thread (the C calls release the GIL).  The reference itself is single-threaded, so `value` above stays the 1-core figure.
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        ncpu = os.cpu_count() or 1
+        per = (rows // ncpu // 65536) * 65536
+        if ncpu > 1 and per > 0:
+            views = []
+            for k in range(ncpu):
+                tk = O.Table(block_size=65536)
+                tk.add_column("x", O.gen_i64(SEED, k * per, per))
+                views.append((tk, tk.view().add_predicate((ir.col(0) > THRESHOLD).to_ir())))
+            import time
+            best_mt = None
+            with ThreadPoolExecutor(ncpu) as ex:
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    list(ex.map(lambda tv: tv[1].bench_scan(per // 5)[0], views))
+                    dt = time.perf_counter() - t0
+                    best_mt = dt if best_mt is None else min(best_mt, dt)
+            res["all_cores"] = dict(value=per * ncpu / best_mt, unit="rows/s", cores=ncpu, sample=f"{per * ncpu} rows split over {ncpu} threads")
+    except Exception as e:      # context figure only: never fail the bench for it
+        res["all_cores"] = dict(error=str(e))
+    return res
 
 
 def main():
