@@ -140,3 +140,85 @@ def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
         assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
         assert np.array_equal(oa[lo:hi].cpu().numpy(), oracle.gen_i64(seed(1), r0, 65536)[m])
     t.close()
+
+
+def test_interpreter_large_properties(oracle, dfdb_mod, ctx):
+    """A predicate and a computed column that only the device interpreter can run, at 2e8 rows: torch evaluates the same
+    Int64 / Float64 arithmetic on the device as a third opinion, the oracle checks sampled blocks bit for bit."""
+    import torch
+    from dfdb import _native as N, ir
+    dev = torch.device("cuda", 0)
+
+    def seed(k):
+        return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+    n = 200_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(0), n)
+    t.add_generated("b", dfdb_mod.GEN_I64_MOD1M, seed(1), n)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, seed(2), n)
+    pred = ((t.a * 2 + t.b) % 7 == 0) & (t.x * 0.5 < 400.0)
+    v = t[pred, {"k": t.a * 3 - t.b, "r": t.x / 3.0 + t.a}]
+    q = v._query()
+    nsel = q.count()
+    cols = []
+    for name, dt in (("a", torch.int64), ("b", torch.int64), ("x", torch.float64)):
+        full = torch.empty(n, dtype=dt, device=dev)
+        qa = dfdb_mod.DFView(t)[dfdb_mod.ALL, [name]]._query()
+        N.check(N.load().dfdb_materialize(qa._h, (N.OutCol * 1)(_dev_outcol(N, full)), 1))
+        cols.append(full)
+    torch.cuda.synchronize()
+    a, b, x = cols
+    mask = (torch.remainder(a * 2 + b, 7) == 0) & (x * 0.5 < 400.0)     # operands are non-negative: rem == mod
+    assert int(mask.sum()) == nsel
+    idx = torch.empty(nsel, dtype=torch.int64, device=dev)
+    q.indices_device(idx.data_ptr(), nsel)
+    ok = torch.empty(nsel, dtype=torch.int64, device=dev); orr = torch.empty(nsel, dtype=torch.float64, device=dev)
+    N.check(N.load().dfdb_materialize(q._h, (N.OutCol * 2)(_dev_outcol(N, ok), _dev_outcol(N, orr)), 2))
+    torch.cuda.synchronize()
+    assert torch.equal(idx, torch.nonzero(mask).flatten() + 1)
+    assert torch.equal(ok, (a * 3 - b)[mask])
+    # (torch divides by a Python scalar as x * (1/3.0): not IEEE division.  A tensor divisor takes the true-division kernel.)
+    three = torch.full((1,), 3.0, dtype=torch.float64, device=dev)
+    assert torch.equal(orr.view(torch.int64), (torch.div(x, three) + a.to(torch.float64))[mask].view(torch.int64))   # IEEE: same two roundings
+    hidx = idx.cpu().numpy(); hk = ok.cpu().numpy(); hr = orr.cpu().numpy()
+    for r0 in (0, 65536 * 777, n - 65536):
+        oa = oracle.gen_i64(seed(0), r0, 65536); ob_ = oracle.gen_i64(seed(1), r0, 65536); ox_ = oracle.gen_f64(seed(2), r0, 65536)
+        m = ((oa * 2 + ob_) % 7 == 0) & (ox_ * 0.5 < 400.0)
+        lo, hi = np.searchsorted(hidx, r0 + 1), np.searchsorted(hidx, r0 + 65536 + 1)
+        assert np.array_equal(hidx[lo:hi], np.nonzero(m)[0] + r0 + 1)
+        assert np.array_equal(hk[lo:hi], (oa * 3 - ob_)[m])
+        assert np.array_equal(hr[lo:hi].view(np.uint64), (ox_ / 3.0 + oa)[m].view(np.uint64))     # numpy: IEEE division and addition
+    t.close()
+
+
+def test_writer_large_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
+    """5e7 rows x (Int64, Float64, String) written by the device encoder, read back by the device decoder: equal on the device."""
+    import torch
+    from dfdb import _native as N
+    dev = torch.device("cuda", 0)
+    n = 50_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, SEED, n)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, SEED + 1, n)
+    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, SEED + 2, n)
+    st = t.save(str(tmp_path / "big"))
+    assert st["rows"] == n and st["compressed"] < st["uncompressed"]
+    t2 = dfdb_mod.open_table(str(tmp_path / "big"))
+
+    def column(tb, name, dt, count):
+        out = torch.empty(count, dtype=dt, device=dev)
+        qa = dfdb_mod.DFView(tb)[dfdb_mod.ALL, [name]]._query()
+        N.check(N.load().dfdb_materialize(qa._h, (N.OutCol * 1)(_dev_outcol(N, out)), 1))
+        torch.cuda.synchronize()          # device outputs are ordered on the ENGINE's stream, not on torch's
+        return out
+    for name, dt in (("a", torch.int64), ("x", torch.int64)):          # Float64 compared as bit patterns
+        assert torch.equal(column(t, name, dt, n), column(t2, name, dt, n))
+    v1, v2 = t[t.s == "sony", ["a"]], t2[t2.s == "sony", ["a"]]
+    assert dfdb_mod.nrow(v1) == dfdb_mod.nrow(v2) > 0
+    assert v1.a.sum() == v2.a.sum()
+    # and liblz4 (the oracle) agrees on the first and the last block of the Int64 column
+    ot = oracle.Table.open(str(tmp_path / "big"))
+    ov = ot.view(); ov.set_projection([("a", __import__("dfdb").ir.col(0).to_ir())]); ov.add_range(n - 70_000, 1, n)
+    got = ov.materialize()[0]
+    assert np.array_equal(got, oracle.gen_i64(SEED, n - 70_001, 70_001))
+    t.close(); t2.close()
