@@ -72,8 +72,11 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 
 // vec with lane `lane` (wave-uniform) replaced by the wave-uniform value sval (v_writelane_b32)
 __device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t sval, int lane) {
-  // one constant-bus operand per VALU instruction on gfx9: the lane select travels in M0
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(__builtin_amdgcn_readfirstlane(sval)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0");
+  // one constant-bus operand per VALU instruction on gfx9: the lane select travels in M0 (saved and restored: the
+  // compiler treats M0 as reserved and does not accept it in a clobber list)
+  uint32_t keep;
+  asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+      : "+v"(vec), "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(sval)), "s"(__builtin_amdgcn_readfirstlane(lane)));
   return vec;
 }
 

@@ -185,23 +185,28 @@ __global__ __launch_bounds__(kBlock) void k_lz4_decode_lds(const uint8_t* __rest
 //   * the ring is flushed to HBM in coalesced dword stores every 2 KB; nothing in the chain waits for a store.
 // Longer runs take the same steps 64 bytes at a time; a match that reaches further back than the ring is copied from
 // HBM behind a fence (rare on columnar data; costs what every v1 sequence cost).
-constexpr int kStage = 4096;      // two 2 KB chunks
-constexpr int kChunk = 2048;
-constexpr int kRing = 8192;
 constexpr int kV3Waves = 4;
+constexpr int kV4Waves = 1;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-__global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                                  const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage_sh[kV3Waves][kStage];
-  __shared__ __attribute__((aligned(16))) uint8_t ring_sh[kV3Waves][kRing];
+// BATCH (v4, see below the kernel): up to 21 short sequences found in a 64-byte window are executed together
+template <int WAVES, bool BATCH, int kRing, int kStage, int kBatchBytes>
+__global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                               const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage_sh[WAVES][kStage];
+  __shared__ __attribute__((aligned(16))) uint8_t ring_sh[WAVES][kRing];
+  __shared__ int16_t refs_sh[BATCH ? WAVES : 1][BATCH ? kBatchBytes : 1];
   const uint32_t lane = (uint32_t)lane_id();
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* stage = stage_sh[wib];
   uint8_t* ring = ring_sh[wib];
-  const int64_t wave = (int64_t)blockIdx.x * kV3Waves + wib;
-  const int64_t nwaves = (int64_t)gridDim.x * kV3Waves;
+  int16_t* refs = refs_sh[BATCH ? wib : 0];
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  constexpr int kChunk = kStage / 2;            // two chunks staged, a third in flight
+  constexpr int kNF = kChunk / 512;             // 8-byte words per lane of the chunk in flight
+  static_assert(kChunk >= 1024 && kChunk % 512 == 0, "the 512-byte register window plus one sequence's look-ahead must fit behind ip");
   for (int64_t b = wave; b < nblocks; b += nwaves) {
     const Lz4Block blk = blocks[b];
     const uint8_t* in = src + blk.src_off;
@@ -211,17 +216,17 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
     uint32_t cb = 0;                   // staged: input bytes [cb, cb + 4096); invariant cb <= ip < cb + 2048
     uint32_t wbase = 0, wlo = 0, whi = 0;
     int err = 0;
-    uint64_t f[4];                     // the chunk in flight: input bytes [cb + 4096, cb + 6144), 32 per lane
+    uint64_t f[kNF];                   // the chunk in flight: input bytes [cb + kStage, cb + kStage + kChunk)
 
     auto chunk_load = [&](uint32_t pos) {          // global -> registers (bytes past in_len are never consumed)
-      const uint32_t g = pos + lane * 32;
+      const uint32_t g = pos + lane * (8 * kNF);
 #pragma unroll
-      for (int i = 0; i < 4; i++) f[i] = g + 8 * i < in_len ? ld_u64_unaligned(in + g + 8 * i) : 0ull;
+      for (int i = 0; i < kNF; i++) f[i] = g + 8 * i < in_len ? ld_u64_unaligned(in + g + 8 * i) : 0ull;
     };
     auto chunk_store = [&](uint32_t pos) {         // registers -> staging slot of input position pos (a multiple of 2048)
-      uint64_t* d = (uint64_t*)(stage + (pos & (kStage - 1)) + lane * 32);
+      uint64_t* d = (uint64_t*)(stage + (pos & (kStage - 1)) + lane * (8 * kNF));
 #pragma unroll
-      for (int i = 0; i < 4; i++) d[i] = f[i];
+      for (int i = 0; i < kNF; i++) d[i] = f[i];
     };
     auto window_load = [&](uint32_t pos8) {        // 512 input bytes from pos8 (multiple of 8), 8 per lane
       wbase = pos8;
@@ -229,13 +234,16 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
       wlo = w.x; whi = w.y;
     };
     // make input bytes [p, p + 72) parseable: advance the staging buffer and refresh the register window as needed
-    auto ensure = [&](uint32_t p) {
+    auto advance = [&](uint32_t p) {
       while (p >= cb + kChunk) {                   // p left the first staged chunk: recycle its slot for the chunk in flight
         chunk_store(cb + kStage);                  // (waits for those loads: issued a whole chunk ago)
         cb += kChunk;
         chunk_load(cb + kStage);
-        if (wbase < cb) { wbase = 0xffffffffu; }   // window no longer backed: force a reload below
+        if (wbase < cb) { wbase = 0xffffffffu; }   // window no longer backed: force a reload when it is next used
       }
+    };
+    auto ensure = [&](uint32_t p) {
+      advance(p);
       if (p < wbase || p - wbase > 432u) window_load(p & ~7u);
     };
     // the same without recycling staging slots: used while the literals of the current sequence still sit in the staging
@@ -276,6 +284,63 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
     window_load(0);
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
+      if (BATCH) {
+        // ---- v4: 64 candidate sequence starts at once.  Lane l decodes the token at ip + l AS IF a sequence began there
+        // (literal length, offset, match length: three LDS byte reads, no scalar parsing); the real starts are the chain
+        // 0 -> next(0) -> next(next(0)) ... walked with one v_readlane per sequence.  The sequences found (<= 21, each
+        // <= 14 literals + 18 match bytes, no length-extension bytes) are then executed TOGETHER: every output byte gets
+        // a reference (a literal's input position, or the earlier output byte it copies), references that point into this
+        // batch are resolved by pointer doubling 64 bytes at a time, and each byte is fetched once.  Anything else (length
+        // extensions, long runs, far offsets, the last sequence) takes the one-sequence path below.
+        advance(ip);
+        const uint32_t pos = ip + lane;
+        const uint32_t token = stage[pos & (kStage - 1)];
+        const uint32_t lit = token >> 4, mlc = token & 15u;
+        const uint32_t opos = pos + 1 + lit;                               // the 2-byte offset field
+        const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+        const bool simple = lit != 15u && mlc != 15u && opos + 2 < in_len && offset != 0 && offset + (uint32_t)kBatchBytes <= (uint32_t)kRing;
+        const uint64_t S = __ballot(simple);
+        const uint32_t nxt = lane + 3 + lit;                               // start of the following sequence, relative to ip
+        uint32_t cur = 0; uint64_t starts = 0;
+        const uint32_t seqbytes = lit + mlc + 4u;
+        uint32_t room = (uint32_t)kBatchBytes;                             // output bytes the reference array can still take
+        while (cur < 64u && ((S >> cur) & 1ull)) {
+          const uint32_t need = rl(seqbytes, cur);
+          if (need > room) break;
+          room -= need; starts |= 1ull << cur; cur = rl(nxt, cur);
+        }
+        if (starts) {
+          const bool mine = (starts >> lane) & 1ull;
+          const uint32_t tot = mine ? seqbytes : 0u;
+          const uint32_t incl = wave_incl_scan(tot);
+          const uint32_t ostart = incl - tot;                              // first output byte of my sequence, relative to op
+          const uint32_t T = rl(incl, 63);
+          if (__ballot(mine && offset > op + ostart + lit) != 0 || T > out_len - op) { err = 5; break; }
+          for (uint32_t bi = 0; __ballot(bi < tot) != 0; bi++) {           // one reference per output byte
+            if (bi < tot) {
+              const uint32_t j = ostart + bi;
+              refs[j] = bi < lit ? (int16_t)(0x4000 + lane + 1 + bi)       // literal: input byte ip + lane + 1 + bi
+                                 : (int16_t)((int32_t)j - (int32_t)offset); // match: output byte j - offset (< 0: before this batch)
+            }
+          }
+          for (uint32_t c = 0; c < T; c += 64) {
+            const uint32_t j = c + lane;
+            int32_t r = j < T ? (int32_t)refs[j] : 0x4000;
+            for (;;) {                                                     // pointer doubling inside the chunk; earlier chunks are final
+              const bool unres = r >= 0 && r < 0x4000;
+              if (__ballot(unres) == 0) break;
+              if (unres) { r = (int32_t)refs[r]; refs[j] = (int16_t)r; }
+            }
+            if (j < T) {
+              const uint8_t v = r >= 0x4000 ? stage[(ip + (uint32_t)(r - 0x4000)) & (kStage - 1)] : ring[(op + (uint32_t)r) & (kRing - 1)];
+              ring[(op + j) & (kRing - 1)] = v;
+            }
+          }
+          op += T; ip += cur;
+          if (op - flushed >= 2048u) flush_to(op & ~255u);
+          continue;
+        }
+      }
       ensure(ip);
       const uint64_t t64 = fetch64(ip);
       const uint32_t token = (uint32_t)t64 & 255u;
@@ -290,26 +355,22 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
       const uint32_t lit_ip = ip;                  // the literals are input bytes [lit_ip, lit_ip + lit)
       const bool last = ip + lit >= in_len;        // the last sequence is literals only
       uint32_t offset = 0, ml = 0;
+      // the match fields of a sequence with > 64 literals or with match-length extension bytes (up to 2056 of them) are
+      // parsed AFTER its literals have left the staging buffer: walking them may recycle staging slots
+      const bool defer = lit > 64u || (token & 15u) == 15u;
       if (!last) {
-        uint32_t mp = ip + lit;                    // position of the 2-byte offset
+        const uint32_t mp = ip + lit;              // position of the 2-byte offset
         if (mp + 2 > in_len) { err = 3; break; }
-        if (lit <= 5) offset = (uint32_t)(t64 >> (8u * (1u + lit))) & 0xffffu;   // still inside the 8 bytes already fetched
-        else if (lit <= 64) { window_only(mp); offset = (uint32_t)fetch64(mp) & 0xffffu; }
-        mp += 2;
-        ml = token & 15u;
-        if (lit <= 64) {
-          if (ml == 15) {
-            uint32_t bb;
-            do { if (mp >= in_len) { err = 4; break; } window_only(mp); bb = byte_at(mp); mp++; ml += bb; } while (bb == 255);
-            if (err) break;
-          }
-          ml += 4;
+        if (!defer) {
+          if (lit <= 5) offset = (uint32_t)(t64 >> (8u * (1u + lit))) & 0xffffu;   // still inside the 8 bytes already fetched
+          else { window_only(mp); offset = (uint32_t)fetch64(mp) & 0xffffu; }
+          ml = (token & 15u) + 4u;
           if (offset == 0 || offset > op + lit || ml > out_len - op - lit) { err = 5; break; }
+          ip = mp + 2;
         }
-        ip = mp;                                   // (for lit > 64 the match fields are parsed after the literal copy)
       } else ip += lit;
 
-      if (lit + ml <= 64u && lit <= 64u && offset + 64u <= (uint32_t)kRing) {
+      if (!defer && lit + ml <= 64u && offset + 64u <= (uint32_t)kRing) {
         // ---- fast path: the whole sequence is <= 64 bytes; lane k makes output byte op + k
         const uint32_t total = lit + ml, mbase = op + lit;
         if (total) {
@@ -334,7 +395,7 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
           if (op - flushed >= 2048u) flush_to(op & ~255u);
         }
         if (!last) {
-          if (lit > 64) {                                                // match fields of a long-literal sequence
+          if (defer) {                                                   // match fields parsed now: the literals are out of the staging buffer
             uint32_t mp = lp;
             ensure(mp); offset = (uint32_t)fetch64(mp) & 0xffffu; mp += 2;
             ml = token & 15u;
@@ -383,11 +444,11 @@ __global__ __launch_bounds__(kV3Waves * 64) void k_lz4_decode_v3(const uint8_t* 
 }
 
 // Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format), GB/s of
-// decoded output: v1 26 (3815 blocks) / 30 (7630 blocks); v2 18; v3 22 / 26.  v3 removes every memory round trip from the
-// per-sequence chain (SQ_WAIT_INST_ANY 7 % of wave cycles) but spends 110 SALU + 45 VALU + 2.3 LDS instructions per
-// sequence at 12 waves/CU (LDS), and one wave retires an instruction of this branchy scalar code only every ~12 cycles:
-// it is instruction-issue bound, where v1 hides its L2 round trips behind 2.7x the waves.  v1 stays the default.
-static int g_lz4_variant = 0;
+// decoded output at 3815 / 7630 blocks: v1 26 / 30; v2 18; v3 22 / 26; v4 (v3 + batch execution, 7 KB of LDS per wave)
+// 44 / 45.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3.  Neither waits on memory
+// (SQ_WAIT_INST_ANY 7 % of wave cycles); a single wave retires this dependent, branchy code at ~1 instruction per 12
+// cycles, so the lever is instructions per sequence x resident waves, which is what v4 moves.  v4 is the default.
+static int g_lz4_variant = 3;
 void set_lz4_variant(int v) { g_lz4_variant = v; }
 
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
@@ -397,7 +458,11 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   if (grid > 65535) grid = 65535;
   if (g_lz4_variant == 0) hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
   else if (g_lz4_variant == 1) hipLaunchKernelGGL(k_lz4_decode_lds, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
-  else hipLaunchKernelGGL(k_lz4_decode_v3, dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+  else if (g_lz4_variant == 2) hipLaunchKernelGGL((k_lz4_decode_v3<kV3Waves, false, 8192, 4096, 1>), dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+  else {
+    int64_t g4 = ((int64_t)nblocks + kV4Waves - 1) / kV4Waves; if (g4 > (1 << 20)) g4 = 1 << 20;
+    hipLaunchKernelGGL((k_lz4_decode_v3<kV4Waves, true, 4096, 2048, 512>), dim3((unsigned)g4), dim3(kV4Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+  }
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

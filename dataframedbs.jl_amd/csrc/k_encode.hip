@@ -25,7 +25,6 @@ __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
   typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
   return *(const u32u*)p;
 }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // length field continuation bytes (255, 255, ..., rest) for a value that did not fit the 4-bit token field
 __device__ __forceinline__ uint32_t put_length(uint8_t* out, uint32_t op, uint32_t rem, uint32_t lane) {

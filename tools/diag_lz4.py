@@ -14,7 +14,7 @@ ctx = dfdb.default_context(0)
 ctx.set_option("lz4_variant", variant)
 rng = np.random.default_rng(1)
 n = 200_003
-cols = {"a": O.gen_i64(0x9E3779B97F4A7C15, 0, n), "iota": np.arange(1, n + 1, dtype=np.int64), "zeros": np.zeros(n, np.int64),
+cols = {"a": O.gen_i64(0x9E3779B97F4A7C15, 0, n), "x": O.gen_f64(1, 0, n), "iota": np.arange(1, n + 1, dtype=np.int64), "zeros": np.zeros(n, np.int64),
         "rnd": rng.integers(-2**62, 2**62, n).astype(np.int64), "i16": rng.integers(-300, 300, n).astype(np.int16),
         "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n]}
 d = tempfile.mkdtemp()
