@@ -309,11 +309,18 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __r
         if (d0 + cs <= out_cap) {
           uint8_t* dp = out_bytes + d0;
           uint32_t b = 0;
-          for (; b + 8 <= cs; b += 8) {                      // unaligned 8-byte moves stay inside this row's bytes
-            typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
-            *(u64u*)(dp + b) = *(const u64u*)(sp + b);
+          typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+          for (; b + 8 <= cs; b += 8) *(u64u*)(dp + b) = *(const u64u*)(sp + b);   // unaligned 8-byte moves inside this row's bytes
+          const uint32_t rem = cs - b;                         // 0..7 bytes left: ONE 8-byte load (the arena is padded), <= 3 stores
+          if (rem) {
+            typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+            typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
+            uint64_t v = *(const u64u*)(sp + b);
+            uint8_t* d = dp + b;
+            if (rem & 4u) { *(u32u*)d = (uint32_t)v; d += 4; v >>= 32; }
+            if (rem & 2u) { *(u16u*)d = (uint16_t)v; d += 2; v >>= 16; }
+            if (rem & 1u) *d = (uint8_t)v;
           }
-          for (; b < cs; b++) dp[b] = sp[b];
         }
       }
       drun += (int64_t)__shfl(incl, 63, 64);
