@@ -87,6 +87,13 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
     delete ctx;
   });
 }
+int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) { return guard([&] { NEEDQ(q); NEED(out); stream_open(q, chunk_blocks, out); }); }
+int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row) {
+  return guard([&] { NEED(s); NEED(chunk); *chunk = nullptr; *chunk = stream_next(s, chunk_rows, first_row); });
+}
+int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats) { return guard([&] { NEED(s); NEED(stats); stream_stats(s, stats); }); }
+int32_t dfdb_stream_close(dfdb_stream* s) { return guard([&] { stream_close(s); }); }
+
 int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx) { return guard([&] { NEED(ctx); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
 int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out) {
   return guard([&] {
@@ -282,3 +289,13 @@ int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { retu
 int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQ(q); query_aggregate(q, op, i, out_i, out_f); }); }
 
 }  // extern "C"
+
+namespace dfdb {
+// a second context on the same device with its own stream and the same options (stream.cpp: loader / consumer slots)
+int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out) {
+  const int32_t rc = dfdb_ctx_create(like->device, nullptr, out);
+  if (rc == 0) (*out)->options = like->options;
+  return rc;
+}
+void ctx_destroy(dfdb_ctx* c) { (void)dfdb_ctx_destroy(c); }
+}  // namespace dfdb

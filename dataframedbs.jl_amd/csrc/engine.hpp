@@ -51,6 +51,10 @@ struct dfdb_table {
   int64_t row_base = 0;        // global 0-based row of local row 0 (block-range shard)
   int64_t block_first = 0;     // first resident block
   std::vector<dfdb_query*> queries;   // live queries over this table (orphaned, not dangling, when the table closes)
+  // block-loading scratch (compressed bytes staged in HBM, packed bodies, block descriptors).  Freed after a load unless
+  // the table is a stream slot that reloads a new block range every few milliseconds (hipMalloc/hipFree would dominate).
+  dfdb::DevBuf ld_staged, ld_bodies, ld_blocks, ld_status, ld_aux;
+  bool keep_load_scratch = false;
 };
 
 struct dfdb_query {
@@ -86,6 +90,13 @@ int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
+// stream.cpp: block-streamed execution over a non-resident table
+void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
+dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
+void stream_close(dfdb_stream* s);
+void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
+int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
+void ctx_destroy(dfdb_ctx* c);
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp
 void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
 void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p);       // add_column!(t, name, lazy column)

@@ -1,0 +1,331 @@
+// stream.cpp — block-streamed execution of a query over a table that is NOT resident in HBM:
+// the reference's Base.iterate(::BlocksIterator) (src/io/blocksiterator.jl:98-145) at the granularity of a CHUNK of
+// blocks instead of one block.
+//
+// Each call of stream_next() hands out a query over the next chunk (block range [b0, b1) of every required column,
+// decoded in HBM); the caller uses the ordinary dfdb_count / dfdb_select_indices / dfdb_materialize on it, exactly
+// as the reference's consumers use the NamedTuple an iteration yields (valid until the next iterate).  While the
+// caller works on chunk i, a loader thread reads the compressed bytes of chunk i+1 from the column files, copies
+// them to the device and LZ4-decodes them on ITS OWN HIP stream (two contexts, two streams, alternating slots),
+// so file I/O, PCIe, K7 and the scan/gather kernels overlap.  HBM holds two chunks, never the table.
+//
+// The reference's per-stage running state carries over between chunks the same way it carries over between blocks:
+//   * a leading range stage numbers table rows            -> dfdb_table row_base = b0 * block_size
+//   * a range stage after a predicate numbers survivors    -> stage_base += survivors of the chunk (RangeToProcess.offset,
+//     selection.jl:68-75,107)
+//   * skip_if_can / is_finished (selection.jl:177-196)     -> chunks before the first requested row are never read, and the
+//     stream ends as soon as a range stage has passed its last element
+#include "engine.hpp"
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <fcntl.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
+#include <chrono>
+
+namespace dfdb {
+
+void required_columns(const Node& n, std::vector<int>& out);
+
+namespace {
+
+struct BlockLoc { int64_t off; int32_t rows; int64_t origin, compressed; };
+
+// read_sizes over a column file without reading the bodies (BlockStreams.jl:68-78: read header, skip(io, compressed))
+std::vector<BlockLoc> index_blocks(const Column& c) {
+  std::vector<BlockLoc> v;
+  const int fd = open(c.file.c_str(), O_RDONLY);
+  if (fd < 0) fail(DFDB_ERR_IO, "column file '%s' for column %s don't exists", c.file.c_str(), c.name.c_str());
+  const off_t end = lseek(fd, 0, SEEK_END);
+  off_t pos = (off_t)c.data_off;
+  uint8_t h[20];
+  while (pos < end) {
+    if (pread(fd, h, 20, pos) != 20) { close(fd); fail(DFDB_ERR_FORMAT, "truncated block header in %s", c.file.c_str()); }
+    BlockLoc b; b.off = pos; memcpy(&b.rows, h, 4); memcpy(&b.origin, h + 4, 8); memcpy(&b.compressed, h + 12, 8);
+    if (b.rows < 0 || b.origin < 0 || b.compressed < 0 || b.compressed > end - pos - 20) { close(fd); fail(DFDB_ERR_FORMAT, "corrupt block header in %s", c.file.c_str()); }
+    pos += 20 + b.compressed;
+    v.push_back(b);
+  }
+  close(fd);
+  return v;
+}
+
+struct Slot {
+  dfdb_ctx* ctx = nullptr;
+  dfdb_table* tbl = nullptr;
+  dfdb_query* q = nullptr;
+  int64_t b0 = 0, b1 = 0;
+  bool loading = false;            // a load of this slot is queued or running on the loader thread
+  bool has_chunk = false;          // tbl holds a decoded chunk the caller may be using
+  int err_code = 0; std::string err_msg;
+  uint8_t* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for the file bytes (DMA-able: the H2D copy is truly async)
+};
+
+}  // namespace
+}  // namespace dfdb
+
+using namespace dfdb;
+
+struct dfdb_stream {
+  dfdb_query* src = nullptr;       // the caller's query (stages + projection) over the non-resident table
+  dfdb_table* t = nullptr;
+  int64_t chunk_blocks = 0, nblocks = 0, next_block = 0;
+  std::vector<int> required;       // table ordinals the query touches
+  std::vector<std::vector<BlockLoc>> index;   // per required column
+  std::vector<int64_t> base;       // per stage: survivors of stages [0,k) in the chunks already consumed
+  Slot slot[2];
+  int cur = -1;                    // slot handed to the caller (-1: none yet)
+  bool done = false;
+  int64_t compressed = 0, uncompressed = 0, rows = 0;
+  // ONE loader thread for the life of the stream (a fresh host thread pays the HIP runtime's per-thread set-up, ~45 ms,
+  // on its first call): requests are slot numbers, completion is signalled per slot
+  std::thread loader;
+  std::mutex mu; std::condition_variable cv;
+  int request = -1;                // slot to load, -1 = none
+  bool quit = false;
+  bool slot_done[2] = {false, false};
+};
+
+namespace dfdb {
+
+
+namespace {
+
+// file bytes [lo, hi) -> dst with a few concurrent preads (page cache -> pinned memory is a memcpy: one core moves ~5 GB/s)
+bool read_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi) {
+  const int fd = open(file.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  const int64_t n = hi - lo;
+  const int parts = n > (8 << 20) ? 4 : 1;
+  std::vector<std::thread> th;
+  std::vector<char> ok((size_t)parts, 1);
+  for (int k = 0; k < parts; k++) {
+    const int64_t a = lo + n * k / parts, b = lo + n * (k + 1) / parts;
+    auto work = [fd, dst, lo, a, b, k, &ok] {
+      int64_t got = a;
+      while (got < b) { const ssize_t r = pread(fd, dst + (got - lo), (size_t)(b - got), (off_t)got); if (r <= 0) { ok[(size_t)k] = 0; return; } got += r; }
+    };
+    if (k + 1 < parts) th.emplace_back(work); else work();
+  }
+  for (auto& t : th) t.join();
+  close(fd);
+  for (char c : ok) if (!c) return false;
+  return true;
+}
+
+// loader thread: column files -> HBM (decoded) for blocks [b0, b1), into the slot's persistent table (buffers are reused)
+void load_chunk(dfdb_stream* s, Slot* sl) {
+  try {
+    HIP_CHECK(hipSetDevice(sl->ctx->device));
+    dfdb_table* tb = sl->tbl;
+    tb->nrows = -1; tb->block_first = 0;
+    for (Column& c : tb->cols) c.resident = false;
+    for (size_t k = 0; k < s->required.size(); k++) {
+      const Column& c = s->t->cols[(size_t)s->required[k]];
+      const std::vector<BlockLoc>& ix = s->index[k];
+      const int64_t lo = ix[(size_t)sl->b0].off, hi = ix[(size_t)sl->b1 - 1].off + 20 + ix[(size_t)sl->b1 - 1].compressed;
+      const size_t need = c.data_off + (size_t)(hi - lo);
+      if (need > sl->pin_cap) {
+        if (sl->pin) (void)hipHostFree(sl->pin);
+        sl->pin = nullptr; sl->pin_cap = 0;
+        HIP_CHECK(hipHostMalloc((void**)&sl->pin, need + need / 4, hipHostMallocDefault));
+        sl->pin_cap = need + need / 4;
+      }
+      // the column header (re-validated by the loader), then the blocks
+      const auto t0 = std::chrono::steady_clock::now();
+      if (!read_range(c.file, sl->pin, 0, (int64_t)c.data_off) || !read_range(c.file, sl->pin + c.data_off, lo, hi))
+        fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      const auto t1 = std::chrono::steady_clock::now();
+      dfdb_sizestats st{0, 0, 0};
+      table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st);
+      if (getenv("DFDB_STREAM_DEBUG")) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[stream] blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n", (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)(hi - lo) / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
+      }
+    }
+    tb->block_first = 0;
+    tb->row_base = sl->b0 * s->t->block_size;
+    sl->has_chunk = true;
+  } catch (const Error& e) { sl->err_code = e.code; sl->err_msg = e.what(); }
+  catch (const std::exception& e) { sl->err_code = DFDB_ERR_DEVICE; sl->err_msg = e.what(); }
+}
+
+void wait_loaded(dfdb_stream* s, Slot& sl) {
+  if (!sl.loading) return;
+  std::unique_lock<std::mutex> lk(s->mu);
+  const int idx = (int)(&sl - s->slot);
+  s->cv.wait(lk, [&] { return s->slot_done[idx]; });
+  sl.loading = false;
+}
+void release_slot(dfdb_stream* s, Slot& sl) {   // the caller is done with this slot's chunk (buffers stay for the next one)
+  wait_loaded(s, sl);
+  (void)hipStreamSynchronize(sl.ctx->stream);
+  sl.has_chunk = false;
+}
+void loader_main(dfdb_stream* s) {
+  for (;;) {
+    int idx;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->quit || s->request >= 0; });
+      if (s->quit) return;
+      idx = s->request; s->request = -1;
+    }
+    load_chunk(s, &s->slot[idx]);
+    { std::lock_guard<std::mutex> lk(s->mu); s->slot_done[idx] = true; }
+    s->cv.notify_all();
+  }
+}
+
+bool range_like(const Stage& st) { return st.kind != ST_PRED; }
+
+// start loading the next chunk that can still contribute rows into `sl`; false when the stream is exhausted
+bool prefetch(dfdb_stream* s, Slot* sl) {
+  const int64_t B = s->t->block_size;
+  // skip_if_can (selection.jl:177-190): a leading range stage whose first element lies beyond a chunk skips it unread
+  if (!s->src->stages.empty() && range_like(s->src->stages[0])) {
+    const Stage& st = s->src->stages[0];
+    const bool empty = (st.kind == ST_RANGE && st.n == 0) || (st.kind != ST_RANGE && st.idx.empty());
+    if (empty) return false;
+    const int64_t first_block = (st.first() - 1) / B;
+    if (first_block > s->next_block) s->next_block = (first_block / s->chunk_blocks) * s->chunk_blocks;   // keep chunk boundaries fixed
+    if (st.last() <= s->next_block * B) return false;                                  // is_finished (:192-196)
+  }
+  if (s->next_block >= s->nblocks) return false;
+  sl->b0 = s->next_block; sl->b1 = std::min(s->nblocks, s->next_block + s->chunk_blocks);
+  s->next_block = sl->b1;
+  sl->err_code = 0; sl->err_msg.clear();
+  sl->loading = true;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    const int idx = (int)(sl - s->slot);
+    s->slot_done[idx] = false; s->request = idx;
+  }
+  s->cv.notify_all();
+  return true;
+}
+
+}  // namespace
+
+static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s);
+void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) {
+  if (q->t->path.empty()) fail(DFDB_ERR_ARGUMENT, "streaming needs a table opened from files (dfdb_table_open)");
+  dfdb_stream* s = new dfdb_stream();
+  try { stream_open_impl(q, chunk_blocks, s); } catch (...) { stream_close(s); throw; }
+  *out = s;
+}
+static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s) {
+  dfdb_table* t = q->t;
+  s->src = q; s->t = t;
+  // one block is decoded by one wave in ~30-50 ms however many run beside it (K7 is serial inside a block), so a chunk
+  // should hold thousands of blocks: 4096 blocks = 2 GB of Int64 per slot
+  s->chunk_blocks = chunk_blocks > 0 ? chunk_blocks : 4096;
+  // required_columns(view) (view.jl:183-190): selection columns first, then projection-only columns
+  std::vector<int> req;
+  for (const Stage& st : q->stages) if (st.kind == ST_PRED) required_columns(*st.pred, req);
+  for (const ProjCol& p : q->proj) required_columns(*p.expr, req);
+  if (req.empty() && !t->cols.empty()) req.push_back(0);   // the row count of a block must come from some column (blocksiterator.jl:30)
+  std::sort(req.begin(), req.end()); req.erase(std::unique(req.begin(), req.end()), req.end());
+  s->required = req;
+  for (int o : req) {
+    const Column& c = t->cols[(size_t)o];
+    if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
+    s->index.push_back(index_blocks(c));
+  }
+  s->nblocks = s->index.empty() ? 0 : (int64_t)s->index[0].size();
+  for (size_t k = 0; k < s->index.size(); k++) {
+    if ((int64_t)s->index[k].size() != s->nblocks) fail(DFDB_ERR_FORMAT, "columns of %s have different block counts", t->path.c_str());
+    for (int64_t b = 0; b < s->nblocks; b++) {
+      if (s->index[k][(size_t)b].rows != s->index[0][(size_t)b].rows) fail(DFDB_ERR_FORMAT, "columns of %s have different block boundaries", t->path.c_str());
+      if (b + 1 < s->nblocks && s->index[k][(size_t)b].rows != t->block_size) fail(DFDB_ERR_FORMAT, "block %lld holds %d rows, expected block_size %lld", (long long)b, s->index[k][(size_t)b].rows, (long long)t->block_size);
+      s->compressed += s->index[k][(size_t)b].compressed + 24; s->uncompressed += s->index[k][(size_t)b].origin;
+    }
+  }
+  for (int64_t b = 0; b < s->nblocks; b++) s->rows += s->index[0][(size_t)b].rows;
+  s->base.assign(q->stages.size(), 0);
+  for (int i = 0; i < 2; i++) {
+    Slot& sl = s->slot[i];
+    if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context");
+    auto tb = std::make_unique<dfdb_table>();            // the slot's chunk table: same columns, its own stream, reused buffers
+    tb->ctx = sl.ctx; tb->path = t->path; tb->block_size = t->block_size; tb->format_version = t->format_version;
+    tb->keep_load_scratch = true;
+    for (const Column& c : t->cols) { Column n; n.name = c.name; n.id = c.id; n.dtype = c.dtype; n.file = c.file; n.data_off = c.data_off; tb->cols.push_back(std::move(n)); }
+    auto cq = std::make_unique<dfdb_query>();             // the caller's query re-stated over the chunk table
+    cq->t = tb.get();
+    for (const Stage& st : q->stages) {
+      Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx;
+      if (st.pred) c.pred = st.pred->clone();
+      cq->stages.push_back(std::move(c));
+    }
+    for (const ProjCol& p : q->proj) cq->proj.push_back(ProjCol{p.name, p.expr->clone()});
+    tb->queries.push_back(cq.get());
+    sl.tbl = tb.release(); sl.q = cq.release();
+  }
+  s->loader = std::thread(loader_main, s);
+  if (!prefetch(s, &s->slot[0])) s->done = true;
+}
+
+// the next chunk as a query (nullptr at the end).  The previous chunk's query dies here.
+dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row) {
+  // 1. retire the chunk the caller just used: its survivors move the bases of the later range stages (RangeToProcess.offset)
+  if (s->cur >= 0) {
+    Slot& old = s->slot[s->cur];
+    if (old.has_chunk) {
+      for (size_t k = 1; k < s->src->stages.size(); k++)
+        if (range_like(s->src->stages[k])) s->base[k] += query_count(old.q, (int)k);
+      // is_finished: a range stage that has seen its last element ends the scan (selection.jl:192-196)
+      for (size_t k = 1; k < s->src->stages.size(); k++) {
+        const Stage& st = s->src->stages[k];
+        if (!range_like(st)) continue;
+        const bool empty = (st.kind == ST_RANGE && st.n == 0) || (st.kind != ST_RANGE && st.idx.empty());
+        if (empty || st.last() <= s->base[k]) s->done = true;
+      }
+    }
+  }
+  const int nxt = s->cur < 0 ? 0 : 1 - s->cur;
+  Slot& sl = s->slot[nxt];
+  if (s->cur >= 0) release_slot(s, s->slot[s->cur]);
+  if (s->done || !sl.loading) {          // nothing was prefetched: end of stream
+    if (sl.loading) release_slot(s, sl);
+    s->done = true; s->cur = -1;
+    return nullptr;
+  }
+  // 2. wait for the prefetched chunk, immediately start the one after it into the slot just retired
+  wait_loaded(s, sl);
+  if (sl.err_code) { const int c = sl.err_code; const std::string m = sl.err_msg; s->done = true; fail(c, "%s", m.c_str()); }
+  s->cur = nxt;
+  if (!prefetch(s, &s->slot[1 - nxt])) { /* last chunk */ }
+  // 3. the slot's query, re-based for this chunk
+  for (size_t k = 0; k < sl.q->stages.size(); k++) sl.q->stages[k].stage_base = s->base[k];
+  sl.q->executed_stages = -1; sl.q->count = -1; sl.q->prefix_valid = false; sl.q->bitmap_rows = -1;
+  if (chunk_rows) *chunk_rows = sl.tbl->nrows < 0 ? 0 : sl.tbl->nrows;
+  if (first_row) *first_row = sl.tbl->row_base;
+  return sl.q;
+}
+
+void stream_close(dfdb_stream* s) {
+  if (!s) return;
+  for (int i = 0; i < 2; i++) if (s->slot[i].ctx) wait_loaded(s, s->slot[i]);
+  if (s->loader.joinable()) {
+    { std::lock_guard<std::mutex> lk(s->mu); s->quit = true; }
+    s->cv.notify_all();
+    s->loader.join();
+  }
+  for (int i = 0; i < 2; i++) {
+    Slot& sl = s->slot[i];
+    if (sl.ctx) { release_slot(s, sl); }
+    delete sl.q; sl.q = nullptr;
+    delete sl.tbl; sl.tbl = nullptr;
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.ctx) ctx_destroy(sl.ctx);
+  }
+  delete s;
+}
+
+void stream_stats(const dfdb_stream* s, dfdb_sizestats* st) { st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed; }
+
+}  // namespace dfdb

@@ -207,7 +207,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
   const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
 
   // stage the compressed byte range in HBM
-  DevBuf staged, bodies, dblocks, dstatus, d_aux;
+  DevBuf &staged = t->ld_staged, &bodies = t->ld_bodies, &dblocks = t->ld_blocks, &dstatus = t->ld_status, &d_aux = t->ld_aux;
   staged.ensure((size_t)(comp_hi - comp_lo) + 64);
   if (comp_hi > comp_lo) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
 
@@ -277,6 +277,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
   }
   if (t->nrows < 0) { t->nrows = nrows; t->block_first = block_first; t->row_base = block_first * t->block_size; }
   c.resident = true;
+  if (!t->keep_load_scratch) { HIP_CHECK(hipStreamSynchronize(s)); staged.release(); bodies.release(); dblocks.release(); dstatus.release(); d_aux.release(); }
   if (stats) {   // SizeStats incl. the 24-byte header quirk (BlockStreams.jl:7,23)
     stats->rows = nrows;
     for (int64_t b = block_first; b < block_last; b++) { stats->compressed += all[b].compressed + 24; stats->uncompressed += all[b].origin; }

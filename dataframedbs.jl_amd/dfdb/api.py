@@ -717,6 +717,96 @@ class _Query:
         return of.value if dt in (ir.F32, ir.F64) else oi.value
 
 
+class _ChunkQuery(_Query):
+    """One chunk of a streamed view: the engine owns the handle (valid until the stream advances)."""
+
+    def __init__(self, view: DFView, handle, chunk_rows: int, first_row: int):
+        self.view, self._h, self.chunk_rows, self.first_row = view, handle, chunk_rows, first_row
+
+    def __del__(self):
+        pass
+
+    def bitmap(self) -> np.ndarray:
+        out = np.zeros((self.chunk_rows + 63) // 64, np.uint64)
+        if len(out):
+            N.check(N.load().dfdb_select_bitmap(self._h, out.ctypes.data, N.MEM_HOST))
+        return out
+
+
+class Stream:
+    """Base.iterate(::BlocksIterator) in chunks of blocks (blocksiterator.jl:98-145) for a view over a table that was opened
+    with load=False: `for part in dfdb.stream(v, chunk_blocks=256): part.count(), part.indices(), part.materialize()`.
+    The next chunk is read, copied and LZ4-decoded on another HIP stream while the caller works on the current one."""
+
+    def __init__(self, v: Union[DFView, DFTable], chunk_blocks: int = 4096):
+        self.view = v if isinstance(v, DFView) else DFView(v)
+        self._q = _Query(self.view)
+        self._h = C.c_void_p()
+        N.check(N.load().dfdb_stream_open(self._q._h, chunk_blocks, C.byref(self._h)))
+
+    def stats(self) -> dict:
+        st = N.SizeStats()
+        N.check(N.load().dfdb_stream_stats(self._h, C.byref(st)))
+        return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> _ChunkQuery:
+        if not self._h:
+            raise StopIteration
+        h, rows, first = C.c_void_p(), C.c_int64(), C.c_int64()
+        N.check(N.load().dfdb_stream_next(self._h, C.byref(h), C.byref(rows), C.byref(first)))
+        if not h:
+            self.close()
+            raise StopIteration
+        return _ChunkQuery(self.view, h, rows.value, first.value)
+
+    def close(self):
+        if self._h:
+            N.load().dfdb_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def __del__(self):
+        try:
+            import sys
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+
+def stream(v: Union[DFView, DFTable], chunk_blocks: int = 4096) -> Stream:
+    return Stream(v, chunk_blocks)
+
+
+def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 4096) -> int:
+    """nrow(v) without holding the table in HBM: sum of the per-chunk counts (BlockRowsIterator, view.jl:192-206)."""
+    with Stream(v, chunk_blocks) as s:
+        return sum(part.count() for part in s)
+
+
+def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 4096):
+    """materialize(v) chunk by chunk: per-chunk buffers appended on the host like materialization.jl:33-37."""
+    import pandas as pd
+    view = v if isinstance(v, DFView) else DFView(v)
+    names = view.names()
+    parts = []
+    with Stream(view, chunk_blocks) as s:
+        for part in s:
+            parts.append([_to_user(c) for c in part.materialize()])
+    if not parts:                      # nothing streamed (empty table / exhausted range): typed empty columns of the plain path
+        return pd.DataFrame({n: [] for n in names})
+    cols = {}
+    for i, n in enumerate(names):
+        chunks = [p[i] for p in parts]
+        cols[n] = np.ma.concatenate(chunks) if isinstance(chunks[0], np.ma.MaskedArray) else np.concatenate(chunks)
+    return pd.DataFrame(cols)
+
+
 def _flat_to_strings(sizes: np.ndarray, data: np.ndarray) -> List[Optional[str]]:
     out, o = [], 0
     raw = data.tobytes()

@@ -60,6 +60,7 @@ enum { DFDB_AGG_COUNT = 0, DFDB_AGG_SUM = 1, DFDB_AGG_MIN = 2, DFDB_AGG_MAX = 3 
 typedef struct dfdb_ctx dfdb_ctx;     /* device + stream + workspace */
 typedef struct dfdb_table dfdb_table; /* DFTable whose columns are decoded and resident in HBM */
 typedef struct dfdb_query dfdb_query; /* DFView: projection + SelectionQueue over one table */
+typedef struct dfdb_stream dfdb_stream; /* block-streamed execution of a query over a non-resident table */
 
 typedef struct dfdb_device_info {
   char name[128];
@@ -213,6 +214,20 @@ int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 /* sum/min/max/count of projection column i over the selected rows; Float64 sums are pairwise
  * (tolerance documented in DESIGN.md), integer results exact */
 int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
+
+/* ---- block-streamed execution: Base.iterate(::BlocksIterator) (src/io/blocksiterator.jl:98-145) in chunks of blocks ----
+ * For a query over a table opened with dfdb_table_open but NOT loaded (tables larger than HBM, one-off scans).  Each
+ * dfdb_stream_next yields a query over the next chunk of `chunk_blocks` blocks of every required column, decoded in HBM:
+ * use dfdb_count / dfdb_select_indices (global 1-based row numbers) / dfdb_materialize / dfdb_aggregate on it; it is
+ * owned by the stream and valid until the next dfdb_stream_next / dfdb_stream_close (never dfdb_query_free it) — the
+ * contract of the NamedTuple an iteration of the reference yields.  *chunk == NULL marks the end.  While the caller works
+ * on chunk i a loader thread reads, copies and LZ4-decodes chunk i+1 on its own HIP stream.  The per-stage running offsets
+ * of RangeToProcess (selection.jl:68-75,107), skip_if_can and is_finished (:177-196) carry over between chunks, so
+ * t[pred, :][1:100, :] or head(t) read only the chunks they need. */
+int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
+int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row);
+int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats);   /* table_stats over the required columns (headers only) */
+int32_t dfdb_stream_close(dfdb_stream* s);
 
 #ifdef __cplusplus
 }

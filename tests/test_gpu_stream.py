@@ -1,0 +1,111 @@
+"""Block-streamed execution: the same views evaluated chunk by chunk over a table that is never
+resident as a whole must give, concatenated, exactly what the oracle's block iterator gives — including range stages
+whose running offsets cross chunk boundaries, skip_if_can / is_finished, late chunks that contribute nothing."""
+import numpy as np
+import pytest
+
+from helpers import Pair, apply_stages
+
+pytestmark = pytest.mark.gpu
+SEED = 0x9E3779B97F4A7C15
+
+
+def col_seed(k):
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def files(oracle, dfdb_mod, tmp_path_factory):
+    n = 131_072 * 3 + 777          # 393 993 rows: 6 full blocks of 65 536 + 777
+    rng = np.random.default_rng(4)
+    strs = oracle.flat_to_strings(*oracle.gen_str(col_seed(3), 0, n))
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": strs,
+            "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.2),
+            "iota": np.arange(1, n + 1, dtype=np.int64)}
+    out = {}
+    for bs in (65536, 5000):
+        path = str(tmp_path_factory.mktemp("stream") / f"tb{bs}")
+        p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=path)
+        p.d.close()
+        p.d = dfdb_mod.open_table(path, load=False)      # metadata only: nothing resident
+        out[bs] = p
+    return out
+
+
+def streamed(dfdb, dv, chunk_blocks):
+    idx, cnt, cols, nchunks = [], 0, None, 0
+    with dfdb.stream(dv, chunk_blocks) as s:
+        for part in s:
+            nchunks += 1
+            c = part.count()
+            cnt += c
+            i = part.indices()
+            assert len(i) == c
+            idx.append(i)
+            got = part.materialize()
+            cols = [[g] for g in got] if cols is None else [a + [g] for a, g in zip(cols, got)]
+    return cnt, (np.concatenate(idx) if idx else np.zeros(0, np.int64)), cols, nchunks
+
+
+def check(p, stages, chunk_blocks, proj=None):
+    ov, dv = apply_stages(p, stages, proj=proj)
+    cnt, idx, cols, nchunks = streamed(p.dfdb, dv, chunk_blocks)
+    assert cnt == ov.nrow()
+    assert np.array_equal(idx, ov.select_indices())
+    want = ov.materialize()
+    if cols is None:
+        assert cnt == 0
+        return nchunks
+    for w, parts in zip(want, cols):
+        if isinstance(w, tuple):
+            assert np.array_equal(w[0], np.concatenate([g[0] for g in parts])) and np.array_equal(w[1], np.concatenate([g[1] for g in parts]))
+        elif isinstance(w, np.ma.MaskedArray):
+            g = np.ma.concatenate(parts)
+            assert np.array_equal(np.ma.getmaskarray(w), np.ma.getmaskarray(g)) and np.array_equal(w.compressed(), g.compressed())
+        else:
+            assert np.array_equal(w.view(np.uint8), np.concatenate(parts).view(np.uint8))
+    return nchunks
+
+
+@pytest.mark.parametrize("bs,chunk", [(65536, 1), (65536, 2), (65536, 100), (5000, 7), (5000, 1)])
+def test_streamed_views_equal_the_block_iterator(files, bs, chunk):
+    from dfdb import ir
+    p = files[bs]
+    a, x, s, m, iota = (ir.col(k) for k in range(5))
+    n = p.nrows
+    nblocks = -(-n // bs)
+    full = -(-nblocks // chunk)
+    assert check(p, [], chunk) == full
+    assert check(p, [("pred", a > 899_999)], chunk) == full
+    assert check(p, [("pred", (a > 500_000) & (s == "sony"))], chunk, proj=[("s", s), ("k", a * 2 + iota)]) == full
+    assert check(p, [("pred", ir.ismissing(m))], chunk, proj=[("m", m), ("x", x)]) == full
+    # a range stage AFTER a predicate numbers the survivors across chunk boundaries (RangeToProcess.offset) and ends the scan early
+    k = check(p, [("pred", a > 500_000), ("range", 1000, 1, 1999)], chunk)
+    assert k <= full
+    check(p, [("pred", a > 500_000), ("range", 10, 7, 150_000), ("pred", x < 1000.0), ("range", 5, 1, 50)], chunk)
+    check(p, [("pred", a % 3 == 0), ("idx", [5, 1, 70_000, 99_999, 5])], chunk)
+    # a LEADING range: chunks before its first row are never read (skip_if_can), chunks after its last end the stream (is_finished)
+    lo, hi = n // 2, n // 2 + 10
+    k = check(p, [("range", lo, 1, hi), ("pred", a >= 0)], chunk)
+    assert k <= 2
+    assert check(p, [("int", n)], chunk) == 1
+    assert check(p, [("range", 1, 1, 10)], chunk) == 1                       # head(t): one chunk
+    check(p, [("range", 1, 1, 0)], chunk)                                    # empty range: nothing is read
+    check(p, [("range", 1, 3, n), ("range", 100, 1, 120_000)], chunk)        # range∘range collapses to one leading stage
+
+
+def test_streamed_conveniences_and_errors(files, oracle, dfdb_mod):
+    from dfdb import ir
+    p = files[65536]
+    v = p.d[(p.d.a > 899_999), ["a", "s"]]
+    want_idx = np.nonzero(oracle.gen_i64(col_seed(0), 0, p.nrows) > 899_999)[0]
+    assert dfdb_mod.nrow_streamed(v, 2) == len(want_idx)
+    df = dfdb_mod.materialize_streamed(v, 2)
+    assert list(df.columns) == ["a", "s"] and len(df) == len(want_idx)
+    assert np.array_equal(df["a"].to_numpy(), oracle.gen_i64(col_seed(0), 0, p.nrows)[want_idx])
+    with dfdb_mod.stream(v, 3) as s:
+        st = s.stats()
+        assert st["rows"] == p.nrows and st["compressed"] < st["uncompressed"]
+    mem = dfdb_mod.DFTable.from_columns({"a": np.arange(10, dtype=np.int64)})
+    with pytest.raises(ValueError):                                           # an in-memory table has no files to stream
+        dfdb_mod.stream(mem[dfdb_mod.ALL, dfdb_mod.ALL])
