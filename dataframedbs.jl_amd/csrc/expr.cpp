@@ -41,11 +41,21 @@ int promote_num(int a, int b) {   // Julia promote_type restricted to the column
   return dt_issigned(a) ? b : a;
 }
 
-// result dtype; throws ArgumentError for Missing-propagating expressions, UNSUPPORTED for absent methods
+// result dtype; UNSUPPORTED for absent methods.  An operand of type Union{T,Missing} makes the result Union{R,Missing}
+// (every Base method on the path propagates missing; `&` / `|` with three-valued logic), except ismissing (Bool) and
+// coalesce (nullable only if its LAST argument is).  A selection function must still return plain Bool (selection.jl:52-55).
+static int infer_base(int op, int ta, int tb);
 static int infer(int op, int ta, int tb) {
   if (op == DFIR_ISMISSING) return DFDB_BOOL;
-  if (dt_nullable(ta) || (tb && dt_nullable(tb)))
-    fail(DFDB_ERR_ARGUMENT, "ArgumentError: expression over a Union{T,Missing} column yields Missing (wrap it in ismissing)");
+  if (op == DFIR_COALESCE) {
+    if (dt_base(ta) != dt_base(tb) || !dt_isnum(dt_base(ta)))
+      fail(DFDB_ERR_UNSUPPORTED, "coalesce(%s, %s): the result would be a Union of two value types", dt_name(ta).c_str(), dt_name(tb).c_str());
+    return dt_base(ta) | (dt_nullable(tb) ? DFDB_NULLABLE : 0);
+  }
+  const int r = infer_base(op, ta, tb);
+  return (dt_nullable(ta) || (tb && dt_nullable(tb))) ? (r | DFDB_NULLABLE) : r;
+}
+static int infer_base(int op, int ta, int tb) {
   const int a = dt_base(ta), b = tb ? dt_base(tb) : 0;
   auto nomethod = [&]() -> int { fail(DFDB_ERR_UNSUPPORTED, "no method for IR op 0x%02x on (%s, %s)", op, dt_name(ta).c_str(), tb ? dt_name(tb).c_str() : "-"); };
   switch (op) {
@@ -143,18 +153,17 @@ NodePtr parse_ir(const dfdb_table& t, const uint8_t* ir, size_t len) {
         n->a = pop();
         if (n->a->op == DFIR_CONST_SET) fail(DFDB_ERR_ARGUMENT, "a set is only valid as the second argument of in");
         if (op == DFIR_CAST) {
-          if (!dt_isnum(n->a->dtype) || dt_nullable(n->a->dtype) || !dt_isnum(n->cast_to) || dt_nullable(n->cast_to))
+          if (!dt_isnum(n->a->dtype) || !dt_isnum(n->cast_to) || dt_nullable(n->cast_to))
             fail(DFDB_ERR_UNSUPPORTED, "unsupported conversion %s -> %s", dt_name(n->a->dtype).c_str(), dt_name(n->cast_to).c_str());
-          n->dtype = n->cast_to;
+          n->dtype = n->cast_to | (dt_nullable(n->a->dtype) ? DFDB_NULLABLE : 0);
         } else {
-          if (op == DFIR_ISMISSING && n->a->op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "ismissing is supported on columns only");
           n->dtype = infer(op, n->a->dtype, 0);
         }
         break;
       }
       default: {
         const bool known = (op >= DFIR_ADD && op <= DFIR_MAX) || (op >= DFIR_EQ && op <= DFIR_GE) || (op >= DFIR_AND && op <= DFIR_XOR) ||
-                           op == DFIR_IN_SET || op == DFIR_STARTSWITH || op == DFIR_ENDSWITH;
+                           op == DFIR_IN_SET || op == DFIR_STARTSWITH || op == DFIR_ENDSWITH || op == DFIR_COALESCE;
         if (!known) fail(DFDB_ERR_UNSUPPORTED, "unknown IR opcode 0x%02x", op);
         n->b = pop(); n->a = pop();
         if (op == DFIR_IN_SET) {

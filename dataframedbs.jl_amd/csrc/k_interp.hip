@@ -38,8 +38,11 @@ enum Handler : uint8_t {
   H_IADD, H_ISUB, H_IMUL, H_IMIN_S, H_IMIN_U, H_IMAX_S, H_IMAX_U, H_IDIVOP, H_INEG, H_IABS, H_WRAP,
   H_BAND1, H_BOR1, H_AND, H_OR, H_XOR, H_NOT,
   H_CMP_FF, H_CMP_SS, H_CMP_UU, H_CMP_US, H_CMP_IF,
-  H_STRCMP, H_STRPRE, H_STRSUF, H_ISMISS, H_INSET, H_CAST
+  H_INSET, H_CAST,
+  // handlers that set the missing flag of their result themselves (everything above: flag = union of the operands' flags)
+  H_STRCMP, H_STRPRE, H_STRSUF, H_ISMISS, H_AND3, H_OR3, H_COALESCE, H_ISMISSA
 };
+constexpr int kFirstOwnFlag = H_STRCMP;
 enum BSrc : uint8_t { B_NONE = 0, B_IMM = 1, B_COL = 2, B_POP = 3 };
 enum Cvt : uint8_t { CV_NONE = 0, CV_S2D, CV_U2D, CV_S2F, CV_U2F, CV_D2F };
 enum : uint8_t { F_SWAP = 1,   // the fetched operand is the LEFT one: exchange A and B before the handler
@@ -82,6 +85,7 @@ struct IColDesc {
 };
 struct IProgram {
   int32_t n, ncols, result_dtype, nstr;
+  int32_t nullable_result, pad0;     // the value is Union{T,Missing}: flags are written beside it (projection)
   const uint8_t* pool;               // string patterns and set elements
   int32_t str_slot[kMaxStr];         // column slots of the string columns that need byte offsets
   IColDesc cols[kMaxCols];
@@ -241,6 +245,20 @@ __device__ __forceinline__ void load_col(const IColDesc& c, int64_t base, const 
       break;
   }
 }
+// missing flags of the rows just loaded from column c (1 = missing): one wave-uniform 64-bit word per 64 rows for a
+// fixed-width column, the sign of the size for a String
+__device__ __forceinline__ void load_missing(const IColDesc& c, int64_t base, int g, uint32_t lane, const uint64_t (&V)[kW], uint32_t (&M)[kW]) {
+  if (!(c.dtype & DFDB_NULLABLE)) {
+#pragma unroll
+    EACH M[k] = 0;
+  } else if ((c.dtype & DFDB_DTYPE_MASK) == DFDB_STRING) {
+#pragma unroll
+    EACH M[k] = (int64_t)V[k] < 0;
+  } else {
+#pragma unroll
+    EACH { const uint64_t w = c.missing ? c.missing[(base >> 6) + g * kW + k] : 0ull; M[k] = (uint32_t)(w >> lane) & 1u; }
+  }
+}
 __device__ __forceinline__ void convert(uint64_t (&X)[kW], int mode) {
   switch (mode) {
     case CV_S2D:
@@ -294,11 +312,11 @@ __device__ __forceinline__ bool cmp_pick(int op, bool lt, bool eq, bool un) {   
     }                                                                         \
   } break
 
-template <int MODE, bool STR>   // MODE 0: predicate -> bitmap ; 1: computed column at the selected rows -> compacted output
+template <int MODE, bool STR, bool NUL>   // MODE 0: predicate -> bitmap ; 1: computed column at the selected rows -> compacted output; NUL: Union{T,Missing} flags
 __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ prog, uint64_t* __restrict__ bitmap,
                                                    uint32_t* __restrict__ tile_counts, const uint64_t* __restrict__ prefix, void* __restrict__ out,
                                                    int64_t out_cap, int64_t nrows, int64_t ntiles, int and_existing, int* __restrict__ err,
-                                                   int stack_levels) {
+                                                   int stack_levels, uint8_t* __restrict__ out_missing) {
   extern __shared__ uint64_t lds[];   // [stack level | offset array][k][thread]
   const int tid = threadIdx.x, lane = lane_id();
   // everything indexed by the tile is wave-uniform (SGPRs): say so, the compiler cannot see that tid>>6 is
@@ -307,6 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
   const int nins = prog->n, rdt = prog->result_dtype, nstr = STR ? prog->nstr : 0;
   const uint8_t* pool = prog->pool;
   const bool masked = MODE == 1 || and_existing;
+  uint32_t* ldsf = (uint32_t*)(lds + (size_t)(stack_levels + nstr) * kW * kBlock);   // NUL: missing flags of the pushed values
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kTile;
     const uint32_t lastvalid = (uint32_t)(nrows - base < kTile ? nrows - base - 1 : kTile - 1);
@@ -350,8 +369,9 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
         continue;
       }
       uint64_t A[kW], B[kW];
+      uint32_t Am[kW], Bm[kW];             // NUL: 1 = the value is missing
 #pragma unroll
-      EACH { A[k] = 0; B[k] = 0; }
+      EACH { A[k] = 0; B[k] = 0; Am[k] = 0; Bm[k] = 0; }
       int sp = 0;
       for (int pc = 0; pc < nins; pc++) {
         const DInstr& in = prog->ins[pc];
@@ -361,32 +381,54 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
         if (fl & F_PUSH) {
 #pragma unroll
           EACH lds[(sp * kW + k) * kBlock + tid] = A[k];
+          if (NUL) {
+#pragma unroll
+            EACH ldsf[(sp * kW + k) * kBlock + tid] = Am[k];
+          }
           sp++;
         }
-        if (in.aslot) load_col(prog->cols[in.aslot - 1], base, idx, A);   // fused leaf load: `col OP x` is one dispatch
+        if (in.aslot) {                                                   // fused leaf load: `col OP x` is one dispatch
+          load_col(prog->cols[in.aslot - 1], base, idx, A);
+          if (NUL) load_missing(prog->cols[in.aslot - 1], base, g, (uint32_t)lane, A, Am);
+        }
         switch (in_bsrc) {
           case B_IMM: {
             const uint64_t v = in.imm;
 #pragma unroll
-            EACH B[k] = v;
+            EACH { B[k] = v; Bm[k] = 0; }
           } break;
-          case B_COL: load_col(prog->cols[in.slot], base, idx, B); break;
+          case B_COL:
+            load_col(prog->cols[in.slot], base, idx, B);
+            if (NUL) load_missing(prog->cols[in.slot], base, g, (uint32_t)lane, B, Bm);
+            break;
           case B_POP:
             sp--;
 #pragma unroll
             EACH B[k] = lds[(sp * kW + k) * kBlock + tid];
+            if (NUL) {
+#pragma unroll
+              EACH Bm[k] = ldsf[(sp * kW + k) * kBlock + tid];
+            }
+            break;
+          default:
+#pragma unroll
+            EACH Bm[k] = 0;
             break;
         }
         if (fl & F_SWAP) {
 #pragma unroll
-          EACH { const uint64_t t = A[k]; A[k] = B[k]; B[k] = t; }
+          EACH { const uint64_t t = A[k]; A[k] = B[k]; B[k] = t; const uint32_t tm = Am[k]; Am[k] = Bm[k]; Bm[k] = tm; }
+        }
+        if (NUL && in_h != H_LOAD && in_h < kFirstOwnFlag) {              // Base methods propagate missing
+#pragma unroll
+          EACH Am[k] |= Bm[k];
         }
         if (in_cva) convert(A, in_cva);
         if (in_cvb) convert(B, in_cvb);
         switch (in_h) {
           case H_LOAD:
 #pragma unroll
-            EACH A[k] = B[k];
+            EACH { A[k] = B[k]; Am[k] = Bm[k]; }
             break;
           case H_FADD: FLOAT_OP(v = a + b);
           case H_FSUB: FLOAT_OP(v = a - b);
@@ -417,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
             const int op = in_cmp; const bool uns = (fl & F_UNS) != 0; const int64_t tmin = (int64_t)in.imm2;
 #pragma unroll
             EACH {
-              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull);
+              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);   // missing ÷ x is missing, not an error
               const int64_t a = (int64_t)wrapv(A[k], wsh, wsg), b = (int64_t)wrapv(B[k], wsh, wsg);
               const uint64_t v = slow_idivop(a, b, op, uns, tmin, alive, err);
               A[k] = wrapv(v, wsh, wsg);
@@ -469,13 +511,41 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
               const int len = (inb[k] && sz > 0) ? sz : 0;
               const uint8_t* p = c.bytes + (int64_t)lds[((stack_levels + so) * kW + k) * kBlock + tid];
               A[k] = slow_strop(h == H_STRCMP, h == H_STRSUF, p, len, pat, pl, op, flip);
+              Am[k] = (NUL && (c.dtype & DFDB_NULLABLE)) ? (uint32_t)(sz < 0) : 0u;
             }
           } break;
           case H_ISMISS: {
             const uint64_t* m = prog->cols[in.slot].missing;
 #pragma unroll
-            EACH { const int64_t lrow = base + idx[k]; A[k] = m ? ((m[lrow >> 6] >> (lrow & 63)) & 1ull) : 0ull; }
+            EACH { const int64_t lrow = base + idx[k]; A[k] = m ? ((m[lrow >> 6] >> (lrow & 63)) & 1ull) : 0ull; Am[k] = 0; }
           } break;
+          // three-valued logic on Bool (Julia: false & missing == false, true | missing == true): one known operand can settle it
+          case H_AND3:
+#pragma unroll
+            EACH {
+              const uint32_t a = (uint32_t)A[k] & 1u, b = (uint32_t)B[k] & 1u, am = Am[k], bm = Bm[k];
+              const uint32_t decided = (!am && !a) || (!bm && !b);
+              Am[k] = (am | bm) && !decided;
+              A[k] = decided ? 0u : (a & b);
+            }
+            break;
+          case H_OR3:
+#pragma unroll
+            EACH {
+              const uint32_t a = (uint32_t)A[k] & 1u, b = (uint32_t)B[k] & 1u, am = Am[k], bm = Bm[k];
+              const uint32_t decided = (!am && a) || (!bm && b);
+              Am[k] = (am | bm) && !decided;
+              A[k] = decided ? 1u : (a | b);
+            }
+            break;
+          case H_COALESCE:   // the first non-missing argument
+#pragma unroll
+            EACH { if (Am[k]) A[k] = B[k]; Am[k] &= Bm[k]; }
+            break;
+          case H_ISMISSA:    // ismissing of a computed value
+#pragma unroll
+            EACH { A[k] = Am[k]; Am[k] = 0; }
+            break;
           case H_INSET: {
             const uint64_t* set = (const uint64_t*)(pool + in.imm);
             const int ta = in.w2 & 0xff, tb = (in.w2 >> 8) & 0xff, n = in.len;
@@ -486,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
             const int ta = in.w2 & 0xff, rt = (in.w2 >> 16) & 0xff;
 #pragma unroll
             EACH {
-              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull);
+              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);
               A[k] = slow_cast(A[k], ta, rt, alive, err);
             }
           } break;
@@ -516,6 +586,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
               case DFDB_F32: ((float*)out)[o] = (float)bits_d(res); break;
               default: ((uint64_t*)out)[o] = res; break;
             }
+            if (NUL && out_missing) out_missing[o] = (uint8_t)Am[k];
           }
           run_sel += (uint32_t)__popcll(maskword[k]);
         }
@@ -540,6 +611,7 @@ struct Compiler {
   std::vector<int> col_ord;   // slot -> table ordinal
   std::vector<IInstr> code;
   bool a_live = false;        // A holds a value that a later instruction still needs
+  bool nul = false;           // some value of the program is Union{T,Missing}: the kernel carries missing flags
   int sp = 0, max_sp = 0;
 
   int slot_for(int ordinal) {
@@ -675,6 +747,7 @@ struct Compiler {
 
   // emit code that leaves the value of n in A
   void eval(const Node& n) {
+    if (dt_nullable(n.dtype)) nul = true;
     if (leaf(n)) { load_leaf(n); return; }
     if (n.op == DFIR_COL) { IInstr& in = fresh(H_LOAD); in.bsrc = B_COL; in.slot = slot_for(n.col); return; }   // String column: its size
     if (n.op == DFIR_CONST_STR || n.op == DFIR_CONST_SET) fail(DFDB_ERR_UNSUPPORTED, "string/set constant in an unsupported position");
@@ -683,9 +756,9 @@ struct Compiler {
     if (a_str || b_str) {   // string forms: column vs constant only
       if (n.op == DFIR_SIZEOF || n.op == DFIR_ISMISSING) {
         if (n.a->op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "sizeof/ismissing need a String column");
-        eval(*n.a);                                    // the Int32 size; -1 = missing
+        eval(*n.a);                                    // the Int32 size; -1 = missing (the load also raises the missing flag)
         if (n.op == DFIR_SIZEOF) { IInstr& in = ins(H_IMAX_S); in.bsrc = B_IMM; in.imm = 0; }
-        else { IInstr& in = ins(H_CMP_SS); in.bsrc = B_IMM; in.imm = 0; in.cmp = DFIR_LT; }
+        else { nul = true; ins(H_ISMISSA); }           // the flag becomes the (never missing) Bool value
         return;
       }
       const Node *cn = nullptr, *sn = nullptr; bool flipped = false;
@@ -700,8 +773,15 @@ struct Compiler {
       return;
     }
     if (n.op == DFIR_ISMISSING) {
-      if (n.a->op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "ismissing needs a column");
-      IInstr& in = fresh(H_ISMISS); in.slot = slot_for(n.a->col);
+      if (n.a->op == DFIR_COL) { IInstr& in = fresh(H_ISMISS); in.slot = slot_for(n.a->col); return; }
+      nul = true;
+      eval(*n.a);                                      // ismissing of a computed value: its flag becomes the value
+      ins(H_ISMISSA);
+      return;
+    }
+    if (n.op == DFIR_COALESCE) {
+      IInstr* pin = nullptr; nul = true;
+      fetch_operands(n, pin, H_COALESCE);
       return;
     }
     if (n.op == DFIR_IN_SET) {
@@ -768,6 +848,10 @@ struct Compiler {
       return;
     }
     if (n.op >= DFIR_AND && n.op <= DFIR_XOR) {
+      if (n.op != DFIR_XOR && rt == DFDB_BOOL && dt_nullable(n.dtype)) {   // Bool & / | over Union{Bool,Missing}: three-valued
+        fetch_operands(n, pin, n.op == DFIR_AND ? H_AND3 : H_OR3);
+        return;
+      }
       fetch_operands(n, pin, n.op == DFIR_AND ? H_AND : (n.op == DFIR_OR ? H_OR : H_XOR));
       wrap_of(*pin, rt);
       return;
@@ -782,11 +866,14 @@ struct Compiler {
     for (size_t i = 0; i < code.size(); i++) prog.ins[i] = pack_instr(code[i]);
     prog.ncols = (int32_t)col_ord.size();
     prog.result_dtype = dt_base(root.dtype);
+    prog.nullable_result = dt_nullable(root.dtype) ? 1 : 0;
+    if (prog.nullable_result) nul = true;
+    for (int i = 0; i < prog.ncols; i++) if (dt_nullable(prog.cols[i].dtype) && !nul) { /* a nullable column read only through ismissing(col) */ }
     if (max_sp + prog.nstr > kMaxLds) fail(DFDB_ERR_UNSUPPORTED, "expression too deep for the device interpreter");
   }
 };
 
-static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_existing, void* out, int64_t cap) {
+static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_existing, void* out, int64_t cap, uint8_t* out_missing) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   Compiler c; c.t = t; c.compile(root);
   // device copies: [IProgram][pool][err]
@@ -802,15 +889,20 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   if (ntiles == 0) return;
   int64_t grid = ceil_div(ntiles, kWavesPerBlock); if (grid > 16384) grid = 16384;
   int* derr = (int*)(db.as<uint8_t>() + err_off);
-  const size_t lds_bytes = (size_t)(c.max_sp + c.prog.nstr) * kW * kBlock * sizeof(uint64_t);
+  const size_t lds_bytes = (size_t)(c.max_sp + c.prog.nstr) * kW * kBlock * sizeof(uint64_t) + (c.nul ? (size_t)c.max_sp * kW * kBlock * sizeof(uint32_t) : 0);
   {
     LaunchTimer lt(ctx, mode == 0 ? "interp_predicate" : "interp_project");
     const bool str = c.prog.nstr > 0;
-#define DFDB_INTERP_LAUNCH(M, S, AE)                                                                                                        \
-    hipLaunchKernelGGL((k_interp<M, S>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, s, (const IProgram*)db.p, q->bitmap.as<uint64_t>(), \
-                       q->tile_counts.as<uint32_t>(), q->prefix.as<uint64_t>(), out, cap, t->nrows, ntiles, AE, derr, c.max_sp)
-    if (mode == 0) { if (str) DFDB_INTERP_LAUNCH(0, true, and_existing ? 1 : 0); else DFDB_INTERP_LAUNCH(0, false, and_existing ? 1 : 0); }
-    else { if (str) DFDB_INTERP_LAUNCH(1, true, 1); else DFDB_INTERP_LAUNCH(1, false, 1); }
+#define DFDB_INTERP_LAUNCH(M, S, NL, AE)                                                                                                        \
+    hipLaunchKernelGGL((k_interp<M, S, NL>), dim3((unsigned)grid), dim3(kBlock), lds_bytes, s, (const IProgram*)db.p, q->bitmap.as<uint64_t>(), \
+                       q->tile_counts.as<uint32_t>(), q->prefix.as<uint64_t>(), out, cap, t->nrows, ntiles, AE, derr, c.max_sp, out_missing)
+#define DFDB_INTERP_PICK(M, AE)                                                                                                     \
+    do {                                                                                                                            \
+      if (c.nul) { if (str) DFDB_INTERP_LAUNCH(M, true, true, AE); else DFDB_INTERP_LAUNCH(M, false, true, AE); }                  \
+      else       { if (str) DFDB_INTERP_LAUNCH(M, true, false, AE); else DFDB_INTERP_LAUNCH(M, false, false, AE); }                \
+    } while (0)
+    if (mode == 0) DFDB_INTERP_PICK(0, and_existing ? 1 : 0); else DFDB_INTERP_PICK(1, 1);
+#undef DFDB_INTERP_PICK
 #undef DFDB_INTERP_LAUNCH
     HIP_CHECK(hipGetLastError());
   }
@@ -821,7 +913,8 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   if (herr & 2) fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
 }
 
-void run_interp_predicate(dfdb_query* q, const Node& pred, bool and_existing) { run_interp(q, pred, 0, and_existing, nullptr, 0); }
-void run_interp_project(dfdb_query* q, const Node& expr, void* dst, int64_t cap) { run_interp(q, expr, 1, true, dst, cap); }
+void run_interp_predicate(dfdb_query* q, const Node& pred, bool and_existing) { run_interp(q, pred, 0, and_existing, nullptr, 0, nullptr); }
+// missing_dst: one byte per selected row (1 = missing) when the expression is Union{T,Missing}; may be null
+void run_interp_project(dfdb_query* q, const Node& expr, void* dst, int64_t cap, uint8_t* missing_dst) { run_interp(q, expr, 1, true, dst, cap, missing_dst); }
 
 }  // namespace dfdb

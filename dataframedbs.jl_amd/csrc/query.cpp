@@ -17,7 +17,7 @@ namespace dfdb {
 
 // launchers living in k_interp.hip / k_strings.hip that take engine-level descriptions
 void run_interp_predicate(dfdb_query* q, const Node& pred, bool and_existing);
-void run_interp_project(dfdb_query* q, const Node& expr, void* dst, int64_t cap);
+void run_interp_project(dfdb_query* q, const Node& expr, void* dst, int64_t cap, uint8_t* missing_dst);
 
 // ---------------------------------------------------------------- ranges
 static int64_t range_len(int64_t a, int64_t s, int64_t b) {
@@ -352,10 +352,16 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
     if (!dev) stream_wait(ctx);   // staging buffers die at scope exit; device outputs stay stream-ordered, no host wait
   } else {                  // BroadcastExecutor: computed column (projection.jl:128-129)
     if (dt_base(e.dtype) == DFDB_STRING) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
-    DevBuf stage; void* dst = o.data;
+    DevBuf stage, mstage; void* dst = o.data;
     if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
-    run_interp_project(q, e, dst, cnt);
-    if (!dev) { HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
+    uint8_t* mdst = nullptr;                               // Union{R,Missing} result: one flag byte per selected row
+    if (dt_nullable(e.dtype) && o.missing) { mdst = o.missing; if (!dev) { mstage.ensure((size_t)cnt); mdst = mstage.as<uint8_t>(); } }
+    run_interp_project(q, e, dst, cnt, mdst);
+    if (!dev) {
+      HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
+      if (mdst) HIP_CHECK(hipMemcpyAsync(o.missing, mdst, (size_t)cnt, hipMemcpyDeviceToHost, s));
+      stream_wait(ctx);
+    }
   }
 }
 
@@ -422,7 +428,7 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
   else {   // computed column: materialise the selected values, then reduce them all
     const int64_t cnt = query_count(q, -1);
     full.ensure((size_t)std::max<int64_t>(cnt, 1) * dt_width(dt) + 256);
-    if (cnt) run_interp_project(q, e, full.p, cnt);
+    if (cnt) run_interp_project(q, e, full.p, cnt, nullptr);
     const size_t nw = padded_words(cnt);
     ones.ensure(nw * 8);
     HIP_CHECK(hipMemsetAsync(ones.p, 0xff, (size_t)(cnt / 64) * 8, s));

@@ -992,6 +992,14 @@ sizeof = _fn_bc(ir.sizeof)
 float64 = _fn_bc(ir.float64)
 
 
+def coalesce(c, default):
+    """coalesce.(col, default): DFColumn or Expr; `default` may itself be a column of the same view."""
+    if isinstance(c, DFColumn):
+        d = default.expr if isinstance(default, DFColumn) else default
+        return DFColumn(DFView(c.view.table, Projection({"a": ir.coalesce(c.expr, d)}), c.view.selection))
+    return ir.coalesce(c, default)
+
+
 def view_from_columns(**cols: DFColumn) -> DFView:
     """DFView(a = col1, g = col2) (column.jl:143-164)."""
     first = None

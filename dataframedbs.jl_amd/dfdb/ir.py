@@ -55,7 +55,7 @@ COL, CONST, CONST_STR, CONST_SET = 0x01, 0x02, 0x03, 0x04
 ADD, SUB, MUL, DIV, IDIV, REM, MOD, NEG, ABS, MIN, MAX = 0x10, 0x11, 0x12, 0x13, 0x14, 0x15, 0x16, 0x17, 0x18, 0x19, 0x1A
 EQ, NE, LT, LE, GT, GE = 0x20, 0x21, 0x22, 0x23, 0x24, 0x25
 AND, OR, XOR, NOT = 0x30, 0x31, 0x32, 0x33
-IN_SET, STARTSWITH, ENDSWITH, ISMISSING, SIZEOF = 0x40, 0x41, 0x42, 0x43, 0x44
+IN_SET, STARTSWITH, ENDSWITH, ISMISSING, SIZEOF, COALESCE = 0x40, 0x41, 0x42, 0x43, 0x44, 0x45
 CAST = 0x50
 
 
@@ -241,6 +241,11 @@ def ismissing(a) -> Expr:
 
 def sizeof(a) -> Expr:
     return Expr(SIZEOF, (wrap(a),))
+
+
+def coalesce(a, b) -> Expr:
+    """coalesce(a, b): a where it is not missing, else b (the way a Union{T,Missing} expression becomes a predicate)."""
+    return Expr(COALESCE, (wrap(a), wrap(b)))
 
 
 def rem(a, b) -> Expr: return Expr(REM, (wrap(a), wrap(b)))

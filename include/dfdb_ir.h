@@ -65,6 +65,7 @@ enum {
 #define DFIR_ENDSWITH    0x42
 #define DFIR_ISMISSING   0x43 /* unary on a nullable column -> Bool */
 #define DFIR_SIZEOF      0x44 /* unary: sizeof(string) -> Int64 */
+#define DFIR_COALESCE    0x45 /* binary: coalesce(a, b) = a unless it is missing, else b (same base type; result nullable iff b is) */
 
 /* ---- conversion ---- */
 #define DFIR_CAST  0x50 /* payload: u8 dtype ; Julia T(x) / convert */

@@ -41,12 +41,19 @@ static int promote_num(int a, int b) { /* promote_type for the numeric dtypes */
   return dt_issigned(a) ? b : a;          /* tie -> unsigned */
 }
 
-/* result type of op over operand types; -1 = no method (UNSUPPORTED), -2 = missing-propagating */
+/* result type of op over operand types; -1 = no method (UNSUPPORTED).  An operand of type Union{T,Missing} makes the result
+ * Union{R,Missing} (every Base method on the path propagates missing; `&`/`|` do so with three-valued logic), except
+ * ismissing (Bool) and coalesce (the first non-missing argument: nullable only if the LAST argument is). */
+static int infer_base(int op, int a, int b);
 static int infer(int op, int ta, int tb) {
   int na = dt_nullable(ta), nb = tb ? dt_nullable(tb) : 0;
   int a = dt_base(ta), b = tb ? dt_base(tb) : 0;
   if (op == DFIR_ISMISSING) return DFDB_BOOL;
-  if (na || nb) return -2;
+  if (op == DFIR_COALESCE) { if (a != b || !dt_isnum(a)) return -1; return a | (nb ? DFDB_NULLABLE : 0); }
+  int r = infer_base(op, a, b);
+  return (r >= 0 && (na || nb)) ? (r | DFDB_NULLABLE) : r;
+}
+static int infer_base(int op, int a, int b) {
   switch (op) {
     case DFIR_ADD: case DFIR_SUB:
       if (!dt_isnum(a) || !dt_isnum(b)) return -1;
@@ -163,17 +170,15 @@ int expr_parse(const orc_table* t, const uint8_t* ir, size_t len, node_t** out) 
         if (op == DFIR_CAST) { if (pos + 1 > len) { free(n); FAIL(ORC_ERR_ARGUMENT, "truncated IR"); } n->cast_to = ir[pos++]; }
         if (sp < 1) { free(n); FAIL(ORC_ERR_ARGUMENT, "IR stack underflow"); }
         n->a = stack[--sp];
-        int rt = op == DFIR_CAST ? ((dt_isnum(n->a->dtype) && !dt_nullable(n->a->dtype) && dt_isnum(n->cast_to)) ? n->cast_to : -1)
+        int rt = op == DFIR_CAST ? ((dt_isnum(n->a->dtype) && dt_isnum(n->cast_to) && !dt_nullable(n->cast_to)) ? (n->cast_to | (dt_nullable(n->a->dtype) ? DFDB_NULLABLE : 0)) : -1)
                                  : infer(op, n->a->dtype, 0);
-        if (op == DFIR_ISMISSING && n->a->op != DFIR_COL) rt = -1;
         stack[sp++] = n;
-        if (rt == -2) FAIL(ORC_ERR_ARGUMENT, "expression over a Union{T,Missing} column yields Missing");
         if (rt < 0) FAIL(ORC_ERR_UNSUPPORTED, "no method for op 0x%02x on %s", op, dt_name(n->a->dtype));
         n->dtype = rt; break;
       }
       default: {
         if (!((op >= DFIR_ADD && op <= DFIR_MAX) || (op >= DFIR_EQ && op <= DFIR_GE) || (op >= DFIR_AND && op <= DFIR_XOR) ||
-              op == DFIR_IN_SET || op == DFIR_STARTSWITH || op == DFIR_ENDSWITH)) { free(n); FAIL(ORC_ERR_UNSUPPORTED, "unknown IR opcode 0x%02x", op); }
+              op == DFIR_IN_SET || op == DFIR_STARTSWITH || op == DFIR_ENDSWITH || op == DFIR_COALESCE)) { free(n); FAIL(ORC_ERR_UNSUPPORTED, "unknown IR opcode 0x%02x", op); }
         if (sp < 2) { free(n); FAIL(ORC_ERR_ARGUMENT, "IR stack underflow"); }
         n->b = stack[--sp]; n->a = stack[--sp];
         int rt;
@@ -182,7 +187,6 @@ int expr_parse(const orc_table* t, const uint8_t* ir, size_t len, node_t** out) 
         else rt = infer(op, n->a->dtype, n->b->dtype);
         if ((op == DFIR_STARTSWITH || op == DFIR_ENDSWITH) && n->b->op != DFIR_CONST_STR) rt = -1;
         stack[sp++] = n;
-        if (rt == -2) FAIL(ORC_ERR_ARGUMENT, "expression over a Union{T,Missing} column yields Missing");
         if (rt < 0) FAIL(ORC_ERR_UNSUPPORTED, "no method for op 0x%02x", op);
         n->dtype = rt; break;
       }
@@ -276,7 +280,15 @@ static int vec_alloc(ectx_t* c, vec_t* v, int dtype, int64_t n) {
  * contiguous buffer (straight copy when every row is selected) */
 static int gather_col(ectx_t* c, const colbuf_t* b, vec_t* v) {
   int bt = dt_base(b->dtype); int64_t n = c->n; const int32_t* idx = c->idx;
-  if (bt == DFDB_STRING) { memset(v, 0, sizeof *v); v->dtype = b->dtype; v->n = n; v->scol = b; return 0; }
+  if (bt == DFDB_STRING) {
+    memset(v, 0, sizeof *v); v->dtype = b->dtype; v->n = n; v->scol = b;
+    if (dt_nullable(b->dtype)) { /* a missing String is a size of -1 (FlatStringsVectors.jl:80-85) */
+      v->miss = (uint8_t*)arena_alloc(c->ar, (size_t)(n > 0 ? n : 1));
+      if (!v->miss) return orc_fail(ORC_ERR_NOMEM, "oracle arena exhausted");
+      for (int64_t k = 0; k < n; k++) v->miss[k] = b->sizes[idx ? idx[k] : k] < 0;
+    }
+    return 0;
+  }
   int rc = vec_alloc(c, v, bt, n); if (rc) return rc;
   v->dtype = b->dtype;
 #define GATHER(T, dst) do { const T* s = (const T*)b->data; if (!idx) for (int64_t k = 0; k < n; k++) dst[k] = s[k]; else for (int64_t k = 0; k < n; k++) dst[k] = s[idx[k]]; } while (0)
@@ -303,12 +315,14 @@ static int conv(ectx_t* c, const vec_t* s, int to, vec_t* d) {
   if (from == to) { *d = *s; return 0; }
   int64_t n = s->is_const ? 1 : s->n;
   int rc = vec_alloc(c, d, to, n); if (rc) return rc;
-  d->is_const = s->is_const; d->n = s->n;
+  d->is_const = s->is_const; d->n = s->n; d->miss = s->miss;
+  const uint8_t* ms = s->miss;
   if (dt_isint(to)) {
     if (dt_isint(from)) for (int64_t k = 0; k < n; k++) d->i[k] = wrap_int(s->i[k], to);
     else if (from == DFDB_BOOL) for (int64_t k = 0; k < n; k++) d->i[k] = s->b[k];
     else for (int64_t k = 0; k < n; k++) { /* Float -> Int: InexactError unless integral */
       double x = s->f[k];
+      if (ms && ms[k]) { d->i[k] = 0; continue; }
       if (x != trunc(x) || x < -9223372036854775808.0 || x >= 9223372036854775808.0) { c->err = ORC_ERR_ARGUMENT; d->i[k] = 0; }
       else d->i[k] = wrap_int((int64_t)x, to);
     }
@@ -319,8 +333,8 @@ static int conv(ectx_t* c, const vec_t* s, int to, vec_t* d) {
     } else if (from == DFDB_BOOL) for (int64_t k = 0; k < n; k++) d->f[k] = s->b[k];
     else for (int64_t k = 0; k < n; k++) d->f[k] = to == DFDB_F32 ? (double)(float)s->f[k] : s->f[k];
   } else { /* to Bool */
-    if (dt_isint(from)) for (int64_t k = 0; k < n; k++) { if (s->i[k] != 0 && s->i[k] != 1) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->i[k] != 0; }
-    else for (int64_t k = 0; k < n; k++) { if (s->f[k] != 0 && s->f[k] != 1) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->f[k] != 0; }
+    if (dt_isint(from)) for (int64_t k = 0; k < n; k++) { if (s->i[k] != 0 && s->i[k] != 1 && !(ms && ms[k])) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->i[k] != 0; }
+    else for (int64_t k = 0; k < n; k++) { if (s->f[k] != 0 && s->f[k] != 1 && !(ms && ms[k])) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->f[k] != 0; }
   }
   return 0;
 }
@@ -347,8 +361,50 @@ static int str_cmp(const uint8_t* a, int32_t la, const uint8_t* b, int32_t lb) {
   return la < lb ? -1 : (la > lb ? 1 : 0);
 }
 
+/* missing flags of a result: the union of its operands' (constants are never missing) */
+static int miss_union(ectx_t* c, const vec_t* a, const vec_t* b, uint8_t** out) {
+  const uint8_t* ma = a ? a->miss : NULL; const uint8_t* mb = b ? b->miss : NULL;
+  *out = NULL;
+  if (!ma && !mb) return 0;
+  uint8_t* m = (uint8_t*)arena_alloc(c->ar, (size_t)(c->n > 0 ? c->n : 1));
+  if (!m) return orc_fail(ORC_ERR_NOMEM, "oracle arena exhausted");
+  for (int64_t k = 0; k < c->n; k++) m[k] = (uint8_t)((ma ? ma[k] : 0) | (mb ? mb[k] : 0));
+  *out = m; return 0;
+}
+
+static int eval_binary_core(const node_t* nd, ectx_t* c, vec_t* out, vec_t* pva, vec_t* pvb);
 static int eval_binary(const node_t* nd, ectx_t* c, vec_t* out) {
   vec_t va, vb; int rc;
+  memset(&va, 0, sizeof va); memset(&vb, 0, sizeof vb);
+  if (nd->op == DFIR_COALESCE) { /* coalesce(a, b): a where it is not missing, else b */
+    if ((rc = eval(nd->a, c, &va)) || (rc = eval(nd->b, c, &vb))) return rc;
+    int rt = dt_base(nd->dtype); int64_t n = c->n;
+    if ((rc = vec_alloc(c, out, rt, n))) return rc;
+    out->dtype = nd->dtype;
+    int64_t sa = va.is_const ? 0 : 1, sb = vb.is_const ? 0 : 1;
+    for (int64_t k = 0; k < n; k++) {
+      int am = va.miss ? va.miss[k] : 0;
+      if (out->i) out->i[k] = am ? vb.i[k * sb] : va.i[k * sa];
+      else if (out->f) out->f[k] = am ? vb.f[k * sb] : va.f[k * sa];
+      else out->b[k] = am ? vb.b[k * sb] : va.b[k * sa];
+    }
+    if (va.miss && vb.miss) {
+      out->miss = (uint8_t*)arena_alloc(c->ar, (size_t)(n > 0 ? n : 1));
+      if (!out->miss) return orc_fail(ORC_ERR_NOMEM, "oracle arena exhausted");
+      for (int64_t k = 0; k < n; k++) out->miss[k] = va.miss[k] & vb.miss[k];
+    }
+    return 0;
+  }
+  if ((rc = eval_binary_core(nd, c, out, &va, &vb))) return rc;
+  if (!out->miss && (nd->op < DFIR_AND || nd->op > DFIR_OR || dt_base(nd->dtype) != DFDB_BOOL))   /* Bool & / | set their own flags */
+    rc = miss_union(c, &va, nd->op == DFIR_IN_SET ? NULL : &vb, &out->miss);
+  return rc;
+}
+
+static int eval_binary_core(const node_t* nd, ectx_t* c, vec_t* out, vec_t* pva, vec_t* pvb) {
+#define va (*pva)
+#define vb (*pvb)
+  int rc;
   if ((rc = eval(nd->a, c, &va))) return rc;
   if (nd->op == DFIR_IN_SET) {
     const node_t* s = nd->b; int64_t n = c->n;
@@ -426,6 +482,18 @@ static int eval_binary(const node_t* nd, ectx_t* c, vec_t* out) {
   if (op >= DFIR_AND && op <= DFIR_XOR && rt == DFDB_BOOL) {
     if ((rc = vec_alloc(c, out, DFDB_BOOL, n))) return rc;
     const uint8_t *x = va.b, *y = vb.b; uint8_t* o = out->b;
+    if ((va.miss || vb.miss) && op != DFIR_XOR) { /* three-valued logic: false & missing = false, true | missing = true */
+      uint8_t* m = (uint8_t*)arena_alloc(c->ar, (size_t)(n > 0 ? n : 1));
+      if (!m) return orc_fail(ORC_ERR_NOMEM, "oracle arena exhausted");
+      for (int64_t k = 0; k < n; k++) {
+        int am = va.miss ? va.miss[k] : 0, bm = vb.miss ? vb.miss[k] : 0, a = x[k * sa] & 1, b = y[k * sb] & 1;
+        int decided = op == DFIR_AND ? ((!am && !a) || (!bm && !b)) : ((!am && a) || (!bm && b));   /* one known operand settles it */
+        m[k] = (uint8_t)((am | bm) && !decided);
+        o[k] = (uint8_t)(decided ? (op == DFIR_OR) : (m[k] ? 0 : (op == DFIR_AND ? (a & b) : (a | b))));
+      }
+      out->miss = m;
+      return 0;
+    }
     if (op == DFIR_AND) for (int64_t k = 0; k < n; k++) o[k] = x[k * sa] & y[k * sb];
     else if (op == DFIR_OR) for (int64_t k = 0; k < n; k++) o[k] = x[k * sa] | y[k * sb];
     else for (int64_t k = 0; k < n; k++) o[k] = x[k * sa] ^ y[k * sb];
@@ -480,6 +548,7 @@ static int eval_binary(const node_t* nd, ectx_t* c, vec_t* out) {
       case DFIR_MIN: r = uns && ct == DFDB_U64 ? ((uint64_t)a < (uint64_t)b ? a : b) : (a < b ? a : b); break;
       case DFIR_MAX: r = uns && ct == DFDB_U64 ? ((uint64_t)a > (uint64_t)b ? a : b) : (a > b ? a : b); break;
       case DFIR_REM: case DFIR_MOD: case DFIR_IDIV:
+        if ((xa.miss && xa.miss[k * sa]) || (xb.miss && xb.miss[k * sb])) { r = 0; break; }   /* missing ÷ x is missing, not an error */
         if (b == 0) { c->err = ORC_ERR_DIVIDE; r = 0; break; }
         if (uns) {
           uint64_t ua = (uint64_t)a, ub = (uint64_t)b;
@@ -494,6 +563,8 @@ static int eval_binary(const node_t* nd, ectx_t* c, vec_t* out) {
     o[k] = wrap_int(r, ct);
   }
   return 0;
+#undef va
+#undef vb
 }
 
 static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
@@ -511,9 +582,16 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
       vec_t a; if ((rc = eval(nd->a, c, &a))) return rc;
       if ((rc = vec_alloc(c, out, DFDB_BOOL, c->n))) return rc;
       for (int64_t k = 0; k < c->n; k++) out->b[k] = !a.b[a.is_const ? 0 : k];
+      out->miss = a.miss;
       return 0;
     }
     case DFIR_ISMISSING: {
+      if (nd->a->op != DFIR_COL) { /* ismissing of a computed value */
+        vec_t a; if ((rc = eval(nd->a, c, &a))) return rc;
+        if ((rc = vec_alloc(c, out, DFDB_BOOL, c->n))) return rc;
+        for (int64_t k = 0; k < c->n; k++) out->b[k] = a.miss ? a.miss[k] : 0;
+        return 0;
+      }
       const colbuf_t* b = &c->bufs[nd->a->col];
       if ((rc = vec_alloc(c, out, DFDB_BOOL, c->n))) return rc;
       for (int64_t k = 0; k < c->n; k++) {
@@ -526,6 +604,7 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
       vec_t a; if ((rc = eval(nd->a, c, &a))) return rc;
       if ((rc = vec_alloc(c, out, DFDB_I64, c->n))) return rc;
       for (int64_t k = 0; k < c->n; k++) { const uint8_t* p; int32_t l; str_elem(&a, c, k, &p, &l); out->i[k] = l < 0 ? 0 : l; }
+      out->miss = a.miss;
       return 0;
     }
     case DFIR_NEG: case DFIR_ABS: {
@@ -534,7 +613,7 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
       if ((rc = conv(c, &a, rt, &x))) return rc;
       int64_t n = x.is_const ? 1 : c->n;
       if ((rc = vec_alloc(c, out, rt, n))) return rc;
-      out->is_const = x.is_const; out->n = c->n;
+      out->is_const = x.is_const; out->n = c->n; out->miss = a.miss;
       if (rt == DFDB_BOOL) { for (int64_t k = 0; k < n; k++) out->b[k] = x.b[k]; return 0; }
       if (dt_isfloat(rt)) for (int64_t k = 0; k < n; k++) out->f[k] = nd->op == DFIR_NEG ? -x.f[k] : fabs(x.f[k]);
       else for (int64_t k = 0; k < n; k++) {
@@ -547,8 +626,8 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
     case DFIR_CAST: {
       vec_t a; if ((rc = eval(nd->a, c, &a))) return rc;
       vec_t x; if ((rc = conv(c, &a, dt_base(nd->cast_to), &x))) return rc;
-      if (x.is_const || x.i != a.i || x.f != a.f || x.b != a.b) { *out = x; out->dtype = nd->cast_to; return 0; }
-      *out = x; return 0;
+      *out = x; out->dtype = nd->dtype; out->miss = a.miss;
+      return 0;
     }
     default: return eval_binary(nd, c, out);
   }

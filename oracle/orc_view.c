@@ -412,6 +412,11 @@ static int project_block(iter_t* it, accum_t* acc) {
         default: return orc_fail(ORC_ERR_UNSUPPORTED, "computed String columns are outside the IR");
       }
       a->data.n += (size_t)n * w;
+      if (dt_nullable(ex->dtype)) { /* Union{R,Missing} result: the flags travel beside the values */
+        if ((rc = bytes_reserve(&a->missing, a->missing.n + (size_t)n))) return rc;
+        for (int64_t k = 0; k < n; k++) a->missing.p[a->missing.n + k] = r.miss ? r.miss[k] : 0;
+        a->missing.n += (size_t)n;
+      }
     }
     a->count += n;
   }

@@ -406,3 +406,54 @@ def test_block_range_shards_concatenate_to_table_order(oracle, dfdb_mod, ctx, tm
     # sum(x) over shards: one all-reduce of a scalar; tolerance n*eps*sum|x|
     tot = sum(v[dfdb_mod.ALL, "x"].sum() for v in [dfdb_mod.DFView(t) for t in shards])
     assert abs(tot - float(np.sum(cols["x"]))) <= n * np.finfo(float).eps * float(np.abs(cols["x"]).sum())
+
+
+# ------------------------------------------------------------------ Union{T,Missing} inside expressions
+def test_missing_propagation_and_three_valued_logic(oracle, dfdb_mod, ctx):
+    """The known-answer table of tests/test_oracle_cpu.py (Julia's missing propagation, three-valued & and |, coalesce,
+    ismissing of computed values) through the device interpreter, then random nullable columns against the oracle."""
+    from dfdb import ir
+    from test_oracle_cpu import missing_cases
+    cols = {"m": np.ma.masked_array(np.array([1, 99, 3, 77, 0], np.int64), mask=[0, 1, 0, 1, 0]), "c": np.array([0, 0, 5, 5, 0], np.int64),
+            "sm": ["a", None, "b", "ab", None]}
+    p = Pair(oracle, dfdb_mod, cols, block_size=2)
+    for name, e, want, miss in missing_cases():
+        if want is None:
+            with pytest.raises(ZeroDivisionError):
+                dfdb_mod.materialize(dfdb_mod.DFView(p.d, dfdb_mod.Projection({"k": e})))
+            continue
+        ov, dv = apply_stages(p, [], proj=[("k", e)])
+        assert_same(p, ov, dv)
+        got = dv._query().materialize()[0]
+        if miss is None:
+            assert not isinstance(got, np.ma.MaskedArray) and np.array_equal(got, np.array(want, got.dtype)), name
+        else:
+            assert np.array_equal(np.ma.getmaskarray(got), np.array(miss, bool)), name
+    with pytest.raises(ValueError):          # a Union{Missing,Bool} selection function is refused (selection.jl:52-55)
+        dfdb_mod.selection(dfdb_mod.DFView(p.d), ir.col(0) > 2)
+    ov, dv = apply_stages(p, [("pred", ir.coalesce((ir.col(0) > 2) | (ir.col(1) > 1), False))])
+    assert_same(p, ov, dv)
+    assert dv._query().indices().tolist() == [3, 4]
+
+    rng = np.random.default_rng(23)
+    n = 150_011
+    strs = oracle.flat_to_strings(*oracle.gen_str(col_seed(3), 0, n))
+    cols = {"m": np.ma.masked_array(rng.integers(-50, 50, n).astype(np.int64), mask=rng.random(n) < 0.3),
+            "f": np.ma.masked_array(rng.normal(0, 10, n), mask=rng.random(n) < 0.1),
+            "b": np.ma.masked_array(rng.integers(0, 2, n).astype(bool), mask=rng.random(n) < 0.5),
+            "c": rng.integers(-5, 6, n).astype(np.int64), "i8": np.ma.masked_array(rng.integers(-128, 128, n).astype(np.int8), mask=rng.random(n) < 0.2),
+            "sm": [None if i % 7 == 0 else s for i, s in enumerate(strs)]}
+    p = Pair(oracle, dfdb_mod, cols, block_size=4096)
+    m, f, b, c, i8, sm = (ir.col(k) for k in range(6))
+    preds = [ir.coalesce(m > 10, False), ir.coalesce((m > 10) & b, True), ir.coalesce(b | (f < 0.0), False) & (c != 0),
+             ir.ismissing(m + f) | ir.coalesce(sm == "sony", False), ~ir.ismissing(m * i8) & ir.coalesce(ir.rem(m, ir.coalesce(i8, ir.const(1, ir.I8)) * 0 + 7) == 1, False),
+             ir.coalesce(ir.startswith(sm, "s") & (m < 0), False), ir.coalesce(ir.coalesce(m, 0) + ir.coalesce(i8, ir.const(1, ir.I8)) > f, False),
+             ir.coalesce(~b, False) ^ (c > 0), ir.ismissing(sm) & ir.coalesce(b, False)]
+    for pred in preds:
+        ov, dv = apply_stages(p, [("pred", pred)])
+        assert_same(p, ov, dv)
+    projs = [[("k", m + c), ("j", m * f)], [("k", (m > 0) & b), ("j", (m > 0) | b)], [("k", ir.coalesce(m, -1) + i8)], [("k", -f), ("j", abs(i8))],
+             [("k", ir.sizeof(sm) + m)], [("k", ir.float64(m) / 4.0)], [("k", ir.div(m, ir.coalesce(c, 1) * 0 + 3))]]
+    for pr in projs:
+        ov, dv = apply_stages(p, [("pred", c > -3)], proj=pr)
+        assert_same(p, ov, dv)

@@ -213,3 +213,81 @@ def test_generator_formulas(oracle):
     assert oracle.flat_to_strings(sz, by) == [brands[sm((seed + 7 + i) & M) % 10] for i in range(40)]
     big = oracle.gen_i64(seed, 0, 1_000_000)
     assert abs((big > 899_999).mean() - 0.1) < 0.002
+
+
+# ------------------------------------------------------------------ Union{T,Missing} inside expressions
+MISSING_CASES = None
+
+
+def missing_cases():
+    """(name, expr builder, expected values, expected missing flags or None) over
+         m = [1, missing, 3, missing, 0] :: Union{Int64,Missing}   c = [0, 0, 5, 5, 0] :: Int64
+         sm = ["a", missing, "b", "ab", missing] :: Union{String,Missing}
+    Known answers are Julia's: every Base method propagates missing; & and | are three-valued; ismissing / coalesce end it."""
+    from dfdb import ir
+    m, c, sm = ir.col(0), ir.col(1), ir.col(2)
+    T, F = True, False
+    return [
+        ("m+c", m + c, [1, 0, 8, 0, 0], [0, 1, 0, 1, 0]),
+        ("m>2", m > 2, [F, F, T, F, F], [0, 1, 0, 1, 0]),
+        ("!(m>2)", ~(m > 2), [T, F, F, F, T], [0, 1, 0, 1, 0]),
+        ("coalesce(m>2,false)", ir.coalesce(m > 2, False), [F, F, T, F, F], None),
+        ("coalesce(m>2,true)", ir.coalesce(m > 2, True), [F, T, T, T, F], None),
+        ("coalesce(m,-1)", ir.coalesce(m, -1), [1, -1, 3, -1, 0], None),
+        ("(m>2)&(c>1)", (m > 2) & (c > 1), [F, F, T, F, F], [0, 0, 0, 1, 0]),     # missing & false == false
+        ("(c>1)&(m>2)", (c > 1) & (m > 2), [F, F, T, F, F], [0, 0, 0, 1, 0]),
+        ("(m>2)|(c>1)", (m > 2) | (c > 1), [F, F, T, T, F], [0, 1, 0, 0, 0]),     # missing | true == true
+        ("xor", (m > 2) ^ (c > 1), [F, F, F, F, F], [0, 1, 0, 1, 0]),
+        ("ismissing(m+c)", ir.ismissing(m + c), [F, T, F, T, F], None),
+        ("ismissing(m)", ir.ismissing(m), [F, T, F, T, F], None),
+        ("m*2.5", m * 2.5, [2.5, 0, 7.5, 0, 0.0], [0, 1, 0, 1, 0]),
+        ("-m", -m, [-1, 0, -3, 0, 0], [0, 1, 0, 1, 0]),
+        ("in(m,[1,3])", ir.isin(m, [1, 3]), [T, F, T, F, F], [0, 1, 0, 1, 0]),
+        ("sm==a", sm == "a", [T, F, F, F, F], [0, 1, 0, 0, 1]),
+        ("startswith(sm,a)", ir.startswith(sm, "a"), [T, F, F, T, F], [0, 1, 0, 0, 1]),
+        ("coalesce(sm==a,false)|(c>1)", ir.coalesce(sm == "a", False) | (c > 1), [T, F, T, T, F], None),
+        ("sizeof(sm)", ir.sizeof(sm), [1, 0, 1, 2, 0], [0, 1, 0, 0, 1]),
+        ("div(c, coalesce(m,1))", ir.div(c, ir.coalesce(m, 1)), None, None),          # row 5 divides by zero: DivideError
+        ("div(c+1, m)", ir.div(c + 1, ir.coalesce(m + 1, 7) * 0 + m), None, None),    # (m==0 in row 5) DivideError; rows 2,4 are missing, not errors
+        ("rem(c, m+1)", ir.rem(c, m + 1), [0, 0, 1, 0, 0], [0, 1, 0, 1, 0]),          # a missing divisor is not a DivideError
+    ]
+
+
+def missing_table(oracle, block_size=2):
+    t = oracle.Table(block_size=block_size)
+    t.add_column("m", np.array([1, 99, 3, 77, 0], np.int64), missing=np.array([0, 1, 0, 1, 0], np.uint8))
+    t.add_column("c", np.array([0, 0, 5, 5, 0], np.int64))
+    t.add_column("sm", ["a", None, "b", "ab", None])
+    return t
+
+
+def test_missing_propagation_and_three_valued_logic(oracle):
+    from dfdb import ir
+    t = missing_table(oracle)
+    for name, e, want, miss in missing_cases():
+        v = t.view()
+        v.set_projection([("k", e.to_ir())])
+        if want is None:
+            with pytest.raises(ZeroDivisionError):
+                v.materialize()
+            continue
+        got = v.materialize()[0]
+        if miss is None:
+            assert not isinstance(got, np.ma.MaskedArray), name
+            assert np.array_equal(got, np.array(want, got.dtype)), name
+        else:
+            assert isinstance(got, np.ma.MaskedArray), name
+            assert np.array_equal(np.ma.getmaskarray(got), np.array(miss, bool)), name
+            keep = ~np.array(miss, bool)
+            assert np.array_equal(np.asarray(got.data)[keep], np.array(want, got.dtype)[keep]), name
+    # as predicates: a Union{Missing,Bool} function is refused (selection.jl:52-55), its coalesce is a plain predicate
+    with pytest.raises(ValueError):
+        t.view().add_predicate((ir.col(0) > 2).to_ir())
+    v = t.view().add_predicate(ir.coalesce((ir.col(0) > 2) | (ir.col(1) > 1), False).to_ir())
+    assert v.select_indices().tolist() == [3, 4]
+    v = t.view().add_predicate((~ir.ismissing(ir.col(0) + ir.col(1))).to_ir())
+    assert v.select_indices().tolist() == [1, 3, 5]
+    assert oracle.expr_result_type(t, (ir.col(0) + 1.5).to_ir()) == (ir.F64 | ir.NULLABLE)
+    assert oracle.expr_result_type(t, ir.coalesce(ir.col(0), 0).to_ir()) == ir.I64
+    with pytest.raises(NotImplementedError):     # coalesce(Int64?, Float64) would be Union{Int64,Float64}: outside the IR
+        oracle.expr_result_type(t, ir.coalesce(ir.col(0), 0.5).to_ir())
