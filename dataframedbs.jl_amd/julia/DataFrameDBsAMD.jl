@@ -61,7 +61,7 @@ const OPS = Dict{Any,UInt8}(
     min => 0x19, max => 0x1a,
     (==) => 0x20, (!=) => 0x21, (<) => 0x22, (<=) => 0x23, (>) => 0x24, (>=) => 0x25,
     (&) => 0x30, (|) => 0x31, xor => 0x32,
-    startswith => 0x41, endswith => 0x42)
+    startswith => 0x41, endswith => 0x42, coalesce => 0x45)
 const UNARY = Dict{Any,UInt8}((-) => 0x17, abs => 0x18, (!) => 0x33, ismissing => 0x43, sizeof => 0x44)
 
 emit_col(io, ord::Integer) = (write(io, 0x01); write(io, UInt32(ord)))
