@@ -98,9 +98,17 @@ __global__ __launch_bounds__(kBlock) void k_gather(const uint64_t* __restrict__ 
     if (nx < nctiles) { w_next = bitmap[nx * 64 + lane]; ob_next = prefix[nx * 4]; }
     const uint32_t total = stage_positions(w, pos, lane);
     const T* tsrc = src + ct * kCTile;
-    for (uint32_t k = lane; k < total; k += 64) {
-      const int64_t o = obase + k;
-      if (o < out_cap) dst[o] = tsrc[pos[k]];
+    // 4 gathers in flight per lane before the first store: the loop is a chain of dependent HBM round trips otherwise
+    for (uint32_t k0 = 0; k0 < total; k0 += 256) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t k = k0 + (uint32_t)u * 64 + lane; v[u] = k < total ? __builtin_nontemporal_load(tsrc + pos[k]) : T(0); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + (uint32_t)u * 64 + lane;
+        const int64_t o = obase + k;
+        if (k < total && o < out_cap) dst[o] = v[u];
+      }
     }
     wave_lds_fence();
   }
