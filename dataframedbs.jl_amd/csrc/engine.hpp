@@ -65,6 +65,12 @@ struct dfdb_query {
   dfdb::DevBuf bitmap, tile_counts, prefix, scan_scratch, idx_sorted, red_scratch, red_result, tmp_a, tmp_b, tmp_c,
       str_sizes, str_toff, str_bytes, str_scratch, fused_scratch;
   bool fused_pending = false;  // a fused launch whose spin-overrun flag has not been checked yet
+  // dfdb_query_hint_materialize: the projection WILL be materialised after the scan, so a single-stage scan of simple terms
+  // keeps the selected values of one projected 8-byte predicate column (per-tile compact, cap_buf) and that column's
+  // projection becomes a contiguous copy instead of a gather
+  bool hint_materialize = false;
+  int cap_col = -1;            // table ordinal captured by the last execution (-1: none)
+  dfdb::DevBuf cap_buf;
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
   bool prefix_valid = false;

@@ -127,6 +127,43 @@ void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix
   }
 }
 
+// projection of a predicate column whose selected values the scan already wrote per tile (k_scan_cmp / k_scan_terms CAP):
+// one wave per 4096-row ctile = 4 capture tiles; every lane finds its tile from the 5 prefix values and copies
+__global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __restrict__ cap, const uint64_t* __restrict__ prefix,
+                                                             uint64_t* __restrict__ out, int64_t nctiles, int64_t ntiles, int64_t out_cap) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
+    const int64_t t0 = ct * 4;
+    uint64_t pf[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) pf[i] = prefix[t0 + i < ntiles ? t0 + i : ntiles];
+    const uint32_t total = (uint32_t)(pf[4] - pf[0]);
+    for (uint32_t k0 = 0; k0 < total; k0 += 256) {
+      uint64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + (uint32_t)u * 64 + lane;
+        const uint64_t o = pf[0] + k;
+        const int ti = o >= pf[3] ? 3 : (o >= pf[2] ? 2 : (o >= pf[1] ? 1 : 0));
+        v[u] = k < total ? __builtin_nontemporal_load(cap + (t0 + ti) * 1024 + (int64_t)(o - pf[ti])) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + (uint32_t)u * 64 + lane;
+        const int64_t o = (int64_t)pf[0] + k;
+        if (k < total && o < out_cap) out[o] = v[u];
+      }
+    }
+  }
+}
+void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile, nt = (nrows + 1023) / 1024;
+  if (nct == 0) return;
+  hipLaunchKernelGGL(k_compact_captured, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, cap, prefix, out, nct, nt, out_cap);
+}
+
 __global__ __launch_bounds__(kBlock) void k_gather_bits(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
                                                         const uint64_t* __restrict__ srcbits, uint8_t* __restrict__ dst, int64_t nctiles,
                                                         int64_t out_cap) {

@@ -117,12 +117,13 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
   std::vector<const Node*> conj; flatten_and(pred, conj);
   std::vector<const Node*> generic, strs; ScanTerms terms{}; terms.n = 0; terms.combine_or = 0;
   std::vector<ScanTerms> term_batches;
+  std::vector<int> term_ords;
   for (const Node* c : conj) {
     ScanTerm tm; int ord; int mode; std::string pat;
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
       if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }
-      terms.t[terms.n++] = tm;
+      terms.t[terms.n++] = tm; term_ords.push_back(ord);
     } else if (match_string_term(*c, *t, ord, mode, pat)) strs.push_back(c);
     else generic.push_back(c);
   }
@@ -140,17 +141,31 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
     have = true;
   }
+  // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask
+  int cap_term = -1;
+  if (q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1 && !term_batches[0].combine_or) {
+    const ScanTerms& tb = term_batches[0];
+    for (int k = 0; k < tb.n && cap_term < 0; k++) {
+      const int dt = tb.t[k].dtype;
+      if (dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) continue;
+      for (const ProjCol& p : q->proj)
+        if (p.expr->op == DFIR_COL && p.expr->col == term_ords[(size_t)k] && !dt_nullable(p.expr->dtype)) { cap_term = k; break; }
+    }
+    if (cap_term >= 0) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
+  }
   for (const ScanTerms& tb : term_batches) {
+    void* cap = cap_term >= 0 ? q->cap_buf.p : nullptr;
     if (tb.n == 1) {
       LaunchTimer lt(ctx, "scan_cmp");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                      ctx_option(ctx, "scan_nt", 1) != 0);
+                      ctx_option(ctx, "scan_nt", 1) != 0, cap);
     } else {
       LaunchTimer lt(ctx, "scan_terms");
-      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, cap_term, cap);
     }
     have = true;
   }
+  if (cap_term >= 0) q->cap_col = term_ords[(size_t)cap_term];
 }
 
 static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
@@ -182,7 +197,7 @@ void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
-  q->count = -1; q->prefix_valid = false; q->executed_stages = -1;
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1;
   if (nstages == 0) {
     LaunchTimer lt(ctx, "fill_ones");
     launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
@@ -340,8 +355,13 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
     }
     DevBuf stage; void* dst = o.data;
     if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
-    { LaunchTimer lt(ctx, "gather");
-      launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt); }
+    if (q->cap_col == e.col && w == 8 && q->executed_stages == (int)q->stages.size()) {   // the scan kept these values: contiguous copy per tile
+      LaunchTimer lt(ctx, "compact_captured");
+      launch_compact_captured(s, q->cap_buf.as<uint64_t>(), q->prefix.as<uint64_t>(), (uint64_t*)dst, t->nrows, cnt);
+    } else {
+      LaunchTimer lt(ctx, "gather");
+      launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt);
+    }
     if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
     if (dt_nullable(e.dtype) && o.missing) {
       DevBuf ms; uint8_t* md = o.missing;

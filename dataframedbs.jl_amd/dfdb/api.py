@@ -673,8 +673,12 @@ class _Query:
             N.check(N.load().dfdb_select_bitmap(self._h, out.ctypes.data, N.MEM_HOST))
         return out
 
+    def hint_materialize(self, on: bool = True):
+        N.check(N.load().dfdb_query_hint_materialize(self._h, 1 if on else 0))
+
     def materialize(self) -> List[Any]:
         L = N.load()
+        self.hint_materialize(True)       # count() below is the scan: let it keep projected predicate columns
         n = self.count()
         ncols = len(self.view.projection)
         outs = (N.OutCol * max(ncols, 1))()

@@ -194,6 +194,13 @@ int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n);
 /* SelectionExecutor.apply over every resident block (selection.jl:161-167, blocksiterator.jl:98-145):
  * leaves the selection bitmap + per-tile counts + their prefix in HBM.  Asynchronous. */
 int32_t dfdb_query_execute(dfdb_query* q);
+/* materialize(::DFView) evaluates the selection and then copies the projection (materialization.jl:27-40).  Telling the
+ * engine BEFORE the first execution (dfdb_count / dfdb_query_execute) that the projection will be materialised lets a
+ * single-stage scan of simple terms keep the selected values of a projected 8-byte predicate column while it has them in
+ * registers; dfdb_materialize then copies them instead of gathering (re-reading) the column.  Results are identical; the
+ * query holds an extra nrows*8-byte buffer while the hint is on. */
+int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on);
+
 /* forget the cached execution so the next count/indices/materialize re-evaluates the selection (a new
  * BlocksIterator in the reference: blocksiterator.jl:20-44).  dfdb_select_indices on a reset single-predicate
  * query with a device output runs the fused one-pass kernel (scan + look-back + compaction). */

@@ -457,3 +457,32 @@ def test_missing_propagation_and_three_valued_logic(oracle, dfdb_mod, ctx):
     for pr in projs:
         ov, dv = apply_stages(p, [("pred", c > -3)], proj=pr)
         assert_same(p, ov, dv)
+
+
+# ------------------------------------------------------------------ projected predicate columns captured by the scan
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 4097, 65_536 + 7, 300_017])
+def test_materialize_captures_projected_predicate_columns(oracle, dfdb_mod, ctx, n):
+    """materialize() hints the scan (dfdb_query_hint_materialize): a single-stage conjunction of simple terms keeps the selected
+    values of a projected 8-byte predicate column; the result must be what the gather gives (= the oracle), for one term
+    (k_scan_cmp) and several (k_scan_terms), Int64 / Float64 / UInt64, full and ragged tiles, and the capture kernel must run."""
+    from dfdb import ir
+    rng = np.random.default_rng(n)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "b": oracle.gen_i64(col_seed(1), 0, n), "x": oracle.gen_f64(col_seed(2), 0, n),
+            "u": rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2), "i32": rng.integers(-100, 100, n).astype(np.int32)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    a, b, x, u, i32 = (ir.col(k) for k in range(5))
+    cases = [(a > 683_771, None), ((a > 683_771) & (x < 632.456), [("b", b), ("x", x)]), (x <= 1000.0, [("x", x), ("a", a)]),
+             ((u >= 2**63) & (a < 500_000) & (i32 > 0), [("u", u), ("i32", i32)]), (a != 5, [("a2", a), ("a", a)]),
+             ((i32 > 0) & (a >= 0), [("i32", i32)])]
+    for pred, proj in cases:
+        ov, dv = apply_stages(p, [("pred", pred)], proj=proj)
+        ctx.profile(True)
+        assert_same(p, ov, dv)
+        ncap, _ = ctx.profile_get("compact_captured")
+        ctx.profile(False)
+        assert ncap >= 1 or proj == [("i32", i32)] or ov.nrow() == 0        # (a 4-byte column is not captured: plain gather)
+    # not the only stage / an OR / a generic conjunct: no capture, same answers
+    for stages, proj in [([("pred", a > 500_000), ("range", 1, 2, n)], [("a", a)]), ([("pred", (a > 900_000) | (x < 100.0))], [("x", x)]),
+                         ([("pred", (a > 500_000) & (a % 7 == 0))], [("a", a)])]:
+        ov, dv = apply_stages(p, stages, proj=proj)
+        assert_same(p, ov, dv)

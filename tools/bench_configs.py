@@ -23,7 +23,7 @@ import dfdb  # noqa: E402
 from dfdb import ir  # noqa: E402
 
 SEED = 0x9E3779B97F4A7C15
-KERNELS = ["lz4_compress", "scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
+KERNELS = ["lz4_compress", "compact_captured", "scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
            "compact_indices", "gather", "str_gather_sizes", "str_gather_bytes", "reduce", "lz4_decode"]
 
 
@@ -95,6 +95,17 @@ def main():
     ctx.profile(False)
     ctx.set_option("scan_nt", 1)
     print(json.dumps({"config": "2-nt-ab", "scan_cmp_ms_default": sorted(ab[0]), "scan_cmp_ms_nt": sorted(ab[1])}))
+    # materialize(t[x > c, :]) with the values on the device: gather vs capture-in-scan (dfdb_query_hint_materialize)
+    import ctypes as C
+    from dfdb import _native as N
+    xs = torch.empty(nsel, dtype=torch.int64, device=dev)
+    o1 = (N.OutCol * 1)(); o1[0].data, o1[0].memkind = xs.data_ptr(), N.MEM_DEVICE
+    for hint in (False, True):
+        q.hint_materialize(hint)
+        ks, wall = timed(ctx, lambda: (q.execute(), N.check(N.load().dfdb_materialize(q._h, o1, 1))), args.reps)
+        print(json.dumps({"config": "2-materialize", "hint": hint, "kernels_ms": ks, "wall_ms": wall * 1e3}))
+    q.hint_materialize(False)
+    del xs
     cx = v[dfdb.ALL, "x"]
     ks, wall = timed(ctx, lambda: (q.execute(), cx.sum()), args.reps)
     print(json.dumps({"config": "2-sum", "kernels_ms": ks, "wall_ms": wall * 1e3}))
@@ -126,6 +137,9 @@ def main():
         q.execute(); N.check(N.load().dfdb_materialize(q._h, outs, 2))
     ks, wall = timed(ctx, step3, args.reps)
     byts = n * 16 + nsel * 8 + nsel * 16
+    print(json.dumps({"config": "3-gather-only", "rows": n, "kernels_ms": ks, "wall_ms": wall * 1e3, "job_GBps": byts / wall / 1e9}))
+    q.hint_materialize(True)        # what materialize() does: the scan keeps the selected x values, b is still gathered
+    ks, wall = timed(ctx, step3, args.reps)
     print(json.dumps({"config": 3, "rows": n, "selected": nsel, "kernels_ms": ks, "wall_ms": wall * 1e3, "algorithmic_GB": byts / 1e9,
                       "job_GBps": byts / wall / 1e9, "rows_per_s": n / wall}))
     # same predicate through the generic interpreter (x*1 defeats the term matcher)
