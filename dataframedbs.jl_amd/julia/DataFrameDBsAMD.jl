@@ -202,6 +202,7 @@ end
 "materialize(v) on the device (materialization.jl:27-40): the selection is evaluated once, outputs are caller-owned Julia vectors."
 function gpu_materialize(v::DFView)
     with_query(v) do q
+        check(ccall((:dfdb_query_hint_materialize, LIB), Int32, (Ptr{Cvoid}, Int32), q, 1))   # the count below is the scan: let it keep projected predicate columns
         n = Ref{Int64}(0)
         check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
         ncols = length(v.projection)
