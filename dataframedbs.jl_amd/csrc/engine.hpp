@@ -96,6 +96,7 @@ int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
+bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread
 // stream.cpp: block-streamed execution over a non-resident table
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);

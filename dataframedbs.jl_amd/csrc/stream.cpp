@@ -94,28 +94,6 @@ namespace dfdb {
 
 namespace {
 
-// file bytes [lo, hi) -> dst with a few concurrent preads (page cache -> pinned memory is a memcpy: one core moves ~5 GB/s)
-bool read_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi) {
-  const int fd = open(file.c_str(), O_RDONLY);
-  if (fd < 0) return false;
-  const int64_t n = hi - lo;
-  const int parts = n > (8 << 20) ? 4 : 1;
-  std::vector<std::thread> th;
-  std::vector<char> ok((size_t)parts, 1);
-  for (int k = 0; k < parts; k++) {
-    const int64_t a = lo + n * k / parts, b = lo + n * (k + 1) / parts;
-    auto work = [fd, dst, lo, a, b, k, &ok] {
-      int64_t got = a;
-      while (got < b) { const ssize_t r = pread(fd, dst + (got - lo), (size_t)(b - got), (off_t)got); if (r <= 0) { ok[(size_t)k] = 0; return; } got += r; }
-    };
-    if (k + 1 < parts) th.emplace_back(work); else work();
-  }
-  for (auto& t : th) t.join();
-  close(fd);
-  for (char c : ok) if (!c) return false;
-  return true;
-}
-
 // loader thread: column files -> HBM (decoded) for blocks [b0, b1), into the slot's persistent table (buffers are reused)
 void load_chunk(dfdb_stream* s, Slot* sl) {
   try {
@@ -136,7 +114,7 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
       }
       // the column header (re-validated by the loader), then the blocks
       const auto t0 = std::chrono::steady_clock::now();
-      if (!read_range(c.file, sl->pin, 0, (int64_t)c.data_off) || !read_range(c.file, sl->pin + c.data_off, lo, hi))
+      if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off) || !read_file_range(c.file, sl->pin + c.data_off, lo, hi))
         fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
       const auto t1 = std::chrono::steady_clock::now();
       dfdb_sizestats st{0, 0, 0};
