@@ -340,8 +340,13 @@ void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t b
     if (stat(c.file.c_str(), &sb) != 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     const size_t fsz = (size_t)sb.st_size;
     uint8_t* pin = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&pin, fsz + 64, hipHostMallocDefault));
-    struct PinFree { uint8_t* p; ~PinFree() { if (p) (void)hipHostFree(p); } } guard{pin};
+    bool pinned = hipHostMalloc((void**)&pin, fsz + 64, hipHostMallocDefault) == hipSuccess && pin;
+    if (!pinned) {   // (a file larger than the pinnable memory: pageable buffer, the runtime stages the copy)
+      (void)hipGetLastError();
+      pin = (uint8_t*)malloc(fsz + 64);
+      if (!pin) fail(DFDB_ERR_NOMEM, "cannot allocate %zu bytes to read %s", fsz, c.file.c_str());
+    }
+    struct PinFree { uint8_t* p; bool pinned; ~PinFree() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } } } guard{pin, pinned};
     if (!read_file_range(c.file, pin, 0, (int64_t)fsz)) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     dfdb_sizestats st{0, 0, 0};
     load_from_image(t, c, pin, fsz, c.data_off, block_first, block_last, &st);
