@@ -378,6 +378,11 @@ class DFTable:
 
     def names(self) -> List[str]: return [m.name for m in self.columns_meta()]
 
+    def resident(self, ordinal: int) -> bool:
+        ci = N.ColInfo()
+        N.check(N.load().dfdb_table_colinfo(self._h, ordinal, C.byref(ci)))
+        return bool(ci.resident)
+
     def ordinal(self, name: str) -> int:
         o = C.c_int32()
         N.check(N.load().dfdb_table_find_column(self._h, name.encode(), C.byref(o)))
@@ -831,7 +836,19 @@ def nrow(v: Union[DFView, DFTable, "DFColumn"]) -> int:      # view.jl:192-206
         v = v.view
     if len(v.projection) == 0:
         return 0      # isempty(it.streams): nothing to read, zero rows (blocksiterator.jl:101)
+    if _out_of_core(v):
+        return nrow_streamed(v)
     return v._query().count()
+
+
+def _out_of_core(v: DFView) -> bool:
+    """The view touches a column of a file-backed table that is not resident (open_table(path, load=False)): evaluate it
+    block-streamed, the way the reference always does (blocksiterator.jl:98-145), instead of refusing."""
+    t = v.table
+    if not t.path:
+        return False
+    need = set(v.required_columns()) or set(t.names()[:1])
+    return any(not t.resident(t.ordinal(n)) for n in need)
 
 
 def ncol(v: Union[DFView, DFTable]) -> int:
@@ -856,6 +873,8 @@ def materialize(v: Union[DFView, DFTable, "DFColumn"]):
     if isinstance(v, DFTable):
         v = DFView(v)
     import pandas as pd
+    if len(v.projection) and _out_of_core(v):
+        return materialize_streamed(v)
     cols = v._query().materialize() if len(v.projection) else []
     return pd.DataFrame({k: _to_user(c) for k, c in zip(v.projection.keys(), cols)})
 

@@ -106,6 +106,11 @@ def test_streamed_conveniences_and_errors(files, oracle, dfdb_mod):
     with dfdb_mod.stream(v, 3) as s:
         st = s.stats()
         assert st["rows"] == p.nrows and st["compressed"] < st["uncompressed"]
+    # the ordinary entry points stream by themselves when the table was opened without loading
+    assert dfdb_mod.nrow(v) == len(want_idx)
+    df2 = dfdb_mod.materialize(v)
+    assert df2["a"].to_numpy().tolist() == df["a"].to_numpy().tolist() and df2["s"].tolist() == df["s"].tolist()
+    assert len(dfdb_mod.head(p.d)) == 10 and dfdb_mod.head(p.d)["iota"].tolist() == list(range(1, 11))
     mem = dfdb_mod.DFTable.from_columns({"a": np.arange(10, dtype=np.int64)})
     with pytest.raises(ValueError):                                           # an in-memory table has no files to stream
         dfdb_mod.stream(mem[dfdb_mod.ALL, dfdb_mod.ALL])
