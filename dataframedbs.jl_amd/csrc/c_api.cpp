@@ -19,15 +19,28 @@ static int32_t guard(F&& f) noexcept {
 #define NEEDQ(q) do { NEED(q); if (!(q)->t) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); } while (0)
 
 namespace dfdb {
-LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n) : ctx(c), name(n) {
-  if (ctx->profiling) (void)hipEventRecord(ctx->pev0, ctx->stream);
+static hipEvent_t prof_event(dfdb_ctx* ctx) {
+  if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n, hipStream_t on) : ctx(c), name(n), stream(on ? on : c->stream) {
+  if (ctx->profiling) { e0 = prof_event(ctx); (void)hipEventRecord(e0, stream); }
 }
 LaunchTimer::~LaunchTimer() {
-  if (!ctx->profiling) return;
-  (void)hipEventRecord(ctx->pev1, ctx->stream);
-  (void)hipEventSynchronize(ctx->pev1);
-  float ms = 0; (void)hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1);
-  auto& e = ctx->prof[name]; e.launches++; e.ms += ms;
+  if (!e0) return;
+  hipEvent_t e1 = prof_event(ctx);
+  (void)hipEventRecord(e1, stream);
+  ctx->prof_pending.push_back({name, e0, e1});
+  if (ctx->prof_pending.size() >= 8192) profile_resolve(ctx);
+}
+void profile_resolve(dfdb_ctx* ctx) {
+  for (auto& p : ctx->prof_pending) {
+    (void)hipEventSynchronize(p.e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, p.e0, p.e1);
+    auto& e = ctx->prof[p.name]; e.launches++; e.ms += ms;
+    ctx->prof_pool.push_back(p.e0); ctx->prof_pool.push_back(p.e1);
+  }
+  ctx->prof_pending.clear();
 }
 void stream_wait(dfdb_ctx* ctx) {
   HIP_CHECK(hipEventRecord(ctx->sync_ev, ctx->stream));
@@ -70,7 +83,6 @@ int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out) {
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
-    HIP_CHECK(hipEventCreate(&c->pev0)); HIP_CHECK(hipEventCreate(&c->pev1));
     HIP_CHECK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc((void**)&c->pinned_scalar, 64, hipHostMallocDefault));
     *out = c.release();
@@ -81,7 +93,11 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); (void)hipEventDestroy(ctx->pev0); (void)hipEventDestroy(ctx->pev1);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    profile_resolve(ctx);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    for (hipEvent_t e : ctx->pipe_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pinned_scalar) (void)hipHostFree(ctx->pinned_scalar);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -118,10 +134,11 @@ int32_t dfdb_ctx_timer_stop(dfdb_ctx* ctx, double* elapsed_ms) {
     *elapsed_ms = ms;
   });
 }
-int32_t dfdb_ctx_profile_enable(dfdb_ctx* ctx, int32_t on) { return guard([&] { NEED(ctx); ctx->profiling = on != 0; if (on) ctx->prof.clear(); }); }
+int32_t dfdb_ctx_profile_enable(dfdb_ctx* ctx, int32_t on) { return guard([&] { NEED(ctx); profile_resolve(ctx); ctx->profiling = on != 0; if (on) ctx->prof.clear(); }); }
 int32_t dfdb_ctx_profile_get(dfdb_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms) {
   return guard([&] {
     NEED(ctx); NEED(kernel);
+    profile_resolve(ctx);
     auto it = ctx->prof.find(kernel);
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;

@@ -80,18 +80,25 @@ struct dfdb_ctx {
   bool profiling = false;
   struct ProfEntry { int64_t launches = 0; double ms = 0; };
   std::map<std::string, ProfEntry> prof;
-  hipEvent_t pev0 = nullptr, pev1 = nullptr; // per-launch profiling
+  // per-launch profiling without host synchronisation: event pairs are recorded on the launch stream and resolved when the
+  // numbers are read (dfdb_ctx_profile_get / disable), so a profiled step runs at the speed of an unprofiled one
+  struct ProfPending { const char* name; hipEvent_t e0, e1; };
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
   hipDeviceProp_t prop{};
   int64_t* pinned_scalar = nullptr;          // 64 B of pinned host memory for small readbacks
   hipEvent_t sync_ev = nullptr;              // stream_wait()
   std::map<std::string, int64_t> options;    // dfdb_ctx_set_option
+  // second stream + events for work that overlaps the main stream inside ONE call (pipelined select_indices)
+  hipStream_t side = nullptr;
+  hipEvent_t pipe_ev[9] = {};
 };
 
 namespace dfdb {
 // RAII per-launch profiler: when ctx->profiling, brackets a launch with events on the engine stream
 struct LaunchTimer {
-  dfdb_ctx* ctx; const char* name;
-  LaunchTimer(dfdb_ctx* c, const char* n);
+  dfdb_ctx* ctx; const char* name; hipEvent_t e0 = nullptr; hipStream_t stream;
+  LaunchTimer(dfdb_ctx* c, const char* n, hipStream_t on = nullptr);   // on: the stream the launch goes to (default: the engine stream)
   ~LaunchTimer();
 };
 }  // namespace dfdb
@@ -102,4 +109,5 @@ namespace dfdb {
 void stream_wait(dfdb_ctx* ctx);
 // runtime tuning knobs (dfdb_ctx_set_option)
 int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt);
+void profile_resolve(dfdb_ctx* ctx);   // fold the pending event pairs into ctx->prof
 }  // namespace dfdb

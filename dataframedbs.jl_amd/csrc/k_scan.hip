@@ -405,8 +405,10 @@ __global__ __launch_bounds__(kBlock) void k_sc_scan_chunks(uint64_t* __restrict_
   if (threadIdx.x == 0) chunk_sums[nchunks] = carry_sh;
 }
 
+// carry_in / carry_out: the scan of one PIECE of a column continues the previous piece's (pipelined select_indices)
 __global__ __launch_bounds__(kBlock) void k_sc_down(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ chunk_sums,
-                                                    uint64_t* __restrict__ prefix, int64_t ntiles, int64_t nchunks) {
+                                                    uint64_t* __restrict__ prefix, int64_t ntiles, int64_t nchunks,
+                                                    const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ carry_out) {
   __shared__ uint64_t wave_tot[4];
   const int64_t base = (int64_t)blockIdx.x * kScChunk + (int64_t)threadIdx.x * kScPerThread;
   uint32_t v[kScPerThread];
@@ -416,21 +418,23 @@ __global__ __launch_bounds__(kBlock) void k_sc_down(const uint32_t* __restrict__
   const uint64_t incl = wave_incl_scan64(tsum);
   if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
   __syncthreads();
-  uint64_t run = chunk_sums[blockIdx.x] + incl - tsum;
+  const uint64_t carry = carry_in ? *carry_in : 0ull;
+  uint64_t run = carry + chunk_sums[blockIdx.x] + incl - tsum;
   for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
 #pragma unroll
   for (int k = 0; k < kScPerThread; k++) { const int64_t i = base + k; if (i < ntiles) prefix[i] = run; run += v[k]; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) prefix[ntiles] = chunk_sums[nchunks];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { prefix[ntiles] = carry + chunk_sums[nchunks]; if (carry_out) *carry_out = carry + chunk_sums[nchunks]; }
 }
 
 size_t scan_counts_scratch_bytes(int64_t ntiles) { return (size_t)((ntiles + kScChunk - 1) / kScChunk + 2) * 8; }
 
-void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch) {
+void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch, const uint64_t* carry_in,
+                        uint64_t* carry_out) {
   if (ntiles <= 0) { (void)hipMemsetAsync(prefix, 0, 8, s); return; }
   const int64_t nchunks = (ntiles + kScChunk - 1) / kScChunk;
   hipLaunchKernelGGL(k_sc_reduce, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, ntiles);
   hipLaunchKernelGGL(k_sc_scan_chunks, dim3(1), dim3(kBlock), 0, s, scratch, nchunks);
-  hipLaunchKernelGGL(k_sc_down, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, prefix, ntiles, nchunks);
+  hipLaunchKernelGGL(k_sc_down, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, prefix, ntiles, nchunks, carry_in, carry_out);
 }
 
 }  // namespace dfdb

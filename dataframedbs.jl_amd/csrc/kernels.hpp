@@ -43,7 +43,9 @@ void launch_scan_compact(hipStream_t s, const void* col, int32_t dtype, int op, 
 
 // ---- tile-count scan: u32 counts[ntiles] -> u64 prefix[ntiles+1] (prefix[ntiles] = total) -------
 // scratch: >= (ceil(ntiles/4096)+1) * 8 bytes
-void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch);
+// carry_in/carry_out (device, optional): continue the scan of the previous piece of the same column
+void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch,
+                        const uint64_t* carry_in = nullptr, uint64_t* carry_out = nullptr);
 size_t scan_counts_scratch_bytes(int64_t ntiles);
 
 // ---- range stages (selection.jl:94-111 on the packed mask) --------------------------------------

@@ -486,3 +486,35 @@ def test_materialize_captures_projected_predicate_columns(oracle, dfdb_mod, ctx,
                          ([("pred", (a > 500_000) & (a % 7 == 0))], [("a", a)])]:
         ov, dv = apply_stages(p, stages, proj=proj)
         assert_same(p, ov, dv)
+
+
+def test_pipelined_select_indices_option(oracle, dfdb_mod, ctx):
+    """option pipeline=1: K1 in four pieces on the engine stream, count scan + K2 of each piece on a side stream; the indices,
+    the count and the state a later gather uses must be those of the plain path."""
+    import torch
+    from dfdb import _native as N
+    n = (1 << 26) + 12_345          # the pipelined path starts at 2^26 rows
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("x", dfdb_mod.GEN_I64_MOD1M, col_seed(0), n)
+    v = t[("x", lambda x: x > 899_999), dfdb_mod.ALL]
+    dev = torch.device("cuda", 0)
+    res = []
+    for pipe in (0, 1, 1):
+        ctx.set_option("pipeline", pipe)
+        try:
+            q = v._query()
+            cap = n // 5
+            out = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+            got = q.indices_device(out.data_ptr(), cap, want_count=True)
+            xs = torch.empty(got, dtype=torch.int64, device=dev)
+            o = (N.OutCol * 1)(); o[0].data, o[0].memkind = xs.data_ptr(), N.MEM_DEVICE
+            N.check(N.load().dfdb_materialize(q._h, o, 1))
+            ctx.synchronize(); torch.cuda.synchronize()
+            res.append((got, out[:got].clone(), xs.clone(), q.bitmap()))
+        finally:
+            ctx.set_option("pipeline", 0)
+    want = np.nonzero(oracle.gen_i64(col_seed(0), 0, n) > 899_999)[0] + 1
+    for got, idx, xs, bm in res:
+        assert got == len(want) and np.array_equal(idx.cpu().numpy(), want)
+        assert torch.equal(xs, res[0][2]) and np.array_equal(bm, res[0][3])
+    t.close()
