@@ -114,3 +114,41 @@ def test_streamed_conveniences_and_errors(files, oracle, dfdb_mod):
     mem = dfdb_mod.DFTable.from_columns({"a": np.arange(10, dtype=np.int64)})
     with pytest.raises(ValueError):                                           # an in-memory table has no files to stream
         dfdb_mod.stream(mem[dfdb_mod.ALL, dfdb_mod.ALL])
+
+
+def test_streamed_errors_surface(oracle, dfdb_mod, tmp_path):
+    """A corrupt block met while streaming raises "decompression error" (BlockStreams.jl:112) from the iteration that needs it;
+    chunks before it are delivered; a DivideError inside a chunk's predicate surfaces from that chunk's count()."""
+    from dfdb import ir
+    n, bs = 40_000, 4096
+    t = oracle.Table(block_size=bs)
+    t.add_column("a", np.arange(1, n + 1, dtype=np.int64))
+    t.add_column("z", (np.arange(n) < 30_000).astype(np.int64))       # zeros from row 30 001 on
+    path = str(tmp_path / "tb")
+    t.save(path)
+    tb = dfdb_mod.open_table(path, load=False)
+    # DivideError in the chunk that first divides by zero (chunk 3 = rows 24 577 .. 32 768)
+    v = tb[(tb.a % tb.z) == 0, dfdb_mod.ALL]
+    seen = 0
+    with pytest.raises(ZeroDivisionError):
+        with dfdb_mod.stream(v, 2) as s:
+            for part in s:
+                seen += part.count()
+    assert seen == 3 * 8192                                            # the three chunks before the first zero divisor (row 30 001) were counted
+    # corrupt the LZ4 payload of the 6th block of column a
+    import struct
+    f = tmp_path / "tb" / "1.bin"
+    raw = bytearray(f.read_bytes())
+    pos = 8 + 4 + len("Int64")
+    for _ in range(5):
+        rows, origin, comp = struct.unpack_from("<iqq", raw, pos)
+        pos += 20 + comp
+    raw[pos + 20: pos + 24] = b"\xff\xff\xff\xff"
+    f.write_bytes(bytes(raw))
+    tb2 = dfdb_mod.open_table(path, load=False)
+    got = 0
+    with pytest.raises(dfdb_mod.DfdbError, match="decompression error"):
+        with dfdb_mod.stream(tb2[dfdb_mod.ALL, ["a"]], 2) as s:
+            for part in s:
+                got += part.count()
+    assert got == 4 * bs                                               # chunks 0 and 1 (blocks 0-3) were delivered, chunk 2 holds block 5
