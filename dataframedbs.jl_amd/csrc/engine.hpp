@@ -95,6 +95,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
 int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
+void query_unique(dfdb_query* q, int32_t p);
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread
 // stream.cpp: block-streamed execution over a non-resident table

@@ -99,6 +99,13 @@ void launch_reduce(hipStream_t s, const uint64_t* bitmap, const void* col, int32
                    void* result /* 16 bytes: i64/u64 or f64 result + count */);
 size_t reduce_scratch_bytes();
 
+// ---- unique(col) as a selection of first occurrences (k_unique.hip).  pass 0: insert, 1: (strings) verify / (fixed) mark, 2: (strings) mark
+void launch_unique_fixed(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing,
+                         int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t mask, uint64_t* special);
+void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
+                       const uint8_t* bytes, int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
+                       uint64_t* special, uint64_t salt, int* collision);
+
 // ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------
 struct Lz4Block {      // one (column, block) unit of work
   int64_t src_off;     // offset of the compressed bytes inside the staged image

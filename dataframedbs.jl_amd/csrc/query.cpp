@@ -97,6 +97,8 @@ static void ensure_state(dfdb_query* q) {
   }
 }
 
+static uint64_t splitmix64_host(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
+
 static const Column& need_resident(const dfdb_table* t, int ordinal) {
   const Column& c = t->cols[(size_t)ordinal];
   if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
@@ -479,6 +481,52 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
   c.resident = true;
   if (dst->nrows < 0) dst->nrows = cnt;
   dst->cols.push_back(std::move(c));
+}
+
+// unique(col) (column.jl:102-126 driving Base.unique; docs/src/index.md:171-182,479-486): the current selection is narrowed to
+// the rows that hold the FIRST occurrence of their value in projection column p (isequal semantics), so count / materialize
+// afterwards return the distinct values in order of first appearance.  A later reset / execute restores the full selection.
+void query_unique(dfdb_query* q, int32_t p) {
+  ensure_executed(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
+  const Node& e = *q->proj[(size_t)p].expr;
+  if (e.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "unique of a computed column: materialise it as a column first (dfdb_table_add_from_query)");
+  const Column& col = need_resident(t, e.col);
+  const int64_t cnt = query_count(q, -1);
+  if (cnt == 0 || t->nrows == 0) return;
+  uint64_t cap = 1024; while (cap < (uint64_t)cnt * 2) cap <<= 1;
+  const bool is_str = dt_base(col.dtype) == DFDB_STRING;
+  DevBuf keys, rows, aux, rep_off, rep_len;
+  keys.ensure(cap * 8); rows.ensure(cap * 8); aux.ensure(64);
+  if (is_str) { rep_off.ensure(cap * 8); rep_len.ensure(cap * 4); }
+  uint64_t* special = aux.as<uint64_t>(); int* collision = (int*)(aux.as<uint8_t>() + 32);
+  LaunchTimer lt(ctx, "unique");
+  for (uint64_t salt = 0x51ED270B27B4F3CFull, tries = 0;; salt = splitmix64_host(salt), tries++) {
+    HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, cap * 8, s));
+    HIP_CHECK(hipMemsetAsync(rows.p, 0xFF, cap * 8, s));
+    HIP_CHECK(hipMemsetAsync(aux.p, 0xFF, 16, s));
+    HIP_CHECK(hipMemsetAsync((char*)aux.p + 32, 0, 4, s));
+    if (!is_str) {
+      const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
+      launch_unique_fixed(s, 0, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.p, dt_base(col.dtype), miss, t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), cap - 1, special);
+      launch_unique_fixed(s, 1, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.p, dt_base(col.dtype), miss, t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), cap - 1, special);
+      break;
+    }
+    auto pass = [&](int k) {
+      launch_unique_str(s, k, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                        t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), rep_off.as<uint64_t>(), rep_len.as<uint32_t>(), cap - 1, special, salt, collision);
+    };
+    pass(0); pass(1);
+    int hit = 0;
+    HIP_CHECK(hipMemcpyAsync(&hit, collision, 4, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    if (!hit) { pass(2); break; }                          // no two different strings shared a key: the table is exact
+    if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
+  }
+  scan_prefix(q);
+  q->count = -1; q->cap_col = -1;
+  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
 }
 
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {

@@ -939,6 +939,27 @@ class DFColumn:
         dest[:len(vals)] = vals
         return dest
 
+    def unique(self):
+        """unique(col) (docs/src/index.md:171-182): the distinct values in order of first appearance.  On the device the
+        first occurrences are a selection (dfdb_query_unique); over a table that is not resident every chunk is reduced on the
+        device and the (small) per-chunk results are merged in order on the host."""
+        def one(q):
+            q.hint_materialize(True)
+            q.execute()
+            N.check(N.load().dfdb_query_unique(q._h, 0))
+            return _to_user(q.materialize()[0])
+        if _out_of_core(self.view):
+            seen, out = set(), []
+            with Stream(self.view) as s:
+                for part in s:
+                    vals = one(part)
+                    for v in (vals.tolist() if not isinstance(vals, np.ma.MaskedArray) else [None if m else x for x, m in zip(vals.data.tolist(), np.ma.getmaskarray(vals).tolist())]):
+                        k = ("nan",) if isinstance(v, float) and v != v else v
+                        if k not in seen:
+                            seen.add(k); out.append(v)
+            return np.array(out, dtype=object) if out and isinstance(out[0], (str, type(None))) else np.array(out)
+        return one(self.view._query())
+
     def sum(self): return self.view._query().aggregate(N.AGG_SUM)
     def min(self): return self.view._query().aggregate(N.AGG_MIN)
     def max(self): return self.view._query().aggregate(N.AGG_MAX)

@@ -201,6 +201,13 @@ int32_t dfdb_query_execute(dfdb_query* q);
  * query holds an extra nrows*8-byte buffer while the hint is on. */
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on);
 
+/* unique(col) (Base.unique over Base.iterate(::DFColumn), src/tables/column.jl:102-126; docs/src/index.md:171-182,479-486):
+ * narrows the CURRENT selection of q to the rows holding the first occurrence of their value in projection column proj_col
+ * (a plain column; isequal semantics: NaN == NaN, 0.0 != -0.0, missing == missing), so dfdb_count / dfdb_materialize
+ * afterwards give the distinct values in order of first appearance, like Julia.  dfdb_query_reset / _execute restore the
+ * full selection. */
+int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col);
+
 /* forget the cached execution so the next count/indices/materialize re-evaluates the selection (a new
  * BlocksIterator in the reference: blocksiterator.jl:20-44).  dfdb_select_indices on a reset single-predicate
  * query with a device output runs the fused one-pass kernel (scan + look-back + compaction). */

@@ -518,3 +518,57 @@ def test_pipelined_select_indices_option(oracle, dfdb_mod, ctx):
         assert got == len(want) and np.array_equal(idx.cpu().numpy(), want)
         assert torch.equal(xs, res[0][2]) and np.array_equal(bm, res[0][3])
     t.close()
+
+
+# ------------------------------------------------------------------ unique(col): first occurrences as a selection
+def julia_unique(values, missing=None):
+    """Base.unique: first occurrence order, isequal (NaN == NaN, 0.0 != -0.0, missing == missing)."""
+    seen, out = set(), []
+    for i, v in enumerate(values):
+        if missing is not None and missing[i]:
+            k = ("missing",)
+        elif isinstance(v, (float, np.floating)):
+            k = ("nan",) if v != v else ("f", float(v), bool(np.signbit(v)))
+        else:
+            k = v
+        if k not in seen:
+            seen.add(k); out.append(None if k == ("missing",) else v)
+    return out
+
+
+def test_unique_columns(oracle, dfdb_mod, ctx, tmp_path):
+    rng = np.random.default_rng(31)
+    n = 250_007
+    strs = oracle.flat_to_strings(*oracle.gen_str(col_seed(3), 0, n))
+    long_strs = [f"user-{int(k):07d}-{'x' * int(k % 23)}" for k in rng.integers(0, 5000, n)]
+    f = rng.integers(-3, 4, n).astype(np.float64); f[::97] = np.nan; f[5::101] = -0.0
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n) % 1000, "b": rng.integers(-2**62, 2**62, n).astype(np.int64), "f": f,
+            "i8": rng.integers(-128, 128, n).astype(np.int8), "u": np.where(rng.random(n) < 0.01, np.uint64(2**64 - 1), rng.integers(0, 50, n).astype(np.uint64)),
+            "s": strs, "ls": long_strs, "sm": [None if i % 11 == 3 else s for i, s in enumerate(strs)],
+            "m": np.ma.masked_array(rng.integers(0, 30, n).astype(np.int64), mask=rng.random(n) < 0.2), "flag": rng.integers(0, 2, n).astype(bool)}
+    t = dfdb_mod.DFTable.from_columns(cols, block_size=65536)
+    for name in cols:
+        got = getattr(t, name).unique()
+        src = cols[name]
+        if isinstance(src, np.ma.MaskedArray):
+            want = julia_unique(src.data.tolist(), np.ma.getmaskarray(src).tolist())
+            g = [None if mm else x for x, mm in zip(np.asarray(got.data).tolist(), np.ma.getmaskarray(got).tolist())]
+            assert g == want, name
+        elif isinstance(src, list):
+            assert list(got) == julia_unique(src, [x is None for x in src]), name
+        elif src.dtype.kind == "f":
+            want = julia_unique(src.tolist())
+            assert len(got) == len(want) and all((x != x and y != y) or (x == y and np.signbit(x) == np.signbit(y)) for x, y in zip(got.tolist(), want)), name
+        else:
+            assert got.tolist() == julia_unique(src.tolist()), name
+    # unique(t.brand[t.brand .!= ""]) of the docs: over a filtered view, and count == number of distinct values
+    v = t[(t.a > 500) & (t.s != "sony"), ["ls"]]
+    want = julia_unique([x for x, a, s in zip(long_strs, cols["a"], strs) if a > 500 and s != "sony"])
+    assert list(v.ls.unique()) == want
+    with pytest.raises(NotImplementedError):
+        (t.a * 2).unique()
+    # the same column through a table that is never resident: per-chunk unique on the device, merged in order
+    path = str(tmp_path / "tb")
+    t.save(path)
+    tb = dfdb_mod.open_table(path, load=False)
+    assert list(tb.s.unique()) == julia_unique(strs) and tb.a.unique().tolist() == julia_unique(cols["a"].tolist())
