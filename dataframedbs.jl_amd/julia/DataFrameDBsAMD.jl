@@ -200,9 +200,11 @@ function gpu_nrow(v::DFView)
 end
 
 "materialize(v) on the device (materialization.jl:27-40): the selection is evaluated once, outputs are caller-owned Julia vectors."
-function gpu_materialize(v::DFView)
+function gpu_materialize(v::DFView; first_occurrences_of::Int = -1)
     with_query(v) do q
         check(ccall((:dfdb_query_hint_materialize, LIB), Int32, (Ptr{Cvoid}, Int32), q, 1))   # the count below is the scan: let it keep projected predicate columns
+        # unique: narrow the selection to the first occurrence of every value of that projection column (Julia's order)
+        first_occurrences_of >= 0 && check(ccall((:dfdb_query_unique, LIB), Int32, (Ptr{Cvoid}, Int32), q, first_occurrences_of))
         n = Ref{Int64}(0)
         check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
         ncols = length(v.projection)
@@ -242,6 +244,9 @@ function gpu_materialize(v::DFView)
         DataFrames.DataFrame(collect(cols), collect(keys(v.projection)), copycols = false)
     end
 end
+
+"unique(col::DFColumn) on the device (docs/src/index.md:171-182): distinct values in order of first appearance."
+gpu_unique(c::DFColumn) = gpu_materialize(c.view; first_occurrences_of = 0)[!, 1]
 
 # ---------------------------------------------------------------- write side (create_table / add_column!)
 struct SizeStatsC; rows::Int64; compressed::Int64; uncompressed::Int64; end
