@@ -505,6 +505,7 @@ def test_pipelined_select_indices_option(oracle, dfdb_mod, ctx):
             q = v._query()
             cap = n // 5
             out = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()      # torch fills on ITS stream; the engine writes on its own (non-blocking) one
             got = q.indices_device(out.data_ptr(), cap, want_count=True)
             xs = torch.empty(got, dtype=torch.int64, device=dev)
             o = (N.OutCol * 1)(); o[0].data, o[0].memkind = xs.data_ptr(), N.MEM_DEVICE
