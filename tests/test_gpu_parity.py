@@ -305,6 +305,7 @@ def test_fused_scan_compact(oracle, dfdb_mod, ctx, n, dtype):
     for fused in (1, 0, 1):
         ctx.set_option("fused", fused)
         out.fill_(-7)
+        torch.cuda.synchronize()          # torch fills on ITS stream; the engine writes on its own (non-blocking) one
         q.reset()
         got_n = q.indices_device(out.data_ptr(), len(want), want_count=True)
         torch.cuda.synchronize()
