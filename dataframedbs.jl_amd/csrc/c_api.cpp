@@ -173,6 +173,7 @@ int32_t dfdb_table_colinfo(dfdb_table* t, int32_t ordinal, dfdb_colinfo* out) {
     const Column& c = t->cols[(size_t)ordinal];
     memset(out, 0, sizeof *out);
     out->id = c.id; snprintf(out->name, sizeof out->name, "%s", c.name.c_str()); out->dtype = c.dtype; out->resident = c.resident ? 1 : 0;
+    snprintf(out->logical, sizeof out->logical, "%s", c.logical.c_str());
   });
 }
 int32_t dfdb_table_find_column(dfdb_table* t, const char* name, int32_t* ordinal) {
@@ -202,6 +203,17 @@ int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query*
 int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(path); table_save(t, path, stats); }); }
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
   return guard([&] { NEED(t); NEED(file); table_save_column(t, ordinal, file, stats); });
+}
+int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical) {
+  return guard([&] {
+    NEED(t); NEED(logical);
+    if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
+    Column& c = t->cols[(size_t)ordinal];
+    std::string lg;
+    const int32_t want = *logical ? dt_parse_ex(logical, &lg) : c.dtype;
+    if (*logical && (lg.empty() || dt_base(want) != dt_base(c.dtype))) fail(DFDB_ERR_ARGUMENT, "ArgumentError: %s is not the representation of a %s column", dt_name(c.dtype).c_str(), logical);
+    c.logical = lg;
+  });
 }
 int32_t dfdb_table_set_row_base(dfdb_table* t, int64_t row_base) { return guard([&] { NEED(t); t->row_base = row_base; }); }
 

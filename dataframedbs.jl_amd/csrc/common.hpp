@@ -35,6 +35,10 @@ inline bool dt_isnum(int32_t dt) { return dt_isint(dt) || dt_isfloat(dt) || dt_b
 int dt_width(int32_t dt);
 std::string dt_name(int32_t dt);
 int32_t dt_parse(const std::string& s);
+// + the Julia bits types whose blocks are plain integers (Date / DateTime / Time -> Int64, Char -> UInt32): the storage dtype,
+// and the type string itself in *logical ("" for an ordinary dtype)
+int32_t dt_parse_ex(const std::string& s, std::string* logical);
+std::string dt_type_string(int32_t dt, const std::string& logical);
 
 // ---- geometry -----------------------------------------------------------------------------------
 // A "tile" is the unit one wavefront scans: 1024 rows = 16 bitmap words = one 128-B line of bitmap.

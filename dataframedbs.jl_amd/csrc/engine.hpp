@@ -11,6 +11,7 @@ struct Column {
   std::string name;
   int64_t id = 0;
   int32_t dtype = 0;
+  std::string logical;   // "Date" / "DateTime" / "Time" / "Char": a bits type carried as its integer representation ("" otherwise)
   bool resident = false;
   int64_t nrows = 0;
   DevBuf data;       // fixed width: nrows*width bytes (+ pad); String: int32 sizes[nrows] (-1 = missing)

@@ -28,6 +28,22 @@ int32_t dt_parse(const std::string& s0) {
   fail(DFDB_ERR_UNSUPPORTED, "UndefinedType: column type '%s' is outside the engine's dtype set", s0.c_str());
 }
 
+// read_block_body! is a memcpy for every isbits T (src/io/blocks.jl:37-44), so Date / DateTime / Time / Char columns are
+// integer columns to the hot path (days / milliseconds / nanoseconds / the UInt32 holding the UTF-8 bytes); the host side
+// reinterprets values and lowers constants (columntypes/base.jl:108-126 and complex.jl name the type strings)
+static const struct { const char* name; int dtype; } kAlias[] = {{"Date", DFDB_I64}, {"DateTime", DFDB_I64}, {"Time", DFDB_I64}, {"Char", DFDB_U32}};
+int32_t dt_parse_ex(const std::string& s0, std::string* logical) {
+  std::string s = s0; int32_t flag = 0;
+  if (logical) logical->clear();
+  if (s.size() > 9 && s.compare(0, 8, "Missing(") == 0 && s.back() == ')') { flag = DFDB_NULLABLE; s = s.substr(8, s.size() - 9); }
+  for (const auto& a : kAlias) if (s == a.name) { if (logical) *logical = a.name; return a.dtype | flag; }
+  return dt_parse(s0);
+}
+std::string dt_type_string(int32_t dt, const std::string& logical) {
+  if (logical.empty()) return dt_name(dt);
+  return dt_nullable(dt) ? "Missing(" + logical + ")" : logical;
+}
+
 int promote_num(int a, int b) {   // Julia promote_type restricted to the column dtypes
   a = dt_base(a); b = dt_base(b);
   if (a == DFDB_BOOL && b == DFDB_BOOL) return DFDB_BOOL;

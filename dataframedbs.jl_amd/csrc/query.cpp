@@ -455,6 +455,7 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
     fail(DFDB_ERR_ARGUMENT, "ArgumentError: column has %lld rows but the table has %lld", (long long)cnt, (long long)dst->nrows);
   dfdb_ctx* ctx = dst->ctx; hipStream_t s = ctx->stream;
   Column c; c.name = name; c.dtype = e.dtype; c.id = 1; c.nrows = cnt;
+  if (e.op == DFIR_COL) c.logical = q->t->cols[(size_t)e.col].logical;   // a projected Date / DateTime / Char column keeps its type
   for (auto& o : dst->cols) c.id = std::max(c.id, o.id + 1);
   dfdb_outcol o{}; o.memkind = DFDB_MEM_DEVICE;
   DevBuf flags;

@@ -231,7 +231,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     auto tb = std::make_unique<dfdb_table>();            // the slot's chunk table: same columns, its own stream, reused buffers
     tb->ctx = sl.ctx; tb->path = t->path; tb->block_size = t->block_size; tb->format_version = t->format_version;
     tb->keep_load_scratch = true;
-    for (const Column& c : t->cols) { Column n; n.name = c.name; n.id = c.id; n.dtype = c.dtype; n.file = c.file; n.data_off = c.data_off; tb->cols.push_back(std::move(n)); }
+    for (const Column& c : t->cols) { Column n; n.name = c.name; n.id = c.id; n.dtype = c.dtype; n.logical = c.logical; n.file = c.file; n.data_off = c.data_off; tb->cols.push_back(std::move(n)); }
     auto cq = std::make_unique<dfdb_query>();             // the caller's query re-stated over the chunk table
     cq->t = tb.get();
     for (const Stage& st : q->stages) {

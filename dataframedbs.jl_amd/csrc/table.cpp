@@ -72,7 +72,7 @@ void table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out) {
   for (int64_t i = 0; i < ncols; i++) {
     Column c; std::string ty;
     if (!r.i64(c.id) || !r.str(c.name) || !r.str(ty)) fail(DFDB_ERR_FORMAT, "bad meta.bin in %s", path);
-    c.dtype = dt_parse(ty);
+    c.dtype = dt_parse_ex(ty, &c.logical);
     c.file = dir + "/" + std::to_string(c.id) + ".bin";   // columnpath: filesystem.jl:11
     t->cols.push_back(std::move(c));
   }
@@ -83,7 +83,8 @@ void table_open(dfdb_ctx* ctx, const char* path, dfdb_table** out) {
     int64_t bs; std::string ty;
     if (!hr.i64(bs) || !hr.str(ty)) fail(DFDB_ERR_FORMAT, "bad column header in %s", c.file.c_str());
     if (bs != t->block_size) fail(DFDB_ERR_FORMAT, "column %s has blocksize %lld, but table has blocksize %lld", c.name.c_str(), (long long)bs, (long long)t->block_size);
-    if (dt_parse(ty) != c.dtype) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_name(c.dtype).c_str());
+    std::string lg;
+    if (dt_parse_ex(ty, &lg) != c.dtype || lg != c.logical) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_type_string(c.dtype, c.logical).c_str());
     c.data_off = hr.pos;
   }
   *out = t.release();
@@ -318,7 +319,8 @@ void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size
   Rd hr{image, nbytes, 0}; int64_t bs; std::string ty;
   if (!hr.i64(bs) || !hr.str(ty)) fail(DFDB_ERR_FORMAT, "bad column header");
   if (bs != t->block_size) fail(DFDB_ERR_FORMAT, "column %s has blocksize %lld, but table has blocksize %lld", c.name.c_str(), (long long)bs, (long long)t->block_size);
-  if (dt_parse(ty) != c.dtype) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_name(c.dtype).c_str());
+  std::string lg;
+  if (dt_parse_ex(ty, &lg) != c.dtype || lg != c.logical) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_type_string(c.dtype, c.logical).c_str());
   dfdb_sizestats st{0, 0, 0};
   load_from_image(t, c, image, nbytes, hr.pos, block_first, block_last, &st);
   if (stats) *stats = st;

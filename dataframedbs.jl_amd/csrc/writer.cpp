@@ -56,7 +56,7 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
   const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
 
   File f(file);
-  { Wr h; h.i64(B); h.str(dt_name(c.dtype)); f.put(h.b.data(), h.b.size()); }   // write_column_head: filesystem.jl:14-23
+  { Wr h; h.i64(B); h.str(dt_type_string(c.dtype, c.logical)); f.put(h.b.data(), h.b.size()); }   // write_column_head: filesystem.jl:14-23
   dfdb_sizestats st{0, 0, 0};
   st.rows = nrows;
 
@@ -155,7 +155,7 @@ void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) {
     tot.rows = st.rows; tot.compressed += st.compressed; tot.uncompressed += st.uncompressed;
   }
   Wr m; m.i64(t->format_version); m.i64(t->block_size); m.i64((int64_t)t->cols.size());
-  for (auto& c : t->cols) { m.i64(c.id); m.str(c.name); m.str(dt_name(c.dtype)); }
+  for (auto& c : t->cols) { m.i64(c.id); m.str(c.name); m.str(dt_type_string(c.dtype, c.logical)); }
   File f(dir + "/meta.bin");   // written last: a table without meta.bin "don't exists" (creators.jl:9)
   f.put(m.b.data(), m.b.size());
   f.close();

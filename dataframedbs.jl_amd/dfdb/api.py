@@ -256,12 +256,15 @@ def default_context(device: int = 0) -> Context:
 
 
 class ColumnMeta:
-    def __init__(self, id: int, name: str, dtype: int):
-        self.id, self.name, self.dtype = id, name, dtype
+    def __init__(self, id: int, name: str, dtype: int, logical: str = ""):
+        self.id, self.name, self.dtype, self.logical = id, name, dtype, logical
 
     @property
-    def type(self) -> str: return ir.dtype_name(self.dtype)
-    def __eq__(self, o): return isinstance(o, ColumnMeta) and (self.id, self.name, self.dtype) == (o.id, o.name, o.dtype)
+    def type(self) -> str:
+        if not self.logical:
+            return ir.dtype_name(self.dtype)
+        return f"Missing({self.logical})" if self.dtype & ir.NULLABLE else self.logical     # Date / DateTime / Time / Char
+    def __eq__(self, o): return isinstance(o, ColumnMeta) and (self.id, self.name, self.dtype, self.logical) == (o.id, o.name, o.dtype, o.logical)
     def __repr__(self): return f"ColumnMeta({self.id}, :{self.name}, {self.type})"
 
 
@@ -291,8 +294,27 @@ class DFTable:
             t.add_column(name, v)
         return t
 
-    def add_column(self, name: str, values, dtype: Optional[int] = None):
+    def add_column(self, name: str, values, dtype: Optional[int] = None, logical: Optional[str] = None):
+        """values: numpy array (datetime64 / timedelta64 become Date / DateTime / Time columns), masked array, or a list of str / None.
+        logical="Char" with 1-character strings makes a Char column."""
         L = N.load()
+        if logical == "Char":
+            values = np.array([ir.julia_char(c) for c in values], np.uint32)
+        elif isinstance(values, np.ndarray) and values.dtype.kind in "Mm":
+            fill = None
+            if isinstance(values, np.ma.MaskedArray):
+                fill = np.ma.getmaskarray(values); values = values.filled(values.dtype.type(0))
+            if values.dtype.kind == "m":
+                ints, logical = values.astype("timedelta64[ns]").astype(np.int64), "Time"
+            elif np.datetime_data(values.dtype)[0] in ("D", "W", "M", "Y"):
+                ints, logical = values.astype("datetime64[D]").astype(np.int64) + ir.RATA_DIE_DAYS, "Date"
+            else:
+                ints, logical = values.astype("datetime64[ms]").astype(np.int64) + ir.RATA_DIE_MS, "DateTime"
+            values = np.ma.masked_array(ints, mask=fill) if fill is not None else ints
+        if logical:
+            self.add_column(name, values, dtype)
+            N.check(L.dfdb_table_set_logical_type(self._h, self.ordinal(name), logical.encode()))
+            return
         if isinstance(values, (list, tuple)) and (len(values) == 0 or isinstance(values[0], (str, bytes, type(None)))) and not isinstance(values, np.ndarray):
             enc = [None if v is None else (v.encode() if isinstance(v, str) else bytes(v)) for v in values]
             sizes = np.array([-1 if e is None else len(e) for e in enc], np.int32)
@@ -373,7 +395,7 @@ class DFTable:
         for i in range(self.ncols):
             ci = N.ColInfo()
             N.check(N.load().dfdb_table_colinfo(self._h, i, C.byref(ci)))
-            out.append(ColumnMeta(ci.id, ci.name.decode(), ci.dtype))
+            out.append(ColumnMeta(ci.id, ci.name.decode(), ci.dtype, ci.logical.decode()))
         return out
 
     def names(self) -> List[str]: return [m.name for m in self.columns_meta()]
@@ -803,10 +825,11 @@ def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 4096):
     import pandas as pd
     view = v if isinstance(v, DFView) else DFView(v)
     names = view.names()
+    lgs = _logicals(view)
     parts = []
     with Stream(view, chunk_blocks) as s:
         for part in s:
-            parts.append([_to_user(c) for c in part.materialize()])
+            parts.append([_to_user(c, lgs[i]) for i, c in enumerate(part.materialize())])
     if not parts:                      # nothing streamed (empty table / exhausted range): typed empty columns of the plain path
         return pd.DataFrame({n: [] for n in names})
     cols = {}
@@ -868,20 +891,33 @@ def size(v, dim: Optional[int] = None):
 def materialize(v: Union[DFView, DFTable, "DFColumn"]):
     """materialize(::DFView) -> pandas.DataFrame (stand-in for DataFrames.DataFrame); materialize(::DFColumn) -> array."""
     if isinstance(v, DFColumn):
+        if _out_of_core(v.view):
+            return materialize_streamed(v.view).iloc[:, 0].to_numpy()
         cols = v.view._query().materialize()
-        return _to_user(cols[0])
+        return _to_user(cols[0], _logicals(v.view)[0])
     if isinstance(v, DFTable):
         v = DFView(v)
     import pandas as pd
     if len(v.projection) and _out_of_core(v):
         return materialize_streamed(v)
     cols = v._query().materialize() if len(v.projection) else []
-    return pd.DataFrame({k: _to_user(c) for k, c in zip(v.projection.keys(), cols)})
+    lg = _logicals(v)
+    return pd.DataFrame({k: _to_user(c, lg[i]) for i, (k, c) in enumerate(zip(v.projection.keys(), cols))})
 
 
-def _to_user(c):
+def _logicals(v: DFView) -> List[str]:
+    """per projection column: the bits type a plain column stands for ("" for ordinary dtypes and computed columns)"""
+    metas = v.table.columns_meta()
+    return [metas[e.payload].logical if e.op == ir.COL else "" for e in v.projection.cols.values()]
+
+
+def _to_user(c, logical: str = ""):
     if isinstance(c, tuple):
         return np.array(_flat_to_strings(*c), dtype=object)
+    if logical:
+        if isinstance(c, np.ma.MaskedArray):
+            return np.ma.masked_array(ir.from_logical(np.asarray(c.data), logical), mask=np.ma.getmaskarray(c))
+        return ir.from_logical(c, logical)
     return c
 
 
@@ -947,7 +983,7 @@ class DFColumn:
             q.hint_materialize(True)
             q.execute()
             N.check(N.load().dfdb_query_unique(q._h, 0))
-            return _to_user(q.materialize()[0])
+            return _to_user(q.materialize()[0], _logicals(self.view)[0])
         if _out_of_core(self.view):
             seen, out = set(), []
             with Stream(self.view) as s:

@@ -195,6 +195,8 @@ def const(value, dtype: int | None = None) -> Expr:
         return value
     if isinstance(value, (bytes, str)):
         return Expr(CONST_STR, (), value.encode() if isinstance(value, str) else bytes(value))
+    if dtype is None and julia_instant(value) is not None:      # Date / DateTime / Time constants compare as their Int64 instants
+        value, dtype = julia_instant(value)[0], I64
     if dtype is None:
         if isinstance(value, (bool, np.bool_)):
             dtype = BOOL
@@ -208,6 +210,49 @@ def const(value, dtype: int | None = None) -> Expr:
             # arrays are rejected exactly like the reference (broadcast.jl:23-29)
             raise ValueError("Cannot do BlockBroadcasting with arrays")
     return Expr(CONST, (), (dtype, value))
+
+
+# ---- Julia bits types carried as integers (Date / DateTime / Time / Char): include/dfdb.h dfdb_colinfo.logical -------------
+RATA_DIE_DAYS = 719163               # Date(1970,1,1).instant: days since 0000-12-31
+RATA_DIE_MS = RATA_DIE_DAYS * 86_400_000
+
+
+def julia_instant(x):
+    """numpy / datetime value -> (Int64 representation, logical type) as Julia's Dates stores it, or None."""
+    import datetime as _dt
+    if isinstance(x, np.datetime64):
+        unit = np.datetime_data(x.dtype)[0]
+        if unit in ("D", "W", "M", "Y"):
+            return int(x.astype("datetime64[D]").astype(np.int64)) + RATA_DIE_DAYS, "Date"
+        return int(x.astype("datetime64[ms]").astype(np.int64)) + RATA_DIE_MS, "DateTime"
+    if isinstance(x, np.timedelta64):
+        return int(x.astype("timedelta64[ns]").astype(np.int64)), "Time"
+    if isinstance(x, _dt.datetime):
+        return julia_instant(np.datetime64(x, "ms"))
+    if isinstance(x, _dt.date):
+        return julia_instant(np.datetime64(x, "D"))
+    return None
+
+
+def julia_char(ch: str) -> int:
+    """reinterpret(UInt32, c::Char): the UTF-8 bytes left-aligned in a big-endian word."""
+    b = ch.encode("utf8")
+    if len(ch) != 1 or len(b) > 4:
+        raise ValueError("a Char is one Unicode scalar")
+    return int.from_bytes(b.ljust(4, b"\0"), "big")
+
+
+def from_logical(arr: np.ndarray, logical: str):
+    """the integer representation back to numpy datetime64 / timedelta64 / 1-character strings"""
+    if logical == "Date":
+        return (arr.astype(np.int64) - RATA_DIE_DAYS).astype("datetime64[D]")
+    if logical == "DateTime":
+        return (arr.astype(np.int64) - RATA_DIE_MS).astype("datetime64[ms]")
+    if logical == "Time":
+        return arr.astype(np.int64).astype("timedelta64[ns]")
+    if logical == "Char":
+        return np.array([int(x).to_bytes(4, "big").rstrip(b"\0").decode("utf8") for x in arr.tolist()], dtype=object)
+    return arr
 
 
 def wrap(x) -> Expr:

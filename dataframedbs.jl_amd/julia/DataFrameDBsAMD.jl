@@ -17,6 +17,7 @@
 # DFDB_ERR_UNSUPPORTED (or the tracer throw), and the call falls back to the stock Julia path.
 module DataFrameDBsAMD
 
+import Dates
 using DataFrameDBs
 using DataFrameDBs: DFTable, DFView, DFColumn, ColRef, BlockBroadcasting, SelectionQueue, Projection
 import DataFrames
@@ -54,6 +55,10 @@ const NULLABLE = 0x80
 dtype(::Type{Union{T,Missing}}) where {T} = DT[T] | NULLABLE
 dtype(::Type{T}) where {T} = DT[T]
 jltype(dt::Integer) = (dt & NULLABLE) != 0 ? Union{JT[UInt8(dt & 0x3f)],Missing} : JT[UInt8(dt & 0x3f)]
+# the element type the REFERENCE declares for a projection column (Date, DateTime, Time, Char come back as Int64 / UInt32)
+relabel(::Type{T}, v::Vector) where {T} = v
+relabel(::Type{T}, v::Vector{Int64}) where {T<:Union{Dates.Date,Dates.DateTime,Dates.Time}} = T === Dates.Time ? Dates.Time.(Dates.Nanosecond.(v)) : reinterpret(T, v)
+relabel(::Type{Char}, v::Vector{UInt32}) = reinterpret(Char, v)
 
 # ---------------------------------------------------------------- IR emission
 const OPS = Dict{Any,UInt8}(
@@ -70,6 +75,10 @@ function emit_const(io, v::T) where {T<:Union{Int8,Int16,Int32,Int64,UInt8,UInt1
     T == Float64 ? write(io, v) : T == Float32 ? (write(io, v); write(io, UInt32(0))) : write(io, Int64(v) % Int64)
 end
 emit_const(io, s::AbstractString) = (write(io, 0x03); write(io, UInt32(sizeof(s))); write(io, String(s)))
+# Date / DateTime / Time / Char columns are integer columns to the engine (dfdb_colinfo.logical): constants travel as the
+# integers Julia itself stores (Dates.value: days / milliseconds / nanoseconds; reinterpret(UInt32, ::Char))
+emit_const(io, d::Union{Dates.Date,Dates.DateTime,Dates.Time}) = emit_const(io, Int64(Dates.value(d)))
+emit_const(io, c::Char) = emit_const(io, reinterpret(UInt32, c))
 emit_const(io, r::Base.RefValue) = emit_const(io, r[])
 function emit_const(io, v::AbstractVector{T}) where {T<:Union{Integer,AbstractFloat}}     # Ref([1,11,21]) for in.()
     E = T <: AbstractFloat ? Float64 : Int64

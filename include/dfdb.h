@@ -75,6 +75,8 @@ typedef struct dfdb_colinfo {   /* ColumnMeta(id,name,type): src/tables/meta.jl:
   char    name[128];
   int32_t dtype;      /* DFDB_* | DFDB_NULLABLE */
   int32_t resident;   /* 1 once decoded blocks are in HBM */
+  char    logical[32]; /* "Date" / "DateTime" / "Time" (dtype Int64: days / ms / ns) or "Char" (dtype UInt32): a Julia bits type the
+                        * hot path carries as its integer representation (read_block_body! is a memcpy: blocks.jl:37-44); "" otherwise */
 } dfdb_colinfo;
 
 typedef struct dfdb_sizestats { /* SizeStats: src/io/sizestats.jl:2-10 (compressed adds 24 B/block, quirk Q10) */
@@ -157,6 +159,10 @@ int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query*
 int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);
 /* one column file (header + blocks) */
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
+
+/* declare a caller-supplied Int64 / UInt32 column to be one of the bits types above, so that dfdb_table_save writes that type
+ * string and the reference's open_table reads the column back as Date / DateTime / Time / Char */
+int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical);
 
 /* global row number (0-based) of this shard's first row, so that selection indices and leading
  * range stages refer to table rows when a table is block-range sharded over ranks */

@@ -78,6 +78,10 @@ int orc_table_find(orc_table* t, const char* name);      /* ordinal or -1 */
  * strings: data = int32 sizes (-1 missing), bytes = arena. missing: n bytes or NULL */
 int orc_table_add_column(orc_table* t, const char* name, int32_t dtype, int64_t nrows,
                          const void* data, const uint8_t* bytes, const uint8_t* missing);
+/* the same for a Julia bits type stored as an integer: logical = "Date" | "DateTime" | "Time" (Int64) | "Char" (UInt32) */
+int orc_table_add_column_as(orc_table* t, const char* name, int32_t dtype, const char* logical, int64_t nrows,
+                            const void* data, const uint8_t* bytes, const uint8_t* missing);
+int orc_table_col_logical(orc_table* t, int i, char* buf, size_t cap);
 /* raw image of column i's file (header + blocks) */
 const uint8_t* orc_table_image(orc_table* t, int i, size_t* nbytes);
 /* table_stats-style pass (skip_block over every block: misc.jl:6-42) */

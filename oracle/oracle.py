@@ -155,6 +155,12 @@ class Table:
         _check(lib().orc_table_colinfo(self._h, i, C.byref(cid), name, C.c_size_t(128), C.byref(dt)))
         return cid.value, name.value.decode(), dt.value
 
+    def logical(self, i: int) -> str:
+        """"Date" / "DateTime" / "Time" / "Char" when the column is one of those bits types carried as an integer, else ""."""
+        buf = C.create_string_buffer(32)
+        _check(lib().orc_table_col_logical(self._h, i, buf, C.c_size_t(32)))
+        return buf.value.decode()
+
     def names(self) -> List[str]:
         return [self.colinfo(i)[1] for i in range(self.ncols)]
 
@@ -164,7 +170,7 @@ class Table:
             raise KeyError(name)
         return i
 
-    def add_column(self, name: str, values, dtype: Optional[int] = None, missing: Optional[np.ndarray] = None):
+    def add_column(self, name: str, values, dtype: Optional[int] = None, missing: Optional[np.ndarray] = None, logical: Optional[str] = None):
         """Write a whole column block by block (write_column: columns.jl:30-53)."""
         if isinstance(values, tuple):                      # (sizes, bytes) flat strings
             sizes, data = values
@@ -184,7 +190,7 @@ class Table:
         if missing is not None:
             dtype |= NULLABLE
             m = np.ascontiguousarray(missing, np.uint8)
-        _check(lib().orc_table_add_column(self._h, name.encode(), dtype, C.c_int64(len(arr)), _ptr(arr), None, _ptr(m)))
+        _check(lib().orc_table_add_column_as(self._h, name.encode(), dtype, logical.encode() if logical else None, C.c_int64(len(arr)), _ptr(arr), None, _ptr(m)))
 
     def image(self, i: int) -> bytes:
         n = C.c_size_t()

@@ -50,6 +50,31 @@ int dt_parse(const char* s, size_t n, int32_t* out) {
   return orc_fail(ORC_ERR_UNSUPPORTED, "undefined column type '%.*s'", (int)n, s);
 }
 
+/* Julia bits types whose blocks are plain integers (read_block_body! is a memcpy for every isbits T: blocks.jl:37-44;
+ * type strings: columntypes/base.jl:108-126, Dates in columntypes/complex.jl).  The hot path treats them as their
+ * integer representation (Date: days, DateTime: milliseconds, Time: nanoseconds since the Rata Die epoch / midnight,
+ * Char: the UInt32 the UTF-8 bytes are left-aligned in); the type string travels beside the storage dtype. */
+static const struct { const char* name; int dtype; } k_alias[] = {{"Date", DFDB_I64}, {"DateTime", DFDB_I64}, {"Time", DFDB_I64}, {"Char", DFDB_U32}};
+int dt_parse_ex(const char* s, size_t n, int32_t* out, char* logical) {
+  int32_t flag = 0;
+  if (logical) logical[0] = 0;
+  const char* b = s; size_t bn = n;
+  if (n > 9 && memcmp(s, "Missing(", 8) == 0 && s[n - 1] == ')') { flag = DFDB_NULLABLE; b += 8; bn -= 9; }
+  for (size_t k = 0; k < sizeof k_alias / sizeof k_alias[0]; k++)
+    if (strlen(k_alias[k].name) == bn && memcmp(k_alias[k].name, b, bn) == 0) {
+      *out = k_alias[k].dtype | flag;
+      if (logical) snprintf(logical, 32, "%s", k_alias[k].name);
+      return 0;
+    }
+  return dt_parse(s, n, out);
+}
+const char* dt_type_string(int32_t dt, const char* logical) {
+  static __thread char buf[64];
+  if (!logical || !logical[0]) return dt_name(dt);
+  if (dt_nullable(dt)) { snprintf(buf, sizeof buf, "Missing(%s)", logical); return buf; }
+  return logical;
+}
+
 /* ---------------------------------------------------------------- little-endian IO helpers */
 static int put_i32(bytes_t* b, int32_t v) { return bytes_append(b, &v, 4); }
 static int put_i64(bytes_t* b, int64_t v) { return bytes_append(b, &v, 8); }
@@ -101,7 +126,7 @@ const uint8_t* orc_table_image(orc_table* t, int i, size_t* nbytes) {
 /* make_column_file header: Int64 block_size + type string (filesystem.jl:14-23) */
 static int write_col_header(col_t* c, int64_t block_size) {
   int rc = put_i64(&c->image, block_size); if (rc) return rc;
-  rc = put_string(&c->image, dt_name(c->dtype)); if (rc) return rc;
+  rc = put_string(&c->image, dt_type_string(c->dtype, c->logical)); if (rc) return rc;
   c->data_off = c->image.n; return 0;
 }
 
@@ -158,6 +183,20 @@ static int build_body(bytes_t* body, int32_t dtype, int64_t r0, int64_t rows, co
 
 int orc_table_add_column(orc_table* t, const char* name, int32_t dtype, int64_t nrows,
                          const void* data, const uint8_t* bytes, const uint8_t* missing) {
+  return orc_table_add_column_as(t, name, dtype, NULL, nrows, data, bytes, missing);
+}
+int orc_table_col_logical(orc_table* t, int i, char* buf, size_t cap) {
+  if (i < 0 || i >= t->ncols) return orc_fail(ORC_ERR_BOUNDS, "column %d out of range", i);
+  snprintf(buf, cap, "%s", t->cols[i].logical); return 0;
+}
+/* logical: NULL, or "Date" / "DateTime" / "Time" (dtype Int64) / "Char" (dtype UInt32): the type string written to the files */
+int orc_table_add_column_as(orc_table* t, const char* name, int32_t dtype, const char* logical, int64_t nrows,
+                            const void* data, const uint8_t* bytes, const uint8_t* missing) {
+  if (logical && logical[0]) {
+    int32_t want; char lg[32];
+    if (dt_parse_ex(logical, strlen(logical), &want, lg) || !lg[0] || dt_base(want) != dt_base(dtype))
+      return orc_fail(ORC_ERR_ARGUMENT, "logical type %s does not go with dtype %d", logical, dtype);
+  }
   if (orc_table_find(t, name) >= 0) return orc_fail(ORC_ERR_ARGUMENT, "Duplicated column %s", name);
   if (dt_base(dtype) < 1 || dt_base(dtype) > 12) return orc_fail(ORC_ERR_UNSUPPORTED, "unsupported dtype %d", dtype);
   col_t* nc = (col_t*)realloc(t->cols, sizeof(col_t) * (size_t)(t->ncols + 1));
@@ -168,6 +207,7 @@ int orc_table_add_column(orc_table* t, const char* name, int32_t dtype, int64_t 
   c->id = t->ncols + 1; /* DFTableMeta ctor numbers ids 1..n: meta.jl:26-29 */
   snprintf(c->name, sizeof c->name, "%s", name);
   c->dtype = dtype; c->nrows = nrows;
+  if (logical) snprintf(c->logical, sizeof c->logical, "%s", logical);
   int rc = write_col_header(c, t->block_size); if (rc) return rc;
   int64_t* soff = NULL;
   if (dt_base(dtype) == DFDB_STRING) {
@@ -192,7 +232,7 @@ int orc_table_save(orc_table* t, const char* path) {
   if (mkdir(path, 0777) != 0 && errno != EEXIST) return orc_fail(ORC_ERR_IO, "cannot create %s", path);
   bytes_t m = {0, 0, 0}; /* write_table_meta: table_io.jl:9-19 */
   put_i64(&m, t->format_version); put_i64(&m, t->block_size); put_i64(&m, t->ncols);
-  for (int i = 0; i < t->ncols; i++) { put_i64(&m, t->cols[i].id); put_string(&m, t->cols[i].name); put_string(&m, dt_name(t->cols[i].dtype)); }
+  for (int i = 0; i < t->ncols; i++) { put_i64(&m, t->cols[i].id); put_string(&m, t->cols[i].name); put_string(&m, dt_type_string(t->cols[i].dtype, t->cols[i].logical)); }
   char fn[1024];
   snprintf(fn, sizeof fn, "%s/meta.bin", path);
   FILE* f = fopen(fn, "wb"); if (!f) { free(m.p); return orc_fail(ORC_ERR_IO, "cannot write %s", fn); }
@@ -227,7 +267,7 @@ int orc_table_open(const char* path, orc_table** out) {
     col_t* c = &t->cols[i]; char ty[128]; size_t tl;
     if (get_i64(&r, &c->id) || get_string(&r, c->name, sizeof c->name, NULL) || get_string(&r, ty, sizeof ty, &tl))
       rc = orc_fail(ORC_ERR_FORMAT, "bad meta.bin in %s", path);
-    else rc = dt_parse(ty, tl, &c->dtype);
+    else rc = dt_parse_ex(ty, tl, &c->dtype, c->logical);
     if (!rc) t->ncols++;
   }
   free(m.p);
@@ -238,8 +278,9 @@ int orc_table_open(const char* path, orc_table** out) {
     rd_t h = {c->image.p, c->image.n, 0}; int64_t bs; char ty[128]; size_t tl; int32_t dt;
     if (get_i64(&h, &bs) || get_string(&h, ty, sizeof ty, &tl)) { rc = orc_fail(ORC_ERR_FORMAT, "bad header in %s", fn); break; }
     if (bs != t->block_size) { rc = orc_fail(ORC_ERR_FORMAT, "column %s has blocksize %lld, but table has blocksize %lld", c->name, (long long)bs, (long long)t->block_size); break; }
-    rc = dt_parse(ty, tl, &dt); if (rc) break;
-    if (dt != c->dtype) { rc = orc_fail(ORC_ERR_FORMAT, "column %s stored type is %s, but another expected", c->name, ty); break; }
+    char lg[32];
+    rc = dt_parse_ex(ty, tl, &dt, lg); if (rc) break;
+    if (dt != c->dtype || strcmp(lg, c->logical) != 0) { rc = orc_fail(ORC_ERR_FORMAT, "column %s stored type is %s, but another expected", c->name, ty); break; }
     c->data_off = h.pos;
   }
   if (rc) { orc_table_free(t); return rc; }

@@ -26,12 +26,15 @@ static inline int dt_isnum(int32_t dt) { return dt_isint(dt) || dt_isfloat(dt) |
 int dt_width(int32_t dt);               /* bytes per row on disk (String: 0) */
 const char* dt_name(int32_t dt);        /* ColumnTypes.typestring */
 int dt_parse(const char* s, size_t n, int32_t* out);
+int dt_parse_ex(const char* s, size_t n, int32_t* out, char* logical /*[32]*/);   /* + the bits types carried as integers */
+const char* dt_type_string(int32_t dt, const char* logical);
 
 /* ---- table ---- */
 typedef struct {
   int64_t id;
   char name[128];
   int32_t dtype;
+  char logical[32]; /* bits types stored as an integer: "Date", "DateTime", "Time" (Int64), "Char" (UInt32); "" otherwise */
   bytes_t image;   /* <id>.bin : header + blocks */
   size_t  data_off; /* first block */
   int64_t nrows;

@@ -186,3 +186,59 @@ def test_incompressible_and_degenerate_blocks(oracle, dfdb_mod, ctx, tmp_path):
         assert np.array_equal(got[0], cols["v"]) and np.array_equal(got[1], cols["z"])
         back = dfdb_mod.materialize(dfdb_mod.open_table(path))
         assert np.array_equal(np.asarray(back["v"]), cols["v"])
+
+
+def test_date_datetime_time_char_columns(oracle, dfdb_mod, ctx, tmp_path):
+    """Julia bits types the block format stores as plain integers (read_block_body! is a memcpy: blocks.jl:37-44): the type
+    strings "Date", "DateTime", "Time", "Char", "Missing(DateTime)" must open, filter, materialise and round-trip."""
+    from dfdb import ir
+    rng = np.random.default_rng(2)
+    n = 70_003
+    days = (np.datetime64("2019-10-01") + rng.integers(0, 61, n).astype("timedelta64[D]")).astype("datetime64[D]")
+    stamps = (np.datetime64("2019-10-01T00:00:00", "ms") + rng.integers(0, 61 * 86_400_000, n).astype("timedelta64[ms]"))
+    tod = rng.integers(0, 86_400 * 10**9, n).astype("timedelta64[ns]")
+    chars = rng.choice(list("abcé€z"), n)
+    mask = rng.random(n) < 0.15
+    # written by the oracle under the reference's type strings
+    ot = oracle.Table(block_size=4096)
+    ot.add_column("d", days.astype(np.int64) + ir.RATA_DIE_DAYS, logical="Date")
+    ot.add_column("ts", stamps.astype(np.int64) + ir.RATA_DIE_MS, logical="DateTime")
+    ot.add_column("tod", tod.astype(np.int64), logical="Time")
+    ot.add_column("c", np.array([ir.julia_char(x) for x in chars], np.uint32), logical="Char")
+    ot.add_column("tsm", stamps.astype(np.int64) + ir.RATA_DIE_MS, missing=mask, logical="DateTime")
+    ot.add_column("a", np.arange(n, dtype=np.int64))
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    raw = open(os.path.join(path, "meta.bin"), "rb").read()
+    for ty in (b"Date", b"DateTime", b"Time", b"Char", b"Missing(DateTime)"):
+        assert ty in raw
+    t = dfdb_mod.open_table(path)
+    assert [m.type for m in t.columns_meta()] == ["Date", "DateTime", "Time", "Char", "Missing(DateTime)", "Int64"]
+    df = dfdb_mod.materialize(t)
+    assert np.array_equal(df["d"].to_numpy().astype("datetime64[D]"), days) and np.array_equal(df["ts"].to_numpy().astype("datetime64[ms]"), stamps)
+    assert np.array_equal(df["tod"].to_numpy().astype("timedelta64[ns]"), tod) and df["c"].tolist() == chars.tolist()
+    # predicates: constants are lowered to the Int64 instants Julia stores
+    cut = np.datetime64("2019-11-01T00:00:00")
+    v = t[(t.ts >= cut) & (t.d < np.datetime64("2019-11-15")) & (t.c == ir.julia_char("é")), ["a", "ts"]]
+    want = np.nonzero((stamps >= cut) & (days < np.datetime64("2019-11-15")) & (chars == "é"))[0]
+    got = dfdb_mod.materialize(v)
+    assert got["a"].tolist() == want.tolist() and np.array_equal(got["ts"].to_numpy().astype("datetime64[ms]"), stamps[want])
+    assert dfdb_mod.nrow(t[ir.ismissing(ir.col(4)), dfdb_mod.ALL]) == int(mask.sum())
+    assert list(t.d.unique()) == list(dict.fromkeys(days.tolist()))
+    # write side: the engine keeps the type strings; the oracle reads the same values back
+    out = str(tmp_path / "out")
+    t.save(out)
+    ot2 = oracle.Table.open(out)
+    assert [ot2.logical(i) for i in range(6)] == ["Date", "DateTime", "Time", "Char", "DateTime", ""]
+    back = ot2.view().materialize()
+    assert np.array_equal(back[0], days.astype(np.int64) + ir.RATA_DIE_DAYS) and np.array_equal(back[3], np.array([ir.julia_char(x) for x in chars], np.uint32))
+    assert np.array_equal(np.ma.getmaskarray(back[4]), mask)
+    # caller-supplied numpy datetimes become Date / DateTime / Time columns
+    t2 = dfdb_mod.DFTable.from_columns({"d": days, "ts": stamps, "tod": tod})
+    assert [m.type for m in t2.columns_meta()] == ["Date", "DateTime", "Time"]
+    assert dfdb_mod.nrow(t2[t2.ts >= cut, dfdb_mod.ALL]) == int((stamps >= cut).sum())
+    # a type outside the set is still refused, by name
+    with pytest.raises(NotImplementedError, match="UndefinedType"):
+        meta = bytearray(raw); i = meta.index(b"Int64"); meta[i:i + 5] = b"Int99"
+        open(os.path.join(path, "meta.bin"), "wb").write(bytes(meta))
+        dfdb_mod.open_table(path)
