@@ -204,6 +204,7 @@ int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) 
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
   return guard([&] { NEED(t); NEED(file); table_save_column(t, ordinal, file, stats); });
 }
+int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(stats); table_column_stats(t, ordinal, stats); }); }
 int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical) {
   return guard([&] {
     NEED(t); NEED(logical);

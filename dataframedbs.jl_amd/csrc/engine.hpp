@@ -104,6 +104,7 @@ void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
 void stream_close(dfdb_stream* s);
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
+void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
 void ctx_destroy(dfdb_ctx* c);
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp

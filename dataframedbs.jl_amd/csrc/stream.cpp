@@ -304,6 +304,15 @@ void stream_close(dfdb_stream* s) {
   delete s;
 }
 
+// table_stats (src/tables/misc.jl:6-43): skip_block over one column file — block headers only, nothing is decoded
+void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
+  const Column& c = t->cols[(size_t)ordinal];
+  if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
+  st->rows = st->compressed = st->uncompressed = 0;
+  for (const BlockLoc& b : index_blocks(c)) { st->rows += b.rows; st->compressed += b.compressed + 24; st->uncompressed += b.origin; }   // +24: quirk Q10
+}
+
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st) { st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed; }
 
 }  // namespace dfdb

@@ -1093,6 +1093,22 @@ def view_from_columns(**cols: DFColumn) -> DFView:
     return DFView(first.view.table, Projection({k: c.expr for k, c in cols.items()}), first.view.selection)
 
 
+def table_stats(t: DFTable):
+    """table_stats(table) (misc.jl:6-43): rows, uncompressed and compressed size and ratio per column + the table total, from the
+    block headers of the column files (numbers, not the reference's pretty-printed strings)."""
+    import pandas as pd
+    rows = []
+    tot = [0, 0, 0]
+    for i, m in enumerate(t.columns_meta()):
+        st = N.SizeStats()
+        N.check(N.load().dfdb_table_column_stats(t._h, i, C.byref(st)))
+        rows.append((m.name, m.type, st.rows, st.uncompressed, st.compressed, st.uncompressed / st.compressed if st.compressed else float("nan")))
+        tot = [st.rows, tot[1] + st.uncompressed, tot[2] + st.compressed]
+    if rows:
+        rows.append(("Table total", "", tot[0], tot[1], tot[2], tot[1] / tot[2] if tot[2] else float("nan")))
+    return pd.DataFrame(rows, columns=["column", "type", "rows", "uncompressed size", "compressed size", "compression ratio"])
+
+
 def create_table(path: str, from_=None, block_size: int = 65536, ctx: Optional[Context] = None, **columns) -> "DFTable":
     """create_table(path; from=..., block_size=...) (creators.jl:18-60).  `from_`: a dict of host columns, a DFTable, or a
     DFView / DFColumn(s) to materialise (on the device) first.  Writes the table directory and returns the opened table."""

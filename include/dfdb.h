@@ -160,6 +160,10 @@ int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);
 /* one column file (header + blocks) */
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
 
+/* table_stats(table) (src/tables/misc.jl:6-43): SizeStats of one column file from its block headers alone (skip_block,
+ * BlockStreams.jl:74-78); nothing is read or decoded beyond the 20-byte headers */
+int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats);
+
 /* declare a caller-supplied Int64 / UInt32 column to be one of the bits types above, so that dfdb_table_save writes that type
  * string and the reference's open_table reads the column back as Date / DateTime / Time / Char */
 int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical);

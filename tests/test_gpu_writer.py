@@ -131,6 +131,9 @@ def test_file_layout_and_compression(oracle, dfdb_mod, ctx, tmp_path):
         if name == "a":
             assert ratio > 1.25                                                    # 20 random bits per 8 bytes
     assert (st["compressed"], st["uncompressed"]) == (tot_c, tot_u)                 # SizeStats with the 24-byte quirk (Q10)
+    ts = dfdb_mod.table_stats(dfdb_mod.open_table(str(tmp_path / "tb"), load=False))       # table_stats: headers only
+    assert ts["column"].tolist() == list(cols) + ["Table total"] and ts["rows"].tolist() == [n] * 6
+    assert ts["compressed size"].iloc[-1] == tot_c and ts["uncompressed size"].iloc[-1] == tot_u and ts["type"].iloc[3] == "Missing(Int32)"
 
 
 def test_add_column_from_lazy_column_and_create_table(oracle, dfdb_mod, ctx, tmp_path):
