@@ -185,23 +185,45 @@ __global__ __launch_bounds__(kBlock) void k_lz4_decode_lds(const uint8_t* __rest
 //   * the ring is flushed to HBM in coalesced dword stores every 2 KB; nothing in the chain waits for a store.
 // Longer runs take the same steps 64 bytes at a time; a match that reaches further back than the ring is copied from
 // HBM behind a fence (rare on columnar data; costs what every v1 sequence cost).
+#ifdef DFDB_LZ4_PROF   // tools/bench_lz4.hip only: cycles per phase of block 0 (s_memtime also drains the LDS queue: phase boundaries only)
+__device__ unsigned long long g_lz4_prof[16];
+#define LZ4_PROF(k) { const uint64_t pf_t = __builtin_readcyclecounter(); pf_acc[k] += pf_t - pf_t0; pf_t0 = pf_t; }
+#define LZ4_COUNT(k, n) { pf_acc[k] += (n); }
+#else
+#define LZ4_PROF(k)
+#define LZ4_COUNT(k, n)
+#endif
 constexpr int kV3Waves = 4;
 constexpr int kV4Waves = 1;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
 // BATCH (v4, see below the kernel): up to 21 short sequences found in a 64-byte window are executed together
-template <int WAVES, bool BATCH, int kRing, int kStage, int kBatchBytes>
+template <int WAVES, int BATCH, int kRing, int kStage, int kBatchBytes, int W = 1>
 __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage_sh[WAVES][kStage];
-  __shared__ __attribute__((aligned(16))) uint8_t ring_sh[WAVES][kRing];
-  __shared__ int16_t refs_sh[BATCH ? WAVES : 1][BATCH ? kBatchBytes : 1];
+  // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
+  constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
+  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[WAVES][kStage + kRing + (BATCH == 2 ? kFarMax * 24 : 0)];
+  __shared__ uint32_t fard_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kFarMax : 1];
+  __shared__ int16_t refs_sh[BATCH == 1 ? WAVES : 1][BATCH == 1 ? kBatchBytes : 1];
+  constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
+  __shared__ uint32_t bits_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kBatchBytes / 32 + 2 : 1];   // + two words that stay zero
+  __shared__ uint2 info_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kSeqMax : 1];
   const uint32_t lane = (uint32_t)lane_id();
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* stage = stage_sh[wib];
-  uint8_t* ring = ring_sh[wib];
-  int16_t* refs = refs_sh[BATCH ? wib : 0];
+  uint8_t* lds = lds_sh[wib];
+  uint8_t* stage = lds;
+  uint8_t* ring = lds + kStage;
+  int16_t* refs = refs_sh[BATCH == 1 ? wib : 0];
+  uint32_t* bits = bits_sh[BATCH == 2 ? wib : 0];
+  uint2* info = info_sh[BATCH == 2 ? wib : 0];
+  uint32_t* fard = fard_sh[BATCH == 2 ? wib : 0];
+  if (BATCH == 2 && lane < 2) bits[kBatchBytes / 32 + lane] = 0;
+  // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
+  constexpr uint32_t kFlush = BATCH == 2 ? (kRing >= 4096 ? 1024u : 512u) : 2048u;
+  static_assert(BATCH != 2 || (kFlush + 256 + kBatchBytes <= kRing && kBatchBytes >= 704 && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * (W + 1) + 24 <= kStage / 2),
+                "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
   constexpr int kChunk = kStage / 2;            // two chunks staged, a third in flight
@@ -216,6 +238,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
     uint32_t cb = 0;                   // staged: input bytes [cb, cb + 4096); invariant cb <= ip < cb + 2048
     uint32_t wbase = 0, wlo = 0, whi = 0;
     int err = 0;
+#ifdef DFDB_LZ4_PROF
+    uint64_t pf_acc[16] = {}; uint64_t pf_t0 = __builtin_readcyclecounter(); const uint64_t pf_start = pf_t0;
+#endif
     uint64_t f[kNF];                   // the chunk in flight: input bytes [cb + kStage, cb + kStage + kChunk)
 
     auto chunk_load = [&](uint32_t pos) {          // global -> registers (bytes past in_len are never consumed)
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
     window_load(0);
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
-      if (BATCH) {
+      if (BATCH == 1) {
         // ---- v4: 64 candidate sequence starts at once.  Lane l decodes the token at ip + l AS IF a sequence began there
         // (literal length, offset, match length: three LDS byte reads, no scalar parsing); the real starts are the chain
         // 0 -> next(0) -> next(next(0)) ... walked with one v_readlane per sequence.  The sequences found (<= 21, each
@@ -337,8 +362,158 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
             }
           }
           op += T; ip += cur;
-          if (op - flushed >= 2048u) flush_to(op & ~255u);
+          if (op - flushed >= kFlush) flush_to(op & ~255u);
           continue;
+        }
+      }
+      if (BATCH == 2) {
+        // ---- v5: a SUPERBATCH of W 64-byte windows.  The candidate decode of v4 (lane l = the token at window start + l,
+        // taken AS IF a sequence began there) runs for all W windows up front, so its two dependent LDS round trips are
+        // paid once; the chain of real starts is walked window after window with v_readlane only (four predicated hops per
+        // loop trip, no per-sequence branch); the sequences' output positions come from one DPP scan per window.  Every
+        // accepted sequence leaves one 8-byte record (output start, literal count, offset, literal input position) and
+        // one START BIT per output byte position.  The bytes are then produced 64 at a time IN OUTPUT ORDER: a lane finds
+        // its sequence as the rank of its position among the start bits, turns it into either an LDS address (a literal in
+        // the staging buffer, or a ring byte that precedes this 64-byte chunk) or a pointer to a lower lane of the same
+        // chunk, pointers are collapsed with ds_bpermute doubling, and each byte is fetched once.  No per-sequence loop.
+        LZ4_PROF(4);
+        advance(ip);
+        uint32_t A[W], NX[W], OFS[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          const uint32_t pos = ip + 64u * (uint32_t)w + lane;
+          const uint32_t token = stage[pos & (kStage - 1)];
+          const uint32_t lit = token >> 4, mlc = token & 15u;
+          const uint32_t opos = pos + 1 + lit;                             // the 2-byte offset field
+          const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+          const bool simple = lit != 15u && mlc != 15u && opos + 2 < in_len && offset != 0;
+          NX[w] = simple ? lane + 3u + lit : 127u;   // start of the following sequence, window-relative (<= 80); 127: a sequence the batch does not take
+          A[w] = lit | mlc << 4;
+          OFS[w] = offset;
+        }
+        bits[lane & (kBatchBytes / 32 - 1)] = 0;
+        LZ4_PROF(0);
+        uint32_t p = 0;                  // next sequence start, relative to the window being walked
+        uint32_t T = 0, nseq = 0;        // output bytes / sequences accepted so far
+        uint32_t nfar = 0;               // of them, matches that reach back further than the ring
+        uint32_t consumed = 0;           // input bytes they cover = where the next sequence starts, relative to ip
+        bool nonsimple = false;          // the walk ended on a sequence the batch does not take
+        bool bad = false;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          const uint32_t entry = p;
+          // the walk: p hops from start to start and parks on the last start of the window (whose successor is >= 64); four
+          // instructions per hop, no branch: v_readlane, s_bitset1, s_cmp, s_cselect.  A parked p only sets its own bit again.
+          uint64_t mask = 0;
+          for (int h = 0; h < 6; h++) {
+            const uint32_t p0 = p;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t a = rl(NX[w], p);
+              asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(p));
+              p = a < 64u ? a : p;
+            }
+            if (p == p0) break;
+          }
+          const uint32_t exitp = rl(NX[w], p);
+          nonsimple = exitp == 127u;
+          mask &= __ballot(NX[w] != 127u);                                  // (a sequence the batch does not take got a bit too)
+          const bool mine = (mask >> lane) & 1ull;
+          const uint32_t lit = A[w] & 15u, mlc = A[w] >> 4;
+          const uint32_t tot = mine ? lit + mlc + 4u : 0u;
+          const uint32_t incl = wave_incl_scan(tot);
+          const uint32_t Tw = rl(incl, 63);
+          const bool far = mine && OFS[w] + 64u > (uint32_t)kRing;
+          const uint64_t farmask = __ballot(far);
+          const uint32_t nfw = (uint32_t)__builtin_popcountll(farmask);
+          if (T + Tw > (uint32_t)kBatchBytes || nfar + nfw > (uint32_t)kFarMax) {   // the window does not fit any more: next superbatch
+            consumed = 64u * (uint32_t)w + entry; nonsimple = false; break;
+          }
+          const uint32_t ostart = T + incl - tot;
+          const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (mine) {
+            bad = bad || OFS[w] > op + ostart + lit;
+            const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
+            if (far) fard[fo] = op + ostart + lit - OFS[w];                 // where its source starts in the block's output
+            info[ord] = make_uint2(ostart | lit << 16 | (far ? 0x80000000u : 0u), (far ? fo * 24u : OFS[w]) | (64u * (uint32_t)w + lane + 1u) << 16);
+            atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
+          }
+          T += Tw; nseq += (uint32_t)__builtin_popcountll(mask); nfar += nfw;
+          if (nonsimple) { consumed = 64u * (uint32_t)w + p; break; }
+          p = exitp - 64u; consumed = 64u * (uint32_t)(w + 1) + p;
+        }
+        LZ4_PROF(1);
+        if (T) {
+          if (__ballot(bad) != 0 || T > out_len - op) { err = 5; break; }
+          wave_lds_fence();
+          LZ4_COUNT(6, 1); LZ4_COUNT(7, (T + 63) / 64); LZ4_COUNT(9, nseq); LZ4_COUNT(10, nfar);
+          if (nfar) {
+            // far sources were flushed before this superbatch began (they lie > kRing - 64 - kBatchBytes behind op and at most
+            // kFlush + 256 bytes are ever unflushed): 24 bytes each, HBM/L2 -> LDS, ONE memory round trip for the whole superbatch
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane < nfar) {
+              const uint32_t so = fard[lane];
+              uint64_t* d = (uint64_t*)(lds + kStage + kRing + lane * 24u);
+              if (so + 24u <= out_len) {
+                const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
+                d[0] = a; d[1] = b2; d[2] = c2;
+              } else {
+                uint8_t* db = (uint8_t*)d;
+                for (uint32_t k = 0; k < 24u && so + k < out_len; k++) db[k] = out[so + k];
+              }
+            }
+            wave_lds_fence();
+            LZ4_PROF(5);
+          }
+          uint32_t cnt = 0;                                                // sequences that start before the chunk
+          constexpr int U = 2;                                             // chunks per trip: their LDS round trips overlap, only the final byte fetches are ordered
+          for (uint32_t c = 0; c < T; c += 64u * U) {
+            uint32_t R[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const uint32_t cc = c + 64u * (uint32_t)u, j = cc + lane;
+              const uint32_t bw = bits[(cc >> 5) + (lane & 1u)];           // (a chunk past T reads the two spare zero words)
+              const uint32_t w0 = rl(bw, 0), w1 = rl(bw, 1);
+              const uint32_t own = ((lane < 32u ? w0 >> lane : w1 >> (lane - 32u)) & 1u);
+              const uint32_t ordinal = cnt + __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0u)) + own - 1u;
+              cnt += (uint32_t)__builtin_popcount(w0) + (uint32_t)__builtin_popcount(w1);
+              const uint2 inf = info[ordinal];
+              const uint32_t ostart = inf.x & 0xffffu, lit = (inf.x >> 16) & 15u, offset = inf.y & 0xffffu, inpos = inf.y >> 16;
+              const bool far = (inf.x >> 31) != 0u;                        // then `offset` is where the prefetched source bytes are
+              const uint32_t bi = j - ostart;
+              const int32_t sp = (int32_t)j - (int32_t)offset;             // a match byte copies output byte op + sp
+              const bool is_lit = bi < lit;
+              const bool root = is_lit || far || sp < (int32_t)cc || j >= T;
+              const uint32_t k = bi - lit;
+              uint32_t addr = (uint32_t)kStage + ((op + (uint32_t)sp) & (uint32_t)(kRing - 1));
+              addr = far ? (uint32_t)(kStage + kRing) + offset + (k < 24u ? k : 0u) : addr;
+              addr = is_lit ? ((ip + inpos + bi) & (uint32_t)(kStage - 1)) : addr;
+              R[u] = root ? (0x80000000u | addr) : (uint32_t)(sp - (int32_t)cc);   // else: the lane of this chunk that makes the source byte
+            }
+            for (;;) {                                                     // pointer doubling: R[j] = R[R[j]] (always a lower lane)
+              bool any = false;
+#pragma unroll
+              for (int u = 0; u < U; u++) any = any || (R[u] >> 31) == 0u;
+              if (__ballot(any) == 0) break;
+#pragma unroll
+              for (int u = 0; u < U; u++) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((R[u] & 63u) << 2), (int)R[u]);
+                if ((R[u] >> 31) == 0u) R[u] = t;
+              }
+              LZ4_COUNT(8, 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const uint32_t j = c + 64u * (uint32_t)u + lane;
+              const uint8_t v = lds[R[u] & 0xffffu];
+              if (j < T) ring[(op + j) & (kRing - 1)] = v;
+            }
+          }
+          op += T; ip += consumed;
+          LZ4_PROF(2);
+          if (op - flushed >= kFlush) flush_to(op & ~255u);
+          LZ4_PROF(3);
+          if (!nonsimple) continue;
         }
       }
       ensure(ip);
@@ -392,7 +567,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
           const uint32_t n = rem < 64u ? rem : 64u;
           if (lane < n) ring[(op + lane) & (kRing - 1)] = stage[(lp + lane) & (kStage - 1)];
           lp += n; op += n; rem -= n;
-          if (op - flushed >= 2048u) flush_to(op & ~255u);
+          if (op - flushed >= kFlush) flush_to(op & ~255u);
         }
         if (!last) {
           if (defer) {                                                   // match fields parsed now: the literals are out of the staging buffer
@@ -416,7 +591,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
               const uint32_t s = op - offset + j;
               if (lane < n) { const uint8_t v = ring[s & (kRing - 1)]; ring[(op + lane) & (kRing - 1)] = v; }
               op += n; done += n;
-              if (op - flushed >= 2048u) flush_to(op & ~255u);
+              if (op - flushed >= kFlush) flush_to(op & ~255u);
             }
           } else {                                                       // far match: through HBM, v1 style
             flush_to(op);
@@ -433,11 +608,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
           }
         }
       }
-      if (op - flushed >= 2048u) flush_to(op & ~255u);
+      if (op - flushed >= kFlush) flush_to(op & ~255u);
       if (last) break;
     }
     if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
     if (!err) flush_to(op);
+#ifdef DFDB_LZ4_PROF
+    if (b == 0 && lane == 0) { pf_acc[15] = __builtin_readcyclecounter() - pf_start; for (int k = 0; k < 16; k++) g_lz4_prof[k] = pf_acc[k]; }
+#endif
     if (lane == 0) status[b] = err;
     wave_lds_fence();
   }
@@ -448,7 +626,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
 // 44 / 45.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3.  Neither waits on memory
 // (SQ_WAIT_INST_ANY 7 % of wave cycles); a single wave retires this dependent, branchy code at ~1 instruction per 12
 // cycles, so the lever is instructions per sequence x resident waves, which is what v4 moves.  v4 is the default.
-static int g_lz4_variant = 3;
+static int g_lz4_variant = 4;
 void set_lz4_variant(int v) { g_lz4_variant = v; }
 
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
@@ -458,10 +636,13 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   if (grid > 65535) grid = 65535;
   if (g_lz4_variant == 0) hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
   else if (g_lz4_variant == 1) hipLaunchKernelGGL(k_lz4_decode_lds, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
-  else if (g_lz4_variant == 2) hipLaunchKernelGGL((k_lz4_decode_v3<kV3Waves, false, 8192, 4096, 1>), dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
-  else {
+  else if (g_lz4_variant == 2) hipLaunchKernelGGL((k_lz4_decode_v3<kV3Waves, 0, 8192, 4096, 1>), dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+  else if (g_lz4_variant == 3) {
     int64_t g4 = ((int64_t)nblocks + kV4Waves - 1) / kV4Waves; if (g4 > (1 << 20)) g4 = 1 << 20;
-    hipLaunchKernelGGL((k_lz4_decode_v3<kV4Waves, true, 4096, 2048, 512>), dim3((unsigned)g4), dim3(kV4Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+    hipLaunchKernelGGL((k_lz4_decode_v3<kV4Waves, 1, 4096, 2048, 512>), dim3((unsigned)g4), dim3(kV4Waves * 64), 0, s, src, dst, blocks, nblocks, status);
+  } else {
+    int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
+    hipLaunchKernelGGL((k_lz4_decode_v3<1, 2, 2048, 2048, 1024, 8>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status);
   }
 }
 

@@ -193,7 +193,7 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
             "zeros": np.zeros(n, np.int64), "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n],
             "far": np.concatenate([rng.integers(-2**62, 2**62, 3000), np.zeros(10, np.int64)] * (n // 3010 + 1))[:n].astype(np.int64)}
     cols["far"][6000:9000] = cols["far"][0:3000]          # a 24-KB repeat at distance 48 KB
-    for bs, variant in ((65536, 1), (1000, 1), (65536, 0), (65536, 2), (1000, 2), (65536, 3), (1000, 3)):
+    for bs, variant in ((65536, 1), (1000, 1), (65536, 0), (65536, 2), (1000, 2), (65536, 3), (1000, 3), (65536, 4), (1000, 4)):
         ctx.set_option("lz4_variant", variant)
         p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"tb{bs}_{variant}"))
         ov, dv = apply_stages(p, [])
@@ -202,10 +202,10 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
         assert_same(p, ov, dv)
         ov, dv = apply_stages(p, [("pred", ir.ismissing(ir.col(6)) | ir.ismissing(ir.col(3)))])
         assert_same(p, ov, dv)
-    ctx.set_option("lz4_variant", 3)
+    ctx.set_option("lz4_variant", 4)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
     """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
     matches with offset < 64, = 64, > 64), literal runs of 0..400 bytes between matches (length-byte chains), matches at
@@ -226,7 +226,18 @@ def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
         if not pos:
             pieces.insert(0, base); pos = 1
     mixed = np.concatenate(pieces)[:n]
-    cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "noise": rng.integers(0, 256, n).astype(np.uint8),
+    # short sequences back to back (<= 14 literals, 4..18 match bytes) with match distances from 1 byte to 60 KB: the batch
+    # decoders' candidate windows, in-chunk pointer chains, far-source prefetch slots and output-budget cuts
+    short = bytearray(rng.integers(0, 256, 4096).astype(np.uint8).tobytes())
+    while len(short) < n:
+        short += rng.integers(0, 256, int(rng.integers(0, 15))).astype(np.uint8).tobytes()
+        ml = int(rng.integers(4, 19))
+        hi = (8, 64, 2000, 60_000)[int(rng.integers(0, 4))]
+        d = int(rng.integers(1, min(hi, len(short)) + 1))
+        for k in range(ml):
+            short.append(short[len(short) - d])
+    shortseq = np.frombuffer(bytes(short[:n]), np.uint8)
+    cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "noise": rng.integers(0, 256, n).astype(np.uint8), "shortseq": shortseq,
             "runs": np.repeat(rng.integers(0, 4, n // 50 + 1).astype(np.uint8), rng.integers(1, 100, n // 50 + 1))[:n]}
     cols["runs"] = np.resize(cols["runs"], n)
     ctx.set_option("lz4_variant", variant)
@@ -236,7 +247,7 @@ def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
             ov, dv = apply_stages(p, [])
             assert_same(p, ov, dv)
     finally:
-        ctx.set_option("lz4_variant", 3)
+        ctx.set_option("lz4_variant", 4)
 
 
 def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):

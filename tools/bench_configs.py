@@ -189,7 +189,7 @@ def main():
     import tempfile
     d = tempfile.mkdtemp()
     ot.save(os.path.join(d, "tb"))
-    for variant in (0, 3, 0, 3):
+    for variant in (0, 3, 4, 3, 4):
         ctx.set_option("lz4_variant", variant)
         ctx.profile(True)
         t0 = time.perf_counter()

@@ -1,0 +1,75 @@
+// bench_lz4.hip — standalone harness for the K7 LZ4 block decoders: N blocks of the benchmark's Int64 column compressed by the
+// system liblz4 (dlopen), decoded by each variant, verified byte for byte, timed with HIP events; the v5 kernel is compiled with
+// cycle probes (DFDB_LZ4_PROF) and prints where block 0 spent its cycles.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDFDB_LZ4_PROF -Idataframedbs.jl_amd/csrc tools/bench_lz4.hip -o tools/bench_lz4 -ldl
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include "../dataframedbs.jl_amd/csrc/k_decode.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+using namespace dfdb;
+
+int main(int argc, char** argv) {
+  const int nblocks = argc > 1 ? atoi(argv[1]) : 4096;
+  const int mode = argc > 2 ? atoi(argv[2]) : 0;          // 0: h mod 1e6 (benchmark column), 1: 1..n, 2: h mod 1000
+  void* h = dlopen("liblz4.so.1", RTLD_NOW);
+  if (!h) { printf("no liblz4.so.1\n"); return 1; }
+  auto compress = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
+  const int rows = 65536, body = rows * 8;
+  const int distinct = nblocks < 64 ? nblocks : 64;      // compress 64 different blocks, repeat them
+  std::vector<std::vector<uint8_t>> comp((size_t)distinct);
+  std::vector<int64_t> plain((size_t)distinct * rows);
+  for (int b = 0; b < distinct; b++) {
+    int64_t* v = plain.data() + (size_t)b * rows;
+    for (int i = 0; i < rows; i++) {
+      const uint64_t r = splitmix64(0x9E3779B97F4A7C15ull + (uint64_t)b * rows + (uint64_t)i);
+      v[i] = mode == 0 ? (int64_t)(r % 1000000ull) : mode == 1 ? (int64_t)b * rows + i + 1 : (int64_t)(r % 1000ull);
+    }
+    comp[(size_t)b].resize((size_t)body + body / 255 + 64);
+    const int n = compress((const char*)v, (char*)comp[(size_t)b].data(), body, (int)comp[(size_t)b].size());
+    comp[(size_t)b].resize((size_t)n);
+  }
+  std::vector<Lz4Block> blk((size_t)nblocks);
+  std::vector<uint8_t> img;
+  for (int b = 0; b < nblocks; b++) {
+    const auto& c = comp[(size_t)(b % distinct)];
+    while (img.size() % 8) img.push_back(0);
+    blk[(size_t)b] = Lz4Block{(int64_t)img.size(), (int32_t)c.size(), body, (int64_t)b * body};
+    img.insert(img.end(), c.begin(), c.end());
+  }
+  img.resize(img.size() + 64);
+  printf("blocks %d, compressed %.1f MB, ratio %.3f\n", nblocks, img.size() / 1e6, (double)nblocks * body / img.size());
+  uint8_t *dsrc, *ddst; Lz4Block* dblk; int32_t* dstat;
+  CK(hipMalloc(&dsrc, img.size())); CK(hipMalloc(&ddst, (size_t)nblocks * body)); CK(hipMalloc(&dblk, blk.size() * sizeof(Lz4Block))); CK(hipMalloc(&dstat, nblocks * 4));
+  CK(hipMemcpy(dsrc, img.data(), img.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dblk, blk.data(), blk.size() * sizeof(Lz4Block), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<uint8_t> back((size_t)distinct * body);
+  std::vector<int32_t> stat((size_t)nblocks);
+  for (int variant : {3, 4, 3, 4}) {
+    set_lz4_variant(variant);
+    CK(hipMemset(ddst, 0xAB, (size_t)nblocks * body));
+    CK(hipEventRecord(e0, nullptr));
+    launch_lz4_decode(nullptr, dsrc, ddst, dblk, nblocks, dstat);
+    CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(stat.data(), dstat, nblocks * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(back.data(), ddst + (size_t)(nblocks - distinct) * body, back.size(), hipMemcpyDeviceToHost));
+    int bad = 0; for (int b = 0; b < nblocks; b++) bad += stat[(size_t)b] != 0;
+    int wrong = 0;
+    for (int k = 0; k < distinct; k++) {
+      const int b = nblocks - distinct + k;
+      wrong += memcmp(back.data() + (size_t)k * body, plain.data() + (size_t)(b % distinct) * rows, body) != 0;
+    }
+    printf("variant %d: %.3f ms  %.1f GB/s out  status!=0: %d  wrong blocks: %d\n", variant, ms, (double)nblocks * body / ms / 1e6, bad, wrong);
+    if (variant >= 4) {
+      unsigned long long pf[16];
+      CK(hipMemcpyFromSymbol(pf, HIP_SYMBOL(g_lz4_prof), sizeof(pf)));
+      printf("  block 0 cycles: total %llu | candidates %llu  walk+records %llu  far %llu  resolve %llu  flush %llu  other %llu | superbatches %llu chunks %llu rounds %llu seqs %llu far %llu\n",
+             pf[15], pf[0], pf[1], pf[5], pf[2], pf[3], pf[4], pf[6], pf[7], pf[8], pf[9], pf[10]);
+    }
+  }
+  return 0;
+}
