@@ -99,6 +99,7 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     for (hipEvent_t e : ctx->pipe_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pinned_scalar) (void)hipHostFree(ctx->pinned_scalar);
+    for (int i = 0; i < 2; i++) { if (ctx->pin_ring[i]) (void)hipHostFree(ctx->pin_ring[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
   });

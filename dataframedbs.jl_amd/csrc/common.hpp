@@ -96,6 +96,10 @@ struct dfdb_ctx {
   // second stream + events for work that overlaps the main stream inside ONE call (pipelined select_indices)
   hipStream_t side = nullptr;
   hipEvent_t pipe_ev[9] = {};
+  // two pinned bounce buffers for dfdb_table_load: the file is read piece by piece into one while the other is in flight to HBM
+  uint8_t* pin_ring[2] = {nullptr, nullptr};
+  size_t pin_ring_cap = 0;
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
 
 namespace dfdb {

@@ -5,9 +5,10 @@
 // Each call of stream_next() hands out a query over the next chunk (block range [b0, b1) of every required column,
 // decoded in HBM); the caller uses the ordinary dfdb_count / dfdb_select_indices / dfdb_materialize on it, exactly
 // as the reference's consumers use the NamedTuple an iteration yields (valid until the next iterate).  While the
-// caller works on chunk i, a loader thread reads the compressed bytes of chunk i+1 from the column files, copies
-// them to the device and LZ4-decodes them on ITS OWN HIP stream (two contexts, two streams, alternating slots),
-// so file I/O, PCIe, K7 and the scan/gather kernels overlap.  HBM holds two chunks, never the table.
+// caller works on chunk i, two loader threads read the compressed bytes of chunks i+1 and i+2 from the column files,
+// copy them to the device and LZ4-decode them, each slot on ITS OWN HIP stream (three contexts, three streams, slots
+// used round-robin), so file I/O of one chunk overlaps PCIe + K7 of the other and the caller's scan/gather kernels.
+// HBM holds three chunks, never the table.
 //
 // The reference's per-stage running state carries over between chunks the same way it carries over between blocks:
 //   * a leading range stage numbers table rows            -> dfdb_table row_base = b0 * block_size
@@ -21,6 +22,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <unistd.h>
@@ -76,17 +78,18 @@ struct dfdb_stream {
   std::vector<int> required;       // table ordinals the query touches
   std::vector<std::vector<BlockLoc>> index;   // per required column
   std::vector<int64_t> base;       // per stage: survivors of stages [0,k) in the chunks already consumed
-  Slot slot[2];
+  static constexpr int kSlots = 4, kLoaders = 3;
+  Slot slot[kSlots];
   int cur = -1;                    // slot handed to the caller (-1: none yet)
   bool done = false;
   int64_t compressed = 0, uncompressed = 0, rows = 0;
-  // ONE loader thread for the life of the stream (a fresh host thread pays the HIP runtime's per-thread set-up, ~45 ms,
-  // on its first call): requests are slot numbers, completion is signalled per slot
-  std::thread loader;
+  // the loader threads live as long as the stream (a fresh host thread pays the HIP runtime's per-thread set-up, ~45 ms,
+  // on its first call): requests are slot numbers served first in first out, completion is signalled per slot
+  std::thread loader[kLoaders];
   std::mutex mu; std::condition_variable cv;
-  int request = -1;                // slot to load, -1 = none
+  std::deque<int> requests;        // slots waiting for a loader
   bool quit = false;
-  bool slot_done[2] = {false, false};
+  bool slot_done[kSlots] = {};
 };
 
 namespace dfdb {
@@ -121,7 +124,9 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
       table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st);
       if (getenv("DFDB_STREAM_DEBUG")) {
         const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[stream] blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n", (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
+        static const auto epoch = std::chrono::steady_clock::now();
+        fprintf(stderr, "[stream] t=%.2f ms slot %d blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n",
+                std::chrono::duration<double, std::milli>(t0 - epoch).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
                 std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)(hi - lo) / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
       }
     }
@@ -149,9 +154,9 @@ void loader_main(dfdb_stream* s) {
     int idx;
     {
       std::unique_lock<std::mutex> lk(s->mu);
-      s->cv.wait(lk, [&] { return s->quit || s->request >= 0; });
+      s->cv.wait(lk, [&] { return s->quit || !s->requests.empty(); });
       if (s->quit) return;
-      idx = s->request; s->request = -1;
+      idx = s->requests.front(); s->requests.pop_front();
     }
     load_chunk(s, &s->slot[idx]);
     { std::lock_guard<std::mutex> lk(s->mu); s->slot_done[idx] = true; }
@@ -181,7 +186,7 @@ bool prefetch(dfdb_stream* s, Slot* sl) {
   {
     std::lock_guard<std::mutex> lk(s->mu);
     const int idx = (int)(sl - s->slot);
-    s->slot_done[idx] = false; s->request = idx;
+    s->slot_done[idx] = false; s->requests.push_back(idx);
   }
   s->cv.notify_all();
   return true;
@@ -199,9 +204,9 @@ void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) {
 static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s) {
   dfdb_table* t = q->t;
   s->src = q; s->t = t;
-  // one block is decoded by one wave in ~30-50 ms however many run beside it (K7 is serial inside a block), so a chunk
-  // should hold thousands of blocks: 4096 blocks = 2 GB of Int64 per slot
-  s->chunk_blocks = chunk_blocks > 0 ? chunk_blocks : 4096;
+  // one block is decoded by one wave in ~5-8 ms (K7 is serial inside a block) and the chip holds ~5000 waves, so a chunk
+  // should hold several hundred blocks: 512 blocks = 0.25 GB of Int64 per slot, four slots
+  s->chunk_blocks = chunk_blocks > 0 ? chunk_blocks : 512;
   // required_columns(view) (view.jl:183-190): selection columns first, then projection-only columns
   std::vector<int> req;
   for (const Stage& st : q->stages) if (st.kind == ST_PRED) required_columns(*st.pred, req);
@@ -225,7 +230,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   }
   for (int64_t b = 0; b < s->nblocks; b++) s->rows += s->index[0][(size_t)b].rows;
   s->base.assign(q->stages.size(), 0);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
     if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context");
     auto tb = std::make_unique<dfdb_table>();            // the slot's chunk table: same columns, its own stream, reused buffers
@@ -243,8 +248,9 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     tb->queries.push_back(cq.get());
     sl.tbl = tb.release(); sl.q = cq.release();
   }
-  s->loader = std::thread(loader_main, s);
+  for (auto& th : s->loader) th = std::thread(loader_main, s);
   if (!prefetch(s, &s->slot[0])) s->done = true;
+  else for (int i = 1; i + 1 < dfdb_stream::kSlots; i++) if (!prefetch(s, &s->slot[i])) break;
 }
 
 // the next chunk as a query (nullptr at the end).  The previous chunk's query dies here.
@@ -264,11 +270,12 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
       }
     }
   }
-  const int nxt = s->cur < 0 ? 0 : 1 - s->cur;
+  constexpr int K = dfdb_stream::kSlots;
+  const int nxt = s->cur < 0 ? 0 : (s->cur + 1) % K;
   Slot& sl = s->slot[nxt];
   if (s->cur >= 0) release_slot(s, s->slot[s->cur]);
   if (s->done || !sl.loading) {          // nothing was prefetched: end of stream
-    if (sl.loading) release_slot(s, sl);
+    for (Slot& o : s->slot) if (o.loading) release_slot(s, o);
     s->done = true; s->cur = -1;
     return nullptr;
   }
@@ -276,7 +283,7 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
   wait_loaded(s, sl);
   if (sl.err_code) { const int c = sl.err_code; const std::string m = sl.err_msg; s->done = true; fail(c, "%s", m.c_str()); }
   s->cur = nxt;
-  if (!prefetch(s, &s->slot[1 - nxt])) { /* last chunk */ }
+  if (!prefetch(s, &s->slot[(nxt + K - 1) % K])) { /* no chunk left to start */ }
   // 3. the slot's query, re-based for this chunk
   for (size_t k = 0; k < sl.q->stages.size(); k++) sl.q->stages[k].stage_base = s->base[k];
   sl.q->executed_stages = -1; sl.q->count = -1; sl.q->prefix_valid = false; sl.q->bitmap_rows = -1;
@@ -287,13 +294,11 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
 
 void stream_close(dfdb_stream* s) {
   if (!s) return;
-  for (int i = 0; i < 2; i++) if (s->slot[i].ctx) wait_loaded(s, s->slot[i]);
-  if (s->loader.joinable()) {
-    { std::lock_guard<std::mutex> lk(s->mu); s->quit = true; }
-    s->cv.notify_all();
-    s->loader.join();
-  }
-  for (int i = 0; i < 2; i++) {
+  for (Slot& sl : s->slot) if (sl.ctx) wait_loaded(s, sl);
+  { std::lock_guard<std::mutex> lk(s->mu); s->quit = true; }
+  s->cv.notify_all();
+  for (auto& th : s->loader) if (th.joinable()) th.join();
+  for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
     if (sl.ctx) { release_slot(s, sl); }
     delete sl.q; sl.q = nullptr;

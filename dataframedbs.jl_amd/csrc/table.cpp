@@ -37,11 +37,17 @@ static std::vector<uint8_t> slurp(const std::string& fn, bool& ok, size_t max_by
 }
 
 // file bytes [lo, hi) -> dst with a few concurrent preads (page cache -> pinned memory is a memcpy: one core moves ~5 GB/s)
+bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi);
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi) {
   const int fd = open(file.c_str(), O_RDONLY);
   if (fd < 0) return false;
+  const bool ok = read_file_range_fd(fd, dst, lo, hi);
+  close(fd);
+  return ok;
+}
+bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi) {
   const int64_t n = hi - lo;
-  const int parts = n > (8 << 20) ? 4 : 1;
+  const int parts = (int)std::min<int64_t>(8, std::max<int64_t>(1, n / (4 << 20)));
   std::vector<std::thread> th;
   std::vector<char> ok((size_t)parts, 1);
   for (int k = 0; k < parts; k++) {
@@ -53,7 +59,6 @@ bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t 
     if (k + 1 < parts) th.emplace_back(work); else work();
   }
   for (auto& t : th) t.join();
-  close(fd);
   for (char c : ok) if (!c) return false;
   return true;
 }
@@ -212,36 +217,23 @@ void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t*
 void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* byte_off,
                            int32_t nblocks, int32_t* sizes, uint8_t* bytes);
 
-static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t nbytes, size_t data_off, int64_t block_first,
-                            int64_t block_last, dfdb_sizestats* stats) {
+// the blocks hs[0..nb) of column c — block ordinals block_first.. — whose compressed bodies already sit in t->ld_staged (the body of
+// hs[i] at staged + hs[i].body_off - comp_lo): K7 + K8 / string unpack into the column
+static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t nb, int64_t block_first, int64_t comp_lo, dfdb_sizestats* stats) {
   dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  std::vector<BlockHdr> all = walk_blocks(img, nbytes, data_off);
-  const int64_t nb_total = (int64_t)all.size();
-  if (block_last < 0 || block_last > nb_total) block_last = nb_total;
-  if (block_first < 0) block_first = 0;
-  if (block_first > block_last) block_first = block_last;
-  const int64_t nb = block_last - block_first;
-  for (int64_t b = 0; b + 1 < nb_total; b++)
-    if (all[b].rows != t->block_size) fail(DFDB_ERR_FORMAT, "block %lld of column %s holds %d rows, expected block_size %lld", (long long)b, c.name.c_str(), all[b].rows, (long long)t->block_size);
-  int64_t nrows = 0, comp_lo = 0, comp_hi = 0, origin_total = 0;
-  for (int64_t b = block_first; b < block_last; b++) { nrows += all[b].rows; origin_total += all[b].origin; }
-  if (nb) { comp_lo = (int64_t)all[block_first].body_off; comp_hi = (int64_t)(all[block_last - 1].body_off + all[block_last - 1].compressed); }
+  int64_t nrows = 0;
+  for (int64_t i = 0; i < nb; i++) nrows += hs[i].rows;
   if (t->nrows >= 0 && t->nrows != nrows)
     fail(DFDB_ERR_ARGUMENT, "column %s would load %lld rows but the table holds %lld resident rows", c.name.c_str(), (long long)nrows, (long long)t->nrows);
   if (t->nrows >= 0 && t->block_first != block_first) fail(DFDB_ERR_ARGUMENT, "all columns of a table must load the same block range");
   const int w = dt_width(c.dtype);
   const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
-
-  // stage the compressed byte range in HBM
   DevBuf &staged = t->ld_staged, &bodies = t->ld_bodies, &dblocks = t->ld_blocks, &dstatus = t->ld_status, &d_aux = t->ld_aux;
-  staged.ensure((size_t)(comp_hi - comp_lo) + 64);
-  if (comp_hi > comp_lo) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
-
   std::vector<Lz4Block> blocks((size_t)nb);
   std::vector<int64_t> body_off((size_t)nb + 1), row_off((size_t)nb + 1), byte_off((size_t)nb + 1);
   int64_t bo = 0, ro = 0, so = 0;
   for (int64_t i = 0; i < nb; i++) {
-    const BlockHdr& h = all[block_first + i];
+    const BlockHdr& h = hs[i];
     if (h.origin > 0x7fffffffLL || h.compressed > 0x7fffffffLL) fail(DFDB_ERR_FORMAT, "block larger than the LZ4 block limit");
     int64_t expect_min = is_str ? 4 + 4ll * h.rows : (is_null ? 8 * ceil_div(h.rows, 64) + (int64_t)w * h.rows : (int64_t)w * h.rows);
     if (is_str ? h.origin < expect_min : h.origin != expect_min)
@@ -259,7 +251,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
     c.data.ensure((size_t)nrows * w + 256);
     decode_dst = c.data.as<uint8_t>();
     int64_t off = 0;
-    for (int64_t i = 0; i < nb; i++) { blocks[i].dst_off = off; off += (int64_t)w * all[block_first + i].rows; }
+    for (int64_t i = 0; i < nb; i++) { blocks[i].dst_off = off; off += (int64_t)w * hs[i].rows; }
   } else {
     bodies.ensure((size_t)bo + 64);
     decode_dst = bodies.as<uint8_t>();
@@ -306,9 +298,108 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
   if (!t->keep_load_scratch) { HIP_CHECK(hipStreamSynchronize(s)); staged.release(); bodies.release(); dblocks.release(); dstatus.release(); d_aux.release(); }
   if (stats) {   // SizeStats incl. the 24-byte header quirk (BlockStreams.jl:7,23)
     stats->rows = nrows;
-    for (int64_t b = block_first; b < block_last; b++) { stats->compressed += all[b].compressed + 24; stats->uncompressed += all[b].origin; }
+    for (int64_t i = 0; i < nb; i++) { stats->compressed += hs[i].compressed + 24; stats->uncompressed += hs[i].origin; }
   }
-  (void)origin_total;
+}
+
+static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t nbytes, size_t data_off, int64_t block_first,
+                            int64_t block_last, dfdb_sizestats* stats) {
+  hipStream_t s = t->ctx->stream;
+  std::vector<BlockHdr> all = walk_blocks(img, nbytes, data_off);
+  const int64_t nb_total = (int64_t)all.size();
+  if (block_last < 0 || block_last > nb_total) block_last = nb_total;
+  if (block_first < 0) block_first = 0;
+  if (block_first > block_last) block_first = block_last;
+  const int64_t nb = block_last - block_first;
+  for (int64_t b = 0; b + 1 < nb_total; b++)
+    if (all[b].rows != t->block_size) fail(DFDB_ERR_FORMAT, "block %lld of column %s holds %d rows, expected block_size %lld", (long long)b, c.name.c_str(), all[b].rows, (long long)t->block_size);
+  int64_t comp_lo = 0, comp_hi = 0;
+  if (nb) { comp_lo = (int64_t)all[block_first].body_off; comp_hi = (int64_t)(all[block_last - 1].body_off + all[block_last - 1].compressed); }
+  // stage the compressed byte range in HBM
+  DevBuf& staged = t->ld_staged;
+  staged.ensure((size_t)(comp_hi - comp_lo) + 64);
+  if (comp_hi > comp_lo) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
+  decode_staged(t, c, all.data() + block_first, nb, block_first, comp_lo, stats);
+}
+
+// dfdb_table_load: the column file -> HBM without ever holding it in host memory.  Blocks before block_first are skipped header by
+// header (skip_block, BlockStreams.jl:74-78); from there the file is read in 64-MB pieces with concurrent preads into one of two pinned
+// bounce buffers while the previous piece is in flight to the device, the 20-byte headers are walked as the bytes arrive, and the
+// blocks are decoded by ONE K7 launch once the last piece has been queued.
+static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int fd = open(c.file.c_str(), O_RDONLY);
+  if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
+  struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
+  const int64_t fsz = (int64_t)lseek(fd, 0, SEEK_END);
+  if (block_first < 0) block_first = 0;
+  auto parse = [&](const uint8_t* h, int64_t pos, BlockHdr& o) {
+    memcpy(&o.rows, h, 4); memcpy(&o.origin, h + 4, 8); memcpy(&o.compressed, h + 12, 8);
+    if (o.rows < 0 || o.origin < 0 || o.compressed < 0 || o.compressed > fsz - pos - 20) fail(DFDB_ERR_FORMAT, "corrupt block header");
+    o.body_off = (size_t)pos + 20;
+  };
+  auto check_rows = [&](const BlockHdr& h, int64_t b, int64_t next_pos) {      // every block but the last holds block_size rows
+    if (next_pos < fsz && h.rows != t->block_size)
+      fail(DFDB_ERR_FORMAT, "block %lld of column %s holds %d rows, expected block_size %lld", (long long)b, c.name.c_str(), h.rows, (long long)t->block_size);
+  };
+  int64_t pos = (int64_t)c.data_off, b = 0;
+  uint8_t hb[20];
+  while (b < block_first && pos < fsz) {
+    if (pos + 20 > fsz || pread(fd, hb, 20, (off_t)pos) != 20) fail(DFDB_ERR_FORMAT, "truncated block header");
+    BlockHdr h; parse(hb, pos, h);
+    pos += 20 + h.compressed; check_rows(h, b, pos); b++;
+  }
+  if (b < block_first) block_first = b;                                        // fewer blocks than asked for: an empty range at the end
+  const int64_t lo = pos;
+  std::vector<BlockHdr> hs;
+  int64_t hi = fsz;
+  if (block_last >= 0) {                                                       // a block range (sharded load): find where it ends
+    while (b < block_last && pos < fsz) {
+      if (pos + 20 > fsz || pread(fd, hb, 20, (off_t)pos) != 20) fail(DFDB_ERR_FORMAT, "truncated block header");
+      BlockHdr h; parse(hb, pos, h);
+      pos += 20 + h.compressed; check_rows(h, b, pos); b++;
+      hs.push_back(h);
+    }
+    hi = pos;
+  }
+  const bool walk = block_last < 0;
+  constexpr int64_t kPiece = 64ll << 20;
+  if (ctx->pin_ring_cap < (size_t)kPiece) {
+    for (int i = 0; i < 2; i++) {
+      if (ctx->pin_ring[i]) { (void)hipHostFree(ctx->pin_ring[i]); ctx->pin_ring[i] = nullptr; }
+      HIP_CHECK(hipHostMalloc((void**)&ctx->pin_ring[i], (size_t)kPiece, hipHostMallocDefault));
+      if (!ctx->pin_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    }
+    ctx->pin_ring_cap = (size_t)kPiece;
+  }
+  DevBuf& staged = t->ld_staged;
+  staged.ensure((size_t)(hi - lo) + 64);
+  uint8_t tail[20]; int64_t tail_end = -1;                                     // the last 20 bytes of the previous piece (a header may straddle)
+  pos = lo;
+  bool used[2] = {false, false};
+  int k = 0;
+  for (int64_t a = lo; a < hi; a += kPiece, k ^= 1) {
+    const int64_t e = std::min(hi, a + kPiece);
+    uint8_t* buf = ctx->pin_ring[k];
+    if (used[k]) HIP_CHECK(hipEventSynchronize(ctx->pin_ev[k]));              // its previous copy has left the buffer
+    if (!read_file_range_fd(fd, buf, a, e)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+    HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(ctx->pin_ev[k], s)); used[k] = true;
+    if (walk) {
+      while (pos + 20 <= e) {
+        const uint8_t* hp;
+        if (pos >= a) hp = buf + (pos - a);
+        else { const int64_t n0 = a - pos; memcpy(hb, tail + (20 - (tail_end - pos)), (size_t)n0); memcpy(hb + n0, buf, (size_t)(20 - n0)); hp = hb; }
+        BlockHdr h; parse(hp, pos, h);
+        pos += 20 + h.compressed; check_rows(h, b, pos); b++;
+        hs.push_back(h);
+      }
+      if (e - a >= 20) { memcpy(tail, buf + (e - a - 20), 20); tail_end = e; }
+      else if (e < hi) fail(DFDB_ERR_FORMAT, "truncated block header");
+    }
+  }
+  if (walk && pos != hi) fail(DFDB_ERR_FORMAT, "truncated block header");
+  decode_staged(t, c, hs.data(), (int64_t)hs.size(), block_first, lo, stats);
 }
 
 void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,
@@ -336,22 +427,8 @@ void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t b
     Column& c = t->cols[(size_t)o];
     if (c.resident) continue;
     if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
-    // the whole file into PINNED memory with a few concurrent preads (no zero-fill, no pageable staging copy: the H2D
-    // copy of the compressed bytes is a straight DMA), then the same loader as dfdb_table_load_image
-    struct stat sb;
-    if (stat(c.file.c_str(), &sb) != 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
-    const size_t fsz = (size_t)sb.st_size;
-    uint8_t* pin = nullptr;
-    bool pinned = hipHostMalloc((void**)&pin, fsz + 64, hipHostMallocDefault) == hipSuccess && pin;
-    if (!pinned) {   // (a file larger than the pinnable memory: pageable buffer, the runtime stages the copy)
-      (void)hipGetLastError();
-      pin = (uint8_t*)malloc(fsz + 64);
-      if (!pin) fail(DFDB_ERR_NOMEM, "cannot allocate %zu bytes to read %s", fsz, c.file.c_str());
-    }
-    struct PinFree { uint8_t* p; bool pinned; ~PinFree() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } } } guard{pin, pinned};
-    if (!read_file_range(c.file, pin, 0, (int64_t)fsz)) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     dfdb_sizestats st{0, 0, 0};
-    load_from_image(t, c, pin, fsz, c.data_off, block_first, block_last, &st);
+    load_from_file(t, c, block_first, block_last, &st);
     tot.rows = st.rows; tot.compressed += st.compressed; tot.uncompressed += st.uncompressed;
   }
   if (stats) *stats = tot;

@@ -769,7 +769,7 @@ class Stream:
     with load=False: `for part in dfdb.stream(v, chunk_blocks=256): part.count(), part.indices(), part.materialize()`.
     The next chunk is read, copied and LZ4-decoded on another HIP stream while the caller works on the current one."""
 
-    def __init__(self, v: Union[DFView, DFTable], chunk_blocks: int = 4096):
+    def __init__(self, v: Union[DFView, DFTable], chunk_blocks: int = 512):
         self.view = v if isinstance(v, DFView) else DFView(v)
         self._q = _Query(self.view)
         self._h = C.c_void_p()
@@ -810,17 +810,17 @@ class Stream:
             pass
 
 
-def stream(v: Union[DFView, DFTable], chunk_blocks: int = 4096) -> Stream:
+def stream(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> Stream:
     return Stream(v, chunk_blocks)
 
 
-def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 4096) -> int:
+def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> int:
     """nrow(v) without holding the table in HBM: sum of the per-chunk counts (BlockRowsIterator, view.jl:192-206)."""
     with Stream(v, chunk_blocks) as s:
         return sum(part.count() for part in s)
 
 
-def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 4096):
+def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 512):
     """materialize(v) chunk by chunk: per-chunk buffers appended on the host like materialization.jl:33-37."""
     import pandas as pd
     view = v if isinstance(v, DFView) else DFView(v)

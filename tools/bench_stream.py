@@ -27,7 +27,7 @@ try:
     t.close()
     tb = dfdb.open_table(os.path.join(d, "tb"), load=False)
     v = tb[("x", lambda x: x > 899_999), dfdb.ALL]
-    for chunk in (1024, 4096, 8192):
+    for chunk in (256, 512, 1024):
         for rep in range(2):
             t0 = time.perf_counter()
             got = dfdb.nrow_streamed(v, chunk)
