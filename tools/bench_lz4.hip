@@ -14,7 +14,7 @@ using namespace dfdb;
 
 int main(int argc, char** argv) {
   const int nblocks = argc > 1 ? atoi(argv[1]) : 4096;
-  const int mode = argc > 2 ? atoi(argv[2]) : 0;          // 0: h mod 1e6 (benchmark column), 1: 1..n, 2: h mod 1000
+  const int mode = argc > 2 ? atoi(argv[2]) : 0;          // 0: h mod 1e6 (benchmark column), 1: 1..n, 2: h mod 1000, 3: random doubles, 4: zeros, 5: runs + noise, 6: string body
   void* h = dlopen("liblz4.so.1", RTLD_NOW);
   if (!h) { printf("no liblz4.so.1\n"); return 1; }
   auto compress = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
@@ -26,7 +26,16 @@ int main(int argc, char** argv) {
     int64_t* v = plain.data() + (size_t)b * rows;
     for (int i = 0; i < rows; i++) {
       const uint64_t r = splitmix64(0x9E3779B97F4A7C15ull + (uint64_t)b * rows + (uint64_t)i);
-      v[i] = mode == 0 ? (int64_t)(r % 1000000ull) : mode == 1 ? (int64_t)b * rows + i + 1 : (int64_t)(r % 1000ull);
+      v[i] = mode == 0 ? (int64_t)(r % 1000000ull) : mode == 1 ? (int64_t)b * rows + i + 1 : mode == 2 ? (int64_t)(r % 1000ull) : 0;
+      if (mode == 3) { const double x = (double)(r >> 11) * 0x1.0p-53 * 2000.0; memcpy(&v[i], &x, 8); }          // incompressible
+      if (mode == 5) v[i] = (int64_t)((r % 10ull) < 3 ? r % 1000000ull : (uint64_t)i / 7);                           // runs of equal values between noisy ones
+    }
+    if (mode == 6) {   // a String block body: Int32 datasize, Int32 sizes, bytes of 10 brand names
+      static const char* brands[10] = {"apple", "samsung", "huawei", "microsoft", "dell", "xbox", "sony", "intel", "lenovo", "asus"};
+      uint8_t* p8 = (uint8_t*)v; int32_t* sz = (int32_t*)p8; const int nr = 52000; size_t o = 4 + 4 * (size_t)nr;
+      for (int i = 0; i < nr; i++) { const char* w = brands[splitmix64((uint64_t)b * 65536 + i) % 10]; const int L = (int)strlen(w); sz[1 + i] = L; memcpy(p8 + o, w, L); o += L; }
+      sz[0] = (int32_t)(o - 4 - 4 * (size_t)nr);
+      memset(p8 + o, 0, body - o);
     }
     comp[(size_t)b].resize((size_t)body + body / 255 + 64);
     const int n = compress((const char*)v, (char*)comp[(size_t)b].data(), body, (int)comp[(size_t)b].size());
