@@ -198,7 +198,7 @@ constexpr int kV4Waves = 1;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-// BATCH (v4, see below the kernel): up to 21 short sequences found in a 64-byte window are executed together
+// BATCH = 1 (v4): up to 21 short sequences found in a 64-byte window are executed together; BATCH = 2 (v5): W windows at once
 template <int WAVES, int BATCH, int kRing, int kStage, int kBatchBytes, int W = 1>
 __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
@@ -622,10 +622,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
 }
 
 // Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format), GB/s of
-// decoded output at 3815 / 7630 blocks: v1 26 / 30; v2 18; v3 22 / 26; v4 (v3 + batch execution, 7 KB of LDS per wave)
-// 44 / 45.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3.  Neither waits on memory
-// (SQ_WAIT_INST_ANY 7 % of wave cycles); a single wave retires this dependent, branchy code at ~1 instruction per 12
-// cycles, so the lever is instructions per sequence x resident waves, which is what v4 moves.  v4 is the default.
+// decoded output at 4096 / 15259 blocks (tools/bench_lz4): v1 26 / 30; v2 18; v3 22 / 26; v4 (v3 + batch execution of one
+// 64-byte window, 7 KB of LDS per wave) 47 / 54; v5 (superbatch of 8 windows, far sources prefetched, 7.4 KB of LDS per wave)
+// 240 / 256.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3.  None of them waits on
+// memory; a single wave retires this dependent code at ~1 instruction per 8-12 cycles, so the lever is instructions per
+// sequence x resident waves.  v5 is the default; the others stay selectable (ctx option "lz4_variant" 0..4).
 static int g_lz4_variant = 4;
 void set_lz4_variant(int v) { g_lz4_variant = v; }
 

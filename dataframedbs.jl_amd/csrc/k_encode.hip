@@ -6,7 +6,7 @@
 // not a parity target (CodecLz4 / liblz4 versions differ): the contract is the frozen LZ4 block
 // format — any conforming decoder (liblz4 in the test oracle, K7 here) must give back the body bit for bit.
 //
-// Compressor: greedy, 64 candidate positions per step.  Lane l hashes the 4 bytes at ip+l, reads the hash table's
+// Compressor v1 (kept selectable, ctx option "lz4_enc_variant" = 0; v2 below is the default): greedy, 64 candidate positions per step.  Lane l hashes the 4 bytes at ip+l, reads the hash table's
 // previous occupant (an earlier position with the same hash, or nothing), stores its own position, and verifies the
 // candidate (distance <= 65535, the 4 bytes equal).  The first verified lane (ballot + ffs) starts a match; the wave
 // extends it forward 64 bytes per ballot, emits one sequence (token, literal length, literals, offset, match
@@ -24,6 +24,11 @@ constexpr uint32_t kNoPos = 0xffffffffu;
 __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
   typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
   return *(const u32u*)p;
+}
+
+__device__ __forceinline__ uint64_t ld_u64_unaligned_e(const uint8_t* p) {
+  typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+  return *(const u64u*)p;
 }
 
 // length field continuation bytes (255, 255, ..., rest) for a value that did not fit the 4-bit token field
@@ -107,11 +112,191 @@ __global__ __launch_bounds__(kEncWaves * 64) void k_lz4_compress(const uint8_t* 
   }
 }
 
+// ---- compressor v2: every match of a 64-byte window in one step --------------------------------------------------
+// v1 emits ONE sequence per step and pays four dependent memory round trips for it (the 4 bytes at p, the candidate's 4 bytes, the
+// extension bytes, the literals): 7 GB/s on 8-byte integer columns, one sequence per 8 bytes.  v2 keeps the candidate search of v1 —
+// lane l looks at position ip + l — but every lane also measures ITS match (one 8-byte compare: 4..11 bytes, or "12 and more"),
+// and the wave then takes the leftmost non-overlapping matches of the whole window at once:
+//   * NH[l] = the first hit at or after lane l (ctz of the ballot), J[l] = NH[l + length of l's match]: the greedy parse is the
+//     chain NH[0] -> J -> J ..., walked with v_readlane + s_bitset1 (four instructions per hop, no branch);
+//   * each selected match is one sequence: its literal count is the distance to the end of the previous selected match
+//     (exclusive max-scan), its output offset an exclusive sum of the sequence sizes; token, offset and the literals of the
+//     whole window are written by all lanes together (a literal finds its sequence as the next selected lane above it);
+//   * a match of 12+ bytes ends the window: the wave extends it 64 bytes per ballot like v1 and continues behind it.
+// The hash table is read by all 64 lanes before any of them inserts, so a match never points into its own window: period-k data
+// matches at the first multiple of k that reaches the previous window instead of at k itself (same ratio, valid offsets).
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_max(T x, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const T t = (T)__shfl_up((int)x, d, 64); if (lane >= (uint32_t)d && t > x) x = t; }
+  return x;
+}
+
+__global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ out_len) {
+  __shared__ uint32_t ht[1 << kHashBits];
+  const uint32_t lane = (uint32_t)lane_id();
+  for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    const uint32_t n = (uint32_t)blk.src_len;
+    for (uint32_t k = lane; k < (1u << kHashBits); k += 64) ht[k] = kNoPos;
+    wave_lds_fence();
+    uint32_t anchor = 0, ip = 0, op = 0;
+    if (n > 12) {
+      const uint32_t mflimit = n - 12, matchlimit = n - 5;
+      while (ip < mflimit) {
+        const uint32_t p = ip + lane;
+        const bool inr = p < mflimit;
+        uint32_t v = 0, cand = kNoPos, h = 0;
+        if (inr) {
+          v = ld_u32_unaligned(in + p);
+          h = (v * 2654435761u) >> (32 - kHashBits);
+          cand = ht[h];
+        }
+        wave_lds_fence();
+        if (inr) ht[h] = p;                       // after every lane has read: several lanes may share h, any of them may win
+        bool ok = inr && cand != kNoPos && cand < p && p - cand <= 65535u;
+        uint32_t ml = 0; bool capped = false;
+        if (ok) ok = ld_u32_unaligned(in + cand) == v;
+        if (ok) {                                 // p + 12 <= n: the 8 bytes behind the 4 are inside the block on both sides
+          const uint64_t x = ld_u64_unaligned_e(in + p + 4) ^ ld_u64_unaligned_e(in + cand + 4);
+          capped = x == 0;
+          ml = capped ? 12u : 4u + ((uint32_t)__builtin_ctzll(x) >> 3);
+          const uint32_t lim = matchlimit - p;    // >= 7
+          if (ml >= lim) { ml = lim; capped = false; }
+        }
+        const uint64_t M = __ballot(ok);
+        if (M == 0) { ip += 64; continue; }
+        const uint64_t sh = M >> lane;
+        const uint32_t NH = sh ? lane + (uint32_t)__builtin_ctzll(sh) : 64u;
+        const uint32_t E = lane + ml;                                    // hit lanes: the window-relative end of the match
+        const uint32_t nhE = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((E & 63u) << 2), (int)NH);
+        const uint32_t J = capped ? 127u : (E >= 64u ? 64u : nhE);       // the next selected lane; >= 64: this one is the last
+        uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)NH, 0);
+        uint64_t SEL = 0;
+        for (int t = 0; t < 4; t++) {                                    // <= 16 matches of >= 4 bytes in a window
+          const uint32_t a0 = a;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)J, (int)a);
+            asm("s_bitset1_b64 %0, %1" : "+s"(SEL) : "s"(a));
+            a = j < 64u ? j : a;
+          }
+          if (a == a0) break;
+        }
+        const uint32_t last = a;
+        const bool capped_last = (uint32_t)__builtin_amdgcn_readlane((int)J, (int)last) == 127u;
+        uint32_t mlL = (uint32_t)__builtin_amdgcn_readlane((int)ml, (int)last);
+        const uint32_t candL = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)last);
+        if (capped_last) {                                               // forward extension, 64 bytes per ballot
+          const uint32_t mp = ip + last;
+          for (;;) {
+            const uint32_t q = mp + mlL + lane;
+            const bool diff = q >= matchlimit || in[q] != in[candL + mlL + lane];
+            const uint64_t d = __ballot(diff);
+            if (d) { mlL += (uint32_t)__builtin_ctzll(d); break; }
+            mlL += 64;
+          }
+        }
+        const bool sel = (SEL >> lane) & 1ull;
+        const uint32_t myml = lane == last ? mlL : ml;
+        const uint32_t myE = sel ? lane + myml : 0u;
+        const uint32_t cm = wave_incl_scan_max<uint32_t>(myE, lane);     // the furthest end of a selected match that starts at or before this lane
+        uint32_t pe = (uint32_t)__shfl_up((int)cm, 1, 64); if (lane == 0) pe = 0;   // ... that starts before this lane
+        const uint32_t pend = ip - anchor;                               // literals left over from the windows before
+        const uint32_t first = (uint32_t)__builtin_ctzll(SEL);
+        const uint32_t lit = sel ? (pe ? lane - pe : lane + pend) : 0u;  // (no match ends at 0: pe == 0 means "the first sequence")
+        const uint32_t ml4 = myml - 4u;
+        const uint32_t litx = lit >= 15u ? 1u + (lit - 15u) / 255u : 0u, mlx = (sel && ml4 >= 15u) ? 1u + (ml4 - 15u) / 255u : 0u;
+        const uint32_t size = sel ? 1u + litx + lit + 2u + mlx : 0u;
+        const uint32_t incl = wave_incl_scan(size);
+        const uint32_t ostart = op + incl - size;
+        const uint32_t lbase = ostart + 1u + litx;                       // where the sequence's literals go
+        if (sel) {
+          out[ostart] = (uint8_t)((lit < 15u ? lit : 15u) << 4 | (ml4 < 15u ? ml4 : 15u));
+          if (lit >= 15u && lane != first) out[ostart + 1] = (uint8_t)(lit - 15u);       // < 64 literals inside the window: one length byte
+          const uint32_t off = p - cand;
+          out[lbase + lit] = (uint8_t)(off & 255u); out[lbase + lit + 1] = (uint8_t)(off >> 8);
+        }
+        // the first sequence may carry any number of literals from before the window
+        const uint32_t lit0 = (uint32_t)__builtin_amdgcn_readlane((int)lit, (int)first);
+        const uint32_t os0 = (uint32_t)__builtin_amdgcn_readlane((int)ostart, (int)first);
+        const uint32_t lb0 = (uint32_t)__builtin_amdgcn_readlane((int)lbase, (int)first);
+        if (lit0 >= 15u) (void)put_length(out, os0 + 1, lit0 - 15u, lane);
+        for (uint32_t k = lane; k < pend; k += 64) out[lb0 + k] = in[anchor + k];
+        // literals inside the window: every uncovered position below the last selected match belongs to the next selected lane
+        {
+          const uint32_t pk = lbase - (pe ? pe : 0u - pend);             // literal at window position q of this sequence -> out[pk + q]
+          const uint64_t above = lane < 63u ? SEL >> (lane + 1u) : 0ull;
+          const uint32_t ns = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 0u;
+          const uint32_t pkn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ns << 2), (int)pk);
+          if (above != 0 && cm <= lane) out[pkn + lane] = (uint8_t)(v & 255u);
+        }
+        // the last match may be long: its length bytes
+        const uint32_t osL = (uint32_t)__builtin_amdgcn_readlane((int)(lbase + lit + 2u), (int)last);
+        const uint32_t szL = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (mlL - 4u >= 15u) (void)put_length(out, osL, mlL - 19u, lane);
+        op += szL;
+        const uint32_t endrel = last + mlL;
+        anchor = ip + endrel;
+        ip = (capped_last || endrel >= 64u) ? ip + endrel : ip + 64u;
+      }
+    }
+    // last sequence: literals only
+    const uint32_t lit = n - anchor;
+    if (lane == 0) out[op] = (uint8_t)((lit < 15 ? lit : 15u) << 4);
+    op++;
+    if (lit >= 15) op = put_length(out, op, lit - 15, lane);
+    for (uint32_t k = lane; k < lit; k += 64) out[op + k] = in[anchor + k];
+    op += lit;
+    if (lane == 0) out_len[b] = (int32_t)op;
+    wave_lds_fence();
+  }
+}
+
+static int g_lz4_enc_variant = 1;
+void set_lz4_enc_variant(int v) { g_lz4_enc_variant = v; }
+
 void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* out_len) {
   if (nblocks <= 0) return;
+  if (g_lz4_enc_variant == 1) {
+    hipLaunchKernelGGL(k_lz4_compress_v2, dim3((unsigned)nblocks), dim3(64), 0, s, src, dst, blocks, nblocks, out_len);
+    return;
+  }
   int64_t grid = ((int64_t)nblocks + kEncWaves - 1) / kEncWaves;
   if (grid > 65535) grid = 65535;
   hipLaunchKernelGGL(k_lz4_compress, dim3((unsigned)grid), dim3(kEncWaves * 64), 0, s, src, dst, blocks, nblocks, out_len);
+}
+
+// ---------------------------------------------------------------- file image
+// One workgroup per block: the 20-byte block header (Int32 rows, Int64 origin, Int64 compressed: BlockStreams.jl:50-53) and the
+// compressed bytes, at the block's offset inside the batch's piece of the column file.
+__global__ __launch_bounds__(256) void k_pack_file_image(const uint8_t* __restrict__ comp, const Lz4Block* __restrict__ blocks, const int32_t* __restrict__ lens,
+                                                         const int64_t* __restrict__ pos, const int32_t* __restrict__ rows, uint8_t* __restrict__ image) {
+  const int b = blockIdx.x;
+  const Lz4Block blk = blocks[b];
+  const int64_t len = lens[b];
+  uint8_t* d = image + pos[b];
+  if (threadIdx.x < 20) {
+    const int64_t origin = blk.src_len;
+    const int32_t r = rows[b];
+    uint8_t h[20];
+    __builtin_memcpy(h, &r, 4); __builtin_memcpy(h + 4, &origin, 8); __builtin_memcpy(h + 12, &len, 8);
+    d[threadIdx.x] = h[threadIdx.x];
+  }
+  d += 20;
+  const uint8_t* sp = comp + blk.dst_off;                       // 16-byte aligned slot of the compression arena
+  typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+  const int64_t n4 = len >> 2;
+  for (int64_t k = threadIdx.x; k < n4; k += 256) *(u32u*)(d + 4 * k) = *(const uint32_t*)(sp + 4 * k);
+  for (int64_t k = (n4 << 2) + threadIdx.x; k < len; k += 256) d[k] = sp[k];
+}
+void launch_pack_file_image(hipStream_t s, const uint8_t* comp, const Lz4Block* blocks, const int32_t* lens, const int64_t* pos, const int32_t* rows,
+                            int32_t nblocks, uint8_t* image) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(k_pack_file_image, dim3((unsigned)nblocks), dim3(256), 0, s, comp, blocks, lens, pos, rows, image);
 }
 
 // ---------------------------------------------------------------- block bodies

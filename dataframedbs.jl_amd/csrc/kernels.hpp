@@ -113,7 +113,7 @@ struct Lz4Block {      // one (column, block) unit of work
   int32_t dst_len;     // expected uncompressed bytes (origin)
   int64_t dst_off;     // where the decoded body goes inside the body arena
 };
-void set_lz4_variant(int v);   // 0 = v1 (global round trips), 1 = v2 (LDS staging + ring), 2 = v3 (register-window parser), 3 = v4 (v3 + batch execution, default)
+void set_lz4_variant(int v);   // 0 = v1 (global round trips), 1 = v2 (LDS staging + ring), 2 = v3 (register-window parser), 3 = v4 (v3 + one-window batch), 4 = v5 (superbatch, default)
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status);
 
 }  // namespace dfdb

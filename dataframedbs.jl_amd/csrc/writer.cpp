@@ -10,11 +10,18 @@
 #include <cerrno>
 #include <cstring>
 #include <cstdio>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 
 namespace dfdb {
 
 void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* out_len);
+void launch_pack_file_image(hipStream_t s, const uint8_t* comp, const Lz4Block* blocks, const int32_t* lens, const int64_t* pos, const int32_t* rows,
+                            int32_t nblocks, uint8_t* image);
+void set_lz4_enc_variant(int v);   // 0 = v1 (one sequence per step), 1 = v2 (every match of a 64-byte window per step, default)
 void launch_pack_nullable(hipStream_t s, const uint8_t* values, const uint64_t* missing_bits, const int64_t* row_off, const int64_t* body_off,
                           int32_t nblocks, int width, uint8_t* bodies);
 void launch_pack_strings(hipStream_t s, const int32_t* sizes, const uint8_t* bytes, const int64_t* row_off, const int64_t* byte_off,
@@ -30,12 +37,43 @@ struct Wr {   // little-endian writer (native Julia `write`)
   void str(const std::string& s) { i32((int32_t)s.size()); b.insert(b.end(), s.begin(), s.end()); }   // write_string: common_io.jl:1-4
 };
 
-struct File {
-  FILE* f = nullptr; std::string name;
-  File(const std::string& fn) : name(fn) { f = fopen(fn.c_str(), "wb"); if (!f) fail(DFDB_ERR_IO, "cannot create %s: %s", fn.c_str(), strerror(errno)); }
-  ~File() { if (f) fclose(f); }
-  void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) fail(DFDB_ERR_IO, "short write to %s", name.c_str()); }
-  void close() { if (f && fclose(f) != 0) { f = nullptr; fail(DFDB_ERR_IO, "cannot close %s", name.c_str()); } f = nullptr; }
+struct File {   // sequential writer over a file descriptor; large pieces go out as concurrent pwrites
+  int fd = -1; std::string name; int64_t pos = 0;
+  File(const std::string& fn) : name(fn) { fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666); if (fd < 0) fail(DFDB_ERR_IO, "cannot create %s: %s", fn.c_str(), strerror(errno)); }
+  ~File() { if (fd >= 0) ::close(fd); }
+  static bool pwrite_all(int fd, const uint8_t* p, int64_t n, int64_t at) {
+    while (n > 0) { const ssize_t r = pwrite(fd, p, (size_t)n, (off_t)at); if (r <= 0) return false; p += r; n -= r; at += r; }
+    return true;
+  }
+  void put(const void* p, size_t n) {
+    if (!n) return;
+    const uint8_t* b = (const uint8_t*)p;
+    if (n < (size_t)(8 << 20)) {
+      if (!pwrite_all(fd, b, (int64_t)n, pos)) fail(DFDB_ERR_IO, "short write to %s", name.c_str());
+      pos += (int64_t)n; return;
+    }
+    // a large piece: write()s to one file serialise on the inode lock, page faults on a shared mapping do not — grow the file,
+    // map the piece and fill it with concurrent memcpys
+    if (ftruncate(fd, (off_t)(pos + (int64_t)n)) != 0) fail(DFDB_ERR_IO, "cannot grow %s: %s", name.c_str(), strerror(errno));
+    const int64_t page = 4096, m0 = pos / page * page, mlen = pos + (int64_t)n - m0;
+    void* mp = mmap(nullptr, (size_t)mlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);
+    if (mp == MAP_FAILED) {                                            // (a file system without shared mappings)
+      if (!pwrite_all(fd, b, (int64_t)n, pos)) fail(DFDB_ERR_IO, "short write to %s", name.c_str());
+      pos += (int64_t)n; return;
+    }
+    uint8_t* d = (uint8_t*)mp + (pos - m0);
+    const int parts = 8;
+    std::vector<std::thread> th;
+    for (int k = 0; k < parts; k++) {
+      const int64_t a = (int64_t)n * k / parts, e = (int64_t)n * (k + 1) / parts;
+      auto work = [d, b, a, e] { memcpy(d + a, b + a, (size_t)(e - a)); };
+      if (k + 1 < parts) th.emplace_back(work); else work();
+    }
+    for (auto& t : th) t.join();
+    munmap(mp, (size_t)mlen);
+    pos += (int64_t)n;
+  }
+  void close() { if (fd >= 0 && ::close(fd) != 0) { fd = -1; fail(DFDB_ERR_IO, "cannot close %s", name.c_str()); } fd = -1; }
 };
 
 inline int64_t lz4_bound(int64_t n) { return n + n / 255 + 16; }   // LZ4_COMPRESSBOUND
@@ -78,8 +116,7 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
     return (int64_t)w * rows;
   };
 
-  DevBuf bodies, comp, dblocks, dlens, daux;
-  std::vector<uint8_t> hcomp;
+  DevBuf bodies, comp, dblocks, dlens, daux, image, dpos;
   int64_t b0 = 0;
   while (b0 < nb) {
     // batch [b0, b1): bounded by kBatchBodyBytes of bodies
@@ -116,24 +153,50 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
     dblocks.ensure(sizeof(Lz4Block) * (size_t)n);
     dlens.ensure(4 * (size_t)n);
     HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)n, hipMemcpyHostToDevice, s));
+    set_lz4_enc_variant((int)ctx_option(ctx, "lz4_enc_variant", 1));
     { LaunchTimer lt(ctx, "lz4_compress"); launch_lz4_compress(s, csrc, comp.as<uint8_t>(), dblocks.as<Lz4Block>(), (int32_t)n, dlens.as<int32_t>()); }
     std::vector<int32_t> lens((size_t)n);
     HIP_CHECK(hipMemcpyAsync(lens.data(), dlens.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    // compressed bytes: one D2H copy per run of blocks (the arena is sparse: every slot is sized for the worst case)
-    hcomp.resize((size_t)co);
+    // the batch's piece of the file — 20-byte header + compressed bytes of every block, back to back (commit_block_write!:
+    // BlockStreams.jl:50-53) — is assembled on the device and leaves through the two pinned bounce buffers: the copy of one piece
+    // overlaps the pwrite of the previous one
+    std::vector<int64_t> fpos((size_t)n + 1); std::vector<int32_t> brow((size_t)n);
+    int64_t fo = 0;
     for (int64_t i = 0; i < n; i++) {
       if (lens[(size_t)i] <= 0 || lens[(size_t)i] > blocks[(size_t)i].dst_len) fail(DFDB_ERR_DEVICE, "LZ4 compression failed in block %lld of column %s", (long long)(b0 + i), c.name.c_str());
-      HIP_CHECK(hipMemcpyAsync(hcomp.data() + blocks[(size_t)i].dst_off, comp.as<uint8_t>() + blocks[(size_t)i].dst_off, (size_t)lens[(size_t)i], hipMemcpyDeviceToHost, s));
-    }
-    HIP_CHECK(hipStreamSynchronize(s));
-    for (int64_t i = 0; i < n; i++) {   // commit_block_write!: BlockStreams.jl:50-53
-      const int64_t b = b0 + i;
-      const int32_t rows = (int32_t)std::min(B, nrows - b * B);
-      Wr h; h.i32(rows); h.i64(blocks[(size_t)i].src_len); h.i64(lens[(size_t)i]);
-      f.put(h.b.data(), h.b.size());
-      f.put(hcomp.data() + blocks[(size_t)i].dst_off, (size_t)lens[(size_t)i]);
+      fpos[(size_t)i] = fo; fo += 20 + lens[(size_t)i];
+      brow[(size_t)i] = (int32_t)std::min(B, nrows - (b0 + i) * B);
       st.compressed += lens[(size_t)i] + 24; st.uncompressed += blocks[(size_t)i].src_len;   // SizeStats incl. the 24-byte header quirk (:7,23)
+    }
+    fpos[(size_t)n] = fo;
+    image.ensure((size_t)fo + 64);
+    dpos.ensure(8 * ((size_t)n + 1) + 4 * (size_t)n);
+    int64_t* d_pos = dpos.as<int64_t>(); int32_t* d_rows = (int32_t*)(d_pos + n + 1);
+    HIP_CHECK(hipMemcpyAsync(d_pos, fpos.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_rows, brow.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    launch_pack_file_image(s, comp.as<uint8_t>(), dblocks.as<Lz4Block>(), dlens.as<int32_t>(), d_pos, d_rows, (int32_t)n, image.as<uint8_t>());
+    constexpr int64_t kPiece = 64ll << 20;
+    if (ctx->pin_ring_cap < (size_t)kPiece) {
+      for (int i = 0; i < 2; i++) {
+        if (ctx->pin_ring[i]) { (void)hipHostFree(ctx->pin_ring[i]); ctx->pin_ring[i] = nullptr; }
+        HIP_CHECK(hipHostMalloc((void**)&ctx->pin_ring[i], (size_t)kPiece, hipHostMallocDefault));
+        if (!ctx->pin_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+      }
+      ctx->pin_ring_cap = (size_t)kPiece;
+    }
+    const int64_t npieces = ceil_div(fo, kPiece);
+    auto start_copy = [&](int64_t k) {
+      const int64_t a = k * kPiece, e = std::min(fo, a + kPiece);
+      HIP_CHECK(hipMemcpyAsync(ctx->pin_ring[k & 1], image.as<uint8_t>() + a, (size_t)(e - a), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipEventRecord(ctx->pin_ev[k & 1], s));
+    };
+    if (npieces) start_copy(0);
+    for (int64_t k = 0; k < npieces; k++) {
+      HIP_CHECK(hipEventSynchronize(ctx->pin_ev[k & 1]));
+      if (k + 1 < npieces) start_copy(k + 1);                     // into the other buffer, which the previous pwrite has left
+      const int64_t a = k * kPiece, e = std::min(fo, a + kPiece);
+      f.put(ctx->pin_ring[k & 1], (size_t)(e - a));
     }
     b0 = b1;
   }

@@ -45,14 +45,19 @@ def sample_columns(oracle, n, rng):
             "period3": np.tile(np.array([7, -1, 2**40], np.int64), n // 3 + 1)[:n]}
 
 
+@pytest.mark.parametrize("enc", [1, 0])
 @pytest.mark.parametrize("n,bs", [(200_003, 65536), (200_003, 1000), (70_001, 999), (5, 65536), (12, 3), (0, 65536)])
-def test_saved_table_reads_back_everywhere(oracle, dfdb_mod, ctx, tmp_path, n, bs):
+def test_saved_table_reads_back_everywhere(oracle, dfdb_mod, ctx, tmp_path, n, bs, enc):
     from dfdb import ir
     rng = np.random.default_rng(3)
     cols = sample_columns(oracle, n, rng)
     t = dfdb_mod.DFTable.from_columns(cols, block_size=bs)
     path = str(tmp_path / "tb")
-    st = t.save(path)
+    ctx.set_option("lz4_enc_variant", enc)          # 1: window-parallel compressor (default), 0: one sequence per step
+    try:
+        st = t.save(path)
+    finally:
+        ctx.set_option("lz4_enc_variant", 1)
     assert st["rows"] == n
     assert sorted(os.listdir(path)) == sorted(["meta.bin"] + [f"{i + 1}.bin" for i in range(len(cols))])   # test/tables.jl:36-44
     # the oracle (liblz4 + the reference's reader logic) and the engine's decoders agree with the source on every observable
@@ -245,3 +250,50 @@ def test_date_datetime_time_char_columns(oracle, dfdb_mod, ctx, tmp_path):
         meta = bytearray(raw); i = meta.index(b"Int64"); meta[i:i + 5] = b"Int99"
         open(os.path.join(path, "meta.bin"), "wb").write(bytes(meta))
         dfdb_mod.open_table(path)
+
+
+@pytest.mark.parametrize("enc", [1, 0])
+def test_encoder_corner_cases(oracle, dfdb_mod, ctx, tmp_path, enc):
+    """Byte columns that push the device LZ4 compressors through every emission path: periodic data of every period 1..130
+    (matches that overlap their source, long extensions), literal runs of 0..400 bytes between matches (length-byte chains on the
+    FIRST sequence of a window), dense short matches at mixed distances, incompressible noise, runs; block sizes that end a block
+    inside a match / a literal run.  Every file must be decoded to the source by liblz4 (the oracle) and by K7."""
+    rng = np.random.default_rng(11)
+    n = 200_000
+    periodic = np.concatenate([np.tile(rng.integers(0, 256, per).astype(np.uint8), 1600 // per + 1)[:1600] for per in range(1, 131)])
+    base = rng.integers(0, 256, 20_000).astype(np.uint8)
+    pieces, tot = [base], len(base)
+    while tot < n:
+        lit = rng.integers(0, 256, int(rng.integers(0, 401))).astype(np.uint8)
+        ln = int(rng.choice([4, 5, 11, 12, 13, 18, 19, 20, 64, 65, 270, 271, 300, 1000, 9000]))
+        start = int(rng.integers(0, len(base) - ln))
+        pieces += [lit, base[start:start + ln]]; tot += len(lit) + ln
+    mixed = np.concatenate(pieces)[:n]
+    short = bytearray(rng.integers(0, 256, 4096).astype(np.uint8).tobytes())
+    while len(short) < n:
+        short += rng.integers(0, 256, int(rng.integers(0, 15))).astype(np.uint8).tobytes()
+        ml = int(rng.integers(4, 19)); hi = (8, 64, 2000, 60_000)[int(rng.integers(0, 4))]
+        d = int(rng.integers(1, min(hi, len(short)) + 1))
+        for k in range(ml):
+            short.append(short[len(short) - d])
+    cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "shortseq": np.frombuffer(bytes(short[:n]), np.uint8),
+            "noise": rng.integers(0, 256, n).astype(np.uint8), "zeros": np.zeros(n, np.uint8),
+            "runs": np.resize(np.repeat(rng.integers(0, 4, n // 50 + 1).astype(np.uint8), rng.integers(1, 100, n // 50 + 1)), n),
+            "i64": oracle.gen_i64(col_seed(0), 0, n), "iota": np.arange(1, n + 1, dtype=np.int64)}
+    ctx.set_option("lz4_enc_variant", enc)
+    try:
+        for bs in (65536, 4099, 13):
+            m = n if bs > 100 else 2000
+            sub = {k: v[:m] for k, v in cols.items()}
+            t = dfdb_mod.DFTable.from_columns(sub, block_size=bs)
+            path = str(tmp_path / f"e{bs}")
+            st = t.save(path)
+            assert st["rows"] == m
+            p = Reopened(oracle, dfdb_mod, path, list(sub), m)
+            ov, dv = apply_stages(p, [])
+            assert_same(p, ov, dv)
+            got = p.o.view().materialize()                              # and against the source itself, not only each other
+            for (k, v), g in zip(sub.items(), got):
+                assert np.array_equal(np.asarray(g).view(np.uint8), v.view(np.uint8)), k
+    finally:
+        ctx.set_option("lz4_enc_variant", 1)
