@@ -9,6 +9,7 @@
 // match equals source byte k mod offset, all of which precede the write pointer, so it is also copied in
 // parallel.  Reads of bytes this wave wrote earlier are ordered by a workgroup-scope fence (same CU, same
 // L1) before every match copy.
+#include <type_traits>
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -200,7 +201,7 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 
 // BATCH = 1 (v4): up to 21 short sequences found in a 64-byte window are executed together; BATCH = 2 (v5): W windows at once
 template <int WAVES, int BATCH, int kRing, int kStage, int kBatchBytes, int W = 1>
-__global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
   if (BATCH == 2 && lane < 2) bits[kBatchBytes / 32 + lane] = 0;
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
   constexpr uint32_t kFlush = BATCH == 2 ? (kRing >= 4096 ? 1024u : 512u) : 2048u;
-  static_assert(BATCH != 2 || (kFlush + 256 + kBatchBytes <= kRing && kBatchBytes >= 704 && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * (W + 1) + 24 <= kStage / 2),
+  static_assert(BATCH != 2 || (kFlush + 256 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
     uint32_t cb = 0;                   // staged: input bytes [cb, cb + 4096); invariant cb <= ip < cb + 2048
     uint32_t wbase = 0, wlo = 0, whi = 0;
     int err = 0;
+    uint32_t extstops = 0;             // v5: tokens with a length of 15 met by the one-sequence path
 #ifdef DFDB_LZ4_PROF
     uint64_t pf_acc[16] = {}; uint64_t pf_t0 = __builtin_readcyclecounter(); const uint64_t pf_start = pf_t0;
 #endif
@@ -378,70 +380,96 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
         // chunk, pointers are collapsed with ds_bpermute doubling, and each byte is fetched once.  No per-sequence loop.
         LZ4_PROF(4);
         advance(ip);
-        uint32_t A[W], NX[W], OFS[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-          const uint32_t pos = ip + 64u * (uint32_t)w + lane;
-          const uint32_t token = stage[pos & (kStage - 1)];
-          const uint32_t lit = token >> 4, mlc = token & 15u;
-          const uint32_t opos = pos + 1 + lit;                             // the 2-byte offset field
-          const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
-          const bool simple = lit != 15u && mlc != 15u && opos + 2 < in_len && offset != 0;
-          NX[w] = simple ? lane + 3u + lit : 127u;   // start of the following sequence, window-relative (<= 80); 127: a sequence the batch does not take
-          A[w] = lit | mlc << 4;
-          OFS[w] = offset;
-        }
-        bits[lane & (kBatchBytes / 32 - 1)] = 0;
-        LZ4_PROF(0);
-        uint32_t p = 0;                  // next sequence start, relative to the window being walked
         uint32_t T = 0, nseq = 0;        // output bytes / sequences accepted so far
         uint32_t nfar = 0;               // of them, matches that reach back further than the ring
         uint32_t consumed = 0;           // input bytes they cover = where the next sequence starts, relative to ip
         bool nonsimple = false;          // the walk ended on a sequence the batch does not take
         bool bad = false;
+        // Two forms of the window phase.  The plain one takes sequences whose lengths fit the token (<= 14 literals, <= 18 match
+        // bytes).  The EXT one also takes a length of 15 that continues in ONE more byte (a 255 there — lengths >= 270 / 274 — still
+        // leaves the sequence to the one-sequence path): two more LDS reads per candidate, sequences that jump over whole windows.
+        // A block switches to it for good once the one-sequence path has met two such tokens.
+        auto windows = [&](auto extc) {
+          constexpr bool EXT = decltype(extc)::value;
+          uint32_t A[W], NX[W], OFS[W];
 #pragma unroll
-        for (int w = 0; w < W; w++) {
-          const uint32_t entry = p;
-          // the walk: p hops from start to start and parks on the last start of the window (whose successor is >= 64); four
-          // instructions per hop, no branch: v_readlane, s_bitset1, s_cmp, s_cselect.  A parked p only sets its own bit again.
-          uint64_t mask = 0;
-          for (int h = 0; h < 6; h++) {
-            const uint32_t p0 = p;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t a = rl(NX[w], p);
-              asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(p));
-              p = a < 64u ? a : p;
+          for (int w = 0; w < W; w++) {
+            const uint32_t pos = ip + 64u * (uint32_t)w + lane;
+            const uint32_t token = stage[pos & (kStage - 1)];
+            if (!EXT) {
+              const uint32_t lit = token >> 4, mlc = token & 15u;
+              const uint32_t opos = pos + 1u + lit;                              // the 2-byte offset field
+              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+              const bool simple = lit != 15u && mlc != 15u && opos + 2u < in_len && offset != 0;
+              NX[w] = simple ? lane + 3u + lit : 1023u;  // where the following sequence starts, window-relative; 1023: a sequence the batch does not take
+              A[w] = lit | (mlc + 4u) << 9;
+              OFS[w] = offset;
+            } else {
+              const uint32_t e1 = stage[(pos + 1) & (kStage - 1)];
+              const bool le = (token >> 4) == 15u, me = (token & 15u) == 15u;
+              const uint32_t lit = le ? 15u + e1 : token >> 4;
+              const uint32_t opos = pos + 1u + (le ? 1u : 0u) + lit;
+              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+              const uint32_t m1 = stage[(opos + 2) & (kStage - 1)];
+              const uint32_t ml = 4u + (me ? 15u + m1 : (token & 15u));
+              const uint32_t end = opos + 2u + (me ? 1u : 0u);
+              const bool simple = !(le && e1 == 255u) && !(me && m1 == 255u) && end < in_len && offset != 0 &&
+                                  !(offset + 64u > (uint32_t)kRing && ml > 24u);   // (a far source is prefetched 24 bytes deep)
+              NX[w] = simple ? end - (ip + 64u * (uint32_t)w) : 1023u;           // <= 63 + 274
+              A[w] = lit | ml << 9 | (le ? 1u << 18 : 0u);
+              OFS[w] = offset;
             }
-            if (p == p0) break;
           }
-          const uint32_t exitp = rl(NX[w], p);
-          nonsimple = exitp == 127u;
-          mask &= __ballot(NX[w] != 127u);                                  // (a sequence the batch does not take got a bit too)
-          const bool mine = (mask >> lane) & 1ull;
-          const uint32_t lit = A[w] & 15u, mlc = A[w] >> 4;
-          const uint32_t tot = mine ? lit + mlc + 4u : 0u;
-          const uint32_t incl = wave_incl_scan(tot);
-          const uint32_t Tw = rl(incl, 63);
-          const bool far = mine && OFS[w] + 64u > (uint32_t)kRing;
-          const uint64_t farmask = __ballot(far);
-          const uint32_t nfw = (uint32_t)__builtin_popcountll(farmask);
-          if (T + Tw > (uint32_t)kBatchBytes || nfar + nfw > (uint32_t)kFarMax) {   // the window does not fit any more: next superbatch
-            consumed = 64u * (uint32_t)w + entry; nonsimple = false; break;
+          bits[lane & (kBatchBytes / 32 - 1)] = 0;
+          LZ4_PROF(0);
+          uint32_t p = 0;                  // next sequence start, relative to the window being walked
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            if (EXT && p >= 64u) { p -= 64u; consumed = 64u * (uint32_t)(w + 1) + p; continue; }   // a long sequence jumped over this window
+            const uint32_t entry = p;
+            // the walk: p hops from start to start and parks on the last start of the window (whose successor is >= 64); four
+            // instructions per hop, no branch: v_readlane, s_bitset1, s_cmp, s_cselect.  A parked p only sets its own bit again.
+            uint64_t mask = 0;
+            for (int h = 0; h < 6; h++) {
+              const uint32_t p0 = p;
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const uint32_t a = rl(NX[w], p);
+                asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(p));
+                p = a < 64u ? a : p;
+              }
+              if (p == p0) break;
+            }
+            const uint32_t exitp = rl(NX[w], p);
+            nonsimple = exitp == 1023u;
+            mask &= __ballot(NX[w] != 1023u);                                  // (a sequence the batch does not take got a bit too)
+            const bool mine = (mask >> lane) & 1ull;
+            const uint32_t lit = A[w] & 511u, ml = (A[w] >> 9) & 511u;
+            const uint32_t tot = mine ? lit + ml : 0u;
+            const uint32_t incl = wave_incl_scan(tot);
+            const uint32_t Tw = rl(incl, 63);
+            const bool far = mine && OFS[w] + 64u > (uint32_t)kRing;
+            const uint64_t farmask = __ballot(far);
+            const uint32_t nfw = (uint32_t)__builtin_popcountll(farmask);
+            if (T + Tw > (uint32_t)kBatchBytes || nfar + nfw > (uint32_t)kFarMax) {   // the window does not fit any more: next superbatch
+              consumed = 64u * (uint32_t)w + entry; nonsimple = T == 0;          // (nothing accepted yet: its first sequence goes the one-sequence way)
+              break;
+            }
+            const uint32_t ostart = T + incl - tot;
+            const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (mine) {
+              bad = bad || OFS[w] > op + ostart + lit;
+              const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
+              if (far) fard[fo] = op + ostart + lit - OFS[w];                 // where its source starts in the block's output
+              info[ord] = make_uint2(ostart | lit << 16 | (far ? 0x80000000u : 0u), (far ? fo * 24u : OFS[w]) | (64u * (uint32_t)w + lane + 1u + (A[w] >> 18)) << 16);
+              atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
+            }
+            T += Tw; nseq += (uint32_t)__builtin_popcountll(mask); nfar += nfw;
+            if (nonsimple) { consumed = 64u * (uint32_t)w + p; break; }
+            p = exitp - 64u; consumed = 64u * (uint32_t)(w + 1) + p;
           }
-          const uint32_t ostart = T + incl - tot;
-          const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          if (mine) {
-            bad = bad || OFS[w] > op + ostart + lit;
-            const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
-            if (far) fard[fo] = op + ostart + lit - OFS[w];                 // where its source starts in the block's output
-            info[ord] = make_uint2(ostart | lit << 16 | (far ? 0x80000000u : 0u), (far ? fo * 24u : OFS[w]) | (64u * (uint32_t)w + lane + 1u) << 16);
-            atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
-          }
-          T += Tw; nseq += (uint32_t)__builtin_popcountll(mask); nfar += nfw;
-          if (nonsimple) { consumed = 64u * (uint32_t)w + p; break; }
-          p = exitp - 64u; consumed = 64u * (uint32_t)(w + 1) + p;
-        }
+        };
+        if (extstops >= 2u) windows(std::true_type{}); else windows(std::false_type{});
         LZ4_PROF(1);
         if (T) {
           if (__ballot(bad) != 0 || T > out_len - op) { err = 5; break; }
@@ -478,7 +506,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
               const uint32_t ordinal = cnt + __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0u)) + own - 1u;
               cnt += (uint32_t)__builtin_popcount(w0) + (uint32_t)__builtin_popcount(w1);
               const uint2 inf = info[ordinal];
-              const uint32_t ostart = inf.x & 0xffffu, lit = (inf.x >> 16) & 15u, offset = inf.y & 0xffffu, inpos = inf.y >> 16;
+              const uint32_t ostart = inf.x & 0xffffu, lit = (inf.x >> 16) & 511u, offset = inf.y & 0xffffu, inpos = inf.y >> 16;
               const bool far = (inf.x >> 31) != 0u;                        // then `offset` is where the prefetched source bytes are
               const uint32_t bi = j - ostart;
               const int32_t sp = (int32_t)j - (int32_t)offset;             // a match byte copies output byte op + sp
@@ -491,10 +519,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
               R[u] = root ? (0x80000000u | addr) : (uint32_t)(sp - (int32_t)cc);   // else: the lane of this chunk that makes the source byte
             }
             for (;;) {                                                     // pointer doubling: R[j] = R[R[j]] (always a lower lane)
-              bool any = false;
+              uint32_t unres = 0;                                          // bit 31 set: some row of this lane still holds a pointer
 #pragma unroll
-              for (int u = 0; u < U; u++) any = any || (R[u] >> 31) == 0u;
-              if (__ballot(any) == 0) break;
+              for (int u = 0; u < U; u++) unres |= ~R[u];
+              if (__ballot((unres >> 31) != 0u) == 0) break;
 #pragma unroll
               for (int u = 0; u < U; u++) {
                 const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((R[u] & 63u) << 2), (int)R[u]);
@@ -521,6 +549,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz4_decode_v3(const uint8_t* __r
       const uint32_t token = (uint32_t)t64 & 255u;
       ip++;
       uint32_t lit = token >> 4;
+      if (BATCH == 2 && (lit == 15u || (token & 15u) == 15u)) extstops++;
       if (lit == 15) {
         uint32_t bb;
         do { if (ip >= in_len) { err = 1; break; } ensure(ip); bb = byte_at(ip); ip++; lit += bb; } while (bb == 255);
