@@ -3,12 +3,18 @@
 // Replaces LZ4_decompress_safe as called per (column, block) by BlockStream.read_block
 // (src/io/BlockStreams.jl:101-119) and read_block_body! for nullable and String columns
 // (src/io/blocks.jl:46-71).  The LZ4 *block* format is serial inside a block, so parallelism comes from
-// the blocks: one wavefront decodes one block (15 259 blocks per 1e9-row column), all lanes parse the same
-// token (wave-uniform control flow) and the literal / match copies are spread over the 64 lanes.
+// the blocks: one wavefront decodes one block (15 259 blocks per 1e9-row column).  Five decoders live here, oldest
+// first; the default is the last one (ctx option "lz4_variant" selects, launch_lz4_decode dispatches):
+//   v1 k_lz4_decode       all lanes parse the same token through L2 round trips, copies spread over the 64 lanes
+//   v2 k_lz4_decode_lds   v1 with the input staged in LDS and an LDS ring of the output
+//   v3 k_lz4_decode_v3<..,0,..>  register-window parser (v_readlane), one LDS round trip per sequence
+//   v4 k_lz4_decode_v3<..,1,..>  v3 + the short sequences of one 64-byte window executed together
+//   v5 k_lz4_decode_v3<..,2,..>  superbatch of 8 windows: branch-free chain walk, start bits + sequence records,
+//                                far sources prefetched from HBM, bytes produced in output order (see the kernel)
 // A match whose source overlaps its destination (offset < length) is a periodic pattern: byte k of the
 // match equals source byte k mod offset, all of which precede the write pointer, so it is also copied in
-// parallel.  Reads of bytes this wave wrote earlier are ordered by a workgroup-scope fence (same CU, same
-// L1) before every match copy.
+// parallel.  v1's reads of bytes this wave wrote earlier are ordered by a workgroup-scope fence (same CU, same
+// L1) before every match copy; v3-v5 keep recent output in LDS and only fence for sources that left the ring.
 #include <type_traits>
 #include "device_utils.hpp"
 #include "kernels.hpp"
