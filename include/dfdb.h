@@ -105,7 +105,12 @@ int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out);
 int32_t dfdb_ctx_destroy(dfdb_ctx* ctx);
 int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx);
 int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
-/* tuning knobs, e.g. "scan_nt" (1 = nontemporal column loads in the scan kernels, default 1) */
+/* tuning knobs (defaults are what the benchmarks use; the others keep measured alternatives selectable for A/B runs):
+ *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
+ *   "fused"           1 = one-pass scan + look-back + compaction kernel instead of K1 + count scan + K2 (default 0)
+ *   "pipeline"        1 = dfdb_select_indices_device in 4 pieces, compaction on a side stream (default 0)
+ *   "lz4_variant"     LZ4 block decoder: 0 v1 .. 3 v4, 4 = v5 superbatch decoder (default 4)
+ *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);
