@@ -1,5 +1,7 @@
 """GPU parity: the HIP engine (through the C ABI / Python mirror) against the CPU oracle on the same
 seeded inputs.  Integer, byte and index results must be bit-exact."""
+import shutil
+
 import numpy as np
 import pytest
 
@@ -274,6 +276,78 @@ def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
     assert ot.view().nrow() == 25            # range-only count never decompresses (isonly_range: blocksiterator.jl:135)
     with pytest.raises(OSError):
         ot.view().materialize()
+
+
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, variant):
+    """LZ4_decompress_safe semantics (BlockStreams.jl:110-112): a damaged block either still decodes to `origin` bytes or raises
+    "decompression error" — it never writes outside the block, hangs or takes the device down.  Random byte flips, truncated
+    sequences, zero / huge offsets and endless length chains in the payloads of valid files; after every attempt the intact file
+    must still load and compare equal."""
+    import struct
+    rng = np.random.default_rng(17 + variant)
+    n = 150_000
+    short = bytearray(rng.integers(0, 256, 4096).astype(np.uint8).tobytes())
+    while len(short) < n:
+        short += rng.integers(0, 256, int(rng.integers(0, 15))).astype(np.uint8).tobytes()
+        ml = int(rng.integers(4, 40)); d = int(rng.integers(1, min(60_000, len(short)) + 1))
+        for k in range(ml):
+            short.append(short[len(short) - d])
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "s": np.frombuffer(bytes(short[:n]), np.uint8)}
+    good = tmp_path / "good"
+    ot = oracle.Table(block_size=65536)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    ot.save(str(good))
+    ctx.set_option("lz4_variant", variant)
+    try:
+        outcomes = {"error": 0, "decoded": 0}
+        for trial in range(24):
+            bad = tmp_path / f"bad{trial}"
+            shutil.copytree(good, bad)
+            fn = bad / ("1.bin" if trial % 2 == 0 else "2.bin")
+            raw = bytearray(fn.read_bytes())
+            tl, = struct.unpack_from("<i", raw, 8)
+            pos, blocks = 12 + tl, []
+            while pos < len(raw):
+                rows, origin, comp = struct.unpack_from("<iqq", raw, pos)
+                blocks.append((pos + 20, comp)); pos += 20 + comp
+            b0, blen = blocks[int(rng.integers(0, len(blocks)))]
+            kind = trial % 6
+            if kind == 0:                                   # scattered byte flips
+                for _ in range(int(rng.integers(1, 20))):
+                    raw[b0 + int(rng.integers(0, blen))] ^= int(rng.integers(1, 256))
+            elif kind == 1:                                 # a run of 0xff: endless length chains
+                at = b0 + int(rng.integers(0, max(1, blen - 600)))
+                raw[at:at + 600] = b"\xff" * min(600, b0 + blen - at)
+            elif kind == 2:                                 # a run of zeros: zero offsets, zero-length tokens
+                at = b0 + int(rng.integers(0, max(1, blen - 300)))
+                raw[at:at + 300] = b"\x00" * min(300, b0 + blen - at)
+            elif kind == 3:                                 # the first sequence points before the start of the output
+                raw[b0:b0 + 4] = bytes([0x10, 0x41, 0xff, 0xff])
+            elif kind == 4:                                 # random garbage over the tail of the block
+                k = int(rng.integers(1, min(blen, 5000)))
+                raw[b0 + blen - k:b0 + blen] = rng.integers(0, 256, k).astype(np.uint8).tobytes()
+            else:                                           # random garbage over the head of the block
+                k = int(rng.integers(1, min(blen, 5000)))
+                raw[b0:b0 + k] = rng.integers(0, 256, k).astype(np.uint8).tobytes()
+            fn.write_bytes(bytes(raw))
+            try:
+                t = dfdb_mod.open_table(str(bad))
+                assert dfdb_mod.nrow(t) == n                # decoded to origin bytes (LZ4 carries no checksum: the bytes may differ)
+                t.close()
+                outcomes["decoded"] += 1
+            except dfdb_mod.DfdbError as e:
+                assert "decompression error" in str(e)
+                outcomes["error"] += 1
+            shutil.rmtree(bad)
+            t = dfdb_mod.open_table(str(good))              # the device is still healthy and exact
+            got = dfdb_mod.materialize(t)
+            assert np.array_equal(np.asarray(got["a"]), cols["a"]) and np.array_equal(np.asarray(got["s"]), cols["s"])
+            t.close()
+        assert outcomes["error"] >= 8                       # most of these damages cannot decode
+    finally:
+        ctx.set_option("lz4_variant", 4)
 
 
 # ------------------------------------------------------------------ aggregates
