@@ -72,6 +72,10 @@ struct dfdb_query {
   bool hint_materialize = false;
   int cap_col = -1;            // table ordinal captured by the last execution (-1: none)
   dfdb::DevBuf cap_buf;
+  // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena
+  // offset, selected byte totals per tile
+  int cap_str_col = -1;
+  dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
   bool prefix_valid = false;

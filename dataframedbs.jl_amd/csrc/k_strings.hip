@@ -127,11 +127,43 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
 //   A  wave prefix-sums of the sizes -> per-row byte offsets       (ALU only)
 //   B  one unaligned 8-byte probe per candidate row (size matches) (8 loads in flight per lane)
 //   C  masked compare + ballot = bitmap word
-template <bool AND_EXISTING, int MODE>
+// exact copy of one string (len bytes): unaligned 8-byte moves, then ONE 8-byte load (the arenas are padded) and <= 3 stores
+__device__ __forceinline__ void copy_string(uint8_t* dp, const uint8_t* sp, uint32_t len) {
+  typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+  typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+  typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
+  uint32_t b = 0;
+  for (; b + 8 <= len; b += 8) *(u64u*)(dp + b) = *(const u64u*)(sp + b);
+  const uint32_t rem = len - b;
+  if (rem) {
+    uint64_t v = *(const u64u*)(sp + b);
+    uint8_t* d = dp + b;
+    if (rem & 4u) { *(u32u*)d = (uint32_t)v; d += 4; v >>= 32; }
+    if (rem & 2u) { *(u16u*)d = (uint16_t)v; d += 2; v >>= 16; }
+    if (rem & 1u) *d = (uint8_t)v;
+  }
+}
+
+// the low `len` (<= 8) bytes of v
+__device__ __forceinline__ void store_small(uint8_t* d, uint64_t v, uint32_t len) {
+  typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+  typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+  typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
+  if (len >= 8u) { *(u64u*)d = v; return; }
+  if (len & 4u) { *(u32u*)d = (uint32_t)v; d += 4; v >>= 32; }
+  if (len & 2u) { *(u16u*)d = (uint16_t)v; d += 2; v >>= 16; }
+  if (len & 1u) *d = (uint8_t)v;
+}
+
+// CAP (dfdb_query_hint_materialize, the string column itself is projected): the pass that decides the rows also keeps them — the
+// size of every selected row at cap_sizes[tile * 1024 + rank], its bytes packed at the tile's own arena offset in cap_bytes, the
+// tile's selected byte total in sel_tile_bytes — so K6 does not read the column again: the projection is a contiguous copy per tile.
+template <bool AND_EXISTING, int MODE, bool CAP>
 __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
                                                             const uint8_t* __restrict__ bytes, uint64_t patw, int plen,
                                                             uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows,
-                                                            int64_t ntiles) {
+                                                            int64_t ntiles, int32_t* __restrict__ cap_sizes, uint8_t* __restrict__ cap_bytes,
+                                                            uint32_t* __restrict__ sel_tile_bytes) {
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -150,6 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
     for (int j = 0; j < 16; j++) { const int64_t i = base + j * 64 + lane; sz[j] = i < nrows ? __builtin_nontemporal_load(sizes + i) : -2; }
     uint64_t myword = 0;
     uint32_t run = 0;
+    uint32_t cap_n = 0, cap_b = 0;                                    // CAP: selected rows / bytes of this tile so far
+    uint8_t* const cb = CAP ? cap_bytes + tile_off[tile] : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       uint32_t rel[8]; uint64_t v[8]; bool cand[8];
@@ -174,8 +208,28 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
         const bool r = MODE == 1 ? (sz[h * 8 + j] != -2 && !eq) : eq;
         const uint64_t m = __ballot(r);
         if (lane == h * 8 + j) myword = m;
+        if (CAP && m != 0) {
+          const int32_t s0 = sz[h * 8 + j];
+          const uint32_t len = s0 > 0 ? (uint32_t)s0 : 0u;
+          const uint32_t rank = cap_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          uint32_t bpos;
+          if (MODE == 0) { bpos = rank * (uint32_t)plen; cap_b += (uint32_t)__popcll(m) * (uint32_t)plen; }   // every selected row is plen bytes long
+          else {
+            const uint32_t sl = r ? len : 0u;
+            const uint32_t incl = wave_incl_scan(sl);
+            bpos = cap_b + incl - sl;
+            cap_b += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          }
+          if (r) {
+            cap_sizes[base + rank] = s0;
+            if (MODE == 0) store_small(cb + bpos, v[j], len);                    // the probe already holds the whole string (<= 8 bytes)
+            else if (len) copy_string(cb + bpos, tb + rel[j], len);
+          }
+          cap_n += (uint32_t)__popcll(m);
+        }
       }
     }
+    if (CAP && lane == 0) sel_tile_bytes[tile] = cap_b;
     if (AND_EXISTING) myword &= existing;
     uint32_t cnt = lane < 16 ? (uint32_t)__popcll(myword) : 0u;
 #pragma unroll
@@ -187,14 +241,18 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
 
 template <int MODE>
 static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, uint64_t patw, int plen,
-                         uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles) {
-  if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles);
-  else hipLaunchKernelGGL((k_str_match_short<false, MODE>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles);
+                         uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, const StrCapture* cap) {
+  if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
+                              cap->sizes, cap->bytes, cap->tile_bytes);
+  else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
+                                  (int32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL((k_str_match_short<false, MODE, false>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
+                          (int32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
 }
 
 void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
                       const uint8_t* pat_dev, int32_t patlen, int mode, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
-                      bool and_existing) {
+                      bool and_existing, const StrCapture* cap) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   Pattern pat; memset(&pat, 0, sizeof pat); pat.len = patlen;
@@ -202,10 +260,10 @@ void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_o
   const int grid = grid_for(ntiles, 2048);
   if (patlen <= 8) {
     switch (mode) {
-      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
-      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
-      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
-      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles); break;
+      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
+      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
+      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
+      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
     }
     return;
   }
@@ -307,20 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __r
         const uint8_t* sp = sb + pre[p];
         const int64_t d0 = drun + (int64_t)(incl - cs);
         if (d0 + cs <= out_cap) {
-          uint8_t* dp = out_bytes + d0;
-          uint32_t b = 0;
-          typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
-          for (; b + 8 <= cs; b += 8) *(u64u*)(dp + b) = *(const u64u*)(sp + b);   // unaligned 8-byte moves inside this row's bytes
-          const uint32_t rem = cs - b;                         // 0..7 bytes left: ONE 8-byte load (the arena is padded), <= 3 stores
-          if (rem) {
-            typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
-            typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
-            uint64_t v = *(const u64u*)(sp + b);
-            uint8_t* d = dp + b;
-            if (rem & 4u) { *(u32u*)d = (uint32_t)v; d += 4; v >>= 32; }
-            if (rem & 2u) { *(u16u*)d = (uint16_t)v; d += 2; v >>= 16; }
-            if (rem & 1u) *d = (uint8_t)v;
-          }
+          copy_string(out_bytes + d0, sp, cs);
         }
       }
       drun += (int64_t)__shfl(incl, 63, 64);
@@ -334,6 +379,35 @@ void launch_str_gather_bytes(hipStream_t s, const uint64_t* bitmap, const int32_
   if (nt == 0) return;
   hipLaunchKernelGGL(k_str_gather_bytes, dim3(grid_for(nt)), dim3(kBlock), 0, s, bitmap, sizes, tile_off, bytes, out_tile_off, out_bytes, nrows,
                      nt, out_bytes_cap);
+}
+
+// projection of a String column whose selected rows K5 kept (CAP): per 1024-row tile a contiguous copy of its sizes and bytes
+__global__ __launch_bounds__(kBlock) void k_str_compact_captured(const int32_t* __restrict__ cap_sizes, const uint8_t* __restrict__ cap_bytes,
+                                                                 const uint64_t* __restrict__ prefix, const int64_t* __restrict__ tile_off,
+                                                                 const uint64_t* __restrict__ out_tile_off, int32_t* __restrict__ out_sizes,
+                                                                 uint8_t* __restrict__ out_bytes, int64_t ntiles, int64_t out_rows, int64_t out_bytes_cap) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t r0 = (int64_t)prefix[tile], r1 = (int64_t)prefix[tile + 1];
+    const int64_t b0 = (int64_t)out_tile_off[tile], b1 = (int64_t)out_tile_off[tile + 1];
+    const int32_t* ss = cap_sizes + tile * kTile;
+    for (int64_t k = lane; k < r1 - r0; k += 64) if (r0 + k < out_rows) out_sizes[r0 + k] = ss[k];
+    const uint8_t* sb = cap_bytes + tile_off[tile];
+    const int64_t nb = b1 <= out_bytes_cap ? b1 - b0 : 0;
+    const int64_t n8 = nb & ~7ll;
+    for (int64_t k = (int64_t)lane * 8; k < n8; k += 512) *(u64u*)(out_bytes + b0 + k) = *(const u64u*)(sb + k);
+    for (int64_t k = n8 + lane; k < nb; k += 64) out_bytes[b0 + k] = sb[k];
+  }
+}
+void launch_str_compact_captured(hipStream_t s, const StrCapture& cap, const uint64_t* prefix, const int64_t* tile_off, const uint64_t* out_tile_off,
+                                 int32_t* out_sizes, uint8_t* out_bytes, int64_t nrows, int64_t out_rows, int64_t out_bytes_cap) {
+  const int64_t nt = (nrows + kTile - 1) / kTile;
+  if (nt == 0) return;
+  hipLaunchKernelGGL(k_str_compact_captured, dim3(grid_for(nt)), dim3(kBlock), 0, s, cap.sizes, cap.bytes, prefix, tile_off, out_tile_off, out_sizes, out_bytes, nt,
+                     out_rows, out_bytes_cap);
 }
 
 }  // namespace dfdb

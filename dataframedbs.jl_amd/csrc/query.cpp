@@ -138,9 +138,26 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
     const Column& col = need_resident(t, ord);
     DevBuf& pb = q->tmp_a; pb.ensure(pat.size() + 64);
     if (pat.size() > 64) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); stream_wait(q->t->ctx); }
+    // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask and the column it reads is
+    // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
+    StrCapture capture{nullptr, nullptr, nullptr};
+    bool do_cap = q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 8;
+    if (do_cap) {
+      do_cap = false;
+      for (const ProjCol& p : q->proj) if (p.expr->op == DFIR_COL && p.expr->col == ord) { do_cap = true; break; }
+    }
+    if (do_cap) {
+      const int64_t nt = ceil_div(nrows, kTileRows);
+      q->cap_str_sizes.ensure((size_t)nt * kTileRows * 4 + 256);
+      q->cap_str_bytes.ensure((size_t)col.nbytes + 256);
+      q->cap_str_tb.ensure((size_t)(nt + 8) * 4);
+      capture = StrCapture{q->cap_str_sizes.as<int32_t>(), q->cap_str_bytes.as<uint8_t>(), q->cap_str_tb.as<uint32_t>()};
+    }
     LaunchTimer lt(ctx, "str_match");
     launch_str_match(s, col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(), (const uint8_t*)pat.data(),
-                     pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+                     pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
+                     do_cap ? &capture : nullptr);
+    if (do_cap) q->cap_str_col = ord;
     have = true;
   }
   // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask
@@ -199,7 +216,7 @@ void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
-  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1;
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1;
   if (nstages == 0) {
     LaunchTimer lt(ctx, "fill_ones");
     launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
@@ -300,7 +317,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
     q->scan_scratch.ensure((sc_stride * P + P + 2) * 8 + 256);
     uint64_t* carry = q->scan_scratch.as<uint64_t>() + sc_stride * P;
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
-    q->count = -1; q->cap_col = -1;
+    q->count = -1; q->cap_col = -1; q->cap_str_col = -1;
     for (int p = 0; p < P; p++) {
       const int64_t r0 = (int64_t)p * piece;
       if (r0 >= t->nrows) break;
@@ -342,6 +359,10 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
 }
 
 // ---------------------------------------------------------------- materialize
+static bool string_captured(const dfdb_query* q, const Column& col) {
+  return q->cap_str_col >= 0 && &q->t->cols[(size_t)q->cap_str_col] == &col && q->executed_stages == (int)q->stages.size();
+}
+
 // selected string bytes per 1024-row tile -> exclusive scan (output arena offsets); returns total
 static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_sizes_tmp, int32_t* out_sizes, int64_t cap, DevBuf& tile_off_out) {
   dfdb_ctx* ctx = q->t->ctx; hipStream_t s = ctx->stream;
@@ -351,6 +372,12 @@ static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_
   DevBuf& scratch = q->str_scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
   int32_t* dst_sizes = out_sizes;
   if (!dst_sizes) { out_sizes_tmp.ensure((size_t)std::max<int64_t>(cap, 1) * 4); dst_sizes = out_sizes_tmp.as<int32_t>(); }
+  if (string_captured(q, col)) {     // K5 kept the selected rows: their byte totals per tile are already there
+    launch_scan_counts(s, q->cap_str_tb.as<uint32_t>(), tile_off_out.as<uint64_t>(), nct, scratch.as<uint64_t>());
+    HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 1, tile_off_out.as<uint64_t>() + nct, 8, hipMemcpyDeviceToHost, s));
+    stream_wait(q->t->ctx);
+    return ctx->pinned_scalar[1];
+  }
   { LaunchTimer lt(ctx, "str_gather_sizes");
     launch_str_gather_sizes(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.as<int32_t>(), dst_sizes, tb.as<uint32_t>(), q->t->nrows, cap); }
   launch_scan_counts(s, tb.as<uint32_t>(), tile_off_out.as<uint64_t>(), nct, scratch.as<uint64_t>());
@@ -390,7 +417,11 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
       if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
       uint8_t* d_bytes = dev ? o.bytes : nullptr;
       if (!dev) { dbytes.ensure((size_t)total + 64); d_bytes = dbytes.as<uint8_t>(); }
-      if (total > 0) {
+      if (string_captured(q, col)) {     // sizes and bytes: one contiguous copy per tile out of the match pass's capture
+        LaunchTimer lt(ctx, "str_compact_captured");
+        const StrCapture sc{q->cap_str_sizes.as<int32_t>(), q->cap_str_bytes.as<uint8_t>(), q->cap_str_tb.as<uint32_t>()};
+        launch_str_compact_captured(s, sc, q->prefix.as<uint64_t>(), (const int64_t*)col.tile_off.p, toff.as<uint64_t>(), d_sizes, d_bytes, t->nrows, cnt, total);
+      } else if (total > 0) {
         LaunchTimer lt(ctx, "str_gather_bytes");
         launch_str_gather_bytes(s, q->bitmap.as<uint64_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
                                 toff.as<uint64_t>(), d_bytes, t->nrows, total);
@@ -526,7 +557,7 @@ void query_unique(dfdb_query* q, int32_t p) {
     if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
   }
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1;
+  q->count = -1; q->cap_col = -1; q->cap_str_col = -1;
   HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
 }
 

@@ -350,6 +350,35 @@ def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, va
         ctx.set_option("lz4_variant", 4)
 
 
+@pytest.mark.parametrize("n", [1, 1023, 1025, 70_001, 300_000])
+def test_string_capture_in_match_pass(oracle, dfdb_mod, ctx, n):
+    """materialize(t[s OP "const", :]) with s projected: the match kernel keeps the selected rows' sizes and bytes per tile (K5 CAP)
+    and the projection of s is a contiguous copy per tile.  Every short-pattern operator, empty strings, missing values, multi-byte
+    characters; the result must equal the oracle's (getindex(a, r): FlatStringsVectors.jl:136-157) and the captured path must
+    actually have run."""
+    from dfdb import ir
+    rng = np.random.default_rng(n)
+    words = ["sony", "so", "", "sonya", "apple", "x", "samsungs", "né", "sonysony", "asony"]
+    strs = [words[int(k)] for k in rng.integers(0, len(words), n)]
+    strs_m = [None if rng.random() < 0.1 else w for w in strs]
+    cols = {"s": strs, "sm": strs_m, "a": oracle.gen_i64(col_seed(0), 0, n)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    ctx.profile(True)
+    try:
+        # (a comparison with a Union{String,Missing} column is not a Bool selection — ArgumentError on both sides — so the captured
+        # column is the plain one; the nullable one rides along through the ordinary gather)
+        for pred in (ir.col(0) == "sony", ir.col(0) != "sony", ir.startswith(ir.col(0), "so"), ir.endswith(ir.col(0), "ny"),
+                     ir.col(0) == "", ir.col(0) == "samsungs", ir.startswith(ir.col(0), ""), ir.endswith(ir.col(0), "é")):
+            n0, _ = ctx.profile_get("str_compact_captured")
+            ov, dv = apply_stages(p, [("pred", pred)])
+            assert_same(p, ov, dv)
+            n1, _ = ctx.profile_get("str_compact_captured")
+            if ov.nrow() > 0:
+                assert n1 > n0, "the capture path did not run"
+    finally:
+        ctx.profile(False)
+
+
 # ------------------------------------------------------------------ aggregates
 def test_aggregates(oracle, dfdb_mod, ctx):
     from dfdb import ir
