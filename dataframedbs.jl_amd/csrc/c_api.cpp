@@ -301,6 +301,9 @@ int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { re
 // ------------------------------------------------------------------ execution
 int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQ(q); query_execute(q, -1); }); }
 int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQ(q); query_unique(q, proj_col); }); }
+int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
+  return guard([&] { NEEDQ(q); q->hint_agg_op = op; q->hint_agg_proj = proj_col; });   // (affects the NEXT execution only: an executed query keeps its results)
+}
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on) {
   return guard([&] { NEEDQ(q); if (q->hint_materialize != (on != 0)) { q->hint_materialize = on != 0; q->executed_stages = -1; q->count = -1; q->prefix_valid = false; } });
 }

@@ -75,6 +75,14 @@ struct dfdb_query {
   // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena
   // offset, selected byte totals per tile
   int cap_str_col = -1;
+  // dfdb_query_hint_aggregate: sum(projection column) WILL be asked for: when that column is a simple term of the launch that produces
+  // the final mask, the scan adds up the selected values while it holds them (one partial per 1024-row tile) and dfdb_aggregate only
+  // reduces the partials
+  int hint_agg_op = 0, hint_agg_proj = -1;
+  int agg_col = -1;            // table ordinal whose per-tile sums agg_partials holds (-1: none)
+  int agg_dtype = 0;
+  dfdb::DevBuf agg_partials, agg_ones;
+  int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)

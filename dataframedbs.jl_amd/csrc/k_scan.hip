@@ -180,60 +180,72 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
   return myword;
 }
 
-// the capture term: an 8-byte column whose loaded values are kept in registers until the tile's final mask is known
-// (re-reading the selected rows after the mask instead costs more: 4.0 vs 3.5 ms per 1e9 rows of two columns)
-template <typename T>
-__device__ __forceinline__ uint64_t term_word_keep(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, uint64_t (&keep)[kWordsPerTile]) {
+// The LAST term of an AND of terms can do more than compare: when it is evaluated the mask of everything before it (the other
+// terms, the earlier stages) is known, so the tile's final mask falls out word by word while the term's values are still in
+// registers.  EXTRA = 1 (capture, see k_scan_cmp CAP): the values of the finally selected rows go to an LDS staging tile in rank
+// order.  EXTRA = 2 (sum): they are added up per lane.  Nothing is kept across terms (the first capture version held the 16
+// loaded values in 32 VGPRs until the mask was complete: +0.75 ms on the two-term scan of 1e9 rows).
+template <typename T, int EXTRA>
+__device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, uint64_t before,
+                                                   uint64_t* stage, uint32_t& run, T& lsum) {
   const T* p = (const T*)colv + base + lane;
   const T c = from_bits<T>(cbits);
   uint64_t myword = 0;
-  if (base + kTile <= nrows) {
-    T v[kWordsPerTile];
+  const bool full = base + kTile <= nrows;
+  T v[kWordsPerTile];
 #pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);   // 16 loads in flight, like term_word
+  for (int j = 0; j < kWordsPerTile; j++) {
+    if (full) v[j] = __builtin_nontemporal_load(p + j * 64);               // 16 loads in flight, like term_word
+    else v[j] = base + j * 64 + lane < nrows ? p[j * 64] : T(0);
+  }
 #pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) {
-      __builtin_memcpy(&keep[j], &v[j], 8);
-      uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == j) myword = m;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) {
-      T x = T(0); bool r = false;
-      if (base + j * 64 + lane < nrows) { x = p[j * 64]; r = cmp_sel<T>(x, c, sel); }
-      __builtin_memcpy(&keep[j], &x, 8);
-      uint64_t m = __ballot(r); if (lane == j) myword = m;
-    }
+  for (int j = 0; j < kWordsPerTile; j++) {
+    const bool inb = full || base + j * 64 + lane < nrows;
+    const uint64_t bj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)before, j) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(before >> 32), j) << 32;   // word j of the mask so far
+    const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel)) & bj;
+    if (lane == j) myword = m;
+    const bool mine = (m >> lane) & 1ull;
+    if (EXTRA == 1) { if (mine) { uint64_t bits; __builtin_memcpy(&bits, &v[j], 8); stage[run + rank_in(m)] = bits; } run += (uint32_t)__popcll(m); }
+    if (EXTRA == 2) { if (mine) lsum += v[j]; }
   }
   return myword;
 }
 
-template <bool AND_EXISTING, bool CAP>
+template <typename T> __device__ __forceinline__ T wave_sum_t(T v);
+template <> __device__ __forceinline__ double wave_sum_t<double>(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+template <> __device__ __forceinline__ uint64_t wave_sum_t<uint64_t>(uint64_t v) { return wave_sum64(v); }
+
+// EXTRA: 0 plain; 1 capture the values of the LAST term's 8-byte column at the finally selected rows -> extra_out[tile*1024 + rank];
+// 2 sum them -> one partial per tile in extra_out (Float64 column: doubles; Int64 / UInt64 column: wrapping 64-bit sums, as Julia's)
+template <bool AND_EXISTING, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
-                                                       int64_t nrows, int64_t ntiles, int cap_term, uint64_t* __restrict__ cap) {
+                                                       int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out) {
+  __shared__ uint64_t capt_sh[EXTRA == 1 ? kWavesPerBlock : 1][EXTRA == 1 ? kTile : 1];
+  uint64_t* stage = capt_sh[EXTRA == 1 ? (threadIdx.x >> 6) : 0];
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int nplain = EXTRA ? terms.n - 1 : terms.n;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t base = tile * kTile;
     uint64_t existing = ~0ull;
     if (AND_EXISTING) {
       existing = lane < kWordsPerTile ? bitmap[tile * kWordsPerTile + lane] : 0ull;
-      if (__ballot(existing != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+      if (__ballot(existing != 0) == 0) {
+        if (lane == 0) { tile_counts[tile] = 0; if (EXTRA == 2) extra_out[tile] = 0; }
+        continue;
+      }
     }
     uint64_t acc = terms.combine_or ? 0ull : ~0ull;
-    uint64_t keep[kWordsPerTile];   // (dead, and removed by the compiler, unless CAP)
-    for (int t = 0; t < terms.n; t++) {
+    for (int t = 0; t < nplain; t++) {
       const ScanTerm& tm = terms.t[t];
       const uint32_t sel = op_sel(tm.op);
       uint64_t w;
-      if constexpr (CAP) if (t == cap_term) {   // wave-uniform; 8-byte dtypes only (the host checks)
-        if (tm.dtype == DFDB_I64) w = term_word_keep<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane, keep);
-        else if (tm.dtype == DFDB_U64) w = term_word_keep<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane, keep);
-        else w = term_word_keep<double>(tm.col, tm.cbits, sel, base, nrows, lane, keep);
-        acc = terms.combine_or ? (acc | w) : (acc & w);
-        continue;
-      }
       switch (tm.dtype) {   // wave-uniform
         case DFDB_I8:  w = term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
         case DFDB_I16: w = term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
@@ -250,29 +262,47 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
     }
     // rows past nrows never set: every term's tail ballot is false (AND) — for OR also false
     if (AND_EXISTING) acc &= existing;
+    if (EXTRA) {     // the last term (AND only, 8-byte dtypes only: the host checks), evaluated against the mask so far
+      const ScanTerm& tm = terms.t[terms.n - 1];
+      const uint32_t sel = op_sel(tm.op);
+      uint32_t run = 0;
+      if (tm.dtype == DFDB_F64) {
+        double ls = 0.0;
+        acc = term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
+        if (EXTRA == 2) { ls = wave_sum_t<double>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
+      } else if (tm.dtype == DFDB_I64) {
+        int64_t ls = 0;
+        acc = term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
+        if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>((uint64_t)ls); if (lane == 0) extra_out[tile] = u; }
+      } else {
+        uint64_t ls = 0;
+        acc = term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
+        if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>(ls); if (lane == 0) extra_out[tile] = u; }
+      }
+      if (EXTRA == 1) {   // staged in rank order: out as full 512-B stores
+        wave_lds_fence();
+        for (uint32_t k = lane; k < run; k += 64) extra_out[base + k] = stage[k];
+        wave_lds_fence();
+      }
+    }
     const uint32_t cnt = tile_popcount(acc, lane);
     if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = acc;
     if (lane == 0) tile_counts[tile] = cnt;
-    if (CAP) {   // the kept values of the rows that passed EVERY term, compacted inside the tile
-      uint32_t run = 0;
-#pragma unroll
-      for (int j = 0; j < kWordsPerTile; j++) {
-        const uint64_t m = __shfl(acc, j, 64);
-        if ((m >> lane) & 1ull) cap[base + run + rank_in(m)] = keep[j];
-        run += (uint32_t)__popcll(m);
-      }
-    }
   }
 }
 
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows, bool and_existing,
-                       int cap_term, void* cap) {
+                       int extra, void* extra_out) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
-  const int grid = grid_for_tiles(ntiles);
-  if (cap && cap_term >= 0 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, true>), dim3(grid), dim3(kBlock), 0, s, terms, bitmap, tile_counts, nrows, ntiles, cap_term, (uint64_t*)cap);
-  else if (and_existing) hipLaunchKernelGGL((k_scan_terms<true, false>), dim3(grid), dim3(kBlock), 0, s, terms, bitmap, tile_counts, nrows, ntiles, -1, (uint64_t*)nullptr);
-  else hipLaunchKernelGGL((k_scan_terms<false, false>), dim3(grid), dim3(kBlock), 0, s, terms, bitmap, tile_counts, nrows, ntiles, -1, (uint64_t*)nullptr);
+  const dim3 g(grid_for_tiles(ntiles)), b(kBlock);
+  uint64_t* eo = (uint64_t*)extra_out;
+  if (extra == 1 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 2 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 2) hipLaunchKernelGGL((k_scan_terms<true, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (and_existing) hipLaunchKernelGGL((k_scan_terms<true, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
+  else hipLaunchKernelGGL((k_scan_terms<false, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -27,9 +27,10 @@ struct ScanTerms {
 // single column `x OP c`; and_existing: bitmap &= result (a predicate stage after a range stage)
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap,
                      uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr);
-// cap (optional): values of term cap_term's 8-byte column at the selected rows, compacted per tile at cap[tile*1024 + rank]
+// extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
+// extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
-                       bool and_existing, int cap_term = -1, void* cap = nullptr);
+                       bool and_existing, int extra = 0, void* extra_out = nullptr);
 // captured values (per-tile compact) -> the output column: out[prefix[tile] + k] = cap[tile*1024 + k]
 void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap);
 

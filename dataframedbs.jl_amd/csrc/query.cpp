@@ -113,7 +113,7 @@ static void scan_prefix(dfdb_query* q) {
 }
 
 // predicate stage = AND of its conjuncts, each routed to the cheapest kernel that is exact for it
-static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
+static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, bool last_stage) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int64_t nrows = t->nrows;
   std::vector<const Node*> conj; flatten_and(pred, conj);
@@ -160,31 +160,51 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage) {
     if (do_cap) q->cap_str_col = ord;
     have = true;
   }
-  // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask
-  int cap_term = -1;
-  if (q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1 && !term_batches[0].combine_or) {
-    const ScanTerms& tb = term_batches[0];
-    for (int k = 0; k < tb.n && cap_term < 0; k++) {
-      const int dt = tb.t[k].dtype;
-      if (dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) continue;
-      for (const ProjCol& p : q->proj)
-        if (p.expr->op == DFIR_COL && p.expr->col == term_ords[(size_t)k] && !dt_nullable(p.expr->dtype)) { cap_term = k; break; }
+  // The launch that produces the query's final mask can do more with its LAST term (k_scan_terms EXTRA):
+  //   sum     (dfdb_query_hint_aggregate): the hinted column is a term of the last batch of the last stage -> per-tile partial sums
+  //   capture (dfdb_query_hint_materialize): a single-stage query of one batch of terms, one of them a projected 8-byte column
+  int extra = 0, special = -1;
+  if (!term_batches.empty() && !term_batches.back().combine_or) {
+    ScanTerms& lb = term_batches.back();
+    const size_t ord0 = term_ords.size() - (size_t)lb.n;           // term_ords of the last batch start here
+    if (q->hint_agg_op == DFDB_AGG_SUM && last_stage && q->hint_agg_proj >= 0 && (size_t)q->hint_agg_proj < q->proj.size()) {
+      const Node& pe = *q->proj[(size_t)q->hint_agg_proj].expr;
+      if (pe.op == DFIR_COL && !dt_nullable(pe.dtype))
+        for (int k = 0; k < lb.n && special < 0; k++) {
+          const int dt = lb.t[k].dtype;
+          if (term_ords[ord0 + (size_t)k] == pe.col && (dt == DFDB_I64 || dt == DFDB_U64 || dt == DFDB_F64)) { special = k; extra = 2; }
+        }
     }
-    if (cap_term >= 0) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
+    if (!extra && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1) {
+      for (int k = 0; k < lb.n && special < 0; k++) {
+        const int dt = lb.t[k].dtype;
+        if (dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) continue;
+        for (const ProjCol& p : q->proj)
+          if (p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype)) { special = k; extra = 1; break; }
+      }
+    }
+    if (extra) {                                                     // the special term goes last
+      std::swap(lb.t[special], lb.t[lb.n - 1]);
+      std::swap(term_ords[ord0 + (size_t)special], term_ords[ord0 + (size_t)lb.n - 1]);
+      if (extra == 1) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
+      else q->agg_partials.ensure((size_t)(ceil_div(nrows, kTileRows) + 8) * 8);
+    }
   }
-  for (const ScanTerms& tb : term_batches) {
-    void* cap = cap_term >= 0 ? q->cap_buf.p : nullptr;
-    if (tb.n == 1) {
+  for (size_t bi = 0; bi < term_batches.size(); bi++) {
+    const ScanTerms& tb = term_batches[bi];
+    const int ex = bi + 1 == term_batches.size() ? extra : 0;
+    if (tb.n == 1 && ex != 2) {
       LaunchTimer lt(ctx, "scan_cmp");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                      ctx_option(ctx, "scan_nt", 1) != 0, cap);
+                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr);
     } else {
       LaunchTimer lt(ctx, "scan_terms");
-      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, cap_term, cap);
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex == 2 ? q->agg_partials.p : nullptr);
     }
     have = true;
   }
-  if (cap_term >= 0) q->cap_col = term_ords[(size_t)cap_term];
+  if (extra == 1) q->cap_col = term_ords.back();
+  if (extra == 2) { q->agg_col = term_ords.back(); q->agg_dtype = term_batches.back().t[term_batches.back().n - 1].dtype; }
 }
 
 static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
@@ -216,14 +236,14 @@ void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
-  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1;
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
   if (nstages == 0) {
     LaunchTimer lt(ctx, "fill_ones");
     launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
   }
   for (int i = 0; i < nstages; i++) {
     const Stage& st = q->stages[(size_t)i];
-    if (st.kind == ST_PRED) { run_predicate(q, *st.pred, i == 0); q->prefix_valid = false; }
+    if (st.kind == ST_PRED) { run_predicate(q, *st.pred, i == 0, i + 1 == (int)q->stages.size()); q->prefix_valid = false; }
     else run_range(q, st, i == 0);
   }
   scan_prefix(q);
@@ -317,7 +337,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
     q->scan_scratch.ensure((sc_stride * P + P + 2) * 8 + 256);
     uint64_t* carry = q->scan_scratch.as<uint64_t>() + sc_stride * P;
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
-    q->count = -1; q->cap_col = -1; q->cap_str_col = -1;
+    q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
     for (int p = 0; p < P; p++) {
       const int64_t r0 = (int64_t)p * piece;
       if (r0 >= t->nrows) break;
@@ -557,7 +577,7 @@ void query_unique(dfdb_query* q, int32_t p) {
     if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
   }
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1; q->cap_str_col = -1;
+  q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
   HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
 }
 
@@ -571,6 +591,22 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
   const void* src; DevBuf full; int dt = dt_base(e.dtype);
   const uint64_t* mask = q->bitmap.as<uint64_t>();
   DevBuf ones;
+  if (op == DFDB_AGG_SUM && e.op == DFIR_COL && q->agg_col == e.col && q->executed_stages == (int)q->stages.size()) {
+    // the scan already added up the selected values of this column per tile (k_scan_terms EXTRA = 2): reduce the partials
+    const int64_t nt = ceil_div(t->nrows, kTileRows);
+    if (q->agg_ones_tiles != nt) {
+      q->agg_ones.ensure(padded_words(nt) * 8);
+      HIP_CHECK(hipMemsetAsync(q->agg_ones.p, 0xff, (size_t)(nt / 64) * 8, s));
+      const uint64_t tail = (nt & 63) ? ((1ull << (nt & 63)) - 1ull) : 0ull;
+      HIP_CHECK(hipMemcpyAsync((uint64_t*)q->agg_ones.p + nt / 64, &tail, 8, hipMemcpyHostToDevice, s));
+      stream_wait(ctx);
+      q->agg_ones_tiles = nt;
+    }
+    dt = q->agg_dtype == DFDB_F64 ? DFDB_F64 : (q->agg_dtype == DFDB_U64 ? DFDB_U64 : DFDB_I64);
+    q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
+    { LaunchTimer lt(ctx, "reduce_partials"); launch_reduce(s, q->agg_ones.as<uint64_t>(), q->agg_partials.p, dt, op, nt, q->red_scratch.p, q->red_result.p); }
+    goto readback;
+  }
   if (e.op == DFIR_COL) src = need_resident(t, e.col).data.p;
   else {   // computed column: materialise the selected values, then reduce them all
     const int64_t cnt = query_count(q, -1);

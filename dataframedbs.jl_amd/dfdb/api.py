@@ -741,8 +741,13 @@ class _Query:
                 res.append(a[:n].copy())
         return res
 
+    def hint_aggregate(self, op: int, col: int = 0):
+        N.check(N.load().dfdb_query_hint_aggregate(self._h, op, col))
+
     def aggregate(self, op: int, col: int = 0):
         oi, of = C.c_int64(), C.c_double()
+        if op == N.AGG_SUM:
+            self.hint_aggregate(op, col)      # a first execution below lets the scan add the column up while it holds it
         N.check(N.load().dfdb_aggregate(self._h, op, col, C.byref(oi), C.byref(of)))
         dt = self.coltype(col) & ir.DTYPE_MASK if op != N.AGG_COUNT else ir.I64
         return of.value if dt in (ir.F32, ir.F64) else oi.value
@@ -1001,6 +1006,7 @@ class DFColumn:
     def max(self): return self.view._query().aggregate(N.AGG_MAX)
 
     def mean(self):
+        self.view._query().hint_aggregate(N.AGG_SUM)      # before the count below executes the selection
         n = len(self)
         if n == 0:
             return float("nan")

@@ -257,6 +257,23 @@ end
 "unique(col::DFColumn) on the device (docs/src/index.md:171-182): distinct values in order of first appearance."
 gpu_unique(c::DFColumn) = gpu_materialize(c.view; first_occurrences_of = 0)[!, 1]
 
+"""
+sum(col::DFColumn) / mean(col) on the device (the reference iterates the column: column.jl:102-126, docs/src/index.md:503-509).
+The hint lets the scan that evaluates the selection add the selected values up while it holds them (dfdb_query_hint_aggregate);
+the count comes out of the same execution.  Returns (sum, count).
+"""
+function gpu_sum_count(c::DFColumn)
+    with_query(c.view) do q
+        check(ccall((:dfdb_query_hint_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32), q, 1, 0))          # DFDB_AGG_SUM of projection column 0
+        si = Ref{Int64}(0); sf = Ref{Float64}(0.0); n = Ref{Int64}(0)
+        check(ccall((:dfdb_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Float64}), q, 1, 0, si, sf))
+        check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        (eltype(c) <: AbstractFloat ? sf[] : si[], n[])
+    end
+end
+gpu_sum(c::DFColumn) = gpu_sum_count(c)[1]
+gpu_mean(c::DFColumn) = ((s, n) = gpu_sum_count(c); s / n)
+
 # ---------------------------------------------------------------- write side (create_table / add_column!)
 struct SizeStatsC; rows::Int64; compressed::Int64; uncompressed::Int64; end
 

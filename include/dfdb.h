@@ -215,6 +215,12 @@ int32_t dfdb_query_execute(dfdb_query* q);
  * registers; dfdb_materialize then copies them instead of gathering (re-reading) the column.  Results are identical; the
  * query holds an extra nrows*8-byte buffer while the hint is on. */
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on);
+/* sum(col) / mean(col) over a filtered view (Base.iterate(::DFColumn), src/tables/column.jl:102-126; docs/src/index.md:503-509) evaluates
+ * the selection and then adds up the column.  Telling the engine BEFORE the first execution that dfdb_aggregate(q, DFDB_AGG_SUM, proj_col)
+ * will follow lets the scan that produces the final mask add up the selected values of that column while it holds them (the column must
+ * be a simple `col OP const` term of the last predicate stage, Int64 / UInt64 / Float64); dfdb_aggregate then only reduces one partial
+ * per 1024-row tile.  op = 0 clears the hint.  Results: Int sums identical (wrapping), Float64 within the stated tolerance. */
+int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col);
 
 /* unique(col) (Base.unique over Base.iterate(::DFColumn), src/tables/column.jl:102-126; docs/src/index.md:171-182,479-486):
  * narrows the CURRENT selection of q to the rows holding the first occurrence of their value in projection column proj_col

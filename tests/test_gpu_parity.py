@@ -399,6 +399,62 @@ def test_aggregates(oracle, dfdb_mod, ctx):
     assert abs(cx.mean() - want / sel.sum()) <= tol
 
 
+@pytest.mark.parametrize("n", [1000, 250_001])
+def test_sum_fused_into_the_scan(oracle, dfdb_mod, ctx, n):
+    """sum(col) / mean(col) over a filtered view (docs/src/index.md:503-509): when the column is a simple term of the launch that
+    produces the final mask, the scan adds the selected values up per tile (k_scan_terms EXTRA = 2) and dfdb_aggregate only reduces
+    the partials.  Int64 sums are exact (wrapping), Float64 within n * eps * sum|x|; shapes that cannot fuse take the ordinary
+    reduce and agree too."""
+    from dfdb import ir
+    sizes, data = oracle.gen_str(col_seed(3), 0, n)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": oracle.flat_to_strings(sizes, data),
+            "big": (oracle.gen_i64(col_seed(5), 0, n).astype(np.int64) << 44) - 7}          # sums wrap around Int64
+    t = dfdb_mod.DFTable.from_columns(cols, block_size=65536)
+    a, x, big = cols["a"], cols["x"], cols["big"]
+    strs = np.array(cols["s"], dtype=object)
+    ctx.profile(True)
+    try:
+        def fused(fn):
+            n0, _ = ctx.profile_get("reduce_partials")
+            r = fn()
+            n1, _ = ctx.profile_get("reduce_partials")
+            return r, n1 > n0
+        def ftol(sel): return max(1, int(sel.sum())) * np.finfo(np.float64).eps * float(np.abs(x[sel]).sum()) + 1e-300
+        # one term, Int64
+        sel = a > 500_000
+        r, f = fused(lambda: t[t.a > 500_000, dfdb_mod.ALL][dfdb_mod.ALL, "a"].sum())
+        assert f and r == int(a[sel].sum())
+        # wrapping Int64 sum, two terms (the summed column is not the first term)
+        sel = (a > 100_000) & (big > -(1 << 62))
+        r, f = fused(lambda: t[(t.a > 100_000) & (t.big > -(1 << 62)), dfdb_mod.ALL][dfdb_mod.ALL, "big"].sum())
+        want = int(np.sum(big[sel].astype(np.uint64), dtype=np.uint64).astype(np.int64)) if sel.any() else 0
+        assert f and r == want
+        # Float64 under a conjunction with a string term (the string kernel runs first, the terms last, against its mask)
+        sel = (a > 300_000) & (x < 1500.0) & (strs != "sony")
+        v = t[(t.a > 300_000) & (t.x < 1500.0) & (t.s != "sony"), dfdb_mod.ALL]
+        r, f = fused(lambda: v[dfdb_mod.ALL, "x"].sum())
+        assert f and abs(r - float(x[sel].sum())) <= ftol(sel)
+        r, f = fused(lambda: v[dfdb_mod.ALL, "x"].mean())
+        assert f and abs(r - float(x[sel].mean())) <= ftol(sel) / max(1, sel.sum()) * 4
+        assert dfdb_mod.nrow(v) == int(sel.sum())
+        # a range stage first, the predicate last: still the launch that makes the final mask
+        m = min(n, 100_000)
+        sel = np.zeros(n, bool); sel[:m] = x[:m] < 700.0
+        r, f = fused(lambda: t[dfdb_mod.jr(1, m), dfdb_mod.ALL][("x", lambda c: c < 700.0), dfdb_mod.ALL][dfdb_mod.ALL, "x"].sum())
+        assert f and abs(r - float(x[sel].sum())) <= ftol(sel)
+        # shapes that cannot fuse: the predicate is not the last stage / the column is not a term / an OR
+        r, f = fused(lambda: t[t.x < 700.0, dfdb_mod.ALL][dfdb_mod.jr(1, 50), dfdb_mod.ALL][dfdb_mod.ALL, "x"].sum())
+        idx = np.flatnonzero(x < 700.0)[:50]
+        assert not f and abs(r - float(x[idx].sum())) <= 1e-9
+        r, f = fused(lambda: t[t.a > 500_000, dfdb_mod.ALL][dfdb_mod.ALL, "x"].sum())
+        assert not f and abs(r - float(x[a > 500_000].sum())) <= ftol(a > 500_000)
+        r, f = fused(lambda: t[(t.a > 900_000) | (t.x < 100.0), dfdb_mod.ALL][dfdb_mod.ALL, "x"].sum())
+        sel = (a > 900_000) | (x < 100.0)
+        assert not f and abs(r - float(x[sel].sum())) <= ftol(sel)
+    finally:
+        ctx.profile(False)
+
+
 # ------------------------------------------------------------------ fused one-pass kernel (scan + look-back + compaction)
 @pytest.mark.parametrize("n", [1, 1023, 65535, 65536, 65537, 131072, 1_000_003, 5_000_011])
 @pytest.mark.parametrize("dtype", [np.int64, np.float64, np.int32])

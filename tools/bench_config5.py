@@ -57,14 +57,14 @@ def main():
     t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed(2), n, row_first=r0)
     t.set_row_base(r0)
     v = t[(t.a > 683_771) & (t.x < 632.456) & (t.s != "sony"), dfdb.ALL]
-    q = v._query()
     cx = v[dfdb.ALL, "x"]
-    res = torch.zeros(2, dtype=torch.float64, device=dev)
+    q = cx.view._query()               # ONE evaluation of the selection gives both numbers: sum() hints the scan to add x up while
+    res = torch.zeros(2, dtype=torch.float64, device=dev)   # it holds it (dfdb_query_hint_aggregate), count() reads the same execution
 
     def step():
         q.reset()
-        cnt = q.count()
         sx = cx.sum()
+        cnt = q.count()
         res[0] = float(cnt); res[1] = sx
         if world > 1:
             dist.all_reduce(res)

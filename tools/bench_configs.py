@@ -24,7 +24,7 @@ from dfdb import ir  # noqa: E402
 
 SEED = 0x9E3779B97F4A7C15
 KERNELS = ["lz4_compress", "compact_captured", "scan_cmp", "scan_terms", "str_match", "interp_predicate", "interp_project", "scan_counts", "range_stage", "fill_ones",
-           "compact_indices", "gather", "str_gather_sizes", "str_gather_bytes", "str_compact_captured", "reduce", "lz4_decode"]
+           "compact_indices", "gather", "str_gather_sizes", "str_gather_bytes", "str_compact_captured", "reduce", "reduce_partials", "lz4_decode"]
 
 
 def seed(k):
@@ -107,8 +107,16 @@ def main():
     q.hint_materialize(False)
     del xs
     cx = v[dfdb.ALL, "x"]
-    ks, wall = timed(ctx, lambda: (q.execute(), cx.sum()), args.reps)
-    print(json.dumps({"config": "2-sum", "kernels_ms": ks, "wall_ms": wall * 1e3}))
+    cq = cx.view._query()
+    for hint in (False, True):          # True is what sum() does: the scan adds the selected values up per tile (k_scan_terms EXTRA = 2)
+        def step_sum():
+            cq.reset()
+            N.check(N.load().dfdb_query_hint_aggregate(cq._h, N.AGG_SUM if hint else 0, 0))
+            oi, of = C.c_int64(), C.c_double()
+            N.check(N.load().dfdb_aggregate(cq._h, N.AGG_SUM, 0, C.byref(oi), C.byref(of)))
+            return oi.value
+        ks, wall = timed(ctx, step_sum, args.reps)
+        print(json.dumps({"config": "2-sum", "hint": hint, "sum": step_sum(), "kernels_ms": ks, "wall_ms": wall * 1e3}))
     # leading range stage then predicate: t[1:100000, :][x -> x > c, :] -- later stages skip tiles without survivors
     vh = t[dfdb.jr(1, 100_000), dfdb.ALL][("x", lambda x: x > 899_999), dfdb.ALL]
     qh = vh._query()
