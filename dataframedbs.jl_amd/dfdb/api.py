@@ -1001,16 +1001,45 @@ class DFColumn:
             return np.array(out, dtype=object) if out and isinstance(out[0], (str, type(None))) else np.array(out)
         return one(self.view._query())
 
-    def sum(self): return self.view._query().aggregate(N.AGG_SUM)
-    def min(self): return self.view._query().aggregate(N.AGG_MIN)
-    def max(self): return self.view._query().aggregate(N.AGG_MAX)
+    def _aggregate(self, op: int, with_count: bool = False):
+        """sum / min / max driven by Base.iterate(::DFColumn) in the reference (column.jl:102-126).  Over a table that is not resident
+        every chunk is reduced on the device and the per-chunk results are combined here, block order = the reference's order."""
+        if not _out_of_core(self.view):
+            q = self.view._query()
+            if op == N.AGG_SUM:
+                q.hint_aggregate(op)                       # before anything executes the selection
+            r = q.aggregate(op)
+            return (r, q.count()) if with_count else r
+        isint = (self.eltype & ir.DTYPE_MASK) not in (ir.F32, ir.F64)
+        acc, total = None, 0
+        with Stream(self.view) as s:
+            for part in s:
+                c = part.count()
+                if c == 0:
+                    continue                              # (min / max of an empty chunk would raise)
+                total += c
+                r = part.aggregate(op)
+                if acc is None:
+                    acc = r
+                elif op == N.AGG_SUM:
+                    acc = acc + r
+                    if isint:
+                        acc = (acc + (1 << 63)) % (1 << 64) - (1 << 63)    # Int64 sums wrap, like Julia's
+                else:
+                    acc = min(acc, r) if op == N.AGG_MIN else max(acc, r)
+        if acc is None:
+            if op != N.AGG_SUM:
+                raise ValueError("ArgumentError: reducing over an empty collection is not allowed")
+            acc = 0 if isint else 0.0
+        return (acc, total) if with_count else acc
+
+    def sum(self): return self._aggregate(N.AGG_SUM)
+    def min(self): return self._aggregate(N.AGG_MIN)
+    def max(self): return self._aggregate(N.AGG_MAX)
 
     def mean(self):
-        self.view._query().hint_aggregate(N.AGG_SUM)      # before the count below executes the selection
-        n = len(self)
-        if n == 0:
-            return float("nan")
-        return self.view._query().aggregate(N.AGG_SUM) / n
+        s, n = self._aggregate(N.AGG_SUM, with_count=True)      # one evaluation of the selection gives both
+        return float("nan") if n == 0 else s / n
 
     # -- broadcasting (columnbroadcast.jl:19-62): every DFColumn argument must share (table, selection)
     def _bc(self, op: int, other, swap: bool = False) -> "DFColumn":

@@ -111,6 +111,19 @@ def test_streamed_conveniences_and_errors(files, oracle, dfdb_mod):
     df2 = dfdb_mod.materialize(v)
     assert df2["a"].to_numpy().tolist() == df["a"].to_numpy().tolist() and df2["s"].tolist() == df["s"].tolist()
     assert len(dfdb_mod.head(p.d)) == 10 and dfdb_mod.head(p.d)["iota"].tolist() == list(range(1, 11))
+    # aggregates over a table that is not resident: per-chunk device reductions combined in block order
+    a_all, x_all = oracle.gen_i64(col_seed(0), 0, p.nrows), oracle.gen_f64(col_seed(1), 0, p.nrows)
+    sel = (a_all > 500_000) & (x_all < 1200.0)
+    vv = p.d[(p.d.a > 500_000) & (p.d.x < 1200.0), dfdb_mod.ALL]
+    ca, cx = vv[dfdb_mod.ALL, "a"], vv[dfdb_mod.ALL, "x"]
+    assert ca.sum() == int(a_all[sel].sum()) and ca.min() == int(a_all[sel].min()) and ca.max() == int(a_all[sel].max())
+    tol = sel.sum() * np.finfo(np.float64).eps * float(np.abs(x_all[sel]).sum())
+    assert abs(cx.sum() - float(x_all[sel].sum())) <= tol and abs(cx.mean() - float(x_all[sel].mean())) <= tol
+    assert cx.min() == float(x_all[sel].min()) and cx.max() == float(x_all[sel].max())
+    none = p.d[p.d.a > 10_000_000, dfdb_mod.ALL][dfdb_mod.ALL, "x"]
+    assert none.sum() == 0.0 and np.isnan(none.mean())
+    with pytest.raises(ValueError):
+        none.min()
     mem = dfdb_mod.DFTable.from_columns({"a": np.arange(10, dtype=np.int64)})
     with pytest.raises(ValueError):                                           # an in-memory table has no files to stream
         dfdb_mod.stream(mem[dfdb_mod.ALL, dfdb_mod.ALL])
