@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgc
 // that re-reads ~81 % of the column's 128-B lines at 10 % selectivity (late materialization: the scan already holds the values)
 template <typename T, int OP, bool AND_EXISTING, bool NT, bool CAP>
 __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
-                                                     uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles, T* __restrict__ cap) {
+                                                     uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles, T* __restrict__ cap, int wt_store) {
   __shared__ T cap_sh[CAP ? kWavesPerBlock : 1][CAP ? kTile : 1];   // CAP: the tile's selected values, staged so they leave as full 512-B stores
   T* stage = cap_sh[CAP ? (threadIdx.x >> 6) : 0];
   const int lane = lane_id();
@@ -97,10 +97,18 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
     }
     if (AND_EXISTING) myword &= existing;
     const uint32_t cnt = tile_popcount(myword, lane);
-    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = myword;   // one 128-B line
+    if (lane < kWordsPerTile) {                                                // one 128-B line
+      // wt_store: write-through (system-scope) store — the bitmap is 1.5 % of the kernel's traffic but its write-backs out of L2,
+      // interleaved with the read stream, cost 7-19 % of the pure read time; pushed straight through they cost 2-3 % less
+      if (wt_store) __hip_atomic_store(&bitmap[tile * kWordsPerTile + lane], myword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else bitmap[tile * kWordsPerTile + lane] = myword;
+    }
     if (lane == 0) tile_counts[tile] = cnt;
   }
 }
+
+static int g_scan_wt_store = 1;
+void set_scan_wt_store(int v) { g_scan_wt_store = v; }
 
 template <typename T, int OP>
 static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing, bool nt, void* cap) {
@@ -109,11 +117,11 @@ static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_
   if (ntiles == 0) return;
   const int grid = grid_for_tiles(ntiles);
   if constexpr (sizeof(T) == 8) {
-    if (cap && !and_existing) { hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)cap); return; }
+    if (cap && !and_existing) { hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)cap, g_scan_wt_store); return; }
   }
-  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr);
-  else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr);
-  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr);
+  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
+  else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
+  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
 }
 template <typename T>
 static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae, bool nt, void* cap) {
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       }
     }
     const uint32_t cnt = tile_popcount(acc, lane);
-    if (lane < kWordsPerTile) bitmap[tile * kWordsPerTile + lane] = acc;
+    if (lane < kWordsPerTile) __hip_atomic_store(&bitmap[tile * kWordsPerTile + lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, see k_scan_cmp
     if (lane == 0) tile_counts[tile] = cnt;
   }
 }

@@ -24,6 +24,7 @@ struct ScanTerms {
 };
 
 // ---- K1: predicate scan -> bitmap (+ per-1024-row tile counts) ----------------------------------
+void set_scan_wt_store(int v);   // 1 (default): K1 writes its bitmap with write-through stores
 // single column `x OP c`; and_existing: bitmap &= result (a predicate stage after a range stage)
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap,
                      uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr);

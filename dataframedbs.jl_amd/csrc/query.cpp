@@ -195,6 +195,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     const int ex = bi + 1 == term_batches.size() ? extra : 0;
     if (tb.n == 1 && ex != 2) {
       LaunchTimer lt(ctx, "scan_cmp");
+      set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
                       ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr);
     } else {

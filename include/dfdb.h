@@ -107,6 +107,7 @@ int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx);
 int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
 /* tuning knobs (defaults are what the benchmarks use; the others keep measured alternatives selectable for A/B runs):
  *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
+ *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
  *   "fused"           1 = one-pass scan + look-back + compaction kernel instead of K1 + count scan + K2 (default 0)
  *   "pipeline"        1 = dfdb_select_indices_device in 4 pieces, compaction on a side stream (default 0)
  *   "lz4_variant"     LZ4 block decoder: 0 v1 .. 3 v4, 4 = v5 superbatch decoder (default 4)

@@ -95,6 +95,19 @@ def main():
     ctx.profile(False)
     ctx.set_option("scan_nt", 1)
     print(json.dumps({"config": "2-nt-ab", "scan_cmp_ms_default": sorted(ab[0]), "scan_cmp_ms_nt": sorted(ab[1])}))
+    ab = {0: [], 1: []}
+    ctx.profile(True)
+    for r in range(6):
+        for wt in (0, 1):
+            ctx.set_option("scan_wt_store", wt)
+            n0, ms0 = ctx.profile_get("scan_cmp")
+            q.execute()
+            n1, ms1 = ctx.profile_get("scan_cmp")
+            if r:
+                ab[wt].append(ms1 - ms0)
+    ctx.profile(False)
+    ctx.set_option("scan_wt_store", 1)
+    print(json.dumps({"config": "2-wt-store-ab", "scan_cmp_ms_plain_store": sorted(ab[0]), "scan_cmp_ms_wt_store": sorted(ab[1])}))
     # materialize(t[x > c, :]) with the values on the device: gather vs capture-in-scan (dfdb_query_hint_materialize)
     import ctypes as C
     from dfdb import _native as N
