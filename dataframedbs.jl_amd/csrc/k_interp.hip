@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
       }
     }
     if (MODE == 0) {
-      if (lane < 16) bitmap[tile * 16 + lane] = (uint64_t)myword_hi << 32 | myword_lo;
+      if (lane < 16) __hip_atomic_store(&bitmap[tile * 16 + lane], (uint64_t)myword_hi << 32 | myword_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through: see k_scan_cmp
       if (lane == 0) tile_counts[tile] = tile_cnt;
     }
   }

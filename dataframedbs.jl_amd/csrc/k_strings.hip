@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
     uint32_t cnt = lane < 16 ? (uint32_t)__popcll(myword) : 0u;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-    if (lane < 16) bitmap[tile * 16 + lane] = myword;
+    if (lane < 16) __hip_atomic_store(&bitmap[tile * 16 + lane], myword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through: see k_scan_cmp
     if (lane == 0) tile_counts[tile] = cnt;
   }
 }
