@@ -193,5 +193,15 @@ int main(int argc, char** argv) {
     printf("column %2d: scan %.4f  scan4 %.4f  scan4 nt-store %.4f  2KB bursts %.4f  sys-scope store %.4f  2KB nt %.4f  no writes %.4f  read %.4f ms\n", i, time_one(col), time_scan4(col, 3), time_k(col, 0), time_k(col, 1), time_k(col, 2), time_k(col, 3), time_scan4(col, 0), time_read(col));
   }
   for (int i = 0; i < ncols; i++) printf("again  %2d: %.4f ms\n", i, time_one(cols[i]));
+  // the other way round: the same columns against eight differently placed bitmap buffers
+  uint64_t* bm0 = bm;
+  for (int b = 0; b < 8; b++) {
+    uint64_t* nb; CK(hipMalloc(&nb, ntiles * 128 + 4096 + (size_t)b * (5u << 20)));
+    bm = nb;
+    printf("bitmap buffer %d at %p:", b, (void*)nb);
+    for (int i = 0; i < ncols && i < 4; i++) printf("  col %d %.4f", i, time_one(cols[i]));
+    printf("\n");
+  }
+  bm = bm0;
   return 0;
 }
