@@ -181,8 +181,9 @@ __device__ __forceinline__ bool cmp_sel(T x, T c, uint32_t sel) {
   const bool lt = x < c, eq = x == c, gt = x > c;
   return ((sel & 1u) && lt) || ((sel & 2u) && eq) || ((sel & 4u) && gt) || ((sel & 8u) && !(lt || eq || gt));
 }
+// the 16 bitmap words of one tile for one term; word j lands in lane l0 + j (l0 = 16 x the tile's place in its group of four)
 template <typename T, bool NT = true>
-__device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane) {
+__device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, int l0 = 0) {
   const T* p = (const T*)colv + base + lane;
   const T c = from_bits<T>(cbits);
   uint64_t myword = 0;
@@ -191,13 +192,13 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
 #pragma unroll
     for (int j = 0; j < kWordsPerTile; j++) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
 #pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == j) myword = m; }
+    for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == l0 + j) myword = m; }
   } else {
 #pragma unroll
     for (int j = 0; j < kWordsPerTile; j++) {
       bool r = false;
       if (base + j * 64 + lane < nrows) r = cmp_sel<T>(p[j * 64], c, sel);
-      uint64_t m = __ballot(r); if (lane == j) myword = m;
+      uint64_t m = __ballot(r); if (lane == l0 + j) myword = m;
     }
   }
   return myword;
@@ -210,7 +211,7 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
 // loaded values in 32 VGPRs until the mask was complete: +0.75 ms on the two-term scan of 1e9 rows).
 template <typename T, int EXTRA>
 __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, uint64_t before,
-                                                   uint64_t* stage, uint32_t& run, T& lsum) {
+                                                   uint64_t* stage, uint32_t& run, T& lsum, int l0) {
   const T* p = (const T*)colv + base + lane;
   const T c = from_bits<T>(cbits);
   uint64_t myword = 0;
@@ -224,10 +225,10 @@ __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cb
 #pragma unroll
   for (int j = 0; j < kWordsPerTile; j++) {
     const bool inb = full || base + j * 64 + lane < nrows;
-    const uint64_t bj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)before, j) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(before >> 32), j) << 32;   // word j of the mask so far
+    const uint64_t bj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)before, l0 + j) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(before >> 32), l0 + j) << 32;   // word j of the tile's mask so far
     const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel)) & bj;
-    if (lane == j) myword = m;
+    if (lane == l0 + j) myword = m;
     const bool mine = (m >> lane) & 1ull;
     if (EXTRA == 1) { if (mine) { uint64_t bits; __builtin_memcpy(&bits, &v[j], 8); stage[run + rank_in(m)] = bits; } run += (uint32_t)__popcll(m); }
     if (EXTRA == 2) { if (mine) lsum += v[j]; }
@@ -254,13 +255,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const int nplain = EXTRA ? terms.n - 1 : terms.n;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    const int64_t base = tile * kTile;
-    uint64_t existing = ~0ull;
+  // four consecutive tiles per trip, like k_scan_cmp: lane 16k + j holds word j of tile k, one 512-byte bitmap store per group
+  const int64_t ngroups = (ntiles + 3) / 4;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    const int64_t t0 = g * 4;
+    const int nk = ntiles - t0 < 4 ? (int)(ntiles - t0) : 4;
+    uint64_t existing = ~0ull, live = ~0ull;
     if (AND_EXISTING) {
-      existing = lane < kWordsPerTile ? bitmap[tile * kWordsPerTile + lane] : 0ull;
-      if (__ballot(existing != 0) == 0) {
-        if (lane == 0) { tile_counts[tile] = 0; if (EXTRA == 2) extra_out[tile] = 0; }
+      existing = bitmap[g * 64 + lane];
+      live = __ballot(existing != 0);
+      if (live == 0) {
+        if ((lane & 15) == 0 && (lane >> 4) < nk) { tile_counts[t0 + (lane >> 4)] = 0; if (EXTRA == 2) extra_out[t0 + (lane >> 4)] = 0; }
         continue;
       }
     }
@@ -268,18 +273,23 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
     for (int t = 0; t < nplain; t++) {
       const ScanTerm& tm = terms.t[t];
       const uint32_t sel = op_sel(tm.op);
-      uint64_t w;
-      switch (tm.dtype) {   // wave-uniform
-        case DFDB_I8:  w = term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_I16: w = term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_I32: w = term_word<int32_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_I64: w = term_word<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_U8: case DFDB_BOOL: w = term_word<uint8_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_U16: w = term_word<uint16_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_U32: w = term_word<uint32_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_U64: w = term_word<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        case DFDB_F32: w = term_word<float>(tm.col, tm.cbits, sel, base, nrows, lane); break;
-        default:       w = term_word<double>(tm.col, tm.cbits, sel, base, nrows, lane); break;
+      uint64_t w = 0;
+      for (int k = 0; k < nk; k++) {
+        if (AND_EXISTING && ((live >> (16 * k)) & 0xffffull) == 0) continue;   // late materialization, tile by tile
+        const int64_t base = (t0 + k) * kTile;
+        const int l0 = 16 * k;
+        switch (tm.dtype) {   // wave-uniform
+          case DFDB_I8:  w |= term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_I16: w |= term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_I32: w |= term_word<int32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_I64: w |= term_word<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_U8: case DFDB_BOOL: w |= term_word<uint8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_U16: w |= term_word<uint16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_U32: w |= term_word<uint32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_U64: w |= term_word<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_F32: w |= term_word<float>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          default:       w |= term_word<double>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+        }
       }
       acc = terms.combine_or ? (acc | w) : (acc & w);
     }
@@ -288,29 +298,39 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
     if (EXTRA) {     // the last term (AND only, 8-byte dtypes only: the host checks), evaluated against the mask so far
       const ScanTerm& tm = terms.t[terms.n - 1];
       const uint32_t sel = op_sel(tm.op);
-      uint32_t run = 0;
-      if (tm.dtype == DFDB_F64) {
-        double ls = 0.0;
-        acc = term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
-        if (EXTRA == 2) { ls = wave_sum_t<double>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
-      } else if (tm.dtype == DFDB_I64) {
-        int64_t ls = 0;
-        acc = term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
-        if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>((uint64_t)ls); if (lane == 0) extra_out[tile] = u; }
-      } else {
-        uint64_t ls = 0;
-        acc = term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, acc, stage, run, ls);
-        if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>(ls); if (lane == 0) extra_out[tile] = u; }
+      const uint64_t before = acc;
+      uint64_t fin = 0;
+      for (int k = 0; k < nk; k++) {
+        const int64_t tile = t0 + k, base = tile * kTile;
+        const int l0 = 16 * k;
+        if (AND_EXISTING && ((live >> l0) & 0xffffull) == 0) { if (EXTRA == 2 && lane == 0) extra_out[tile] = 0; continue; }
+        uint32_t run = 0;
+        if (tm.dtype == DFDB_F64) {
+          double ls = 0.0;
+          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          if (EXTRA == 2) { ls = wave_sum_t<double>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
+        } else if (tm.dtype == DFDB_I64) {
+          int64_t ls = 0;
+          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>((uint64_t)ls); if (lane == 0) extra_out[tile] = u; }
+        } else {
+          uint64_t ls = 0;
+          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>(ls); if (lane == 0) extra_out[tile] = u; }
+        }
+        if (EXTRA == 1) {   // staged in rank order: out as full 512-B stores
+          wave_lds_fence();
+          for (uint32_t q = lane; q < run; q += 64) extra_out[base + q] = stage[q];
+          wave_lds_fence();
+        }
       }
-      if (EXTRA == 1) {   // staged in rank order: out as full 512-B stores
-        wave_lds_fence();
-        for (uint32_t k = lane; k < run; k += 64) extra_out[base + k] = stage[k];
-        wave_lds_fence();
-      }
+      acc = fin;
     }
-    const uint32_t cnt = tile_popcount(acc, lane);
-    if (lane < kWordsPerTile) __hip_atomic_store(&bitmap[tile * kWordsPerTile + lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, see k_scan_cmp
-    if (lane == 0) tile_counts[tile] = cnt;
+    uint32_t cnt = (uint32_t)__popcll(acc);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);          // every 16-lane group adds up its own tile
+    __hip_atomic_store(&bitmap[g * 64 + lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, see k_scan_cmp
+    if ((lane & 15) == 0 && (lane >> 4) < nk) tile_counts[t0 + (lane >> 4)] = cnt;
   }
 }
 
@@ -318,7 +338,7 @@ void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, 
                        int extra, void* extra_out) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
-  const dim3 g(grid_for_tiles(ntiles)), b(kBlock);
+  const dim3 g(grid_for_tiles((ntiles + 3) / 4)), b(kBlock);
   uint64_t* eo = (uint64_t*)extra_out;
   if (extra == 1 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
