@@ -142,6 +142,76 @@ def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
     t.close()
 
 
+def test_hinted_paths_equal_the_plain_ones_at_scale(oracle, dfdb_mod, ctx):
+    """The two execution hints never change a result: at 1e8 / 2e8 rows the captured projections (numeric terms: k_scan_terms
+    EXTRA = 1, String: K5 CAP) are byte-identical to the gathered ones, the sum folded into the scan (EXTRA = 2) equals the
+    separate reduce pass exactly for Int64 and within n * eps * sum|x| for Float64."""
+    import torch
+    from dfdb import _native as N, ir
+    dev = torch.device("cuda", 0)
+
+    def seed(k):
+        return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+    lib = N.load()
+    # ---- numeric capture + fused sums
+    n = 200_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(0), n)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, seed(2), n)
+    v = t[(t.a > 683_771) & (t.x < 632.456), ["a", "x"]]
+    q = v._query()
+    outs_by_hint = {}
+    for hint in (False, True):
+        q.hint_materialize(hint)
+        q.reset()
+        nsel = q.count()
+        oa = torch.empty(nsel, dtype=torch.int64, device=dev); ox = torch.empty(nsel, dtype=torch.float64, device=dev)
+        outs = (N.OutCol * 2)(_dev_outcol(N, oa), _dev_outcol(N, ox))
+        N.check(lib.dfdb_materialize(q._h, outs, 2))
+        torch.cuda.synchronize()
+        outs_by_hint[hint] = (oa, ox)
+    assert torch.equal(outs_by_hint[False][0], outs_by_hint[True][0])
+    assert torch.equal(outs_by_hint[False][1].view(torch.int64), outs_by_hint[True][1].view(torch.int64))
+    q.hint_materialize(False)
+    sums = {}
+    for hint in (0, N.AGG_SUM):
+        for col in (0, 1):
+            q.reset()
+            N.check(lib.dfdb_query_hint_aggregate(q._h, hint, col))
+            oi, of = C.c_int64(), C.c_double()
+            N.check(lib.dfdb_aggregate(q._h, N.AGG_SUM, col, C.byref(oi), C.byref(of)))
+            sums[(hint, col)] = (oi.value, of.value)
+    assert sums[(0, 0)][0] == sums[(N.AGG_SUM, 0)][0] == int(outs_by_hint[True][0].sum().item())
+    xs = outs_by_hint[True][1]
+    tol = xs.numel() * np.finfo(np.float64).eps * float(xs.abs().sum().item())
+    assert abs(sums[(0, 1)][1] - sums[(N.AGG_SUM, 1)][1]) <= tol and abs(sums[(N.AGG_SUM, 1)][1] - float(xs.sum().item())) <= tol
+    del outs_by_hint, xs
+    t.close()
+    # ---- String capture: variable-length survivors (startswith "s": sony, samsung) and a 90 % selection (!= "sony")
+    n = 100_000_000
+    t = dfdb_mod.DFTable.new()
+    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, seed(0), n)
+    for v in (t[dfdb_mod.startswith(t.s, "s"), dfdb_mod.ALL], t[t.s != "sony", dfdb_mod.ALL]):
+        q = v._query()
+        got = {}
+        for hint in (False, True):
+            q.hint_materialize(hint)
+            q.reset()
+            nsel = q.count()
+            nb = C.c_int64()
+            N.check(lib.dfdb_result_string_bytes(q._h, 0, C.byref(nb)))
+            osz = torch.empty(nsel, dtype=torch.int32, device=dev)
+            oby = torch.zeros(nb.value + 64, dtype=torch.uint8, device=dev)
+            outs = (N.OutCol * 1)(_dev_outcol(N, osz, oby))
+            N.check(lib.dfdb_materialize(q._h, outs, 1))
+            torch.cuda.synchronize()
+            got[hint] = (nsel, nb.value, osz, oby)
+        assert got[False][0] == got[True][0] and got[False][1] == got[True][1] and got[True][1] == int(got[True][2].sum().item())
+        assert torch.equal(got[False][2], got[True][2]) and torch.equal(got[False][3][:got[True][1]], got[True][3][:got[True][1]])
+        del got
+    t.close()
+
+
 def test_interpreter_large_properties(oracle, dfdb_mod, ctx):
     """A predicate and a computed column that only the device interpreter can run, at 2e8 rows: torch evaluates the same
     Int64 / Float64 arithmetic on the device as a third opinion, the oracle checks sampled blocks bit for bit."""
