@@ -155,8 +155,6 @@ __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restric
           h = (v * 2654435761u) >> (32 - kHashBits);
           cand = ht[h];
         }
-        wave_lds_fence();
-        if (inr) ht[h] = p;                       // after every lane has read: several lanes may share h, any of them may win
         bool ok = inr && cand != kNoPos && cand < p && p - cand <= 65535u;
         uint32_t ml = 0; bool capped = false;
         if (ok) ok = ld_u32_unaligned(in + cand) == v;
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restric
           if (ml >= lim) { ml = lim; capped = false; }
         }
         const uint64_t M = __ballot(ok);
-        if (M == 0) { ip += 64; continue; }
+        if (M == 0) { wave_lds_fence(); if (inr) ht[h] = p; ip += 64; continue; }   // (after every lane has read; several lanes may share h, any of them may win)
         const uint64_t sh = M >> lane;
         const uint32_t NH = sh ? lane + (uint32_t)__builtin_ctzll(sh) : 64u;
         const uint32_t E = lane + ml;                                    // hit lanes: the window-relative end of the match
@@ -205,6 +203,10 @@ __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restric
         const uint32_t myE = sel ? lane + myml : 0u;
         const uint32_t cm = wave_incl_scan_max<uint32_t>(myE, lane);     // the furthest end of a selected match that starts at or before this lane
         uint32_t pe = (uint32_t)__shfl_up((int)cm, 1, 64); if (lane == 0) pe = 0;   // ... that starts before this lane
+        // remember the positions a sequential compressor would have looked at — literals and match starts, not the inside of a match:
+        // inserting all 64 wears the 4096-entry table out 2.5 times faster and costs 4 % of the ratio
+        wave_lds_fence();
+        if (inr && (sel || cm <= lane)) ht[h] = p;
         const uint32_t pend = ip - anchor;                               // literals left over from the windows before
         const uint32_t first = (uint32_t)__builtin_ctzll(SEL);
         const uint32_t lit = sel ? (pe ? lane - pe : lane + pend) : 0u;  // (no match ends at 0: pe == 0 means "the first sequence")
