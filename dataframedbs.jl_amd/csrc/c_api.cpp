@@ -336,4 +336,15 @@ int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out) {
   return rc;
 }
 void ctx_destroy(dfdb_ctx* c) { (void)dfdb_ctx_destroy(c); }
+namespace dfdb {
+void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes) {
+  if (ctx->pin_ring_cap >= bytes) return;
+  for (int i = 0; i < 2; i++) {
+    if (ctx->pin_ring[i]) { (void)hipHostFree(ctx->pin_ring[i]); ctx->pin_ring[i] = nullptr; }
+    HIP_CHECK(hipHostMalloc((void**)&ctx->pin_ring[i], bytes, hipHostMallocDefault));
+    if (!ctx->pin_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+  }
+  ctx->pin_ring_cap = bytes;
+}
+}  // namespace dfdb
 }  // namespace dfdb

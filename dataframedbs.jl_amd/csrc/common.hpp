@@ -118,4 +118,6 @@ void stream_wait(dfdb_ctx* ctx);
 // runtime tuning knobs (dfdb_ctx_set_option)
 int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt);
 void profile_resolve(dfdb_ctx* ctx);   // fold the pending event pairs into ctx->prof
+// the context's two pinned bounce buffers (file <-> HBM pipelines of dfdb_table_load / dfdb_table_save), at least `bytes` each
+void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes);
 }  // namespace dfdb

@@ -364,14 +364,7 @@ static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_
   }
   const bool walk = block_last < 0;
   constexpr int64_t kPiece = 64ll << 20;
-  if (ctx->pin_ring_cap < (size_t)kPiece) {
-    for (int i = 0; i < 2; i++) {
-      if (ctx->pin_ring[i]) { (void)hipHostFree(ctx->pin_ring[i]); ctx->pin_ring[i] = nullptr; }
-      HIP_CHECK(hipHostMalloc((void**)&ctx->pin_ring[i], (size_t)kPiece, hipHostMallocDefault));
-      if (!ctx->pin_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
-    }
-    ctx->pin_ring_cap = (size_t)kPiece;
-  }
+  ensure_pin_ring(ctx, (size_t)kPiece);
   DevBuf& staged = t->ld_staged;
   staged.ensure((size_t)(hi - lo) + 64);
   uint8_t tail[20]; int64_t tail_end = -1;                                     // the last 20 bytes of the previous piece (a header may straddle)

@@ -177,14 +177,7 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
     HIP_CHECK(hipMemcpyAsync(d_rows, brow.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
     launch_pack_file_image(s, comp.as<uint8_t>(), dblocks.as<Lz4Block>(), dlens.as<int32_t>(), d_pos, d_rows, (int32_t)n, image.as<uint8_t>());
     constexpr int64_t kPiece = 64ll << 20;
-    if (ctx->pin_ring_cap < (size_t)kPiece) {
-      for (int i = 0; i < 2; i++) {
-        if (ctx->pin_ring[i]) { (void)hipHostFree(ctx->pin_ring[i]); ctx->pin_ring[i] = nullptr; }
-        HIP_CHECK(hipHostMalloc((void**)&ctx->pin_ring[i], (size_t)kPiece, hipHostMallocDefault));
-        if (!ctx->pin_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
-      }
-      ctx->pin_ring_cap = (size_t)kPiece;
-    }
+    ensure_pin_ring(ctx, (size_t)kPiece);
     const int64_t npieces = ceil_div(fo, kPiece);
     auto start_copy = [&](int64_t k) {
       const int64_t a = k * kPiece, e = std::min(fo, a + kPiece);

@@ -1,5 +1,6 @@
 """GPU parity: the HIP engine (through the C ABI / Python mirror) against the CPU oracle on the same
 seeded inputs.  Integer, byte and index results must be bit-exact."""
+import os
 import shutil
 
 import numpy as np
@@ -302,7 +303,8 @@ def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, va
     ctx.set_option("lz4_variant", variant)
     try:
         outcomes = {"error": 0, "decoded": 0}
-        for trial in range(24):
+        ntrials = int(os.environ.get("DFDB_FUZZ_TRIALS", "24"))          # (a soak run: DFDB_FUZZ_TRIALS=400)
+        for trial in range(ntrials):
             bad = tmp_path / f"bad{trial}"
             shutil.copytree(good, bad)
             fn = bad / ("1.bin" if trial % 2 == 0 else "2.bin")
@@ -345,7 +347,7 @@ def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, va
             got = dfdb_mod.materialize(t)
             assert np.array_equal(np.asarray(got["a"]), cols["a"]) and np.array_equal(np.asarray(got["s"]), cols["s"])
             t.close()
-        assert outcomes["error"] >= 8                       # most of these damages cannot decode
+        assert outcomes["error"] >= ntrials // 3            # most of these damages cannot decode
     finally:
         ctx.set_option("lz4_variant", 4)
 
