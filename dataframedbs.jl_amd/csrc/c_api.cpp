@@ -336,7 +336,6 @@ int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out) {
   return rc;
 }
 void ctx_destroy(dfdb_ctx* c) { (void)dfdb_ctx_destroy(c); }
-namespace dfdb {
 void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes) {
   if (ctx->pin_ring_cap >= bytes) return;
   for (int i = 0; i < 2; i++) {
@@ -346,5 +345,4 @@ void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes) {
   }
   ctx->pin_ring_cap = bytes;
 }
-}  // namespace dfdb
 }  // namespace dfdb
