@@ -698,6 +698,16 @@ __global__ __launch_bounds__(kBlock) void k_unpack_nullable(const uint8_t* __res
   const int64_t nbytes = rows * width;
   uint8_t* vdst = values + r0 * width;
   for (int64_t k = threadIdx.x; k < nbytes; k += kBlock) vdst[k] = vals[k];
+  if ((r0 & 63) == 0) {     // the usual case (block_size a multiple of 64): the block's chunks ARE the column's bitmap words
+    uint64_t* mw = missing_bits + (r0 >> 6);
+    for (int64_t k = threadIdx.x; k < nchunks; k += kBlock) {
+      uint64_t w = chunks[k];
+      const int64_t left = rows - k * 64;
+      if (left < 64) w &= (1ull << left) - 1ull;                  // bits past the block's last row are not rows
+      if (w) atomicOr((unsigned long long*)&mw[k], w);           // (the next block may share the last word when rows % 64 != 0)
+    }
+    return;
+  }
   for (int64_t i = threadIdx.x; i < rows; i += kBlock) {
     if ((chunks[i >> 6] >> (i & 63)) & 1ull) {
       const int64_t g = r0 + i;
