@@ -80,7 +80,7 @@ struct dfdb_query {
   // reduces the partials
   int hint_agg_op = 0, hint_agg_proj = -1;
   int agg_col = -1;            // table ordinal whose per-tile sums agg_partials holds (-1: none)
-  int agg_dtype = 0;
+  int agg_dtype = 0, agg_op = 0;
   dfdb::DevBuf agg_partials, agg_ones;
   int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;

@@ -204,6 +204,28 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
   return myword;
 }
 
+// EXTRA = 2 / 3 / 4: sum / min / max of the finally selected values (Julia: Int sums wrap, min / max of Float64 propagate NaN)
+template <typename T, int EXTRA> __device__ __forceinline__ T agg_identity() {
+  if (EXTRA == 3) return std::is_same<T, double>::value ? (T)__builtin_inf() : (std::is_same<T, int64_t>::value ? (T)INT64_MAX : (T)~0ull);
+  if (EXTRA == 4) return std::is_same<T, double>::value ? (T)-__builtin_inf() : (std::is_same<T, int64_t>::value ? (T)INT64_MIN : (T)0);
+  return (T)0;
+}
+template <typename T, int EXTRA> __device__ __forceinline__ T agg_combine(T a, T b) {
+  if (EXTRA == 2) return a + b;
+  if (std::is_same<T, double>::value) { if (a != a) return a; if (b != b) return b; }
+  if (EXTRA == 3) return b < a ? b : a;
+  return b > a ? b : a;
+}
+template <typename T, int EXTRA> __device__ __forceinline__ T wave_agg(T v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const T t = __shfl_xor(v, d, 64); v = agg_combine<T, EXTRA>(v, t); }
+  return v;
+}
+template <int EXTRA> __device__ __forceinline__ uint64_t agg_identity_bits(int dtype) {
+  if (dtype == DFDB_F64) { const double d = agg_identity<double, EXTRA>(); uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
+  if (dtype == DFDB_I64) return (uint64_t)agg_identity<int64_t, EXTRA>();
+  return agg_identity<uint64_t, EXTRA>();
+}
 // The LAST term of an AND of terms can do more than compare: when it is evaluated the mask of everything before it (the other
 // terms, the earlier stages) is known, so the tile's final mask falls out word by word while the term's values are still in
 // registers.  EXTRA = 1 (capture, see k_scan_cmp CAP): the values of the finally selected rows go to an LDS staging tile in rank
@@ -231,7 +253,7 @@ __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cb
     if (lane == l0 + j) myword = m;
     const bool mine = (m >> lane) & 1ull;
     if (EXTRA == 1) { if (mine) { uint64_t bits; __builtin_memcpy(&bits, &v[j], 8); stage[run + rank_in(m)] = bits; } run += (uint32_t)__popcll(m); }
-    if (EXTRA == 2) { if (mine) lsum += v[j]; }
+    if (EXTRA >= 2) { if (mine) lsum = agg_combine<T, EXTRA>(lsum, v[j]); }
   }
   return myword;
 }
@@ -245,7 +267,8 @@ template <> __device__ __forceinline__ double wave_sum_t<double>(double v) {
 template <> __device__ __forceinline__ uint64_t wave_sum_t<uint64_t>(uint64_t v) { return wave_sum64(v); }
 
 // EXTRA: 0 plain; 1 capture the values of the LAST term's 8-byte column at the finally selected rows -> extra_out[tile*1024 + rank];
-// 2 sum them -> one partial per tile in extra_out (Float64 column: doubles; Int64 / UInt64 column: wrapping 64-bit sums, as Julia's)
+// 2 / 3 / 4 sum / min / max of them -> one partial per tile in extra_out (Float64 column: doubles; Int64 / UInt64 column: wrapping
+// 64-bit sums, as Julia's; an empty tile holds the identity)
 template <bool AND_EXISTING, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
                                                        int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out) {
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       existing = bitmap[g * 64 + lane];
       live = __ballot(existing != 0);
       if (live == 0) {
-        if ((lane & 15) == 0 && (lane >> 4) < nk) { tile_counts[t0 + (lane >> 4)] = 0; if (EXTRA == 2) extra_out[t0 + (lane >> 4)] = 0; }
+        if ((lane & 15) == 0 && (lane >> 4) < nk) { tile_counts[t0 + (lane >> 4)] = 0; if (EXTRA >= 2) extra_out[t0 + (lane >> 4)] = agg_identity_bits<EXTRA>(terms.t[terms.n - 1].dtype); }
         continue;
       }
     }
@@ -303,20 +326,20 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       for (int k = 0; k < nk; k++) {
         const int64_t tile = t0 + k, base = tile * kTile;
         const int l0 = 16 * k;
-        if (AND_EXISTING && ((live >> l0) & 0xffffull) == 0) { if (EXTRA == 2 && lane == 0) extra_out[tile] = 0; continue; }
+        if (AND_EXISTING && ((live >> l0) & 0xffffull) == 0) { if (EXTRA >= 2 && lane == 0) extra_out[tile] = agg_identity_bits<EXTRA>(tm.dtype); continue; }
         uint32_t run = 0;
         if (tm.dtype == DFDB_F64) {
-          double ls = 0.0;
+          double ls = agg_identity<double, EXTRA>();
           fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
-          if (EXTRA == 2) { ls = wave_sum_t<double>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
+          if (EXTRA >= 2) { ls = wave_agg<double, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
         } else if (tm.dtype == DFDB_I64) {
-          int64_t ls = 0;
+          int64_t ls = agg_identity<int64_t, EXTRA>();
           fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
-          if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>((uint64_t)ls); if (lane == 0) extra_out[tile] = u; }
+          if (EXTRA >= 2) { ls = wave_agg<int64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = (uint64_t)ls; }
         } else {
-          uint64_t ls = 0;
+          uint64_t ls = agg_identity<uint64_t, EXTRA>();
           fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
-          if (EXTRA == 2) { const uint64_t u = wave_sum_t<uint64_t>(ls); if (lane == 0) extra_out[tile] = u; }
+          if (EXTRA >= 2) { ls = wave_agg<uint64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = ls; }
         }
         if (EXTRA == 1) {   // staged in rank order: out as full 512-B stores
           wave_lds_fence();
@@ -344,6 +367,10 @@ void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, 
   else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (extra == 2 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (extra == 2) hipLaunchKernelGGL((k_scan_terms<true, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 3 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 3) hipLaunchKernelGGL((k_scan_terms<true, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 4 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
+  else if (extra == 4) hipLaunchKernelGGL((k_scan_terms<true, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (and_existing) hipLaunchKernelGGL((k_scan_terms<true, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
   else hipLaunchKernelGGL((k_scan_terms<false, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
 }

@@ -167,12 +167,15 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   if (!term_batches.empty() && !term_batches.back().combine_or) {
     ScanTerms& lb = term_batches.back();
     const size_t ord0 = term_ords.size() - (size_t)lb.n;           // term_ords of the last batch start here
-    if (q->hint_agg_op == DFDB_AGG_SUM && last_stage && q->hint_agg_proj >= 0 && (size_t)q->hint_agg_proj < q->proj.size()) {
+    if ((q->hint_agg_op == DFDB_AGG_SUM || q->hint_agg_op == DFDB_AGG_MIN || q->hint_agg_op == DFDB_AGG_MAX) && last_stage && q->hint_agg_proj >= 0 &&
+        (size_t)q->hint_agg_proj < q->proj.size()) {
       const Node& pe = *q->proj[(size_t)q->hint_agg_proj].expr;
       if (pe.op == DFIR_COL && !dt_nullable(pe.dtype))
         for (int k = 0; k < lb.n && special < 0; k++) {
           const int dt = lb.t[k].dtype;
-          if (term_ords[ord0 + (size_t)k] == pe.col && (dt == DFDB_I64 || dt == DFDB_U64 || dt == DFDB_F64)) { special = k; extra = 2; }
+          if (term_ords[ord0 + (size_t)k] == pe.col && (dt == DFDB_I64 || dt == DFDB_U64 || dt == DFDB_F64)) {
+            special = k; extra = q->hint_agg_op == DFDB_AGG_SUM ? 2 : (q->hint_agg_op == DFDB_AGG_MIN ? 3 : 4);
+          }
         }
     }
     if (!extra && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1) {
@@ -193,19 +196,19 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   for (size_t bi = 0; bi < term_batches.size(); bi++) {
     const ScanTerms& tb = term_batches[bi];
     const int ex = bi + 1 == term_batches.size() ? extra : 0;
-    if (tb.n == 1 && ex != 2) {
+    if (tb.n == 1 && ex < 2) {
       LaunchTimer lt(ctx, "scan_cmp");
       set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
                       ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr);
     } else {
       LaunchTimer lt(ctx, "scan_terms");
-      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex == 2 ? q->agg_partials.p : nullptr);
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr);
     }
     have = true;
   }
   if (extra == 1) q->cap_col = term_ords.back();
-  if (extra == 2) { q->agg_col = term_ords.back(); q->agg_dtype = term_batches.back().t[term_batches.back().n - 1].dtype; }
+  if (extra >= 2) { q->agg_col = term_ords.back(); q->agg_dtype = term_batches.back().t[term_batches.back().n - 1].dtype; q->agg_op = q->hint_agg_op; }
 }
 
 static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
@@ -592,8 +595,9 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
   const void* src; DevBuf full; int dt = dt_base(e.dtype);
   const uint64_t* mask = q->bitmap.as<uint64_t>();
   DevBuf ones;
-  if (op == DFDB_AGG_SUM && e.op == DFIR_COL && q->agg_col == e.col && q->executed_stages == (int)q->stages.size()) {
-    // the scan already added up the selected values of this column per tile (k_scan_terms EXTRA = 2): reduce the partials
+  if (op == q->agg_op && e.op == DFIR_COL && q->agg_col == e.col && q->executed_stages == (int)q->stages.size()) {
+    // the scan already reduced the selected values of this column per tile (k_scan_terms EXTRA = 2 / 3 / 4): reduce the partials
+    if (op != DFDB_AGG_SUM && query_count(q, -1) == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
     const int64_t nt = ceil_div(t->nrows, kTileRows);
     if (q->agg_ones_tiles != nt) {
       q->agg_ones.ensure(padded_words(nt) * 8);

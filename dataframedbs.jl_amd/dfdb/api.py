@@ -746,8 +746,8 @@ class _Query:
 
     def aggregate(self, op: int, col: int = 0):
         oi, of = C.c_int64(), C.c_double()
-        if op == N.AGG_SUM:
-            self.hint_aggregate(op, col)      # a first execution below lets the scan add the column up while it holds it
+        if op in (N.AGG_SUM, N.AGG_MIN, N.AGG_MAX):
+            self.hint_aggregate(op, col)      # a first execution below lets the scan reduce the column while it holds it
         N.check(N.load().dfdb_aggregate(self._h, op, col, C.byref(oi), C.byref(of)))
         dt = self.coltype(col) & ir.DTYPE_MASK if op != N.AGG_COUNT else ir.I64
         return of.value if dt in (ir.F32, ir.F64) else oi.value
@@ -1006,8 +1006,7 @@ class DFColumn:
         every chunk is reduced on the device and the per-chunk results are combined here, block order = the reference's order."""
         if not _out_of_core(self.view):
             q = self.view._query()
-            if op == N.AGG_SUM:
-                q.hint_aggregate(op)                       # before anything executes the selection
+            q.hint_aggregate(op)                           # before anything executes the selection
             r = q.aggregate(op)
             return (r, q.count()) if with_count else r
         isint = (self.eltype & ir.DTYPE_MASK) not in (ir.F32, ir.F64)

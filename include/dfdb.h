@@ -218,9 +218,10 @@ int32_t dfdb_query_execute(dfdb_query* q);
  * the selected rows' sizes and bytes.  Results are identical; while the hint is on the query holds an extra nrows*8-byte buffer
  * (numeric capture) or nrows*4 bytes + a copy-sized byte arena (String capture). */
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on);
-/* sum(col) / mean(col) over a filtered view (Base.iterate(::DFColumn), src/tables/column.jl:102-126; docs/src/index.md:503-509) evaluates
- * the selection and then adds up the column.  Telling the engine BEFORE the first execution that dfdb_aggregate(q, DFDB_AGG_SUM, proj_col)
- * will follow lets the scan that produces the final mask add up the selected values of that column while it holds them (the column must
+/* sum(col) / mean(col) / minimum / maximum over a filtered view (Base.iterate(::DFColumn), src/tables/column.jl:102-126;
+ * docs/src/index.md:503-509) evaluate the selection and then reduce the column.  Telling the engine BEFORE the first execution that
+ * dfdb_aggregate(q, op, proj_col) will follow (op = DFDB_AGG_SUM / _MIN / _MAX) lets the scan that produces the final mask reduce the
+ * selected values of that column while it holds them (the column must
  * be a simple `col OP const` term of the last predicate stage, Int64 / UInt64 / Float64); dfdb_aggregate then only reduces one partial
  * per 1024-row tile.  op = 0 clears the hint.  Results: Int sums identical (wrapping), Float64 within the stated tolerance. */
 int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col);

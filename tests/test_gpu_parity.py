@@ -438,6 +438,15 @@ def test_sum_fused_into_the_scan(oracle, dfdb_mod, ctx, n):
         assert f and abs(r - float(x[sel].sum())) <= ftol(sel)
         r, f = fused(lambda: v[dfdb_mod.ALL, "x"].mean())
         assert f and abs(r - float(x[sel].mean())) <= ftol(sel) / max(1, sel.sum()) * 4
+        # min / max are folded the same way (EXTRA = 3 / 4); an empty selection still raises
+        r, f = fused(lambda: v[dfdb_mod.ALL, "x"].min())
+        assert f and r == float(x[sel].min())
+        r, f = fused(lambda: v[dfdb_mod.ALL, "a"].max())
+        assert f and r == int(a[sel].max())
+        r, f = fused(lambda: t[(t.a > 100_000) & (t.big > -(1 << 62)), dfdb_mod.ALL][dfdb_mod.ALL, "big"].min())
+        assert f and r == int(big[(a > 100_000) & (big > -(1 << 62))].min())
+        with pytest.raises(ValueError):
+            t[(t.a > 5_000_000) & (t.x < 1.0), dfdb_mod.ALL][dfdb_mod.ALL, "x"].max()
         assert dfdb_mod.nrow(v) == int(sel.sum())
         # a range stage first, the predicate last: still the launch that makes the final mask
         m = min(n, 100_000)
