@@ -659,7 +659,7 @@ __global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v
 // Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format), GB/s of
 // decoded output at 4096 / 15259 blocks (tools/bench_lz4): v1 26 / 30; v2 18; v3 22 / 26; v4 (v3 + batch execution of one
 // 64-byte window, 7 KB of LDS per wave) 47 / 54; v5 (superbatch of 8 windows, far sources prefetched, 7.4 KB of LDS per wave)
-// 240 / 256.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3.  None of them waits on
+// 240 / 256.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3, v5 13 + 15 + 1.3.  None of them waits on
 // memory; a single wave retires this dependent code at ~1 instruction per 8-12 cycles, so the lever is instructions per
 // sequence x resident waves.  v5 is the default; the others stay selectable (ctx option "lz4_variant" 0..4).
 static int g_lz4_variant = 4;
