@@ -120,8 +120,28 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   std::vector<const Node*> generic, strs; ScanTerms terms{}; terms.n = 0; terms.combine_or = 0;
   std::vector<ScanTerms> term_batches;
   std::vector<int> term_ords;
+  // a conjunct that is itself a disjunction of simple terms — (a > c1) | (x < c2) — is one k_scan_terms pass with combine_or
+  std::vector<ScanTerms> or_batches;
+  auto match_or = [&](const Node& n, ScanTerms& out) {
+    std::vector<const Node*> leaves, todo{&n};
+    while (!todo.empty()) {
+      const Node* x = todo.back(); todo.pop_back();
+      if (x->op == DFIR_OR && x->a && x->b) { todo.push_back(x->b.get()); todo.push_back(x->a.get()); } else leaves.push_back(x);
+    }
+    if (leaves.size() < 2 || leaves.size() > (size_t)kMaxTerms) return false;
+    out = ScanTerms{}; out.n = 0; out.combine_or = 1;
+    for (const Node* l : leaves) {
+      ScanTerm tm; int ord;
+      if (!match_simple_term(*l, *t, tm, ord)) return false;
+      tm.col = need_resident(t, ord).data.p;
+      out.t[out.n++] = tm;
+    }
+    return true;
+  };
   for (const Node* c : conj) {
     ScanTerm tm; int ord; int mode; std::string pat;
+    ScanTerms ob;
+    if (c->op == DFIR_OR && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
       if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }
@@ -158,6 +178,11 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
                      do_cap ? &capture : nullptr);
     if (do_cap) q->cap_str_col = ord;
+    have = true;
+  }
+  for (const ScanTerms& ob : or_batches) {
+    LaunchTimer lt(ctx, "scan_terms");
+    launch_scan_terms(s, ob, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, 0, nullptr);
     have = true;
   }
   // The launch that produces the query's final mask can do more with its LAST term (k_scan_terms EXTRA):

@@ -381,6 +381,35 @@ def test_string_capture_in_match_pass(oracle, dfdb_mod, ctx, n):
         ctx.profile(False)
 
 
+def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx):
+    """(a > c1) | (x < c2) | ... is one k_scan_terms pass (combine_or), alone, beside AND terms / a string term, and after a range
+    stage (ANDed with the mask so far); the interpreter is not launched for it."""
+    from dfdb import ir
+    n = 200_003
+    sizes, data = oracle.gen_str(col_seed(3), 0, n)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": oracle.flat_to_strings(sizes, data),
+            "i16": np.random.default_rng(9).integers(-300, 300, n).astype(np.int16)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=65536)
+    a, x, s, i16 = ir.col(0), ir.col(1), ir.col(2), ir.col(3)
+    ctx.profile(True)
+    try:
+        cases = [
+            [("pred", (a > 900_000) | (x < 100.0))],
+            [("pred", (a > 990_000) | (x < 10.0) | (i16 == 7) | (a <= 5))],
+            [("pred", ((a > 900_000) | (x < 100.0)) & (i16 > 0) & (s == "sony"))],
+            [("range", 1000, 1, 150_000), ("pred", (a < 100_000) | (i16 >= 299.5))],
+            [("pred", ((a > 500_000) | (x < 1000.0)) & ((i16 < 0) | (a == 123_456)))],
+        ]
+        for stages in cases:
+            n0, _ = ctx.profile_get("interp_predicate")
+            ov, dv = apply_stages(p, stages)
+            assert_same(p, ov, dv)
+            n1, _ = ctx.profile_get("interp_predicate")
+            assert n1 == n0, "a disjunction of simple terms went to the interpreter"
+    finally:
+        ctx.profile(False)
+
+
 # ------------------------------------------------------------------ aggregates
 def test_aggregates(oracle, dfdb_mod, ctx):
     from dfdb import ir
