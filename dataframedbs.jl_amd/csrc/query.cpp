@@ -128,20 +128,32 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       const Node* x = todo.back(); todo.pop_back();
       if (x->op == DFIR_OR && x->a && x->b) { todo.push_back(x->b.get()); todo.push_back(x->a.get()); } else leaves.push_back(x);
     }
-    if (leaves.size() < 2 || leaves.size() > (size_t)kMaxTerms) return false;
     out = ScanTerms{}; out.n = 0; out.combine_or = 1;
     for (const Node* l : leaves) {
+      // in.(col, Ref([v1, v2, ...])) (test/broadcast.jl:63-71) with a few values is the disjunction col == v1 | col == v2 | ...
+      if (l->op == DFIR_IN_SET && l->a && l->b && l->a->op == DFIR_COL && l->b->op == DFIR_CONST_SET && !l->b->set.empty()) {
+        for (uint64_t bits : l->b->set) {
+          Node eq; eq.op = DFIR_EQ; eq.dtype = DFDB_BOOL;
+          eq.a = l->a->clone();
+          eq.b = std::make_unique<Node>(); eq.b->op = DFIR_CONST; eq.b->dtype = l->b->set_dtype; eq.b->cbits = bits;
+          ScanTerm tm; int ord;
+          if (out.n == kMaxTerms || !match_simple_term(eq, *t, tm, ord)) return false;
+          tm.col = need_resident(t, ord).data.p;
+          out.t[out.n++] = tm;
+        }
+        continue;
+      }
       ScanTerm tm; int ord;
-      if (!match_simple_term(*l, *t, tm, ord)) return false;
+      if (out.n == kMaxTerms || !match_simple_term(*l, *t, tm, ord)) return false;
       tm.col = need_resident(t, ord).data.p;
       out.t[out.n++] = tm;
     }
-    return true;
+    return out.n >= 2;
   };
   for (const Node* c : conj) {
     ScanTerm tm; int ord; int mode; std::string pat;
     ScanTerms ob;
-    if (c->op == DFIR_OR && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
+    if ((c->op == DFIR_OR || c->op == DFIR_IN_SET) && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
       if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }

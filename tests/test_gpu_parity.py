@@ -399,6 +399,9 @@ def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx
             [("pred", ((a > 900_000) | (x < 100.0)) & (i16 > 0) & (s == "sony"))],
             [("range", 1000, 1, 150_000), ("pred", (a < 100_000) | (i16 >= 299.5))],
             [("pred", ((a > 500_000) | (x < 1000.0)) & ((i16 < 0) | (a == 123_456)))],
+            [("pred", ir.isin(i16, [1, 11, 21]))],                                       # in.(a, Ref([1,11,21])): test/broadcast.jl:63-71
+            [("pred", ir.isin(a, [5.0, 7, 123_456.5]) | (x < 1.0))],                      # Int column, Float members: exact ==
+            [("pred", ir.isin(i16, [1, 2, 3]) & (a > 100_000))],
         ]
         for stages in cases:
             n0, _ = ctx.profile_get("interp_predicate")
@@ -406,6 +409,8 @@ def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx
             assert_same(p, ov, dv)
             n1, _ = ctx.profile_get("interp_predicate")
             assert n1 == n0, "a disjunction of simple terms went to the interpreter"
+        ov, dv = apply_stages(p, [("pred", ir.isin(i16, list(range(0, 40, 3))))])   # 14 members: the interpreter's set probe
+        assert_same(p, ov, dv)
     finally:
         ctx.profile(False)
 
