@@ -239,6 +239,10 @@ static void int_vs_int(ScanTerm& term, int coldt, int op, __int128 c) {
 }
 
 bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& ordinal) {
+  if (n.op == DFIR_COL && n.dtype == DFDB_BOOL) {   // a Bool column as the selection itself (DFColumn{Bool}: view.jl:60-72): its bytes != 0
+    term.col = nullptr; term.dtype = DFDB_BOOL; term.op = CMP_NE; term.cbits = 0; ordinal = n.col;
+    return true;
+  }
   int op = cmp_from_ir(n.op);
   if (op < 0 || !n.a || !n.b) return false;
   const Node *coln = nullptr, *cn = nullptr;

@@ -388,9 +388,9 @@ def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx
     n = 200_003
     sizes, data = oracle.gen_str(col_seed(3), 0, n)
     cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": oracle.flat_to_strings(sizes, data),
-            "i16": np.random.default_rng(9).integers(-300, 300, n).astype(np.int16)}
+            "i16": np.random.default_rng(9).integers(-300, 300, n).astype(np.int16), "b": np.random.default_rng(10).integers(0, 2, n).astype(bool)}
     p = Pair(oracle, dfdb_mod, cols, block_size=65536)
-    a, x, s, i16 = ir.col(0), ir.col(1), ir.col(2), ir.col(3)
+    a, x, s, i16, b = ir.col(0), ir.col(1), ir.col(2), ir.col(3), ir.col(4)
     ctx.profile(True)
     try:
         cases = [
@@ -402,6 +402,9 @@ def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx
             [("pred", ir.isin(i16, [1, 11, 21]))],                                       # in.(a, Ref([1,11,21])): test/broadcast.jl:63-71
             [("pred", ir.isin(a, [5.0, 7, 123_456.5]) | (x < 1.0))],                      # Int column, Float members: exact ==
             [("pred", ir.isin(i16, [1, 2, 3]) & (a > 100_000))],
+            [("pred", b)],                                                               # a Bool column is a selection by itself
+            [("pred", b & (a > 500_000))],
+            [("pred", b | (x < 50.0))],
         ]
         for stages in cases:
             n0, _ = ctx.profile_get("interp_predicate")
