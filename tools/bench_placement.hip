@@ -91,6 +91,54 @@ __global__ __launch_bounds__(256) void k_scanG(const int64_t* __restrict__ col, 
     }
   }
 }
+// PHASED: the bitmap of G tiles per wave stays in LDS while the whole grid reads; then a grid-wide barrier, every wave writes its
+// G x 128 bytes, another barrier: the bitmap is never written INSIDE the read stream.  All workgroups must be resident.
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned nblocks, unsigned& epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    epoch++;
+    __threadfence();
+    atomicAdd(ctr, 1u);
+    for (int it = 0; it < (1 << 17) && atomicAdd(ctr, 0u) < epoch * nblocks; it++) __builtin_amdgcn_s_sleep(2);   // (bounded: a harness must not hang the box)
+    __threadfence();
+  }
+  __syncthreads();
+}
+template <int G>
+__global__ __launch_bounds__(256) void k_scan_phased(const int64_t* __restrict__ col, int64_t c, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ counts,
+                                                     int64_t ntiles, unsigned* ctr) {
+  __shared__ uint64_t bm_sh[4][G * 16];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wib, nwaves = (int64_t)gridDim.x * 4;
+  unsigned epoch = 0;
+  const int64_t per_phase = nwaves * G;
+  for (int64_t t0 = 0; t0 < ntiles; t0 += per_phase) {
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+      const int64_t tile = t0 + (int64_t)g * nwaves + wave;
+      if (tile < ntiles) {
+        const int64_t* p = col + tile * 1024 + lane;
+        int64_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = __builtin_nontemporal_load(p + j * 64);
+        uint64_t my = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { uint64_t m = __ballot(v[j] > c); if (lane == j) my = m; }
+        uint32_t cn = lane < 16 ? (uint32_t)__popcll(my) : 0u;
+        for (int d = 8; d >= 1; d >>= 1) cn += __shfl_xor(cn, d, 64);
+        if (lane < 16) bm_sh[wib][g * 16 + lane] = my;
+        if (lane == 0) counts[tile] = cn;
+      }
+    }
+    grid_barrier(ctr, gridDim.x, epoch);
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+      const int64_t tile = t0 + (int64_t)g * nwaves + wave;
+      if (tile < ntiles && lane < 16) bitmap[tile * 16 + lane] = bm_sh[wib][g * 16 + lane];
+    }
+    grid_barrier(ctr, gridDim.x, epoch);
+  }
+}
 __global__ __launch_bounds__(256) void k_read(const int64_t* __restrict__ col, int64_t ntiles, unsigned long long* out) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -106,6 +154,7 @@ __global__ __launch_bounds__(256) void k_read(const int64_t* __restrict__ col, i
   if (acc == 0x123456789abcull) out[0] = acc;
 }
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const int64_t n = 1000000000LL, ntiles = n / 1024;
   const int ncols = argc > 1 ? atoi(argv[1]) : 12;
   uint64_t* bm; uint32_t* cnt;
@@ -157,6 +206,28 @@ int main(int argc, char** argv) {
     std::sort(ms.begin(), ms.end());
     return ms[3];
   };
+  unsigned* gctr; CK(hipMalloc(&gctr, 64));
+  int occ16 = 0, occ32 = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, k_scan_phased<16>, 256, 0));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, k_scan_phased<32>, 256, 0));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("phased kernels: %d / %d resident workgroups per CU, %d CUs\n", occ16, occ32, prop.multiProcessorCount);
+  const int phased_grid = argc > 4 ? atoi(argv[4]) : 1024;
+  auto time_phased = [&](int64_t* col, int G) {
+    const int grid = phased_grid;
+    std::vector<float> ms;
+    for (int r = 0; r < 7; r++) {
+      CK(hipMemsetAsync(gctr, 0, 64, nullptr));
+      CK(hipEventRecord(e0, nullptr));
+      if (G == 16) hipLaunchKernelGGL((k_scan_phased<16>), dim3(grid), dim3(256), 0, 0, col, (int64_t)899999, bm, cnt, ntiles, gctr);
+      else hipLaunchKernelGGL((k_scan_phased<32>), dim3(grid), dim3(256), 0, 0, col, (int64_t)899999, bm, cnt, ntiles, gctr);
+      CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+      float t; CK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+      if (r == 0) { unsigned h = 0; CK(hipMemcpy(&h, gctr, 4, hipMemcpyDeviceToHost)); printf("[phased G=%d grid %d: counter ends at %u = %.2f x grid] ", G, grid, h, (double)h / grid); }
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[3];
+  };
   unsigned long long* sink; CK(hipMalloc(&sink, 64));
   auto time_read = [&](int64_t* col) {
     std::vector<float> ms;
@@ -190,7 +261,7 @@ int main(int argc, char** argv) {
     }
     hipLaunchKernelGGL(k_gen, dim3(8192), dim3(256), 0, 0, col, n); CK(hipDeviceSynchronize());
     cols.push_back(col);
-    printf("column %2d: scan %.4f  scan4 %.4f  scan4 nt-store %.4f  2KB bursts %.4f  sys-scope store %.4f  2KB nt %.4f  no writes %.4f  read %.4f ms\n", i, time_one(col), time_scan4(col, 3), time_k(col, 0), time_k(col, 1), time_k(col, 2), time_k(col, 3), time_scan4(col, 0), time_read(col));
+    printf("column %2d: scan %.4f  scan4 %.4f  scan4+wt %.4f  PHASED G=16 %.4f  G=32 %.4f  no writes %.4f  read %.4f ms\n", i, time_one(col), time_scan4(col, 3), time_k(col, 2), time_phased(col, 16), time_phased(col, 32), time_scan4(col, 0), time_read(col));
   }
   for (int i = 0; i < ncols; i++) printf("again  %2d: %.4f ms\n", i, time_one(cols[i]));
   // the other way round: the same columns against eight differently placed bitmap buffers
