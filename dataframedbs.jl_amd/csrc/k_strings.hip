@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
   }
 }
 
-// Short patterns (<= 8 bytes: the common case of brand / event-type equality): three phases per 8 steps so that
+// Patterns up to 64 bytes (brand / event-type equality; the first 8 bytes decide for almost every row): three phases per 8 steps so that
 // the byte probes of 8 x 64 rows are all in flight together instead of one dependent round trip per 64 rows:
 //   A  wave prefix-sums of the sizes -> per-row byte offsets       (ALU only)
 //   B  one unaligned 8-byte probe per candidate row (size matches) (8 loads in flight per lane)
@@ -158,17 +158,21 @@ __device__ __forceinline__ void store_small(uint8_t* d, uint64_t v, uint32_t len
 // CAP (dfdb_query_hint_materialize, the string column itself is projected): the pass that decides the rows also keeps them — the
 // size of every selected row at cap_sizes[tile * 1024 + rank], its bytes packed at the tile's own arena offset in cap_bytes, the
 // tile's selected byte total in sel_tile_bytes — so K6 does not read the column again: the projection is a contiguous copy per tile.
-template <bool AND_EXISTING, int MODE, bool CAP>
+// LONG: patterns of 9..64 bytes (a second probe rides along, the rest is compared where 16 bytes matched); !LONG keeps the one-probe kernel as it was
+template <bool AND_EXISTING, int MODE, bool CAP, bool LONG>
 __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
-                                                            const uint8_t* __restrict__ bytes, uint64_t patw, int plen,
-                                                            uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows,
+                                                            const uint8_t* __restrict__ bytes, uint64_t patw, uint64_t patw1, int plen,
+                                                            const uint8_t* __restrict__ pat_dev, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows,
                                                             int64_t ntiles, int32_t* __restrict__ cap_sizes, uint8_t* __restrict__ cap_bytes,
                                                             uint32_t* __restrict__ sel_tile_bytes) {
+  // patw / patw1: bytes 0..7 / 8..15 of the pattern; pat_dev: the whole pattern in device memory (read only where 16 bytes matched)
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const uint64_t mask = plen >= 8 ? ~0ull : ((1ull << (8 * plen)) - 1ull);
   const uint64_t want = patw & mask;
+  const uint64_t mask2 = plen >= 16 ? ~0ull : (plen > 8 ? ((1ull << (8 * (plen - 8))) - 1ull) : 0ull);
+  const uint64_t want2 = patw1 & mask2;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     uint64_t existing = ~0ull;
     if (AND_EXISTING) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
     uint8_t* const cb = CAP ? cap_bytes + tile_off[tile] : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      uint32_t rel[8]; uint64_t v[8]; bool cand[8];
+      uint32_t rel[8]; uint64_t v[8], v2[LONG ? 8 : 1]; bool cand[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {                                   // A
         const uint32_t c = clamp_size(sz[h * 8 + j]);
@@ -199,12 +203,22 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
         const int32_t s0 = sz[h * 8 + j];
         const int len = s0 > 0 ? s0 : 0;
         cand[j] = s0 != -2 && (MODE <= 1 ? len == plen : len >= plen);
-        v[j] = 0;
-        if (cand[j] && plen > 0) v[j] = load_u64_unaligned(tb + rel[j] + (MODE == 3 ? len - plen : 0));
+        v[j] = 0; if (LONG) v2[j] = 0;
+        if (cand[j] && plen > 0) {
+          const uint8_t* p = tb + rel[j] + (MODE == 3 ? len - plen : 0);
+          v[j] = load_u64_unaligned(p);
+          if (LONG) v2[j] = load_u64_unaligned(p + 8);                 // bytes 8..15 of the compared span ride along
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {                                   // C
-        const bool eq = cand[j] && ((v[j] & mask) == want);
+        bool eq = cand[j] && ((v[j] & mask) == want);
+        if (LONG) eq = eq && ((v2[j] & mask2) == want2);
+        if (LONG && plen > 16 && eq) {                                        // still longer: the few rows whose first 16 bytes match compare the rest
+          const int32_t s1 = sz[h * 8 + j];
+          const uint8_t* p = tb + rel[j] + (MODE == 3 ? (s1 > 0 ? s1 : 0) - plen : 0);
+          eq = bytes_equal_long(p + 16, pat_dev + 16, plen - 16);
+        }
         const bool r = MODE == 1 ? (sz[h * 8 + j] != -2 && !eq) : eq;
         const uint64_t m = __ballot(r);
         if (lane == h * 8 + j) myword = m;
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
           }
           if (r) {
             cap_sizes[base + rank] = s0;
-            if (MODE == 0) store_small(cb + bpos, v[j], len);                    // the probe already holds the whole string (<= 8 bytes)
+            if (MODE == 0 && !LONG) store_small(cb + bpos, v[j], len);       // the probe already holds the whole string (<= 8 bytes)
             else if (len) copy_string(cb + bpos, tb + rel[j], len);
           }
           cap_n += (uint32_t)__popcll(m);
@@ -240,14 +254,19 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
 }
 
 template <int MODE>
-static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, uint64_t patw, int plen,
-                         uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, const StrCapture* cap) {
-  if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
-                              cap->sizes, cap->bytes, cap->tile_bytes);
-  else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
-                                  (int32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
-  else hipLaunchKernelGGL((k_str_match_short<false, MODE, false>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, patw, plen, bitmap, tc, nrows, ntiles,
-                          (int32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const Pattern& pat,
+                         const uint8_t* pat_dev, uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, const StrCapture* cap) {
+  const dim3 g(grid), b(kBlock);
+  int32_t* cs = cap ? cap->sizes : nullptr; uint8_t* cby = cap ? cap->bytes : nullptr; uint32_t* ctb = cap ? cap->tile_bytes : nullptr;
+  if (pat.len > 8) {
+    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+  } else {
+    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+  }
 }
 
 void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
@@ -258,12 +277,12 @@ void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_o
   Pattern pat; memset(&pat, 0, sizeof pat); pat.len = patlen;
   if (patlen > 0 && patlen <= 64) memcpy(pat.w, pat_host, (size_t)patlen);   // short patterns ride in the kernel arguments
   const int grid = grid_for(ntiles, 2048);
-  if (patlen <= 8) {
+  if (patlen <= 64) {
     switch (mode) {
-      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
-      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
-      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
-      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat.w[0], patlen, bitmap, tile_counts, nrows, ntiles, cap); break;
+      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
+      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
+      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
+      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
     }
     return;
   }

@@ -169,11 +169,11 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
     const Column& col = need_resident(t, ord);
     DevBuf& pb = q->tmp_a; pb.ensure(pat.size() + 64);
-    if (pat.size() > 64) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); stream_wait(q->t->ctx); }
+    if (pat.size() > 16) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); stream_wait(q->t->ctx); }   // (bytes past 16 are compared against the device copy)
     // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask and the column it reads is
     // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
     StrCapture capture{nullptr, nullptr, nullptr};
-    bool do_cap = q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 8;
+    bool do_cap = q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 64;
     if (do_cap) {
       do_cap = false;
       for (const ProjCol& p : q->proj) if (p.expr->op == DFIR_COL && p.expr->col == ord) { do_cap = true; break; }

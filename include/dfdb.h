@@ -214,7 +214,7 @@ int32_t dfdb_query_execute(dfdb_query* q);
  * engine BEFORE the first execution (dfdb_count / dfdb_query_execute) that the projection will be materialised lets a
  * single-stage scan of simple terms keep the selected values of a projected 8-byte predicate column while it has them in
  * registers; dfdb_materialize then copies them instead of gathering (re-reading) the column.  The same holds for a String column
- * filtered by ONE short-pattern term (== / != / startswith / endswith, pattern <= 8 bytes) and projected itself: the match pass keeps
+ * filtered by ONE string term (== / != / startswith / endswith, pattern <= 64 bytes) and projected itself: the match pass keeps
  * the selected rows' sizes and bytes.  Results are identical; while the hint is on the query holds an extra nrows*8-byte buffer
  * (numeric capture) or nrows*4 bytes + a copy-sized byte arena (String capture). */
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on);

@@ -360,7 +360,8 @@ def test_string_capture_in_match_pass(oracle, dfdb_mod, ctx, n):
     actually have run."""
     from dfdb import ir
     rng = np.random.default_rng(n)
-    words = ["sony", "so", "", "sonya", "apple", "x", "samsungs", "né", "sonysony", "asony"]
+    words = ["sony", "so", "", "sonya", "apple", "x", "samsungs", "né", "sonysony", "asony", "microsoft", "microsoftware", "microsofa",
+             "a-rather-long-category-name-that-needs-several-probes-to-compare", "a-rather-long-category-name-that-needs-several-probes-to-compara"]
     strs = [words[int(k)] for k in rng.integers(0, len(words), n)]
     strs_m = [None if rng.random() < 0.1 else w for w in strs]
     cols = {"s": strs, "sm": strs_m, "a": oracle.gen_i64(col_seed(0), 0, n)}
@@ -370,7 +371,11 @@ def test_string_capture_in_match_pass(oracle, dfdb_mod, ctx, n):
         # (a comparison with a Union{String,Missing} column is not a Bool selection — ArgumentError on both sides — so the captured
         # column is the plain one; the nullable one rides along through the ordinary gather)
         for pred in (ir.col(0) == "sony", ir.col(0) != "sony", ir.startswith(ir.col(0), "so"), ir.endswith(ir.col(0), "ny"),
-                     ir.col(0) == "", ir.col(0) == "samsungs", ir.startswith(ir.col(0), ""), ir.endswith(ir.col(0), "é")):
+                     ir.col(0) == "", ir.col(0) == "samsungs", ir.startswith(ir.col(0), ""), ir.endswith(ir.col(0), "é"),
+                     # patterns longer than one 8-byte probe (the rest is compared only where the first 8 bytes match)
+                     ir.col(0) == "microsoft", ir.col(0) != "microsoftware", ir.startswith(ir.col(0), "microsoft"), ir.endswith(ir.col(0), "osoftware"),
+                     ir.endswith(ir.col(0), "icrosoft"), ir.col(0) == "a-rather-long-category-name-that-needs-several-probes-to-compare",
+                     ir.startswith(ir.col(0), "a-rather-long-category-name-that-needs-several-probes-to-compar")):
             n0, _ = ctx.profile_get("str_compact_captured")
             ov, dv = apply_stages(p, [("pred", pred)])
             assert_same(p, ov, dv)
