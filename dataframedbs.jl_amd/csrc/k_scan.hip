@@ -432,11 +432,33 @@ __global__ __launch_bounds__(kBlock) void k_range_stage(RangeSpec r, uint64_t* _
       const int64_t rlast = rank + c - 1;
       if (rlast < r.first || rank > r.last) nw = 0;
       else if (r.kind == 0 && r.step == 1 && rank >= r.first && rlast <= r.last) nw = w;
-      else {
+      else if (r.kind == 0) {
+        // a:s:b — one modulo per word, then a running remainder (a 64-bit modulo per survivor made t[1:10:end, :] 6 ms per 1e9 rows)
+        const int64_t d = rank - r.first;
+        int64_t rem = r.step == 1 ? 0 : (d >= 0 ? d % r.step : (r.step - ((-d) % r.step)) % r.step);
+        if (w == ~0ull) {   // a full word (a leading a:s:b over the table itself): the hits are every s-th bit from the first one
+          const int64_t bmax = r.last - rank < 63 ? r.last - rank : 63;
+          int64_t b = rem == 0 ? 0 : r.step - rem;
+          if (rank + b < r.first) b += (r.first - rank - b + r.step - 1) / r.step * r.step;   // (only near the range's start)
+          for (; b <= bmax; b += r.step) nw |= 1ull << b;
+        } else {
+          uint64_t ww = w;
+          while (ww) {
+            const uint64_t bit = ww & (0 - ww);
+            if (rem == 0 && rank >= r.first && rank <= r.last) nw |= bit;
+            ww ^= bit; rank++;
+            if (r.step != 1) { rem++; if (rem == r.step) rem = 0; }
+          }
+        }
+      } else {
+        // sorted unique index list: one binary search for the word's first survivor, then the cursor only moves forward
+        int64_t lo = 0, hi = r.nsorted;
+        while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (r.sorted[m] < rank) lo = m + 1; else hi = m; }
         uint64_t ww = w;
-        while (ww) {
+        while (ww && lo < r.nsorted) {
           const uint64_t bit = ww & (0 - ww);
-          if (range_contains(r, rank)) nw |= bit;
+          if (r.sorted[lo] < rank) lo++;
+          if (lo < r.nsorted && r.sorted[lo] == rank) nw |= bit;
           ww ^= bit; rank++;
         }
       }
