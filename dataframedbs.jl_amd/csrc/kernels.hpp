@@ -60,6 +60,8 @@ struct RangeSpec {
 // otherwise rank = rank_base + prefix[tile] + position among the survivors.
 void launch_range_stage(hipStream_t s, const RangeSpec& r, uint64_t* bitmap, const uint64_t* prefix, uint32_t* tile_counts,
                         int64_t nrows, int64_t rank_base, bool implicit_ones);
+// ismissing(col) / !ismissing(col): the column's missing bitmap (words padded like the selection bitmap) is the mask
+void launch_missing_mask(hipStream_t s, const uint64_t* missing, bool negate, bool and_existing, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
 // all-ones mask (empty SelectionQueue): bitmap + counts
 void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
 

@@ -150,9 +150,23 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     }
     return out.n >= 2;
   };
+  // ismissing(col) / !ismissing(col) over a nullable fixed-width column: its missing bitmap is the mask
+  struct MissTerm { const uint64_t* bits; bool negate; };
+  std::vector<MissTerm> miss;
+  auto match_missing = [&](const Node& n, MissTerm& out) {
+    const Node* m = &n; bool neg = false;
+    if (m->op == DFIR_NOT && m->a) { m = m->a.get(); neg = true; }
+    if (m->op != DFIR_ISMISSING || !m->a || m->a->op != DFIR_COL) return false;
+    const Column& col = need_resident(t, m->a->col);
+    if (!dt_nullable(col.dtype) || dt_base(col.dtype) == DFDB_STRING || !col.missing.p) return false;
+    out = MissTerm{col.missing.as<uint64_t>(), neg};
+    return true;
+  };
   for (const Node* c : conj) {
     ScanTerm tm; int ord; int mode; std::string pat;
     ScanTerms ob;
+    MissTerm mt;
+    if (match_missing(*c, mt)) { miss.push_back(mt); continue; }
     if ((c->op == DFIR_OR || c->op == DFIR_IN_SET) && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
@@ -190,6 +204,11 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
                      do_cap ? &capture : nullptr);
     if (do_cap) q->cap_str_col = ord;
+    have = true;
+  }
+  for (const MissTerm& mt : miss) {
+    LaunchTimer lt(ctx, "missing_mask");
+    launch_missing_mask(s, mt.bits, mt.negate, have, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows);
     have = true;
   }
   for (const ScanTerms& ob : or_batches) {

@@ -423,6 +423,30 @@ def test_disjunctions_of_simple_terms_take_the_scan_kernel(oracle, dfdb_mod, ctx
         ctx.profile(False)
 
 
+def test_ismissing_of_a_column_is_its_bitmap(oracle, dfdb_mod, ctx):
+    """ismissing(col) / !ismissing(col) over a Union{T,Missing} fixed-width column never runs the interpreter: the column's missing
+    bitmap is the mask (alone, negated, beside other terms, after a range stage, in blocks that do not start on a word boundary)."""
+    from dfdb import ir
+    n = 150_001
+    rng = np.random.default_rng(21)
+    cols = {"a": oracle.gen_i64(col_seed(0), 0, n), "m": np.ma.masked_array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.3),
+            "mf": np.ma.masked_array(rng.random(n).astype(np.float32), mask=rng.random(n) < 0.6)}
+    for bs in (65536, 1000):
+        p = Pair(oracle, dfdb_mod, cols, block_size=bs)
+        a, m, mf = ir.col(0), ir.col(1), ir.col(2)
+        ctx.profile(True)
+        try:
+            for stages in ([("pred", ir.ismissing(m))], [("pred", ~ir.ismissing(mf))], [("pred", ir.ismissing(m) & (a > 500_000) & ~ir.ismissing(mf))],
+                           [("range", 100, 3, 140_000), ("pred", ~ir.ismissing(m))], [("pred", a < 300_000), ("pred", ir.ismissing(mf))]):
+                n0, _ = ctx.profile_get("interp_predicate"); k0, _ = ctx.profile_get("missing_mask")
+                ov, dv = apply_stages(p, stages)
+                assert_same(p, ov, dv)
+                n1, _ = ctx.profile_get("interp_predicate"); k1, _ = ctx.profile_get("missing_mask")
+                assert n1 == n0 and k1 > k0
+        finally:
+            ctx.profile(False)
+
+
 # ------------------------------------------------------------------ aggregates
 def test_aggregates(oracle, dfdb_mod, ctx):
     from dfdb import ir
