@@ -1004,6 +1004,12 @@ class DFColumn:
     def _aggregate(self, op: int, with_count: bool = False):
         """sum / min / max driven by Base.iterate(::DFColumn) in the reference (column.jl:102-126).  Over a table that is not resident
         every chunk is reduced on the device and the per-chunk results are combined here, block order = the reference's order."""
+        # sum(f.(cols)) of a computed Bool column — `sum(ismissing.(t.col))`, docs/src/index.md:326-328 — is the number of selected rows for
+        # which it holds: one more predicate on the selection (routed to the scan kernels like any other) instead of a materialised
+        # Bool per row and a reduction over it
+        if op == N.AGG_SUM and self.eltype == ir.BOOL and self.expr.op != ir.COL:
+            cnt = nrow(DFView(self.view.table, self.view.projection, self.view.selection.add(self.expr)))
+            return (cnt, nrow(self.view)) if with_count else cnt
         if not _out_of_core(self.view):
             q = self.view._query()
             q.hint_aggregate(op)                           # before anything executes the selection

@@ -443,6 +443,14 @@ def test_ismissing_of_a_column_is_its_bitmap(oracle, dfdb_mod, ctx):
                 assert_same(p, ov, dv)
                 n1, _ = ctx.profile_get("interp_predicate"); k1, _ = ctx.profile_get("missing_mask")
                 assert n1 == n0 and k1 > k0
+            # sum(ismissing.(t.m)) (docs/src/index.md:326-328) and friends: a computed Bool column is summed as one more predicate
+            mm, am = np.ma.getmaskarray(cols["m"]), cols["a"]
+            assert dfdb_mod.ismissing(p.d.m).sum() == int(mm.sum())
+            assert (p.d.a > 500_000).sum() == int((am > 500_000).sum())
+            sel = am < 300_000
+            v = p.d[p.d.a < 300_000, dfdb_mod.ALL]
+            assert dfdb_mod.ismissing(v.m).sum() == int(mm[sel].sum())
+            assert abs(dfdb_mod.ismissing(v.m).mean() - mm[sel].mean()) < 1e-12
         finally:
             ctx.profile(False)
 
