@@ -202,6 +202,7 @@ def test_hinted_paths_equal_the_plain_ones_at_scale(oracle, dfdb_mod, ctx):
             N.check(lib.dfdb_result_string_bytes(q._h, 0, C.byref(nb)))
             osz = torch.empty(nsel, dtype=torch.int32, device=dev)
             oby = torch.zeros(nb.value + 64, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()          # (torch's fill runs on torch's stream, the engine writes on its own)
             outs = (N.OutCol * 1)(_dev_outcol(N, osz, oby))
             N.check(lib.dfdb_materialize(q._h, outs, 1))
             torch.cuda.synchronize()
