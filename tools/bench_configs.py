@@ -200,46 +200,40 @@ def main():
     del osz, oby, oa, q, v
     t.close()
 
-    # ---- LZ4 decode stage: reference-format image written by the test oracle's liblz4 writer
-    from oracle import oracle as O
-    m = args.lz4_rows
-    ot = O.Table(block_size=65536)
-    ot.add_column("x", O.gen_i64(SEED, 0, m))
-    img = ot.image(0)
-    st = ot.column_stats(0)
-    t = dfdb.DFTable.new()
-    # declare the column through a file-less table: write to tmp and open
+    # ---- LZ4 stages: a reference-format table written by the device compressor, decoded by each decoder variant
+    # (blocks compressed by the system liblz4 instead: tools/bench_lz4, which also checks every decoded block)
+    import shutil
     import tempfile
-    d = tempfile.mkdtemp()
-    ot.save(os.path.join(d, "tb"))
-    for variant in (0, 3, 4, 3, 4):
-        ctx.set_option("lz4_variant", variant)
+    m = args.lz4_rows
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        src = dfdb.DFTable.new()
+        src.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, m)
         ctx.profile(True)
         t0 = time.perf_counter()
-        tb = dfdb.open_table(os.path.join(d, "tb"))
+        st = src.save(os.path.join(d, "tb"))
         wall = time.perf_counter() - t0
-        nl, ms = ctx.profile_get("lz4_decode")
+        nl, ms = ctx.profile_get("lz4_compress")
         ctx.profile(False)
-        print(json.dumps({"config": "lz4", "variant": variant, "rows": m, "lz4_decode_ms": ms, "decode_GBps_out": m * 8 / (ms * 1e-3) / 1e9 if ms else None,
-                          "open_table_wall_s": wall}))
-    print(json.dumps({"config": "lz4", "rows": m, "blocks": st["blocks"], "compressed_MB": len(img) / 1e6, "uncompressed_MB": m * 8 / 1e6,
-                      "lz4_decode_ms": ms, "decode_GBps_out": m * 8 / (ms * 1e-3) / 1e9 if ms else None, "open_table_wall_s": wall}))
-    # write side: the decoded column back to disk (device LZ4 compression, k_encode.hip)
-    import shutil
-    ctx.profile(True)
-    t0 = time.perf_counter()
-    st = tb.save(os.path.join(d, "tb_out"))
-    wall = time.perf_counter() - t0
-    nl, ms = ctx.profile_get("lz4_compress")
-    ctx.profile(False)
-    print(json.dumps({"config": "lz4-write", "rows": m, "lz4_compress_ms": ms, "compress_GBps_in": m * 8 / (ms * 1e-3) / 1e9 if ms else None,
-                      "ratio": st["uncompressed"] / max(1, st["compressed"]), "liblz4_ratio": m * 8 / len(img), "save_wall_s": wall}))
-    shutil.rmtree(os.path.join(d, "tb_out"), ignore_errors=True)
-    t0 = time.perf_counter()
-    nrow = ot.view().add_predicate((ir.col(0) > 899_999).to_ir()).nrow()
-    cpu = time.perf_counter() - t0
-    print(json.dumps({"config": "lz4-cpu", "rows": m, "oracle_scan_s": cpu, "oracle_rows_per_s": m / cpu, "selected": nrow,
-                      "engine_selected": dfdb.nrow(tb[("x", lambda x: x > 899_999), dfdb.ALL])}))
+        print(json.dumps({"config": "lz4-write", "rows": m, "lz4_compress_ms": ms, "compress_GBps_in": m * 8 / (ms * 1e-3) / 1e9 if ms else None,
+                          "ratio": st["uncompressed"] / max(1, st["compressed"]), "save_wall_s": wall}))
+        want = dfdb.nrow(src[("x", lambda x: x > 899_999), dfdb.ALL])
+        src.close()
+        for variant in (0, 3, 4, 3, 4):
+            ctx.set_option("lz4_variant", variant)
+            ctx.profile(True)
+            t0 = time.perf_counter()
+            tb = dfdb.open_table(os.path.join(d, "tb"))
+            wall = time.perf_counter() - t0
+            nl, ms = ctx.profile_get("lz4_decode")
+            ctx.profile(False)
+            assert dfdb.nrow(tb[("x", lambda x: x > 899_999), dfdb.ALL]) == want
+            tb.close()
+            print(json.dumps({"config": "lz4", "variant": variant, "rows": m, "blocks": -(-m // 65536), "compressed_MB": st["compressed"] / 1e6,
+                              "lz4_decode_ms": ms, "decode_GBps_out": m * 8 / (ms * 1e-3) / 1e9 if ms else None, "open_table_wall_s": wall}))
+        ctx.set_option("lz4_variant", 4)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Block-streamed scan of a table that is never resident: files -> pread -> PCIe -> K7 -> K1, chunk by chunk,
-the loader thread one chunk ahead on its own HIP stream.  Prints one JSON line per chunk size + the oracle's CPU scan of the
-same files.   python tools/bench_stream.py [--rows 2.5e8]"""
+the loader thread one chunk ahead on its own HIP stream.  Prints one JSON line per chunk size (the CPU baseline of the same scan is bench.py's cpu_baseline leg).   python tools/bench_stream.py [--rows 2.5e8]"""
 import argparse, json, os, shutil, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
@@ -11,7 +10,6 @@ import dfdb
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=float, default=2.5e8)
-ap.add_argument("--cpu-rows", type=float, default=5e7)
 args = ap.parse_args()
 n = int(args.rows)
 SEED = 0x9E3779B97F4A7C15
@@ -41,15 +39,5 @@ try:
     dt = time.perf_counter() - t0
     print(json.dumps({"config": "load-all-then-count", "rows": n, "seconds": dt, "rows_per_s": n / dt}))
     tr.close()
-    # the oracle (liblz4, one core) over the first cpu_rows of the same data
-    from oracle import oracle as O
-    from dfdb import ir
-    m = int(args.cpu_rows)
-    ot = O.Table(block_size=65536)
-    ot.add_column("x", O.gen_i64(SEED, 0, m))
-    t0 = time.perf_counter()
-    c = ot.view().add_predicate((ir.col(0) > 899_999).to_ir()).nrow()
-    dt = time.perf_counter() - t0
-    print(json.dumps({"config": "oracle-cpu-count", "rows": m, "seconds": dt, "rows_per_s": m / dt}))
 finally:
     shutil.rmtree(d, ignore_errors=True)
