@@ -455,6 +455,27 @@ def test_ismissing_of_a_column_is_its_bitmap(oracle, dfdb_mod, ctx):
             ctx.profile(False)
 
 
+def test_arrow_string_output(oracle, dfdb_mod, ctx):
+    """materialize() with set_string_output("arrow"): String columns come back as pyarrow-backed pandas arrays over the engine's own
+    (sizes, arena) buffers; same strings, missing rows are nulls."""
+    n = 30_000
+    sizes, data = oracle.gen_str(col_seed(3), 0, n)
+    strs = oracle.flat_to_strings(sizes, data)
+    cols = {"s": strs, "sm": [None if i % 7 == 0 else w for i, w in enumerate(strs)], "a": oracle.gen_i64(col_seed(0), 0, n)}
+    t = dfdb_mod.DFTable.from_columns(cols)
+    v = t[t.a > 500_000, dfdb_mod.ALL]
+    want = dfdb_mod.materialize(v)
+    dfdb_mod.set_string_output("arrow")
+    try:
+        got = dfdb_mod.materialize(v)
+    finally:
+        dfdb_mod.set_string_output("object")
+    assert len(got) == len(want) and got["a"].tolist() == want["a"].tolist()
+    assert got["s"].tolist() == want["s"].tolist()
+    import pandas as pd
+    assert [None if pd.isna(x) else x for x in got["sm"].tolist()] == want["sm"].tolist()
+
+
 # ------------------------------------------------------------------ aggregates
 def test_aggregates(oracle, dfdb_mod, ctx):
     from dfdb import ir

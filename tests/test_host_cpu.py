@@ -220,3 +220,17 @@ def test_two_rank_plan_matches_oracle(oracle):
         cat = got[0][name][0] + got[1][name][0]          # rank order = table order
         assert cat == want, name
         assert got[0][name][1] == got[1][name][1] == len(want)
+
+
+def test_flat_strings_to_arrow_matches_the_per_row_conversion():
+    """set_string_output("arrow") wraps the engine's (sizes, arena) pair without per-row work; it must denote the same strings,
+    missing rows (size -1) included, as the Vector{String}-like object conversion (projection.jl:99-100)."""
+    from dfdb import api
+    rng = np.random.default_rng(3)
+    words = ["", "a", "sony", "né", "microsoft", "x" * 40]
+    pick = rng.integers(0, len(words), 5000)
+    sizes = np.array([len(words[i].encode()) for i in pick], np.int32)
+    sizes[::11] = -1
+    data = np.frombuffer(b"".join(words[i].encode() for k, i in enumerate(pick) if sizes[k] >= 0), np.uint8)
+    assert api._flat_to_arrow(sizes, data).to_pylist() == api._flat_to_strings(sizes, data)
+    assert api._flat_to_arrow(np.zeros(0, np.int32), np.zeros(0, np.uint8)).to_pylist() == []
