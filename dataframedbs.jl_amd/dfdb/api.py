@@ -509,7 +509,7 @@ class DFView:
             arr = np.asarray(el)
             if arr.dtype == bool:
                 raise TypeError("Bool masks enter only as lazy DFColumn{Bool} (quirk Q4)")
-            return DFView(self.table, self.projection, self.selection.add([int(x) for x in arr]))
+            return DFView(self.table, self.projection, self.selection.add(arr.astype(np.int64).tolist()))
         raise TypeError(f"unsupported selector {el!r}; use jr(a, b) for ranges (1-based, inclusive)")
 
     # -- projection(v, p) (view.jl:75-109)
