@@ -10,7 +10,11 @@ scan `x > 899999` -> selection bitmap + tile counts (K1), exclusive scan of the 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Multi-GPU: contiguous block-range shards (rank r owns rows [r*rows, (r+1)*rows)), no data-path collective,
-one RCCL all-reduce of the 8-byte count per step ("scaling": "weak").
+one RCCL all-reduce of the 8-byte count per step ("scaling": "weak").  One process per GPU: under torch.distributed.run the
+ranks come from the environment; started plainly with --gpus N > 1 (WORLD_SIZE unset) this script spawns its own N ranks
+BEFORE anything touches a GPU (fresh child processes, never a re-exec) and fails if fewer than N complete.
+`--exchange lib` takes the per-step all-reduce through the library's own RCCL communicator (dfdb_group_create_rank /
+dfdb_group_count, include/dfdb.h) instead of torch.distributed's.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -75,6 +79,80 @@ def cpu_baseline(rows: int, repeats: int):
     return res
 
 
+def launch_ranks(n: int) -> int:
+    """WORLD_SIZE unset and --gpus n > 1: be the launcher.  n fresh child processes of this script, one rank each, with the
+    environment torch.distributed.run would give them; this parent never imports torch or touches a GPU.  Rank 0's stdout (the
+    JSON line) passes through.  Non-zero exit if any rank fails; the others are then stopped by PID."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for k in pending:
+                    procs[k].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
+    """The like-for-like GPU figure for `cpu_baseline` (which includes the LZ4 decode): the column lives in HBM as the reference's
+    LZ4 blocks (written by the device encoder, read back through the ordinary file loader with option keep_compressed), and every
+    step decodes all of them (K7) before the same scan + compaction.  Extra keys only: never part of `value`."""
+    import shutil
+    import tempfile
+    need = rows * 6          # the column file is ~4.6 B/row
+    base = next((d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d) and shutil.disk_usage(d).free > need + (4 << 30)), None)
+    if base is None:
+        return {"skipped": "no scratch directory with %d free bytes for the column file" % need}
+    d = tempfile.mkdtemp(prefix="dfdb_bench_", dir=base)
+    try:
+        st = t.save(os.path.join(d, "tb"))
+        ctx.set_option("keep_compressed", 1)
+        t2 = dfdb.open_table(os.path.join(d, "tb"), ctx=ctx, load=False)
+        t2.load()
+        ctx.set_option("keep_compressed", 0)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    q2 = t2[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
+    nsel2 = q2.count()
+
+    def step():
+        t2.decode_resident("x")
+        q2.reset()
+        q2.indices_device(out_ptr, cap)
+        q2.count_device(cnt_ptr)
+
+    step()
+    ctx.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    el = (time.perf_counter() - t0) / steps
+    n7, ms7 = ctx.profile_get("lz4_decode")
+    ctx.profile(False)
+    res = {"rows_per_s": rows / el, "ms_per_step": el * 1e3, "steps": steps, "selected": nsel2,
+           "blocks": -(-rows // 65536), "compressed_bytes": st["compressed"], "ratio": st["uncompressed"] / max(st["compressed"], 1),
+           "lz4_decode_avg_ms": ms7 / n7 if n7 else None, "decoded_GBps": rows * 8 / (ms7 / n7 * 1e-3) / 1e9 if n7 else None,
+           "what": "compressed-resident column (reference LZ4 blocks in HBM) -> K7 decode of every block -> K1 scan -> count scan -> K2 indices, per step"}
+    t2.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,11 +161,15 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
-    ap.add_argument("--fused", action="store_true", help="one-pass k_scan_compact (decoupled look-back) instead of K1 + count scan + K2; "
-                    "measured 8-10 %% slower than the three-kernel pipeline on MI355X (DESIGN.md §4), kept as an option")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
+                    "or the library's own RCCL communicator behind the C ABI (dfdb_group_create_rank + dfdb_group_count)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -95,7 +177,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU number as {args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
     if args.all_on_device0:
         local = 0
     torch.cuda.set_device(local)
@@ -117,33 +200,56 @@ def main():
             tensor.copy_(h)
 
     import dfdb
-    from dfdb import ir
+    from dfdb import group as G
     # ONE stream for the engine's kernels, torch's tensors and the collective: a non-default torch stream made current
     # (the default stream's handle is 0, which the C ABI reads as "create a private stream")
     stream_obj = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream_obj)
-    ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
-    info = ctx.device_info()
-
     rows = args.rows
-    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
-    t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
-    t.set_row_base(rank * rows)
-    v = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]
-    q = v._query()
-    nsel = q.count()                                   # exact selected count from the first (untimed) execution
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    lib = args.exchange == "lib"
+    if lib:
+        # the C-ABI group: this process is rank `rank` of `world`; the RCCL id travels through torch.distributed's store
+        uid = None
+        if world > 1:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("dfdb_group_uid", G.Group.unique_id())
+            uid = bytes(store.get("dfdb_group_uid"))
+        grp = G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream)
+        ctx = grp.ctx(0)
+        nblocks_per = -(-(-(-(rows * world) // 65536)) // world)        # ceil(ceil(total / 65536) / world): the library's block-range rule
+        gt = G.GroupTable.new(grp)
+        gt.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows * world)   # every rank generates its own block range
+        t = gt.shard(0)
+        gq = G.GroupQuery(gt, gt.view()[("x", lambda x: x > THRESHOLD), dfdb.ALL])
+        nsel = gq.shard_counts()[rank]
+        local_rows = t.view()._query().count()
+        assert local_rows <= nblocks_per * 65536
+    else:
+        ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
+        t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+        t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
+        t.set_row_base(rank * rows)
+        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
+        nsel = q.count()                                   # exact selected count from the first (untimed) execution
+        local_rows = rows
+    info = ctx.device_info()
     cap = nsel
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    ctx.set_option("fused", 1 if args.fused else 0)
-
-    def step():
-        q.reset()                                      # a fresh evaluation every step (nothing cached)
-        q.indices_device(out.data_ptr(), cap)          # K1 scan -> bitmap + tile counts, count scan, K2 compaction
-        q.count_device(cnt.data_ptr())                 # (--fused: all three in one launch)
-        if world > 1:
-            all_reduce(cnt)
+    if lib:
+        def step():
+            gq.reset()                                     # a fresh evaluation every step (nothing cached)
+            gq.indices_device([out.data_ptr()], [cap])     # K1 scan -> bitmap + tile counts, count scan, K2 compaction
+            gq.count_async()                               # all-reduce of the count on the engine stream, no host wait
+    else:
+        def step():
+            q.reset()
+            q.indices_device(out.data_ptr(), cap)
+            q.count_device(cnt.data_ptr())
+            if world > 1:
+                all_reduce(cnt)
 
     for _ in range(args.warmup):
         step()
@@ -164,10 +270,11 @@ def main():
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce(el, dist.ReduceOp.MAX)
         elapsed = float(el.item())
-    total_sel = int(cnt.item())
+    total_sel = gq.count() if lib else int(cnt.item())
+    total_rows = rows * world
 
     kernels = {}
-    for k in ("scan_compact", "scan_cmp", "scan_counts", "compact_indices"):
+    for k in ("scan_cmp", "scan_counts", "compact_indices"):
         n, ms = ctx.profile_get(k)
         if n:
             kernels[k] = dict(launches=n, avg_ms=ms / n)
@@ -175,22 +282,14 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * rows * args.steps / elapsed
-        sigma = nsel / rows
-        if "scan_compact" in kernels:
-            # ONE k_scan_compact launch: 8 B/row column + 1/8 bitmap + 12 B per 1024-row tile (count + prefix) + 8*sigma index
-            kname, pmc_name = "k_scan_compact<int64,GT>", "r1_pmc_scan_compact.json"
-            scan_bytes = rows * (8 + 1 / 8 + 12 / 1024 + 8 * sigma)
-            scan_ms = kernels["scan_compact"]["avg_ms"]
-        else:
-            # ONE k_scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
-            # (the pipelined path scans the column in equal pieces: one launch covers rows / launches_per_step rows)
-            kname, pmc_name = "k_scan_cmp<int64,GT>", "r1_pmc_scan_cmp.json"
-            lps = max(1, round(kernels.get("scan_cmp", {}).get("launches", args.steps) / args.steps))
-            scan_bytes = rows / lps * (8 + 1 / 8 + 4 / 1024)
-            scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
+        value = total_rows * args.steps / elapsed
+        sigma = nsel / local_rows
+        # ONE k_scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
+        kname, pmc_name = "k_scan_cmp<int64,GT>", "r1_pmc_scan_cmp.json"
+        scan_bytes = local_rows * (8 + 1 / 8 + 4 / 1024)
+        scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
-        job_bytes = rows * (8 + 8 * sigma)             # 8 + 8*sigma B/row for the whole job
+        job_bytes = total_rows * (8 + 8 * sigma)       # 8 + 8*sigma B/row for the whole job
         # HBM traffic of that kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command; FETCH_SIZE doubled per the gfx950 correction, calibrated on a known-byte read): profiles/
         traffic, traffic_src = None, None
@@ -199,7 +298,7 @@ def main():
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("rows"):
-                traffic = pj["hbm_bytes_per_launch_corrected"] * (scan_bytes / (8 + 1 / 8 + 4 / 1024) if "scan_compact" not in kernels else rows) / pj["rows"]
+                traffic = pj["hbm_bytes_per_launch_corrected"] * local_rows / pj["rows"]
                 traffic_src = f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
         res = {
             "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
@@ -208,19 +307,24 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "Int64 column, selection(x -> x > 899999) -> ascending 1-based Int64 row indices + count",
                        "rows_per_gpu": rows, "selected_per_gpu": nsel, "selectivity": sigma, "block_size": 65536,
-                       "pipeline": "fused: k_scan_compact (one pass, decoupled look-back)" if args.fused else
-                                   ("k_scan_cmp on the engine stream in %d pieces; count scan + k_compact_indices of each finished piece on a side stream" % lps if lps > 1
-                                    else "k_scan_cmp + count scan + k_compact_indices"),
-                       "sharding": f"contiguous block ranges x{world}, all-reduce(count) per step" if world > 1 else "single GPU",
+                       "pipeline": "k_scan_cmp + count scan + k_compact_indices",
+                       "sharding": (f"contiguous block ranges x{world}, all-reduce(count) per step by " +
+                                    ("libdfdb_hip's RCCL communicator (dfdb_group_count)" if lib else f"torch.distributed {args.backend}")) if world > 1 else "single GPU",
+                       "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
                        "device": info["name"], "global_selected": total_sel},
-            "job_hbm_gbps": job_bytes * world / (elapsed / args.steps) / 1e9,
+            "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }
+        if world == 1 and not lib and not args.no_decode_leg:
+            try:
+                res["decode_scan"] = decode_scan_leg(dfdb, ctx, t, rows, max(3, min(args.steps, 10)), out.data_ptr(), cap, cnt.data_ptr(), torch.cuda.synchronize)
+            except Exception as e:      # an extra figure: never fail the bench line for it
+                res["decode_scan"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu and world == 1:      # the CPU baseline is an N=1, rank-0 figure
             res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -6,6 +6,7 @@
 using namespace dfdb;
 
 static thread_local std::string g_last_error;
+namespace dfdb { void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; } }   // group.cpp reports through the same thread-local text
 
 template <class F>
 static int32_t guard(F&& f) noexcept {
@@ -206,6 +207,7 @@ int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file,
   return guard([&] { NEED(t); NEED(file); table_save_column(t, ordinal, file, stats); });
 }
 int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(stats); table_column_stats(t, ordinal, stats); }); }
+int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal) { return guard([&] { NEED(t); table_decode_resident(t, ordinal); }); }
 int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical) {
   return guard([&] {
     NEED(t); NEED(logical);

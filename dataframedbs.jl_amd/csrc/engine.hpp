@@ -19,6 +19,10 @@ struct Column {
   int64_t nbytes = 0;
   DevBuf tile_off;   // String: u64[nstrtiles+1] byte offset of each 1024-row tile (K4)
   DevBuf missing;    // nullable fixed width: bitmap, 1 = missing, padded like the selection bitmap
+  // compressed-resident form (ctx option "keep_compressed" at load time; plain fixed-width columns): the column's LZ4 blocks as they
+  // sit in the file stay in HBM with their descriptors, and dfdb_table_decode_resident re-runs K7 from them into `data`
+  DevBuf comp, comp_blocks, comp_status;
+  int64_t comp_nblocks = 0;
   // on-disk source (tables opened from files)
   std::string file;
   size_t data_off = 0;  // first block inside the file
@@ -117,6 +121,7 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
 void stream_close(dfdb_stream* s);
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
+void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp
 int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
 void ctx_destroy(dfdb_ctx* c);
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp

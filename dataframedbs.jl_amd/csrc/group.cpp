@@ -1,0 +1,765 @@
+// group.cpp — one table block-range sharded over the GPUs of a node, behind the C ABI (SURVEY.md §8e, §8b backend HIP_N).
+//
+// The reference is single-process and walks blocks serially (src/io/blocksiterator.jl:98-145); its blocks are independent
+// 65 536-row units that every column shares (check_column_head, src/io/filesystem.jl:47-54).  Here rank g of G owns the contiguous
+// block range [g*ceil(nb/G), (g+1)*ceil(nb/G)) of EVERY column, evaluates the view over its shard with the ordinary single-GPU
+// engine, and the shards meet only in
+//   * nrow(v) / length(col)  (src/tables/view.jl:192-206)            -> one RCCL all-reduce of an Int64
+//   * sum / minimum / maximum (Base.iterate(::DFColumn), column.jl:102-126) -> one RCCL all-reduce of {value, count}
+//   * a range stage AFTER a predicate stage numbers the global survivor stream (selection.jl:94-111, RangeToProcess.offset :68-75)
+//     -> all-gather of one Int64 per rank + exclusive scan = the survivors on lower ranks (dfdb_query_set_stage_base)
+// No column data ever crosses xGMI; results stay sharded on the devices or are written to the caller's host buffers in rank order
+// (= table order).
+//
+// Two ways to form a group:
+//   dfdb_group_create(devices, n)            one process drives n GPUs: a host worker thread per GPU issues that shard's launches,
+//                                            ncclCommInitAll connects them (what a Julia session calling the drop-in gets)
+//   dfdb_group_create_rank(dev, id, r, G)    one process per GPU (bench.py under torch.distributed.run): ncclCommInitRank with an id
+//                                            made by dfdb_group_unique_id on rank 0 and handed round by the launcher
+// RCCL is loaded lazily (dlopen "librccl.so.1"): a single-GPU user never touches it, and a process that already holds RCCL (PyTorch)
+// shares that copy.  DFDB_EXCHANGE_HOST does the same exchanges through host memory; it exists for single-process groups whose
+// "ranks" share one physical GPU (functional tests on a 1-GPU box: RCCL refuses duplicate devices).
+#include "engine.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace dfdb {
+int query_aggregate_device(dfdb_query* q, int32_t op, int32_t i);   // query.cpp
+
+// ---------------------------------------------------------------- RCCL, resolved at run time
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.h) break;
+    }
+    if (!r.h) return;
+    auto sym = [&](const char* n) { return dlsym(r.h, n); };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  });
+  if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.GroupStart || !r.GroupEnd)
+    fail(DFDB_ERR_DEVICE, "RCCL (librccl.so.1) could not be loaded: %s", r.h ? "missing symbols" : dlerror());
+  return r;
+}
+#define RCCL_CHECK(expr)                                                                                          \
+  do {                                                                                                            \
+    ncclResult_t _r = (expr);                                                                                     \
+    if (_r != ncclSuccess) ::dfdb::fail(DFDB_ERR_DEVICE, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "rccl error"); \
+  } while (0)
+
+// ---------------------------------------------------------------- one host thread per local shard
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, quit = false;
+  int device = 0;
+  void start(int dev) {
+    device = dev;
+    th = std::thread([this] {
+      (void)hipSetDevice(device);
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        auto j = std::move(job); has_job = false;
+        lk.unlock(); j(); lk.lock();
+        done = true; cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; done = false; cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); }
+  void stop() { { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+};
+}  // namespace dfdb
+
+using namespace dfdb;
+
+constexpr int kXSlots = 16;   // 8-byte exchange slots per shard before the all-gather area
+
+struct dfdb_group {
+  int world = 1, first_rank = 0, exchange = DFDB_EXCHANGE_HOST;
+  std::vector<dfdb_ctx*> ctx;            // one per local shard; owned
+  std::vector<ncclComm_t> comm;          // RCCL only
+  std::vector<std::unique_ptr<Worker>> workers;   // single-process groups with more than one shard
+  std::vector<DevBuf> xbuf;              // per shard: kXSlots reduce slots + world all-gather slots (device)
+  std::vector<int64_t*> xpin;            // the same, pinned host memory
+  int nlocal() const { return (int)ctx.size(); }
+};
+struct dfdb_gtable {
+  dfdb_group* g = nullptr;
+  std::vector<dfdb_table*> shard;        // owned
+  int64_t total_rows = -1;               // rows of the whole table (all ranks); -1 until something is resident
+  std::vector<dfdb_gquery*> queries;
+};
+struct dfdb_gquery {
+  dfdb_gtable* gt = nullptr;
+  std::vector<dfdb_query*> shard;        // owned
+  bool planned = false;                  // stage bases are set for the current stage list
+  bool count_enqueued = false;           // the reduced count sits in slot 0 of every shard's exchange buffer
+  int64_t count = -1;                    // host copy of the global count
+};
+
+namespace dfdb {
+
+// run fn(local shard) on every shard's own thread (or inline for a one-shard group); the first failure is rethrown on the caller
+static void for_shards(dfdb_group* g, const std::function<void(int)>& fn) {
+  const int n = g->nlocal();
+  if (g->workers.empty()) {
+    for (int l = 0; l < n; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); fn(l); }
+    return;
+  }
+  std::vector<std::unique_ptr<Error>> errs((size_t)n);
+  for (int l = 0; l < n; l++)
+    g->workers[(size_t)l]->submit([&, l] {
+      try { fn(l); }
+      catch (const Error& e) { errs[(size_t)l] = std::make_unique<Error>(e.code, e.what()); }
+      catch (const std::exception& e) { errs[(size_t)l] = std::make_unique<Error>(DFDB_ERR_DEVICE, e.what()); }
+    });
+  for (int l = 0; l < n; l++) g->workers[(size_t)l]->wait();
+  for (int l = 0; l < n; l++) if (errs[(size_t)l]) throw Error(errs[(size_t)l]->code, errs[(size_t)l]->what());
+}
+
+// a one-rank RCCL group still issues its collectives (they are copies): the same code runs at every world size
+static bool exchanges(const dfdb_group* g) { return g->world > 1 || g->exchange == DFDB_EXCHANGE_RCCL; }
+
+static void group_alloc_exchange(dfdb_group* g) {
+  const int n = g->nlocal();
+  g->xbuf.resize((size_t)n); g->xpin.assign((size_t)n, nullptr);
+  const size_t bytes = (size_t)(kXSlots + g->world + 8) * 8;
+  for (int l = 0; l < n; l++) {
+    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+    g->xbuf[(size_t)l].ensure(bytes);
+    HIP_CHECK(hipMemset(g->xbuf[(size_t)l].p, 0, bytes));
+    HIP_CHECK(hipHostMalloc((void**)&g->xpin[(size_t)l], bytes, hipHostMallocDefault));
+    memset(g->xpin[(size_t)l], 0, bytes);
+  }
+}
+
+// ---- exchanges.  Every shard's operands are already in its xbuf (written on its engine stream); results come back there.
+static ncclDataType_t nccl_type(int dt) { return dt == DFDB_F64 ? ncclFloat64 : (dt == DFDB_U64 ? ncclUint64 : ncclInt64); }
+static ncclRedOp_t nccl_op(int op) { return op == DFDB_AGG_MIN ? ncclMin : (op == DFDB_AGG_MAX ? ncclMax : ncclSum); }
+
+template <class T> static T fold(T a, T b, int op) { return op == DFDB_AGG_MIN ? std::min(a, b) : (op == DFDB_AGG_MAX ? std::max(a, b) : (T)(a + b)); }
+static uint64_t fold_bits(uint64_t a, uint64_t b, int dt, int op) {
+  if (dt == DFDB_F64) {
+    double x, y; memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+    double r = op == DFDB_AGG_SUM ? x + y : ((std::isnan(x) || std::isnan(y)) ? NAN : fold<double>(x, y, op));   // Julia: min / max propagate NaN
+    uint64_t o; memcpy(&o, &r, 8); return o;
+  }
+  if (dt == DFDB_U64) return op == DFDB_AGG_SUM ? a + b : fold<uint64_t>(a, b, op);
+  return op == DFDB_AGG_SUM ? a + b : (uint64_t)fold<int64_t>((int64_t)a, (int64_t)b, op);
+}
+
+// slots [slot, slot+n) of every shard := reduction over all ranks (in place, on the engine streams; no host wait with RCCL)
+static void exchange_reduce(dfdb_group* g, int slot, int n, int dt, int op) {
+  const int nl = g->nlocal();
+  if (g->exchange == DFDB_EXCHANGE_RCCL) {
+    Rccl& r = rccl();
+    RCCL_CHECK(r.GroupStart());
+    for (int l = 0; l < nl; l++) {
+      uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>() + slot;
+      RCCL_CHECK(r.AllReduce(p, p, (size_t)n, nccl_type(dt), nccl_op(op), g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+    }
+    RCCL_CHECK(r.GroupEnd());
+    return;
+  }
+  // host exchange (single-process groups only): read every shard's operands, fold in rank order, write the result back
+  for (int l = 0; l < nl; l++) {
+    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+    HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + slot, g->xbuf[(size_t)l].as<uint64_t>() + slot, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
+  }
+  for (int l = 0; l < nl; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); stream_wait(g->ctx[(size_t)l]); }
+  for (int k = 0; k < n; k++) {
+    uint64_t acc = (uint64_t)g->xpin[0][slot + k];
+    for (int l = 1; l < nl; l++) acc = fold_bits(acc, (uint64_t)g->xpin[(size_t)l][slot + k], dt, op);
+    for (int l = 0; l < nl; l++) g->xpin[(size_t)l][slot + k] = (int64_t)acc;
+  }
+  for (int l = 0; l < nl; l++) {
+    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+    HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, (size_t)n * 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+  }
+}
+
+// slot `slot` of every rank, gathered in rank order -> host vector of `world` values (waits)
+static std::vector<int64_t> exchange_gather(dfdb_group* g, int slot) {
+  const int nl = g->nlocal();
+  std::vector<int64_t> all((size_t)g->world, 0);
+  if (g->exchange == DFDB_EXCHANGE_RCCL) {
+    Rccl& r = rccl();
+    RCCL_CHECK(r.GroupStart());
+    for (int l = 0; l < nl; l++) {
+      uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>();
+      RCCL_CHECK(r.AllGather(p + slot, p + kXSlots, 1, ncclInt64, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+    }
+    RCCL_CHECK(r.GroupEnd());
+    HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+    HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kXSlots, g->xbuf[0].as<uint64_t>() + kXSlots, (size_t)g->world * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    stream_wait(g->ctx[0]);
+    for (int k = 0; k < g->world; k++) all[(size_t)k] = g->xpin[0][kXSlots + k];
+    return all;
+  }
+  for (int l = 0; l < nl; l++) {
+    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+    HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + slot, g->xbuf[(size_t)l].as<uint64_t>() + slot, 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
+  }
+  for (int l = 0; l < nl; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); stream_wait(g->ctx[(size_t)l]); all[(size_t)l] = g->xpin[(size_t)l][slot]; }
+  return all;
+}
+
+// host value -> slot of shard l (stream-ordered)
+static void put_slot(dfdb_group* g, int l, int slot, int64_t v) {
+  g->xpin[(size_t)l][slot] = v;
+  HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+}
+static int64_t get_slot0(dfdb_group* g, int slot, int n, int64_t* out) {   // slots of local shard 0 -> host (waits)
+  HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+  HIP_CHECK(hipMemcpyAsync(g->xpin[0] + slot, g->xbuf[0].as<uint64_t>() + slot, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+  stream_wait(g->ctx[0]);
+  for (int k = 0; k < n; k++) out[k] = g->xpin[0][slot + k];
+  return out[0];
+}
+
+// blocks [first, last) owned by `rank`: g * ceil(nb/G) .. (g+1) * ceil(nb/G), clipped (the rule of dfdb/sharding.py and DESIGN.md §8)
+static void block_range(int64_t nblocks, int rank, int world, int64_t& first, int64_t& last) {
+  const int64_t per = world > 0 ? ceil_div(nblocks, world) : nblocks;
+  first = std::min<int64_t>((int64_t)rank * per, nblocks);
+  last = std::min<int64_t>(first + per, nblocks);
+}
+
+static void group_finish_create(std::unique_ptr<dfdb_group>& g) {
+  group_alloc_exchange(g.get());
+  if (g->nlocal() > 1) {
+    for (int l = 0; l < g->nlocal(); l++) { g->workers.push_back(std::make_unique<Worker>()); g->workers.back()->start(g->ctx[(size_t)l]->device); }
+  }
+}
+
+static void group_destroy(dfdb_group* g) {
+  if (!g) return;
+  for (auto& w : g->workers) w->stop();
+  for (size_t l = 0; l < g->ctx.size(); l++) {
+    (void)hipSetDevice(g->ctx[l]->device);
+    (void)hipStreamSynchronize(g->ctx[l]->stream);
+    if (l < g->comm.size() && g->comm[l]) (void)rccl().CommDestroy(g->comm[l]);
+    if (l < g->xpin.size() && g->xpin[l]) (void)hipHostFree(g->xpin[l]);
+    if (l < g->xbuf.size()) g->xbuf[l].release();
+    ctx_destroy(g->ctx[l]);
+  }
+  delete g;
+}
+
+// ---- stage bases: for every range-like stage that follows another stage, the survivors of the stages before it that live on lower
+// ranks (all-gather + exclusive scan; left to right because a later base depends on the earlier ones being set)
+static void plan_stage_bases(dfdb_gquery* gq) {
+  if (gq->planned) return;
+  dfdb_group* g = gq->gt->g;
+  const size_t ns = gq->shard[0]->stages.size();
+  if (exchanges(g))
+    for (size_t k = 1; k < ns; k++) {
+      if (gq->shard[0]->stages[k].kind == ST_PRED) continue;
+      for_shards(g, [&](int l) {
+        dfdb_query* q = gq->shard[(size_t)l];
+        query_execute(q, (int)k);
+        const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
+        HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 1, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
+        q->executed_stages = -1;   // a partial evaluation is not the view's result
+      });
+      const std::vector<int64_t> counts = exchange_gather(g, 1);
+      int64_t base = 0;
+      for (int r = 0; r < g->first_rank; r++) base += counts[(size_t)r];
+      for (int l = 0; l < g->nlocal(); l++) {
+        dfdb_query* q = gq->shard[(size_t)l];
+        q->stages[k].stage_base = base; q->executed_stages = -1; q->count = -1;
+        base += counts[(size_t)(g->first_rank + l)];
+      }
+    }
+  gq->planned = true;
+}
+
+static void gq_invalidate(dfdb_gquery* gq) { gq->planned = false; gq->count_enqueued = false; gq->count = -1; }
+
+static bool shard_needs_exec(const dfdb_query* q) { return q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows; }
+
+// evaluate the view on every shard and leave the GLOBAL count in slot 0 of every shard's exchange buffer (no host wait with RCCL)
+static void group_count_enqueue(dfdb_gquery* gq) {
+  dfdb_group* g = gq->gt->g;
+  plan_stage_bases(gq);
+  for_shards(g, [&](int l) {
+    dfdb_query* q = gq->shard[(size_t)l];
+    if (shard_needs_exec(q)) query_execute(q, -1);
+    const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
+    HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>(), q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
+  });
+  if (exchanges(g)) exchange_reduce(g, 0, 1, DFDB_I64, DFDB_AGG_SUM);
+  gq->count_enqueued = true; gq->count = -1;
+}
+
+static int64_t group_count(dfdb_gquery* gq) {
+  if (gq->count >= 0) return gq->count;
+  bool stale = !gq->count_enqueued;
+  for (dfdb_query* q : gq->shard) stale = stale || shard_needs_exec(q);
+  if (stale) group_count_enqueue(gq);
+  int64_t n = 0;
+  get_slot0(gq->gt->g, 0, 1, &n);
+  gq->count = n;
+  return n;
+}
+
+}  // namespace dfdb
+
+// =================================================================================================== C ABI
+namespace dfdb { void set_last_error(const char* msg); }   // c_api.cpp: the thread-local text dfdb_last_error returns
+
+template <class F>
+static int32_t gguard(F&& f) noexcept {
+  try { f(); return DFDB_OK; }
+  catch (const Error& e) { set_last_error(e.what()); return e.code; }
+  catch (const std::bad_alloc&) { set_last_error("out of host memory"); return DFDB_ERR_NOMEM; }
+  catch (const std::exception& e) { set_last_error(e.what()); return DFDB_ERR_DEVICE; }
+  catch (...) { set_last_error("unknown error"); return DFDB_ERR_DEVICE; }
+}
+#define GNEED(p) do { if (!(p)) fail(DFDB_ERR_ARGUMENT, "null argument: " #p); } while (0)
+#define GNEEDQ(gq) do { GNEED(gq); if (!(gq)->gt) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); } while (0)
+
+extern "C" {
+
+int32_t dfdb_group_create(const int32_t* device_ids, int32_t n, int32_t exchange, dfdb_group** out) {
+  return gguard([&] {
+    GNEED(out); if (n > 0) GNEED(device_ids);
+    if (n <= 0 || n > 64) fail(DFDB_ERR_ARGUMENT, "a group needs 1..64 devices, got %d", n);
+    bool distinct = true;
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (device_ids[i] == device_ids[j]) distinct = false;
+    if (exchange == DFDB_EXCHANGE_AUTO) exchange = distinct ? DFDB_EXCHANGE_RCCL : DFDB_EXCHANGE_HOST;
+    if (exchange != DFDB_EXCHANGE_RCCL && exchange != DFDB_EXCHANGE_HOST) fail(DFDB_ERR_ARGUMENT, "unknown exchange %d", exchange);
+    if (exchange == DFDB_EXCHANGE_RCCL && !distinct) fail(DFDB_ERR_ARGUMENT, "RCCL needs distinct devices: use DFDB_EXCHANGE_HOST when shards share a GPU");
+    std::unique_ptr<dfdb_group> g(new dfdb_group);
+    g->world = n; g->first_rank = 0; g->exchange = exchange;
+    try {
+      for (int i = 0; i < n; i++) {
+        dfdb_ctx* c = nullptr;
+        const int32_t rc = dfdb_ctx_create(device_ids[i], nullptr, &c);
+        if (rc != DFDB_OK) { char buf[512]; dfdb_last_error(buf, sizeof buf); fail(rc, "%s", buf); }
+        g->ctx.push_back(c);
+      }
+      if (exchange == DFDB_EXCHANGE_RCCL) {
+        g->comm.assign((size_t)n, nullptr);
+        std::vector<int> devs(device_ids, device_ids + n);
+        RCCL_CHECK(rccl().CommInitAll(g->comm.data(), n, devs.data()));
+      }
+      group_finish_create(g);
+    } catch (...) { group_destroy(g.release()); throw; }
+    *out = g.release();
+  });
+}
+
+int32_t dfdb_group_unique_id(uint8_t id[DFDB_GROUP_ID_BYTES]) {
+  return gguard([&] {
+    GNEED(id);
+    static_assert(sizeof(ncclUniqueId) <= DFDB_GROUP_ID_BYTES, "ncclUniqueId grew");
+    ncclUniqueId u; memset(&u, 0, sizeof u);
+    RCCL_CHECK(rccl().GetUniqueId(&u));
+    memset(id, 0, DFDB_GROUP_ID_BYTES); memcpy(id, &u, sizeof u);
+  });
+}
+
+int32_t dfdb_group_create_rank(int32_t device_id, void* hip_stream, const uint8_t id[DFDB_GROUP_ID_BYTES], int32_t rank, int32_t world, dfdb_group** out) {
+  return gguard([&] {
+    GNEED(out);
+    if (world < 1 || rank < 0 || rank >= world) fail(DFDB_ERR_ARGUMENT, "rank %d of %d", rank, world);
+    std::unique_ptr<dfdb_group> g(new dfdb_group);
+    g->world = world; g->first_rank = rank; g->exchange = DFDB_EXCHANGE_RCCL;
+    try {
+      dfdb_ctx* c = nullptr;
+      const int32_t rc = dfdb_ctx_create(device_id, hip_stream, &c);
+      if (rc != DFDB_OK) { char buf[512]; dfdb_last_error(buf, sizeof buf); fail(rc, "%s", buf); }
+      g->ctx.push_back(c);
+      g->comm.assign(1, nullptr);
+      ncclUniqueId u; memset(&u, 0, sizeof u);
+      if (id) memcpy(&u, id, sizeof u);
+      else if (world == 1) RCCL_CHECK(rccl().GetUniqueId(&u));      // a one-rank group needs nobody else's id
+      else fail(DFDB_ERR_ARGUMENT, "null argument: id (dfdb_group_unique_id on rank 0, handed to every rank)");
+      HIP_CHECK(hipSetDevice(device_id));
+      RCCL_CHECK(rccl().CommInitRank(&g->comm[0], world, u, rank));
+      group_finish_create(g);
+    } catch (...) { group_destroy(g.release()); throw; }
+    *out = g.release();
+  });
+}
+
+int32_t dfdb_group_destroy(dfdb_group* g) { return gguard([&] { group_destroy(g); }); }
+
+int32_t dfdb_group_info(dfdb_group* g, int32_t* world, int32_t* nlocal, int32_t* first_rank, int32_t* exchange) {
+  return gguard([&] { GNEED(g); if (world) *world = g->world; if (nlocal) *nlocal = g->nlocal(); if (first_rank) *first_rank = g->first_rank; if (exchange) *exchange = g->exchange; });
+}
+int32_t dfdb_group_ctx(dfdb_group* g, int32_t local, dfdb_ctx** ctx) {
+  return gguard([&] { GNEED(g); GNEED(ctx); if (local < 0 || local >= g->nlocal()) fail(DFDB_ERR_BOUNDS, "BoundsError: local shard %d", local); *ctx = g->ctx[(size_t)local]; });
+}
+int32_t dfdb_group_synchronize(dfdb_group* g) {
+  return gguard([&] { GNEED(g); for (dfdb_ctx* c : g->ctx) { HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipStreamSynchronize(c->stream)); } });
+}
+int32_t dfdb_group_set_option(dfdb_group* g, const char* key, int64_t value) {
+  return gguard([&] { GNEED(g); GNEED(key); for (dfdb_ctx* c : g->ctx) c->options[key] = value; });
+}
+int32_t dfdb_group_barrier(dfdb_group* g) {   // every rank's engine stream has drained, on every rank
+  return gguard([&] {
+    GNEED(g);
+    for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, 2, 1); }
+    if (exchanges(g)) exchange_reduce(g, 2, 1, DFDB_I64, DFDB_AGG_SUM);
+    for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); HIP_CHECK(hipStreamSynchronize(g->ctx[(size_t)l]->stream)); }
+  });
+}
+/* all-reduce of a few caller scalars over the ranks (e.g. the MAX of a per-rank wall time): vals[nlocal][n] in, reduced in place */
+int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t op) {
+  return gguard([&] {
+    GNEED(g); GNEED(vals);
+    if (n < 1 || n > kXSlots - 4) fail(DFDB_ERR_ARGUMENT, "1..%d values", kXSlots - 4);
+    for (int l = 0; l < g->nlocal(); l++) {
+      HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+      for (int k = 0; k < n; k++) { int64_t b; memcpy(&b, &vals[(size_t)l * n + k], 8); put_slot(g, l, 4 + k, b); }
+    }
+    if (exchanges(g)) exchange_reduce(g, 4, n, DFDB_F64, op);
+    for (int l = 0; l < g->nlocal(); l++) {
+      HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+      HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + 4, g->xbuf[(size_t)l].as<uint64_t>() + 4, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
+      stream_wait(g->ctx[(size_t)l]);
+      for (int k = 0; k < n; k++) memcpy(&vals[(size_t)l * n + k], &g->xpin[(size_t)l][4 + k], 8);
+    }
+  });
+}
+
+// ------------------------------------------------------------------ tables
+static dfdb_gtable* new_gtable(dfdb_group* g) { auto* gt = new dfdb_gtable; gt->g = g; gt->shard.assign((size_t)g->nlocal(), nullptr); return gt; }
+static void gtable_free(dfdb_gtable* gt) {
+  if (!gt) return;
+  for (dfdb_gquery* gq : gt->queries) gq->gt = nullptr;
+  for (size_t l = 0; l < gt->shard.size(); l++) if (gt->shard[l]) { (void)hipSetDevice(gt->g->ctx[l]->device); (void)dfdb_table_close(gt->shard[l]); }
+  delete gt;
+}
+static void rethrow_rc(int32_t rc) { if (rc != DFDB_OK) { char buf[1024]; dfdb_last_error(buf, sizeof buf); fail(rc, "%s", buf); } }
+
+int32_t dfdb_group_table_open(dfdb_group* g, const char* path, dfdb_gtable** out) {
+  return gguard([&] {
+    GNEED(g); GNEED(path); GNEED(out);
+    std::unique_ptr<dfdb_gtable, void (*)(dfdb_gtable*)> gt(new_gtable(g), gtable_free);
+    for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); table_open(g->ctx[(size_t)l], path, &gt->shard[(size_t)l]); }
+    *out = gt.release();
+  });
+}
+int32_t dfdb_group_table_new(dfdb_group* g, int64_t block_size, dfdb_gtable** out) {
+  return gguard([&] {
+    GNEED(g); GNEED(out);
+    std::unique_ptr<dfdb_gtable, void (*)(dfdb_gtable*)> gt(new_gtable(g), gtable_free);
+    for (int l = 0; l < g->nlocal(); l++) rethrow_rc(dfdb_table_new(g->ctx[(size_t)l], block_size, &gt->shard[(size_t)l]));
+    *out = gt.release();
+  });
+}
+int32_t dfdb_group_table_close(dfdb_gtable* gt) { return gguard([&] { gtable_free(gt); }); }
+int32_t dfdb_group_table_shard(dfdb_gtable* gt, int32_t local, dfdb_table** t) {
+  return gguard([&] { GNEED(gt); GNEED(t); if (local < 0 || (size_t)local >= gt->shard.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: local shard %d", local); *t = gt->shard[(size_t)local]; });
+}
+int32_t dfdb_group_table_nrows(dfdb_gtable* gt, int64_t* total) { return gguard([&] { GNEED(gt); GNEED(total); *total = gt->total_rows < 0 ? 0 : gt->total_rows; }); }
+
+/* every shard loads its block range of the listed columns (NULL = all): dfdb_table_load(block_range(nblocks, rank, world)) */
+int32_t dfdb_group_table_load(dfdb_gtable* gt, const int32_t* ordinals, int32_t ncols, dfdb_sizestats* stats) {
+  return gguard([&] {
+    GNEED(gt);
+    dfdb_group* g = gt->g;
+    dfdb_table* t0 = gt->shard[0];
+    if (t0->cols.empty()) fail(DFDB_ERR_ARGUMENT, "the table has no columns");
+    // the block count comes from the headers of one column (every column shares the block boundaries)
+    const int32_t probe = ordinals && ncols > 0 ? ordinals[0] : 0;
+    dfdb_sizestats hs{0, 0, 0};
+    table_column_stats(t0, probe, &hs);
+    const int64_t nblocks = ceil_div(hs.rows, t0->block_size);
+    std::vector<dfdb_sizestats> st((size_t)g->nlocal(), dfdb_sizestats{0, 0, 0});
+    for_shards(g, [&](int l) {
+      int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+      table_load(gt->shard[(size_t)l], ordinals, ncols, b0, b1, &st[(size_t)l]);
+      gt->shard[(size_t)l]->row_base = b0 * t0->block_size;
+    });
+    gt->total_rows = hs.rows;
+    if (stats) { *stats = dfdb_sizestats{0, 0, 0}; for (auto& s : st) { stats->rows += s.rows; stats->compressed += s.compressed; stats->uncompressed += s.uncompressed; } }
+  });
+}
+
+/* synthetic column of nrows_total rows: every shard generates the rows of its block range on its own device */
+int32_t dfdb_group_table_add_generated(dfdb_gtable* gt, const char* name, int32_t generator, uint64_t seed, int64_t nrows_total) {
+  return gguard([&] {
+    GNEED(gt); GNEED(name);
+    if (nrows_total < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
+    if (gt->total_rows >= 0 && gt->total_rows != nrows_total) fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table has %lld", (long long)nrows_total, (long long)gt->total_rows);
+    dfdb_group* g = gt->g;
+    const int64_t bs = gt->shard[0]->block_size, nblocks = ceil_div(nrows_total, bs);
+    for_shards(g, [&](int l) {
+      int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+      const int64_t r0 = std::min(b0 * bs, nrows_total), r1 = std::min(b1 * bs, nrows_total);
+      table_add_generated(gt->shard[(size_t)l], name, generator, seed, r0, r1 - r0);
+      gt->shard[(size_t)l]->row_base = r0; gt->shard[(size_t)l]->block_first = b0;
+    });
+    gt->total_rows = nrows_total;
+  });
+}
+
+/* caller-supplied decoded column of the WHOLE table (host memory, layout of dfdb_table_add_column): every shard uploads the rows
+ * of its block range */
+int32_t dfdb_group_table_add_column(dfdb_gtable* gt, const char* name, int32_t dtype, int64_t nrows_total, const void* data, const uint8_t* bytes,
+                                    int64_t nbytes, const uint8_t* missing) {
+  return gguard([&] {
+    GNEED(gt); GNEED(name); if (nrows_total > 0) GNEED(data);
+    if (nrows_total < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
+    if (gt->total_rows >= 0 && gt->total_rows != nrows_total) fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table has %lld", (long long)nrows_total, (long long)gt->total_rows);
+    dfdb_group* g = gt->g;
+    const int64_t bs = gt->shard[0]->block_size, nblocks = ceil_div(nrows_total, bs);
+    const bool is_str = dt_base(dtype) == DFDB_STRING;
+    const int w = is_str ? 4 : dt_width(dtype);
+    // byte offset of every local shard's first row inside the arena (String columns)
+    std::vector<int64_t> r0s((size_t)g->nlocal()), r1s((size_t)g->nlocal()), boff((size_t)g->nlocal() + 1, 0);
+    for (int l = 0; l < g->nlocal(); l++) {
+      int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+      r0s[(size_t)l] = std::min(b0 * bs, nrows_total); r1s[(size_t)l] = std::min(b1 * bs, nrows_total);
+    }
+    if (is_str) {
+      const int32_t* sz = (const int32_t*)data;
+      int64_t acc = 0, r = 0;
+      for (int l = 0; l < g->nlocal(); l++) {
+        for (; r < r0s[(size_t)l]; r++) acc += sz[r] > 0 ? sz[r] : 0;
+        boff[(size_t)l] = acc;
+      }
+      for (; r < r1s[(size_t)g->nlocal() - 1]; r++) acc += sz[r] > 0 ? sz[r] : 0;
+      boff[(size_t)g->nlocal()] = acc;
+      if (acc > nbytes) fail(DFDB_ERR_ARGUMENT, "string sizes sum to %lld bytes but the arena holds %lld", (long long)acc, (long long)nbytes);
+    }
+    for_shards(g, [&](int l) {
+      const int64_t r0 = r0s[(size_t)l], n = r1s[(size_t)l] - r0;
+      const int64_t nb = is_str ? boff[(size_t)l + 1] - boff[(size_t)l] : 0;
+      table_add_column(gt->shard[(size_t)l], name, dtype, n, (const char*)data + r0 * w, is_str && bytes ? bytes + boff[(size_t)l] : bytes, nb, missing ? missing + r0 : nullptr);
+      gt->shard[(size_t)l]->row_base = r0; gt->shard[(size_t)l]->block_first = r0 / bs;
+    });
+    gt->total_rows = nrows_total;
+  });
+}
+
+// ------------------------------------------------------------------ queries
+static void gquery_free(dfdb_gquery* gq) {
+  if (!gq) return;
+  if (gq->gt) {
+    auto& v = gq->gt->queries;
+    for (size_t i = 0; i < v.size(); i++) if (v[i] == gq) { v[i] = v.back(); v.pop_back(); break; }
+    for (size_t l = 0; l < gq->shard.size(); l++) if (gq->shard[l]) { (void)hipSetDevice(gq->gt->g->ctx[l]->device); (void)dfdb_query_free(gq->shard[l]); }
+  } else for (dfdb_query* q : gq->shard) if (q) (void)dfdb_query_free(q);
+  delete gq;
+}
+
+int32_t dfdb_group_query_new(dfdb_gtable* gt, dfdb_gquery** out) {
+  return gguard([&] {
+    GNEED(gt); GNEED(out);
+    std::unique_ptr<dfdb_gquery, void (*)(dfdb_gquery*)> gq(new dfdb_gquery, gquery_free);
+    gq->gt = gt; gq->shard.assign(gt->shard.size(), nullptr);
+    gt->queries.push_back(gq.get());
+    for (size_t l = 0; l < gt->shard.size(); l++) rethrow_rc(dfdb_query_new(gt->shard[l], &gq->shard[l]));
+    *out = gq.release();
+  });
+}
+int32_t dfdb_group_query_free(dfdb_gquery* gq) { return gguard([&] { gquery_free(gq); }); }
+int32_t dfdb_group_query_shard(dfdb_gquery* gq, int32_t local, dfdb_query** q) {
+  return gguard([&] { GNEEDQ(gq); GNEED(q); if (local < 0 || (size_t)local >= gq->shard.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: local shard %d", local); *q = gq->shard[(size_t)local]; });
+}
+// the composition rules (selection.jl:37-60) are applied per shard by the single-GPU entry points; a stage the first shard rejects
+// (BoundsError, ArgumentError) is rejected before any other shard saw it, so the shards never diverge
+int32_t dfdb_group_query_add_range(dfdb_gquery* gq, int64_t start, int64_t step, int64_t stop) {
+  return gguard([&] { GNEEDQ(gq); gq_invalidate(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_add_range(q, start, step, stop)); });
+}
+int32_t dfdb_group_query_add_indices(dfdb_gquery* gq, const int64_t* idx, int64_t n) {
+  return gguard([&] { GNEEDQ(gq); gq_invalidate(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_add_indices(q, idx, n)); });
+}
+int32_t dfdb_group_query_add_integer(dfdb_gquery* gq, int64_t i) {
+  return gguard([&] { GNEEDQ(gq); gq_invalidate(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_add_integer(q, i)); });
+}
+int32_t dfdb_group_query_add_predicate(dfdb_gquery* gq, const uint8_t* ir, size_t len) {
+  return gguard([&] { GNEEDQ(gq); gq_invalidate(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_add_predicate(q, ir, len)); });
+}
+int32_t dfdb_group_query_set_projection(dfdb_gquery* gq, int32_t n, const char* const* names, const uint8_t* const* irs, const size_t* lens) {
+  return gguard([&] { GNEEDQ(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_set_projection(q, n, names, irs, lens)); });
+}
+int32_t dfdb_group_query_hint_aggregate(dfdb_gquery* gq, int32_t op, int32_t proj_col) {
+  return gguard([&] { GNEEDQ(gq); for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_hint_aggregate(q, op, proj_col)); });
+}
+int32_t dfdb_group_query_hint_materialize(dfdb_gquery* gq, int32_t on) {
+  return gguard([&] { GNEEDQ(gq); gq->count_enqueued = false; gq->count = -1; for (dfdb_query* q : gq->shard) rethrow_rc(dfdb_query_hint_materialize(q, on)); });
+}
+int32_t dfdb_group_query_reset(dfdb_gquery* gq) {
+  return gguard([&] { GNEEDQ(gq); gq->count_enqueued = false; gq->count = -1; for (dfdb_query* q : gq->shard) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; } });
+}
+
+/* nrow(v) over the whole table: per-shard scans, the stage-base exchanges a range-after-predicate needs, one all-reduce.
+ * n == NULL: only enqueue (no host wait; the reduced count stays on the devices until a later call asks for it) */
+int32_t dfdb_group_count(dfdb_gquery* gq, int64_t* n) {
+  return gguard([&] { GNEEDQ(gq); if (!n) { group_count_enqueue(gq); return; } *n = group_count(gq); });
+}
+/* selected rows on every rank, in rank order (world values): what a caller needs to place sharded results */
+int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts) {
+  return gguard([&] {
+    GNEEDQ(gq); GNEED(counts);
+    dfdb_group* g = gq->gt->g;
+    group_count(gq);
+    for_shards(g, [&](int l) {
+      dfdb_query* q = gq->shard[(size_t)l];
+      const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
+      HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 1, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
+    });
+    const std::vector<int64_t> all = exchange_gather(g, 1);
+    for (int r = 0; r < g->world; r++) counts[r] = all[(size_t)r];
+  });
+}
+
+/* sum / minimum / maximum / count of projection column i over the whole table (exact for integers: wrapping 64-bit sums are
+ * associative; Float64 sums add the per-GPU partial sums, within the tolerance of DESIGN.md §5) */
+int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
+  return gguard([&] {
+    GNEEDQ(gq);
+    dfdb_group* g = gq->gt->g;
+    if (op == DFDB_AGG_COUNT) { const int64_t n = group_count(gq); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
+    if (op != DFDB_AGG_SUM && op != DFDB_AGG_MIN && op != DFDB_AGG_MAX) fail(DFDB_ERR_ARGUMENT, "unknown aggregate %d", op);
+    plan_stage_bases(gq);
+    std::vector<int> dts((size_t)g->nlocal(), DFDB_I64);
+    for_shards(g, [&](int l) {
+      dfdb_query* q = gq->shard[(size_t)l];
+      dts[(size_t)l] = query_aggregate_device(q, op, i);          // {value, count} in q->red_result, identity when the shard selects nothing
+      HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 8, q->red_result.p, 16, hipMemcpyDeviceToDevice, q->t->ctx->stream));
+    });
+    const int dt = dts[0];
+    int64_t res[2] = {0, 0};
+    if (exchanges(g)) {
+      if (dt == DFDB_F64 && op != DFDB_AGG_SUM && g->exchange == DFDB_EXCHANGE_RCCL) {
+        // Julia's minimum / maximum propagate NaN, ncclMin / ncclMax need not: gather the per-rank partials and fold them on the host
+        const std::vector<int64_t> vals = exchange_gather(g, 8);
+        uint64_t acc = (uint64_t)vals[0];
+        for (int r = 1; r < g->world; r++) acc = fold_bits(acc, (uint64_t)vals[(size_t)r], DFDB_F64, op);
+        exchange_reduce(g, 9, 1, DFDB_I64, DFDB_AGG_SUM);
+        get_slot0(g, 9, 1, &res[1]);
+        res[0] = (int64_t)acc;
+      } else {
+        exchange_reduce(g, 8, 1, dt, op);
+        exchange_reduce(g, 9, 1, DFDB_I64, DFDB_AGG_SUM);
+        get_slot0(g, 8, 2, res);
+      }
+    } else get_slot0(g, 8, 2, res);
+    if (res[1] == 0 && op != DFDB_AGG_SUM) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
+    if (dt == DFDB_F64) { double d; memcpy(&d, &res[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
+    else { if (out_i) *out_i = res[0]; if (out_f) *out_f = dt == DFDB_U64 ? (double)(uint64_t)res[0] : (double)res[0]; }
+  });
+}
+
+/* ascending 1-based TABLE row numbers of the local shards' selected rows, each shard into its own DEVICE buffer
+ * (outs[l], caps[l]); asynchronous */
+int32_t dfdb_group_select_indices_device(dfdb_gquery* gq, int64_t* const* outs, const int64_t* caps) {
+  return gguard([&] {
+    GNEEDQ(gq); GNEED(outs); GNEED(caps);
+    plan_stage_bases(gq);
+    for_shards(gq->gt->g, [&](int l) { query_select_indices(gq->shard[(size_t)l], outs[l], caps[l], DFDB_MEM_DEVICE, nullptr); });
+  });
+}
+/* the same into ONE host buffer: the local shards' row numbers concatenated in rank order (= table order).  *n = rows written
+ * by this process; a one-process group therefore gets the whole result */
+int32_t dfdb_group_select_indices(dfdb_gquery* gq, int64_t* out, int64_t cap, int64_t* n) {
+  return gguard([&] {
+    GNEEDQ(gq); if (cap > 0) GNEED(out);
+    dfdb_group* g = gq->gt->g;
+    plan_stage_bases(gq);
+    std::vector<int64_t> cnt((size_t)g->nlocal(), 0), base((size_t)g->nlocal() + 1, 0);
+    for_shards(g, [&](int l) { cnt[(size_t)l] = query_count(gq->shard[(size_t)l], -1); });
+    for (int l = 0; l < g->nlocal(); l++) base[(size_t)l + 1] = base[(size_t)l] + cnt[(size_t)l];
+    if (n) *n = base[(size_t)g->nlocal()];
+    for_shards(g, [&](int l) {
+      const int64_t room = std::max<int64_t>(0, std::min(cnt[(size_t)l], cap - base[(size_t)l]));
+      if (room > 0) query_select_indices(gq->shard[(size_t)l], out + base[(size_t)l], room, DFDB_MEM_HOST, nullptr);
+    });
+  });
+}
+
+/* string bytes projection column i needs over the local shards */
+int32_t dfdb_group_result_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbytes) {
+  return gguard([&] {
+    GNEEDQ(gq); GNEED(nbytes);
+    dfdb_group* g = gq->gt->g;
+    plan_stage_bases(gq);
+    std::vector<int64_t> nb((size_t)g->nlocal(), 0);
+    for_shards(g, [&](int l) { nb[(size_t)l] = query_string_bytes(gq->shard[(size_t)l], i); });
+    *nbytes = 0; for (int64_t b : nb) *nbytes += b;
+  });
+}
+
+/* materialize(v) into caller-owned HOST buffers sized for the local shards' rows (dfdb_group_count for a one-process group):
+ * every shard writes its rows at its rank-order offset, so the buffers hold the view in table order */
+int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols) {
+  return gguard([&] {
+    GNEEDQ(gq); if (ncols > 0) GNEED(outs);
+    dfdb_group* g = gq->gt->g;
+    const int nl = g->nlocal();
+    for (int32_t p = 0; p < ncols; p++) if (outs[p].memkind != DFDB_MEM_HOST) fail(DFDB_ERR_ARGUMENT, "dfdb_group_materialize writes host buffers (use the shard queries for device outputs)");
+    plan_stage_bases(gq);
+    std::vector<int64_t> cnt((size_t)nl, 0), base((size_t)nl + 1, 0);
+    std::vector<std::vector<int64_t>> sb((size_t)nl, std::vector<int64_t>((size_t)ncols, 0));
+    for_shards(g, [&](int l) {
+      dfdb_query* q = gq->shard[(size_t)l];
+      if (ncols != (int32_t)q->proj.size()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: view has %zu columns, %d outputs given", q->proj.size(), ncols);
+      cnt[(size_t)l] = query_count(q, -1);
+      for (int32_t p = 0; p < ncols; p++) if (dt_base(q->proj[(size_t)p].expr->dtype) == DFDB_STRING) sb[(size_t)l][(size_t)p] = query_string_bytes(q, p);
+    });
+    for (int l = 0; l < nl; l++) base[(size_t)l + 1] = base[(size_t)l] + cnt[(size_t)l];
+    std::vector<std::vector<int64_t>> boff((size_t)nl + 1, std::vector<int64_t>((size_t)ncols, 0));
+    for (int l = 0; l < nl; l++) for (int32_t p = 0; p < ncols; p++) boff[(size_t)l + 1][(size_t)p] = boff[(size_t)l][(size_t)p] + sb[(size_t)l][(size_t)p];
+    for (int32_t p = 0; p < ncols; p++)
+      if (boff[(size_t)nl][(size_t)p] > outs[p].bytes_cap && boff[(size_t)nl][(size_t)p] > 0)
+        fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)boff[(size_t)nl][(size_t)p], (long long)outs[p].bytes_cap);
+    std::vector<std::vector<dfdb_outcol>> so((size_t)nl, std::vector<dfdb_outcol>((size_t)ncols));
+    for_shards(g, [&](int l) {
+      dfdb_query* q = gq->shard[(size_t)l];
+      for (int32_t p = 0; p < ncols; p++) {
+        dfdb_outcol o = outs[p];
+        const int32_t dt = q->proj[(size_t)p].expr->dtype;
+        const int w = dt_base(dt) == DFDB_STRING ? 4 : dt_width(dt);
+        if (o.data) o.data = (char*)o.data + base[(size_t)l] * w;
+        if (o.bytes) { o.bytes += boff[(size_t)l][(size_t)p]; o.bytes_cap = sb[(size_t)l][(size_t)p]; }
+        if (o.missing) o.missing += base[(size_t)l];
+        so[(size_t)l][(size_t)p] = o;
+      }
+      query_materialize(q, so[(size_t)l].data(), ncols);
+    });
+    for (int32_t p = 0; p < ncols; p++) {
+      outs[p].dtype = so[0][(size_t)p].dtype; outs[p].count = base[(size_t)nl]; outs[p].nbytes = boff[(size_t)nl][(size_t)p];
+    }
+  });
+}
+
+}  // extern "C"

@@ -641,19 +641,19 @@ void query_unique(dfdb_query* q, int32_t p) {
   HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
 }
 
-void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
+// the device half of an aggregate: leaves {value, selected count} (16 bytes) of sum / min / max over projection column i in
+// q->red_result on the engine stream and returns the accumulator dtype (DFDB_I64 / DFDB_U64 / DFDB_F64).  No host wait: the group
+// layer (group.cpp) hands the 16 bytes to the RCCL all-reduce as they are; an empty selection leaves the identity of `op`.
+int query_aggregate_device(dfdb_query* q, int32_t op, int32_t i) {
   ensure_executed(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  if (op == DFDB_AGG_COUNT) { const int64_t n = query_count(q, -1); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
   if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
   const Node& e = *q->proj[(size_t)i].expr;
   if (!dt_isnum(e.dtype) || dt_nullable(e.dtype)) fail(DFDB_ERR_UNSUPPORTED, "aggregate over %s is not supported", dt_name(e.dtype).c_str());
-  const void* src; DevBuf full; int dt = dt_base(e.dtype);
-  const uint64_t* mask = q->bitmap.as<uint64_t>();
-  DevBuf ones;
+  int dt = dt_base(e.dtype);
+  q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
   if (op == q->agg_op && e.op == DFIR_COL && q->agg_col == e.col && q->executed_stages == (int)q->stages.size()) {
     // the scan already reduced the selected values of this column per tile (k_scan_terms EXTRA = 2 / 3 / 4): reduce the partials
-    if (op != DFDB_AGG_SUM && query_count(q, -1) == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
     const int64_t nt = ceil_div(t->nrows, kTileRows);
     if (q->agg_ones_tiles != nt) {
       q->agg_ones.ensure(padded_words(nt) * 8);
@@ -664,13 +664,14 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
       q->agg_ones_tiles = nt;
     }
     dt = q->agg_dtype == DFDB_F64 ? DFDB_F64 : (q->agg_dtype == DFDB_U64 ? DFDB_U64 : DFDB_I64);
-    q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
     { LaunchTimer lt(ctx, "reduce_partials"); launch_reduce(s, q->agg_ones.as<uint64_t>(), q->agg_partials.p, dt, op, nt, q->red_scratch.p, q->red_result.p); }
-    goto readback;
-  }
-  if (e.op == DFIR_COL) src = need_resident(t, e.col).data.p;
-  else {   // computed column: materialise the selected values, then reduce them all
+    // the count slot of the partial reduce counts TILES: the selected rows are the scan total
+    HIP_CHECK(hipMemcpyAsync((uint64_t*)q->red_result.p + 1, q->prefix.as<uint64_t>() + nt, 8, hipMemcpyDeviceToDevice, s));
+  } else if (e.op == DFIR_COL) {
+    { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, q->bitmap.as<uint64_t>(), need_resident(t, e.col).data.p, dt, op, t->nrows, q->red_scratch.p, q->red_result.p); }
+  } else {   // computed column: materialise the selected values, then reduce them all
     const int64_t cnt = query_count(q, -1);
+    DevBuf &full = q->tmp_b, &ones = q->tmp_c;
     full.ensure((size_t)std::max<int64_t>(cnt, 1) * dt_width(dt) + 256);
     if (cnt) run_interp_project(q, e, full.p, cnt, nullptr);
     const size_t nw = padded_words(cnt);
@@ -679,18 +680,19 @@ void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, doubl
     uint64_t tail = (cnt & 63) ? ((1ull << (cnt & 63)) - 1ull) : 0ull;
     HIP_CHECK(hipMemcpyAsync((uint64_t*)ones.p + cnt / 64, &tail, 8, hipMemcpyHostToDevice, s));
     stream_wait(q->t->ctx);
-    src = full.p; mask = ones.as<uint64_t>();
-    q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
-    { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, cnt, q->red_scratch.p, q->red_result.p); }
-    goto readback;
+    { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, ones.as<uint64_t>(), full.p, dt, op, cnt, q->red_scratch.p, q->red_result.p); }
   }
-  q->red_scratch.ensure(reduce_scratch_bytes()); q->red_result.ensure(64);
-  { LaunchTimer lt(ctx, "reduce"); launch_reduce(s, mask, src, dt, op, t->nrows, q->red_scratch.p, q->red_result.p); }
-readback:
-  HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->red_result.p, 16, hipMemcpyDeviceToHost, s));
-  stream_wait(q->t->ctx);
+  return dt_isfloat(dt) ? DFDB_F64 : (dt == DFDB_U64 ? DFDB_U64 : DFDB_I64);
+}
+
+void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
+  if (op == DFDB_AGG_COUNT) { const int64_t n = query_count(q, -1); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
+  const int dt = query_aggregate_device(q, op, i);
+  dfdb_ctx* ctx = q->t->ctx;
+  HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->red_result.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  stream_wait(ctx);
   if (ctx->pinned_scalar[1] == 0 && op != DFDB_AGG_SUM) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
-  if (dt_isfloat(dt)) { double d; memcpy(&d, &ctx->pinned_scalar[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
+  if (dt == DFDB_F64) { double d; memcpy(&d, &ctx->pinned_scalar[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
   else { const int64_t v = ctx->pinned_scalar[0]; if (out_i) *out_i = v; if (out_f) *out_f = dt == DFDB_U64 ? (double)(uint64_t)v : (double)v; }
 }
 

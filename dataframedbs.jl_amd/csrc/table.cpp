@@ -295,6 +295,10 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
   }
   if (t->nrows < 0) { t->nrows = nrows; t->block_first = block_first; t->row_base = block_first * t->block_size; }
   c.resident = true;
+  if (!is_str && !is_null && nb && ctx_option(ctx, "keep_compressed", 0) != 0) {   // the compressed blocks stay: dfdb_table_decode_resident
+    HIP_CHECK(hipStreamSynchronize(s));
+    c.comp = std::move(staged); c.comp_blocks = std::move(dblocks); c.comp_status = std::move(dstatus); c.comp_nblocks = nb;
+  }
   if (!t->keep_load_scratch) { HIP_CHECK(hipStreamSynchronize(s)); staged.release(); bodies.release(); dblocks.release(); dstatus.release(); d_aux.release(); }
   if (stats) {   // SizeStats incl. the 24-byte header quirk (BlockStreams.jl:7,23)
     stats->rows = nrows;
@@ -393,6 +397,18 @@ static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_
   }
   if (walk && pos != hi) fail(DFDB_ERR_FORMAT, "truncated block header");
   decode_staged(t, c, hs.data(), (int64_t)hs.size(), block_first, lo, stats);
+}
+
+// K7 again over the compressed blocks a column kept at load time (option "keep_compressed"): every block of the column decoded into
+// its resident array, asynchronously.  What a query over a compressed-resident column pays before its scan.
+void table_decode_resident(dfdb_table* t, int32_t ordinal) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  if (!c.comp_nblocks) fail(DFDB_ERR_ARGUMENT, "column %s holds no compressed blocks (load it with option keep_compressed = 1)", c.name.c_str());
+  dfdb_ctx* ctx = t->ctx;
+  for (dfdb_query* q : t->queries) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }
+  LaunchTimer lt(ctx, "lz4_decode");
+  launch_lz4_decode(ctx->stream, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>());
 }
 
 void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,

@@ -51,13 +51,24 @@ SYMBOLS = [
     "dfdb_ctx_timer_stop", "dfdb_ctx_set_option", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
     "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",
     "dfdb_table_colinfo", "dfdb_table_find_column", "dfdb_table_load", "dfdb_table_load_image", "dfdb_table_add_column",
-    "dfdb_table_add_generated", "dfdb_table_set_row_base", "dfdb_table_set_logical_type", "dfdb_table_column_stats", "dfdb_table_add_from_query", "dfdb_table_save", "dfdb_table_save_column", "dfdb_query_hint_materialize", "dfdb_query_hint_aggregate", "dfdb_query_unique", "dfdb_stream_open", "dfdb_stream_next", "dfdb_stream_stats", "dfdb_stream_close",
+    "dfdb_table_add_generated", "dfdb_table_decode_resident", "dfdb_table_set_row_base", "dfdb_table_set_logical_type", "dfdb_table_column_stats", "dfdb_table_add_from_query", "dfdb_table_save", "dfdb_table_save_column", "dfdb_query_hint_materialize", "dfdb_query_hint_aggregate", "dfdb_query_unique", "dfdb_stream_open", "dfdb_stream_next", "dfdb_stream_stats", "dfdb_stream_close",
     "dfdb_query_new", "dfdb_query_free", "dfdb_query_add_range", "dfdb_query_add_indices", "dfdb_query_add_integer",
     "dfdb_query_add_predicate", "dfdb_query_nstages", "dfdb_query_set_projection", "dfdb_query_ncols", "dfdb_query_coltype",
     "dfdb_expr_result_type", "dfdb_query_set_stage_base", "dfdb_query_count_prefix",
     "dfdb_query_execute", "dfdb_query_reset", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
     "dfdb_materialize", "dfdb_aggregate",
+    # multi-GPU groups (block-range shards + RCCL)
+    "dfdb_group_create", "dfdb_group_unique_id", "dfdb_group_create_rank", "dfdb_group_destroy", "dfdb_group_info", "dfdb_group_ctx",
+    "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_set_option", "dfdb_group_allreduce_f64",
+    "dfdb_group_table_open", "dfdb_group_table_new", "dfdb_group_table_close", "dfdb_group_table_load", "dfdb_group_table_add_generated",
+    "dfdb_group_table_add_column", "dfdb_group_table_nrows", "dfdb_group_table_shard",
+    "dfdb_group_query_new", "dfdb_group_query_free", "dfdb_group_query_add_range", "dfdb_group_query_add_indices", "dfdb_group_query_add_integer",
+    "dfdb_group_query_add_predicate", "dfdb_group_query_set_projection", "dfdb_group_query_hint_aggregate", "dfdb_group_query_hint_materialize",
+    "dfdb_group_query_reset", "dfdb_group_query_shard", "dfdb_group_count", "dfdb_group_shard_counts", "dfdb_group_aggregate",
+    "dfdb_group_select_indices_device", "dfdb_group_select_indices", "dfdb_group_result_string_bytes", "dfdb_group_materialize",
 ]
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
+GROUP_ID_BYTES = 128
 
 _lib = None
 
@@ -77,6 +88,7 @@ def load() -> C.CDLL:
         lib.dfdb_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
         lib.dfdb_table_load_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p]
         lib.dfdb_table_set_row_base.argtypes = [C.c_void_p, C.c_int64]
+        lib.dfdb_table_decode_resident.argtypes = [C.c_void_p, C.c_int32]
         lib.dfdb_table_set_logical_type.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
         lib.dfdb_table_column_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SizeStats)]
         lib.dfdb_table_add_from_query.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]
@@ -100,6 +112,38 @@ def load() -> C.CDLL:
         lib.dfdb_select_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         lib.dfdb_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dfdb_ctx_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        lib.dfdb_group_unique_id.argtypes = [C.c_void_p]
+        lib.dfdb_group_create_rank.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        lib.dfdb_group_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        lib.dfdb_group_ctx.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.dfdb_group_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        lib.dfdb_group_table_open.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        lib.dfdb_group_table_new.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dfdb_group_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_table_add_generated.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_uint64, C.c_int64]
+        lib.dfdb_group_table_add_column.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dfdb_group_table_nrows.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_table_shard.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_query_new.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_query_add_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+        lib.dfdb_group_query_add_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        lib.dfdb_group_query_add_integer.argtypes = [C.c_void_p, C.c_int64]
+        lib.dfdb_group_query_add_predicate.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.dfdb_group_query_set_projection.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_query_hint_aggregate.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.dfdb_group_query_hint_materialize.argtypes = [C.c_void_p, C.c_int32]
+        lib.dfdb_group_query_shard.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_count.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_shard_counts.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_aggregate.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_select_indices_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_select_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dfdb_group_result_string_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_materialize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        for f in ("dfdb_group_destroy", "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_table_close", "dfdb_group_query_free", "dfdb_group_query_reset"):
+            getattr(lib, f).argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 

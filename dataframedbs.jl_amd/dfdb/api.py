@@ -354,6 +354,10 @@ class DFTable:
         N.check(N.load().dfdb_table_load_image(self._h, self.ordinal(column), image, len(image), block_first, block_last, C.byref(st)))
         return dict(rows=st.rows, compressed=st.compressed, uncompressed=st.uncompressed)
 
+    def decode_resident(self, column: str):
+        """K7 over the LZ4 blocks the column kept in HBM (ctx option keep_compressed at load time), asynchronously"""
+        N.check(N.load().dfdb_table_decode_resident(self._h, self.ordinal(column)))
+
     def set_row_base(self, row_base: int): N.check(N.load().dfdb_table_set_row_base(self._h, row_base))
 
     def add_column_from(self, name: str, col) -> None:

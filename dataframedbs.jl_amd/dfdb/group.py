@@ -1,0 +1,326 @@
+"""Multi-GPU groups: one table block-range sharded over the GPUs of a node, through the C ABI (include/dfdb.h, "multi-GPU groups").
+
+The lazy algebra is unchanged: `GroupTable.view()` is an ordinary DFView (built over the metadata of shard 0), and
+`gnrow / gindices / gmaterialize / gaggregate` replay its SelectionQueue and Projection onto a group query, the way
+`nrow / materialize` (view.jl:192-206, materialization.jl:27-40) do for one GPU.  The exchanges (all-reduce of the count /
+aggregate over RCCL, all-gather + exclusive scan for a range stage after a predicate) happen inside libdfdb_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from . import api, ir
+
+
+class Group:
+    """dfdb_group: `Group.create([0, 1, ...])` = one process drives the GPUs; `Group.create_rank(...)` = one process per GPU."""
+
+    def __init__(self, handle):
+        self._h = handle
+        w, nl, fr, ex = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(N.load().dfdb_group_info(self._h, C.byref(w), C.byref(nl), C.byref(fr), C.byref(ex)))
+        self.world, self.nlocal, self.first_rank, self.exchange = w.value, nl.value, fr.value, ex.value
+
+    @classmethod
+    def create(cls, devices: Sequence[int], exchange: int = N.EXCHANGE_AUTO) -> "Group":
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_create(devs, len(devices), exchange, C.byref(h)))
+        return cls(h)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(N.GROUP_ID_BYTES)
+        N.check(N.load().dfdb_group_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def create_rank(cls, device: int, uid: Optional[bytes], rank: int, world: int, stream: Optional[int] = None) -> "Group":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(uid, N.GROUP_ID_BYTES) if uid is not None else None
+        N.check(N.load().dfdb_group_create_rank(device, C.c_void_p(stream) if stream else None, buf, rank, world, C.byref(h)))
+        return cls(h)
+
+    def ctx(self, local: int = 0) -> api.Context:
+        """borrowed Context of one local shard (profiling, options, device info)"""
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_ctx(self._h, local, C.byref(h)))
+        c = api.Context.__new__(api.Context)
+        c._h, c.device = h, -1
+        c.close = lambda: None          # owned by the group
+        return c
+
+    def synchronize(self): N.check(N.load().dfdb_group_synchronize(self._h))
+
+    def barrier(self): N.check(N.load().dfdb_group_barrier(self._h))
+
+    def set_option(self, key: str, value: int): N.check(N.load().dfdb_group_set_option(self._h, key.encode(), value))
+
+    def allreduce(self, vals: Sequence[Sequence[float]], op: int = N.AGG_SUM) -> List[List[float]]:
+        """vals[local shard][k] -> reduced over every rank"""
+        n = len(vals[0])
+        a = np.ascontiguousarray(vals, np.float64).reshape(self.nlocal, n)
+        N.check(N.load().dfdb_group_allreduce_f64(self._h, a.ctypes.data, n, op))
+        return a.tolist()
+
+    def close(self):
+        if self._h:
+            N.load().dfdb_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class _ShardTable(api.DFTable):
+    """the ordinary handle of one shard, borrowed from the group table (metadata, per-shard queries); never closed from here"""
+
+    def close(self):
+        object.__setattr__(self, "_h", C.c_void_p())
+        object.__setattr__(self, "is_opened", False)
+
+
+class GroupTable:
+    def __init__(self, handle, group: Group, path: str = ""):
+        self._h, self.group, self.path = handle, group, path
+
+    @classmethod
+    def new(cls, group: Group, block_size: int = 65536) -> "GroupTable":
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_table_new(group._h, block_size, C.byref(h)))
+        return cls(h, group)
+
+    @classmethod
+    def open(cls, group: Group, path: str, load: bool = True, columns: Optional[Sequence[str]] = None) -> "GroupTable":
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_table_open(group._h, path.encode(), C.byref(h)))
+        t = cls(h, group, path)
+        if load:
+            t.load(columns)
+        return t
+
+    def shard(self, local: int = 0) -> api.DFTable:
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_table_shard(self._h, local, C.byref(h)))
+        return _ShardTable(h, self.group.ctx(local), self.path)
+
+    def load(self, columns: Optional[Sequence[str]] = None) -> dict:
+        st = N.SizeStats()
+        if columns is None:
+            N.check(N.load().dfdb_group_table_load(self._h, None, 0, C.byref(st)))
+        else:
+            meta = self.shard(0)
+            ords = (C.c_int32 * len(columns))(*[meta.ordinal(c) for c in columns])
+            N.check(N.load().dfdb_group_table_load(self._h, ords, len(columns), C.byref(st)))
+        return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
+
+    def add_generated(self, name: str, generator: int, seed: int, nrows_total: int):
+        N.check(N.load().dfdb_group_table_add_generated(self._h, name.encode(), generator, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), nrows_total))
+
+    def add_column(self, name: str, values, dtype: Optional[int] = None):
+        """whole-table host column (numpy array, masked array or list of str / None); every shard uploads its block range"""
+        L = N.load()
+        if isinstance(values, (list, tuple)) and (len(values) == 0 or isinstance(values[0], (str, bytes, type(None)))):
+            enc = [None if v is None else (v.encode() if isinstance(v, str) else bytes(v)) for v in values]
+            sizes = np.array([-1 if e is None else len(e) for e in enc], np.int32)
+            data = np.frombuffer(b"".join(e for e in enc if e), np.uint8).copy()
+            dt = ir.STRING | (ir.NULLABLE if any(e is None for e in enc) or (dtype or 0) & ir.NULLABLE else 0)
+            N.check(L.dfdb_group_table_add_column(self._h, name.encode(), dt, len(sizes), sizes.ctypes.data, data.ctypes.data if len(data) else None, len(data), None))
+            return
+        missing = None
+        if isinstance(values, np.ma.MaskedArray):
+            missing = np.ascontiguousarray(np.ma.getmaskarray(values), np.uint8)
+            values = values.filled(0)
+        arr = np.ascontiguousarray(values)
+        if dtype is None:
+            dtype = ir.dtype_of_numpy(arr.dtype)
+        arr = np.ascontiguousarray(arr.astype(ir.numpy_of_dtype(dtype), copy=False))
+        if missing is not None:
+            dtype |= ir.NULLABLE
+        N.check(L.dfdb_group_table_add_column(self._h, name.encode(), dtype, len(arr), arr.ctypes.data if len(arr) else None, None, 0,
+                                              missing.ctypes.data if missing is not None else None))
+
+    @classmethod
+    def from_columns(cls, group: Group, columns: Dict[str, Any], block_size: int = 65536) -> "GroupTable":
+        t = cls.new(group, block_size)
+        for k, v in columns.items():
+            t.add_column(k, v)
+        return t
+
+    @property
+    def nrows(self) -> int:
+        n = C.c_int64()
+        N.check(N.load().dfdb_group_table_nrows(self._h, C.byref(n)))
+        return n.value
+
+    def view(self) -> api.DFView:
+        """the lazy view algebra runs over shard 0's metadata; evaluation goes through gnrow / gmaterialize / ..."""
+        t = self.shard(0)
+        object.__setattr__(t, "_group_table", self)      # every view derived from this one finds the group through its table
+        return api.DFView(t)
+
+    def __getitem__(self, key):
+        v = self.view()[key]
+        return v
+
+    def close(self):
+        if self._h:
+            N.load().dfdb_group_table_close(self._h)
+            self._h = C.c_void_p()
+
+
+class GroupQuery:
+    """dfdb_gquery built from a DFView's SelectionQueue + Projection"""
+
+    def __init__(self, gt: GroupTable, v: api.DFView):
+        L = N.load()
+        self.gt, self.view = gt, v
+        self._h = C.c_void_p()
+        N.check(L.dfdb_group_query_new(gt._h, C.byref(self._h)))
+        try:
+            for st in v.selection.queue:
+                if isinstance(st, ir.Expr):
+                    b = st.to_ir()
+                    N.check(L.dfdb_group_query_add_predicate(self._h, b, len(b)))
+                elif isinstance(st, api.JRange):
+                    N.check(L.dfdb_group_query_add_range(self._h, int(st.start), int(st.step), int(st.stop)))
+                elif isinstance(st, int):
+                    N.check(L.dfdb_group_query_add_integer(self._h, st))
+                else:
+                    a = np.ascontiguousarray(st, np.int64)
+                    N.check(L.dfdb_group_query_add_indices(self._h, a.ctypes.data if len(a) else None, len(a)))
+            items = [(k, e.to_ir()) for k, e in v.projection.cols.items()]
+            n = len(items)
+            names = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in items])
+            bufs = [C.create_string_buffer(b, len(b)) for _, b in items]
+            irs = (C.c_void_p * max(n, 1))(*[C.cast(b, C.c_void_p) for b in bufs])
+            lens = (C.c_size_t * max(n, 1))(*[len(b) for _, b in items])
+            N.check(L.dfdb_group_query_set_projection(self._h, n, names, irs, lens))
+        except Exception:
+            L.dfdb_group_query_free(self._h)
+            self._h = C.c_void_p()
+            raise
+
+    def close(self):
+        if self._h:
+            N.load().dfdb_group_query_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            import sys
+            if self._h and not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+    def reset(self): N.check(N.load().dfdb_group_query_reset(self._h))
+
+    def count(self) -> int:
+        n = C.c_int64()
+        N.check(N.load().dfdb_group_count(self._h, C.byref(n)))
+        return n.value
+
+    def count_async(self): N.check(N.load().dfdb_group_count(self._h, None))
+
+    def shard_counts(self) -> List[int]:
+        a = (C.c_int64 * self.gt.group.world)()
+        N.check(N.load().dfdb_group_shard_counts(self._h, a))
+        return list(a)
+
+    def coltype(self, i: int) -> int:
+        q = C.c_void_p()
+        N.check(N.load().dfdb_group_query_shard(self._h, 0, C.byref(q)))
+        dt = C.c_int32()
+        N.check(N.load().dfdb_query_coltype(q, i, C.byref(dt)))
+        return dt.value
+
+    def local_count(self) -> int:
+        g = self.gt.group
+        return sum(self.shard_counts()[g.first_rank:g.first_rank + g.nlocal])
+
+    def indices(self) -> np.ndarray:
+        n = self.local_count()
+        out = np.empty(n, np.int64)
+        got = C.c_int64()
+        N.check(N.load().dfdb_group_select_indices(self._h, out.ctypes.data if n else None, n, C.byref(got)))
+        assert got.value == n
+        return out
+
+    def indices_device(self, dev_ptrs: Sequence[int], caps: Sequence[int]):
+        nl = self.gt.group.nlocal
+        outs = (C.c_void_p * nl)(*dev_ptrs)
+        cps = (C.c_int64 * nl)(*caps)
+        N.check(N.load().dfdb_group_select_indices_device(self._h, outs, cps))
+
+    def hint_aggregate(self, op: int, col: int = 0): N.check(N.load().dfdb_group_query_hint_aggregate(self._h, op, col))
+
+    def aggregate(self, op: int, col: int = 0):
+        oi, of = C.c_int64(), C.c_double()
+        if op in (N.AGG_SUM, N.AGG_MIN, N.AGG_MAX):
+            self.hint_aggregate(op, col)
+        N.check(N.load().dfdb_group_aggregate(self._h, op, col, C.byref(oi), C.byref(of)))
+        dt = self.coltype(col) & ir.DTYPE_MASK if op != N.AGG_COUNT else ir.I64
+        return of.value if dt in (ir.F32, ir.F64) else oi.value
+
+    def materialize(self) -> List[Any]:
+        L = N.load()
+        N.check(L.dfdb_group_query_hint_materialize(self._h, 1))
+        n = self.local_count()
+        ncols = len(self.view.projection)
+        outs = (N.OutCol * max(ncols, 1))()
+        keep = []
+        for i in range(ncols):
+            dt = self.coltype(i)
+            o = outs[i]
+            o.memkind = N.MEM_HOST
+            if (dt & ir.DTYPE_MASK) == ir.STRING:
+                nb = C.c_int64()
+                N.check(L.dfdb_group_result_string_bytes(self._h, i, C.byref(nb)))
+                sizes = np.empty(max(n, 1), np.int32)
+                data = np.empty(max(nb.value, 1), np.uint8)
+                keep.append((dt, sizes, data, None))
+                o.data, o.bytes, o.bytes_cap = sizes.ctypes.data, data.ctypes.data, nb.value
+            else:
+                arr = np.empty(max(n, 1), ir.numpy_of_dtype(dt))
+                miss = np.zeros(max(n, 1), np.uint8) if dt & ir.NULLABLE else None
+                keep.append((dt, arr, None, miss))
+                o.data = arr.ctypes.data
+                if miss is not None:
+                    o.missing = miss.ctypes.data
+        if ncols:
+            N.check(L.dfdb_group_materialize(self._h, outs, ncols))
+        res = []
+        for i, (dt, a, b, m) in enumerate(keep):
+            if (dt & ir.DTYPE_MASK) == ir.STRING:
+                res.append((a[:n].copy(), b[:outs[i].nbytes].copy()))
+            elif m is not None:
+                res.append(np.ma.masked_array(a[:n].copy(), mask=m[:n].astype(bool)))
+            else:
+                res.append(a[:n].copy())
+        return res
+
+
+def _gq(v) -> GroupQuery:
+    if isinstance(v, api.DFColumn):
+        v = v.view
+    gt = getattr(v.table, "_group_table", None)
+    if gt is None:
+        raise ValueError("not a view of a GroupTable")
+    q = getattr(v, "_gq", None)
+    if q is None:
+        q = v._gq = GroupQuery(gt, v)
+    return q
+
+
+def gnrow(v: api.DFView) -> int: return _gq(v).count()
+def gindices(v: api.DFView) -> np.ndarray: return _gq(v).indices()
+def gaggregate(v: api.DFView, op: int, col: int = 0): return _gq(v).aggregate(op, col)
+
+
+def gmaterialize(v: api.DFView):
+    import pandas as pd
+    cols = _gq(v).materialize() if len(v.projection) else []
+    lg = api._logicals(v)
+    return pd.DataFrame({k: api._to_user(c, lg[i]) for i, (k, c) in enumerate(zip(v.projection.keys(), cols))})

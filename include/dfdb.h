@@ -111,7 +111,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "fused"           1 = one-pass scan + look-back + compaction kernel instead of K1 + count scan + K2 (default 0)
  *   "pipeline"        1 = dfdb_select_indices_device in 4 pieces, compaction on a side stream (default 0)
  *   "lz4_variant"     LZ4 block decoder: 0 v1 .. 3 v4, 4 = v5 superbatch decoder (default 4)
- *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1) */
+ *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
+ *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);
@@ -169,6 +170,12 @@ int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file,
 /* table_stats(table) (src/tables/misc.jl:6-43): SizeStats of one column file from its block headers alone (skip_block,
  * BlockStreams.jl:74-78); nothing is read or decoded beyond the 20-byte headers */
 int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats);
+
+/* compressed-resident columns.  With ctx option "keep_compressed" = 1 at dfdb_table_load time a plain fixed-width column keeps its
+ * LZ4 blocks (as they sit in the file) in HBM beside the decoded array; dfdb_table_decode_resident runs the block decoder (K7,
+ * read_block: BlockStreams.jl:101-119) over all of them again, asynchronously, into the resident array.  It is the device-side
+ * equivalent of re-reading the column through BlockStream and what bench.py's decode-inclusive figure times. */
+int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal);
 
 /* declare a caller-supplied Int64 / UInt32 column to be one of the bits types above, so that dfdb_table_save writes that type
  * string and the reference's open_table reads the column back as Date / DateTime / Time / Char */
@@ -267,6 +274,73 @@ int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out)
 int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row);
 int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats);   /* table_stats over the required columns (headers only) */
 int32_t dfdb_stream_close(dfdb_stream* s);
+
+/* ---- multi-GPU groups: ONE table block-range sharded over the GPUs of a node (§8b backend HIP_N) ----
+ * Blocks are independent units every column shares (check_column_head, filesystem.jl:47-54): rank g of G owns blocks
+ * [g*ceil(nb/G), (g+1)*ceil(nb/G)) of every column and runs the ordinary engine over them.  The shards meet only in
+ * nrow(v) (view.jl:192-206: one RCCL all-reduce of an Int64), sum / minimum / maximum (Base.iterate(::DFColumn), column.jl:102-126:
+ * one all-reduce of {value, count}) and in a range stage that follows a predicate stage, which numbers the GLOBAL survivor
+ * stream (RangeToProcess.offset, selection.jl:68-75,94-111: all-gather of one Int64 per rank + exclusive scan, done inside).
+ * No column data crosses xGMI.  Rank order = table order.
+ *   dfdb_group_create        one process drives n GPUs (a host thread per GPU, ncclCommInitAll): what a Julia session gets
+ *   dfdb_group_create_rank   one process per GPU (ncclCommInitRank; the id comes from dfdb_group_unique_id on rank 0 and is
+ *                            handed round by the launcher: MPI, Distributed.jl, a torch.distributed store)
+ * RCCL is dlopen'ed on first use.  DFDB_EXCHANGE_HOST does the same exchanges through host memory and exists for one-process
+ * groups whose shards share a physical GPU (functional tests on a 1-GPU box; RCCL refuses duplicate devices). */
+typedef struct dfdb_group dfdb_group;
+typedef struct dfdb_gtable dfdb_gtable;   /* a DFTable, sharded */
+typedef struct dfdb_gquery dfdb_gquery;   /* a DFView over it */
+enum { DFDB_EXCHANGE_AUTO = 0, DFDB_EXCHANGE_RCCL = 1, DFDB_EXCHANGE_HOST = 2 };
+#define DFDB_GROUP_ID_BYTES 128
+
+int32_t dfdb_group_create(const int32_t* device_ids, int32_t n, int32_t exchange, dfdb_group** out);
+int32_t dfdb_group_unique_id(uint8_t id[DFDB_GROUP_ID_BYTES]);
+int32_t dfdb_group_create_rank(int32_t device_id, void* hip_stream, const uint8_t id[DFDB_GROUP_ID_BYTES], int32_t rank, int32_t world,
+                               dfdb_group** out);
+int32_t dfdb_group_destroy(dfdb_group* g);
+int32_t dfdb_group_info(dfdb_group* g, int32_t* world, int32_t* nlocal, int32_t* first_rank, int32_t* exchange);
+int32_t dfdb_group_ctx(dfdb_group* g, int32_t local, dfdb_ctx** ctx);          /* borrowed */
+int32_t dfdb_group_synchronize(dfdb_group* g);                                 /* the local engine streams have drained */
+int32_t dfdb_group_barrier(dfdb_group* g);                                     /* ... on every rank */
+int32_t dfdb_group_set_option(dfdb_group* g, const char* key, int64_t value);  /* dfdb_ctx_set_option on every local shard */
+/* all-reduce (DFDB_AGG_SUM / _MIN / _MAX) of n <= 12 caller scalars per local shard, vals[nlocal][n], in place */
+int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t op);
+
+int32_t dfdb_group_table_open(dfdb_group* g, const char* path, dfdb_gtable** out);       /* open_table: creators.jl:7-16 */
+int32_t dfdb_group_table_new(dfdb_group* g, int64_t block_size, dfdb_gtable** out);
+int32_t dfdb_group_table_close(dfdb_gtable* gt);
+/* every shard loads ITS block range of the listed columns (NULL = all): dfdb_table_load(block range of rank) */
+int32_t dfdb_group_table_load(dfdb_gtable* gt, const int32_t* ordinals, int32_t ncols, dfdb_sizestats* stats);
+/* columns of the WHOLE table (nrows_total rows); every shard generates / uploads the rows of its block range */
+int32_t dfdb_group_table_add_generated(dfdb_gtable* gt, const char* name, int32_t generator, uint64_t seed, int64_t nrows_total);
+int32_t dfdb_group_table_add_column(dfdb_gtable* gt, const char* name, int32_t dtype, int64_t nrows_total, const void* data,
+                                    const uint8_t* bytes, int64_t nbytes, const uint8_t* missing);
+int32_t dfdb_group_table_nrows(dfdb_gtable* gt, int64_t* total);                         /* rows of the whole table */
+int32_t dfdb_group_table_shard(dfdb_gtable* gt, int32_t local, dfdb_table** t);          /* borrowed: the ordinary handle of one shard */
+
+int32_t dfdb_group_query_new(dfdb_gtable* gt, dfdb_gquery** out);                        /* DFView(table): view.jl:50 */
+int32_t dfdb_group_query_free(dfdb_gquery* gq);
+int32_t dfdb_group_query_add_range(dfdb_gquery* gq, int64_t start, int64_t step, int64_t stop);   /* as dfdb_query_add_*, on every shard */
+int32_t dfdb_group_query_add_indices(dfdb_gquery* gq, const int64_t* idx, int64_t n);
+int32_t dfdb_group_query_add_integer(dfdb_gquery* gq, int64_t i);
+int32_t dfdb_group_query_add_predicate(dfdb_gquery* gq, const uint8_t* ir, size_t len);
+int32_t dfdb_group_query_set_projection(dfdb_gquery* gq, int32_t n, const char* const* names, const uint8_t* const* irs, const size_t* lens);
+int32_t dfdb_group_query_hint_aggregate(dfdb_gquery* gq, int32_t op, int32_t proj_col);
+int32_t dfdb_group_query_hint_materialize(dfdb_gquery* gq, int32_t on);
+int32_t dfdb_group_query_reset(dfdb_gquery* gq);
+int32_t dfdb_group_query_shard(dfdb_gquery* gq, int32_t local, dfdb_query** q);          /* borrowed */
+/* nrow(v) over the whole table (view.jl:192-206).  n == NULL only enqueues: the reduced count stays on the devices, no host wait */
+int32_t dfdb_group_count(dfdb_gquery* gq, int64_t* n);
+int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts /* world values, rank order */);
+/* sum / minimum / maximum / count over the whole table; integers exact, Float64 sums within the tolerance of DESIGN.md */
+int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* out_i, double* out_f);
+/* 1-based TABLE row numbers: each local shard into its own device buffer (asynchronous) ... */
+int32_t dfdb_group_select_indices_device(dfdb_gquery* gq, int64_t* const* outs, const int64_t* caps);
+/* ... or the local shards concatenated in rank order into ONE host buffer (*n = rows written by this process) */
+int32_t dfdb_group_select_indices(dfdb_gquery* gq, int64_t* out, int64_t cap, int64_t* n);
+int32_t dfdb_group_result_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbytes);
+/* materialize(v) (materialization.jl:27-40) into caller-owned HOST buffers: the local shards' rows in rank order = table order */
+int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,284 @@
+"""GPU: the multi-GPU group API of include/dfdb.h (block-range shards + RCCL / host exchange) against the oracle's single table.
+
+A 1-GPU box cannot hold two RCCL ranks on distinct devices, so the sharded paths are driven three ways:
+  * one-process groups whose shards all live on device 0 with DFDB_EXCHANGE_HOST (every code path of group.cpp except the
+    two RCCL calls: worker threads, block-range loads, stage-base planning, rank-order concatenation, aggregates),
+  * a one-rank group with DFDB_EXCHANGE_RCCL (dlopen of librccl, ncclCommInitAll / ncclCommInitRank, all-reduce and all-gather
+    really issued on the engine stream),
+  * two PROCESSES on device 0 over torch.distributed gloo running the real engine per rank (dfdb/sharding.py), and bench.py's
+    own launcher.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import Pair  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def col_seed(k):
+    return (0x9E3779B97F4A7C15 + 0x1234567 * k) & 0xFFFFFFFFFFFFFFFF
+
+
+def _columns(oracle, n):
+    sizes, data = oracle.gen_str(col_seed(2), 0, n)
+    return {"a": oracle.gen_i64(col_seed(0), 0, n), "x": oracle.gen_f64(col_seed(1), 0, n), "s": oracle.flat_to_strings(sizes, data)}
+
+
+def _stage_sets(ir):
+    a, x, s = ir.col(0), ir.col(1), ir.col(2)
+    return {
+        "pred": [("pred", (a > 700_000) & (s != "sony"))],
+        "lead_range": [("range", 5, 7, 250_000), ("pred", x < 1000.0)],
+        "range_after_pred": [("pred", a > 500_000), ("range", 11, 3, 90_000)],
+        "two_exchanges": [("pred", a % 2 == 0), ("range", 10, 1, 100_000), ("pred", s == "dell"), ("idx", [1, 5, 400, 4999, 10**9])],
+        "integer_after_pred": [("pred", a > 999_000), ("int", 17)],
+        "nothing_selected": [("pred", a > 2_000_000)],
+        "count_all": [],
+    }
+
+
+def _build(dfdb, ov, gv, stages):
+    for st in stages:
+        if st[0] == "pred":
+            ov.add_predicate(st[1].to_ir()); gv = dfdb.selection(gv, st[1])
+        elif st[0] == "range":
+            ov.add_range(st[1], st[2], st[3]); gv = dfdb.selection(gv, dfdb.jr(st[1], st[2], st[3]))
+        elif st[0] == "int":
+            ov.add_integer(st[1]); gv = dfdb.selection(gv, st[1])
+        else:
+            ov.add_indices(st[1]); gv = dfdb.selection(gv, list(st[1]))
+    return ov, gv
+
+
+def _check_group_against_oracle(oracle, dfdb, ot, gt, cols, n):
+    from dfdb import ir, group as G, _native as N
+    for name, stages in _stage_sets(ir).items():
+        ov, gv = _build(dfdb, ot.view(), gt.view(), stages)
+        want_idx = ov.select_indices()
+        assert G.gnrow(gv) == ov.nrow() == len(want_idx), name
+        assert np.array_equal(G.gindices(gv), want_idx), name
+        assert sum(G._gq(gv).shard_counts()) == len(want_idx), name
+        want = ov.materialize()
+        got = G._gq(gv).materialize()
+        assert np.array_equal(got[0], want[0]), name
+        assert np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)), name
+        assert np.array_equal(got[2][0], want[2][0]) and np.array_equal(got[2][1], want[2][1]), name
+        sel = want_idx - 1
+        # aggregates: Int64 exact (wrapping sums are associative), Float64 sum within n*eps*sum|x|
+        av = gv[dfdb.ALL, "a"]
+        assert G.gaggregate(av, N.AGG_SUM) == int(cols["a"][sel].sum()), name
+        assert G.gaggregate(av, N.AGG_COUNT) == len(sel), name
+        xv = gv[dfdb.ALL, "x"]
+        xs = cols["x"][sel]
+        assert abs(G.gaggregate(xv, N.AGG_SUM) - float(xs.sum())) <= max(1, n) * np.finfo(float).eps * float(np.abs(xs).sum()) + 0.0, name
+        if len(sel):
+            assert G.gaggregate(av, N.AGG_MIN) == int(cols["a"][sel].min()) and G.gaggregate(av, N.AGG_MAX) == int(cols["a"][sel].max()), name
+            assert G.gaggregate(xv, N.AGG_MIN) == float(xs.min()) and G.gaggregate(xv, N.AGG_MAX) == float(xs.max()), name
+        else:
+            with pytest.raises(ValueError, match="empty collection"):
+                G.gaggregate(av, N.AGG_MIN)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_group_host_exchange_files_vs_oracle(oracle, dfdb_mod, ctx, tmp_path, world):
+    """world shards of one file-backed table on device 0 (world = 5 over 74 blocks; the last shard is short)"""
+    from dfdb import group as G, _native as N
+    n, bs = 300_007, 4096
+    cols = _columns(oracle, n)
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    g = G.Group.create([0] * world, N.EXCHANGE_HOST if world > 1 else N.EXCHANGE_AUTO)
+    try:
+        assert (g.world, g.nlocal, g.first_rank) == (world, world, 0)
+        gt = G.GroupTable.open(g, path)
+        assert gt.nrows == n
+        rows = [gt.shard(l).view()._query().count() for l in range(world)]
+        assert sum(rows) == n and all(r % bs == 0 for r in rows[:-1])
+        _check_group_against_oracle(oracle, dfdb_mod, ot, gt, cols, n)
+        gt.close()
+    finally:
+        g.close()
+
+
+def test_group_more_shards_than_blocks_and_host_columns(oracle, dfdb_mod, ctx):
+    """3 blocks over 5 shards: shards 3 and 4 hold zero rows; columns come from host arrays split by block range"""
+    from dfdb import group as G, _native as N
+    n, bs = 2 * 4096 + 17, 4096
+    cols = _columns(oracle, n)
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    g = G.Group.create([0] * 5, N.EXCHANGE_HOST)
+    try:
+        gt = G.GroupTable.from_columns(g, cols, block_size=bs)
+        assert [gt.shard(l).view()._query().count() for l in range(5)] == [4096, 4096, 17, 0, 0]
+        _check_group_against_oracle(oracle, dfdb_mod, ot, gt, cols, n)
+        gt.close()
+    finally:
+        g.close()
+
+
+def test_group_generated_columns_match_single_table(oracle, dfdb_mod, ctx):
+    """dfdb_group_table_add_generated: every shard generates the rows of its own block range (row_first = its first row)"""
+    from dfdb import group as G, _native as N, ir
+    n = 5 * 65536 + 123
+    g = G.Group.create([0, 0, 0], N.EXCHANGE_HOST)
+    try:
+        gt = G.GroupTable.new(g)
+        gt.add_generated("x", dfdb_mod.GEN_I64_MOD1M, col_seed(0), n)
+        gt.add_generated("f", dfdb_mod.GEN_F64_U2000, col_seed(1), n)
+        x = oracle.gen_i64(col_seed(0), 0, n)
+        f = oracle.gen_f64(col_seed(1), 0, n)
+        v = gt.view()[(ir.col(0) > 899_999) & (ir.col(1) < 1000.0), dfdb_mod.ALL]
+        m = (x > 899_999) & (f < 1000.0)
+        assert G.gnrow(v) == int(m.sum())
+        assert np.array_equal(G.gindices(v), np.nonzero(m)[0] + 1)
+        got = G._gq(v).materialize()
+        assert np.array_equal(got[0], x[m]) and np.array_equal(got[1].view(np.uint64), f[m].view(np.uint64))
+        # an async count (no host wait) followed by the read
+        q = G._gq(v)
+        q.reset(); q.count_async()
+        assert q.count() == int(m.sum())
+        gt.close()
+    finally:
+        g.close()
+
+
+def test_group_rccl_single_rank(oracle, dfdb_mod, ctx):
+    """DFDB_EXCHANGE_RCCL with one rank: librccl is dlopen'ed, ncclCommInitAll / ncclCommInitRank run, and the all-reduce /
+    all-gather of count, aggregates and stage bases are really issued on the engine stream (world = 1 makes them copies)"""
+    from dfdb import group as G, _native as N, ir
+    n = 200_000
+    x = oracle.gen_i64(col_seed(0), 0, n)
+    for make in (lambda: G.Group.create([0], N.EXCHANGE_RCCL), lambda: G.Group.create_rank(0, None, 0, 1)):
+        g = make()
+        try:
+            gt = G.GroupTable.from_columns(g, {"x": x}, block_size=4096)
+            v = gt.view()[ir.col(0) > 500_000, dfdb_mod.ALL]
+            m = x > 500_000
+            assert G.gnrow(v) == int(m.sum())
+            assert G.gaggregate(v, N.AGG_SUM) == int(x[m].sum()) and G.gaggregate(v, N.AGG_MAX) == int(x[m].max())
+            v2 = dfdb_mod.selection(v, dfdb_mod.jr(3, 2, 1000))
+            assert np.array_equal(G.gindices(v2), (np.nonzero(m)[0] + 1)[2:1000:2])
+            g.barrier()
+            assert g.allreduce([[1.5, -2.0]], N.AGG_MAX) == [[1.5, -2.0]]
+            gt.close()
+        finally:
+            g.close()
+    uid = G.Group.unique_id()
+    assert len(uid) == N.GROUP_ID_BYTES and any(uid)
+
+
+def test_group_rejects_bad_arguments(dfdb_mod, ctx):
+    from dfdb import group as G, _native as N
+    with pytest.raises(ValueError, match="distinct"):
+        G.Group.create([0, 0], N.EXCHANGE_RCCL)
+    with pytest.raises(ValueError):
+        G.Group.create([], N.EXCHANGE_AUTO)
+    with pytest.raises(ValueError, match="out of range"):
+        G.Group.create([0, 99], N.EXCHANGE_HOST)
+    g = G.Group.create([0, 0], N.EXCHANGE_HOST)
+    try:
+        gt = G.GroupTable.from_columns(g, {"a": np.arange(10, dtype=np.int64)}, block_size=4)
+        with pytest.raises(ValueError, match="rows"):
+            gt.add_column("b", np.arange(11, dtype=np.int64))
+        v = gt.view()
+        with pytest.raises(IndexError):                     # range[range] out of bounds is rejected on every shard alike
+            G.gnrow(dfdb_mod.selection(dfdb_mod.selection(v, dfdb_mod.jr(1, 1, 5)), dfdb_mod.jr(1, 1, 9)))
+        gt.close()
+    finally:
+        g.close()
+
+
+# ---------------------------------------------------------------- two processes, one device, gloo: the torch.distributed path
+_RANK_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "dataframedbs.jl_amd"))
+import numpy as np, torch, torch.distributed as dist
+import dfdb
+from dfdb import ir, sharding
+rank, world, path = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ctx = dfdb.Context(0)
+t = dfdb.open_table(path, ctx=ctx, load=False)
+nrows = int(dfdb.table_stats(t)["rows"].iloc[0])
+nb = -(-nrows // t.blocksize)
+b0, b1 = sharding.block_range(nb, rank, world)
+t.load(None, b0, b1)
+a, x, s = ir.col(0), ir.col(1), ir.col(2)
+views = {
+  "pred": dfdb.selection(t.view(), (a > 700_000) & (s != "sony")),
+  "range_after_pred": dfdb.selection(dfdb.selection(t.view(), a > 500_000), dfdb.jr(11, 3, 90_000)),
+  "two_exchanges": dfdb.selection(dfdb.selection(dfdb.selection(dfdb.selection(t.view(), a % 2 == 0), dfdb.jr(10, 1, 100_000)), s == "dell"), [1, 5, 400, 4999, 10**9]),
+}
+out = {}
+for name, v in views.items():
+    total = sharding.sharded_count(v)
+    out[name] = dict(total=total, idx=v._query().indices().tolist())
+json.dump(out, open(sys.argv[3] + f".{rank}", "w"))
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_processes_gloo_real_engine(oracle, dfdb_mod, ctx, tmp_path):
+    """world_size 2, both ranks on device 0, gloo: each rank loads its block range into the real engine and
+    dfdb/sharding.py's exchanges (all-gather + exclusive scan, all-reduce) give the oracle's single-table answer"""
+    from dfdb import ir
+    n, bs = 300_007, 4096
+    cols = _columns(oracle, n)
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, path, str(tmp_path / "out")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = [json.load(open(str(tmp_path / "out") + f".{r}")) for r in range(2)]
+    a, x, s = ir.col(0), ir.col(1), ir.col(2)
+    want = {
+        "pred": ot.view().add_predicate(((a > 700_000) & (s != "sony")).to_ir()),
+        "range_after_pred": ot.view().add_predicate((a > 500_000).to_ir()).add_range(11, 3, 90_000),
+        "two_exchanges": ot.view().add_predicate((a % 2 == 0).to_ir()).add_range(10, 1, 100_000).add_predicate((s == "dell").to_ir()).add_indices([1, 5, 400, 4999, 10**9]),
+    }
+    for name, ov in want.items():
+        w = ov.select_indices().tolist()
+        assert got[0][name]["idx"] + got[1][name]["idx"] == w, name            # rank order = table order
+        assert got[0][name]["total"] == got[1][name]["total"] == len(w), name
+
+
+def test_bench_self_launches_ranks(ctx):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset spawns its own two ranks (here both on device 0 over gloo) and reports
+    n_gpus = 2; the aggregate count is the sum of both shards"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-on-device0", "--backend", "gloo", "--rows", "20000000",
+                        "--steps", "3", "--warmup", "1", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
+    assert r["config"]["global_selected"] > 2 * 0.09 * 20_000_000
+    assert r["value"] > 0
