@@ -97,8 +97,7 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     profile_resolve(ctx);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    for (hipEvent_t e : ctx->pipe_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
     if (ctx->pinned_scalar) (void)hipHostFree(ctx->pinned_scalar);
     for (int i = 0; i < 2; i++) { if (ctx->pin_ring[i]) (void)hipHostFree(ctx->pin_ring[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -68,8 +68,7 @@ struct dfdb_query {
   std::vector<dfdb::ProjCol> proj;
   // device state of the last execution
   dfdb::DevBuf bitmap, tile_counts, prefix, scan_scratch, idx_sorted, red_scratch, red_result, tmp_a, tmp_b, tmp_c,
-      str_sizes, str_toff, str_bytes, str_scratch, fused_scratch;
-  bool fused_pending = false;  // a fused launch whose spin-overrun flag has not been checked yet
+      str_sizes, str_toff, str_bytes, str_scratch;
   // dfdb_query_hint_materialize: the projection WILL be materialised after the scan, so a single-stage scan of simple terms
   // keeps the selected values of one projected 8-byte predicate column (per-tile compact, cap_buf) and that column's
   // projection becomes a contiguous copy instead of a gather

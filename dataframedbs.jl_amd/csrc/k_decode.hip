@@ -3,18 +3,13 @@
 // Replaces LZ4_decompress_safe as called per (column, block) by BlockStream.read_block
 // (src/io/BlockStreams.jl:101-119) and read_block_body! for nullable and String columns
 // (src/io/blocks.jl:46-71).  The LZ4 *block* format is serial inside a block, so parallelism comes from
-// the blocks: one wavefront decodes one block (15 259 blocks per 1e9-row column).  Five decoders live here, oldest
-// first; the default is the last one (ctx option "lz4_variant" selects, launch_lz4_decode dispatches):
-//   v1 k_lz4_decode       all lanes parse the same token through L2 round trips, copies spread over the 64 lanes
-//   v2 k_lz4_decode_lds   v1 with the input staged in LDS and an LDS ring of the output
-//   v3 k_lz4_decode_v3<..,0,..>  register-window parser (v_readlane), one LDS round trip per sequence
-//   v4 k_lz4_decode_v3<..,1,..>  v3 + the short sequences of one 64-byte window executed together
-//   v5 k_lz4_decode_v3<..,2,..>  superbatch of 8 windows: branch-free chain walk, start bits + sequence records,
-//                                far sources prefetched from HBM, bytes produced in output order (see the kernel)
+// the blocks: one wavefront decodes one block (15 259 blocks per 1e9-row column).
+//   k_lz4_decode: superbatch of 8 windows of 64 input bytes: the candidate decode of all 512 positions up front, a branch-free chain
+//   walk over the real sequence starts, one start bit + one 8-byte record per sequence, far sources prefetched from HBM, bytes
+//   produced in output order (see the kernel).  Recent output lives in an LDS ring; only sources that left the ring cost a fence.
 // A match whose source overlaps its destination (offset < length) is a periodic pattern: byte k of the
 // match equals source byte k mod offset, all of which precede the write pointer, so it is also copied in
-// parallel.  v1's reads of bytes this wave wrote earlier are ordered by a workgroup-scope fence (same CU, same
-// L1) before every match copy; v3-v5 keep recent output in LDS and only fence for sources that left the ring.
+// parallel.
 #include <type_traits>
 #include "device_utils.hpp"
 #include "kernels.hpp"
@@ -22,162 +17,13 @@
 namespace dfdb {
 
 constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = 4;
-
-// a byte every lane reads from the same address, pinned to a scalar register so the token parse stays
-// wave-uniform (scalar branches, no exec masking)
-__device__ __forceinline__ uint32_t ubyte(const uint8_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*p); }
-
-__global__ __launch_bounds__(kBlock) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                       const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
-  const int lane = lane_id();
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const Lz4Block blk = blocks[b];
-    const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
-    const uint32_t in_len = (uint32_t)blk.src_len, out_len = (uint32_t)blk.dst_len;
-    uint32_t ip = 0, op = 0;
-    int err = 0;
-    while (ip < in_len) {                       // every quantity below is wave-uniform
-      const uint32_t token = ubyte(in + ip); ip++;
-      uint32_t lit = token >> 4;
-      if (lit == 15) {
-        uint32_t bb;
-        do { if (ip >= in_len) { err = 1; break; } bb = ubyte(in + ip); ip++; lit += bb; } while (bb == 255);
-        if (err) break;
-      }
-      if (lit > in_len - ip || lit > out_len - op) { err = 2; break; }
-      for (uint32_t k = lane; k < lit; k += 64) out[op + k] = in[ip + k];      // literal run
-      ip += lit; op += lit;
-      if (ip >= in_len) break;                  // the last sequence is literals only
-      if (ip + 2 > in_len) { err = 3; break; }
-      const uint32_t offset = ubyte(in + ip) | (ubyte(in + ip + 1) << 8);
-      ip += 2;
-      uint32_t ml = token & 15u;
-      if (ml == 15) {
-        uint32_t bb;
-        do { if (ip >= in_len) { err = 4; break; } bb = ubyte(in + ip); ip++; ml += bb; } while (bb == 255);
-        if (err) break;
-      }
-      ml += 4;
-      if (offset == 0 || offset > op || ml > out_len - op) { err = 5; break; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // this wave's earlier stores are visible to its loads
-      const uint8_t* m = out + op - offset;
-      if (offset >= ml) { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k]; }
-      else              { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k % offset]; }
-      op += ml;
-    }
-    if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
-    if (lane == 0) status[b] = err;
-  }
-}
-
-// ---- K7 v2: the same wave-per-block decoder with the two latency chains moved into LDS -------------------
-// Profiling v1 (one dependent HBM/L2 round trip for the token, the literals, the offset and — behind a fence —
-// the match source of EVERY sequence) gave 8 GB/s on 8-byte integer columns (one sequence per ~8 bytes).  Here
-//   * the compressed stream is staged 2 KB at a time into a per-wave LDS buffer (unaligned 8-byte loads),
-//     so token / length / offset / literal bytes come from LDS;
-//   * the last 8 KB of OUTPUT are mirrored in a per-wave LDS ring, so a match whose source lies inside the
-//     ring (offset + length <= 8 KB: every match of typical columnar data) never touches memory or a fence.
-// Far / very long matches fall back to the v1 path (global source behind a workgroup fence) and invalidate
-// the ring up to their end.  Output bytes go to the ring and, fire-and-forget, to HBM.
-constexpr int kInCap = 2048;
-constexpr int kWin = 8192;
 
 __device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t* p) {
   typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
   return *(const u64u*)p;
 }
 
-__global__ __launch_bounds__(kBlock) void k_lz4_decode_lds(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                           const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) uint8_t in_sh[kWavesPerBlock][kInCap + 64];
-  __shared__ __attribute__((aligned(16))) uint8_t win_sh[kWavesPerBlock][kWin];
-  const int lane = lane_id();
-  const int wib = threadIdx.x >> 6;
-  uint8_t* ib = in_sh[wib];
-  uint8_t* win = win_sh[wib];
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const Lz4Block blk = blocks[b];
-    const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
-    const uint32_t in_len = (uint32_t)blk.src_len, out_len = (uint32_t)blk.dst_len;
-    uint32_t ip = 0, op = 0, ib_base = 0, ib_len = 0, win_valid_from = 0;
-    int err = 0;
-    // byte at absolute input position p (wave-uniform)
-    auto rd = [&](uint32_t p) -> uint32_t {
-      const uint32_t r = p - ib_base;
-      const int v = r < ib_len ? (int)ib[r] : (int)in[p];
-      return (uint32_t)__builtin_amdgcn_readfirstlane(v);
-    };
-    while (ip < in_len) {
-      if (ip - ib_base + 64 > ib_len && ib_base + ib_len < in_len) {   // refill: stage [ip, ip + 2 KB)
-        wave_lds_fence();
-        const uint32_t n = in_len - ip < (uint32_t)kInCap ? in_len - ip : (uint32_t)kInCap;
-        for (uint32_t k = lane * 8; k < n; k += 512) *(uint64_t*)(ib + k) = ld_u64_unaligned(in + ip + k);   // staged image is padded
-        ib_base = ip; ib_len = n;
-        wave_lds_fence();
-      }
-      const uint32_t token = rd(ip); ip++;
-      uint32_t lit = token >> 4;
-      if (lit == 15) {
-        uint32_t bb;
-        do { if (ip >= in_len) { err = 1; break; } bb = rd(ip); ip++; lit += bb; } while (bb == 255);
-        if (err) break;
-      }
-      if (lit > in_len - ip || lit > out_len - op) { err = 2; break; }
-      if (lit) {
-        const uint32_t r0 = ip - ib_base;
-        const bool staged = r0 + lit <= ib_len;
-        for (uint32_t k = lane; k < lit; k += 64) {
-          const uint8_t v = staged ? ib[r0 + k] : in[ip + k];
-          win[(op + k) & (kWin - 1)] = v;
-          out[op + k] = v;
-        }
-        ip += lit; op += lit;
-      }
-      if (ip >= in_len) break;                  // the last sequence is literals only
-      if (ip + 2 > in_len) { err = 3; break; }
-      const uint32_t offset = rd(ip) | (rd(ip + 1) << 8);
-      ip += 2;
-      uint32_t ml = token & 15u;
-      if (ml == 15) {
-        uint32_t bb;
-        do { if (ip >= in_len) { err = 4; break; } bb = rd(ip); ip++; ml += bb; } while (bb == 255);
-        if (err) break;
-      }
-      ml += 4;
-      if (offset == 0 || offset > op || ml > out_len - op) { err = 5; break; }
-      if (offset + ml <= (uint32_t)kWin && op - offset >= win_valid_from) {
-        wave_lds_fence();                       // the ring bytes other lanes just wrote
-        const uint32_t s0 = op - offset;
-        for (uint32_t k = lane; k < ml; k += 64) {
-          const uint32_t sk = offset >= ml ? k : k % offset;
-          const uint8_t v = win[(s0 + sk) & (kWin - 1)];
-          win[(op + k) & (kWin - 1)] = v;       // never a slot still needed as a source: offset + ml <= kWin
-          out[op + k] = v;
-        }
-      } else {                                  // far or very long match: v1 path
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const uint8_t* m = out + op - offset;
-        if (offset >= ml) { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k]; }
-        else              { for (uint32_t k = lane; k < ml; k += 64) out[op + k] = m[k % offset]; }
-        win_valid_from = op + ml;               // the ring does not hold these bytes
-      }
-      op += ml;
-    }
-    if (!err && op != out_len) err = 6;
-    if (lane == 0) status[b] = err;
-    wave_lds_fence();
-  }
-}
-
-
-// ---- K7 v3: register-window parse + one LDS round trip per sequence ------------------------------------------
+// ---- K7: register-window parse for the one-sequence path + superbatch execution ------------------------------------------
 // v1 measured 26 GB/s on 8-byte integer columns (one sequence per ~8 output bytes): ~2800 cycles per sequence, all of
 // it dependent L2/HBM round trips (token, literals, offset, a fence, the match source).  v3 keeps the whole
 // per-sequence dependency chain on chip:
@@ -200,36 +46,31 @@ __device__ unsigned long long g_lz4_prof[16];
 #define LZ4_PROF(k)
 #define LZ4_COUNT(k, n)
 #endif
-constexpr int kV3Waves = 4;
-constexpr int kV4Waves = 1;
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-// BATCH = 1 (v4): up to 21 short sequences found in a 64-byte window are executed together; BATCH = 2 (v5): W windows at once
-template <int WAVES, int BATCH, int kRing, int kStage, int kBatchBytes, int W = 1>
-__global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v3(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W>
+__global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
-  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[WAVES][kStage + kRing + (BATCH == 2 ? kFarMax * 24 : 0)];
-  __shared__ uint32_t fard_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kFarMax : 1];
-  __shared__ int16_t refs_sh[BATCH == 1 ? WAVES : 1][BATCH == 1 ? kBatchBytes : 1];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[WAVES][kStage + kRing + kFarMax * 24];
+  __shared__ uint32_t fard_sh[WAVES][kFarMax];
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
-  __shared__ uint32_t bits_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kBatchBytes / 32 + 2 : 1];   // + two words that stay zero
-  __shared__ uint2 info_sh[BATCH == 2 ? WAVES : 1][BATCH == 2 ? kSeqMax : 1];
+  __shared__ uint32_t bits_sh[WAVES][kBatchBytes / 32 + 2];   // + two words that stay zero
+  __shared__ uint2 info_sh[WAVES][kSeqMax];
   const uint32_t lane = (uint32_t)lane_id();
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* lds = lds_sh[wib];
   uint8_t* stage = lds;
   uint8_t* ring = lds + kStage;
-  int16_t* refs = refs_sh[BATCH == 1 ? wib : 0];
-  uint32_t* bits = bits_sh[BATCH == 2 ? wib : 0];
-  uint2* info = info_sh[BATCH == 2 ? wib : 0];
-  uint32_t* fard = fard_sh[BATCH == 2 ? wib : 0];
-  if (BATCH == 2 && lane < 2) bits[kBatchBytes / 32 + lane] = 0;
+  uint32_t* bits = bits_sh[wib];
+  uint2* info = info_sh[wib];
+  uint32_t* fard = fard_sh[wib];
+  if (lane < 2) bits[kBatchBytes / 32 + lane] = 0;
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
-  constexpr uint32_t kFlush = BATCH == 2 ? (kRing >= 4096 ? 1024u : 512u) : 2048u;
-  static_assert(BATCH != 2 || (kFlush + 256 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
+  constexpr uint32_t kFlush = kRing >= 4096 ? 1024u : 512u;
+  static_assert((kFlush + 256 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
@@ -317,64 +158,7 @@ __global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v
     window_load(0);
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
-      if (BATCH == 1) {
-        // ---- v4: 64 candidate sequence starts at once.  Lane l decodes the token at ip + l AS IF a sequence began there
-        // (literal length, offset, match length: three LDS byte reads, no scalar parsing); the real starts are the chain
-        // 0 -> next(0) -> next(next(0)) ... walked with one v_readlane per sequence.  The sequences found (<= 21, each
-        // <= 14 literals + 18 match bytes, no length-extension bytes) are then executed TOGETHER: every output byte gets
-        // a reference (a literal's input position, or the earlier output byte it copies), references that point into this
-        // batch are resolved by pointer doubling 64 bytes at a time, and each byte is fetched once.  Anything else (length
-        // extensions, long runs, far offsets, the last sequence) takes the one-sequence path below.
-        advance(ip);
-        const uint32_t pos = ip + lane;
-        const uint32_t token = stage[pos & (kStage - 1)];
-        const uint32_t lit = token >> 4, mlc = token & 15u;
-        const uint32_t opos = pos + 1 + lit;                               // the 2-byte offset field
-        const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
-        const bool simple = lit != 15u && mlc != 15u && opos + 2 < in_len && offset != 0 && offset + (uint32_t)kBatchBytes <= (uint32_t)kRing;
-        const uint64_t S = __ballot(simple);
-        const uint32_t nxt = lane + 3 + lit;                               // start of the following sequence, relative to ip
-        uint32_t cur = 0; uint64_t starts = 0;
-        const uint32_t seqbytes = lit + mlc + 4u;
-        uint32_t room = (uint32_t)kBatchBytes;                             // output bytes the reference array can still take
-        while (cur < 64u && ((S >> cur) & 1ull)) {
-          const uint32_t need = rl(seqbytes, cur);
-          if (need > room) break;
-          room -= need; starts |= 1ull << cur; cur = rl(nxt, cur);
-        }
-        if (starts) {
-          const bool mine = (starts >> lane) & 1ull;
-          const uint32_t tot = mine ? seqbytes : 0u;
-          const uint32_t incl = wave_incl_scan(tot);
-          const uint32_t ostart = incl - tot;                              // first output byte of my sequence, relative to op
-          const uint32_t T = rl(incl, 63);
-          if (__ballot(mine && offset > op + ostart + lit) != 0 || T > out_len - op) { err = 5; break; }
-          for (uint32_t bi = 0; __ballot(bi < tot) != 0; bi++) {           // one reference per output byte
-            if (bi < tot) {
-              const uint32_t j = ostart + bi;
-              refs[j] = bi < lit ? (int16_t)(0x4000 + lane + 1 + bi)       // literal: input byte ip + lane + 1 + bi
-                                 : (int16_t)((int32_t)j - (int32_t)offset); // match: output byte j - offset (< 0: before this batch)
-            }
-          }
-          for (uint32_t c = 0; c < T; c += 64) {
-            const uint32_t j = c + lane;
-            int32_t r = j < T ? (int32_t)refs[j] : 0x4000;
-            for (;;) {                                                     // pointer doubling inside the chunk; earlier chunks are final
-              const bool unres = r >= 0 && r < 0x4000;
-              if (__ballot(unres) == 0) break;
-              if (unres) { r = (int32_t)refs[r]; refs[j] = (int16_t)r; }
-            }
-            if (j < T) {
-              const uint8_t v = r >= 0x4000 ? stage[(ip + (uint32_t)(r - 0x4000)) & (kStage - 1)] : ring[(op + (uint32_t)r) & (kRing - 1)];
-              ring[(op + j) & (kRing - 1)] = v;
-            }
-          }
-          op += T; ip += cur;
-          if (op - flushed >= kFlush) flush_to(op & ~255u);
-          continue;
-        }
-      }
-      if (BATCH == 2) {
+      {
         // ---- v5: a SUPERBATCH of W 64-byte windows.  The candidate decode of v4 (lane l = the token at window start + l,
         // taken AS IF a sequence began there) runs for all W windows up front, so its two dependent LDS round trips are
         // paid once; the chain of real starts is walked window after window with v_readlane only (four predicated hops per
@@ -555,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v
       const uint32_t token = (uint32_t)t64 & 255u;
       ip++;
       uint32_t lit = token >> 4;
-      if (BATCH == 2 && (lit == 15u || (token & 15u) == 15u)) extstops++;
+      if ((lit == 15u || (token & 15u) == 15u)) extstops++;
       if (lit == 15) {
         uint32_t bb;
         do { if (ip >= in_len) { err = 1; break; } ensure(ip); bb = byte_at(ip); ip++; lit += bb; } while (bb == 255);
@@ -656,30 +440,14 @@ __global__ __launch_bounds__(WAVES * 64, BATCH == 2 ? 5 : 1) void k_lz4_decode_v
   }
 }
 
-// Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format), GB/s of
-// decoded output at 4096 / 15259 blocks (tools/bench_lz4): v1 26 / 30; v2 18; v3 22 / 26; v4 (v3 + batch execution of one
-// 64-byte window, 7 KB of LDS per wave) 47 / 54; v5 (superbatch of 8 windows, far sources prefetched, 7.4 KB of LDS per wave)
-// 240 / 256.  rocprofv3 counters per sequence: v3 110 SALU + 45 VALU + 2.3 LDS, v4 43 + 31 + 3.3, v5 13 + 15 + 1.3.  None of them waits on
-// memory; a single wave retires this dependent code at ~1 instruction per 8-12 cycles, so the lever is instructions per
-// sequence x resident waves.  v5 is the default; the others stay selectable (ctx option "lz4_variant" 0..4).
-static int g_lz4_variant = 4;
-void set_lz4_variant(int v) { g_lz4_variant = v; }
-
+// Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format): see DESIGN.md §4 K7.
+// (The four earlier decoders — plain global round trips, LDS staging, register-window parser, one-window batches: 26-54 GB/s — were
+// dropped from the library in round 2; git history and DESIGN.md §10 keep what they taught.)
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
-  int64_t grid = ((int64_t)nblocks + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (grid > 65535) grid = 65535;
-  if (g_lz4_variant == 0) hipLaunchKernelGGL(k_lz4_decode, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
-  else if (g_lz4_variant == 1) hipLaunchKernelGGL(k_lz4_decode_lds, dim3((unsigned)grid), dim3(kBlock), 0, s, src, dst, blocks, nblocks, status);
-  else if (g_lz4_variant == 2) hipLaunchKernelGGL((k_lz4_decode_v3<kV3Waves, 0, 8192, 4096, 1>), dim3((unsigned)grid), dim3(kV3Waves * 64), 0, s, src, dst, blocks, nblocks, status);
-  else if (g_lz4_variant == 3) {
-    int64_t g4 = ((int64_t)nblocks + kV4Waves - 1) / kV4Waves; if (g4 > (1 << 20)) g4 = 1 << 20;
-    hipLaunchKernelGGL((k_lz4_decode_v3<kV4Waves, 1, 4096, 2048, 512>), dim3((unsigned)g4), dim3(kV4Waves * 64), 0, s, src, dst, blocks, nblocks, status);
-  } else {
-    int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-    hipLaunchKernelGGL((k_lz4_decode_v3<1, 2, 2048, 2048, 1024, 8>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status);
-  }
+  int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
+  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -35,14 +35,6 @@ void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, 
 // captured values (per-tile compact) -> the output column: out[prefix[tile] + k] = cap[tile*1024 + k]
 void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap);
 
-// ---- fused single pass: K1 + count scan + K2 (decoupled look-back) for `x OP c` -> indices (k_fused.hip) ----
-// scratch: fused_scratch_bytes(nrows), zeroed by the launcher; ((uint32_t*)scratch)[1] != 0 afterwards = spin overrun
-bool fused_supported(int32_t dtype);
-void set_fused_diag(int d);
-size_t fused_scratch_bytes(int64_t nrows);
-void launch_scan_compact(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tile_counts,
-                         uint64_t* prefix, int64_t* out, int64_t out_cap, int64_t nrows, int64_t row_base, void* scratch);
-
 // ---- tile-count scan: u32 counts[ntiles] -> u64 prefix[ntiles+1] (prefix[ntiles] = total) -------
 // scratch: >= (ceil(ntiles/4096)+1) * 8 bytes
 // carry_in/carry_out (device, optional): continue the scan of the previous piece of the same column
@@ -120,7 +112,6 @@ struct Lz4Block {      // one (column, block) unit of work
   int32_t dst_len;     // expected uncompressed bytes (origin)
   int64_t dst_off;     // where the decoded body goes inside the body arena
 };
-void set_lz4_variant(int v);   // 0 = v1 (global round trips), 1 = v2 (LDS staging + ring), 2 = v3 (register-window parser), 3 = v4 (v3 + one-window batch), 4 = v5 (superbatch, default)
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status);
 
 }  // namespace dfdb

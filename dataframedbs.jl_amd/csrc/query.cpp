@@ -320,34 +320,10 @@ int64_t query_count(dfdb_query* q, int nstages) {
   dfdb_ctx* ctx = q->t->ctx;
   const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (q->fused_pending) HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 2, q->fused_scratch.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   stream_wait(ctx);
-  if (q->fused_pending) {
-    q->fused_pending = false;
-    if (((const uint32_t*)(ctx->pinned_scalar + 2))[1] != 0) {
-      q->executed_stages = -1;
-      fail(DFDB_ERR_DEVICE, "fused scan: look-back spin overrun (a predecessor chunk never published)");
-    }
-  }
   const int64_t n = ctx->pinned_scalar[0];
   if (nstages < 0) q->count = n;
   return n;
-}
-
-// single stage, single `col OP const` term
-static bool single_term_plan(dfdb_query* q, ScanTerm& tm) {
-  dfdb_table* t = q->t;
-  if (q->stages.size() != 1 || q->stages[0].kind != ST_PRED) return false;
-  std::vector<const Node*> conj; flatten_and(*q->stages[0].pred, conj);
-  int ord;
-  if (conj.size() != 1 || !match_simple_term(*conj[0], *t, tm, ord)) return false;
-  tm.col = need_resident(t, ord).data.p;
-  return true;
-}
-// ... over a dtype the fused kernel is instantiated for
-static bool fused_plan(dfdb_query* q, ScanTerm& tm) {
-  if (ctx_option(q->t->ctx, "fused", 0) == 0) return false;   // opt-in: measured slower than K1 + scan + K2
-  return single_term_plan(q, tm) && fused_supported(tm.dtype);
 }
 
 void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
@@ -361,65 +337,6 @@ void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
 
 void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  ScanTerm tm;
-  const bool need_exec = q->executed_stages != (int)q->stages.size() || q->bitmap_rows != t->nrows;
-  if (memkind == DFDB_MEM_DEVICE && need_exec && t->nrows > 0 && fused_plan(q, tm)) {
-    // one pass: bitmap + tile counts + per-tile prefix + total + indices (k_fused.hip)
-    ensure_state(q);
-    set_fused_diag((int)ctx_option(ctx, "fused_diag", 0));
-    q->fused_scratch.ensure(fused_scratch_bytes(t->nrows));
-    q->count = -1;
-    { LaunchTimer lt(ctx, "scan_compact");
-      launch_scan_compact(s, tm.col, tm.dtype, tm.op, tm.cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), q->prefix.as<uint64_t>(),
-                          out, cap, t->nrows, t->row_base, q->fused_scratch.p); }
-    q->prefix_valid = true; q->executed_stages = 1; q->fused_pending = true;
-    if (n) *n = query_count(q, -1);
-    return;
-  }
-  // pipelined (option "pipeline", default off: measured +2..4 % on the whole job but the four shorter K1 launches each run
-  // 2-4 % below the single launch, and the side stream's small kernels only get CU slots when K1's persistent blocks retire):
-  // the column is scanned in pieces on the engine stream while a side stream turns each finished piece into
-  // its count scan + row indices (K2 is write-bound, K1 read-bound: together they overlap instead of queueing).  Only the
-  // last piece's K2 stays exposed.  Same kernels, same bytes, same results as the plain path.
-  if (memkind == DFDB_MEM_DEVICE && need_exec && t->nrows >= (int64_t)1 << 26 && ctx_option(ctx, "pipeline", 0) != 0 && single_term_plan(q, tm)) {
-    ensure_state(q);
-    if (!ctx->side) {
-      int least = 0, greatest = 0;   // the side stream's kernels are small and on the critical path of the LAST piece: highest priority
-      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIP_CHECK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
-      for (auto& e : ctx->pipe_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    constexpr int P = 4;
-    const int w = dt_width(tm.dtype);
-    const int64_t piece = round_up(ceil_div(t->nrows, P), kCTileRows);
-    const int64_t ntiles_all = ceil_div(t->nrows, kTileRows);
-    const size_t sc_stride = scan_counts_scratch_bytes(ceil_div(piece, kTileRows)) / 8 + 8;
-    q->scan_scratch.ensure((sc_stride * P + P + 2) * 8 + 256);
-    uint64_t* carry = q->scan_scratch.as<uint64_t>() + sc_stride * P;
-    const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
-    q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
-    for (int p = 0; p < P; p++) {
-      const int64_t r0 = (int64_t)p * piece;
-      if (r0 >= t->nrows) break;
-      const int64_t rows = std::min(piece, t->nrows - r0), t0 = r0 / kTileRows, nt_p = ceil_div(rows, kTileRows);
-      { LaunchTimer lt(ctx, "scan_cmp");
-        launch_scan_cmp(s, (const char*)tm.col + r0 * w, tm.dtype, tm.op, tm.cbits, q->bitmap.as<uint64_t>() + r0 / 64, q->tile_counts.as<uint32_t>() + t0,
-                        rows, false, nt); }
-      HIP_CHECK(hipEventRecord(ctx->pipe_ev[p], s));
-      HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->pipe_ev[p], 0));
-      { LaunchTimer lt(ctx, "scan_counts", ctx->side);
-        launch_scan_counts(ctx->side, q->tile_counts.as<uint32_t>() + t0, q->prefix.as<uint64_t>() + t0, nt_p, q->scan_scratch.as<uint64_t>() + sc_stride * p,
-                           p ? carry + p : nullptr, carry + p + 1); }
-      { LaunchTimer lt(ctx, "compact_indices", ctx->side);
-        launch_compact_indices(ctx->side, q->bitmap.as<uint64_t>() + r0 / 64, q->prefix.as<uint64_t>() + t0, out, rows, t->row_base + r0, cap); }
-    }
-    HIP_CHECK(hipEventRecord(ctx->pipe_ev[8], ctx->side));
-    HIP_CHECK(hipStreamWaitEvent(s, ctx->pipe_ev[8], 0));
-    (void)ntiles_all;
-    q->prefix_valid = true; q->executed_stages = 1;
-    if (n) *n = query_count(q, -1);
-    return;
-  }
   ensure_executed(q);
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");

@@ -108,9 +108,6 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
 /* tuning knobs (defaults are what the benchmarks use; the others keep measured alternatives selectable for A/B runs):
  *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
  *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
- *   "fused"           1 = one-pass scan + look-back + compaction kernel instead of K1 + count scan + K2 (default 0)
- *   "pipeline"        1 = dfdb_select_indices_device in 4 pieces, compaction on a side stream (default 0)
- *   "lz4_variant"     LZ4 block decoder: 0 v1 .. 3 v4, 4 = v5 superbatch decoder (default 4)
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
@@ -241,8 +238,7 @@ int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col);
 int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col);
 
 /* forget the cached execution so the next count/indices/materialize re-evaluates the selection (a new
- * BlocksIterator in the reference: blocksiterator.jl:20-44).  dfdb_select_indices on a reset single-predicate
- * query with a device output runs the fused one-pass kernel (scan + look-back + compaction). */
+ * BlocksIterator in the reference: blocksiterator.jl:20-44). */
 int32_t dfdb_query_reset(dfdb_query* q);
 /* nrow(v) / size(v,1) / length(col): view.jl:192-206, column.jl:46-52 */
 int32_t dfdb_count(dfdb_query* q, int64_t* n);

@@ -11,7 +11,6 @@ ctx = dfdb.default_context(0)
 d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 try:
     t = dfdb.DFTable.new(); t.add_generated("x", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15, m); t.save(os.path.join(d, "tb")); t.close()
-    ctx.set_option("lz4_variant", variant)
     for _ in range(2):
         ctx.profile(True)
         tb = dfdb.open_table(os.path.join(d, "tb"))
