@@ -193,17 +193,37 @@ DFDB_SLOW uint64_t slow_inset(uint64_t x, int ta, const uint64_t* set, int n, in
   for (int i = 0; i < n && !hit; i++) hit = cmp3(x, ta, set[i], tb) == 0;
   return hit;
 }
+// DFIR_CAST = Julia's T(x) / convert(T, x): exact or InexactError (Int8(300), Int8(300.0), UInt64(-1), UInt64(-1.0), Int64(typemax(UInt64)),
+// Bool(2) all throw; Float32(x) rounds).  The implicit promotions of arithmetic wrap instead (`a % T`, Base int.jl) and do not come here.
+__device__ __forceinline__ bool int_fits(uint64_t x, bool src_unsigned, int rt) {
+  int64_t lo, hi;                                   // [typemin, typemax] of the targets below 64 bits
+  switch (rt) {
+    case DFDB_I8: lo = -128; hi = 127; break;        case DFDB_I16: lo = -32768; hi = 32767; break;
+    case DFDB_I32: lo = -2147483648LL; hi = 2147483647LL; break;
+    case DFDB_U8: lo = 0; hi = 255; break;           case DFDB_U16: lo = 0; hi = 65535; break;
+    case DFDB_U32: lo = 0; hi = 4294967295LL; break;
+    case DFDB_I64: return !src_unsigned || (int64_t)x >= 0;      // a UInt64 above typemax(Int64)
+    case DFDB_U64: return src_unsigned || (int64_t)x >= 0;       // a negative signed value
+    default: return true;
+  }
+  if (src_unsigned) return x <= (uint64_t)hi;
+  return (int64_t)x >= lo && (int64_t)x <= hi;
+}
 DFDB_SLOW uint64_t slow_cast(uint64_t xa, int ta, int rt, bool alive, int* err) {
   if (isf(rt)) return d_bits(as_float(xa, ta, rt));
-  if (isf(ta)) {   // Float -> Int / Bool: InexactError unless integral and in range
+  if (isf(ta)) {   // Float -> Int / Bool: InexactError unless integral and inside the TARGET's range
     const double d = bits_d(xa);
-    const bool okr = d == __builtin_trunc(d) && d >= -9223372036854775808.0 && d < 9223372036854775808.0;
+    bool okr = d == __builtin_trunc(d);
+    uint64_t v = 0;
+    if (rt == DFDB_U64) { okr = okr && d >= 0.0 && d < 18446744073709551616.0; if (okr) v = (uint64_t)d; }
+    else { okr = okr && d >= -9223372036854775808.0 && d < 9223372036854775808.0; if (okr) { v = (uint64_t)(int64_t)d; okr = rt == DFDB_BOOL || int_fits(v, false, rt); } }
     if (!okr && alive) atomicOr(err, 2);
-    const int64_t v = okr ? (int64_t)d : 0;
-    if (rt == DFDB_BOOL) { if (v != 0 && v != 1 && alive) atomicOr(err, 2); return v != 0; }
-    return (uint64_t)wrap_to(v, rt);
+    if (!okr) v = 0;
+    if (rt == DFDB_BOOL) { if (v > 1 && alive) atomicOr(err, 2); return v != 0; }
+    return (uint64_t)wrap_to((int64_t)v, rt);
   }
   if (rt == DFDB_BOOL) { if (xa > 1 && alive) atomicOr(err, 2); return xa != 0; }
+  if (ta != DFDB_BOOL && !int_fits(xa, ta >= DFDB_U8 && ta <= DFDB_U64, rt) && alive) atomicOr(err, 2);
   return (uint64_t)wrap_to((int64_t)xa, rt);
 }
 

@@ -177,8 +177,15 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   }
   if (terms.n) term_batches.push_back(terms);
   bool have = !first_stage;   // does the bitmap already hold a mask to AND with?
-  // generic conjuncts first: their DivideError check sees exactly the rows that reached this stage
-  for (const Node* c : generic) { run_interp_predicate(q, *c, have); have = true; }
+  // generic conjuncts first, as ONE interpreter program over `c1 & c2 & ...`: Julia's fused `&` is not short-circuit
+  // (BlockBroadcasting(&, (old, elem)), selection.jl:44-47), so every conjunct is evaluated — and may raise DivideError /
+  // InexactError — on every row that REACHED this stage, not only on the rows an earlier conjunct kept
+  if (generic.size() == 1) { run_interp_predicate(q, *generic[0], have); have = true; }
+  else if (!generic.empty()) {
+    NodePtr all = generic[0]->clone();
+    for (size_t i = 1; i < generic.size(); i++) all = make_and(std::move(all), generic[i]->clone());
+    run_interp_predicate(q, *all, have); have = true;
+  }
   for (const Node* c : strs) {
     int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
     const Column& col = need_resident(t, ord);

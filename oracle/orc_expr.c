@@ -323,8 +323,12 @@ static int conv(ectx_t* c, const vec_t* s, int to, vec_t* d) {
     else for (int64_t k = 0; k < n; k++) { /* Float -> Int: InexactError unless integral */
       double x = s->f[k];
       if (ms && ms[k]) { d->i[k] = 0; continue; }
-      if (x != trunc(x) || x < -9223372036854775808.0 || x >= 9223372036854775808.0) { c->err = ORC_ERR_ARGUMENT; d->i[k] = 0; }
-      else d->i[k] = wrap_int((int64_t)x, to);
+      /* (only an explicit T(x) converts Float -> Int: promotion goes the other way; the range is the TARGET's) */
+      int ok = x == trunc(x);
+      if (to == DFDB_U64) ok = ok && x >= 0.0 && x < 18446744073709551616.0;
+      else ok = ok && x >= -9223372036854775808.0 && x < 9223372036854775808.0;
+      if (!ok) { c->err = ORC_ERR_ARGUMENT; d->i[k] = 0; }
+      else d->i[k] = to == DFDB_U64 ? (int64_t)(uint64_t)x : wrap_int((int64_t)x, to);
     }
   } else if (dt_isfloat(to)) {
     if (dt_isint(from)) {
@@ -624,7 +628,35 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
       return 0;
     }
     case DFIR_CAST: {
+      /* T(x) / convert(T, x): exact or InexactError (Base: Int8(300), Int8(300.0), UInt64(-1), UInt64(-1.0), Int64(typemax(UInt64)) throw);
+       * conv() itself wraps, which is what the implicit promotions of arithmetic do (`a % T`, Base int.jl), so the range is checked here */
       vec_t a; if ((rc = eval(nd->a, c, &a))) return rc;
+      {
+        const int from = dt_base(a.dtype), to = dt_base(nd->cast_to);
+        const int64_t na = a.is_const ? 1 : a.n;
+        if (dt_isint(to) && from != to && from != DFDB_BOOL) {
+          int64_t lo = int_min_of(to), hi;
+          switch (to) { case DFDB_I8: hi = 127; break; case DFDB_I16: hi = 32767; break; case DFDB_I32: hi = 2147483647LL; break;
+                        case DFDB_U8: hi = 255; break; case DFDB_U16: hi = 65535; break; case DFDB_U32: hi = 4294967295LL; break; default: hi = INT64_MAX; }
+          for (int64_t k = 0; k < na; k++) {
+            if (a.miss && a.miss[k]) continue;
+            int ok;
+            if (dt_isfloat(from)) {
+              double x = a.f[k];
+              if (to == DFDB_U64) ok = x == trunc(x) && x >= 0.0 && x < 18446744073709551616.0;
+              else if (to == DFDB_I64) ok = x == trunc(x) && x >= -9223372036854775808.0 && x < 9223372036854775808.0;
+              else ok = x == trunc(x) && x >= (double)lo && x <= (double)hi;
+            } else if (from == DFDB_U64) {
+              uint64_t u = (uint64_t)a.i[k];
+              ok = to == DFDB_U64 ? 1 : u <= (uint64_t)hi;
+            } else {
+              int64_t v = a.i[k];
+              ok = to == DFDB_U64 ? v >= 0 : (v >= lo && v <= hi);
+            }
+            if (!ok) c->err = ORC_ERR_ARGUMENT;
+          }
+        }
+      }
       vec_t x; if ((rc = conv(c, &a, dt_base(nd->cast_to), &x))) return rc;
       *out = x; out->dtype = nd->dtype; out->miss = a.miss;
       return 0;

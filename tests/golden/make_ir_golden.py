@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/ir_golden.json: hand-assembled IR byte strings for EVERY operator of include/dfdb_ir.h with the answer Julia
+gives for them, independent of the product's own encoder (dfdb/ir.py) and of the Julia shim's OPS / UNARY tables.
+
+Why: the parity tests build the engine's and the oracle's predicates with the same encoder, so a mis-encoded operator would be
+invisible to engine-vs-oracle comparison.  Here the bytes are assembled from mnemonics by the ten-line assembler below, which reads
+the opcode VALUES out of the header text itself (never from dfdb/ir.py); the expected answers are literals typed from Julia's
+semantics (rem / mod / div signs, `/` -> Float64, non-short-circuit `&`, exact Int-vs-Float comparison, InexactError of T(x)).
+The tests then check, without a GPU, that (1) the oracle evaluates each byte string to the typed answer, (2) dfdb/ir.py emits
+exactly these bytes for the same expression, (3) the Julia shim's tables carry the header's numbers; and on the GPU that (4) the
+engine evaluates each byte string to the same answer.
+
+Table the cases run over (5 rows, block_size 2):
+  a  :: Int64            = [-7, -1, 0, 3, 10]
+  x  :: Float64          = [0.5, -2.0, 3.0, 1e10, NaN]
+  s  :: String           = ["apple", "sony", "", "sonic", "xs"]
+  m  :: Union{Int64,Missing} = [1, missing, 3, missing, 0]
+  u  :: UInt8            = [0, 1, 127, 128, 255]
+
+    python tests/golden/make_ir_golden.py        (rewrites ir_golden.json next to this file)
+"""
+import json
+import os
+import re
+import struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "..", "include", "dfdb_ir.h")
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    sym = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define\s+(DFIR_\w+)\s+(0x[0-9a-fA-F]+)", txt)}
+    enum = re.search(r"enum\s*\{(.*?)\};", txt, re.S).group(1)
+    for m in re.finditer(r"(DFDB_\w+)\s*=\s*(0x[0-9a-fA-F]+|\d+)", enum):
+        sym[m.group(1)] = int(m.group(2), 0)
+    return sym
+
+
+S = header_symbols()
+A, X, STR, M, U = 0, 1, 2, 3, 4      # column ordinals
+
+
+def col(k): return bytes([S["DFIR_COL"]]) + struct.pack("<I", k)
+def ci(v, dt="DFDB_I64"): return bytes([S["DFIR_CONST"], S[dt]]) + struct.pack("<q" if v < 0 else "<Q", v)
+def cf(v): return bytes([S["DFIR_CONST"], S["DFDB_F64"]]) + struct.pack("<d", v)
+def cb(v): return bytes([S["DFIR_CONST"], S["DFDB_BOOL"]]) + struct.pack("<q", 1 if v else 0)
+def cs(t): return bytes([S["DFIR_CONST_STR"]]) + struct.pack("<I", len(t.encode())) + t.encode()
+def cset(vals, dt="DFDB_I64"): return bytes([S["DFIR_CONST_SET"], S[dt]]) + struct.pack("<I", len(vals)) + b"".join(struct.pack("<q", v) for v in vals)
+def op(name): return bytes([S["DFIR_" + name]])
+def cast(dt): return bytes([S["DFIR_CAST"], S[dt]])
+
+
+T, F = True, False
+NAN = float("nan")
+MISS = "missing"
+# (name, Julia expression, bytes, expected result type, expected values | "DivideError" | "InexactError", dfdb/ir.py expression)
+CASES = [
+    ("add", "a .+ 2", col(A) + ci(2) + op("ADD"), "Int64", [-5, 1, 2, 5, 12], "A + 2"),
+    ("sub", "a .- 2", col(A) + ci(2) + op("SUB"), "Int64", [-9, -3, -2, 1, 8], "A - 2"),
+    ("rsub", "2 .- a", ci(2) + col(A) + op("SUB"), "Int64", [9, 3, 2, -1, -8], "2 - A"),
+    ("mul", "a .* 3", col(A) + ci(3) + op("MUL"), "Int64", [-21, -3, 0, 9, 30], "A * 3"),
+    ("div", "a ./ 2", col(A) + ci(2) + op("DIV"), "Float64", [-3.5, -0.5, 0.0, 1.5, 5.0], "A / 2"),
+    ("idiv", "a .÷ 2", col(A) + ci(2) + op("IDIV"), "Int64", [-3, 0, 0, 1, 5], "ir.div(A, 2)"),
+    ("rem", "a .% 3", col(A) + ci(3) + op("REM"), "Int64", [-1, -1, 0, 0, 1], "A % 3"),
+    ("mod", "mod.(a, 3)", col(A) + ci(3) + op("MOD"), "Int64", [2, 2, 0, 0, 1], "ir.mod(A, 3)"),
+    ("mod_negative_divisor", "mod.(a, -3)", col(A) + ci(-3) + op("MOD"), "Int64", [-1, -1, 0, 0, -2], "ir.mod(A, -3)"),
+    ("neg", "-a", col(A) + op("NEG"), "Int64", [7, 1, 0, -3, -10], "-A"),
+    ("abs", "abs.(a)", col(A) + op("ABS"), "Int64", [7, 1, 0, 3, 10], "abs(A)"),
+    ("min", "min.(a, 2)", col(A) + ci(2) + op("MIN"), "Int64", [-7, -1, 0, 2, 2], "ir.minimum(A, 2)"),
+    ("max", "max.(a, 2)", col(A) + ci(2) + op("MAX"), "Int64", [2, 2, 2, 3, 10], "ir.maximum(A, 2)"),
+    ("eq", "a .== 3", col(A) + ci(3) + op("EQ"), "Bool", [F, F, F, T, F], "A == 3"),
+    ("ne", "a .!= 3", col(A) + ci(3) + op("NE"), "Bool", [T, T, T, F, T], "A != 3"),
+    ("lt", "a .< 0", col(A) + ci(0) + op("LT"), "Bool", [T, T, F, F, F], "A < 0"),
+    ("le", "a .<= 0", col(A) + ci(0) + op("LE"), "Bool", [T, T, T, F, F], "A <= 0"),
+    ("gt", "a .> 0", col(A) + ci(0) + op("GT"), "Bool", [F, F, F, T, T], "A > 0"),
+    ("ge", "a .>= 0", col(A) + ci(0) + op("GE"), "Bool", [F, F, T, T, T], "A >= 0"),
+    ("and", "(a .> -2) .& (a .< 5)", col(A) + ci(-2) + op("GT") + col(A) + ci(5) + op("LT") + op("AND"), "Bool", [F, T, T, T, F], "(A > -2) & (A < 5)"),
+    ("or", "(a .< -2) .| (a .> 5)", col(A) + ci(-2) + op("LT") + col(A) + ci(5) + op("GT") + op("OR"), "Bool", [T, F, F, F, T], "(A < -2) | (A > 5)"),
+    ("xor", "xor.(a .> -2, a .> 1)", col(A) + ci(-2) + op("GT") + col(A) + ci(1) + op("GT") + op("XOR"), "Bool", [F, T, T, F, F], "(A > -2) ^ (A > 1)"),
+    ("not", ".!(a .> 0)", col(A) + ci(0) + op("GT") + op("NOT"), "Bool", [T, T, T, F, F], "~(A > 0)"),
+    ("bitand", "a .& 6", col(A) + ci(6) + op("AND"), "Int64", [0, 6, 0, 2, 2], "A & 6"),
+    ("bitor", "a .| 1", col(A) + ci(1) + op("OR"), "Int64", [-7, -1, 1, 3, 11], "A | 1"),
+    ("in_set", "in.(a, Ref([3, 10, 99]))", col(A) + cset([3, 10, 99]) + op("IN_SET"), "Bool", [F, F, F, T, T], "ir.isin(A, [3, 10, 99])"),
+    ("str_eq", 's .== "sony"', col(STR) + cs("sony") + op("EQ"), "Bool", [F, T, F, F, F], 'St == "sony"'),
+    ("str_ne", 's .!= "sony"', col(STR) + cs("sony") + op("NE"), "Bool", [T, F, T, T, T], 'St != "sony"'),
+    ("str_lt", 's .< "sonic"', col(STR) + cs("sonic") + op("LT"), "Bool", [T, F, T, F, F], 'St < "sonic"'),
+    ("startswith", 'startswith.(s, "so")', col(STR) + cs("so") + op("STARTSWITH"), "Bool", [F, T, F, T, F], 'ir.startswith(St, "so")'),
+    ("endswith", 'endswith.(s, "s")', col(STR) + cs("s") + op("ENDSWITH"), "Bool", [F, F, F, F, T], 'ir.endswith(St, "s")'),
+    ("sizeof", "sizeof.(s)", col(STR) + op("SIZEOF"), "Int64", [5, 4, 0, 5, 2], "ir.sizeof(St)"),
+    ("ismissing", "ismissing.(m)", col(M) + op("ISMISSING"), "Bool", [F, T, F, T, F], "ir.ismissing(Mi)"),
+    ("coalesce", "coalesce.(m, 42)", col(M) + ci(42) + op("COALESCE"), "Int64", [1, 42, 3, 42, 0], "ir.coalesce(Mi, 42)"),
+    ("missing_propagates", "m .+ 1", col(M) + ci(1) + op("ADD"), "Missing(Int64)", [2, MISS, 4, MISS, 1], "Mi + 1"),
+    ("float_lt_nan", "x .< 1.0", col(X) + cf(1.0) + op("LT"), "Bool", [T, T, F, F, F], "Xf < 1.0"),
+    ("float_ne_nan", "x .!= 3.0", col(X) + cf(3.0) + op("NE"), "Bool", [T, T, F, T, T], "Xf != 3.0"),
+    ("int_vs_float_exact", "a .< x", col(A) + col(X) + op("LT"), "Bool", [T, F, T, T, F], "A < Xf"),
+    ("float_mul", "x .* 2.0", col(X) + cf(2.0) + op("MUL"), "Float64", [1.0, -4.0, 6.0, 2e10, NAN], "Xf * 2.0"),
+    ("promote_int_float", "a .+ 0.5", col(A) + cf(0.5) + op("ADD"), "Float64", [-6.5, -0.5, 0.5, 3.5, 10.5], "A + 0.5"),
+    ("uint8_widens", "u .+ 1", col(U) + ci(1) + op("ADD"), "Int64", [1, 2, 128, 129, 256], "Uc + 1"),
+    ("uint8_wraps", "u .+ 0x01", col(U) + ci(1, "DFDB_U8") + op("ADD"), "UInt8", [1, 2, 128, 129, 0], "Uc + ir.const(1, ir.U8)"),
+    ("bool_const", "(a .> 0) .& true", col(A) + ci(0) + op("GT") + cb(True) + op("AND"), "Bool", [F, F, F, T, T], "(A > 0) & True"),
+    ("cast_float64", "Float64.(a)", col(A) + cast("DFDB_F64"), "Float64", [-7.0, -1.0, 0.0, 3.0, 10.0], "ir.cast(A, ir.F64)"),
+    ("cast_int8", "Int8.(a)", col(A) + cast("DFDB_I8"), "Int8", [-7, -1, 0, 3, 10], "ir.cast(A, ir.I8)"),
+    ("cast_uint8_to_int8_inexact", "Int8.(u)", col(U) + cast("DFDB_I8"), "Int8", "InexactError", "ir.cast(Uc, ir.I8)"),
+    ("cast_negative_to_unsigned_inexact", "UInt64.(a)", col(A) + cast("DFDB_U64"), "UInt64", "InexactError", "ir.cast(A, ir.U64)"),
+    ("cast_const_300_int8_inexact", "Int8.(a .* 0 .+ 300)", col(A) + ci(0) + op("MUL") + ci(300) + op("ADD") + cast("DFDB_I8"), "Int8", "InexactError", "ir.cast(A * 0 + 300, ir.I8)"),
+    ("cast_300f_int8_inexact", "Int8.(a .* 0 .+ 300.0)", col(A) + ci(0) + op("MUL") + cf(300.0) + op("ADD") + cast("DFDB_I8"), "Int8", "InexactError", "ir.cast(A * 0 + 300.0, ir.I8)"),
+    ("cast_minus1f_uint64_inexact", "UInt64.(a .* 0 .- 1.0)", col(A) + ci(0) + op("MUL") + cf(1.0) + op("SUB") + cast("DFDB_U64"), "UInt64", "InexactError", "ir.cast(A * 0 - 1.0, ir.U64)"),
+    ("cast_2p63f_uint64", "UInt64.(a .* 0 .+ 2.0^63)", col(A) + ci(0) + op("MUL") + cf(2.0 ** 63) + op("ADD") + cast("DFDB_U64"), "UInt64", [2 ** 63] * 5, "ir.cast(A * 0 + 2.0 ** 63, ir.U64)"),
+    ("cast_2p63f_int64_inexact", "Int64.(a .* 0 .+ 2.0^63)", col(A) + ci(0) + op("MUL") + cf(2.0 ** 63) + op("ADD") + cast("DFDB_I64"), "Int64", "InexactError", "ir.cast(A * 0 + 2.0 ** 63, ir.I64)"),
+    ("cast_fraction_inexact", "Int64.(x)", col(X) + cast("DFDB_I64"), "Int64", "InexactError", "ir.cast(Xf, ir.I64)"),
+    ("cast_float32_rounds", "Float32.(a ./ 3)", col(A) + ci(3) + op("DIV") + cast("DFDB_F32"), "Float32",
+     [struct.unpack("<f", struct.pack("<f", v / 3))[0] for v in (-7, -1, 0, 3, 10)], "ir.cast(A / 3, ir.F32)"),
+    ("rem_by_zero", "a .% 0", col(A) + ci(0) + op("REM"), "Int64", "DivideError", "A % 0"),
+    ("idiv_by_zero", "a .÷ 0", col(A) + ci(0) + op("IDIV"), "Int64", "DivideError", "ir.div(A, 0)"),
+]
+
+
+def main():
+    out = {"comment": "hand-assembled from include/dfdb_ir.h by tests/golden/make_ir_golden.py; expected = Julia semantics",
+           "table": {"a": [-7, -1, 0, 3, 10], "x": [0.5, -2.0, 3.0, 1e10, "NaN"], "s": ["apple", "sony", "", "sonic", "xs"],
+                     "m": [1, None, 3, None, 0], "u": [0, 1, 127, 128, 255], "block_size": 2},
+           "opcodes": {k: v for k, v in sorted(S.items()) if k.startswith("DFIR_")},
+           "dtypes": {k: v for k, v in sorted(S.items()) if k.startswith("DFDB_")},
+           "cases": []}
+    for name, julia, b, rtype, want, py in CASES:
+        if isinstance(want, list):
+            want = ["NaN" if isinstance(v, float) and v != v else v for v in want]
+        out["cases"].append({"name": name, "julia": julia, "hex": b.hex(), "type": rtype, "expect": want, "ir_py": py})
+    with open(os.path.join(HERE, "ir_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

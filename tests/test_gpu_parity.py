@@ -173,6 +173,24 @@ def test_divide_error_and_bad_predicates(oracle, dfdb_mod, ctx):
         ov.nrow()
     with pytest.raises(ZeroDivisionError):
         dfdb_mod.nrow(dv)
+    # two generic conjuncts, the zero divisor only on rows the FIRST one rejects: Julia's fused `&` is not short-circuit
+    # (BlockBroadcasting(&, (old, elem)), selection.jl:44-47), so the second is evaluated on every row that reached the stage and raises
+    z1 = np.full(11, 3, np.int64)
+    z2 = np.where(a % 3 == 0, 2, 0).astype(np.int64)          # zero exactly where a % z1 != 0
+    b = np.arange(11, dtype=np.int64) * 2
+    p2 = Pair(oracle, dfdb_mod, {"a": a, "b": b, "z1": z1, "z2": z2}, block_size=4)
+    A, B, Z1, Z2 = ir.col(0), ir.col(1), ir.col(2), ir.col(3)
+    for stages in ([("pred", (A % Z1 == 0) & (B % Z2 == 0))],                       # one fused predicate
+                   [("pred", A % Z1 == 0), ("pred", B % Z2 == 0)],                  # two selections: fused by the queue
+                   [("pred", (A > 100) & (B % Z2 == 0))]):                          # a simple term rejects every row: still raises
+        ov, dv = apply_stages(p2, stages)
+        with pytest.raises(ZeroDivisionError):
+            ov.nrow()
+        with pytest.raises(ZeroDivisionError):
+            dfdb_mod.nrow(dv)
+    # ... but a range stage in between really removes the rows (a new stage, not a fused `&`): rows 3, 6, 9 (a = -3, 0, 3) have z2 != 0
+    ov, dv = apply_stages(p2, [("idx", [3, 6, 9]), ("pred", B % Z2 == 0)])
+    assert_same(p2, ov, dv)
     with pytest.raises(ValueError):      # non-Bool predicate: selection.jl:52-55
         dfdb_mod.selection(dfdb_mod.DFView(p.d), ir.col(0) * 3)
     with pytest.raises(ValueError):

@@ -1,0 +1,138 @@
+"""The expression IR pinned three ways: tests/golden/ir_golden.json holds byte strings hand-assembled from
+include/dfdb_ir.h (tests/golden/make_ir_golden.py, which never imports dfdb/ir.py) with the answers Julia gives.
+CPU: the header's numbers == dfdb/ir.py's == the Julia shim's tables; dfdb/ir.py emits exactly the golden bytes; the oracle evaluates
+the golden bytes to the golden answers.  GPU: the engine evaluates the same bytes to the same answers."""
+import ctypes as C
+import json
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = json.load(open(os.path.join(HERE, "golden", "ir_golden.json")))
+NP_OF = {"Int64": np.int64, "Int8": np.int8, "UInt8": np.uint8, "UInt64": np.uint64, "Float64": np.float64, "Float32": np.float32, "Bool": np.bool_}
+
+
+def _columns():
+    t = G["table"]
+    return {"a": np.array(t["a"], np.int64), "x": np.array([float("nan") if v == "NaN" else v for v in t["x"]], np.float64), "s": list(t["s"]),
+            "m": np.ma.masked_array(np.array([0 if v is None else v for v in t["m"]], np.int64), mask=[v is None for v in t["m"]]),
+            "u": np.array(t["u"], np.uint8)}
+
+
+def _check(case, got):
+    want = case["expect"]
+    base = case["type"].replace("Missing(", "").replace(")", "")
+    if case["type"].startswith("Missing("):
+        assert isinstance(got, np.ma.MaskedArray), case["name"]
+        miss = [v == "missing" for v in want]
+        assert np.ma.getmaskarray(got).tolist() == miss, case["name"]
+        assert [int(v) for v, m in zip(np.asarray(got.data), miss) if not m] == [v for v in want if v != "missing"], case["name"]
+        return
+    assert not isinstance(got, np.ma.MaskedArray), case["name"]
+    assert got.dtype == np.dtype(NP_OF[base]), (case["name"], got.dtype)
+    w = np.array([float("nan") if v == "NaN" else v for v in want], NP_OF[base])
+    assert np.array_equal(got, w, equal_nan=got.dtype.kind == "f"), (case["name"], got, w)
+
+
+def test_header_python_and_julia_tables_agree():
+    from dfdb import ir
+    ops = G["opcodes"]
+    hdr = open(os.path.join(ROOT, "include", "dfdb_ir.h")).read()
+    assert {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define\s+(DFIR_\w+)\s+(0x[0-9a-fA-F]+)", hdr)} == ops     # the JSON is current
+    for name, val in ops.items():
+        assert getattr(ir, name[len("DFIR_"):]) == val, name                                        # dfdb/ir.py carries the header's numbers
+    for name, val in G["dtypes"].items():
+        short = {"DFDB_STRING": "STRING", "DFDB_BOOL": "BOOL", "DFDB_NULLABLE": "NULLABLE", "DFDB_DTYPE_MASK": "DTYPE_MASK"}.get(name, name[len("DFDB_"):])
+        assert getattr(ir, short) == val, name
+    # the Julia shim: OPS / UNARY / the literal opcodes it writes
+    jl = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "DataFrameDBsAMD.jl")).read()
+    want = {"(+)": "ADD", "(-)": "SUB", "(*)": "MUL", "(/)": "DIV", "div": "IDIV", "(÷)": "IDIV", "rem": "REM", "(%)": "REM", "mod": "MOD", "min": "MIN", "max": "MAX",
+            "(==)": "EQ", "(!=)": "NE", "(<)": "LT", "(<=)": "LE", "(>)": "GT", "(>=)": "GE", "(&)": "AND", "(|)": "OR", "xor": "XOR",
+            "startswith": "STARTSWITH", "endswith": "ENDSWITH", "coalesce": "COALESCE"}
+    ops_src = jl[jl.index("const OPS = Dict"):jl.index("const UNARY")]
+    found = dict(re.findall(r"(\([^()\s]+\)|\w+)\s*=>\s*(0x[0-9a-f]+)", ops_src))
+    assert {k: int(v, 16) for k, v in found.items()} == {k: ops["DFIR_" + v] for k, v in want.items()}
+    un_src = jl[jl.index("const UNARY"):jl.index("\n", jl.index("const UNARY"))]
+    found = dict(re.findall(r"(\([^()\s]+\)|\w+)\s*=>\s*(0x[0-9a-f]+)", un_src))
+    assert {k: int(v, 16) for k, v in found.items()} == {"(-)": ops["DFIR_NEG"], "abs": ops["DFIR_ABS"], "(!)": ops["DFIR_NOT"], "ismissing": ops["DFIR_ISMISSING"], "sizeof": ops["DFIR_SIZEOF"]}
+    assert re.search(r"emit_col\(io, ord::Integer\) = \(write\(io, 0x01\)", jl) and "write(io, 0x02); write(io, DT[T])" in jl and "write(io, 0x03)" in jl
+    assert "0x40))" in jl and "0x50, DT[Float64]" in jl                                            # in.() and Float64()
+    dt_src = jl[jl.index("const DT = Dict"):]
+    dt_src = dt_src[:dt_src.index(")\n") + 1]
+    jdt = dict(re.findall(r"(\w+)\s*=>\s*(\d+)", dt_src))
+    for jname, dname in (("Int8", "I8"), ("Int16", "I16"), ("Int32", "I32"), ("Int64", "I64"), ("UInt8", "U8"), ("UInt16", "U16"), ("UInt32", "U32"),
+                         ("UInt64", "U64"), ("Float32", "F32"), ("Float64", "F64"), ("Bool", "BOOL"), ("String", "STRING")):
+        assert int(jdt[jname]) == G["dtypes"]["DFDB_" + dname], jname
+
+
+def test_ir_py_emits_the_golden_bytes():
+    from dfdb import ir
+    env = {"ir": ir, "A": ir.col(0), "Xf": ir.col(1), "St": ir.col(2), "Mi": ir.col(3), "Uc": ir.col(4)}
+    for c in G["cases"]:
+        e = eval(c["ir_py"], env)
+        assert e.to_ir().hex() == c["hex"], (c["name"], e.to_ir().hex(), c["hex"])
+
+
+def test_oracle_evaluates_golden_bytes(oracle):
+    cols = _columns()
+    t = oracle.Table(block_size=G["table"]["block_size"])
+    for k, v in cols.items():
+        if isinstance(v, np.ma.MaskedArray):
+            t.add_column(k, np.ascontiguousarray(v.filled(0)), missing=np.ma.getmaskarray(v))
+        else:
+            t.add_column(k, v)
+    for c in G["cases"]:
+        v = t.view().set_projection([("k", bytes.fromhex(c["hex"]))])
+        if c["expect"] == "DivideError":
+            with pytest.raises(ZeroDivisionError):
+                v.materialize()
+        elif c["expect"] == "InexactError":
+            with pytest.raises(ValueError, match="InexactError"):
+                v.materialize()
+        else:
+            _check(c, v.materialize()[0])
+        # a Bool-typed case is also a selection function: the selected rows are where the answer is true
+        if c["type"] == "Bool" and isinstance(c["expect"], list):
+            sel = t.view().add_predicate(bytes.fromhex(c["hex"])).select_indices()
+            assert sel.tolist() == [i + 1 for i, b in enumerate(c["expect"]) if b], c["name"]
+
+
+@pytest.mark.gpu
+def test_engine_evaluates_golden_bytes(dfdb_mod, ctx):
+    from dfdb import _native as N, api
+    L = N.load()
+    t = dfdb_mod.DFTable.from_columns(_columns(), block_size=G["table"]["block_size"])
+
+    def query(proj_hex=None, pred_hex=None):
+        q = api._Query.__new__(api._Query)
+        q._h = C.c_void_p()
+        N.check(L.dfdb_query_new(t._h, C.byref(q._h)))
+        if pred_hex:
+            b = bytes.fromhex(pred_hex)
+            N.check(L.dfdb_query_add_predicate(q._h, b, len(b)))
+        if proj_hex:
+            b = bytes.fromhex(proj_hex)
+            buf = C.create_string_buffer(b, len(b))
+            N.check(L.dfdb_query_set_projection(q._h, 1, (C.c_char_p * 1)(b"k"), (C.c_void_p * 1)(C.cast(buf, C.c_void_p)), (C.c_size_t * 1)(len(b))))
+            q.view = types.SimpleNamespace(projection=[0])
+        else:
+            q.view = types.SimpleNamespace(projection=[0] * t.ncols)
+        return q
+
+    for c in G["cases"]:
+        q = query(proj_hex=c["hex"])
+        if c["expect"] == "DivideError":
+            with pytest.raises(ZeroDivisionError):
+                q.materialize()
+        elif c["expect"] == "InexactError":
+            with pytest.raises(ValueError, match="InexactError"):
+                q.materialize()
+        else:
+            _check(c, q.materialize()[0])
+        if c["type"] == "Bool" and isinstance(c["expect"], list):
+            assert query(pred_hex=c["hex"]).indices().tolist() == [i + 1 for i, b in enumerate(c["expect"]) if b], c["name"]
