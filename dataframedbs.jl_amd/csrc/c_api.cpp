@@ -61,6 +61,9 @@ int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt) {
 extern "C" {
 
 int32_t dfdb_version(void) { return DFDB_ABI_VERSION; }
+int32_t dfdb_device_count(int32_t* n) {
+  return guard([&] { NEED(n); int nd = 0; if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); nd = 0; } *n = nd; });
+}
 
 int32_t dfdb_last_error(char* buf, size_t cap) {
   if (buf && cap) { snprintf(buf, cap, "%s", g_last_error.c_str()); }

@@ -46,7 +46,7 @@ class OutCol(C.Structure):
 
 # every exported symbol of include/dfdb.h: (restype is always int32 status)
 SYMBOLS = [
-    "dfdb_version", "dfdb_last_error",
+    "dfdb_version", "dfdb_device_count", "dfdb_last_error",
     "dfdb_ctx_create", "dfdb_ctx_destroy", "dfdb_ctx_synchronize", "dfdb_ctx_device_info", "dfdb_ctx_timer_start",
     "dfdb_ctx_timer_stop", "dfdb_ctx_set_option", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
     "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",

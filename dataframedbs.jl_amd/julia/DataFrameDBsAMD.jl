@@ -4,7 +4,8 @@
 #
 # NOT EXECUTED IN THE BUILD IMAGE (julia is not installed there: SURVEY.md "Facts").  It is the binding a
 # DataFrameDBs.jl maintainer would add; INTEGRATION.md walks through it.  Every ccall below targets a symbol
-# declared in include/dfdb.h, whose comments name the Julia method each one stands in for.
+# declared in include/dfdb.h, whose comments name the Julia method each one stands in for; julia/STATIC_REVIEW.md walks every
+# ccall signature against that header.
 #
 #   using DataFrameDBs, DataFrameDBsAMD
 #   DataFrameDBsAMD.enable!()                 # route materialize/nrow of DFView through the GPU
@@ -15,9 +16,19 @@
 # include/dfdb_ir.h.  Named Base functions map 1:1; closures (`:a => x -> x > c`) are traced by calling
 # them on a symbolic `Tr` value.  Anything outside the IR op set makes the engine answer
 # DFDB_ERR_UNSUPPORTED (or the tracer throw), and the call falls back to the stock Julia path.
+#
+# Closure grammar the tracer accepts: any composition of the functions in OPS / UNARY, `in(x, vector)`, `Float64(x)`, over the
+# closure's arguments and literal numbers / strings / Dates / Chars — `x -> x > c`, `(a, b) -> (a % 10 == 0) & (b < 5.0)`,
+# `x -> startswith(x, "so") | (sizeof(x) > 4)`.  NOT traceable, by construction: anything that needs a real `Bool` out of a traced
+# value — `&&`, `||`, `if`, `ifelse`, `?:`, and therefore chained comparisons (`65 > a > 34` lowers to `(65 > a) && (a > 34)`;
+# test/selection.jl:53) — and calls to functions outside the tables.  Those raise a `TypeError` / `MethodError` inside the trace,
+# which `lower` turns into `Unsupported`, and the view is evaluated by the reference's own Julia path (results are the same, only
+# slower).  The DFColumn-broadcasting form of the same predicate, `(65 .> t.a) .& (t.a .> 34)`, never goes through a closure: its
+# BlockBroadcasting tree names `>` and `&` directly and lowers 1:1.
 module DataFrameDBsAMD
 
 import Dates
+import Statistics
 using DataFrameDBs
 using DataFrameDBs: DFTable, DFView, DFColumn, ColRef, BlockBroadcasting, SelectionQueue, Projection
 import DataFrames
@@ -130,21 +141,41 @@ function lower(b::BlockBroadcasting, ord)
     end
 end
 
-# ---------------------------------------------------------------- device tables (one per opened DFTable path)
+# ---------------------------------------------------------------- devices: one GPU, or a block-range sharded group of all of them
+# With more than one GPU visible (and DFDB_GPUS != "1") every opened table is sharded by block range over ALL of them
+# (dfdb_group_*: a host thread per GPU inside the library, RCCL all-reduce for nrow / sum / minimum / maximum, rank-order
+# concatenation for materialize; include/dfdb.h "multi-GPU groups").  `unique` and the write side use GPU 0 alone.
 mutable struct Device
-    ctx::Ptr{Cvoid}
-    tables::Dict{String,Ptr{Cvoid}}
+    ctx::Ptr{Cvoid}                       # single-GPU context (GPU 0)
+    group::Ptr{Cvoid}                     # dfdb_group* or C_NULL
+    tables::Dict{String,Ptr{Cvoid}}       # dfdb_table*  per opened DFTable path (GPU 0, whole table)
+    gtables::Dict{String,Ptr{Cvoid}}      # dfdb_gtable* per opened DFTable path (sharded)
 end
 const DEV = Ref{Union{Nothing,Device}}(nothing)
+
+function ngpus()
+    n = Ref{Int32}(0)
+    check(ccall((:dfdb_device_count, LIB), Int32, (Ptr{Int32},), n))
+    want = tryparse(Int, get(ENV, "DFDB_GPUS", ""))
+    want === nothing ? Int(n[]) : min(Int(n[]), want)
+end
 
 function device()
     if DEV[] === nothing
         ctx = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dfdb_ctx_create, LIB), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), 0, C_NULL, ctx))
-        DEV[] = Device(ctx[], Dict{String,Ptr{Cvoid}}())
+        grp = Ref{Ptr{Cvoid}}(C_NULL)
+        n = ngpus()
+        if n > 1
+            ids = Int32[i for i in 0:n-1]
+            # exchange = 0 (DFDB_EXCHANGE_AUTO): RCCL over xGMI for distinct devices
+            GC.@preserve ids check(ccall((:dfdb_group_create, LIB), Int32, (Ptr{Int32}, Int32, Int32, Ptr{Ptr{Cvoid}}), ids, n, 0, grp))
+        end
+        DEV[] = Device(ctx[], grp[], Dict{String,Ptr{Cvoid}}(), Dict{String,Ptr{Cvoid}}())
     end
     DEV[]
 end
+sharded() = device().group != C_NULL
 
 # open_table + read_block! of every block, once: decoded columns stay resident in HBM
 function device_table(t::DFTable)
@@ -156,40 +187,62 @@ function device_table(t::DFTable)
         h[]
     end
 end
+# the same, every GPU loading only its block range
+function device_gtable(t::DFTable)
+    d = device()
+    get!(d.gtables, t.path) do
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dfdb_group_table_open, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Ptr{Cvoid}}), d.group, t.path, h))
+        check(ccall((:dfdb_group_table_load, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Ptr{Cvoid}), h[], C_NULL, 0, C_NULL))
+        h[]
+    end
+end
 
 ordinals(t::DFTable) = Dict(m.name => i - 1 for (i, m) in enumerate(t.meta.columns))
+struct PredCode                            # a lowered predicate stage (told apart from an index-vector stage by type)
+    code::Vector{UInt8}
+end
 
-# ---------------------------------------------------------------- DFView -> dfdb_query
-function with_query(f, v::DFView)
-    th = device_table(v.table)
-    ord = ordinals(v.table)
-    q = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:dfdb_query_new, LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), th, q))
-    try
-        for el in v.selection.queue           # SelectionQueue stages, already composed by DataFrameDBs.add
-            if el isa BlockBroadcasting
-                code = lower(el, ord).code
-                GC.@preserve code check(ccall((:dfdb_query_add_predicate, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), q[], code, length(code)))
-            elseif el isa AbstractRange
-                check(ccall((:dfdb_query_add_range, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64), q[], first(el), step(el), last(el)))
-            elseif el isa Integer
-                check(ccall((:dfdb_query_add_integer, LIB), Int32, (Ptr{Cvoid}, Int64), q[], el))
-            else
-                idx = collect(Int64, el)
-                GC.@preserve idx check(ccall((:dfdb_query_add_indices, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64), q[], idx, length(idx)))
-            end
-        end
+# ---------------------------------------------------------------- DFView -> dfdb_query / dfdb_gquery
+# One builder, generated twice: the group entry points take the same arguments as the single-GPU ones (include/dfdb.h).
+for (fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ) in (
+        (:with_query, :device_table, :dfdb_query_new, :dfdb_query_free, :dfdb_query_add_range, :dfdb_query_add_integer,
+         :dfdb_query_add_indices, :dfdb_query_add_predicate, :dfdb_query_set_projection),
+        (:with_gquery, :device_gtable, :dfdb_group_query_new, :dfdb_group_query_free, :dfdb_group_query_add_range, :dfdb_group_query_add_integer,
+         :dfdb_group_query_add_indices, :dfdb_group_query_add_predicate, :dfdb_group_query_set_projection))
+    @eval function $fname(f, v::DFView)
+        ord = ordinals(v.table)
+        # lower everything BEFORE touching the device: an untraceable closure must fall back without side effects
+        stages = Any[el isa BlockBroadcasting ? PredCode(lower(el, ord).code) : el for el in v.selection.queue]
         names = [string(k) for k in keys(v.projection)]
         codes = [lower(c, ord).code for c in values(v.projection.cols)]
-        lens = Csize_t[length(c) for c in codes]
-        GC.@preserve names codes begin
-            np = [pointer(n) for n in names]; cp = [pointer(c) for c in codes]
-            check(ccall((:dfdb_query_set_projection, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Ptr{UInt8}}, Ptr{Csize_t}),
-                        q[], length(names), np, cp, lens))
+        th = $tabfn(v.table)
+        q = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall(($(QuoteNode(NEW)), LIB), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), th, q))
+        try
+            for el in stages                      # SelectionQueue stages, already composed by DataFrameDBs.add
+                if el isa PredCode
+                    code = el.code
+                    GC.@preserve code check(ccall(($(QuoteNode(PRED)), LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), q[], code, length(code)))
+                elseif el isa AbstractRange
+                    check(ccall(($(QuoteNode(RANGE)), LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64), q[], first(el), step(el), last(el)))
+                elseif el isa Integer
+                    check(ccall(($(QuoteNode(INTEGER)), LIB), Int32, (Ptr{Cvoid}, Int64), q[], el))
+                else
+                    idx = collect(Int64, el)
+                    GC.@preserve idx check(ccall(($(QuoteNode(INDICES)), LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64), q[], idx, length(idx)))
+                end
+            end
+            lens = Csize_t[length(c) for c in codes]
+            GC.@preserve names codes begin
+                np = [pointer(n) for n in names]; cp = [pointer(c) for c in codes]
+                check(ccall(($(QuoteNode(PROJ)), LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Ptr{UInt8}}, Ptr{Csize_t}),
+                            q[], length(names), np, cp, lens))
+            end
+            return f(q[])
+        finally
+            ccall(($(QuoteNode(FREE)), LIB), Int32, (Ptr{Cvoid},), q[])
         end
-        return f(q[])
-    finally
-        ccall((:dfdb_query_free, LIB), Int32, (Ptr{Cvoid},), q[])
     end
 end
 
@@ -199,80 +252,154 @@ struct OutCol
     memkind::Int32; dtype::Int32; count::Int64; nbytes::Int64
 end
 
-"nrow(v) on the device (view.jl:192-206): one predicate scan, no block loop."
+"nrow(v) on the device(s) (view.jl:192-206): one predicate scan per GPU, one RCCL all-reduce of the count when sharded."
 function gpu_nrow(v::DFView)
-    with_query(v) do q
-        n = Ref{Int64}(0)
-        check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
-        n[]
+    length(v.projection) == 0 && return 0            # isempty(it.streams): nothing to read (blocksiterator.jl:101)
+    n = Ref{Int64}(0)
+    if sharded()
+        with_gquery(v) do q
+            check(ccall((:dfdb_group_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        end
+    else
+        with_query(v) do q
+            check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        end
+    end
+    n[]
+end
+
+# shard 0's ordinary query handle: column types are the same on every shard
+function gquery_coltype(gq, i)
+    q0 = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dfdb_group_query_shard, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{Cvoid}}), gq, 0, q0))
+    dt = Ref{Int32}(0)
+    check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q0[], i, dt))
+    dt[]
+end
+
+# caller-owned Julia vectors for the n selected rows of every projection column; `strbytes(i)` = string bytes column i needs
+function alloc_outputs(v::DFView, n::Integer, coltype, strbytes)
+    ncols = length(v.projection)
+    outs = Vector{OutCol}(undef, ncols)
+    bufs = Any[]
+    for i in 1:ncols
+        dt = coltype(i - 1)
+        T = jltype(dt)
+        if (dt & 0x3f) == 12                                     # String: sizes + byte arena
+            nb = strbytes(i - 1)
+            sizes = Vector{Int32}(undef, n); arena = Vector{UInt8}(undef, nb)
+            push!(bufs, (T, sizes, arena, nothing))
+            outs[i] = OutCol(pointer(sizes), pointer(arena), C_NULL, nb, 0, 0, 0, 0)
+        else
+            B = Base.nonmissingtype(T)
+            vals = Vector{B}(undef, n); miss = T === B ? nothing : Vector{UInt8}(undef, n)
+            push!(bufs, (T, vals, nothing, miss))
+            outs[i] = OutCol(pointer(vals), C_NULL, miss === nothing ? C_NULL : pointer(miss), 0, 0, 0, 0, 0)
+        end
+    end
+    outs, bufs
+end
+
+# engine buffers -> the containers the reference materialises into (make_materialization: Vector{T}, BitVector for Bool;
+# FlatStrings -> Vector{String} like projection.jl:99-100), relabelled to the column's declared element type
+function finish_columns(v::DFView, bufs)
+    decl = [DataFrameDBs.coltype(v.projection, i) for i in 1:length(v.projection)]
+    map(enumerate(bufs)) do (i, (T, a, arena, miss))
+        if arena !== nothing
+            res = Vector{T}(undef, length(a)); o = 0
+            for (k, s) in enumerate(a)
+                res[k] = s < 0 ? missing : (str = unsafe_string(pointer(arena) + o, s); o += s; str)
+            end
+            res
+        elseif miss !== nothing
+            T[m != 0 ? missing : x for (x, m) in zip(a, miss)]
+        elseif T === Bool
+            BitVector(a)                                          # make_materialization(::Type{Bool}) = BitVector (materialization.jl:10)
+        else
+            relabel(Base.nonmissingtype(decl[i]), a)
+        end
     end
 end
 
-"materialize(v) on the device (materialization.jl:27-40): the selection is evaluated once, outputs are caller-owned Julia vectors."
-function gpu_materialize(v::DFView; first_occurrences_of::Int = -1)
+"materialize(v) on the device(s) (materialization.jl:27-40): the selection is evaluated once, outputs are caller-owned Julia vectors."
+function gpu_materialize_columns(v::DFView; first_occurrences_of::Int = -1)
+    if sharded() && first_occurrences_of < 0
+        return with_gquery(v) do q
+            check(ccall((:dfdb_group_query_hint_materialize, LIB), Int32, (Ptr{Cvoid}, Int32), q, 1))
+            n = Ref{Int64}(0)
+            check(ccall((:dfdb_group_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))     # one process drives every shard: the local rows are all rows
+            outs, bufs = alloc_outputs(v, n[], i -> gquery_coltype(q, i), i -> begin
+                nb = Ref{Int64}(0)
+                check(ccall((:dfdb_group_result_string_bytes, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), q, i, nb)); nb[]
+            end)
+            GC.@preserve bufs outs check(ccall((:dfdb_group_materialize, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Int32), q, outs, length(outs)))
+            finish_columns(v, bufs)
+        end
+    end
     with_query(v) do q
         check(ccall((:dfdb_query_hint_materialize, LIB), Int32, (Ptr{Cvoid}, Int32), q, 1))   # the count below is the scan: let it keep projected predicate columns
         # unique: narrow the selection to the first occurrence of every value of that projection column (Julia's order)
         first_occurrences_of >= 0 && check(ccall((:dfdb_query_unique, LIB), Int32, (Ptr{Cvoid}, Int32), q, first_occurrences_of))
         n = Ref{Int64}(0)
         check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
-        ncols = length(v.projection)
-        outs = Vector{OutCol}(undef, ncols)
-        bufs = Any[]
-        for i in 1:ncols
+        outs, bufs = alloc_outputs(v, n[], i -> begin
             dt = Ref{Int32}(0)
-            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, i - 1, dt))
-            T = jltype(dt[])
-            if (dt[] & 0x3f) == 12                                   # String: sizes + byte arena
-                nb = Ref{Int64}(0)
-                check(ccall((:dfdb_result_string_bytes, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), q, i - 1, nb))
-                sizes = Vector{Int32}(undef, n[]); arena = Vector{UInt8}(undef, nb[])
-                push!(bufs, (T, sizes, arena, nothing))
-                outs[i] = OutCol(pointer(sizes), pointer(arena), C_NULL, nb[], 0, 0, 0, 0)
-            else
-                B = Base.nonmissingtype(T)
-                vals = Vector{B}(undef, n[]); miss = T === B ? nothing : Vector{UInt8}(undef, n[])
-                push!(bufs, (T, vals, nothing, miss))
-                outs[i] = OutCol(pointer(vals), C_NULL, miss === nothing ? C_NULL : pointer(miss), 0, 0, 0, 0, 0)
-            end
-        end
-        GC.@preserve bufs outs check(ccall((:dfdb_materialize, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Int32), q, outs, ncols))
-        cols = map(bufs) do (T, a, arena, miss)
-            if arena !== nothing                                     # FlatStrings -> Vector{String} like projection.jl:99-100
-                res = Vector{T}(undef, length(a)); o = 0
-                for (k, s) in enumerate(a)
-                    res[k] = s < 0 ? missing : (str = unsafe_string(pointer(arena) + o, s); o += s; str)
-                end
-                res
-            elseif miss !== nothing
-                T[m != 0 ? missing : x for (x, m) in zip(a, miss)]
-            else
-                a
-            end
-        end
-        DataFrames.DataFrame(collect(cols), collect(keys(v.projection)), copycols = false)
+            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, i, dt)); dt[]
+        end, i -> begin
+            nb = Ref{Int64}(0)
+            check(ccall((:dfdb_result_string_bytes, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), q, i, nb)); nb[]
+        end)
+        GC.@preserve bufs outs check(ccall((:dfdb_materialize, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Int32), q, outs, length(outs)))
+        finish_columns(v, bufs)
     end
 end
+
+function gpu_materialize(v::DFView; first_occurrences_of::Int = -1)
+    cols = gpu_materialize_columns(v; first_occurrences_of = first_occurrences_of)
+    DataFrames.DataFrame(collect(cols), collect(keys(v.projection)), copycols = false)
+end
+
+"materialize(c::DFColumn) on the device(s) (materialization.jl:46-52): the one projection column as a Vector{T} / BitVector."
+gpu_materialize(c::DFColumn) = gpu_materialize_columns(c.view)[1]
 
 "unique(col::DFColumn) on the device (docs/src/index.md:171-182): distinct values in order of first appearance."
-gpu_unique(c::DFColumn) = gpu_materialize(c.view; first_occurrences_of = 0)[!, 1]
+gpu_unique(c::DFColumn) = gpu_materialize_columns(c.view; first_occurrences_of = 0)[1]
 
 """
-sum(col::DFColumn) / mean(col) on the device (the reference iterates the column: column.jl:102-126, docs/src/index.md:503-509).
-The hint lets the scan that evaluates the selection add the selected values up while it holds them (dfdb_query_hint_aggregate);
-the count comes out of the same execution.  Returns (sum, count).
+sum / minimum / maximum of a DFColumn on the device(s) (the reference iterates the column: column.jl:102-126, docs/src/index.md:503-509).
+The hint lets the scan that evaluates the selection reduce the selected values while it holds them (dfdb_query_hint_aggregate);
+the count comes out of the same execution.  op: 1 = sum, 2 = minimum, 3 = maximum (DFDB_AGG_*).  Returns (value, count).
+Integer results are exact (wrapping 64-bit sums like Julia's); a Float64 sum is within n*eps*sum|x| of the left-to-right sum.
 """
-function gpu_sum_count(c::DFColumn)
-    with_query(c.view) do q
-        check(ccall((:dfdb_query_hint_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32), q, 1, 0))          # DFDB_AGG_SUM of projection column 0
-        si = Ref{Int64}(0); sf = Ref{Float64}(0.0); n = Ref{Int64}(0)
-        check(ccall((:dfdb_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Float64}), q, 1, 0, si, sf))
-        check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
-        (eltype(c) <: AbstractFloat ? sf[] : si[], n[])
+function gpu_aggregate(c::DFColumn{T}, op::Integer) where {T}
+    T <: Union{Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64,Bool,Float64} || throw(Unsupported("aggregate over $(T)"))
+    vi = Ref{Int64}(0); vf = Ref{Float64}(0.0); n = Ref{Int64}(0)
+    if sharded()
+        with_gquery(c.view) do q
+            check(ccall((:dfdb_group_query_hint_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32), q, op, 0))
+            check(ccall((:dfdb_group_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Float64}), q, op, 0, vi, vf))
+            check(ccall((:dfdb_group_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        end
+    else
+        with_query(c.view) do q
+            check(ccall((:dfdb_query_hint_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32), q, op, 0))
+            check(ccall((:dfdb_aggregate, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Float64}), q, op, 0, vi, vf))
+            check(ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n))
+        end
+    end
+    if T === Float64
+        return (vf[], n[])
+    elseif op == 1                                   # Base.sum widens: signed and Bool -> Int64, unsigned -> UInt64 (Base.add_sum)
+        return (T <: Unsigned ? reinterpret(UInt64, vi[]) : vi[], n[])
+    else                                             # minimum / maximum keep the element type
+        return (T <: Unsigned ? (reinterpret(UInt64, vi[]) % T) : (T === Bool ? vi[] != 0 : vi[] % T), n[])
     end
 end
-gpu_sum(c::DFColumn) = gpu_sum_count(c)[1]
-gpu_mean(c::DFColumn) = ((s, n) = gpu_sum_count(c); s / n)
+gpu_sum(c::DFColumn) = gpu_aggregate(c, 1)[1]
+gpu_minimum(c::DFColumn) = gpu_aggregate(c, 2)[1]
+gpu_maximum(c::DFColumn) = gpu_aggregate(c, 3)[1]
+gpu_mean(c::DFColumn) = ((s, n) = gpu_aggregate(c, 1); s / n)
+gpu_sum_count(c::DFColumn) = gpu_aggregate(c, 1)
 
 # ---------------------------------------------------------------- write side (create_table / add_column!)
 struct SizeStatsC; rows::Int64; compressed::Int64; uncompressed::Int64; end
@@ -317,29 +444,70 @@ function gpu_write_column(file::AbstractString, col::DFColumn)
 end
 
 # ---------------------------------------------------------------- drop-in switch
-"Route materialize(::DFView) / nrow(::DFView) through the MI355X engine, falling back to the stock path
-when a predicate is outside the IR op set."
+# The overrides REPLACE the reference's methods (same signatures), so the stock implementation cannot be reached by `invoke`
+# afterwards.  It stays reachable in the WORLD AGE recorded before the first override was defined: `Base.invoke_in_world(WORLD0[], f,
+# args...)` dispatches among the methods that existed then — the reference's own `materialize(::DFView)`, whose inner `nrow(v)` call is
+# resolved in that same old world too.  No recursion is possible: the old world does not contain the overrides.
+const WORLD0 = Ref{UInt}(0)
+const ENABLED = Ref(false)
+
+"run `gpu()`; on `Unsupported` (an expression outside the IR, an untraceable closure) evaluate `stock` with the reference's own methods"
+function with_fallback(gpu, f, args...)
+    try
+        return gpu()
+    catch e
+        e isa Unsupported || rethrow()
+        return Base.invoke_in_world(WORLD0[], f, args...)
+    end
+end
+
+"""
+Route the hot-path consumers of DataFrameDBs through the MI355X engine, falling back to the stock path when an expression is outside the IR:
+`materialize(::DFView)`, `nrow(::DFView)` (and with it `size` / `length(::DFColumn)`), `materialize(::DFColumn)`, `copyto!(dest, ::DFColumn)`,
+`copyto!(dest, ::Broadcasted{DFColumnStyle})` (`dest .= col_expr`), and `sum` / `minimum` / `maximum` / `Statistics.mean` / `unique` of a DFColumn
+(which otherwise pull one element at a time through `Base.iterate(::DFColumn)`, column.jl:102-126).
+"""
 function enable!()
-    @eval DataFrameDBs begin
-        const _cpu_materialize = materialize
-        const _cpu_nrow = nrow
-    end
-    @eval function DataFrameDBs.materialize(v::DFView)
-        try
-            return DataFrameDBsAMD.gpu_materialize(v)
-        catch e
-            e isa DataFrameDBsAMD.Unsupported || rethrow()
-            return invoke(DataFrameDBs._cpu_materialize, Tuple{DFView}, v)
+    ENABLED[] && return nothing
+    WORLD0[] = Base.get_world_counter()               # only the reference's methods exist in this world
+    @eval begin
+        DataFrameDBs.materialize(v::DFView) = with_fallback(() -> gpu_materialize(v), DataFrameDBs.materialize, v)
+        DataFrameDBs.nrow(v::DFView) = with_fallback(() -> gpu_nrow(v), DataFrameDBs.nrow, v)
+        DataFrameDBs.materialize(c::DFColumn) = with_fallback(() -> gpu_materialize(c), DataFrameDBs.materialize, c)
+        function Base.copyto!(dest::AbstractVector, src::DFColumn)
+            with_fallback(Base.copyto!, dest, src) do
+                vals = gpu_materialize(src)
+                length(dest) >= length(vals) || throw(BoundsError(dest, length(vals)))
+                copyto!(dest, 1, vals, 1, length(vals))
+                dest
+            end
         end
-    end
-    @eval function DataFrameDBs.nrow(v::DFView)
-        try
-            return DataFrameDBsAMD.gpu_nrow(v)
-        catch e
-            e isa DataFrameDBsAMD.Unsupported || rethrow()
-            return invoke(DataFrameDBs._cpu_nrow, Tuple{DFView}, v)
+        function Base.copyto!(dest::AbstractArray, bc::Base.Broadcast.Broadcasted{DataFrameDBs.DFColumnStyle})
+            with_fallback(Base.copyto!, dest, bc) do
+                col = Base.Broadcast.materialize(bc)      # the lazy DFColumn of the whole expression (columnbroadcast.jl:35-62)
+                vals = gpu_materialize(col)
+                length(dest) >= length(vals) || throw(BoundsError(dest, length(vals)))
+                copyto!(dest, 1, vals, 1, length(vals))
+                dest
+            end
         end
+        Base.sum(c::DFColumn) = with_fallback(() -> gpu_sum(c), Base.sum, c)
+        Base.minimum(c::DFColumn) = with_fallback(() -> gpu_minimum(c), Base.minimum, c)
+        Base.maximum(c::DFColumn) = with_fallback(() -> gpu_maximum(c), Base.maximum, c)
+        Statistics.mean(c::DFColumn) = with_fallback(() -> gpu_mean(c), Statistics.mean, c)
+        Base.unique(c::DFColumn) = with_fallback(() -> gpu_unique(c), Base.unique, c)
     end
+    ENABLED[] = true
+    nothing
+end
+
+"forget the device-resident copies (e.g. after the table's files changed on disk)"
+function reset!()
+    d = DEV[]
+    d === nothing && return nothing
+    for h in values(d.gtables); ccall((:dfdb_group_table_close, LIB), Int32, (Ptr{Cvoid},), h); end
+    for h in values(d.tables); ccall((:dfdb_table_close, LIB), Int32, (Ptr{Cvoid},), h); end
+    empty!(d.gtables); empty!(d.tables)
     nothing
 end
 

@@ -97,6 +97,7 @@ typedef struct dfdb_outcol {
 
 /* ------------------------------------------------------------------ misc */
 int32_t dfdb_version(void);
+int32_t dfdb_device_count(int32_t* n);   /* visible HIP devices (0 without a GPU: no error); the Julia shim forms a group when n > 1 */
 int32_t dfdb_last_error(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------ context */

@@ -234,3 +234,27 @@ def test_flat_strings_to_arrow_matches_the_per_row_conversion():
     data = np.frombuffer(b"".join(words[i].encode() for k, i in enumerate(pick) if sizes[k] >= 0), np.uint8)
     assert api._flat_to_arrow(sizes, data).to_pylist() == api._flat_to_strings(sizes, data)
     assert api._flat_to_arrow(np.zeros(0, np.int32), np.zeros(0, np.uint8)).to_pylist() == []
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """Julia is not installed here, so the shim's FFI is checked statically: every ccall of julia/DataFrameDBsAMD.jl against the
+    prototype of the same symbol in include/dfdb.h (exists, arity, argument class and width, Int32 return) and the two mirrored
+    structs field by field; julia/STATIC_REVIEW.md is the committed rendering of the same walk and must be current."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("julia_static_review", os.path.join(ROOT, "tools", "julia_static_review.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows, errors = mod.check()
+    assert not errors, errors
+    assert len(rows) >= 50
+    syms = {r[1] for r in rows}
+    # the consumers VERDICT r1 asked for are bound: one-column routes, aggregates, unique, and the multi-GPU group
+    for s in ("dfdb_materialize", "dfdb_aggregate", "dfdb_query_unique", "dfdb_group_create", "dfdb_group_count", "dfdb_group_aggregate", "dfdb_group_materialize"):
+        assert s in syms, s
+    review = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "STATIC_REVIEW.md")).read()
+    assert f"**{len(rows)} ccall sites, 0 mismatches**" in review, "run tools/julia_static_review.py"
+    jl = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "DataFrameDBsAMD.jl")).read()
+    assert "Base.invoke_in_world(WORLD0[]" in jl and "invoke(DataFrameDBs._cpu" not in jl          # the fallback cannot re-enter an override
+    for route in ("DataFrameDBs.materialize(c::DFColumn)", "Base.copyto!(dest::AbstractVector, src::DFColumn)", "Base.sum(c::DFColumn)",
+                  "Statistics.mean(c::DFColumn)", "Base.unique(c::DFColumn)", "Broadcasted{DataFrameDBs.DFColumnStyle}"):
+        assert route in jl, route
