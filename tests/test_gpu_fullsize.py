@@ -79,21 +79,55 @@ def test_config2_full_size_properties(oracle, dfdb_mod, ctx, n):
     t.close()
 
 
-def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
-    """3-column conjunction + projection and string equality + materialize at 2e8 / 1e8 rows."""
+def _need_hbm(gb):
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < gb * 1e9:
+        pytest.skip(f"needs ~{gb} GB of free HBM")
+
+
+def _seed(k):
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def test_config1_file_table_materialize(oracle, dfdb_mod, ctx, tmp_path):
+    """BASELINE config 1 at its stated size: a single Int64 column of 1e6 rows in a reference-format file table (16 blocks of 65 536
+    rows, the last one 16 960 rows), written by the oracle's liblz4 writer, opened and fully materialised by the engine == the generator;
+    and the same table written by the DEVICE encoder, read back by the oracle (liblz4) == the generator."""
+    n = 1_000_000
+    x = oracle.gen_i64(SEED, 0, n)
+    ot = oracle.Table(block_size=65536)
+    ot.add_column("x", x)
+    ot.save(str(tmp_path / "c1"))
+    t = dfdb_mod.open_table(str(tmp_path / "c1"))
+    st = dfdb_mod.table_stats(t)
+    assert int(st["rows"].iloc[0]) == n and -(-n // 65536) == 16 and n - 15 * 65536 == 16_960
+    got = dfdb_mod.materialize(t)
+    assert list(got.columns) == ["x"] and got["x"].dtype == np.int64 and np.array_equal(got["x"].to_numpy(), x)
+    assert dfdb_mod.nrow(t) == n
+    assert np.array_equal(dfdb_mod.materialize(t[dfdb_mod.jr(n - 16_959, n), dfdb_mod.ALL])["x"].to_numpy(), x[-16_960:])      # the short last block
+    t.save(str(tmp_path / "c1_dev"))
+    back = oracle.Table.open(str(tmp_path / "c1_dev")).view().materialize()[0]
+    assert np.array_equal(back, x)
+    t.close()
+
+
+@pytest.mark.parametrize("n", [200_000_000, 1_000_000_000])
+def test_config3_conjunction_projection(oracle, dfdb_mod, ctx, n):
+    """BASELINE config 3 (at 2e8 and at its stated 1e9 rows): 3-column Int64 + Float64 table, conjunctive predicate + projection.
+    Properties at full size (torch as the third opinion: the count, every projected value, the index checksum) + sampled 65 536-row
+    blocks against the oracle's generators bit for bit."""
     import torch
     from dfdb import _native as N
+    _need_hbm(n * 24 / 1e9 + n * 18 / 1e9 + 6)
     dev = torch.device("cuda", 0)
-
-    def seed(k):
-        return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
-    n = 200_000_000
     t = dfdb_mod.DFTable.new()
-    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(0), n)
-    t.add_generated("b", dfdb_mod.GEN_I64_MOD1M, seed(1), n)
-    t.add_generated("x", dfdb_mod.GEN_F64_U2000, seed(2), n)
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, _seed(0), n)
+    t.add_generated("b", dfdb_mod.GEN_I64_MOD1M, _seed(1), n)
+    t.add_generated("x", dfdb_mod.GEN_F64_U2000, _seed(2), n)
     v = t[(t.a > 683_771) & (t.x < 632.456), ["b", "x"]]
     q = v._query()
+    q.hint_materialize(True)
     nsel = q.count()
     assert abs(nsel / n - 0.1) < 2e-3
     ob = torch.empty(nsel, dtype=torch.int64, device=dev)
@@ -102,21 +136,44 @@ def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
     N.check(N.load().dfdb_materialize(q._h, outs, 2))
     torch.cuda.synchronize()
     assert bool((ox < 632.456).all())
-    idx = q.indices()
-    for r0 in (0, 65536 * 1000, n - 65536):                             # sampled blocks vs the oracle's generators
-        a = oracle.gen_i64(seed(0), r0, 65536); b = oracle.gen_i64(seed(1), r0, 65536); x = oracle.gen_f64(seed(2), r0, 65536)
+    # third opinion: the whole columns through the ABI into torch, torch's own mask
+    full = {}
+    for name, dt in (("a", torch.int64), ("b", torch.int64), ("x", torch.float64)):
+        full[name] = torch.empty(n, dtype=dt, device=dev)
+        qa = dfdb_mod.DFView(t)[dfdb_mod.ALL, [name]]._query()
+        N.check(N.load().dfdb_materialize(qa._h, (N.OutCol * 1)(_dev_outcol(N, full[name])), 1))
+    torch.cuda.synchronize()
+    mask = (full["a"] > 683_771) & (full["x"] < 632.456)
+    assert int(mask.sum()) == nsel
+    assert torch.equal(ob, full["b"][mask]) and torch.equal(ox.view(torch.int64), full["x"][mask].view(torch.int64))
+    didx = torch.empty(nsel, dtype=torch.int64, device=dev)
+    q.indices_device(didx.data_ptr(), nsel)
+    torch.cuda.synchronize()
+    assert torch.equal(didx, torch.nonzero(mask).flatten() + 1)
+    del mask, full
+    idx = didx.cpu().numpy()
+    for r0 in (0, 65536 * 1000, (n // 65536 - 1) * 65536, n - 65536):      # sampled blocks vs the oracle's generators
+        a = oracle.gen_i64(_seed(0), r0, 65536); b = oracle.gen_i64(_seed(1), r0, 65536); x = oracle.gen_f64(_seed(2), r0, 65536)
         m = (a > 683_771) & (x < 632.456)
         lo, hi = np.searchsorted(idx, r0 + 1), np.searchsorted(idx, r0 + 65536 + 1)
         assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
         assert np.array_equal(ob[lo:hi].cpu().numpy(), b[m]) and np.array_equal(ox[lo:hi].cpu().numpy().view(np.uint64), x[m].view(np.uint64))
     t.close()
 
-    n = 100_000_000
+
+@pytest.mark.parametrize("n", [100_000_000, 500_000_000])
+def test_config4_string_equality_materialize(oracle, dfdb_mod, ctx, n):
+    """BASELINE config 4 (at 1e8 and at its stated 5e8 rows): FlatStringsVector + Int64, string-equality filter + materialize."""
+    import torch
+    from dfdb import _native as N
+    _need_hbm(n * 30 / 1e9 + 6)
+    dev = torch.device("cuda", 0)
     t = dfdb_mod.DFTable.new()
-    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, seed(0), n)
-    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, seed(1), n)
+    t.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, _seed(0), n)
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, _seed(1), n)
     v = t[t.s == "sony", dfdb_mod.ALL]
     q = v._query()
+    q.hint_materialize(True)
     nsel = q.count()
     assert abs(nsel / n - 0.1) < 2e-3
     nb = C.c_int64()
@@ -129,17 +186,85 @@ def test_config3_and_4_large_properties(oracle, dfdb_mod, ctx):
     N.check(N.load().dfdb_materialize(q._h, outs, 2))
     torch.cuda.synchronize()
     assert bool((osz == 4).all())
-    assert bytes(oby[:nb.value].view(nsel, 4)[:: max(1, nsel // 1000)].cpu().numpy().tobytes()) == b"sony" * len(range(0, nsel, max(1, nsel // 1000)))
     assert bool((oby[:nb.value].view(nsel, 4) == torch.tensor(list(b"sony"), dtype=torch.uint8, device=dev)).all())
-    idx = q.indices()
+    # third opinion for the Int64 projection: the whole column through the ABI, gathered by torch at the engine's row numbers
+    didx = torch.empty(nsel, dtype=torch.int64, device=dev)
+    q.indices_device(didx.data_ptr(), nsel)
+    full = torch.empty(n, dtype=torch.int64, device=dev)
+    qa = dfdb_mod.DFView(t)[dfdb_mod.ALL, ["a"]]._query()
+    N.check(N.load().dfdb_materialize(qa._h, (N.OutCol * 1)(_dev_outcol(N, full)), 1))
+    torch.cuda.synchronize()
+    assert bool((didx[1:] > didx[:-1]).all()) and torch.equal(oa, full[didx - 1])
+    # ... and for the selection itself: the sizes column says which rows CAN be "sony" (4 bytes: sony, dell, xbox, asus): the plain
+    # != selection over the same column must select the complement
+    q2 = t[t.s != "sony", ["a"]]._query()
+    assert q2.count() == n - nsel
+    del full
+    idx = didx.cpu().numpy()
     for r0 in (0, 65536 * 700, n - 65536):
-        sz, by = oracle.gen_str(seed(0), r0, 65536)
+        sz, by = oracle.gen_str(_seed(0), r0, 65536)
         strs = oracle.flat_to_strings(sz, by)
         m = np.array([s == "sony" for s in strs])
         lo, hi = np.searchsorted(idx, r0 + 1), np.searchsorted(idx, r0 + 65536 + 1)
         assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
-        assert np.array_equal(oa[lo:hi].cpu().numpy(), oracle.gen_i64(seed(1), r0, 65536)[m])
+        assert np.array_equal(oa[lo:hi].cpu().numpy(), oracle.gen_i64(_seed(1), r0, 65536)[m])
     t.close()
+
+
+def test_config5_one_shard_count_and_sum(oracle, dfdb_mod, ctx):
+    """BASELINE config 5's per-GPU share at its stated size: 1e10 rows over 8 GPUs = 1.25e9 rows x (Int64, Float64, String) on one device
+    (32 GB), conjunctive predicate over all three columns, count() + sum(x) — through a ONE-rank group (dfdb_group_*: the code path the
+    8-GPU run takes, with its RCCL all-reduce issued for real) and through the plain query; torch is the third opinion for the numeric
+    conjuncts and for the sum, sampled blocks go against the oracle's generators."""
+    import torch
+    from dfdb import _native as N, group as G
+    n = 1_250_000_000
+    _need_hbm(n * 26 / 1e9 + n * 17 / 1e9 + 10)
+    dev = torch.device("cuda", 0)
+    g = G.Group.create([0], N.EXCHANGE_RCCL)
+    try:
+        gt = G.GroupTable.new(g)
+        gt.add_generated("a", dfdb_mod.GEN_I64_MOD1M, _seed(0), n)
+        gt.add_generated("x", dfdb_mod.GEN_F64_U2000, _seed(1), n)
+        gt.add_generated("s", dfdb_mod.GEN_STR_BRANDS10, _seed(2), n)
+        t = gt.shard(0)
+        base = gt.view()
+        v = base[(base.a > 500_000) & (base.x < 800.0) & (base.s != "sony"), dfdb_mod.ALL]
+        cnt = G.gnrow(v)
+        sx = G.gaggregate(v[dfdb_mod.ALL, "x"], N.AGG_SUM)
+        # the plain single-GPU query over the same shard agrees exactly on the count and within tolerance on the sum
+        pv = t[(t.a > 500_000) & (t.x < 800.0) & (t.s != "sony"), dfdb_mod.ALL]
+        assert dfdb_mod.nrow(pv) == cnt
+        assert abs(cnt / n - 0.5 * 0.4 * 0.9) < 1e-3
+        # third opinion: numeric conjuncts by torch, the string conjunct through the engine's own != selection as a bitmap
+        full = {}
+        for name, dt in (("a", torch.int64), ("x", torch.float64)):
+            full[name] = torch.empty(n, dtype=dt, device=dev)
+            qa = dfdb_mod.DFView(t)[dfdb_mod.ALL, [name]]._query()
+            N.check(N.load().dfdb_materialize(qa._h, (N.OutCol * 1)(_dev_outcol(N, full[name])), 1))
+        torch.cuda.synchronize()
+        num = (full["a"] > 500_000) & (full["x"] < 800.0)
+        nnum = int(num.sum())
+        assert dfdb_mod.nrow(t[(t.a > 500_000) & (t.x < 800.0), dfdb_mod.ALL]) == nnum
+        assert dfdb_mod.nrow(t[(t.a > 500_000) & (t.x < 800.0) & (t.s == "sony"), dfdb_mod.ALL]) == nnum - cnt      # the complement inside A & B
+        bm = torch.from_numpy(pv._query().bitmap().view(np.int64)).to(dev)                                    # the final mask, 1 bit per row
+        bits = ((bm.view(-1, 1) >> torch.arange(64, device=dev, dtype=torch.int64)) & 1).to(torch.bool).view(-1)[:n]
+        assert int(bits.sum()) == cnt and bool((bits <= num).all())                                              # selected rows are a subset of A & B
+        want_sum = float(full["x"][bits].sum().item())
+        tol = cnt * np.finfo(np.float64).eps * float(full["x"][bits].abs().sum().item())
+        assert abs(sx - want_sum) <= tol
+        del full, num, bits, bm
+        idx = pv._query().indices()
+        for r0 in (0, 65536 * 9000, (n // 65536) * 65536 - 65536):
+            a = oracle.gen_i64(_seed(0), r0, 65536); x = oracle.gen_f64(_seed(1), r0, 65536)
+            sz, by = oracle.gen_str(_seed(2), r0, 65536)
+            strs = oracle.flat_to_strings(sz, by)
+            m = (a > 500_000) & (x < 800.0) & np.array([s != "sony" for s in strs])
+            lo, hi = np.searchsorted(idx, r0 + 1), np.searchsorted(idx, r0 + 65536 + 1)
+            assert np.array_equal(idx[lo:hi], np.nonzero(m)[0] + r0 + 1)
+        gt.close()
+    finally:
+        g.close()
 
 
 def test_hinted_paths_equal_the_plain_ones_at_scale(oracle, dfdb_mod, ctx):
@@ -150,8 +275,7 @@ def test_hinted_paths_equal_the_plain_ones_at_scale(oracle, dfdb_mod, ctx):
     from dfdb import _native as N, ir
     dev = torch.device("cuda", 0)
 
-    def seed(k):
-        return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+    seed = _seed
     lib = N.load()
     # ---- numeric capture + fused sums
     n = 200_000_000
