@@ -39,8 +39,8 @@ __device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t* p) {
 // Longer runs take the same steps 64 bytes at a time; a match that reaches further back than the ring is copied from
 // HBM behind a fence (rare on columnar data; costs what every v1 sequence cost).
 #ifdef DFDB_LZ4_PROF   // tools/bench_lz4.hip only: cycles per phase of block 0 (s_memtime also drains the LDS queue: phase boundaries only)
-__device__ unsigned long long g_lz4_prof[16];
-#define LZ4_PROF(k) { const uint64_t pf_t = __builtin_readcyclecounter(); pf_acc[k] += pf_t - pf_t0; pf_t0 = pf_t; }
+__device__ unsigned long long g_lz4_prof[32];
+#define LZ4_PROF(k) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const uint64_t pf_t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); pf_acc[k] += pf_t - pf_t0; pf_t0 = pf_t; }
 #define LZ4_COUNT(k, n) { pf_acc[k] += (n); }
 #else
 #define LZ4_PROF(k)
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
   __shared__ uint32_t fard_sh[WAVES][kFarMax];
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
   __shared__ uint32_t bits_sh[WAVES][kBatchBytes / 32 + 2];   // + two words that stay zero
+  __shared__ uint2 bitsx_sh[WAVES][kBatchBytes / 32 + 8];     // {start-bit word, starts before it - 1}; the tail stays {0, -1}
   __shared__ uint2 info_sh[WAVES][kSeqMax];
   const uint32_t lane = (uint32_t)lane_id();
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -65,11 +66,15 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
   uint8_t* stage = lds;
   uint8_t* ring = lds + kStage;
   uint32_t* bits = bits_sh[wib];
+  uint2* bitsx = bitsx_sh[wib];
+  if (lane < 8) bitsx[kBatchBytes / 32 + lane] = make_uint2(0u, 0xffffffffu);
+  const uint32_t lane_below = (2u << (lane & 31u)) - 1u;         // bits 0 .. lane mod 32
   uint2* info = info_sh[wib];
   uint32_t* fard = fard_sh[wib];
   if (lane < 2) bits[kBatchBytes / 32 + lane] = 0;
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
   constexpr uint32_t kFlush = kRing >= 4096 ? 1024u : 512u;
+  static_assert(kStage == kRing, "production addresses staging buffer, ring and far bytes as ((j + B) & (kStage - 1)) | O");
   static_assert((kFlush + 256 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
     int err = 0;
     uint32_t extstops = 0;             // v5: tokens with a length of 15 met by the one-sequence path
 #ifdef DFDB_LZ4_PROF
-    uint64_t pf_acc[16] = {}; uint64_t pf_t0 = __builtin_readcyclecounter(); const uint64_t pf_start = pf_t0;
+    uint64_t pf_acc[32] = {}; uint64_t pf_t0 = __builtin_readcyclecounter(); const uint64_t pf_start = pf_t0;
 #endif
     uint64_t f[kNF];                   // the chunk in flight: input bytes [cb + kStage, cb + kStage + kChunk)
 
@@ -159,108 +164,161 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
       {
-        // ---- v5: a SUPERBATCH of W 64-byte windows.  The candidate decode of v4 (lane l = the token at window start + l,
-        // taken AS IF a sequence began there) runs for all W windows up front, so its two dependent LDS round trips are
-        // paid once; the chain of real starts is walked window after window with v_readlane only (four predicated hops per
-        // loop trip, no per-sequence branch); the sequences' output positions come from one DPP scan per window.  Every
-        // accepted sequence leaves one 8-byte record (output start, literal count, offset, literal input position) and
-        // one START BIT per output byte position.  The bytes are then produced 64 at a time IN OUTPUT ORDER: a lane finds
-        // its sequence as the rank of its position among the start bits, turns it into either an LDS address (a literal in
-        // the staging buffer, or a ring byte that precedes this 64-byte chunk) or a pointer to a lower lane of the same
-        // chunk, pointers are collapsed with ds_bpermute doubling, and each byte is fetched once.  No per-sequence loop.
+        // ---- a SUPERBATCH of W 64-byte windows of input, in five phases that each expose their parallelism to the hardware:
+        //  1. candidates: lane l decodes the token at window start + l AS IF a sequence began there (literal count, match length, offset,
+        //     where the next sequence would start).  All W windows together: the two dependent LDS round trips are paid once.
+        //  2. walk: the chain of REAL starts, window after window, v_readlane only.  A start whose successor leaves the window points at
+        //     itself, so a hop is `p = readlane(next, p)` + one s_bitset1 into the window's start mask and the walk simply parks.
+        //  3. dense records: every start writes its candidate to LDS at its ordinal among the starts (mbcnt of the mask); the <= 171 sequences
+        //     are then finished 64 per row — output position by one DPP scan per ROW (not per window), far-source slots, validity, the
+        //     budget cut at SEQUENCE granularity — leaving an 8-byte record each and one START BIT at its first output byte.
+        //  4. sources that have left the ring are fetched from HBM, 24 bytes each, one memory round trip for the whole superbatch.
+        //  5. production, IN OUTPUT ORDER, four 64-byte rows per trip: a lane finds its sequence as the rank of its position among the start
+        //     bits (the bitmap sits in a register: two v_readlane per row), gathers the record, and turns it into an LDS address (literal in
+        //     the staging buffer / ring byte before the row / prefetched far byte) or a pointer to a lower lane of its row; pointers are
+        //     collapsed by ds_bpermute doubling; the rows' gathers are in flight together, only the final byte fetches are ordered.
         LZ4_PROF(4);
         advance(ip);
-        uint32_t T = 0, nseq = 0;        // output bytes / sequences accepted so far
-        uint32_t nfar = 0;               // of them, matches that reach back further than the ring
+        uint32_t T = 0;                  // output bytes accepted
+        uint32_t nseq = 0;               // sequences found by the walk
         uint32_t consumed = 0;           // input bytes they cover = where the next sequence starts, relative to ip
         bool nonsimple = false;          // the walk ended on a sequence the batch does not take
         bool bad = false;
-        // Two forms of the window phase.  The plain one takes sequences whose lengths fit the token (<= 14 literals, <= 18 match
+        uint32_t nfar = 0;
+        // Two forms of the candidate phase.  The plain one takes sequences whose lengths fit the token (<= 14 literals, <= 18 match
         // bytes).  The EXT one also takes a length of 15 that continues in ONE more byte (a 255 there — lengths >= 270 / 274 — still
         // leaves the sequence to the one-sequence path): two more LDS reads per candidate, sequences that jump over whole windows.
         // A block switches to it for good once the one-sequence path has met two such tokens.
         auto windows = [&](auto extc) {
           constexpr bool EXT = decltype(extc)::value;
           uint32_t A[W], NX[W], OFS[W];
+          // ---- phase 1
+          uint32_t tok[W], e1[W];
 #pragma unroll
           for (int w = 0; w < W; w++) {
             const uint32_t pos = ip + 64u * (uint32_t)w + lane;
-            const uint32_t token = stage[pos & (kStage - 1)];
+            tok[w] = stage[pos & (kStage - 1)];
+            if (EXT) e1[w] = stage[(pos + 1) & (kStage - 1)];
+          }
+          uint32_t o0[W], o1[W], m1[W];
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t pos = ip + 64u * (uint32_t)w + lane;
+            const bool le = EXT && (tok[w] >> 4) == 15u;
+            const uint32_t lit = le ? 15u + e1[w] : tok[w] >> 4;
+            const uint32_t opos = pos + 1u + (le ? 1u : 0u) + lit;                  // the 2-byte offset field
+            o0[w] = stage[opos & (kStage - 1)]; o1[w] = stage[(opos + 1) & (kStage - 1)];
+            if (EXT) m1[w] = stage[(opos + 2) & (kStage - 1)];
+          }
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t pos = ip + 64u * (uint32_t)w + lane;
+            const uint32_t token = tok[w];
+            const uint32_t offset = o0[w] | o1[w] << 8;
             if (!EXT) {
               const uint32_t lit = token >> 4, mlc = token & 15u;
-              const uint32_t opos = pos + 1u + lit;                              // the 2-byte offset field
-              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+              const uint32_t opos = pos + 1u + lit;
               const bool simple = lit != 15u && mlc != 15u && opos + 2u < in_len && offset != 0;
-              NX[w] = simple ? lane + 3u + lit : 1023u;  // where the following sequence starts, window-relative; 1023: a sequence the batch does not take
+              NX[w] = simple ? lane + 3u + lit : 1023u;   // where the following sequence starts, window-relative; 1023: a sequence the batch does not take
               A[w] = lit | (mlc + 4u) << 9;
-              OFS[w] = offset;
             } else {
-              const uint32_t e1 = stage[(pos + 1) & (kStage - 1)];
               const bool le = (token >> 4) == 15u, me = (token & 15u) == 15u;
-              const uint32_t lit = le ? 15u + e1 : token >> 4;
+              const uint32_t lit = le ? 15u + e1[w] : token >> 4;
               const uint32_t opos = pos + 1u + (le ? 1u : 0u) + lit;
-              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
-              const uint32_t m1 = stage[(opos + 2) & (kStage - 1)];
-              const uint32_t ml = 4u + (me ? 15u + m1 : (token & 15u));
+              const uint32_t ml = 4u + (me ? 15u + m1[w] : (token & 15u));
               const uint32_t end = opos + 2u + (me ? 1u : 0u);
-              const bool simple = !(le && e1 == 255u) && !(me && m1 == 255u) && end < in_len && offset != 0 &&
+              const bool simple = !(le && e1[w] == 255u) && !(me && m1[w] == 255u) && end < in_len && offset != 0 &&
                                   !(offset + 64u > (uint32_t)kRing && ml > 24u);   // (a far source is prefetched 24 bytes deep)
-              NX[w] = simple ? end - (ip + 64u * (uint32_t)w) : 1023u;           // <= 63 + 274
+              NX[w] = simple ? end - (ip + 64u * (uint32_t)w) : 1023u;             // <= 63 + 274
               A[w] = lit | ml << 9 | (le ? 1u << 18 : 0u);
-              OFS[w] = offset;
             }
+            OFS[w] = offset;
           }
           bits[lane & (kBatchBytes / 32 - 1)] = 0;
           LZ4_PROF(0);
+          // ---- phases 2 + 3a: walk a window, drop its starts' candidates at their ordinals
           uint32_t p = 0;                  // next sequence start, relative to the window being walked
 #pragma unroll
           for (int w = 0; w < W; w++) {
             if (EXT && p >= 64u) { p -= 64u; consumed = 64u * (uint32_t)(w + 1) + p; continue; }   // a long sequence jumped over this window
-            const uint32_t entry = p;
-            // the walk: p hops from start to start and parks on the last start of the window (whose successor is >= 64); four
-            // instructions per hop, no branch: v_readlane, s_bitset1, s_cmp, s_cselect.  A parked p only sets its own bit again.
+            // a start whose successor lies outside the window (or that the batch does not take) points at itself
+            const uint32_t nxp = NX[w] < 64u ? NX[w] : lane;
             uint64_t mask = 0;
-            for (int h = 0; h < 6; h++) {
-              const uint32_t p0 = p;
+            for (int h = 0; h < 3; h++) {                                        // <= 22 starts per window: 24 hops always reach the parking start
+              uint32_t last = p;
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const uint32_t a = rl(NX[w], p);
+              for (int u = 0; u < 8; u++) {
+                last = p;
                 asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(p));
-                p = a < 64u ? a : p;
+                p = rl(nxp, p);
               }
-              if (p == p0) break;
+              if (p == last) break;
             }
+            LZ4_PROF(13);
             const uint32_t exitp = rl(NX[w], p);
             nonsimple = exitp == 1023u;
-            mask &= __ballot(NX[w] != 1023u);                                  // (a sequence the batch does not take got a bit too)
-            const bool mine = (mask >> lane) & 1ull;
-            const uint32_t lit = A[w] & 511u, ml = (A[w] >> 9) & 511u;
-            const uint32_t tot = mine ? lit + ml : 0u;
-            const uint32_t incl = wave_incl_scan(tot);
-            const uint32_t Tw = rl(incl, 63);
-            const bool far = mine && OFS[w] + 64u > (uint32_t)kRing;
-            const uint64_t farmask = __ballot(far);
-            const uint32_t nfw = (uint32_t)__builtin_popcountll(farmask);
-            if (T + Tw > (uint32_t)kBatchBytes || nfar + nfw > (uint32_t)kFarMax) {   // the window does not fit any more: next superbatch
-              consumed = 64u * (uint32_t)w + entry; nonsimple = T == 0;          // (nothing accepted yet: its first sequence goes the one-sequence way)
-              break;
+            mask &= __ballot(NX[w] != 1023u);                                    // (a parked start the batch does not take got a bit too)
+            // (nseq + popcount(mask) <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
+            if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+              info[ord] = make_uint2(A[w], OFS[w] | (64u * (uint32_t)w + lane + 1u + (A[w] >> 18)) << 16);
             }
-            const uint32_t ostart = T + incl - tot;
-            const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (mine) {
-              bad = bad || OFS[w] > op + ostart + lit;
-              const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
-              if (far) fard[fo] = op + ostart + lit - OFS[w];                 // where its source starts in the block's output
-              info[ord] = make_uint2(ostart | lit << 16 | (far ? 0x80000000u : 0u), (far ? fo * 24u : OFS[w]) | (64u * (uint32_t)w + lane + 1u + (A[w] >> 18)) << 16);
-              atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
-            }
-            T += Tw; nseq += (uint32_t)__builtin_popcountll(mask); nfar += nfw;
+            nseq += (uint32_t)__builtin_popcountll(mask);
+            LZ4_PROF(14);
             if (nonsimple) { consumed = 64u * (uint32_t)w + p; break; }
             p = exitp - 64u; consumed = 64u * (uint32_t)(w + 1) + p;
           }
         };
         if (extstops >= 2u) windows(std::true_type{}); else windows(std::false_type{});
-        LZ4_PROF(1);
+        LZ4_PROF(11);
+        if (nseq) {
+          wave_lds_fence();
+          // ---- phase 3b: the sequences, dense, 64 per row
+          uint32_t nacc = 0;
+          for (uint32_t r0 = 0; r0 < nseq; r0 += 64u) {
+            const uint32_t k = r0 + lane;
+            const bool valid = k < nseq;
+            const uint2 c = valid ? info[k] : make_uint2(0u, 0u);
+            const uint32_t lit = c.x & 511u, ml = (c.x >> 9) & 511u, offset = c.y & 0xffffu, inpos = c.y >> 16;
+            const uint32_t tot = lit + ml;                                       // (0 for a lane past the last sequence)
+            const uint32_t incl = T + wave_incl_scan(tot);
+            const uint32_t ostart = incl - tot;
+            const bool far = valid && offset + 64u > (uint32_t)kRing;
+            const uint64_t farmask = __ballot(far);
+            const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
+            // the budget cut: output bytes and far slots both grow with the ordinal, so the accepted sequences are a prefix
+            const bool acc = valid && incl <= (uint32_t)kBatchBytes && fo + (far ? 1u : 0u) <= (uint32_t)kFarMax;
+            const uint32_t na = (uint32_t)__builtin_popcountll(__ballot(acc));
+            if (acc) {
+              bad = bad || offset > op + ostart + lit;
+              if (far) fard[fo] = op + ostart + lit - offset;                   // where its source starts in the block's output
+              // the record production reads, as 16-bit fields.  A byte j of the sequence comes from LDS address ((j + B) & (kStage - 1)) | O
+              // with (B, O) = the literal pair below its literal end and the match pair from there on:
+              //   literal  B = ip + inpos - ostart          O = 0                 (staging buffer)
+              //   match    B = op - offset                  O = kStage            (ring; valid when the source precedes the row)
+              //   far      B = 24 fo - (ostart + lit)       O = kStage + kRing    (prefetched source bytes)
+              // off7 = the match distance when it can fall inside a 64-byte row (else 127): lane - off7 is then the lane that makes the byte
+              const uint32_t litend = ostart + lit;
+              const uint32_t lbo = (ip + inpos - ostart) & (uint32_t)(kStage - 1);
+              const uint32_t mbo = far ? (((fo * 24u - litend) & (uint32_t)(kStage - 1)) | (uint32_t)(kStage + kRing))
+                                       : (((op - offset) & (uint32_t)(kStage - 1)) | (uint32_t)kStage);
+              const uint32_t off7 = far || offset > 127u ? 127u : offset;
+              info[k] = make_uint2(litend | lbo << 16, mbo | off7 << 16);
+              atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
+            }
+            if (na) T = rl(incl, na - 1u);
+            nacc += na;
+            nfar += (uint32_t)__builtin_popcountll(farmask & (na >= 64u ? ~0ull : ((1ull << na) - 1ull)));
+            const uint32_t nvalid = nseq - r0 < 64u ? nseq - r0 : 64u;
+            if (na < nvalid) {                                                   // cut here: the next superbatch starts with sequence r0 + na
+              consumed = rl(inpos - 1u - ((c.x >> 18) & 1u), na);
+              nonsimple = false;
+              break;
+            }
+          }
+          (void)nacc;
+        }
+        LZ4_PROF(12);
         if (T) {
           if (__ballot(bad) != 0 || T > out_len - op) { err = 5; break; }
           wave_lds_fence();
@@ -283,31 +341,41 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             wave_lds_fence();
             LZ4_PROF(5);
           }
-          uint32_t cnt = 0;                                                // sequences that start before the chunk
-          constexpr int U = 2;                                             // chunks per trip: their LDS round trips overlap, only the final byte fetches are ordered
+          // ---- phase 5
+          // rank of an output position among the start bits = its sequence's ordinal.  Kept in the vector domain (a v_readlane of the bitmap
+          // followed by scalar popcounts cost a VALU -> SGPR round trip of ~50 cycles per row): word and exclusive prefix sit side by side in LDS
+          {
+            const uint32_t w = bits[lane & (kBatchBytes / 32 - 1)];
+            const uint32_t cw = (uint32_t)__builtin_popcount(w);
+            const uint32_t incl = wave_incl_scan(lane < 32u ? cw : 0u);
+            if (lane < 32u) bitsx[lane] = make_uint2(w, incl - cw - 1u);
+          }
+          wave_lds_fence();
+          constexpr int U = 4;                                             // rows per trip
           for (uint32_t c = 0; c < T; c += 64u * U) {
+            uint32_t ORD[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const uint2 e = bitsx[(c >> 5) + 2u * (uint32_t)u + (lane >> 5)];          // (a row past T reads the {0, -1} tail)
+              ORD[u] = e.y + (uint32_t)__builtin_popcount(e.x & lane_below);
+            }
+            uint2 INF[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) INF[u] = info[ORD[u] < (uint32_t)kSeqMax ? ORD[u] : 0u];   // (rows past T: any record, the byte is never written)
+            LZ4_PROF(16);
             uint32_t R[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-              const uint32_t cc = c + 64u * (uint32_t)u, j = cc + lane;
-              const uint32_t bw = bits[(cc >> 5) + (lane & 1u)];           // (a chunk past T reads the two spare zero words)
-              const uint32_t w0 = rl(bw, 0), w1 = rl(bw, 1);
-              const uint32_t own = ((lane < 32u ? w0 >> lane : w1 >> (lane - 32u)) & 1u);
-              const uint32_t ordinal = cnt + __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0u)) + own - 1u;
-              cnt += (uint32_t)__builtin_popcount(w0) + (uint32_t)__builtin_popcount(w1);
-              const uint2 inf = info[ordinal];
-              const uint32_t ostart = inf.x & 0xffffu, lit = (inf.x >> 16) & 511u, offset = inf.y & 0xffffu, inpos = inf.y >> 16;
-              const bool far = (inf.x >> 31) != 0u;                        // then `offset` is where the prefetched source bytes are
-              const uint32_t bi = j - ostart;
-              const int32_t sp = (int32_t)j - (int32_t)offset;             // a match byte copies output byte op + sp
-              const bool is_lit = bi < lit;
-              const bool root = is_lit || far || sp < (int32_t)cc || j >= T;
-              const uint32_t k = bi - lit;
-              uint32_t addr = (uint32_t)kStage + ((op + (uint32_t)sp) & (uint32_t)(kRing - 1));
-              addr = far ? (uint32_t)(kStage + kRing) + offset + (k < 24u ? k : 0u) : addr;
-              addr = is_lit ? ((ip + inpos + bi) & (uint32_t)(kStage - 1)) : addr;
-              R[u] = root ? (0x80000000u | addr) : (uint32_t)(sp - (int32_t)cc);   // else: the lane of this chunk that makes the source byte
+              const uint32_t j = c + 64u * (uint32_t)u + lane;
+              const uint2 inf = INF[u];
+              const uint32_t litend = inf.x & 0xffffu, lbo = inf.x >> 16, mbo = inf.y & 0xffffu, off7 = inf.y >> 16;
+              const bool is_lit = j < litend;
+              const uint32_t x = is_lit ? lbo : mbo;
+              const uint32_t addr = ((j + x) & (uint32_t)(kStage - 1)) | (x & ~(uint32_t)(kStage - 1));
+              const bool inrow = !is_lit && off7 <= lane;                  // the source byte is made by a lower lane of this very row
+              R[u] = inrow ? lane - off7 : (0x80000000u | addr);           // (pointers only ever go down: lane 0 is always a root, rows past T included)
             }
+            LZ4_PROF(17);
             for (;;) {                                                     // pointer doubling: R[j] = R[R[j]] (always a lower lane)
               uint32_t unres = 0;                                          // bit 31 set: some row of this lane still holds a pointer
 #pragma unroll
@@ -320,13 +388,15 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
               }
               LZ4_COUNT(8, 1);
             }
+            LZ4_PROF(18);
 #pragma unroll
-            for (int u = 0; u < U; u++) {
+            for (int u = 0; u < U; u++) {                                  // in row order: a later row may copy bytes an earlier row of this trip wrote
               const uint32_t j = c + 64u * (uint32_t)u + lane;
               const uint8_t v = lds[R[u] & 0xffffu];
               if (j < T) ring[(op + j) & (kRing - 1)] = v;
             }
           }
+          LZ4_PROF(19);
           op += T; ip += consumed;
           LZ4_PROF(2);
           if (op - flushed >= kFlush) flush_to(op & ~255u);
@@ -433,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
     if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
     if (!err) flush_to(op);
 #ifdef DFDB_LZ4_PROF
-    if (b == 0 && lane == 0) { pf_acc[15] = __builtin_readcyclecounter() - pf_start; for (int k = 0; k < 16; k++) g_lz4_prof[k] = pf_acc[k]; }
+    if (b == 0 && lane == 0) { pf_acc[15] = __builtin_readcyclecounter() - pf_start; for (int k = 0; k < 32; k++) g_lz4_prof[k] = pf_acc[k]; }
 #endif
     if (lane == 0) status[b] = err;
     wave_lds_fence();

@@ -72,12 +72,15 @@ int main(int argc, char** argv) {
       wrong += memcmp(back.data() + (size_t)k * body, plain.data() + (size_t)(b % distinct) * rows, body) != 0;
     }
     printf("variant %d: %.3f ms  %.1f GB/s out  status!=0: %d  wrong blocks: %d\n", variant, ms, (double)nblocks * body / ms / 1e6, bad, wrong);
+#ifdef DFDB_LZ4_PROF
     if (variant >= 4) {
-      unsigned long long pf[16];
+      unsigned long long pf[32];
       CK(hipMemcpyFromSymbol(pf, HIP_SYMBOL(g_lz4_prof), sizeof(pf)));
-      printf("  block 0 cycles: total %llu | candidates %llu  walk+records %llu  far %llu  resolve %llu  flush %llu  other %llu | superbatches %llu chunks %llu rounds %llu seqs %llu far %llu\n",
-             pf[15], pf[0], pf[1], pf[5], pf[2], pf[3], pf[4], pf[6], pf[7], pf[8], pf[9], pf[10]);
+      printf("  block 0 cycles: total %llu | candidates %llu  walk+partial %llu  dense %llu  far %llu  resolve %llu  flush %llu  other %llu | superbatches %llu chunks %llu rounds %llu seqs %llu far %llu\n",
+             pf[15], pf[0], pf[11], pf[12], pf[5], pf[2], pf[3], pf[4], pf[6], pf[7], pf[8], pf[9], pf[10]);
+      printf("    walk: hops %llu  per-window rest %llu | production: ordinals+gather %llu  addresses %llu  pointer rounds %llu  bytes %llu\n", pf[13], pf[14], pf[16], pf[17], pf[18], pf[19]);
     }
+#endif
   }
   return 0;
 }
