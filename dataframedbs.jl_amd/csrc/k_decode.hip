@@ -164,19 +164,25 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
       {
-        // ---- a SUPERBATCH of W 64-byte windows of input, in five phases that each expose their parallelism to the hardware:
-        //  1. candidates: lane l decodes the token at window start + l AS IF a sequence began there (literal count, match length, offset,
-        //     where the next sequence would start).  All W windows together: the two dependent LDS round trips are paid once.
-        //  2. walk: the chain of REAL starts, window after window, v_readlane only.  A start whose successor leaves the window points at
-        //     itself, so a hop is `p = readlane(next, p)` + one s_bitset1 into the window's start mask and the walk simply parks.
-        //  3. dense records: every start writes its candidate to LDS at its ordinal among the starts (mbcnt of the mask); the <= 171 sequences
-        //     are then finished 64 per row — output position by one DPP scan per ROW (not per window), far-source slots, validity, the
-        //     budget cut at SEQUENCE granularity — leaving an 8-byte record each and one START BIT at its first output byte.
+        // ---- a SUPERBATCH of W 64-byte windows of input, in five phases that each expose their parallelism to the hardware.  What shaped
+        // them (cycle probes in tools/bench_lz4, rocprofv3 instruction counters): one wave retires this code at ~10 cycles per instruction,
+        // a block's time is the length of its dependent chains, and the expensive links are (a) VALU -> SGPR -> anything (v_readlane / ballot
+        // feeding scalar code or a lane select: ~50 cycles) and (b) an LDS round trip (~55).  So: few of those links per sequence, many
+        // independent ones in flight together, everything else in the vector domain.
+        //  1. candidates: lane l decodes the token at window start + l AS IF a sequence began there (literal count, match length, where the
+        //     next sequence would start).  All W windows together: the two dependent LDS round trips are paid once.
+        //  2. walk: the chain of REAL starts.  A start whose successor leaves the window points at itself, so walks park on the last start.
+        //     next^2, next^4, next^8 come from three rounds of W independent ds_bpermute; the serial walk then visits every eighth start
+        //     (three v_readlane hops per window instead of up to 22) and three forward ds_permute levels mark the starts in between.
+        //  3. dense records: every start writes its candidate to LDS at its ordinal among the starts (mbcnt of the start mask); the <= 171
+        //     sequences are then finished 64 per row — output position by one DPP scan per ROW (not per window), far-source slots, validity,
+        //     the budget cut at SEQUENCE granularity — leaving an 8-byte record each and one START BIT at its first output byte.
         //  4. sources that have left the ring are fetched from HBM, 24 bytes each, one memory round trip for the whole superbatch.
         //  5. production, IN OUTPUT ORDER, four 64-byte rows per trip: a lane finds its sequence as the rank of its position among the start
-        //     bits (the bitmap sits in a register: two v_readlane per row), gathers the record, and turns it into an LDS address (literal in
-        //     the staging buffer / ring byte before the row / prefetched far byte) or a pointer to a lower lane of its row; pointers are
-        //     collapsed by ds_bpermute doubling; the rows' gathers are in flight together, only the final byte fetches are ordered.
+        //     bits (bitmap word + exclusive prefix side by side in LDS: one read, one v_bcnt), gathers the record — four 16-bit fields that
+        //     make the byte's LDS address ((j + B) & mask) | O for literal / ring / far byte alike, or name the lower lane of the row that
+        //     makes it — and pointers are collapsed by ds_bpermute doubling; the rows' gathers are in flight together, only the final byte
+        //     fetches are ordered.
         LZ4_PROF(4);
         advance(ip);
         uint32_t T = 0;                  // output bytes accepted
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
         // A block switches to it for good once the one-sequence path has met two such tokens.
         auto windows = [&](auto extc) {
           constexpr bool EXT = decltype(extc)::value;
-          uint32_t A[W], NX[W], OFS[W];
+          uint32_t A[W], NX[W];
           // ---- phase 1
           uint32_t tok[W], e1[W];
 #pragma unroll
@@ -232,42 +238,72 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
               NX[w] = simple ? end - (ip + 64u * (uint32_t)w) : 1023u;             // <= 63 + 274
               A[w] = lit | ml << 9 | (le ? 1u << 18 : 0u);
             }
-            OFS[w] = offset;
           }
           bits[lane & (kBatchBytes / 32 - 1)] = 0;
           LZ4_PROF(0);
-          // ---- phases 2 + 3a: walk a window, drop its starts' candidates at their ordinals
+          // ---- phase 2a: next^2, next^4 and next^8 of every candidate, all windows together (three rounds of W independent ds_bpermute).
+          // A start whose successor lies outside the window (or that the batch does not take) points at itself, so do its powers: walks park there.
+          uint32_t X8[W];
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t nxp = NX[w] < 64u ? NX[w] : lane;
+            const uint32_t nxp2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp << 2), (int)nxp);
+            const uint32_t nxp4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp2 << 2), (int)nxp2);
+            X8[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp4 << 2), (int)nxp4);
+            // one register per window from here on: exit value (10 bits) | next^2 | next | taken | next^4
+            NX[w] |= nxp2 << 10 | nxp << 16 | (NX[w] != 1023u ? 1u << 22 : 0u) | nxp4 << 23;
+          }
+          // ---- phase 2b: the serial part.  A hop is a VALU -> SGPR -> VALU round trip (v_readlane with a lane select that the previous
+          // v_readlane produced: ~50 cycles on this part), and a block's latency is made of them, so the walk visits every EIGHTH start only:
+          // three hops reach the last of the <= 22 starts of a window.
+          uint64_t V[W];
           uint32_t p = 0;                  // next sequence start, relative to the window being walked
+#pragma unroll
+          for (int w = 0; w < W; w++) V[w] = 0;
 #pragma unroll
           for (int w = 0; w < W; w++) {
             if (EXT && p >= 64u) { p -= 64u; consumed = 64u * (uint32_t)(w + 1) + p; continue; }   // a long sequence jumped over this window
-            // a start whose successor lies outside the window (or that the batch does not take) points at itself
-            const uint32_t nxp = NX[w] < 64u ? NX[w] : lane;
-            uint64_t mask = 0;
-            for (int h = 0; h < 3; h++) {                                        // <= 22 starts per window: 24 hops always reach the parking start
-              uint32_t last = p;
+            uint64_t v = 0;
 #pragma unroll
-              for (int u = 0; u < 8; u++) {
-                last = p;
-                asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(p));
-                p = rl(nxp, p);
-              }
-              if (p == last) break;
+            for (int u = 0; u < 3; u++) {
+              asm("s_bitset1_b64 %0, %1" : "+s"(v) : "s"(p));
+              p = rl(X8[w], p);
             }
-            LZ4_PROF(13);
-            const uint32_t exitp = rl(NX[w], p);
+            V[w] = v;                                                            // p: the last start of the window
+            const uint32_t exitp = rl(NX[w], p) & 1023u;
             nonsimple = exitp == 1023u;
-            mask &= __ballot(NX[w] != 1023u);                                    // (a parked start the batch does not take got a bit too)
-            // (nseq + popcount(mask) <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
-            if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
-              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-              info[ord] = make_uint2(A[w], OFS[w] | (64u * (uint32_t)w + lane + 1u + (A[w] >> 18)) << 16);
-            }
-            nseq += (uint32_t)__builtin_popcountll(mask);
-            LZ4_PROF(14);
             if (nonsimple) { consumed = 64u * (uint32_t)w + p; break; }
             p = exitp - 64u; consumed = 64u * (uint32_t)(w + 1) + p;
           }
+          LZ4_PROF(13);
+          // ---- phases 2c + 3a: the starts between the visited ones (three forward permutes: the visited starts mark their fourth
+          // successors, all of those their second, all of those their first; a lane that is no source sends to lane 0, which no hop can
+          // target: a hop moves at least three positions), then every start drops its candidate at its ordinal.  The 2-byte offset is read again here, for the
+          // starts only, instead of living in W registers through the walk.
+          // (in the vector domain until the one ballot per window that the ordinals need: flags are 0 / 1 registers, a permute address is
+          //  flag * 4 * next — a ballot that feeds scalar code that feeds an inverse ballot costs two ~50-cycle crossings per level)
+          const uint32_t ge3 = lane >= 3u ? 1u : 0u;
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t inv = __builtin_amdgcn_inverse_ballot_w64(V[w]) ? 1u : 0u;
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 21) & 0xfcu) * inv), (int)inv);      // 4 * next^4
+            const uint32_t in0 = inv | (r0 & ge3);
+            const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 8) & 0xfcu) * in0), (int)in0);      // 4 * next^2
+            const uint32_t in1 = in0 | (r1 & ge3);
+            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 14) & 0xfcu) * in1), (int)in1);     // 4 * next
+            const uint32_t in2 = (in1 | (r2 & ge3)) & (NX[w] >> 22);             // bit 22: a sequence the batch takes (a parked start that it does not take is marked too)
+            const uint64_t mask = __ballot(in2 != 0u);
+            // (nseq + popcount(mask) <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
+            if (in2 != 0u) {
+              const uint32_t le = (A[w] >> 18) & 1u, inpos = 64u * (uint32_t)w + lane + 1u + le;
+              const uint32_t opos = ip + inpos + (A[w] & 511u);
+              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+              info[ord] = make_uint2(A[w], offset | inpos << 16);
+            }
+            nseq += (uint32_t)__builtin_popcountll(mask);
+          }
+          LZ4_PROF(14);
         };
         if (extstops >= 2u) windows(std::true_type{}); else windows(std::false_type{});
         LZ4_PROF(11);
