@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
+    ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
@@ -228,6 +229,8 @@ def main():
         assert local_rows <= nblocks_per * 65536
     else:
         ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
+        if args.no_placement:
+            ctx.set_option("placement_calibrate", 0)
         t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
         t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
         t.set_row_base(rank * rows)
@@ -235,6 +238,9 @@ def main():
         nsel = q.count()                                   # exact selected count from the first (untimed) execution
         local_rows = rows
     info = ctx.device_info()
+    # placement calibration happened inside that first execution (query.cpp: place_mask): what it saw
+    pl_n, pl_best = ctx.profile_get("placement_best_us")
+    _, pl_worst = ctx.profile_get("placement_worst_us")
     cap = nsel
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
 
@@ -311,7 +317,10 @@ def main():
                        "sharding": (f"contiguous block ranges x{world}, all-reduce(count) per step by " +
                                     ("libdfdb_hip's RCCL communicator (dfdb_group_count)" if lib else f"torch.distributed {args.backend}")) if world > 1 else "single GPU",
                        "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
-                       "device": info["name"], "global_selected": total_sel},
+                       "device": info["name"], "global_selected": total_sel,
+                       "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows,
+                                                  "what": "one-time: the scan timed against 9 bitmap allocations, the fastest kept (ctx option placement_calibrate)"}
+                                                 if pl_n else "off")},
             "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,

@@ -242,6 +242,7 @@ int32_t dfdb_query_free(dfdb_query* q) {
     if (!q) return;
     if (q->t) {
       (void)hipStreamSynchronize(q->t->ctx->stream);
+      query_return_mask(q);
       auto& v = q->t->queries;
       for (size_t i = 0; i < v.size(); i++) if (v[i] == q) { v[i] = v.back(); v.pop_back(); break; }
     } else (void)hipDeviceSynchronize();

@@ -23,6 +23,11 @@ struct Column {
   // sit in the file stay in HBM with their descriptors, and dfdb_table_decode_resident re-runs K7 from them into `data`
   DevBuf comp, comp_blocks, comp_status;
   int64_t comp_nblocks = 0;
+  // placement calibration (query.cpp: place_mask): the selection bitmap this column's scans run fastest against, found once by timing
+  // the scan against a few candidate allocations; lent to one query at a time
+  DevBuf mask_pref;
+  bool mask_calibrated = false, mask_lent = false;
+  float mask_ms_best = 0, mask_ms_worst = 0;   // per scanned sample, for dfdb_ctx_profile / the bench's JSON
   // on-disk source (tables opened from files)
   std::string file;
   size_t data_off = 0;  // first block inside the file
@@ -87,6 +92,7 @@ struct dfdb_query {
   dfdb::DevBuf agg_partials, agg_ones;
   int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
+  int mask_from = -1;          // table ordinal of the column whose calibrated bitmap this query has borrowed (-1: its own)
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
   bool prefix_valid = false;
@@ -112,6 +118,7 @@ int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 void query_unique(dfdb_query* q, int32_t p);
+void query_return_mask(dfdb_query* q);            // give a borrowed calibrated bitmap back to its column
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread
 // stream.cpp: block-streamed execution over a non-resident table

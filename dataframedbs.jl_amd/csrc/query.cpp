@@ -97,6 +97,78 @@ static void ensure_state(dfdb_query* q) {
   }
 }
 
+// ---------------------------------------------------------------- placement calibration
+// K1 reads a column at ~7 TB/s while writing 1/64 of that as the bitmap.  How fast the pair runs depends on WHERE the two allocations sit
+// relative to each other in physical memory (tools/bench_offset: every 8-GB column timed against every one of twelve bitmap allocations —
+// 1.18 ms for some pairs, 1.32 ms for others, repeatably; offsets INSIDE an allocation change nothing), presumably DRAM bank conflicts between
+// the read stream and the open bitmap rows under the address hash.  Neither hipMalloc nor the virtual-memory API lets the caller choose
+// physical placement, so the engine measures: the first time a column of >= 2^26 rows is the target of a fresh-mask scan, the scan is timed
+// against a few candidate bitmap allocations spread over free HBM (spacer allocations in between, released
+// afterwards) and the fastest stays with the column.  Queries that scan the column borrow it (one at a time; others use their own).
+// ctx option "placement_calibrate" = 0 turns it off.  One-time cost: 27 scans (~35 ms per 1e9-row column).
+void query_return_mask(dfdb_query* q) {
+  if (q->mask_from < 0 || !q->t) { q->mask_from = -1; return; }
+  Column& c = q->t->cols[(size_t)q->mask_from];
+  std::swap(q->bitmap, c.mask_pref); c.mask_lent = false; q->mask_from = -1;
+  q->executed_stages = -1; q->count = -1; q->prefix_valid = false;
+}
+template <class Launch>
+static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t* bitmap, int64_t rows) */) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int64_t nrows = t->nrows;
+  if (nrows < ((int64_t)1 << 26) || ctx_option(ctx, "placement_calibrate", 1) == 0) return;
+  if (q->mask_from == ordinal) return;
+  query_return_mask(q);
+  Column& c = t->cols[(size_t)ordinal];
+  const size_t bytes = padded_words(nrows) * 8;
+  if (!c.mask_calibrated) {
+    c.mask_calibrated = true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    constexpr int kCand = 8;
+    const size_t spacer = std::min<size_t>((size_t)12 << 30, free_b / (4 * kCand));
+    if (free_b < (size_t)kCand * (bytes + spacer) + ((size_t)4 << 30)) return;      // not enough room to look around: keep the query's own
+    std::vector<DevBuf> cand((size_t)kCand), space((size_t)kCand);
+    try {
+      for (int k = 0; k < kCand; k++) { cand[(size_t)k].ensure(bytes); if (spacer >= ((size_t)64 << 20)) space[(size_t)k].ensure(spacer); }
+    } catch (const Error&) { return; }
+    const int64_t sample = nrows;      // the WHOLE column: how a bitmap allocation pairs with the first eighth says little about the rest (measured)
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    auto time_on = [&](uint64_t* bm) {
+      float best = 1e30f;
+      for (int r = 0; r < 3; r++) {
+        HIP_CHECK(hipEventRecord(e0, s));
+        launch(bm, sample);
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms < best) best = ms;
+      }
+      return best;
+    };
+    float tbest = time_on(q->bitmap.as<uint64_t>()), tworst = tbest; int kbest = -1;
+    for (int k = 0; k < kCand; k++) {
+      const float tk = time_on(cand[(size_t)k].as<uint64_t>());
+      if (tk < tbest) { tbest = tk; kbest = k; }
+      if (tk > tworst) tworst = tk;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c.mask_ms_best = tbest; c.mask_ms_worst = tworst;
+    auto& pe = ctx->prof["placement_best_us"]; pe.launches++; pe.ms += tbest * 1e3;
+    auto& pw = ctx->prof["placement_worst_us"]; pw.launches++; pw.ms += tworst * 1e3;
+    if (kbest >= 0 && tbest < 0.985f * tworst) {       // a real difference, and the query's own allocation is not the winner
+      c.mask_pref = std::move(cand[(size_t)kbest]);
+      HIP_CHECK(hipMemsetAsync(c.mask_pref.p, 0, bytes, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));                 // candidates and spacers die here
+    HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, bytes, s));
+  }
+  if (c.mask_pref.p && !c.mask_lent && c.mask_pref.bytes >= bytes) {
+    std::swap(q->bitmap, c.mask_pref); c.mask_lent = true; q->mask_from = ordinal;
+  }
+}
+
 static uint64_t splitmix64_host(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
 
 static const Column& need_resident(const dfdb_table* t, int ordinal) {
@@ -255,6 +327,16 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       if (extra == 1) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
       else q->agg_partials.ensure((size_t)(ceil_div(nrows, kTileRows) + 8) * 8);
     }
+  }
+  if (!have && !term_batches.empty() && first_stage) {
+    // the launch that writes a fresh mask over the whole column: run it against the bitmap allocation this column pairs best with
+    const ScanTerms tb0 = term_batches[0];
+    const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
+    set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
+    place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows) {
+      if (tb0.n == 1) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr);
+      else launch_scan_terms(s, tb0, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
+    });
   }
   for (size_t bi = 0; bi < term_batches.size(); bi++) {
     const ScanTerms& tb = term_batches[bi];

@@ -110,6 +110,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
  *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
+ *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself against a few candidate bitmap allocations
+ *                     and the column keeps the fastest for the queries that scan it (27 scans once per column; query.cpp: place_mask; default 1)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
