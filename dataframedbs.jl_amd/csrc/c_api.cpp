@@ -240,6 +240,7 @@ int32_t dfdb_query_new(dfdb_table* t, dfdb_query** out) {
 int32_t dfdb_query_free(dfdb_query* q) {
   return guard([&] {
     if (!q) return;
+    if (q->stream_owned) fail(DFDB_ERR_ARGUMENT, "ArgumentError: a chunk query belongs to its stream (it dies at the next dfdb_stream_next / dfdb_stream_close)");
     if (q->t) {
       (void)hipStreamSynchronize(q->t->ctx->stream);
       query_return_mask(q);

@@ -92,6 +92,7 @@ struct dfdb_query {
   dfdb::DevBuf agg_partials, agg_ones;
   int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
+  bool stream_owned = false;   // a chunk query handed out by dfdb_stream_next: owned by the stream
   int mask_from = -1;          // table ordinal of the column whose calibrated bitmap this query has borrowed (-1: its own)
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)

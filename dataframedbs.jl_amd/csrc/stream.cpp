@@ -72,8 +72,13 @@ struct Slot {
 using namespace dfdb;
 
 struct dfdb_stream {
-  dfdb_query* src = nullptr;       // the caller's query (stages + projection) over the non-resident table
-  dfdb_table* t = nullptr;
+  // everything the stream needs from the caller's query and table is COPIED at open (stages, block size, the required columns' files):
+  // the stream stays valid after dfdb_query_free / dfdb_table_close of the handles it was opened from
+  std::vector<dfdb::Stage> stages;
+  int64_t block_size = 0;
+  std::string path;
+  struct ColSrc { std::string name, file; size_t data_off; };
+  std::vector<ColSrc> colsrc;      // per required column
   int64_t chunk_blocks = 0, nblocks = 0, next_block = 0;
   std::vector<int> required;       // table ordinals the query touches
   std::vector<std::vector<BlockLoc>> index;   // per required column
@@ -105,7 +110,7 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
     tb->nrows = -1; tb->block_first = 0;
     for (Column& c : tb->cols) c.resident = false;
     for (size_t k = 0; k < s->required.size(); k++) {
-      const Column& c = s->t->cols[(size_t)s->required[k]];
+      const dfdb_stream::ColSrc& c = s->colsrc[k];
       const std::vector<BlockLoc>& ix = s->index[k];
       const int64_t lo = ix[(size_t)sl->b0].off, hi = ix[(size_t)sl->b1 - 1].off + 20 + ix[(size_t)sl->b1 - 1].compressed;
       const size_t need = c.data_off + (size_t)(hi - lo);
@@ -131,7 +136,7 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
       }
     }
     tb->block_first = 0;
-    tb->row_base = sl->b0 * s->t->block_size;
+    tb->row_base = sl->b0 * s->block_size;
     sl->has_chunk = true;
   } catch (const Error& e) { sl->err_code = e.code; sl->err_msg = e.what(); }
   catch (const std::exception& e) { sl->err_code = DFDB_ERR_DEVICE; sl->err_msg = e.what(); }
@@ -168,10 +173,10 @@ bool range_like(const Stage& st) { return st.kind != ST_PRED; }
 
 // start loading the next chunk that can still contribute rows into `sl`; false when the stream is exhausted
 bool prefetch(dfdb_stream* s, Slot* sl) {
-  const int64_t B = s->t->block_size;
+  const int64_t B = s->block_size;
   // skip_if_can (selection.jl:177-190): a leading range stage whose first element lies beyond a chunk skips it unread
-  if (!s->src->stages.empty() && range_like(s->src->stages[0])) {
-    const Stage& st = s->src->stages[0];
+  if (!s->stages.empty() && range_like(s->stages[0])) {
+    const Stage& st = s->stages[0];
     const bool empty = (st.kind == ST_RANGE && st.n == 0) || (st.kind != ST_RANGE && st.idx.empty());
     if (empty) return false;
     const int64_t first_block = (st.first() - 1) / B;
@@ -203,7 +208,11 @@ void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) {
 }
 static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s) {
   dfdb_table* t = q->t;
-  s->src = q; s->t = t;
+  s->block_size = t->block_size; s->path = t->path;
+  for (const Stage& st : q->stages) {
+    Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx;   // (predicates live in the slots' queries)
+    s->stages.push_back(std::move(c));
+  }
   // one block is decoded by one wave in ~5-8 ms (K7 is serial inside a block) and the chip holds ~5000 waves, so a chunk
   // should hold several hundred blocks: 512 blocks = 0.25 GB of Int64 per slot, four slots
   s->chunk_blocks = chunk_blocks > 0 ? chunk_blocks : 512;
@@ -218,6 +227,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     const Column& c = t->cols[(size_t)o];
     if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
     s->index.push_back(index_blocks(c));
+    s->colsrc.push_back(dfdb_stream::ColSrc{c.name, c.file, c.data_off});
   }
   s->nblocks = s->index.empty() ? 0 : (int64_t)s->index[0].size();
   for (size_t k = 0; k < s->index.size(); k++) {
@@ -245,6 +255,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
       cq->stages.push_back(std::move(c));
     }
     for (const ProjCol& p : q->proj) cq->proj.push_back(ProjCol{p.name, p.expr->clone()});
+    cq->stream_owned = true;                              // dfdb_query_free refuses it: it dies with the stream
     tb->queries.push_back(cq.get());
     sl.tbl = tb.release(); sl.q = cq.release();
   }
@@ -259,11 +270,11 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
   if (s->cur >= 0) {
     Slot& old = s->slot[s->cur];
     if (old.has_chunk) {
-      for (size_t k = 1; k < s->src->stages.size(); k++)
-        if (range_like(s->src->stages[k])) s->base[k] += query_count(old.q, (int)k);
+      for (size_t k = 1; k < s->stages.size(); k++)
+        if (range_like(s->stages[k])) s->base[k] += query_count(old.q, (int)k);
       // is_finished: a range stage that has seen its last element ends the scan (selection.jl:192-196)
-      for (size_t k = 1; k < s->src->stages.size(); k++) {
-        const Stage& st = s->src->stages[k];
+      for (size_t k = 1; k < s->stages.size(); k++) {
+        const Stage& st = s->stages[k];
         if (!range_like(st)) continue;
         const bool empty = (st.kind == ST_RANGE && st.n == 0) || (st.kind != ST_RANGE && st.idx.empty());
         if (empty || st.last() <= s->base[k]) s->done = true;

@@ -128,8 +128,12 @@ void set_string_tile_offsets(dfdb_ctx* ctx, Column& c) {
 void table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nrows, const void* data, const uint8_t* bytes,
                       int64_t nbytes, const uint8_t* missing) {
   if (nrows < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
-  set_table_rows(t, nrows);
+  if (t->nrows >= 0 && t->nrows != nrows)
+    fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table holds %lld resident rows", (long long)nrows, (long long)t->nrows);
+  // the column is built aside and only joins the table (and sets its row count) once its upload has succeeded
+  struct Rollback { dfdb_table* t; size_t n; int64_t rows; bool armed = true; ~Rollback() { if (armed) { t->cols.resize(n); t->nrows = rows; } } } rb{t, t->cols.size(), t->nrows};
   Column& c = new_column(t, name, dtype);
+  set_table_rows(t, nrows);
   hipStream_t s = t->ctx->stream;
   c.nrows = nrows;
   if (dt_base(dtype) == DFDB_STRING) {
@@ -155,10 +159,16 @@ void table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nr
   }
   HIP_CHECK(hipStreamSynchronize(s));
   c.resident = true;
+  rb.armed = false;
 }
 
 void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t seed, int64_t row_first, int64_t nrows) {
   if (nrows < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
+  if (t->nrows >= 0 && t->nrows != nrows)
+    fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table holds %lld resident rows", (long long)nrows, (long long)t->nrows);
+  if (gen < DFDB_GEN_I64_MOD1M || gen > DFDB_GEN_I64_IOTA) fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
+  for (auto& c : t->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
+  struct Rollback { dfdb_table* t; size_t n; int64_t rows; bool armed = true; ~Rollback() { if (armed) { t->cols.resize(n); t->nrows = rows; } } } rb{t, t->cols.size(), t->nrows};
   set_table_rows(t, nrows);
   hipStream_t s = t->ctx->stream;
   switch (gen) {
@@ -192,6 +202,7 @@ void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t 
     default: fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
   }
   HIP_CHECK(hipStreamSynchronize(s));
+  rb.armed = false;
 }
 
 // ---------------------------------------------------------------- block loading (D1-D6)

@@ -39,7 +39,11 @@ struct Wr {   // little-endian writer (native Julia `write`)
 
 struct File {   // sequential writer over a file descriptor; large pieces go out as concurrent pwrites
   int fd = -1; std::string name; int64_t pos = 0;
-  File(const std::string& fn) : name(fn) { fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666); if (fd < 0) fail(DFDB_ERR_IO, "cannot create %s: %s", fn.c_str(), strerror(errno)); }
+  // O_EXCL: an existing file is an error, like make_column_file (filesystem.jl:14-17: "Column file ... already exists")
+  File(const std::string& fn) : name(fn) {
+    fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0666);
+    if (fd < 0) fail(DFDB_ERR_IO, errno == EEXIST ? "file %s already exists" : "cannot create %s: %s", fn.c_str(), strerror(errno));
+  }
   ~File() { if (fd >= 0) ::close(fd); }
   static bool pwrite_all(int fd, const uint8_t* p, int64_t n, int64_t at) {
     while (n > 0) { const ssize_t r = pwrite(fd, p, (size_t)n, (off_t)at); if (r <= 0) return false; p += r; n -= r; at += r; }
@@ -54,10 +58,12 @@ struct File {   // sequential writer over a file descriptor; large pieces go out
     }
     // a large piece: write()s to one file serialise on the inode lock, page faults on a shared mapping do not — grow the file,
     // map the piece and fill it with concurrent memcpys
-    if (ftruncate(fd, (off_t)(pos + (int64_t)n)) != 0) fail(DFDB_ERR_IO, "cannot grow %s: %s", name.c_str(), strerror(errno));
+    // RESERVE the space first: a sparse ftruncate always succeeds and a full disk would then surface as SIGBUS inside the memcpy
+    const int fa = posix_fallocate(fd, (off_t)pos, (off_t)n);
+    if (fa == ENOSPC || fa == EDQUOT || fa == EFBIG) fail(DFDB_ERR_IO, "cannot reserve %zu bytes in %s: %s", n, name.c_str(), strerror(fa));
     const int64_t page = 4096, m0 = pos / page * page, mlen = pos + (int64_t)n - m0;
-    void* mp = mmap(nullptr, (size_t)mlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);
-    if (mp == MAP_FAILED) {                                            // (a file system without shared mappings)
+    void* mp = fa == 0 ? mmap(nullptr, (size_t)mlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0) : MAP_FAILED;
+    if (mp == MAP_FAILED) {                                            // (a file system without fallocate or shared mappings: plain writes report errors themselves)
       if (!pwrite_all(fd, b, (int64_t)n, pos)) fail(DFDB_ERR_IO, "short write to %s", name.c_str());
       pos += (int64_t)n; return;
     }
@@ -73,7 +79,11 @@ struct File {   // sequential writer over a file descriptor; large pieces go out
     munmap(mp, (size_t)mlen);
     pos += (int64_t)n;
   }
-  void close() { if (fd >= 0 && ::close(fd) != 0) { fd = -1; fail(DFDB_ERR_IO, "cannot close %s", name.c_str()); } fd = -1; }
+  void close(bool sync = false) {
+    if (fd >= 0 && sync && fdatasync(fd) != 0) { ::close(fd); fd = -1; fail(DFDB_ERR_IO, "cannot sync %s: %s", name.c_str(), strerror(errno)); }
+    if (fd >= 0 && ::close(fd) != 0) { fd = -1; fail(DFDB_ERR_IO, "cannot close %s", name.c_str()); }
+    fd = -1;
+  }
 };
 
 inline int64_t lz4_bound(int64_t n) { return n + n / 255 + 16; }   // LZ4_COMPRESSBOUND
@@ -193,16 +203,18 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
     }
     b0 = b1;
   }
-  f.close();
+  f.close(ctx_option(ctx, "save_fsync", 0) != 0);      // option save_fsync: the column's bytes are on stable storage before meta.bin names the table
   if (stats) *stats = st;
 }
 
 // make_table / create_table: meta.bin + one file per column (creators.jl:18-60, table_io.jl:9-19)
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) {
   const std::string dir(path);
-  struct stat sb;
-  if (stat((dir + "/meta.bin").c_str(), &sb) == 0) fail(DFDB_ERR_IO, "table %s already exists", path);
-  if (mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) fail(DFDB_ERR_IO, "cannot create directory %s: %s", path, strerror(errno));
+  // table_exists(path) = isdir(path) (filesystem.jl:38): an existing directory IS an existing table for make_table_files (:31)
+  if (mkdir(dir.c_str(), 0777) != 0) {
+    if (errno == EEXIST) fail(DFDB_ERR_IO, "Table %s already exists", path);
+    fail(DFDB_ERR_IO, "cannot create directory %s: %s", path, strerror(errno));
+  }
   for (auto& c : t->cols) if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
   dfdb_sizestats tot{0, 0, 0};
   for (size_t i = 0; i < t->cols.size(); i++) {
@@ -214,7 +226,7 @@ void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) {
   for (auto& c : t->cols) { m.i64(c.id); m.str(c.name); m.str(dt_type_string(c.dtype, c.logical)); }
   File f(dir + "/meta.bin");   // written last: a table without meta.bin "don't exists" (creators.jl:9)
   f.put(m.b.data(), m.b.size());
-  f.close();
+  f.close(ctx_option(t->ctx, "save_fsync", 0) != 0);
   if (stats) *stats = tot;
 }
 

@@ -112,6 +112,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
  *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself against a few candidate bitmap allocations
  *                     and the column keeps the fastest for the queries that scan it (27 scans once per column; query.cpp: place_mask; default 1)
+ *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
@@ -162,7 +163,8 @@ int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query*
  * column -> `<path>/<id>.bin` in the reference's block format (write_column_head filesystem.jl:14-23, write_block_body
  * blocks.jl:2-33, commit_block_write! BlockStreams.jl:36-60) + `<path>/meta.bin` (write_table_meta table_io.jl:9-19).
  * Block bodies are packed and LZ4-compressed on the device; only compressed bytes cross PCIe.  The files open with the
- * reference's open_table and with dfdb_table_open.  ErrorException (DFDB_ERR_IO) if the table already exists. */
+ * reference's open_table and with dfdb_table_open.  ErrorException (DFDB_ERR_IO) if `path` exists at all (table_exists = isdir:
+ * filesystem.jl:31,38) or a column file does (make_column_file :16); a full disk is DFDB_ERR_IO too (space is reserved before it is written). */
 int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);
 /* one column file (header + blocks) */
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);

@@ -165,3 +165,40 @@ def test_streamed_errors_surface(oracle, dfdb_mod, tmp_path):
             for part in s:
                 got += part.count()
     assert got == 4 * bs                                               # chunks 0 and 1 (blocks 0-3) were delivered, chunk 2 holds block 5
+
+
+def test_stream_outlives_its_source_handles(oracle, dfdb_mod, ctx, tmp_path):
+    """dfdb_stream copies what it needs at open (stages, block size, column files): freeing the source query and closing the source table
+    while the stream is running must not matter, and a chunk query cannot be freed by the caller (it belongs to the stream)."""
+    import ctypes as C
+    from dfdb import _native as N
+    n, bs = 60_000, 4096
+    a = np.arange(1, n + 1, dtype=np.int64)
+    t = oracle.Table(block_size=bs)
+    t.add_column("a", a)
+    path = str(tmp_path / "tb")
+    t.save(path)
+    L = N.load()
+    tb = dfdb_mod.open_table(path, load=False)
+    v = dfdb_mod.selection(tb[("a", lambda x: x % 3 == 0), dfdb_mod.ALL], dfdb_mod.jr(5, 2, 9000))
+    q = v._query()
+    s = C.c_void_p()
+    N.check(L.dfdb_stream_open(q._h, 2, C.byref(s)))
+    # the handles the stream was opened from go away first
+    N.check(L.dfdb_query_free(q._h)); q._h = C.c_void_p()
+    tb.close()
+    total, rows = 0, []
+    while True:
+        cq, cr, fr = C.c_void_p(), C.c_int64(), C.c_int64()
+        N.check(L.dfdb_stream_next(s, C.byref(cq), C.byref(cr), C.byref(fr)))
+        if not cq:
+            break
+        assert L.dfdb_query_free(cq) == N.ERR_ARGUMENT and "belongs to its stream" in N.last_error()
+        cnt = C.c_int64()
+        N.check(L.dfdb_count(cq, C.byref(cnt)))
+        out = np.empty(cnt.value, np.int64)
+        N.check(L.dfdb_select_indices(cq, out.ctypes.data if cnt.value else None, cnt.value, N.MEM_HOST, None))
+        rows.append(out); total += cnt.value
+    N.check(L.dfdb_stream_close(s))
+    want = (np.nonzero(a % 3 == 0)[0] + 1)[4:9000:2]
+    assert total == len(want) and np.array_equal(np.concatenate(rows), want)

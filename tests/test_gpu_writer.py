@@ -175,6 +175,27 @@ def test_add_column_from_lazy_column_and_create_table(oracle, dfdb_mod, ctx, tmp
             assert np.array_equal(w, g)
     with pytest.raises(dfdb_mod.DfdbError):               # create_table refuses an existing table
         sub.save(path)
+    # table_exists(path) = isdir(path) (filesystem.jl:31,38): ANY existing directory is refused, nothing in it is touched;
+    # an existing column file is refused too (make_column_file, filesystem.jl:16)
+    empty = tmp_path / "empty_dir"
+    empty.mkdir()
+    (empty / "1.bin").write_bytes(b"precious")
+    with pytest.raises(dfdb_mod.DfdbError, match="already exists"):
+        sub.save(str(empty))
+    assert (empty / "1.bin").read_bytes() == b"precious"
+    with pytest.raises(dfdb_mod.DfdbError, match="already exists"):
+        sub.save_column(sub.names()[0], str(empty / "1.bin"))
+    # a rejected add leaves the table as it was (no phantom column, no row count set on an empty table)
+    t0 = dfdb_mod.DFTable.new()
+    from dfdb import _native as N
+    five = np.arange(5, dtype=np.int64)
+    assert N.load().dfdb_table_add_column(t0._h, b"bad", 63, 5, five.ctypes.data, None, 0, None) == N.ERR_UNSUPPORTED
+    assert t0.ncols == 0
+    t0.add_column("ok", np.arange(7, dtype=np.int64))                # 7 rows: the rejected 5-row column did not pin the row count
+    assert dfdb_mod.nrow(t0) == 7
+    with pytest.raises(ValueError, match="Duplicated"):
+        t0.add_column("ok", np.arange(7, dtype=np.int64))
+    assert t0.ncols == 1
 
 
 def test_incompressible_and_degenerate_blocks(oracle, dfdb_mod, ctx, tmp_path):
