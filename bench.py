@@ -291,7 +291,7 @@ def main():
         value = total_rows * args.steps / elapsed
         sigma = nsel / local_rows
         # ONE k_scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
-        kname, pmc_name = "k_scan_cmp<int64,GT>", "r1_pmc_scan_cmp.json"
+        kname, pmc_name = "k_scan_cmp<int64,GT>", "r2_pmc_scan_cmp.json"
         scan_bytes = local_rows * (8 + 1 / 8 + 4 / 1024)
         scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
