@@ -59,9 +59,10 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
   __shared__ uint32_t bits_sh[WAVES][kBatchBytes / 32 + 2];   // + two words that stay zero
   __shared__ uint2 bitsx_sh[WAVES][kBatchBytes / 32 + 8];     // {start-bit word, starts before it - 1}; the tail stays {0, -1}
-  __shared__ uint2 info_sh[WAVES][kSeqMax];
+  __shared__ uint2 info_sh[WAVES][kSeqMax + 1];               // entry 0 is a dummy: production's ordinal -1 (a row past the last byte) reads it
   const uint32_t lane = (uint32_t)lane_id();
-  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (one wave per workgroup in the shipped configuration: every LDS array then sits at a compile-time address that folds into the ds instructions' offset field)
+  const int wib = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* lds = lds_sh[wib];
   uint8_t* stage = lds;
   uint8_t* ring = lds + kStage;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
   uint2* bitsx = bitsx_sh[wib];
   if (lane < 8) bitsx[kBatchBytes / 32 + lane] = make_uint2(0u, 0xffffffffu);
   const uint32_t lane_below = (2u << (lane & 31u)) - 1u;         // bits 0 .. lane mod 32
-  uint2* info = info_sh[wib];
+  uint2* info = info_sh[wib] + 1;
   uint32_t* fard = fard_sh[wib];
   if (lane < 2) bits[kBatchBytes / 32 + lane] = 0;
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
         // A block switches to it for good once the one-sequence path has met two such tokens.
         auto windows = [&](auto extc) {
           constexpr bool EXT = decltype(extc)::value;
-          uint32_t A[W], NX[W];
-          // ---- phase 1
+          uint32_t NX[W];
+          // ---- phase 1: only WHERE the next sequence would start (and whether the batch can take this one at all) is decoded for every
+          // position; lengths and offsets are decoded later, 64 real sequences per row instead of 64 positions per window
           uint32_t tok[W], e1[W];
 #pragma unroll
           for (int w = 0; w < W; w++) {
@@ -206,37 +208,20 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             tok[w] = stage[pos & (kStage - 1)];
             if (EXT) e1[w] = stage[(pos + 1) & (kStage - 1)];
           }
-          uint32_t o0[W], o1[W], m1[W];
-#pragma unroll
-          for (int w = 0; w < W; w++) {
-            const uint32_t pos = ip + 64u * (uint32_t)w + lane;
-            const bool le = EXT && (tok[w] >> 4) == 15u;
-            const uint32_t lit = le ? 15u + e1[w] : tok[w] >> 4;
-            const uint32_t opos = pos + 1u + (le ? 1u : 0u) + lit;                  // the 2-byte offset field
-            o0[w] = stage[opos & (kStage - 1)]; o1[w] = stage[(opos + 1) & (kStage - 1)];
-            if (EXT) m1[w] = stage[(opos + 2) & (kStage - 1)];
-          }
 #pragma unroll
           for (int w = 0; w < W; w++) {
             const uint32_t pos = ip + 64u * (uint32_t)w + lane;
             const uint32_t token = tok[w];
-            const uint32_t offset = o0[w] | o1[w] << 8;
             if (!EXT) {
-              const uint32_t lit = token >> 4, mlc = token & 15u;
-              const uint32_t opos = pos + 1u + lit;
-              const bool simple = lit != 15u && mlc != 15u && opos + 2u < in_len && offset != 0;
+              const uint32_t lit = token >> 4;
+              const bool simple = token < 0xf0u && (token & 15u) != 15u && pos + lit + 3u < in_len;
               NX[w] = simple ? lane + 3u + lit : 1023u;   // where the following sequence starts, window-relative; 1023: a sequence the batch does not take
-              A[w] = lit | (mlc + 4u) << 9;
             } else {
-              const bool le = (token >> 4) == 15u, me = (token & 15u) == 15u;
+              const bool le = token >= 0xf0u, me = (token & 15u) == 15u;
               const uint32_t lit = le ? 15u + e1[w] : token >> 4;
-              const uint32_t opos = pos + 1u + (le ? 1u : 0u) + lit;
-              const uint32_t ml = 4u + (me ? 15u + m1[w] : (token & 15u));
-              const uint32_t end = opos + 2u + (me ? 1u : 0u);
-              const bool simple = !(le && e1[w] == 255u) && !(me && m1[w] == 255u) && end < in_len && offset != 0 &&
-                                  !(offset + 64u > (uint32_t)kRing && ml > 24u);   // (a far source is prefetched 24 bytes deep)
+              const uint32_t end = pos + 3u + (le ? 1u : 0u) + lit + (me ? 1u : 0u);
+              const bool simple = !(le && e1[w] == 255u) && end < in_len;
               NX[w] = simple ? end - (ip + 64u * (uint32_t)w) : 1023u;             // <= 63 + 274
-              A[w] = lit | ml << 9 | (le ? 1u << 18 : 0u);
             }
           }
           bits[lane & (kBatchBytes / 32 - 1)] = 0;
@@ -278,8 +263,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           LZ4_PROF(13);
           // ---- phases 2c + 3a: the starts between the visited ones (three forward permutes: the visited starts mark their fourth
           // successors, all of those their second, all of those their first; a lane that is no source sends to lane 0, which no hop can
-          // target: a hop moves at least three positions), then every start drops its candidate at its ordinal.  The 2-byte offset is read again here, for the
-          // starts only, instead of living in W registers through the walk.
+          // target: a hop moves at least three positions), then every start drops its POSITION at its ordinal.
           // (in the vector domain until the one ballot per window that the ordinals need: flags are 0 / 1 registers, a permute address is
           //  flag * 4 * next — a ballot that feeds scalar code that feeds an inverse ballot costs two ~50-cycle crossings per level)
           const uint32_t ge3 = lane >= 3u ? 1u : 0u;
@@ -295,17 +279,15 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             const uint64_t mask = __ballot(in2 != 0u);
             // (nseq + popcount(mask) <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
             if (in2 != 0u) {
-              const uint32_t le = (A[w] >> 18) & 1u, inpos = 64u * (uint32_t)w + lane + 1u + le;
-              const uint32_t opos = ip + inpos + (A[w] & 511u);
-              const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
               const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-              info[ord] = make_uint2(A[w], offset | inpos << 16);
+              info[ord].x = 64u * (uint32_t)w + lane;                              // where the sequence starts, relative to ip
             }
             nseq += (uint32_t)__builtin_popcountll(mask);
           }
           LZ4_PROF(14);
         };
-        if (extstops >= 2u) windows(std::true_type{}); else windows(std::false_type{});
+        const bool ext_mode = extstops >= 2u;
+        if (ext_mode) windows(std::true_type{}); else windows(std::false_type{});
         LZ4_PROF(11);
         if (nseq) {
           wave_lds_fence();
@@ -314,8 +296,20 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           for (uint32_t r0 = 0; r0 < nseq; r0 += 64u) {
             const uint32_t k = r0 + lane;
             const bool valid = k < nseq;
-            const uint2 c = valid ? info[k] : make_uint2(0u, 0u);
-            const uint32_t lit = c.x & 511u, ml = (c.x >> 9) & 511u, offset = c.y & 0xffffu, inpos = c.y >> 16;
+            // the sequence at that position, decoded now that it is known to be one (the candidate phase only found where it ends)
+            const uint32_t spos = ip + (valid ? info[k].x : 0u);
+            const uint32_t token = stage[spos & (kStage - 1)];
+            const bool le = ext_mode && token >= 0xf0u, me = ext_mode && (token & 15u) == 15u;
+            const uint32_t e1 = ext_mode ? (uint32_t)stage[(spos + 1) & (kStage - 1)] : 0u;
+            const uint32_t lit = valid ? (le ? 15u + e1 : token >> 4) : 0u;
+            const uint32_t opos = spos + 1u + (le ? 1u : 0u) + lit;             // the 2-byte offset field
+            const uint32_t offset = (uint32_t)stage[opos & (kStage - 1)] | (uint32_t)stage[(opos + 1) & (kStage - 1)] << 8;
+            const uint32_t m1 = ext_mode ? (uint32_t)stage[(opos + 2) & (kStage - 1)] : 0u;
+            const uint32_t ml = valid ? 4u + (me ? 15u + m1 : (token & 15u)) : 0u;
+            const uint32_t inpos = spos - ip + 1u + (le ? 1u : 0u);             // its literals, relative to ip
+            // EXT form only: a length that continues past its one extension byte, or a far source longer than the 24 prefetched bytes,
+            // belongs to the one-sequence path: the superbatch ends in front of it
+            const bool reject = ext_mode && ((me && m1 == 255u) || (offset + 64u > (uint32_t)kRing && ml > 24u));
             const uint32_t tot = lit + ml;                                       // (0 for a lane past the last sequence)
             const uint32_t incl = T + wave_incl_scan(tot);
             const uint32_t ostart = incl - tot;
@@ -323,10 +317,13 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             const uint64_t farmask = __ballot(far);
             const uint32_t fo = nfar + __builtin_amdgcn_mbcnt_hi((uint32_t)(farmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)farmask, 0u));
             // the budget cut: output bytes and far slots both grow with the ordinal, so the accepted sequences are a prefix
-            const bool acc = valid && incl <= (uint32_t)kBatchBytes && fo + (far ? 1u : 0u) <= (uint32_t)kFarMax;
+            const bool ok = valid && !reject;
+            const uint64_t okmask = __ballot(ok) | ~__ballot(valid);             // the sequences before the first rejected one
+            const bool before = okmask == ~0ull || lane < (uint32_t)__builtin_ctzll(~okmask);
+            const bool acc = valid && before && incl <= (uint32_t)kBatchBytes && fo + (far ? 1u : 0u) <= (uint32_t)kFarMax;
             const uint32_t na = (uint32_t)__builtin_popcountll(__ballot(acc));
             if (acc) {
-              bad = bad || offset > op + ostart + lit;
+              bad = bad || offset == 0u || offset > op + ostart + lit;
               if (far) fard[fo] = op + ostart + lit - offset;                   // where its source starts in the block's output
               // the record production reads, as 16-bit fields.  A byte j of the sequence comes from LDS address ((j + B) & (kStage - 1)) | O
               // with (B, O) = the literal pair below its literal end and the match pair from there on:
@@ -347,8 +344,8 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             nfar += (uint32_t)__builtin_popcountll(farmask & (na >= 64u ? ~0ull : ((1ull << na) - 1ull)));
             const uint32_t nvalid = nseq - r0 < 64u ? nseq - r0 : 64u;
             if (na < nvalid) {                                                   // cut here: the next superbatch starts with sequence r0 + na
-              consumed = rl(inpos - 1u - ((c.x >> 18) & 1u), na);
-              nonsimple = false;
+              consumed = rl(spos - ip, na);
+              nonsimple = ((~okmask >> na) & 1ull) != 0;                          // stopped by a sequence only the one-sequence path takes
               break;
             }
           }
@@ -397,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             }
             uint2 INF[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) INF[u] = info[ORD[u] < (uint32_t)kSeqMax ? ORD[u] : 0u];   // (rows past T: any record, the byte is never written)
+            for (int u = 0; u < U; u++) INF[u] = info[(int32_t)ORD[u]];                   // (rows past T: ordinal -1 or the last sequence's: any record, the byte is never written)
             LZ4_PROF(16);
             uint32_t R[U];
 #pragma unroll
