@@ -228,16 +228,25 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           LZ4_PROF(0);
           // ---- phase 2a: next^2, next^4 and next^8 of every candidate, all windows together (three rounds of W independent ds_bpermute).
           // A start whose successor lies outside the window (or that the batch does not take) points at itself, so do its powers: walks park there.
-          uint32_t X8[W];
+          // (level by level, each level's W gathers issued back to back and waited for once: see the pins in phase 2c)
+          static_assert(W == 8, "the pins below name eight registers");
+#define DFDB_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+          uint32_t X8[W], P2[W], P4[W];
 #pragma unroll
           for (int w = 0; w < W; w++) {
             const uint32_t nxp = NX[w] < 64u ? NX[w] : lane;
-            const uint32_t nxp2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp << 2), (int)nxp);
-            const uint32_t nxp4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp2 << 2), (int)nxp2);
-            X8[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp4 << 2), (int)nxp4);
+            P2[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxp << 2), (int)nxp);
             // one register per window from here on: exit value (10 bits) | next^2 | next | taken | next^4
-            NX[w] |= nxp2 << 10 | nxp << 16 | (NX[w] != 1023u ? 1u << 22 : 0u) | nxp4 << 23;
+            NX[w] |= nxp << 16 | (NX[w] != 1023u ? 1u << 22 : 0u);
           }
+          DFDB_PIN8(P2);
+#pragma unroll
+          for (int w = 0; w < W; w++) { P4[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(P2[w] << 2), (int)P2[w]); NX[w] |= P2[w] << 10; }
+          DFDB_PIN8(P4);
+#pragma unroll
+          for (int w = 0; w < W; w++) { X8[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(P4[w] << 2), (int)P4[w]); NX[w] |= P4[w] << 23; }
+          DFDB_PIN8(X8);
+#undef DFDB_PIN8
           // ---- phase 2b: the serial part.  A hop is a VALU -> SGPR -> VALU round trip (v_readlane with a lane select that the previous
           // v_readlane produced: ~50 cycles on this part), and a block's latency is made of them, so the walk visits every EIGHTH start only:
           // three hops reach the last of the <= 22 starts of a window.
@@ -266,23 +275,45 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           // target: a hop moves at least three positions), then every start drops its POSITION at its ordinal.
           // (in the vector domain until the one ballot per window that the ordinals need: flags are 0 / 1 registers, a permute address is
           //  flag * 4 * next — a ballot that feeds scalar code that feeds an inverse ballot costs two ~50-cycle crossings per level)
+          // Level by level over ALL windows: the W permutes of a level are issued back to back and waited for once (the empty asm pins that
+          // order: the compiler would otherwise sink every permute to its use and pay W x 3 LDS round trips one after another).
           const uint32_t ge3 = lane >= 3u ? 1u : 0u;
+          static_assert(W == 8, "the pins below name eight registers");
+          uint32_t FL[W], RP[W];
+#define DFDB_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 #pragma unroll
           for (int w = 0; w < W; w++) {
-            const uint32_t inv = __builtin_amdgcn_inverse_ballot_w64(V[w]) ? 1u : 0u;
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 21) & 0xfcu) * inv), (int)inv);      // 4 * next^4
-            const uint32_t in0 = inv | (r0 & ge3);
-            const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 8) & 0xfcu) * in0), (int)in0);      // 4 * next^2
-            const uint32_t in1 = in0 | (r1 & ge3);
-            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 14) & 0xfcu) * in1), (int)in1);     // 4 * next
-            const uint32_t in2 = (in1 | (r2 & ge3)) & (NX[w] >> 22);             // bit 22: a sequence the batch takes (a parked start that it does not take is marked too)
-            const uint64_t mask = __ballot(in2 != 0u);
-            // (nseq + popcount(mask) <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
-            if (in2 != 0u) {
-              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            FL[w] = __builtin_amdgcn_inverse_ballot_w64(V[w]) ? 1u : 0u;
+            RP[w] = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 21) & 0xfcu) * FL[w]), (int)FL[w]);      // 4 * next^4
+          }
+          DFDB_PIN8(RP);
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            FL[w] |= RP[w] & ge3;
+            RP[w] = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 8) & 0xfcu) * FL[w]), (int)FL[w]);       // 4 * next^2
+          }
+          DFDB_PIN8(RP);
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            FL[w] |= RP[w] & ge3;
+            RP[w] = (uint32_t)__builtin_amdgcn_ds_permute((int)(((NX[w] >> 14) & 0xfcu) * FL[w]), (int)FL[w]);      // 4 * next
+          }
+          DFDB_PIN8(RP);
+#undef DFDB_PIN8
+          uint64_t MASK[W];
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            FL[w] = (FL[w] | (RP[w] & ge3)) & (NX[w] >> 22) & 1u;                 // bit 22: a sequence the batch takes (a parked start that it does not take is marked too)
+            MASK[w] = __ballot(FL[w] != 0u);
+          }
+          // (nseq <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            if (FL[w] != 0u) {
+              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(MASK[w] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)MASK[w], 0u));
               info[ord].x = 64u * (uint32_t)w + lane;                              // where the sequence starts, relative to ip
             }
-            nseq += (uint32_t)__builtin_popcountll(mask);
+            nseq += (uint32_t)__builtin_popcountll(MASK[w]);
           }
           LZ4_PROF(14);
         };
