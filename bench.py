@@ -129,26 +129,45 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
     q2 = t2[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
     nsel2 = q2.count()
 
-    def step():
+    def step_unfused():                                   # K7, then the ordinary K1 over the decoded column
         t2.decode_resident("x")
         q2.reset()
         q2.indices_device(out_ptr, cap)
         q2.count_device(cnt_ptr)
 
-    step()
-    ctx.profile(True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    def step_fused():                                     # K7 with the predicate fused in (ctx option decode_on_scan): decode and filter in one pass
+        q2.reset()
+        q2.indices_device(out_ptr, cap)
+        q2.count_device(cnt_ptr)
+
+    def timed(step):
         step()
-    sync()
-    el = (time.perf_counter() - t0) / steps
-    n7, ms7 = ctx.profile_get("lz4_decode")
-    ctx.profile(False)
-    res = {"rows_per_s": rows / el, "ms_per_step": el * 1e3, "steps": steps, "selected": nsel2,
+        ctx.profile(True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        el = (time.perf_counter() - t0) / steps
+        prof = {k: ctx.profile_get(k) for k in ("lz4_decode", "lz4_decode_scan", "scan_cmp")}
+        ctx.profile(False)
+        return el, {k: (ms / n if n else None) for k, (n, ms) in prof.items()}
+
+    el_u, k_u = timed(step_unfused)
+    ctx.set_option("decode_on_scan", 1)
+    try:
+        el_f, k_f = timed(step_fused)
+        nsel3 = q2.count()
+    finally:
+        ctx.set_option("decode_on_scan", 0)
+    ms7 = k_u["lz4_decode"]
+    res = {"rows_per_s": rows / el_f, "ms_per_step": el_f * 1e3, "steps": steps, "selected": nsel2 if nsel3 == nsel2 else [nsel2, nsel3],
            "blocks": -(-rows // 65536), "compressed_bytes": st["compressed"], "ratio": st["uncompressed"] / max(st["compressed"], 1),
-           "lz4_decode_avg_ms": ms7 / n7 if n7 else None, "decoded_GBps": rows * 8 / (ms7 / n7 * 1e-3) / 1e9 if n7 else None,
-           "what": "compressed-resident column (reference LZ4 blocks in HBM) -> K7 decode of every block -> K1 scan -> count scan -> K2 indices, per step"}
+           "lz4_decode_scan_avg_ms": k_f["lz4_decode_scan"], "decoded_GBps": rows * 8 / (k_f["lz4_decode_scan"] * 1e-3) / 1e9 if k_f["lz4_decode_scan"] else None,
+           "unfused": {"rows_per_s": rows / el_u, "ms_per_step": el_u * 1e3, "lz4_decode_avg_ms": ms7, "scan_cmp_avg_ms": k_u["scan_cmp"],
+                       "decoded_GBps": rows * 8 / (ms7 * 1e-3) / 1e9 if ms7 else None},
+           "what": "compressed-resident column (reference LZ4 blocks in HBM) -> K7 decode of every block FUSED with the predicate (bitmap + tile counts leave the "
+                   "decoder) -> count scan -> K2 indices, per step; `unfused` = K7, then K1 over the decoded column"}
     t2.close()
     return res
 

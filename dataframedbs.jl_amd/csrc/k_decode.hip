@@ -49,9 +49,29 @@ __device__ unsigned long long g_lz4_prof[32];
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-template <int WAVES, int kRing, int kStage, int kBatchBytes, int W>
+// SCAN = 1: decode fused with the first predicate of the scan (the reference's loop body decodes a block and evaluates
+// the selection over it in one iteration, src/io/blocksiterator.jl:98-121): every 512 decoded bytes of an 8-byte column pass the
+// comparison `value OP c` on their way from the LDS ring to HBM and leave their 64-bit mask word — the bitmap and the per-1024-row
+// counts K1 would have produced from a second pass over the decoded column.
+__device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int op) {
+  int r;                                                         // -1 / 0 / 1, 2 = unordered
+  if (dtype == DFDB_F64) { const double a = __builtin_bit_cast(double, v), b = __builtin_bit_cast(double, c); r = (a != a || b != b) ? 2 : (a < b ? -1 : (a > b ? 1 : 0)); }
+  else if (dtype == DFDB_U64) r = v < c ? -1 : (v > c ? 1 : 0);
+  else r = (int64_t)v < (int64_t)c ? -1 : ((int64_t)v > (int64_t)c ? 1 : 0);
+  switch (op) {
+    case CMP_EQ: return r == 0;
+    case CMP_NE: return r != 0;
+    case CMP_LT: return r == -1;
+    case CMP_LE: return r == -1 || r == 0;
+    case CMP_GT: return r == 1;
+    default:     return r == 1 || r == 0;
+  }
+}
+
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN>
 __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                               const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status) {
+                                                               const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
+                                                               LzScan sc) {
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
   __shared__ __attribute__((aligned(16))) uint8_t lds_sh[WAVES][kStage + kRing + kFarMax * 24];
@@ -76,7 +96,8 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
   constexpr uint32_t kFlush = kRing >= 4096 ? 1024u : 512u;
   static_assert(kStage == kRing, "production addresses staging buffer, ring and far bytes as ((j + B) & (kStage - 1)) | O");
-  static_assert((kFlush + 256 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
+  constexpr uint32_t kFA = SCAN ? 511u : 255u;                    // flushes end on multiples of kFA + 1 bytes (SCAN: whole 64-row mask words)
+  static_assert((kFlush + kFA + 1 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
@@ -143,8 +164,27 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
       const uint64_t lo = (uint64_t)rl(whi, q) << 32 | rl(wlo, q);
       return (uint32_t)(lo >> sh) & 255u;
     };
+    // SCAN: mask words of this block so far, the current tile's words (word k of the tile in lane k) and its selected count
+    uint32_t sc_words = 0, sc_tile_count = 0; uint64_t sc_myword = 0;
+    const int64_t sc_word0 = blk.dst_off / 512;                   // the block's first mask word (host: the block starts on a 1024-row tile)
     // ring -> HBM, bytes [flushed, upto)
     auto flush_to = [&](uint32_t upto) {
+      if (SCAN) {
+        // `flushed` is a multiple of 512 here; a group shorter than 512 bytes can only be the block's last
+        for (uint32_t g = flushed; g < upto; g += 512u) {
+          const bool have = g + lane * 8u + 8u <= upto;
+          const uint64_t v = have ? *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1))) : 0ull;
+          const uint64_t m = __ballot(have && lz_cmp8(v, sc.cbits, sc.dtype, sc.op));
+          if (lane == (sc_words & 15u)) sc_myword = m;
+          sc_tile_count += (uint32_t)__builtin_popcountll(m);
+          sc_words++;
+          if ((sc_words & 15u) == 0u) {                            // a 1024-row tile is complete: one 128-byte line of bitmap + its count
+            if (lane < 16u) sc.bitmap[sc_word0 + sc_words - 16u + lane] = sc_myword;
+            if (lane == 0u) sc.counts[(sc_word0 + sc_words - 16u) >> 4] = sc_tile_count;
+            sc_tile_count = 0;
+          }
+        }
+      }
       if ((flushed & 3u) == 0 && (((uintptr_t)out) & 3u) == 0) {
         const uint32_t n4 = (upto - flushed) & ~3u;
         for (uint32_t o = lane * 4; o < n4; o += 256) {
@@ -463,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           LZ4_PROF(19);
           op += T; ip += consumed;
           LZ4_PROF(2);
-          if (op - flushed >= kFlush) flush_to(op & ~255u);
+          if (op - flushed >= kFlush) flush_to(op & ~kFA);
           LZ4_PROF(3);
           if (!nonsimple) continue;
         }
@@ -520,7 +560,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           const uint32_t n = rem < 64u ? rem : 64u;
           if (lane < n) ring[(op + lane) & (kRing - 1)] = stage[(lp + lane) & (kStage - 1)];
           lp += n; op += n; rem -= n;
-          if (op - flushed >= kFlush) flush_to(op & ~255u);
+          if (op - flushed >= kFlush) flush_to(op & ~kFA);
         }
         if (!last) {
           if (defer) {                                                   // match fields parsed now: the literals are out of the staging buffer
@@ -544,7 +584,18 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
               const uint32_t s = op - offset + j;
               if (lane < n) { const uint8_t v = ring[s & (kRing - 1)]; ring[(op + lane) & (kRing - 1)] = v; }
               op += n; done += n;
-              if (op - flushed >= kFlush) flush_to(op & ~255u);
+              if (op - flushed >= kFlush) flush_to(op & ~kFA);
+            }
+          } else if (SCAN) {
+            // far match, SCAN form: the bytes must pass the ring (and the predicate) like all others, so they come back from HBM 64 at a
+            // time (the source lies more than kRing - 64 bytes back: always flushed, never inside the step)
+            uint32_t done = 0, fenced = 0xffffffffu;
+            while (done < ml) {
+              const uint32_t n = ml - done < 64u ? ml - done : 64u;
+              if (fenced != flushed) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = flushed; }
+              if (lane < n) { const uint8_t v = __builtin_nontemporal_load(out + op - offset + lane); ring[(op + lane) & (kRing - 1)] = v; }
+              op += n; done += n;
+              if (op - flushed >= kFlush) flush_to(op & ~kFA);
             }
           } else {                                                       // far match: through HBM, v1 style
             flush_to(op);
@@ -561,11 +612,15 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
           }
         }
       }
-      if (op - flushed >= kFlush) flush_to(op & ~255u);
+      if (op - flushed >= kFlush) flush_to(op & ~kFA);
       if (last) break;
     }
     if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
     if (!err) flush_to(op);
+    if (SCAN && !err && (sc_words & 15u) != 0u) {                 // the column's last, shorter block: a partial tile
+      if (lane < (sc_words & 15u)) sc.bitmap[sc_word0 + (sc_words & ~15u) + lane] = sc_myword;
+      if (lane == 0u) sc.counts[(sc_word0 + sc_words) >> 4] = sc_tile_count;
+    }
 #ifdef DFDB_LZ4_PROF
     if (b == 0 && lane == 0) { pf_acc[15] = __builtin_readcyclecounter() - pf_start; for (int k = 0; k < 32; k++) g_lz4_prof[k] = pf_acc[k]; }
 #endif
@@ -581,7 +636,13 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status);
+  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+}
+// decode + `value OP c` over an 8-byte column in one pass: dst receives the decoded column, sc.bitmap / sc.counts what K1 would write
+void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc) {
+  if (nblocks <= 0) return;
+  int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
+  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -341,6 +341,21 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   for (size_t bi = 0; bi < term_batches.size(); bi++) {
     const ScanTerms& tb = term_batches[bi];
     const int ex = bi + 1 == term_batches.size() ? extra : 0;
+    // decode -> scan fusion: a fresh-mask scan of ONE simple term over an 8-byte column that holds its LZ4 blocks in HBM
+    // (ctx option keep_compressed at load time) decodes the blocks and evaluates the term in the same pass (K7 SCAN): what the reference's loop
+    // body does per block (read_block! then apply the selection, blocksiterator.jl:98-121).  ctx option "decode_on_scan" = 1 asks for it;
+    // the decoded column is (re)written on the way, so everything after this launch sees an ordinary resident column.
+    if (tb.n == 1 && ex == 0 && !have && first_stage && bi == 0 && ctx_option(ctx, "decode_on_scan", 0) != 0) {
+      Column& fc = t->cols[(size_t)term_ords[0]];
+      const int fdt = tb.t[0].dtype;
+      if (fc.comp_nblocks > 0 && !dt_nullable(fc.dtype) && (fdt == DFDB_I64 || fdt == DFDB_U64 || fdt == DFDB_F64) && t->block_size % kTileRows == 0) {
+        LaunchTimer lt(ctx, "lz4_decode_scan");
+        launch_lz4_decode_scan(s, fc.comp.as<uint8_t>(), fc.data.as<uint8_t>(), fc.comp_blocks.as<Lz4Block>(), (int32_t)fc.comp_nblocks, fc.comp_status.as<int32_t>(),
+                               LzScan{q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), tb.t[0].cbits, fdt, tb.t[0].op});
+        have = true;
+        continue;
+      }
+    }
     if (tb.n == 1 && ex < 2) {
       LaunchTimer lt(ctx, "scan_cmp");
       set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));

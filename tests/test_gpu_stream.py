@@ -202,3 +202,55 @@ def test_stream_outlives_its_source_handles(oracle, dfdb_mod, ctx, tmp_path):
     N.check(L.dfdb_stream_close(s))
     want = (np.nonzero(a % 3 == 0)[0] + 1)[4:9000:2]
     assert total == len(want) and np.array_equal(np.concatenate(rows), want)
+
+
+def test_decode_fused_with_the_first_predicate(oracle, dfdb_mod, ctx, tmp_path):
+    """SURVEY.md §8f-2, decode -> scan fusion: a column that keeps its LZ4 blocks in HBM (ctx option keep_compressed) is decoded AND filtered by
+    one kernel (K7 SCAN, ctx option decode_on_scan) — bitmap, tile counts, indices and the (re)decoded column must equal the oracle's for
+    every comparison, Int64 / UInt64 / Float64 (NaN included), rows that are no multiple of 64 or 1024, data with far and long matches."""
+    from dfdb import ir
+    rng = np.random.default_rng(23)
+    n = 200_003
+    far = np.concatenate([rng.integers(-2**62, 2**62, 3000), np.zeros(10, np.int64)] * (n // 3010 + 1))[:n].astype(np.int64)
+    far[6000:9000] = far[0:3000]                                   # a 24-KB repeat at distance 48 KB: the long far match path
+    f = oracle.gen_f64(0x1234, 0, n)
+    f[::977] = np.nan
+    cols = {"a": oracle.gen_i64(0x9E37, 0, n), "u": rng.integers(0, 2**64 - 1, n, dtype=np.uint64), "f": f, "far": far,
+            "z": np.zeros(n, np.int64), "i32": rng.integers(-5, 5, n).astype(np.int32)}
+    for bs in (65536, 4096, 1000):
+        ot = oracle.Table(block_size=bs)
+        for k, v in cols.items():
+            ot.add_column(k, v)
+        path = str(tmp_path / f"t{bs}")
+        ot.save(path)
+        ctx.set_option("keep_compressed", 1)
+        try:
+            tb = dfdb_mod.open_table(path)
+        finally:
+            ctx.set_option("keep_compressed", 0)
+        ctx.set_option("decode_on_scan", 1)
+        ctx.profile(True)
+        try:
+            preds = [ir.col(0) > 899_999, ir.col(0) <= 5, ir.col(0) == 77, ir.col(1) >= 2**63, ir.col(1) != 12345, ir.col(2) < 632.456, ir.col(2) != 1.0,
+                     ir.col(2) >= 1999.0, ir.col(3) == 0, ir.col(3) < 0, ir.col(4) == 0, ir.col(4) > 0, ir.col(5) > 2]
+            for e in preds:
+                ov = ot.view().add_predicate(e.to_ir())
+                dv = dfdb_mod.selection(tb.view(), e)
+                q = dv._query()
+                assert q.count() == ov.nrow(), (bs, e)
+                assert np.array_equal(q.indices(), ov.select_indices()), (bs, e)
+                assert np.array_equal(q.bitmap(), ov.select_bitmap(n)), (bs, e)
+                got, want = q.materialize(), ov.materialize()
+                for g, w in zip(got, want):
+                    assert np.array_equal(g.view(np.uint8), w.view(np.uint8)), (bs, e)
+                # a second stage after the fused one
+                ov2 = ot.view().add_predicate(e.to_ir()).add_range(3, 2, 5000)
+                dv2 = dfdb_mod.selection(dfdb_mod.selection(tb.view(), e), dfdb_mod.jr(3, 2, 5000))
+                assert np.array_equal(dv2._query().indices(), ov2.select_indices()), (bs, e)
+            launches, _ = ctx.profile_get("lz4_decode_scan")
+            # fused for the 8-byte columns when blocks start on 1024-row tiles; block size 1000 and the Int32 column take the ordinary kernels
+            assert launches == (0 if bs == 1000 else 2 * 12), (bs, launches)
+        finally:
+            ctx.profile(False)
+            ctx.set_option("decode_on_scan", 0)
+        tb.close()
