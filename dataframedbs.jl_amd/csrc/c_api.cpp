@@ -307,6 +307,12 @@ int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { re
 // ------------------------------------------------------------------ execution
 int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQ(q); query_execute(q, -1); }); }
 int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQ(q); query_unique(q, proj_col); }); }
+int32_t dfdb_query_groupreduce(dfdb_query* q, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes) {
+  return guard([&] { NEEDQ(q); query_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); });
+}
+int32_t dfdb_query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f) {
+  return guard([&] { NEEDQ(q); query_groupreduce_fetch(q, keys, counts, values_i, values_f); });
+}
 int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
   return guard([&] { NEEDQ(q); q->hint_agg_op = op; q->hint_agg_proj = proj_col; });   // (affects the NEXT execution only: an executed query keeps its results)
 }

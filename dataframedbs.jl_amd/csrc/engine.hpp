@@ -93,6 +93,9 @@ struct dfdb_query {
   int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
   bool stream_owned = false;   // a chunk query handed out by dfdb_stream_next: owned by the stream
+  // dfdb_query_groupreduce: the full selection set aside, per-group counts / values, what the fetch needs
+  dfdb::DevBuf gr_sel, gr_cnt, gr_val;
+  int64_t gr_n = 0; int gr_key = -1, gr_op = 0, gr_kind = 0, gr_state = 0;   // state 0: none, 1: empty result, 2: results + narrowed selection pending
   int mask_from = -1;          // table ordinal of the column whose calibrated bitmap this query has borrowed (-1: its own)
   int64_t bitmap_rows = -1;    // rows the bitmap was sized (and zero-padded) for
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
@@ -119,6 +122,8 @@ int64_t query_string_bytes(dfdb_query* q, int i);
 void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 void query_unique(dfdb_query* q, int32_t p);
+void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, int64_t* ngroups, int64_t* key_bytes);
+void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f);
 void query_return_mask(dfdb_query* q);            // give a borrowed calibrated bitmap back to its column
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread

@@ -192,4 +192,174 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
   else hipLaunchKernelGGL((k_unique_str<2>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, ntiles, keys, rows, rep_off, rep_len, mask, special, salt, collision);
 }
 
+// ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
+// The reference's groupreduce numbers the groups in order of first appearance of the key (group_map[elem] = length(group_map) + 1) and stops
+// there (it is unfinished: it prints the map).  Completed to that intent on top of unique's table: after the unique passes the table maps a
+// key to the row of its first occurrence and the bitmap holds exactly those rows, so a group's number is the RANK of its first row among them
+// (k_group_ids turns the table's row slots into group numbers, once per group); k_group_accumulate then sends every selected row's value to its
+// group's accumulator — privatised in LDS per workgroup when there are few groups (ten brands over 5e8 rows would otherwise be 5e8 atomics on ten
+// addresses), global atomics otherwise.  Accumulators are 64-bit: counts, wrapping integer sums (Julia's), double sums, and min / max through an
+// order-preserving image (a NaN wins both, like Julia's minimum / maximum).
+constexpr int kGroupLds = 1024;                      // groups that fit the per-workgroup accumulators
+
+__device__ __forceinline__ uint64_t rank_of_row(const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix, uint64_t row) {
+  const uint64_t tile = row >> 10, w = (row & 1023) >> 6;
+  uint64_t r = uprefix[tile];
+  for (uint64_t k = 0; k < w; k++) r += (uint64_t)__popcll(ubits[tile * 16 + k]);
+  return r + (uint64_t)__popcll(ubits[tile * 16 + w] & ((1ull << (row & 63)) - 1ull));
+}
+__global__ __launch_bounds__(kBlock) void k_group_ids(const uint64_t* __restrict__ keys, uint64_t* __restrict__ rows, uint64_t cap, uint64_t* __restrict__ special,
+                                                      const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < cap && keys[i] != kEmpty) rows[i] = rank_of_row(ubits, uprefix, rows[i]);
+  if (i < 2 && special[i] != kEmpty) special[i] = rank_of_row(ubits, uprefix, special[i]);
+}
+
+// the value of row `row` as the accumulator sees it: 0 = int64 (wrapping sum / signed order), 1 = uint64, 2 = double
+__device__ __forceinline__ uint64_t value_bits(const void* col, int dtype, int64_t row, int& kind) {
+  switch (dtype) {
+    case DFDB_I8:  kind = 0; return (uint64_t)(int64_t)((const int8_t*)col)[row];
+    case DFDB_I16: kind = 0; return (uint64_t)(int64_t)((const int16_t*)col)[row];
+    case DFDB_I32: kind = 0; return (uint64_t)(int64_t)((const int32_t*)col)[row];
+    case DFDB_I64: kind = 0; return ((const uint64_t*)col)[row];
+    case DFDB_U8: case DFDB_BOOL: kind = 1; return ((const uint8_t*)col)[row];
+    case DFDB_U16: kind = 1; return ((const uint16_t*)col)[row];
+    case DFDB_U32: kind = 1; return ((const uint32_t*)col)[row];
+    case DFDB_U64: kind = 1; return ((const uint64_t*)col)[row];
+    case DFDB_F32: { kind = 2; const double d = (double)((const float*)col)[row]; return (uint64_t)__double_as_longlong(d); }
+    default:       { kind = 2; return ((const uint64_t*)col)[row]; }
+  }
+}
+// order-preserving 64-bit image for min / max (unsigned compare); a NaN maps to the end that wins the reduction
+__device__ __forceinline__ uint64_t order_image(uint64_t bits, int kind, int op) {
+  if (kind == 1) return bits;
+  if (kind == 0) return bits ^ (1ull << 63);
+  const double d = __longlong_as_double((long long)bits);
+  if (d != d) return op == DFDB_AGG_MIN ? 0ull : ~0ull;
+  return (bits >> 63) ? ~bits : (bits | (1ull << 63));
+}
+__device__ __forceinline__ void group_add(uint64_t* cnt, uint64_t* val, uint64_t gid, uint64_t bits, int kind, int op, bool has_val) {
+  atomicAdd((unsigned long long*)&cnt[gid], 1ull);
+  if (!has_val) return;
+  if (op == DFDB_AGG_SUM) { if (kind == 2) atomicAdd((double*)&val[gid], __longlong_as_double((long long)bits)); else atomicAdd((unsigned long long*)&val[gid], (unsigned long long)bits); }
+  else if (op == DFDB_AGG_MIN) atomicMin((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, op));
+  else if (op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, op));
+}
+// merge a workgroup's LDS accumulators into the global ones (val_kind: 2 = double sums)
+__device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t* lval, uint64_t* cnt, uint64_t* val, int ngroups, int op, int val_kind, bool has_val) {
+  for (int g = threadIdx.x; g < ngroups; g += kBlock) {
+    const uint64_t c = lcnt[g];
+    if (!c) continue;
+    atomicAdd((unsigned long long*)&cnt[g], (unsigned long long)c);
+    if (!has_val) continue;
+    if (op == DFDB_AGG_SUM) { if (val_kind == 2) atomicAdd((double*)&val[g], __longlong_as_double((long long)lval[g])); else atomicAdd((unsigned long long*)&val[g], (unsigned long long)lval[g]); }
+    else if (op == DFDB_AGG_MIN) atomicMin((unsigned long long*)&val[g], (unsigned long long)lval[g]);
+    else if (op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&val[g], (unsigned long long)lval[g]);
+  }
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
+                                                             const void* __restrict__ valcol, int valdt, int op, int64_t nrows,
+                                                             const uint64_t* __restrict__ keys, const uint64_t* __restrict__ gids, uint64_t mask,
+                                                             const uint64_t* __restrict__ special, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
+  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
+  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
+  int val_kind = 0;
+  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
+    uint64_t gid;
+    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) gid = special[1];
+    else { const uint64_t key = key_fixed(keycol, keydt, row); gid = key == kEmpty ? special[0] : gids[table_find(keys, mask, key)]; }
+    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
+    val_kind = kind;
+    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
+  }
+  if (LDS) {
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);      // (the value kind is a property of the column)
+    (void)val_kind;
+    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
+  }
+}
+
+// String keys: one wave per 1024-row tile (byte offsets are a wave prefix sum of the sizes, as in k_unique_str)
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_group_accumulate_str(const uint64_t* __restrict__ sel, const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
+                                                                 const uint8_t* __restrict__ bytes, const void* __restrict__ valcol, int valdt, int op, int64_t nrows, int64_t ntiles,
+                                                                 const uint64_t* __restrict__ keys, const uint64_t* __restrict__ gids, uint64_t mask,
+                                                                 const uint64_t* __restrict__ special, uint64_t salt, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
+  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
+  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
+  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const uint64_t mine = lane < 16 ? sel[tile * 16 + lane] : 0ull;
+    if (__ballot(mine != 0) == 0) continue;
+    int64_t run = tile_off[tile];
+    for (int j = 0; j < 16; j++) {
+      const int64_t row = tile * kTile + j * 64 + lane;
+      const int32_t sz = row < nrows ? sizes[row] : 0;
+      const uint32_t c = sz > 0 ? (uint32_t)sz : 0u;
+      const uint32_t incl = wave_incl_scan(c);
+      const int64_t off = run + (int64_t)(incl - c);
+      run += (int64_t)__shfl(incl, 63, 64);
+      const uint64_t w = __shfl(mine, j, 64);
+      if (row < nrows && ((w >> lane) & 1ull)) {
+        uint64_t gid;
+        if (sz < 0) gid = special[1];
+        else { uint64_t key = hash_bytes(bytes + off, sz, salt); if (key == kEmpty) key = 0x1234567ull; gid = gids[table_find(keys, mask, key)]; }
+        int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
+        if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
+      }
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
+    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
+  }
+}
+
+void launch_group_ids(hipStream_t s, const uint64_t* keys, uint64_t* rows, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
+  hipLaunchKernelGGL(k_group_ids, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, rows, cap, special, ubits, uprefix);
+}
+int group_lds_limit() { return kGroupLds; }
+void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+                             int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
+                             int64_t ngroups, uint64_t val_init) {
+  if (nrows <= 0) return;
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, keys, gids, mask, special, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, keys, gids, mask, special, cnt, val, (int)ngroups, val_init);
+}
+void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
+                                 int op, int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t salt,
+                                 uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
+  if (nrows <= 0) return;
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  const int g = grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles);
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_str<true>), dim3(g), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, keys, gids, mask, special, salt, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate_str<false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, keys, gids, mask, special, salt, cnt, val, (int)ngroups, val_init);
+}
+// accumulators -> results: min / max images back to values (in place)
+__global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng || (op != DFDB_AGG_MIN && op != DFDB_AGG_MAX)) return;
+  const uint64_t im = val[g];
+  uint64_t bits;
+  if (kind == 1) bits = im;
+  else if (kind == 0) bits = im ^ (1ull << 63);
+  else if (im == 0ull || im == ~0ull) bits = 0x7ff8000000000000ull;                      // the NaN images
+  else bits = (im >> 63) ? (im & ~(1ull << 63)) : ~im;
+  val[g] = bits;
+}
+void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int op) {
+  if (ng <= 0) return;
+  hipLaunchKernelGGL(k_group_finish, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, val, ng, kind, op);
+}
+
 }  // namespace dfdb

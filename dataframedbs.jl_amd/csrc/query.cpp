@@ -619,7 +619,8 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
 // unique(col) (column.jl:102-126 driving Base.unique; docs/src/index.md:171-182,479-486): the current selection is narrowed to
 // the rows that hold the FIRST occurrence of their value in projection column p (isequal semantics), so count / materialize
 // afterwards return the distinct values in order of first appearance.  A later reset / execute restores the full selection.
-void query_unique(dfdb_query* q, int32_t p) {
+struct UniqueTables { DevBuf keys, rows, aux, rep_off, rep_len; uint64_t cap = 0, salt = 0; bool is_str = false; };
+static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   ensure_executed(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
@@ -635,7 +636,9 @@ void query_unique(dfdb_query* q, int32_t p) {
   if (is_str) { rep_off.ensure(cap * 8); rep_len.ensure(cap * 4); }
   uint64_t* special = aux.as<uint64_t>(); int* collision = (int*)(aux.as<uint8_t>() + 32);
   LaunchTimer lt(ctx, "unique");
+  uint64_t used_salt = 0;
   for (uint64_t salt = 0x51ED270B27B4F3CFull, tries = 0;; salt = splitmix64_host(salt), tries++) {
+    used_salt = salt;
     HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, cap * 8, s));
     HIP_CHECK(hipMemsetAsync(rows.p, 0xFF, cap * 8, s));
     HIP_CHECK(hipMemsetAsync(aux.p, 0xFF, 16, s));
@@ -659,8 +662,102 @@ void query_unique(dfdb_query* q, int32_t p) {
   }
   scan_prefix(q);
   q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
-  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
+  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here (or move to the caller: groupreduce looks rows up in them)
+  if (keep) { keep->keys = std::move(keys); keep->rows = std::move(rows); keep->aux = std::move(aux); keep->rep_off = std::move(rep_off); keep->rep_len = std::move(rep_len);
+              keep->cap = cap; keep->salt = used_salt; keep->is_str = is_str; }
 }
+void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
+
+// groupreduce(view, (:key,); out = :val => Stat()) (src/tables/aggregate.jl:1-36; unfinished in the reference: it numbers the groups in order of
+// first appearance of the key and prints the map).  Completed to that intent: one group per distinct key (isequal), groups in order of first
+// appearance, count and one reduced value per group.  Device side: unique's table + k_group_ids + k_group_accumulate (k_unique.hip).
+void launch_group_ids(hipStream_t s, const uint64_t* keys, uint64_t* rows, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix);
+void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+                             int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
+                             int64_t ngroups, uint64_t val_init);
+void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
+                                 int op, int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t salt,
+                                 uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
+void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int op);
+
+void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, int64_t* ngroups, int64_t* key_bytes) {
+  ensure_executed(q);
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (key_p < 0 || (size_t)key_p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", key_p);
+  const Node& ke = *q->proj[(size_t)key_p].expr;
+  if (ke.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "groupreduce by a computed column: materialise it as a column first (dfdb_table_add_from_query)");
+  if (op != DFDB_AGG_COUNT && op != DFDB_AGG_SUM && op != DFDB_AGG_MIN && op != DFDB_AGG_MAX) fail(DFDB_ERR_ARGUMENT, "unknown statistic %d", op);
+  const Column* vc = nullptr;
+  if (op != DFDB_AGG_COUNT) {
+    if (val_p < 0 || (size_t)val_p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", val_p);
+    const Node& ve = *q->proj[(size_t)val_p].expr;
+    if (ve.op != DFIR_COL || !dt_isnum(ve.dtype) || dt_nullable(ve.dtype)) fail(DFDB_ERR_UNSUPPORTED, "groupreduce over %s: a plain numeric column is needed", dt_name(ve.dtype).c_str());
+    vc = &need_resident(t, ve.col);
+  }
+  const Column& kc = need_resident(t, ke.col);
+  q->gr_n = 0; q->gr_key = key_p; q->gr_op = op; q->gr_kind = 0;
+  if (vc) { const int b = dt_base(vc->dtype); q->gr_kind = dt_isfloat(b) ? 2 : (dt_issigned(b) ? 0 : 1); }
+  if (ngroups) *ngroups = 0;
+  if (key_bytes) *key_bytes = 0;
+  if (query_count(q, -1) == 0 || t->nrows == 0) { q->gr_state = 1; return; }
+  // the full selection is kept aside: unique narrows q's bitmap to the first occurrences (= the groups, in order)
+  const size_t nw = padded_words(t->nrows);
+  q->gr_sel.ensure(nw * 8);
+  HIP_CHECK(hipMemcpyAsync(q->gr_sel.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
+  UniqueTables T;
+  unique_impl(q, key_p, &T);
+  const int64_t ng = query_count(q, -1);
+  uint64_t* special = T.aux.as<uint64_t>();
+  launch_group_ids(s, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap, special, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>());
+  q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
+  const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
+  HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
+  HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+  { LaunchTimer lt(ctx, "group_accumulate");
+    if (T.is_str)
+      launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
+                                  vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap - 1, special, T.salt,
+                                  q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
+    else
+      launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr, vc ? vc->data.p : nullptr,
+                              vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap - 1, special,
+                              q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
+  launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
+  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
+  q->gr_n = ng; q->gr_state = 2;
+  if (ngroups) *ngroups = ng;
+  if (key_bytes && dt_base(kc.dtype) == DFDB_STRING) *key_bytes = query_string_bytes(q, key_p);
+}
+
+// the groups' keys (gathered over the first occurrences, i.e. in order of first appearance), counts and values -> caller buffers (host);
+// restores the query's full selection afterwards
+void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (q->gr_state == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_query_groupreduce has not been called");
+  const int64_t ng = q->gr_n;
+  if (ng > 0) {
+    if (keys) { keys->memkind = keys->memkind == DFDB_MEM_DEVICE ? DFDB_MEM_DEVICE : DFDB_MEM_HOST; materialize_col(q, q->gr_key, *keys, ng); }
+    std::vector<uint64_t> c((size_t)ng), v((size_t)ng);
+    HIP_CHECK(hipMemcpyAsync(c.data(), q->gr_cnt.p, (size_t)ng * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(v.data(), q->gr_val.p, (size_t)ng * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t g = 0; g < ng; g++) {
+      if (counts) counts[g] = (int64_t)c[(size_t)g];
+      const uint64_t b = v[(size_t)g];
+      double d; memcpy(&d, &b, 8);
+      if (q->gr_kind == 2) { if (vals_f) vals_f[g] = d; if (vals_i) vals_i[g] = (int64_t)d; }
+      else { if (vals_i) vals_i[g] = (int64_t)b; if (vals_f) vals_f[g] = q->gr_kind == 1 ? (double)b : (double)(int64_t)b; }
+    }
+  } else if (keys) { keys->count = 0; keys->nbytes = 0; }
+  if (q->gr_state == 2) {                                  // back to the full selection: bitmap + tile counts + prefix
+    launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
+    scan_prefix(q);
+    q->count = -1;
+  }
+  q->gr_state = 0;
+}
+
+
 
 // the device half of an aggregate: leaves {value, selected count} (16 bytes) of sum / min / max over projection column i in
 // q->red_result on the engine stream and returns the accumulator dtype (DFDB_I64 / DFDB_U64 / DFDB_F64).  No host wait: the group

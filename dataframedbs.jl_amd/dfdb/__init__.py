@@ -7,7 +7,7 @@ expression IR.  Importing the package does not need a GPU; creating a Context do
 from . import ir
 from ._native import (AGG_COUNT, AGG_MAX, AGG_MIN, AGG_SUM, GEN_F64_U2000, GEN_I64_IOTA, GEN_I64_MOD1M, GEN_STR_BRANDS10,
                       LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS, DfdbError, load)
-from .api import (ALL, END, ColumnMeta, Context, DFColumn, DFTable, DFView, JRange, Projection, SelectionQueue, coalesce, col_equal,
+from .api import (ALL, END, groupreduce, ColumnMeta, Context, DFColumn, DFTable, DFView, JRange, Projection, SelectionQueue, coalesce, col_equal,
                   create_table, default_context, endswith, float64, head, isin, ismissing, issameselection, jr, map_to_column, materialize,
                   materialize_streamed, ncol, nrow, nrow_streamed, open_table, projection, selection, selproj, set_string_output, size, sizeof, startswith, stream, table_stats, view_from_columns)
 from .ir import div, maximum, minimum, mod, rem

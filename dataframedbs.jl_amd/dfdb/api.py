@@ -1198,3 +1198,53 @@ def create_table(path: str, from_=None, block_size: int = 65536, ctx: Optional[C
 def map_to_column(f: Callable, v: Union[DFView, DFTable]) -> DFColumn:   # view.jl:160-164
     v = v if isinstance(v, DFView) else DFView(v)
     return v[ALL, (tuple(v.names()), f)]
+
+
+# ---------------------------------------------------------------- groupreduce (aggregate.jl:1-36, completed to its evident intent)
+_STATS = {"count": N.AGG_COUNT, "sum": N.AGG_SUM, "min": N.AGG_MIN, "minimum": N.AGG_MIN, "max": N.AGG_MAX, "maximum": N.AGG_MAX, "mean": N.AGG_SUM}
+
+
+def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, stat: str = "count"):
+    """groupreduce(view, (:by,); out = :col => Stat()): one row per distinct value of `by` over the view's selected rows, in order of first
+    appearance (the reference's group_map numbering), with the group's row count and stat(col) — stat in count / sum / min / max / mean.
+    Returns a pandas.DataFrame with columns [by, "count", stat]."""
+    import pandas as pd
+    v = v if isinstance(v, DFView) else DFView(v)
+    if stat not in _STATS:
+        raise ValueError(f"ArgumentError: unknown statistic {stat}")
+    names = [by] if col is None or stat == "count" else [by, col]
+    sub = v[ALL, names] if len(names) > 1 else DFView(v.table, Projection({by: v.projection.cols[by]}), v.selection)
+    q = _Query(sub)
+    L = N.load()
+    ng, kb = C.c_int64(), C.c_int64()
+    N.check(L.dfdb_query_groupreduce(q._h, 0, 1 if len(names) > 1 else -1, _STATS[stat], C.byref(ng), C.byref(kb)))
+    n = ng.value
+    kdt = q.coltype(0)
+    out = N.OutCol()
+    out.memkind = N.MEM_HOST
+    if (kdt & ir.DTYPE_MASK) == ir.STRING:
+        ksz = np.empty(max(n, 1), np.int32); kby = np.empty(max(kb.value, 1), np.uint8)
+        out.data, out.bytes, out.bytes_cap = ksz.ctypes.data, kby.ctypes.data, kb.value
+    else:
+        karr = np.empty(max(n, 1), ir.numpy_of_dtype(kdt))
+        kmiss = np.zeros(max(n, 1), np.uint8) if kdt & ir.NULLABLE else None
+        out.data = karr.ctypes.data
+        if kmiss is not None:
+            out.missing = kmiss.ctypes.data
+    counts = np.zeros(max(n, 1), np.int64); vi = np.zeros(max(n, 1), np.int64); vf = np.zeros(max(n, 1), np.float64)
+    N.check(L.dfdb_query_groupreduce_fetch(q._h, C.byref(out), counts.ctypes.data, vi.ctypes.data, vf.ctypes.data))
+    if (kdt & ir.DTYPE_MASK) == ir.STRING:
+        keys = _to_user((ksz[:n].copy(), kby[:out.nbytes].copy()))
+    elif kdt & ir.NULLABLE:
+        keys = np.ma.masked_array(karr[:n].copy(), mask=kmiss[:n].astype(bool))
+    else:
+        keys = karr[:n].copy()
+    res = {by: keys, "count": counts[:n].copy()}
+    if stat != "count":
+        vdt = q.coltype(1) & ir.DTYPE_MASK
+        isf = vdt in (ir.F32, ir.F64)
+        vals = vf[:n].copy() if isf else (vi[:n].astype(np.uint64) if vdt in (ir.U8, ir.U16, ir.U32, ir.U64) and stat != "mean" else vi[:n].copy())
+        if stat == "mean":
+            vals = (vf[:n] if isf else (vi[:n].astype(np.uint64).astype(np.float64) if vdt in (ir.U8, ir.U16, ir.U32, ir.U64) else vi[:n].astype(np.float64))) / np.maximum(counts[:n], 1)
+        res[stat] = vals
+    return pd.DataFrame(res)

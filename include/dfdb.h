@@ -244,6 +244,17 @@ int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col);
  * full selection. */
 int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col);
 
+/* groupreduce(view, (:key,); out = :val => Stat()) (src/tables/aggregate.jl:1-36, exported by the reference but unfinished there: it numbers the
+ * groups in order of first appearance of the key — group_map[elem] = length(group_map) + 1 — and stops).  Completed to that intent: one group per
+ * distinct value of projection column key_col (a plain column; isequal, missing is a group), groups in order of FIRST APPEARANCE, per group the
+ * row count and stat(val_col) with stat = DFDB_AGG_COUNT / _SUM / _MIN / _MAX over a plain numeric column (Mean() = sum / count; integer sums wrap
+ * like Julia's, Float64 sums are atomic adds in no fixed order: tolerance of DESIGN.md section 5; minimum / maximum propagate NaN).
+ * Call 1 evaluates on the device and returns the number of groups (and the key column's string bytes); call 2 copies keys (a dfdb_outcol sized
+ * for ngroups rows), counts and values (values_i for integer columns, values_f for floats; either may be NULL) to the caller and puts the query's
+ * full selection back (between the two calls the selection is narrowed to the first occurrences, as after dfdb_query_unique). */
+int32_t dfdb_query_groupreduce(dfdb_query* q, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes);
+int32_t dfdb_query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f);
+
 /* forget the cached execution so the next count/indices/materialize re-evaluates the selection (a new
  * BlocksIterator in the reference: blocksiterator.jl:20-44). */
 int32_t dfdb_query_reset(dfdb_query* q);

@@ -783,3 +783,72 @@ def test_unique_columns(oracle, dfdb_mod, ctx, tmp_path):
     t.save(path)
     tb = dfdb_mod.open_table(path, load=False)
     assert list(tb.s.unique()) == julia_unique(strs) and tb.a.unique().tolist() == julia_unique(cols["a"].tolist())
+
+
+# ------------------------------------------------------------------ groupreduce (aggregate.jl:1-36, completed to its intent)
+def _np_group_ids(keys):
+    """numpy restatement of the reference's numbering: group_map[elem] = length(group_map) + 1 on first appearance (aggregate.jl:21-28)"""
+    order, gid, seen = [], np.empty(len(keys), np.int64), {}
+    for i, k in enumerate(keys):
+        kk = "missing" if k is None or k is np.ma.masked else (("nan",) if isinstance(k, float) and k != k else k)
+        if kk not in seen:
+            seen[kk] = len(seen); order.append(k)
+        gid[i] = seen[kk]
+    return order, gid
+
+
+def _np_groupreduce(ids, vals, stat):
+    order, gid = ids
+    ng = len(order)
+    cnt = np.bincount(gid, minlength=ng)
+    if stat == "count":
+        return order, cnt, None
+    if stat in ("sum", "mean"):
+        acc = np.zeros(ng, np.float64 if vals.dtype.kind == "f" else np.int64)
+        np.add.at(acc, gid, vals.astype(acc.dtype))
+        return order, cnt, acc if stat == "sum" else acc.astype(np.float64) / np.maximum(cnt, 1)
+    acc = np.full(ng, vals.max() if stat == "min" else vals.min(), vals.dtype)
+    (np.minimum if stat == "min" else np.maximum).at(acc, gid, vals)
+    return order, cnt, acc
+
+
+@pytest.mark.parametrize("n", [0, 1, 5000, 300_000])
+def test_groupreduce_matches_first_appearance_numbering(oracle, dfdb_mod, ctx, n):
+    """test/aggregate.jl:20 calls groupreduce(tb[:, :], (:a,), c = :c => Mean()); the reference's function stops after numbering the groups.
+    Here: groups in order of first appearance, count + sum / min / max / mean per group, Int64 and String keys (few groups: LDS accumulators;
+    many groups: global atomics), a nullable key (missing is a group), over a filtered view; the selection is intact afterwards."""
+    rng = np.random.default_rng(31 + n)
+    a = rng.integers(0, 7, n).astype(np.int64) * 1000 - 3000
+    many = rng.integers(0, max(n // 3, 1), n).astype(np.int64)
+    c = rng.integers(-1000, 1000, n).astype(np.int64)
+    x = rng.normal(size=n) * 100
+    u8 = rng.integers(0, 255, n).astype(np.uint8)
+    words = ["apple", "sony", "dell", "", "microsoft", "né"]
+    s = [words[i] for i in rng.integers(0, len(words), n)]
+    m = np.ma.masked_array(rng.integers(0, 4, n).astype(np.int64), mask=rng.random(n) < 0.3)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "many": many, "c": c, "x": x, "u8": u8, "s": s, "m": m}, block_size=4096)
+    sel = c > -500
+    v = t[t.c > -500, dfdb_mod.ALL]
+    for by, keys in (("a", a), ("many", many), ("s", np.array(s, dtype=object)), ("m", m)):
+        ids = _np_group_ids([keys[i] for i in np.nonzero(sel)[0]])
+        for col, vals, stats in (("c", c, ("count", "sum", "min", "max", "mean")), ("x", x, ("sum", "min", "max", "mean")), ("u8", u8, ("sum", "max"))):
+            for stat in stats:
+                got = dfdb_mod.groupreduce(v, by, col, stat)
+                order, cnt, want = _np_groupreduce(ids, vals[sel], stat)
+                assert len(got) == len(order), (by, col, stat)
+                import pandas as pd
+                gk = [None if (not isinstance(k, str) and pd.isna(k)) else (k if isinstance(k, str) else int(k)) for k in got[by].tolist()]
+                wk = [None if (k is np.ma.masked or k is None) else (k if isinstance(k, str) else int(k)) for k in order]
+                assert gk == wk, (by, col, stat)
+                assert got["count"].tolist() == cnt.tolist(), (by, col, stat)
+                if stat != "count" and len(order):
+                    g = got[stat].to_numpy()
+                    if col == "x" and stat in ("sum", "mean"):
+                        assert np.allclose(g, want, rtol=1e-9, atol=1e-6), (by, col, stat)      # atomic double adds: no fixed order
+                    elif stat == "mean":
+                        assert np.allclose(g, want, rtol=1e-12), (by, col, stat)
+                    else:
+                        assert np.array_equal(g.astype(np.float64) if col == "x" else g.astype(np.int64), want.astype(np.float64) if col == "x" else want.astype(np.int64)), (by, col, stat)
+    assert dfdb_mod.nrow(v) == int(sel.sum())            # the view's own query is untouched
+    with pytest.raises(NotImplementedError):
+        dfdb_mod.groupreduce(t[dfdb_mod.ALL, dfdb_mod.ALL], "a", "s", "sum")     # a String is no value column
