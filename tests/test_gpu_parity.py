@@ -803,6 +803,8 @@ def _np_groupreduce(ids, vals, stat):
     cnt = np.bincount(gid, minlength=ng)
     if stat == "count":
         return order, cnt, None
+    if ng == 0:
+        return order, cnt, np.zeros(0)
     if stat in ("sum", "mean"):
         acc = np.zeros(ng, np.float64 if vals.dtype.kind == "f" else np.int64)
         np.add.at(acc, gid, vals.astype(acc.dtype))
