@@ -401,6 +401,38 @@ gpu_maximum(c::DFColumn) = gpu_aggregate(c, 3)[1]
 gpu_mean(c::DFColumn) = ((s, n) = gpu_aggregate(c, 1); s / n)
 gpu_sum_count(c::DFColumn) = gpu_aggregate(c, 1)
 
+"""
+groupreduce(view, (:by,); out = :col => Stat()) on the device (src/tables/aggregate.jl:1-36: exported by the reference, unfinished there — it numbers the
+groups in order of first appearance and stops).  Returns a DataFrame with one row per distinct value of `by` in order of first appearance, the group's
+row count and `stat(col)`, stat in (:count, :sum, :minimum, :maximum, :mean).  GPU 0 (the hash table of `unique` is not sharded).
+"""
+function gpu_groupreduce(v::DFView, by::Symbol, col::Union{Symbol,Nothing} = nothing, stat::Symbol = :count)
+    code = Dict(:count => 0, :sum => 1, :minimum => 2, :maximum => 3, :mean => 1)[stat]
+    two = col !== nothing && stat != :count
+    sub = two ? v[:, [by, col]] : v[:, [by]]
+    with_query(sub) do q
+        ng = Ref{Int64}(0); kb = Ref{Int64}(0)
+        check(ccall((:dfdb_query_groupreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int64}, Ptr{Int64}), q, 0, two ? 1 : -1, code, ng, kb))
+        n = ng[]
+        keyview = sub[:, [by]]
+        outs, bufs = alloc_outputs(keyview, n, i -> begin
+            dt = Ref{Int32}(0)
+            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, 0, dt)); dt[]
+        end, i -> kb[])
+        counts = Vector{Int64}(undef, n); vi = Vector{Int64}(undef, n); vf = Vector{Float64}(undef, n)
+        GC.@preserve bufs outs counts vi vf check(ccall((:dfdb_query_groupreduce_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), q, outs, counts, vi, vf))
+        keys = finish_columns(keyview, bufs)[1]
+        res = DataFrames.DataFrame(by => keys, :count => counts)
+        if two
+            T = Base.nonmissingtype(DataFrameDBs.coltype(sub.projection, 2))
+            vals = stat == :mean ? (T <: AbstractFloat ? vf : (T <: Unsigned ? Float64.(reinterpret(UInt64, vi)) : Float64.(vi))) ./ max.(counts, 1) :
+                   T <: AbstractFloat ? vf : (T <: Unsigned ? reinterpret(UInt64, vi) : vi)
+            res[!, stat] = vals
+        end
+        res
+    end
+end
+
 # ---------------------------------------------------------------- write side (create_table / add_column!)
 struct SizeStatsC; rows::Int64; compressed::Int64; uncompressed::Int64; end
 
