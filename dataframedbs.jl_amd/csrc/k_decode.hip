@@ -68,39 +68,57 @@ __device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int o
   }
 }
 
-template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN>
-__global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+// PIPE = 1: TWO waves per block.  Wave 0 parses (candidates, walk, dense records: everything up to the records and the start bitmap of a
+// superbatch), wave 1 produces (far prefetch, byte production, flush) one superbatch behind, out of double-buffered records in LDS.  A block's
+// latency becomes max(parse, produce) instead of their sum — what matters when there are fewer blocks than wave slots (a streamed chunk, a small
+// table: at 1 526 blocks the chip is a quarter full and a block takes as long as it takes).  Sequences only the one-sequence path handles are
+// executed by wave 0 once wave 1 has drained; ownership of the ring and of the output position passes through LDS control words.
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE>
+__global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
                                                                LzScan sc) {
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
-  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[WAVES][kStage + kRing + kFarMax * 24];
-  __shared__ uint32_t fard_sh[WAVES][kFarMax];
+  static_assert(!PIPE || (WAVES == 2 && !SCAN), "the two-wave pipeline is its own configuration");
+  constexpr int NW = PIPE ? 1 : WAVES;           // sets of LDS arrays per workgroup
+  constexpr int NS = PIPE ? 2 : 1;               // record slots (PIPE: one being parsed into, one being produced from)
+  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[NW][kStage + kRing + kFarMax * 24];
+  __shared__ uint32_t fard_sh[NW][NS][kFarMax];
+  __shared__ uint32_t ctl_sh[PIPE ? 16 : 1];     // PIPE control words (below)
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
-  __shared__ uint32_t bits_sh[WAVES][kBatchBytes / 32 + 2];   // + two words that stay zero
-  __shared__ uint2 bitsx_sh[WAVES][kBatchBytes / 32 + 8];     // {start-bit word, starts before it - 1}; the tail stays {0, -1}
-  __shared__ uint2 info_sh[WAVES][kSeqMax + 1];               // entry 0 is a dummy: production's ordinal -1 (a row past the last byte) reads it
+  __shared__ uint32_t bits_sh[NW][kBatchBytes / 32 + 2];   // + two words that stay zero
+  __shared__ uint2 bitsx_sh[NW][NS][kBatchBytes / 32 + 8];     // {start-bit word, starts before it - 1}; the tail stays {0, -1}
+  __shared__ uint2 info_sh[NW][NS][kSeqMax + 1];               // entry 0 is a dummy: production's ordinal -1 (a row past the last byte) reads it
   const uint32_t lane = (uint32_t)lane_id();
   // (one wave per workgroup in the shipped configuration: every LDS array then sits at a compile-time address that folds into the ds instructions' offset field)
-  const int wib = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wib = (WAVES == 1 || PIPE) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int role = PIPE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // PIPE: 0 parses, 1 produces
   uint8_t* lds = lds_sh[wib];
   uint8_t* stage = lds;
   uint8_t* ring = lds + kStage;
   uint32_t* bits = bits_sh[wib];
-  uint2* bitsx = bitsx_sh[wib];
-  if (lane < 8) bitsx[kBatchBytes / 32 + lane] = make_uint2(0u, 0xffffffffu);
+  uint2* bitsx = bitsx_sh[wib][0];
+  if (lane < 8 && role == 0) { for (int sl = 0; sl < NS; sl++) bitsx_sh[wib][sl][kBatchBytes / 32 + lane] = make_uint2(0u, 0xffffffffu); }
   const uint32_t lane_below = (2u << (lane & 31u)) - 1u;         // bits 0 .. lane mod 32
-  uint2* info = info_sh[wib] + 1;
-  uint32_t* fard = fard_sh[wib];
-  if (lane < 2) bits[kBatchBytes / 32 + lane] = 0;
+  uint2* info = info_sh[wib][0] + 1;
+  uint32_t* fard = fard_sh[wib][0];
+  auto use_slot = [&](int sl) { bitsx = bitsx_sh[wib][sl]; info = info_sh[wib][sl] + 1; fard = fard_sh[wib][sl]; };
+  if (lane < 2 && role == 0) bits[kBatchBytes / 32 + lane] = 0;
+  // PIPE control words.  PUB: superbatches published by the parser; CONS: consumed by the producer; HT / HNF [slot]: output bytes and far sources of
+  // the superbatch in that slot; H_OP / H_FL: the output position and the flushed position, written by whoever owned the ring last; HAND: bumped by
+  // the parser after it used the ring itself; END: nothing more will be published; ERR: either wave gave up (a bounded spin ran out)
+  enum { C_PUB = 0, C_CONS = 1, C_HT = 2, C_HNF = 4, C_OP = 6, C_FL = 7, C_HAND = 8, C_END = 9, C_ERR = 10 };
+  volatile uint32_t* ctl = ctl_sh;
+  constexpr uint32_t kSpinLimit = 1u << 24;
+  const int64_t wgid = PIPE ? (int64_t)blockIdx.x : 0;
   // the ring must keep every byte that is not in HBM yet: flush this often (a v5 superbatch adds up to kBatchBytes on top)
   constexpr uint32_t kFlush = kRing >= 4096 ? 1024u : 512u;
   static_assert(kStage == kRing, "production addresses staging buffer, ring and far bytes as ((j + B) & (kStage - 1)) | O");
   constexpr uint32_t kFA = SCAN ? 511u : 255u;                    // flushes end on multiples of kFA + 1 bytes (SCAN: whole 64-row mask words)
   static_assert((kFlush + kFA + 1 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
-  const int64_t wave = (int64_t)blockIdx.x * WAVES + wib;
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  const int64_t wave = PIPE ? wgid : (int64_t)blockIdx.x * WAVES + wib;
+  const int64_t nwaves = PIPE ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES;
   constexpr int kChunk = kStage / 2;            // two chunks staged, a third in flight
   constexpr int kNF = kChunk / 512;             // 8-byte words per lane of the chunk in flight
   static_assert(kChunk >= 1024 && kChunk % 512 == 0, "the 512-byte register window plus one sequence's look-ahead must fit behind ip");
@@ -136,7 +154,8 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
     };
     // make input bytes [p, p + 72) parseable: advance the staging buffer and refresh the register window as needed
     auto advance = [&](uint32_t p) {
-      while (p >= cb + kChunk) {                   // p left the first staged chunk: recycle its slot for the chunk in flight
+      // (PIPE: the producer still reads the PREVIOUS superbatch's literals out of the staging buffer, so 1 KB behind p stays staged)
+      while (p >= cb + kChunk + (PIPE ? 1024u : 0u)) {   // p left the first staged chunk: recycle its slot for the chunk in flight
         chunk_store(cb + kStage);                  // (waits for those loads: issued a whole chunk ago)
         cb += kChunk;
         chunk_load(cb + kStage);
@@ -197,6 +216,105 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
       flushed = upto;
     };
 
+    // far prefetch + byte production + flush of ONE superbatch out of the current record slot (info / bitsx / fard): T output bytes, nfar far sources
+    auto produce = [&](uint32_t T, uint32_t nfar) {
+          LZ4_COUNT(6, 1); LZ4_COUNT(7, (T + 63) / 64); LZ4_COUNT(10, nfar);
+      if (nfar) {
+        // far sources were flushed before this superbatch began (they lie > kRing - 64 - kBatchBytes behind op and at most
+        // kFlush + 256 bytes are ever unflushed): 24 bytes each, HBM/L2 -> LDS, ONE memory round trip for the whole superbatch
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane < nfar) {
+          const uint32_t so = fard[lane];
+          uint64_t* d = (uint64_t*)(lds + kStage + kRing + lane * 24u);
+          if (so + 24u <= out_len) {
+            const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
+            d[0] = a; d[1] = b2; d[2] = c2;
+          } else {
+            uint8_t* db = (uint8_t*)d;
+            for (uint32_t k = 0; k < 24u && so + k < out_len; k++) db[k] = out[so + k];
+          }
+        }
+        wave_lds_fence();
+        LZ4_PROF(5);
+      }
+      // ---- phase 5
+      constexpr int U = 4;                                             // rows per trip
+      for (uint32_t c = 0; c < T; c += 64u * U) {
+        uint32_t ORD[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint2 e = bitsx[(c >> 5) + 2u * (uint32_t)u + (lane >> 5)];          // (a row past T reads the {0, -1} tail)
+          ORD[u] = e.y + (uint32_t)__builtin_popcount(e.x & lane_below);
+        }
+        uint2 INF[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) INF[u] = info[(int32_t)ORD[u]];                   // (rows past T: ordinal -1 or the last sequence's: any record, the byte is never written)
+        LZ4_PROF(16);
+        uint32_t R[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t j = c + 64u * (uint32_t)u + lane;
+          const uint2 inf = INF[u];
+          const uint32_t litend = inf.x & 0xffffu, lbo = inf.x >> 16, mbo = inf.y & 0xffffu, off7 = inf.y >> 16;
+          const bool is_lit = j < litend;
+          const uint32_t x = is_lit ? lbo : mbo;
+          const uint32_t addr = ((j + x) & (uint32_t)(kStage - 1)) | (x & ~(uint32_t)(kStage - 1));
+          const bool inrow = !is_lit && off7 <= lane;                  // the source byte is made by a lower lane of this very row
+          R[u] = inrow ? lane - off7 : (0x80000000u | addr);           // (pointers only ever go down: lane 0 is always a root, rows past T included)
+        }
+        LZ4_PROF(17);
+        for (;;) {                                                     // pointer doubling: R[j] = R[R[j]] (always a lower lane)
+          uint32_t unres = 0;                                          // bit 31 set: some row of this lane still holds a pointer
+#pragma unroll
+          for (int u = 0; u < U; u++) unres |= ~R[u];
+          if (__ballot((unres >> 31) != 0u) == 0) break;
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((R[u] & 63u) << 2), (int)R[u]);
+            if ((R[u] >> 31) == 0u) R[u] = t;
+          }
+          LZ4_COUNT(8, 1);
+        }
+        LZ4_PROF(18);
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                  // in row order: a later row may copy bytes an earlier row of this trip wrote
+          const uint32_t j = c + 64u * (uint32_t)u + lane;
+          const uint8_t v = lds[R[u] & 0xffffu];
+          if (j < T) ring[(op + j) & (kRing - 1)] = v;
+        }
+      }
+      LZ4_PROF(19);
+      op += T;
+      LZ4_PROF(2);
+      if (op - flushed >= kFlush) flush_to(op & ~kFA);
+      LZ4_PROF(3);
+    };
+    uint32_t npub = 0; int pslot = 0; bool owned = !PIPE;   // PIPE parser: superbatches published, the slot being parsed into, whether it owns the ring right now
+    if (PIPE) {
+      use_slot(0);
+      if (role == 0 && lane == 0) { for (int c = 0; c < 16; c++) ctl[c] = 0; }
+      __syncthreads();
+      if (role == 1) {
+        // ---- the producer: superbatch after superbatch as the parser publishes them
+        uint32_t done = 0, hand = 0;
+        for (;;) {
+          uint32_t spins = 0, pub;
+          while ((pub = ctl[C_PUB]) <= done && !ctl[C_END]) { __builtin_amdgcn_s_sleep(2); if (++spins > kSpinLimit || ctl[C_ERR]) { ctl[C_ERR] = 1; break; } }
+          if (ctl[C_ERR]) break;
+          if (pub <= done) { if (ctl[C_PUB] <= done) break; else continue; }       // END and nothing left
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (ctl[C_HAND] != hand) { hand = ctl[C_HAND]; op = ctl[C_OP]; flushed = ctl[C_FL]; }
+          const int sl = (int)(done & 1u);
+          use_slot(sl);
+          produce(ctl[C_HT + sl], ctl[C_HNF + sl]);
+          ctl[C_OP] = op; ctl[C_FL] = flushed;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          done++; ctl[C_CONS] = done;
+        }
+        __syncthreads();
+        continue;                                    // next block
+      }
+    }
     // prime the staging buffer: chunks 0 and 1 in LDS, chunk 2 in flight
     chunk_load(0); chunk_store(0);
     chunk_load(kChunk); chunk_store(kChunk);
@@ -204,6 +322,12 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
     window_load(0);
 
     while (ip < in_len) {                          // every quantity that steers control flow is wave-uniform
+      if (PIPE && owned) {                           // the parser used the ring itself (one-sequence path): give it back, with the positions
+        ctl[C_OP] = op; ctl[C_FL] = flushed;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ctl[C_HAND] = ctl[C_HAND] + 1u;
+        owned = false;
+      }
       {
         // ---- a SUPERBATCH of W 64-byte windows of input, in five phases that each expose their parallelism to the hardware.  What shaped
         // them (cycle probes in tools/bench_lz4, rocprofv3 instruction counters): one wave retires this code at ~10 cycles per instruction,
@@ -426,26 +550,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
         if (T) {
           if (__ballot(bad) != 0 || T > out_len - op) { err = 5; break; }
           wave_lds_fence();
-          LZ4_COUNT(6, 1); LZ4_COUNT(7, (T + 63) / 64); LZ4_COUNT(9, nseq); LZ4_COUNT(10, nfar);
-          if (nfar) {
-            // far sources were flushed before this superbatch began (they lie > kRing - 64 - kBatchBytes behind op and at most
-            // kFlush + 256 bytes are ever unflushed): 24 bytes each, HBM/L2 -> LDS, ONE memory round trip for the whole superbatch
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lane < nfar) {
-              const uint32_t so = fard[lane];
-              uint64_t* d = (uint64_t*)(lds + kStage + kRing + lane * 24u);
-              if (so + 24u <= out_len) {
-                const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
-                d[0] = a; d[1] = b2; d[2] = c2;
-              } else {
-                uint8_t* db = (uint8_t*)d;
-                for (uint32_t k = 0; k < 24u && so + k < out_len; k++) db[k] = out[so + k];
-              }
-            }
-            wave_lds_fence();
-            LZ4_PROF(5);
-          }
-          // ---- phase 5
+          LZ4_COUNT(9, nseq);
           // rank of an output position among the start bits = its sequence's ordinal.  Kept in the vector domain (a v_readlane of the bitmap
           // followed by scalar popcounts cost a VALU -> SGPR round trip of ~50 cycles per row): word and exclusive prefix sit side by side in LDS
           {
@@ -455,58 +560,33 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
             if (lane < 32u) bitsx[lane] = make_uint2(w, incl - cw - 1u);
           }
           wave_lds_fence();
-          constexpr int U = 4;                                             // rows per trip
-          for (uint32_t c = 0; c < T; c += 64u * U) {
-            uint32_t ORD[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-              const uint2 e = bitsx[(c >> 5) + 2u * (uint32_t)u + (lane >> 5)];          // (a row past T reads the {0, -1} tail)
-              ORD[u] = e.y + (uint32_t)__builtin_popcount(e.x & lane_below);
-            }
-            uint2 INF[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) INF[u] = info[(int32_t)ORD[u]];                   // (rows past T: ordinal -1 or the last sequence's: any record, the byte is never written)
-            LZ4_PROF(16);
-            uint32_t R[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-              const uint32_t j = c + 64u * (uint32_t)u + lane;
-              const uint2 inf = INF[u];
-              const uint32_t litend = inf.x & 0xffffu, lbo = inf.x >> 16, mbo = inf.y & 0xffffu, off7 = inf.y >> 16;
-              const bool is_lit = j < litend;
-              const uint32_t x = is_lit ? lbo : mbo;
-              const uint32_t addr = ((j + x) & (uint32_t)(kStage - 1)) | (x & ~(uint32_t)(kStage - 1));
-              const bool inrow = !is_lit && off7 <= lane;                  // the source byte is made by a lower lane of this very row
-              R[u] = inrow ? lane - off7 : (0x80000000u | addr);           // (pointers only ever go down: lane 0 is always a root, rows past T included)
-            }
-            LZ4_PROF(17);
-            for (;;) {                                                     // pointer doubling: R[j] = R[R[j]] (always a lower lane)
-              uint32_t unres = 0;                                          // bit 31 set: some row of this lane still holds a pointer
-#pragma unroll
-              for (int u = 0; u < U; u++) unres |= ~R[u];
-              if (__ballot((unres >> 31) != 0u) == 0) break;
-#pragma unroll
-              for (int u = 0; u < U; u++) {
-                const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((R[u] & 63u) << 2), (int)R[u]);
-                if ((R[u] >> 31) == 0u) R[u] = t;
-              }
-              LZ4_COUNT(8, 1);
-            }
-            LZ4_PROF(18);
-#pragma unroll
-            for (int u = 0; u < U; u++) {                                  // in row order: a later row may copy bytes an earlier row of this trip wrote
-              const uint32_t j = c + 64u * (uint32_t)u + lane;
-              const uint8_t v = lds[R[u] & 0xffffu];
-              if (j < T) ring[(op + j) & (kRing - 1)] = v;
-            }
+          if (PIPE) {
+            // hand the superbatch to the producer and go on parsing; the slot after next is free once the producer has consumed the one before
+            ctl[C_HT + pslot] = T; ctl[C_HNF + pslot] = nfar;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            npub++; ctl[C_PUB] = npub;
+            op += T; ip += consumed;
+            pslot ^= 1; use_slot(pslot);
+            { uint32_t spins = 0; while (npub >= 2u && ctl[C_CONS] + 1u < npub) { __builtin_amdgcn_s_sleep(2); if (++spins > kSpinLimit || ctl[C_ERR]) { err = 7; break; } } }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (err) break;
+            if (!nonsimple) continue;
+          } else {
+            produce(T, nfar);
+            ip += consumed;
+            if (!nonsimple) continue;
           }
-          LZ4_PROF(19);
-          op += T; ip += consumed;
-          LZ4_PROF(2);
-          if (op - flushed >= kFlush) flush_to(op & ~kFA);
-          LZ4_PROF(3);
-          if (!nonsimple) continue;
         }
+      }
+      if (PIPE) {
+        // a sequence only the one-sequence path takes: wait until the producer has drained, take the ring over
+        uint32_t spins = 0;
+        while (ctl[C_CONS] != npub) { __builtin_amdgcn_s_sleep(2); if (++spins > kSpinLimit || ctl[C_ERR]) { err = 7; break; } }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (err) break;
+        flushed = ctl[C_FL];
+        if (ctl[C_OP] != op) { err = 8; break; }
+        owned = true;
       }
       ensure(ip);
       const uint64_t t64 = fetch64(ip);
@@ -615,6 +695,16 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
       if (op - flushed >= kFlush) flush_to(op & ~kFA);
       if (last) break;
     }
+    if (PIPE) {
+      if (!owned && !err) {                       // take the ring back for the epilogue
+        uint32_t spins = 0;
+        while (ctl[C_CONS] != npub) { __builtin_amdgcn_s_sleep(2); if (++spins > kSpinLimit || ctl[C_ERR]) { err = 7; break; } }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!err) { flushed = ctl[C_FL]; if (ctl[C_OP] != op) err = 8; }
+      }
+      if (err) ctl[C_ERR] = 1;
+      ctl[C_END] = 1;                              // the producer leaves its loop
+    }
     if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
     if (!err) flush_to(op);
     if (SCAN && !err && (sc_words & 15u) != 0u) {                 // the column's last, shorter block: a partial tile
@@ -626,23 +716,32 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_lz4_decode(const uint8_t* __r
 #endif
     if (lane == 0) status[b] = err;
     wave_lds_fence();
+    if (PIPE) __syncthreads();                    // (the producer waits here too: the next block reuses every LDS array)
+    (void)owned; (void)npub; (void)pslot;
   }
 }
 
 // Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format): see DESIGN.md §4 K7.
 // (The four earlier decoders — plain global round trips, LDS staging, register-window parser, one-window batches: 26-54 GB/s — were
 // dropped from the library in round 2; git history and DESIGN.md §10 keep what they taught.)
+static int g_lz4_pipe = -1;          // -1: by block count, 0: one wave per block, 1: two-wave pipeline (ctx option "lz4_pipeline", tools/bench_lz4)
+void set_lz4_pipe(int v) { g_lz4_pipe = v; }
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+  // fewer blocks than the chip has wave slots (20 one-wave workgroups per CU x 256 CUs): the two-wave pipeline halves what matters then, a block's latency
+  // (measured crossover on one MI355X: 2048 blocks 301 vs 252 GB/s for the pipeline, 3072 blocks 275 vs 326 against it: its 13.8 KB of LDS hold 11 blocks per CU)
+  if (g_lz4_pipe == 1 || (g_lz4_pipe < 0 && nblocks <= 2560))
+    hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+  else
+    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
 }
 // decode + `value OP c` over an 8-byte column in one pass: dst receives the decoded column, sc.bitmap / sc.counts what K1 would write
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc) {
   if (nblocks <= 0) return;
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
+  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 1, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -113,6 +113,7 @@ struct Lz4Block {      // one (column, block) unit of work
   int64_t dst_off;     // where the decoded body goes inside the body arena
 };
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status);
+void set_lz4_pipe(int v);   // -1 (default): two waves per block when there are fewer blocks than wave slots, 0: never, 1: always
 // K7 fused with the first predicate of a scan (decode -> scan fusion): 8-byte columns whose blocks start on 1024-row tiles
 struct LzScan { uint64_t* bitmap; uint32_t* counts; uint64_t cbits; int32_t dtype; int32_t op; };
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc);

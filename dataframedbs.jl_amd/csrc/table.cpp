@@ -272,6 +272,7 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     dstatus.ensure(4 * (size_t)nb);
     HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)nb, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4 * (size_t)nb, s));
+    set_lz4_pipe((int)ctx_option(ctx, "lz4_pipeline", -1));
     { LaunchTimer lt(ctx, "lz4_decode"); launch_lz4_decode(s, staged.as<uint8_t>(), decode_dst, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>()); }
     std::vector<int32_t> st((size_t)nb);
     HIP_CHECK(hipMemcpyAsync(st.data(), dstatus.p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
