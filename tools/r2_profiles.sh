@@ -14,8 +14,9 @@ done
 python3 $R/bench.py --gpus 2 --all-on-device0 --backend gloo --rows 200000000 --steps 5 --warmup 1 --no-cpu > $O/bench_2ranks_gloo_device0.json 2>/dev/null
 python3 $R/bench.py --exchange lib --steps 10 --warmup 2 --no-cpu --no-decode-leg > $O/bench_exchange_lib.json 2>/dev/null
 # 5. LZ4 harness + instruction counters per sequence
-( for n in 15259 1526; do $R/tools/bench_lz4_noprof $n 0; done; for m in 1 2 5 6 3 4; do $R/tools/bench_lz4_noprof 8192 $m; done; $R/tools/bench_lz4 1526 0 ) > $O/lz4_harness.txt 2>&1
+( for n in 15259 1526; do $R/tools/bench_lz4_noprof $n 0; done; for pm in 0 1; do echo pipe=$pm; $R/tools/bench_lz4_noprof 1526 0 $pm; $R/tools/bench_lz4_noprof 15259 0 $pm; done; for m in 1 2 5 6 3 4; do $R/tools/bench_lz4_noprof 8192 $m; done; $R/tools/bench_lz4 1526 0 ) > $O/lz4_harness.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_lz4 -o k7 -- $R/tools/bench_lz4_noprof 1526 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_lz4_1w -o k7 -- $R/tools/bench_lz4_noprof 15259 0 > /dev/null 2>&1
 # 6. configs 2-4, interpreter, LZ4 through the engine, under per-kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg -o c -- python3 $R/tools/bench_configs.py --reps 3 --lz4-rows 100000000 > $O/configs_bench.jsonl 2> $O/configs_bench.err
 python3 $R/tools/bench_config5.py > $O/config5_one_gpu.json 2> $O/config5.err
