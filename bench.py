@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
     ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
+    ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
+    ap.add_argument("--placement-candidates", type=int, default=None, help="A/B: candidate bitmaps the calibration tries (ctx option placement_candidates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
@@ -238,6 +240,7 @@ def main():
             uid = bytes(store.get("dfdb_group_uid"))
         grp = G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream)
         ctx = grp.ctx(0)
+        ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
         nblocks_per = -(-(-(-(rows * world) // 65536)) // world)        # ceil(ceil(total / 65536) / world): the library's block-range rule
         gt = G.GroupTable.new(grp)
         gt.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows * world)   # every rank generates its own block range
@@ -248,8 +251,12 @@ def main():
         assert local_rows <= nblocks_per * 65536
     else:
         ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
-        if args.no_placement:
-            ctx.set_option("placement_calibrate", 0)
+        # the resident column is scanned by every step: the engine's opt-in bitmap placement calibration pays here (its one-time cost is reported below)
+        ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
+        if args.placement_spacer_mb is not None:
+            ctx.set_option("placement_spacer_mb", args.placement_spacer_mb)
+        if args.placement_candidates is not None:
+            ctx.set_option("placement_candidates", args.placement_candidates)
         t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
         t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
         t.set_row_base(rank * rows)
@@ -260,6 +267,7 @@ def main():
     # placement calibration happened inside that first execution (query.cpp: place_mask): what it saw
     pl_n, pl_best = ctx.profile_get("placement_best_us")
     _, pl_worst = ctx.profile_get("placement_worst_us")
+    _, pl_wall = ctx.profile_get("placement_wall_us")
     cap = nsel
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
 
@@ -337,7 +345,7 @@ def main():
                                     ("libdfdb_hip's RCCL communicator (dfdb_group_count)" if lib else f"torch.distributed {args.backend}")) if world > 1 else "single GPU",
                        "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
                        "device": info["name"], "global_selected": total_sel,
-                       "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows,
+                       "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows, "one_time_seconds": pl_wall / 1e6,
                                                   "what": "one-time: the scan timed against 9 bitmap allocations, the fastest kept (ctx option placement_calibrate)"}
                                                  if pl_n else "off")},
             "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,

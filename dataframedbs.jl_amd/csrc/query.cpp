@@ -12,6 +12,7 @@
 // dfdb_count reads the scan total, dfdb_materialize reuses the same bitmap.
 #include "engine.hpp"
 #include <algorithm>
+#include <chrono>
 
 namespace dfdb {
 
@@ -105,7 +106,9 @@ static void ensure_state(dfdb_query* q) {
 // physical placement, so the engine measures: the first time a column of >= 2^26 rows is the target of a fresh-mask scan, the scan is timed
 // against a few candidate bitmap allocations spread over free HBM (spacer allocations in between, released
 // afterwards) and the fastest stays with the column.  Queries that scan the column borrow it (one at a time; others use their own).
-// ctx option "placement_calibrate" = 0 turns it off.  One-time cost: 27 scans (~35 ms per 1e9-row column).
+// ctx option "placement_calibrate" = 1 asks for it (default 0).  One-time cost per column: 27 scans (~35 ms per 1e9 rows) plus allocating and releasing
+// the spacers, 0.03-1.4 s measured (profiles/r2_placement_cost.txt) — worth it for a column that stays resident and is scanned thousands of times, not
+// for a short session, which is why it is opt-in; stream slots never calibrate.  "placement_spacer_mb" / "placement_candidates" size the search.
 void query_return_mask(dfdb_query* q) {
   if (q->mask_from < 0 || !q->t) { q->mask_from = -1; return; }
   Column& c = q->t->cols[(size_t)q->mask_from];
@@ -116,7 +119,7 @@ template <class Launch>
 static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t* bitmap, int64_t rows) */) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int64_t nrows = t->nrows;
-  if (nrows < ((int64_t)1 << 26) || ctx_option(ctx, "placement_calibrate", 1) == 0) return;
+  if (nrows < ((int64_t)1 << 26) || ctx_option(ctx, "placement_calibrate", 0) == 0) return;
   if (q->mask_from == ordinal) return;
   query_return_mask(q);
   Column& c = t->cols[(size_t)ordinal];
@@ -125,8 +128,9 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     c.mask_calibrated = true;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
-    constexpr int kCand = 8;
-    const size_t spacer = std::min<size_t>((size_t)12 << 30, free_b / (4 * kCand));
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int kCand = (int)std::min<int64_t>(16, std::max<int64_t>(1, ctx_option(ctx, "placement_candidates", 8)));
+    const size_t spacer = std::min<size_t>((size_t)std::max<int64_t>(0, ctx_option(ctx, "placement_spacer_mb", 12288)) << 20, free_b / (4 * (size_t)kCand));
     if (free_b < (size_t)kCand * (bytes + spacer) + ((size_t)4 << 30)) return;      // not enough room to look around: keep the query's own
     std::vector<DevBuf> cand((size_t)kCand), space((size_t)kCand);
     try {
@@ -163,6 +167,9 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     }
     HIP_CHECK(hipStreamSynchronize(s));                 // candidates and spacers die here
     HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, bytes, s));
+    cand.clear(); space.clear();                        // (freed inside the timed span: releasing the spacers is most of the cost)
+    auto& pt = ctx->prof["placement_wall_us"]; pt.launches++;
+    pt.ms += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - wall0).count();
   }
   if (c.mask_pref.p && !c.mask_lent && c.mask_pref.bytes >= bytes) {
     std::swap(q->bitmap, c.mask_pref); c.mask_lent = true; q->mask_from = ordinal;

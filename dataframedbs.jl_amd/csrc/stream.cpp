@@ -243,6 +243,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
     if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context");
+    sl.ctx->options["placement_calibrate"] = 0;          // a slot's column lives for one chunk: nothing to calibrate for (and a 1024-block chunk is exactly 2^26 rows)
     auto tb = std::make_unique<dfdb_table>();            // the slot's chunk table: same columns, its own stream, reused buffers
     tb->ctx = sl.ctx; tb->path = t->path; tb->block_size = t->block_size; tb->format_version = t->format_version;
     tb->keep_load_scratch = true;
