@@ -96,6 +96,7 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
   return guard([&] {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    stream_drop_parked(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     profile_resolve(ctx);

@@ -97,6 +97,10 @@ struct dfdb_ctx {
   uint8_t* pin_ring[2] = {nullptr, nullptr};
   size_t pin_ring_cap = 0;
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  // a closed dfdb_stream parked for the next dfdb_stream_open on this context (slot contexts, pinned buffers, device buffers and loader
+  // threads are what opening and closing a stream costs: ~40 ms); `alive` lets a stream that outlives its context notice (stream.cpp)
+  void* parked_stream = nullptr;
+  std::shared_ptr<int> alive = std::make_shared<int>(0);
 };
 
 namespace dfdb {

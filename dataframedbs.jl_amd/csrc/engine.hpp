@@ -65,6 +65,7 @@ struct dfdb_table {
   // the table is a stream slot that reloads a new block range every few milliseconds (hipMalloc/hipFree would dominate).
   dfdb::DevBuf ld_staged, ld_bodies, ld_blocks, ld_status, ld_aux;
   bool keep_load_scratch = false;
+  bool ld_prestaged = false;      // the caller has already queued the image's compressed byte range into ld_staged on this table's stream (stream.cpp)
 };
 
 struct dfdb_query {
@@ -131,6 +132,7 @@ bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t 
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
 void stream_close(dfdb_stream* s);
+void stream_drop_parked(dfdb_ctx* ctx);   // dfdb_ctx_destroy: the parked stream dies with its context
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp

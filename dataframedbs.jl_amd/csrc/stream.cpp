@@ -29,6 +29,7 @@
 #include <chrono>
 
 namespace dfdb {
+static double dbg_ms() { static const auto e = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e).count(); }
 
 void required_columns(const Node& n, std::vector<int>& out);
 
@@ -95,6 +96,7 @@ struct dfdb_stream {
   std::deque<int> requests;        // slots waiting for a loader
   bool quit = false;
   bool slot_done[kSlots] = {};
+  dfdb_ctx* parent = nullptr; std::weak_ptr<int> parent_alive;   // where a closed stream parks (if that context still exists)
 };
 
 namespace dfdb {
@@ -120,18 +122,32 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
         HIP_CHECK(hipHostMalloc((void**)&sl->pin, need + need / 4, hipHostMallocDefault));
         sl->pin_cap = need + need / 4;
       }
-      // the column header (re-validated by the loader), then the blocks
+      // the column header (re-validated by the loader), then the blocks: read in 32-MB pieces (concurrent preads), each piece on its way to
+      // HBM while the next is read — PCIe and the page-cache copy overlap inside the chunk, not only across the loaders (which fall into
+      // lockstep: all reading, then all copying)
       const auto t0 = std::chrono::steady_clock::now();
-      if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off) || !read_file_range(c.file, sl->pin + c.data_off, lo, hi))
-        fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
+      DevBuf& staged = tb->ld_staged;
+      staged.ensure(need - comp_lo + 64);
+      constexpr size_t kPiece = (size_t)32 << 20;
+      for (size_t a = c.data_off; a < need; a += kPiece) {
+        const size_t b = std::min(need, a + kPiece);
+        if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+        const size_t ca = std::max(a, comp_lo);
+        if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
+      }
       const auto t1 = std::chrono::steady_clock::now();
       dfdb_sizestats st{0, 0, 0};
-      table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st);
+      tb->ld_prestaged = true;
+      try { table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st); } catch (...) { tb->ld_prestaged = false; throw; }
+      tb->ld_prestaged = false;
       if (getenv("DFDB_STREAM_DEBUG")) {
         const auto t2 = std::chrono::steady_clock::now();
         static const auto epoch = std::chrono::steady_clock::now();
+        (void)epoch;
         fprintf(stderr, "[stream] t=%.2f ms slot %d blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n",
-                std::chrono::duration<double, std::milli>(t0 - epoch).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
+                dbg_ms() - std::chrono::duration<double, std::milli>(t2 - t0).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
                 std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)(hi - lo) / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
       }
     }
@@ -200,11 +216,31 @@ bool prefetch(dfdb_stream* s, Slot* sl) {
 }  // namespace
 
 static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s);
+static void stream_destroy(dfdb_stream* s);
+// a parked stream becomes a fresh one: everything that described the previous query goes, what was expensive to make stays (slot contexts,
+// pinned buffers, the slots' tables with their device buffers — stream_open_impl moves those into the new tables —, loader threads)
+static void stream_rearm(dfdb_stream* s) {
+  s->stages.clear(); s->colsrc.clear(); s->required.clear(); s->index.clear(); s->base.clear();
+  s->chunk_blocks = s->nblocks = s->next_block = 0; s->cur = -1; s->done = false;
+  s->compressed = s->uncompressed = s->rows = 0;
+  s->requests.clear();
+  for (int i = 0; i < dfdb_stream::kSlots; i++) {
+    Slot& sl = s->slot[i];
+    s->slot_done[i] = false; sl.loading = false; sl.has_chunk = false; sl.err_code = 0; sl.err_msg.clear(); sl.b0 = sl.b1 = 0;
+    delete sl.q; sl.q = nullptr;
+  }
+}
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) {
+  if (getenv("DFDB_STREAM_DEBUG")) fprintf(stderr, "[stream] open begins at %.2f ms\n", dbg_ms());
   if (q->t->path.empty()) fail(DFDB_ERR_ARGUMENT, "streaming needs a table opened from files (dfdb_table_open)");
-  dfdb_stream* s = new dfdb_stream();
-  try { stream_open_impl(q, chunk_blocks, s); } catch (...) { stream_close(s); throw; }
+  dfdb_ctx* pc = q->t->ctx;
+  dfdb_stream* s = nullptr;
+  if (pc->parked_stream) { s = (dfdb_stream*)pc->parked_stream; pc->parked_stream = nullptr; stream_rearm(s); }
+  else s = new dfdb_stream();
+  s->parent = pc; s->parent_alive = pc->alive;
+  try { stream_open_impl(q, chunk_blocks, s); } catch (...) { stream_destroy(s); throw; }
   *out = s;
+  if (getenv("DFDB_STREAM_DEBUG")) fprintf(stderr, "[stream] open ends at %.2f ms\n", dbg_ms());
 }
 static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s) {
   dfdb_table* t = q->t;
@@ -242,7 +278,9 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   s->base.assign(q->stages.size(), 0);
   for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
-    if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context");
+    if (!sl.ctx) { if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context"); }
+    else sl.ctx->options = t->ctx->options;                // a re-armed slot: same device (same parent context), today's options
+    sl.ctx->options["keep_compressed"] = 0;               // (a slot's staging buffer is reused by the next chunk)
     sl.ctx->options["placement_calibrate"] = 0;          // a slot's column lives for one chunk: nothing to calibrate for (and a 1024-block chunk is exactly 2^26 rows)
     auto tb = std::make_unique<dfdb_table>();            // the slot's chunk table: same columns, its own stream, reused buffers
     tb->ctx = sl.ctx; tb->path = t->path; tb->block_size = t->block_size; tb->format_version = t->format_version;
@@ -258,9 +296,25 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     for (const ProjCol& p : q->proj) cq->proj.push_back(ProjCol{p.name, p.expr->clone()});
     cq->stream_owned = true;                              // dfdb_query_free refuses it: it dies with the stream
     tb->queries.push_back(cq.get());
+    if (sl.tbl) {                                         // re-armed: the previous tables' device buffers carry over (grown on demand by ensure())
+      dfdb_table* old = sl.tbl;
+      tb->ld_staged = std::move(old->ld_staged); tb->ld_bodies = std::move(old->ld_bodies); tb->ld_blocks = std::move(old->ld_blocks);
+      tb->ld_status = std::move(old->ld_status); tb->ld_aux = std::move(old->ld_aux);
+      // only the required columns ever held buffers: hand them to the new required columns in order
+      std::vector<Column*> had;
+      for (Column& oc : old->cols) if (oc.data.p || oc.bytes.p || oc.missing.p) had.push_back(&oc);
+      size_t h = 0;
+      for (int o : s->required) {
+        if (h >= had.size()) break;
+        Column& nc = tb->cols[(size_t)o]; Column& oc = *had[h++];
+        nc.data = std::move(oc.data); nc.bytes = std::move(oc.bytes); nc.missing = std::move(oc.missing); nc.tile_off = std::move(oc.tile_off);
+      }
+      old->queries.clear();
+      delete old;
+    }
     sl.tbl = tb.release(); sl.q = cq.release();
   }
-  for (auto& th : s->loader) th = std::thread(loader_main, s);
+  for (auto& th : s->loader) if (!th.joinable()) th = std::thread(loader_main, s);
   if (!prefetch(s, &s->slot[0])) s->done = true;
   else for (int i = 1; i + 1 < dfdb_stream::kSlots; i++) if (!prefetch(s, &s->slot[i])) break;
 }
@@ -304,8 +358,7 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
   return sl.q;
 }
 
-void stream_close(dfdb_stream* s) {
-  if (!s) return;
+static void stream_destroy(dfdb_stream* s) {
   for (Slot& sl : s->slot) if (sl.ctx) wait_loaded(s, sl);
   { std::lock_guard<std::mutex> lk(s->mu); s->quit = true; }
   s->cv.notify_all();
@@ -319,6 +372,27 @@ void stream_close(dfdb_stream* s) {
     if (sl.ctx) ctx_destroy(sl.ctx);
   }
   delete s;
+}
+void stream_close(dfdb_stream* s) {
+  if (!s) return;
+  const bool dbg = getenv("DFDB_STREAM_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[stream] close begins at %.2f ms\n", dbg_ms());
+  // park it on its context for the next dfdb_stream_open (ctx option "stream_cache" = 0: never), unless that context is gone or already holds one
+  bool park = false;
+  if (!s->parent_alive.expired() && s->parent && !s->parent->parked_stream && ctx_option(s->parent, "stream_cache", 1) != 0) {
+    park = true;
+    for (Slot& sl : s->slot) if (!sl.ctx || !sl.tbl) park = false;      // (an open that failed half-way)
+  }
+  if (park) {
+    for (Slot& sl : s->slot) release_slot(s, sl);         // loads in flight finish, the slots' streams drain
+    s->parent->parked_stream = s;
+  } else stream_destroy(s);
+  if (dbg) fprintf(stderr, "[stream] close ends at %.2f ms (%s)\n", dbg_ms(), park ? "parked" : "destroyed");
+}
+void stream_drop_parked(dfdb_ctx* ctx) {
+  if (!ctx->parked_stream) return;
+  dfdb_stream* s = (dfdb_stream*)ctx->parked_stream; ctx->parked_stream = nullptr;
+  stream_destroy(s);
 }
 
 // table_stats (src/tables/misc.jl:6-43): skip_block over one column file — block headers only, nothing is decoded

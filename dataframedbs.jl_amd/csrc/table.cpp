@@ -333,7 +333,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
   // stage the compressed byte range in HBM
   DevBuf& staged = t->ld_staged;
   staged.ensure((size_t)(comp_hi - comp_lo) + 64);
-  if (comp_hi > comp_lo) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
+  if (comp_hi > comp_lo && !t->ld_prestaged) HIP_CHECK(hipMemcpyAsync(staged.p, img + comp_lo, (size_t)(comp_hi - comp_lo), hipMemcpyHostToDevice, s));
   decode_staged(t, c, all.data() + block_first, nb, block_first, comp_lo, stats);
 }
 

@@ -254,3 +254,37 @@ def test_decode_fused_with_the_first_predicate(oracle, dfdb_mod, ctx, tmp_path):
             ctx.profile(False)
             ctx.set_option("decode_on_scan", 0)
         tb.close()
+
+
+def test_stream_parking_reuses_slots_across_tables_and_queries(oracle, dfdb_mod, tmp_path):
+    """A closed stream parks on its context and the next dfdb_stream_open re-arms it (slot contexts, pinned buffers, device buffers, loader
+    threads): results over a DIFFERENT table / query / chunk size must not see anything of the previous stream; stream_cache = 0 turns it off."""
+    dfdb = dfdb_mod
+    ctx = dfdb.default_context(0)
+    rng = np.random.default_rng(7)
+    a = rng.integers(-1000, 1000, 300_000).astype(np.int64)
+    x = rng.random(300_000)
+    sl = ["k%d" % (i % 17) for i in range(50_000)]
+    s = np.array(sl, dtype=object)
+    b = rng.integers(0, 50, 50_000).astype(np.int32)
+    p1 = Pair(oracle, dfdb, {"a": a, "x": x}, block_size=4096, via_files=str(tmp_path / "t1")); p1.d.close()
+    p2 = Pair(oracle, dfdb, {"s": sl, "b": b}, block_size=1000, via_files=str(tmp_path / "t2")); p2.d.close()
+    t1 = dfdb.open_table(str(tmp_path / "t1"), load=False)
+    t2 = dfdb.open_table(str(tmp_path / "t2"), load=False)
+    for rep in range(3):
+        v1 = t1[("a", lambda a: a > 100), dfdb.ALL]
+        assert dfdb.nrow_streamed(v1, 7 + rep) == int((a > 100).sum())
+        v2 = t2[t2.s == "k3", dfdb.ALL]
+        got = dfdb.materialize_streamed(v2, 3)
+        keep = s == "k3"
+        assert list(got["s"]) == list(s[keep]) and np.array_equal(got["b"], b[keep])
+        v3 = dfdb.selection(dfdb.DFView(t1), dfdb.jr(5, 1, 250_000))[("x", lambda x: x < 0.25), ("x", "a")]
+        got = dfdb.materialize_streamed(v3, 11)
+        keep = np.zeros(len(a), bool); keep[4:250_000] = True; keep &= x < 0.25
+        assert np.array_equal(got["a"], a[keep]) and np.array_equal(got["x"], x[keep])
+    ctx.set_option("stream_cache", 0)
+    try:
+        assert dfdb.nrow_streamed(t1[("a", lambda a: a > 100), dfdb.ALL], 5) == int((a > 100).sum())
+    finally:
+        ctx.set_option("stream_cache", 1)
+    t1.close(); t2.close()
