@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
     ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
+    ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores 0 plain, 1 nontemporal, 2 write-through (ctx option compact_store)")
     ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
     ap.add_argument("--placement-candidates", type=int, default=None, help="A/B: candidate bitmaps the calibration tries (ctx option placement_candidates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
@@ -253,6 +254,8 @@ def main():
         ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
         # the resident column is scanned by every step: the engine's opt-in bitmap placement calibration pays here (its one-time cost is reported below)
         ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
+        if args.compact_store is not None:
+            ctx.set_option("compact_store", args.compact_store)
         if args.placement_spacer_mb is not None:
             ctx.set_option("placement_spacer_mb", args.placement_spacer_mb)
         if args.placement_candidates is not None:

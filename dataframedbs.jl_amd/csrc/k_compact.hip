@@ -44,6 +44,12 @@ __device__ __forceinline__ uint32_t stage_positions(uint64_t w, uint16_t* pos, i
   return total;
 }
 
+// STORE: 0 plain, 1 nontemporal (default), 2 write-through.  K2 in isolation is fastest with plain stores (0.188 / 0.207 / 0.25 ms per 1e9 rows at 10 %),
+// but the last few hundred MB of plain-stored indices are still leaving L2 / MALL when the next scan starts: the K1 that follows runs 4-7 % slower and
+// varies from process to process (1.35-1.39 ms against a steady 1.285 after nontemporal stores; profiles/r2_k2_store_policy.txt).  The step is what counts.
+// (With a host synchronisation between steps the drain happens in the gap and plain stores are 0.01-0.02 ms ahead; K3's and the captured copies' output
+// stores measured the same either way and stay plain.)
+template <int STORE>
 __global__ __launch_bounds__(kBlock) void k_compact_indices(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
                                                             int64_t* __restrict__ out, int64_t nctiles, int64_t row_base, int64_t out_cap) {
   __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
@@ -66,17 +72,25 @@ __global__ __launch_bounds__(kBlock) void k_compact_indices(const uint64_t* __re
     const int64_t row1 = row_base + ct * kCTile + 1;   // 1-based table row of in-tile position 0
     for (uint32_t k = lane; k < total; k += 64) {
       const int64_t o = obase + k;
-      if (o < out_cap) out[o] = row1 + pos[k];
+      if (o < out_cap) {
+        if (STORE == 1) __builtin_nontemporal_store(row1 + pos[k], out + o);
+        else if (STORE == 2) __hip_atomic_store(out + o, row1 + pos[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else out[o] = row1 + pos[k];
+      }
     }
     wave_lds_fence();
   }
 }
 
+static int g_compact_store = 1;
+void set_compact_store(int v) { g_compact_store = v; }
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows, int64_t row_base,
                             int64_t out_cap) {
   const int64_t nct = (nrows + kCTile - 1) / kCTile;
   if (nct == 0) return;
-  hipLaunchKernelGGL(k_compact_indices, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  if (g_compact_store == 1) hipLaunchKernelGGL(k_compact_indices<1>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  else if (g_compact_store == 2) hipLaunchKernelGGL(k_compact_indices<2>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  else hipLaunchKernelGGL(k_compact_indices<0>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
 }
 
 template <typename T>

@@ -58,6 +58,7 @@ void launch_missing_mask(hipStream_t s, const uint64_t* missing, bool negate, bo
 void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
 
 // ---- K2: bitmap -> ascending 1-based row numbers -------------------------------------------------
+void set_compact_store(int v);   // index stores: 0 plain, 1 nontemporal (default), 2 write-through
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows,
                             int64_t row_base, int64_t out_cap);
 // ---- K3: projection gather of a fixed-width column (width 1,2,4,8 bytes) -------------------------

@@ -449,6 +449,7 @@ void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
 void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   ensure_executed(q);
+  set_compact_store((int)ctx_option(ctx, "compact_store", 1));
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");
       launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap); }

@@ -113,6 +113,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself against a few candidate bitmap allocations
  *                     and the column keeps the fastest for the queries that scan it (query.cpp: place_mask; default 0: 27 scans + 0.03-1.4 s of allocations once
  *                     per column buys ~3 % of K1 on average; bench.py turns it on); "placement_spacer_mb" (12288) / "placement_candidates" (8) size the search
+ *   "compact_store"   K2's index stores: 0 plain, 1 nontemporal (default: 10 % slower alone, but the scan that follows runs 4-7 % faster), 2 write-through
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
  *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)

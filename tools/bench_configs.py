@@ -59,8 +59,11 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lz4-rows", type=int, default=50_000_000)
+    ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores: 0 plain, 1 nontemporal (default), 2 write-through")
     args = ap.parse_args()
     ctx = dfdb.default_context(0)
+    if args.compact_store is not None:
+        ctx.set_option("compact_store", args.compact_store)
     info = ctx.device_info()
     print(json.dumps({"device": info}))
     import torch
