@@ -183,22 +183,29 @@ __device__ __forceinline__ bool cmp_sel(T x, T c, uint32_t sel) {
   return ((sel & 1u) && lt) || ((sel & 2u) && eq) || ((sel & 4u) && gt) || ((sel & 8u) && !(lt || eq || gt));
 }
 // the 16 bitmap words of one tile for one term; word j lands in lane l0 + j (l0 = 16 x the tile's place in its group of four)
+// sel2 != 0: an interval term, both comparisons on the value just loaded (wave-uniform branch outside the unrolled loops)
 template <typename T, bool NT = true>
-__device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, int l0 = 0) {
+__device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, int l0 = 0,
+                                              uint32_t sel2 = 0, uint64_t cbits2 = 0) {
   const T* p = (const T*)colv + base + lane;
-  const T c = from_bits<T>(cbits);
+  const T c = from_bits<T>(cbits), c2 = from_bits<T>(cbits2);
   uint64_t myword = 0;
   if (base + kTile <= nrows) {
     T v[kWordsPerTile];
 #pragma unroll
     for (int j = 0; j < kWordsPerTile; j++) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+    if (sel2) {
 #pragma unroll
-    for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == l0 + j) myword = m; }
+      for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel) && cmp_sel<T>(v[j], c2, sel2)); if (lane == l0 + j) myword = m; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) { uint64_t m = __ballot(cmp_sel<T>(v[j], c, sel)); if (lane == l0 + j) myword = m; }
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < kWordsPerTile; j++) {
       bool r = false;
-      if (base + j * 64 + lane < nrows) r = cmp_sel<T>(p[j * 64], c, sel);
+      if (base + j * 64 + lane < nrows) { const T x = p[j * 64]; r = cmp_sel<T>(x, c, sel) && (sel2 == 0 || cmp_sel<T>(x, c2, sel2)); }
       uint64_t m = __ballot(r); if (lane == l0 + j) myword = m;
     }
   }
@@ -234,9 +241,9 @@ template <int EXTRA> __device__ __forceinline__ uint64_t agg_identity_bits(int d
 // loaded values in 32 VGPRs until the mask was complete: +0.75 ms on the two-term scan of 1e9 rows).
 template <typename T, int EXTRA>
 __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, uint64_t before,
-                                                   uint64_t* stage, uint32_t& run, T& lsum, int l0) {
+                                                   uint64_t* stage, uint32_t& run, T& lsum, int l0, uint32_t sel2 = 0, uint64_t cbits2 = 0) {
   const T* p = (const T*)colv + base + lane;
-  const T c = from_bits<T>(cbits);
+  const T c = from_bits<T>(cbits), c2 = from_bits<T>(cbits2);
   uint64_t myword = 0;
   const bool full = base + kTile <= nrows;
   T v[kWordsPerTile];
@@ -250,7 +257,7 @@ __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cb
     const bool inb = full || base + j * 64 + lane < nrows;
     const uint64_t bj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)before, l0 + j) |
                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(before >> 32), l0 + j) << 32;   // word j of the tile's mask so far
-    const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel)) & bj;
+    const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel) && (sel2 == 0 || cmp_sel<T>(v[j], c2, sel2))) & bj;
     if (lane == l0 + j) myword = m;
     const bool mine = (m >> lane) & 1ull;
     if (EXTRA == 1) { if (mine) { uint64_t bits; __builtin_memcpy(&bits, &v[j], 8); stage[run + rank_in(m)] = bits; } run += (uint32_t)__popcll(m); }
@@ -295,23 +302,24 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
     uint64_t acc = terms.combine_or ? 0ull : ~0ull;
     for (int t = 0; t < nplain; t++) {
       const ScanTerm& tm = terms.t[t];
-      const uint32_t sel = op_sel(tm.op);
+      const uint32_t sel = op_sel(tm.op), sel2 = tm.op2 >= 0 ? op_sel(tm.op2) : 0u;
+      const uint64_t cb2 = tm.cbits2;
       uint64_t w = 0;
       for (int k = 0; k < nk; k++) {
         if (AND_EXISTING && ((live >> (16 * k)) & 0xffffull) == 0) continue;   // late materialization, tile by tile
         const int64_t base = (t0 + k) * kTile;
         const int l0 = 16 * k;
         switch (tm.dtype) {   // wave-uniform
-          case DFDB_I8:  w |= term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_I16: w |= term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_I32: w |= term_word<int32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_I64: w |= term_word<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_U8: case DFDB_BOOL: w |= term_word<uint8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_U16: w |= term_word<uint16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_U32: w |= term_word<uint32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_U64: w |= term_word<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          case DFDB_F32: w |= term_word<float>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
-          default:       w |= term_word<double>(tm.col, tm.cbits, sel, base, nrows, lane, l0); break;
+          case DFDB_I8:  w |= term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_I16: w |= term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_I32: w |= term_word<int32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_I64: w |= term_word<int64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_U8: case DFDB_BOOL: w |= term_word<uint8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_U16: w |= term_word<uint16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_U32: w |= term_word<uint32_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_U64: w |= term_word<uint64_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          case DFDB_F32: w |= term_word<float>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
+          default:       w |= term_word<double>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
         }
       }
       acc = terms.combine_or ? (acc | w) : (acc & w);
@@ -320,7 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
     if (AND_EXISTING) acc &= existing;
     if (EXTRA) {     // the last term (AND only, 8-byte dtypes only: the host checks), evaluated against the mask so far
       const ScanTerm& tm = terms.t[terms.n - 1];
-      const uint32_t sel = op_sel(tm.op);
+      const uint32_t sel = op_sel(tm.op), sel2 = tm.op2 >= 0 ? op_sel(tm.op2) : 0u;
+      const uint64_t cb2 = tm.cbits2;
       const uint64_t before = acc;
       uint64_t fin = 0;
       for (int k = 0; k < nk; k++) {
@@ -331,15 +340,15 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
         if (EXTRA == 1) stage = extra_out + base;   // straight to the tile's slot: a contiguous run per 64-row word, merged in L2
         if (tm.dtype == DFDB_F64) {
           double ls = agg_identity<double, EXTRA>();
-          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
           if (EXTRA >= 2) { ls = wave_agg<double, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
         } else if (tm.dtype == DFDB_I64) {
           int64_t ls = agg_identity<int64_t, EXTRA>();
-          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
           if (EXTRA >= 2) { ls = wave_agg<int64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = (uint64_t)ls; }
         } else {
           uint64_t ls = agg_identity<uint64_t, EXTRA>();
-          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0);
+          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
           if (EXTRA >= 2) { ls = wave_agg<uint64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = ls; }
         }
       }

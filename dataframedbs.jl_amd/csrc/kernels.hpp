@@ -9,12 +9,15 @@ namespace dfdb {
 
 enum CmpOp : int { CMP_EQ = 0, CMP_NE = 1, CMP_LT = 2, CMP_LE = 3, CMP_GT = 4, CMP_GE = 5 };
 
-// one simple term `col OP const` of a conjunction/disjunction (K1 multi-column form)
+// one simple term `col OP const` of a conjunction/disjunction (K1 multi-column form).  op2 >= 0: the term is the INTERVAL
+// `col OP const  &  col OP2 const2` — two AND-ed comparisons of the same column (`65 > x > 34`, test/selection.jl:53) read it once
 struct ScanTerm {
   const void* col;
   int32_t dtype;     // DFDB_* base dtype of the column
   int32_t op;        // CmpOp
   uint64_t cbits;    // constant already converted to the column's own type (bit pattern)
+  int32_t op2 = -1;  // CmpOp of the second comparison, -1 = none
+  uint64_t cbits2 = 0;
 };
 constexpr int kMaxTerms = 6;
 struct ScanTerms {

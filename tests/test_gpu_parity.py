@@ -854,3 +854,60 @@ def test_groupreduce_matches_first_appearance_numbering(oracle, dfdb_mod, ctx, n
     assert dfdb_mod.nrow(v) == int(sel.sum())            # the view's own query is untouched
     with pytest.raises(NotImplementedError):
         dfdb_mod.groupreduce(t[dfdb_mod.ALL, dfdb_mod.ALL], "a", "s", "sum")     # a String is no value column
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int32, np.int64, np.uint16, np.uint64, np.float32, np.float64])
+def test_two_comparisons_of_one_column_fold_into_an_interval_term(oracle, dfdb_mod, ctx, dtype):
+    """`65 > x > 34` (test/selection.jl:53) lowers to (65 > x) & (x > 34): two simple terms over ONE column.  The engine folds them into one
+    interval term of the scan kernel (the column is read once); every pair of operators must give what the oracle and numpy give, alone,
+    beside terms of other columns, as the captured / summed last term, and after a range stage (AND_EXISTING form)."""
+    from dfdb import ir
+    import operator
+    rng = np.random.default_rng(11)
+    n = 70_003
+    kind = np.dtype(dtype).kind
+    if kind == "f":
+        x = (rng.integers(-400, 400, n) / 4).astype(dtype); x[::89] = np.nan
+        lo, hi = dtype(-20.25), dtype(33.5)
+    elif kind == "u":
+        x = rng.integers(0, 200, n).astype(dtype); lo, hi = 34, 65
+    else:
+        x = rng.integers(-100, 100, n).astype(dtype); lo, hi = -34, 65
+    y = rng.integers(0, 1000, n).astype(np.int64)
+    z = (x.astype(np.float64) * 3).astype(np.float64) if kind != "f" else rng.random(n)
+    p = Pair(oracle, dfdb_mod, {"x": x, "y": y, "z": z}, block_size=8192)
+    cx, cy = ir.col(0), ir.col(1)
+    ops = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge, "==": operator.eq, "!=": operator.ne}
+    ctx.profile(True)
+    try:
+        for o1, f1 in ops.items():
+            for o2, f2 in ops.items():
+                n0, _ = ctx.profile_get("scan_terms")
+                ov, dv = apply_stages(p, [("pred", f1(ir.const(hi), cx) & f2(cx, ir.const(lo)))])
+                assert_same(p, ov, dv)
+                with np.errstate(invalid="ignore"):
+                    want = np.nonzero(f1(hi, x) & f2(x, lo))[0] + 1
+                assert np.array_equal(dv._query().indices(), want), (o1, o2)
+                n1, _ = ctx.profile_get("scan_terms")
+                assert n1 > n0                                  # the folded term runs in the multi-term scan kernel, not the interpreter
+        n0i, _ = ctx.profile_get("interp_predicate")
+        # beside another column's term; three comparisons of x (the third starts a second term); after a range stage
+        for stages in ([("pred", (cx > lo) & (cy < 700) & (cx <= hi))], [("pred", (cx > lo) & (cx <= hi) & (cx != lo + 1) & (cy >= 10))],
+                       [("range", 100, 3, n - 5), ("pred", (cx >= lo) & (cx < hi))]):
+            ov, dv = apply_stages(p, stages)
+            assert_same(p, ov, dv)
+        n1i, _ = ctx.profile_get("interp_predicate")
+        assert n1i == n0i
+    finally:
+        ctx.profile(False)
+    if dtype in (np.int64, np.uint64, np.float64):              # the interval as the capturing / summing last term
+        ov, dv = apply_stages(p, [("pred", (cy < 900) & (cx > lo) & (cx < hi))], proj=[("x", cx), ("y", cy)])
+        assert_same(p, ov, dv)
+        t = p.d
+        with np.errstate(invalid="ignore"):
+            sel = (x > lo) & (x < hi)
+        got = t[(t.x > lo) & (t.x < hi), dfdb_mod.ALL][dfdb_mod.ALL, "x"].sum()
+        if kind == "f":
+            assert abs(got - float(x[sel].astype(np.float64).sum())) <= 1e-9 * max(1.0, float(np.abs(x[sel]).sum()))
+        else:
+            assert got == int(x[sel].astype(np.int64).sum())
