@@ -246,13 +246,45 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
   int op = cmp_from_ir(n.op);
   if (op < 0 || !n.a || !n.b) return false;
   const Node *coln = nullptr, *cn = nullptr;
-  if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST) { coln = n.a.get(); cn = n.b.get(); }
-  else if (n.a->op == DFIR_CONST && n.b->op == DFIR_COL) { coln = n.b.get(); cn = n.a.get(); op = flip(op); }
-  else return false;
-  const int ct = dt_base(coln->dtype), kt = dt_base(cn->dtype);
+  // rem(col, m) OP const  (`a % 50 == 0`): a signed integer column, an integer constant m other than 0 (DivideError stays with the interpreter), 1, -1
+  auto rem_of_col = [](const Node* e) {
+    return e->op == DFIR_REM && e->a && e->b && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_I64 && !dt_nullable(e->dtype);
+  };
+  const Node* remn = nullptr;
+  if (rem_of_col(n.a.get()) && n.b->op == DFIR_CONST) { remn = n.a.get(); cn = n.b.get(); }
+  else if (n.a->op == DFIR_CONST && rem_of_col(n.b.get())) { remn = n.b.get(); cn = n.a.get(); op = flip(op); }
+  if (remn) {
+    coln = remn->a.get();
+    const int cdt = dt_base(coln->dtype), mdt = dt_base(remn->b->dtype);
+    const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
+    const bool mint = mdt == DFDB_I8 || mdt == DFDB_I16 || mdt == DFDB_I32 || mdt == DFDB_I64;
+    if (!sint || !mint || dt_nullable(coln->dtype)) return false;
+    const int64_t m = (int64_t)remn->b->cbits;
+    if (m == 0 || m == 1 || m == -1) return false;
+    const uint64_t d = m < 0 ? 0ull - (uint64_t)m : (uint64_t)m;          // |m|, 2 <= d <= 2^63
+    // unsigned division by the invariant d, branch-free form: q = mulhi(magic, x); floor(x / d) = (((x - q) >> 1) + q) >> shift
+    const int fl = 63 - __builtin_clzll(d);
+    uint64_t magic; int shift;
+    if ((d & (d - 1)) == 0) { magic = 0; shift = fl - 1; }
+    else {
+      const unsigned __int128 num = (unsigned __int128)1 << (64 + fl);
+      unsigned __int128 pm = num / d; const uint64_t rem = (uint64_t)(num % d);
+      pm += pm;
+      const uint64_t twice = rem + rem;
+      if (twice >= d || twice < rem) pm += 1;
+      magic = (uint64_t)pm + 1; shift = fl;
+    }
+    term.pre = 1; term.pre_magic = magic; term.pre_shift = shift; term.pre_d = d;
+  } else {
+    if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST) { coln = n.a.get(); cn = n.b.get(); }
+    else if (n.a->op == DFIR_CONST && n.b->op == DFIR_COL) { coln = n.b.get(); cn = n.a.get(); op = flip(op); }
+    else return false;
+  }
+  const int coldt = dt_base(coln->dtype);
+  const int ct = remn ? (int)DFDB_I64 : coldt, kt = dt_base(cn->dtype);       // ct: the type the comparison happens in
   if (dt_nullable(coln->dtype) || !dt_isnum(ct) || ct == DFDB_BOOL) return false;
   (void)t;
-  term.col = nullptr; term.dtype = ct; ordinal = coln->col;
+  term.col = nullptr; term.dtype = coldt; ordinal = coln->col;
   if (dt_isint(ct)) {
     if (dt_isint(kt) || kt == DFDB_BOOL) {
       __int128 c = (kt == DFDB_U64) ? (__int128)(uint64_t)cn->cbits : (__int128)(int64_t)cn->cbits;

@@ -212,6 +212,43 @@ __device__ __forceinline__ uint64_t term_word(const void* colv, uint64_t cbits, 
   return myword;
 }
 
+// ScanTerm.pre = 1: the compared value is rem(x, m) in Int64 (Julia `%`: the sign of the dividend).  |x| / |m| by the branch-free multiply-shift form
+// of division by an invariant (magic and shift from the host: expr.cpp), one 64 x 64 -> high 64 multiply per row.
+template <typename T>
+__device__ __forceinline__ uint64_t term_word_rem(const ScanTerm& tm, uint32_t sel, uint32_t sel2, int64_t base, int64_t nrows, int lane, int l0) {
+  const T* p = (const T*)tm.col + base + lane;
+  const int64_t c = (int64_t)tm.cbits, c2 = (int64_t)tm.cbits2;
+  const uint64_t magic = tm.pre_magic, d = tm.pre_d;
+  const int sh = tm.pre_shift;
+  auto rem64 = [&](int64_t x) -> int64_t {
+    const uint64_t ux = x < 0 ? 0ull - (uint64_t)x : (uint64_t)x;
+    const uint64_t q0 = __umul64hi(magic, ux);
+    const uint64_t q = (((ux - q0) >> 1) + q0) >> sh;
+    const uint64_t r = ux - q * d;
+    return x < 0 ? -(int64_t)r : (int64_t)r;
+  };
+  uint64_t myword = 0;
+  if (base + kTile <= nrows) {
+    T v[kWordsPerTile];
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) {
+      const int64_t r = rem64((int64_t)v[j]);
+      const uint64_t m = __ballot(cmp_sel<int64_t>(r, c, sel) && (sel2 == 0 || cmp_sel<int64_t>(r, c2, sel2)));
+      if (lane == l0 + j) myword = m;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) {
+      bool ok = false;
+      if (base + j * 64 + lane < nrows) { const int64_t r = rem64((int64_t)p[j * 64]); ok = cmp_sel<int64_t>(r, c, sel) && (sel2 == 0 || cmp_sel<int64_t>(r, c2, sel2)); }
+      const uint64_t m = __ballot(ok); if (lane == l0 + j) myword = m;
+    }
+  }
+  return myword;
+}
+
 // EXTRA = 2 / 3 / 4: sum / min / max of the finally selected values (Julia: Int sums wrap, min / max of Float64 propagate NaN)
 template <typename T, int EXTRA> __device__ __forceinline__ T agg_identity() {
   if (EXTRA == 3) return std::is_same<T, double>::value ? (T)__builtin_inf() : (std::is_same<T, int64_t>::value ? (T)INT64_MAX : (T)~0ull);
@@ -309,6 +346,15 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
         if (AND_EXISTING && ((live >> (16 * k)) & 0xffffull) == 0) continue;   // late materialization, tile by tile
         const int64_t base = (t0 + k) * kTile;
         const int l0 = 16 * k;
+        if (tm.pre) {          // rem(col, m) OP c: signed integer columns only (the host checks)
+          switch (tm.dtype) {
+            case DFDB_I8:  w |= term_word_rem<int8_t>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_rem<int16_t>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_rem<int32_t>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_rem<int64_t>(tm, sel, sel2, base, nrows, lane, l0); break;
+          }
+          continue;
+        }
         switch (tm.dtype) {   // wave-uniform
           case DFDB_I8:  w |= term_word<int8_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;
           case DFDB_I16: w |= term_word<int16_t>(tm.col, tm.cbits, sel, base, nrows, lane, l0, sel2, cb2); break;

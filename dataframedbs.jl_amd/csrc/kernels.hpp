@@ -18,6 +18,10 @@ struct ScanTerm {
   uint64_t cbits;    // constant already converted to the column's own type (bit pattern)
   int32_t op2 = -1;  // CmpOp of the second comparison, -1 = none
   uint64_t cbits2 = 0;
+  // pre = 1: the compared value is rem(col, m) for a signed integer column and a constant m (`a % 50 == 0`, test/selection.jl:21): computed in
+  // Int64 as sign(x) * (|x| mod |m|), |x| / |m| by multiplication with a precomputed magic number (pre_magic, pre_shift); cbits / cbits2 are Int64
+  int32_t pre = 0, pre_shift = 0;
+  uint64_t pre_magic = 0, pre_d = 0;
 };
 constexpr int kMaxTerms = 6;
 struct ScanTerms {

@@ -254,7 +254,8 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       bool folded = false;
       const size_t ord0 = term_ords.size() - (size_t)terms.n;
       for (int k = 0; k < terms.n && !folded; k++)
-        if (term_ords[ord0 + (size_t)k] == ord && terms.t[k].op2 < 0 && terms.t[k].dtype == tm.dtype) { terms.t[k].op2 = tm.op; terms.t[k].cbits2 = tm.cbits; folded = true; }
+        if (term_ords[ord0 + (size_t)k] == ord && terms.t[k].op2 < 0 && terms.t[k].dtype == tm.dtype && terms.t[k].pre == tm.pre &&
+            (tm.pre == 0 || (terms.t[k].pre_d == tm.pre_d && terms.t[k].pre_magic == tm.pre_magic))) { terms.t[k].op2 = tm.op; terms.t[k].cbits2 = tm.cbits; folded = true; }
       if (folded) continue;
       if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }
       terms.t[terms.n++] = tm; term_ords.push_back(ord);
@@ -322,6 +323,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       if (pe.op == DFIR_COL && !dt_nullable(pe.dtype))
         for (int k = 0; k < lb.n && special < 0; k++) {
           const int dt = lb.t[k].dtype;
+          if (lb.t[k].pre) continue;                              // (a rem term compares rem(x, m): not the value to add up)
           if (term_ords[ord0 + (size_t)k] == pe.col && (dt == DFDB_I64 || dt == DFDB_U64 || dt == DFDB_F64)) {
             special = k; extra = q->hint_agg_op == DFDB_AGG_SUM ? 2 : (q->hint_agg_op == DFDB_AGG_MIN ? 3 : 4);
           }
@@ -330,7 +332,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     if (!extra && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1) {
       for (int k = 0; k < lb.n && special < 0; k++) {
         const int dt = lb.t[k].dtype;
-        if (dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) continue;
+        if ((dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) || lb.t[k].pre) continue;
         for (const ProjCol& p : q->proj)
           if (p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype)) { special = k; extra = 1; break; }
       }
@@ -348,7 +350,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
     set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
     place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows) {
-      if (tb0.n == 1 && tb0.t[0].op2 < 0) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr);
+      if (tb0.n == 1 && tb0.t[0].op2 < 0 && tb0.t[0].pre == 0) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr);
       else launch_scan_terms(s, tb0, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
     });
   }
@@ -359,7 +361,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // (ctx option keep_compressed at load time) decodes the blocks and evaluates the term in the same pass (K7 SCAN): what the reference's loop
     // body does per block (read_block! then apply the selection, blocksiterator.jl:98-121).  ctx option "decode_on_scan" = 1 asks for it;
     // the decoded column is (re)written on the way, so everything after this launch sees an ordinary resident column.
-    if (tb.n == 1 && tb.t[0].op2 < 0 && ex == 0 && !have && first_stage && bi == 0 && ctx_option(ctx, "decode_on_scan", 0) != 0) {
+    if (tb.n == 1 && tb.t[0].op2 < 0 && tb.t[0].pre == 0 && ex == 0 && !have && first_stage && bi == 0 && ctx_option(ctx, "decode_on_scan", 0) != 0) {
       Column& fc = t->cols[(size_t)term_ords[0]];
       const int fdt = tb.t[0].dtype;
       if (fc.comp_nblocks > 0 && !dt_nullable(fc.dtype) && (fdt == DFDB_I64 || fdt == DFDB_U64 || fdt == DFDB_F64) && t->block_size % kTileRows == 0) {
@@ -370,7 +372,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
         continue;
       }
     }
-    if (tb.n == 1 && tb.t[0].op2 < 0 && ex < 2) {
+    if (tb.n == 1 && tb.t[0].op2 < 0 && tb.t[0].pre == 0 && ex < 2) {
       LaunchTimer lt(ctx, "scan_cmp");
       set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,

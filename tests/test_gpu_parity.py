@@ -911,3 +911,48 @@ def test_two_comparisons_of_one_column_fold_into_an_interval_term(oracle, dfdb_m
             assert abs(got - float(x[sel].astype(np.float64).sum())) <= 1e-9 * max(1.0, float(np.abs(x[sel]).sum()))
         else:
             assert got == int(x[sel].astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.int64])
+def test_rem_by_a_constant_is_a_scan_term(oracle, dfdb_mod, ctx, dtype):
+    """`a % 50 == 0` (test/selection.jl:21, test/view.jl): rem(col, m) OP const over a signed integer column runs in the scan kernel (division by
+    the invariant |m| as multiply + shift), not in the interpreter.  Julia's rem takes the sign of the dividend; the result must equal the
+    oracle's generic evaluation and numpy's fmod for every operator, small / large / negative / power-of-two divisors and the extreme values."""
+    from dfdb import ir
+    import operator
+    rng = np.random.default_rng(5)
+    n = 50_021
+    info = np.iinfo(dtype)
+    x = rng.integers(info.min, info.max, n, dtype=np.int64, endpoint=True).astype(dtype)
+    x[:6] = [info.min, info.max, 0, -1, 1, info.min + 1]
+    y = rng.integers(0, 100, n).astype(np.int64)
+    p = Pair(oracle, dfdb_mod, {"x": x, "y": y}, block_size=4096)
+    cx, cy = ir.col(0), ir.col(1)
+    ops = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge, "==": operator.eq, "!=": operator.ne}
+    divisors = [2, 3, 50, -7, 64, -128, 1000003, 2**40 + 1, -(2**62) - 5, -(2**63), 2**63 - 1]
+    ctx.profile(True)
+    try:
+        n0i, _ = ctx.profile_get("interp_predicate")
+        for m in divisors:
+            r = np.fmod(x.astype(np.int64), np.int64(m)) if m != -(2**63) else np.where(x.astype(np.int64) == -(2**63), 0, x.astype(np.int64))
+            for name, f in ops.items():
+                c = 0 if name in ("==", "!=") else (1 if m > 0 else -1)
+                ov, dv = apply_stages(p, [("pred", f(cx % ir.const(m), ir.const(c)))])
+                assert_same(p, ov, dv)
+                assert np.array_equal(dv._query().indices(), np.nonzero(f(r, c))[0] + 1), (m, name)
+        # constant on the left, an interval of remainders, beside another column's term, after a range stage, in a disjunction
+        for stages in ([("pred", ir.const(0) == cx % ir.const(50))], [("pred", (cx % ir.const(50) > -10) & (cx % ir.const(50) <= 3))],
+                       [("pred", (cx % ir.const(7) == 0) & (cy < 93))], [("range", 5, 2, n - 3), ("pred", cx % ir.const(50) == 0)],
+                       [("pred", (cx % ir.const(9) == 4) | (cy > 97))]):
+            ov, dv = apply_stages(p, stages)
+            assert_same(p, ov, dv)
+        n1i, _ = ctx.profile_get("interp_predicate")
+        assert n1i == n0i                                        # none of the above went through the interpreter
+        # m = 1 / -1 / 0 stay with the interpreter (0 raises DivideError on both sides)
+        ov, dv = apply_stages(p, [("pred", cx % ir.const(1) == 0)])
+        assert_same(p, ov, dv)
+        ov, dv = apply_stages(p, [("pred", cx % ir.const(0) == 0)])
+        with pytest.raises(Exception, match="DivideError"):
+            dv._query().count()
+    finally:
+        ctx.profile(False)

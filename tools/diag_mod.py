@@ -12,8 +12,10 @@ ctx = dfdb.default_context(0)
 t = dfdb.DFTable.new()
 t.add_generated("a", dfdb.GEN_I64_MOD1M, 1, n)
 t.add_generated("x", dfdb.GEN_F64_U2000, 2, n)
+t.add_generated("b", dfdb.GEN_I64_MOD1M, 3, n)
 preds = {"a % 50 == 0": lambda: t.a % 50 == 0, "a * 2 + 1 > 1000000": lambda: t.a * 2 + 1 > 1_000_000, "x * 1.0 < 632.456": lambda: t.x * 1.0 < 632.456,
-         "a / 50 > 10000.5": lambda: t.a / 50 > 10000.5, "(a > 5e5) | (x < 100)": lambda: (t.a > 500_000) | (t.x < 100.0)}
+         "a / 50 > 10000.5": lambda: t.a / 50 > 10000.5, "(a > 5e5) | (x < 100)": lambda: (t.a > 500_000) | (t.x < 100.0), "a > b": lambda: t.a > t.b, "a == b": lambda: t.a == t.b,
+         "(a % 50 == 0) & (b < 930000)": lambda: (t.a % 50 == 0) & (t.b < 930_000)}
 for name, mk in preds.items():
     q = t[mk(), dfdb.ALL]._query()
     q.execute(); ctx.synchronize()
