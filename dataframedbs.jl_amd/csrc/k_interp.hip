@@ -28,7 +28,7 @@ constexpr int64_t kTile = 1024;
 constexpr int kW = 4;            // 64-row words a wave carries through one instruction dispatch
 constexpr int kGroups = 16 / kW;
 constexpr int kMaxIns = 96;
-constexpr int kMaxCols = 8;
+constexpr int kMaxCols = 32;     // (a queue of fused predicate stages is ONE program: eight columns was reached by three ordinary stages)
 constexpr int kMaxStr = 4;       // string columns whose bytes are read (need per-row byte offsets)
 constexpr int kMaxLds = 8;       // stack levels + offset arrays: 8 KB of dynamic LDS each per workgroup
 

@@ -426,6 +426,17 @@ void query_execute(dfdb_query* q, int nstages) {
     if (st.kind == ST_PRED) { run_predicate(q, *st.pred, i == 0, i + 1 == (int)q->stages.size()); q->prefix_valid = false; }
     else run_range(q, st, i == 0);
   }
+  // A view that needs NO column at all — range-like stages only and a projection of constants — iterates nothing in the reference: BlocksIterator
+  // opens one stream per required column and `isempty(it.streams)` ends the iteration before the first block (blocksiterator.jl:101,125).  Same here.
+  if (nstages == (int)q->stages.size()) {
+    std::vector<int> req;
+    for (const Stage& st : q->stages) if (st.kind == ST_PRED) required_columns(*st.pred, req);
+    for (const ProjCol& p : q->proj) required_columns(*p.expr, req);
+    if (req.empty() && !q->proj.empty()) {
+      HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, ctx->stream));
+      HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, ctx->stream));
+    }
+  }
   scan_prefix(q);
   q->executed_stages = nstages;
 }

@@ -256,7 +256,10 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   std::vector<int> req;
   for (const Stage& st : q->stages) if (st.kind == ST_PRED) required_columns(*st.pred, req);
   for (const ProjCol& p : q->proj) required_columns(*p.expr, req);
-  if (req.empty() && !t->cols.empty()) req.push_back(0);   // the row count of a block must come from some column (blocksiterator.jl:30)
+  // no required column at all (range stages + a projection of constants): the reference iterates nothing (`isempty(it.streams)`, blocksiterator.jl:101);
+  // an empty projection (count only) takes its block sizes from the first column
+  const bool nothing_to_read = req.empty() && !q->proj.empty();
+  if (req.empty() && !t->cols.empty()) req.push_back(0);
   std::sort(req.begin(), req.end()); req.erase(std::unique(req.begin(), req.end()), req.end());
   s->required = req;
   for (int o : req) {
@@ -315,6 +318,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     sl.tbl = tb.release(); sl.q = cq.release();
   }
   for (auto& th : s->loader) if (!th.joinable()) th = std::thread(loader_main, s);
+  if (nothing_to_read) { s->done = true; return; }
   if (!prefetch(s, &s->slot[0])) s->done = true;
   else for (int i = 1; i + 1 < dfdb_stream::kSlots; i++) if (!prefetch(s, &s->slot[i])) break;
 }

@@ -86,6 +86,12 @@ def assert_same(pair: Pair, ov, dv, check_indices: bool = True, float_exact: boo
             assert np.array_equal(w.compressed(), g.compressed()), f"column {i}: values differ"   # bytes under a missing bit are garbage (Q11)
         else:
             assert w.dtype == g.dtype, f"column {i}: dtype {g.dtype} != {w.dtype}"
+            if w.dtype.kind == "f":
+                # NaN is NaN: its sign and payload bits are not part of the contract (isequal(NaN, -NaN) in Julia; `c - NaN` keeps the operand's sign on
+                # x86 and flips it on the GPU, which subtracts by adding the negation) — positions must agree, every other value bit for bit
+                wn, gn = np.isnan(w), np.isnan(g)
+                assert np.array_equal(wn, gn), f"column {i}: NaN positions differ"
+                w, g = np.where(wn, 0, w).astype(w.dtype), np.where(gn, 0, g).astype(g.dtype)
             if float_exact or w.dtype.kind != "f":
                 assert np.array_equal(w.view(np.uint8), g.view(np.uint8)), f"column {i}: values differ: {g[:5]} vs {w[:5]}"
             else:

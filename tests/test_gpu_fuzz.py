@@ -1,0 +1,158 @@
+"""Seeded differential fuzz of the whole path: random typed expression trees (every arithmetic / comparison / logical operator of the IR over
+every column type, missing values, strings) inside random selection queues (ranges, index vectors, predicates) with random projections —
+the engine's count, indices, bitmap and materialised columns must equal the oracle's, byte for byte, and where Julia would raise
+(DivideError, InexactError) both must raise the same error.  The fixed shapes of the other suites pick the kernels; this one picks nothing."""
+import numpy as np
+import pytest
+
+from helpers import Pair, apply_stages, assert_same
+
+pytestmark = pytest.mark.gpu
+N = 12_345
+
+
+@pytest.fixture(scope="module")
+def pair(oracle, dfdb_mod):
+    rng = np.random.default_rng(2024)
+    f64 = rng.normal(0, 50, N); f64[::101] = np.nan; f64[5::997] = np.inf; f64[7::991] = -0.0
+    f32 = rng.normal(0, 8, N).astype(np.float32); f32[::113] = np.nan
+    cols = {
+        "a": rng.integers(-60, 60, N).astype(np.int64),                       # 0
+        "b": rng.integers(-2**62, 2**62, N).astype(np.int64),                 # 1  (overflow territory)
+        "c": rng.integers(1, 40, N).astype(np.int64),                         # 2  (never zero: a safe divisor)
+        "i32": rng.integers(-2**31, 2**31 - 1, N).astype(np.int32),           # 3
+        "i8": rng.integers(-128, 127, N).astype(np.int8),                     # 4
+        "u16": rng.integers(0, 2**16 - 1, N).astype(np.uint16),               # 5
+        "u64": rng.integers(0, 2**63, N).astype(np.uint64) * np.uint64(2),    # 6
+        "x": f64,                                                             # 7
+        "f": f32,                                                             # 8
+        "flag": rng.integers(0, 2, N).astype(bool),                           # 9
+        "m": np.ma.masked_array(rng.integers(-9, 9, N).astype(np.int64), mask=rng.random(N) < 0.25),   # 10
+        "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)],   # 11
+        "z": rng.integers(-2, 3, N).astype(np.int64),                         # 12 (zeros: a divisor that raises)
+    }
+    return Pair(oracle, dfdb_mod, cols, block_size=1000)
+
+
+NUM_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+INT_COLS = [0, 1, 2, 3, 4, 5, 6]
+
+
+class Gen:
+    def __init__(self, ir, seed, risky):
+        self.ir, self.rng, self.risky = ir, np.random.default_rng(seed), risky
+
+    def pick(self, xs):
+        return xs[int(self.rng.integers(0, len(xs)))]
+
+    def const(self):
+        r = self.rng.random()
+        if r < 0.5:
+            return self.ir.const(int(self.rng.integers(-70, 70)))
+        if r < 0.8:
+            return self.ir.const(float(np.round(self.rng.normal(0, 30), 2)))
+        return self.ir.const(self.pick([0, 1, -1, 2**31, -2**31 - 1, 2**53 + 1, 0.5, -0.0, float("inf"), float("nan"), 255, 65536]))
+
+    def num(self, depth):
+        ir = self.ir
+        if depth <= 0 or self.rng.random() < 0.3:
+            return ir.col(self.pick(NUM_COLS)) if self.rng.random() < 0.75 else self.const()
+        k = int(self.rng.integers(0, 12))
+        a = self.num(depth - 1)
+        if k == 0: return -a
+        if k == 1: return abs(a)
+        if k == 2:                                                               # T(x): InexactError where the value does not fit (risky seeds only)
+            return ir.cast(a, self.pick([ir.I8, ir.I32, ir.I64, ir.U16, ir.U64, ir.F32, ir.F64])) if self.risky else ir.float64(a)
+        b = self.num(depth - 1)
+        if k == 3: return a + b
+        if k == 4: return a - b
+        if k == 5: return a * b
+        if k == 6: return ir.minimum(a, b)
+        if k == 7: return ir.maximum(a, b)
+        if k == 8: return a / (b if self.risky else ir.col(2))
+        # integer-only operators: integer operands (÷, rem, mod are defined for floats too, but keep the divisor's zero under control)
+        ia = ir.col(self.pick(INT_COLS)) if self.rng.random() < 0.8 else ir.col(self.pick([7, 8]))     # (rem / mod / div of floats too)
+        ib = (ir.col(12) if self.risky and self.rng.random() < 0.5 else self.pick([ir.col(2), ir.const(7), ir.const(-3), ir.col(2) * 2 + 1]))
+        if k == 9: return ia % ib
+        if k == 10: return ir.mod(ia, ib)
+        return ir.div(ia, ib)
+
+    def boolean(self, depth):
+        ir = self.ir
+        r = self.rng.random()
+        if depth <= 0 or r < 0.45:
+            k = int(self.rng.integers(0, 9))
+            if k <= 3:
+                f = self.pick([lambda p, q: p == q, lambda p, q: p != q, lambda p, q: p < q, lambda p, q: p <= q, lambda p, q: p > q, lambda p, q: p >= q])
+                return f(self.num(min(depth, 2)), self.num(min(depth, 2)) if self.rng.random() < 0.6 else self.const())
+            if k == 4: return ir.col(9)
+            if k == 5: return ir.isin(ir.col(self.pick([0, 3, 4, 5])), [int(v) for v in self.rng.integers(-60, 60, int(self.rng.integers(1, 9)))])
+            if k == 6: return ir.ismissing(ir.col(10)) if self.rng.random() < 0.5 else (ir.coalesce(ir.col(10), ir.const(int(self.rng.integers(-3, 3)))) > self.const())
+            if k == 7: return self.pick([ir.col(11) == "a7", ir.col(11) != "bb11", ir.startswith(ir.col(11), "aa"), ir.endswith(ir.col(11), "2"), ir.sizeof(ir.col(11)) > 2])
+            return ir.coalesce(ir.col(10), ir.col(0)) * 2 >= ir.col(4)           # a nullable column made whole by another column
+        a, b = self.boolean(depth - 1), self.boolean(depth - 1)
+        k = int(self.rng.integers(0, 4))
+        return (a & b) if k == 0 else (a | b) if k == 1 else (a ^ b) if k == 2 else ~a
+
+    def stages(self):
+        # `bound`: the statically known size of the queue so far (Julia checks a range / index stage against it when the stage before is one)
+        out, bound = [], N
+        for _ in range(int(self.rng.integers(1, 4))):
+            k = self.rng.random()
+            if k < 0.55 or bound < 2:
+                out.append(("pred", self.boolean(int(self.rng.integers(0, 3)))))
+            elif k < 0.8:
+                lo = int(self.rng.integers(1, bound // 2 + 1)); step = int(self.pick([1, 1, 2, 3, 7, 64, 1000]))
+                hi = int(self.rng.integers(lo, bound + 1))
+                out.append(("range", lo, step, hi)); bound = len(range(lo, hi + 1, step))
+            elif k < 0.9:
+                idx = [int(v) for v in self.rng.integers(1, bound + 1, int(self.rng.integers(0, 40)))]
+                out.append(("idx", idx)); bound = len(set(idx))
+            else:
+                out.append(("int", int(self.rng.integers(1, bound + 1))))
+                break                                                            # nothing indexes a scalar selection
+        return out
+
+    def proj(self):
+        if self.rng.random() < 0.3:
+            return None
+        ir, out = self.ir, []
+        for k in range(int(self.rng.integers(1, 4))):
+            r = self.rng.random()
+            e = ir.col(int(self.rng.integers(0, 13))) if r < 0.5 else (self.num(2) if r < 0.85 else self.boolean(1))
+            out.append(("p%d" % k, e))
+        return out
+
+
+def outcome(fn):
+    try:
+        return ("ok", fn())
+    except Exception as e:          # noqa: BLE001 — the class is what is compared
+        return ("err", type(e).__name__)
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
+    from dfdb import ir
+    g = Gen(ir, seed, risky=seed % 4 == 3)
+    stages, proj = g.stages(), g.proj()
+    try:
+        ov, dv = apply_stages(pair, stages, proj=proj)
+    except Exception as e:          # noqa: BLE001
+        # refused while the queue is built (a range beyond the statically known size of the stage before it, a non-Bool predicate): helpers.apply_stages
+        # builds the oracle's view first, so an error raised by the engine's mirror alone would show up as a different message here
+        pytest.skip("refused at build time: %s: %s" % (type(e).__name__, str(e)[:90]))
+    want = outcome(lambda: ov.nrow())
+    got = outcome(lambda: dfdb_mod.nrow(dv))
+    assert want[0] == got[0], f"oracle {want}, engine {got} for {stages} / {proj}"
+    # which error: Julia raises the one of the first row (then the leftmost sub-expression) that fails; when a queue holds both a zero divisor and an
+    # inexact conversion (risky seeds) the GPU, which evaluates a block at once, may report the other of the two — that both raise is what is checked there
+    if want[0] == "err":
+        assert want[1] == got[1] or g.risky, f"oracle raises {want[1]}, engine {got[1]} for {stages}"
+        return
+    w2 = outcome(lambda: ov.materialize())
+    if w2[0] == "err":              # the projection raises (DivideError / InexactError on a selected row)
+        g2 = outcome(lambda: dv._query().materialize())
+        assert g2 == w2 or (g.risky and g2[0] == "err"), f"oracle {w2}, engine {g2} for {proj}"
+        return
+    assert_same(pair, ov, dv)
