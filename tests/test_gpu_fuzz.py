@@ -2,6 +2,8 @@
 every column type, missing values, strings) inside random selection queues (ranges, index vectors, predicates) with random projections —
 the engine's count, indices, bitmap and materialised columns must equal the oracle's, byte for byte, and where Julia would raise
 (DivideError, InexactError) both must raise the same error.  The fixed shapes of the other suites pick the kernels; this one picks nothing."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from helpers import Pair, apply_stages, assert_same
 
 pytestmark = pytest.mark.gpu
 N = 12_345
+SCALE = int(os.environ.get("DFDB_FUZZ_SCALE", "1"))      # DFDB_FUZZ_SCALE=20 python -m pytest tests/test_gpu_fuzz.py: 20 x the seeds
 
 
 @pytest.fixture(scope="module")
@@ -131,7 +134,7 @@ def outcome(fn):
         return ("err", type(e).__name__)
 
 
-@pytest.mark.parametrize("seed", range(400))
+@pytest.mark.parametrize("seed", range(400 * SCALE))
 def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
     from dfdb import ir
     g = Gen(ir, seed, risky=seed % 4 == 3)
@@ -156,3 +159,73 @@ def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
         assert g2 == w2 or (g.risky and g2[0] == "err"), f"oracle {w2}, engine {g2} for {proj}"
         return
     assert_same(pair, ov, dv)
+
+
+# ---------------------------------------------------------------- the same random queues, block-streamed and block-range sharded
+@pytest.fixture(scope="module")
+def filed(oracle, dfdb_mod, tmp_path_factory):
+    """The fuzz table without its nullable column (group tables split host columns by block range: plain arrays), written by the oracle (liblz4),
+    opened three ways: resident, not loaded (for streaming), and as a 3-shard group on device 0 with the host exchange."""
+    from dfdb import group as G, _native as NAT
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 50, N); x[::101] = np.nan
+    cols = {"a": rng.integers(-60, 60, N).astype(np.int64), "b": rng.integers(-2**62, 2**62, N).astype(np.int64), "c": rng.integers(1, 40, N).astype(np.int64),
+            "i32": rng.integers(-2**31, 2**31 - 1, N).astype(np.int32), "i8": rng.integers(-128, 127, N).astype(np.int8),
+            "u16": rng.integers(0, 2**16 - 1, N).astype(np.uint16), "u64": rng.integers(0, 2**63, N).astype(np.uint64) * np.uint64(2), "x": x,
+            "f": rng.normal(0, 8, N).astype(np.float32), "flag": rng.integers(0, 2, N).astype(bool),
+            "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)]}
+    path = str(tmp_path_factory.mktemp("fuzz") / "tb")
+    p = Pair(oracle, dfdb_mod, cols, block_size=1000, via_files=path)
+    lazy = dfdb_mod.open_table(path, load=False)
+    g = G.Group.create([0, 0, 0], NAT.EXCHANGE_HOST)
+    gt = G.GroupTable.open(g, path)
+    yield p, lazy, gt
+    gt.close(); g.close(); lazy.close()
+
+
+class GenNoMissing(Gen):
+    """column ordinals of `filed`: a b c i32 i8 u16 u64 x f flag s  (no nullable column, no zero-divisor column)"""
+    def boolean(self, depth):
+        ir = self.ir
+        if depth <= 0 or self.rng.random() < 0.45:
+            k = int(self.rng.integers(0, 7))
+            if k <= 3:
+                f = self.pick([lambda p, q: p == q, lambda p, q: p != q, lambda p, q: p < q, lambda p, q: p <= q, lambda p, q: p > q, lambda p, q: p >= q])
+                return f(self.num(min(depth, 2)), self.num(min(depth, 2)) if self.rng.random() < 0.6 else self.const())
+            if k == 4: return ir.col(9)
+            if k == 5: return ir.isin(ir.col(self.pick([0, 3, 4, 5])), [int(v) for v in self.rng.integers(-60, 60, int(self.rng.integers(1, 9)))])
+            return self.pick([ir.col(10) == "a7", ir.col(10) != "bb11", ir.startswith(ir.col(10), "aa"), ir.endswith(ir.col(10), "2"), ir.sizeof(ir.col(10)) > 2])
+        a, b = self.boolean(depth - 1), self.boolean(depth - 1)
+        k = int(self.rng.integers(0, 4))
+        return (a & b) if k == 0 else (a | b) if k == 1 else (a ^ b) if k == 2 else ~a
+
+
+@pytest.mark.parametrize("seed", range(120 * SCALE))
+def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
+    """Range and index stages after predicates number the SURVIVORS: across chunk boundaries (streaming) and across shards (the stage-base exchange)
+    their running offsets must continue exactly where the previous chunk / the lower ranks stopped."""
+    from dfdb import ir, group as G
+    pair, lazy, gt = filed
+    g = GenNoMissing(ir, 10_000 + seed, risky=False)
+    stages = g.stages()
+    proj = [("a", ir.col(0)), ("x", ir.col(7)), ("k", ir.col(3) * 2 - ir.col(4))]
+    try:
+        ov, dv = apply_stages(pair, stages, proj=proj)
+    except Exception as e:          # noqa: BLE001
+        pytest.skip("refused at build time: %s" % type(e).__name__)
+    want_idx = ov.select_indices()
+    want = ov.materialize()
+    assert np.array_equal(dv._query().indices(), want_idx)
+    # block-streamed over the table that is not resident, chunk size 1..5 blocks
+    sv = dfdb_mod.DFView(lazy, dv.projection, dv.selection)
+    assert dfdb_mod.nrow_streamed(sv, 1 + seed % 5) == len(want_idx)
+    got = dfdb_mod.materialize_streamed(sv, 1 + (seed // 5) % 5)
+    assert np.array_equal(np.asarray(got["a"], dtype=np.int64), want[0]) and np.array_equal(np.asarray(got["k"], dtype=np.int64), want[2])
+    gx, wx = np.asarray(got["x"], dtype=np.float64), want[1]
+    assert np.array_equal(np.isnan(gx), np.isnan(wx)) and np.array_equal(gx[~np.isnan(gx)], wx[~np.isnan(wx)])
+    # three block-range shards
+    gv = dfdb_mod.DFView(gt.view().table, dv.projection, dv.selection)
+    assert G.gnrow(gv) == len(want_idx)
+    assert np.array_equal(G.gindices(gv), want_idx)
+    gm = G._gq(gv).materialize()
+    assert np.array_equal(gm[0], want[0]) and np.array_equal(gm[2], want[2])
