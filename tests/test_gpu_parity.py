@@ -224,8 +224,9 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
         assert_same(p, ov, dv)
 
 
+@pytest.mark.parametrize("pipe", [0, 1])             # K7 one wave per block / the two-wave pipeline (by default the block count chooses: these files are small)
 @pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded data sets)
-def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
+def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
     """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
     matches with offset < 64, = 64, > 64), literal runs of 0..400 bytes between matches (length-byte chains), matches at
     distances beyond the 8-KB LDS ring, incompressible blocks (one 64-KB literal run), sequences that straddle the 2-KB
@@ -259,10 +260,28 @@ def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant):
     cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "noise": rng.integers(0, 256, n).astype(np.uint8), "shortseq": shortseq,
             "runs": np.repeat(rng.integers(0, 4, n // 50 + 1).astype(np.uint8), rng.integers(1, 100, n // 50 + 1))[:n]}
     cols["runs"] = np.resize(cols["runs"], n)
-    for bs in (65536, 50_000, 4099):
-        p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"c{bs}"))
-        ov, dv = apply_stages(p, [])
-        assert_same(p, ov, dv)
+    ctx.set_option("lz4_pipeline", pipe)
+    try:
+        for bs in (65536, 50_000, 4099):
+            p = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / f"c{bs}"))
+            ov, dv = apply_stages(p, [])
+            assert_same(p, ov, dv)
+        # the same bytes as an Int64 column, decoded FUSED with a predicate (K7 SCAN: the bitmap leaves the decoder) and re-decoded in place
+        ctx.set_option("keep_compressed", 1)
+        for name in ("mixed", "shortseq", "periodic"):
+            v8 = np.ascontiguousarray(cols[name][: n // 8 * 8]).view(np.int64)
+            p8 = Pair(oracle, dfdb_mod, {"v": v8}, block_size=8192, via_files=str(tmp_path / f"v8{name}"))
+            from dfdb import ir
+            c = int(np.median(v8))
+            ctx.set_option("decode_on_scan", 1)
+            ov, dv = apply_stages(p8, [("pred", ir.col(0) > c)])
+            assert_same(p8, ov, dv)
+            ctx.set_option("decode_on_scan", 0)
+            p8.d.decode_resident("v")
+            ov, dv = apply_stages(p8, [("pred", ir.col(0) <= c)])
+            assert_same(p8, ov, dv)
+    finally:
+        ctx.set_option("lz4_pipeline", -1); ctx.set_option("keep_compressed", 0); ctx.set_option("decode_on_scan", 0)
 
 
 def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
@@ -291,8 +310,9 @@ def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
         ot.view().materialize()
 
 
+@pytest.mark.parametrize("pipe", [0, 1])             # both forms of K7 (see test_lz4_decode_corner_cases)
 @pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded damage sets)
-def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, variant):
+def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
     """LZ4_decompress_safe semantics (BlockStreams.jl:110-112): a damaged block either still decodes to `origin` bytes or raises
     "decompression error" — it never writes outside the block, hangs or takes the device down.  Random byte flips, truncated
     sequences, zero / huge offsets and endless length chains in the payloads of valid files; after every attempt the intact file
@@ -312,7 +332,8 @@ def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, va
     for k, v in cols.items():
         ot.add_column(k, v)
     ot.save(str(good))
-    if True:
+    ctx.set_option("lz4_pipeline", pipe)
+    try:
         outcomes = {"error": 0, "decoded": 0}
         ntrials = int(os.environ.get("DFDB_FUZZ_TRIALS", "24"))          # (a soak run: DFDB_FUZZ_TRIALS=400)
         for trial in range(ntrials):
@@ -359,6 +380,8 @@ def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, va
             assert np.array_equal(np.asarray(got["a"]), cols["a"]) and np.array_equal(np.asarray(got["s"]), cols["s"])
             t.close()
         assert outcomes["error"] >= ntrials // 3            # most of these damages cannot decode
+    finally:
+        ctx.set_option("lz4_pipeline", -1)
 
 
 @pytest.mark.parametrize("n", [1, 1023, 1025, 70_001, 300_000])
