@@ -108,6 +108,9 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
     delete ctx;
   });
 }
+int32_t dfdb_table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries, int64_t* entries) {
+  return guard([&] { NEED(t); const int64_t n = table_build_dictionary(t, ordinal, max_entries); if (entries) *entries = n; });
+}
 int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) { return guard([&] { NEEDQ(q); NEED(out); stream_open(q, chunk_blocks, out); }); }
 int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row) {
   return guard([&] { NEED(s); NEED(chunk); *chunk = nullptr; *chunk = stream_next(s, chunk_rows, first_row); });

@@ -28,6 +28,11 @@ struct Column {
   DevBuf mask_pref;
   bool mask_calibrated = false, mask_lent = false;
   float mask_ms_best = 0, mask_ms_worst = 0;   // per scanned sample, for dfdb_ctx_profile / the bench's JSON
+  // dictionary form of a low-cardinality String column (dfdb_table_build_dictionary / ctx option "string_dictionary"; k_dict.hip): one 16-bit code per
+  // row beside the flat form, the distinct strings once on the device and on the host (predicates are evaluated on the host copy)
+  DevBuf dict_codes, dict_len, dict_off, dict_bytes;
+  std::vector<std::string> dict_host;
+  int32_t dict_n = 0;           // 0 = no dictionary
   // on-disk source (tables opened from files)
   std::string file;
   size_t data_off = 0;  // first block inside the file
@@ -84,6 +89,8 @@ struct dfdb_query {
   // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena
   // offset, selected byte totals per tile
   int cap_str_col = -1;
+  // a conjunct `strcol == "const"` of some stage holds for every finally selected row: the projection of that column is `const` repeated
+  int const_str_col = -1; std::string const_str;
   // dfdb_query_hint_aggregate: sum(projection column) WILL be asked for: when that column is a simple term of the launch that produces
   // the final mask, the scan adds up the selected values while it holds them (one partial per 1024-row tile) and dfdb_aggregate only
   // reduces the partials
@@ -94,6 +101,7 @@ struct dfdb_query {
   int64_t agg_ones_tiles = -1;
   dfdb::DevBuf cap_str_sizes, cap_str_bytes, cap_str_tb;
   bool stream_owned = false;   // a chunk query handed out by dfdb_stream_next: owned by the stream
+  dfdb::DevBuf dict_sel;       // K9: the selected rows' dictionary codes (materialize of a dictionary column)
   // dfdb_query_groupreduce: the full selection set aside, per-group counts / values, what the fetch needs
   dfdb::DevBuf gr_sel, gr_cnt, gr_val;
   int64_t gr_n = 0; int gr_key = -1, gr_op = 0, gr_kind = 0, gr_state = 0;   // state 0: none, 1: empty result, 2: results + narrowed selection pending
@@ -132,7 +140,9 @@ bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t 
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
 void stream_close(dfdb_stream* s);
-void stream_drop_parked(dfdb_ctx* ctx);   // dfdb_ctx_destroy: the parked stream dies with its context
+void stream_drop_parked(dfdb_ctx* ctx);
+// K9: codes + dictionary for String column `ordinal` if it has at most max_entries distinct values; returns the number of entries (0: none built)
+int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries);   // dfdb_ctx_destroy: the parked stream dies with its context
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp

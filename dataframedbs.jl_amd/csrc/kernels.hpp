@@ -100,6 +100,27 @@ void launch_str_gather_sizes(hipStream_t s, const uint64_t* bitmap, const uint64
 void launch_str_gather_bytes(hipStream_t s, const uint64_t* bitmap, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes,
                              const uint64_t* out_tile_off, uint8_t* out_bytes, int64_t nrows, int64_t out_bytes_cap);
 
+// n rows that all hold the same string: sizes[i] = plen, bytes = the pattern (device memory) n times
+void launch_fill_const_strings(hipStream_t s, int32_t* out_sizes, uint8_t* out_bytes, int64_t n, const uint8_t* pat_dev, int32_t plen);
+
+// ---- K9: dictionary codes of a low-cardinality String column (k_dict.hip) ------------------------------
+struct DictSlot { uint64_t key8; uint32_t len, code, off, pad; };      // open addressing; len = 0xffffffff: empty.  key8 = the first min(len, 8) bytes
+struct DictMiss {                                                     // rows whose string is not in the table yet report here
+  unsigned long long* count; unsigned long long* bytes_used;          // rows reported in all; bytes of `arena` handed out
+  uint32_t* rec_off; int32_t* rec_len; uint8_t* arena;                // per reported row (the first max_records): its bytes in the arena (len -1: no room, -2: too long)
+  int64_t max_records, bytes_cap; int32_t max_len;
+};
+uint64_t dict_hash_host(uint64_t key8, uint32_t len);
+void launch_dict_encode(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const DictSlot* slots, uint32_t nslots,
+                        const uint8_t* dict_bytes, uint16_t* codes, int64_t nrows, const DictMiss& miss);
+// lut: one bit per code, 1 = the row is selected; lut_words = ceil(entries / 32) <= 2048
+void launch_dict_scan(hipStream_t s, const uint16_t* codes, const uint32_t* lut, int32_t lut_words, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
+                      bool and_existing);
+// the projection of a dictionary column over n selected rows whose codes K3 has compacted: sizes + per-1024-output-row byte totals, then the bytes
+void launch_dict_expand_sizes(hipStream_t s, const uint16_t* codes, int64_t n, const int32_t* dict_len, int32_t* out_sizes, uint32_t* out_tile_bytes);
+void launch_dict_expand_bytes(hipStream_t s, const uint16_t* codes, int64_t n, const int32_t* dict_len, const uint32_t* dict_off, const uint8_t* dict_bytes,
+                              const uint64_t* out_tile_off, uint8_t* out_bytes, int64_t out_bytes_cap);
+
 // ---- reductions ------------------------------------------------------------------------------------
 // sum/min/max of a fixed-width column over the selected rows -> partials then final (2 launches)
 void launch_reduce(hipStream_t s, const uint64_t* bitmap, const void* col, int32_t dtype, int op, int64_t nrows, void* partials,

@@ -276,12 +276,35 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   for (const Node* c : strs) {
     int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
     const Column& col = need_resident(t, ord);
+    // `col == "const"` is an AND-ed conjunct of this stage, and later stages only remove rows: every row the query finally selects holds exactly
+    // `const` in this column, so its projection needs neither the column nor a capture (materialize_col: launch_fill_const_strings)
+    if (mode == 0) { q->const_str_col = ord; q->const_str = pat; }
+    if (col.dict_n > 0) {
+      // K9: the column has a dictionary — the term is decided once per distinct string on the host, the rows are a bit-table lookup of their codes
+      const int32_t words = (col.dict_n + 31) / 32;
+      std::vector<uint32_t> lut((size_t)words, 0u);
+      for (int32_t k = 0; k < col.dict_n; k++) {
+        const std::string& e = col.dict_host[(size_t)k];
+        bool r;
+        if (mode <= 1) { r = e == pat; if (mode == 1) r = !r; }
+        else if (mode == 2) r = e.size() >= pat.size() && e.compare(0, pat.size(), pat) == 0;
+        else r = e.size() >= pat.size() && e.compare(e.size() - pat.size(), pat.size(), pat) == 0;
+        if (r) lut[(size_t)k >> 5] |= 1u << (k & 31);
+      }
+      DevBuf& lb = q->tmp_a; lb.ensure((size_t)words * 4 + 64);
+      HIP_CHECK(hipMemcpyAsync(lb.p, lut.data(), (size_t)words * 4, hipMemcpyHostToDevice, s));
+      stream_wait(q->t->ctx);                                      // `lut` is pageable host memory
+      LaunchTimer lt(ctx, "dict_scan");
+      launch_dict_scan(s, col.dict_codes.as<uint16_t>(), lb.as<uint32_t>(), words, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+      have = true;
+      continue;
+    }
     DevBuf& pb = q->tmp_a; pb.ensure(pat.size() + 64);
     if (pat.size() > 16) { HIP_CHECK(hipMemcpyAsync(pb.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s)); stream_wait(q->t->ctx); }   // (bytes past 16 are compared against the device copy)
     // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask and the column it reads is
     // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
     StrCapture capture{nullptr, nullptr, nullptr};
-    bool do_cap = q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 64;
+    bool do_cap = mode != 0 && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 64;
     if (do_cap) {
       do_cap = false;
       for (const ProjCol& p : q->proj) if (p.expr->op == DFIR_COL && p.expr->col == ord) { do_cap = true; break; }
@@ -416,7 +439,7 @@ void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
-  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
   if (nstages == 0) {
     LaunchTimer lt(ctx, "fill_ones");
     launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
@@ -501,6 +524,22 @@ static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_
   DevBuf& scratch = q->str_scratch; scratch.ensure(scan_counts_scratch_bytes(nct));
   int32_t* dst_sizes = out_sizes;
   if (!dst_sizes) { out_sizes_tmp.ensure((size_t)std::max<int64_t>(cap, 1) * 4); dst_sizes = out_sizes_tmp.as<int32_t>(); }
+  if (col.dict_n > 0) {
+    // K9: the selected rows' codes, compacted by K3 (kept in q->dict_sel for the bytes pass), then sizes and byte totals per 1024 OUTPUT rows
+    const int64_t n = std::min<int64_t>(cap, query_count(q, -1));
+    const int64_t not_ = ceil_div(std::max<int64_t>(n, 1), kTileRows);
+    q->dict_sel.ensure((size_t)std::max<int64_t>(n, 1) * 2 + 256);
+    { LaunchTimer lt(ctx, "gather"); launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.dict_codes.p, q->dict_sel.p, 2, q->t->nrows, n); }
+    DevBuf& otb = q->tmp_c; otb.ensure((size_t)(not_ + 8) * 4);
+    tile_off_out.ensure((size_t)(not_ + 8) * 8);
+    scratch.ensure(scan_counts_scratch_bytes(not_));
+    HIP_CHECK(hipMemsetAsync(otb.p, 0, (size_t)(not_ + 8) * 4, s));
+    { LaunchTimer lt(ctx, "dict_expand_sizes"); launch_dict_expand_sizes(s, q->dict_sel.as<uint16_t>(), n, col.dict_len.as<int32_t>(), dst_sizes, otb.as<uint32_t>()); }
+    launch_scan_counts(s, otb.as<uint32_t>(), tile_off_out.as<uint64_t>(), not_, scratch.as<uint64_t>());
+    HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 1, tile_off_out.as<uint64_t>() + not_, 8, hipMemcpyDeviceToHost, s));
+    stream_wait(q->t->ctx);
+    return ctx->pinned_scalar[1];
+  }
   if (string_captured(q, col)) {     // K5 kept the selected rows: their byte totals per tile are already there
     launch_scan_counts(s, q->cap_str_tb.as<uint32_t>(), tile_off_out.as<uint64_t>(), nct, scratch.as<uint64_t>());
     HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar + 1, tile_off_out.as<uint64_t>() + nct, 8, hipMemcpyDeviceToHost, s));
@@ -523,6 +562,7 @@ int64_t query_string_bytes(dfdb_query* q, int i) {
   if (e.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "computed String columns are outside the IR");
   const Column& col = need_resident(q->t, e.col);
   const int64_t cnt = query_count(q, -1);
+  if (q->const_str_col == e.col && q->executed_stages == (int)q->stages.size()) return cnt * (int64_t)q->const_str.size();
   return string_out_offsets(q, col, q->str_sizes, nullptr, cnt, q->str_toff);
 }
 
@@ -538,6 +578,23 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
   if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
     const Column& col = need_resident(t, e.col);
     if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
+      if (q->const_str_col == e.col && q->executed_stages == (int)q->stages.size()) {   // every selected row holds q->const_str (run_predicate)
+        const int64_t plen = (int64_t)q->const_str.size(), total = cnt * plen;
+        o.nbytes = total;
+        if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
+        DevBuf &csz = q->str_sizes, &cby = q->str_bytes;
+        int32_t* d_sizes = dev ? (int32_t*)o.data : (csz.ensure((size_t)cnt * 4), csz.as<int32_t>());
+        uint8_t* d_bytes = dev ? o.bytes : (cby.ensure((size_t)total + 64), cby.as<uint8_t>());
+        DevBuf& pb = q->tmp_a; pb.ensure((size_t)plen + 64);
+        if (plen) { HIP_CHECK(hipMemcpyAsync(pb.p, q->const_str.data(), (size_t)plen, hipMemcpyHostToDevice, s)); stream_wait(ctx); }
+        { LaunchTimer lt(ctx, "fill_const_strings"); launch_fill_const_strings(s, d_sizes, d_bytes, cnt, pb.as<uint8_t>(), (int32_t)plen); }
+        if (!dev) {
+          HIP_CHECK(hipMemcpyAsync(o.data, d_sizes, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+          if (total > 0) HIP_CHECK(hipMemcpyAsync(o.bytes, d_bytes, (size_t)total, hipMemcpyDeviceToHost, s));
+          stream_wait(ctx);
+        }
+        return;
+      }
       DevBuf &dsz = q->str_sizes, &toff = q->str_toff, &dbytes = q->str_bytes;   // reused across calls (hipFree would sync the device)
       int32_t* d_sizes = dev ? (int32_t*)o.data : nullptr;
       const int64_t total = string_out_offsets(q, col, dsz, d_sizes, cnt, toff);
@@ -546,7 +603,12 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
       if (total > o.bytes_cap) fail(DFDB_ERR_ARGUMENT, "output column %d needs %lld string bytes, capacity is %lld", p, (long long)total, (long long)o.bytes_cap);
       uint8_t* d_bytes = dev ? o.bytes : nullptr;
       if (!dev) { dbytes.ensure((size_t)total + 64); d_bytes = dbytes.as<uint8_t>(); }
-      if (string_captured(q, col)) {     // sizes and bytes: one contiguous copy per tile out of the match pass's capture
+      if (col.dict_n > 0) {              // K9: the compacted codes of string_out_offsets -> bytes out of the dictionary
+        if (total > 0) {
+          LaunchTimer lt(ctx, "dict_expand_bytes");
+          launch_dict_expand_bytes(s, q->dict_sel.as<uint16_t>(), cnt, col.dict_len.as<int32_t>(), col.dict_off.as<uint32_t>(), col.dict_bytes.as<uint8_t>(), toff.as<uint64_t>(), d_bytes, total);
+        }
+      } else if (string_captured(q, col)) {     // sizes and bytes: one contiguous copy per tile out of the match pass's capture
         LaunchTimer lt(ctx, "str_compact_captured");
         const StrCapture sc{q->cap_str_sizes.as<int32_t>(), q->cap_str_bytes.as<uint8_t>(), q->cap_str_tb.as<uint32_t>()};
         launch_str_compact_captured(s, sc, q->prefix.as<uint64_t>(), (const int64_t*)col.tile_off.p, toff.as<uint64_t>(), d_sizes, d_bytes, t->nrows, cnt, total);

@@ -11,6 +11,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <thread>
+#include <unordered_map>
 #include <unistd.h>
 
 namespace dfdb {
@@ -160,6 +161,8 @@ void table_add_column(dfdb_table* t, const char* name, int32_t dtype, int64_t nr
   HIP_CHECK(hipStreamSynchronize(s));
   c.resident = true;
   rb.armed = false;
+  if (dt_base(dtype) == DFDB_STRING && !dt_nullable(dtype))
+    if (const int64_t dn = ctx_option(t->ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(t->cols.size() - 1), dn);
 }
 
 void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t seed, int64_t row_first, int64_t nrows) {
@@ -197,7 +200,9 @@ void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t 
       c.bytes.ensure((size_t)total + 64);
       HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + total, 0, 64, s));
       launch_gen_brand_bytes(s, c.data.as<int32_t>(), (const int64_t*)c.tile_off.p, c.bytes.as<uint8_t>(), seed, row_first, nrows);
-      c.resident = true; break;
+      c.resident = true;
+      if (const int64_t dn = ctx_option(t->ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(t->cols.size() - 1), dn);
+      break;
     }
     default: fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
   }
@@ -306,6 +311,9 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
   }
   if (t->nrows < 0) { t->nrows = nrows; t->block_first = block_first; t->row_base = block_first * t->block_size; }
   c.resident = true;
+  c.dict_n = 0; c.dict_host.clear();
+  if (is_str && !is_null && !t->keep_load_scratch)                 // (keep_load_scratch: a stream slot, whose columns live for one chunk)
+    if (const int64_t dn = ctx_option(ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(&c - t->cols.data()), dn);
   if (!is_str && !is_null && nb && ctx_option(ctx, "keep_compressed", 0) != 0) {   // the compressed blocks stay: dfdb_table_decode_resident
     HIP_CHECK(hipStreamSynchronize(s));
     c.comp = std::move(staged); c.comp_blocks = std::move(dblocks); c.comp_status = std::move(dstatus); c.comp_nblocks = nb;
@@ -435,6 +443,93 @@ void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size
   dfdb_sizestats st{0, 0, 0};
   load_from_image(t, c, image, nbytes, hr.pos, block_first, block_last, &st);
   if (stats) *stats = st;
+}
+
+// ---------------------------------------------------------------- K9: dictionary of a low-cardinality String column
+// The dictionary starts from the distinct strings of the column's first rows; k_dict_encode then codes every row against an open-addressing
+// table of it and reports the rows it could not code (their strings land in a staging arena); the host adds those and runs the pass again.
+// Gives up (returns 0, nothing kept) past max_entries, for a nullable column, or for a string too long for the staging arena.
+int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  if (dt_base(c.dtype) != DFDB_STRING) fail(DFDB_ERR_ARGUMENT, "ArgumentError: column %s is not a String column", c.name.c_str());
+  if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  c.dict_n = 0; c.dict_host.clear();
+  if (dt_nullable(c.dtype) || c.nrows <= 0) return 0;
+  if (max_entries <= 0) return 0;
+  if (max_entries > 65535) max_entries = 65535;                   // 0xffff is "not coded"
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  constexpr int64_t kMaxRecords = 8192; constexpr int32_t kMaxLen = 4096; constexpr int64_t kArena = 4 << 20;
+  std::vector<std::string> dict;
+  std::unordered_map<std::string, uint32_t> index;
+  auto add = [&](std::string&& v) { if (index.emplace(v, (uint32_t)dict.size()).second) dict.push_back(std::move(v)); };
+  // seed: the first tile's rows
+  {
+    const int64_t m = std::min<int64_t>(c.nrows, kStrTileRows);
+    std::vector<int32_t> sz((size_t)m);
+    HIP_CHECK(hipMemcpyAsync(sz.data(), c.data.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    int64_t nb = 0; for (int32_t v : sz) nb += v > 0 ? v : 0;
+    std::vector<uint8_t> by((size_t)nb + 1);
+    if (nb) HIP_CHECK(hipMemcpy(by.data(), c.bytes.p, (size_t)nb, hipMemcpyDeviceToHost));
+    int64_t o = 0;
+    for (int32_t v : sz) { const int64_t l = v > 0 ? v : 0; add(std::string((const char*)by.data() + o, (size_t)l)); o += l; if ((int64_t)dict.size() > max_entries) return 0; }
+  }
+  DevBuf codes, slots, dbytes, mcount, moff, mlen, marena;
+  codes.ensure((size_t)round_up(c.nrows, kCTileRows) * 2 + 256);
+  mcount.ensure(64); moff.ensure(kMaxRecords * 4); mlen.ensure(kMaxRecords * 4); marena.ensure(kArena + 64);
+  std::vector<uint32_t> off_host;
+  for (int round = 0; round < 64; round++) {
+    // the table: 4 x entries slots, a power of two
+    uint32_t nslots = 64; while (nslots < 4 * dict.size()) nslots <<= 1;
+    std::vector<DictSlot> hs(nslots, DictSlot{0, 0xffffffffu, 0, 0, 0});
+    std::vector<uint8_t> hb; off_host.assign(dict.size(), 0);
+    for (size_t k = 0; k < dict.size(); k++) { off_host[k] = (uint32_t)hb.size(); hb.insert(hb.end(), dict[k].begin(), dict[k].end()); }
+    hb.resize(hb.size() + 64, 0);                                    // (8-byte probes read past the last entry)
+    for (size_t k = 0; k < dict.size(); k++) {
+      const uint32_t len = (uint32_t)dict[k].size();
+      uint64_t key8 = 0; memcpy(&key8, dict[k].data(), std::min<size_t>(8, len));
+      uint32_t at = (uint32_t)dict_hash_host(key8, len) & (nslots - 1);
+      while (hs[at].len != 0xffffffffu) at = (at + 1) & (nslots - 1);
+      hs[at] = DictSlot{key8, len, (uint32_t)k, off_host[k], 0};
+    }
+    slots.ensure(hs.size() * sizeof(DictSlot)); dbytes.ensure(hb.size());
+    HIP_CHECK(hipMemcpyAsync(slots.p, hs.data(), hs.size() * sizeof(DictSlot), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(dbytes.p, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(mcount.p, 0, 64, s));
+    HIP_CHECK(hipStreamSynchronize(s));                               // hs / hb are pageable host memory
+    DictMiss miss{(unsigned long long*)mcount.p, (unsigned long long*)mcount.p + 1, moff.as<uint32_t>(), mlen.as<int32_t>(), marena.as<uint8_t>(), kMaxRecords, kArena, kMaxLen};
+    { LaunchTimer lt(ctx, "dict_encode");
+      launch_dict_encode(s, c.data.as<int32_t>(), (const int64_t*)c.tile_off.p, c.bytes.as<uint8_t>(), slots.as<DictSlot>(), nslots, dbytes.as<uint8_t>(), codes.as<uint16_t>(), c.nrows, miss); }
+    unsigned long long cnt[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(cnt, mcount.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (cnt[0] == 0) {                                                // every row has its code: keep
+      c.dict_codes = std::move(codes); c.dict_bytes = std::move(dbytes);
+      std::vector<int32_t> lens(dict.size()); for (size_t k = 0; k < dict.size(); k++) lens[k] = (int32_t)dict[k].size();
+      c.dict_len.ensure(lens.size() * 4 + 64); c.dict_off.ensure(off_host.size() * 4 + 64);
+      HIP_CHECK(hipMemcpy(c.dict_len.p, lens.data(), lens.size() * 4, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(c.dict_off.p, off_host.data(), off_host.size() * 4, hipMemcpyHostToDevice));
+      c.dict_host = std::move(dict); c.dict_n = (int32_t)c.dict_host.size();
+      return c.dict_n;
+    }
+    const int64_t nrec = (int64_t)std::min<unsigned long long>(cnt[0], (unsigned long long)kMaxRecords);
+    std::vector<uint32_t> ro((size_t)nrec); std::vector<int32_t> rl((size_t)nrec);
+    const size_t used = (size_t)std::min<unsigned long long>(cnt[1], (unsigned long long)kArena);
+    std::vector<uint8_t> ar(used + 1);
+    HIP_CHECK(hipMemcpy(ro.data(), moff.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(rl.data(), mlen.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+    if (used) HIP_CHECK(hipMemcpy(ar.data(), marena.p, used, hipMemcpyDeviceToHost));
+    size_t before = dict.size();
+    for (int64_t k = 0; k < nrec; k++) {
+      if (rl[(size_t)k] == -2) return 0;                              // a string longer than the dictionary takes
+      if (rl[(size_t)k] < 0) continue;                                // no room this round
+      add(std::string((const char*)ar.data() + ro[(size_t)k], (size_t)rl[(size_t)k]));
+      if ((int64_t)dict.size() > max_entries) return 0;
+    }
+    if (dict.size() == before) return 0;                              // (cannot happen: a reported row always adds its string)
+  }
+  return 0;
 }
 
 void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {

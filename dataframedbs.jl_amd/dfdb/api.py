@@ -358,6 +358,13 @@ class DFTable:
         """K7 over the LZ4 blocks the column kept in HBM (ctx option keep_compressed at load time), asynchronously"""
         N.check(N.load().dfdb_table_decode_resident(self._h, self.ordinal(column)))
 
+    def build_dictionary(self, column: str, max_entries: int = 4096) -> int:
+        """K9: 16-bit codes + the distinct strings of a resident String column (kept beside its flat form); returns the number of distinct
+        strings, 0 when none was built (more than max_entries, nullable, a string over 4 KB).  Results of every query stay the same."""
+        n = C.c_int64()
+        N.check(N.load().dfdb_table_build_dictionary(self._h, self.ordinal(column), max_entries, C.byref(n)))
+        return n.value
+
     def set_row_base(self, row_base: int): N.check(N.load().dfdb_table_set_row_base(self._h, row_base))
 
     def add_column_from(self, name: str, col) -> None:

@@ -164,12 +164,17 @@ function device()
     if DEV[] === nothing
         ctx = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dfdb_ctx_create, LIB), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), 0, C_NULL, ctx))
+        # String columns with at most DFDB_STRING_DICTIONARY (default 4096) distinct values get 16-bit codes beside their flat form when they are
+        # loaded: `t.brand .== "sony"` then scans 2 bytes per row (include/dfdb.h: dfdb_table_build_dictionary); 0 turns it off
+        dictn = something(tryparse(Int, get(ENV, "DFDB_STRING_DICTIONARY", "")), 4096)
+        check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "string_dictionary", dictn))
         grp = Ref{Ptr{Cvoid}}(C_NULL)
         n = ngpus()
         if n > 1
             ids = Int32[i for i in 0:n-1]
             # exchange = 0 (DFDB_EXCHANGE_AUTO): RCCL over xGMI for distinct devices
             GC.@preserve ids check(ccall((:dfdb_group_create, LIB), Int32, (Ptr{Int32}, Int32, Int32, Ptr{Ptr{Cvoid}}), ids, n, 0, grp))
+            check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "string_dictionary", dictn))
         end
         DEV[] = Device(ctx[], grp[], Dict{String,Ptr{Cvoid}}(), Dict{String,Ptr{Cvoid}}())
     end

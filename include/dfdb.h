@@ -114,6 +114,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     and the column keeps the fastest for the queries that scan it (query.cpp: place_mask; default 0: 27 scans + 0.03-1.4 s of allocations once
  *                     per column buys ~3 % of K1 on average; bench.py turns it on); "placement_spacer_mb" (12288) / "placement_candidates" (8) size the search
  *   "compact_store"   K2's index stores: 0 plain, 1 nontemporal (default: 10 % slower alone, but the scan that follows runs 4-7 % faster), 2 write-through
+ *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
  *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
@@ -186,6 +187,13 @@ int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* 
  * read_block: BlockStreams.jl:101-119) over all of them again, asynchronously, into the resident array.  It is the device-side
  * equivalent of re-reading the column through BlockStream and what bench.py's decode-inclusive figure times. */
 int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal);
+/* Dictionary form of a resident, non-nullable String column with at most max_entries (<= 65535) distinct values: one 16-bit code per row and the
+ * distinct strings once, kept BESIDE the FlatStringsVector form (the reference has no such form: docs/src/index.md lists dictionary encoding under
+ * "Future plans").  From then on `col == / != / startswith / endswith "const"` is decided once per distinct string and becomes a bit-table lookup of
+ * the codes (2 B per row instead of 4 + L), and materialize copies the selected rows' strings out of the dictionary; results are unchanged.
+ * *entries = the dictionary's size, 0 when none was built (too many distinct values, a nullable column, a string over 4 KB).  ctx option
+ * "string_dictionary" = N > 0 builds one automatically, with max_entries = N, whenever a String column becomes resident. */
+int32_t dfdb_table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries, int64_t* entries);
 
 /* declare a caller-supplied Int64 / UInt32 column to be one of the bits types above, so that dfdb_table_save writes that type
  * string and the reference's open_table reads the column back as Date / DateTime / Time / Char */

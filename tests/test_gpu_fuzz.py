@@ -14,8 +14,8 @@ N = 12_345
 SCALE = int(os.environ.get("DFDB_FUZZ_SCALE", "1"))      # DFDB_FUZZ_SCALE=20 python -m pytest tests/test_gpu_fuzz.py: 20 x the seeds
 
 
-@pytest.fixture(scope="module")
-def pair(oracle, dfdb_mod):
+@pytest.fixture(scope="module", params=["flat strings", "string dictionary"])
+def pair(oracle, dfdb_mod, request):
     rng = np.random.default_rng(2024)
     f64 = rng.normal(0, 50, N); f64[::101] = np.nan; f64[5::997] = np.inf; f64[7::991] = -0.0
     f32 = rng.normal(0, 8, N).astype(np.float32); f32[::113] = np.nan
@@ -34,7 +34,10 @@ def pair(oracle, dfdb_mod):
         "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)],   # 11
         "z": rng.integers(-2, 3, N).astype(np.int64),                         # 12 (zeros: a divisor that raises)
     }
-    return Pair(oracle, dfdb_mod, cols, block_size=1000)
+    p = Pair(oracle, dfdb_mod, cols, block_size=1000)
+    if request.param == "string dictionary":             # K9: every string predicate and projection of `s` goes through the codes
+        assert p.d.build_dictionary("s") == len(set(cols["s"]))
+    return p
 
 
 NUM_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 8]

@@ -408,12 +408,16 @@ def test_string_capture_in_match_pass(oracle, dfdb_mod, ctx, n):
                      ir.col(0) == "microsoft", ir.col(0) != "microsoftware", ir.startswith(ir.col(0), "microsoft"), ir.endswith(ir.col(0), "osoftware"),
                      ir.endswith(ir.col(0), "icrosoft"), ir.col(0) == "a-rather-long-category-name-that-needs-several-probes-to-compare",
                      ir.startswith(ir.col(0), "a-rather-long-category-name-that-needs-several-probes-to-compar")):
-            n0, _ = ctx.profile_get("str_compact_captured")
+            n0, _ = ctx.profile_get("str_compact_captured"); f0, _ = ctx.profile_get("fill_const_strings")
             ov, dv = apply_stages(p, [("pred", pred)])
             assert_same(p, ov, dv)
-            n1, _ = ctx.profile_get("str_compact_captured")
+            n1, _ = ctx.profile_get("str_compact_captured"); f1, _ = ctx.profile_get("fill_const_strings")
             if ov.nrow() > 0:
-                assert n1 > n0, "the capture path did not run"
+                # `col == "const"` pins the projected column to one value: it is written out as a constant, nothing is captured or gathered
+                if pred.op == ir.EQ:
+                    assert f1 > f0 and n1 == n0, "the constant-column path did not run"
+                else:
+                    assert n1 > n0, "the capture path did not run"
     finally:
         ctx.profile(False)
 
@@ -979,3 +983,69 @@ def test_rem_by_a_constant_is_a_scan_term(oracle, dfdb_mod, ctx, dtype):
             dv._query().count()
     finally:
         ctx.profile(False)
+
+
+def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_path):
+    """K9: a dictionary (16-bit codes + the distinct strings) beside a low-cardinality String column turns == / != / startswith / endswith into a
+    bit-table lookup of the codes and the column's projection into copies out of the dictionary.  Every answer must be the oracle's, with the dictionary
+    built explicitly, automatically (ctx option string_dictionary) for host arrays / generated columns / files, alone and inside longer queues; columns
+    it cannot take (too many distinct values, nullable, a 5-KB string) keep working through the flat kernels."""
+    from dfdb import ir
+    rng = np.random.default_rng(9)
+    n = 70_001
+    words = ["", "a", "sony", "sonya", "huawei", "apple", "apple pie", "xiaomi-redmi-note-12", "é", "日本語", "0123456789abcdef0123456789abcdef0123456789", "so"]
+    s = [words[int(k)] for k in rng.integers(0, len(words), n)]
+    a = rng.integers(0, 1000, n).astype(np.int64)
+    many = ["v%d" % int(k) for k in rng.integers(0, 9000, n)]                 # 9000 distinct values
+    p = Pair(oracle, dfdb_mod, {"s": s, "a": a, "many": many}, block_size=4096)
+    t = p.d
+    assert t.build_dictionary("s") == len(set(s))
+    assert t.build_dictionary("many", 4096) == 0 and t.build_dictionary("many", 20000) == len(set(many))
+    S, A, M = ir.col(0), ir.col(1), ir.col(2)
+    ctx.profile(True)
+    try:
+        n0, _ = ctx.profile_get("str_match")
+        d0, _ = ctx.profile_get("dict_scan")
+        cases = [[("pred", S == "sony")], [("pred", S != "sony")], [("pred", S == "nokia")], [("pred", S != "nokia")], [("pred", S == "")],
+                 [("pred", ir.startswith(S, "so"))], [("pred", ir.endswith(S, "a"))], [("pred", ir.startswith(S, ""))], [("pred", ir.endswith(S, "日本語"))],
+                 [("pred", S == "0123456789abcdef0123456789abcdef0123456789")], [("pred", (S == "apple") & (A > 500))], [("pred", (A > 500) & (S != "apple") & ir.startswith(S, "a"))],
+                 [("range", 100, 3, 60_000), ("pred", S == "huawei")], [("pred", A < 300), ("range", 5, 1, 2000), ("pred", ir.endswith(S, "i"))],
+                 [("pred", M == "v17")], [("pred", ir.startswith(M, "v89") & (S == "é"))], [("pred", (S == "sony") | (A == 7))], [("idx", [5, 77, 4096, 70_001])]]
+        for stages in cases:
+            ov, dv = apply_stages(p, stages)
+            assert_same(p, ov, dv)
+            ov, dv = apply_stages(p, stages, proj=[("s", S), ("k", A * 2)])
+            assert_same(p, ov, dv)
+        n1, _ = ctx.profile_get("str_match")
+        d1, _ = ctx.profile_get("dict_scan")
+        g1, _ = ctx.profile_get("dict_expand_bytes")
+        assert n1 == n0 and d1 > d0 and g1 > 0                       # K5 never ran: the dictionary kernels did
+    finally:
+        ctx.profile(False)
+    # automatic, for every way a String column becomes resident
+    ctx.set_option("string_dictionary", 64)
+    try:
+        path = str(tmp_path / "tb")
+        p2 = Pair(oracle, dfdb_mod, {"s": s, "a": a, "many": many}, block_size=5000, via_files=path)      # files (device LZ4 decode + unpack)
+        g = dfdb_mod.DFTable.new(); g.add_generated("b", dfdb_mod.GEN_STR_BRANDS10, 3, 50_000)             # generated
+        nullable = [None if k % 7 == 0 else w for k, w in enumerate(s)]
+        p3 = Pair(oracle, dfdb_mod, {"s": nullable, "big": ["x" * 5000 if k == 9 else "y" for k in range(n)]}, block_size=4096)
+        ctx.profile(True)
+        d0, _ = ctx.profile_get("dict_scan"); k0, _ = ctx.profile_get("str_match")
+        for stages in ([("pred", S == "sony")], [("pred", ir.startswith(S, "app") & (A < 900))]):
+            ov, dv = apply_stages(p2, stages, proj=[("s", S), ("a", A)])
+            assert_same(p2, ov, dv)
+        assert dfdb_mod.nrow(g[g.b == "sony", dfdb_mod.ALL]) == int((np.array(oracle.flat_to_strings(*oracle.gen_str(3, 0, 50_000)), dtype=object) == "sony").sum())
+        d1, _ = ctx.profile_get("dict_scan"); k1, _ = ctx.profile_get("str_match")
+        assert d1 >= d0 + 3 and k1 == k0
+        ov, dv = apply_stages(p2, [("pred", M == "v17")], proj=[("many", M)])                              # 9000 distinct > 64: the flat kernels
+        assert_same(p2, ov, dv)
+        for stages in ([("pred", ir.col(1) == "y")], [("pred", ir.startswith(ir.col(1), "xx"))], [("range", 3, 2, 5000)]):   # nullable / a 5-KB string: no dictionary
+            ov, dv = apply_stages(p3, stages, proj=[("s", ir.col(0)), ("big", ir.col(1))])
+            assert_same(p3, ov, dv)
+        k2, _ = ctx.profile_get("str_match")
+        assert k2 > k1
+        ctx.profile(False)
+        g.close()
+    finally:
+        ctx.set_option("string_dictionary", 0)
