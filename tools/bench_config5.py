@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--total-rows", type=float, default=0.0, help="rows of the whole table (default: 1.25e9 per rank)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-dictionary", action="store_true", help="keep the String column flat only (no K9 codes beside it)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -47,6 +48,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = dfdb.Context(local, stream=stream.cuda_stream)
+    if not args.no_dictionary:
+        ctx.set_option("string_dictionary", 4096)       # s has 10 distinct values: 16-bit codes beside the flat column, s != "sony" scans those
     bs = 65536
     total = int(args.total_rows) if args.total_rows else 1_250_000_000 * world
     r0, r1 = sharding.row_range(total, bs, rank, world)
@@ -88,7 +91,9 @@ def main():
         sec = dt.item() / args.steps
         bytes_row = 8 + 8 + 4 + 5.4            # predicate columns a, x, sizes + bytes of s
         print(json.dumps({"config": 5, "n_gpus": world, "total_rows": total, "rows_per_gpu": n, "count": int(res[0].item()), "sum_x": res[1].item(),
-                          "ms_per_step": sec * 1e3, "rows_per_s": total / sec, "algorithmic_GBps": total * bytes_row / sec / 1e9}))
+                          "ms_per_step": sec * 1e3, "rows_per_s": total / sec, "algorithmic_GBps": total * bytes_row / sec / 1e9,
+                          "string_dictionary": not args.no_dictionary,
+                          "note": "algorithmic bytes count the flat String column (4 + 5.4 B/row); with the dictionary the scan of s reads 2 B/row, so the figure can exceed what HBM delivers"}))
     if world > 1:
         dist.destroy_process_group()
 
