@@ -13,6 +13,7 @@
 #include "engine.hpp"
 #include <algorithm>
 #include <chrono>
+#include <functional>
 
 namespace dfdb {
 
@@ -191,6 +192,21 @@ static void scan_prefix(dfdb_query* q) {
   q->prefix_valid = true;
 }
 
+// K9: does dictionary entry `e` satisfy the string term (mode 0 ==, 1 !=, 2 startswith, 3 endswith; k_strings.hip's modes)?
+static bool dict_entry_matches(const std::string& e, int mode, const std::string& pat) {
+  if (mode <= 1) { const bool r = e == pat; return mode == 1 ? !r : r; }
+  if (mode == 2) return e.size() >= pat.size() && e.compare(0, pat.size(), pat) == 0;
+  return e.size() >= pat.size() && e.compare(e.size() - pat.size(), pat.size(), pat) == 0;
+}
+static void run_dict_scan(dfdb_query* q, const Column& col, const std::vector<uint32_t>& lut, bool have) {
+  dfdb_ctx* ctx = q->t->ctx; hipStream_t s = ctx->stream;
+  DevBuf& lb = q->tmp_a; lb.ensure(lut.size() * 4 + 64);
+  HIP_CHECK(hipMemcpyAsync(lb.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
+  stream_wait(ctx);                                      // `lut` is pageable host memory
+  LaunchTimer lt(ctx, "dict_scan");
+  launch_dict_scan(s, col.dict_codes.as<uint16_t>(), lb.as<uint32_t>(), (int32_t)lut.size(), q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), q->t->nrows, have);
+}
+
 // predicate stage = AND of its conjuncts, each routed to the cheapest kernel that is exact for it
 static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, bool last_stage) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
@@ -230,6 +246,27 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     return out.n >= 2;
   };
   // ismissing(col) / !ismissing(col) over a nullable fixed-width column: its missing bitmap is the mask
+  // a disjunction (and negations) of string terms over ONE dictionary column — (brand == "sony") | (brand == "apple"), !startswith(brand, "x") — is a
+  // Boolean function of the dictionary entry: one bit-table lookup of the codes instead of string compares in the interpreter
+  struct DictLut { int ord; std::vector<uint32_t> lut; };
+  std::vector<DictLut> dict_luts;
+  std::function<bool(const Node&, int&)> dict_only = [&](const Node& n, int& ord) -> bool {
+    if ((n.op == DFIR_OR || n.op == DFIR_AND || n.op == DFIR_XOR) && n.a && n.b) return dict_only(*n.a, ord) && dict_only(*n.b, ord);
+    if (n.op == DFIR_NOT && n.a) return dict_only(*n.a, ord);
+    int o, mode; std::string pat;
+    if (!match_string_term(n, *t, o, mode, pat)) return false;
+    if (ord >= 0 && o != ord) return false;
+    if (t->cols[(size_t)o].dict_n <= 0 || !t->cols[(size_t)o].resident) return false;
+    ord = o; return true;
+  };
+  std::function<bool(const Node&, const std::string&)> dict_eval = [&](const Node& n, const std::string& e) -> bool {
+    if (n.op == DFIR_OR) return dict_eval(*n.a, e) | dict_eval(*n.b, e);
+    if (n.op == DFIR_AND) return dict_eval(*n.a, e) & dict_eval(*n.b, e);
+    if (n.op == DFIR_XOR) return dict_eval(*n.a, e) ^ dict_eval(*n.b, e);
+    if (n.op == DFIR_NOT) return !dict_eval(*n.a, e);
+    int o, mode; std::string pat; match_string_term(n, *t, o, mode, pat);
+    return dict_entry_matches(e, mode, pat);
+  };
   struct MissTerm { const uint64_t* bits; bool negate; };
   std::vector<MissTerm> miss;
   auto match_missing = [&](const Node& n, MissTerm& out) {
@@ -246,6 +283,16 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     ScanTerms ob;
     MissTerm mt;
     if (match_missing(*c, mt)) { miss.push_back(mt); continue; }
+    if (c->op == DFIR_OR || c->op == DFIR_NOT || c->op == DFIR_XOR) {
+      int dord = -1;
+      if (dict_only(*c, dord) && dord >= 0) {
+        const Column& dc = t->cols[(size_t)dord];
+        DictLut dl{dord, std::vector<uint32_t>((size_t)(dc.dict_n + 31) / 32, 0u)};
+        for (int32_t k = 0; k < dc.dict_n; k++) if (dict_eval(*c, dc.dict_host[(size_t)k])) dl.lut[(size_t)k >> 5] |= 1u << (k & 31);
+        dict_luts.push_back(std::move(dl));
+        continue;
+      }
+    }
     if ((c->op == DFIR_OR || c->op == DFIR_IN_SET) && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
@@ -273,6 +320,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     for (size_t i = 1; i < generic.size(); i++) all = make_and(std::move(all), generic[i]->clone());
     run_interp_predicate(q, *all, have); have = true;
   }
+  for (const DictLut& dl : dict_luts) { run_dict_scan(q, t->cols[(size_t)dl.ord], dl.lut, have); have = true; }
   for (const Node* c : strs) {
     int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
     const Column& col = need_resident(t, ord);
@@ -281,21 +329,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     if (mode == 0) { q->const_str_col = ord; q->const_str = pat; }
     if (col.dict_n > 0) {
       // K9: the column has a dictionary — the term is decided once per distinct string on the host, the rows are a bit-table lookup of their codes
-      const int32_t words = (col.dict_n + 31) / 32;
-      std::vector<uint32_t> lut((size_t)words, 0u);
-      for (int32_t k = 0; k < col.dict_n; k++) {
-        const std::string& e = col.dict_host[(size_t)k];
-        bool r;
-        if (mode <= 1) { r = e == pat; if (mode == 1) r = !r; }
-        else if (mode == 2) r = e.size() >= pat.size() && e.compare(0, pat.size(), pat) == 0;
-        else r = e.size() >= pat.size() && e.compare(e.size() - pat.size(), pat.size(), pat) == 0;
-        if (r) lut[(size_t)k >> 5] |= 1u << (k & 31);
-      }
-      DevBuf& lb = q->tmp_a; lb.ensure((size_t)words * 4 + 64);
-      HIP_CHECK(hipMemcpyAsync(lb.p, lut.data(), (size_t)words * 4, hipMemcpyHostToDevice, s));
-      stream_wait(q->t->ctx);                                      // `lut` is pageable host memory
-      LaunchTimer lt(ctx, "dict_scan");
-      launch_dict_scan(s, col.dict_codes.as<uint16_t>(), lb.as<uint32_t>(), words, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have);
+      std::vector<uint32_t> lut((size_t)(col.dict_n + 31) / 32, 0u);
+      for (int32_t k = 0; k < col.dict_n; k++) if (dict_entry_matches(col.dict_host[(size_t)k], mode, pat)) lut[(size_t)k >> 5] |= 1u << (k & 31);
+      run_dict_scan(q, col, lut, have);
       have = true;
       continue;
     }

@@ -1016,6 +1016,16 @@ def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_pat
             assert_same(p, ov, dv)
             ov, dv = apply_stages(p, stages, proj=[("s", S), ("k", A * 2)])
             assert_same(p, ov, dv)
+        # Boolean combinations of string terms over the one dictionary column: a function of the entry, one lookup (never the interpreter)
+        i0, _ = ctx.profile_get("interp_predicate")
+        for pred in ((S == "sony") | (S == "apple"), ~(S == "sony"), ~ir.startswith(S, "a") | (S == ""), (S == "sony") ^ ir.endswith(S, "y"),
+                     ((S == "sony") | (S == "so") | ir.startswith(S, "hua")) & (A > 100), ~((S != "é") & ~ir.endswith(S, "語"))):
+            ov, dv = apply_stages(p, [("pred", pred)], proj=[("s", S), ("a", A)])
+            assert_same(p, ov, dv)
+        i1, _ = ctx.profile_get("interp_predicate")
+        assert i1 == i0
+        ov, dv = apply_stages(p, [("pred", (S == "sony") | (M == "v17"))])          # two different columns: the interpreter, same answer
+        assert_same(p, ov, dv)
         n1, _ = ctx.profile_get("str_match")
         d1, _ = ctx.profile_get("dict_scan")
         g1, _ = ctx.profile_get("dict_expand_bytes")
