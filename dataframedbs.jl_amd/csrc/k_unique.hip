@@ -328,6 +328,75 @@ __global__ __launch_bounds__(kBlock) void k_group_accumulate_str(const uint64_t*
 void launch_group_ids(hipStream_t s, const uint64_t* keys, uint64_t* rows, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
   hipLaunchKernelGGL(k_group_ids, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, rows, cap, special, ubits, uprefix);
 }
+// ---- K9 fast path: the key is a String column with a dictionary (k_dict.hip) — its 16-bit codes ARE group labels.  What is left of `unique` is the
+// first selected row of every code (the reference numbers groups by first appearance), and `groupreduce` accumulates by rank_of_code[code]: no hash
+// table (the generic path sizes one by the number of selected rows: 30 GB for 5e8 rows of ten brands).
+// A wave walks its tiles and the rows of a tile in increasing order, so the first time it meets a code is its smallest row for that code: a per-wave
+// bit set in LDS keeps every later meeting away from the global atomicMin (ten brands over 5e8 rows: <= waves x 10 atomics, not 5e8).
+__global__ __launch_bounds__(kBlock) void k_dict_first_rows(const uint64_t* __restrict__ sel, const uint16_t* __restrict__ codes, int64_t nrows, int64_t ntiles,
+                                                            unsigned long long* __restrict__ first, int lut_words) {
+  __shared__ uint32_t seen_sh[kBlock / 64][2048];
+  uint32_t* seen = seen_sh[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  for (int k = lane; k < lut_words; k += 64) seen[k] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    for (int j = 0; j < 16; j++) {
+      const uint64_t w = sel[tile * 16 + j];
+      if (w == 0) continue;                                                  // (wave-uniform)
+      const int64_t row = tile * 1024 + j * 64 + lane;
+      if (!((w >> lane) & 1ull) || row >= nrows) continue;
+      const uint32_t c = codes[row];
+      if ((seen[c >> 5] >> (c & 31u)) & 1u) continue;
+      atomicMin(&first[c], (unsigned long long)row);
+      atomicOr(&seen[c >> 5], 1u << (c & 31u));
+    }
+  }
+}
+void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* codes, int64_t nrows, uint64_t* first, int dict_n) {
+  const int64_t ntiles = (nrows + 1023) / 1024;
+  if (ntiles == 0) return;
+  hipLaunchKernelGGL(k_dict_first_rows, dim3(grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, codes, nrows, ntiles, (unsigned long long*)first, (dict_n + 31) / 32);
+}
+// the bitmap that holds exactly `rows` (ascending, n <= 65 535): what unique leaves behind
+__global__ void k_set_rows(const uint64_t* __restrict__ rows, int n, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = rows[i];
+  atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63));
+  atomicAdd(&tile_counts[r >> 10], 1u);
+}
+void launch_set_rows(hipStream_t s, const uint64_t* rows, int n, uint64_t* bitmap, uint32_t* tile_counts) {
+  if (n > 0) hipLaunchKernelGGL(k_set_rows, dim3((n + 255) / 256), dim3(256), 0, s, rows, n, bitmap, tile_counts);
+}
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_group_accumulate_codes(const uint64_t* __restrict__ sel, const uint16_t* __restrict__ codes, const uint32_t* __restrict__ rank_of_code,
+                                                                   const void* __restrict__ valcol, int valdt, int op, int64_t nrows, uint64_t* cnt, uint64_t* val,
+                                                                   int ngroups, uint64_t val_init) {
+  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
+  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
+  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
+    const uint64_t gid = rank_of_code[codes[row]];
+    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
+    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
+  }
+  if (LDS) {
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
+    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
+  }
+}
+void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uint16_t* codes, const uint32_t* rank_of_code, const void* valcol, int valdt, int op,
+                                   int64_t nrows, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
+  if (nrows <= 0) return;
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_codes<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, codes, rank_of_code, valcol, valdt, op, nrows, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate_codes<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, codes, rank_of_code, valcol, valdt, op, nrows, cnt, val, (int)ngroups, val_init);
+}
+
 int group_lds_limit() { return kGroupLds; }
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                              int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,

@@ -745,7 +745,41 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
 // unique(col) (column.jl:102-126 driving Base.unique; docs/src/index.md:171-182,479-486): the current selection is narrowed to
 // the rows that hold the FIRST occurrence of their value in projection column p (isequal semantics), so count / materialize
 // afterwards return the distinct values in order of first appearance.  A later reset / execute restores the full selection.
+void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* codes, int64_t nrows, uint64_t* first, int dict_n);
+void launch_set_rows(hipStream_t s, const uint64_t* rows, int n, uint64_t* bitmap, uint32_t* tile_counts);
+void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uint16_t* codes, const uint32_t* rank_of_code, const void* valcol, int valdt, int op,
+                                   int64_t nrows, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
 struct UniqueTables { DevBuf keys, rows, aux, rep_off, rep_len; uint64_t cap = 0, salt = 0; bool is_str = false; };
+// K9: unique over a String column that has a dictionary — the first selected row of every code, no hash table.  Leaves what unique_impl leaves (the
+// bitmap holds exactly the first occurrences, prefix scanned); rank_of_code (optional) maps a code to its group number in order of first appearance.
+static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_code) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int dn = col.dict_n;
+  DevBuf first; first.ensure((size_t)dn * 8 + 64);
+  HIP_CHECK(hipMemsetAsync(first.p, 0xFF, (size_t)dn * 8, s));
+  { LaunchTimer lt(ctx, "unique");
+    launch_dict_first_rows(s, q->bitmap.as<uint64_t>(), col.dict_codes.as<uint16_t>(), t->nrows, first.as<uint64_t>(), dn); }
+  std::vector<uint64_t> fr((size_t)dn);
+  HIP_CHECK(hipMemcpyAsync(fr.data(), first.p, (size_t)dn * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<std::pair<uint64_t, uint32_t>> present;
+  for (int k = 0; k < dn; k++) if (fr[(size_t)k] != ~0ull) present.emplace_back(fr[(size_t)k], (uint32_t)k);
+  std::sort(present.begin(), present.end());
+  const int64_t ng = (int64_t)present.size();
+  std::vector<uint64_t> rows((size_t)std::max<int64_t>(ng, 1));
+  std::vector<uint32_t> rank((size_t)dn, 0xffffffffu);
+  for (int64_t g = 0; g < ng; g++) { rows[(size_t)g] = present[(size_t)g].first; rank[present[(size_t)g].second] = (uint32_t)g; }
+  DevBuf drows; drows.ensure(rows.size() * 8 + 64);
+  HIP_CHECK(hipMemcpyAsync(drows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, s));
+  if (rank_of_code) { rank_of_code->ensure(rank.size() * 4 + 64); HIP_CHECK(hipMemcpyAsync(rank_of_code->p, rank.data(), rank.size() * 4, hipMemcpyHostToDevice, s)); }
+  HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
+  HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
+  launch_set_rows(s, drows.as<uint64_t>(), (int)ng, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
+  scan_prefix(q);
+  q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory; first / drows die here
+  return ng;
+}
 static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   ensure_executed(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
@@ -755,6 +789,7 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   const Column& col = need_resident(t, e.col);
   const int64_t cnt = query_count(q, -1);
   if (cnt == 0 || t->nrows == 0) return;
+  if (!keep && col.dict_n > 0) { dict_unique(q, col, nullptr); return; }
   uint64_t cap = 1024; while (cap < (uint64_t)cnt * 2) cap <<= 1;
   const bool is_str = dt_base(col.dtype) == DFDB_STRING;
   DevBuf keys, rows, aux, rep_off, rep_len;
@@ -830,6 +865,23 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   const size_t nw = padded_words(t->nrows);
   q->gr_sel.ensure(nw * 8);
   HIP_CHECK(hipMemcpyAsync(q->gr_sel.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
+  if (kc.dict_n > 0) {                                       // K9: group by the dictionary codes
+    DevBuf rank;
+    const int64_t ng = dict_unique(q, kc, &rank);
+    q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
+    const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
+    HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
+    HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+    { LaunchTimer lt(ctx, "group_accumulate");
+      launch_group_accumulate_codes(s, q->gr_sel.as<uint64_t>(), kc.dict_codes.as<uint16_t>(), rank.as<uint32_t>(), vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op,
+                                    t->nrows, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
+    launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
+    HIP_CHECK(hipStreamSynchronize(s));                      // `rank` dies here
+    q->gr_n = ng; q->gr_state = 2;
+    if (ngroups) *ngroups = ng;
+    if (key_bytes) *key_bytes = query_string_bytes(q, key_p);
+    return;
+  }
   UniqueTables T;
   unique_impl(q, key_p, &T);
   const int64_t ng = query_count(q, -1);

@@ -1032,6 +1032,17 @@ def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_pat
         assert n1 == n0 and d1 > d0 and g1 > 0                       # K5 never ran: the dictionary kernels did
     finally:
         ctx.profile(False)
+    # unique / groupreduce keyed by the dictionary column: the codes are the group labels (no hash table); same frames as over the flat column
+    import pandas as pd
+    flat = dfdb_mod.DFTable.from_columns({"s": s, "a": a}, block_size=4096)
+    for view_of in (lambda tb: tb, lambda tb: tb[(tb.a > 300) & (tb.s != "sony"), dfdb_mod.ALL], lambda tb: tb[tb.a > 10_000, dfdb_mod.ALL]):
+        for stat in ("count", "sum", "min", "max", "mean"):
+            got, want = dfdb_mod.groupreduce(view_of(t), "s", "a", stat), dfdb_mod.groupreduce(view_of(flat), "s", "a", stat)
+            pd.testing.assert_frame_equal(got, want)
+    assert list(t.s.unique()) == list(flat.s.unique()) == list(dict.fromkeys(s))
+    sel = a > 300
+    assert list(t[t.a > 300, dfdb_mod.ALL][dfdb_mod.ALL, "s"].unique()) == list(dict.fromkeys(np.array(s, dtype=object)[sel]))
+    flat.close()
     # automatic, for every way a String column becomes resident
     ctx.set_option("string_dictionary", 64)
     try:
