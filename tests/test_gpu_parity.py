@@ -1001,6 +1001,8 @@ def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_pat
     t = p.d
     assert t.build_dictionary("s") == len(set(s))
     assert t.build_dictionary("many", 4096) == 0 and t.build_dictionary("many", 20000) == len(set(many))
+    with pytest.raises(Exception, match="not a String column"):
+        t.build_dictionary("a")
     S, A, M = ir.col(0), ir.col(1), ir.col(2)
     ctx.profile(True)
     try:
