@@ -1,5 +1,6 @@
 // expr.cpp — IR parsing, Julia result typing and kernel routing (see expr.hpp).
 #include "expr.hpp"
+#include <functional>
 #include "engine.hpp"
 #include <cmath>
 #include <cstdarg>
@@ -253,6 +254,67 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
   const Node* remn = nullptr;
   if (rem_of_col(n.a.get()) && n.b->op == DFIR_CONST) { remn = n.a.get(); cn = n.b.get(); }
   else if (n.a->op == DFIR_CONST && rem_of_col(n.b.get())) { remn = n.b.get(); cn = n.a.get(); op = flip(op); }
+  // (col * k + d) OP const, with at most one multiplication applied to the column and one addition / subtraction after it (`a * 2 + 1 > c`,
+  // `x - 5.0 > 0`, `1.2 * price > 100`): all in wrapping Int64 (a signed integer column, integer constants) or all in Float64 (any numeric column;
+  // the kernel rounds after the multiplication and after the addition exactly as Julia's two operations do — no fused multiply-add)
+  struct Affine { const Node* col = nullptr; bool flt = false; __int128 imul = 1, iadd = 0; double fmul = 1.0, fadd = 0.0; bool has_add = false, has_mul = false; };
+  auto const_is_int = [](const Node* k) { const int d = dt_base(k->dtype); return d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64; };
+  auto const_as_double = [](const Node* k, double& out) {
+    const int d = dt_base(k->dtype);
+    if (d == DFDB_F64) { memcpy(&out, &k->cbits, 8); return true; }
+    if (d == DFDB_F32) { float f; memcpy(&f, &k->cbits, 4); out = (double)f; return true; }
+    if (d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64) { out = (double)(int64_t)k->cbits; return true; }
+    return false;
+  };
+  std::function<bool(const Node*, Affine&, int)> affine = [&](const Node* e, Affine& A, int depth) -> bool {
+    if (e->op == DFIR_COL) { A.col = e; return !dt_nullable(e->dtype); }
+    if (depth > 2 || !e->a || !e->b || dt_nullable(e->dtype)) return false;
+    const int rt = dt_base(e->dtype);
+    if (rt != DFDB_I64 && rt != DFDB_F64) return false;
+    const bool flt = rt == DFDB_F64;
+    const Node *x = nullptr, *k = nullptr; bool k_left = false;
+    if (e->b->op == DFIR_CONST) { x = e->a.get(); k = e->b.get(); } else if (e->a->op == DFIR_CONST) { x = e->b.get(); k = e->a.get(); k_left = true; } else return false;
+    if (e->op == DFIR_MUL) {
+      if (x->op != DFIR_COL || !affine(x, A, depth + 1) || A.has_mul || A.has_add) return false;   // the multiplication touches the column itself
+      if (flt) { double kv; if (!const_as_double(k, kv)) return false; A.flt = true; A.fmul = kv; }
+      else { if (!const_is_int(k)) return false; A.imul = (__int128)(int64_t)k->cbits; }
+      A.has_mul = true; return true;
+    }
+    if (e->op != DFIR_ADD && e->op != DFIR_SUB) return false;
+    if (!affine(x, A, depth + 1) || A.has_add) return false;
+    if (x->op != DFIR_COL && (dt_base(x->dtype) == DFDB_F64) != flt) return false;             // (col * k) in one type, the sum in another: not one form
+    if (flt) {
+      double kv; if (!const_as_double(k, kv)) return false;
+      if (!A.flt && A.has_mul) return false;
+      A.flt = true;
+      if (e->op == DFIR_ADD) A.fadd = kv;
+      else if (!k_left) A.fadd = -kv;                       // x - k  =  x + (-k)   (exact: negation does not round)
+      else { A.fmul = -A.fmul; A.fadd = kv; }               // k - x  =  (-x) + k
+    } else {
+      if (!const_is_int(k) || A.flt) return false;
+      const __int128 kv = (__int128)(int64_t)k->cbits;
+      if (e->op == DFIR_ADD) A.iadd = kv; else if (!k_left) A.iadd = -kv; else { A.imul = -A.imul; A.iadd = kv; }
+    }
+    A.has_add = true; return true;
+  };
+  Affine aff; const Node* affn = nullptr;
+  if (!remn) {
+    const Node *ea = n.a.get(), *eb = n.b.get();
+    if ((ea->op == DFIR_MUL || ea->op == DFIR_ADD || ea->op == DFIR_SUB) && eb->op == DFIR_CONST && affine(ea, aff, 0)) { affn = ea; cn = eb; }
+    else if ((eb->op == DFIR_MUL || eb->op == DFIR_ADD || eb->op == DFIR_SUB) && ea->op == DFIR_CONST && affine(eb, aff, 0)) { affn = eb; cn = ea; op = flip(op); }
+    if (affn) {
+      const int cdt = dt_base(aff.col->dtype);
+      const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
+      const bool isflt = dt_base(affn->dtype) == DFDB_F64;
+      if (isflt != aff.flt && !(isflt && !aff.has_mul && !aff.has_add)) affn = nullptr;
+      else if (!isflt && !sint) affn = nullptr;
+      else if (isflt && !(dt_isnum(cdt) && cdt != DFDB_BOOL)) affn = nullptr;
+      if (affn) {
+        if (isflt) { term.pre = 3; memcpy(&term.pre_magic, &aff.fmul, 8); memcpy(&term.pre_d, &aff.fadd, 8); }
+        else { term.pre = 2; term.pre_magic = (uint64_t)aff.imul; term.pre_d = (uint64_t)aff.iadd; }
+      } else cn = nullptr;
+    }
+  }
   if (remn) {
     coln = remn->a.get();
     const int cdt = dt_base(coln->dtype), mdt = dt_base(remn->b->dtype);
@@ -275,13 +337,15 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
       magic = (uint64_t)pm + 1; shift = fl;
     }
     term.pre = 1; term.pre_magic = magic; term.pre_shift = shift; term.pre_d = d;
+  } else if (affn) {
+    coln = aff.col;
   } else {
     if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST) { coln = n.a.get(); cn = n.b.get(); }
     else if (n.a->op == DFIR_CONST && n.b->op == DFIR_COL) { coln = n.b.get(); cn = n.a.get(); op = flip(op); }
     else return false;
   }
   const int coldt = dt_base(coln->dtype);
-  const int ct = remn ? (int)DFDB_I64 : coldt, kt = dt_base(cn->dtype);       // ct: the type the comparison happens in
+  const int ct = remn || term.pre == 2 ? (int)DFDB_I64 : (term.pre == 3 ? (int)DFDB_F64 : coldt), kt = dt_base(cn->dtype);   // ct: the type the comparison happens in
   if (dt_nullable(coln->dtype) || !dt_isnum(ct) || ct == DFDB_BOOL) return false;
   (void)t;
   term.col = nullptr; term.dtype = coldt; ordinal = coln->col;

@@ -249,6 +249,40 @@ __device__ __forceinline__ uint64_t term_word_rem(const ScanTerm& tm, uint32_t s
   return myword;
 }
 
+// ScanTerm.pre = 2 / 3: the compared value is x * k + d — in wrapping Int64 (FLT = false), or in Float64 with a rounding after the multiplication
+// and another after the addition, as Julia's two operations round (FLT = true; __dmul_rn / __dadd_rn are never contracted into an fma)
+template <typename T, bool FLT>
+__device__ __forceinline__ uint64_t term_word_affine(const ScanTerm& tm, uint32_t sel, uint32_t sel2, int64_t base, int64_t nrows, int lane, int l0) {
+  const T* p = (const T*)tm.col + base + lane;
+  using V = typename std::conditional<FLT, double, int64_t>::type;
+  const V c = from_bits<V>(tm.cbits), c2 = from_bits<V>(tm.cbits2);
+  const V k = from_bits<V>(tm.pre_magic), d = from_bits<V>(tm.pre_d);
+  auto f = [&](T x) -> V {
+    if constexpr (FLT) return __dadd_rn(__dmul_rn((double)x, k), d);
+    else return (int64_t)((uint64_t)(int64_t)x * (uint64_t)k + (uint64_t)d);
+  };
+  uint64_t myword = 0;
+  if (base + kTile <= nrows) {
+    T v[kWordsPerTile];
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) {
+      const V y = f(v[j]);
+      const uint64_t m = __ballot(cmp_sel<V>(y, c, sel) && (sel2 == 0 || cmp_sel<V>(y, c2, sel2)));
+      if (lane == l0 + j) myword = m;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kWordsPerTile; j++) {
+      bool ok = false;
+      if (base + j * 64 + lane < nrows) { const V y = f(p[j * 64]); ok = cmp_sel<V>(y, c, sel) && (sel2 == 0 || cmp_sel<V>(y, c2, sel2)); }
+      const uint64_t m = __ballot(ok); if (lane == l0 + j) myword = m;
+    }
+  }
+  return myword;
+}
+
 // EXTRA = 2 / 3 / 4: sum / min / max of the finally selected values (Julia: Int sums wrap, min / max of Float64 propagate NaN)
 template <typename T, int EXTRA> __device__ __forceinline__ T agg_identity() {
   if (EXTRA == 3) return std::is_same<T, double>::value ? (T)__builtin_inf() : (std::is_same<T, int64_t>::value ? (T)INT64_MAX : (T)~0ull);
@@ -346,12 +380,36 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
         if (AND_EXISTING && ((live >> (16 * k)) & 0xffffull) == 0) continue;   // late materialization, tile by tile
         const int64_t base = (t0 + k) * kTile;
         const int l0 = 16 * k;
-        if (tm.pre) {          // rem(col, m) OP c: signed integer columns only (the host checks)
+        if (tm.pre == 1) {     // rem(col, m) OP c: signed integer columns only (the host checks)
           switch (tm.dtype) {
             case DFDB_I8:  w |= term_word_rem<int8_t>(tm, sel, sel2, base, nrows, lane, l0); break;
             case DFDB_I16: w |= term_word_rem<int16_t>(tm, sel, sel2, base, nrows, lane, l0); break;
             case DFDB_I32: w |= term_word_rem<int32_t>(tm, sel, sel2, base, nrows, lane, l0); break;
             default:       w |= term_word_rem<int64_t>(tm, sel, sel2, base, nrows, lane, l0); break;
+          }
+          continue;
+        }
+        if (tm.pre == 2) {     // (col * k + d) OP c in wrapping Int64
+          switch (tm.dtype) {
+            case DFDB_I8:  w |= term_word_affine<int8_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_affine<int16_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_affine<int32_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_affine<int64_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
+          }
+          continue;
+        }
+        if (tm.pre == 3) {     // the same in Float64, any numeric column
+          switch (tm.dtype) {
+            case DFDB_I8:  w |= term_word_affine<int8_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_affine<int16_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_affine<int32_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I64: w |= term_word_affine<int64_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U8:  w |= term_word_affine<uint8_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U16: w |= term_word_affine<uint16_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U32: w |= term_word_affine<uint32_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U64: w |= term_word_affine<uint64_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_F32: w |= term_word_affine<float, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_affine<double, true>(tm, sel, sel2, base, nrows, lane, l0); break;
           }
           continue;
         }

@@ -1072,3 +1072,48 @@ def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_pat
         g.close()
     finally:
         ctx.set_option("string_dictionary", 0)
+
+
+def test_affine_forms_of_one_column_are_scan_terms(oracle, dfdb_mod, ctx):
+    """(col * k + d) OP const — `a * 2 + 1 > c`, `x - 5.0 > 0`, `1.2 * price > 100` — runs in the scan kernel: wrapping Int64 arithmetic for signed integer
+    columns with integer constants, Float64 with a rounding after the multiplication and another after the addition (never a fused multiply-add)
+    otherwise.  Same answers as the oracle's generic evaluation, including overflow wrap-around, NaN / Inf / -0.0, Int64 values beyond 2^53 converted to
+    Float64, mixed forms the term cannot take (they stay with the interpreter), and the interpreter is not used for the forms it can."""
+    from dfdb import ir
+    rng = np.random.default_rng(21)
+    n = 60_007
+    x = rng.normal(0, 1000, n); x[::97] = np.nan; x[3::501] = np.inf; x[5::499] = -0.0; x[7::503] = 1e308
+    cols = {"a": rng.integers(-1000, 1000, n).astype(np.int64), "b": rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64), "i8": rng.integers(-128, 127, n).astype(np.int8),
+            "x": x, "f": rng.normal(0, 10, n).astype(np.float32), "u16": rng.integers(0, 65535, n).astype(np.uint16), "i32": rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)}
+    p = Pair(oracle, dfdb_mod, cols, block_size=8192)
+    a, b, i8, X, f, u16, i32 = (ir.col(k) for k in range(7))
+    term_forms = [a * 2 + 1 > 100, 3 * a - 7 <= -50, a + 5 == 10, 100 - a > 1050, b * 3 > 0, b * 2**62 + 2**62 < 0, b - 1 >= 2**63 - 2, i8 * 100 + 28 > 12_000,
+                  i32 * 4_000_000_000 < 0, X * 1.5 + 0.25 > 100.0, X - 5.0 > 0, 1.2 * X > 100, 2.0 - X >= 1e308, X * 3 < 7, X + 1e308 > 1.5e308, a * 0.1 > 12.3,
+                  b * 1.0 > 9.2e18, b + 0.5 < -9.2e18, f * 2.5 + 1 > 3.5, u16 * 0.5 + 0.25 >= 1000.25, i32 * 1e10 > 1e19,
+                  (a * 2 + 1 > 100) & (a * 2 + 1 < 900), (X * 1.5 > 10.0) & (a - 3 != 0) & (b * 3 > 0)]
+    ctx.profile(True)
+    try:
+        i0, _ = ctx.profile_get("interp_predicate")
+        for k, pred in enumerate(term_forms):
+            j0, _ = ctx.profile_get("interp_predicate")
+            ov, dv = apply_stages(p, [("pred", pred)])
+            assert_same(p, ov, dv)
+            j1, _ = ctx.profile_get("interp_predicate")
+            assert j1 == j0, f"form {k} ({pred!r}) went through the interpreter"
+        ov, dv = apply_stages(p, [("range", 10, 3, n - 11), ("pred", (a * 7 - 1 > 0) & (X * 0.5 < 3.0))], proj=[("a", a), ("x", X)])
+        assert_same(p, ov, dv)
+        i1, _ = ctx.profile_get("interp_predicate")
+        assert i1 == i0, "an affine form went through the interpreter"
+        # not one form: a Float32 product (Float32 * Int stays Float32), two multiplications, an Int64 product under a Float64 sum, an Int8 product (stays Int8 and wraps there), unsigned wrap-around
+        for pred in (f * 2 > 3.5, (a * 2) * 3 > 5, a * 2 + 0.5 > 10, (a + 1) * 2 > 10, i8 * ir.const(100, ir.I8) > 10, u16 * 70000 > 100, X * X > 4.0, a * b > 0):
+            ov, dv = apply_stages(p, [("pred", pred)])
+            assert_same(p, ov, dv)
+    finally:
+        ctx.profile(False)
+    # third opinion on a few (numpy evaluates in the same types)
+    with np.errstate(invalid="ignore", over="ignore"):
+        av, bv, xv = cols["a"], cols["b"], cols["x"]
+        for pred, want in ((a * 2 + 1 > 100, av * 2 + 1 > 100), (b * 3 > 0, bv * np.int64(3) > 0), (X * 1.5 + 0.25 > 100.0, xv * 1.5 + 0.25 > 100.0),
+                           (2.0 - X >= 1e308, 2.0 - xv >= 1e308), (b * 1.0 > 9.2e18, bv * 1.0 > 9.2e18)):
+            ov, dv = apply_stages(p, [("pred", pred)])
+            assert np.array_equal(dv._query().indices(), np.nonzero(want)[0] + 1)
