@@ -302,7 +302,19 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
     const Node *ea = n.a.get(), *eb = n.b.get();
     if ((ea->op == DFIR_MUL || ea->op == DFIR_ADD || ea->op == DFIR_SUB) && eb->op == DFIR_CONST && affine(ea, aff, 0)) { affn = ea; cn = eb; }
     else if ((eb->op == DFIR_MUL || eb->op == DFIR_ADD || eb->op == DFIR_SUB) && ea->op == DFIR_CONST && affine(eb, aff, 0)) { affn = eb; cn = ea; op = flip(op); }
-    if (affn) {
+    // col / k OP const: Julia's `/` is Float64 division for every numeric column (one rounding): pre = 4
+    if (!affn) {
+      auto div_of_col = [&](const Node* e) { return e->op == DFIR_DIV && e->a && e->b && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_F64 &&
+                                                    !dt_nullable(e->dtype) && !dt_nullable(e->a->dtype) && dt_isnum(e->a->dtype) && dt_base(e->a->dtype) != DFDB_BOOL &&
+                                                    dt_base(e->a->dtype) != DFDB_F32; };
+      const Node* dn = nullptr;
+      if (div_of_col(ea) && eb->op == DFIR_CONST) { dn = ea; cn = eb; }
+      else if (div_of_col(eb) && ea->op == DFIR_CONST) { dn = eb; cn = ea; op = flip(op); }
+      double kv;
+      if (dn && const_as_double(dn->b.get(), kv)) { affn = dn; aff.col = dn->a.get(); term.pre = 4; memcpy(&term.pre_magic, &kv, 8); term.pre_d = 0; }
+      else if (dn) cn = nullptr;
+    }
+    if (affn && term.pre != 4) {
       const int cdt = dt_base(aff.col->dtype);
       const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
       const bool isflt = dt_base(affn->dtype) == DFDB_F64;
@@ -345,7 +357,7 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
     else return false;
   }
   const int coldt = dt_base(coln->dtype);
-  const int ct = remn || term.pre == 2 ? (int)DFDB_I64 : (term.pre == 3 ? (int)DFDB_F64 : coldt), kt = dt_base(cn->dtype);   // ct: the type the comparison happens in
+  const int ct = remn || term.pre == 2 ? (int)DFDB_I64 : (term.pre >= 3 ? (int)DFDB_F64 : coldt), kt = dt_base(cn->dtype);   // ct: the type the comparison happens in
   if (dt_nullable(coln->dtype) || !dt_isnum(ct) || ct == DFDB_BOOL) return false;
   (void)t;
   term.col = nullptr; term.dtype = coldt; ordinal = coln->col;

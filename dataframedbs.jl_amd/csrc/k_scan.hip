@@ -251,14 +251,15 @@ __device__ __forceinline__ uint64_t term_word_rem(const ScanTerm& tm, uint32_t s
 
 // ScanTerm.pre = 2 / 3: the compared value is x * k + d — in wrapping Int64 (FLT = false), or in Float64 with a rounding after the multiplication
 // and another after the addition, as Julia's two operations round (FLT = true; __dmul_rn / __dadd_rn are never contracted into an fma)
-template <typename T, bool FLT>
+template <typename T, int FLT>      // 0: Int64, 1: Float64 multiply + add, 2: Float64 division
 __device__ __forceinline__ uint64_t term_word_affine(const ScanTerm& tm, uint32_t sel, uint32_t sel2, int64_t base, int64_t nrows, int lane, int l0) {
   const T* p = (const T*)tm.col + base + lane;
-  using V = typename std::conditional<FLT, double, int64_t>::type;
+  using V = typename std::conditional<FLT != 0, double, int64_t>::type;
   const V c = from_bits<V>(tm.cbits), c2 = from_bits<V>(tm.cbits2);
   const V k = from_bits<V>(tm.pre_magic), d = from_bits<V>(tm.pre_d);
   auto f = [&](T x) -> V {
-    if constexpr (FLT) return __dadd_rn(__dmul_rn((double)x, k), d);
+    if constexpr (FLT == 2) return __ddiv_rn((double)x, k);
+    else if constexpr (FLT == 1) return __dadd_rn(__dmul_rn((double)x, k), d);
     else return (int64_t)((uint64_t)(int64_t)x * (uint64_t)k + (uint64_t)d);
   };
   uint64_t myword = 0;
@@ -391,25 +392,39 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
         }
         if (tm.pre == 2) {     // (col * k + d) OP c in wrapping Int64
           switch (tm.dtype) {
-            case DFDB_I8:  w |= term_word_affine<int8_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_I16: w |= term_word_affine<int16_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_I32: w |= term_word_affine<int32_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
-            default:       w |= term_word_affine<int64_t, false>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I8:  w |= term_word_affine<int8_t, 0>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_affine<int16_t, 0>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_affine<int32_t, 0>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_affine<int64_t, 0>(tm, sel, sel2, base, nrows, lane, l0); break;
+          }
+          continue;
+        }
+        if (tm.pre == 4) {     // Float64(col) / k
+          switch (tm.dtype) {
+            case DFDB_I8:  w |= term_word_affine<int8_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_affine<int16_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_affine<int32_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I64: w |= term_word_affine<int64_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U8:  w |= term_word_affine<uint8_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U16: w |= term_word_affine<uint16_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U32: w |= term_word_affine<uint32_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U64: w |= term_word_affine<uint64_t, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_affine<double, 2>(tm, sel, sel2, base, nrows, lane, l0); break;
           }
           continue;
         }
         if (tm.pre == 3) {     // the same in Float64, any numeric column
           switch (tm.dtype) {
-            case DFDB_I8:  w |= term_word_affine<int8_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_I16: w |= term_word_affine<int16_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_I32: w |= term_word_affine<int32_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_I64: w |= term_word_affine<int64_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_U8:  w |= term_word_affine<uint8_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_U16: w |= term_word_affine<uint16_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_U32: w |= term_word_affine<uint32_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_U64: w |= term_word_affine<uint64_t, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            case DFDB_F32: w |= term_word_affine<float, true>(tm, sel, sel2, base, nrows, lane, l0); break;
-            default:       w |= term_word_affine<double, true>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I8:  w |= term_word_affine<int8_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I16: w |= term_word_affine<int16_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I32: w |= term_word_affine<int32_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_I64: w |= term_word_affine<int64_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U8:  w |= term_word_affine<uint8_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U16: w |= term_word_affine<uint16_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U32: w |= term_word_affine<uint32_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_U64: w |= term_word_affine<uint64_t, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            case DFDB_F32: w |= term_word_affine<float, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
+            default:       w |= term_word_affine<double, 1>(tm, sel, sel2, base, nrows, lane, l0); break;
           }
           continue;
         }

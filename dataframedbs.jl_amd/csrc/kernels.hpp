@@ -21,7 +21,8 @@ struct ScanTerm {
   // pre = 1: the compared value is rem(col, m) for a signed integer column and a constant m (`a % 50 == 0`, test/selection.jl:21): computed in
   // Int64 as sign(x) * (|x| mod |m|), |x| / |m| by multiplication with a precomputed magic number (pre_magic, pre_shift); cbits / cbits2 are Int64
   // pre = 2: the compared value is col * pre_magic + pre_d in wrapping Int64 (`a * 2 + 1 > c`; a signed integer column, integer constants);
-  // pre = 3: the same in Float64 — fl(fl(Float64(x) * k) + d), two roundings, never fused (pre_magic / pre_d hold the doubles' bits)
+  // pre = 3: the same in Float64 — fl(fl(Float64(x) * k) + d), two roundings, never fused (pre_magic / pre_d hold the doubles' bits);
+  // pre = 4: Float64(x) / k (Julia's `/`: one correctly rounded division)
   int32_t pre = 0, pre_shift = 0;
   uint64_t pre_magic = 0, pre_d = 0;
 };

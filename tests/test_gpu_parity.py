@@ -1089,7 +1089,7 @@ def test_affine_forms_of_one_column_are_scan_terms(oracle, dfdb_mod, ctx):
     a, b, i8, X, f, u16, i32 = (ir.col(k) for k in range(7))
     term_forms = [a * 2 + 1 > 100, 3 * a - 7 <= -50, a + 5 == 10, 100 - a > 1050, b * 3 > 0, b * 2**62 + 2**62 < 0, b - 1 >= 2**63 - 2, i8 * 100 + 28 > 12_000,
                   i32 * 4_000_000_000 < 0, X * 1.5 + 0.25 > 100.0, X - 5.0 > 0, 1.2 * X > 100, 2.0 - X >= 1e308, X * 3 < 7, X + 1e308 > 1.5e308, a * 0.1 > 12.3,
-                  b * 1.0 > 9.2e18, b + 0.5 < -9.2e18, f * 2.5 + 1 > 3.5, u16 * 0.5 + 0.25 >= 1000.25, i32 * 1e10 > 1e19,
+                  b * 1.0 > 9.2e18, b + 0.5 < -9.2e18, f * 2.5 + 1 > 3.5, u16 * 0.5 + 0.25 >= 1000.25, i32 * 1e10 > 1e19, a / 50 > 10.5, b / 3 < -1e18, X / 0.1 >= 33.0, X / 0 > 0, 7 <= i8 / -3, u16 / 7.5 == 8.0,
                   (a * 2 + 1 > 100) & (a * 2 + 1 < 900), (X * 1.5 > 10.0) & (a - 3 != 0) & (b * 3 > 0)]
     ctx.profile(True)
     try:
