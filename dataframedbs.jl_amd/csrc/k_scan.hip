@@ -714,11 +714,32 @@ __global__ __launch_bounds__(kBlock) void k_sc_down(const uint32_t* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) { prefix[ntiles] = carry + chunk_sums[nchunks]; if (carry_out) *carry_out = carry + chunk_sums[nchunks]; }
 }
 
+// up to 4096 tiles (4 M rows): the three passes in ONE workgroup — a small table's query is a handful of 5-10 us launches, two fewer matter
+__global__ __launch_bounds__(kBlock) void k_sc_small(const uint32_t* __restrict__ counts, uint64_t* __restrict__ prefix, int64_t ntiles,
+                                                     const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ carry_out) {
+  __shared__ uint64_t wave_tot[4];
+  const int64_t base = (int64_t)threadIdx.x * kScPerThread;
+  uint32_t v[kScPerThread];
+  uint64_t tsum = 0;
+#pragma unroll
+  for (int k = 0; k < kScPerThread; k++) { const int64_t i = base + k; v[k] = i < ntiles ? counts[i] : 0u; tsum += v[k]; }
+  const uint64_t incl = wave_incl_scan64(tsum);
+  if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  const uint64_t carry = carry_in ? *carry_in : 0ull;
+  uint64_t run = carry + incl - tsum;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kScPerThread; k++) { const int64_t i = base + k; if (i < ntiles) prefix[i] = run; run += v[k]; }
+  if (threadIdx.x == kBlock - 1) { prefix[ntiles] = run; if (carry_out) *carry_out = run; }
+}
+
 size_t scan_counts_scratch_bytes(int64_t ntiles) { return (size_t)((ntiles + kScChunk - 1) / kScChunk + 2) * 8; }
 
 void launch_scan_counts(hipStream_t s, const uint32_t* counts, uint64_t* prefix, int64_t ntiles, uint64_t* scratch, const uint64_t* carry_in,
                         uint64_t* carry_out) {
   if (ntiles <= 0) { (void)hipMemsetAsync(prefix, 0, 8, s); return; }
+  if (ntiles <= kScChunk) { hipLaunchKernelGGL(k_sc_small, dim3(1), dim3(kBlock), 0, s, counts, prefix, ntiles, carry_in, carry_out); return; }
   const int64_t nchunks = (ntiles + kScChunk - 1) / kScChunk;
   hipLaunchKernelGGL(k_sc_reduce, dim3((unsigned)nchunks), dim3(kBlock), 0, s, counts, scratch, ntiles);
   hipLaunchKernelGGL(k_sc_scan_chunks, dim3(1), dim3(kBlock), 0, s, scratch, nchunks);
