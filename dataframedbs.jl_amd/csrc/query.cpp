@@ -340,7 +340,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // capture (see dfdb_query.hint_materialize): only when this ONE launch produces the query's final mask and the column it reads is
     // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
     StrCapture capture{nullptr, nullptr, nullptr};
-    bool do_cap = mode != 0 && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && strs.size() == 1 && pat.size() <= 64;
+    // (every other kind of conjunct runs AFTER this launch and narrows the mask: the capture would keep rows the query drops — found by tests/test_gpu_fuzz.py)
+    bool do_cap = mode != 0 && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && or_batches.empty() && miss.empty() &&
+                  dict_luts.empty() && strs.size() == 1 && pat.size() <= 64;
     if (do_cap) {
       do_cap = false;
       for (const ProjCol& p : q->proj) if (p.expr->op == DFIR_COL && p.expr->col == ord) { do_cap = true; break; }

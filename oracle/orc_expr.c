@@ -668,6 +668,8 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
 int expr_eval(const node_t* nd, const colbuf_t* bufs, const int32_t* idx, int64_t n, arena_t* ar, vec_t* out) {
   ectx_t c = {bufs, idx, n, ar, 0};
   vec_t v; int rc = eval(nd, &c, &v); if (rc) return rc;
+  if (n == 0) c.err = 0;   /* no row reached this evaluation: a broadcast over nothing calls nothing, so even a constant sub-expression that always throws
+                              (`UInt16(-42.0)`) does not (found by tests/test_gpu_fuzz.py: the engine was right) */
   if (c.err == ORC_ERR_DIVIDE) return orc_fail(ORC_ERR_DIVIDE, "DivideError: integer division error");
   if (c.err) return orc_fail(c.err, "InexactError in conversion");
   if (v.is_const && !v.scol && !v.cstr) { /* broadcast a scalar result to n elements */
