@@ -761,7 +761,10 @@ class _Query:
             self.hint_aggregate(op, col)      # a first execution below lets the scan reduce the column while it holds it
         N.check(N.load().dfdb_aggregate(self._h, op, col, C.byref(oi), C.byref(of)))
         dt = self.coltype(col) & ir.DTYPE_MASK if op != N.AGG_COUNT else ir.I64
-        return of.value if dt in (ir.F32, ir.F64) else oi.value
+        if dt in (ir.F32, ir.F64):
+            return of.value
+        # Base.sum widens unsigned element types to UInt64 (Base.add_sum), minimum / maximum keep them: the 64 bits are an unsigned number
+        return oi.value & 0xFFFFFFFFFFFFFFFF if dt in (ir.U8, ir.U16, ir.U32, ir.U64) else oi.value
 
 
 class _ChunkQuery(_Query):
@@ -1064,7 +1067,9 @@ class DFColumn:
                     acc = r
                 elif op == N.AGG_SUM:
                     acc = acc + r
-                    if isint:
+                    if isint and (self.eltype & ir.DTYPE_MASK) in (ir.U8, ir.U16, ir.U32, ir.U64):
+                        acc %= 1 << 64                                     # UInt64 sums wrap
+                    elif isint:
                         acc = (acc + (1 << 63)) % (1 << 64) - (1 << 63)    # Int64 sums wrap, like Julia's
                 else:
                     acc = min(acc, r) if op == N.AGG_MIN else max(acc, r)

@@ -232,3 +232,56 @@ def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     assert np.array_equal(G.gindices(gv), want_idx)
     gm = G._gq(gv).materialize()
     assert np.array_equal(gm[0], want[0]) and np.array_equal(gm[2], want[2])
+
+
+@pytest.mark.parametrize("seed", range(200 * SCALE))
+def test_random_aggregates(pair, dfdb_mod, seed):
+    """sum / min / max / count of a random numeric column over a random queue: the fused forms (the scan adds up or keeps the extremum of a column
+    that is itself a term of the last launch) and the plain reduce must both equal numpy over the rows the oracle selects — Int sums exactly
+    (wrapping, small integer types widened as Julia's `sum` does), Float sums within n * eps * sum|x|, min / max exactly (NaN wins both)."""
+    from dfdb import ir
+    g = Gen(ir, 50_000 + seed, risky=False)
+    stages = g.stages()
+    ci = int(g.pick([0, 1, 2, 3, 4, 5, 6, 7, 8]))
+    name = pair.names[ci]
+    try:
+        ov, dv = apply_stages(pair, stages)
+    except Exception as e:          # noqa: BLE001
+        pytest.skip("refused at build time: %s" % type(e).__name__)
+    idx = ov.select_indices() - 1
+    host = np.asarray(pair.d.ctx and pair_columns(pair)[name])[idx]
+    col = dv[dfdb_mod.ALL, name]
+    assert dfdb_mod.nrow(dv) == len(idx)
+    if len(idx) == 0:
+        assert col.sum() == 0
+        with pytest.raises(ValueError, match="empty collection"):
+            col.min()
+        return
+    if host.dtype.kind == "f":
+        want = float(host.astype(np.float64).sum())
+        with np.errstate(invalid="ignore"):
+            tol = len(idx) * np.finfo(np.float64).eps * float(np.nansum(np.abs(host.astype(np.float64)))) + 1e-300
+        got = col.sum()
+        assert (np.isnan(want) and np.isnan(got)) or (np.isinf(want) and got == want) or abs(got - want) <= tol, (got, want)
+        wmin, wmax = (float("nan"), float("nan")) if np.isnan(host).any() else (float(host.min()), float(host.max()))
+        gmin, gmax = col.min(), col.max()
+        assert (np.isnan(wmin) and np.isnan(gmin)) or gmin == wmin
+        assert (np.isnan(wmax) and np.isnan(gmax)) or gmax == wmax
+    else:
+        wide = np.uint64 if host.dtype.kind == "u" else np.int64
+        with np.errstate(over="ignore"):
+            want = int(host.astype(wide).sum(dtype=wide))
+        assert col.sum() == want
+        assert col.min() == int(host.min()) and col.max() == int(host.max())
+
+
+_PAIR_COLUMNS = {}
+
+
+def pair_columns(pair):
+    """the host copy of the fuzz table's columns (materialised once per fixture through the oracle: what the engine must agree with)"""
+    key = id(pair)
+    if key not in _PAIR_COLUMNS:
+        out = pair.o.view().materialize()
+        _PAIR_COLUMNS[key] = {n: (c if not isinstance(c, tuple) else None) for n, c in zip(pair.names, out)}
+    return _PAIR_COLUMNS[key]
