@@ -285,3 +285,67 @@ def pair_columns(pair):
         out = pair.o.view().materialize()
         _PAIR_COLUMNS[key] = {n: (c if not isinstance(c, tuple) else None) for n, c in zip(pair.names, out)}
     return _PAIR_COLUMNS[key]
+
+
+@pytest.mark.parametrize("seed", range(100 * SCALE))
+def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
+    """groupreduce / unique over a random queue, keyed by an integer column, the nullable column (missing is a group) or the String column (through the
+    hash table when it is flat, through the 16-bit codes when it has a dictionary): groups in order of first appearance among the rows the oracle selects,
+    exact counts, integer sums / extrema exact, Float sums within n * eps * sum|x|."""
+    from dfdb import ir
+    from test_gpu_parity import _np_group_ids, _np_groupreduce
+    g = Gen(ir, 90_000 + seed, risky=False)
+    stages = g.stages()
+    key = g.pick(["a", "i8", "s", "m", "c"])
+    val = g.pick([v for v in ["a", "b", "i32", "u16", "x", "c"] if v != key])      # (a projection cannot name a column twice)
+    stat = g.pick(["count", "sum", "min", "max", "mean"])
+    try:
+        ov, dv = apply_stages(pair, stages)
+    except Exception as e:          # noqa: BLE001
+        pytest.skip("refused at build time: %s" % type(e).__name__)
+    idx = ov.select_indices() - 1
+    cols = full_columns(pair)
+    keys = cols[key][idx] if not isinstance(cols[key], list) else [cols[key][i] for i in idx]
+    if isinstance(keys, np.ma.MaskedArray):
+        keys = [None if m else int(v) for v, m in zip(keys.data, np.ma.getmaskarray(keys))]
+    elif not isinstance(keys, list):
+        keys = keys.tolist()
+    vals = cols[val][idx]
+    ids = _np_group_ids(keys)
+    order, cnt, acc = _np_groupreduce(ids, vals, "sum" if stat in ("min", "max") else stat)
+    if stat in ("min", "max") and len(order):       # per group, the way Julia's minimum / maximum do it: a NaN in the group wins
+        gid = ids[1]
+        acc = np.array([(np.nan if (vals.dtype.kind == "f" and np.isnan(vals[gid == k]).any()) else (vals[gid == k].min() if stat == "min" else vals[gid == k].max()))
+                        for k in range(len(order))], dtype=np.float64 if vals.dtype.kind == "f" else vals.dtype)
+    got = dfdb_mod.groupreduce(dv, key, val, stat)
+    gk = [None if (k is None or k is np.ma.masked or (isinstance(k, float) and k != k)) else k for k in got[key].tolist()]
+    assert gk == [None if k is None else k for k in order], (key, stages)
+    assert got["count"].tolist() == cnt.tolist()
+    if stat != "count" and len(order):
+        gv = np.asarray(got[stat])
+        if vals.dtype.kind == "f" or stat == "mean":
+            with np.errstate(invalid="ignore"):
+                tol = max(1, len(idx)) * np.finfo(np.float64).eps * float(np.nansum(np.abs(vals.astype(np.float64)))) + 1e-300
+                a, b = gv.astype(np.float64), np.asarray(acc, np.float64)
+                ok = (np.abs(a - b) <= tol) | np.isnan(a) | (a == b)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.all(ok), (stat, a[:4], b[:4])
+        else:
+            assert gv.astype(np.int64).tolist() == np.asarray(acc).astype(np.int64).tolist(), (stat, val)
+    # unique of the key column over the same queue
+    uk = dv[dfdb_mod.ALL, key].unique()
+    uk = [None if (k is None or k is np.ma.masked) else k for k in (uk.tolist() if hasattr(uk, "tolist") else list(uk))]
+    assert uk == [None if k is None else k for k in order]
+
+
+_FULL_COLUMNS = {}
+
+
+def full_columns(pair):
+    key = id(pair)
+    if key not in _FULL_COLUMNS:
+        out = pair.o.view().materialize()
+        d = {}
+        for n, c in zip(pair.names, out):
+            d[n] = pair.O.flat_to_strings(*c) if isinstance(c, tuple) else c
+        _FULL_COLUMNS[key] = d
+    return _FULL_COLUMNS[key]
