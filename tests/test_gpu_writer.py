@@ -364,3 +364,8 @@ def test_random_tables_written_by_the_device_read_back(oracle, dfdb_mod, ctx, tm
     lazy = dfdb_mod.open_table(path, load=False)
     assert dfdb_mod.nrow_streamed(lazy, 1 + seed % 4) == n
     lazy.close(); p.d.close(); want.d.close()
+    # the other direction: the ORACLE writes the same table (liblz4's bytes), the device decoder + unpackers read it
+    back = Pair(oracle, dfdb_mod, cols, block_size=bs, via_files=str(tmp_path / "by_oracle"))
+    ov3, dv3 = apply_stages(back, [])
+    assert_same(back, ov3, dv3)
+    back.d.close()
