@@ -33,6 +33,8 @@ def pair(oracle, dfdb_mod, request):
         "m": np.ma.masked_array(rng.integers(-9, 9, N).astype(np.int64), mask=rng.random(N) < 0.25),   # 10
         "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)],   # 11
         "z": rng.integers(-2, 3, N).astype(np.int64),                         # 12 (zeros: a divisor that raises)
+        "sm": [None if i % 11 == 3 else "%s%d" % ("xy"[i % 2] * (i % 4), i % 7) for i in range(N)],                   # 13 Union{String,Missing}
+        "mf": np.ma.masked_array(rng.normal(0, 5, N), mask=rng.random(N) < 0.4),                                         # 14 Union{Float64,Missing}
     }
     p = Pair(oracle, dfdb_mod, cols, block_size=1000)
     if request.param == "string dictionary":             # K9: every string predicate and projection of `s` goes through the codes
@@ -93,6 +95,9 @@ class Gen:
                 return f(self.num(min(depth, 2)), self.num(min(depth, 2)) if self.rng.random() < 0.6 else self.const())
             if k == 4: return ir.col(9)
             if k == 5: return ir.isin(ir.col(self.pick([0, 3, 4, 5])), [int(v) for v in self.rng.integers(-60, 60, int(self.rng.integers(1, 9)))])
+            if k == 6 and self.rng.random() < 0.4:
+                return self.pick([ir.ismissing(ir.col(13)), ~ir.ismissing(ir.col(13)), ir.ismissing(ir.col(14)), ir.coalesce(ir.col(14), 0.5) * 2 > ir.col(8),
+                                  ir.coalesce(ir.col(14), ir.col(7)) <= self.const(), ir.ismissing(ir.col(14)) | (ir.col(0) > 3), ir.sizeof(ir.col(13)) > 2])
             if k == 6: return ir.ismissing(ir.col(10)) if self.rng.random() < 0.5 else (ir.coalesce(ir.col(10), ir.const(int(self.rng.integers(-3, 3)))) > self.const())
             if k == 7: return self.pick([ir.col(11) == "a7", ir.col(11) != "bb11", ir.startswith(ir.col(11), "aa"), ir.endswith(ir.col(11), "2"), ir.sizeof(ir.col(11)) > 2])
             return ir.coalesce(ir.col(10), ir.col(0)) * 2 >= ir.col(4)           # a nullable column made whole by another column
@@ -125,7 +130,7 @@ class Gen:
         ir, out = self.ir, []
         for k in range(int(self.rng.integers(1, 4))):
             r = self.rng.random()
-            e = ir.col(int(self.rng.integers(0, 13))) if r < 0.5 else (self.num(2) if r < 0.85 else self.boolean(1))
+            e = ir.col(int(self.rng.integers(0, 15))) if r < 0.5 else (self.num(2) if r < 0.85 else self.boolean(1))
             out.append(("p%d" % k, e))
         return out
 
