@@ -10,7 +10,8 @@ import pytest
 from helpers import Pair, apply_stages, assert_same
 
 pytestmark = pytest.mark.gpu
-N = 12_345
+N = int(os.environ.get("DFDB_FUZZ_ROWS", "12345"))          # (DFDB_FUZZ_ROWS=300007 DFDB_FUZZ_BLOCK=65536: the same queues over a bigger table)
+BLOCK = int(os.environ.get("DFDB_FUZZ_BLOCK", "1000"))
 SCALE = int(os.environ.get("DFDB_FUZZ_SCALE", "1"))      # DFDB_FUZZ_SCALE=20 python -m pytest tests/test_gpu_fuzz.py: 20 x the seeds
 
 
@@ -36,7 +37,7 @@ def pair(oracle, dfdb_mod, request):
         "sm": [None if i % 11 == 3 else "%s%d" % ("xy"[i % 2] * (i % 4), i % 7) for i in range(N)],                   # 13 Union{String,Missing}
         "mf": np.ma.masked_array(rng.normal(0, 5, N), mask=rng.random(N) < 0.4),                                         # 14 Union{Float64,Missing}
     }
-    p = Pair(oracle, dfdb_mod, cols, block_size=1000)
+    p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK)
     if request.param == "string dictionary":             # K9: every string predicate and projection of `s` goes through the codes
         assert p.d.build_dictionary("s") == len(set(cols["s"]))
     return p
@@ -183,7 +184,7 @@ def filed(oracle, dfdb_mod, tmp_path_factory):
             "f": rng.normal(0, 8, N).astype(np.float32), "flag": rng.integers(0, 2, N).astype(bool),
             "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)]}
     path = str(tmp_path_factory.mktemp("fuzz") / "tb")
-    p = Pair(oracle, dfdb_mod, cols, block_size=1000, via_files=path)
+    p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK, via_files=path)
     lazy = dfdb_mod.open_table(path, load=False)
     g = G.Group.create([0, 0, 0], NAT.EXCHANGE_HOST)
     gt = G.GroupTable.open(g, path)
