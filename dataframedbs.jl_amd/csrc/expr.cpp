@@ -239,101 +239,23 @@ static void int_vs_int(ScanTerm& term, int coldt, int op, __int128 c) {
   term.op = op; term.cbits = int_bits(c);
 }
 
-bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& ordinal) {
-  if (n.op == DFIR_COL && n.dtype == DFDB_BOOL) {   // a Bool column as the selection itself (DFColumn{Bool}: view.jl:60-72): its bytes != 0
-    term.col = nullptr; term.dtype = DFDB_BOOL; term.op = CMP_NE; term.cbits = 0; ordinal = n.col;
-    return true;
-  }
-  int op = cmp_from_ir(n.op);
-  if (op < 0 || !n.a || !n.b) return false;
-  const Node *coln = nullptr, *cn = nullptr;
-  // rem(col, m) OP const  (`a % 50 == 0`): a signed integer column, an integer constant m other than 0 (DivideError stays with the interpreter), 1, -1
-  auto rem_of_col = [](const Node* e) {
-    return e->op == DFIR_REM && e->a && e->b && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_I64 && !dt_nullable(e->dtype);
-  };
-  const Node* remn = nullptr;
-  if (rem_of_col(n.a.get()) && n.b->op == DFIR_CONST) { remn = n.a.get(); cn = n.b.get(); }
-  else if (n.a->op == DFIR_CONST && rem_of_col(n.b.get())) { remn = n.b.get(); cn = n.a.get(); op = flip(op); }
-  // (col * k + d) OP const, with at most one multiplication applied to the column and one addition / subtraction after it (`a * 2 + 1 > c`,
-  // `x - 5.0 > 0`, `1.2 * price > 100`): all in wrapping Int64 (a signed integer column, integer constants) or all in Float64 (any numeric column;
-  // the kernel rounds after the multiplication and after the addition exactly as Julia's two operations do — no fused multiply-add)
-  struct Affine { const Node* col = nullptr; bool flt = false; __int128 imul = 1, iadd = 0; double fmul = 1.0, fadd = 0.0; bool has_add = false, has_mul = false; };
-  auto const_is_int = [](const Node* k) { const int d = dt_base(k->dtype); return d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64; };
-  auto const_as_double = [](const Node* k, double& out) {
-    const int d = dt_base(k->dtype);
-    if (d == DFDB_F64) { memcpy(&out, &k->cbits, 8); return true; }
-    if (d == DFDB_F32) { float f; memcpy(&f, &k->cbits, 4); out = (double)f; return true; }
-    if (d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64) { out = (double)(int64_t)k->cbits; return true; }
-    return false;
-  };
-  std::function<bool(const Node*, Affine&, int)> affine = [&](const Node* e, Affine& A, int depth) -> bool {
-    if (e->op == DFIR_COL) { A.col = e; return !dt_nullable(e->dtype); }
-    if (depth > 2 || !e->a || !e->b || dt_nullable(e->dtype)) return false;
-    const int rt = dt_base(e->dtype);
-    if (rt != DFDB_I64 && rt != DFDB_F64) return false;
-    const bool flt = rt == DFDB_F64;
-    const Node *x = nullptr, *k = nullptr; bool k_left = false;
-    if (e->b->op == DFIR_CONST) { x = e->a.get(); k = e->b.get(); } else if (e->a->op == DFIR_CONST) { x = e->b.get(); k = e->a.get(); k_left = true; } else return false;
-    if (e->op == DFIR_MUL) {
-      if (x->op != DFIR_COL || !affine(x, A, depth + 1) || A.has_mul || A.has_add) return false;   // the multiplication touches the column itself
-      if (flt) { double kv; if (!const_as_double(k, kv)) return false; A.flt = true; A.fmul = kv; }
-      else { if (!const_is_int(k)) return false; A.imul = (__int128)(int64_t)k->cbits; }
-      A.has_mul = true; return true;
-    }
-    if (e->op != DFIR_ADD && e->op != DFIR_SUB) return false;
-    if (!affine(x, A, depth + 1) || A.has_add) return false;
-    if (x->op != DFIR_COL && (dt_base(x->dtype) == DFDB_F64) != flt) return false;             // (col * k) in one type, the sum in another: not one form
-    if (flt) {
-      double kv; if (!const_as_double(k, kv)) return false;
-      if (!A.flt && A.has_mul) return false;
-      A.flt = true;
-      if (e->op == DFIR_ADD) A.fadd = kv;
-      else if (!k_left) A.fadd = -kv;                       // x - k  =  x + (-k)   (exact: negation does not round)
-      else { A.fmul = -A.fmul; A.fadd = kv; }               // k - x  =  (-x) + k
-    } else {
-      if (!const_is_int(k) || A.flt) return false;
-      const __int128 kv = (__int128)(int64_t)k->cbits;
-      if (e->op == DFIR_ADD) A.iadd = kv; else if (!k_left) A.iadd = -kv; else { A.imul = -A.imul; A.iadd = kv; }
-    }
-    A.has_add = true; return true;
-  };
-  Affine aff; const Node* affn = nullptr;
-  if (!remn) {
-    const Node *ea = n.a.get(), *eb = n.b.get();
-    if ((ea->op == DFIR_MUL || ea->op == DFIR_ADD || ea->op == DFIR_SUB) && eb->op == DFIR_CONST && affine(ea, aff, 0)) { affn = ea; cn = eb; }
-    else if ((eb->op == DFIR_MUL || eb->op == DFIR_ADD || eb->op == DFIR_SUB) && ea->op == DFIR_CONST && affine(eb, aff, 0)) { affn = eb; cn = ea; op = flip(op); }
-    // col / k OP const: Julia's `/` is Float64 division for every numeric column (one rounding): pre = 4
-    if (!affn) {
-      auto div_of_col = [&](const Node* e) { return e->op == DFIR_DIV && e->a && e->b && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_F64 &&
-                                                    !dt_nullable(e->dtype) && !dt_nullable(e->a->dtype) && dt_isnum(e->a->dtype) && dt_base(e->a->dtype) != DFDB_BOOL &&
-                                                    dt_base(e->a->dtype) != DFDB_F32; };
-      const Node* dn = nullptr;
-      if (div_of_col(ea) && eb->op == DFIR_CONST) { dn = ea; cn = eb; }
-      else if (div_of_col(eb) && ea->op == DFIR_CONST) { dn = eb; cn = ea; op = flip(op); }
-      double kv;
-      if (dn && const_as_double(dn->b.get(), kv)) { affn = dn; aff.col = dn->a.get(); term.pre = 4; memcpy(&term.pre_magic, &kv, 8); term.pre_d = 0; }
-      else if (dn) cn = nullptr;
-    }
-    if (affn && term.pre != 4) {
-      const int cdt = dt_base(aff.col->dtype);
-      const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
-      const bool isflt = dt_base(affn->dtype) == DFDB_F64;
-      if (isflt != aff.flt && !(isflt && !aff.has_mul && !aff.has_add)) affn = nullptr;
-      else if (!isflt && !sint) affn = nullptr;
-      else if (isflt && !(dt_isnum(cdt) && cdt != DFDB_BOOL)) affn = nullptr;
-      if (affn) {
-        if (isflt) { term.pre = 3; memcpy(&term.pre_magic, &aff.fmul, 8); memcpy(&term.pre_d, &aff.fadd, 8); }
-        else { term.pre = 2; term.pre_magic = (uint64_t)aff.imul; term.pre_d = (uint64_t)aff.iadd; }
-      } else cn = nullptr;
-    }
-  }
-  if (remn) {
-    coln = remn->a.get();
-    const int cdt = dt_base(coln->dtype), mdt = dt_base(remn->b->dtype);
+// A value the scan kernels (and the transforming gather) can make from ONE column on the fly: the column itself (pre 0), rem(col, m) for a signed
+// integer column and an integer m other than 0 / 1 / -1 (pre 1: the DivideError of m = 0 stays with the interpreter), col * k + d with at most one
+// multiplication on the column and one addition / subtraction after it — all in wrapping Int64 (pre 2: a signed integer column, integer constants) or all
+// in Float64 with a rounding after each step, never fused (pre 3: any numeric column) — and col / k, Julia's Float64 division (pre 4).  `out` gets the
+// pre / pre_magic / pre_shift / pre_d fields of a ScanTerm; `coln` the column node.
+bool match_column_transform(const Node* e, ScanTerm& out, const Node*& coln) {
+  out.pre = 0; out.pre_shift = 0; out.pre_magic = 0; out.pre_d = 0;
+  if (e->op == DFIR_COL) { coln = e; return true; }
+  if (!e->a || !e->b || dt_nullable(e->dtype)) return false;
+  // rem(col, m)
+  if (e->op == DFIR_REM && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_I64) {
+    coln = e->a.get();
+    const int cdt = dt_base(coln->dtype), mdt = dt_base(e->b->dtype);
     const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
     const bool mint = mdt == DFDB_I8 || mdt == DFDB_I16 || mdt == DFDB_I32 || mdt == DFDB_I64;
     if (!sint || !mint || dt_nullable(coln->dtype)) return false;
-    const int64_t m = (int64_t)remn->b->cbits;
+    const int64_t m = (int64_t)e->b->cbits;
     if (m == 0 || m == 1 || m == -1) return false;
     const uint64_t d = m < 0 ? 0ull - (uint64_t)m : (uint64_t)m;          // |m|, 2 <= d <= 2^63
     // unsigned division by the invariant d, branch-free form: q = mulhi(magic, x); floor(x / d) = (((x - q) >> 1) + q) >> shift
@@ -348,14 +270,86 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
       if (twice >= d || twice < rem) pm += 1;
       magic = (uint64_t)pm + 1; shift = fl;
     }
-    term.pre = 1; term.pre_magic = magic; term.pre_shift = shift; term.pre_d = d;
-  } else if (affn) {
-    coln = aff.col;
-  } else {
-    if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST) { coln = n.a.get(); cn = n.b.get(); }
-    else if (n.a->op == DFIR_CONST && n.b->op == DFIR_COL) { coln = n.b.get(); cn = n.a.get(); op = flip(op); }
-    else return false;
+    out.pre = 1; out.pre_magic = magic; out.pre_shift = shift; out.pre_d = d;
+    return true;
   }
+  auto const_is_int = [](const Node* k) { const int d = dt_base(k->dtype); return d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64; };
+  auto const_as_double = [](const Node* k, double& o) {
+    const int d = dt_base(k->dtype);
+    if (d == DFDB_F64) { memcpy(&o, &k->cbits, 8); return true; }
+    if (d == DFDB_F32) { float f; memcpy(&f, &k->cbits, 4); o = (double)f; return true; }
+    if (d == DFDB_I8 || d == DFDB_I16 || d == DFDB_I32 || d == DFDB_I64) { o = (double)(int64_t)k->cbits; return true; }
+    return false;
+  };
+  // col / k
+  if (e->op == DFIR_DIV && e->a->op == DFIR_COL && e->b->op == DFIR_CONST && dt_base(e->dtype) == DFDB_F64 && !dt_nullable(e->a->dtype) && dt_isnum(e->a->dtype) &&
+      dt_base(e->a->dtype) != DFDB_BOOL && dt_base(e->a->dtype) != DFDB_F32) {
+    double kv;
+    if (!const_as_double(e->b.get(), kv)) return false;
+    coln = e->a.get(); out.pre = 4; memcpy(&out.pre_magic, &kv, 8);
+    return true;
+  }
+  // col * k + d
+  struct Affine { const Node* col = nullptr; bool flt = false; __int128 imul = 1, iadd = 0; double fmul = 1.0, fadd = 0.0; bool has_add = false, has_mul = false; };
+  std::function<bool(const Node*, Affine&, int)> affine = [&](const Node* x0, Affine& A, int depth) -> bool {
+    if (x0->op == DFIR_COL) { A.col = x0; return !dt_nullable(x0->dtype); }
+    if (depth > 2 || !x0->a || !x0->b || dt_nullable(x0->dtype)) return false;
+    const int rt = dt_base(x0->dtype);
+    if (rt != DFDB_I64 && rt != DFDB_F64) return false;
+    const bool flt = rt == DFDB_F64;
+    const Node *x = nullptr, *k = nullptr; bool k_left = false;
+    if (x0->b->op == DFIR_CONST) { x = x0->a.get(); k = x0->b.get(); } else if (x0->a->op == DFIR_CONST) { x = x0->b.get(); k = x0->a.get(); k_left = true; } else return false;
+    if (x0->op == DFIR_MUL) {
+      if (x->op != DFIR_COL || !affine(x, A, depth + 1) || A.has_mul || A.has_add) return false;   // the multiplication touches the column itself
+      if (flt) { double kv; if (!const_as_double(k, kv)) return false; A.flt = true; A.fmul = kv; }
+      else { if (!const_is_int(k)) return false; A.imul = (__int128)(int64_t)k->cbits; }
+      A.has_mul = true; return true;
+    }
+    if (x0->op != DFIR_ADD && x0->op != DFIR_SUB) return false;
+    if (!affine(x, A, depth + 1) || A.has_add) return false;
+    if (x->op != DFIR_COL && (dt_base(x->dtype) == DFDB_F64) != flt) return false;             // (col * k) in one type, the sum in another: not one form
+    if (flt) {
+      double kv; if (!const_as_double(k, kv)) return false;
+      if (!A.flt && A.has_mul) return false;
+      A.flt = true;
+      if (x0->op == DFIR_ADD) A.fadd = kv;
+      else if (!k_left) A.fadd = -kv;                       // x - k  =  x + (-k)   (exact: negation does not round)
+      else { A.fmul = -A.fmul; A.fadd = kv; }               // k - x  =  (-x) + k
+    } else {
+      if (!const_is_int(k) || A.flt) return false;
+      const __int128 kv = (__int128)(int64_t)k->cbits;
+      if (x0->op == DFIR_ADD) A.iadd = kv; else if (!k_left) A.iadd = -kv; else { A.imul = -A.imul; A.iadd = kv; }
+    }
+    A.has_add = true; return true;
+  };
+  if (e->op != DFIR_MUL && e->op != DFIR_ADD && e->op != DFIR_SUB) return false;
+  Affine aff;
+  if (!affine(e, aff, 0)) return false;
+  const int cdt = dt_base(aff.col->dtype);
+  const bool sint = cdt == DFDB_I8 || cdt == DFDB_I16 || cdt == DFDB_I32 || cdt == DFDB_I64;
+  const bool isflt = dt_base(e->dtype) == DFDB_F64;
+  if (isflt != aff.flt) return false;
+  if (!isflt && !sint) return false;
+  if (isflt && !(dt_isnum(cdt) && cdt != DFDB_BOOL)) return false;
+  coln = aff.col;
+  if (isflt) { out.pre = 3; memcpy(&out.pre_magic, &aff.fmul, 8); memcpy(&out.pre_d, &aff.fadd, 8); }
+  else { out.pre = 2; out.pre_magic = (uint64_t)aff.imul; out.pre_d = (uint64_t)aff.iadd; }
+  return true;
+}
+
+bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& ordinal) {
+  if (n.op == DFIR_COL && n.dtype == DFDB_BOOL) {   // a Bool column as the selection itself (DFColumn{Bool}: view.jl:60-72): its bytes != 0
+    term.col = nullptr; term.dtype = DFDB_BOOL; term.op = CMP_NE; term.cbits = 0; ordinal = n.col;
+    return true;
+  }
+  int op = cmp_from_ir(n.op);
+  if (op < 0 || !n.a || !n.b) return false;
+  const Node *coln = nullptr, *cn = nullptr;
+  // <column transform> OP const, either way round (match_column_transform: the column itself, rem, col * k + d, col / k)
+  if (n.b->op == DFIR_CONST && match_column_transform(n.a.get(), term, coln)) cn = n.b.get();
+  else if (n.a->op == DFIR_CONST && match_column_transform(n.b.get(), term, coln)) { cn = n.a.get(); op = flip(op); }
+  else { term.pre = 0; return false; }
+  const bool remn = term.pre == 1;
   const int coldt = dt_base(coln->dtype);
   const int ct = remn || term.pre == 2 ? (int)DFDB_I64 : (term.pre >= 3 ? (int)DFDB_F64 : coldt), kt = dt_base(cn->dtype);   // ct: the type the comparison happens in
   if (dt_nullable(coln->dtype) || !dt_isnum(ct) || ct == DFDB_BOOL) return false;

@@ -36,6 +36,7 @@ void flatten_and(const Node& n, std::vector<const Node*>& out);
 // own type; fills term (col pointer left null: the caller resolves the ordinal) and returns the ordinal.
 // always: set to +1/-1 when the comparison is constant true/false for every value of the column type.
 bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& ordinal);
+bool match_column_transform(const Node* e, ScanTerm& out, const Node*& coln);   // the column itself / rem / col * k + d / col / k (ScanTerm::pre)
 
 // `strcol == "x"`, `!=`, startswith, endswith  -> mode 0..3 (launch_str_match)
 bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat);

@@ -141,6 +141,72 @@ void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix
   }
 }
 
+// K3 with a column transform on the way (ScanTerm::pre: rem(col, m), col * k + d in wrapping Int64 or two-rounding Float64, col / k): the projection
+// `k = a * 2 + 1` over a filtered view costs the gather of `a` (1.4 ms per 1e9 rows at 10 %), not an interpreter pass over every tile (3.6 ms).
+// The arithmetic is the scan terms' (k_scan.hip term_word_rem / term_word_affine): same bits as the interpreter and as Julia.
+template <typename T>
+__device__ __forceinline__ uint64_t transform_value(T x, int pre, uint64_t magic, int shift, uint64_t dd) {
+  if (pre == 1) {
+    const int64_t xi = (int64_t)x;
+    const uint64_t ux = xi < 0 ? 0ull - (uint64_t)xi : (uint64_t)xi;
+    const uint64_t q0 = __umul64hi(magic, ux);
+    const uint64_t q = (((ux - q0) >> 1) + q0) >> shift;
+    const uint64_t r = ux - q * dd;
+    return (uint64_t)(xi < 0 ? -(int64_t)r : (int64_t)r);
+  }
+  if (pre == 2) return (uint64_t)(int64_t)x * magic + dd;
+  const double k = __longlong_as_double((long long)magic), d = __longlong_as_double((long long)dd);
+  const double y = pre == 3 ? __dadd_rn(__dmul_rn((double)x, k), d) : __ddiv_rn((double)x, k);
+  return (uint64_t)__double_as_longlong(y);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_transform(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                             const T* __restrict__ src, uint64_t* __restrict__ dst, int64_t nctiles, int64_t out_cap,
+                                                             int pre, uint64_t magic, int shift, uint64_t dd) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  int64_t ct = wave;
+  uint64_t w_next = ct < nctiles ? bitmap[ct * 64 + lane] : 0ull;
+  uint64_t ob_next = ct < nctiles ? prefix[ct * 4] : 0ull;
+  for (; ct < nctiles; ct += nwaves) {
+    const uint64_t w = w_next;
+    const int64_t obase = (int64_t)ob_next;
+    const int64_t nx = ct + nwaves;
+    if (nx < nctiles) { w_next = bitmap[nx * 64 + lane]; ob_next = prefix[nx * 4]; }
+    const uint32_t total = stage_positions(w, pos, lane);
+    const T* tsrc = src + ct * kCTile;
+    for (uint32_t k0 = 0; k0 < total; k0 += 256) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t k = k0 + (uint32_t)u * 64 + lane; v[u] = k < total ? __builtin_nontemporal_load(tsrc + pos[k]) : T(0); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + (uint32_t)u * 64 + lane;
+        const int64_t o = obase + k;
+        if (k < total && o < out_cap) dst[o] = transform_value<T>(v[u], pre, magic, shift, dd);
+      }
+    }
+    wave_lds_fence();
+  }
+}
+void launch_gather_transform(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, int32_t src_dtype, const ScanTerm& tf, void* dst,
+                             int64_t nrows, int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile;
+  if (nct == 0) return;
+  const dim3 g(grid_for_ctiles(nct)), b(kBlock);
+#define DFDB_GT(T) hipLaunchKernelGGL((k_gather_transform<T>), g, b, 0, s, bitmap, prefix, (const T*)src, (uint64_t*)dst, nct, out_cap, (int)tf.pre, tf.pre_magic, (int)tf.pre_shift, tf.pre_d)
+  switch (src_dtype) {
+    case DFDB_I8: DFDB_GT(int8_t); break; case DFDB_I16: DFDB_GT(int16_t); break; case DFDB_I32: DFDB_GT(int32_t); break; case DFDB_I64: DFDB_GT(int64_t); break;
+    case DFDB_U8: DFDB_GT(uint8_t); break; case DFDB_U16: DFDB_GT(uint16_t); break; case DFDB_U32: DFDB_GT(uint32_t); break; case DFDB_U64: DFDB_GT(uint64_t); break;
+    case DFDB_F32: DFDB_GT(float); break; default: DFDB_GT(double); break;
+  }
+#undef DFDB_GT
+}
+
 // projection of a predicate column whose selected values the scan already wrote per tile (k_scan_cmp / k_scan_terms CAP):
 // one wave per 4096-row ctile = 4 capture tiles; every lane finds its tile from the 5 prefix values and copies
 __global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __restrict__ cap, const uint64_t* __restrict__ prefix,

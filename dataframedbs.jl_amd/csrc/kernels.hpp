@@ -74,6 +74,9 @@ void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_
 // ---- K3: projection gather of a fixed-width column (width 1,2,4,8 bytes) -------------------------
 void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, void* dst, int width,
                    int64_t nrows, int64_t out_cap);
+// K3 with a column transform (ScanTerm::pre = 1..4: rem / col * k + d / col / k) applied to the gathered values; dst holds 8-byte results (Int64 or Float64)
+void launch_gather_transform(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, int32_t src_dtype, const ScanTerm& tf, void* dst,
+                             int64_t nrows, int64_t out_cap);
 // bitmap (1 = missing) of the source gathered into one byte per selected row
 void launch_gather_bits(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const uint64_t* srcbits, uint8_t* dst,
                         int64_t nrows, int64_t out_cap);

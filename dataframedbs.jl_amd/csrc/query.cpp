@@ -685,6 +685,13 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
     if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
     uint8_t* mdst = nullptr;                               // Union{R,Missing} result: one flag byte per selected row
     if (dt_nullable(e.dtype) && o.missing) { mdst = o.missing; if (!dev) { mstage.ensure((size_t)cnt); mdst = mstage.as<uint8_t>(); } }
+    // a transform of ONE plain column (rem / col * k + d / col / k: expr.cpp match_column_transform) rides on the gather of that column
+    ScanTerm tf; const Node* tcol = nullptr;
+    if (w == 8 && !dt_nullable(e.dtype) && match_column_transform(&e, tf, tcol) && tf.pre != 0 && !dt_nullable(tcol->dtype) && t->cols[(size_t)tcol->col].resident) {
+      const Column& sc = t->cols[(size_t)tcol->col];
+      LaunchTimer lt(ctx, "gather");
+      launch_gather_transform(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), sc.data.p, dt_base(sc.dtype), tf, dst, t->nrows, cnt);
+    } else
     run_interp_project(q, e, dst, cnt, mdst);
     if (!dev) {
       HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
