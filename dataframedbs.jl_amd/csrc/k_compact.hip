@@ -156,8 +156,10 @@ __device__ __forceinline__ uint64_t transform_value(T x, int pre, uint64_t magic
   }
   if (pre == 2) return (uint64_t)(int64_t)x * magic + dd;
   const double k = __longlong_as_double((long long)magic), d = __longlong_as_double((long long)dd);
-  const double y = pre == 3 ? __dadd_rn(__dmul_rn((double)x, k), d) : __ddiv_rn((double)x, k);
-  return (uint64_t)__double_as_longlong(y);
+  if (pre == 4) return (uint64_t)__double_as_longlong(__ddiv_rn((double)x, k));
+  double prod = (double)x * k;
+  asm volatile("" : "+v"(prod));                  // (no fma: see term_word_affine in k_scan.hip)
+  return (uint64_t)__double_as_longlong(prod + d);
 }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gather_transform(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,

@@ -259,7 +259,14 @@ __device__ __forceinline__ uint64_t term_word_affine(const ScanTerm& tm, uint32_
   const V k = from_bits<V>(tm.pre_magic), d = from_bits<V>(tm.pre_d);
   auto f = [&](T x) -> V {
     if constexpr (FLT == 2) return __ddiv_rn((double)x, k);
-    else if constexpr (FLT == 1) return __dadd_rn(__dmul_rn((double)x, k), d);
+    else if constexpr (FLT == 1) {
+      // two roundings, like Julia's two operations: hipcc contracts a * b + c into an fma by default (and __dmul_rn / __dadd_rn are plain * and +
+      // to it), which rounds once — one ulp off in 2 % of the rows of a 1e19-sized column (found by the fuzz soak).  The empty asm makes the
+      // product an opaque value the add cannot fuse with.
+      double prod = (double)x * k;
+      asm volatile("" : "+v"(prod));
+      return prod + d;
+    }
     else return (int64_t)((uint64_t)(int64_t)x * (uint64_t)k + (uint64_t)d);
   };
   uint64_t myword = 0;

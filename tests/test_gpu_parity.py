@@ -1102,8 +1102,16 @@ def test_affine_forms_of_one_column_are_scan_terms(oracle, dfdb_mod, ctx):
             assert j1 == j0, f"form {k} ({pred!r}) went through the interpreter"
         ov, dv = apply_stages(p, [("range", 10, 3, n - 11), ("pred", (a * 7 - 1 > 0) & (X * 0.5 < 3.0))], proj=[("a", a), ("x", X)])
         assert_same(p, ov, dv)
+        # the same transforms as PROJECTIONS ride on the gather (k_gather_transform).  Two roundings, never an fma: with |b| ~ 1e18 the addend is
+        # below one ulp of the product and a fused multiply-add lands one ulp away in ~2 % of the rows (found by the fuzz soak)
+        ov, dv = apply_stages(p, [("pred", a > -2000)], proj=[("k", b * -1.91 - (-36)), ("j", X * 3 + 1), ("r", i8 % 7), ("d", b / 3), ("w", b * 3 + 1), ("h", 0.5 - u16 * 0.1)])
+        assert_same(p, ov, dv)
+        with np.errstate(invalid="ignore", over="ignore"):
+            got = dv._query().materialize()
+            assert np.array_equal(got[0], cols["b"].astype(np.float64) * -1.91 + 36.0) and np.array_equal(got[4], cols["b"] * np.int64(3) + np.int64(1))
         i1, _ = ctx.profile_get("interp_predicate")
-        assert i1 == i0, "an affine form went through the interpreter"
+        j1, _ = ctx.profile_get("interp_project")
+        assert i1 == i0 and j1 == 0, "an affine form went through the interpreter"
         # not one form: a Float32 product (Float32 * Int stays Float32), two multiplications, an Int64 product under a Float64 sum, an Int8 product (stays Int8 and wraps there), unsigned wrap-around
         for pred in (f * 2 > 3.5, (a * 2) * 3 > 5, a * 2 + 0.5 > 10, (a + 1) * 2 > 10, i8 * ir.const(100, ir.I8) > 10, u16 * 70000 > 100, X * X > 4.0, a * b > 0):
             ov, dv = apply_stages(p, [("pred", pred)])
