@@ -290,7 +290,8 @@ bool match_column_transform(const Node* e, ScanTerm& out, const Node*& coln) {
     return true;
   }
   // col * k + d
-  struct Affine { const Node* col = nullptr; bool flt = false; __int128 imul = 1, iadd = 0; double fmul = 1.0, fadd = 0.0; bool has_add = false, has_mul = false; };
+  // (fadd starts at -0.0, the additive identity of IEEE arithmetic: x + (-0.0) == x for every x, -0.0 included; +0.0 would turn a -0.0 product into +0.0)
+  struct Affine { const Node* col = nullptr; bool flt = false; __int128 imul = 1, iadd = 0; double fmul = 1.0, fadd = -0.0; bool has_add = false, has_mul = false; };
   std::function<bool(const Node*, Affine&, int)> affine = [&](const Node* x0, Affine& A, int depth) -> bool {
     if (x0->op == DFIR_COL) { A.col = x0; return !dt_nullable(x0->dtype); }
     if (depth > 2 || !x0->a || !x0->b || dt_nullable(x0->dtype)) return false;

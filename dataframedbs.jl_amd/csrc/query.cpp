@@ -478,6 +478,18 @@ void query_execute(dfdb_query* q, int nstages) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
   q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  // A range-like stage that is EMPTY (an empty range, an empty index vector) finishes the reference's iteration before the first block is read:
+  // is_finished (selection.jl:192-196: `last <= offset` for ANY range stage of the queue) is tested ahead of every block (blocksiterator.jl:69-78).
+  // Nothing is evaluated — a predicate of another stage that would raise DivideError on some row never runs (found by the fuzz soak: the engine raised).
+  for (const Stage& st : q->stages) {
+    const bool empty = (st.kind == ST_RANGE && st.n == 0) || ((st.kind == ST_INDICES || st.kind == ST_INTEGER) && st.idx.empty());
+    if (!empty) continue;
+    HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, ctx->stream));
+    scan_prefix(q);
+    q->executed_stages = nstages;
+    return;
+  }
   if (nstages == 0) {
     LaunchTimer lt(ctx, "fill_ones");
     launch_fill_ones(ctx->stream, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);

@@ -1104,7 +1104,8 @@ def test_affine_forms_of_one_column_are_scan_terms(oracle, dfdb_mod, ctx):
         assert_same(p, ov, dv)
         # the same transforms as PROJECTIONS ride on the gather (k_gather_transform).  Two roundings, never an fma: with |b| ~ 1e18 the addend is
         # below one ulp of the product and a fused multiply-add lands one ulp away in ~2 % of the rows (found by the fuzz soak)
-        ov, dv = apply_stages(p, [("pred", a > -2000)], proj=[("k", b * -1.91 - (-36)), ("j", X * 3 + 1), ("r", i8 % 7), ("d", b / 3), ("w", b * 3 + 1), ("h", 0.5 - u16 * 0.1)])
+        ov, dv = apply_stages(p, [("pred", a > -2000)], proj=[("k", b * -1.91 - (-36)), ("j", X * 3 + 1), ("r", i8 % 7), ("d", b / 3), ("w", b * 3 + 1), ("h", 0.5 - u16 * 0.1),
+                                                             ("z", a * -2.5), ("z2", -3.0 * X), ("z3", X * -1.0 + 0.0)])       # (a product of zero keeps its sign: -2.5 * 0 is -0.0)
         assert_same(p, ov, dv)
         with np.errstate(invalid="ignore", over="ignore"):
             got = dv._query().materialize()
