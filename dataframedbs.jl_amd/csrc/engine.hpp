@@ -95,6 +95,9 @@ struct dfdb_query {
   // the final mask, the scan adds up the selected values while it holds them (one partial per 1024-row tile) and dfdb_aggregate only
   // reduces the partials
   int hint_agg_op = 0, hint_agg_proj = -1;
+  // the smallest rows on which a predicate of the current execution hit DivideError [0] / InexactError [1] (~0: none); decided at the end of query_execute
+  uint64_t err_row[2] = {~0ull, ~0ull};
+  bool err_checking = false;   // inside error_is_reached's partial executions: errors are not raised
   int agg_col = -1;            // table ordinal whose per-tile sums agg_partials holds (-1: none)
   int agg_dtype = 0, agg_op = 0;
   dfdb::DevBuf agg_partials, agg_ones;

@@ -171,12 +171,18 @@ DFDB_SLOW double slow_fmod(double a, double b) {
   if (v == 0.0) v = __builtin_copysign(v, b); else if ((v > 0.0) != (b > 0.0)) v += b;
   return v;
 }
+// err[0]: flags (1 DivideError, 2 InexactError); the two 64-bit words at err + 2: the SMALLEST row each kind happened on (the host decides from it
+// whether the reference's block-by-block iteration would have reached that row at all: query.cpp error_is_reached)
+__device__ __forceinline__ void flag_error(int* err, int code, uint64_t row) {
+  atomicOr(err, code);
+  atomicMin((unsigned long long*)(err + 2) + (code == 1 ? 0 : 1), (unsigned long long)row);
+}
 DFDB_SLOW double slow_fidiv(double a, double b) { return __builtin_rint((a - fmod(a, b)) / b); }
-DFDB_SLOW uint64_t slow_idivop(int64_t a, int64_t b, int op, bool uns, int64_t tmin, bool alive, int* err) {
+DFDB_SLOW uint64_t slow_idivop(int64_t a, int64_t b, int op, bool uns, int64_t tmin, bool alive, int* err, uint64_t row) {
   int64_t v = 0;
-  if (b == 0) { if (alive) atomicOr(err, 1); }
+  if (b == 0) { if (alive) flag_error(err, 1, row); }
   else if (uns) v = op == DFIR_IDIV ? (int64_t)((uint64_t)a / (uint64_t)b) : (int64_t)((uint64_t)a % (uint64_t)b);
-  else if (b == -1) { if (op == DFIR_IDIV) { if (a == tmin) { if (alive) atomicOr(err, 1); } else v = -a; } }
+  else if (b == -1) { if (op == DFIR_IDIV) { if (a == tmin) { if (alive) flag_error(err, 1, row); } else v = -a; } }
   else if (op == DFIR_IDIV) v = a / b;
   else { v = a % b; if (op == DFIR_MOD && v != 0 && ((v < 0) != (b < 0))) v += b; }
   return (uint64_t)v;
@@ -209,7 +215,7 @@ __device__ __forceinline__ bool int_fits(uint64_t x, bool src_unsigned, int rt) 
   if (src_unsigned) return x <= (uint64_t)hi;
   return (int64_t)x >= lo && (int64_t)x <= hi;
 }
-DFDB_SLOW uint64_t slow_cast(uint64_t xa, int ta, int rt, bool alive, int* err) {
+DFDB_SLOW uint64_t slow_cast(uint64_t xa, int ta, int rt, bool alive, int* err, uint64_t row) {
   if (isf(rt)) return d_bits(as_float(xa, ta, rt));
   if (isf(ta)) {   // Float -> Int / Bool: InexactError unless integral and inside the TARGET's range
     const double d = bits_d(xa);
@@ -217,13 +223,13 @@ DFDB_SLOW uint64_t slow_cast(uint64_t xa, int ta, int rt, bool alive, int* err) 
     uint64_t v = 0;
     if (rt == DFDB_U64) { okr = okr && d >= 0.0 && d < 18446744073709551616.0; if (okr) v = (uint64_t)d; }
     else { okr = okr && d >= -9223372036854775808.0 && d < 9223372036854775808.0; if (okr) { v = (uint64_t)(int64_t)d; okr = rt == DFDB_BOOL || int_fits(v, false, rt); } }
-    if (!okr && alive) atomicOr(err, 2);
+    if (!okr && alive) flag_error(err, 2, row);
     if (!okr) v = 0;
-    if (rt == DFDB_BOOL) { if (v > 1 && alive) atomicOr(err, 2); return v != 0; }
+    if (rt == DFDB_BOOL) { if (v > 1 && alive) flag_error(err, 2, row); return v != 0; }
     return (uint64_t)wrap_to((int64_t)v, rt);
   }
-  if (rt == DFDB_BOOL) { if (xa > 1 && alive) atomicOr(err, 2); return xa != 0; }
-  if (ta != DFDB_BOOL && !int_fits(xa, ta >= DFDB_U8 && ta <= DFDB_U64, rt) && alive) atomicOr(err, 2);
+  if (rt == DFDB_BOOL) { if (xa > 1 && alive) flag_error(err, 2, row); return xa != 0; }
+  if (ta != DFDB_BOOL && !int_fits(xa, ta >= DFDB_U8 && ta <= DFDB_U64, rt) && alive) flag_error(err, 2, row);
   return (uint64_t)wrap_to((int64_t)xa, rt);
 }
 
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
             EACH {
               const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);   // missing ÷ x is missing, not an error
               const int64_t a = (int64_t)wrapv(A[k], wsh, wsg), b = (int64_t)wrapv(B[k], wsh, wsg);
-              const uint64_t v = slow_idivop(a, b, op, uns, tmin, alive, err);
+              const uint64_t v = slow_idivop(a, b, op, uns, tmin, alive, err, (uint64_t)(base + idx[k]));
               A[k] = wrapv(v, wsh, wsg);
             }
           } break;
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
 #pragma unroll
             EACH {
               const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);
-              A[k] = slow_cast(A[k], ta, rt, alive, err);
+              A[k] = slow_cast(A[k], ta, rt, alive, err, (uint64_t)(base + idx[k]));
             }
           } break;
         }
@@ -903,6 +909,7 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   std::vector<uint8_t> img(err_off + 64, 0);
   memcpy(img.data(), &c.prog, sizeof(IProgram));
   if (!c.pool.empty()) memcpy(img.data() + pool_off, c.pool.data(), c.pool.size());
+  memset(img.data() + err_off + 8, 0xFF, 16);            // the smallest erroring rows: none yet
   HIP_CHECK(hipMemcpyAsync(db.p, img.data(), img.size(), hipMemcpyHostToDevice, s));
   stream_wait(q->t->ctx);
   const int64_t ntiles = ceil_div(t->nrows, kTile);
@@ -926,11 +933,19 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
 #undef DFDB_INTERP_LAUNCH
     HIP_CHECK(hipGetLastError());
   }
-  int herr = 0;
-  HIP_CHECK(hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, s));
+  struct { int flags, pad; uint64_t row[2]; } herr{0, 0, {~0ull, ~0ull}};
+  HIP_CHECK(hipMemcpyAsync(&herr, derr, 24, hipMemcpyDeviceToHost, s));
   stream_wait(q->t->ctx);
-  if (herr & 1) fail(DFDB_ERR_DIVIDE, "DivideError: integer division error");
-  if (herr & 2) fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
+  if (!herr.flags) return;
+  if (mode == 0) {
+    // a predicate: WHETHER the reference raises depends on whether its block-by-block iteration reaches the row (query_execute decides once every
+    // stage has run: error_is_reached); the erroring rows count as not selected until then
+    if (herr.flags & 1) q->err_row[0] = std::min(q->err_row[0], herr.row[0]);
+    if (herr.flags & 2) q->err_row[1] = std::min(q->err_row[1], herr.row[1]);
+    return;
+  }
+  if ((herr.flags & 1) && (!(herr.flags & 2) || herr.row[0] <= herr.row[1])) fail(DFDB_ERR_DIVIDE, "DivideError: integer division error");
+  fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
 }
 
 void run_interp_predicate(dfdb_query* q, const Node& pred, bool and_existing) { run_interp(q, pred, 0, and_existing, nullptr, 0, nullptr); }

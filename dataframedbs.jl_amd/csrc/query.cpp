@@ -185,6 +185,7 @@ static const Column& need_resident(const dfdb_table* t, int ordinal) {
   return c;
 }
 
+static void raise_reached_errors(dfdb_query* q, int nstages);
 static void scan_prefix(dfdb_query* q) {
   dfdb_ctx* ctx = q->t->ctx;
   LaunchTimer lt(ctx, "scan_counts");
@@ -473,11 +474,68 @@ static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
   q->prefix_valid = false;
 }
 
+// A predicate hit DivideError / InexactError on some rows.  Julia raises it only if the reference's iteration EVALUATES the block such a row lives in
+// (src/io/blocksiterator.jl:69-121): blocks wholly before the first element of a leading range stage are skipped unread (skip_if_can,
+// selection.jl:177-190), and once ANY range-like stage has been fed its last element (`last <= offset`, is_finished :192-196, tested before every block)
+// nothing more is read.  `offset` of stage k before a block = the survivors of stages [0, k) in the rows before that block (+ stage_base on a shard).
+// The rows before the erroring block raise nothing (it is the SMALLEST erroring row), so those counts come from ordinary partial executions.
+static int64_t selected_before(dfdb_query* q, int64_t row) {                 // set bits of q's current bitmap in rows [0, row)
+  dfdb_ctx* ctx = q->t->ctx; hipStream_t s = ctx->stream;
+  const int64_t tile = row / kTileRows, words = (row % kTileRows) / 64, rem = row % 64;
+  uint64_t pre = 0, w[17] = {0};
+  HIP_CHECK(hipMemcpyAsync(&pre, q->prefix.as<uint64_t>() + tile, 8, hipMemcpyDeviceToHost, s));
+  if (row % kTileRows) HIP_CHECK(hipMemcpyAsync(w, q->bitmap.as<uint64_t>() + tile * 16, (size_t)(words + 1) * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  int64_t c = (int64_t)pre;
+  for (int64_t k = 0; k < words; k++) c += __builtin_popcountll(w[k]);
+  if (rem) c += __builtin_popcountll(w[words] & ((1ull << rem) - 1ull));
+  return c;
+}
+static bool error_is_reached(dfdb_query* q, uint64_t erow) {
+  dfdb_table* t = q->t;
+  const int64_t bs = t->block_size;
+  const int64_t blk_row0 = ((int64_t)erow / bs) * bs;                          // first local row of the erroring block
+  for (size_t k = 0; k < q->stages.size(); k++) {
+    const Stage& st = q->stages[k];
+    if (st.kind == ST_PRED) continue;
+    if (k == 0) {
+      // a leading range numbers table rows: blocks that end before its first element are skipped, blocks after its last are never read
+      if (st.first() - (t->row_base + blk_row0) > bs) return false;         // _skip_if_can: elem.first - elem.offset > size_to_skip (the table's block size)
+      if (st.last() <= t->row_base + blk_row0) return false;
+      continue;
+    }
+    query_execute(q, (int)k);                                                  // survivors of stages [0, k): what stage k is fed
+    if (st.last() <= st.stage_base + selected_before(q, blk_row0)) return false;
+  }
+  return true;
+}
+static void raise_reached_errors(dfdb_query* q, int nstages) {
+  const uint64_t er[2] = {q->err_row[0], q->err_row[1]};
+  bool any_range = false;
+  for (const Stage& st : q->stages) any_range = any_range || st.kind != ST_PRED;
+  int raise = -1;
+  if (!any_range) raise = er[0] <= er[1] ? 0 : 1;                             // every block is evaluated: the error of the smaller row
+  else {
+    q->err_checking = true;
+    try {
+      // in row order: the first error the iteration reaches is the one Julia throws
+      const int first = er[0] <= er[1] ? 0 : 1;
+      for (int i = 0; i < 2 && raise < 0; i++) { const int kind = i == 0 ? first : 1 - first; if (er[kind] != ~0ull && error_is_reached(q, er[kind])) raise = kind; }
+      if (raise < 0) query_execute(q, nstages);                                // not reached: the result stands (the erroring rows are beyond the finish)
+    } catch (...) { q->err_checking = false; throw; }
+    q->err_checking = false;
+  }
+  q->err_row[0] = q->err_row[1] = ~0ull;
+  if (raise == 0) { q->executed_stages = -1; fail(DFDB_ERR_DIVIDE, "DivideError: integer division error"); }
+  if (raise == 1) { q->executed_stages = -1; fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact"); }
+}
+
 void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
   q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  q->err_row[0] = q->err_row[1] = ~0ull;
   // A range-like stage that is EMPTY (an empty range, an empty index vector) finishes the reference's iteration before the first block is read:
   // is_finished (selection.jl:192-196: `last <= offset` for ANY range stage of the queue) is tested ahead of every block (blocksiterator.jl:69-78).
   // Nothing is evaluated — a predicate of another stage that would raise DivideError on some row never runs (found by the fuzz soak: the engine raised).
@@ -512,6 +570,7 @@ void query_execute(dfdb_query* q, int nstages) {
   }
   scan_prefix(q);
   q->executed_stages = nstages;
+  if (!q->err_checking && (q->err_row[0] != ~0ull || q->err_row[1] != ~0ull)) raise_reached_errors(q, nstages);
 }
 
 static void ensure_executed(dfdb_query* q) {

@@ -36,6 +36,9 @@ def pair(oracle, dfdb_mod, request):
         "z": rng.integers(-2, 3, N).astype(np.int64),                         # 12 (zeros: a divisor that raises)
         "sm": [None if i % 11 == 3 else "%s%d" % ("xy"[i % 2] * (i % 4), i % 7) for i in range(N)],                   # 13 Union{String,Missing}
         "mf": np.ma.masked_array(rng.normal(0, 5, N), mask=rng.random(N) < 0.4),                                         # 14 Union{Float64,Missing}
+        # 15: a divisor whose zeros all sit in the LAST third of the table: whether `a % zl` raises depends on whether the reference's block-by-block
+        # iteration gets that far (a later range stage that has seen its last element ends it: is_finished, selection.jl:192-196)
+        "zl": np.where(np.arange(N) >= 2 * N // 3, rng.integers(0, 2, N), rng.integers(1, 5, N)).astype(np.int64),
     }
     p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK)
     if request.param == "string dictionary":             # K9: every string predicate and projection of `s` goes through the codes
@@ -81,7 +84,7 @@ class Gen:
         if k == 8: return a / (b if self.risky else ir.col(2))
         # integer-only operators: integer operands (÷, rem, mod are defined for floats too, but keep the divisor's zero under control)
         ia = ir.col(self.pick(INT_COLS)) if self.rng.random() < 0.8 else ir.col(self.pick([7, 8]))     # (rem / mod / div of floats too)
-        ib = (ir.col(12) if self.risky and self.rng.random() < 0.5 else self.pick([ir.col(2), ir.const(7), ir.const(-3), ir.col(2) * 2 + 1]))
+        ib = (ir.col(15) if self.risky and self.rng.random() < 0.35 else ir.col(12) if self.risky and self.rng.random() < 0.5 else self.pick([ir.col(2), ir.const(7), ir.const(-3), ir.col(2) * 2 + 1]))
         if k == 9: return ia % ib
         if k == 10: return ir.mod(ia, ib)
         return ir.div(ia, ib)

@@ -1126,3 +1126,49 @@ def test_affine_forms_of_one_column_are_scan_terms(oracle, dfdb_mod, ctx):
                            (2.0 - X >= 1e308, 2.0 - xv >= 1e308), (b * 1.0 > 9.2e18, bv * 1.0 > 9.2e18)):
             ov, dv = apply_stages(p, [("pred", pred)])
             assert np.array_equal(dv._query().indices(), np.nonzero(want)[0] + 1)
+
+
+def test_errors_surface_only_where_the_block_iteration_gets(oracle, dfdb_mod, ctx):
+    """DivideError / InexactError of a predicate are raised by the reference only if its block-by-block iteration EVALUATES the block the offending
+    row lives in: blocks wholly before the first element of a leading range are skipped unread (skip_if_can, selection.jl:177-190) and once any range
+    stage has seen its last element nothing more is read (is_finished :192-196).  The engine evaluates whole columns, records the smallest erroring row
+    and decides the same way (query.cpp error_is_reached); oracle and engine must agree case by case, raising and not raising."""
+    from dfdb import ir
+    n, bs = 10_000, 1000
+    a = np.arange(1, n + 1, dtype=np.int64)
+    z = np.ones(n, np.int64); z[7_500] = 0                       # one zero divisor, in block 7 (rows 7001..8000)
+    f = np.full(n, 2.0); f[3_200] = 2.5                          # one inexact conversion, in block 3
+    p = Pair(oracle, dfdb_mod, {"a": a, "z": z, "f": f}, block_size=bs)
+    A, Z, F = ir.col(0), ir.col(1), ir.col(2)
+    risky_div, risky_cast = (A % Z == 0), (ir.cast(F, ir.I64) == 2)
+    cases = [
+        ([("pred", risky_div)], "ZeroDivisionError"),                                        # no range stage: every block is evaluated
+        ([("pred", risky_div), ("range", 1, 1, 50)], None),                                  # the range is satisfied inside block 0
+        ([("pred", risky_div), ("range", 1, 1, 7_000)], None),                               # ... exactly at the end of block 6: block 7 is never read
+        ([("pred", risky_div), ("range", 1, 1, 7_001)], "ZeroDivisionError"),                # one more survivor needed: block 7 is read
+        ([("range", 1, 1, 7_500), ("pred", risky_div)], None),                               # a predicate after a range sees the range's rows only: row 7501 is not one
+        ([("range", 1, 1, 7_501), ("pred", risky_div)], "ZeroDivisionError"),
+        ([("range", 7_502, 1, 9_000), ("pred", risky_div)], None),
+        ([("range", 7_501, 7, 9_000), ("pred", risky_div)], "ZeroDivisionError"),
+        ([("pred", risky_div), ("range", 6_900, 1, 7_000), ("range", 1, 1, 2)], None),       # two range stages: the LAST one is done in block 6
+        ([("pred", A > 6_990), ("idx", [3, 5, 9]), ("pred", risky_div)], None),              # survivors 3, 5, 9 of stage 1 all live in block 6
+        ([("pred", A > 6_990), ("idx", [3, 5, 511]), ("pred", risky_div)], "ZeroDivisionError"),   # survivor 511 is row 7501: the zero divisor itself
+        ([("pred", risky_div), ("pred", A > 6_990), ("idx", [3, 5, 11])], "ZeroDivisionError"),    # survivor 11 is row 7001: block 7 is read, all of it evaluated
+        ([("pred", risky_div), ("pred", A > 6_990), ("idx", [3, 5, 10])], None),                   # ... row 7000: done in block 6
+        ([("pred", risky_cast), ("range", 1, 2, 3_000)], None),                              # InexactError lurking in block 3, range done in block 2
+        ([("pred", risky_cast), ("range", 1, 2, 3_001)], "ValueError"),
+        ([("pred", risky_cast & risky_div), ("range", 1, 1, 9_999)], "ValueError"),          # both lurk: the iteration meets block 3 first
+        ([("pred", risky_div), ("pred", A < 100)], "ZeroDivisionError"),                     # predicates only: fused, every row evaluated
+    ]
+    for stages, want_err in cases:
+        ov, dv = apply_stages(p, stages)
+        o = None
+        try: o_n = ov.nrow()
+        except Exception as e: o = type(e).__name__      # noqa: E722,BLE001
+        d = None
+        try: d_n = dfdb_mod.nrow(dv)
+        except Exception as e: d = type(e).__name__      # noqa: BLE001
+        assert o == want_err, (stages, "oracle", o)
+        assert d == want_err, (stages, "engine", d)
+        if want_err is None:
+            assert_same(p, ov, dv)
