@@ -264,7 +264,13 @@ static inline int cmp_to_bool(int op, int c) {
 /* ---------------------------------------------------------------- evaluation */
 typedef struct {
   const colbuf_t* bufs; const int32_t* idx; int64_t n; arena_t* ar; int err;
+  int64_t erow[2];   /* the first evaluated element each kind of error happened on ([0] DivideError, [1] InexactError): Julia throws the one of the earlier row */
 } ectx_t;
+static void flag_err(ectx_t* c, int code, int64_t k) {
+  c->err = code;
+  int kind = code == ORC_ERR_DIVIDE ? 0 : 1;
+  if (k < c->erow[kind]) c->erow[kind] = k;
+}
 
 static int vec_alloc(ectx_t* c, vec_t* v, int dtype, int64_t n) {
   memset(v, 0, sizeof *v); v->dtype = dtype; v->n = n;
@@ -327,7 +333,7 @@ static int conv(ectx_t* c, const vec_t* s, int to, vec_t* d) {
       int ok = x == trunc(x);
       if (to == DFDB_U64) ok = ok && x >= 0.0 && x < 18446744073709551616.0;
       else ok = ok && x >= -9223372036854775808.0 && x < 9223372036854775808.0;
-      if (!ok) { c->err = ORC_ERR_ARGUMENT; d->i[k] = 0; }
+      if (!ok) { flag_err(c, ORC_ERR_ARGUMENT, k); d->i[k] = 0; }
       else d->i[k] = to == DFDB_U64 ? (int64_t)(uint64_t)x : wrap_int((int64_t)x, to);
     }
   } else if (dt_isfloat(to)) {
@@ -337,8 +343,8 @@ static int conv(ectx_t* c, const vec_t* s, int to, vec_t* d) {
     } else if (from == DFDB_BOOL) for (int64_t k = 0; k < n; k++) d->f[k] = s->b[k];
     else for (int64_t k = 0; k < n; k++) d->f[k] = to == DFDB_F32 ? (double)(float)s->f[k] : s->f[k];
   } else { /* to Bool */
-    if (dt_isint(from)) for (int64_t k = 0; k < n; k++) { if (s->i[k] != 0 && s->i[k] != 1 && !(ms && ms[k])) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->i[k] != 0; }
-    else for (int64_t k = 0; k < n; k++) { if (s->f[k] != 0 && s->f[k] != 1 && !(ms && ms[k])) c->err = ORC_ERR_ARGUMENT; d->b[k] = s->f[k] != 0; }
+    if (dt_isint(from)) for (int64_t k = 0; k < n; k++) { if (s->i[k] != 0 && s->i[k] != 1 && !(ms && ms[k])) flag_err(c, ORC_ERR_ARGUMENT, k); d->b[k] = s->i[k] != 0; }
+    else for (int64_t k = 0; k < n; k++) { if (s->f[k] != 0 && s->f[k] != 1 && !(ms && ms[k])) flag_err(c, ORC_ERR_ARGUMENT, k); d->b[k] = s->f[k] != 0; }
   }
   return 0;
 }
@@ -553,12 +559,12 @@ static int eval_binary_core(const node_t* nd, ectx_t* c, vec_t* out, vec_t* pva,
       case DFIR_MAX: r = uns && ct == DFDB_U64 ? ((uint64_t)a > (uint64_t)b ? a : b) : (a > b ? a : b); break;
       case DFIR_REM: case DFIR_MOD: case DFIR_IDIV:
         if ((xa.miss && xa.miss[k * sa]) || (xb.miss && xb.miss[k * sb])) { r = 0; break; }   /* missing ÷ x is missing, not an error */
-        if (b == 0) { c->err = ORC_ERR_DIVIDE; r = 0; break; }
+        if (b == 0) { flag_err(c, ORC_ERR_DIVIDE, k); r = 0; break; }
         if (uns) {
           uint64_t ua = (uint64_t)a, ub = (uint64_t)b;
           r = op == DFIR_IDIV ? (int64_t)(ua / ub) : (int64_t)(ua % ub);
         } else if (b == -1) {
-          if (op == DFIR_IDIV) { if (a == int_min_of(ct)) { c->err = ORC_ERR_DIVIDE; r = 0; } else r = -a; }
+          if (op == DFIR_IDIV) { if (a == int_min_of(ct)) { flag_err(c, ORC_ERR_DIVIDE, k); r = 0; } else r = -a; }
           else r = 0;
         } else if (op == DFIR_IDIV) r = a / b;
         else { r = a % b; if (op == DFIR_MOD && r != 0 && ((r < 0) != (b < 0))) r += b; }
@@ -653,7 +659,7 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
               int64_t v = a.i[k];
               ok = to == DFDB_U64 ? v >= 0 : (v >= lo && v <= hi);
             }
-            if (!ok) c->err = ORC_ERR_ARGUMENT;
+            if (!ok) flag_err(c, ORC_ERR_ARGUMENT, k);
           }
         }
       }
@@ -666,12 +672,12 @@ static int eval(const node_t* nd, ectx_t* c, vec_t* out) {
 }
 
 int expr_eval(const node_t* nd, const colbuf_t* bufs, const int32_t* idx, int64_t n, arena_t* ar, vec_t* out) {
-  ectx_t c = {bufs, idx, n, ar, 0};
+  ectx_t c = {bufs, idx, n, ar, 0, {INT64_MAX, INT64_MAX}};
   vec_t v; int rc = eval(nd, &c, &v); if (rc) return rc;
   if (n == 0) c.err = 0;   /* no row reached this evaluation: a broadcast over nothing calls nothing, so even a constant sub-expression that always throws
                               (`UInt16(-42.0)`) does not (found by tests/test_gpu_fuzz.py: the engine was right) */
-  if (c.err == ORC_ERR_DIVIDE) return orc_fail(ORC_ERR_DIVIDE, "DivideError: integer division error");
-  if (c.err) return orc_fail(c.err, "InexactError in conversion");
+  if (c.err && c.erow[0] <= c.erow[1]) return orc_fail(ORC_ERR_DIVIDE, "DivideError: integer division error");   /* the earlier row's error (same row: the division) */
+  if (c.err) return orc_fail(ORC_ERR_ARGUMENT, "InexactError in conversion");
   if (v.is_const && !v.scol && !v.cstr) { /* broadcast a scalar result to n elements */
     vec_t w; int rt = dt_base(v.dtype); ectx_t c2 = c;
     if ((rc = vec_alloc(&c2, &w, rt, n))) return rc;

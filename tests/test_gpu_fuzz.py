@@ -160,15 +160,14 @@ def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
     want = outcome(lambda: ov.nrow())
     got = outcome(lambda: dfdb_mod.nrow(dv))
     assert want[0] == got[0], f"oracle {want}, engine {got} for {stages} / {proj}"
-    # which error: Julia raises the one of the first row (then the leftmost sub-expression) that fails; when a queue holds both a zero divisor and an
-    # inexact conversion (risky seeds) the GPU, which evaluates a block at once, may report the other of the two — that both raise is what is checked there
+    # which error: Julia raises the one of the first row that fails; oracle and engine both report the kind of the EARLIEST erroring row
     if want[0] == "err":
-        assert want[1] == got[1] or g.risky, f"oracle raises {want[1]}, engine {got[1]} for {stages}"
+        assert want[1] == got[1], f"oracle raises {want[1]}, engine {got[1]} for {stages}"
         return
     w2 = outcome(lambda: ov.materialize())
     if w2[0] == "err":              # the projection raises (DivideError / InexactError on a selected row)
         g2 = outcome(lambda: dv._query().materialize())
-        assert g2 == w2 or (g.risky and g2[0] == "err"), f"oracle {w2}, engine {g2} for {proj}"
+        assert g2 == w2, f"oracle {w2}, engine {g2} for {proj}"
         return
     assert_same(pair, ov, dv)
 
