@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 N = int(os.environ.get("DFDB_FUZZ_ROWS", "12345"))          # (DFDB_FUZZ_ROWS=300007 DFDB_FUZZ_BLOCK=65536: the same queues over a bigger table)
 BLOCK = int(os.environ.get("DFDB_FUZZ_BLOCK", "1000"))
 SCALE = int(os.environ.get("DFDB_FUZZ_SCALE", "1"))      # DFDB_FUZZ_SCALE=20 python -m pytest tests/test_gpu_fuzz.py: 20 x the seeds
+SEED0 = int(os.environ.get("DFDB_FUZZ_SEED0", "0"))      # DFDB_FUZZ_SEED0=10000000: the same number of cases from fresh seeds (soaks)
 
 
 @pytest.fixture(scope="module", params=["flat strings", "string dictionary"])
@@ -146,7 +147,7 @@ def outcome(fn):
         return ("err", type(e).__name__)
 
 
-@pytest.mark.parametrize("seed", range(400 * SCALE))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 400 * SCALE))
 def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
     from dfdb import ir
     g = Gen(ir, seed, risky=seed % 4 == 3)
@@ -211,7 +212,7 @@ class GenNoMissing(Gen):
         return (a & b) if k == 0 else (a | b) if k == 1 else (a ^ b) if k == 2 else ~a
 
 
-@pytest.mark.parametrize("seed", range(120 * SCALE))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 120 * SCALE))
 def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     """Range and index stages after predicates number the SURVIVORS: across chunk boundaries (streaming) and across shards (the stage-base exchange)
     their running offsets must continue exactly where the previous chunk / the lower ranks stopped."""
@@ -242,7 +243,7 @@ def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     assert np.array_equal(gm[0], want[0]) and np.array_equal(gm[2], want[2])
 
 
-@pytest.mark.parametrize("seed", range(200 * SCALE))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 200 * SCALE))
 def test_random_aggregates(pair, dfdb_mod, seed):
     """sum / min / max / count of a random numeric column over a random queue: the fused forms (the scan adds up or keeps the extremum of a column
     that is itself a term of the last launch) and the plain reduce must both equal numpy over the rows the oracle selects — Int sums exactly
@@ -295,7 +296,7 @@ def pair_columns(pair):
     return _PAIR_COLUMNS[key]
 
 
-@pytest.mark.parametrize("seed", range(100 * SCALE))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 100 * SCALE))
 def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
     """groupreduce / unique over a random queue, keyed by an integer column, the nullable column (missing is a group) or the String column (through the
     hash table when it is flat, through the 16-bit codes when it has a dictionary): groups in order of first appearance among the rows the oracle selects,

@@ -316,7 +316,7 @@ def test_encoder_corner_cases(oracle, dfdb_mod, ctx, tmp_path, enc):
         ctx.set_option("lz4_enc_variant", 1)
 
 
-@pytest.mark.parametrize("seed", range(24 * int(os.environ.get("DFDB_FUZZ_SCALE", "1"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DFDB_FUZZ_SEED0", "0")), int(os.environ.get("DFDB_FUZZ_SEED0", "0")) + 24 * int(os.environ.get("DFDB_FUZZ_SCALE", "1"))))
 def test_random_tables_written_by_the_device_read_back(oracle, dfdb_mod, ctx, tmp_path, seed):
     """Seeded fuzz of the write side: a table of random shape (row count, block size, 1-6 columns of random type — every integer width, floats, Bool,
     Strings, nullable forms — with contents from incompressible to constant, with LZ77-shaped byte structure in between), saved by the device packer +
