@@ -98,6 +98,7 @@ struct dfdb_query {
   // the smallest rows on which a predicate of the current execution hit DivideError [0] / InexactError [1] (~0: none); decided at the end of query_execute
   uint64_t err_row[2] = {~0ull, ~0ull};
   bool err_checking = false;   // inside error_is_reached's partial executions: errors are not raised
+  uint64_t* proj_err = nullptr; // query_materialize: the first erroring row per kind of the projection column being computed lands here instead of raising
   int agg_col = -1;            // table ordinal whose per-tile sums agg_partials holds (-1: none)
   int agg_dtype = 0, agg_op = 0;
   dfdb::DevBuf agg_partials, agg_ones;

@@ -944,6 +944,11 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
     if (herr.flags & 2) q->err_row[1] = std::min(q->err_row[1], herr.row[1]);
     return;
   }
+  if (q->proj_err) {          // one of several projection columns: query_materialize picks the error the reference's block-by-block, column-by-column order meets first
+    if (herr.flags & 1) q->proj_err[0] = std::min(q->proj_err[0], herr.row[0]);
+    if (herr.flags & 2) q->proj_err[1] = std::min(q->proj_err[1], herr.row[1]);
+    return;
+  }
   if ((herr.flags & 1) && (!(herr.flags & 2) || herr.row[0] <= herr.row[1])) fail(DFDB_ERR_DIVIDE, "DivideError: integer division error");
   fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
 }

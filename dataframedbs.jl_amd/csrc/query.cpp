@@ -776,7 +776,24 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
   ensure_executed(q);
   if (ncols != (int32_t)q->proj.size()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: view has %zu columns, %d outputs given", q->proj.size(), ncols);
   const int64_t cnt = query_count(q, -1);
-  for (int32_t p = 0; p < ncols; p++) materialize_col(q, p, outs[p], cnt);
+  // a computed column that raises (DivideError / InexactError on a selected row): the reference evaluates block by block and, inside a block, the projection's
+  // columns in order (projection.jl:149-154 under blocksiterator.jl:98-121) — the error it throws is the one of the first BLOCK that holds an erroring row, the
+  // first such COLUMN in that block, the first such row of that column.  The columns are computed whole here, so their first erroring rows are collected and
+  // the choice is made at the end.
+  uint64_t pe[2], best_block = ~0ull; int best_kind = -1;
+  const uint64_t bs = (uint64_t)std::max<int64_t>(q->t->block_size, 1);
+  q->proj_err = pe;
+  try {
+    for (int32_t p = 0; p < ncols; p++) {
+      pe[0] = pe[1] = ~0ull;
+      materialize_col(q, p, outs[p], cnt);
+      const uint64_t r = std::min(pe[0], pe[1]);
+      if (r != ~0ull && r / bs < best_block) { best_block = r / bs; best_kind = pe[0] <= pe[1] ? 0 : 1; }
+    }
+  } catch (...) { q->proj_err = nullptr; throw; }
+  q->proj_err = nullptr;
+  if (best_kind == 0) fail(DFDB_ERR_DIVIDE, "DivideError: integer division error");
+  if (best_kind == 1) fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact");
 }
 
 // add_column!(table, name, lazy_col) (src/tables/table.jl:96-124): the p-th column of the view materialised into a new

@@ -1216,20 +1216,20 @@ def map_to_column(f: Callable, v: Union[DFView, DFTable]) -> DFColumn:   # view.
 _STATS = {"count": N.AGG_COUNT, "sum": N.AGG_SUM, "min": N.AGG_MIN, "minimum": N.AGG_MIN, "max": N.AGG_MAX, "maximum": N.AGG_MAX, "mean": N.AGG_SUM}
 
 
-def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, stat: str = "count"):
-    """groupreduce(view, (:by,); out = :col => Stat()): one row per distinct value of `by` over the view's selected rows, in order of first
-    appearance (the reference's group_map numbering), with the group's row count and stat(col) — stat in count / sum / min / max / mean.
-    Returns a pandas.DataFrame with columns [by, "count", stat]."""
-    import pandas as pd
+def _groupreduce_view(v: Union[DFView, DFTable], by: str, col: Optional[str], stat: str):
     v = v if isinstance(v, DFView) else DFView(v)
     if stat not in _STATS:
         raise ValueError(f"ArgumentError: unknown statistic {stat}")
     names = [by] if col is None or stat == "count" else [by, col]
-    sub = v[ALL, names] if len(names) > 1 else DFView(v.table, Projection({by: v.projection.cols[by]}), v.selection)
-    q = _Query(sub)
+    return (v[ALL, names] if len(names) > 1 else DFView(v.table, Projection({by: v.projection.cols[by]}), v.selection)), len(names) > 1
+
+
+def _groupreduce_raw(q: "_Query", with_value: bool, stat: str):
+    """dfdb_query_groupreduce + _fetch on one query handle -> (keys, counts, values as Int64 bits, values as Float64, value dtype or None);
+    keys are a numpy array, a masked array (nullable key) or a list of str / None."""
     L = N.load()
     ng, kb = C.c_int64(), C.c_int64()
-    N.check(L.dfdb_query_groupreduce(q._h, 0, 1 if len(names) > 1 else -1, _STATS[stat], C.byref(ng), C.byref(kb)))
+    N.check(L.dfdb_query_groupreduce(q._h, 0, 1 if with_value else -1, _STATS[stat], C.byref(ng), C.byref(kb)))
     n = ng.value
     kdt = q.coltype(0)
     out = N.OutCol()
@@ -1251,12 +1251,25 @@ def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, s
         keys = np.ma.masked_array(karr[:n].copy(), mask=kmiss[:n].astype(bool))
     else:
         keys = karr[:n].copy()
-    res = {by: keys, "count": counts[:n].copy()}
+    return keys, counts[:n].copy(), vi[:n].copy(), vf[:n].copy(), (q.coltype(1) & ir.DTYPE_MASK if with_value else None)
+
+
+def _groupreduce_frame(by: str, stat: str, keys, counts, vi, vf, vdt):
+    import pandas as pd
+    res = {by: keys, "count": counts}
     if stat != "count":
-        vdt = q.coltype(1) & ir.DTYPE_MASK
         isf = vdt in (ir.F32, ir.F64)
-        vals = vf[:n].copy() if isf else (vi[:n].astype(np.uint64) if vdt in (ir.U8, ir.U16, ir.U32, ir.U64) and stat != "mean" else vi[:n].copy())
+        uns = vdt in (ir.U8, ir.U16, ir.U32, ir.U64)
+        vals = vf if isf else (vi.astype(np.uint64) if uns and stat != "mean" else vi)
         if stat == "mean":
-            vals = (vf[:n] if isf else (vi[:n].astype(np.uint64).astype(np.float64) if vdt in (ir.U8, ir.U16, ir.U32, ir.U64) else vi[:n].astype(np.float64))) / np.maximum(counts[:n], 1)
+            vals = (vf if isf else (vi.astype(np.uint64).astype(np.float64) if uns else vi.astype(np.float64))) / np.maximum(counts, 1)
         res[stat] = vals
     return pd.DataFrame(res)
+
+
+def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, stat: str = "count"):
+    """groupreduce(view, (:by,); out = :col => Stat()): one row per distinct value of `by` over the view's selected rows, in order of first
+    appearance (the reference's group_map numbering), with the group's row count and stat(col) — stat in count / sum / min / max / mean.
+    Returns a pandas.DataFrame with columns [by, "count", stat]."""
+    sub, with_value = _groupreduce_view(v, by, col, stat)
+    return _groupreduce_frame(by, stat, *_groupreduce_raw(_Query(sub), with_value, stat))

@@ -324,3 +324,121 @@ def gmaterialize(v: api.DFView):
     cols = _gq(v).materialize() if len(v.projection) else []
     lg = api._logicals(v)
     return pd.DataFrame({k: api._to_user(c, lg[i]) for i, (k, c) in enumerate(zip(v.projection.keys(), cols))})
+
+
+# ---------------------------------------------------------------- unique / groupreduce over shards
+# Every shard reduces its own rows on its own device (dfdb_query_unique / dfdb_query_groupreduce on the shard's query, after the
+# group has run the selection — range stages count across shards, so the shard queries hold the group's selection); what crosses
+# shards is one small record per distinct key, merged here in rank order, which is the table's row order: the merged keys come out
+# in order of first appearance over the whole table, as Base.unique / the reference's group_map numbering give them.
+def _key_of(v):
+    if v is None:
+        return ("missing",)
+    if isinstance(v, float):
+        return ("nan",) if v != v else (v, np.signbit(v).item())       # isequal: NaN == NaN, -0.0 != 0.0
+    return v
+
+
+def _listed(keys) -> list:
+    if isinstance(keys, np.ma.MaskedArray):
+        return [None if m else x for x, m in zip(keys.data.tolist(), np.ma.getmaskarray(keys).tolist())]
+    return keys.tolist() if isinstance(keys, np.ndarray) else list(keys)
+
+
+def _all_ranks(g: Group, local_parts: list) -> list:
+    """the per-shard records of every rank, rank order; one process per GPU hands its records round through torch.distributed"""
+    if g.nlocal == g.world:
+        return local_parts
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        raise RuntimeError("a group of one process per GPU merges unique / groupreduce through torch.distributed: init_process_group first")
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, local_parts)
+    return [p for parts in box for p in parts]
+
+
+def _shard_queries(gq: GroupQuery):
+    L = N.load()
+    for l in range(gq.gt.group.nlocal):
+        h = C.c_void_p()
+        N.check(L.dfdb_group_query_shard(gq._h, l, C.byref(h)))
+        yield api._ChunkQuery(gq.view, h, 0, 0)          # borrowed: the group query owns the handle
+
+
+def _keys_array(keys: list, kdt: int):
+    if (kdt & ir.DTYPE_MASK) == ir.STRING:
+        return np.array(keys, dtype=object)
+    if kdt & ir.NULLABLE:
+        return np.ma.masked_array(np.array([0 if k is None else k for k in keys], ir.numpy_of_dtype(kdt)), mask=[k is None for k in keys])
+    return np.array(keys, ir.numpy_of_dtype(kdt))
+
+
+def gunique(col: api.DFColumn):
+    """unique(col) over every shard: the distinct values in order of first appearance in the whole table"""
+    v = col.view
+    gt = getattr(v.table, "_group_table", None)
+    if gt is None:
+        raise ValueError("not a column of a GroupTable")
+    gq = GroupQuery(gt, v)
+    try:
+        N.check(N.load().dfdb_group_query_hint_materialize(gq._h, 1))
+        gq.count()
+        kdt = gq.coltype(0)
+        parts = []
+        for q in _shard_queries(gq):
+            N.check(N.load().dfdb_query_unique(q._h, 0))
+            parts.append(_listed(api._to_user(q.materialize()[0], api._logicals(v)[0])))
+        seen, out = set(), []
+        for part in _all_ranks(gt.group, parts):
+            for x in part:
+                k = _key_of(x)
+                if k not in seen:
+                    seen.add(k); out.append(x)
+        return _keys_array(out, kdt)
+    finally:
+        gq.close()
+
+
+def ggroupreduce(v: api.DFView, by: str, col: Optional[str] = None, stat: str = "count"):
+    """groupreduce(view, (:by,); out = :col => Stat()) over every shard: per-shard groups merged by key in rank order (counts and sums add —
+    Int64 sums wrap as on one device, Float64 sums are sums of the shards' sums —, min / max fold); same frame as dfdb.groupreduce."""
+    sub, with_value = api._groupreduce_view(v, by, col, stat)
+    gt = getattr(sub.table, "_group_table", None)
+    if gt is None:
+        raise ValueError("not a view of a GroupTable")
+    gq = GroupQuery(gt, sub)
+    try:
+        gq.count()
+        kdt = gq.coltype(0)
+        vdt = gq.coltype(1) & ir.DTYPE_MASK if with_value else None
+        parts = []
+        for q in _shard_queries(gq):
+            keys, counts, vi, vf, _ = api._groupreduce_raw(q, with_value, stat)
+            parts.append((_listed(keys), counts, vi, vf))
+        slot, keys, counts, vis, vfs = {}, [], [], [], []
+        isf = vdt in (ir.F32, ir.F64)
+        uns = vdt in (ir.U8, ir.U16, ir.U32, ir.U64)
+        fold = {"min": min, "minimum": min, "max": max, "maximum": max}.get(stat)
+        for pk, pc, pi, pf in _all_ranks(gt.group, parts):
+            for j, x in enumerate(pk):
+                k = _key_of(x)
+                a, b = int(pi[j]), float(pf[j])
+                if uns:
+                    a &= (1 << 64) - 1
+                g = slot.get(k)
+                if g is None:
+                    slot[k] = len(keys); keys.append(x); counts.append(int(pc[j])); vis.append(a); vfs.append(b)
+                    continue
+                counts[g] += int(pc[j])
+                if fold is None:                         # count / sum / mean
+                    vis[g] += a; vfs[g] += b
+                elif isf:                                # min / max over Float64: a NaN in either shard is the answer (Base.min / max)
+                    vfs[g] = b if b != b else (vfs[g] if vfs[g] != vfs[g] else fold(vfs[g], b))
+                else:
+                    vis[g] = fold(vis[g], a)
+        wrap = [((x + (1 << 63)) % (1 << 64)) - (1 << 63) for x in vis]            # back to Int64 bits (sums wrap; UInt64 is a view of them)
+        vi = np.array(wrap, np.int64) if wrap else np.zeros(0, np.int64)
+        vf = np.array(vfs, np.float64) if isf or not vis else (vi.astype(np.uint64).astype(np.float64) if uns else vi.astype(np.float64))
+        return api._groupreduce_frame(by, stat, _keys_array(keys, kdt), np.array(counts, np.int64), vi, vf, vdt)
+    finally:
+        gq.close()

@@ -282,3 +282,59 @@ def test_bench_self_launches_ranks(ctx):
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
     assert r["config"]["global_selected"] > 2 * 0.09 * 20_000_000
     assert r["value"] > 0
+
+
+@pytest.mark.parametrize("world,dictionary", [(1, 4096), (3, 4096), (5, 0)])
+def test_group_unique_and_groupreduce_match_the_single_table(oracle, dfdb_mod, ctx, world, dictionary):
+    """unique / groupreduce over block-range shards (per-shard reduction on the device, one record per distinct key merged in rank order)
+    against the same calls on ONE table holding every row: keys in order of first appearance in the whole table, counts, sums (Int64 sums
+    wrap), min / max; selections with range stages that count across shards; a shard without rows; nullable and String keys, with the
+    String column dictionary-coded or flat."""
+    from dfdb import group as G, _native as N
+    n, bs = 9 * 4096 + 123, 4096
+    base = _columns(oracle, n)
+    a = base["a"]
+    rng = np.random.default_rng(5)
+    cols = {"a": a, "x": base["x"], "s": base["s"],
+            "k": (a % 37).astype(np.int16),
+            "u": (a.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)),                      # UInt64 sums wrap
+            "big": (a * 9_000_000_000_000 + 1),                                               # Int64 sums wrap
+            "nk": np.ma.masked_array((a % 11).astype(np.int32), mask=(a % 7 == 0)),
+            "ns": [None if v % 13 == 0 else "k%d" % (v % 19) for v in a.tolist()],
+            "f": np.where(rng.random(n) < 0.01, np.nan, np.round(base["x"] / 100.0))}
+    ctx.set_option("string_dictionary", dictionary)
+    g = G.Group.create([0] * world, N.EXCHANGE_HOST if world > 1 else N.EXCHANGE_AUTO)
+    g.set_option("string_dictionary", dictionary)
+    try:
+        t1 = dfdb_mod.DFTable.from_columns(cols, block_size=bs, ctx=ctx)
+        gt = G.GroupTable.from_columns(g, cols, block_size=bs)
+        for name, stages in _stage_sets(__import__("dfdb").ir).items():
+            v1, gv = dfdb_mod.DFView(t1), gt.view()
+            for st in stages:
+                sel = st[1] if st[0] == "pred" else dfdb_mod.jr(st[1], st[2], st[3]) if st[0] == "range" else st[1] if st[0] == "int" else list(st[1])
+                v1, gv = dfdb_mod.selection(v1, sel), dfdb_mod.selection(gv, sel)
+            for key in ("k", "s", "nk", "ns", "f"):
+                want, got = getattr(v1, key).unique(), G.gunique(getattr(gv, key))
+                assert _same_keys(want, got), (name, key, want, got)
+                for col, stat in ((None, "count"), ("a", "sum"), ("big", "sum"), ("u", "sum"), ("u", "max"), ("a", "min"), ("x", "max"), ("a", "mean")):
+                    w = dfdb_mod.groupreduce(v1, key, col, stat)
+                    r = G.ggroupreduce(gv, key, col, stat)
+                    assert _same_keys(w[key].to_numpy(), r[key].to_numpy()), (name, key, stat)
+                    assert (w["count"].to_numpy() == r["count"].to_numpy()).all(), (name, key, stat)
+                    if stat != "count":
+                        assert w[stat].dtype == r[stat].dtype and (w[stat].to_numpy() == r[stat].to_numpy()).all(), (name, key, col, stat, w, r)
+                # Float64 sums: the sharded sum is a sum of per-shard sums — equal up to the reassociation
+                w, r = dfdb_mod.groupreduce(v1, key, "x", "sum"), G.ggroupreduce(gv, key, "x", "sum")
+                assert np.allclose(w["sum"].to_numpy(), r["sum"].to_numpy(), rtol=1e-12, atol=0.0), (name, key)
+        gt.close(); t1.close()
+    finally:
+        g.close()
+        ctx.set_option("string_dictionary", 0)
+
+
+def _same_keys(want, got):
+    def canon(v):
+        if isinstance(v, np.ma.MaskedArray):
+            return [None if m else x for x, m in zip(v.data.tolist(), np.ma.getmaskarray(v).tolist())]
+        return ["nan" if isinstance(x, float) and x != x else x for x in (v.tolist() if isinstance(v, np.ndarray) else list(v))]
+    return canon(want) == canon(got)

@@ -1172,3 +1172,24 @@ def test_errors_surface_only_where_the_block_iteration_gets(oracle, dfdb_mod, ct
         assert d == want_err, (stages, "engine", d)
         if want_err is None:
             assert_same(p, ov, dv)
+    # computed projection columns that raise: the reference evaluates block by block and, inside a block, the projection's columns in order
+    # (projection.jl:149-154) — first erroring BLOCK, then first such COLUMN, then first such row
+    div, cast = A % Z, ir.cast(F, ir.I64)
+    f2 = np.full(n, 2.0); f2[7_100] = 2.5                        # a second inexact conversion in block 7, BEFORE the zero divisor's row 7500
+    p2 = Pair(oracle, dfdb_mod, {"a": a, "z": z, "f": f2}, block_size=bs)
+    proj_cases = [
+        (p, [("d", div), ("c", cast)], "ValueError"),              # block 3 (the conversion) comes before block 7 (the division), column order regardless
+        (p, [("c", cast), ("d", div)], "ValueError"),
+        (p2, [("d", div), ("c", cast)], "ZeroDivisionError"),      # both in block 7: the first COLUMN raises, though the other column's row is earlier
+        (p2, [("c", cast), ("d", div)], "ValueError"),
+        (p2, [("k", A + 1), ("c", cast), ("d", div)], "ValueError"),
+    ]
+    for pr, proj, want_err in proj_cases:
+        ov, dv = apply_stages(pr, [("pred", A > 5)], proj=proj)
+        assert ov.nrow() == dfdb_mod.nrow(dv) == n - 5
+        o = d = None
+        try: ov.materialize()
+        except Exception as e: o = type(e).__name__      # noqa: BLE001
+        try: dv._query().materialize()
+        except Exception as e: d = type(e).__name__      # noqa: BLE001
+        assert (o, d) == (want_err, want_err), ([k for k, _ in proj], "oracle", o, "engine", d)
