@@ -283,7 +283,9 @@ int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind);
 int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n);
 /* string bytes the i-th projection column will need (0 for fixed width) */
 int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes);
-/* materialize(v): materialization.jl:27-40 (projection gather projection.jl:128-154 + append) */
+/* materialize(v): materialization.jl:27-40 (projection gather projection.jl:128-154 + append).  When computed columns raise (DivideError /
+ * InexactError on a selected row) the error returned is the one the reference's iteration meets first: first block, then first column of
+ * the projection, then first row. */
 int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
 /* sum/min/max/count of projection column i over the selected rows; Float64 sums are pairwise
  * (tolerance documented in DESIGN.md), integer results exact */
