@@ -289,7 +289,11 @@ static void plan_stage_bases(dfdb_gquery* gq) {
       if (gq->shard[0]->stages[k].kind == ST_PRED) continue;
       for_shards(g, [&](int l) {
         dfdb_query* q = gq->shard[(size_t)l];
-        query_execute(q, (int)k);
+        // planning raises nothing: whether a DivideError / InexactError of a predicate is reached is decided by the full execution, once every
+        // stage knows the survivors on the lower ranks (query.cpp: error_is_reached); the erroring rows count as not selected meanwhile
+        q->err_checking = true;
+        try { query_execute(q, (int)k); } catch (...) { q->err_checking = false; throw; }
+        q->err_checking = false;
         const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
         HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 1, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
         q->executed_stages = -1;   // a partial evaluation is not the view's result

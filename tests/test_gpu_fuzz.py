@@ -52,6 +52,8 @@ INT_COLS = [0, 1, 2, 3, 4, 5, 6]
 
 
 class Gen:
+    ZCOL, ZLCOL = 12, 15            # ordinals of the zero-holding divisor columns
+
     def __init__(self, ir, seed, risky):
         self.ir, self.rng, self.risky = ir, np.random.default_rng(seed), risky
 
@@ -85,7 +87,7 @@ class Gen:
         if k == 8: return a / (b if self.risky else ir.col(2))
         # integer-only operators: integer operands (÷, rem, mod are defined for floats too, but keep the divisor's zero under control)
         ia = ir.col(self.pick(INT_COLS)) if self.rng.random() < 0.8 else ir.col(self.pick([7, 8]))     # (rem / mod / div of floats too)
-        ib = (ir.col(15) if self.risky and self.rng.random() < 0.35 else ir.col(12) if self.risky and self.rng.random() < 0.5 else self.pick([ir.col(2), ir.const(7), ir.const(-3), ir.col(2) * 2 + 1]))
+        ib = (ir.col(self.ZLCOL) if self.risky and self.rng.random() < 0.35 else ir.col(self.ZCOL) if self.risky and self.rng.random() < 0.5 else self.pick([ir.col(2), ir.const(7), ir.const(-3), ir.col(2) * 2 + 1]))
         if k == 9: return ia % ib
         if k == 10: return ir.mod(ia, ib)
         return ir.div(ia, ib)
@@ -186,6 +188,8 @@ def filed(oracle, dfdb_mod, tmp_path_factory):
             "u16": rng.integers(0, 2**16 - 1, N).astype(np.uint16), "u64": rng.integers(0, 2**63, N).astype(np.uint64) * np.uint64(2), "x": x,
             "f": rng.normal(0, 8, N).astype(np.float32), "flag": rng.integers(0, 2, N).astype(bool),
             "s": ["%s%d" % ("ab"[i % 2] * (i % 3), i % 23) for i in range(N)]}
+    cols["z"] = rng.integers(-2, 3, N).astype(np.int64)                                                        # 11: zeros everywhere
+    cols["zl"] = np.where(np.arange(N) >= 2 * N // 3, rng.integers(0, 2, N), rng.integers(1, 5, N)).astype(np.int64)   # 12: zeros in the last third only
     path = str(tmp_path_factory.mktemp("fuzz") / "tb")
     p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK, via_files=path)
     lazy = dfdb_mod.open_table(path, load=False)
@@ -196,7 +200,9 @@ def filed(oracle, dfdb_mod, tmp_path_factory):
 
 
 class GenNoMissing(Gen):
-    """column ordinals of `filed`: a b c i32 i8 u16 u64 x f flag s  (no nullable column, no zero-divisor column)"""
+    """column ordinals of `filed`: a b c i32 i8 u16 u64 x f flag s z zl  (no nullable column)"""
+    ZCOL, ZLCOL = 11, 12
+
     def boolean(self, depth):
         ir = self.ir
         if depth <= 0 or self.rng.random() < 0.45:
@@ -241,6 +247,26 @@ def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     assert np.array_equal(G.gindices(gv), want_idx)
     gm = G._gq(gv).materialize()
     assert np.array_equal(gm[0], want[0]) and np.array_equal(gm[2], want[2])
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 120 * SCALE))
+def test_random_risky_queue_streamed_and_sharded(filed, dfdb_mod, seed):
+    """Queues whose predicates may raise (zero divisors, inexact conversions), block-streamed and over three shards: WHETHER and WHICH error surfaces
+    must not depend on where the chunk / shard boundaries fall (the survivors fed to a later range stage continue across them)."""
+    from dfdb import ir, group as G
+    pair, lazy, gt = filed
+    g = GenNoMissing(ir, 20_000 + seed, risky=True)
+    stages = g.stages()
+    try:
+        ov, dv = apply_stages(pair, stages, proj=[("a", ir.col(0))])
+    except Exception as e:          # noqa: BLE001
+        pytest.skip("refused at build time: %s" % type(e).__name__)
+    want = outcome(lambda: ov.nrow())
+    assert outcome(lambda: dfdb_mod.nrow(dv)) == want, stages
+    sv = dfdb_mod.DFView(lazy, dv.projection, dv.selection)
+    assert outcome(lambda: dfdb_mod.nrow_streamed(sv, 1 + seed % 5)) == want, ("streamed", stages)
+    gv = dfdb_mod.DFView(gt.view().table, dv.projection, dv.selection)
+    assert outcome(lambda: G.gnrow(gv)) == want, ("sharded", stages)
 
 
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + 200 * SCALE))
