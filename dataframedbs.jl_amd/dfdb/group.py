@@ -342,6 +342,8 @@ def _key_of(v):
 def _listed(keys) -> list:
     if isinstance(keys, np.ma.MaskedArray):
         return [None if m else x for x, m in zip(keys.data.tolist(), np.ma.getmaskarray(keys).tolist())]
+    if hasattr(keys, "to_pylist"):                      # set_string_output("arrow")
+        return keys.to_pylist()
     return keys.tolist() if isinstance(keys, np.ndarray) else list(keys)
 
 
