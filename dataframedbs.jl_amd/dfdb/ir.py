@@ -267,6 +267,14 @@ def wrap(x) -> Expr:
 def isin(a, values: Iterable, dtype: int | None = None) -> Expr:
     """`in.(a, Ref(values))` (test/broadcast.jl:63-71)."""
     vals = list(values)
+    if vals and all(isinstance(v, (str, bytes)) for v in vals):
+        # a set of strings: `any(==(x), values)` spelled out — (a == v1) | (a == v2) | ... (three-valued like Base.in: missing unless some value
+        # matches).  Over a dictionary-coded column the engine folds the whole chain into one bit-table lookup of the codes (K9).
+        a = wrap(a)
+        out = a == vals[0]
+        for v in vals[1:]:
+            out = out | (a == v)
+        return out
     if dtype is None:
         dtype = F64 if any(isinstance(v, (float, np.floating)) for v in vals) else I64
     return Expr(IN_SET, (wrap(a), Expr(CONST_SET, (), (dtype, vals))))

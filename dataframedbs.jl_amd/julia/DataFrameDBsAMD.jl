@@ -115,6 +115,8 @@ for (f, op) in UNARY
     @eval Base.$(nameof(f))(a::Tr) = Tr(vcat(a.code, $op))
 end
 Base.in(a::Tr, s::AbstractVector) = Tr(vcat(a.code, tr(s).code, 0x40))
+# a set of strings: any(==(x), s) spelled out, (a == s1) | (a == s2) | ... — one bit-table lookup over a dictionary-coded column (K9)
+Base.in(a::Tr, s::AbstractVector{<:AbstractString}) = isempty(s) ? throw(Unsupported("in.() over an empty set of strings")) : reduce((x, y) -> x | y, [a == v for v in s])
 Base.Float64(a::Tr) = Tr(vcat(a.code, 0x50, DT[Float64]))
 Base.convert(::Type{Float64}, a::Tr) = Float64(a)
 

@@ -106,7 +106,8 @@ class Gen:
                 return self.pick([ir.ismissing(ir.col(13)), ~ir.ismissing(ir.col(13)), ir.ismissing(ir.col(14)), ir.coalesce(ir.col(14), 0.5) * 2 > ir.col(8),
                                   ir.coalesce(ir.col(14), ir.col(7)) <= self.const(), ir.ismissing(ir.col(14)) | (ir.col(0) > 3), ir.sizeof(ir.col(13)) > 2])
             if k == 6: return ir.ismissing(ir.col(10)) if self.rng.random() < 0.5 else (ir.coalesce(ir.col(10), ir.const(int(self.rng.integers(-3, 3)))) > self.const())
-            if k == 7: return self.pick([ir.col(11) == "a7", ir.col(11) != "bb11", ir.startswith(ir.col(11), "aa"), ir.endswith(ir.col(11), "2"), ir.sizeof(ir.col(11)) > 2])
+            if k == 7: return self.pick([ir.col(11) == "a7", ir.col(11) != "bb11", ir.startswith(ir.col(11), "aa"), ir.endswith(ir.col(11), "2"), ir.sizeof(ir.col(11)) > 2,
+                                         ir.isin(ir.col(11), ["a7", "bb11", "nope", "0"])])
             return ir.coalesce(ir.col(10), ir.col(0)) * 2 >= ir.col(4)           # a nullable column made whole by another column
         a, b = self.boolean(depth - 1), self.boolean(depth - 1)
         k = int(self.rng.integers(0, 4))

@@ -1021,7 +1021,8 @@ def test_string_dictionary_gives_the_same_answers(oracle, dfdb_mod, ctx, tmp_pat
         # Boolean combinations of string terms over the one dictionary column: a function of the entry, one lookup (never the interpreter)
         i0, _ = ctx.profile_get("interp_predicate")
         for pred in ((S == "sony") | (S == "apple"), ~(S == "sony"), ~ir.startswith(S, "a") | (S == ""), (S == "sony") ^ ir.endswith(S, "y"),
-                     ((S == "sony") | (S == "so") | ir.startswith(S, "hua")) & (A > 100), ~((S != "é") & ~ir.endswith(S, "語"))):
+                     ((S == "sony") | (S == "so") | ir.startswith(S, "hua")) & (A > 100), ~((S != "é") & ~ir.endswith(S, "語")),
+                     ir.isin(S, ["sony", "dell", "no such brand", ""]), ~ir.isin(S, ["asus"]) & (A < 500_000)):       # in.(s, Ref([...])) over strings
             ov, dv = apply_stages(p, [("pred", pred)], proj=[("s", S), ("a", A)])
             assert_same(p, ov, dv)
         i1, _ = ctx.profile_get("interp_predicate")

@@ -78,6 +78,17 @@ def test_ir_py_emits_the_golden_bytes():
         assert e.to_ir().hex() == c["hex"], (c["name"], e.to_ir().hex(), c["hex"])
 
 
+def test_isin_over_strings_is_the_spelled_out_any():
+    """in.(s, Ref(["a", "b"])) has no opcode of its own: both front ends lower it to (s == "a") | (s == "b") (three-valued like Base.in)"""
+    from dfdb import ir
+    St = ir.col(2)
+    assert ir.isin(St, ["sony", "dell", "é"]).to_ir() == ((St == "sony") | (St == "dell") | (St == "é")).to_ir()
+    assert ir.isin(St, ["sony"]).to_ir() == (St == "sony").to_ir()
+    assert ir.isin(ir.col(0), [1, 2]).to_ir()[-1] == ir.IN_SET                        # numbers keep DFIR_IN_SET
+    jl = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "DataFrameDBsAMD.jl")).read()
+    assert "Base.in(a::Tr, s::AbstractVector{<:AbstractString})" in jl and "[a == v for v in s]" in jl
+
+
 def test_oracle_evaluates_golden_bytes(oracle):
     cols = _columns()
     t = oracle.Table(block_size=G["table"]["block_size"])
