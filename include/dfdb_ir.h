@@ -60,7 +60,7 @@ enum {
 #define DFIR_NOT   0x33 /* unary `!` */
 
 /* ---- set / string / missing ---- */
-#define DFIR_IN_SET      0x40 /* stack: value, set        -> Bool   (in.(a, Ref(v))) */
+#define DFIR_IN_SET      0x40 /* stack: value, set        -> Bool   (in.(a, Ref(v)), numeric sets; a set of strings is lowered by the front ends to (a == v1) | (a == v2) | ...) */
 #define DFIR_STARTSWITH  0x41 /* stack: string col, const -> Bool */
 #define DFIR_ENDSWITH    0x42
 #define DFIR_ISMISSING   0x43 /* unary on a nullable column -> Bool */
