@@ -261,9 +261,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     ord = o; return true;
   };
   std::function<bool(const Node&, const std::string&)> dict_eval = [&](const Node& n, const std::string& e) -> bool {
-    if (n.op == DFIR_OR) return dict_eval(*n.a, e) | dict_eval(*n.b, e);
-    if (n.op == DFIR_AND) return dict_eval(*n.a, e) & dict_eval(*n.b, e);
-    if (n.op == DFIR_XOR) return dict_eval(*n.a, e) ^ dict_eval(*n.b, e);
+    if (n.op == DFIR_OR) return dict_eval(*n.a, e) || dict_eval(*n.b, e);
+    if (n.op == DFIR_AND) return dict_eval(*n.a, e) && dict_eval(*n.b, e);
+    if (n.op == DFIR_XOR) return dict_eval(*n.a, e) != dict_eval(*n.b, e);
     if (n.op == DFIR_NOT) return !dict_eval(*n.a, e);
     int o, mode; std::string pat; match_string_term(n, *t, o, mode, pat);
     return dict_entry_matches(e, mode, pat);
