@@ -258,3 +258,19 @@ def test_julia_shim_ccalls_match_the_header():
     for route in ("DataFrameDBs.materialize(c::DFColumn)", "Base.copyto!(dest::AbstractVector, src::DFColumn)", "Base.sum(c::DFColumn)",
                   "Statistics.mean(c::DFColumn)", "Base.unique(c::DFColumn)", "Broadcasted{DataFrameDBs.DFColumnStyle}"):
         assert route in jl, route
+
+
+def test_shard_merge_keys_follow_isequal():
+    """dfdb/group.py merges per-shard unique / groupreduce records on the host: keys meet under isequal (NaN is one key, -0.0 and 0.0 are two,
+    missing is a key), listed forms of plain / masked / string key columns, and the typed array the merged keys go back into."""
+    from dfdb import group as G, ir
+    nan1, nan2 = float("nan"), np.float64("nan").item()
+    assert G._key_of(nan1) == G._key_of(nan2) and G._key_of(0.0) != G._key_of(-0.0) and G._key_of(None) == G._key_of(None)
+    assert G._key_of(3) == 3 and G._key_of("sony") == "sony" and G._key_of(None) != G._key_of("missing")
+    assert G._listed(np.array([3, 1, 2], np.int16)) == [3, 1, 2]
+    assert G._listed(np.ma.masked_array(np.array([5, 6, 7], np.int32), mask=[False, True, False])) == [5, None, 7]
+    assert G._listed(["a", None, "b"]) == ["a", None, "b"]
+    k = G._keys_array([4, None, 9], ir.I32 | ir.NULLABLE)
+    assert isinstance(k, np.ma.MaskedArray) and k.dtype == np.int32 and np.ma.getmaskarray(k).tolist() == [False, True, False] and k.data[0] == 4 and k.data[2] == 9
+    assert G._keys_array(["a", None], ir.STRING | ir.NULLABLE).tolist() == ["a", None]
+    assert G._keys_array([1.5, 2.5], ir.F64).dtype == np.float64
