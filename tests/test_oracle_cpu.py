@@ -291,3 +291,44 @@ def test_missing_propagation_and_three_valued_logic(oracle):
     assert oracle.expr_result_type(t, ir.coalesce(ir.col(0), 0).to_ir()) == ir.I64
     with pytest.raises(NotImplementedError):     # coalesce(Int64?, Float64) would be Union{Int64,Float64}: outside the IR
         oracle.expr_result_type(t, ir.coalesce(ir.col(0), 0.5).to_ir())
+
+
+def test_oracle_raises_the_error_the_block_iteration_meets_first(oracle):
+    """Known answers for WHICH error a view with several faults raises (derived by hand from the reference's loops): predicates — the earliest
+    erroring row, if the iteration reaches its block (skip_if_can / is_finished, selection.jl:177-196); computed projection columns — per block the
+    columns in order (projection.jl:149-154): first erroring block, then first such column."""
+    from dfdb import ir
+    n, bs = 10_000, 1000
+    a = np.arange(1, n + 1, dtype=np.int64)
+    z = np.ones(n, np.int64); z[7_500] = 0                       # zero divisor in block 7
+    f = np.full(n, 2.0); f[3_200] = 2.5                          # inexact conversion in block 3
+    f2 = np.full(n, 2.0); f2[7_100] = 2.5                        # ... in block 7, before the zero divisor's row
+    A, Z, F = ir.col(0), ir.col(1), ir.col(2)
+    div, cast = A % Z, ir.cast(F, ir.I64)
+
+    def table(fcol):
+        t = oracle.Table(block_size=bs)
+        for k, v in (("a", a), ("z", z), ("f", fcol)):
+            t.add_column(k, v)
+        return t
+
+    def raised(fn):
+        try:
+            fn()
+        except Exception as e:          # noqa: BLE001
+            return type(e).__name__
+        return None
+
+    t1, t2 = table(f), table(f2)
+    for t, proj, want in ((t1, [("d", div), ("c", cast)], "ValueError"), (t1, [("c", cast), ("d", div)], "ValueError"),
+                          (t2, [("d", div), ("c", cast)], "ZeroDivisionError"), (t2, [("c", cast), ("d", div)], "ValueError")):
+        v = t.view(); v.set_projection([(k, e.to_ir()) for k, e in proj])
+        assert raised(v.materialize) == want, [k for k, _ in proj]
+    for t, stages, want in ((t1, [("pred", (div == 0) & (cast == 2))], "ValueError"),                        # row 3200 comes before row 7500
+                            (t2, [("pred", (div == 0) & (cast == 2))], "ValueError"),                        # row 7100 before row 7500
+                            (t1, [("pred", div == 0), ("range", 1, 1, 7_000)], None),                         # done at the end of block 6
+                            (t1, [("pred", div == 0), ("range", 1, 1, 7_001)], "ZeroDivisionError")):
+        v = t.view()
+        for st in stages:
+            v.add_predicate(st[1].to_ir()) if st[0] == "pred" else v.add_range(st[1], st[2], st[3])
+        assert raised(v.nrow) == want, stages
