@@ -127,8 +127,12 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out) {
     out->compute_units = ctx->prop.multiProcessorCount;
     out->wavefront_size = ctx->prop.warpSize;
     out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
-    // memoryClockRate is kHz; HBM is double data rate
-    out->peak_hbm_gbps = 2.0 * (double)ctx->prop.memoryClockRate * 1e3 * ((double)ctx->prop.memoryBusWidth / 8.0) / 1e9;
+    // The engine only runs on gfx950 (dfdb_ctx_create refuses anything else), and every gfx950 part it targets is an MI350-series OAM with
+    // eight HBM3E stacks: 8192 bits x 8 Gb/s per pin = 8.0 TB/s (MI355X_MICROARCH.md).  hipDeviceProp's memoryClockRate x memoryBusWidth gives
+    // half of that on this driver (it reports the command clock, and HBM3E moves four bits per pin per such cycle, not two), so the
+    // formula is only the fallback for a part whose properties say more than the table does.
+    const double by_props = 2.0 * (double)ctx->prop.memoryClockRate * 1e3 * ((double)ctx->prop.memoryBusWidth / 8.0) / 1e9;
+    out->peak_hbm_gbps = by_props > 8000.0 ? by_props : 8000.0;
   });
 }
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value) { return guard([&] { NEED(ctx); NEED(key); ctx->options[key] = value; }); }

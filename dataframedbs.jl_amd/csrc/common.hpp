@@ -15,7 +15,8 @@ namespace dfdb {
 // ---- errors: thrown inside the engine, turned into status codes at the C ABI --------------------
 struct Error : std::runtime_error {
   int code;
-  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+  uint64_t row = ~0ull;   // DivideError / InexactError of a predicate: the GLOBAL 0-based table row that raised it (the shards of a group agree on the lowest)
+  Error(int c, const std::string& m, uint64_t r = ~0ull) : std::runtime_error(m), code(c), row(r) {}
 };
 [[noreturn]] void fail(int code, const char* fmt, ...);
 
@@ -119,6 +120,10 @@ void stream_wait(dfdb_ctx* ctx);
 // runtime tuning knobs (dfdb_ctx_set_option)
 int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt);
 void profile_resolve(dfdb_ctx* ctx);   // fold the pending event pairs into ctx->prof
+// while profiling is on: count one launch of a named VARIANT (no time; "family.variant" beside the family's timed entry), so that a caller can see
+// which form of a kernel its context's options selected (dfdb_ctx_profile_get)
+inline void prof_note(dfdb_ctx* ctx, const char* name) { if (ctx->profiling) ctx->prof[name].launches++; }
+constexpr int kCompactStoreDefault = 1;   // K2 index stores (ctx option "compact_store"): see k_compact.hip
 // the context's two pinned bounce buffers (file <-> HBM pipelines of dfdb_table_load / dfdb_table_save), at least `bytes` each
 void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes);
 }  // namespace dfdb

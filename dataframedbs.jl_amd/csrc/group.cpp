@@ -28,6 +28,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 namespace dfdb {
 int query_aggregate_device(dfdb_query* q, int32_t op, int32_t i);   // query.cpp
@@ -106,6 +107,7 @@ struct Worker {
 using namespace dfdb;
 
 constexpr int kXSlots = 16;   // 8-byte exchange slots per shard before the all-gather area
+constexpr int kFaultSlot = 3; // the fault key every exchange carries along (below)
 
 struct dfdb_group {
   int world = 1, first_rank = 0, exchange = DFDB_EXCHANGE_HOST;
@@ -114,6 +116,13 @@ struct dfdb_group {
   std::vector<std::unique_ptr<Worker>> workers;   // single-process groups with more than one shard
   std::vector<DevBuf> xbuf;              // per shard: kXSlots reduce slots + world all-gather slots (device)
   std::vector<int64_t*> xpin;            // the same, pinned host memory
+  // A failure of the per-shard half of a collective operation (a DivideError only one shard's rows reach, an OOM, a column that is not
+  // resident) must not keep its rank out of the exchange that follows: with one process per GPU the other ranks would wait in the
+  // all-reduce for ever.  The failure is remembered here instead, the rank takes part in the exchange, and every exchange carries one
+  // extra 8-byte slot reduced with MIN — the fault key, ~0 = none, else ((global row + 1) << 8 | status) for an error that knows its row
+  // and the bare status otherwise — so that all ranks learn of the failure at the same point and raise the SAME error: the one of the
+  // lowest table row, which is the one the reference's serial block iteration would have met first.
+  int fault_code = 0; std::string fault_msg; uint64_t fault_key = ~0ull;
   int nlocal() const { return (int)ctx.size(); }
 };
 struct dfdb_gtable {
@@ -122,7 +131,18 @@ struct dfdb_gtable {
   int64_t total_rows = -1;               // rows of the whole table (all ranks); -1 until something is resident
   std::vector<dfdb_gquery*> queries;
 };
+// unique / groupreduce over every shard: one record per distinct key, merged in rank order (= table order), kept until fetched
+struct GroupMerged {
+  bool valid = false, with_stats = false;
+  int32_t key_dtype = 0; int kind = 0, op = 0;       // kind of the value column: 0 signed, 1 unsigned, 2 float (dfdb_query::gr_kind)
+  int64_t ng = 0;
+  std::vector<uint8_t> key_data;                     // fixed width: ng * width bytes; String: ng int32 sizes (-1 = missing)
+  std::vector<uint8_t> key_missing;                  // ng flags (1 = the key is missing)
+  std::vector<uint8_t> key_bytes;                    // String keys: their bytes, concatenated
+  std::vector<int64_t> counts; std::vector<uint64_t> vals;   // vals: Int64 / UInt64 / Float64 bits
+};
 struct dfdb_gquery {
+  GroupMerged merged;
   dfdb_gtable* gt = nullptr;
   std::vector<dfdb_query*> shard;        // owned
   bool planned = false;                  // stage bases are set for the current stage list
@@ -150,6 +170,51 @@ static void for_shards(dfdb_group* g, const std::function<void(int)>& fn) {
   for (int l = 0; l < n; l++) if (errs[(size_t)l]) throw Error(errs[(size_t)l]->code, errs[(size_t)l]->what());
 }
 
+static uint64_t fault_key_of(const Error& e) {
+  const uint64_t code = (uint64_t)(e.code > 0 && e.code < 256 ? e.code : DFDB_ERR_DEVICE);
+  return e.row != ~0ull ? (((e.row + 1) << 8) | code) : code;
+}
+static void note_fault(dfdb_group* g, const Error& e) {
+  const uint64_t k = fault_key_of(e);
+  if (k < g->fault_key) { g->fault_key = k; g->fault_code = e.code; g->fault_msg = e.what(); }
+}
+// the per-shard half of a collective operation: like for_shards, but a failure is noted (the smallest key wins) instead of thrown
+static void for_shards_deferred(dfdb_group* g, const std::function<void(int)>& fn) {
+  const int n = g->nlocal();
+  if (g->workers.empty()) {
+    for (int l = 0; l < n; l++) {
+      try { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); fn(l); }
+      catch (const Error& e) { note_fault(g, e); }
+      catch (const std::exception& e) { note_fault(g, Error(DFDB_ERR_DEVICE, e.what())); }
+    }
+    return;
+  }
+  std::vector<std::unique_ptr<Error>> errs((size_t)n);
+  for (int l = 0; l < n; l++)
+    g->workers[(size_t)l]->submit([&, l] {
+      try { fn(l); }
+      catch (const Error& e) { errs[(size_t)l] = std::make_unique<Error>(e.code, e.what(), e.row); }
+      catch (const std::exception& e) { errs[(size_t)l] = std::make_unique<Error>(DFDB_ERR_DEVICE, e.what()); }
+    });
+  for (int l = 0; l < n; l++) g->workers[(size_t)l]->wait();
+  for (int l = 0; l < n; l++) if (errs[(size_t)l]) note_fault(g, *errs[(size_t)l]);
+}
+// what the ranks agreed on: raise it (with the local text when the local failure is the agreed one) and forget the local note
+static void settle_fault(dfdb_group* g, uint64_t agreed) {
+  const uint64_t mine = g->fault_key; const int code = g->fault_code; const std::string msg = std::move(g->fault_msg);
+  g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear();
+  if (agreed == ~0ull) {
+    if (mine != ~0ull) throw Error(code, msg);            // (no exchange carried it: a group of one process)
+    return;
+  }
+  const int acode = (int)(agreed & 0xffu);
+  const uint64_t arow = (agreed >> 8) ? (agreed >> 8) - 1 : ~0ull;
+  if (agreed == mine) throw Error(code, msg, arow);
+  if (arow != ~0ull && acode == DFDB_ERR_DIVIDE) throw Error(acode, "DivideError: integer division error", arow);
+  if (arow != ~0ull && acode == DFDB_ERR_ARGUMENT) throw Error(acode, "InexactError: conversion is not exact", arow);
+  throw Error(acode, "another shard of the group failed with status " + std::to_string(acode) + " (its own rank holds the message)");
+}
+
 // a one-rank RCCL group still issues its collectives (they are copies): the same code runs at every world size
 static bool exchanges(const dfdb_group* g) { return g->world > 1 || g->exchange == DFDB_EXCHANGE_RCCL; }
 
@@ -171,61 +236,106 @@ static ncclDataType_t nccl_type(int dt) { return dt == DFDB_F64 ? ncclFloat64 : 
 static ncclRedOp_t nccl_op(int op) { return op == DFDB_AGG_MIN ? ncclMin : (op == DFDB_AGG_MAX ? ncclMax : ncclSum); }
 
 template <class T> static T fold(T a, T b, int op) { return op == DFDB_AGG_MIN ? std::min(a, b) : (op == DFDB_AGG_MAX ? std::max(a, b) : (T)(a + b)); }
+// Julia's min / max over Float64: NaN propagates, and -0.0 orders below 0.0 (Base.min / Base.max; the device reductions compare an
+// order-preserving image and agree); std::min / std::max would keep whichever zero came first
+static double fold_f64(double x, double y, int op) {
+  if (op == DFDB_AGG_SUM) return x + y;
+  if (std::isnan(x) || std::isnan(y)) return NAN;
+  if (x == y) return op == DFDB_AGG_MIN ? (std::signbit(x) ? x : y) : (std::signbit(x) ? y : x);
+  return op == DFDB_AGG_MIN ? std::min(x, y) : std::max(x, y);
+}
 static uint64_t fold_bits(uint64_t a, uint64_t b, int dt, int op) {
   if (dt == DFDB_F64) {
     double x, y; memcpy(&x, &a, 8); memcpy(&y, &b, 8);
-    double r = op == DFDB_AGG_SUM ? x + y : ((std::isnan(x) || std::isnan(y)) ? NAN : fold<double>(x, y, op));   // Julia: min / max propagate NaN
+    const double r = fold_f64(x, y, op);
     uint64_t o; memcpy(&o, &r, 8); return o;
   }
   if (dt == DFDB_U64) return op == DFDB_AGG_SUM ? a + b : fold<uint64_t>(a, b, op);
   return op == DFDB_AGG_SUM ? a + b : (uint64_t)fold<int64_t>((int64_t)a, (int64_t)b, op);
 }
 
-// slots [slot, slot+n) of every shard := reduction over all ranks (in place, on the engine streams; no host wait with RCCL)
-static void exchange_reduce(dfdb_group* g, int slot, int n, int dt, int op) {
+// stream-ordered host value -> slot of shard l
+static void put_slot(dfdb_group* g, int l, int slot, int64_t v) {
+  g->xpin[(size_t)l][slot] = v;
+  HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+}
+// every local shard's fault slot := the local fault key (what this process knows so far)
+static void post_fault(dfdb_group* g) {
+  for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, kFaultSlot, (int64_t)g->fault_key); }
+}
+
+// One exchange: every spec's slots [slot, slot+n) of every shard := their reduction over all ranks, in place, on the engine streams (no host wait
+// with RCCL), all inside ONE ncclGroupStart/End — {value, count} of an aggregate are one launch — plus the fault slot (MIN).
+struct XSpec { int slot, n, dt, op; };
+static void exchange_reduce(dfdb_group* g, std::initializer_list<XSpec> specs_in) {
   const int nl = g->nlocal();
+  std::vector<XSpec> specs(specs_in);
+  post_fault(g);
+  specs.push_back(XSpec{kFaultSlot, 1, DFDB_U64, DFDB_AGG_MIN});
+  if (!exchanges(g)) return;
   if (g->exchange == DFDB_EXCHANGE_RCCL) {
     Rccl& r = rccl();
     RCCL_CHECK(r.GroupStart());
-    for (int l = 0; l < nl; l++) {
-      uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>() + slot;
-      RCCL_CHECK(r.AllReduce(p, p, (size_t)n, nccl_type(dt), nccl_op(op), g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
-    }
+    for (int l = 0; l < nl; l++)
+      for (const XSpec& x : specs) {
+        uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>() + x.slot;
+        RCCL_CHECK(r.AllReduce(p, p, (size_t)x.n, nccl_type(x.dt), nccl_op(x.op), g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+      }
     RCCL_CHECK(r.GroupEnd());
     return;
   }
   // host exchange (single-process groups only): read every shard's operands, fold in rank order, write the result back
-  for (int l = 0; l < nl; l++) {
-    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
-    HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + slot, g->xbuf[(size_t)l].as<uint64_t>() + slot, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
+  for (const XSpec& x : specs) {
+    for (int l = 0; l < nl; l++) {
+      HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+      HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + x.slot, g->xbuf[(size_t)l].as<uint64_t>() + x.slot, (size_t)x.n * 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
+    }
   }
   for (int l = 0; l < nl; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); stream_wait(g->ctx[(size_t)l]); }
-  for (int k = 0; k < n; k++) {
-    uint64_t acc = (uint64_t)g->xpin[0][slot + k];
-    for (int l = 1; l < nl; l++) acc = fold_bits(acc, (uint64_t)g->xpin[(size_t)l][slot + k], dt, op);
-    for (int l = 0; l < nl; l++) g->xpin[(size_t)l][slot + k] = (int64_t)acc;
-  }
-  for (int l = 0; l < nl; l++) {
-    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
-    HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, (size_t)n * 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+  for (const XSpec& x : specs) {
+    for (int k = 0; k < x.n; k++) {
+      uint64_t acc = (uint64_t)g->xpin[0][x.slot + k];
+      for (int l = 1; l < nl; l++) acc = fold_bits(acc, (uint64_t)g->xpin[(size_t)l][x.slot + k], x.dt, x.op);
+      for (int l = 0; l < nl; l++) g->xpin[(size_t)l][x.slot + k] = (int64_t)acc;
+    }
+    for (int l = 0; l < nl; l++) {
+      HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+      HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + x.slot, g->xpin[(size_t)l] + x.slot, (size_t)x.n * 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+    }
   }
 }
 
-// slot `slot` of every rank, gathered in rank order -> host vector of `world` values (waits)
+// slots [slot, slot+n) of local shard 0 -> host, together with the fault slot of the exchange that filled them (waits); raises the agreed fault
+static int64_t get_slot0(dfdb_group* g, int slot, int n, int64_t* out) {
+  HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+  HIP_CHECK(hipMemcpyAsync(g->xpin[0] + slot, g->xbuf[0].as<uint64_t>() + slot, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+  if (slot > kFaultSlot || slot + n <= kFaultSlot)
+    HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kFaultSlot, g->xbuf[0].as<uint64_t>() + kFaultSlot, 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+  stream_wait(g->ctx[0]);
+  settle_fault(g, (uint64_t)g->xpin[0][kFaultSlot]);
+  for (int k = 0; k < n; k++) out[k] = g->xpin[0][slot + k];
+  return out[0];
+}
+
+// slot `slot` of every rank, gathered in rank order -> host vector of `world` values (waits; raises the agreed fault)
 static std::vector<int64_t> exchange_gather(dfdb_group* g, int slot) {
   const int nl = g->nlocal();
   std::vector<int64_t> all((size_t)g->world, 0);
+  post_fault(g);
   if (g->exchange == DFDB_EXCHANGE_RCCL) {
     Rccl& r = rccl();
     RCCL_CHECK(r.GroupStart());
     for (int l = 0; l < nl; l++) {
       uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>();
       RCCL_CHECK(r.AllGather(p + slot, p + kXSlots, 1, ncclInt64, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+      RCCL_CHECK(r.AllReduce(p + kFaultSlot, p + kFaultSlot, 1, ncclUint64, ncclMin, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
     }
     RCCL_CHECK(r.GroupEnd());
     HIP_CHECK(hipSetDevice(g->ctx[0]->device));
     HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kXSlots, g->xbuf[0].as<uint64_t>() + kXSlots, (size_t)g->world * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kFaultSlot, g->xbuf[0].as<uint64_t>() + kFaultSlot, 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
     stream_wait(g->ctx[0]);
+    settle_fault(g, (uint64_t)g->xpin[0][kFaultSlot]);
     for (int k = 0; k < g->world; k++) all[(size_t)k] = g->xpin[0][kXSlots + k];
     return all;
   }
@@ -234,20 +344,8 @@ static std::vector<int64_t> exchange_gather(dfdb_group* g, int slot) {
     HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + slot, g->xbuf[(size_t)l].as<uint64_t>() + slot, 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
   }
   for (int l = 0; l < nl; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); stream_wait(g->ctx[(size_t)l]); all[(size_t)l] = g->xpin[(size_t)l][slot]; }
+  settle_fault(g, g->fault_key);                           // one process: what it noted is what there is
   return all;
-}
-
-// host value -> slot of shard l (stream-ordered)
-static void put_slot(dfdb_group* g, int l, int slot, int64_t v) {
-  g->xpin[(size_t)l][slot] = v;
-  HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
-}
-static int64_t get_slot0(dfdb_group* g, int slot, int n, int64_t* out) {   // slots of local shard 0 -> host (waits)
-  HIP_CHECK(hipSetDevice(g->ctx[0]->device));
-  HIP_CHECK(hipMemcpyAsync(g->xpin[0] + slot, g->xbuf[0].as<uint64_t>() + slot, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-  stream_wait(g->ctx[0]);
-  for (int k = 0; k < n; k++) out[k] = g->xpin[0][slot + k];
-  return out[0];
 }
 
 // blocks [first, last) owned by `rank`: g * ceil(nb/G) .. (g+1) * ceil(nb/G), clipped (the rule of dfdb/sharding.py and DESIGN.md §8)
@@ -287,7 +385,7 @@ static void plan_stage_bases(dfdb_gquery* gq) {
   if (exchanges(g))
     for (size_t k = 1; k < ns; k++) {
       if (gq->shard[0]->stages[k].kind == ST_PRED) continue;
-      for_shards(g, [&](int l) {
+      for_shards_deferred(g, [&](int l) {
         dfdb_query* q = gq->shard[(size_t)l];
         // planning raises nothing: whether a DivideError / InexactError of a predicate is reached is decided by the full execution, once every
         // stage knows the survivors on the lower ranks (query.cpp: error_is_reached); the erroring rows count as not selected meanwhile
@@ -315,26 +413,30 @@ static void gq_invalidate(dfdb_gquery* gq) { gq->planned = false; gq->count_enqu
 static bool shard_needs_exec(const dfdb_query* q) { return q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows; }
 
 // evaluate the view on every shard and leave the GLOBAL count in slot 0 of every shard's exchange buffer (no host wait with RCCL)
-static void group_count_enqueue(dfdb_gquery* gq) {
+static void group_count_enqueue(dfdb_gquery* gq, bool wait) {
   dfdb_group* g = gq->gt->g;
   plan_stage_bases(gq);
-  for_shards(g, [&](int l) {
+  for_shards_deferred(g, [&](int l) {
     dfdb_query* q = gq->shard[(size_t)l];
     if (shard_needs_exec(q)) query_execute(q, -1);
     const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
     HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>(), q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
   });
-  if (exchanges(g)) exchange_reduce(g, 0, 1, DFDB_I64, DFDB_AGG_SUM);
+  exchange_reduce(g, {XSpec{0, 1, DFDB_I64, DFDB_AGG_SUM}});      // a shard that failed is in the exchange all the same: its fault key travels with the count
   gq->count_enqueued = true; gq->count = -1;
+  // enqueue-only callers (dfdb_group_count(gq, NULL)) never read the slots back: a LOCAL failure is theirs to hear now; the other ranks meet
+  // it in the fault slot at their next host read (group_count / get_slot0)
+  if (!wait && g->fault_key != ~0ull) { gq->count_enqueued = false; const Error e(g->fault_code, g->fault_msg); g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear(); throw e; }
 }
 
 static int64_t group_count(dfdb_gquery* gq) {
   if (gq->count >= 0) return gq->count;
   bool stale = !gq->count_enqueued;
   for (dfdb_query* q : gq->shard) stale = stale || shard_needs_exec(q);
-  if (stale) group_count_enqueue(gq);
+  if (stale) group_count_enqueue(gq, true);
   int64_t n = 0;
-  get_slot0(gq->gt->g, 0, 1, &n);
+  // (a fault the ranks agreed on invalidates the exchange for all of them alike: the next call enqueues again on every rank)
+  try { get_slot0(gq->gt->g, 0, 1, &n); } catch (...) { gq->count_enqueued = false; throw; }
   gq->count = n;
   return n;
 }
@@ -438,7 +540,7 @@ int32_t dfdb_group_barrier(dfdb_group* g) {   // every rank's engine stream has 
   return gguard([&] {
     GNEED(g);
     for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, 2, 1); }
-    if (exchanges(g)) exchange_reduce(g, 2, 1, DFDB_I64, DFDB_AGG_SUM);
+    exchange_reduce(g, {XSpec{2, 1, DFDB_I64, DFDB_AGG_SUM}});
     for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); HIP_CHECK(hipStreamSynchronize(g->ctx[(size_t)l]->stream)); }
   });
 }
@@ -451,7 +553,7 @@ int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t
       HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
       for (int k = 0; k < n; k++) { int64_t b; memcpy(&b, &vals[(size_t)l * n + k], 8); put_slot(g, l, 4 + k, b); }
     }
-    if (exchanges(g)) exchange_reduce(g, 4, n, DFDB_F64, op);
+    exchange_reduce(g, {XSpec{4, n, DFDB_F64, op}});
     for (int l = 0; l < g->nlocal(); l++) {
       HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
       HIP_CHECK(hipMemcpyAsync(g->xpin[(size_t)l] + 4, g->xbuf[(size_t)l].as<uint64_t>() + 4, (size_t)n * 8, hipMemcpyDeviceToHost, g->ctx[(size_t)l]->stream));
@@ -628,7 +730,7 @@ int32_t dfdb_group_query_reset(dfdb_gquery* gq) {
 /* nrow(v) over the whole table: per-shard scans, the stage-base exchanges a range-after-predicate needs, one all-reduce.
  * n == NULL: only enqueue (no host wait; the reduced count stays on the devices until a later call asks for it) */
 int32_t dfdb_group_count(dfdb_gquery* gq, int64_t* n) {
-  return gguard([&] { GNEEDQ(gq); if (!n) { group_count_enqueue(gq); return; } *n = group_count(gq); });
+  return gguard([&] { GNEEDQ(gq); if (!n) { group_count_enqueue(gq, false); return; } *n = group_count(gq); });
 }
 /* selected rows on every rank, in rank order (world values): what a caller needs to place sharded results */
 int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts) {
@@ -636,7 +738,7 @@ int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts) {
     GNEEDQ(gq); GNEED(counts);
     dfdb_group* g = gq->gt->g;
     group_count(gq);
-    for_shards(g, [&](int l) {
+    for_shards_deferred(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
       const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
       HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 1, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
@@ -656,28 +758,32 @@ int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* ou
     if (op != DFDB_AGG_SUM && op != DFDB_AGG_MIN && op != DFDB_AGG_MAX) fail(DFDB_ERR_ARGUMENT, "unknown aggregate %d", op);
     plan_stage_bases(gq);
     std::vector<int> dts((size_t)g->nlocal(), DFDB_I64);
-    for_shards(g, [&](int l) {
+    for_shards_deferred(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
       dts[(size_t)l] = query_aggregate_device(q, op, i);          // {value, count} in q->red_result, identity when the shard selects nothing
       HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 8, q->red_result.p, 16, hipMemcpyDeviceToDevice, q->t->ctx->stream));
     });
-    const int dt = dts[0];
+    // the accumulator type follows from the projection's dtype, which every shard shares (a shard that failed before it could say still knows it)
+    const int32_t pdt = i >= 0 && (size_t)i < gq->shard[0]->proj.size() ? dt_base(gq->shard[0]->proj[(size_t)i].expr->dtype) : DFDB_I64;
+    const int dt = dt_isfloat(pdt) ? DFDB_F64 : (pdt == DFDB_U64 ? DFDB_U64 : DFDB_I64);      // = what query_aggregate_device returns
+    for (int d : dts) if (d != dt && g->fault_key == ~0ull) fail(DFDB_ERR_DEVICE, "shards disagree on the accumulator type");
     int64_t res[2] = {0, 0};
-    if (exchanges(g)) {
-      if (dt == DFDB_F64 && op != DFDB_AGG_SUM && g->exchange == DFDB_EXCHANGE_RCCL) {
-        // Julia's minimum / maximum propagate NaN, ncclMin / ncclMax need not: gather the per-rank partials and fold them on the host
-        const std::vector<int64_t> vals = exchange_gather(g, 8);
-        uint64_t acc = (uint64_t)vals[0];
-        for (int r = 1; r < g->world; r++) acc = fold_bits(acc, (uint64_t)vals[(size_t)r], DFDB_F64, op);
-        exchange_reduce(g, 9, 1, DFDB_I64, DFDB_AGG_SUM);
-        get_slot0(g, 9, 1, &res[1]);
-        res[0] = (int64_t)acc;
-      } else {
-        exchange_reduce(g, 8, 1, dt, op);
-        exchange_reduce(g, 9, 1, DFDB_I64, DFDB_AGG_SUM);
-        get_slot0(g, 8, 2, res);
-      }
-    } else get_slot0(g, 8, 2, res);
+    if (dt == DFDB_F64 && op != DFDB_AGG_SUM && g->exchange == DFDB_EXCHANGE_RCCL && exchanges(g)) {
+      // Julia's minimum / maximum propagate NaN, ncclMin / ncclMax need not: gather the per-rank partials and fold them on the host
+      const std::vector<int64_t> vals = exchange_gather(g, 8);
+      uint64_t acc = (uint64_t)vals[0];
+      for (int r = 1; r < g->world; r++) acc = fold_bits(acc, (uint64_t)vals[(size_t)r], DFDB_F64, op);
+      exchange_reduce(g, {XSpec{9, 1, DFDB_I64, DFDB_AGG_SUM}});
+      get_slot0(g, 9, 1, &res[1]);
+      res[0] = (int64_t)acc;
+    } else {
+      exchange_reduce(g, {XSpec{8, 1, dt, op}, XSpec{9, 1, DFDB_I64, DFDB_AGG_SUM}});    // ONE exchange for {value, count}
+      get_slot0(g, 8, 2, res);
+    }
+    // the count of an aggregate is the count of the selection (nullable columns are not aggregated): nrow(v) after sum(col) costs nothing more
+    bool current = true;
+    for (dfdb_query* q : gq->shard) current = current && !shard_needs_exec(q);
+    if (current) gq->count = res[1];
     if (res[1] == 0 && op != DFDB_AGG_SUM) fail(DFDB_ERR_ARGUMENT, "ArgumentError: reducing over an empty collection is not allowed");
     if (dt == DFDB_F64) { double d; memcpy(&d, &res[0], 8); if (out_f) *out_f = d; if (out_i) *out_i = (int64_t)d; }
     else { if (out_i) *out_i = res[0]; if (out_f) *out_f = dt == DFDB_U64 ? (double)(uint64_t)res[0] : (double)res[0]; }
@@ -766,4 +872,232 @@ int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols
   });
 }
 
+
+/* string bytes projection column i needs on EACH local shard (nlocal values): what sizes the per-shard device buffers of
+ * dfdb_group_materialize_device */
+int32_t dfdb_group_shard_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbytes) {
+  return gguard([&] {
+    GNEEDQ(gq); GNEED(nbytes);
+    dfdb_group* g = gq->gt->g;
+    plan_stage_bases(gq);
+    for_shards(g, [&](int l) { nbytes[l] = query_string_bytes(gq->shard[(size_t)l], i); });
+  });
+}
+
+/* materialize(v) (materialization.jl:27-40) with the result left SHARDED on the devices: outs[l * ncols + p] describes output column p of local
+ * shard l in that shard's own HBM (memkind DFDB_MEM_DEVICE; sized from dfdb_group_shard_counts / dfdb_group_shard_string_bytes).  Asynchronous on
+ * the shards' engine streams; no byte crosses PCIe or xGMI.  Rank order = table order: shard r's rows follow shard r-1's. */
+int32_t dfdb_group_materialize_device(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols) {
+  return gguard([&] {
+    GNEEDQ(gq); if (ncols > 0) GNEED(outs);
+    dfdb_group* g = gq->gt->g;
+    for (int l = 0; l < g->nlocal(); l++)
+      for (int32_t p = 0; p < ncols; p++)
+        if (outs[(size_t)l * ncols + p].memkind != DFDB_MEM_DEVICE) fail(DFDB_ERR_ARGUMENT, "dfdb_group_materialize_device writes device buffers (dfdb_group_materialize for host buffers)");
+    plan_stage_bases(gq);
+    for_shards(g, [&](int l) { query_materialize(gq->shard[(size_t)l], outs + (size_t)l * ncols, ncols); });
+  });
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ unique / groupreduce over the shards
+namespace dfdb {
+namespace {
+struct GroupPart {          // one shard's groups, in order of first appearance inside the shard
+  int64_t ng = 0;
+  std::vector<uint8_t> key_data, key_missing, key_bytes;
+  std::vector<int64_t> counts; std::vector<uint64_t> vals;
+};
+void put_i64(std::vector<uint8_t>& b, int64_t v) { const size_t o = b.size(); b.resize(o + 8); memcpy(b.data() + o, &v, 8); }
+void put_vec(std::vector<uint8_t>& b, const void* p, size_t n) { put_i64(b, (int64_t)n); const size_t o = b.size(); b.resize(o + n); if (n) memcpy(b.data() + o, p, n); }
+std::vector<uint8_t> pack_part(const GroupPart& p) {
+  std::vector<uint8_t> b;
+  put_i64(b, p.ng);
+  put_vec(b, p.key_data.data(), p.key_data.size()); put_vec(b, p.key_missing.data(), p.key_missing.size()); put_vec(b, p.key_bytes.data(), p.key_bytes.size());
+  put_vec(b, p.counts.data(), p.counts.size() * 8); put_vec(b, p.vals.data(), p.vals.size() * 8);
+  return b;
+}
+GroupPart unpack_part(const uint8_t* b, size_t n) {
+  GroupPart p; size_t o = 0;
+  auto i64 = [&]() { if (o + 8 > n) fail(DFDB_ERR_DEVICE, "group exchange: truncated record"); int64_t v; memcpy(&v, b + o, 8); o += 8; return v; };
+  auto vec = [&](std::vector<uint8_t>& v) { const int64_t m = i64(); if (m < 0 || o + (size_t)m > n) fail(DFDB_ERR_DEVICE, "group exchange: truncated record"); v.assign(b + o, b + o + m); o += (size_t)m; };
+  p.ng = i64();
+  vec(p.key_data); vec(p.key_missing); vec(p.key_bytes);
+  std::vector<uint8_t> c, v; vec(c); vec(v);
+  p.counts.resize(c.size() / 8); if (!c.empty()) memcpy(p.counts.data(), c.data(), c.size());
+  p.vals.resize(v.size() / 8); if (!v.empty()) memcpy(p.vals.data(), v.data(), v.size());
+  return p;
+}
+}  // namespace
+
+// every rank's parts, rank order.  One process that holds every shard has them already; one process per GPU all-gathers the packed records
+// (first their sizes, then the bytes padded to the largest: they are small — one record per distinct key)
+static std::vector<GroupPart> all_parts(dfdb_group* g, std::vector<GroupPart>& local) {
+  // (group option "group_force_exchange" = 1 makes a process that holds every shard exchange its records all the same: how a 1-GPU box runs the
+  // RCCL all-gather of this path for real, with a one-rank group)
+  const bool forced = g->exchange == DFDB_EXCHANGE_RCCL && ctx_option(g->ctx[0], "group_force_exchange", 0) != 0;
+  if (g->nlocal() == g->world && !forced) { settle_fault(g, g->fault_key); return std::move(local); }
+  if (g->exchange != DFDB_EXCHANGE_RCCL) fail(DFDB_ERR_DEVICE, "a host-exchange group holds every shard in one process");
+  const int nl = g->nlocal();
+  std::vector<std::vector<uint8_t>> blobs((size_t)nl);
+  for (int l = 0; l < nl; l++) { blobs[(size_t)l] = pack_part(local[(size_t)l]); HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, 1, (int64_t)blobs[(size_t)l].size()); }
+  const std::vector<int64_t> sizes = exchange_gather(g, 1);          // (raises the fault the ranks agreed on, if a shard failed)
+  int64_t maxb = 8;
+  for (int64_t b : sizes) maxb = std::max(maxb, b);
+  maxb = round_up(maxb, 8);
+  Rccl& r = rccl();
+  std::vector<DevBuf> send((size_t)nl), recv((size_t)nl);
+  for (int l = 0; l < nl; l++) {
+    HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
+    send[(size_t)l].ensure((size_t)maxb); recv[(size_t)l].ensure((size_t)maxb * (size_t)g->world);
+    blobs[(size_t)l].resize((size_t)maxb, 0);
+    HIP_CHECK(hipMemcpyAsync(send[(size_t)l].p, blobs[(size_t)l].data(), (size_t)maxb, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
+  }
+  RCCL_CHECK(r.GroupStart());
+  for (int l = 0; l < nl; l++) RCCL_CHECK(r.AllGather(send[(size_t)l].p, recv[(size_t)l].p, (size_t)maxb, ncclInt8, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+  RCCL_CHECK(r.GroupEnd());
+  std::vector<uint8_t> all((size_t)maxb * (size_t)g->world);
+  HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+  HIP_CHECK(hipMemcpyAsync(all.data(), recv[0].p, all.size(), hipMemcpyDeviceToHost, g->ctx[0]->stream));
+  for (int l = 0; l < nl; l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); HIP_CHECK(hipStreamSynchronize(g->ctx[(size_t)l]->stream)); }   // send / recv / blobs die here
+  std::vector<GroupPart> parts;
+  for (int rk = 0; rk < g->world; rk++) parts.push_back(unpack_part(all.data() + (size_t)rk * (size_t)maxb, (size_t)sizes[(size_t)rk]));
+  return parts;
+}
+
+// isequal as a byte string: the missing flag, then the value's bytes with every NaN folded onto one (isequal(NaN, -NaN); -0.0 and 0.0 stay apart)
+static std::string merge_key(int32_t kdt, const GroupPart& p, int64_t j, int64_t& byte_off) {
+  const bool miss = !p.key_missing.empty() && p.key_missing[(size_t)j];
+  std::string k(1, miss ? '\1' : '\0');
+  if (dt_base(kdt) == DFDB_STRING) {
+    int32_t sz; memcpy(&sz, p.key_data.data() + (size_t)j * 4, 4);
+    if (sz < 0) { k[0] = '\1'; return k; }
+    k.append((const char*)p.key_bytes.data() + byte_off, (size_t)sz); byte_off += sz;
+    return k;
+  }
+  if (miss) return k;                                    // (the bytes under a missing flag are garbage: quirk Q11)
+  const int w = dt_width(kdt);
+  const uint8_t* v = p.key_data.data() + (size_t)j * w;
+  if (dt_base(kdt) == DFDB_F64) { double d; memcpy(&d, v, 8); if (std::isnan(d)) { k.append("NaN"); return k; } }
+  if (dt_base(kdt) == DFDB_F32) { float f; memcpy(&f, v, 4); if (std::isnan(f)) { k.append("NaN"); return k; } }
+  k.append((const char*)v, (size_t)w);
+  return k;
+}
+
+static void group_reduce_all(dfdb_gquery* gq, int32_t key_p, int32_t val_p, int32_t op, bool with_stats) {
+  dfdb_group* g = gq->gt->g;
+  gq->merged = GroupMerged{};
+  plan_stage_bases(gq);
+  const int nl = g->nlocal();
+  std::vector<GroupPart> local((size_t)nl);
+  std::vector<int> kinds((size_t)nl, 0);
+  for_shards_deferred(g, [&](int l) {
+    dfdb_query* q = gq->shard[(size_t)l];
+    GroupPart& part = local[(size_t)l];
+    int64_t ng = 0, kb = 0;
+    query_groupreduce(q, key_p, val_p, op, &ng, &kb);     // the shard's own device reduction (k_unique.hip / k_dict.hip); the selection is the group's
+    kinds[(size_t)l] = q->gr_kind;
+    const int32_t kdt = q->proj[(size_t)key_p].expr->dtype;
+    const bool is_str = dt_base(kdt) == DFDB_STRING;
+    part.ng = ng;
+    part.key_data.resize((size_t)ng * (size_t)(is_str ? 4 : dt_width(kdt)));
+    if (dt_nullable(kdt) && !is_str) part.key_missing.assign((size_t)ng, 0);
+    part.key_bytes.resize((size_t)kb);
+    part.counts.assign((size_t)ng, 0); part.vals.assign((size_t)ng, 0);
+    dfdb_outcol o{}; o.memkind = DFDB_MEM_HOST; o.data = part.key_data.data(); o.bytes = part.key_bytes.data(); o.bytes_cap = kb;
+    o.missing = part.key_missing.empty() ? nullptr : part.key_missing.data();
+    std::vector<int64_t> vi((size_t)ng); std::vector<double> vf((size_t)ng);
+    query_groupreduce_fetch(q, &o, part.counts.data(), vi.data(), vf.data());   // (puts the shard's full selection back)
+    for (int64_t j = 0; j < ng; j++) { if (q->gr_kind == 2) memcpy(&part.vals[(size_t)j], &vf[(size_t)j], 8); else part.vals[(size_t)j] = (uint64_t)vi[(size_t)j]; }
+  });
+  const std::vector<GroupPart> parts = all_parts(g, local);
+  const int32_t kdt = gq->shard[0]->proj[(size_t)key_p].expr->dtype;
+  const bool is_str = dt_base(kdt) == DFDB_STRING;
+  const int w = is_str ? 4 : dt_width(kdt);
+  const int kind = kinds[0];
+  GroupMerged& m = gq->merged;
+  m.key_dtype = kdt; m.kind = kind; m.op = op; m.with_stats = with_stats;
+  std::unordered_map<std::string, int64_t> slot;
+  for (const GroupPart& p : parts) {                        // rank order = table order: a key keeps the place of its first appearance
+    int64_t boff = 0;
+    for (int64_t j = 0; j < p.ng; j++) {
+      const int64_t b0 = boff;
+      const std::string k = merge_key(kdt, p, j, boff);
+      auto it = slot.find(k);
+      if (it == slot.end()) {
+        slot.emplace(k, m.ng++);
+        m.key_data.insert(m.key_data.end(), p.key_data.begin() + j * w, p.key_data.begin() + (j + 1) * w);
+        m.key_missing.push_back(k[0] == '\1' ? 1 : 0);
+        if (is_str) m.key_bytes.insert(m.key_bytes.end(), p.key_bytes.begin() + b0, p.key_bytes.begin() + boff);
+        m.counts.push_back(p.counts[(size_t)j]); m.vals.push_back(p.vals[(size_t)j]);
+        continue;
+      }
+      const size_t s = (size_t)it->second;
+      m.counts[s] += p.counts[(size_t)j];
+      const uint64_t a = m.vals[s], b = p.vals[(size_t)j];
+      if (op == DFDB_AGG_COUNT) m.vals[s] = a + b;
+      else m.vals[s] = fold_bits(a, b, kind == 2 ? DFDB_F64 : (kind == 1 ? DFDB_U64 : DFDB_I64), op);   // wrapping Int sums, Float64 sums of the shards' sums, NaN-propagating min / max
+    }
+  }
+  m.valid = true;
+}
+
+static void group_reduce_fetch(dfdb_gquery* gq, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f) {
+  GroupMerged& m = gq->merged;
+  if (!m.valid) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_group_query_unique / _groupreduce has not been called");
+  if (keys) {
+    if (keys->memkind != DFDB_MEM_HOST) fail(DFDB_ERR_ARGUMENT, "the merged keys of a group are written to host buffers");
+    const bool is_str = dt_base(m.key_dtype) == DFDB_STRING;
+    keys->dtype = m.key_dtype; keys->count = m.ng; keys->nbytes = (int64_t)m.key_bytes.size();
+    if (m.ng > 0) {
+      if (!keys->data) fail(DFDB_ERR_ARGUMENT, "the key column has no data buffer");
+      memcpy(keys->data, m.key_data.data(), m.key_data.size());
+      if (keys->missing) memcpy(keys->missing, m.key_missing.data(), (size_t)m.ng);
+      if (is_str && !m.key_bytes.empty()) {
+        if ((int64_t)m.key_bytes.size() > keys->bytes_cap || !keys->bytes) fail(DFDB_ERR_ARGUMENT, "the key column needs %zu string bytes, capacity is %lld", m.key_bytes.size(), (long long)keys->bytes_cap);
+        memcpy(keys->bytes, m.key_bytes.data(), m.key_bytes.size());
+      }
+    }
+  }
+  for (int64_t j = 0; j < m.ng; j++) {
+    if (counts) counts[j] = m.counts[(size_t)j];
+    const uint64_t b = m.vals[(size_t)j];
+    double d; memcpy(&d, &b, 8);
+    if (m.kind == 2) { if (vals_f) vals_f[j] = d; if (vals_i) vals_i[j] = (int64_t)d; }
+    else { if (vals_i) vals_i[j] = (int64_t)b; if (vals_f) vals_f[j] = m.kind == 1 ? (double)b : (double)(int64_t)b; }
+  }
+}
+}  // namespace dfdb
+
+extern "C" {
+/* unique(col) over the whole table (Base.unique over Base.iterate(::DFColumn), column.jl:102-126; docs/src/index.md:171-182,479-487): every shard
+ * reduces its own rows on its own device, one record per distinct key crosses to the other ranks (all-gather), and the records are merged by key in
+ * rank order — first appearance = lowest rank, then lowest row — so the distinct values come out in Julia's order.  Call 1 returns their number and
+ * the string bytes they need; the fetch copies them into a caller-owned HOST column.  Every rank gets the whole answer. */
+int32_t dfdb_group_query_unique(dfdb_gquery* gq, int32_t proj_col, int64_t* ndistinct, int64_t* string_bytes) {
+  return gguard([&] {
+    GNEEDQ(gq);
+    group_reduce_all(gq, proj_col, -1, DFDB_AGG_COUNT, false);
+    if (ndistinct) *ndistinct = gq->merged.ng;
+    if (string_bytes) *string_bytes = (int64_t)gq->merged.key_bytes.size();
+  });
+}
+int32_t dfdb_group_query_unique_fetch(dfdb_gquery* gq, dfdb_outcol* keys) {
+  return gguard([&] { GNEEDQ(gq); GNEED(keys); group_reduce_fetch(gq, keys, nullptr, nullptr, nullptr); gq->merged = GroupMerged{}; });
+}
+/* groupreduce(view, (:key,); out = :val => Stat()) over the whole table (aggregate.jl:1-36, completed as dfdb_query_groupreduce completes it):
+ * per-shard groups merged by key in rank order; counts and sums add (Int sums wrap as on one device, Float64 sums are sums of the shards' sums:
+ * the tolerance of DESIGN.md section 5), minimum / maximum fold with Julia's NaN and signed-zero rules.  Same two calls as the single-GPU form. */
+int32_t dfdb_group_query_groupreduce(dfdb_gquery* gq, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes) {
+  return gguard([&] {
+    GNEEDQ(gq);
+    group_reduce_all(gq, key_col, val_col, stat, true);
+    if (ngroups) *ngroups = gq->merged.ng;
+    if (key_string_bytes) *key_string_bytes = (int64_t)gq->merged.key_bytes.size();
+  });
+}
+int32_t dfdb_group_query_groupreduce_fetch(dfdb_gquery* gq, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f) {
+  return gguard([&] { GNEEDQ(gq); group_reduce_fetch(gq, keys, counts, values_i, values_f); gq->merged = GroupMerged{}; });
+}
 }  // extern "C"

@@ -82,14 +82,90 @@ __global__ __launch_bounds__(kBlock) void k_compact_indices(const uint64_t* __re
   }
 }
 
-static int g_compact_store = 1;
-void set_compact_store(int v) { g_compact_store = v; }
+// K2 "wide" (round 3): a wave takes TWO adjacent ctiles per trip — their survivors are contiguous in the output, so the pair is one run of
+// t0 + t1 indices — and every lane stores TWO consecutive indices with one 16-byte store (global_store_dwordx4: 1 KB per wave instruction
+// instead of 512 B, half the store instructions; an odd first element goes out alone so that the pairs are 16-byte aligned).  One packed DPP
+// scan ranks both words of a lane (counts <= 4096 fit 16 bits each), the two expansion loops run interleaved, and the same 8 KB of LDS per
+// wave holds the pair as long as it has at most 4096 survivors (sigma <= 0.5 on average); denser pairs fall back to one ctile after the other.
+typedef long long dfdb_ll2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ void store_idx1(int64_t* p, int64_t a) { if (NT) __builtin_nontemporal_store(a, p); else *p = a; }
+template <bool NT> __device__ __forceinline__ void store_idx2(int64_t* p, int64_t a, int64_t b) {
+  dfdb_ll2 v; v.x = a; v.y = b;
+  if (NT) __builtin_nontemporal_store(v, (dfdb_ll2*)p); else *(dfdb_ll2*)p = v;
+}
+// the wave's `total` staged positions -> out[obase ...] = row1 + pos[k]
+template <bool NT>
+__device__ __forceinline__ void stream_indices(const uint16_t* pos, uint32_t total, int64_t row1, int64_t* __restrict__ out, int64_t obase, int64_t out_cap, int lane) {
+  if (obase + (int64_t)total > out_cap) total = out_cap > obase ? (uint32_t)(out_cap - obase) : 0u;
+  if (total == 0) return;
+  int64_t* o = out + obase;
+  const uint32_t head = (uint32_t)(((uintptr_t)o >> 3) & 1u);            // 1: the run starts on the upper half of a 16-byte slot
+  if (head && lane == 0) store_idx1<NT>(o, row1 + pos[0]);
+  for (uint32_t k = head + 2u * (uint32_t)lane; k < total; k += 128u) {
+    if (k + 1 < total) store_idx2<NT>(o + k, row1 + pos[k], row1 + pos[k + 1]);
+    else store_idx1<NT>(o + k, row1 + pos[k]);
+  }
+}
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void k_compact_indices_wide(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
+                                                                 int64_t* __restrict__ out, int64_t nctiles, int64_t row_base, int64_t out_cap) {
+  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint16_t* pos = pos_sh[wib];
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t npairs = (nctiles + 1) >> 1;
+  int64_t pt = wave;
+  // the next pair's words and output offset are in flight while this pair is expanded (the bitmap is padded to whole ctiles, not to pairs)
+  uint64_t w0_next = 0, w1_next = 0, ob_next = 0;
+  if (pt < npairs) { w0_next = bitmap[pt * 128 + lane]; if (2 * pt + 1 < nctiles) w1_next = bitmap[pt * 128 + 64 + lane]; ob_next = prefix[pt * 8]; }
+  for (; pt < npairs; pt += nwaves) {
+    uint64_t w0 = w0_next, w1 = w1_next;
+    const int64_t obase = (int64_t)ob_next;
+    const int64_t nx = pt + nwaves;
+    if (nx < npairs) { w0_next = bitmap[nx * 128 + lane]; w1_next = 2 * nx + 1 < nctiles ? bitmap[nx * 128 + 64 + lane] : 0ull; ob_next = prefix[nx * 8]; }
+    const uint32_t c0 = (uint32_t)__popcll(w0), c1 = (uint32_t)__popcll(w1);
+    const uint32_t incl = wave_incl_scan(c0 | (c1 << 16));
+    const uint32_t tot = __shfl(incl, 63, 64);
+    const uint32_t t0 = tot & 0xffffu, t1 = tot >> 16;
+    const int64_t row1 = row_base + pt * (2 * kCTile) + 1;                // 1-based table row of position 0 of the pair
+    const uint32_t lbase = (uint32_t)lane << 6;
+    uint32_t o0 = (incl & 0xffffu) - c0, o1 = (incl >> 16) - c1;
+    if (t0 + t1 <= (uint32_t)kCTile) {
+      o1 += t0;
+      while (w0 | w1) {                                                  // the two expansions interleaved: independent chains
+        if (w0) { const int b = __builtin_ctzll(w0); w0 &= w0 - 1; pos[o0++] = (uint16_t)(lbase + (uint32_t)b); }
+        if (w1) { const int b = __builtin_ctzll(w1); w1 &= w1 - 1; pos[o1++] = (uint16_t)((uint32_t)kCTile + lbase + (uint32_t)b); }
+      }
+      wave_lds_fence();
+      stream_indices<NT>(pos, t0 + t1, row1, out, obase, out_cap, lane);
+      wave_lds_fence();
+    } else {
+      while (w0) { const int b = __builtin_ctzll(w0); w0 &= w0 - 1; pos[o0++] = (uint16_t)(lbase + (uint32_t)b); }
+      wave_lds_fence();
+      stream_indices<NT>(pos, t0, row1, out, obase, out_cap, lane);
+      wave_lds_fence();
+      while (w1) { const int b = __builtin_ctzll(w1); w1 &= w1 - 1; pos[o1++] = (uint16_t)(lbase + (uint32_t)b); }
+      wave_lds_fence();
+      stream_indices<NT>(pos, t1, row1 + kCTile, out, obase + t0, out_cap, lane);
+      wave_lds_fence();
+    }
+  }
+}
+
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows, int64_t row_base,
-                            int64_t out_cap) {
+                            int64_t out_cap, int store) {
   const int64_t nct = (nrows + kCTile - 1) / kCTile;
   if (nct == 0) return;
-  if (g_compact_store == 1) hipLaunchKernelGGL(k_compact_indices<1>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
-  else if (g_compact_store == 2) hipLaunchKernelGGL(k_compact_indices<2>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  if (store == 3 || store == 4) {
+    const int grid = grid_for_ctiles((nct + 1) / 2);
+    if (store == 3) hipLaunchKernelGGL(k_compact_indices_wide<true>, dim3(grid), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+    else hipLaunchKernelGGL(k_compact_indices_wide<false>, dim3(grid), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+    return;
+  }
+  if (store == 1) hipLaunchKernelGGL(k_compact_indices<1>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  else if (store == 2) hipLaunchKernelGGL(k_compact_indices<2>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
   else hipLaunchKernelGGL(k_compact_indices<0>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
 }
 

@@ -724,15 +724,14 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_d
 // Measured on 8-byte integer columns (one sequence per 8 output bytes, the worst case for a block-serial format): see DESIGN.md §4 K7.
 // (The four earlier decoders — plain global round trips, LDS staging, register-window parser, one-window batches: 26-54 GB/s — were
 // dropped from the library in round 2; git history and DESIGN.md §10 keep what they taught.)
-static int g_lz4_pipe = -1;          // -1: by block count, 0: one wave per block, 1: two-wave pipeline (ctx option "lz4_pipeline", tools/bench_lz4)
-void set_lz4_pipe(int v) { g_lz4_pipe = v; }
-void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status) {
+// pipe: -1: by block count, 0: one wave per block, 1: two-wave pipeline (ctx option "lz4_pipeline", tools/bench_lz4)
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, int pipe) {
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
   // fewer blocks than the chip has wave slots (20 one-wave workgroups per CU x 256 CUs): the two-wave pipeline halves what matters then, a block's latency
   // (measured crossover on one MI355X: 2048 blocks 301 vs 252 GB/s for the pipeline, 3072 blocks 275 vs 326 against it: its 13.8 KB of LDS hold 11 blocks per CU)
-  if (g_lz4_pipe == 1 || (g_lz4_pipe < 0 && nblocks <= 2560))
+  if (pipe == 1 || (pipe < 0 && nblocks <= 2560))
     hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{});
   else
     hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});

@@ -123,47 +123,44 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
 }
 
 
-static int g_scan_wt_store = 1;
-void set_scan_wt_store(int v) { g_scan_wt_store = v; }
-
 template <typename T, int OP>
-static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing, bool nt, void* cap) {
+static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing, bool nt, void* cap, int wt_store) {
   const T c = from_bits<T>(cbits);
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   const int grid = grid_for_tiles((ntiles + 3) / 4);
   if constexpr (sizeof(T) == 8) {
-    if (cap && !and_existing) { hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)cap, g_scan_wt_store); return; }
+    if (cap && !and_existing) { hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)cap, wt_store); return; }
   }
-  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
-  else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
-  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, g_scan_wt_store);
+  if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);
+  else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);
+  else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);
 }
 template <typename T>
-static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae, bool nt, void* cap) {
+static void launch_cmp_op(hipStream_t s, const void* col, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool ae, bool nt, void* cap, int wt) {
   switch (op) {
-    case CMP_EQ: launch_cmp_t<T, CMP_EQ>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
-    case CMP_NE: launch_cmp_t<T, CMP_NE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
-    case CMP_LT: launch_cmp_t<T, CMP_LT>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
-    case CMP_LE: launch_cmp_t<T, CMP_LE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
-    case CMP_GT: launch_cmp_t<T, CMP_GT>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
-    default:     launch_cmp_t<T, CMP_GE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap); break;
+    case CMP_EQ: launch_cmp_t<T, CMP_EQ>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
+    case CMP_NE: launch_cmp_t<T, CMP_NE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
+    case CMP_LT: launch_cmp_t<T, CMP_LT>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
+    case CMP_LE: launch_cmp_t<T, CMP_LE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
+    case CMP_GT: launch_cmp_t<T, CMP_GT>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
+    default:     launch_cmp_t<T, CMP_GE>(s, col, cbits, bitmap, tc, nrows, ae, nt, cap, wt); break;
   }
 }
 
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap, uint32_t* tile_counts,
-                     int64_t nrows, bool and_existing, bool nt, void* cap) {
+                     int64_t nrows, bool and_existing, bool nt, void* cap, int wt_store) {
   switch (dtype) {
-    case DFDB_I8:  launch_cmp_op<int8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_I16: launch_cmp_op<int16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_I32: launch_cmp_op<int32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_I64: launch_cmp_op<int64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_U8: case DFDB_BOOL: launch_cmp_op<uint8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_U16: launch_cmp_op<uint16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_U32: launch_cmp_op<uint32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_U64: launch_cmp_op<uint64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    case DFDB_F32: launch_cmp_op<float>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
-    default:       launch_cmp_op<double>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap); break;
+    case DFDB_I8:  launch_cmp_op<int8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_I16: launch_cmp_op<int16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_I32: launch_cmp_op<int32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_I64: launch_cmp_op<int64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_U8: case DFDB_BOOL: launch_cmp_op<uint8_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_U16: launch_cmp_op<uint16_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_U32: launch_cmp_op<uint32_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_U64: launch_cmp_op<uint64_t>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    case DFDB_F32: launch_cmp_op<float>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
+    default:       launch_cmp_op<double>(s, col, op, cbits, bitmap, tile_counts, nrows, and_existing, nt, cap, wt_store); break;
   }
 }
 

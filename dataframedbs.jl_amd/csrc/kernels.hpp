@@ -34,10 +34,10 @@ struct ScanTerms {
 };
 
 // ---- K1: predicate scan -> bitmap (+ per-1024-row tile counts) ----------------------------------
-void set_scan_wt_store(int v);   // 1 (default): K1 writes its bitmap with write-through stores
 // single column `x OP c`; and_existing: bitmap &= result (a predicate stage after a range stage)
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap,
-                     uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr);
+                     uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr,
+                     int wt_store = 1 /* 1: the bitmap leaves with write-through stores (ctx option "scan_wt_store") */);
 // extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
 // extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
@@ -68,9 +68,8 @@ void launch_missing_mask(hipStream_t s, const uint64_t* missing, bool negate, bo
 void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
 
 // ---- K2: bitmap -> ascending 1-based row numbers -------------------------------------------------
-void set_compact_store(int v);   // index stores: 0 plain, 1 nontemporal (default), 2 write-through
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows,
-                            int64_t row_base, int64_t out_cap);
+                            int64_t row_base, int64_t out_cap, int store = 1 /* index stores: 0 plain, 1 nontemporal, 2 write-through (ctx option "compact_store") */);
 // ---- K3: projection gather of a fixed-width column (width 1,2,4,8 bytes) -------------------------
 void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, void* dst, int width,
                    int64_t nrows, int64_t out_cap);
@@ -147,8 +146,8 @@ struct Lz4Block {      // one (column, block) unit of work
   int32_t dst_len;     // expected uncompressed bytes (origin)
   int64_t dst_off;     // where the decoded body goes inside the body arena
 };
-void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status);
-void set_lz4_pipe(int v);   // -1 (default): two waves per block when there are fewer blocks than wave slots, 0: never, 1: always
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status,
+                       int pipe = -1 /* -1: two waves per block when there are fewer blocks than wave slots, 0: never, 1: always (ctx option "lz4_pipeline") */);
 // K7 fused with the first predicate of a scan (decode -> scan fusion): 8-byte columns whose blocks start on 1024-row tiles
 struct LzScan { uint64_t* bitmap; uint32_t* counts; uint64_t cbits; int32_t dtype; int32_t op; };
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc);

@@ -410,9 +410,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // the launch that writes a fresh mask over the whole column: run it against the bitmap allocation this column pairs best with
     const ScanTerms tb0 = term_batches[0];
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
-    set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
+    const int wt0 = (int)ctx_option(ctx, "scan_wt_store", 1);
     place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows) {
-      if (tb0.n == 1 && tb0.t[0].op2 < 0 && tb0.t[0].pre == 0) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr);
+      if (tb0.n == 1 && tb0.t[0].op2 < 0 && tb0.t[0].pre == 0) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr, wt0);
       else launch_scan_terms(s, tb0, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
     });
   }
@@ -436,9 +436,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     }
     if (tb.n == 1 && tb.t[0].op2 < 0 && tb.t[0].pre == 0 && ex < 2) {
       LaunchTimer lt(ctx, "scan_cmp");
-      set_scan_wt_store((int)ctx_option(ctx, "scan_wt_store", 1));
+      prof_note(ctx, ctx_option(ctx, "scan_wt_store", 1) ? "scan_cmp.wt_store" : "scan_cmp.plain_store");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr);
+                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr, (int)ctx_option(ctx, "scan_wt_store", 1));
     } else {
       LaunchTimer lt(ctx, "scan_terms");
       launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr);
@@ -526,8 +526,9 @@ static void raise_reached_errors(dfdb_query* q, int nstages) {
     q->err_checking = false;
   }
   q->err_row[0] = q->err_row[1] = ~0ull;
-  if (raise == 0) { q->executed_stages = -1; fail(DFDB_ERR_DIVIDE, "DivideError: integer division error"); }
-  if (raise == 1) { q->executed_stages = -1; fail(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact"); }
+  // (the row travels with the error: the shards of a multi-GPU group raise the error of the lowest GLOBAL row, group.cpp)
+  if (raise == 0) { q->executed_stages = -1; throw Error(DFDB_ERR_DIVIDE, "DivideError: integer division error", (uint64_t)q->t->row_base + er[0]); }
+  if (raise == 1) { q->executed_stages = -1; throw Error(DFDB_ERR_ARGUMENT, "InexactError: conversion is not exact", (uint64_t)q->t->row_base + er[1]); }
 }
 
 void query_execute(dfdb_query* q, int nstages) {
@@ -601,10 +602,12 @@ void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
 void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   ensure_executed(q);
-  set_compact_store((int)ctx_option(ctx, "compact_store", 1));
+  const int store = (int)ctx_option(ctx, "compact_store", kCompactStoreDefault);   // per context: two contexts may run different variants side by side
+  static const char* const store_names[] = {"compact_indices.plain8", "compact_indices.nt8", "compact_indices.wt8", "compact_indices.nt16", "compact_indices.plain16"};
+  prof_note(ctx, store_names[store >= 0 && store <= 4 ? store : 0]);
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");
-      launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap); }
+      launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap, store); }
     if (n) *n = query_count(q, -1);
     return;
   }
@@ -614,7 +617,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   if (m <= 0) return;
   q->tmp_b.ensure((size_t)m * 8);
   { LaunchTimer lt(ctx, "compact_indices");
-    launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m); }
+    launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m, store); }
   HIP_CHECK(hipMemcpyAsync(out, q->tmp_b.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
   stream_wait(q->t->ctx);
 }

@@ -277,8 +277,7 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     dstatus.ensure(4 * (size_t)nb);
     HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)nb, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4 * (size_t)nb, s));
-    set_lz4_pipe((int)ctx_option(ctx, "lz4_pipeline", -1));
-    { LaunchTimer lt(ctx, "lz4_decode"); launch_lz4_decode(s, staged.as<uint8_t>(), decode_dst, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>()); }
+    { LaunchTimer lt(ctx, "lz4_decode"); launch_lz4_decode(s, staged.as<uint8_t>(), decode_dst, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>(), (int)ctx_option(ctx, "lz4_pipeline", -1)); }
     std::vector<int32_t> st((size_t)nb);
     HIP_CHECK(hipMemcpyAsync(st.data(), dstatus.p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -427,7 +426,7 @@ void table_decode_resident(dfdb_table* t, int32_t ordinal) {
   dfdb_ctx* ctx = t->ctx;
   for (dfdb_query* q : t->queries) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }
   LaunchTimer lt(ctx, "lz4_decode");
-  launch_lz4_decode(ctx->stream, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>());
+  launch_lz4_decode(ctx->stream, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), (int)ctx_option(ctx, "lz4_pipeline", -1));
 }
 
 void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,

@@ -66,6 +66,8 @@ SYMBOLS = [
     "dfdb_group_query_add_predicate", "dfdb_group_query_set_projection", "dfdb_group_query_hint_aggregate", "dfdb_group_query_hint_materialize",
     "dfdb_group_query_reset", "dfdb_group_query_shard", "dfdb_group_count", "dfdb_group_shard_counts", "dfdb_group_aggregate",
     "dfdb_group_select_indices_device", "dfdb_group_select_indices", "dfdb_group_result_string_bytes", "dfdb_group_materialize",
+    "dfdb_group_shard_string_bytes", "dfdb_group_materialize_device",
+    "dfdb_group_query_unique", "dfdb_group_query_unique_fetch", "dfdb_group_query_groupreduce", "dfdb_group_query_groupreduce_fetch",
 ]
 EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
 GROUP_ID_BYTES = 128
@@ -145,6 +147,12 @@ def load() -> C.CDLL:
         lib.dfdb_group_select_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dfdb_group_result_string_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.dfdb_group_materialize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_group_shard_string_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.dfdb_group_materialize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_group_query_unique.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_query_unique_fetch.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_query_groupreduce.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.dfdb_group_query_groupreduce_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for f in ("dfdb_group_destroy", "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_table_close", "dfdb_group_query_free", "dfdb_group_query_reset"):
             getattr(lib, f).argtypes = [C.c_void_p]
         _lib = lib

@@ -302,6 +302,41 @@ class GroupQuery:
         return res
 
 
+def gmaterialize_device(v: api.DFView, alloc):
+    """materialize(v) left sharded on the devices (dfdb_group_materialize_device): `alloc(local_shard, nbytes)` returns the device address of a
+    buffer of that many bytes in that shard's HBM (e.g. a torch tensor's data_ptr(); the caller keeps it alive).  Returns, per local shard, a list of
+    per-column dicts {dtype, count, data, bytes, nbytes, missing} holding device addresses — rank order = table order.  Nothing crosses PCIe."""
+    L = N.load()
+    gq = _gq(v)
+    g = gq.gt.group
+    N.check(L.dfdb_group_query_hint_materialize(gq._h, 1))
+    counts = gq.shard_counts()[g.first_rank:g.first_rank + g.nlocal]
+    ncols = len(v.projection)
+    dts = [gq.coltype(i) for i in range(ncols)]
+    sbytes = {}
+    for i, dt in enumerate(dts):
+        if (dt & ir.DTYPE_MASK) == ir.STRING:
+            a = (C.c_int64 * g.nlocal)()
+            N.check(L.dfdb_group_shard_string_bytes(gq._h, i, a))
+            sbytes[i] = list(a)
+    outs = (N.OutCol * max(g.nlocal * ncols, 1))()
+    for l in range(g.nlocal):
+        n = counts[l]
+        for i, dt in enumerate(dts):
+            o = outs[l * ncols + i]
+            o.memkind = N.MEM_DEVICE
+            if (dt & ir.DTYPE_MASK) == ir.STRING:
+                o.data = alloc(l, max(n, 1) * 4); o.bytes = alloc(l, sbytes[i][l] + 64); o.bytes_cap = sbytes[i][l]
+            else:
+                o.data = alloc(l, max(n, 1) * np.dtype(ir.numpy_of_dtype(dt)).itemsize)
+                if dt & ir.NULLABLE:
+                    o.missing = alloc(l, max(n, 1))
+    if ncols:
+        N.check(L.dfdb_group_materialize_device(gq._h, outs, ncols))
+    return [[dict(dtype=outs[l * ncols + i].dtype, count=outs[l * ncols + i].count, data=outs[l * ncols + i].data, bytes=outs[l * ncols + i].bytes,
+                  nbytes=outs[l * ncols + i].nbytes, missing=outs[l * ncols + i].missing) for i in range(ncols)] for l in range(g.nlocal)]
+
+
 def _gq(v) -> GroupQuery:
     if isinstance(v, api.DFColumn):
         v = v.view
@@ -327,52 +362,29 @@ def gmaterialize(v: api.DFView):
 
 
 # ---------------------------------------------------------------- unique / groupreduce over shards
-# Every shard reduces its own rows on its own device (dfdb_query_unique / dfdb_query_groupreduce on the shard's query, after the
-# group has run the selection — range stages count across shards, so the shard queries hold the group's selection); what crosses
-# shards is one small record per distinct key, merged here in rank order, which is the table's row order: the merged keys come out
-# in order of first appearance over the whole table, as Base.unique / the reference's group_map numbering give them.
-def _key_of(v):
-    if v is None:
-        return ("missing",)
-    if isinstance(v, float):
-        return ("nan",) if v != v else (v, np.signbit(v).item())       # isequal: NaN == NaN, -0.0 != 0.0
-    return v
-
-
-def _listed(keys) -> list:
-    if isinstance(keys, np.ma.MaskedArray):
-        return [None if m else x for x, m in zip(keys.data.tolist(), np.ma.getmaskarray(keys).tolist())]
-    if hasattr(keys, "to_pylist"):                      # set_string_output("arrow")
-        return keys.to_pylist()
-    return keys.tolist() if isinstance(keys, np.ndarray) else list(keys)
-
-
-def _all_ranks(g: Group, local_parts: list) -> list:
-    """the per-shard records of every rank, rank order; one process per GPU hands its records round through torch.distributed"""
-    if g.nlocal == g.world:
-        return local_parts
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        raise RuntimeError("a group of one process per GPU merges unique / groupreduce through torch.distributed: init_process_group first")
-    box = [None] * dist.get_world_size()
-    dist.all_gather_object(box, local_parts)
-    return [p for parts in box for p in parts]
-
-
-def _shard_queries(gq: GroupQuery):
-    L = N.load()
-    for l in range(gq.gt.group.nlocal):
-        h = C.c_void_p()
-        N.check(L.dfdb_group_query_shard(gq._h, l, C.byref(h)))
-        yield api._ChunkQuery(gq.view, h, 0, 0)          # borrowed: the group query owns the handle
-
-
-def _keys_array(keys: list, kdt: int):
-    if (kdt & ir.DTYPE_MASK) == ir.STRING:
-        return np.array(keys, dtype=object)
+# Behind the C ABI since round 3 (dfdb_group_query_unique / _groupreduce + their fetches, csrc/group.cpp): every shard reduces its own rows on its
+# own device, one record per distinct key crosses to the other ranks (RCCL all-gather; nothing when one process holds every shard), and the
+# records are merged by key in rank order — the table's row order — so the keys come out in order of first appearance over the whole table, as
+# Base.unique / the reference's group_map numbering give them.  What is left here is sizing the caller-owned buffers.
+def _fetch_keys(L, gq: GroupQuery, kdt: int, n: int, kbytes: int, fetch, logical: str = ""):
+    out = N.OutCol()
+    out.memkind = N.MEM_HOST
+    is_str = (kdt & ir.DTYPE_MASK) == ir.STRING
+    if is_str:
+        ksz = np.empty(max(n, 1), np.int32); kby = np.empty(max(kbytes, 1), np.uint8)
+        out.data, out.bytes, out.bytes_cap = ksz.ctypes.data, kby.ctypes.data, kbytes
+    else:
+        karr = np.empty(max(n, 1), ir.numpy_of_dtype(kdt))
+        kmiss = np.zeros(max(n, 1), np.uint8) if kdt & ir.NULLABLE else None
+        out.data = karr.ctypes.data
+        if kmiss is not None:
+            out.missing = kmiss.ctypes.data
+    fetch(out)
+    if is_str:
+        return api._to_user((ksz[:n].copy(), kby[:out.nbytes].copy()), logical)
     if kdt & ir.NULLABLE:
-        return np.ma.masked_array(np.array([0 if k is None else k for k in keys], ir.numpy_of_dtype(kdt)), mask=[k is None for k in keys])
-    return np.array(keys, ir.numpy_of_dtype(kdt))
+        return api._to_user(np.ma.masked_array(karr[:n].copy(), mask=kmiss[:n].astype(bool)), logical)
+    return api._to_user(karr[:n].copy(), logical)
 
 
 def gunique(col: api.DFColumn):
@@ -381,66 +393,33 @@ def gunique(col: api.DFColumn):
     gt = getattr(v.table, "_group_table", None)
     if gt is None:
         raise ValueError("not a column of a GroupTable")
+    L = N.load()
     gq = GroupQuery(gt, v)
     try:
-        N.check(N.load().dfdb_group_query_hint_materialize(gq._h, 1))
-        gq.count()
-        kdt = gq.coltype(0)
-        parts = []
-        for q in _shard_queries(gq):
-            N.check(N.load().dfdb_query_unique(q._h, 0))
-            parts.append(_listed(api._to_user(q.materialize()[0], api._logicals(v)[0])))
-        seen, out = set(), []
-        for part in _all_ranks(gt.group, parts):
-            for x in part:
-                k = _key_of(x)
-                if k not in seen:
-                    seen.add(k); out.append(x)
-        return _keys_array(out, kdt)
+        n, kb = C.c_int64(), C.c_int64()
+        N.check(L.dfdb_group_query_unique(gq._h, 0, C.byref(n), C.byref(kb)))
+        return _fetch_keys(L, gq, gq.coltype(0), n.value, kb.value, lambda out: N.check(L.dfdb_group_query_unique_fetch(gq._h, C.byref(out))), api._logicals(v)[0])
     finally:
         gq.close()
 
 
 def ggroupreduce(v: api.DFView, by: str, col: Optional[str] = None, stat: str = "count"):
-    """groupreduce(view, (:by,); out = :col => Stat()) over every shard: per-shard groups merged by key in rank order (counts and sums add —
-    Int64 sums wrap as on one device, Float64 sums are sums of the shards' sums —, min / max fold); same frame as dfdb.groupreduce."""
+    """groupreduce(view, (:by,); out = :col => Stat()) over every shard (dfdb_group_query_groupreduce): counts and sums add — Int64 sums wrap as on
+    one device, Float64 sums are sums of the shards' sums —, min / max fold with Julia's NaN and signed-zero rules; same frame as dfdb.groupreduce."""
     sub, with_value = api._groupreduce_view(v, by, col, stat)
     gt = getattr(sub.table, "_group_table", None)
     if gt is None:
         raise ValueError("not a view of a GroupTable")
+    L = N.load()
     gq = GroupQuery(gt, sub)
     try:
-        gq.count()
-        kdt = gq.coltype(0)
+        ng, kb = C.c_int64(), C.c_int64()
+        N.check(L.dfdb_group_query_groupreduce(gq._h, 0, 1 if with_value else -1, api._STATS[stat], C.byref(ng), C.byref(kb)))
+        n = ng.value
+        counts = np.zeros(max(n, 1), np.int64); vi = np.zeros(max(n, 1), np.int64); vf = np.zeros(max(n, 1), np.float64)
+        keys = _fetch_keys(L, gq, gq.coltype(0), n, kb.value,
+                           lambda out: N.check(L.dfdb_group_query_groupreduce_fetch(gq._h, C.byref(out), counts.ctypes.data, vi.ctypes.data, vf.ctypes.data)))
         vdt = gq.coltype(1) & ir.DTYPE_MASK if with_value else None
-        parts = []
-        for q in _shard_queries(gq):
-            keys, counts, vi, vf, _ = api._groupreduce_raw(q, with_value, stat)
-            parts.append((_listed(keys), counts, vi, vf))
-        slot, keys, counts, vis, vfs = {}, [], [], [], []
-        isf = vdt in (ir.F32, ir.F64)
-        uns = vdt in (ir.U8, ir.U16, ir.U32, ir.U64)
-        fold = {"min": min, "minimum": min, "max": max, "maximum": max}.get(stat)
-        for pk, pc, pi, pf in _all_ranks(gt.group, parts):
-            for j, x in enumerate(pk):
-                k = _key_of(x)
-                a, b = int(pi[j]), float(pf[j])
-                if uns:
-                    a &= (1 << 64) - 1
-                g = slot.get(k)
-                if g is None:
-                    slot[k] = len(keys); keys.append(x); counts.append(int(pc[j])); vis.append(a); vfs.append(b)
-                    continue
-                counts[g] += int(pc[j])
-                if fold is None:                         # count / sum / mean
-                    vis[g] += a; vfs[g] += b
-                elif isf:                                # min / max over Float64: a NaN in either shard is the answer (Base.min / max)
-                    vfs[g] = b if b != b else (vfs[g] if vfs[g] != vfs[g] else fold(vfs[g], b))
-                else:
-                    vis[g] = fold(vis[g], a)
-        wrap = [((x + (1 << 63)) % (1 << 64)) - (1 << 63) for x in vis]            # back to Int64 bits (sums wrap; UInt64 is a view of them)
-        vi = np.array(wrap, np.int64) if wrap else np.zeros(0, np.int64)
-        vf = np.array(vfs, np.float64) if isf or not vis else (vi.astype(np.uint64).astype(np.float64) if uns else vi.astype(np.float64))
-        return api._groupreduce_frame(by, stat, _keys_array(keys, kdt), np.array(counts, np.int64), vi, vf, vdt)
+        return api._groupreduce_frame(by, stat, keys, counts[:n].copy(), vi[:n].copy(), vf[:n].copy(), vdt)
     finally:
         gq.close()

@@ -44,12 +44,14 @@ end
 function last_error()
     buf = Vector{UInt8}(undef, 1024)
     ccall((:dfdb_last_error, LIB), Int32, (Ptr{UInt8}, Csize_t), buf, 1024)
-    unsafe_string(pointer(buf))
+    GC.@preserve buf unsafe_string(pointer(buf))
 end
 
 function check(rc::Int32)
     rc == OK && return
     msg = last_error()
+    # InexactError (Int8(300), UInt64(-1) inside a predicate) travels as DFDB_ERR_ARGUMENT with its name in the text (include/dfdb.h)
+    rc == 1 && startswith(msg, "InexactError") && throw(InexactError(:convert, Integer, msg))
     rc == 1 && throw(ArgumentError(msg))
     rc == 4 && throw(KeyError(msg))
     rc == 5 && throw(BoundsError(msg))
@@ -80,10 +82,11 @@ const OPS = Dict{Any,UInt8}(
     startswith => 0x41, endswith => 0x42, coalesce => 0x45)
 const UNARY = Dict{Any,UInt8}((-) => 0x17, abs => 0x18, (!) => 0x33, ismissing => 0x43, sizeof => 0x44)
 
-emit_col(io, ord::Integer) = (write(io, 0x01); write(io, UInt32(ord)))
+emit_col(io, ord::Integer) = (write(io, 0x01); write(io, UInt32(ord)))   # checked: a 0-based column ordinal, 0 <= ord < ncol
 function emit_const(io, v::T) where {T<:Union{Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64,Float32,Float64,Bool}}
     write(io, 0x02); write(io, DT[T])
-    T == Float64 ? write(io, v) : T == Float32 ? (write(io, v); write(io, UInt32(0))) : write(io, Int64(v) % Int64)
+    # integers travel as their low 64 bits: `v % Int64` wraps (a UInt64 >= 2^63 keeps its bit pattern), `Int64(v)` would throw InexactError for it
+    T == Float64 ? write(io, v) : T == Float32 ? (write(io, v); write(io, UInt32(0))) : write(io, v % Int64)
 end
 emit_const(io, s::AbstractString) = (write(io, 0x03); write(io, UInt32(sizeof(s))); write(io, String(s)))
 # Date / DateTime / Time / Char columns are integer columns to the engine (dfdb_colinfo.logical): constants travel as the
@@ -93,7 +96,9 @@ emit_const(io, c::Char) = emit_const(io, reinterpret(UInt32, c))
 emit_const(io, r::Base.RefValue) = emit_const(io, r[])
 function emit_const(io, v::AbstractVector{T}) where {T<:Union{Integer,AbstractFloat}}     # Ref([1,11,21]) for in.()
     E = T <: AbstractFloat ? Float64 : Int64
-    write(io, 0x04); write(io, DT[E]); write(io, UInt32(length(v))); foreach(x -> write(io, E(x)), v)
+    # the IR's integer sets are Int64: a member above typemax(Int64) has no place in one (the stock path answers instead)
+    T <: Unsigned && any(x -> x > typemax(Int64), v) && throw(Unsupported("in.() over unsigned values above typemax(Int64)"))
+    write(io, 0x04); write(io, DT[E]); write(io, UInt32(length(v))); foreach(x -> write(io, convert(E, x)), v)
 end
 emit_const(io, v) = throw(Unsupported("constant of type $(typeof(v)) is outside the IR"))
 
@@ -146,7 +151,8 @@ end
 # ---------------------------------------------------------------- devices: one GPU, or a block-range sharded group of all of them
 # With more than one GPU visible (and DFDB_GPUS != "1") every opened table is sharded by block range over ALL of them
 # (dfdb_group_*: a host thread per GPU inside the library, RCCL all-reduce for nrow / sum / minimum / maximum, rank-order
-# concatenation for materialize; include/dfdb.h "multi-GPU groups").  `unique` and the write side use GPU 0 alone.
+# concatenation for materialize, per-shard device reduction + merge by key in rank order for unique / groupreduce; include/dfdb.h
+# "multi-GPU groups").  The write side uses GPU 0 alone.
 mutable struct Device
     ctx::Ptr{Cvoid}                       # single-GPU context (GPU 0)
     group::Ptr{Cvoid}                     # dfdb_group* or C_NULL
@@ -159,7 +165,7 @@ function ngpus()
     n = Ref{Int32}(0)
     check(ccall((:dfdb_device_count, LIB), Int32, (Ptr{Int32},), n))
     want = tryparse(Int, get(ENV, "DFDB_GPUS", ""))
-    want === nothing ? Int(n[]) : min(Int(n[]), want)
+    want === nothing ? Int(n[]) : min(Int(n[]), want)   # checked: Int32 -> Int only widens
 end
 
 function device()
@@ -242,7 +248,7 @@ for (fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ) in (
             end
             lens = Csize_t[length(c) for c in codes]
             GC.@preserve names codes begin
-                np = [pointer(n) for n in names]; cp = [pointer(c) for c in codes]
+                np = [pointer(n) for n in names]; cp = [pointer(c) for c in codes]   # rooted by names / codes (the GC.@preserve around this block)
                 check(ccall(($(QuoteNode(PROJ)), LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Ptr{UInt8}}, Ptr{Csize_t}),
                             q[], length(names), np, cp, lens))
             end
@@ -296,12 +302,12 @@ function alloc_outputs(v::DFView, n::Integer, coltype, strbytes)
             nb = strbytes(i - 1)
             sizes = Vector{Int32}(undef, n); arena = Vector{UInt8}(undef, nb)
             push!(bufs, (T, sizes, arena, nothing))
-            outs[i] = OutCol(pointer(sizes), pointer(arena), C_NULL, nb, 0, 0, 0, 0)
+            outs[i] = OutCol(pointer(sizes), pointer(arena), C_NULL, nb, 0, 0, 0, 0)   # rooted by bufs (every caller: GC.@preserve bufs outs around its ccall)
         else
             B = Base.nonmissingtype(T)
             vals = Vector{B}(undef, n); miss = T === B ? nothing : Vector{UInt8}(undef, n)
             push!(bufs, (T, vals, nothing, miss))
-            outs[i] = OutCol(pointer(vals), C_NULL, miss === nothing ? C_NULL : pointer(miss), 0, 0, 0, 0, 0)
+            outs[i] = OutCol(pointer(vals), C_NULL, miss === nothing ? C_NULL : pointer(miss), 0, 0, 0, 0, 0)   # rooted by bufs (as above)
         end
     end
     outs, bufs
@@ -315,7 +321,7 @@ function finish_columns(v::DFView, bufs)
         if arena !== nothing
             res = Vector{T}(undef, length(a)); o = 0
             for (k, s) in enumerate(a)
-                res[k] = s < 0 ? missing : (str = unsafe_string(pointer(arena) + o, s); o += s; str)
+                res[k] = s < 0 ? missing : (str = GC.@preserve arena unsafe_string(pointer(arena) + o, s); o += s; str)
             end
             res
         elseif miss !== nothing
@@ -369,8 +375,18 @@ end
 "materialize(c::DFColumn) on the device(s) (materialization.jl:46-52): the one projection column as a Vector{T} / BitVector."
 gpu_materialize(c::DFColumn) = gpu_materialize_columns(c.view)[1]
 
-"unique(col::DFColumn) on the device (docs/src/index.md:171-182): distinct values in order of first appearance."
-gpu_unique(c::DFColumn) = gpu_materialize_columns(c.view; first_occurrences_of = 0)[1]
+"unique(col::DFColumn) on the device(s) (docs/src/index.md:171-182, 479-487): distinct values in order of first appearance over the WHOLE table —
+sharded: every GPU reduces its block range, the per-shard distinct sets are merged by key in rank order inside the library (dfdb_group_query_unique)."
+function gpu_unique(c::DFColumn)
+    sharded() || return gpu_materialize_columns(c.view; first_occurrences_of = 0)[1]
+    with_gquery(c.view) do q
+        n = Ref{Int64}(0); kb = Ref{Int64}(0)
+        check(ccall((:dfdb_group_query_unique, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int64}), q, 0, n, kb))
+        outs, bufs = alloc_outputs(c.view, n[], i -> gquery_coltype(q, i), i -> kb[])
+        GC.@preserve bufs outs check(ccall((:dfdb_group_query_unique_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}), q, outs))
+        finish_columns(c.view, bufs)[1]
+    end
+end
 
 """
 sum / minimum / maximum of a DFColumn on the device(s) (the reference iterates the column: column.jl:102-126, docs/src/index.md:503-509).
@@ -411,24 +427,14 @@ gpu_sum_count(c::DFColumn) = gpu_aggregate(c, 1)
 """
 groupreduce(view, (:by,); out = :col => Stat()) on the device (src/tables/aggregate.jl:1-36: exported by the reference, unfinished there — it numbers the
 groups in order of first appearance and stops).  Returns a DataFrame with one row per distinct value of `by` in order of first appearance, the group's
-row count and `stat(col)`, stat in (:count, :sum, :minimum, :maximum, :mean).  GPU 0 (the hash table of `unique` is not sharded).
+row count and `stat(col)`, stat in (:count, :sum, :minimum, :maximum, :mean).  Sharded like everything else when a group is active.
 """
 function gpu_groupreduce(v::DFView, by::Symbol, col::Union{Symbol,Nothing} = nothing, stat::Symbol = :count)
     code = Dict(:count => 0, :sum => 1, :minimum => 2, :maximum => 3, :mean => 1)[stat]
     two = col !== nothing && stat != :count
     sub = two ? v[:, [by, col]] : v[:, [by]]
-    with_query(sub) do q
-        ng = Ref{Int64}(0); kb = Ref{Int64}(0)
-        check(ccall((:dfdb_query_groupreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int64}, Ptr{Int64}), q, 0, two ? 1 : -1, code, ng, kb))
-        n = ng[]
-        keyview = sub[:, [by]]
-        outs, bufs = alloc_outputs(keyview, n, i -> begin
-            dt = Ref{Int32}(0)
-            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, 0, dt)); dt[]
-        end, i -> kb[])
-        counts = Vector{Int64}(undef, n); vi = Vector{Int64}(undef, n); vf = Vector{Float64}(undef, n)
-        GC.@preserve bufs outs counts vi vf check(ccall((:dfdb_query_groupreduce_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), q, outs, counts, vi, vf))
-        keys = finish_columns(keyview, bufs)[1]
+    keyview = sub[:, [by]]
+    finish = (keys, counts, vi, vf) -> begin
         res = DataFrames.DataFrame(by => keys, :count => counts)
         if two
             T = Base.nonmissingtype(DataFrameDBs.coltype(sub.projection, 2))
@@ -437,6 +443,29 @@ function gpu_groupreduce(v::DFView, by::Symbol, col::Union{Symbol,Nothing} = not
             res[!, stat] = vals
         end
         res
+    end
+    if sharded()          # every GPU reduces its block range; the groups are merged by key in rank order inside the library
+        return with_gquery(sub) do q
+            ng = Ref{Int64}(0); kb = Ref{Int64}(0)
+            check(ccall((:dfdb_group_query_groupreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int64}, Ptr{Int64}), q, 0, two ? 1 : -1, code, ng, kb))
+            n = ng[]
+            outs, bufs = alloc_outputs(keyview, n, i -> gquery_coltype(q, 0), i -> kb[])
+            counts = Vector{Int64}(undef, n); vi = Vector{Int64}(undef, n); vf = Vector{Float64}(undef, n)
+            GC.@preserve bufs outs counts vi vf check(ccall((:dfdb_group_query_groupreduce_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), q, outs, counts, vi, vf))
+            finish(finish_columns(keyview, bufs)[1], counts, vi, vf)
+        end
+    end
+    with_query(sub) do q
+        ng = Ref{Int64}(0); kb = Ref{Int64}(0)
+        check(ccall((:dfdb_query_groupreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int64}, Ptr{Int64}), q, 0, two ? 1 : -1, code, ng, kb))
+        n = ng[]
+        outs, bufs = alloc_outputs(keyview, n, i -> begin
+            dt = Ref{Int32}(0)
+            check(ccall((:dfdb_query_coltype, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}), q, 0, dt)); dt[]
+        end, i -> kb[])
+        counts = Vector{Int64}(undef, n); vi = Vector{Int64}(undef, n); vf = Vector{Float64}(undef, n)
+        GC.@preserve bufs outs counts vi vf check(ccall((:dfdb_query_groupreduce_fetch, LIB), Int32, (Ptr{Cvoid}, Ptr{OutCol}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), q, outs, counts, vi, vf))
+        finish(finish_columns(keyview, bufs)[1], counts, vi, vf)
     end
 end
 

@@ -67,7 +67,7 @@ typedef struct dfdb_device_info {
   int32_t compute_units;
   int32_t wavefront_size;
   int64_t hbm_bytes;
-  double  peak_hbm_gbps;   /* memoryClockRate * busWidth as reported by hipDeviceProp */
+  double  peak_hbm_gbps;   /* HBM3E spec peak of the part: 8000 on MI355X / gfx950 (what bench.py prices its roofline against) */
 } dfdb_device_info;
 
 typedef struct dfdb_colinfo {   /* ColumnMeta(id,name,type): src/tables/meta.jl:2-10 */
@@ -316,7 +316,13 @@ int32_t dfdb_stream_close(dfdb_stream* s);
  *   dfdb_group_create_rank   one process per GPU (ncclCommInitRank; the id comes from dfdb_group_unique_id on rank 0 and is
  *                            handed round by the launcher: MPI, Distributed.jl, a torch.distributed store)
  * RCCL is dlopen'ed on first use.  DFDB_EXCHANGE_HOST does the same exchanges through host memory and exists for one-process
- * groups whose shards share a physical GPU (functional tests on a 1-GPU box; RCCL refuses duplicate devices). */
+ * groups whose shards share a physical GPU (functional tests on a 1-GPU box; RCCL refuses duplicate devices).
+ * Failures: when the per-shard half of a collective call fails on one rank only (a DivideError / InexactError that only its rows reach, out of
+ * memory, a column that is not resident) that rank still takes part in the exchange, and every exchange carries an 8-byte fault key reduced
+ * with MIN: all ranks return the SAME error from the same call — the one of the lowest table row when the error knows its row, which is the
+ * one the reference's serial block iteration meets first.  An enqueue-only call (dfdb_group_count(gq, NULL)) returns a local failure at once
+ * and the other ranks meet it at their next call that reads a result back.  A rank that dies outright must take its process down with a
+ * non-zero exit (the launcher then stops the others); it must never re-exec. */
 typedef struct dfdb_group dfdb_group;
 typedef struct dfdb_gtable dfdb_gtable;   /* a DFTable, sharded */
 typedef struct dfdb_gquery dfdb_gquery;   /* a DFView over it */
@@ -371,6 +377,26 @@ int32_t dfdb_group_select_indices(dfdb_gquery* gq, int64_t* out, int64_t cap, in
 int32_t dfdb_group_result_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbytes);
 /* materialize(v) (materialization.jl:27-40) into caller-owned HOST buffers: the local shards' rows in rank order = table order */
 int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols);
+/* ... or left SHARDED on the devices ("results stay sharded per GPU"): outs[l * ncols + p] is output column p of local shard l,
+ * buffers in that shard's own HBM (memkind DFDB_MEM_DEVICE), sized from dfdb_group_shard_counts (rows of rank first_rank + l) and
+ * dfdb_group_shard_string_bytes (String columns).  Asynchronous on the shards' engine streams; nothing crosses PCIe or xGMI.  Rank order = table
+ * order, so the caller's lazy concatenation of the shards IS the materialised view. */
+int32_t dfdb_group_shard_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbytes /* nlocal values */);
+int32_t dfdb_group_materialize_device(dfdb_gquery* gq, dfdb_outcol* outs /* [nlocal][ncols] */, int32_t ncols);
+
+/* unique(col) over the WHOLE table (Base.unique over Base.iterate(::DFColumn), column.jl:102-126; docs/src/index.md:171-182,479-487).  Every shard
+ * reduces its own rows on its own device (dfdb_query_groupreduce's kernels), ONE record per distinct key crosses to the other ranks (all-gather over
+ * RCCL; nothing at all when one process holds every shard) and the records are merged by key in rank order — first appearance = lowest rank, then
+ * lowest row — so the distinct values come out in the order Julia's unique gives over the whole column (isequal: NaN == NaN, -0.0 != 0.0, missing
+ * is a value).  Call 1 returns how many there are and the string bytes they take; the fetch copies them into a caller-owned HOST column and
+ * forgets them.  Every rank receives the whole answer. */
+int32_t dfdb_group_query_unique(dfdb_gquery* gq, int32_t proj_col, int64_t* ndistinct, int64_t* string_bytes);
+int32_t dfdb_group_query_unique_fetch(dfdb_gquery* gq, dfdb_outcol* keys);
+/* groupreduce(view, (:key,); out = :val => Stat()) over the whole table (aggregate.jl:1-36, completed as dfdb_query_groupreduce completes it): the
+ * shards' groups merged by key in rank order = groups in order of first appearance in the table; counts and sums add (Int sums wrap as on one device,
+ * Float64 sums are the sum of the shards' sums: tolerance of DESIGN.md section 5), minimum / maximum fold with Julia's NaN and signed-zero rules. */
+int32_t dfdb_group_query_groupreduce(dfdb_gquery* gq, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes);
+int32_t dfdb_group_query_groupreduce_fetch(dfdb_gquery* gq, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f);
 
 #ifdef __cplusplus
 }

@@ -247,7 +247,25 @@ def test_julia_shim_ccalls_match_the_header():
     rows, errors = mod.check()
     assert not errors, errors
     assert len(rows) >= 50
+    # the semantic lint (checked integer conversions, unrooted pointers, unchecked statuses) is clean on the shim ...
+    assert mod.lint() == [], mod.lint()
+    # ... and does find what it is there for: round 2's constant emitter, a bare pointer, a status nobody looks at
+    import tempfile
+    real = mod.JL
+    with tempfile.NamedTemporaryFile("w", suffix=".jl", delete=False) as f:
+        f.write("function emit_const(io, v)\n    write(io, Int64(v) % Int64)\nend\n"
+                "function f(buf, q, n)\n    p = pointer(buf)\n    ccall((:dfdb_count, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}), q, n)\n    n[]\nend\n")
+    try:
+        mod.JL = f.name
+        bad = mod.lint()
+    finally:
+        mod.JL = real
+        os.unlink(f.name)
+    assert len(bad) == 3 and "Int64(v)" in bad[0] and "pointer(buf)" in bad[1] and "dfdb_count" in bad[2], bad
     syms = {r[1] for r in rows}
+    # round 3: sharded unique / groupreduce go through the library's own merge
+    for s in ("dfdb_group_query_unique", "dfdb_group_query_unique_fetch", "dfdb_group_query_groupreduce", "dfdb_group_query_groupreduce_fetch"):
+        assert s in syms, s
     # the consumers VERDICT r1 asked for are bound: one-column routes, aggregates, unique, and the multi-GPU group
     for s in ("dfdb_materialize", "dfdb_aggregate", "dfdb_query_unique", "dfdb_group_create", "dfdb_group_count", "dfdb_group_aggregate", "dfdb_group_materialize"):
         assert s in syms, s
@@ -260,17 +278,15 @@ def test_julia_shim_ccalls_match_the_header():
         assert route in jl, route
 
 
-def test_shard_merge_keys_follow_isequal():
-    """dfdb/group.py merges per-shard unique / groupreduce records on the host: keys meet under isequal (NaN is one key, -0.0 and 0.0 are two,
-    missing is a key), listed forms of plain / masked / string key columns, and the typed array the merged keys go back into."""
-    from dfdb import group as G, ir
-    nan1, nan2 = float("nan"), np.float64("nan").item()
-    assert G._key_of(nan1) == G._key_of(nan2) and G._key_of(0.0) != G._key_of(-0.0) and G._key_of(None) == G._key_of(None)
-    assert G._key_of(3) == 3 and G._key_of("sony") == "sony" and G._key_of(None) != G._key_of("missing")
-    assert G._listed(np.array([3, 1, 2], np.int16)) == [3, 1, 2]
-    assert G._listed(np.ma.masked_array(np.array([5, 6, 7], np.int32), mask=[False, True, False])) == [5, None, 7]
-    assert G._listed(["a", None, "b"]) == ["a", None, "b"]
-    k = G._keys_array([4, None, 9], ir.I32 | ir.NULLABLE)
-    assert isinstance(k, np.ma.MaskedArray) and k.dtype == np.int32 and np.ma.getmaskarray(k).tolist() == [False, True, False] and k.data[0] == 4 and k.data[2] == 9
-    assert G._keys_array(["a", None], ir.STRING | ir.NULLABLE).tolist() == ["a", None]
-    assert G._keys_array([1.5, 2.5], ir.F64).dtype == np.float64
+def test_sharded_unique_and_groupreduce_live_behind_the_abi():
+    """round 2 merged the shards' unique / groupreduce records in Python (dfdb/group.py: _key_of, _all_ranks over torch.distributed); since round 3
+    the merge is the library's (csrc/group.cpp: group_reduce_all) and the Python layer only sizes buffers — a Julia caller gets the same answers"""
+    from dfdb import group as G
+    import dfdb
+    for gone in ("_key_of", "_all_ranks", "_shard_queries"):
+        assert not hasattr(G, gone), gone
+    for s in ("dfdb_group_query_unique", "dfdb_group_query_unique_fetch", "dfdb_group_query_groupreduce", "dfdb_group_query_groupreduce_fetch",
+              "dfdb_group_materialize_device", "dfdb_group_shard_string_bytes"):
+        assert s in dfdb.SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "dfdb.h")).read()
+    assert "first appearance = lowest rank, then" in hdr and "fault key" in hdr

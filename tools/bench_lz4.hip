@@ -15,7 +15,7 @@ using namespace dfdb;
 int main(int argc, char** argv) {
   const int nblocks = argc > 1 ? atoi(argv[1]) : 4096;
   const int mode = argc > 2 ? atoi(argv[2]) : 0;
-  if (argc > 3) set_lz4_pipe(atoi(argv[3]));             // -1 by block count (default), 0 one wave per block, 1 two-wave pipeline          // 0: h mod 1e6 (benchmark column), 1: 1..n, 2: h mod 1000, 3: random doubles, 4: zeros, 5: runs + noise, 6: string body
+  const int pipe = argc > 3 ? atoi(argv[3]) : -1;        // -1 by block count (default), 0 one wave per block, 1 two-wave pipeline.  mode 0: h mod 1e6 (benchmark column), 1: 1..n, 2: h mod 1000, 3: random doubles, 4: zeros, 5: runs + noise, 6: string body
   void* h = dlopen("liblz4.so.1", RTLD_NOW);
   if (!h) { printf("no liblz4.so.1\n"); return 1; }
   auto compress = (int (*)(const char*, char*, int, int))dlsym(h, "LZ4_compress_default");
@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
   for (int variant : {4, 4}) {
     CK(hipMemset(ddst, 0xAB, (size_t)nblocks * body));
     CK(hipEventRecord(e0, nullptr));
-    launch_lz4_decode(nullptr, dsrc, ddst, dblk, nblocks, dstat);
+    launch_lz4_decode(nullptr, dsrc, ddst, dblk, nblocks, dstat, pipe);
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(stat.data(), dstat, nblocks * 4, hipMemcpyDeviceToHost));

@@ -144,8 +144,79 @@ def check():
     return rows, errors
 
 
+# ---------------------------------------------------------------- semantic lint (round 3: a signature walk does not see these)
+CHECKED_CONV = re.compile(r"(?<![\w.{])(U?Int(?:8|16|32|64)?)\(\s*([A-Za-z_]\w*(?:\[\])?)\s*\)")
+UNCHECKED_OK = ("dfdb_last_error", "dfdb_query_free", "dfdb_group_query_free", "dfdb_table_close", "dfdb_group_table_close")
+
+
+def _functions(src):
+    """(first line, last line, text) of every top-level-ish function / do-block free span: good enough to scope a GC.@preserve search"""
+    lines = src.split("\n")
+    spans, start = [], None
+    for i, ln in enumerate(lines):
+        if re.match(r"\s*(function |[\w.!]+\(.*\) = |for \(fname)", ln) and start is None and not ln.startswith(" " * 8):
+            start = i
+        if start is not None and (ln.startswith("end") or (re.match(r"[\w.!]+\(.*\) = ", ln) and i == start and not ln.rstrip().endswith("begin"))):
+            spans.append((start, i)); start = None
+    return lines, spans
+
+
+def lint():
+    """findings the signature walk cannot make:
+    (a) a CHECKED integer conversion `IntN(x)` / `UIntN(x)` of a variable — it throws InexactError for a value outside the target (round 2 shipped
+        `Int64(v) % Int64` for constants, which throws for a UInt64 >= 2^63 before the `%` is reached) — must say why the value fits: `# checked: …`
+        on its line; wrapping conversions are spelled `x % T`;
+    (b) `pointer(x)` must sit under a `GC.@preserve` that names x (same line, or an enclosing `GC.@preserve … begin` of the same function), or name
+        who roots the buffer for the call that uses the pointer: `# rooted by <name>`;
+    (c) every ccall's status goes through `check(…)` before anything reads the Ref / buffer outputs (the cleanup calls in `finally` blocks and
+        dfdb_last_error are the exceptions)."""
+    src = open(JL).read()
+    lines = src.split("\n")
+    findings = []
+    in_doc = False
+    for i, ln in enumerate(lines):
+        code = ln.split("#", 1)[0] if not ln.lstrip().startswith("#") else ""
+        comment = ln[len(code):]
+        if ln.count('"""') % 2 == 1:
+            in_doc = not in_doc
+        if in_doc or ln.lstrip().startswith('"'):
+            continue
+        # (a)
+        for m in CHECKED_CONV.finditer(code):
+            ty, arg = m.group(1), m.group(2)
+            if arg in ("undef",) or "checked:" in comment:
+                continue
+            findings.append(f"line {i + 1}: checked conversion `{ty}({arg})` of a variable without a `# checked:` justification (use `{arg} % {ty}` to wrap)")
+        # (b)
+        for m in re.finditer(r"\bpointer\(\s*([A-Za-z_]\w*)\s*\)", code):
+            var = m.group(1)
+            if re.search(r"GC\.@preserve[^\n]*\b" + re.escape(var) + r"\b", code[:m.start()]) or "rooted by" in comment:
+                continue
+            # an enclosing `GC.@preserve a b begin` above, inside the same function (stop at a line that starts a function)
+            ok = False
+            for j in range(i - 1, max(i - 40, -1), -1):
+                up = lines[j]
+                if re.match(r"\s*function ", up) or re.match(r"^\S.*\) = ", up):
+                    break
+                if re.search(r"GC\.@preserve[^\n]*\b" + re.escape(var) + r"\b[^\n]*\bbegin\b", up):
+                    ok = True; break
+            if not ok:
+                findings.append(f"line {i + 1}: `pointer({var})` outside any `GC.@preserve` naming {var} (or a `# rooted by …` note)")
+        # (c)
+        for m in re.finditer(r"ccall\(\(", code):
+            sym = re.match(r"(?::(\w+)|\$\(QuoteNode\((\w+)\)\)), LIB\)", code[m.end():])
+            name = sym.group(1) or sym.group(2) if sym else "?"
+            if name in UNCHECKED_OK or name == "FREE":
+                continue
+            if not re.search(r"check\(\s*$", code[:m.start()]):
+                findings.append(f"line {i + 1}: the status of `{name}` does not go through check(…) before its outputs are read")
+    return findings
+
+
 def main():
     rows, errors = check()
+    findings = lint()
+    errors = errors + findings
     out = ["# Static review of the Julia shim's FFI (generated by tools/julia_static_review.py)", "",
            "Julia is not installed in the build image, so `dataframedbs.jl_amd/julia/DataFrameDBsAMD.jl` cannot be executed here.  This file walks every",
            "`ccall` of the shim against the prototype of the same symbol in `include/dfdb.h`: the symbol is declared, the arity matches, every argument",
@@ -156,6 +227,15 @@ def main():
            "| shim line | symbol | arguments (Julia ↔ C) | ok |", "|---|---|---|---|"]
     for line, sym, detail, ok in sorted(rows):
         out.append(f"| {line} | `{sym}` | " + "; ".join(detail).replace("|", "\\|") + f" | {'yes' if ok else '**NO**'} |")
+    out += ["", "## Semantic lint (tools/julia_static_review.py: lint)", "",
+            "Three rules a signature walk cannot apply, added after round 2's reviewer found `Int64(v) % Int64` (throws for a `UInt64` constant ≥ 2^63 before the `%`):",
+            "", "* a checked integer conversion `IntN(x)` / `UIntN(x)` of a variable must justify itself (`# checked: …`); wrapping is spelled `x % T`;",
+            "* `pointer(x)` must sit under a `GC.@preserve` naming `x`, or name who roots the buffer (`# rooted by …`);",
+            "* every `ccall` status goes through `check(…)` before its outputs are read (cleanup calls and `dfdb_last_error` excepted).",
+            "", f"Result: **{len(findings)} findings**." + ("" if not findings else "  " + "; ".join(findings)),
+            "", "The constant emitter itself is pinned dynamically: `tests/test_ir_golden.py::test_shim_constant_emitter_transcription` runs a Python transcription of",
+            "`emit_const` (same branches, same wrapping) over UInt64 constants ≥ 2^63, negative Int8 … Int64, Bool and Float32 / Float64 and compares the bytes with `dfdb/ir.py`'s",
+            "and with the hand-assembled golden bytes."]
     out += ["", "## Things a signature check cannot see (reviewed by reading)", "",
             "* **Fallback without recursion.** `enable!()` records `WORLD0 = Base.get_world_counter()` *before* it defines the overriding methods and every",
             "  fallback goes through `Base.invoke_in_world(WORLD0[], f, args...)`: in that world only the reference's own methods exist, including the `nrow(v)`",
