@@ -15,6 +15,17 @@ ranks come from the environment; started plainly with --gpus N > 1 (WORLD_SIZE u
 BEFORE anything touches a GPU (fresh child processes, never a re-exec) and fails if fewer than N complete.
 `--exchange lib` takes the per-step all-reduce through the library's own RCCL communicator (dfdb_group_create_rank /
 dfdb_group_count, include/dfdb.h) instead of torch.distributed's.
+
+Beside `value` (config 2, never anything else) the same JSON line carries, as extra keys:
+  configs         BASELINE.json configs 3 / 4 / 5 at their stated per-GPU sizes, at EVERY N (every rank runs them on its own shard; times are the
+                  MAX over ranks): "3" (a, b, x: conjunctive predicate + projection [b, x]), "4" (String equality + materialize, flat), "4_dictionary"
+                  (the same with K9's 16-bit codes beside the column), "5_shard" (the mixed Int64 + Float64 + FlatStrings scan, count() + sum(x) in ONE
+                  exchange through the library's own group path: dfdb_group_* with its RCCL communicator), "5_shard_dictionary", "5_shard_materialize"
+                  ([a, x] left sharded on the devices: dfdb_group_materialize_device).  Each: rows, selected, ms_per_step, per-kernel avg_ms,
+                  algorithmic_GB, rows_per_s (whole job) and roofline {achieved, peak, frac} in algorithmic bytes per GPU.
+  default_config  config 2 again with the opt-in bitmap placement calibration OFF (what a caller gets who sets no option)
+  decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate)
+  cpu_baseline    N = 1: the oracle on the host cores
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,7 +41,14 @@ for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
 
 SEED = 0x9E3779B97F4A7C15
 THRESHOLD = 899_999          # x > c over h mod 1e6  ->  10 % selectivity
-HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable); the run reads it from dfdb_ctx_device_info
+KERNELS = ["scan_cmp", "scan_terms", "str_match", "dict_scan", "interp_predicate", "scan_counts", "compact_indices", "compact_captured", "gather",
+           "str_gather_sizes", "str_gather_bytes", "str_compact_captured", "dict_expand_sizes", "dict_expand_bytes", "fill_const_strings",
+           "reduce", "reduce_partials", "range_stage"]
+
+
+def seed_of(k):              # column k of a table uses seed * (k + 1)
+    return (SEED * (k + 1)) & 0xFFFFFFFFFFFFFFFF
 
 
 def cpu_baseline(rows: int, repeats: int):
@@ -82,28 +100,42 @@ def cpu_baseline(rows: int, repeats: int):
 def launch_ranks(n: int) -> int:
     """WORLD_SIZE unset and --gpus n > 1: be the launcher.  n fresh child processes of this script, one rank each, with the
     environment torch.distributed.run would give them; this parent never imports torch or touches a GPU.  Rank 0's stdout (the
-    JSON line) passes through.  Non-zero exit if any rank fails; the others are then stopped by PID."""
+    JSON line) passes through.  Non-zero exit if any rank fails; the others are then stopped by PID.  The rendezvous port is found by
+    bind-and-close, which another process can win before rank 0 binds it: a launch that dies within 60 s is retried on a fresh port."""
     import socket
     import subprocess
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    pending = set(range(n))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
-                for k in pending:
-                    procs[k].terminate()
-        time.sleep(0.05)
+    import tempfile
+    rc = 1
+    for attempt in range(3):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        t_start = time.time()
+        errf = tempfile.TemporaryFile()                   # rank 0's stderr: forwarded below, and read for the one failure that is worth a retry
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL,
+                                          stderr=errf if r == 0 else None))
+        rc = 0
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for k in pending:
+                        procs[k].terminate()
+            time.sleep(0.05)
+        errf.seek(0)
+        err0 = errf.read().decode(errors="replace")
+        errf.close()
+        sys.stderr.write(err0)
+        if rc == 0 or not (("EADDRINUSE" in err0 or "address already in use" in err0.lower()) and time.time() - t_start < 60):
+            return rc
+        print(f"bench.py: port {port} was taken before rank 0 bound it; retrying ({attempt + 1}/3)", file=sys.stderr)
     return rc
 
 
@@ -172,6 +204,268 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
     return res
 
 
+
+# ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 (extra keys, never part of `value`)
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; this script's stdout is ONE JSON line.  File descriptor 1 points at
+    stderr while a communicator is being made (the banner is written by C code: sys.stdout redirection would not catch it)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+
+
+class Legs:
+    """shared plumbing of the config legs: every rank runs the same leg on its own shard; a leg's time is the MAX over ranks of the wall time of
+    `steps` back-to-back steps (barrier + device sync on both sides, like the headline); per-kernel times are rank 0's HIP-event averages"""
+
+    def __init__(self, torch, dist, dev, ctx, world, rank, backend, steps, peak):
+        self.torch, self.dist, self.dev, self.ctx, self.world, self.rank, self.backend, self.steps, self.peak = torch, dist, dev, ctx, world, rank, backend, steps, peak
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, sec):
+        if self.world == 1:
+            return sec
+        t = self.torch.tensor([sec], dtype=self.torch.float64, device=self.dev)
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        else:
+            h = t.cpu(); self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX); t.copy_(h)
+        return float(t.item())
+
+    def timed(self, step, ctx=None):
+        ctx = ctx or self.ctx
+        step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(self.steps):
+            step()
+        self.barrier()
+        sec = self.max_over_ranks((time.perf_counter() - t0) / self.steps)
+        ctx.profile(True)                                 # a second, profiled pass for the per-kernel averages (event pairs on the launch stream)
+        for _ in range(2):
+            step()
+        self.torch.cuda.synchronize()
+        ks = {}
+        for k in KERNELS:
+            n, ms = ctx.profile_get(k)
+            if n:
+                ks[k] = round(ms / n, 4)
+        ctx.profile(False)
+        return sec, ks
+
+    def record(self, rows, selected, sec, ks, bytes_per_gpu, what, **extra):
+        gbps = bytes_per_gpu / sec / 1e9
+        r = {"what": what, "rows_per_gpu": rows, "selected_per_gpu": selected, "ms_per_step": sec * 1e3, "steps": self.steps, "kernels_avg_ms": ks,
+             "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world / sec,
+             "roofline": {"bound": "hbm", "achieved": gbps, "peak": self.peak, "unit": "GB/s", "frac": gbps / self.peak,
+                          "what": "algorithmic bytes of the whole job per GPU (SURVEY.md section 8d) / step time"}}
+        r.update(extra)
+        return r
+
+
+def config3_leg(L, dfdb, rows, rank):
+    """config 3: 3-column Int64 + Float64 table, (a > c1) & (x < c2) at 10 %, projection [b, x] materialised into device buffers
+    (docs/src/index.md:503-517: filter + projection; materialization.jl:27-40)"""
+    import ctypes as C
+    from dfdb import _native as N
+    torch = L.torch
+    t = dfdb.DFTable.new(block_size=65536, ctx=L.ctx)
+    for k, (name, gen) in enumerate((("a", dfdb.GEN_I64_MOD1M), ("b", dfdb.GEN_I64_MOD1M), ("x", dfdb.GEN_F64_U2000))):
+        t.add_generated(name, gen, seed_of(k), rows, row_first=rank * rows)
+    q = t[(t.a > 683_771) & (t.x < 632.456), ["b", "x"]]._query()
+    q.hint_materialize(True)                              # what materialize() does: the scan keeps the selected x, b is gathered
+    nsel = q.count()
+    ob = torch.empty(max(nsel, 1), dtype=torch.int64, device=L.dev)
+    ox = torch.empty(max(nsel, 1), dtype=torch.float64, device=L.dev)
+    outs = (N.OutCol * 2)()
+    outs[0].data, outs[0].memkind = ob.data_ptr(), N.MEM_DEVICE
+    outs[1].data, outs[1].memkind = ox.data_ptr(), N.MEM_DEVICE
+    lib = N.load()
+
+    def step():
+        q.execute()
+        N.check(lib.dfdb_materialize(q._h, outs, 2))
+    sec, ks = L.timed(step)
+    res = L.record(rows, nsel, sec, ks, rows * 16 + nsel * 8 + nsel * 16,
+                   "a, b: Int64, x: Float64; (a > 683771) & (x < 632.456) -> materialize [b, x] into device buffers (x captured by the scan, b gathered)")
+    del ob, ox, q
+    t.close()
+    return res
+
+
+def config4_legs(L, dfdb, rows, rank):
+    """config 4: FlatStringsVector + Int64, s == "sony" (10 %), materialize s and a; flat, then with K9's dictionary codes beside the column"""
+    import ctypes as C
+    from dfdb import _native as N
+    torch = L.torch
+    t = dfdb.DFTable.new(block_size=65536, ctx=L.ctx)
+    t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(0), rows, row_first=rank * rows)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(1), rows, row_first=rank * rows)
+    q = t[t.s == "sony", dfdb.ALL]._query()
+    q.hint_materialize(True)
+    nsel = q.count()
+    lib = N.load()
+    nb = C.c_int64()
+    N.check(lib.dfdb_result_string_bytes(q._h, 0, C.byref(nb)))
+    osz = torch.empty(max(nsel, 1), dtype=torch.int32, device=L.dev)
+    oby = torch.empty(nb.value + 64, dtype=torch.uint8, device=L.dev)
+    oa = torch.empty(max(nsel, 1), dtype=torch.int64, device=L.dev)
+    outs = (N.OutCol * 2)()
+    outs[0].data, outs[0].bytes, outs[0].bytes_cap, outs[0].memkind = osz.data_ptr(), oby.data_ptr(), nb.value, N.MEM_DEVICE
+    outs[1].data, outs[1].memkind = oa.data_ptr(), N.MEM_DEVICE
+
+    def step():
+        q.execute()
+        N.check(lib.dfdb_materialize(q._h, outs, 2))
+    lbar = 5.4                                            # mean brand length (SURVEY.md section 8d)
+    byts = rows * (4 + lbar) + nsel * (8 + 8 + 4 + 4)
+    res = {}
+    sec, ks = L.timed(step)
+    res["4"] = L.record(rows, nsel, sec, ks, byts, 's: String (10 brands), a: Int64; s == "sony" -> materialize [s, a] into device buffers; flat FlatStringsVector scan (K5)',
+                        string_bytes_out=nb.value)
+    t0 = time.perf_counter()
+    nd = t.build_dictionary("s")
+    L.torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    sec, ks = L.timed(step)
+    res["4_dictionary"] = L.record(rows, nsel, sec, ks, byts, "the same query with 16-bit dictionary codes beside s (dfdb_table_build_dictionary): the predicate is a bit-table lookup; "
+                                   "algorithmic bytes still count the FLAT column, so the fraction can exceed what HBM delivers", dictionary_entries=nd, dictionary_build_s=build_s)
+    del osz, oby, oa, q
+    t.close()
+    return res
+
+
+def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
+    """config 5's per-GPU shard: mixed-type table (a Int64, x Float64, s String), conjunctive predicate over all three, count() + sum(x) — through the
+    library's own group path (dfdb_group_*): every rank scans its block range and ONE exchange carries {sum, count} (docs/src/index.md:503-517,
+    view.jl:192-206).  With torch.distributed over gloo (functional runs on a 1-GPU box) RCCL cannot connect ranks that share a device, so the
+    per-rank building blocks + a gloo all-reduce stand in and the record says so."""
+    import ctypes as C
+    from dfdb import _native as N
+    torch, dist, world = L.torch, L.dist, L.world
+    res = {}
+    total = rows * world
+    bytes_row = 8 + 8 + 4 + 5.4                           # SURVEY.md section 8d: a, x, sizes + bytes of s
+    own = None
+    if host_shards > 1:                                   # functional: ONE process, host-exchange group of `host_shards` shards on this device
+        own = grp = G.Group.create([local] * host_shards, N.EXCHANGE_HOST)
+        total = rows
+    elif world == 1 or L.backend == "nccl":
+        if grp is None:
+            uid = None
+            if world > 1:
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("dfdb_group_uid_c5", G.Group.unique_id())
+                uid = bytes(store.get("dfdb_group_uid_c5"))
+            with stdout_to_stderr():
+                own = grp = G.Group.create_rank(local, uid, rank, world, stream=stream)
+    if grp is not None:
+        gctx = grp.ctx(0)
+        gt = G.GroupTable.new(grp)
+        gt.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(0), total)
+        gt.add_generated("x", dfdb.GEN_F64_U2000, seed_of(1), total)
+        gt.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(2), total)
+        v = gt.view()
+        v = v[(v.a > 683_771) & (v.x < 632.456) & (v.s != "sony"), dfdb.ALL]
+        gq = G.GroupQuery(gt, v[dfdb.ALL, ["x"]])
+        out = {}
+
+        def step():
+            gq.reset()
+            out["sum"] = gq.aggregate(N.AGG_SUM, 0)       # the scan adds x up while it holds it; ONE exchange of {sum, count}
+            out["count"] = gq.count()                     # the same exchange's count: no second scan, no second collective
+        exch = ("libdfdb_hip's RCCL communicator (dfdb_group_aggregate: one grouped all-reduce of {sum, count} + the fault key)" if grp.exchange == N.EXCHANGE_RCCL
+                else f"host exchange between {host_shards} shards of one process (functional)")
+        sec, ks = L.timed(step, gctx)
+        mine = gq.shard_counts()[grp.first_rank] if host_shards <= 1 else out["count"]
+        per_gpu_rows = rows if host_shards <= 1 else total
+        res["5_shard"] = L.record(per_gpu_rows, mine, sec, ks, per_gpu_rows * bytes_row,
+                                  "a: Int64, x: Float64, s: String; (a > 683771) & (x < 632.456) & (s != \"sony\") -> count() + sum(x), flat String scan", exchange=exch,
+                                  global_count=out["count"], global_sum_x=out["sum"], total_rows=total)
+        # [a, x] of the selected rows left sharded on the devices (dfdb_group_materialize_device): no PCIe, no xGMI
+        gm = G.GroupQuery(gt, v[dfdb.ALL, ["a", "x"]])
+        N.check(N.load().dfdb_group_query_hint_materialize(gm._h, 1))
+        cnts = gm.shard_counts()[grp.first_rank:grp.first_rank + grp.nlocal]
+        bufs = [[torch.empty(max(c, 1), dtype=torch.int64, device=L.dev), torch.empty(max(c, 1), dtype=torch.float64, device=L.dev)] for c in cnts]
+        mouts = (N.OutCol * (2 * grp.nlocal))()
+        for l in range(grp.nlocal):
+            for p_ in range(2):
+                mouts[2 * l + p_].data, mouts[2 * l + p_].memkind = bufs[l][p_].data_ptr(), N.MEM_DEVICE
+
+        def step_m():
+            gm.reset()
+            N.check(N.load().dfdb_group_materialize_device(gm._h, mouts, 2))
+        sec, ks = L.timed(step_m, gctx)
+        nsel_m = sum(cnts)
+        res["5_shard_materialize"] = L.record(per_gpu_rows, nsel_m, sec, ks, per_gpu_rows * bytes_row + nsel_m * 32,
+                                              "the same selection, materialize [a, x] into per-shard DEVICE buffers (dfdb_group_materialize_device): results stay sharded", exchange=exch)
+        del bufs
+        gm.close()
+        # the same with K9's codes beside s on every shard
+        t0 = time.perf_counter()
+        nd = [gt.shard(l).build_dictionary("s") for l in range(grp.nlocal)]
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        sec, ks = L.timed(step, gctx)
+        res["5_shard_dictionary"] = L.record(per_gpu_rows, mine, sec, ks, per_gpu_rows * bytes_row,
+                                             "the same with 16-bit dictionary codes beside s: s != \"sony\" scans 2 B/row (algorithmic bytes still count the flat column)", exchange=exch,
+                                             global_count=out["count"], global_sum_x=out["sum"], dictionary_entries=nd[0], dictionary_build_s=build_s)
+        gq.close(); gt.close()
+        if own is not None:
+            own.close()
+        return res
+    # gloo functional path: per-rank tables (dfdb_table_set_row_base) + torch.distributed all-reduce of {count, sum}
+    t = dfdb.DFTable.new(block_size=65536, ctx=L.ctx)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(0), rows, row_first=rank * rows)
+    t.add_generated("x", dfdb.GEN_F64_U2000, seed_of(1), rows, row_first=rank * rows)
+    t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(2), rows, row_first=rank * rows)
+    t.set_row_base(rank * rows)
+    cx = t[(t.a > 683_771) & (t.x < 632.456) & (t.s != "sony"), dfdb.ALL][dfdb.ALL, "x"]
+    q = cx.view._query()
+    acc = torch.zeros(2, dtype=torch.float64)
+
+    def step():
+        q.reset()
+        sx = cx.sum()
+        acc[0] = float(q.count()); acc[1] = sx
+        dist.all_reduce(acc)
+    sec, ks = L.timed(step)
+    res["5_shard"] = L.record(rows, q.count(), sec, ks, rows * bytes_row,
+                              "a: Int64, x: Float64, s: String; (a > 683771) & (x < 632.456) & (s != \"sony\") -> count() + sum(x), flat String scan",
+                              exchange=f"torch.distributed {L.backend} all-reduce of {{count, sum}} (functional run: RCCL cannot connect ranks that share a device)",
+                              global_count=int(acc[0].item()), global_sum_x=float(acc[1].item()), total_rows=total)
+    t.close()
+    return res
+
+
+def run_config_legs(L, dfdb, G, args, rank, local, stream, grp):
+    out = {}
+    sc = args.config_scale
+    legs = [("3", lambda: {"3": config3_leg(L, dfdb, int(1_000_000_000 * sc), rank)}),
+            ("4", lambda: config4_legs(L, dfdb, int(500_000_000 * sc), rank)),
+            ("5_shard", lambda: config5_legs(L, dfdb, G, int(1_250_000_000 * sc), rank, local, stream, grp, args.config5_host_shards))]
+    for name, fn in legs:
+        try:
+            out.update(fn())
+        except Exception as e:      # extra figures: the headline line survives a failing leg, and says which one failed (every rank fails alike or the launcher stops)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            if L.world > 1:
+                raise
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +483,11 @@ def main():
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
                     "or the library's own RCCL communicator behind the C ABI (dfdb_group_create_rank + dfdb_group_count)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 legs (extra keys)")
+    ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the config legs (functional runs; 1.0 = BASELINE.json's sizes)")
+    ap.add_argument("--config-steps", type=int, default=None, help="timed steps per config leg (default: min(steps, 10), at least 3)")
+    ap.add_argument("--config5-host-shards", type=int, default=0, help="N = 1, functional: run the config-5 leg through a ONE-process host-exchange group of this many "
+                    "shards on the device (every path of csrc/group.cpp but the RCCL calls)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -239,7 +538,8 @@ def main():
             if rank == 0:
                 store.set("dfdb_group_uid", G.Group.unique_id())
             uid = bytes(store.get("dfdb_group_uid"))
-        grp = G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream)
+        with stdout_to_stderr():
+            grp = G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream)
         ctx = grp.ctx(0)
         ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
         nblocks_per = -(-(-(-(rows * world) // 65536)) // world)        # ceil(ceil(total / 65536) / world): the library's block-range rule
@@ -315,27 +615,64 @@ def main():
         if n:
             kernels[k] = dict(launches=n, avg_ms=ms / n)
     ctx.profile(False)
+    peak = float(info.get("peak_hbm_gbps") or HBM_PEAK_GBPS)      # dfdb_ctx_device_info: 8000 on MI355X
+    scan_row_bytes = 8 + 1 / 8 + 4 / 1024                          # ONE k_scan_cmp launch: 8 B/row column + 1/8 B/row bitmap + 4 B per 1024-row tile count
 
+    # ---- the same step with the library's DEFAULT options (placement calibration off): what a caller gets who sets nothing
+    default_cfg = None
+    if not lib and not args.no_placement:
+        ctx.set_option("placement_calibrate", 0)
+        q.close() if hasattr(q, "close") else None
+        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()  # a fresh query: its own bitmap, not the calibrated one the first query borrowed
+        for _ in range(max(args.warmup, 1)):
+            step()
+        ctx.profile(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            e2 = torch.tensor([el2], dtype=torch.float64, device=dev)
+            all_reduce(e2, dist.ReduceOp.MAX)
+            el2 = float(e2.item())
+        n2, ms2 = ctx.profile_get("scan_cmp")
+        n3, ms3 = ctx.profile_get("compact_indices")
+        ctx.profile(False)
+        sms = ms2 / n2 if n2 else None
+        default_cfg = {"what": "the same step with ctx option placement_calibrate = 0 (the library's default): a fresh query scanning into its own bitmap",
+                       "value": total_rows * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "scan_cmp_avg_ms": sms, "compact_indices_avg_ms": ms3 / n3 if n3 else None,
+                       "roofline_frac": (local_rows * scan_row_bytes / (sms * 1e-3) / 1e9 / peak) if sms else None,
+                       "job_hbm_gbps": total_rows * (8 + 8 * nsel / local_rows) / (el2 / args.steps) / 1e9}
+
+    res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rows * args.steps / elapsed
         sigma = nsel / local_rows
-        # ONE k_scan_cmp launch: 8 B/row column read + 1/8 B/row bitmap + 4 B per 1024-row tile count
-        kname, pmc_name = "k_scan_cmp<int64,GT>", "r2_pmc_scan_cmp.json"
-        scan_bytes = local_rows * (8 + 1 / 8 + 4 / 1024)
+        kname = "k_scan_cmp<int64,GT>"
+        scan_bytes = local_rows * scan_row_bytes
         scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
         job_bytes = total_rows * (8 + 8 * sigma)       # 8 + 8*sigma B/row for the whole job
         # HBM traffic of that kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command; FETCH_SIZE doubled per the gfx950 correction, calibrated on a known-byte read): profiles/
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.exists(pmc):
+        for pmc_name in ("r3_pmc_scan_cmp.json", "r2_pmc_scan_cmp.json"):
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
+            if not os.path.exists(pmc):
+                continue
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("rows"):
                 traffic = pj["hbm_bytes_per_launch_corrected"] * local_rows / pj["rows"]
                 traffic_src = f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
+                break
         res = {
             "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -349,18 +686,33 @@ def main():
                        "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
                        "device": info["name"], "global_selected": total_sel,
                        "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows, "one_time_seconds": pl_wall / 1e6,
-                                                  "what": "one-time: the scan timed against 9 bitmap allocations, the fastest kept (ctx option placement_calibrate)"}
+                                                  "what": "one-time: the scan timed against 9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in; "
+                                                          "`default_config` is the same step without it)"}
                                                  if pl_n else "off")},
             "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "GB/s",
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }
+        if default_cfg is not None:
+            res["default_config"] = default_cfg
         if world == 1 and not lib and not args.no_decode_leg:
             try:
                 res["decode_scan"] = decode_scan_leg(dfdb, ctx, t, rows, max(3, min(args.steps, 10)), out.data_ptr(), cap, cnt.data_ptr(), torch.cuda.synchronize)
             except Exception as e:      # an extra figure: never fail the bench line for it
                 res["decode_scan"] = {"error": f"{type(e).__name__}: {e}"}
+    # ---- configs 3 / 4 / 5 on every rank (the column of config 2 goes first: the legs bring their own tables)
+    if not args.no_configs:
+        ctx.set_option("placement_calibrate", 0)
+        del out
+        if not lib:
+            t.close()
+        torch.cuda.empty_cache()
+        L = Legs(torch, dist, dev, ctx, world, rank, args.backend, args.config_steps or max(3, min(args.steps, 10)), peak)
+        legs = run_config_legs(L, dfdb, G, args, rank, local, stream_obj.cuda_stream, grp if lib else None)
+        if res is not None:
+            res["configs"] = legs
+    if res is not None:
         if not args.no_cpu and world == 1:      # the CPU baseline is an N=1, rank-0 figure
             res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)
         print(json.dumps(res), flush=True)

@@ -16,6 +16,14 @@ Table the cases run over (5 rows, block_size 2):
   s  :: String           = ["apple", "sony", "", "sonic", "xs"]
   m  :: Union{Int64,Missing} = [1, missing, 3, missing, 0]
   u  :: UInt8            = [0, 1, 127, 128, 255]
+round 3 (the corners engine and oracle could get wrong TOGETHER — they share an author):
+  i8 :: Int8             = [-128, -1, 0, 1, 127]
+  w  :: UInt64           = [0, 1, 2^63, 2^63 + 5, 2^64 - 1]
+  z  :: Float64          = [-0.0, 0.0, NaN, 1.0, -1.0]
+  f  :: Float32          = [0.1f0, -2.5f0, 16777216f0, NaN32, 3f0]
+  b  :: Bool             = [true, false, true, false, true]
+  mb :: Union{Bool,Missing} = [true, missing, false, missing, true]
+  big:: Int64            = [typemin(Int64), -1, 0, 1, typemax(Int64)]
 
     python tests/golden/make_ir_golden.py        (rewrites ir_golden.json next to this file)
 """
@@ -39,6 +47,7 @@ def header_symbols():
 
 S = header_symbols()
 A, X, STR, M, U = 0, 1, 2, 3, 4      # column ordinals
+I8C, W, Z, FF, B, MB, BIG = 5, 6, 7, 8, 9, 10, 11
 
 
 def col(k): return bytes([S["DFIR_COL"]]) + struct.pack("<I", k)
@@ -47,6 +56,7 @@ def cf(v): return bytes([S["DFIR_CONST"], S["DFDB_F64"]]) + struct.pack("<d", v)
 def cb(v): return bytes([S["DFIR_CONST"], S["DFDB_BOOL"]]) + struct.pack("<q", 1 if v else 0)
 def cs(t): return bytes([S["DFIR_CONST_STR"]]) + struct.pack("<I", len(t.encode())) + t.encode()
 def cset(vals, dt="DFDB_I64"): return bytes([S["DFIR_CONST_SET"], S[dt]]) + struct.pack("<I", len(vals)) + b"".join(struct.pack("<q", v) for v in vals)
+def csetf(vals): return bytes([S["DFIR_CONST_SET"], S["DFDB_F64"]]) + struct.pack("<I", len(vals)) + b"".join(struct.pack("<d", v) for v in vals)
 def op(name): return bytes([S["DFIR_" + name]])
 def cast(dt): return bytes([S["DFIR_CAST"], S[dt]])
 
@@ -115,11 +125,90 @@ CASES = [
     ("idiv_by_zero", "a .÷ 0", col(A) + ci(0) + op("IDIV"), "Int64", "DivideError", "ir.div(A, 0)"),
 ]
 
+# ---- round 3: answers typed from Julia's semantics, never from the oracle's output ------------------------------------------------------
+TMIN, TMAX = -(2 ** 63), 2 ** 63 - 1
+INF = "Inf"
+
+
+def f32(v): return struct.unpack("<f", struct.pack("<f", v))[0]          # round to Float32 (IEEE, independent of numpy and of the oracle)
+
+
+F32COL = [f32(0.1), -2.5, 16777216.0, NAN, 3.0]
+CASES += [
+    # typemin: checked division, wrapping negation / abs (Base: div(typemin(T), -1) throws DivideError, rem(typemin, -1) == 0, abs(typemin) == typemin)
+    ("typemin_idiv_minus1_divide_error", "big .÷ -1", col(BIG) + ci(-1) + op("IDIV"), "Int64", "DivideError", "ir.div(Big, -1)"),
+    ("typemin_rem_minus1_is_zero", "big .% -1", col(BIG) + ci(-1) + op("REM"), "Int64", [0, 0, 0, 0, 0], "Big % -1"),
+    ("typemin_mod_minus1_is_zero", "mod.(big, -1)", col(BIG) + ci(-1) + op("MOD"), "Int64", [0, 0, 0, 0, 0], "ir.mod(Big, -1)"),
+    ("abs_typemin_wraps", "abs.(big)", col(BIG) + op("ABS"), "Int64", [TMIN, 1, 0, 1, TMAX], "abs(Big)"),
+    ("neg_typemin_wraps", "-big", col(BIG) + op("NEG"), "Int64", [TMIN, 1, 0, -1, TMIN + 1], "-Big"),
+    ("add_wraps_at_typemax", "big .+ 1", col(BIG) + ci(1) + op("ADD"), "Int64", [TMIN + 1, 0, 1, 2, TMIN], "Big + 1"),
+    ("idiv_truncates_toward_zero", "big .÷ 2", col(BIG) + ci(2) + op("IDIV"), "Int64", [-(2 ** 62), 0, 0, 0, 2 ** 62 - 1], "ir.div(Big, 2)"),
+    ("rem_keeps_the_dividends_sign", "big .% 3", col(BIG) + ci(3) + op("REM"), "Int64", [-2, -1, 0, 1, 1], "Big % 3"),
+    ("mod_keeps_the_divisors_sign", "mod.(big, 3)", col(BIG) + ci(3) + op("MOD"), "Int64", [1, 2, 0, 1, 1], "ir.mod(Big, 3)"),
+    ("int_over_zero_is_inf", "a ./ 0", col(A) + ci(0) + op("DIV"), "Float64", ["-Inf", "-Inf", NAN, INF, INF], "A / 0"),
+    # Int8: arithmetic between Int8s stays Int8 and wraps; with an Int64 literal it widens
+    ("abs_int8_typemin_wraps", "abs.(i8)", col(I8C) + op("ABS"), "Int8", [-128, 1, 0, 1, 127], "abs(I8c)"),
+    ("neg_int8_typemin_wraps", "-i8", col(I8C) + op("NEG"), "Int8", [-128, 1, 0, -1, -127], "-I8c"),
+    ("int8_add_wraps", "i8 .+ Int8(1)", col(I8C) + ci(1, "DFDB_I8") + op("ADD"), "Int8", [-127, 0, 1, 2, -128], "I8c + ir.const(1, ir.I8)"),
+    ("int8_sub_wraps", "i8 .- Int8(1)", col(I8C) + ci(1, "DFDB_I8") + op("SUB"), "Int8", [127, -2, -1, 0, 126], "I8c - ir.const(1, ir.I8)"),
+    ("int8_mul_wraps", "i8 .* Int8(2)", col(I8C) + ci(2, "DFDB_I8") + op("MUL"), "Int8", [0, -2, 0, 2, -2], "I8c * ir.const(2, ir.I8)"),
+    ("int8_widens_with_int64", "i8 .+ 1", col(I8C) + ci(1) + op("ADD"), "Int64", [-127, 0, 1, 2, 128], "I8c + 1"),
+    ("int8_typemin_idiv_minus1_divide_error", "i8 .÷ Int8(-1)", col(I8C) + ci(-1, "DFDB_I8") + op("IDIV"), "Int8", "DivideError", "ir.div(I8c, ir.const(-1, ir.I8))"),
+    # signed zeros and NaN: == ignores the sign of zero, min / max do not, NaN propagates through both
+    ("minus_zero_equals_zero", "z .== 0.0", col(Z) + cf(0.0) + op("EQ"), "Bool", [T, T, F, F, F], "Zf == 0.0"),
+    ("nothing_is_below_minus_zero_but_minus_one", "z .< -0.0", col(Z) + cf(-0.0) + op("LT"), "Bool", [F, F, F, F, T], "Zf < -0.0"),
+    ("min_orders_minus_zero_first", "min.(z, 0.0)", col(Z) + cf(0.0) + op("MIN"), "Float64", [-0.0, 0.0, NAN, 0.0, -1.0], "ir.minimum(Zf, 0.0)"),
+    ("max_orders_plus_zero_last", "max.(z, -0.0)", col(Z) + cf(-0.0) + op("MAX"), "Float64", [-0.0, 0.0, NAN, 1.0, -0.0], "ir.maximum(Zf, -0.0)"),
+    ("min_propagates_nan", "min.(x, 1.0)", col(X) + cf(1.0) + op("MIN"), "Float64", [0.5, -2.0, 1.0, 1.0, NAN], "ir.minimum(Xf, 1.0)"),
+    ("max_propagates_nan", "max.(x, 1.0)", col(X) + cf(1.0) + op("MAX"), "Float64", [1.0, 1.0, 3.0, 1e10, NAN], "ir.maximum(Xf, 1.0)"),
+    ("in_uses_double_equals_nan_is_never_in", "in.(z, Ref([NaN, 1.0]))", col(Z) + csetf([NAN, 1.0]) + op("IN_SET"), "Bool", [F, F, F, T, F], "ir.isin(Zf, [float('nan'), 1.0])"),
+    ("in_minus_zero_is_in_zero", "in.(z, Ref([0.0]))", col(Z) + csetf([0.0]) + op("IN_SET"), "Bool", [T, T, F, F, F], "ir.isin(Zf, [0.0])"),
+    # UInt64: compared with signed integers as the mathematical values; arithmetic with an Int64 literal is UInt64 (promote_type) and wraps
+    ("uint64_above_minus_one", "w .> -1", col(W) + ci(-1) + op("GT"), "Bool", [T, T, T, T, T], "Wc > -1"),
+    ("int64_below_uint64", "a .< w", col(A) + col(W) + op("LT"), "Bool", [T, T, T, T, T], "A < Wc"),
+    ("uint64_le_int64", "w .<= big", col(W) + col(BIG) + op("LE"), "Bool", [F, F, F, F, F], "Wc <= Big"),
+    ("uint64_never_equals_negative", "w .== a", col(W) + col(A) + op("EQ"), "Bool", [F, F, F, F, F], "Wc == A"),
+    ("uint64_above_typemax_int64", "w .> typemax(Int64)", col(W) + ci(TMAX) + op("GT"), "Bool", [F, F, T, T, T], "Wc > %d" % TMAX),
+    ("uint64_const_2p63", "w .== 0x8000000000000000", col(W) + ci(2 ** 63, "DFDB_U64") + op("EQ"), "Bool", [F, F, T, F, F], "Wc == ir.const(2 ** 63, ir.U64)"),
+    ("uint64_plus_int64_is_uint64_and_wraps", "w .+ 1", col(W) + ci(1) + op("ADD"), "UInt64", [1, 2, 2 ** 63 + 1, 2 ** 63 + 6, 0], "Wc + 1"),
+    ("uint64_minus_int64_wraps_below_zero", "w .- 1", col(W) + ci(1) + op("SUB"), "UInt64", [2 ** 64 - 1, 0, 2 ** 63 - 1, 2 ** 63 + 4, 2 ** 64 - 2], "Wc - 1"),
+    ("uint64_idiv", "w .÷ 2", col(W) + ci(2) + op("IDIV"), "UInt64", [0, 0, 2 ** 62, 2 ** 62 + 2, 2 ** 63 - 1], "ir.div(Wc, 2)"),
+    ("uint64_rem", "w .% 10", col(W) + ci(10) + op("REM"), "UInt64", [0, 1, 8, 3, 5], "Wc % 10"),
+    ("uint64_to_float64_rounds_to_nearest_even", "w ./ 2", col(W) + ci(2) + op("DIV"), "Float64", [0.0, 0.5, 2.0 ** 62, 2.0 ** 62, 2.0 ** 63], "Wc / 2"),
+    # Float32: stays Float32 against integers, becomes Float64 against a Float64; comparisons with a Float64 literal are exact (0.1f0 != 0.1)
+    ("float32_plus_int64_is_float32", "f .+ a", col(FF) + col(A) + op("ADD"), "Float32", [f32(f32(0.1) + -7.0), -3.5, 16777216.0, NAN, 13.0], "Ff + A"),
+    ("float32_times_int64_is_float32", "f .* 2", col(FF) + ci(2) + op("MUL"), "Float32", [f32(f32(0.1) * 2.0), -5.0, 33554432.0, NAN, 6.0], "Ff * 2"),
+    ("float32_plus_float64_is_float64", "f .+ 0.5", col(FF) + cf(0.5) + op("ADD"), "Float64", [f32(0.1) + 0.5, -2.0, 16777216.5, NAN, 3.5], "Ff + 0.5"),
+    ("float32_is_not_the_float64_literal", "f .== 0.1", col(FF) + cf(0.1) + op("EQ"), "Bool", [F, F, F, F, F], "Ff == 0.1"),
+    ("float32_vs_float64_exact_order", "f .< 0.1", col(FF) + cf(0.1) + op("LT"), "Bool", [F, T, F, F, F], "Ff < 0.1"),
+    # Bool is a number: true + true == 2 (Int64); -true == -1
+    ("bool_plus_bool_is_int64", "b .+ b", col(B) + col(B) + op("ADD"), "Int64", [2, 0, 2, 0, 2], "Bc + Bc"),
+    ("bool_plus_int64", "b .+ 1", col(B) + ci(1) + op("ADD"), "Int64", [2, 1, 2, 1, 2], "Bc + 1"),
+    ("bool_times_float64", "b .* 2.5", col(B) + cf(2.5) + op("MUL"), "Float64", [2.5, 0.0, 2.5, 0.0, 2.5], "Bc * 2.5"),
+    ("neg_bool_is_int64", "-b", col(B) + op("NEG"), "Int64", [-1, 0, -1, 0, -1], "-Bc"),
+    # three-valued logic (Base: missing & false == false, missing | true == true, xor(missing, x) and !missing are missing)
+    ("xor_missing_is_missing", "xor.(mb, true)", col(MB) + cb(True) + op("XOR"), "Missing(Bool)", [F, MISS, T, MISS, F], "Mb ^ True"),
+    ("not_missing_is_missing", ".!mb", col(MB) + op("NOT"), "Missing(Bool)", [F, MISS, T, MISS, F], "~Mb"),
+    ("missing_and_false_is_false", "mb .& false", col(MB) + cb(False) + op("AND"), "Missing(Bool)", [F, F, F, F, F], "Mb & False"),
+    ("missing_or_true_is_true", "mb .| true", col(MB) + cb(True) + op("OR"), "Missing(Bool)", [T, T, T, T, T], "Mb | True"),
+    ("missing_or_false_is_missing", "mb .| false", col(MB) + cb(False) + op("OR"), "Missing(Bool)", [T, MISS, F, MISS, T], "Mb | False"),
+    ("coalesce_bool", "coalesce.(mb, false)", col(MB) + cb(False) + op("COALESCE"), "Bool", [T, F, F, F, T], "ir.coalesce(Mb, False)"),
+    ("coalesce_chain", "coalesce.(m, m .+ 1, 9)", col(M) + col(M) + ci(1) + op("ADD") + op("COALESCE") + ci(9) + op("COALESCE"), "Int64", [1, 9, 3, 9, 0],
+     "ir.coalesce(ir.coalesce(Mi, Mi + 1), 9)"),
+    ("ismissing_of_an_expression", "ismissing.(m .* 2)", col(M) + ci(2) + op("MUL") + op("ISMISSING"), "Bool", [F, T, F, T, F], "ir.ismissing(Mi * 2)"),
+    ("comparison_with_missing_is_missing", "m .== 1", col(M) + ci(1) + op("EQ"), "Missing(Bool)", [T, MISS, F, MISS, F], "Mi == 1"),
+    ("three_valued_and", "(m .== 1) .& (a .> 0)", col(M) + ci(1) + op("EQ") + col(A) + ci(0) + op("GT") + op("AND"), "Missing(Bool)", [F, F, F, MISS, F], "(Mi == 1) & (A > 0)"),
+    ("three_valued_or", "(m .== 1) .| (a .> 0)", col(M) + ci(1) + op("EQ") + col(A) + ci(0) + op("GT") + op("OR"), "Missing(Bool)", [T, MISS, F, T, T], "(Mi == 1) | (A > 0)"),
+]
+
 
 def main():
     out = {"comment": "hand-assembled from include/dfdb_ir.h by tests/golden/make_ir_golden.py; expected = Julia semantics",
            "table": {"a": [-7, -1, 0, 3, 10], "x": [0.5, -2.0, 3.0, 1e10, "NaN"], "s": ["apple", "sony", "", "sonic", "xs"],
-                     "m": [1, None, 3, None, 0], "u": [0, 1, 127, 128, 255], "block_size": 2},
+                     "m": [1, None, 3, None, 0], "u": [0, 1, 127, 128, 255],
+                     "i8": [-128, -1, 0, 1, 127], "w": [0, 1, 2 ** 63, 2 ** 63 + 5, 2 ** 64 - 1], "z": [-0.0, 0.0, "NaN", 1.0, -1.0],
+                     "f": ["NaN" if v != v else v for v in F32COL], "b": [True, False, True, False, True], "mb": [True, None, False, None, True],
+                     "big": [TMIN, -1, 0, 1, TMAX], "block_size": 2},
            "opcodes": {k: v for k, v in sorted(S.items()) if k.startswith("DFIR_")},
            "dtypes": {k: v for k, v in sorted(S.items()) if k.startswith("DFDB_")},
            "cases": []}

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import Pair, apply_stages, assert_same
+from helpers import Pair, apply_stages, apply_stages_both, assert_same
 
 pytestmark = pytest.mark.gpu
 N = int(os.environ.get("DFDB_FUZZ_ROWS", "12345"))          # (DFDB_FUZZ_ROWS=300007 DFDB_FUZZ_BLOCK=65536: the same queues over a bigger table)
@@ -155,12 +155,7 @@ def test_random_queue_equals_the_oracle(pair, dfdb_mod, seed):
     from dfdb import ir
     g = Gen(ir, seed, risky=seed % 4 == 3)
     stages, proj = g.stages(), g.proj()
-    try:
-        ov, dv = apply_stages(pair, stages, proj=proj)
-    except Exception as e:          # noqa: BLE001
-        # refused while the queue is built (a range beyond the statically known size of the stage before it, a non-Bool predicate): helpers.apply_stages
-        # builds the oracle's view first, so an error raised by the engine's mirror alone would show up as a different message here
-        pytest.skip("refused at build time: %s: %s" % (type(e).__name__, str(e)[:90]))
+    ov, dv = apply_stages_both(pair, stages, proj=proj)      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     want = outcome(lambda: ov.nrow())
     got = outcome(lambda: dfdb_mod.nrow(dv))
     assert want[0] == got[0], f"oracle {want}, engine {got} for {stages} / {proj}"
@@ -228,10 +223,7 @@ def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     g = GenNoMissing(ir, 10_000 + seed, risky=False)
     stages = g.stages()
     proj = [("a", ir.col(0)), ("x", ir.col(7)), ("k", ir.col(3) * 2 - ir.col(4))]
-    try:
-        ov, dv = apply_stages(pair, stages, proj=proj)
-    except Exception as e:          # noqa: BLE001
-        pytest.skip("refused at build time: %s" % type(e).__name__)
+    ov, dv = apply_stages_both(pair, stages, proj=proj)      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     want_idx = ov.select_indices()
     want = ov.materialize()
     assert np.array_equal(dv._query().indices(), want_idx)
@@ -258,10 +250,7 @@ def test_random_risky_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     pair, lazy, gt = filed
     g = GenNoMissing(ir, 20_000 + seed, risky=True)
     stages = g.stages()
-    try:
-        ov, dv = apply_stages(pair, stages, proj=[("a", ir.col(0))])
-    except Exception as e:          # noqa: BLE001
-        pytest.skip("refused at build time: %s" % type(e).__name__)
+    ov, dv = apply_stages_both(pair, stages, proj=[("a", ir.col(0))])      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     want = outcome(lambda: ov.nrow())
     assert outcome(lambda: dfdb_mod.nrow(dv)) == want, stages
     sv = dfdb_mod.DFView(lazy, dv.projection, dv.selection)
@@ -280,10 +269,7 @@ def test_random_aggregates(pair, dfdb_mod, seed):
     stages = g.stages()
     ci = int(g.pick([0, 1, 2, 3, 4, 5, 6, 7, 8]))
     name = pair.names[ci]
-    try:
-        ov, dv = apply_stages(pair, stages)
-    except Exception as e:          # noqa: BLE001
-        pytest.skip("refused at build time: %s" % type(e).__name__)
+    ov, dv = apply_stages_both(pair, stages)      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     idx = ov.select_indices() - 1
     host = np.asarray(pair.d.ctx and pair_columns(pair)[name])[idx]
     col = dv[dfdb_mod.ALL, name]
@@ -335,10 +321,7 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
     key = g.pick(["a", "i8", "s", "m", "c"])
     val = g.pick([v for v in ["a", "b", "i32", "u16", "x", "c"] if v != key])      # (a projection cannot name a column twice)
     stat = g.pick(["count", "sum", "min", "max", "mean"])
-    try:
-        ov, dv = apply_stages(pair, stages)
-    except Exception as e:          # noqa: BLE001
-        pytest.skip("refused at build time: %s" % type(e).__name__)
+    ov, dv = apply_stages_both(pair, stages)      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     idx = ov.select_indices() - 1
     cols = full_columns(pair)
     keys = cols[key][idx] if not isinstance(cols[key], list) else [cols[key][i] for i in idx]

@@ -274,7 +274,7 @@ def test_bench_self_launches_ranks(ctx):
     n_gpus = 2; the aggregate count is the sum of both shards"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-on-device0", "--backend", "gloo", "--rows", "20000000",
-                        "--steps", "3", "--warmup", "1", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--config-scale", "0.004"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()
@@ -282,6 +282,46 @@ def test_bench_self_launches_ranks(ctx):
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
     assert r["config"]["global_selected"] > 2 * 0.09 * 20_000_000
     assert r["value"] > 0
+    # round 3: the same line carries configs 3 / 4 / 5 at every N (here 0.4 % of their sizes, both ranks on device 0, the exchange over gloo)
+    cf = r["configs"]
+    for k in ("3", "4", "4_dictionary", "5_shard"):
+        assert "error" not in cf[k], cf[k]
+        assert cf[k]["ms_per_step"] > 0 and cf[k]["rows_per_s"] > 0 and 0 < cf[k]["roofline"]["frac"] < 2 and cf[k]["kernels_avg_ms"], (k, cf[k])
+    n5 = cf["5_shard"]["rows_per_gpu"]
+    assert cf["5_shard"]["total_rows"] == 2 * n5 and 0.05 * 2 * n5 < cf["5_shard"]["global_count"] < 0.12 * 2 * n5
+    assert r["default_config"]["value"] > 0 and r["default_config"]["scan_cmp_avg_ms"] > 0
+
+
+def test_bench_config_legs_through_the_library_group(oracle, ctx):
+    """N = 1: the config legs at 0.4 % of BASELINE.json's sizes.  Config 5 runs twice through the library's own group path — a one-rank RCCL group
+    (the RCCL all-reduce of {sum, count} issued for real) and, with --config5-host-shards 3, a one-process host-exchange group of three shards — and
+    both must report the count and the sum of x the ORACLE gets for the same rows (sum within the Float64 tolerance of DESIGN.md section 5)."""
+    from dfdb import ir
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    outs = []
+    for extra in ([], ["--config5-host-shards", "3"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "5000000", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-decode-leg",
+                            "--config-scale", "0.004"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+        outs.append(json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0]))
+    n = int(1_250_000_000 * 0.004)
+    S = 0x9E3779B97F4A7C15
+    sd = lambda k: (S * (k + 1)) & 0xFFFFFFFFFFFFFFFF
+    a, x = oracle.gen_i64(sd(0), 0, n), oracle.gen_f64(sd(1), 0, n)
+    sz, by = oracle.gen_str(sd(2), 0, n)
+    off = np.concatenate([[0], np.cumsum(sz)])
+    sony = np.array([sz[i] == 4 and bytes(by[off[i]:off[i] + 4]) == b"sony" for i in range(n)])
+    sel = (a > 683_771) & (x < 632.456) & ~sony
+    want_n, want_s = int(sel.sum()), float(x[sel].sum())
+    for r, label in zip(outs, ("rccl", "host")):
+        cf = r["configs"]
+        for k in ("5_shard", "5_shard_dictionary", "5_shard_materialize", "3", "4", "4_dictionary"):
+            assert "error" not in cf[k], (label, k, cf[k])
+        for k in ("5_shard", "5_shard_dictionary"):
+            assert cf[k]["global_count"] == want_n, (label, k, cf[k]["global_count"], want_n)
+            assert abs(cf[k]["global_sum_x"] - want_s) <= 64 * np.finfo(np.float64).eps * float(np.abs(x[sel]).sum()), (label, k)
+        assert cf["5_shard_materialize"]["selected_per_gpu"] == want_n
+        assert ("RCCL" in cf["5_shard"]["exchange"]) == (label == "rccl")
 
 
 @pytest.mark.parametrize("world,dictionary", [(1, 4096), (3, 4096), (5, 0)])
