@@ -123,7 +123,7 @@ void profile_resolve(dfdb_ctx* ctx);   // fold the pending event pairs into ctx-
 // while profiling is on: count one launch of a named VARIANT (no time; "family.variant" beside the family's timed entry), so that a caller can see
 // which form of a kernel its context's options selected (dfdb_ctx_profile_get)
 inline void prof_note(dfdb_ctx* ctx, const char* name) { if (ctx->profiling) ctx->prof[name].launches++; }
-constexpr int kCompactStoreDefault = 1;   // K2 index stores (ctx option "compact_store"): see k_compact.hip
+constexpr int kCompactStoreDefault = 3;   // K2 form (ctx option "compact_store"): wide, nontemporal 16-byte stores — see k_compact.hip / kernels.hpp
 // the context's two pinned bounce buffers (file <-> HBM pipelines of dfdb_table_load / dfdb_table_save), at least `bytes` each
 void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes);
 }  // namespace dfdb

@@ -106,10 +106,12 @@ __device__ __forceinline__ void stream_indices(const uint16_t* pos, uint32_t tot
     else store_idx1<NT>(o + k, row1 + pos[k]);
   }
 }
-template <bool NT>
+// STAGE = staged positions per wave (2 bytes each): 4096 -> 8 KB per wave, 5 workgroups per CU; 2048 -> 4 KB, 10 workgroups (the 8-waves-per-SIMD cap).
+// A pair with more survivors than STAGE goes out in rounds of (ctile, 16-lane group): at most 16 x 64 = 1024 survivors each, in output order.
+template <bool NT, int STAGE>
 __global__ __launch_bounds__(kBlock) void k_compact_indices_wide(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
                                                                  int64_t* __restrict__ out, int64_t nctiles, int64_t row_base, int64_t out_cap) {
-  __shared__ uint16_t pos_sh[kWavesPerBlock][kCTile];
+  __shared__ uint16_t pos_sh[kWavesPerBlock][STAGE];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   uint16_t* pos = pos_sh[wib];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_indices_wide(const uint64_t*
     const int64_t row1 = row_base + pt * (2 * kCTile) + 1;                // 1-based table row of position 0 of the pair
     const uint32_t lbase = (uint32_t)lane << 6;
     uint32_t o0 = (incl & 0xffffu) - c0, o1 = (incl >> 16) - c1;
-    if (t0 + t1 <= (uint32_t)kCTile) {
+    if (t0 + t1 <= (uint32_t)STAGE) {
       o1 += t0;
       while (w0 | w1) {                                                  // the two expansions interleaved: independent chains
         if (w0) { const int b = __builtin_ctzll(w0); w0 &= w0 - 1; pos[o0++] = (uint16_t)(lbase + (uint32_t)b); }
@@ -142,26 +144,40 @@ __global__ __launch_bounds__(kBlock) void k_compact_indices_wide(const uint64_t*
       stream_indices<NT>(pos, t0 + t1, row1, out, obase, out_cap, lane);
       wave_lds_fence();
     } else {
-      while (w0) { const int b = __builtin_ctzll(w0); w0 &= w0 - 1; pos[o0++] = (uint16_t)(lbase + (uint32_t)b); }
-      wave_lds_fence();
-      stream_indices<NT>(pos, t0, row1, out, obase, out_cap, lane);
-      wave_lds_fence();
-      while (w1) { const int b = __builtin_ctzll(w1); w1 &= w1 - 1; pos[o1++] = (uint16_t)(lbase + (uint32_t)b); }
-      wave_lds_fence();
-      stream_indices<NT>(pos, t1, row1 + kCTile, out, obase + t0, out_cap, lane);
-      wave_lds_fence();
+#pragma unroll 1
+      for (int r = 0; r < 8; r++) {                                       // (ctile r / 4, lanes 16 * (r % 4) ... + 15): <= 1024 survivors, in output order
+        const bool second = r >= 4;
+        const int g = r & 3;
+        uint64_t w = (lane >> 4) == g ? (second ? w1 : w0) : 0ull;
+        const uint32_t gstart = __shfl(second ? o1 : o0, g * 16, 64);      // survivors of this ctile before the group
+        const uint32_t gend = g == 3 ? (second ? t1 : t0) : __shfl(second ? o1 : o0, (g + 1) * 16, 64);
+        uint32_t o = (second ? o1 : o0) - gstart;
+        while (w) { const int b = __builtin_ctzll(w); w &= w - 1; pos[o++] = (uint16_t)(lbase + (uint32_t)b); }
+        wave_lds_fence();
+        stream_indices<NT>(pos, gend - gstart, row1 + (second ? kCTile : 0), out, obase + (second ? t0 : 0u) + gstart, out_cap, lane);
+        wave_lds_fence();
+      }
     }
   }
 }
 
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows, int64_t row_base,
-                            int64_t out_cap, int store) {
+                            int64_t out_cap, int store, int grid_cap) {
   const int64_t nct = (nrows + kCTile - 1) / kCTile;
   if (nct == 0) return;
-  if (store == 3 || store == 4) {
-    const int grid = grid_for_ctiles((nct + 1) / 2);
-    if (store == 3) hipLaunchKernelGGL(k_compact_indices_wide<true>, dim3(grid), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
-    else hipLaunchKernelGGL(k_compact_indices_wide<false>, dim3(grid), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+  if (store >= 3 && store <= 6) {        // 3 / 4: wide, nontemporal / plain 16-byte stores, 8 KB of LDS per wave; 5 / 6: the same with 4 KB per wave
+    int64_t blocks = ((nct + 1) / 2 + kWavesPerBlock - 1) / kWavesPerBlock;
+    // one pair per wave up to 65 536 workgroups (2e9 rows): measured in the bench step against a persistent grid of 4096 workgroups, 0.182 -> 0.173
+    // and 0.207 -> 0.186 ms per 1e9 rows on two boxes (profiles/r3_k2_forms.txt) — a pure 0.8-GB fill shows the same preference for many short
+    // workgroups over a grid-stride loop (tools/bench_fill: 6.0-6.3 TB/s at 16 384 workgroups, 4.2-5.2 at 1024-4096)
+    const int64_t cap = grid_cap > 0 ? grid_cap : 65536;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const dim3 gr((unsigned)blocks), bl(kBlock);
+    if (store == 3) hipLaunchKernelGGL((k_compact_indices_wide<true, 4096>), gr, bl, 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+    else if (store == 4) hipLaunchKernelGGL((k_compact_indices_wide<false, 4096>), gr, bl, 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+    else if (store == 5) hipLaunchKernelGGL((k_compact_indices_wide<true, 2048>), gr, bl, 0, s, bitmap, prefix, out, nct, row_base, out_cap);
+    else hipLaunchKernelGGL((k_compact_indices_wide<false, 2048>), gr, bl, 0, s, bitmap, prefix, out, nct, row_base, out_cap);
     return;
   }
   if (store == 1) hipLaunchKernelGGL(k_compact_indices<1>, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, bitmap, prefix, out, nct, row_base, out_cap);

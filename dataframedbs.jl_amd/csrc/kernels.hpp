@@ -68,8 +68,11 @@ void launch_missing_mask(hipStream_t s, const uint64_t* missing, bool negate, bo
 void launch_fill_ones(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows);
 
 // ---- K2: bitmap -> ascending 1-based row numbers -------------------------------------------------
+// store (ctx option "compact_store"): 0 / 1 / 2 = one ctile per wave step, plain / nontemporal / write-through 8-byte stores (round 2: 1);
+// 3 / 4 = wide: two ctiles per wave, nontemporal / plain 16-byte stores (round 3 default: 3); 5 / 6 = wide with 4 KB of LDS per wave.
+// grid_cap (ctx option "compact_grid_cap"; wide forms): most workgroups launched, 0 = the shipped 65 536
 void launch_compact_indices(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, int64_t* out, int64_t nrows,
-                            int64_t row_base, int64_t out_cap, int store = 1 /* index stores: 0 plain, 1 nontemporal, 2 write-through (ctx option "compact_store") */);
+                            int64_t row_base, int64_t out_cap, int store = 3, int grid_cap = 0);
 // ---- K3: projection gather of a fixed-width column (width 1,2,4,8 bytes) -------------------------
 void launch_gather(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const void* src, void* dst, int width,
                    int64_t nrows, int64_t out_cap);

@@ -603,11 +603,13 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   ensure_executed(q);
   const int store = (int)ctx_option(ctx, "compact_store", kCompactStoreDefault);   // per context: two contexts may run different variants side by side
-  static const char* const store_names[] = {"compact_indices.plain8", "compact_indices.nt8", "compact_indices.wt8", "compact_indices.nt16", "compact_indices.plain16"};
-  prof_note(ctx, store_names[store >= 0 && store <= 4 ? store : 0]);
+  static const char* const store_names[] = {"compact_indices.plain8", "compact_indices.nt8", "compact_indices.wt8", "compact_indices.nt16", "compact_indices.plain16",
+                                            "compact_indices.nt16_lds4k", "compact_indices.plain16_lds4k"};
+  prof_note(ctx, store_names[store >= 0 && store <= 6 ? store : 0]);
+  const int gcap = (int)std::max<int64_t>(0, ctx_option(ctx, "compact_grid_cap", 0));
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");
-      launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap, store); }
+      launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap, store, gcap); }
     if (n) *n = query_count(q, -1);
     return;
   }
@@ -617,7 +619,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   if (m <= 0) return;
   q->tmp_b.ensure((size_t)m * 8);
   { LaunchTimer lt(ctx, "compact_indices");
-    launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m, store); }
+    launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m, store, gcap); }
   HIP_CHECK(hipMemcpyAsync(out, q->tmp_b.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
   stream_wait(q->t->ctx);
 }

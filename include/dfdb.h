@@ -113,7 +113,9 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself against a few candidate bitmap allocations
  *                     and the column keeps the fastest for the queries that scan it (query.cpp: place_mask; default 0: 27 scans + 0.03-1.4 s of allocations once
  *                     per column buys ~3 % of K1 on average; bench.py turns it on); "placement_spacer_mb" (12288) / "placement_candidates" (8) size the search
- *   "compact_store"   K2's index stores: 0 plain, 1 nontemporal (default: 10 % slower alone, but the scan that follows runs 4-7 % faster), 2 write-through
+ *   "compact_store"   K2's form: 0 / 1 / 2 = one 4096-row ctile per wave step with plain / nontemporal / write-through 8-byte stores (1 was round 2's default:
+ *                     nontemporal is slower alone, but the scan that follows runs 4-7 % faster); 3 (default) / 4 = two ctiles per wave and nontemporal / plain
+ *                     16-byte stores, one pair per wave; 5 / 6 = the same with 4 KB instead of 8 KB of LDS per wave.  "compact_grid_cap" bounds its workgroups
  *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)

@@ -35,7 +35,7 @@ def test_k2_every_store_form_gives_logicalindex_order(oracle, dfdb_mod, ctx, n):
         t = dfdb_mod.DFTable.from_columns({"b": mask})
         v = t[("b", lambda b: b), dfdb_mod.ALL]
         want = np.flatnonzero(mask).astype(np.int64) + 1
-        for store in (0, 1, 2, 3, 4):
+        for store in (0, 1, 2, 3, 4, 5, 6):
             ctx.set_option("compact_store", store)
             try:
                 q = v._query()
@@ -43,6 +43,7 @@ def test_k2_every_store_form_gives_logicalindex_order(oracle, dfdb_mod, ctx, n):
                 assert np.array_equal(got, want), f"{name}: store {store}, host buffer"
                 # device buffer with room to spare, at an ODD 8-byte offset so that the 16-byte pairs start on the other phase
                 buf = torch.full((len(want) + 3,), -7, dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()                # (the fill runs on torch's stream, K2 on the engine's own: order them)
                 q.indices_device(buf.data_ptr() + 8, len(want))
                 torch.cuda.synchronize()
                 h = buf.cpu().numpy()
@@ -50,12 +51,13 @@ def test_k2_every_store_form_gives_logicalindex_order(oracle, dfdb_mod, ctx, n):
                 if len(want) > 5:                       # a capacity below the count: nothing beyond it is written
                     cap = len(want) - 3
                     buf.fill_(-7)
+                    torch.cuda.synchronize()
                     q.indices_device(buf.data_ptr(), cap)
                     torch.cuda.synchronize()
                     h = buf.cpu().numpy()
                     assert np.array_equal(h[:cap], want[:cap]) and np.all(h[cap:] == -7), f"{name}: store {store}, out_cap"
             finally:
-                ctx.set_option("compact_store", 1)
+                ctx.set_option("compact_store", 3)     # the shipped default
         t.close()
 
 

@@ -36,11 +36,13 @@ def main():
 
     def step():
         q.reset(); q.indices_device(out.data_ptr(), nsel); q.count_device(cnt.data_ptr())
-    forms = [1, 3, 0, 4]
-    res = {f: {"k2": [], "k1": [], "step": []} for f in forms}
+    forms = [("nt8", 1, -1), ("wide_nt16", 3, -1), ("wide_nt16_grid16k", 3, 16384), ("wide_nt16_grid64k", 3, 65536), ("wide_nt16_lds4k", 5, -1),
+             ("wide_nt16_lds4k_grid16k", 5, 16384), ("wide_nt16_lds4k_grid64k", 5, 65536), ("wide_plain16_lds4k_grid64k", 6, 65536), ("plain8", 0, -1)]
+    res = {f[0]: {"k2": [], "k1": [], "step": []} for f in forms}
     for r in range(a.rounds):
-        for f in forms:
+        for name, f, cap in forms:
             ctx.set_option("compact_store", f)
+            ctx.set_option("compact_grid_cap", cap)       # -1: back to the shipped rule
             for _ in range(3):
                 step()
             ctx.profile(True)
@@ -53,9 +55,8 @@ def main():
             n2, ms2 = ctx.profile_get("compact_indices"); n1, ms1 = ctx.profile_get("scan_cmp")
             ctx.profile(False)
             if r:
-                res[f]["k2"].append(round(ms2 / n2, 4)); res[f]["k1"].append(round(ms1 / n1, 4)); res[f]["step"].append(round(el, 4))
-    names = {0: "plain8", 1: "nt8", 3: "wide_nt16", 4: "wide_plain16"}
-    print(json.dumps({"rows": n, "selected": nsel, "forms": {names[f]: {k: {"min": min(v), "median": sorted(v)[len(v) // 2], "all": v} for k, v in d.items()} for f, d in res.items()}}))
+                res[name]["k2"].append(round(ms2 / n2, 4)); res[name]["k1"].append(round(ms1 / n1, 4)); res[name]["step"].append(round(el, 4))
+    print(json.dumps({"rows": n, "selected": nsel, "forms": {k: {kk: {"min": min(v), "median": sorted(v)[len(v) // 2], "all": v} for kk, v in d.items()} for k, d in res.items()}}))
 
 
 if __name__ == "__main__":
