@@ -327,7 +327,7 @@ int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on) {
   return guard([&] { NEEDQ(q); if (q->hint_materialize != (on != 0)) { q->hint_materialize = on != 0; q->executed_stages = -1; q->count = -1; q->prefix_valid = false; } });
 }
-int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }); }
+int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0; }); }
 int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = query_count(q, -1); }); }
 int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind) {
   return guard([&] {

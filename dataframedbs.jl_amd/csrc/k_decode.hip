@@ -73,12 +73,14 @@ __device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int o
 // latency becomes max(parse, produce) instead of their sum — what matters when there are fewer blocks than wave slots (a streamed chunk, a small
 // table: at 1 526 blocks the chip is a quarter full and a block takes as long as it takes).  Sequences only the one-sequence path handles are
 // executed by wave 0 once wave 1 has drained; ownership of the ring and of the output position passes through LDS control words.
-template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE>
-__global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+// OCC: waves per SIMD the register allocation must leave room for; FARMAX: far-source slots per superbatch (24 bytes of LDS each)
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE, int OCC = (PIPE ? 4 : 5), int FARMAX = 64>
+__global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
                                                                LzScan sc) {
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
-  constexpr int kFarMax = 64;                    // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
+  constexpr int kFarMax = FARMAX;                // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
+  constexpr uint32_t kWords = kBatchBytes / 32;  // start-bit words per superbatch
   static_assert(!PIPE || (WAVES == 2 && !SCAN), "the two-wave pipeline is its own configuration");
   constexpr int NW = PIPE ? 1 : WAVES;           // sets of LDS arrays per workgroup
   constexpr int NS = PIPE ? 2 : 1;               // record slots (PIPE: one being parsed into, one being produced from)
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_d
   constexpr uint32_t kFlush = kRing >= 4096 ? 1024u : 512u;
   static_assert(kStage == kRing, "production addresses staging buffer, ring and far bytes as ((j + B) & (kStage - 1)) | O");
   constexpr uint32_t kFA = SCAN ? 511u : 255u;                    // flushes end on multiples of kFA + 1 bytes (SCAN: whole 64-row mask words)
-  static_assert((kFlush + kFA + 1 + kBatchBytes <= kRing && (kBatchBytes / 32 == 64 || kBatchBytes / 32 == 32) && 64 * W + 344 <= kStage / 2),
+  static_assert((kFlush + kFA + 1 + kBatchBytes <= kRing && (kWords == 64 || kWords == 32 || kWords == 16) && 64 * W + 344 <= kStage / 2 && kFarMax <= 64),
                 "v5: superbatch output must fit the ring behind the unflushed bytes; one window alone never exceeds the budget");
   const int64_t wave = PIPE ? wgid : (int64_t)blockIdx.x * WAVES + wib;
   const int64_t nwaves = PIPE ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES;
@@ -393,8 +395,9 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_d
           // ---- phase 2a: next^2, next^4 and next^8 of every candidate, all windows together (three rounds of W independent ds_bpermute).
           // A start whose successor lies outside the window (or that the batch does not take) points at itself, so do its powers: walks park there.
           // (level by level, each level's W gathers issued back to back and waited for once: see the pins in phase 2c)
-          static_assert(W == 8, "the pins below name eight registers");
-#define DFDB_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+          static_assert(W == 8 || W == 4, "the pins below name eight or four registers");
+#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
+                          else asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); } while (0)
           uint32_t X8[W], P2[W], P4[W];
 #pragma unroll
           for (int w = 0; w < W; w++) {
@@ -442,9 +445,10 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_d
           // Level by level over ALL windows: the W permutes of a level are issued back to back and waited for once (the empty asm pins that
           // order: the compiler would otherwise sink every permute to its use and pay W x 3 LDS round trips one after another).
           const uint32_t ge3 = lane >= 3u ? 1u : 0u;
-          static_assert(W == 8, "the pins below name eight registers");
+          static_assert(W == 8 || W == 4, "the pins below name eight or four registers");
           uint32_t FL[W], RP[W];
-#define DFDB_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
+                          else asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); } while (0)
 #pragma unroll
           for (int w = 0; w < W; w++) {
             FL[w] = __builtin_amdgcn_inverse_ballot_w64(V[w]) ? 1u : 0u;
@@ -554,10 +558,11 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, PIPE ? 4 : 5) void k_lz4_d
           // rank of an output position among the start bits = its sequence's ordinal.  Kept in the vector domain (a v_readlane of the bitmap
           // followed by scalar popcounts cost a VALU -> SGPR round trip of ~50 cycles per row): word and exclusive prefix sit side by side in LDS
           {
-            const uint32_t w = bits[lane & (kBatchBytes / 32 - 1)];
+            constexpr uint32_t kW = kWords < 32u ? kWords : 32u;    // (kWords == 64 has never been used: one bitsx entry per lane at most)
+            const uint32_t w = bits[lane & (kWords - 1)];
             const uint32_t cw = (uint32_t)__builtin_popcount(w);
-            const uint32_t incl = wave_incl_scan(lane < 32u ? cw : 0u);
-            if (lane < 32u) bitsx[lane] = make_uint2(w, incl - cw - 1u);
+            const uint32_t incl = wave_incl_scan(lane < kW ? cw : 0u);
+            if (lane < kW) bitsx[lane] = make_uint2(w, incl - cw - 1u);
           }
           wave_lds_fence();
           if (PIPE) {
@@ -731,6 +736,11 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
   // fewer blocks than the chip has wave slots (20 one-wave workgroups per CU x 256 CUs): the two-wave pipeline halves what matters then, a block's latency
   // (measured crossover on one MI355X: 2048 blocks 301 vs 252 GB/s for the pipeline, 3072 blocks 275 vs 326 against it: its 13.8 KB of LDS hold 11 blocks per CU)
+  // experiments (tools/bench_lz4): superbatches of 4 windows / 512 output bytes with a smaller footprint, for more waves per SIMD
+  if (pipe == 14) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
+  if (pipe == 15) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
+  if (pipe == 16) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 8, 16>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
+  if (pipe == 17) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
   if (pipe == 1 || (pipe < 0 && nblocks <= 2560))
     hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{});
   else

@@ -49,7 +49,7 @@ static void normalise(Stage& s) {
 // add(q, elem) with _new_queue's rules (selection.jl:39-49)
 void query_add_stage(dfdb_query* q, Stage&& ns) {
   normalise(ns);
-  q->executed_stages = -1; q->count = -1; q->prefix_valid = false;
+  q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0;
   Stage* last = q->stages.empty() ? nullptr : &q->stages.back();
   const bool new_is_range = ns.kind != ST_PRED;
   if (last && last->kind != ST_PRED && new_is_range) {   // range∘range collapses to old[elem] (:40)
@@ -536,6 +536,7 @@ void query_execute(dfdb_query* q, int nstages) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
   q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  q->gr_state = 0;             // a pending groupreduce belongs to the selection that is being replaced: its fetch must not restore the old one over this
   q->err_row[0] = q->err_row[1] = ~0ull;
   // A range-like stage that is EMPTY (an empty range, an empty index vector) finishes the reference's iteration before the first block is read:
   // is_finished (selection.jl:192-196: `last <= offset` for ANY range stage of the queue) is tested ahead of every block (blocksiterator.jl:69-78).
@@ -857,7 +858,7 @@ struct UniqueTables { DevBuf keys, rows, aux, rep_off, rep_len; uint64_t cap = 0
 static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_code) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int dn = col.dict_n;
-  DevBuf first; first.ensure((size_t)dn * 8 + 64);
+  DevBuf& first = q->du_first; first.ensure((size_t)dn * 8 + 64);      // (scratch kept on the query: every hipFree synchronises the device)
   HIP_CHECK(hipMemsetAsync(first.p, 0xFF, (size_t)dn * 8, s));
   { LaunchTimer lt(ctx, "unique");
     launch_dict_first_rows(s, q->bitmap.as<uint64_t>(), col.dict_codes.as<uint16_t>(), t->nrows, first.as<uint64_t>(), dn); }
@@ -871,7 +872,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   std::vector<uint64_t> rows((size_t)std::max<int64_t>(ng, 1));
   std::vector<uint32_t> rank((size_t)dn, 0xffffffffu);
   for (int64_t g = 0; g < ng; g++) { rows[(size_t)g] = present[(size_t)g].first; rank[present[(size_t)g].second] = (uint32_t)g; }
-  DevBuf drows; drows.ensure(rows.size() * 8 + 64);
+  DevBuf& drows = q->du_rows; drows.ensure(rows.size() * 8 + 64);
   HIP_CHECK(hipMemcpyAsync(drows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, s));
   if (rank_of_code) { rank_of_code->ensure(rank.size() * 4 + 64); HIP_CHECK(hipMemcpyAsync(rank_of_code->p, rank.data(), rank.size() * 4, hipMemcpyHostToDevice, s)); }
   HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
@@ -879,7 +880,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   launch_set_rows(s, drows.as<uint64_t>(), (int)ng, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
   scan_prefix(q);
   q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
-  HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory; first / drows die here
+  HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory
   return ng;
 }
 static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
@@ -968,7 +969,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   q->gr_sel.ensure(nw * 8);
   HIP_CHECK(hipMemcpyAsync(q->gr_sel.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   if (kc.dict_n > 0) {                                       // K9: group by the dictionary codes
-    DevBuf rank;
+    DevBuf& rank = q->du_rank;
     const int64_t ng = dict_unique(q, kc, &rank);
     q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
     const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
@@ -978,7 +979,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       launch_group_accumulate_codes(s, q->gr_sel.as<uint64_t>(), kc.dict_codes.as<uint16_t>(), rank.as<uint32_t>(), vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op,
                                     t->nrows, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
     launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
-    HIP_CHECK(hipStreamSynchronize(s));                      // `rank` dies here
+    HIP_CHECK(hipStreamSynchronize(s));
     q->gr_n = ng; q->gr_state = 2;
     if (ngroups) *ngroups = ng;
     if (key_bytes) *key_bytes = query_string_bytes(q, key_p);
@@ -1013,7 +1014,8 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
 // restores the query's full selection afterwards
 void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  if (q->gr_state == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_query_groupreduce has not been called");
+  if (q->gr_state == 0) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_query_groupreduce has not been called (or the query was executed, reset or changed since)");
+  if (q->bitmap_rows != t->nrows) { q->gr_state = 0; fail(DFDB_ERR_ARGUMENT, "ArgumentError: the table changed between dfdb_query_groupreduce and its fetch"); }
   const int64_t ng = q->gr_n;
   if (ng > 0) {
     if (keys) { keys->memkind = keys->memkind == DFDB_MEM_DEVICE ? DFDB_MEM_DEVICE : DFDB_MEM_HOST; materialize_col(q, q->gr_key, *keys, ng); }

@@ -272,3 +272,48 @@ def test_one_rank_rccl_group_exchanges_its_unique_records(oracle, dfdb_mod, ctx)
         gt.close(); t1.close()
     finally:
         g.close()
+
+
+def test_groupreduce_fetch_refuses_a_selection_that_changed(dfdb_mod, ctx):
+    """between dfdb_query_groupreduce and its fetch the query holds the narrowed selection (first occurrences) and the full one aside; a
+    reset / execute / new stage in between makes the pending result stale — the fetch must refuse, not restore the old selection over the new one"""
+    from dfdb import _native as N
+    L = N.load()
+    k = (np.arange(10_000) % 7).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"k": k, "v": np.arange(10_000, dtype=np.int64)})
+    for spoil in ("reset", "execute", "add"):
+        q = dfdb_mod.DFView(t)._query() if spoil != "add" else dfdb_mod.DFView(t)[dfdb_mod.jr(1, 9000), dfdb_mod.ALL]._query()
+        ng, kb = C.c_int64(), C.c_int64()
+        N.check(L.dfdb_query_groupreduce(q._h, 0, 1, N.AGG_SUM, C.byref(ng), C.byref(kb)))
+        assert ng.value == 7
+        if spoil == "reset":
+            q.reset()
+        elif spoil == "execute":
+            q.execute()
+        else:
+            N.check(L.dfdb_query_add_range(q._h, 1, 1, 100))
+        out = N.OutCol(); keys = np.zeros(7, np.int64); out.data, out.memkind = keys.ctypes.data, N.MEM_HOST
+        cnt = np.zeros(7, np.int64)
+        with pytest.raises(ValueError, match="dfdb_query_groupreduce has not been called"):
+            N.check(L.dfdb_query_groupreduce_fetch(q._h, C.byref(out), cnt.ctypes.data, None, None))
+        assert q.count() == (10_000 if spoil != "add" else 100)          # and the query answers for its own selection
+    t.close()
+
+
+def test_reloading_a_column_forgets_its_compressed_blocks(oracle, dfdb_mod, ctx, tmp_path):
+    """a column loaded with keep_compressed = 1 and loaded AGAIN without it must not keep the first load's LZ4 descriptors"""
+    from helpers import Pair
+    x = oracle.gen_i64(0x5151, 0, 70_000)
+    p = Pair(oracle, dfdb_mod, {"x": x}, block_size=4096, via_files=str(tmp_path / "tb"))
+    t = p.d
+    ctx.set_option("keep_compressed", 1)
+    try:
+        t.load(["x"])
+        t.decode_resident("x")                                   # the blocks are there
+        ctx.set_option("keep_compressed", 0)
+        t.load(["x"])
+        with pytest.raises(ValueError, match="holds no compressed blocks"):
+            t.decode_resident("x")
+        assert np.array_equal(t.view()._query().materialize()[0], x)
+    finally:
+        ctx.set_option("keep_compressed", 0)
