@@ -47,6 +47,9 @@ __device__ unsigned long long g_lz4_prof[32];
 #define LZ4_COUNT(k, n)
 #endif
 
+#ifndef DFDB_LZ4_PIPE_U
+#define DFDB_LZ4_PIPE_U 4
+#endif
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
 // SCAN = 1: decode fused with the first predicate of the scan (the reference's loop body decodes a block and evaluates
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         LZ4_PROF(5);
       }
       // ---- phase 5
-      constexpr int U = 4;                                             // rows per trip
+      constexpr int U = DFDB_LZ4_PIPE_U;                               // rows per trip
       for (uint32_t c = 0; c < T; c += 64u * U) {
         uint32_t ORD[U];
 #pragma unroll
@@ -734,23 +737,27 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  // fewer blocks than the chip has wave slots (20 one-wave workgroups per CU x 256 CUs): the two-wave pipeline halves what matters then, a block's latency
-  // (measured crossover on one MI355X: 2048 blocks 301 vs 252 GB/s for the pipeline, 3072 blocks 275 vs 326 against it: its 13.8 KB of LDS hold 11 blocks per CU)
-  // experiments (tools/bench_lz4): superbatches of 4 windows / 512 output bytes with a smaller footprint, for more waves per SIMD
-  if (pipe == 14) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
+  // fewer blocks than the chip has wave slots: the two-wave pipeline shortens what matters then, a block's latency
+  // Superbatch shape (round 3, tools/bench_lz4 pipe = 10 / 14 / 15 / 16 / 17, profiles/r3_lz4_harness.txt): 4 windows / 512 output bytes / 32 far slots
+  // need 79 VGPRs and 5.9 KB of LDS -> 6 waves per SIMD, and decode 8-byte integer columns at 431-445 GB/s where round 2's 8 windows / 1024 bytes /
+  // 64 far slots (91 VGPRs, 7.7 KB: 5 waves) gave 404-412; +4 ... +17 % on every body tried (1:n 396 -> 438, h mod 1000 370 -> 384, runs 364 -> 391,
+  // String 400 -> 431, incompressible 945 -> 1076, zeros 1195 -> 1406 GB/s).  Asking for 7 waves (72 VGPRs, 24 far slots) gave 415, for 8 (64 VGPRs:
+  // 4 spills) 396, 8 windows at 6 waves 428: past six waves per SIMD the LDS pipeline and instruction issue are what the waves share, not latency.
+  if (pipe == 10) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
   if (pipe == 15) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
-  if (pipe == 16) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 8, 16>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
-  if (pipe == 17) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
-  if (pipe == 1 || (pipe < 0 && nblocks <= 2560))
+  // the two-wave pipeline needs 128 VGPRs per wave: 4 waves per SIMD = 8 workgroups per CU = 2048 blocks resident at once, and a block takes ~3.3 ms
+  // there however few there are (763 blocks 2.6 ms, 1526 3.3 ms, 2048 3.4 ms = 312 GB/s; 2560 blocks need a second round: 5.5 ms, where one wave per
+  // block takes 5.3); superbatches of 4 windows in the pipeline are slower (1526 blocks: 214 vs 242 GB/s: twice the hand-offs)
+  if (pipe == 1 || (pipe < 0 && nblocks <= 2048))
     hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{});
   else
-    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
 }
 // decode + `value OP c` over an 8-byte column in one pass: dst receives the decoded column, sc.bitmap / sc.counts what K1 would write
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc) {
   if (nblocks <= 0) return;
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 1, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
+  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -120,8 +120,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
  *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
- *   "lz4_pipeline"    K7 with two waves per block (one parses, one produces, a superbatch apart): -1 = when a launch has fewer blocks than the
- *                     chip has wave slots (<= 2560; default), 0 = never, 1 = always
+ *   "lz4_pipeline"    K7 with two waves per block (one parses, one produces, a superbatch apart): -1 = when every block of a launch can be resident in
+ *                     that form at once (<= 2048 blocks; default), 0 = never, 1 = always
  *   "decode_on_scan"  1 = a fresh-mask scan of one `col OP const` term over an 8-byte column that holds its LZ4 blocks (keep_compressed) decodes and
  *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array (default 0)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0) */

@@ -301,19 +301,25 @@ def test_groupreduce_fetch_refuses_a_selection_that_changed(dfdb_mod, ctx):
 
 
 def test_reloading_a_column_forgets_its_compressed_blocks(oracle, dfdb_mod, ctx, tmp_path):
-    """a column loaded with keep_compressed = 1 and loaded AGAIN without it must not keep the first load's LZ4 descriptors"""
+    """a column loaded with keep_compressed = 1 and loaded AGAIN without it (dfdb_table_load_image over a resident column) must not keep
+    the first load's LZ4 descriptors: dfdb_table_decode_resident would decode the old blocks into the new array"""
     from helpers import Pair
     x = oracle.gen_i64(0x5151, 0, 70_000)
-    p = Pair(oracle, dfdb_mod, {"x": x}, block_size=4096, via_files=str(tmp_path / "tb"))
-    t = p.d
+    y = oracle.gen_i64(0x7777, 0, 70_000)
+    Pair(oracle, dfdb_mod, {"x": x}, block_size=4096, via_files=str(tmp_path / "tx")).d.close()
+    Pair(oracle, dfdb_mod, {"x": y}, block_size=4096, via_files=str(tmp_path / "ty")).d.close()
+    image_y = open(str(tmp_path / "ty" / "1.bin"), "rb").read()            # `<id>.bin`: header + blocks of the one column
+    t = dfdb_mod.open_table(str(tmp_path / "tx"), load=False)
     ctx.set_option("keep_compressed", 1)
     try:
         t.load(["x"])
-        t.decode_resident("x")                                   # the blocks are there
+        t.decode_resident("x")                                   # the blocks of the first load are there
+        assert np.array_equal(t.view()._query().materialize()[0], x)
         ctx.set_option("keep_compressed", 0)
-        t.load(["x"])
+        t.load_image("x", image_y)                                # the same column, other bytes, nothing kept this time
         with pytest.raises(ValueError, match="holds no compressed blocks"):
             t.decode_resident("x")
-        assert np.array_equal(t.view()._query().materialize()[0], x)
+        assert np.array_equal(t.view()._query().materialize()[0], y)
     finally:
         ctx.set_option("keep_compressed", 0)
+        t.close()
