@@ -206,19 +206,13 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
 
 
 # ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 (extra keys, never part of `value`)
-class stdout_to_stderr:
-    """RCCL prints a version banner on STDOUT when a communicator is created; this script's stdout is ONE JSON line.  File descriptor 1 points at
-    stderr while a communicator is being made (the banner is written by C code: sys.stdout redirection would not catch it)."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self.keep = os.dup(1)
-        os.dup2(2, 1)
-
-    def __exit__(self, *a):
-        sys.stdout.flush()
-        os.dup2(self.keep, 1)
-        os.close(self.keep)
+def claim_stdout():
+    """This script's stdout is ONE JSON line.  RCCL prints a version banner on stdout from C code the first time a communicator is used (sys.stdout
+    redirection does not catch it), so file descriptor 1 points at stderr for the whole run and the JSON line is written to the descriptor saved here."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return keep
 
 
 class Legs:
@@ -349,8 +343,8 @@ def config4_legs(L, dfdb, rows, rank):
 def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
     """config 5's per-GPU shard: mixed-type table (a Int64, x Float64, s String), conjunctive predicate over all three, count() + sum(x) — through the
     library's own group path (dfdb_group_*): every rank scans its block range and ONE exchange carries {sum, count} (docs/src/index.md:503-517,
-    view.jl:192-206).  With torch.distributed over gloo (functional runs on a 1-GPU box) RCCL cannot connect ranks that share a device, so the
-    per-rank building blocks + a gloo all-reduce stand in and the record says so."""
+    view.jl:192-206).  With torch.distributed over gloo (functional runs on a 1-GPU box) RCCL cannot connect ranks that share a device: the group then
+    takes its exchanges from the host's collectives (dfdb_group_create_rank_callbacks) and the record says so."""
     import ctypes as C
     from dfdb import _native as N
     torch, dist, world = L.torch, L.dist, L.world
@@ -361,16 +355,19 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
     if host_shards > 1:                                   # functional: ONE process, host-exchange group of `host_shards` shards on this device
         own = grp = G.Group.create([local] * host_shards, N.EXCHANGE_HOST)
         total = rows
-    elif world == 1 or L.backend == "nccl":
-        if grp is None:
+    elif grp is None:
+        if world == 1 or L.backend == "nccl":
             uid = None
             if world > 1:
                 store = dist.distributed_c10d._get_default_store()
                 if rank == 0:
                     store.set("dfdb_group_uid_c5", G.Group.unique_id())
                 uid = bytes(store.get("dfdb_group_uid_c5"))
-            with stdout_to_stderr():
-                own = grp = G.Group.create_rank(local, uid, rank, world, stream=stream)
+            own = grp = G.Group.create_rank(local, uid, rank, world, stream=stream)
+        else:
+            # functional runs on a 1-GPU box (--backend gloo --all-on-device0): RCCL cannot connect ranks that share a device, so the library's group
+            # takes its two exchanges from the host (dfdb_group_create_rank_callbacks over torch.distributed): every other line of csrc/group.cpp is the same
+            own = grp = G.Group.create_rank_torch(local, stream=stream)
     if grp is not None:
         gctx = grp.ctx(0)
         gt = G.GroupTable.new(grp)
@@ -387,7 +384,8 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
             out["sum"] = gq.aggregate(N.AGG_SUM, 0)       # the scan adds x up while it holds it; ONE exchange of {sum, count}
             out["count"] = gq.count()                     # the same exchange's count: no second scan, no second collective
         exch = ("libdfdb_hip's RCCL communicator (dfdb_group_aggregate: one grouped all-reduce of {sum, count} + the fault key)" if grp.exchange == N.EXCHANGE_RCCL
-                else f"host exchange between {host_shards} shards of one process (functional)")
+                else (f"libdfdb_hip's group over the host's collectives (dfdb_group_create_rank_callbacks, torch.distributed {L.backend}; functional: the ranks share a device)"
+                      if grp.exchange == N.EXCHANGE_CALLBACK else f"host exchange between {host_shards} shards of one process (functional)"))
         sec, ks = L.timed(step, gctx)
         mine = gq.shard_counts()[grp.first_rank] if host_shards <= 1 else out["count"]
         per_gpu_rows = rows if host_shards <= 1 else total
@@ -426,28 +424,7 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
         if own is not None:
             own.close()
         return res
-    # gloo functional path: per-rank tables (dfdb_table_set_row_base) + torch.distributed all-reduce of {count, sum}
-    t = dfdb.DFTable.new(block_size=65536, ctx=L.ctx)
-    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(0), rows, row_first=rank * rows)
-    t.add_generated("x", dfdb.GEN_F64_U2000, seed_of(1), rows, row_first=rank * rows)
-    t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(2), rows, row_first=rank * rows)
-    t.set_row_base(rank * rows)
-    cx = t[(t.a > 683_771) & (t.x < 632.456) & (t.s != "sony"), dfdb.ALL][dfdb.ALL, "x"]
-    q = cx.view._query()
-    acc = torch.zeros(2, dtype=torch.float64)
-
-    def step():
-        q.reset()
-        sx = cx.sum()
-        acc[0] = float(q.count()); acc[1] = sx
-        dist.all_reduce(acc)
-    sec, ks = L.timed(step)
-    res["5_shard"] = L.record(rows, q.count(), sec, ks, rows * bytes_row,
-                              "a: Int64, x: Float64, s: String; (a > 683771) & (x < 632.456) & (s != \"sony\") -> count() + sum(x), flat String scan",
-                              exchange=f"torch.distributed {L.backend} all-reduce of {{count, sum}} (functional run: RCCL cannot connect ranks that share a device)",
-                              global_count=int(acc[0].item()), global_sum_x=float(acc[1].item()), total_rows=total)
-    t.close()
-    return res
+    raise RuntimeError("unreachable: every configuration has a group")
 
 
 def run_config_legs(L, dfdb, G, args, rank, local, stream, grp):
@@ -493,6 +470,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
+    out_fd = claim_stdout()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -533,13 +511,13 @@ def main():
     if lib:
         # the C-ABI group: this process is rank `rank` of `world`; the RCCL id travels through torch.distributed's store
         uid = None
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 store.set("dfdb_group_uid", G.Group.unique_id())
             uid = bytes(store.get("dfdb_group_uid"))
-        with stdout_to_stderr():
-            grp = G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream)
+        grp = (G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream) if world == 1 or args.backend == "nccl"
+               else G.Group.create_rank_torch(local, stream=stream_obj.cuda_stream))
         ctx = grp.ctx(0)
         ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
         nblocks_per = -(-(-(-(rows * world) // 65536)) // world)        # ceil(ceil(total / 65536) / world): the library's block-range rule
@@ -682,7 +660,8 @@ def main():
                        "rows_per_gpu": rows, "selected_per_gpu": nsel, "selectivity": sigma, "block_size": 65536,
                        "pipeline": "k_scan_cmp + count scan + k_compact_indices",
                        "sharding": (f"contiguous block ranges x{world}, all-reduce(count) per step by " +
-                                    ("libdfdb_hip's RCCL communicator (dfdb_group_count)" if lib else f"torch.distributed {args.backend}")) if world > 1 else "single GPU",
+                                    (("libdfdb_hip's RCCL communicator (dfdb_group_count)" if args.backend == "nccl" else f"libdfdb_hip's group over the host's collectives (torch.distributed {args.backend})")
+                                     if lib else f"torch.distributed {args.backend}")) if world > 1 else "single GPU",
                        "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
                        "device": info["name"], "global_selected": total_sel,
                        "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows, "one_time_seconds": pl_wall / 1e6,
@@ -715,7 +694,8 @@ def main():
     if res is not None:
         if not args.no_cpu and world == 1:      # the CPU baseline is an N=1, rank-0 figure
             res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(out_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -123,6 +123,7 @@ struct dfdb_group {
   // and the bare status otherwise — so that all ranks learn of the failure at the same point and raise the SAME error: the one of the
   // lowest table row, which is the one the reference's serial block iteration would have met first.
   int fault_code = 0; std::string fault_msg; uint64_t fault_key = ~0ull;
+  dfdb_exchange_fns fns{nullptr, nullptr, nullptr};   // DFDB_EXCHANGE_CALLBACK: the caller's collectives (host memory, blocking)
   int nlocal() const { return (int)ctx.size(); }
 };
 struct dfdb_gtable {
@@ -284,6 +285,17 @@ static void exchange_reduce(dfdb_group* g, std::initializer_list<XSpec> specs_in
     RCCL_CHECK(r.GroupEnd());
     return;
   }
+  if (g->exchange == DFDB_EXCHANGE_CALLBACK) {       // one shard per process: operands to pinned memory, the caller's all-reduce, results back
+    for (const XSpec& x : specs)
+      HIP_CHECK(hipMemcpyAsync(g->xpin[0] + x.slot, g->xbuf[0].as<uint64_t>() + x.slot, (size_t)x.n * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    stream_wait(g->ctx[0]);
+    for (const XSpec& x : specs) {
+      const int32_t rc = g->fns.allreduce(g->fns.user, g->xpin[0] + x.slot, x.n, x.dt, x.op);
+      if (rc != 0) fail(DFDB_ERR_DEVICE, "the caller's allreduce failed with %d", rc);
+      HIP_CHECK(hipMemcpyAsync(g->xbuf[0].as<uint64_t>() + x.slot, g->xpin[0] + x.slot, (size_t)x.n * 8, hipMemcpyHostToDevice, g->ctx[0]->stream));
+    }
+    return;
+  }
   // host exchange (single-process groups only): read every shard's operands, fold in rank order, write the result back
   for (const XSpec& x : specs) {
     for (int l = 0; l < nl; l++) {
@@ -337,6 +349,17 @@ static std::vector<int64_t> exchange_gather(dfdb_group* g, int slot) {
     stream_wait(g->ctx[0]);
     settle_fault(g, (uint64_t)g->xpin[0][kFaultSlot]);
     for (int k = 0; k < g->world; k++) all[(size_t)k] = g->xpin[0][kXSlots + k];
+    return all;
+  }
+  if (g->exchange == DFDB_EXCHANGE_CALLBACK) {
+    HIP_CHECK(hipMemcpyAsync(g->xpin[0] + slot, g->xbuf[0].as<uint64_t>() + slot, 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    stream_wait(g->ctx[0]);
+    int32_t rc = g->fns.allgather(g->fns.user, g->xpin[0] + slot, all.data(), 8);
+    if (rc != 0) fail(DFDB_ERR_DEVICE, "the caller's allgather failed with %d", rc);
+    uint64_t key = g->fault_key;
+    rc = g->fns.allreduce(g->fns.user, &key, 1, DFDB_U64, DFDB_AGG_MIN);
+    if (rc != 0) fail(DFDB_ERR_DEVICE, "the caller's allreduce failed with %d", rc);
+    settle_fault(g, key);
     return all;
   }
   for (int l = 0; l < nl; l++) {
@@ -426,14 +449,15 @@ static void group_count_enqueue(dfdb_gquery* gq, bool wait) {
   gq->count_enqueued = true; gq->count = -1;
   // enqueue-only callers (dfdb_group_count(gq, NULL)) never read the slots back: a LOCAL failure is theirs to hear now; the other ranks meet
   // it in the fault slot at their next host read (group_count / get_slot0)
-  if (!wait && g->fault_key != ~0ull) { gq->count_enqueued = false; const Error e(g->fault_code, g->fault_msg); g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear(); throw e; }
+  if (!wait && g->fault_key != ~0ull) { const Error e(g->fault_code, g->fault_msg); g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear(); throw e; }
 }
 
 static int64_t group_count(dfdb_gquery* gq) {
   if (gq->count >= 0) return gq->count;
-  bool stale = !gq->count_enqueued;
-  for (dfdb_query* q : gq->shard) stale = stale || shard_needs_exec(q);
-  if (stale) group_count_enqueue(gq, true);
+  // Whether a new exchange is needed must be decided ALIKE on every rank: by the group query's own flag, which only calls that every rank makes
+  // (new stages, reset, hints, table loads) clear — never by a shard's local state.  A shard whose execution failed "needs execution" on its rank only;
+  // re-enqueueing there while the healthy ranks just read their slots would leave it alone in a collective.
+  if (!gq->count_enqueued) group_count_enqueue(gq, true);
   int64_t n = 0;
   // (a fault the ranks agreed on invalidates the exchange for all of them alike: the next call enqueues again on every rank)
   try { get_slot0(gq->gt->g, 0, 1, &n); } catch (...) { gq->count_enqueued = false; throw; }
@@ -522,6 +546,24 @@ int32_t dfdb_group_create_rank(int32_t device_id, void* hip_stream, const uint8_
   });
 }
 
+int32_t dfdb_group_create_rank_callbacks(int32_t device_id, void* hip_stream, int32_t rank, int32_t world, const dfdb_exchange_fns* fns, dfdb_group** out) {
+  return gguard([&] {
+    GNEED(out); GNEED(fns);
+    if (world < 1 || rank < 0 || rank >= world) fail(DFDB_ERR_ARGUMENT, "rank %d of %d", rank, world);
+    if (!fns->allreduce || !fns->allgather) fail(DFDB_ERR_ARGUMENT, "null argument: both allreduce and allgather are needed");
+    std::unique_ptr<dfdb_group> g(new dfdb_group);
+    g->world = world; g->first_rank = rank; g->exchange = DFDB_EXCHANGE_CALLBACK; g->fns = *fns;
+    try {
+      dfdb_ctx* c = nullptr;
+      const int32_t rc = dfdb_ctx_create(device_id, hip_stream, &c);
+      if (rc != DFDB_OK) { char buf[512]; dfdb_last_error(buf, sizeof buf); fail(rc, "%s", buf); }
+      g->ctx.push_back(c);
+      group_finish_create(g);
+    } catch (...) { group_destroy(g.release()); throw; }
+    *out = g.release();
+  });
+}
+
 int32_t dfdb_group_destroy(dfdb_group* g) { return gguard([&] { group_destroy(g); }); }
 
 int32_t dfdb_group_info(dfdb_group* g, int32_t* world, int32_t* nlocal, int32_t* first_rank, int32_t* exchange) {
@@ -564,6 +606,9 @@ int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t
 }
 
 // ------------------------------------------------------------------ tables
+static void gtable_changed(dfdb_gtable* gt) {   // rows came or went on every rank alike: the table's queries start over, in lockstep
+  for (dfdb_gquery* gq : gt->queries) { gq->planned = false; gq->count_enqueued = false; gq->count = -1; gq->merged = GroupMerged{}; }
+}
 static dfdb_gtable* new_gtable(dfdb_group* g) { auto* gt = new dfdb_gtable; gt->g = g; gt->shard.assign((size_t)g->nlocal(), nullptr); return gt; }
 static void gtable_free(dfdb_gtable* gt) {
   if (!gt) return;
@@ -614,6 +659,7 @@ int32_t dfdb_group_table_load(dfdb_gtable* gt, const int32_t* ordinals, int32_t 
       gt->shard[(size_t)l]->row_base = b0 * t0->block_size;
     });
     gt->total_rows = hs.rows;
+    gtable_changed(gt);
     if (stats) { *stats = dfdb_sizestats{0, 0, 0}; for (auto& s : st) { stats->rows += s.rows; stats->compressed += s.compressed; stats->uncompressed += s.uncompressed; } }
   });
 }
@@ -633,6 +679,7 @@ int32_t dfdb_group_table_add_generated(dfdb_gtable* gt, const char* name, int32_
       gt->shard[(size_t)l]->row_base = r0; gt->shard[(size_t)l]->block_first = b0;
     });
     gt->total_rows = nrows_total;
+    gtable_changed(gt);
   });
 }
 
@@ -672,6 +719,7 @@ int32_t dfdb_group_table_add_column(dfdb_gtable* gt, const char* name, int32_t d
       gt->shard[(size_t)l]->row_base = r0; gt->shard[(size_t)l]->block_first = r0 / bs;
     });
     gt->total_rows = nrows_total;
+    gtable_changed(gt);
   });
 }
 
@@ -768,7 +816,7 @@ int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* ou
     const int dt = dt_isfloat(pdt) ? DFDB_F64 : (pdt == DFDB_U64 ? DFDB_U64 : DFDB_I64);      // = what query_aggregate_device returns
     for (int d : dts) if (d != dt && g->fault_key == ~0ull) fail(DFDB_ERR_DEVICE, "shards disagree on the accumulator type");
     int64_t res[2] = {0, 0};
-    if (dt == DFDB_F64 && op != DFDB_AGG_SUM && g->exchange == DFDB_EXCHANGE_RCCL && exchanges(g)) {
+    if (dt == DFDB_F64 && op != DFDB_AGG_SUM && (g->exchange == DFDB_EXCHANGE_RCCL || g->exchange == DFDB_EXCHANGE_CALLBACK) && exchanges(g)) {
       // Julia's minimum / maximum propagate NaN, ncclMin / ncclMax need not: gather the per-rank partials and fold them on the host
       const std::vector<int64_t> vals = exchange_gather(g, 8);
       uint64_t acc = (uint64_t)vals[0];
@@ -938,6 +986,20 @@ static std::vector<GroupPart> all_parts(dfdb_group* g, std::vector<GroupPart>& l
   // RCCL all-gather of this path for real, with a one-rank group)
   const bool forced = g->exchange == DFDB_EXCHANGE_RCCL && ctx_option(g->ctx[0], "group_force_exchange", 0) != 0;
   if (g->nlocal() == g->world && !forced) { settle_fault(g, g->fault_key); return std::move(local); }
+  if (g->exchange == DFDB_EXCHANGE_CALLBACK) {
+    std::vector<uint8_t> blob = pack_part(local[0]);
+    HIP_CHECK(hipSetDevice(g->ctx[0]->device)); put_slot(g, 0, 1, (int64_t)blob.size());
+    const std::vector<int64_t> sizes = exchange_gather(g, 1);          // (raises the fault the ranks agreed on, if a shard failed)
+    int64_t maxb = 8;
+    for (int64_t b : sizes) maxb = std::max(maxb, b);
+    blob.resize((size_t)maxb, 0);
+    std::vector<uint8_t> all((size_t)maxb * (size_t)g->world);
+    const int32_t rc = g->fns.allgather(g->fns.user, blob.data(), all.data(), maxb);
+    if (rc != 0) fail(DFDB_ERR_DEVICE, "the caller's allgather failed with %d", rc);
+    std::vector<GroupPart> parts;
+    for (int rk = 0; rk < g->world; rk++) parts.push_back(unpack_part(all.data() + (size_t)rk * (size_t)maxb, (size_t)sizes[(size_t)rk]));
+    return parts;
+  }
   if (g->exchange != DFDB_EXCHANGE_RCCL) fail(DFDB_ERR_DEVICE, "a host-exchange group holds every shard in one process");
   const int nl = g->nlocal();
   std::vector<std::vector<uint8_t>> blobs((size_t)nl);

@@ -398,9 +398,10 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           // ---- phase 2a: next^2, next^4 and next^8 of every candidate, all windows together (three rounds of W independent ds_bpermute).
           // A start whose successor lies outside the window (or that the batch does not take) points at itself, so do its powers: walks park there.
           // (level by level, each level's W gathers issued back to back and waited for once: see the pins in phase 2c)
-          static_assert(W == 8 || W == 4, "the pins below name eight or four registers");
-#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
-                          else asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); } while (0)
+          static_assert(W == 8 || W == 4 || W == 2, "the pins below name eight, four or two registers");
+#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2 % W]), "+v"(a[3 % W]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
+                          else if constexpr (W == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2 % W]), "+v"(a[3 % W])); \
+                          else asm volatile("" : "+v"(a[0]), "+v"(a[1])); } while (0)
           uint32_t X8[W], P2[W], P4[W];
 #pragma unroll
           for (int w = 0; w < W; w++) {
@@ -448,10 +449,11 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           // Level by level over ALL windows: the W permutes of a level are issued back to back and waited for once (the empty asm pins that
           // order: the compiler would otherwise sink every permute to its use and pay W x 3 LDS round trips one after another).
           const uint32_t ge3 = lane >= 3u ? 1u : 0u;
-          static_assert(W == 8 || W == 4, "the pins below name eight or four registers");
+          static_assert(W == 8 || W == 4 || W == 2, "the pins below name eight, four or two registers");
           uint32_t FL[W], RP[W];
-#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
-                          else asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); } while (0)
+#define DFDB_PIN8(a) do { if constexpr (W == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2 % W]), "+v"(a[3 % W]), "+v"(a[4 % W]), "+v"(a[5 % W]), "+v"(a[6 % W]), "+v"(a[7 % W])); \
+                          else if constexpr (W == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2 % W]), "+v"(a[3 % W])); \
+                          else asm volatile("" : "+v"(a[0]), "+v"(a[1])); } while (0)
 #pragma unroll
           for (int w = 0; w < W; w++) {
             FL[w] = __builtin_amdgcn_inverse_ballot_w64(V[w]) ? 1u : 0u;

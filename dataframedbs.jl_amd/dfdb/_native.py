@@ -58,7 +58,7 @@ SYMBOLS = [
     "dfdb_query_execute", "dfdb_query_reset", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
     "dfdb_materialize", "dfdb_aggregate",
     # multi-GPU groups (block-range shards + RCCL)
-    "dfdb_group_create", "dfdb_group_unique_id", "dfdb_group_create_rank", "dfdb_group_destroy", "dfdb_group_info", "dfdb_group_ctx",
+    "dfdb_group_create", "dfdb_group_unique_id", "dfdb_group_create_rank", "dfdb_group_create_rank_callbacks", "dfdb_group_destroy", "dfdb_group_info", "dfdb_group_ctx",
     "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_set_option", "dfdb_group_allreduce_f64",
     "dfdb_group_table_open", "dfdb_group_table_new", "dfdb_group_table_close", "dfdb_group_table_load", "dfdb_group_table_add_generated",
     "dfdb_group_table_add_column", "dfdb_group_table_nrows", "dfdb_group_table_shard",
@@ -69,7 +69,13 @@ SYMBOLS = [
     "dfdb_group_shard_string_bytes", "dfdb_group_materialize_device",
     "dfdb_group_query_unique", "dfdb_group_query_unique_fetch", "dfdb_group_query_groupreduce", "dfdb_group_query_groupreduce_fetch",
 ]
-EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST, EXCHANGE_CALLBACK = 0, 1, 2, 3
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32)      # (user, vals, n, dtype, op)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)               # (user, send, recv, nbytes)
+
+
+class ExchangeFns(C.Structure):      # dfdb_exchange_fns
+    _fields_ = [("user", C.c_void_p), ("allreduce", ALLREDUCE_FN), ("allgather", ALLGATHER_FN)]
 GROUP_ID_BYTES = 128
 
 _lib = None
@@ -120,6 +126,7 @@ def load() -> C.CDLL:
         lib.dfdb_group_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         lib.dfdb_group_unique_id.argtypes = [C.c_void_p]
         lib.dfdb_group_create_rank.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        lib.dfdb_group_create_rank_callbacks.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         lib.dfdb_group_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         lib.dfdb_group_ctx.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.dfdb_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]

@@ -45,6 +45,58 @@ class Group:
         N.check(N.load().dfdb_group_create_rank(device, C.c_void_p(stream) if stream else None, buf, rank, world, C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def create_rank_callbacks(cls, device: int, rank: int, world: int, allreduce, allgather, stream: Optional[int] = None) -> "Group":
+        """one process per GPU with the HOST's own collectives (dfdb_group_create_rank_callbacks, DFDB_EXCHANGE_CALLBACK):
+        allreduce(vals: np.ndarray[uint64 view of n 8-byte values], dtype, op) reduces in place, allgather(send: bytes) -> bytes of every rank in rank order"""
+        def _ar(user, vals, n, dtype, op):
+            try:
+                allreduce(np.ctypeslib.as_array((C.c_uint64 * n).from_address(vals)), dtype, op)
+                return 0
+            except Exception:      # noqa: BLE001 — an exception must not unwind through the C frames
+                import traceback; traceback.print_exc()
+                return 1
+
+        def _ag(user, send, recv, nbytes):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:      # noqa: BLE001
+                import traceback; traceback.print_exc()
+                return 1
+        fns = N.ExchangeFns(None, N.ALLREDUCE_FN(_ar), N.ALLGATHER_FN(_ag))
+        h = C.c_void_p()
+        N.check(N.load().dfdb_group_create_rank_callbacks(device, C.c_void_p(stream) if stream else None, rank, world, C.byref(fns), C.byref(h)))
+        g = cls(h)
+        g._keep = fns                      # the C side copied the table; the CFUNCTYPE thunks must stay alive
+        return g
+
+    @classmethod
+    def create_rank_torch(cls, device: int, stream: Optional[int] = None) -> "Group":
+        """the same over torch.distributed (any backend that moves CPU tensors: gloo): rank and world come from the initialised process group.
+        The reductions gather the 8-byte patterns and fold them here in the asked dtype (torch has no UInt64 reductions; integer sums wrap)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def gather_rows(a: np.ndarray) -> np.ndarray:
+            mine = torch.from_numpy(a.view(np.int64).copy())
+            box = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(box, mine)
+            return np.stack([b.numpy() for b in box])
+
+        def allreduce(vals, dtype, op):
+            rows = gather_rows(vals).view({ir.F64: np.float64, ir.U64: np.uint64}.get(dtype, np.int64))
+            with np.errstate(over="ignore"):
+                r = rows.sum(axis=0, dtype=rows.dtype) if op == N.AGG_SUM else (rows.min(axis=0) if op == N.AGG_MIN else rows.max(axis=0))
+            vals[:] = np.ascontiguousarray(r).view(np.uint64)
+
+        def allgather(send: bytes) -> bytes:
+            a = np.frombuffer(send + b"\0" * (-len(send) % 8), np.uint8)
+            return b"".join(bytes(row.view(np.uint8)[:len(send)]) for row in gather_rows(a))
+        return cls.create_rank_callbacks(device, rank, world, allreduce, allgather, stream)
+
     def ctx(self, local: int = 0) -> api.Context:
         """borrowed Context of one local shard (profiling, options, device info)"""
         h = C.c_void_p()

@@ -317,6 +317,7 @@ int32_t dfdb_stream_close(dfdb_stream* s);
  *   dfdb_group_create        one process drives n GPUs (a host thread per GPU, ncclCommInitAll): what a Julia session gets
  *   dfdb_group_create_rank   one process per GPU (ncclCommInitRank; the id comes from dfdb_group_unique_id on rank 0 and is
  *                            handed round by the launcher: MPI, Distributed.jl, a torch.distributed store)
+ *   dfdb_group_create_rank_callbacks   one process per GPU, the exchanges through the caller's own collectives (dfdb_exchange_fns)
  * RCCL is dlopen'ed on first use.  DFDB_EXCHANGE_HOST does the same exchanges through host memory and exists for one-process
  * groups whose shards share a physical GPU (functional tests on a 1-GPU box; RCCL refuses duplicate devices).
  * Failures: when the per-shard half of a collective call fails on one rank only (a DivideError / InexactError that only its rows reach, out of
@@ -328,13 +329,25 @@ int32_t dfdb_stream_close(dfdb_stream* s);
 typedef struct dfdb_group dfdb_group;
 typedef struct dfdb_gtable dfdb_gtable;   /* a DFTable, sharded */
 typedef struct dfdb_gquery dfdb_gquery;   /* a DFView over it */
-enum { DFDB_EXCHANGE_AUTO = 0, DFDB_EXCHANGE_RCCL = 1, DFDB_EXCHANGE_HOST = 2 };
+enum { DFDB_EXCHANGE_AUTO = 0, DFDB_EXCHANGE_RCCL = 1, DFDB_EXCHANGE_HOST = 2, DFDB_EXCHANGE_CALLBACK = 3 };
+/* DFDB_EXCHANGE_CALLBACK: one process per GPU whose host brings its OWN collectives (MPI, Distributed.jl, torch.distributed over gloo): the two
+ * exchanges a group needs, over HOST memory, blocking, called by every rank in the same order.  Both return 0 on success.
+ *   allreduce  vals[n] (8-byte values: dtype DFDB_I64 / DFDB_U64 / DFDB_F64; op DFDB_AGG_SUM / _MIN / _MAX) := the reduction over all ranks, in place
+ *              (integer sums wrap; the library never asks for a Float64 MIN / MAX: it gathers and folds with Julia's NaN rules itself)
+ *   allgather  recv[world * nbytes] := every rank's send[nbytes], rank order */
+typedef struct dfdb_exchange_fns {
+  void* user;
+  int32_t (*allreduce)(void* user, void* vals, int32_t n, int32_t dtype, int32_t op);
+  int32_t (*allgather)(void* user, const void* send, void* recv, int64_t nbytes);
+} dfdb_exchange_fns;
 #define DFDB_GROUP_ID_BYTES 128
 
 int32_t dfdb_group_create(const int32_t* device_ids, int32_t n, int32_t exchange, dfdb_group** out);
 int32_t dfdb_group_unique_id(uint8_t id[DFDB_GROUP_ID_BYTES]);
 int32_t dfdb_group_create_rank(int32_t device_id, void* hip_stream, const uint8_t id[DFDB_GROUP_ID_BYTES], int32_t rank, int32_t world,
                                dfdb_group** out);
+/* the same as dfdb_group_create_rank with the caller's collectives instead of RCCL (the function table is copied; `user` must outlive the group) */
+int32_t dfdb_group_create_rank_callbacks(int32_t device_id, void* hip_stream, int32_t rank, int32_t world, const dfdb_exchange_fns* fns, dfdb_group** out);
 int32_t dfdb_group_destroy(dfdb_group* g);
 int32_t dfdb_group_info(dfdb_group* g, int32_t* world, int32_t* nlocal, int32_t* first_rank, int32_t* exchange);
 int32_t dfdb_group_ctx(dfdb_group* g, int32_t local, dfdb_ctx** ctx);          /* borrowed */

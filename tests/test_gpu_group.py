@@ -284,11 +284,12 @@ def test_bench_self_launches_ranks(ctx):
     assert r["value"] > 0
     # round 3: the same line carries configs 3 / 4 / 5 at every N (here 0.4 % of their sizes, both ranks on device 0, the exchange over gloo)
     cf = r["configs"]
-    for k in ("3", "4", "4_dictionary", "5_shard"):
+    for k in ("3", "4", "4_dictionary", "5_shard", "5_shard_dictionary", "5_shard_materialize"):
         assert "error" not in cf[k], cf[k]
         assert cf[k]["ms_per_step"] > 0 and cf[k]["rows_per_s"] > 0 and 0 < cf[k]["roofline"]["frac"] < 2 and cf[k]["kernels_avg_ms"], (k, cf[k])
     n5 = cf["5_shard"]["rows_per_gpu"]
     assert cf["5_shard"]["total_rows"] == 2 * n5 and 0.05 * 2 * n5 < cf["5_shard"]["global_count"] < 0.12 * 2 * n5
+    assert "dfdb_group_create_rank_callbacks" in cf["5_shard"]["exchange"]          # the LIBRARY's group path, its exchanges through gloo
     assert r["default_config"]["value"] > 0 and r["default_config"]["scan_cmp_avg_ms"] > 0
 
 
@@ -378,3 +379,116 @@ def _same_keys(want, got):
             return [None if m else x for x, m in zip(v.data.tolist(), np.ma.getmaskarray(v).tolist())]
         return ["nan" if isinstance(x, float) and x != x else x for x in (v.tolist() if isinstance(v, np.ndarray) else list(v))]
     return canon(want) == canon(got)
+
+
+# ---------------------------------------------------------------- one process per GPU through the LIBRARY's group path, the host's own collectives
+_CALLBACK_RANK_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "dataframedbs.jl_amd"))
+import numpy as np, torch, torch.distributed as dist
+import dfdb
+from dfdb import ir, group as G, _native as N
+rank, world, path = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = G.Group.create_rank_torch(0)                       # dfdb_group_create_rank_callbacks: allreduce / allgather over gloo
+assert (g.world, g.nlocal, g.first_rank, g.exchange) == (world, 1, rank, N.EXCHANGE_CALLBACK)
+gt = G.GroupTable.open(g, path)
+a, x, s, z = ir.col(0), ir.col(1), ir.col(2), ir.col(3)
+base = gt.view()
+views = {
+  "pred": dfdb.selection(base, (a > 700_000) & (s != "sony")),
+  "range_after_pred": dfdb.selection(dfdb.selection(base, a > 500_000), dfdb.jr(11, 3, 90_000)),
+  "two_exchanges": dfdb.selection(dfdb.selection(dfdb.selection(dfdb.selection(base, a % 2 == 0), dfdb.jr(10, 1, 100_000)), s == "dell"), [1, 5, 400, 4999, 10**9]),
+}
+out = {}
+for name, v in views.items():
+    o = dict(total=G.gnrow(v), idx=G.gindices(v).tolist())
+    o["sum_a"] = G.gaggregate(v[dfdb.ALL, ["a"]], N.AGG_SUM); o["min_x"] = G.gaggregate(v[dfdb.ALL, ["x"]], N.AGG_MIN); o["max_x"] = G.gaggregate(v[dfdb.ALL, ["x"]], N.AGG_MAX)
+    o["sum_x"] = G.gaggregate(v[dfdb.ALL, ["x"]], N.AGG_SUM)
+    o["unique_s"] = list(G.gunique(v.s))
+    gr = G.ggroupreduce(v, "s", "a", "sum")
+    o["groups"] = [list(gr["s"]), [int(c) for c in gr["count"]], [int(c) for c in gr["sum"]]]
+    m = G._gq(v[dfdb.ALL, ["a", "s"]]).materialize()
+    o["mat_a"] = m[0].tolist(); o["mat_s_sizes"] = m[1][0].tolist()
+    out[name] = o
+# a DivideError that only the LAST rank's rows reach: every rank must come back from the same call with the same error, none may hang
+bad = dfdb.selection(base, a % z == 0)
+errs = []
+for call in (lambda: G.gnrow(bad), lambda: G.gaggregate(bad[dfdb.ALL, ["a"]], N.AGG_SUM), lambda: G.gunique(bad.s), lambda: G.ggroupreduce(bad, "s", "a", "sum")):
+    try:
+        call(); errs.append("none")
+    except Exception as e:
+        errs.append(type(e).__name__)
+q = G.GroupQuery(gt, bad)
+try:
+    q.count_async(); errs.append("none")                # enqueue only: the failing rank hears of it now ...
+except Exception as e:
+    errs.append(type(e).__name__)
+try:
+    q.count(); errs.append("none")                      # ... every rank here
+except Exception as e:
+    errs.append(type(e).__name__)
+q.close()
+out["errors"] = errs
+out["after"] = G.gnrow(views["pred"])                   # the group is fine afterwards
+g.barrier()
+json.dump(out, open(sys.argv[3] + f".{rank}", "w"))
+gt.close(); g.close()
+dist.destroy_process_group()
+"""
+
+
+def test_three_processes_through_the_library_group_with_host_collectives(oracle, dfdb_mod, ctx, tmp_path):
+    """One process per GPU, the mode the 8-GPU run uses, exercised for real on a 1-GPU box: three processes on device 0 each hold one rank of a
+    dfdb_group whose exchanges go through the host's own collectives (dfdb_group_create_rank_callbacks over torch.distributed gloo; RCCL refuses ranks that
+    share a device).  Everything csrc/group.cpp does between processes runs: the all-reduce of the count and of {value, count}, the all-gather + exclusive
+    scan behind a range stage after a predicate, the all-gather of the packed unique / groupreduce records, rank-order results, and the fault agreement —
+    a DivideError only the last rank's rows reach comes back from the same call on EVERY rank (the others used to wait in the collective)."""
+    from dfdb import ir
+    n, bs, world = 300_007, 4096, 3
+    cols = _columns(oracle, n)
+    z = np.ones(n, np.int64); z[n - 777] = 0                 # a zero divisor in the last rank's block range only
+    cols = {"a": cols["a"], "x": cols["x"], "s": cols["s"], "z": z}
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    script = tmp_path / "rank_cb.py"
+    script.write_text(_CALLBACK_RANK_SCRIPT)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, path, str(tmp_path / "out")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    got = [json.load(open(str(tmp_path / "out") + f".{r}")) for r in range(world)]
+    a, x, s = ir.col(0), ir.col(1), ir.col(2)
+    want = {
+        "pred": ot.view().add_predicate(((a > 700_000) & (s != "sony")).to_ir()),
+        "range_after_pred": ot.view().add_predicate((a > 500_000).to_ir()).add_range(11, 3, 90_000),
+        "two_exchanges": ot.view().add_predicate((a % 2 == 0).to_ir()).add_range(10, 1, 100_000).add_predicate((s == "dell").to_ir()).add_indices([1, 5, 400, 4999, 10**9]),
+    }
+    strs = oracle.flat_to_strings(*cols["s"]) if isinstance(cols["s"], tuple) else list(cols["s"])
+    for name, ov in want.items():
+        w = ov.select_indices()
+        rows = w - 1
+        assert sum((g[name]["idx"] for g in got), []) == w.tolist(), name                       # rank order = table order
+        for g in got:
+            o = g[name]
+            assert o["total"] == len(w), name
+            assert o["sum_a"] == int(cols["a"][rows].sum()), name
+            if len(rows):
+                assert o["min_x"] == float(cols["x"][rows].min()) and o["max_x"] == float(cols["x"][rows].max()), name
+                assert abs(o["sum_x"] - float(cols["x"][rows].sum())) <= 64 * np.finfo(np.float64).eps * float(np.abs(cols["x"][rows]).sum()), name
+            sel = [strs[i] for i in rows.tolist()]
+            first = list(dict.fromkeys(sel))                                                     # distinct values in order of first appearance
+            assert o["unique_s"] == first, name
+            assert o["groups"][0] == first and o["groups"][1] == [sel.count(k) for k in first], name
+            assert o["groups"][2] == [int(sum(int(cols["a"][i]) for i in rows.tolist() if strs[i] == k)) for k in first], name
+        assert sum((g[name]["mat_a"] for g in got), []) == cols["a"][rows].tolist(), name
+    for g in got[:-1]:
+        assert g["errors"] == ["ZeroDivisionError"] * 4 + ["none", "ZeroDivisionError"], g["errors"]        # the healthy ranks hear of it at their next read
+    assert got[-1]["errors"] == ["ZeroDivisionError"] * 6, got[-1]["errors"]                              # the failing rank at once
+    assert all(g["after"] == len(want["pred"].select_indices()) for g in got)
