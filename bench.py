@@ -55,6 +55,7 @@ def cpu_baseline(rows: int, repeats: int):
     """The oracle (C restatement of the reference's block_streams path) on ONE host core over a bounded
     sample of the same workload: LZ4 block decode -> mask -> LogicalIndex -> row indices."""
     import numpy as np
+    import time
     from oracle import oracle as O
     from dfdb import ir
     x = O.gen_i64(SEED, 0, rows)
@@ -94,6 +95,29 @@ def cpu_baseline(rows: int, repeats: int):
             res["all_cores"] = dict(value=per * ncpu / best_mt, unit="rows/s", cores=ncpu, sample=f"{per * ncpu} rows split over {ncpu} threads")
     except Exception as e:      # context figure only: never fail the bench for it
         res["all_cores"] = dict(error=str(e))
+    # the other BASELINE configs on the same one core, bounded samples of the same seeded columns (the reference's path: LZ4 block decode of the required
+    # columns, mask, selection stages, projection gather block by block; materialize(::DFView) evaluates the selection twice — count pre-pass, quirk Q8 —
+    # and count() / sum() are two iterations of the view)
+    try:
+        n = max(1_000_000, rows // 4)
+        a, b, x = O.gen_i64(seed_of(0), 0, n), O.gen_i64(seed_of(1), 0, n), O.gen_f64(seed_of(2), 0, n)
+        t3 = O.Table(block_size=65536)
+        t3.add_column("a", a); t3.add_column("b", b); t3.add_column("x", x)
+        v3 = t3.view().add_predicate(((ir.col(0) > 683_771) & (ir.col(2) < 632.456)).to_ir()).set_projection([("b", ir.col(1).to_ir()), ("x", ir.col(2).to_ir())])
+        t0 = time.perf_counter(); m3 = v3.materialize(); s3 = time.perf_counter() - t0
+        t4 = O.Table(block_size=65536)
+        t4.add_column("s", O.gen_str(seed_of(0), 0, n)); t4.add_column("a", O.gen_i64(seed_of(1), 0, n))
+        v4 = t4.view().add_predicate((ir.col(0) == "sony").to_ir())
+        t0 = time.perf_counter(); m4 = v4.materialize(); s4 = time.perf_counter() - t0
+        t5 = O.Table(block_size=65536)
+        t5.add_column("a", a); t5.add_column("x", O.gen_f64(seed_of(1), 0, n)); t5.add_column("s", O.gen_str(seed_of(2), 0, n))
+        v5 = t5.view().add_predicate(((ir.col(0) > 683_771) & (ir.col(1) < 632.456) & (ir.col(2) != "sony")).to_ir()).set_projection([("x", ir.col(1).to_ir())])
+        t0 = time.perf_counter(); c5 = v5.nrow(); sx = v5.sum_f64(0); s5 = time.perf_counter() - t0
+        res["configs"] = {"sample_rows": n, "cores": 1, "kind": "port",
+                          "3": {"rows_per_s": n / s3, "selected": int(len(m3[0]))}, "4": {"rows_per_s": n / s4, "selected": int(len(m4[1]))},
+                          "5_shard": {"rows_per_s": n / s5, "count": int(c5), "sum_x": float(sx), "what": "nrow(v) + sum(v.x): two iterations, like the reference"}}
+    except Exception as e:
+        res["configs"] = dict(error=f"{type(e).__name__}: {e}")
     return res
 
 
