@@ -171,6 +171,9 @@ static void for_shards(dfdb_group* g, const std::function<void(int)>& fn) {
   for (int l = 0; l < n; l++) if (errs[(size_t)l]) throw Error(errs[(size_t)l]->code, errs[(size_t)l]->what());
 }
 
+// every collective entry point starts with a clean slate: a note left behind by an operation that died on its way to the exchange (a failed RCCL
+// call, a caller's collective that returned an error) must not be taken for this operation's
+static void fresh(dfdb_group* g) { g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear(); }
 static uint64_t fault_key_of(const Error& e) {
   const uint64_t code = (uint64_t)(e.code > 0 && e.code < 256 ? e.code : DFDB_ERR_DEVICE);
   return e.row != ~0ull ? (((e.row + 1) << 8) | code) : code;
@@ -404,6 +407,7 @@ static void group_destroy(dfdb_group* g) {
 static void plan_stage_bases(dfdb_gquery* gq) {
   if (gq->planned) return;
   dfdb_group* g = gq->gt->g;
+  fresh(g);                              // (planning is the first collective step of whatever operation asked for it)
   const size_t ns = gq->shard[0]->stages.size();
   if (exchanges(g))
     for (size_t k = 1; k < ns; k++) {
@@ -581,6 +585,7 @@ int32_t dfdb_group_set_option(dfdb_group* g, const char* key, int64_t value) {
 int32_t dfdb_group_barrier(dfdb_group* g) {   // every rank's engine stream has drained, on every rank
   return gguard([&] {
     GNEED(g);
+    fresh(g);
     for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, 2, 1); }
     exchange_reduce(g, {XSpec{2, 1, DFDB_I64, DFDB_AGG_SUM}});
     for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); HIP_CHECK(hipStreamSynchronize(g->ctx[(size_t)l]->stream)); }
@@ -591,6 +596,7 @@ int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t
   return gguard([&] {
     GNEED(g); GNEED(vals);
     if (n < 1 || n > kXSlots - 4) fail(DFDB_ERR_ARGUMENT, "1..%d values", kXSlots - 4);
+    fresh(g);
     for (int l = 0; l < g->nlocal(); l++) {
       HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
       for (int k = 0; k < n; k++) { int64_t b; memcpy(&b, &vals[(size_t)l * n + k], 8); put_slot(g, l, 4 + k, b); }
@@ -778,13 +784,14 @@ int32_t dfdb_group_query_reset(dfdb_gquery* gq) {
 /* nrow(v) over the whole table: per-shard scans, the stage-base exchanges a range-after-predicate needs, one all-reduce.
  * n == NULL: only enqueue (no host wait; the reduced count stays on the devices until a later call asks for it) */
 int32_t dfdb_group_count(dfdb_gquery* gq, int64_t* n) {
-  return gguard([&] { GNEEDQ(gq); if (!n) { group_count_enqueue(gq, false); return; } *n = group_count(gq); });
+  return gguard([&] { GNEEDQ(gq); fresh(gq->gt->g); if (!n) { group_count_enqueue(gq, false); return; } *n = group_count(gq); });
 }
 /* selected rows on every rank, in rank order (world values): what a caller needs to place sharded results */
 int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts) {
   return gguard([&] {
     GNEEDQ(gq); GNEED(counts);
     dfdb_group* g = gq->gt->g;
+    fresh(g);
     group_count(gq);
     for_shards_deferred(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
@@ -802,6 +809,7 @@ int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* ou
   return gguard([&] {
     GNEEDQ(gq);
     dfdb_group* g = gq->gt->g;
+    fresh(g);
     if (op == DFDB_AGG_COUNT) { const int64_t n = group_count(gq); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
     if (op != DFDB_AGG_SUM && op != DFDB_AGG_MIN && op != DFDB_AGG_MAX) fail(DFDB_ERR_ARGUMENT, "unknown aggregate %d", op);
     plan_stage_bases(gq);
@@ -1049,6 +1057,7 @@ static std::string merge_key(int32_t kdt, const GroupPart& p, int64_t j, int64_t
 
 static void group_reduce_all(dfdb_gquery* gq, int32_t key_p, int32_t val_p, int32_t op, bool with_stats) {
   dfdb_group* g = gq->gt->g;
+  fresh(g);
   gq->merged = GroupMerged{};
   plan_stage_bases(gq);
   const int nl = g->nlocal();

@@ -290,3 +290,31 @@ def test_sharded_unique_and_groupreduce_live_behind_the_abi():
         assert s in dfdb.SYMBOLS
     hdr = open(os.path.join(ROOT, "include", "dfdb.h")).read()
     assert "first appearance = lowest rank, then" in hdr and "fault key" in hdr
+
+
+def test_ctypes_structs_mirror_the_header():
+    """every struct that crosses the ABI by value or by pointer: the Python mirror has the header's fields, in the header's order, in the header's widths"""
+    import ctypes as C
+    import re
+    from dfdb import _native as N
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "dfdb.h")).read(), flags=re.S)
+    width = {"int32_t": 4, "int64_t": 8, "double": 8, "uint64_t": 8}
+    for cname, py in (("dfdb_device_info", N.DeviceInfo), ("dfdb_colinfo", N.ColInfo), ("dfdb_sizestats", N.SizeStats), ("dfdb_outcol", N.OutCol), ("dfdb_exchange_fns", N.ExchangeFns)):
+        body = re.search(r"typedef struct " + cname + r"\s*\{(.*?)\}\s*" + cname + ";", hdr, re.S).group(1)
+        want = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            fp = re.match(r"\w+ \(\*(\w+)\)\(", decl)                       # a function pointer member
+            if fp:
+                want.append((fp.group(1), C.sizeof(C.c_void_p))); continue
+            base = decl.split()[0]
+            for nm in decl[len(base):].split(","):
+                nm = nm.strip()
+                arr = re.match(r"(\w+)\[(\d+)\]", nm)
+                if arr:
+                    want.append((arr.group(1), int(arr.group(2)))); continue     # char name[128]
+                want.append((nm.replace("*", "").strip(), C.sizeof(C.c_void_p) if "*" in nm or "*" in base else width[base]))
+        got = [(n, C.sizeof(t)) for n, t in py._fields_]
+        assert got == want, (cname, got, want)
