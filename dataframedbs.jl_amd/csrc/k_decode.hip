@@ -224,7 +224,11 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     // far prefetch + byte production + flush of ONE superbatch out of the current record slot (info / bitsx / fard): T output bytes, nfar far sources
     auto produce = [&](uint32_t T, uint32_t nfar) {
           LZ4_COUNT(6, 1); LZ4_COUNT(7, (T + 63) / 64); LZ4_COUNT(10, nfar);
+#ifdef DFDB_LZ4_SKIP_FAR      // tools/bench_lz4 experiment only: what the far round trip costs (the output is WRONG without it)
+      if (false) {
+#else
       if (nfar) {
+#endif
         // far sources were flushed before this superbatch began (they lie > kRing - 64 - kBatchBytes behind op and at most
         // kFlush + 256 bytes are ever unflushed): 24 bytes each, HBM/L2 -> LDS, ONE memory round trip for the whole superbatch
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
