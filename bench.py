@@ -451,8 +451,7 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
     raise RuntimeError("unreachable: every configuration has a group")
 
 
-def run_config_legs(L, dfdb, G, args, rank, local, stream, grp):
-    out = {}
+def run_config_legs(L, dfdb, G, args, rank, local, stream, grp, out):
     sc = args.config_scale
     legs = [("3", lambda: {"3": config3_leg(L, dfdb, int(1_000_000_000 * sc), rank)}),
             ("4", lambda: config4_legs(L, dfdb, int(500_000_000 * sc), rank)),
@@ -460,10 +459,8 @@ def run_config_legs(L, dfdb, G, args, rank, local, stream, grp):
     for name, fn in legs:
         try:
             out.update(fn())
-        except Exception as e:      # extra figures: the headline line survives a failing leg, and says which one failed (every rank fails alike or the launcher stops)
-            out[name] = {"error": f"{type(e).__name__}: {e}"}
-            if L.world > 1:
-                raise
+        except Exception as e:      # extra figures: the headline line survives a failing leg and says which one failed.  A failure every rank meets alike
+            out[name] = {"error": f"{type(e).__name__}: {e}"}      # (a missing library, a refused option) lets all of them go on; one that leaves a rank alone in an exchange ends in the deadline
     return out
 
 
@@ -487,6 +484,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 legs (extra keys)")
     ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the config legs (functional runs; 1.0 = BASELINE.json's sizes)")
     ap.add_argument("--config-steps", type=int, default=None, help="timed steps per config leg (default: min(steps, 10), at least 3)")
+    ap.add_argument("--config-deadline", type=float, default=420.0, help="seconds the config legs may take before every rank ends its own process (rank 0 prints the line first)")
     ap.add_argument("--config5-host-shards", type=int, default=0, help="N = 1, functional: run the config-5 leg through a ONE-process host-exchange group of this many "
                     "shards on the device (every path of csrc/group.cpp but the RCCL calls)")
     args = ap.parse_args()
@@ -704,22 +702,40 @@ def main():
                 res["decode_scan"] = decode_scan_leg(dfdb, ctx, t, rows, max(3, min(args.steps, 10)), out.data_ptr(), cap, cnt.data_ptr(), torch.cuda.synchronize)
             except Exception as e:      # an extra figure: never fail the bench line for it
                 res["decode_scan"] = {"error": f"{type(e).__name__}: {e}"}
+    def emit(line):
+        sys.stdout.flush()
+        os.write(out_fd, (json.dumps(line) + "\n").encode())
+
     # ---- configs 3 / 4 / 5 on every rank (the column of config 2 goes first: the legs bring their own tables)
     if not args.no_configs:
+        # The legs are extra keys; the headline must survive them.  They exchange between ranks (barriers, the library's group): should a rank
+        # ever be left waiting in one (the N > 1 path has only run on one physical GPU so far), a deadline ends EVERY rank's process — rank 0 prints
+        # the line first, with whatever legs had finished and a note — instead of the whole run dying in the driver's timeout with nothing printed.
+        import threading
+        done_legs = {}
+
+        def deadline():
+            if rank == 0 and res is not None:
+                res["configs"] = dict(done_legs, error=f"the config legs did not finish within {args.config_deadline} s: the process was ended by its own deadline")
+                emit(res)
+            os._exit(0)
+        watchdog = threading.Timer(args.config_deadline, deadline)
+        watchdog.daemon = True
+        watchdog.start()
         ctx.set_option("placement_calibrate", 0)
         del out
         if not lib:
             t.close()
         torch.cuda.empty_cache()
         L = Legs(torch, dist, dev, ctx, world, rank, args.backend, args.config_steps or max(3, min(args.steps, 10)), peak)
-        legs = run_config_legs(L, dfdb, G, args, rank, local, stream_obj.cuda_stream, grp if lib else None)
+        legs = run_config_legs(L, dfdb, G, args, rank, local, stream_obj.cuda_stream, grp if lib else None, done_legs)
+        watchdog.cancel()
         if res is not None:
             res["configs"] = legs
     if res is not None:
         if not args.no_cpu and world == 1:      # the CPU baseline is an N=1, rank-0 figure
             res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)
-        sys.stdout.flush()
-        os.write(out_fd, (json.dumps(res) + "\n").encode())
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 

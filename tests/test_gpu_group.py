@@ -492,3 +492,16 @@ def test_three_processes_through_the_library_group_with_host_collectives(oracle,
         assert g["errors"] == ["ZeroDivisionError"] * 4 + ["none", "ZeroDivisionError"], g["errors"]        # the healthy ranks hear of it at their next read
     assert got[-1]["errors"] == ["ZeroDivisionError"] * 6, got[-1]["errors"]                              # the failing rank at once
     assert all(g["after"] == len(want["pred"].select_indices()) for g in got)
+
+
+def test_bench_deadline_keeps_the_headline(ctx):
+    """the config legs exchange between ranks; should one ever be left waiting in an exchange, a deadline ends every rank's process and rank 0 prints the
+    line first — headline intact, the finished legs, and a note — instead of the run dying silently in the driver's timeout"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "5000000", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-decode-leg",
+                        "--config-scale", "0.05", "--config-deadline", "0.05"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["value"] > 0 and r["roofline"]["frac"] > 0 and "did not finish within" in r["configs"]["error"]
