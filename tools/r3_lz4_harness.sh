@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3: K7 after the superbatch change — harness table, PMC passes, the engine's own tests and bench
+# round 3: K7 after the superbatch change — the harness table of profiles/r3_lz4_harness.txt, then the PMC passes of profiles/r3_pmc_lz4.txt
+# (tools/bench_lz4_noprof: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Idataframedbs.jl_amd/csrc tools/bench_lz4.hip -o tools/bench_lz4_noprof -ldl)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r3
 export TMPDIR=/tmp
@@ -9,4 +10,3 @@ for m in 1 2 5 6 3 4; do echo "== bench_lz4_noprof 8192 $m -1"; tools/bench_lz4_
 } > gpurun_out/r3/lz4_harness.txt 2>&1
 cat gpurun_out/r3/lz4_harness.txt | grep -v "^blocks" | paste - - | head -40
 bash tools/r3_k7_pmc.sh 15259 -1 > /dev/null 2>&1; cat gpurun_out/r3/k7pmc_15259/summary.txt | grep -E "INSTS_(VALU|SALU|LDS) |WAVE_CYCLES|RDREQ|WRREQ|LDS_IDX|BANK"
-timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/r3/tests_all.log 2>&1; echo "tests_all rc=$?"; tail -4 gpurun_out/r3/tests_all.log
