@@ -7,9 +7,11 @@
 // One wave owns a 4096-row compaction tile = 64 bitmap words, one word per lane.  Each lane expands the
 // set bits of its word into a per-wave LDS staging buffer of 16-bit in-tile positions at its exclusive
 // prefix (wave prefix-sum of popcounts), so the expensive part is O(max popcount in the wave) instead of
-// O(64) ballots; the wave then streams the staged positions out as fully coalesced 512-B stores at the
+// O(64) ballots; the wave then streams the staged positions out as fully coalesced stores at the
 // tile's global offset (exclusive scan of the per-1024-row counts produced by K1).  Output order is
-// table order (stable), as the reference guarantees.
+// table order (stable), as the reference guarantees.  K2 itself ships in the "wide" form since round 3
+// (k_compact_indices_wide: two adjacent ctiles per wave, 16-byte nontemporal stores, one pair per wave);
+// the gathers (K3) keep the one-ctile form.
 //   algorithmic bytes / row: 1/8 (bitmap) + sigma * 8 (index)  |  gather: 1/8 + sigma * 2 * width
 #include "device_utils.hpp"
 #include "kernels.hpp"
