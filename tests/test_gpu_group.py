@@ -505,3 +505,17 @@ def test_bench_deadline_keeps_the_headline(ctx):
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     assert r["value"] > 0 and r["roofline"]["frac"] > 0 and "did not finish within" in r["configs"]["error"]
+
+
+def test_bench_exchange_lib_over_two_ranks(ctx):
+    """`bench.py --gpus 2 --exchange lib` on one device over gloo: the HEADLINE step's count all-reduce goes through the library's group too (its exchanges
+    from the host's collectives here, RCCL on a real node), every rank generating its own block range of the one 2-shard table"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-on-device0", "--backend", "gloo", "--exchange", "lib", "--rows", "10000000",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--no-configs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "libdfdb_hip's group" in r["config"]["sharding"]
+    assert abs(r["config"]["global_selected"] / 2e7 - 0.1) < 0.002                       # both shards' survivors, reduced by the library
