@@ -24,6 +24,8 @@ round 3 (the corners engine and oracle could get wrong TOGETHER — they share a
   b  :: Bool             = [true, false, true, false, true]
   mb :: Union{Bool,Missing} = [true, missing, false, missing, true]
   big:: Int64            = [typemin(Int64), -1, 0, 1, typemax(Int64)]
+  us :: String           = ["é", "ß", "日本", "a", ""]
+  ns :: Union{String,Missing} = ["a", missing, "", missing, "b"]
 
     python tests/golden/make_ir_golden.py        (rewrites ir_golden.json next to this file)
 """
@@ -201,6 +203,45 @@ CASES += [
     ("three_valued_or", "(m .== 1) .| (a .> 0)", col(M) + ci(1) + op("EQ") + col(A) + ci(0) + op("GT") + op("OR"), "Missing(Bool)", [T, MISS, F, T, T], "(Mi == 1) | (A > 0)"),
 ]
 
+# ---- round 3, second batch: negative divisors, float rem / mod / div, exact Int-vs-Float comparison at the edges of the ranges, UTF-8 strings ----------
+US, NS = 12, 13
+CASES += [
+    ("rem_negative_divisor", "a .% -3", col(A) + ci(-3) + op("REM"), "Int64", [-1, -1, 0, 0, 1], "A % -3"),
+    ("idiv_negative_divisor", "a .÷ -3", col(A) + ci(-3) + op("IDIV"), "Int64", [2, 0, 0, -1, -3], "ir.div(A, -3)"),
+    ("float_rem_keeps_the_dividends_sign", "x .% 2.0", col(X) + cf(2.0) + op("REM"), "Float64", [0.5, -0.0, 1.0, 0.0, NAN], "Xf % 2.0"),
+    ("float_mod_takes_the_divisors_sign", "mod.(x, 2.0)", col(X) + cf(2.0) + op("MOD"), "Float64", [0.5, 0.0, 1.0, 0.0, NAN], "ir.mod(Xf, 2.0)"),
+    ("float_mod_negative_divisor", "mod.(x, -2.0)", col(X) + cf(-2.0) + op("MOD"), "Float64", [-1.5, -0.0, -1.0, -0.0, NAN], "ir.mod(Xf, -2.0)"),
+    ("float_idiv_truncates", "x .÷ 2.0", col(X) + cf(2.0) + op("IDIV"), "Float64", [0.0, -1.0, 1.0, 5e9, NAN], "ir.div(Xf, 2.0)"),
+    ("neg_float_flips_the_sign_of_zero", "-z", col(Z) + op("NEG"), "Float64", [0.0, -0.0, NAN, -1.0, 1.0], "-Zf"),
+    ("abs_float", "abs.(z)", col(Z) + op("ABS"), "Float64", [0.0, 0.0, NAN, 1.0, 1.0], "abs(Zf)"),
+    ("nan_is_not_equal_to_itself", "x .== x", col(X) + col(X) + op("EQ"), "Bool", [T, T, T, T, F], "Xf == Xf"),
+    ("nan_differs_from_itself", "x .!= x", col(X) + col(X) + op("NE"), "Bool", [F, F, F, F, T], "Xf != Xf"),
+    # Int64 / UInt64 against Float64 are compared as the exact real values: Float64(typemax(Int64)) is 2^63, which no Int64 equals
+    ("typemax_int64_is_not_2p63", "big .== 2.0^63", col(BIG) + cf(2.0 ** 63) + op("EQ"), "Bool", [F, F, F, F, F], "Big == 2.0 ** 63"),
+    ("every_int64_is_below_2p63", "big .< 2.0^63", col(BIG) + cf(2.0 ** 63) + op("LT"), "Bool", [T, T, T, T, T], "Big < 2.0 ** 63"),
+    ("typemin_int64_equals_minus_2p63", "big .== -2.0^63", col(BIG) + cf(-(2.0 ** 63)) + op("EQ"), "Bool", [T, F, F, F, F], "Big == -(2.0 ** 63)"),
+    ("int64_vs_fraction", "big .> -0.5", col(BIG) + cf(-0.5) + op("GT"), "Bool", [F, F, T, T, T], "Big > -0.5"),
+    ("uint64_equals_2p63_float", "w .== 2.0^63", col(W) + cf(2.0 ** 63) + op("EQ"), "Bool", [F, F, T, F, F], "Wc == 2.0 ** 63"),
+    ("every_uint64_is_below_2p64", "w .< 2.0^64", col(W) + cf(2.0 ** 64) + op("LT"), "Bool", [T, T, T, T, T], "Wc < 2.0 ** 64"),
+    ("uint64_max_is_not_2p64", "w .>= 2.0^64", col(W) + cf(2.0 ** 64) + op("GE"), "Bool", [F, F, F, F, F], "Wc >= 2.0 ** 64"),
+    ("uint64_vs_negative_float", "w .> -1.5", col(W) + cf(-1.5) + op("GT"), "Bool", [T, T, T, T, T], "Wc > -1.5"),
+    # Bool
+    ("not_bool", ".!b", col(B) + op("NOT"), "Bool", [F, T, F, T, F], "~Bc"),
+    ("bool_less_than_true", "b .< true", col(B) + cb(True) + op("LT"), "Bool", [F, T, F, T, F], "Bc < True"),
+    ("bool_equals_int", "b .== 1", col(B) + ci(1) + op("EQ"), "Bool", [T, F, T, F, T], "Bc == 1"),
+    # strings are compared byte-wise (= by code point for valid UTF-8); sizeof counts bytes
+    ("utf8_sizeof", "sizeof.(us)", col(US) + op("SIZEOF"), "Int64", [2, 2, 6, 1, 0], "ir.sizeof(Us)"),
+    ("utf8_equality", 'us .== "日本"', col(US) + cs("日本") + op("EQ"), "Bool", [F, F, T, F, F], 'Us == "日本"'),
+    ("utf8_order", 'us .< "z"', col(US) + cs("z") + op("LT"), "Bool", [F, F, F, T, T], 'Us < "z"'),
+    ("utf8_startswith", 'startswith.(us, "日")', col(US) + cs("日") + op("STARTSWITH"), "Bool", [F, F, T, F, F], 'ir.startswith(Us, "日")'),
+    ("string_ge", 's .>= "sony"', col(STR) + cs("sony") + op("GE"), "Bool", [F, T, F, F, T], 'St >= "sony"'),
+    ("empty_prefix_matches_everything", 'startswith.(s, "")', col(STR) + cs("") + op("STARTSWITH"), "Bool", [T, T, T, T, T], 'ir.startswith(St, "")'),
+    ("empty_suffix_matches_everything", 'endswith.(s, "")', col(STR) + cs("") + op("ENDSWITH"), "Bool", [T, T, T, T, T], 'ir.endswith(St, "")'),
+    ("nullable_string_equality_is_three_valued", 'ns .== "a"', col(NS) + cs("a") + op("EQ"), "Missing(Bool)", [T, MISS, F, MISS, F], 'Ns == "a"'),
+    ("nullable_string_ismissing", "ismissing.(ns)", col(NS) + op("ISMISSING"), "Bool", [F, T, F, T, F], "ir.ismissing(Ns)"),
+    ("nullable_string_coalesced_predicate", 'coalesce.(ns .== "a", false)', col(NS) + cs("a") + op("EQ") + cb(False) + op("COALESCE"), "Bool", [T, F, F, F, F], 'ir.coalesce(Ns == "a", False)'),
+]
+
 
 def main():
     out = {"comment": "hand-assembled from include/dfdb_ir.h by tests/golden/make_ir_golden.py; expected = Julia semantics",
@@ -208,7 +249,7 @@ def main():
                      "m": [1, None, 3, None, 0], "u": [0, 1, 127, 128, 255],
                      "i8": [-128, -1, 0, 1, 127], "w": [0, 1, 2 ** 63, 2 ** 63 + 5, 2 ** 64 - 1], "z": [-0.0, 0.0, "NaN", 1.0, -1.0],
                      "f": ["NaN" if v != v else v for v in F32COL], "b": [True, False, True, False, True], "mb": [True, None, False, None, True],
-                     "big": [TMIN, -1, 0, 1, TMAX], "block_size": 2},
+                     "big": [TMIN, -1, 0, 1, TMAX], "us": ["é", "ß", "日本", "a", ""], "ns": ["a", None, "", None, "b"], "block_size": 2},
            "opcodes": {k: v for k, v in sorted(S.items()) if k.startswith("DFIR_")},
            "dtypes": {k: v for k, v in sorted(S.items()) if k.startswith("DFDB_")},
            "cases": []}

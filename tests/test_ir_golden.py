@@ -30,7 +30,7 @@ def _columns():
             "i8": np.array(t["i8"], np.int8), "w": np.array(t["w"], np.uint64), "z": np.array([_fl(v) for v in t["z"]], np.float64),
             "f": np.array([_fl(v) for v in t["f"]], np.float32), "b": np.array(t["b"], np.bool_),
             "mb": np.ma.masked_array(np.array([bool(v) for v in t["mb"]], np.bool_), mask=[v is None for v in t["mb"]]),
-            "big": np.array(t["big"], np.int64)}
+            "big": np.array(t["big"], np.int64), "us": list(t["us"]), "ns": list(t["ns"])}
 
 
 def _check(case, got):
@@ -85,7 +85,7 @@ def test_header_python_and_julia_tables_agree():
 def test_ir_py_emits_the_golden_bytes():
     from dfdb import ir
     env = {"ir": ir, "A": ir.col(0), "Xf": ir.col(1), "St": ir.col(2), "Mi": ir.col(3), "Uc": ir.col(4),
-           "I8c": ir.col(5), "Wc": ir.col(6), "Zf": ir.col(7), "Ff": ir.col(8), "Bc": ir.col(9), "Mb": ir.col(10), "Big": ir.col(11)}
+           "I8c": ir.col(5), "Wc": ir.col(6), "Zf": ir.col(7), "Ff": ir.col(8), "Bc": ir.col(9), "Mb": ir.col(10), "Big": ir.col(11), "Us": ir.col(12), "Ns": ir.col(13)}
     for c in G["cases"]:
         e = eval(c["ir_py"], env)
         assert e.to_ir().hex() == c["hex"], (c["name"], e.to_ir().hex(), c["hex"])
