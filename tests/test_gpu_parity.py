@@ -224,7 +224,7 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
         assert_same(p, ov, dv)
 
 
-@pytest.mark.parametrize("pipe", [0, 1])             # K7 one wave per block / the two-wave pipeline (by default the block count chooses: these files are small)
+@pytest.mark.parametrize("pipe", [0, 1, 10, 15])     # K7 one wave per block (4-window superbatch), the two-wave pipeline, round 2's 8-window shape, the 7-waves-per-SIMD shape (by default the block count chooses between the first two: these files are small)
 @pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded data sets)
 def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
     """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
@@ -310,7 +310,7 @@ def test_open_table_errors(oracle, dfdb_mod, ctx, tmp_path):
         ot.view().materialize()
 
 
-@pytest.mark.parametrize("pipe", [0, 1])             # both forms of K7 (see test_lz4_decode_corner_cases)
+@pytest.mark.parametrize("pipe", [0, 1, 10, 15])     # every compiled form of K7 (see test_lz4_decode_corner_cases)
 @pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded damage sets)
 def test_lz4_decoders_survive_corrupt_blocks(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
     """LZ4_decompress_safe semantics (BlockStreams.jl:110-112): a damaged block either still decodes to `origin` bytes or raises
