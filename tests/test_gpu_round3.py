@@ -323,3 +323,55 @@ def test_reloading_a_column_forgets_its_compressed_blocks(oracle, dfdb_mod, ctx,
     finally:
         ctx.set_option("keep_compressed", 0)
         t.close()
+
+
+def test_callback_group_with_a_mirrored_peer_and_a_failing_collective(oracle, dfdb_mod, ctx):
+    """DFDB_EXCHANGE_CALLBACK in ONE process: rank 0 of a world of 2 whose collectives pretend that rank 1 holds exactly the same partial results
+    (all-reduce SUM doubles, MIN / MAX keep, all-gather repeats).  Deterministic coverage of the callback code paths — reductions, the stage-base gather,
+    the packed unique records — and of a caller's collective that FAILS: the call returns the device error, nothing is left behind, the next call works."""
+    from dfdb import group as G, _native as N, ir
+    fail = {"on": False}
+
+    def allreduce(vals, dtype, op):
+        if fail["on"]:
+            raise RuntimeError("the host's allreduce is down")
+        if op == N.AGG_SUM:
+            v = vals.view({ir.F64: np.float64, ir.U64: np.uint64}.get(dtype, np.int64))
+            with np.errstate(over="ignore"):
+                v += v
+
+    def allgather(send):
+        return send + send
+
+    g = G.Group.create_rank_callbacks(0, 0, 2, allreduce, allgather)
+    try:
+        assert (g.world, g.nlocal, g.first_rank, g.exchange) == (2, 1, 0, N.EXCHANGE_CALLBACK)
+        n, bs = 10 * 4096, 4096
+        a = oracle.gen_i64(0xABCD, 0, n)
+        cols = {"a": a, "k": (a % 5).astype(np.int64), "x": (a % 1000).astype(np.float64)}
+        gt = G.GroupTable.from_columns(g, cols, block_size=bs)          # rank 0 of 2 keeps the first five blocks
+        half = n // 2
+        v = gt.view()[("a", lambda a: a > 500_000), dfdb_mod.ALL]
+        mine = int((a[:half] > 500_000).sum())
+        assert G.gnrow(v) == 2 * mine                                   # the mirrored peer counted the same
+        assert G.gaggregate(v[dfdb_mod.ALL, ["a"]], N.AGG_SUM) == 2 * int(a[:half][a[:half] > 500_000].sum())
+        assert G.gaggregate(v[dfdb_mod.ALL, ["x"]], N.AGG_MAX) == float(cols["x"][:half][a[:half] > 500_000].max())
+        assert np.array_equal(G.gindices(v), np.flatnonzero(a[:half] > 500_000) + 1)
+        # a range stage after the predicate: the stage base of rank 0 is 0, the gather carries the peer's count
+        v2 = dfdb_mod.selection(v, dfdb_mod.jr(3, 2, 999))
+        assert np.array_equal(G.gindices(v2), (np.flatnonzero(a[:half] > 500_000) + 1)[2:999:2])
+        # unique / groupreduce: the peer's records repeat ours, the merge keeps first appearances and adds the counts
+        sel = a[:half] > 500_000
+        first = list(dict.fromkeys(cols["k"][:half][sel].tolist()))
+        assert G.gunique(v.k).tolist() == first
+        gr = G.ggroupreduce(v, "k", "a", "sum")
+        assert gr["k"].tolist() == first and gr["count"].tolist() == [2 * int((cols["k"][:half][sel] == k).sum()) for k in first]
+        # the host's collective fails: the error surfaces, and the group is usable again once the collective is back
+        fail["on"] = True
+        with pytest.raises(dfdb_mod.DfdbError, match="allreduce failed"):
+            G.gnrow(gt.view()[("a", lambda a: a > 100), dfdb_mod.ALL])
+        fail["on"] = False
+        assert G.gnrow(gt.view()[("a", lambda a: a > 100), dfdb_mod.ALL]) == 2 * int((a[:half] > 100).sum())
+        gt.close()
+    finally:
+        g.close()
