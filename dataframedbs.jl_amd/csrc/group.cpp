@@ -16,9 +16,16 @@
 //                                            ncclCommInitAll connects them (what a Julia session calling the drop-in gets)
 //   dfdb_group_create_rank(dev, id, r, G)    one process per GPU (bench.py under torch.distributed.run): ncclCommInitRank with an id
 //                                            made by dfdb_group_unique_id on rank 0 and handed round by the launcher
+//   dfdb_group_create_rank_callbacks(...)    one process per GPU whose host brings its own collectives (MPI, gloo): DFDB_EXCHANGE_CALLBACK
 // RCCL is loaded lazily (dlopen "librccl.so.1"): a single-GPU user never touches it, and a process that already holds RCCL (PyTorch)
 // shares that copy.  DFDB_EXCHANGE_HOST does the same exchanges through host memory; it exists for single-process groups whose
 // "ranks" share one physical GPU (functional tests on a 1-GPU box: RCCL refuses duplicate devices).
+//
+// Round 3: (1) a shard whose half of a collective call fails still takes part in the exchange — every exchange carries a fault key (MIN) and
+// all ranks raise the same error, the one of the lowest table row (for_shards_deferred / settle_fault); whether an exchange is needed is decided
+// by flags every rank changes alike, never by a shard's local state; (2) {value, count} of an aggregate travel in ONE exchange; (3) unique /
+// groupreduce over the whole table: per-shard device reduction, packed records all-gathered, merged by key in rank order (group_reduce_all);
+// (4) materialize with the result left sharded on the devices.
 #include "engine.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
