@@ -476,6 +476,7 @@ def main():
     ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
     ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores 0 plain, 1 nontemporal, 2 write-through (ctx option compact_store)")
     ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
+    ap.add_argument("--placement-column-candidates", type=int, default=None, help="A/B: fresh allocations of the column the calibration tries (ctx option placement_column_candidates; 0 = bitmaps only)")
     ap.add_argument("--placement-candidates", type=int, default=None, help="A/B: candidate bitmaps the calibration tries (ctx option placement_candidates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
@@ -552,25 +553,21 @@ def main():
         assert local_rows <= nblocks_per * 65536
     else:
         ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
-        # the resident column is scanned by every step: the engine's opt-in bitmap placement calibration pays here (its one-time cost is reported below)
-        ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
         if args.compact_store is not None:
             ctx.set_option("compact_store", args.compact_store)
         if args.placement_spacer_mb is not None:
             ctx.set_option("placement_spacer_mb", args.placement_spacer_mb)
         if args.placement_candidates is not None:
             ctx.set_option("placement_candidates", args.placement_candidates)
+        if args.placement_column_candidates is not None:
+            ctx.set_option("placement_column_candidates", args.placement_column_candidates)
         t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
         t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
         t.set_row_base(rank * rows)
-        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
+        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()       # library defaults: no calibration, the allocations as hipMalloc handed them out
         nsel = q.count()                                   # exact selected count from the first (untimed) execution
         local_rows = rows
     info = ctx.device_info()
-    # placement calibration happened inside that first execution (query.cpp: place_mask): what it saw
-    pl_n, pl_best = ctx.profile_get("placement_best_us")
-    _, pl_worst = ctx.profile_get("placement_worst_us")
-    _, pl_wall = ctx.profile_get("placement_wall_us")
     cap = nsel
     out = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
 
@@ -587,43 +584,14 @@ def main():
             if world > 1:
                 all_reduce(cnt)
 
-    for _ in range(args.warmup):
-        step()
-    # roofline leg: HIP event pairs around every launch, recorded on the launch stream DURING the timed steps and resolved
-    # after them (no host synchronisation inside the region: dfdb_ctx_profile_get folds them)
-    ctx.profile(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce(el, dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-    total_sel = gq.count() if lib else int(cnt.item())
-    total_rows = rows * world
-
-    kernels = {}
-    for k in ("scan_cmp", "scan_counts", "compact_indices"):
-        n, ms = ctx.profile_get(k)
-        if n:
-            kernels[k] = dict(launches=n, avg_ms=ms / n)
-    ctx.profile(False)
     peak = float(info.get("peak_hbm_gbps") or HBM_PEAK_GBPS)      # dfdb_ctx_device_info: 8000 on MI355X
     scan_row_bytes = 8 + 1 / 8 + 4 / 1024                          # ONE k_scan_cmp launch: 8 B/row column + 1/8 B/row bitmap + 4 B per 1024-row tile count
+    total_rows = rows * world
 
-    # ---- the same step with the library's DEFAULT options (placement calibration off): what a caller gets who sets nothing
+    # ---- first the step with the library's DEFAULT options (placement calibration off, the column and the bitmap where hipMalloc put them): what a
+    # caller gets who sets nothing.  It runs BEFORE the calibration, which moves the column.
     default_cfg = None
     if not lib and not args.no_placement:
-        ctx.set_option("placement_calibrate", 0)
-        q.close() if hasattr(q, "close") else None
-        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()  # a fresh query: its own bitmap, not the calibrated one the first query borrowed
         for _ in range(max(args.warmup, 1)):
             step()
         ctx.profile(True)
@@ -645,11 +613,49 @@ def main():
         n3, ms3 = ctx.profile_get("compact_indices")
         ctx.profile(False)
         sms = ms2 / n2 if n2 else None
-        default_cfg = {"what": "the same step with ctx option placement_calibrate = 0 (the library's default): a fresh query scanning into its own bitmap",
+        default_cfg = {"what": "the same step with the library's default options (ctx option placement_calibrate = 0), measured first: the column and the query's bitmap "
+                               "in the allocations hipMalloc handed out",
                        "value": total_rows * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "scan_cmp_avg_ms": sms, "compact_indices_avg_ms": ms3 / n3 if n3 else None,
                        "roofline_frac": (local_rows * scan_row_bytes / (sms * 1e-3) / 1e9 / peak) if sms else None,
                        "job_hbm_gbps": total_rows * (8 + 8 * nsel / local_rows) / (el2 / args.steps) / 1e9}
+        # the resident column is scanned by every step: the engine's opt-in placement calibration pays here (its one-time cost is reported below).
+        # A fresh query's first execution runs it (query.cpp: place_mask).
+        ctx.set_option("placement_calibrate", 1)
+        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
+        assert q.count() == nsel
+    pl_n, pl_best = ctx.profile_get("placement_best_us")
+    _, pl_worst = ctx.profile_get("placement_worst_us")
+    _, pl_wall = ctx.profile_get("placement_wall_us")
+    pc_n, pc_best = ctx.profile_get("placement_column_best_us")
+    _, pc_worst = ctx.profile_get("placement_column_worst_us")
 
+    for _ in range(args.warmup):
+        step()
+    # roofline leg: HIP event pairs around every launch, recorded on the launch stream DURING the timed steps and resolved
+    # after them (no host synchronisation inside the region: dfdb_ctx_profile_get folds them)
+    ctx.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        all_reduce(el, dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    total_sel = gq.count() if lib else int(cnt.item())
+
+    kernels = {}
+    for k in ("scan_cmp", "scan_counts", "compact_indices"):
+        n, ms = ctx.profile_get(k)
+        if n:
+            kernels[k] = dict(launches=n, avg_ms=ms / n)
+    ctx.profile(False)
     res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -687,8 +693,9 @@ def main():
                        "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py spawned its own ranks" if world > 1 else "single process"),
                        "device": info["name"], "global_selected": total_sel,
                        "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows, "one_time_seconds": pl_wall / 1e6,
-                                                  "what": "one-time: the scan timed against 9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in; "
-                                                          "`default_config` is the same step without it)"}
+                                                  "column_candidates_best_ms": pc_best / 1e3 if pc_n else None, "column_candidates_worst_ms": pc_worst / 1e3 if pc_n else None,
+                                                  "what": "one-time: the scan timed on fresh allocations of the column (device-to-device copies; the fastest becomes the column), then against "
+                                                          "9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in; `default_config` is the same step before it)"}
                                                  if pl_n else "off")},
             "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "GB/s",

@@ -116,8 +116,13 @@ void query_return_mask(dfdb_query* q) {
   std::swap(q->bitmap, c.mask_pref); c.mask_lent = false; q->mask_from = -1;
   q->executed_stages = -1; q->count = -1; q->prefix_valid = false;
 }
+// Round 3: it is the COLUMN's allocation that decides most of it.  Six 8-GB columns with the same contents in one process (tools/r3_column_placement.py): one
+// scans at 1.19-1.20 ms whatever bitmap it is paired with, one at 1.25-1.30, four at 1.28-1.32 — the nine bitmap candidates of one column differ by 1-4 %, the
+// columns by 9 %.  So the calibration first RE-PLACES the column: a few fresh allocations of its size (all held until the choice is made: a freed one would be
+// handed out again), the data copied device to device, the scan timed on each against the query's own bitmap; the fastest allocation becomes the column.
+// "placement_column_candidates" (default 8, at most 16; 0 = bitmaps only).  Costs candidates x (the column's size of free HBM + a copy + 3 scans), once per column.
 template <class Launch>
-static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t* bitmap, int64_t rows) */) {
+static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t* bitmap, int64_t rows, const void* column) */) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int64_t nrows = t->nrows;
   if (nrows < ((int64_t)1 << 26) || ctx_option(ctx, "placement_calibrate", 0) == 0) return;
@@ -140,11 +145,12 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     const int64_t sample = nrows;      // the WHOLE column: how a bitmap allocation pairs with the first eighth says little about the rest (measured)
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const void* colp = c.data.p;
     auto time_on = [&](uint64_t* bm) {
       float best = 1e30f;
       for (int r = 0; r < 3; r++) {
         HIP_CHECK(hipEventRecord(e0, s));
-        launch(bm, sample);
+        launch(bm, sample, colp);
         HIP_CHECK(hipEventRecord(e1, s));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -152,6 +158,26 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
       }
       return best;
     };
+    // ---- the column first
+    const int kCol = (int)std::min<int64_t>(16, std::max<int64_t>(0, ctx_option(ctx, "placement_column_candidates", 8)));
+    if (kCol > 0 && dt_base(c.dtype) != DFDB_STRING && c.data.bytes > 0 && free_b > (size_t)(kCol + 1) * c.data.bytes + (size_t)kCand * (bytes + spacer) + ((size_t)8 << 30)) {
+      std::vector<DevBuf> ccand((size_t)kCol);
+      float tcol = time_on(q->bitmap.as<uint64_t>()), tcol_worst = tcol; int cbest = -1;
+      for (int k = 0; k < kCol; k++) {
+        try { ccand[(size_t)k].ensure(c.data.bytes); } catch (const Error&) { break; }
+        HIP_CHECK(hipMemcpyAsync(ccand[(size_t)k].p, c.data.p, c.data.bytes, hipMemcpyDeviceToDevice, s));
+        colp = ccand[(size_t)k].p;
+        const float tk = time_on(q->bitmap.as<uint64_t>());
+        if (tk < tcol) { tcol = tk; cbest = k; }
+        if (tk > tcol_worst) tcol_worst = tk;
+      }
+      auto& pcb = ctx->prof["placement_column_best_us"]; pcb.launches++; pcb.ms += tcol * 1e3;
+      auto& pcw = ctx->prof["placement_column_worst_us"]; pcw.launches++; pcw.ms += tcol_worst * 1e3;
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (cbest >= 0 && tcol < 0.985f * tcol_worst) std::swap(c.data, ccand[(size_t)cbest]);      // the column lives in the fastest allocation from now on
+      colp = c.data.p;
+      ccand.clear();                                      // the others (and the old one) go back
+    }
     float tbest = time_on(q->bitmap.as<uint64_t>()), tworst = tbest; int kbest = -1;
     for (int k = 0; k < kCand; k++) {
       const float tk = time_on(cand[(size_t)k].as<uint64_t>());
@@ -411,10 +437,18 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     const ScanTerms tb0 = term_batches[0];
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
     const int wt0 = (int)ctx_option(ctx, "scan_wt_store", 1);
-    place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows) {
-      if (tb0.n == 1 && tb0.t[0].op2 < 0 && tb0.t[0].pre == 0) launch_scan_cmp(s, tb0.t[0].col, tb0.t[0].dtype, tb0.t[0].op, tb0.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr, wt0);
-      else launch_scan_terms(s, tb0, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
+    const void* const col_before = t->cols[(size_t)term_ords[0]].data.p;
+    place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows, const void* colp) {
+      ScanTerms tbx = tb0;                                          // the calibration may be trying another allocation of the first term's column
+      for (int k = 0; k < tbx.n; k++) if (tbx.t[k].col == col_before) tbx.t[k].col = colp;
+      if (tbx.n == 1 && tbx.t[0].op2 < 0 && tbx.t[0].pre == 0) launch_scan_cmp(s, tbx.t[0].col, tbx.t[0].dtype, tbx.t[0].op, tbx.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr, wt0);
+      else launch_scan_terms(s, tbx, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
     });
+    const void* const col_after = t->cols[(size_t)term_ords[0]].data.p;
+    if (col_after != col_before) {                                  // the column was re-placed: every term of this stage that reads it follows
+      for (ScanTerms& tbk : term_batches) for (int k = 0; k < tbk.n; k++) if (tbk.t[k].col == col_before) tbk.t[k].col = col_after;
+      for (ScanTerms& tbk : or_batches) for (int k = 0; k < tbk.n; k++) if (tbk.t[k].col == col_before) tbk.t[k].col = col_after;
+    }
   }
   for (size_t bi = 0; bi < term_batches.size(); bi++) {
     const ScanTerms& tb = term_batches[bi];

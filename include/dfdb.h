@@ -110,9 +110,13 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
  *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
- *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself against a few candidate bitmap allocations
- *                     and the column keeps the fastest for the queries that scan it (query.cpp: place_mask; default 0: 27 scans + 0.03-1.4 s of allocations once
- *                     per column buys ~3 % of K1 on average; bench.py turns it on); "placement_spacer_mb" (12288) / "placement_candidates" (8) size the search
+ *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself on a few fresh allocations of the column (device-to-device
+ *                     copies: the fastest BECOMES the column, the others are released) and then against a few candidate bitmap allocations, and the column
+ *                     keeps the fastest bitmap for the queries that scan it (query.cpp: place_mask; default 0: ~60 scans, copies of the column and 0.03-1.4 s of
+ *                     allocations once per column buy ~3.5 % of K1 on average and halve its spread; bench.py turns it on).  "placement_column_candidates"
+ *                     (8, at most 16; 0 = leave the column where it is; needs that many times the column's size of free HBM for the duration),
+ *                     "placement_spacer_mb" (12288) / "placement_candidates" (8) size the search.  Pointers obtained from the table before the calibration
+ *                     are not affected: the ABI never hands out a resident column's address
  *   "compact_store"   K2's form: 0 / 1 / 2 = one 4096-row ctile per wave step with plain / nontemporal / write-through 8-byte stores (1 was round 2's default:
  *                     nontemporal is slower alone, but the scan that follows runs 4-7 % faster); 3 (default) / 4 = two ctiles per wave and nontemporal / plain
  *                     16-byte stores, one pair per wave; 5 / 6 = the same with 4 KB instead of 8 KB of LDS per wave.  "compact_grid_cap" bounds its workgroups

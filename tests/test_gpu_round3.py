@@ -375,3 +375,45 @@ def test_callback_group_with_a_mirrored_peer_and_a_failing_collective(oracle, df
         gt.close()
     finally:
         g.close()
+
+
+def test_placement_calibration_moves_the_column_and_changes_no_result(dfdb_mod):
+    """ctx option placement_calibrate (query.cpp: place_mask): the first fresh-mask scan of a column of >= 2^26 rows times the scan on fresh
+    allocations of the column (device-to-device copies; the fastest becomes the column) and on candidate bitmaps.  Whatever it picks, every result
+    of the table — the selection, its count, the materialized columns, a second query borrowing nothing — is what it was before."""
+    n = (1 << 26) + 12_345
+    x = (np.arange(n, dtype=np.int64) * 2_654_435_761) % 1_000_003
+    y = np.arange(n, dtype=np.int32)
+    c = dfdb_mod.Context(0)
+    try:
+        t = dfdb_mod.DFTable.from_columns({"x": x, "y": y}, ctx=c)
+        want = np.flatnonzero(x > 900_000).astype(np.int64) + 1
+        q0 = t[("x", lambda x: x > 900_000), dfdb_mod.ALL]._query()
+        assert np.array_equal(q0.indices(), want)
+        assert c.profile_get("placement_best_us")[0] == 0                # off by default
+        c.set_option("placement_calibrate", 1)
+        c.set_option("placement_spacer_mb", 64)
+        c.set_option("placement_column_candidates", 3)
+        q1 = t[("x", lambda x: x > 900_000), dfdb_mod.ALL]._query()
+        assert q1.count() == want.size
+        nb, best = c.profile_get("placement_best_us"); _, worst = c.profile_get("placement_worst_us")
+        nc, cbest = c.profile_get("placement_column_best_us"); _, cworst = c.profile_get("placement_column_worst_us")
+        assert nb == 1 and nc == 1 and 0 < best <= worst and 0 < cbest <= cworst
+        assert np.array_equal(q1.indices(), want)
+        q2 = t[("x", lambda x: x > 900_000), dfdb_mod.ALL]._query()      # the calibrated bitmap is lent to one query at a time: this one keeps its own
+        assert np.array_equal(q2.indices(), want)
+        assert c.profile_get("placement_best_us")[0] == 1                # once per column
+        q0.reset()
+        assert np.array_equal(q0.indices(), want)                        # a query prepared before the column moved
+        got = dfdb_mod.materialize(t[("x", lambda x: x > 900_000), dfdb_mod.ALL])
+        assert np.array_equal(got["x"].to_numpy(), x[want - 1]) and np.array_equal(got["y"].to_numpy(), y[want - 1])
+        full = dfdb_mod.materialize(t[dfdb_mod.jr(n - 70_000, n), ["x"]])
+        assert np.array_equal(full["x"].to_numpy(), x[-70_001:])
+        # a two-term conjunction on the moved column and an OR over it
+        q3 = t[("x", lambda x: (x > 900_000) & (x < 950_000)), dfdb_mod.ALL]._query()
+        assert np.array_equal(q3.indices(), np.flatnonzero((x > 900_000) & (x < 950_000)).astype(np.int64) + 1)
+        q4 = t[("x", lambda x: (x < 10) | (x > 1_000_000)), dfdb_mod.ALL]._query()
+        assert np.array_equal(q4.indices(), np.flatnonzero((x < 10) | (x > 1_000_000)).astype(np.int64) + 1)
+        t.close()
+    finally:
+        c.close()
