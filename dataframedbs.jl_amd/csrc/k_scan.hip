@@ -51,6 +51,45 @@ __device__ __forceinline__ uint32_t tile_popcount(uint64_t myword, int lane) {
 // lanes below this one that are set in m
 __device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
+// Capture: the selected values of a 64-row word are a run of ~6 at 10 % selectivity; stored straight to the tile's slot they are sixteen sub-line
+// stores per tile.  They go to a 2-KB per-wave LDS buffer instead (one ds_write_b64 per word: nothing waits for it) and leave as contiguous
+// NONTEMPORAL stores when the tile ends (or the buffer fills: selectivities above 25 %).  Measured on 1e9 rows at 10 % (tools/r3_scan2.py, one box):
+// k_scan_cmp with capture 1.90 ms -> 1.55 with nontemporal stores alone (the plain scan is 1.25: written through L2 the captured values cost four
+// times their share of the bytes); the two-term scan 3.62-3.75 -> 3.14-3.19 with the values packed in registers by ds_permute (a round trip per
+// word) -> below with the LDS buffer.
+#ifndef DFDB_CAP_STORE
+#define DFDB_CAP_STORE 1
+#endif
+constexpr uint32_t kCapBuf = 256;      // values per wave
+__device__ __forceinline__ void cap_store(uint64_t* p, uint64_t v) {
+#if DFDB_CAP_STORE == 1
+  __builtin_nontemporal_store(v, p);
+#elif DFDB_CAP_STORE == 2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  *p = v;
+#endif
+}
+struct CapQueue {
+  uint64_t* lds;                        // this wave's kCapBuf slots
+  uint32_t run = 0, out = 0;            // values in the buffer, values already stored (both wave-uniform)
+  __device__ __forceinline__ explicit CapQueue(uint64_t* l) : lds(l) {}
+};
+__device__ __forceinline__ void cap_flush(CapQueue& cq, uint64_t* __restrict__ stage, int lane) {
+  wave_lds_fence();
+  for (uint32_t i = (uint32_t)lane; i < cq.run; i += 64u) cap_store(stage + cq.out + i, cq.lds[i]);
+  wave_lds_fence();
+  cq.out += cq.run; cq.run = 0;
+}
+__device__ __forceinline__ void cap_push(CapQueue& cq, uint64_t* __restrict__ stage, uint64_t m, uint64_t bits, int lane) {
+  const uint32_t cnt = (uint32_t)__popcll(m);                       // wave-uniform
+  if (cq.run + cnt > kCapBuf) cap_flush(cq, stage, lane);
+  if ((m >> lane) & 1ull) cq.lds[cq.run + rank_in(m)] = bits;
+  cq.run += cnt;
+}
+__device__ __forceinline__ void cap_finish(CapQueue& cq, uint64_t* __restrict__ stage, int lane) { if (cq.run) cap_flush(cq, stage, lane); }
+template <typename T> __device__ __forceinline__ uint64_t bits_of(T v) { static_assert(sizeof(T) <= 8, ""); uint64_t b = 0; __builtin_memcpy(&b, &v, sizeof(T)); return b; }
+
 // CAP: the values of the selected rows are also written, compacted per 1024-row tile, to cap[tile*1024 + rank in tile]:
 // a projection of the predicate column itself is then a contiguous copy per tile (k_compact_captured) instead of a gather
 // that re-reads ~81 % of the column's 128-B lines at 10 % selectivity (late materialization: the scan already holds the values)
@@ -59,7 +98,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
                                                      uint32_t* __restrict__ tile_counts, int64_t nrows, int64_t ntiles, T* __restrict__ cap, int wt_store) {
   // CAP: the tile's selected values go straight to the tile's slot, a contiguous run per 64-row word (merged into full lines in L2).  Staging them in
   // LDS for full 512-byte stores (32 KB per workgroup: 5 workgroups per CU instead of 8) measured 3-4 % slower.
-  T* stage = nullptr;
+  uint64_t* stage = nullptr;
+  __shared__ uint64_t cap_lds[CAP ? kWavesPerBlock * kCapBuf : 1];
+  uint64_t* const cap_mine = cap_lds + (CAP ? (threadIdx.x >> 6) * kCapBuf : 0);
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -88,17 +129,18 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
         T v[kWordsPerTile];
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];   // 16 independent coalesced loads in flight; NT: streamed once
-        uint32_t run = 0;
-        if (CAP) stage = cap + base;
+        CapQueue cq(cap_mine);
+        if (CAP) stage = (uint64_t*)(cap + base);
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) {
           uint64_t m = __ballot(cmp_op<OP, T>(v[j], c));
           if (lane == l0 + j) myword = m;
-          if (CAP) { if ((m >> lane) & 1ull) stage[run + rank_in(m)] = v[j]; run += (uint32_t)__popcll(m); }
+          if (CAP) cap_push(cq, stage, m, bits_of(v[j]), lane);
         }
+        if (CAP) cap_finish(cq, stage, lane);
       } else {
-        uint32_t run = 0;
-        if (CAP) stage = cap + base;
+        CapQueue cq(cap_mine);
+        if (CAP) stage = (uint64_t*)(cap + base);
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) {
           const int64_t row = base + j * 64 + lane;
@@ -106,8 +148,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
           if (row < nrows) { x = p[j * 64]; r = cmp_op<OP, T>(x, c); }
           uint64_t m = __ballot(r);
           if (lane == l0 + j) myword = m;
-          if (CAP) { if (r) stage[run + rank_in(m)] = x; run += (uint32_t)__popcll(m); }
+          if (CAP) cap_push(cq, stage, m, bits_of(x), lane);
         }
+        if (CAP) cap_finish(cq, stage, lane);
       }
     }
     if (AND_EXISTING) myword &= existing;
@@ -317,10 +360,11 @@ template <int EXTRA> __device__ __forceinline__ uint64_t agg_identity_bits(int d
 // loaded values in 32 VGPRs until the mask was complete: +0.75 ms on the two-term scan of 1e9 rows).
 template <typename T, int EXTRA>
 __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, uint64_t before,
-                                                   uint64_t* stage, uint32_t& run, T& lsum, int l0, uint32_t sel2 = 0, uint64_t cbits2 = 0) {
+                                                   uint64_t* stage, uint32_t& run, T& lsum, int l0, uint32_t sel2 = 0, uint64_t cbits2 = 0, uint64_t* cap_lds = nullptr) {
   const T* p = (const T*)colv + base + lane;
   const T c = from_bits<T>(cbits), c2 = from_bits<T>(cbits2);
   uint64_t myword = 0;
+  CapQueue cq(cap_lds);
   const bool full = base + kTile <= nrows;
   T v[kWordsPerTile];
 #pragma unroll
@@ -336,9 +380,10 @@ __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cb
     const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel) && (sel2 == 0 || cmp_sel<T>(v[j], c2, sel2))) & bj;
     if (lane == l0 + j) myword = m;
     const bool mine = (m >> lane) & 1ull;
-    if (EXTRA == 1) { if (mine) { uint64_t bits; __builtin_memcpy(&bits, &v[j], 8); stage[run + rank_in(m)] = bits; } run += (uint32_t)__popcll(m); }
+    if (EXTRA == 1) cap_push(cq, stage, m, bits_of(v[j]), lane);
     if (EXTRA >= 2) { if (mine) lsum = agg_combine<T, EXTRA>(lsum, v[j]); }
   }
+  if (EXTRA == 1) { cap_finish(cq, stage, lane); run = cq.out; }
   return myword;
 }
 
@@ -357,6 +402,8 @@ template <bool AND_EXISTING, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
                                                        int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out) {
   uint64_t* stage = nullptr;      // EXTRA 1: the tile's slot in extra_out (see k_scan_cmp CAP)
+  __shared__ uint64_t cap_lds[EXTRA == 1 ? kWavesPerBlock * kCapBuf : 1];
+  uint64_t* const cap_mine = cap_lds + (EXTRA == 1 ? (threadIdx.x >> 6) * kCapBuf : 0);
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -463,15 +510,15 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
         if (EXTRA == 1) stage = extra_out + base;   // straight to the tile's slot: a contiguous run per 64-row word, merged in L2
         if (tm.dtype == DFDB_F64) {
           double ls = agg_identity<double, EXTRA>();
-          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
+          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
           if (EXTRA >= 2) { ls = wave_agg<double, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
         } else if (tm.dtype == DFDB_I64) {
           int64_t ls = agg_identity<int64_t, EXTRA>();
-          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
+          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
           if (EXTRA >= 2) { ls = wave_agg<int64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = (uint64_t)ls; }
         } else {
           uint64_t ls = agg_identity<uint64_t, EXTRA>();
-          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2);
+          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
           if (EXTRA >= 2) { ls = wave_agg<uint64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = ls; }
         }
       }
@@ -485,12 +532,136 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
   }
 }
 
+// The two-column conjunction `(a OP c1) & (b OP c2)` over 8-byte columns (BASELINE configs 3 and 5; docs/src/index.md:503-517) with both
+// column types known at compile time and the two read streams software-pipelined: while the sixteen values of a tile of `a` are compared, the
+// loads of the same tile of `b` and then of the NEXT tile of `a` are already in flight (k_scan_terms takes one term after another through a
+// dtype switch: a wave waits for sixteen loads, compares, and only then asks for the next sixteen).  EXTRA as in k_scan_terms, on `b`.
+template <typename TA, typename TB, int EXTRA>
+__global__ __launch_bounds__(kBlock) void k_scan_pair(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
+                                                      int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out) {
+  __shared__ uint64_t cap_lds[EXTRA == 1 ? kWavesPerBlock * kCapBuf : 1];
+  uint64_t* const cap_mine = cap_lds + (EXTRA == 1 ? (threadIdx.x >> 6) * kCapBuf : 0);
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const ScanTerm& ta = terms.t[0];
+  const ScanTerm& tb = terms.t[1];
+  const uint32_t sela = op_sel(ta.op), sela2 = ta.op2 >= 0 ? op_sel(ta.op2) : 0u;
+  const uint32_t selb = op_sel(tb.op), selb2 = tb.op2 >= 0 ? op_sel(tb.op2) : 0u;
+  const TA ca = from_bits<TA>(ta.cbits), ca2 = from_bits<TA>(ta.cbits2);
+  const TB cb = from_bits<TB>(tb.cbits), cb2 = from_bits<TB>(tb.cbits2);
+  const TA* __restrict__ cola = (const TA*)ta.col;
+  const TB* __restrict__ colb = (const TB*)tb.col;
+  const int64_t ngroups = (ntiles + 3) / 4;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    const int64_t t0 = g * 4;
+    const int nk = ntiles - t0 < 4 ? (int)(ntiles - t0) : 4;
+    uint64_t acc = 0;
+    if ((t0 + 4) * kTile <= nrows) {
+      // ---- four full tiles: the pipelined form
+      const TA* pa = cola + t0 * kTile + lane;
+      const TB* pb = colb + t0 * kTile + lane;
+      TA va[kWordsPerTile]; TB vb[kWordsPerTile];
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) va[j] = __builtin_nontemporal_load(pa + j * 64);
+#pragma unroll
+      for (int j = 0; j < kWordsPerTile; j++) vb[j] = __builtin_nontemporal_load(pb + j * 64);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int l0 = 16 * k;
+        uint64_t wa = 0;
+        if (sela2) {
+#pragma unroll
+          for (int j = 0; j < kWordsPerTile; j++) { const uint64_t m = __ballot(cmp_sel<TA>(va[j], ca, sela) && cmp_sel<TA>(va[j], ca2, sela2)); if (lane == l0 + j) wa = m; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kWordsPerTile; j++) { const uint64_t m = __ballot(cmp_sel<TA>(va[j], ca, sela)); if (lane == l0 + j) wa = m; }
+        }
+        if (k < 3) {
+#pragma unroll
+          for (int j = 0; j < kWordsPerTile; j++) va[j] = __builtin_nontemporal_load(pa + (k + 1) * kTile + j * 64);
+        }
+        CapQueue cq(cap_mine);
+        TB ls = agg_identity<TB, EXTRA>();
+        uint64_t* stage = EXTRA == 1 ? extra_out + (t0 + k) * kTile : nullptr;
+#pragma unroll
+        for (int j = 0; j < kWordsPerTile; j++) {
+          uint64_t m = __ballot(cmp_sel<TB>(vb[j], cb, selb) && (selb2 == 0 || cmp_sel<TB>(vb[j], cb2, selb2)));
+          if (EXTRA) {
+            const uint64_t aj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wa, l0 + j) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wa >> 32), l0 + j) << 32;     // word j of a's mask
+            m &= aj;
+            const bool mine = (m >> lane) & 1ull;
+            if (EXTRA == 1) cap_push(cq, stage, m, bits_of(vb[j]), lane);
+            if (EXTRA >= 2) { if (mine) ls = agg_combine<TB, EXTRA>(ls, vb[j]); }
+            if (lane == l0 + j) acc = m;
+          } else if (lane == l0 + j) acc = m & wa;
+        }
+        if (k < 3) {
+#pragma unroll
+          for (int j = 0; j < kWordsPerTile; j++) vb[j] = __builtin_nontemporal_load(pb + (k + 1) * kTile + j * 64);
+        }
+        if (EXTRA == 1) cap_finish(cq, stage, lane);
+        if (EXTRA >= 2) { ls = wave_agg<TB, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[t0 + k] = b; } }
+      }
+    } else {
+      // ---- the column's last group: tile by tile, bounds checked
+      uint64_t wa = 0;
+      for (int k = 0; k < nk; k++) wa |= term_word<TA>(ta.col, ta.cbits, sela, (t0 + k) * kTile, nrows, lane, 16 * k, sela2, ta.cbits2);
+      if (EXTRA) {
+        for (int k = 0; k < nk; k++) {
+          uint32_t run = 0;
+          TB ls = agg_identity<TB, EXTRA>();
+          acc |= term_word_last<TB, EXTRA>(tb.col, tb.cbits, selb, (t0 + k) * kTile, nrows, lane, wa, EXTRA == 1 ? extra_out + (t0 + k) * kTile : nullptr, run, ls, 16 * k, selb2, tb.cbits2, cap_mine);
+          if (EXTRA >= 2) { ls = wave_agg<TB, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[t0 + k] = b; } }
+        }
+      } else {
+        uint64_t wb = 0;
+        for (int k = 0; k < nk; k++) wb |= term_word<TB>(tb.col, tb.cbits, selb, (t0 + k) * kTile, nrows, lane, 16 * k, selb2, tb.cbits2);
+        acc = wa & wb;
+      }
+    }
+    uint32_t cnt = (uint32_t)__popcll(acc);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    __hip_atomic_store(&bitmap[g * 64 + lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, see k_scan_cmp
+    if ((lane & 15) == 0 && (lane >> 4) < nk) tile_counts[t0 + (lane >> 4)] = cnt;
+  }
+}
+template <typename TA, typename TB>
+static void launch_pair_e(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, int extra, uint64_t* eo, dim3 g, dim3 b) {
+  switch (extra) {
+    case 1:  hipLaunchKernelGGL((k_scan_pair<TA, TB, 1>), g, b, 0, s, terms, bitmap, tc, nrows, ntiles, eo); break;
+    case 2:  hipLaunchKernelGGL((k_scan_pair<TA, TB, 2>), g, b, 0, s, terms, bitmap, tc, nrows, ntiles, eo); break;
+    case 3:  hipLaunchKernelGGL((k_scan_pair<TA, TB, 3>), g, b, 0, s, terms, bitmap, tc, nrows, ntiles, eo); break;
+    case 4:  hipLaunchKernelGGL((k_scan_pair<TA, TB, 4>), g, b, 0, s, terms, bitmap, tc, nrows, ntiles, eo); break;
+    default: hipLaunchKernelGGL((k_scan_pair<TA, TB, 0>), g, b, 0, s, terms, bitmap, tc, nrows, ntiles, eo); break;
+  }
+}
+bool scan_pair_applies(const ScanTerms& terms, bool and_existing) {
+  if (and_existing || terms.n != 2 || terms.combine_or || terms.t[0].pre || terms.t[1].pre) return false;
+  const int da = terms.t[0].dtype, db = terms.t[1].dtype;
+  return (da == DFDB_I64 || da == DFDB_F64) && (db == DFDB_I64 || db == DFDB_F64);
+}
+// true when the pair kernel took the launch: an AND of exactly two plain comparisons (or intervals) on Int64 / Float64 columns over a fresh mask
+static bool launch_scan_pair(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, bool and_existing, int extra, uint64_t* eo) {
+  if (!scan_pair_applies(terms, and_existing)) return false;
+  const int da = terms.t[0].dtype, db = terms.t[1].dtype;
+  const dim3 g(grid_for_tiles((ntiles + 3) / 4)), b(kBlock);
+  if (da == DFDB_I64 && db == DFDB_I64) launch_pair_e<int64_t, int64_t>(s, terms, bitmap, tc, nrows, ntiles, extra, eo, g, b);
+  else if (da == DFDB_I64) launch_pair_e<int64_t, double>(s, terms, bitmap, tc, nrows, ntiles, extra, eo, g, b);
+  else if (db == DFDB_I64) launch_pair_e<double, int64_t>(s, terms, bitmap, tc, nrows, ntiles, extra, eo, g, b);
+  else launch_pair_e<double, double>(s, terms, bitmap, tc, nrows, ntiles, extra, eo, g, b);
+  return true;
+}
+
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows, bool and_existing,
-                       int extra, void* extra_out) {
+                       int extra, void* extra_out, int pair) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   const dim3 g(grid_for_tiles((ntiles + 3) / 4)), b(kBlock);
   uint64_t* eo = (uint64_t*)extra_out;
+  if (pair && launch_scan_pair(s, terms, bitmap, tile_counts, nrows, ntiles, and_existing, extra, eo)) return;
   if (extra == 1 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
   else if (extra == 2 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);

@@ -41,7 +41,10 @@ void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint
 // extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
 // extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
-                       bool and_existing, int extra = 0, void* extra_out = nullptr);
+                       bool and_existing, int extra = 0, void* extra_out = nullptr,
+                       int pair = 1 /* ctx option "scan_pair": two plain 8-byte terms go to the pipelined k_scan_pair */);
+// whether launch_scan_terms hands these terms to k_scan_pair (pair != 0): an AND of exactly two plain comparisons / intervals on Int64 / Float64 columns, fresh mask
+bool scan_pair_applies(const ScanTerms& terms, bool and_existing);
 // captured values (per-tile compact) -> the output column: out[prefix[tile] + k] = cap[tile*1024 + k]
 void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap);
 

@@ -442,7 +442,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       ScanTerms tbx = tb0;                                          // the calibration may be trying another allocation of the first term's column
       for (int k = 0; k < tbx.n; k++) if (tbx.t[k].col == col_before) tbx.t[k].col = colp;
       if (tbx.n == 1 && tbx.t[0].op2 < 0 && tbx.t[0].pre == 0) launch_scan_cmp(s, tbx.t[0].col, tbx.t[0].dtype, tbx.t[0].op, tbx.t[0].cbits, bm, q->tile_counts.as<uint32_t>(), rows, false, nt, nullptr, wt0);
-      else launch_scan_terms(s, tbx, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr);
+      else launch_scan_terms(s, tbx, bm, q->tile_counts.as<uint32_t>(), rows, false, 0, nullptr, (int)ctx_option(ctx, "scan_pair", 1));
     });
     const void* const col_after = t->cols[(size_t)term_ords[0]].data.p;
     if (col_after != col_before) {                                  // the column was re-placed: every term of this stage that reads it follows
@@ -475,7 +475,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
                       ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr, (int)ctx_option(ctx, "scan_wt_store", 1));
     } else {
       LaunchTimer lt(ctx, "scan_terms");
-      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr);
+      const int pair = (int)ctx_option(ctx, "scan_pair", 1);
+      if (pair && scan_pair_applies(tb, have)) prof_note(ctx, "scan_terms.pair");
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr, pair);
     }
     have = true;
   }

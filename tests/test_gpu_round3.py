@@ -417,3 +417,62 @@ def test_placement_calibration_moves_the_column_and_changes_no_result(dfdb_mod):
         t.close()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("kinds", ["ii", "if", "fi", "ff"])
+def test_two_column_conjunctions_every_form(dfdb_mod, kinds, pair):
+    """`(a OP c1) & (b OP c2)` over Int64 / Float64 columns (docs/src/index.md:503-517) through the pipelined pair kernel (ctx option scan_pair = 1)
+    and through the generic term kernel (0): the selection, the projected last-term column (kept by the scan in an LDS-staged capture buffer: sparse,
+    dense enough to flush in the middle of a tile, and all rows), and sum / minimum / maximum over it, on full 4096-row groups, a partial group and
+    a ragged last tile."""
+    n = 4096 * 5 + 1024 * 2 + 777
+    rng = np.random.default_rng(hash(kinds) & 0xffff)
+    def col(k):
+        return rng.integers(-1000, 1000, n).astype(np.int64) if k == "i" else np.round(rng.normal(0, 500, n), 3)
+    a, b = col(kinds[0]), col(kinds[1])
+    if kinds[1] == "f":
+        b[rng.integers(0, n, 5)] = np.nan                       # NaN rows never satisfy an ordered comparison and poison min / max when selected
+    c = dfdb_mod.Context(0)
+    try:
+        c.set_option("scan_pair", pair)
+        t = dfdb_mod.DFTable.from_columns({"a": a, "b": b}, ctx=c)
+        c.profile(True)
+        assert t[(t.a >= 0) & (t.b <= 0), dfdb_mod.ALL]._query().count() == int(((a >= 0) & (b <= 0)).sum())
+        assert c.profile_get("scan_terms")[0] == 1 and c.profile_get("scan_terms.pair")[0] == pair      # which kernel took it
+        c.profile(False)
+        for lo_a, hi_b in ((900, 900), (0, 0), (-2000, 2000), (-2000, -2000)):      # ~0.3 %, 25 %, every row, none
+            for form in ("plain", "interval"):
+                if form == "plain":
+                    v = t[(t.a >= lo_a) & (t.b <= hi_b), ["b"]]
+                    want = (a >= lo_a) & (b <= hi_b)
+                else:
+                    v = t[(t.a >= lo_a) & (t.a < 1500) & (t.b <= hi_b) & (t.b > -1500), ["b"]]
+                    want = (a >= lo_a) & (a < 1500) & (b <= hi_b) & (b > -1500)
+                rows = np.flatnonzero(want)
+                q = v._query()
+                assert np.array_equal(q.indices(), rows.astype(np.int64) + 1), (kinds, pair, lo_a, hi_b, form)
+                got = dfdb_mod.materialize(v)["b"].to_numpy()
+                assert np.array_equal(got, b[rows], equal_nan=True), (kinds, pair, lo_a, hi_b, form)
+                if rows.size:
+                    sel = b[rows]
+                    q2 = v._query()
+                    got_sum = q2.aggregate(dfdb_mod.AGG_SUM, 0)
+                    if kinds[1] == "i":
+                        assert got_sum == int(sel.sum()), (kinds, pair, form)
+                    elif np.isnan(sel).any():
+                        assert np.isnan(got_sum)
+                    else:
+                        assert abs(got_sum - float(np.sum(sel))) <= 64 * np.finfo(np.float64).eps * float(np.abs(sel).sum()) + 1e-300
+                    for op, f in ((dfdb_mod.AGG_MIN, np.min), (dfdb_mod.AGG_MAX, np.max)):
+                        q3 = v._query()
+                        r = q3.aggregate(op, 0)
+                        w = f(sel)
+                        assert (np.isnan(r) and np.isnan(w)) or r == w, (kinds, pair, form, op)
+        # the single-term scan keeps its own column the same way
+        for thr in (900, 0, -2000):
+            v = t[t.a >= thr, ["a"]]
+            assert np.array_equal(dfdb_mod.materialize(v)["a"].to_numpy(), a[a >= thr])
+        t.close()
+    finally:
+        c.close()
