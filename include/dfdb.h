@@ -109,6 +109,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
 /* tuning knobs (defaults are what the benchmarks use; the others keep measured alternatives selectable for A/B runs):
  *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
  *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
+ *   "scan_pair"       1 = an AND of exactly two plain comparisons / intervals on Int64 / Float64 columns runs in the pipelined two-column kernel (default 1;
+ *                     0 = the generic multi-term kernel)
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
  *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself on a few fresh allocations of the column (device-to-device
  *                     copies: the fastest BECOMES the column, the others are released) and then against a few candidate bitmap allocations, and the column
