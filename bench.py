@@ -243,8 +243,9 @@ class Legs:
     """shared plumbing of the config legs: every rank runs the same leg on its own shard; a leg's time is the MAX over ranks of the wall time of
     `steps` back-to-back steps (barrier + device sync on both sides, like the headline); per-kernel times are rank 0's HIP-event averages"""
 
-    def __init__(self, torch, dist, dev, ctx, world, rank, backend, steps, peak):
+    def __init__(self, torch, dist, dev, ctx, world, rank, backend, steps, peak, calibrate=0):
         self.torch, self.dist, self.dev, self.ctx, self.world, self.rank, self.backend, self.steps, self.peak = torch, dist, dev, ctx, world, rank, backend, steps, peak
+        self.calibrate = calibrate                          # ctx option placement_calibrate of the legs' contexts (the headline's setting)
 
     def barrier(self):
         if self.world > 1:
@@ -285,7 +286,7 @@ class Legs:
     def record(self, rows, selected, sec, ks, bytes_per_gpu, what, **extra):
         gbps = bytes_per_gpu / sec / 1e9
         r = {"what": what, "rows_per_gpu": rows, "selected_per_gpu": selected, "ms_per_step": sec * 1e3, "steps": self.steps, "kernels_avg_ms": ks,
-             "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world / sec,
+             "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world / sec, "placement_calibrate": self.calibrate,
              "roofline": {"bound": "hbm", "achieved": gbps, "peak": self.peak, "unit": "GB/s", "frac": gbps / self.peak,
                           "what": "algorithmic bytes of the whole job per GPU (SURVEY.md section 8d) / step time"}}
         r.update(extra)
@@ -394,6 +395,8 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
             own = grp = G.Group.create_rank_torch(local, stream=stream)
     if grp is not None:
         gctx = grp.ctx(0)
+        if host_shards <= 1:
+            gctx.set_option("placement_calibrate", L.calibrate)
         gt = G.GroupTable.new(grp)
         gt.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(0), total)
         gt.add_generated("x", dfdb.GEN_F64_U2000, seed_of(1), total)
@@ -729,12 +732,13 @@ def main():
         watchdog = threading.Timer(args.config_deadline, deadline)
         watchdog.daemon = True
         watchdog.start()
-        ctx.set_option("placement_calibrate", 0)
+        calibrate = 0 if (args.no_placement or args.config5_host_shards > 1) else 1   # the legs' tables stay resident and are scanned every step, like the headline's
+        ctx.set_option("placement_calibrate", calibrate)
         del out
         if not lib:
             t.close()
         torch.cuda.empty_cache()
-        L = Legs(torch, dist, dev, ctx, world, rank, args.backend, args.config_steps or max(3, min(args.steps, 10)), peak)
+        L = Legs(torch, dist, dev, ctx, world, rank, args.backend, args.config_steps or max(3, min(args.steps, 10)), peak, calibrate)
         legs = run_config_legs(L, dfdb, G, args, rank, local, stream_obj.cuda_stream, grp if lib else None, done_legs)
         watchdog.cancel()
         if res is not None:
