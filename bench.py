@@ -209,6 +209,9 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
         ctx.profile(False)
         return el, {k: (ms / n if n else None) for k, (n, ms) in prof.items()}
 
+    ctx.set_option("lz4_index", 0)                        # the decoder as a first decode of these blocks runs it: no sequence-start index
+    el_p, k_p = timed(step_unfused)
+    ctx.set_option("lz4_index", 1)                        # (the library's default: the untimed step inside timed() records the index, the timed ones decode with it)
     el_u, k_u = timed(step_unfused)
     ctx.set_option("decode_on_scan", 1)
     try:
@@ -222,8 +225,13 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
            "lz4_decode_scan_avg_ms": k_f["lz4_decode_scan"], "decoded_GBps": rows * 8 / (k_f["lz4_decode_scan"] * 1e-3) / 1e9 if k_f["lz4_decode_scan"] else None,
            "unfused": {"rows_per_s": rows / el_u, "ms_per_step": el_u * 1e3, "lz4_decode_avg_ms": ms7, "scan_cmp_avg_ms": k_u["scan_cmp"],
                        "decoded_GBps": rows * 8 / (ms7 * 1e-3) / 1e9 if ms7 else None},
+           "without_index": {"rows_per_s": rows / el_p, "ms_per_step": el_p * 1e3, "lz4_decode_avg_ms": k_p["lz4_decode"],
+                             "decoded_GBps": rows * 8 / (k_p["lz4_decode"] * 1e-3) / 1e9 if k_p["lz4_decode"] else None,
+                             "what": "the unfused step with ctx option lz4_index = 0: K7 as a first decode of these blocks runs it (candidate decode + chain walk for every superbatch)"},
+           "sequence_index_bytes": st["compressed"] // 8,
            "what": "compressed-resident column (reference LZ4 blocks in HBM) -> K7 decode of every block FUSED with the predicate (bitmap + tile counts leave the "
-                   "decoder) -> count scan -> K2 indices, per step; `unfused` = K7, then K1 over the decoded column"}
+                   "decoder) -> count scan -> K2 indices, per step; `unfused` = K7, then K1 over the decoded column.  The column's first resident decode recorded "
+                   "where its LZ4 sequences start (one bit per compressed byte, ctx option lz4_index); these steps decode with that index, `without_index` without"}
     t2.close()
     return res
 

@@ -23,6 +23,8 @@ struct Column {
   // sit in the file stay in HBM with their descriptors, and dfdb_table_decode_resident re-runs K7 from them into `data`
   DevBuf comp, comp_blocks, comp_status;
   int64_t comp_nblocks = 0;
+  DevBuf comp_index;            // one bit per byte of comp: where an LZ4 sequence starts (recorded by the first resident decode, read by the later ones)
+  int comp_index_state = 0;     // 0: not recorded yet, 1: recorded
   // placement calibration (query.cpp: place_mask): the selection bitmap this column's scans run fastest against, found once by timing
   // the scan against a few candidate allocations; lent to one query at a time
   DevBuf mask_pref;
@@ -151,6 +153,7 @@ int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entri
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp
+int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index);   // table.cpp: 0 / 1 (record) / 2 (use) for launch_lz4_decode*
 int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
 void ctx_destroy(dfdb_ctx* c);
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp

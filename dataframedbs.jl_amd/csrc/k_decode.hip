@@ -77,10 +77,16 @@ __device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int o
 // table: at 1 526 blocks the chip is a quarter full and a block takes as long as it takes).  Sequences only the one-sequence path handles are
 // executed by wave 0 once wave 1 has drained; ownership of the ring and of the output position passes through LDS control words.
 // OCC: waves per SIMD the register allocation must leave room for; FARMAX: far-source slots per superbatch (24 bytes of LDS each)
-template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE, int OCC = (PIPE ? 4 : 5), int FARMAX = 64>
+// INDEX: a column that keeps its LZ4 blocks in HBM is decoded again and again (dfdb_table_decode_resident, decode_on_scan), and where its sequences
+// start never changes.  INDEX = 1 records that while decoding — one bit per compressed byte, set where a sequence starts — and INDEX = 2 decodes WITH
+// it: the start bits of the superbatch's windows come out of a 64-dword register window of the index (three v_readlane + a funnel shift per window)
+// instead of the candidate decode of every position, the next^2 / next^4 / next^8 tables, the chain walk and the fill-in (phases 1 and 2: 40 % of the
+// vector and a third of the LDS instructions of a superbatch); which sequences the batch takes is decided where their fields are decoded anyway (3b).
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE, int OCC = (PIPE ? 4 : 5), int FARMAX = 64, int INDEX = 0>
 __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
-                                                               LzScan sc) {
+                                                               LzScan sc, uint32_t* __restrict__ index) {
+  static_assert(INDEX == 0 || !PIPE, "the two-wave pipeline neither records nor reads the index");
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = FARMAX;                // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
   constexpr uint32_t kWords = kBatchBytes / 32;  // start-bit words per superbatch
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     uint32_t wbase = 0, wlo = 0, whi = 0;
     int err = 0;
     uint32_t extstops = 0;             // v5: tokens with a length of 15 met by the one-sequence path
+    uint32_t iw = 0; uint64_t ibase = ~0ull;   // INDEX 2: index dwords [ibase / 32 + lane], ibase = the window's first bit (a multiple of 32; ~0: nothing loaded)
 #ifdef DFDB_LZ4_PROF
     uint64_t pf_acc[32] = {}; uint64_t pf_t0 = __builtin_readcyclecounter(); const uint64_t pf_start = pf_t0;
 #endif
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         // bytes).  The EXT one also takes a length of 15 that continues in ONE more byte (a 255 there — lengths >= 270 / 274 — still
         // leaves the sequence to the one-sequence path): two more LDS reads per candidate, sequences that jump over whole windows.
         // A block switches to it for good once the one-sequence path has met two such tokens.
+        uint64_t RECM[W];                // INDEX 1: the start bits the walk found (the EXT walk may run on past a sequence phase 3b rejects: only the accepted prefix is real)
         auto windows = [&](auto extc) {
           constexpr bool EXT = decltype(extc)::value;
           uint32_t NX[W];
@@ -483,6 +491,10 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             FL[w] = (FL[w] | (RP[w] & ge3)) & (NX[w] >> 22) & 1u;                 // bit 22: a sequence the batch takes (a parked start that it does not take is marked too)
             MASK[w] = __ballot(FL[w] != 0u);
           }
+          if (INDEX == 1) {
+#pragma unroll
+            for (int w = 0; w < W; w++) RECM[w] = MASK[w];                      // recorded once phase 3b has said which of them the batch takes
+          }
           // (nseq <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
 #pragma unroll
           for (int w = 0; w < W; w++) {
@@ -495,7 +507,35 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           LZ4_PROF(14);
         };
         const bool ext_mode = extstops >= 2u;
-        if (ext_mode) windows(std::true_type{}); else windows(std::false_type{});
+        if constexpr (INDEX == 2) {
+          // ---- phases 1-3a from the index: the start bits of the W windows, every start's position at its ordinal
+          bits[lane & (kBatchBytes / 32 - 1)] = 0;
+          const uint64_t gbit = (uint64_t)blk.src_off + ip;                 // the index bit of input position ip
+          if (gbit < ibase || gbit + 64u * W + 96u > ibase + 2048u) { ibase = gbit & ~31ull; iw = index[(ibase >> 5) + lane]; }
+          const uint32_t o0 = (uint32_t)(gbit - ibase);
+          // every lane fetches the dword that holds ITS bit (ds_bpermute out of the register window: no LDS memory, and the W fetches are in flight
+          // together) — the scalar form (three v_readlane and a 64-bit funnel shift per window) cost ~25 scalar instructions and a VALU -> SGPR
+          // crossing per window, on the one scalar unit the CU's four SIMDs share
+          uint32_t WD[W];
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t bp = o0 + 64u * (uint32_t)w + lane;
+            WD[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((bp >> 3) & ~3u), (int)iw);
+          }
+          const uint32_t left = in_len - ip;                                   // input bytes from ip on: bits at or past in_len are the next block's
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint32_t rel = 64u * (uint32_t)w + lane, bp = o0 + rel;
+            const bool st = ((WD[w] >> (bp & 31u)) & 1u) != 0u && rel < left;
+            const uint64_t m = __ballot(st);
+            if (st) {
+              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              if (ord < (uint32_t)kSeqMax) info[ord].x = rel;
+            }
+            nseq += (uint32_t)__builtin_popcountll(m);
+          }
+          if (nseq > (uint32_t)kSeqMax || nseq == 0u) { err = 9; break; }    // not an index of this stream
+        } else { if (ext_mode) windows(std::true_type{}); else windows(std::false_type{}); }
         LZ4_PROF(11);
         if (nseq) {
           wave_lds_fence();
@@ -517,7 +557,10 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             const uint32_t inpos = spos - ip + 1u + (le ? 1u : 0u);             // its literals, relative to ip
             // EXT form only: a length that continues past its one extension byte, or a far source longer than the 24 prefetched bytes,
             // belongs to the one-sequence path: the superbatch ends in front of it
-            const bool reject = ext_mode && ((me && m1 == 255u) || (offset + 64u > (uint32_t)kRing && ml > 24u));
+            // INDEX 2: nothing has looked at this sequence yet — what the candidate phase decides per position (can the batch take it at all?) is decided here
+            const bool rej_idx = INDEX == 2 && (ext_mode ? ((le && e1 == 255u) || !(opos + 2u + (me ? 1u : 0u) < in_len))
+                                                         : (token >= 0xf0u || (token & 15u) == 15u || !(spos + lit + 3u < in_len)));
+            const bool reject = rej_idx || (ext_mode && ((me && m1 == 255u) || (offset + 64u > (uint32_t)kRing && ml > 24u)));
             const uint32_t tot = lit + ml;                                       // (0 for a lane past the last sequence)
             const uint32_t incl = T + wave_incl_scan(tot);
             const uint32_t ostart = incl - tot;
@@ -551,6 +594,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             nacc += na;
             nfar += (uint32_t)__builtin_popcountll(farmask & (na >= 64u ? ~0ull : ((1ull << na) - 1ull)));
             const uint32_t nvalid = nseq - r0 < 64u ? nseq - r0 : 64u;
+            if (INDEX == 2 && na == nvalid) consumed = rl(opos + 2u + (me ? 1u : 0u) - ip, nvalid - 1u);   // where the sequence after the last one starts
             if (na < nvalid) {                                                   // cut here: the next superbatch starts with sequence r0 + na
               consumed = rl(spos - ip, na);
               nonsimple = ((~okmask >> na) & 1ull) != 0;                          // stopped by a sequence only the one-sequence path takes
@@ -560,6 +604,22 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           (void)nacc;
         }
         LZ4_PROF(12);
+        if (INDEX == 1 && lane == 0) {
+          // record: the start bits of the sequences this superbatch takes — the walked starts in front of `consumed` (accepted sequences are a prefix in
+          // position order; the start at `consumed` is the next superbatch's, or the one-sequence path's, to record)
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            uint64_t m = RECM[w];
+            const uint32_t lim = consumed > 64u * (uint32_t)w ? consumed - 64u * (uint32_t)w : 0u;
+            if (lim < 64u) m &= (1ull << lim) - 1ull;
+            if (m == 0) continue;
+            const uint64_t gb = (uint64_t)blk.src_off + ip + 64u * (uint32_t)w;
+            const uint32_t sh = (uint32_t)(gb & 63ull);
+            unsigned long long* iw64 = (unsigned long long*)index + (gb >> 6);
+            atomicOr(iw64, (unsigned long long)(m << sh));
+            if (sh) atomicOr(iw64 + 1, (unsigned long long)(m >> (64u - sh)));
+          }
+        }
         if (T) {
           if (__ballot(bad) != 0 || T > out_len - op) { err = 5; break; }
           wave_lds_fence();
@@ -603,6 +663,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         owned = true;
       }
       ensure(ip);
+      if (INDEX == 1 && lane == 0) { const uint64_t gb = (uint64_t)blk.src_off + ip; atomicOr((unsigned long long*)index + (gb >> 6), 1ull << (gb & 63ull)); }
       const uint64_t t64 = fetch64(ip);
       const uint32_t token = (uint32_t)t64 & 255u;
       ip++;
@@ -739,7 +800,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
 // (The four earlier decoders — plain global round trips, LDS staging, register-window parser, one-window batches: 26-54 GB/s — were
 // dropped from the library in round 2; git history and DESIGN.md §10 keep what they taught.)
 // pipe: -1: by block count, 0: one wave per block, 1: two-wave pipeline (ctx option "lz4_pipeline", tools/bench_lz4)
-void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, int pipe) {
+void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, int pipe, uint32_t* index, int index_mode) {
   if (nblocks <= 0) return;
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
@@ -749,21 +810,38 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   // 64 far slots (91 VGPRs, 7.7 KB: 5 waves) gave 404-412; +4 ... +17 % on every body tried (1:n 396 -> 438, h mod 1000 370 -> 384, runs 364 -> 391,
   // String 400 -> 431, incompressible 945 -> 1076, zeros 1195 -> 1406 GB/s).  Asking for 7 waves (72 VGPRs, 24 far slots) gave 415, for 8 (64 VGPRs:
   // 4 spills) 396, 8 windows at 6 waves 428: past six waves per SIMD the LDS pipeline and instruction issue are what the waves share, not latency.
-  if (pipe == 10) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
-  if (pipe == 15) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}); return; }
+  if (pipe == 10) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr); return; }
+  if (pipe == 15) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr); return; }
+  if (index && index_mode == 2 && pipe >= 20) {      // tools/bench_lz4 only: other shapes of the indexed form
+    if (pipe == 20) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+    else if (pipe == 21) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 48, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+    else if (pipe == 22) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+    else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 8, 24, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+    return;
+  }
+  if (pipe >= 20) pipe = 0;
   // the two-wave pipeline needs 128 VGPRs per wave: 4 waves per SIMD = 8 workgroups per CU = 2048 blocks resident at once, and a block takes ~3.3 ms
   // there however few there are (763 blocks 2.6 ms, 1526 3.3 ms, 2048 3.4 ms = 312 GB/s; 2560 blocks need a second round: 5.5 ms, where one wave per
   // block takes 5.3); superbatches of 4 windows in the pipeline are slower (1526 blocks: 214 vs 242 GB/s: twice the hand-offs)
   if (pipe == 1 || (pipe < 0 && nblocks <= 2048))
-    hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+    hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr);
+  else if (index && index_mode == 2)
+    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+  else if (index && index_mode == 1)
+    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
   else
-    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{});
+    hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr);
 }
+// whether launch_lz4_decode would take (record or read) an index for this many blocks under this pipeline setting
+bool lz4_decode_takes_index(int32_t nblocks, int pipe) { return !(pipe == 1 || (pipe < 0 && nblocks <= 2048)) && pipe != 10 && pipe != 15; }
 // decode + `value OP c` over an 8-byte column in one pass: dst receives the decoded column, sc.bitmap / sc.counts what K1 would write
-void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc) {
+void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc,
+                            uint32_t* index, int index_mode) {
   if (nblocks <= 0) return;
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
-  hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc);
+  if (index && index_mode == 2) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
+  else if (index && index_mode == 1) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
+  else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, nullptr);
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

@@ -153,9 +153,12 @@ struct Lz4Block {      // one (column, block) unit of work
   int64_t dst_off;     // where the decoded body goes inside the body arena
 };
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status,
-                       int pipe = -1 /* -1: two waves per block when there are fewer blocks than wave slots, 0: never, 1: always (ctx option "lz4_pipeline") */);
+                       int pipe = -1 /* -1: two waves per block when there are fewer blocks than wave slots, 0: never, 1: always (ctx option "lz4_pipeline") */,
+                       uint32_t* index = nullptr, int index_mode = 0 /* 1: record where the sequences start (one bit per byte of src, zeroed by the caller), 2: decode with it */);
+bool lz4_decode_takes_index(int32_t nblocks, int pipe);
 // K7 fused with the first predicate of a scan (decode -> scan fusion): 8-byte columns whose blocks start on 1024-row tiles
 struct LzScan { uint64_t* bitmap; uint32_t* counts; uint64_t cbits; int32_t dtype; int32_t op; };
-void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc);
+void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc,
+                            uint32_t* index = nullptr, int index_mode = 0);
 
 }  // namespace dfdb

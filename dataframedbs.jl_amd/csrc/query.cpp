@@ -461,9 +461,11 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       Column& fc = t->cols[(size_t)term_ords[0]];
       const int fdt = tb.t[0].dtype;
       if (fc.comp_nblocks > 0 && !dt_nullable(fc.dtype) && (fdt == DFDB_I64 || fdt == DFDB_U64 || fdt == DFDB_F64) && t->block_size % kTileRows == 0) {
+        const int imode = column_lz4_index(ctx, fc, true);
         LaunchTimer lt(ctx, "lz4_decode_scan");
+        prof_note(ctx, imode == 2 ? "lz4_decode_scan.indexed" : imode == 1 ? "lz4_decode_scan.recording" : "lz4_decode_scan.plain");
         launch_lz4_decode_scan(s, fc.comp.as<uint8_t>(), fc.data.as<uint8_t>(), fc.comp_blocks.as<Lz4Block>(), (int32_t)fc.comp_nblocks, fc.comp_status.as<int32_t>(),
-                               LzScan{q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), tb.t[0].cbits, fdt, tb.t[0].op});
+                               LzScan{q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), tb.t[0].cbits, fdt, tb.t[0].op}, fc.comp_index.as<uint32_t>(), imode);
         have = true;
         continue;
       }

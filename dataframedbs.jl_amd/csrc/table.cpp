@@ -316,7 +316,7 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
   // what an earlier load of this column kept is stale now, whatever this load keeps (a reload with keep_compressed = 0 left the old
   // descriptors behind and dfdb_table_decode_resident / decode_on_scan would have decoded them into the new array)
   HIP_CHECK(hipStreamSynchronize(s));
-  c.comp_nblocks = 0; c.comp.release(); c.comp_blocks.release(); c.comp_status.release();
+  c.comp_nblocks = 0; c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release(); c.comp_index_state = 0;
   if (!is_str && !is_null && nb && ctx_option(ctx, "keep_compressed", 0) != 0) {   // the compressed blocks stay: dfdb_table_decode_resident
     c.comp = std::move(staged); c.comp_blocks = std::move(dblocks); c.comp_status = std::move(dstatus); c.comp_nblocks = nb;
   }
@@ -428,8 +428,26 @@ void table_decode_resident(dfdb_table* t, int32_t ordinal) {
   if (!c.comp_nblocks) fail(DFDB_ERR_ARGUMENT, "column %s holds no compressed blocks (load it with option keep_compressed = 1)", c.name.c_str());
   dfdb_ctx* ctx = t->ctx;
   for (dfdb_query* q : t->queries) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }
+  const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
+  const int mode = column_lz4_index(ctx, c, lz4_decode_takes_index((int32_t)c.comp_nblocks, pipe));
   LaunchTimer lt(ctx, "lz4_decode");
-  launch_lz4_decode(ctx->stream, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), (int)ctx_option(ctx, "lz4_pipeline", -1));
+  prof_note(ctx, mode == 2 ? "lz4_decode.indexed" : mode == 1 ? "lz4_decode.recording" : "lz4_decode.plain");
+  launch_lz4_decode(ctx->stream, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), pipe,
+                    c.comp_index.as<uint32_t>(), mode);
+}
+
+// The sequence-start index of a column's resident LZ4 blocks (k_decode.hip INDEX): the first decode that can take it records it, the later ones decode with it.
+// Returns launch_lz4_decode's index_mode (0: none — ctx option "lz4_index" = 0, or a launch form that takes none).
+int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index) {
+  if (!form_takes_index || ctx_option(ctx, "lz4_index", 1) == 0 || !c.comp.p) return 0;
+  if (!c.comp_index.p) {
+    const size_t bytes = (c.comp.bytes + 7) / 8 + 1024;                  // + the 64-dword register window's reach past the last bit
+    c.comp_index.ensure(bytes);
+    HIP_CHECK(hipMemsetAsync(c.comp_index.p, 0, c.comp_index.bytes, ctx->stream));
+    c.comp_index_state = 0;
+  }
+  if (c.comp_index_state == 0) { c.comp_index_state = 1; return 1; }     // this launch records (stream order makes it complete before the next one reads)
+  return 2;
 }
 
 void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,

@@ -224,15 +224,9 @@ def test_table_files_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
         assert_same(p, ov, dv)
 
 
-@pytest.mark.parametrize("pipe", [0, 1, 10, 15])     # K7 one wave per block (4-window superbatch), the two-wave pipeline, round 2's 8-window shape, the 7-waves-per-SIMD shape (by default the block count chooses between the first two: these files are small)
-@pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded data sets)
-def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
-    """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
-    matches with offset < 64, = 64, > 64), literal runs of 0..400 bytes between matches (length-byte chains), matches at
-    distances beyond the 8-KB LDS ring, incompressible blocks (one 64-KB literal run), sequences that straddle the 2-KB
-    staging chunks, and blocks that end right after a match / with a 5-byte literal tail."""
+def lz4_corner_columns(variant, n=300_000):
+    """the byte columns of test_lz4_decode_corner_cases (its docstring says what each is for)"""
     rng = np.random.default_rng(5 + variant)
-    n = 300_000
     periodic = np.concatenate([np.tile(rng.integers(0, 256, per).astype(np.uint8), 2300 // per + 1)[:2300] for per in range(1, 131)])
     pieces = []
     base = rng.integers(0, 256, 20_000).astype(np.uint8)
@@ -260,6 +254,18 @@ def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant, pipe)
     cols = {"periodic": np.resize(periodic, n), "mixed": mixed, "noise": rng.integers(0, 256, n).astype(np.uint8), "shortseq": shortseq,
             "runs": np.repeat(rng.integers(0, 4, n // 50 + 1).astype(np.uint8), rng.integers(1, 100, n // 50 + 1))[:n]}
     cols["runs"] = np.resize(cols["runs"], n)
+    return cols
+
+
+@pytest.mark.parametrize("pipe", [0, 1, 10, 15])     # K7 one wave per block (4-window superbatch), the two-wave pipeline, round 2's 8-window shape, the 7-waves-per-SIMD shape (by default the block count chooses between the first two: these files are small)
+@pytest.mark.parametrize("variant", [0, 1, 2])       # (three differently seeded data sets)
+def test_lz4_decode_corner_cases(oracle, dfdb_mod, ctx, tmp_path, variant, pipe):
+    """Byte columns built to hit every branch of the device LZ4 decoders: periodic data of every period 1..130 (overlapping
+    matches with offset < 64, = 64, > 64), literal runs of 0..400 bytes between matches (length-byte chains), matches at
+    distances beyond the 8-KB LDS ring, incompressible blocks (one 64-KB literal run), sequences that straddle the 2-KB
+    staging chunks, and blocks that end right after a match / with a 5-byte literal tail."""
+    n = 300_000
+    cols = lz4_corner_columns(variant, n)
     ctx.set_option("lz4_pipeline", pipe)
     try:
         for bs in (65536, 50_000, 4099):

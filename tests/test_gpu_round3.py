@@ -476,3 +476,64 @@ def test_two_column_conjunctions_every_form(dfdb_mod, kinds, pair):
         t.close()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant):
+    """A column that keeps its LZ4 blocks in HBM (ctx option keep_compressed; BlockStreams.jl:101-119 is what every decode restates) records where its
+    sequences start during its first resident decode and decodes with that index afterwards (k_decode.hip INDEX; ctx option lz4_index, default 1).
+    Every corner-case body of test_lz4_decode_corner_cases, files written by liblz4 (the oracle's writer) and by the device encoder, at block sizes that
+    leave ragged last blocks: the plain decode (lz4_index = 0), the recording decode and the indexed decodes — alone and fused with a predicate — all
+    leave exactly the bytes liblz4 decodes."""
+    from test_gpu_parity import lz4_corner_columns
+    from helpers import Pair
+    n = 200_000
+    cols = lz4_corner_columns(variant, n)
+    c = dfdb_mod.Context(0)
+    try:
+        c.set_option("lz4_pipeline", 0)                 # (these files have few blocks: by default the two-wave pipeline, which takes no index, would decode them)
+        c.set_option("keep_compressed", 1)
+        for writer in ("liblz4", "device"):
+            for bs in (65536, 8192, 4099):
+                d = str(tmp_path / f"ix{writer}{bs}")
+                if writer == "liblz4":
+                    ot = oracle.Table(block_size=bs)
+                    for k, v in cols.items():
+                        ot.add_column(k, v)
+                    ot.save(d)
+                else:
+                    wt = dfdb_mod.DFTable.from_columns(cols, block_size=bs, ctx=c)
+                    wt.save(d); wt.close()
+                t = dfdb_mod.open_table(d, ctx=c)
+                for name, want in cols.items():
+                    c.set_option("lz4_index", 0)
+                    c.profile(True)
+                    t.decode_resident(name)
+                    assert np.array_equal(dfdb_mod.materialize(t[dfdb_mod.ALL, [name]])[name].to_numpy(), want), (writer, bs, name, "plain")
+                    c.set_option("lz4_index", 1)
+                    for k in range(3):
+                        t.decode_resident(name)
+                        assert np.array_equal(dfdb_mod.materialize(t[dfdb_mod.ALL, [name]])[name].to_numpy(), want), (writer, bs, name, "index", k)
+                    got = {k: c.profile_get("lz4_decode." + k)[0] for k in ("plain", "recording", "indexed")}
+                    c.profile(False)
+                    assert got == {"plain": 1, "recording": 1, "indexed": 2}, got
+                t.close()
+        # fused with a predicate (K7 SCAN), 8-byte view of the same bytes: the first fused decode records, the later ones read the index
+        c.set_option("decode_on_scan", 1)
+        for name in ("mixed", "shortseq", "periodic", "runs"):
+            v8 = np.ascontiguousarray(cols[name][: n // 8 * 8]).view(np.int64)
+            d = str(tmp_path / f"ix8{name}")
+            ot = oracle.Table(block_size=8192); ot.add_column("v", v8); ot.save(d)
+            t = dfdb_mod.open_table(d, ctx=c)
+            med = int(np.median(v8))
+            c.profile(True)
+            for k in range(3):
+                q = t[t.v > med, dfdb_mod.ALL]._query()
+                assert np.array_equal(q.indices(), np.flatnonzero(v8 > med).astype(np.int64) + 1), (name, k)
+                assert np.array_equal(dfdb_mod.materialize(t)["v"].to_numpy(), v8), (name, k)
+            got = {k: c.profile_get("lz4_decode_scan." + k)[0] for k in ("plain", "recording", "indexed")}
+            c.profile(False)
+            assert got == {"plain": 0, "recording": 1, "indexed": 2}, got
+            t.close()
+    finally:
+        c.close()
