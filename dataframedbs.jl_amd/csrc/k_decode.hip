@@ -56,6 +56,20 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 // the selection over it in one iteration, src/io/blocksiterator.jl:98-121): every 512 decoded bytes of an 8-byte column pass the
 // comparison `value OP c` on their way from the LDS ring to HBM and leave their 64-bit mask word — the bitmap and the per-1024-row
 // counts K1 would have produced from a second pass over the decoded column.
+// the same without a branch: `sel` says which of {less, equal, greater, unordered} satisfy the operator (bits 0..3), the three orderings are all computed and the
+// column's type picks one by select — uniform branches are scalar instructions, and the CU's four SIMDs share one scalar unit (this runs once per 512 decoded bytes)
+__device__ __forceinline__ uint32_t lz_op_sel(int op) {
+  return op == CMP_EQ ? 2u : op == CMP_NE ? (1u | 4u | 8u) : op == CMP_LT ? 1u : op == CMP_LE ? (1u | 2u) : op == CMP_GT ? 4u : (4u | 2u);
+}
+__device__ __forceinline__ bool lz_cmp8_sel(uint64_t v, uint64_t c, int dtype, uint32_t sel) {
+  const double a = __builtin_bit_cast(double, v), b = __builtin_bit_cast(double, c);
+  const bool isf = dtype == DFDB_F64, isu = dtype == DFDB_U64;
+  const bool lt = isf ? a < b : (isu ? v < c : (int64_t)v < (int64_t)c);
+  const bool gt = isf ? a > b : (isu ? v > c : (int64_t)v > (int64_t)c);
+  const bool eq = isf ? a == b : v == c;
+  const bool un = !(lt || gt || eq);                                  // a NaN on either side of a Float64 comparison
+  return ((sel & 1u) && lt) || ((sel & 2u) && eq) || ((sel & 4u) && gt) || ((sel & 8u) && un);
+}
 __device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int op) {
   int r;                                                         // -1 / 0 / 1, 2 = unordered
   if (dtype == DFDB_F64) { const double a = __builtin_bit_cast(double, v), b = __builtin_bit_cast(double, c); r = (a != a || b != b) ? 2 : (a < b ? -1 : (a > b ? 1 : 0)); }
@@ -93,8 +107,9 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
   static_assert(!PIPE || (WAVES == 2 && !SCAN), "the two-wave pipeline is its own configuration");
   constexpr int NW = PIPE ? 1 : WAVES;           // sets of LDS arrays per workgroup
   constexpr int NS = PIPE ? 2 : 1;               // record slots (PIPE: one being parsed into, one being produced from)
-  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[NW][kStage + kRing + kFarMax * 24];
-  __shared__ uint32_t fard_sh[NW][NS][kFarMax];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[NW][kStage + kRing + kFarMax * 24 + 64];   // (+ 64 bytes nobody reads: where lanes past a superbatch's last byte put theirs)
+  constexpr uint32_t kDump = kStage + kRing + kFarMax * 24;
+  __shared__ uint32_t fard_sh[NW][NS][kFarMax + 1];   // (+ a slot nobody reads)
   __shared__ uint32_t ctl_sh[PIPE ? 16 : 1];     // PIPE control words (below)
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
   __shared__ uint32_t bits_sh[NW][kBatchBytes / 32 + 2];   // + two words that stay zero
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     };
     // SCAN: mask words of this block so far, the current tile's words (word k of the tile in lane k) and its selected count
     uint32_t sc_words = 0, sc_tile_count = 0; uint64_t sc_myword = 0;
+    const uint32_t sc_sel = SCAN ? lz_op_sel(sc.op) : 0u;
     const int64_t sc_word0 = blk.dst_off / 512;                   // the block's first mask word (host: the block starts on a 1024-row tile)
     // ring -> HBM, bytes [flushed, upto)
     auto flush_to = [&](uint32_t upto) {
@@ -204,8 +220,9 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         // `flushed` is a multiple of 512 here; a group shorter than 512 bytes can only be the block's last
         for (uint32_t g = flushed; g < upto; g += 512u) {
           const bool have = g + lane * 8u + 8u <= upto;
-          const uint64_t v = have ? *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1))) : 0ull;
-          const uint64_t m = __ballot(have && lz_cmp8(v, sc.cbits, sc.dtype, sc.op));
+          const uint64_t v = *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1)));      // (always inside the ring: only the ballot needs `have`)
+          if (g + 512u <= upto) *(uint64_t*)(out + g + lane * 8u) = v;                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
+          const uint64_t m = __ballot(have && lz_cmp8_sel(v, sc.cbits, sc.dtype, sc_sel));
           if (lane == (sc_words & 15u)) sc_myword = m;
           sc_tile_count += (uint32_t)__builtin_popcountll(m);
           sc_words++;
@@ -215,16 +232,31 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             sc_tile_count = 0;
           }
         }
+        flushed += (upto - flushed) & ~511u;                               // (those bytes are in HBM; what is left is a block's last, shorter group)
+      }
+      if (!SCAN && (flushed & 7u) == 0 && (((uintptr_t)out) & 7u) == 0) {        // whole 512-byte steps, 8 bytes per lane
+        const uint32_t n512 = (upto - flushed) & ~511u;
+        for (uint32_t o0 = 0; o0 < n512; o0 += 512) {
+          const uint32_t o = o0 + lane * 8;
+          const uint64_t v = *(const uint64_t*)(ring + ((flushed + o) & (kRing - 1)));
+          *(uint64_t*)(out + flushed + o) = v;
+        }
+        flushed += n512;
       }
       if ((flushed & 3u) == 0 && (((uintptr_t)out) & 3u) == 0) {
-        const uint32_t n4 = (upto - flushed) & ~3u;
-        for (uint32_t o = lane * 4; o < n4; o += 256) {
+        const uint32_t n4 = (upto - flushed) & ~3u, n256 = n4 & ~255u;
+        for (uint32_t o0 = 0; o0 < n256; o0 += 256) {                    // whole 256-byte steps: every lane stores (a wave-uniform loop: no exec bookkeeping)
+          const uint32_t o = o0 + lane * 4;
           const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1)));
           *(uint32_t*)(out + flushed + o) = v;
         }
+        if (n256 != n4) {                                                // (a block's last flush)
+          const uint32_t o = n256 + lane * 4;
+          if (o < n4) { const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1))); *(uint32_t*)(out + flushed + o) = v; }
+        }
         flushed += n4;
       }
-      for (uint32_t o = flushed + lane; o < upto; o += 64) out[o] = ring[o & (kRing - 1)];
+      if (flushed != upto) { for (uint32_t o = flushed + lane; o < upto; o += 64) out[o] = ring[o & (kRing - 1)]; }
       flushed = upto;
     };
 
@@ -242,13 +274,10 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         if (lane < nfar) {
           const uint32_t so = fard[lane];
           uint64_t* d = (uint64_t*)(lds + kStage + kRing + lane * 24u);
-          if (so + 24u <= out_len) {
-            const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
-            d[0] = a; d[1] = b2; d[2] = c2;
-          } else {
-            uint8_t* db = (uint8_t*)d;
-            for (uint32_t k = 0; k < 24u && so + k < out_len; k++) db[k] = out[so + k];
-          }
+          // (24 bytes whatever the match's length: near a block's end the last of them lie past its output — in the next block's, or in the >= 32 bytes
+          //  of slack every caller leaves behind the last block (kernels.hpp) — and are never used: the bytes a sequence copies all precede `op`)
+          const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
+          d[0] = a; d[1] = b2; d[2] = c2;
         }
         wave_lds_fence();
         LZ4_PROF(5);
@@ -296,7 +325,8 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         for (int u = 0; u < U; u++) {                                  // in row order: a later row may copy bytes an earlier row of this trip wrote
           const uint32_t j = c + 64u * (uint32_t)u + lane;
           const uint8_t v = lds[R[u] & 0xffffu];
-          if (j < T) ring[(op + j) & (kRing - 1)] = v;
+          // (a select instead of a branch: every divergent `if` is an exec save / restore on the CU's one scalar unit, and these run eight times per superbatch)
+          lds[j < T ? (uint32_t)kStage + ((op + j) & (uint32_t)(kRing - 1)) : kDump + lane] = v;
         }
       }
       LZ4_PROF(19);
@@ -528,10 +558,8 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             const uint32_t rel = 64u * (uint32_t)w + lane, bp = o0 + rel;
             const bool st = ((WD[w] >> (bp & 31u)) & 1u) != 0u && rel < left;
             const uint64_t m = __ballot(st);
-            if (st) {
-              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-              if (ord < (uint32_t)kSeqMax) info[ord].x = rel;
-            }
+            const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            info[(int32_t)(st && ord < (uint32_t)kSeqMax ? ord : 0xffffffffu)].x = rel;      // (no start here: the dummy entry in front of the records takes it)
             nseq += (uint32_t)__builtin_popcountll(m);
           }
           if (nseq > (uint32_t)kSeqMax || nseq == 0u) { err = 9; break; }    // not an index of this stream
@@ -575,7 +603,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             const uint32_t na = (uint32_t)__builtin_popcountll(__ballot(acc));
             if (acc) {
               bad = bad || offset == 0u || offset > op + ostart + lit;
-              if (far) fard[fo] = op + ostart + lit - offset;                   // where its source starts in the block's output
+              fard[far ? fo : (uint32_t)kFarMax] = op + ostart + lit - offset;  // where its source starts in the block's output (not far: the slot nobody reads)
               // the record production reads, as 16-bit fields.  A byte j of the sequence comes from LDS address ((j + B) & (kStage - 1)) | O
               // with (B, O) = the literal pair below its literal end and the match pair from there on:
               //   literal  B = ip + inpos - ostart          O = 0                 (staging buffer)

@@ -146,6 +146,8 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
                        uint64_t* special, uint64_t salt, int* collision);
 
 // ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------
+// (dst: the decoders may READ up to 32 bytes past the end of the last block's output — far-match sources are fetched 24 bytes at a time — so the
+//  destination needs that much slack behind it; table.cpp's column arrays and body arenas carry 64-256)
 struct Lz4Block {      // one (column, block) unit of work
   int64_t src_off;     // offset of the compressed bytes inside the staged image
   int32_t src_len;     // compressed bytes

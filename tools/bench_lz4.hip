@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
   img.resize(img.size() + 64);
   printf("blocks %d, compressed %.1f MB, ratio %.3f\n", nblocks, img.size() / 1e6, (double)nblocks * body / img.size());
   uint8_t *dsrc, *ddst; Lz4Block* dblk; int32_t* dstat;
-  CK(hipMalloc(&dsrc, img.size())); CK(hipMalloc(&ddst, (size_t)nblocks * body)); CK(hipMalloc(&dblk, blk.size() * sizeof(Lz4Block))); CK(hipMalloc(&dstat, nblocks * 4));
+  CK(hipMalloc(&dsrc, img.size())); CK(hipMalloc(&ddst, (size_t)nblocks * body + 64)); CK(hipMalloc(&dblk, blk.size() * sizeof(Lz4Block))); CK(hipMalloc(&dstat, nblocks * 4));
   CK(hipMemcpy(dsrc, img.data(), img.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dblk, blk.data(), blk.size() * sizeof(Lz4Block), hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<uint8_t> back((size_t)distinct * body);
