@@ -528,10 +528,8 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           // (nseq <= kSeqMax by construction: starts are >= 3 input bytes apart, ceil(64 W / 3) of them at most)
 #pragma unroll
           for (int w = 0; w < W; w++) {
-            if (FL[w] != 0u) {
-              const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(MASK[w] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)MASK[w], 0u));
-              info[ord].x = 64u * (uint32_t)w + lane;                              // where the sequence starts, relative to ip
-            }
+            const uint32_t ord = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(MASK[w] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)MASK[w], 0u));
+            info[(int32_t)(FL[w] != 0u ? ord : 0xffffffffu)].x = 64u * (uint32_t)w + lane;   // where the sequence starts, relative to ip (no start: the dummy record; a select, not a branch)
             nseq += (uint32_t)__builtin_popcountll(MASK[w]);
           }
           LZ4_PROF(14);
