@@ -369,3 +369,19 @@ def test_random_tables_written_by_the_device_read_back(oracle, dfdb_mod, ctx, tm
     ov3, dv3 = apply_stages(back, [])
     assert_same(back, ov3, dv3)
     back.d.close()
+    # both files again with their LZ4 blocks kept in HBM: the first resident decode of every plain fixed-width column records its sequence-start index, the
+    # second decodes with it (k_decode.hip INDEX) — same bytes as the loader's decode
+    ctx.set_option("keep_compressed", 1); ctx.set_option("lz4_pipeline", 0)
+    try:
+        for pth in (path, str(tmp_path / "by_oracle")):
+            kt = dfdb_mod.open_table(pth)
+            for name, v in cols.items():
+                if isinstance(v, (list, np.ma.MaskedArray)) or n == 0:
+                    continue
+                for k in range(2):
+                    kt.decode_resident(name)
+                    got = dfdb_mod.materialize(kt[dfdb_mod.ALL, [name]])[name].to_numpy()
+                    assert np.array_equal(got.view(np.uint8), np.asarray(v).view(np.uint8)), (pth, name, k)
+            kt.close()
+    finally:
+        ctx.set_option("keep_compressed", 0); ctx.set_option("lz4_pipeline", -1)
