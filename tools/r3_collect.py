@@ -59,13 +59,27 @@ def main():
     fk, wk, n = per_launch("k_compact_indices")
     out["k_compact_indices_wide"] = {"FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "launches": n, "hbm_bytes_per_launch_corrected": (2 * fk + wk) * 1024,
                                      "algorithmic_bytes_per_launch": rows // 8 + rows // 1024 * 8 + nsel * 8}
-    fk, wk, n = per_launch("k_lz4_decode")
+    # K7: both passes see the same launches in the same order (the load's decode, the `without_index` leg, the recording launch, the indexed legs, the fused
+    # legs): pair them by position and sort them into the forms by what they moved
     st = bd.get("decode_scan", {})
-    out["k_lz4_decode"] = {"FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "launches": n, "hbm_bytes_per_launch_corrected": (2 * fk + wk) * 1024,
-                           "algorithmic_bytes_per_launch": (st.get("compressed_bytes") or 0) + rows * 8,
-                           "note": "bench.py's decode_scan leg (15 259 blocks of the ENGINE-compressed column per launch): compressed bytes + the 128-byte lines the 24-byte "
-                                   "far-source reads pull in, decoded bytes written; the values kept are the launches within 2 % of the largest (the unfused ones). "
-                                   "profiles/r3_pmc_lz4.txt has the request counters of the liblz4-compressed column and the reconciliation with round 2's two records."}
+    fv, wv = f[("k_lz4_decode", "FETCH_SIZE")], w[("k_lz4_decode", "WRITE_SIZE")]
+    forms = {"plain": [], "recording": [], "indexed": [], "indexed_fused_with_the_predicate": []}
+    if len(fv) == len(wv) and fv:
+        fmin = min(fv)
+        for a_, b_ in zip(fv, wv):
+            if b_ > 1.2 * min(wv): forms["recording"].append((a_, b_))            # the index's atomics count as writes
+            elif a_ < 1.01 * fmin: forms["plain"].append((a_, b_))
+            elif b_ > 1.01 * min(wv): forms["indexed_fused_with_the_predicate"].append((a_, b_))   # + the bitmap and the tile counts
+            else: forms["indexed"].append((a_, b_))
+    lz = {"algorithmic_bytes_per_launch": (st.get("compressed_bytes") or 0) + rows * 8,
+          "note": "bench.py's decode_scan leg (15 259 blocks of the ENGINE-compressed column per launch): compressed bytes + the 128-byte lines the 24-byte far-source "
+                  "reads pull in (+ the sequence-start index where it is read), decoded bytes written.  profiles/r3_pmc_lz4.txt has the request counters of the "
+                  "liblz4-compressed column and the reconciliation with round 2's two records; profiles/r3_lz4_index.txt the instruction counters of the indexed form."}
+    for k, v in forms.items():
+        if v:
+            fk, wk = sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)
+            lz[k] = {"launches": len(v), "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "hbm_bytes_per_launch_corrected": (2 * fk + wk) * 1024}
+    out["k_lz4_decode"] = lz
     with open(os.path.join(DST, "r3_pmc_scan_cmp.json"), "w") as fo:
         json.dump(out, fo, indent=1)
     print(json.dumps(out, indent=1))
