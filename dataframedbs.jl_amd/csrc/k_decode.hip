@@ -100,15 +100,20 @@ template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, in
 __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
                                                                LzScan sc, uint32_t* __restrict__ index) {
-  static_assert(INDEX == 0 || !PIPE, "the two-wave pipeline neither records nor reads the index");
+  static_assert(INDEX != 1 || !PIPE, "the two-wave pipeline does not record the index (it reads it: PIPE with INDEX = 2)");
+  // PIPE with INDEX = 2: with the index the parser wave is the short one, so it also fetches the superbatch's far sources (into a per-slot area): the
+  // producer is left with byte production and the flush, and the two waves are balanced again
+  constexpr bool kParserFar = PIPE && INDEX == 2;
+  constexpr int kFarAreas = kParserFar ? 2 : 1;
   // one array per wave, staging buffer first and the output ring behind it: a byte of either is ONE ds_read_u8 off the same base
   constexpr int kFarMax = FARMAX;                // v5: matches per superbatch whose source has left the ring (fetched from HBM up front)
   constexpr uint32_t kWords = kBatchBytes / 32;  // start-bit words per superbatch
   static_assert(!PIPE || (WAVES == 2 && !SCAN), "the two-wave pipeline is its own configuration");
   constexpr int NW = PIPE ? 1 : WAVES;           // sets of LDS arrays per workgroup
   constexpr int NS = PIPE ? 2 : 1;               // record slots (PIPE: one being parsed into, one being produced from)
-  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[NW][kStage + kRing + kFarMax * 24 + 64];   // (+ 64 bytes nobody reads: where lanes past a superbatch's last byte put theirs)
-  constexpr uint32_t kDump = kStage + kRing + kFarMax * 24;
+  __shared__ __attribute__((aligned(16))) uint8_t lds_sh[NW][kStage + kRing + kFarAreas * kFarMax * 24 + 64];   // (+ 64 bytes nobody reads: where lanes past a superbatch's last byte put theirs)
+  constexpr uint32_t kDump = kStage + kRing + kFarAreas * kFarMax * 24;
+  static_assert(kFarAreas * kFarMax * 24 <= kStage, "far bytes are addressed as ((j + B) & (kStage - 1)) | (kStage + kRing)");
   __shared__ uint32_t fard_sh[NW][NS][kFarMax + 1];   // (+ a slot nobody reads)
   __shared__ uint32_t ctl_sh[PIPE ? 16 : 1];     // PIPE control words (below)
   constexpr int kSeqMax = 21 * W + 3;            // a 64-byte window starts at most 21 sequences (>= 3 input bytes each)
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
 #ifdef DFDB_LZ4_SKIP_FAR      // tools/bench_lz4 experiment only: what the far round trip costs (the output is WRONG without it)
       if (false) {
 #else
-      if (nfar) {
+      if (nfar && !kParserFar) {
 #endif
         // far sources were flushed before this superbatch began (they lie > kRing - 64 - kBatchBytes behind op and at most
         // kFlush + 256 bytes are ever unflushed): 24 bytes each, HBM/L2 -> LDS, ONE memory round trip for the whole superbatch
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
               // off7 = the match distance when it can fall inside a 64-byte row (else 127): lane - off7 is then the lane that makes the byte
               const uint32_t litend = ostart + lit;
               const uint32_t lbo = (ip + inpos - ostart) & (uint32_t)(kStage - 1);
-              const uint32_t mbo = far ? (((fo * 24u - litend) & (uint32_t)(kStage - 1)) | (uint32_t)(kStage + kRing))
+              const uint32_t mbo = far ? (((fo * 24u + (kParserFar ? (uint32_t)pslot * (uint32_t)(kFarMax * 24) : 0u) - litend) & (uint32_t)(kStage - 1)) | (uint32_t)(kStage + kRing))
                                        : (((op - offset) & (uint32_t)(kStage - 1)) | (uint32_t)kStage);
               const uint32_t off7 = far || offset > 127u ? 127u : offset;
               info[k] = make_uint2(litend | lbo << 16, mbo | off7 << 16);
@@ -660,6 +665,21 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             if (lane < kW) bitsx[lane] = make_uint2(w, incl - cw - 1u);
           }
           wave_lds_fence();
+          if constexpr (kParserFar) {
+           if (nfar) {
+            // the far sources of this superbatch, fetched by the PARSER: they lie more than kRing - 64 bytes behind their sequence, i.e. more than
+            // kRing - 64 - 2 kBatchBytes behind the superbatch the producer can still be working on (it has finished the one before that: the wait below),
+            // and everything older than kFlush + 256 bytes behind a finished superbatch's end is in HBM (the producer's release, our acquire at the wait)
+            static_assert(kRing - 64 - 2 * kBatchBytes >= (kRing >= 4096 ? 1024 : 512) + 256, "parser-side far prefetch needs the sources flushed");
+            if (lane < nfar) {
+              const uint32_t so = fard[lane];
+              uint64_t* d = (uint64_t*)(lds + kStage + kRing + (uint32_t)pslot * (uint32_t)(kFarMax * 24) + lane * 24u);
+              const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
+              d[0] = a; d[1] = b2; d[2] = c2;
+            }
+            wave_lds_fence();
+           }
+          }
           if (PIPE) {
             // hand the superbatch to the producer and go on parsing; the slot after next is free once the producer has consumed the one before
             ctl[C_HT + pslot] = T; ctl[C_HNF + pslot] = nfar;
@@ -849,7 +869,10 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   // the two-wave pipeline needs 128 VGPRs per wave: 4 waves per SIMD = 8 workgroups per CU = 2048 blocks resident at once, and a block takes ~3.3 ms
   // there however few there are (763 blocks 2.6 ms, 1526 3.3 ms, 2048 3.4 ms = 312 GB/s; 2560 blocks need a second round: 5.5 ms, where one wave per
   // block takes 5.3); superbatches of 4 windows in the pipeline are slower (1526 blocks: 214 vs 242 GB/s: twice the hand-offs)
-  if (pipe == 1 || (pipe < 0 && nblocks <= 2048))
+  const bool pipeline = pipe == 1 || (pipe < 0 && nblocks <= 2048);
+  if (pipeline && index && index_mode == 2)
+    hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1, 4, 64, 2>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
+  else if (pipeline && !(index && index_mode == 1))                     // (a recording launch takes the one-wave form whatever the block count: once per column)
     hipLaunchKernelGGL((k_lz4_decode<2, 4096, 4096, 1024, 8, 0, 1>), dim3((unsigned)g5), dim3(128), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr);
   else if (index && index_mode == 2)
     hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
@@ -859,7 +882,7 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
     hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr);
 }
 // whether launch_lz4_decode would take (record or read) an index for this many blocks under this pipeline setting
-bool lz4_decode_takes_index(int32_t nblocks, int pipe) { return !(pipe == 1 || (pipe < 0 && nblocks <= 2048)) && pipe != 10 && pipe != 15; }
+bool lz4_decode_takes_index(int32_t nblocks, int pipe) { (void)nblocks; return pipe != 10 && pipe != 15; }
 // decode + `value OP c` over an 8-byte column in one pass: dst receives the decoded column, sc.bitmap / sc.counts what K1 would write
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc,
                             uint32_t* index, int index_mode) {

@@ -134,7 +134,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
  *                     compressed byte, +12.5 % beside the blocks, built inside that decode (which runs ~10 % slower for it) — and every later decode of
  *                     the column reads the index instead of parsing candidates and walking the chain again: 450-490 -> 590-630 GB/s decoded on 8-byte
- *                     integer columns.  Same bytes out, launch forms that take no index (the two-wave pipeline: <= 2048 blocks) ignore it (default 1) */
+ *                     integer columns.  Same bytes out.  The two-wave pipeline (<= 2048 blocks) reads it too — its parser wave then also fetches the far sources, which
+ *                     balances the two waves again: 1 526 blocks 238 -> 328 GB/s, 2 048 blocks 308 -> 418; the recording launch is always one wave per block (default 1) */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);

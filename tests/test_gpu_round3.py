@@ -478,8 +478,9 @@ def test_two_column_conjunctions_every_form(dfdb_mod, kinds, pair):
         c.close()
 
 
+@pytest.mark.parametrize("pipe", [0, 1])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant):
+def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant, pipe):
     """A column that keeps its LZ4 blocks in HBM (ctx option keep_compressed; BlockStreams.jl:101-119 is what every decode restates) records where its
     sequences start during its first resident decode and decodes with that index afterwards (k_decode.hip INDEX; ctx option lz4_index, default 1).
     Every corner-case body of test_lz4_decode_corner_cases, files written by liblz4 (the oracle's writer) and by the device encoder, at block sizes that
@@ -491,7 +492,7 @@ def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant)
     cols = lz4_corner_columns(variant, n)
     c = dfdb_mod.Context(0)
     try:
-        c.set_option("lz4_pipeline", 0)                 # (these files have few blocks: by default the two-wave pipeline, which takes no index, would decode them)
+        c.set_option("lz4_pipeline", pipe)              # 0: one wave per block; 1: the two-wave pipeline (what these small files get by default), whose parser reads the index and fetches the far sources (the recording launch is one wave per block either way)
         c.set_option("keep_compressed", 1)
         for writer in ("liblz4", "device"):
             for bs in (65536, 8192, 4099):
