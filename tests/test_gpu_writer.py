@@ -371,7 +371,7 @@ def test_random_tables_written_by_the_device_read_back(oracle, dfdb_mod, ctx, tm
     back.d.close()
     # both files again with their LZ4 blocks kept in HBM: the first resident decode of every plain fixed-width column records its sequence-start index, the
     # second decodes with it (k_decode.hip INDEX) — same bytes as the loader's decode
-    ctx.set_option("keep_compressed", 1); ctx.set_option("lz4_pipeline", 0)
+    ctx.set_option("keep_compressed", 1); ctx.set_option("lz4_pipeline", (seed >> 1) % 2)      # one wave per block / the two-wave pipeline (both read the index)
     try:
         for pth in (path, str(tmp_path / "by_oracle")):
             kt = dfdb_mod.open_table(pth)
