@@ -858,14 +858,7 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
   // 4 spills) 396, 8 windows at 6 waves 428: past six waves per SIMD the LDS pipeline and instruction issue are what the waves share, not latency.
   if (pipe == 10) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr); return; }
   if (pipe == 15) { hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr); return; }
-  if (index && index_mode == 2 && pipe >= 20) {      // tools/bench_lz4 only: other shapes of the indexed form
-    if (pipe == 20) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
-    else if (pipe == 21) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 1024, 8, 0, 0, 6, 48, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
-    else if (pipe == 22) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 7, 24, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
-    else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 8, 24, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
-    return;
-  }
-  if (pipe >= 20) pipe = 0;
+  // (other shapes of the indexed form — 8 windows / 1024 bytes with 32 or 48 far slots, 7 waves per SIMD — measured within 1 % of this one: profiles/r3_lz4_index.txt)
   // the two-wave pipeline needs 128 VGPRs per wave: 4 waves per SIMD = 8 workgroups per CU = 2048 blocks resident at once, and a block takes ~3.3 ms
   // there however few there are (763 blocks 2.6 ms, 1526 3.3 ms, 2048 3.4 ms = 312 GB/s; 2560 blocks need a second round: 5.5 ms, where one wave per
   // block takes 5.3); superbatches of 4 windows in the pipeline are slower (1526 blocks: 214 vs 242 GB/s: twice the hand-offs)
