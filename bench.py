@@ -454,7 +454,8 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
         sec, ks = L.timed(step, gctx)
         res["5_shard_dictionary"] = L.record(per_gpu_rows, mine, sec, ks, per_gpu_rows * bytes_row,
                                              "the same with 16-bit dictionary codes beside s: s != \"sony\" scans 2 B/row (algorithmic bytes still count the flat column)", exchange=exch,
-                                             global_count=out["count"], global_sum_x=out["sum"], dictionary_entries=nd[0], dictionary_build_s=build_s)
+                                             global_count=out["count"], global_sum_x=out["sum"], dictionary_entries=nd[0], dictionary_build_s=build_s,
+                                             bytes_read_GB=per_gpu_rows * 18 / 1e9, frac_of_peak_in_bytes_read=per_gpu_rows * 18 / sec / 1e9 / L.peak)
         gq.close(); gt.close()
         if own is not None:
             own.close()
