@@ -129,7 +129,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "lz4_pipeline"    K7 with two waves per block (one parses, one produces, a superbatch apart): -1 = when every block of a launch can be resident in
  *                     that form at once (<= 2048 blocks; default), 0 = never, 1 = always
  *   "decode_on_scan"  1 = a fresh-mask scan of one `col OP const` term over an 8-byte column that holds its LZ4 blocks (keep_compressed) decodes and
- *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array (default 0)
+ *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array; with at most 2048 blocks
+ *                     (the two-wave pipeline's range) it decodes with the pipeline and then scans the decoded array, which is shorter there (default 0)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0)
  *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
  *                     compressed byte, +12.5 % beside the blocks, built inside that decode (which runs ~10 % slower for it) — and every later decode of

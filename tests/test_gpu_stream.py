@@ -217,12 +217,15 @@ def test_decode_fused_with_the_first_predicate(oracle, dfdb_mod, ctx, tmp_path):
     f[::977] = np.nan
     cols = {"a": oracle.gen_i64(0x9E37, 0, n), "u": rng.integers(0, 2**64 - 1, n, dtype=np.uint64), "f": f, "far": far,
             "z": np.zeros(n, np.int64), "i32": rng.integers(-5, 5, n).astype(np.int32)}
-    for bs in (65536, 4096, 1000):
+    for bs, pipeline in ((65536, 0), (4096, 0), (1000, 0), (4096, -1)):
+        # lz4_pipeline = 0: the fused kernel whatever the block count; -1 (the default): these files have few blocks, so the two-wave pipeline decodes
+        # them and the ordinary scan follows (query.cpp) — same results, other launches
         ot = oracle.Table(block_size=bs)
         for k, v in cols.items():
             ot.add_column(k, v)
-        path = str(tmp_path / f"t{bs}")
+        path = str(tmp_path / f"t{bs}_{pipeline + 1}")
         ot.save(path)
+        ctx.set_option("lz4_pipeline", pipeline)
         ctx.set_option("keep_compressed", 1)
         try:
             tb = dfdb_mod.open_table(path)
@@ -248,11 +251,14 @@ def test_decode_fused_with_the_first_predicate(oracle, dfdb_mod, ctx, tmp_path):
                 dv2 = dfdb_mod.selection(dfdb_mod.selection(tb.view(), e), dfdb_mod.jr(3, 2, 5000))
                 assert np.array_equal(dv2._query().indices(), ov2.select_indices()), (bs, e)
             launches, _ = ctx.profile_get("lz4_decode_scan")
+            unfused, _ = ctx.profile_get("lz4_decode")
             # fused for the 8-byte columns when blocks start on 1024-row tiles; block size 1000 and the Int32 column take the ordinary kernels
-            assert launches == (0 if bs == 1000 else 2 * 12), (bs, launches)
+            assert launches == (0 if bs == 1000 or pipeline < 0 else 2 * 12), (bs, pipeline, launches)
+            assert unfused == (2 * 12 if pipeline < 0 else 0), (bs, pipeline, unfused)
         finally:
             ctx.profile(False)
             ctx.set_option("decode_on_scan", 0)
+            ctx.set_option("lz4_pipeline", -1)
         tb.close()
 
 
