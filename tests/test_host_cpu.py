@@ -332,3 +332,15 @@ def test_oracle_is_clean_under_address_and_ub_sanitizers():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-4000:]
     assert "no sanitizer report" in r.stdout.decode()
+
+
+def test_every_context_option_the_engine_reads_is_documented_in_the_header():
+    """dfdb_ctx_set_option takes free-form keys: an option the engine reads but include/dfdb.h does not describe cannot be found by a caller"""
+    import glob
+    import re
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "dataframedbs.jl_amd", "csrc", "*.[ch]pp")))
+    read = set(re.findall(r'ctx_option\([^,()]+,\s*"([a-z0-9_]+)"', src))
+    assert len(read) >= 15, read
+    header = open(os.path.join(ROOT, "include", "dfdb.h")).read()
+    missing = sorted(o for o in read if f'"{o}"' not in header)
+    assert not missing, missing
