@@ -132,6 +132,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array; with at most 2048 blocks
  *                     (the two-wave pipeline's range) it decodes with the pipeline and then scans the decoded array, which is shorter there (default 0)
  *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0)
+ *   "group_force_exchange" 1 = a group's unique / groupreduce merge sends its records through the exchange (RCCL all-gather / the callbacks) even when one
+ *                     process holds every shard and could merge them in place (default 0; what the one-GPU tests use to run the exchange code)
  *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
  *                     compressed byte, +12.5 % beside the blocks, built inside that decode (which runs ~10 % slower for it) — and every later decode of
  *                     the column reads the index instead of parsing candidates and walking the chain again: 450-490 -> 590-630 GB/s decoded on 8-byte
