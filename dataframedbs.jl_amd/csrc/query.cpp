@@ -109,7 +109,8 @@ static void ensure_state(dfdb_query* q) {
 // afterwards) and the fastest stays with the column.  Queries that scan the column borrow it (one at a time; others use their own).
 // ctx option "placement_calibrate" = 1 asks for it (default 0).  One-time cost per column: 27 scans (~35 ms per 1e9 rows) plus allocating and releasing
 // the spacers, 0.03-1.4 s measured (profiles/r2_placement_cost.txt) — worth it for a column that stays resident and is scanned thousands of times, not
-// for a short session, which is why it is opt-in; stream slots never calibrate.  "placement_spacer_mb" / "placement_candidates" size the search.
+// for a short session, which is why it is opt-in; stream slots never calibrate.  "placement_spacer_mb" / "placement_candidates" size the search (round 3: no
+// spacers by default — once the column itself is re-placed they change nothing, tools/r3_draws_spacer.sh, and releasing 8 x 12 GB of them was up to 5 s of the one-time cost).
 void query_return_mask(dfdb_query* q) {
   if (q->mask_from < 0 || !q->t) { q->mask_from = -1; return; }
   Column& c = q->t->cols[(size_t)q->mask_from];
@@ -136,7 +137,7 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     const auto wall0 = std::chrono::steady_clock::now();
     const int kCand = (int)std::min<int64_t>(16, std::max<int64_t>(1, ctx_option(ctx, "placement_candidates", 8)));
-    const size_t spacer = std::min<size_t>((size_t)std::max<int64_t>(0, ctx_option(ctx, "placement_spacer_mb", 12288)) << 20, free_b / (4 * (size_t)kCand));
+    const size_t spacer = std::min<size_t>((size_t)std::max<int64_t>(0, ctx_option(ctx, "placement_spacer_mb", 0)) << 20, free_b / (4 * (size_t)kCand));
     if (free_b < (size_t)kCand * (bytes + spacer) + ((size_t)4 << 30)) return;      // not enough room to look around: keep the query's own
     std::vector<DevBuf> cand((size_t)kCand), space((size_t)kCand);
     try {
