@@ -23,8 +23,10 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
                   exchange through the library's own group path: dfdb_group_* with its RCCL communicator), "5_shard_dictionary", "5_shard_materialize"
                   ([a, x] left sharded on the devices: dfdb_group_materialize_device).  Each: rows, selected, ms_per_step, per-kernel avg_ms,
                   algorithmic_GB, rows_per_s (whole job) and roofline {achieved, peak, frac} in algorithmic bytes per GPU.
-  default_config  config 2 again with the opt-in bitmap placement calibration OFF (what a caller gets who sets no option)
-  decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate)
+  default_config  config 2 with the library's default options, measured FIRST in the process (no placement calibration: what a caller gets who sets no option;
+                  the calibration that `value` runs with re-places the column and picks a bitmap allocation, config.placement_calibration says what it saw)
+  decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
+                  sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cpu_baseline    N = 1: the oracle on the host cores
 Prints ONE JSON line on rank 0.
 """
