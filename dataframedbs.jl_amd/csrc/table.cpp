@@ -442,7 +442,7 @@ int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index) {
   if (!form_takes_index || ctx_option(ctx, "lz4_index", 1) == 0 || !c.comp.p) return 0;
   if (!c.comp_index.p) {
     const size_t bytes = (c.comp.bytes + 7) / 8 + 1024;                  // + the 64-dword register window's reach past the last bit
-    c.comp_index.ensure(bytes);
+    try { c.comp_index.ensure(bytes); } catch (const Error&) { (void)hipGetLastError(); return 0; }   // no room for it: decode without
     HIP_CHECK(hipMemsetAsync(c.comp_index.p, 0, c.comp_index.bytes, ctx->stream));
     c.comp_index_state = 0;
   }
