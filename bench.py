@@ -234,6 +234,7 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
            "what": "compressed-resident column (reference LZ4 blocks in HBM) -> K7 decode of every block FUSED with the predicate (bitmap + tile counts leave the "
                    "decoder) -> count scan -> K2 indices, per step; `unfused` = K7, then K1 over the decoded column.  The column's first resident decode recorded "
                    "where its LZ4 sequences start (one bit per compressed byte, ctx option lz4_index); these steps decode with that index, `without_index` without"}
+    res["blocks_that_failed_to_decode"] = t2.decode_status("x")      # dfdb_table_decode_status: 0, or the figures above are not a decode
     t2.close()
     return res
 

@@ -218,6 +218,14 @@ int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file,
 }
 int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(stats); table_column_stats(t, ordinal, stats); }); }
 int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal) { return guard([&] { NEED(t); table_decode_resident(t, ordinal); }); }
+int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_blocks) {
+  return guard([&] {
+    NEED(t);
+    const int64_t bad = table_decode_status(t, ordinal);
+    if (bad_blocks) *bad_blocks = bad;
+    else if (bad > 0) fail(DFDB_ERR_FORMAT, "decompression error: %lld resident block(s) did not decode to their stored size", (long long)bad);
+  });
+}
 int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical) {
   return guard([&] {
     NEED(t); NEED(logical);

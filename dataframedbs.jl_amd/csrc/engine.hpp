@@ -153,6 +153,7 @@ int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entri
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp
+int64_t table_decode_status(dfdb_table* t, int32_t ordinal);   // table.cpp: blocks of the last resident decode whose status is not 0 (synchronises)
 int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index);   // table.cpp: 0 / 1 (record) / 2 (use) for launch_lz4_decode*
 int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
 void ctx_destroy(dfdb_ctx* c);

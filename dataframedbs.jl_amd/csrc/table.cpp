@@ -436,6 +436,18 @@ void table_decode_resident(dfdb_table* t, int32_t ordinal) {
                     c.comp_index.as<uint32_t>(), mode);
 }
 
+int64_t table_decode_status(dfdb_table* t, int32_t ordinal) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  if (!c.comp_nblocks) fail(DFDB_ERR_ARGUMENT, "column %s holds no compressed blocks (load it with option keep_compressed = 1)", c.name.c_str());
+  std::vector<int32_t> st((size_t)c.comp_nblocks);
+  HIP_CHECK(hipMemcpyAsync(st.data(), c.comp_status.p, st.size() * 4, hipMemcpyDeviceToHost, t->ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+  int64_t bad = 0;
+  for (int32_t v : st) bad += v != 0;
+  return bad;
+}
+
 // The sequence-start index of a column's resident LZ4 blocks (k_decode.hip INDEX): the first decode that can take it records it, the later ones decode with it.
 // Returns launch_lz4_decode's index_mode (0: none — ctx option "lz4_index" = 0, or a launch form that takes none).
 int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index) {

@@ -358,6 +358,12 @@ class DFTable:
         """K7 over the LZ4 blocks the column kept in HBM (ctx option keep_compressed at load time), asynchronously"""
         N.check(N.load().dfdb_table_decode_resident(self._h, self.ordinal(column)))
 
+    def decode_status(self, column: str) -> int:
+        """blocks of the column's last resident decode that did not end with their stored size (0 = fine); waits for the stream"""
+        bad = C.c_int64()
+        N.check(N.load().dfdb_table_decode_status(self._h, self.ordinal(column), C.byref(bad)))
+        return bad.value
+
     def build_dictionary(self, column: str, max_entries: int = 4096) -> int:
         """K9: 16-bit codes + the distinct strings of a resident String column (kept beside its flat form); returns the number of distinct
         strings, 0 when none was built (more than max_entries, nullable, a string over 4 KB).  Results of every query stay the same."""

@@ -514,6 +514,7 @@ def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant,
                     c.set_option("lz4_index", 1)
                     for k in range(3):
                         t.decode_resident(name)
+                        assert t.decode_status(name) == 0, (writer, bs, name, "index", k)          # every block ended on its stored size
                         assert np.array_equal(dfdb_mod.materialize(t[dfdb_mod.ALL, [name]])[name].to_numpy(), want), (writer, bs, name, "index", k)
                     got = {k: c.profile_get("lz4_decode." + k)[0] for k in ("plain", "recording", "indexed")}
                     c.profile(False)
@@ -531,11 +532,39 @@ def test_lz4_sequence_index_changes_no_byte(oracle, dfdb_mod, tmp_path, variant,
             for k in range(3):
                 q = t[t.v > med, dfdb_mod.ALL]._query()
                 assert np.array_equal(q.indices(), np.flatnonzero(v8 > med).astype(np.int64) + 1), (name, k)
+                assert t.decode_status("v") == 0, (name, k)
                 assert np.array_equal(dfdb_mod.materialize(t)["v"].to_numpy(), v8), (name, k)
             fam = "lz4_decode." if pipe == 1 else "lz4_decode_scan."           # (the pipeline decodes, then the ordinary scan runs: few blocks)
             got = {k: c.profile_get(fam + k)[0] for k in ("plain", "recording", "indexed")}
             c.profile(False)
             assert got == {"plain": 0, "recording": 1, "indexed": 2}, got
             t.close()
+    finally:
+        c.close()
+
+
+def test_decode_status_reports_what_the_resident_decode_said(oracle, dfdb_mod, tmp_path):
+    """dfdb_table_decode_status: 0 bad blocks after a resident decode of valid blocks (BlockStreams.jl:112's assertion holds for each); a column that
+    kept no blocks is an ArgumentError, an ordinal out of range a KeyError."""
+    n = 150_000
+    x = (np.arange(n, dtype=np.int64) * 7919) % 1000
+    ot = oracle.Table(block_size=4096); ot.add_column("x", x); ot.add_column("s", ["r%d" % (i % 7) for i in range(n)]); ot.save(str(tmp_path / "t"))
+    c = dfdb_mod.Context(0)
+    try:
+        c.set_option("keep_compressed", 1)
+        t = dfdb_mod.open_table(str(tmp_path / "t"), ctx=c)
+        for pipe in (0, 1):
+            c.set_option("lz4_pipeline", pipe)
+            for _ in range(2):
+                t.decode_resident("x")
+                assert t.decode_status("x") == 0
+        with pytest.raises(ValueError, match="holds no compressed blocks"):      # DFDB_ERR_ARGUMENT -> ArgumentError
+            t.decode_status("s")                       # String columns keep none
+        t.close()
+        c.set_option("keep_compressed", 0)
+        t2 = dfdb_mod.open_table(str(tmp_path / "t"), ctx=c)
+        with pytest.raises(ValueError, match="holds no compressed blocks"):      # DFDB_ERR_ARGUMENT -> ArgumentError
+            t2.decode_status("x")
+        t2.close()
     finally:
         c.close()

@@ -380,6 +380,7 @@ def test_random_tables_written_by_the_device_read_back(oracle, dfdb_mod, ctx, tm
                     continue
                 for k in range(2):
                     kt.decode_resident(name)
+                    assert kt.decode_status(name) == 0, (pth, name, k)
                     got = dfdb_mod.materialize(kt[dfdb_mod.ALL, [name]])[name].to_numpy()
                     assert np.array_equal(got.view(np.uint8), np.asarray(v).view(np.uint8)), (pth, name, k)
             kt.close()
