@@ -176,6 +176,9 @@ function device()
         # loaded: `t.brand .== "sony"` then scans 2 bytes per row (include/dfdb.h: dfdb_table_build_dictionary); 0 turns it off
         dictn = something(tryparse(Int, get(ENV, "DFDB_STRING_DICTIONARY", "")), 4096)
         check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "string_dictionary", dictn))
+        # DFDB_KEEP_COMPRESSED=1: plain fixed-width columns keep their LZ4 blocks in HBM beside the decoded array (gpu_redecode! below; include/dfdb.h: keep_compressed)
+        keepc = something(tryparse(Int, get(ENV, "DFDB_KEEP_COMPRESSED", "")), 0)
+        check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "keep_compressed", keepc))
         grp = Ref{Ptr{Cvoid}}(C_NULL)
         n = ngpus()
         if n > 1
@@ -374,6 +377,23 @@ end
 
 "materialize(c::DFColumn) on the device(s) (materialization.jl:46-52): the one projection column as a Vector{T} / BitVector."
 gpu_materialize(c::DFColumn) = gpu_materialize_columns(c.view)[1]
+
+"""
+    gpu_redecode!(t::DFTable, col::Symbol) -> Int
+
+Run the block decoder again over the LZ4 blocks column `col` kept in HBM (DFDB_KEEP_COMPRESSED=1 when the table was first touched) — the device-side
+equivalent of re-reading the column through `BlockStream` (`read_block`, src/io/BlockStreams.jl:101-119) — and return how many blocks did NOT decode to
+their stored size: 0 is the reference's `@assert size == sizes.origin "decompression error"` (:112) holding for every block.  Single-GPU tables only.
+"""
+function gpu_redecode!(t::DFTable, col::Symbol)
+    sharded() && throw(Unsupported("gpu_redecode! over a sharded table"))
+    h = device_table(t)
+    ord = ordinals(t)[col] % Int32        # checked: a 0-based column ordinal, 0 <= ord < ncol
+    check(ccall((:dfdb_table_decode_resident, LIB), Int32, (Ptr{Cvoid}, Int32), h, ord))
+    bad = Ref{Int64}(0)
+    check(ccall((:dfdb_table_decode_status, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), h, ord, bad))
+    Int(bad[])                            # checked: Int64 -> Int is the identity on a 64-bit host
+end
 
 "unique(col::DFColumn) on the device(s) (docs/src/index.md:171-182, 479-487): distinct values in order of first appearance over the WHOLE table —
 sharded: every GPU reduces its block range, the per-shard distinct sets are merged by key in rank order inside the library (dfdb_group_query_unique)."
