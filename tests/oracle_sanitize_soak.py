@@ -3,7 +3,7 @@
 projections / aggregates of tests/test_gpu_fuzz.py evaluated by the ORACLE ALONE, plus file round trips through its LZ4 block writer and reader.  The parity
 suites trust the oracle's answers; undefined behaviour in it (a signed overflow the compiler may fold, a shift by 64, a read past a block) would make those
 answers depend on the compiler.
-    python tools/oracle_sanitize_soak.py [--seeds 3000] [--seed0 0]
+    python tests/oracle_sanitize_soak.py [--seeds 3000] [--seed0 0]
 builds oracle/_san/liboracle.so (gcc -fsanitize=address,undefined -fno-sanitize-recover=undefined) and re-runs itself with the sanitizer runtimes preloaded;
 any report ends the run with a non-zero status."""
 import argparse

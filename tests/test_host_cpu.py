@@ -321,14 +321,14 @@ def test_ctypes_structs_mirror_the_header():
 
 
 def test_oracle_is_clean_under_address_and_ub_sanitizers():
-    """The parity suites take the oracle's word; it must not owe its answers to undefined behaviour.  tools/oracle_sanitize_soak.py rebuilds it with
+    """The parity suites take the oracle's word; it must not owe its answers to undefined behaviour.  tests/oracle_sanitize_soak.py rebuilds it with
     gcc -fsanitize=address,undefined and evaluates the fuzz suite's random queues / projections (and file round trips) with the oracle alone."""
     import shutil
     import subprocess
     import sys
     if not shutil.which("gcc") or not os.path.exists(subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()):
         pytest.skip("gcc's sanitizer runtimes are not installed")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "oracle_sanitize_soak.py"), "--seeds", "1500", "--seed0", "7000000"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "oracle_sanitize_soak.py"), "--seeds", "1500", "--seed0", "7000000"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-4000:]
     assert "no sanitizer report" in r.stdout.decode()
