@@ -30,6 +30,10 @@ def counters(path, want):
 
 def main():
     shutil.copy(os.path.join(SRC, "stats", "b_kernel_stats.csv"), os.path.join(DST, "r3_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "stats_step", "b_kernel_stats.csv")):
+        shutil.copy(os.path.join(SRC, "stats_step", "b_kernel_stats.csv"), os.path.join(DST, "r3_kernel_stats_step_only.csv"))
+        with open(os.path.join(DST, "r3_bench_step_under_rocprof.json"), "w") as f:
+            f.writelines(json_lines(os.path.join(SRC, "bench_step_under_rocprof.json")))
     for a, b in (("bench_under_rocprof.json", "r3_bench_under_rocprof.json"), ("bench_default.json", "r3_bench_default.json"),
                  ("bench_exchange_lib.json", "r3_bench_exchange_lib.json"), ("bench_2ranks_gloo_device0.json", "r3_bench_2ranks_gloo_device0.json"),
                  ("bench_config5_host_shards4.json", "r3_bench_config5_host_shards4.json")):
