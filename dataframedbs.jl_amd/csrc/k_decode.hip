@@ -223,6 +223,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     auto flush_to = [&](uint32_t upto) {
       if (SCAN) {
         // `flushed` is a multiple of 512 here; a group shorter than 512 bytes can only be the block's last
+#pragma unroll 1
         for (uint32_t g = flushed; g < upto; g += 512u) {
           const bool have = g + lane * 8u + 8u <= upto;
           const uint64_t v = *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1)));      // (always inside the ring: only the ballot needs `have`)
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
       }
       if (!SCAN && (flushed & 7u) == 0 && (((uintptr_t)out) & 7u) == 0) {        // whole 512-byte steps, 8 bytes per lane
         const uint32_t n512 = (upto - flushed) & ~511u;
+#pragma unroll 1                                                         // (one or two trips: an unrolled form spends more scalar instructions on its trip count than the loop has work)
         for (uint32_t o0 = 0; o0 < n512; o0 += 512) {
           const uint32_t o = o0 + lane * 8;
           const uint64_t v = *(const uint64_t*)(ring + ((flushed + o) & (kRing - 1)));
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
       }
       if ((flushed & 3u) == 0 && (((uintptr_t)out) & 3u) == 0) {
         const uint32_t n4 = (upto - flushed) & ~3u, n256 = n4 & ~255u;
+#pragma unroll 1
         for (uint32_t o0 = 0; o0 < n256; o0 += 256) {                    // whole 256-byte steps: every lane stores (a wave-uniform loop: no exec bookkeeping)
           const uint32_t o = o0 + lane * 4;
           const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1)));
@@ -615,8 +618,11 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
               // off7 = the match distance when it can fall inside a 64-byte row (else 127): lane - off7 is then the lane that makes the byte
               const uint32_t litend = ostart + lit;
               const uint32_t lbo = (ip + inpos - ostart) & (uint32_t)(kStage - 1);
-              const uint32_t mbo = far ? (((fo * 24u + (kParserFar ? (uint32_t)pslot * (uint32_t)(kFarMax * 24) : 0u) - litend) & (uint32_t)(kStage - 1)) | (uint32_t)(kStage + kRing))
-                                       : (((op - offset) & (uint32_t)(kStage - 1)) | (uint32_t)kStage);
+              // (both forms computed, one kept by a mask: as a conditional the compiler turns it into two exec-masked regions, four scalar instructions per row of sequences)
+              const uint32_t mfar = ((fo * 24u + (kParserFar ? (uint32_t)pslot * (uint32_t)(kFarMax * 24) : 0u) - litend) & (uint32_t)(kStage - 1)) | (uint32_t)(kStage + kRing);
+              const uint32_t mnear = ((op - offset) & (uint32_t)(kStage - 1)) | (uint32_t)kStage;
+              const uint32_t fsel = 0u - (uint32_t)far;
+              const uint32_t mbo = (mfar & fsel) | (mnear & ~fsel);
               const uint32_t off7 = far || offset > 127u ? 127u : offset;
               info[k] = make_uint2(litend | lbo << 16, mbo | off7 << 16);
               atomicOr(&bits[ostart >> 5], 1u << (ostart & 31u));
