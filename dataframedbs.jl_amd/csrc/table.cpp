@@ -445,6 +445,8 @@ int64_t table_decode_status(dfdb_table* t, int32_t ordinal) {
   HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
   int64_t bad = 0;
   for (int32_t v : st) bad += v != 0;
+  // a decode that went wrong may have been reading (or writing) the sequence-start index: drop it, the next decode parses for itself and records a new one
+  if (bad > 0) { c.comp_index.release(); c.comp_index_state = 0; }
   return bad;
 }
 

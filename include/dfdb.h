@@ -207,7 +207,8 @@ int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal);
 /* What the last decode of the column's resident blocks said (dfdb_table_decode_resident, or a decode_on_scan execution): waits for the context's stream and
  * counts the blocks whose decode did not end with exactly the stored size — the reference's `@assert size == sizes.origin "decompression error"`
  * (BlockStreams.jl:112).  *bad_blocks receives the count; with bad_blocks == NULL a count > 0 is DFDB_ERR_FORMAT ("decompression error").  The blocks
- * were validated when the column was loaded, so anything but 0 means the resident copy (or the sequence-start index beside it) was damaged. */
+ * were validated when the column was loaded, so anything but 0 means the resident copy (or the sequence-start index beside it) was damaged; the index is
+ * dropped then, and the next decode parses the blocks for itself and records a new one. */
 int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_blocks);
 /* Dictionary form of a resident, non-nullable String column with at most max_entries (<= 65535) distinct values: one 16-bit code per row and the
  * distinct strings once, kept BESIDE the FlatStringsVector form (the reference has no such form: docs/src/index.md lists dictionary encoding under
