@@ -491,6 +491,7 @@ def main():
     ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
     ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores 0 plain, 1 nontemporal, 2 write-through (ctx option compact_store)")
     ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
+    ap.add_argument("--placement-count-candidates", type=int, default=None, help="A/B: fresh allocations of the query's tile-count array the calibration tries (ctx option placement_count_candidates)")
     ap.add_argument("--placement-column-candidates", type=int, default=None, help="A/B: fresh allocations of the column the calibration tries (ctx option placement_column_candidates; 0 = bitmaps only)")
     ap.add_argument("--placement-candidates", type=int, default=None, help="A/B: candidate bitmaps the calibration tries (ctx option placement_candidates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
@@ -576,6 +577,8 @@ def main():
             ctx.set_option("placement_candidates", args.placement_candidates)
         if args.placement_column_candidates is not None:
             ctx.set_option("placement_column_candidates", args.placement_column_candidates)
+        if args.placement_count_candidates is not None:
+            ctx.set_option("placement_count_candidates", args.placement_count_candidates)
         t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
         t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
         t.set_row_base(rank * rows)
@@ -643,6 +646,8 @@ def main():
     _, pl_wall = ctx.profile_get("placement_wall_us")
     pc_n, pc_best = ctx.profile_get("placement_column_best_us")
     _, pc_worst = ctx.profile_get("placement_column_worst_us")
+    pt_n, pt_best = ctx.profile_get("placement_counts_best_us")
+    _, pt_worst = ctx.profile_get("placement_counts_worst_us")
 
     for _ in range(args.warmup):
         step()
@@ -709,6 +714,7 @@ def main():
                        "device": info["name"], "global_selected": total_sel,
                        "placement_calibration": ({"candidates_best_ms": pl_best / 1e3, "candidates_worst_ms": pl_worst / 1e3, "sample_rows": local_rows, "one_time_seconds": pl_wall / 1e6,
                                                   "column_candidates_best_ms": pc_best / 1e3 if pc_n else None, "column_candidates_worst_ms": pc_worst / 1e3 if pc_n else None,
+                                                  **({"count_candidates_best_ms": pt_best / 1e3, "count_candidates_worst_ms": pt_worst / 1e3} if pt_n else {}),
                                                   "what": "one-time: the scan timed on fresh allocations of the column (device-to-device copies; the fastest becomes the column), then against "
                                                           "9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in; `default_config` is the same step before it)"}
                                                  if pl_n else "off")},

@@ -117,6 +117,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     keeps the fastest bitmap for the queries that scan it (query.cpp: place_mask; default 0: ~60 scans, copies of the column and 0.03-1.4 s of
  *                     allocations once per column buy ~3.5 % of K1 on average and halve its spread; bench.py turns it on).  "placement_column_candidates"
  *                     (8, at most 16; 0 = leave the column where it is; needs that many times the column's size of free HBM for the duration),
+ *                     "placement_count_candidates" (4, at most 16; 0 = leave it: the query's 4-bytes-per-1024-rows tile-count array is tried in a few allocations too: 1-2.5 %),
  *                     "placement_spacer_mb" (0: round 2 held 12288 MB between the candidate bitmaps, which costs seconds to release and buys
  *                     nothing once the column is re-placed) / "placement_candidates" (8) size the search.  Pointers obtained from the table before the calibration
  *                     are not affected: the ABI never hands out a resident column's address
