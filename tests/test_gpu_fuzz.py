@@ -187,11 +187,23 @@ def filed(oracle, dfdb_mod, tmp_path_factory):
     cols["z"] = rng.integers(-2, 3, N).astype(np.int64)                                                        # 11: zeros everywhere
     cols["zl"] = np.where(np.arange(N) >= 2 * N // 3, rng.integers(0, 2, N), rng.integers(1, 5, N)).astype(np.int64)   # 12: zeros in the last third only
     path = str(tmp_path_factory.mktemp("fuzz") / "tb")
-    p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK, via_files=path)
+    # DFDB_FUZZ_KEEP=1 (with DFDB_FUZZ_BLOCK a multiple of 1024): the resident table keeps its LZ4 blocks and every fresh single-term scan of an 8-byte column
+    # decodes them again on the way (decode_on_scan: K7 fused with the predicate, or the two-wave pipeline + scan, with the sequence-start index after the first)
+    keep = os.environ.get("DFDB_FUZZ_KEEP", "0") == "1"
+    ctx0 = dfdb_mod.default_context(0)
+    if keep:
+        ctx0.set_option("keep_compressed", 1)
+    try:
+        p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK, via_files=path)
+    finally:
+        ctx0.set_option("keep_compressed", 0)
+    if keep:
+        ctx0.set_option("decode_on_scan", 1)
     lazy = dfdb_mod.open_table(path, load=False)
     g = G.Group.create([0, 0, 0], NAT.EXCHANGE_HOST)
     gt = G.GroupTable.open(g, path)
     yield p, lazy, gt
+    ctx0.set_option("decode_on_scan", 0)
     gt.close(); g.close(); lazy.close()
 
 
