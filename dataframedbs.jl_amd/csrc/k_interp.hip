@@ -81,7 +81,7 @@ static DInstr pack_instr(const IInstr& i) {
 }
 struct IColDesc {
   const void* data; const uint64_t* missing; const int64_t* tile_off; const uint8_t* bytes;
-  int32_t dtype; int32_t pad;
+  int32_t dtype; int32_t wide;     // wide: an 8-byte column (Int64 / UInt64 / Float64): loaded as it is, no dtype switch
 };
 struct IProgram {
   int32_t n, ncols, result_dtype, nstr;
@@ -256,6 +256,7 @@ __device__ __forceinline__ void load_words(const void* data, int64_t base, const
   }
 }
 __device__ __forceinline__ void load_col(const IColDesc& c, int64_t base, const uint32_t (&idx)[kW], uint64_t (&B)[kW]) {
+  if (c.wide) { load_words<uint64_t, false>(c.data, base, idx, B); return; }      // (one scalar test instead of a ten-way dtype tree)
   switch (c.dtype & DFDB_DTYPE_MASK) {
     case DFDB_I64: case DFDB_U64: case DFDB_F64: load_words<uint64_t, false>(c.data, base, idx, B); break;
     case DFDB_I32: case DFDB_STRING: load_words<int32_t, false>(c.data, base, idx, B); break;   // String: the size
@@ -451,7 +452,10 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
         }
         if (in_cva) convert(A, in_cva);
         if (in_cvb) convert(B, in_cvb);
-        switch (in_h) {
+        // the handlers as a local function of the handler id: called with a CONSTANT id for the commonest ones (the switch folds to that one case), so that a compare or an
+        // add is found after one or two scalar compares instead of the six levels of a 43-way compare tree — the dispatch loop is bound by the CU's one scalar unit
+        auto handler = [&](const int hh) __attribute__((always_inline)) {
+        switch (hh) {
           case H_LOAD:
 #pragma unroll
             EACH { A[k] = B[k]; Am[k] = Bm[k]; }
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
           } break;
           case H_STRCMP: case H_STRPRE: case H_STRSUF: {
             const IColDesc& c = prog->cols[in.slot];
-            const int op = in_cmp, pl = in.len, h = in_h; const bool flip = (fl & F_FLIP) != 0;
+            const int op = in_cmp, pl = in.len, h = hh; const bool flip = (fl & F_FLIP) != 0;
             const uint8_t* pat = pool + in.imm; const int so = in.w2 >> 24;
 #pragma unroll
             EACH {
@@ -587,6 +591,17 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
             }
           } break;
         }
+        };
+        if (in_h == H_CMP_SS) handler(H_CMP_SS);
+        else if (in_h == H_CMP_FF) handler(H_CMP_FF);
+        else if (in_h == H_IADD) handler(H_IADD);
+        else if (in_h == H_IMUL) handler(H_IMUL);
+        else if (in_h == H_ISUB) handler(H_ISUB);
+        else if (in_h == H_FMUL) handler(H_FMUL);
+        else if (in_h == H_FADD) handler(H_FADD);
+        else if (in_h == H_AND) handler(H_AND);
+        else if (in_h == H_OR) handler(H_OR);
+        else handler(in_h);
       }
 #pragma unroll
       EACH {
@@ -647,6 +662,7 @@ struct Compiler {
     if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
     IColDesc d{}; d.data = c.data.p; d.missing = c.missing.as<uint64_t>(); d.tile_off = (const int64_t*)c.tile_off.p; d.bytes = c.bytes.as<uint8_t>();
     d.dtype = c.dtype;
+    { const int b = dt_base(c.dtype); d.wide = (b == DFDB_I64 || b == DFDB_U64 || b == DFDB_F64) ? 1 : 0; }
     prog.cols[col_ord.size()] = d;
     col_ord.push_back(ordinal);
     return (int)col_ord.size() - 1;
