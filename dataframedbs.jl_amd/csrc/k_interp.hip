@@ -454,142 +454,16 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
         if (in_cvb) convert(B, in_cvb);
         // the handlers as a local function of the handler id: called with a CONSTANT id for the commonest ones (the switch folds to that one case), so that a compare or an
         // add is found after one or two scalar compares instead of the six levels of a 43-way compare tree — the dispatch loop is bound by the CU's one scalar unit
+        if constexpr (NUL) {
+          // (the kernels that carry missing flags are register-bound: wrapped in the local function below they lose a wave per SIMD and run 13-16 % slower)
+          const int hh = in_h;
+          switch (hh) {
+#include "k_interp_handlers.inc"
+          }
+        } else {
         auto handler = [&](const int hh) __attribute__((always_inline)) {
         switch (hh) {
-          case H_LOAD:
-#pragma unroll
-            EACH { A[k] = B[k]; Am[k] = Bm[k]; }
-            break;
-          case H_FADD: FLOAT_OP(v = a + b);
-          case H_FSUB: FLOAT_OP(v = a - b);
-          case H_FMUL: FLOAT_OP(v = a * b);
-          case H_FDIV: FLOAT_OP(v = a / b);
-          case H_FREM: FLOAT_OP(v = slow_frem(a, b));
-          case H_FMOD: FLOAT_OP(v = slow_fmod(a, b));
-          case H_FIDIV: FLOAT_OP(v = slow_fidiv(a, b));
-          case H_FMIN: FLOAT_OP(v = jl_fmin(a, b));
-          case H_FMAX: FLOAT_OP(v = jl_fmax(a, b));
-          case H_FNEG: FLOAT_OP(v = -a);
-          case H_FABS: FLOAT_OP(v = __builtin_fabs(a));
-          case H_FROUND32: FLOAT_OP(v = (double)(float)a);   // Float32 arithmetic: the double result rounded once
-          case H_IADD: INT_OP(v = a + b);
-          case H_ISUB: INT_OP(v = a - b);
-          case H_IMUL: INT_OP(v = a * b);
-          case H_IMIN_S: INT_OP(v = (int64_t)a < (int64_t)b ? a : b);
-          case H_IMIN_U: INT_OP(v = a < b ? a : b);
-          case H_IMAX_S: INT_OP(v = (int64_t)a > (int64_t)b ? a : b);
-          case H_IMAX_U: INT_OP(v = a > b ? a : b);
-          case H_INEG: INT_OP(v = 0 - a);
-          case H_IABS: INT_OP(v = (int64_t)a < 0 ? 0 - a : a);
-          case H_WRAP: INT_OP(v = a);
-          case H_AND: INT_OP(v = a & b);
-          case H_OR: INT_OP(v = a | b);
-          case H_XOR: INT_OP(v = a ^ b);
-          case H_IDIVOP: {   // div / rem / mod (Julia: DivideError on ÷0 and typemin ÷ -1)
-            const int op = in_cmp; const bool uns = (fl & F_UNS) != 0; const int64_t tmin = (int64_t)in.imm2;
-#pragma unroll
-            EACH {
-              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);   // missing ÷ x is missing, not an error
-              const int64_t a = (int64_t)wrapv(A[k], wsh, wsg), b = (int64_t)wrapv(B[k], wsh, wsg);
-              const uint64_t v = slow_idivop(a, b, op, uns, tmin, alive, err, (uint64_t)(base + idx[k]));
-              A[k] = wrapv(v, wsh, wsg);
-            }
-          } break;
-          case H_BAND1:
-#pragma unroll
-            EACH A[k] = A[k] & B[k] & 1ull;
-            break;
-          case H_BOR1:
-#pragma unroll
-            EACH A[k] = (A[k] | B[k]) & 1ull;
-            break;
-          case H_NOT:
-#pragma unroll
-            EACH A[k] = !(A[k] & 1ull);
-            break;
-#define CMP_CASES(TYPE, LOADA, LOADB)                                                                              \
-          {                                                                                                        \
-            switch (in_cmp) {                                                                                      \
-              case DFIR_EQ: _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a == b; } break;      \
-              case DFIR_NE: _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a != b; } break;      \
-              case DFIR_LT: _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a < b; } break;       \
-              case DFIR_LE: _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a <= b; } break;      \
-              case DFIR_GT: _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a > b; } break;       \
-              default:      _Pragma("unroll") EACH { const TYPE a = LOADA, b = LOADB; A[k] = a >= b; } break;      \
-            }                                                                                                      \
-          } break
-          case H_CMP_FF: CMP_CASES(double, bits_d(A[k]), bits_d(B[k]));   // IEEE: every ordered comparison with NaN is false, != true
-          case H_CMP_SS: CMP_CASES(int64_t, (int64_t)A[k], (int64_t)B[k]);
-          case H_CMP_UU: CMP_CASES(uint64_t, A[k], B[k]);
-          case H_CMP_US: {   // UInt64 vs a signed integer
-            const int op = in_cmp;
-#pragma unroll
-            EACH { const uint64_t a = A[k]; const int64_t b = (int64_t)B[k]; const bool neg = b < 0; A[k] = cmp_pick(op, !neg && a < (uint64_t)b, !neg && a == (uint64_t)b, false); }
-          } break;
-          case H_CMP_IF: {   // integer vs float, exact (no rounding of the integer)
-            const int op = in_cmp; const bool xu = (fl & F_UNS) != 0;
-#pragma unroll
-            EACH { const int c = slow_cmp_int_float((int64_t)A[k], xu, bits_d(B[k])); A[k] = cmp_pick(op, c == -1, c == 0, c == 2); }
-          } break;
-          case H_STRCMP: case H_STRPRE: case H_STRSUF: {
-            const IColDesc& c = prog->cols[in.slot];
-            const int op = in_cmp, pl = in.len, h = hh; const bool flip = (fl & F_FLIP) != 0;
-            const uint8_t* pat = pool + in.imm; const int so = in.w2 >> 24;
-#pragma unroll
-            EACH {
-              const int32_t sz = ((const int32_t*)c.data + base)[idx[k]];   // idx is clamped: always a valid row
-              const int len = (inb[k] && sz > 0) ? sz : 0;
-              const uint8_t* p = c.bytes + (int64_t)lds[((stack_levels + so) * kW + k) * kBlock + tid];
-              A[k] = slow_strop(h == H_STRCMP, h == H_STRSUF, p, len, pat, pl, op, flip);
-              Am[k] = (NUL && (c.dtype & DFDB_NULLABLE)) ? (uint32_t)(sz < 0) : 0u;
-            }
-          } break;
-          case H_ISMISS: {
-            const uint64_t* m = prog->cols[in.slot].missing;
-#pragma unroll
-            EACH { const int64_t lrow = base + idx[k]; A[k] = m ? ((m[lrow >> 6] >> (lrow & 63)) & 1ull) : 0ull; Am[k] = 0; }
-          } break;
-          // three-valued logic on Bool (Julia: false & missing == false, true | missing == true): one known operand can settle it
-          case H_AND3:
-#pragma unroll
-            EACH {
-              const uint32_t a = (uint32_t)A[k] & 1u, b = (uint32_t)B[k] & 1u, am = Am[k], bm = Bm[k];
-              const uint32_t decided = (!am && !a) || (!bm && !b);
-              Am[k] = (am | bm) && !decided;
-              A[k] = decided ? 0u : (a & b);
-            }
-            break;
-          case H_OR3:
-#pragma unroll
-            EACH {
-              const uint32_t a = (uint32_t)A[k] & 1u, b = (uint32_t)B[k] & 1u, am = Am[k], bm = Bm[k];
-              const uint32_t decided = (!am && a) || (!bm && b);
-              Am[k] = (am | bm) && !decided;
-              A[k] = decided ? 1u : (a | b);
-            }
-            break;
-          case H_COALESCE:   // the first non-missing argument
-#pragma unroll
-            EACH { if (Am[k]) A[k] = B[k]; Am[k] &= Bm[k]; }
-            break;
-          case H_ISMISSA:    // ismissing of a computed value
-#pragma unroll
-            EACH { A[k] = Am[k]; Am[k] = 0; }
-            break;
-          case H_INSET: {
-            const uint64_t* set = (const uint64_t*)(pool + in.imm);
-            const int ta = in.w2 & 0xff, tb = (in.w2 >> 8) & 0xff, n = in.len;
-#pragma unroll
-            EACH A[k] = slow_inset(A[k], ta, set, n, tb);
-          } break;
-          case H_CAST: {
-            const int ta = in.w2 & 0xff, rt = (in.w2 >> 16) & 0xff;
-#pragma unroll
-            EACH {
-              const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull) && !(NUL && Am[k]);
-              A[k] = slow_cast(A[k], ta, rt, alive, err, (uint64_t)(base + idx[k]));
-            }
-          } break;
+#include "k_interp_handlers.inc"
         }
         };
         if (in_h == H_CMP_SS) handler(H_CMP_SS);
@@ -602,6 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
         else if (in_h == H_AND) handler(H_AND);
         else if (in_h == H_OR) handler(H_OR);
         else handler(in_h);
+        }
       }
 #pragma unroll
       EACH {

@@ -6,7 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
+from dfdb import _native as _N  # noqa: E402
+if os.environ.get("R3_LIB"):                 # A/B against another build of the library (this tool only)
+    _N.LIB_PATH = os.path.abspath(os.environ["R3_LIB"])
 import dfdb  # noqa: E402
+import numpy as np  # noqa: E402
 
 
 def main():
@@ -24,6 +28,12 @@ def main():
              "a * 3 + b * 2 - 7 > 4e6 (2 cols)": t[t.a * 3 + t.b * 2 - 7 > 4_000_000, dfdb.ALL],
              "(a + b) * x > 3e9 (3 cols, 24 B/row)": t[(t.a + t.b) * t.x > 3e9, dfdb.ALL],
              "(a > b) | (x * 2 > a) (3 cols)": t[(t.a > t.b) | (t.x * 2 > t.a), dfdb.ALL]}
+    # a nullable column (Union{Int64,Missing}): the kernels that carry missing flags
+    nn = min(a.rows, 200_000_000)
+    tn = dfdb.DFTable.from_columns({"m": np.ma.masked_array(np.arange(nn, dtype=np.int64) % 1000, mask=(np.arange(nn) % 7 == 0)), "a": (np.arange(nn, dtype=np.int64) * 7919) % 1000}, ctx=ctx)
+    from dfdb import ir
+    cases["coalesce(m, 0) + a > 900 (nullable, 2e8 rows)"] = tn[ir.coalesce(ir.col(0), 0) + ir.col(1) > 900, dfdb.ALL]
+    cases["(m > 500) & (a < 900) three-valued (nullable, 2e8 rows)"] = tn[ir.coalesce((ir.col(0) > 500) & (ir.col(1) < 900), False), dfdb.ALL]
     for name, v in cases.items():
         q = v._query(); n = q.count()
         ctx.profile(True)
