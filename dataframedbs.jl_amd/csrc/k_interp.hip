@@ -450,8 +450,10 @@ __global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ 
 #pragma unroll
           EACH Am[k] |= Bm[k];
         }
-        if (in_cva) convert(A, in_cva);
-        if (in_cvb) convert(B, in_cvb);
+        if (w0 >> 16) {                                                     // (one test for the usual case: neither operand is converted)
+          if (in_cva) convert(A, in_cva);
+          if (in_cvb) convert(B, in_cvb);
+        }
         // the handlers as a local function of the handler id: called with a CONSTANT id for the commonest ones (the switch folds to that one case), so that a compare or an
         // add is found after one or two scalar compares instead of the six levels of a 43-way compare tree — the dispatch loop is bound by the CU's one scalar unit
         if constexpr (NUL) {
