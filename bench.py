@@ -23,8 +23,8 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
                   exchange through the library's own group path: dfdb_group_* with its RCCL communicator), "5_shard_dictionary", "5_shard_materialize"
                   ([a, x] left sharded on the devices: dfdb_group_materialize_device).  Each: rows, selected, ms_per_step, per-kernel avg_ms,
                   algorithmic_GB, rows_per_s (whole job) and roofline {achieved, peak, frac} in algorithmic bytes per GPU.
-  default_config  config 2 with the library's default options, measured FIRST in the process (no placement calibration: what a caller gets who sets no option;
-                  the calibration that `value` runs with re-places the column and picks a bitmap allocation, config.placement_calibration says what it saw)
+  calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
+                  `value` itself is the library-default configuration (no ctx option set)
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cpu_baseline    N = 1: the oracle on the host cores
@@ -294,12 +294,21 @@ class Legs:
         ctx.profile(False)
         return sec, ks
 
-    def record(self, rows, selected, sec, ks, bytes_per_gpu, what, **extra):
+    def record(self, rows, selected, sec, ks, bytes_per_gpu, what, bytes_read=None, **extra):
+        """bytes_per_gpu: SURVEY.md section 8d's algorithmic bytes of the job.  A leg that reads a SMALLER representation than the one those bytes are counted on
+        (dictionary codes instead of the flat String column) passes bytes_read = what it really moves: `roofline.frac` is then that over time over peak — a
+        fraction of something the HBM delivered — and the flat-column figure is kept beside it as `frac_flat_equivalent`."""
         gbps = bytes_per_gpu / sec / 1e9
         r = {"what": what, "rows_per_gpu": rows, "selected_per_gpu": selected, "ms_per_step": sec * 1e3, "steps": self.steps, "kernels_avg_ms": ks,
              "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world / sec, "placement_calibrate": self.calibrate,
              "roofline": {"bound": "hbm", "achieved": gbps, "peak": self.peak, "unit": "GB/s", "frac": gbps / self.peak,
                           "what": "algorithmic bytes of the whole job per GPU (SURVEY.md section 8d) / step time"}}
+        if bytes_read is not None:
+            rg = bytes_read / sec / 1e9
+            r["bytes_read_GB"] = bytes_read / 1e9
+            r["roofline"] = {"bound": "hbm", "achieved": rg, "peak": self.peak, "unit": "GB/s", "frac": rg / self.peak, "frac_flat_equivalent": gbps / self.peak,
+                             "what": "bytes this leg really reads and writes per GPU (the dictionary's 2-byte codes stand in for the flat String column) / step time; "
+                                     "frac_flat_equivalent prices the FLAT column's algorithmic bytes instead and is not a fraction of delivered bandwidth"}
         r.update(extra)
         return r
 
@@ -369,8 +378,9 @@ def config4_legs(L, dfdb, rows, rank):
     L.torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     sec, ks = L.timed(step)
-    res["4_dictionary"] = L.record(rows, nsel, sec, ks, byts, "the same query with 16-bit dictionary codes beside s (dfdb_table_build_dictionary): the predicate is a bit-table lookup; "
-                                   "algorithmic bytes still count the FLAT column, so the fraction can exceed what HBM delivers", dictionary_entries=nd, dictionary_build_s=build_s)
+    res["4_dictionary"] = L.record(rows, nsel, sec, ks, byts, "the same query with 16-bit dictionary codes beside s (dfdb_table_build_dictionary): the predicate is a bit-table lookup, "
+                                   "s == const makes the projected s a constant column",
+                                   bytes_read=rows * 2 + nsel * (8 + 8 + 4 + 4), dictionary_entries=nd, dictionary_build_s=build_s)
     del osz, oby, oa, q
     t.close()
     return res
@@ -456,9 +466,8 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
         build_s = time.perf_counter() - t0
         sec, ks = L.timed(step, gctx)
         res["5_shard_dictionary"] = L.record(per_gpu_rows, mine, sec, ks, per_gpu_rows * bytes_row,
-                                             "the same with 16-bit dictionary codes beside s: s != \"sony\" scans 2 B/row (algorithmic bytes still count the flat column)", exchange=exch,
-                                             global_count=out["count"], global_sum_x=out["sum"], dictionary_entries=nd[0], dictionary_build_s=build_s,
-                                             bytes_read_GB=per_gpu_rows * 18 / 1e9, frac_of_peak_in_bytes_read=per_gpu_rows * 18 / sec / 1e9 / L.peak)
+                                             "the same with 16-bit dictionary codes beside s: s != \"sony\" scans 2 B/row", exchange=exch, bytes_read=per_gpu_rows * 18,
+                                             global_count=out["count"], global_sum_x=out["sum"], dictionary_entries=nd[0], dictionary_build_s=build_s)
         gq.close(); gt.close()
         if own is not None:
             own.close()
@@ -488,7 +497,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
-    ap.add_argument("--no-placement", action="store_true", help="A/B: turn the one-time bitmap placement calibration off (ctx option placement_calibrate = 0)")
+    ap.add_argument("--placement", action="store_true", help="also measure the step with the opt-in placement calibration (ctx option placement_calibrate = 1) and report it as the "
+                    "extra key `calibrated_config`; `value` is always the library-default configuration")
+    ap.add_argument("--no-placement", action="store_true", help="(accepted for older command lines: the calibration is off unless --placement asks for it)")
     ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores 0 plain, 1 nontemporal, 2 write-through (ctx option compact_store)")
     ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
     ap.add_argument("--placement-count-candidates", type=int, default=None, help="A/B: fresh allocations of the query's tile-count array the calibration tries (ctx option placement_count_candidates)")
@@ -558,7 +569,7 @@ def main():
         grp = (G.Group.create_rank(local, uid, rank, world, stream=stream_obj.cuda_stream) if world == 1 or args.backend == "nccl"
                else G.Group.create_rank_torch(local, stream=stream_obj.cuda_stream))
         ctx = grp.ctx(0)
-        ctx.set_option("placement_calibrate", 0 if args.no_placement else 1)
+        ctx.set_option("placement_calibrate", 1 if args.placement else 0)
         nblocks_per = -(-(-(-(rows * world) // 65536)) // world)        # ceil(ceil(total / 65536) / world): the library's block-range rule
         gt = G.GroupTable.new(grp)
         gt.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows * world)   # every rank generates its own block range
@@ -606,49 +617,6 @@ def main():
     scan_row_bytes = 8 + 1 / 8 + 4 / 1024                          # ONE k_scan_cmp launch: 8 B/row column + 1/8 B/row bitmap + 4 B per 1024-row tile count
     total_rows = rows * world
 
-    # ---- first the step with the library's DEFAULT options (placement calibration off, the column and the bitmap where hipMalloc put them): what a
-    # caller gets who sets nothing.  It runs BEFORE the calibration, which moves the column.
-    default_cfg = None
-    if not lib and not args.no_placement:
-        for _ in range(max(args.warmup, 1)):
-            step()
-        ctx.profile(True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el2 = time.perf_counter() - t0
-        if world > 1:
-            e2 = torch.tensor([el2], dtype=torch.float64, device=dev)
-            all_reduce(e2, dist.ReduceOp.MAX)
-            el2 = float(e2.item())
-        n2, ms2 = ctx.profile_get("scan_cmp")
-        n3, ms3 = ctx.profile_get("compact_indices")
-        ctx.profile(False)
-        sms = ms2 / n2 if n2 else None
-        default_cfg = {"what": "the same step with the library's default options (ctx option placement_calibrate = 0), measured first: the column and the query's bitmap "
-                               "in the allocations hipMalloc handed out",
-                       "value": total_rows * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "scan_cmp_avg_ms": sms, "compact_indices_avg_ms": ms3 / n3 if n3 else None,
-                       "roofline_frac": (local_rows * scan_row_bytes / (sms * 1e-3) / 1e9 / peak) if sms else None,
-                       "job_hbm_gbps": total_rows * (8 + 8 * nsel / local_rows) / (el2 / args.steps) / 1e9}
-        # the resident column is scanned by every step: the engine's opt-in placement calibration pays here (its one-time cost is reported below).
-        # A fresh query's first execution runs it (query.cpp: place_mask).
-        ctx.set_option("placement_calibrate", 1)
-        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
-        assert q.count() == nsel
-    pl_n, pl_best = ctx.profile_get("placement_best_us")
-    _, pl_worst = ctx.profile_get("placement_worst_us")
-    _, pl_wall = ctx.profile_get("placement_wall_us")
-    pc_n, pc_best = ctx.profile_get("placement_column_best_us")
-    _, pc_worst = ctx.profile_get("placement_column_worst_us")
-    pt_n, pt_best = ctx.profile_get("placement_counts_best_us")
-    _, pt_worst = ctx.profile_get("placement_counts_worst_us")
-
     for _ in range(args.warmup):
         step()
     # roofline leg: HIP event pairs around every launch, recorded on the launch stream DURING the timed steps and resolved
@@ -676,6 +644,46 @@ def main():
         if n:
             kernels[k] = dict(launches=n, avg_ms=ms / n)
     ctx.profile(False)
+
+    # ---- opt-in (--placement): the same step after the engine's one-time placement calibration (query.cpp: place_mask re-places the column and picks a
+    # bitmap allocation).  An extra key; `value` above is what a caller gets who sets no option.
+    calibrated_cfg = None
+    if args.placement and not lib:
+        ctx.set_option("placement_calibrate", 1)
+        q = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()      # a fresh query's first execution runs the calibration
+        assert q.count() == nsel
+        for _ in range(max(args.warmup, 1)):
+            step()
+        ctx.profile(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            e2 = torch.tensor([el2], dtype=torch.float64, device=dev)
+            all_reduce(e2, dist.ReduceOp.MAX)
+            el2 = float(e2.item())
+        n2, ms2 = ctx.profile_get("scan_cmp")
+        n3, ms3 = ctx.profile_get("compact_indices")
+        ctx.profile(False)
+        sms = ms2 / n2 if n2 else None
+        calibrated_cfg = {"what": "the same step with ctx option placement_calibrate = 1 (opt-in), measured after `value`",
+                          "value": total_rows * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "scan_cmp_avg_ms": sms, "compact_indices_avg_ms": ms3 / n3 if n3 else None,
+                          "roofline_frac": (local_rows * scan_row_bytes / (sms * 1e-3) / 1e9 / peak) if sms else None,
+                          "job_hbm_gbps": total_rows * (8 + 8 * nsel / local_rows) / (el2 / args.steps) / 1e9}
+    pl_n, pl_best = ctx.profile_get("placement_best_us")
+    _, pl_worst = ctx.profile_get("placement_worst_us")
+    _, pl_wall = ctx.profile_get("placement_wall_us")
+    pc_n, pc_best = ctx.profile_get("placement_column_best_us")
+    _, pc_worst = ctx.profile_get("placement_column_worst_us")
+    pt_n, pt_best = ctx.profile_get("placement_counts_best_us")
+    _, pt_worst = ctx.profile_get("placement_counts_worst_us")
     res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -716,15 +724,16 @@ def main():
                                                   "column_candidates_best_ms": pc_best / 1e3 if pc_n else None, "column_candidates_worst_ms": pc_worst / 1e3 if pc_n else None,
                                                   **({"count_candidates_best_ms": pt_best / 1e3, "count_candidates_worst_ms": pt_worst / 1e3} if pt_n else {}),
                                                   "what": "one-time: the scan timed on fresh allocations of the column (device-to-device copies; the fastest becomes the column), then against "
-                                                          "9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in; `default_config` is the same step before it)"}
+                                                          "9 bitmap allocations, the fastest kept (ctx option placement_calibrate, opt-in: --placement; `value` is measured before it)"}
                                                  if pl_n else "off")},
             "job_hbm_gbps": job_bytes / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "GB/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }
-        if default_cfg is not None:
-            res["default_config"] = default_cfg
+        res["config"]["options"] = "library defaults (no ctx option set; placement_calibrate = 0)" if not (lib and args.placement) else "placement_calibrate = 1"
+        if calibrated_cfg is not None:
+            res["calibrated_config"] = calibrated_cfg
         if world == 1 and not lib and not args.no_decode_leg:
             try:
                 res["decode_scan"] = decode_scan_leg(dfdb, ctx, t, rows, max(3, min(args.steps, 10)), out.data_ptr(), cap, cnt.data_ptr(), torch.cuda.synchronize)
@@ -746,11 +755,11 @@ def main():
             if rank == 0 and res is not None:
                 res["configs"] = dict(done_legs, error=f"the config legs did not finish within {args.config_deadline} s: the process was ended by its own deadline")
                 emit(res)
-            os._exit(0)
+            os._exit(3)                                    # the line is out, and the exit status says the run did not end by itself (never a re-exec, nothing started)
         watchdog = threading.Timer(args.config_deadline, deadline)
         watchdog.daemon = True
         watchdog.start()
-        calibrate = 0 if (args.no_placement or args.config5_host_shards > 1) else 1   # the legs' tables stay resident and are scanned every step, like the headline's
+        calibrate = 1 if (args.placement and args.config5_host_shards <= 1) else 0   # library defaults unless --placement asks for the opt-in calibration
         ctx.set_option("placement_calibrate", calibrate)
         del out
         if not lib:

@@ -115,6 +115,7 @@ using namespace dfdb;
 
 constexpr int kXSlots = 16;   // 8-byte exchange slots per shard before the all-gather area
 constexpr int kFaultSlot = 3; // the fault key every exchange carries along (below)
+constexpr int kCountPin = 12; // pinned landing place (kFaultSlot + 1 slots, host side only) of a query's own {count, .., fault key} copy
 
 struct dfdb_group {
   int world = 1, first_rank = 0, exchange = DFDB_EXCHANGE_HOST;
@@ -154,8 +155,13 @@ struct dfdb_gquery {
   dfdb_gtable* gt = nullptr;
   std::vector<dfdb_query*> shard;        // owned
   bool planned = false;                  // stage bases are set for the current stage list
-  bool count_enqueued = false;           // the reduced count sits in slot 0 of every shard's exchange buffer
+  bool count_enqueued = false;           // the reduced count and the fault key of ITS exchange sit in `cres` (device, local shard 0)
   int64_t count = -1;                    // host copy of the global count
+  // {global count, .., fault key} (slots 0 .. kFaultSlot) of the exchange group_count_enqueue made for THIS query.  The group's exchange slots are shared by every
+  // collective of the group: a barrier, an allreduce_f64, another query's count or a failed aggregate between an enqueue-only
+  // dfdb_group_count(gq, NULL) and the call that reads the count rewrite slot 0 and the fault slot.  The pair is therefore copied out of the
+  // slots on the engine stream right behind the exchange, and group_count reads this copy: a count answers for its own exchange only.
+  DevBuf cres;
 };
 
 namespace dfdb {
@@ -457,9 +463,15 @@ static void group_count_enqueue(dfdb_gquery* gq, bool wait) {
     HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>(), q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
   });
   exchange_reduce(g, {XSpec{0, 1, DFDB_I64, DFDB_AGG_SUM}});      // a shard that failed is in the exchange all the same: its fault key travels with the count
+  // the pair this exchange produced, kept apart from the shared slots (dfdb_gquery::cres)
+  HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+  gq->cres.ensure((kFaultSlot + 1) * 8);                          // slots 0 .. kFaultSlot in one copy: the count is slot 0, the key the last
+  HIP_CHECK(hipMemcpyAsync(gq->cres.p, g->xbuf[0].p, (kFaultSlot + 1) * 8, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
   gq->count_enqueued = true; gq->count = -1;
-  // enqueue-only callers (dfdb_group_count(gq, NULL)) never read the slots back: a LOCAL failure is theirs to hear now; the other ranks meet
-  // it in the fault slot at their next host read (group_count / get_slot0)
+  // enqueue-only callers (dfdb_group_count(gq, NULL)) never read the result back: a LOCAL failure is theirs to hear now; the other ranks — and
+  // this one again — meet the agreed key in `cres` at their next read (group_count).  count_enqueued stays set on the failing rank too: clearing
+  // it here would make this rank alone enqueue a new exchange at the next dfdb_group_count(gq, &n) while the healthy ranks only read; the read
+  // raises on every rank alike (the key in `cres` includes this rank's) and THAT clears the flag everywhere.
   if (!wait && g->fault_key != ~0ull) { const Error e(g->fault_code, g->fault_msg); g->fault_key = ~0ull; g->fault_code = 0; g->fault_msg.clear(); throw e; }
 }
 
@@ -471,7 +483,14 @@ static int64_t group_count(dfdb_gquery* gq) {
   if (!gq->count_enqueued) group_count_enqueue(gq, true);
   int64_t n = 0;
   // (a fault the ranks agreed on invalidates the exchange for all of them alike: the next call enqueues again on every rank)
-  try { get_slot0(gq->gt->g, 0, 1, &n); } catch (...) { gq->count_enqueued = false; throw; }
+  dfdb_group* g = gq->gt->g;
+  try {
+    HIP_CHECK(hipSetDevice(g->ctx[0]->device));
+    HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kCountPin, gq->cres.p, (kFaultSlot + 1) * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    stream_wait(g->ctx[0]);
+    settle_fault(g, (uint64_t)g->xpin[0][kCountPin + kFaultSlot]);
+    n = g->xpin[0][kCountPin];
+  } catch (...) { gq->count_enqueued = false; throw; }
   gq->count = n;
   return n;
 }
@@ -607,6 +626,18 @@ int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t
     for (int l = 0; l < g->nlocal(); l++) {
       HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device));
       for (int k = 0; k < n; k++) { int64_t b; memcpy(&b, &vals[(size_t)l * n + k], 8); put_slot(g, l, 4 + k, b); }
+    }
+    if (op != DFDB_AGG_SUM && (g->exchange == DFDB_EXCHANGE_RCCL || g->exchange == DFDB_EXCHANGE_CALLBACK) && exchanges(g)) {
+      // Float64 MIN / MAX never reach ncclMin / ncclMax or the caller's allreduce (dfdb_exchange_fns promises that: a callback written to the
+      // header may only know integer min / max, and Julia's min / max propagate NaN): gather every rank's value and fold on the host, as
+      // dfdb_group_aggregate does
+      for (int k = 0; k < n; k++) {
+        const std::vector<int64_t> all = exchange_gather(g, 4 + k);
+        uint64_t acc = (uint64_t)all[0];
+        for (int r = 1; r < g->world; r++) acc = fold_bits(acc, (uint64_t)all[(size_t)r], DFDB_F64, op);
+        for (int l = 0; l < g->nlocal(); l++) memcpy(&vals[(size_t)l * n + k], &acc, 8);
+      }
+      return;
     }
     exchange_reduce(g, {XSpec{4, n, DFDB_F64, op}});
     for (int l = 0; l < g->nlocal(); l++) {

@@ -144,8 +144,12 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
       for (int k = 0; k < kCand; k++) { cand[(size_t)k].ensure(bytes); if (spacer >= ((size_t)64 << 20)) space[(size_t)k].ensure(spacer); }
     } catch (const Error&) { return; }
     const int64_t sample = nrows;      // the WHOLE column: how a bitmap allocation pairs with the first eighth says little about the rest (measured)
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    struct EventPair {                 // (a HIP_CHECK that throws inside time_on must not leak them: ADVICE r3)
+      hipEvent_t a = nullptr, b = nullptr;
+      ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     const void* colp = c.data.p;
     auto time_on = [&](uint64_t* bm) {
       float best = 1e30f;
@@ -191,21 +195,20 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     if (kTc > 0 && q->tile_counts.bytes > 0) {
       uint64_t* const bmx = kbest >= 0 ? cand[(size_t)kbest].as<uint64_t>() : q->bitmap.as<uint64_t>();
       std::vector<DevBuf> tcand((size_t)kTc);
-      float tc_best = time_on(bmx), tc_worst = tc_best; int tbest = -1;
+      float tc_best = time_on(bmx), tc_worst = tc_best; int tc_k = -1;
       for (int k = 0; k < kTc; k++) {
         try { tcand[(size_t)k].ensure(q->tile_counts.bytes); } catch (const Error&) { break; }
         std::swap(q->tile_counts, tcand[(size_t)k]);
         const float tk = time_on(bmx);
         std::swap(q->tile_counts, tcand[(size_t)k]);
-        if (tk < tc_best) { tc_best = tk; tbest = k; }
+        if (tk < tc_best) { tc_best = tk; tc_k = k; }
         if (tk > tc_worst) tc_worst = tk;
       }
       auto& pcb = ctx->prof["placement_counts_best_us"]; pcb.launches++; pcb.ms += tc_best * 1e3;
       auto& pcw = ctx->prof["placement_counts_worst_us"]; pcw.launches++; pcw.ms += tc_worst * 1e3;
       HIP_CHECK(hipStreamSynchronize(s));
-      if (tbest >= 0) std::swap(q->tile_counts, tcand[(size_t)tbest]);
+      if (tc_k >= 0) std::swap(q->tile_counts, tcand[(size_t)tc_k]);
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c.mask_ms_best = tbest; c.mask_ms_worst = tworst;
     auto& pe = ctx->prof["placement_best_us"]; pe.launches++; pe.ms += tbest * 1e3;
     auto& pw = ctx->prof["placement_worst_us"]; pw.launches++; pw.ms += tworst * 1e3;
@@ -482,6 +485,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       Column& fc = t->cols[(size_t)term_ords[0]];
       const int fdt = tb.t[0].dtype;
       if (fc.comp_nblocks > 0 && !dt_nullable(fc.dtype) && (fdt == DFDB_I64 || fdt == DFDB_U64 || fdt == DFDB_F64) && t->block_size % kTileRows == 0) {
+        q->decoded_col = term_ords[0];                   // query_count looks at the blocks' statuses where it waits for the count anyway
         // few blocks (every one resident in the two-wave pipeline at once): the pipeline, then the ordinary scan of the decoded column, is the shorter way —
         // a block's latency is what a small launch pays, and the fused form is one wave per block (1 526 blocks: 328 GB/s + a 0.13-ms scan against ~210 GB/s fused)
         const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
@@ -606,6 +610,7 @@ void query_execute(dfdb_query* q, int nstages) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
   q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  q->decoded_col = -1;
   q->gr_state = 0;             // a pending groupreduce belongs to the selection that is being replaced: its fetch must not restore the old one over this
   q->err_row[0] = q->err_row[1] = ~0ull;
   // A range-like stage that is EMPTY (an empty range, an empty index vector) finishes the reference's iteration before the first block is read:
@@ -656,7 +661,22 @@ int64_t query_count(dfdb_query* q, int nstages) {
   const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
   stream_wait(ctx);
-  const int64_t n = ctx->pinned_scalar[0];
+  int64_t n = ctx->pinned_scalar[0];
+  // An execution that decoded a column's resident LZ4 blocks on its way (decode_on_scan) has results only as good as that decode: a block K7 gave
+  // up on (a damaged copy, or err 9 — a sequence-start index that is not this stream's) leaves stale mask words, tile counts and column bytes
+  // behind.  The statuses are read here, where the host waits for the count anyway.  A bad block drops the index
+  // (table_decode_status); ONE more execution decodes by parsing and records a new one; bad again -> the blocks themselves are damaged.
+  if (q->decoded_col >= 0) {
+    const int col = q->decoded_col;
+    if (table_decode_status(q->t, col) > 0) {
+      query_execute(q, nstages < 0 ? -1 : nstages);
+      int64_t bad = q->decoded_col >= 0 ? table_decode_status(q->t, col) : 0;
+      if (bad > 0) { q->executed_stages = -1; fail(DFDB_ERR_FORMAT, "column %s: %lld of its resident LZ4 blocks do not decode", q->t->cols[(size_t)col].name.c_str(), (long long)bad); }
+      HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+      stream_wait(ctx);
+      n = ctx->pinned_scalar[0];
+    }
+  }
   if (nstages < 0) q->count = n;
   return n;
 }

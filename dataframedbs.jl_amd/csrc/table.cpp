@@ -315,8 +315,11 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     if (const int64_t dn = ctx_option(ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(&c - t->cols.data()), dn);
   // what an earlier load of this column kept is stale now, whatever this load keeps (a reload with keep_compressed = 0 left the old
   // descriptors behind and dfdb_table_decode_resident / decode_on_scan would have decoded them into the new array)
-  HIP_CHECK(hipStreamSynchronize(s));
-  c.comp_nblocks = 0; c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release(); c.comp_index_state = 0;
+  if (c.comp.p || c.comp_blocks.p || c.comp_status.p || c.comp_index.p) {      // (a stream slot, which never keeps anything, pays no drain here)
+    HIP_CHECK(hipStreamSynchronize(s));
+    c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release();
+  }
+  c.comp_nblocks = 0; c.comp_index_state = 0;
   if (!is_str && !is_null && nb && ctx_option(ctx, "keep_compressed", 0) != 0) {   // the compressed blocks stay: dfdb_table_decode_resident
     c.comp = std::move(staged); c.comp_blocks = std::move(dblocks); c.comp_status = std::move(dstatus); c.comp_nblocks = nb;
   }

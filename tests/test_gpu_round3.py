@@ -222,6 +222,46 @@ def test_a_failing_shard_takes_part_in_the_exchange(oracle, dfdb_mod, ctx):
         g.close()
 
 
+def test_an_enqueued_count_answers_for_its_own_exchange_only(oracle, dfdb_mod, ctx):
+    """the group's exchange slots are shared by every collective, so between dfdb_group_count(gq, NULL) and the call that reads the
+    count (a) a LATER collective that failed must not make the healthy count raise, and (b) a later healthy collective (a barrier, an allreduce,
+    another query's count) must not erase the fault key of a count whose shard failed — the stale slot-0 value would come back as a valid count.
+    The pair {count, fault key} is copied out of the slots behind its own exchange (dfdb_gquery::cres)."""
+    from dfdb import ir
+    G, g = _group(dfdb_mod, 3)
+    try:
+        n, bs = 6 * 4096, 4096
+        a = np.arange(1, n + 1, dtype=np.int64)
+        z = np.ones(n, np.int64); z[5 * 4096 + 17] = 0            # a zero divisor in the LAST shard only
+        gt = G.GroupTable.from_columns(g, {"a": a, "z": z}, block_size=bs)
+        healthy = G.GroupQuery(gt, dfdb_mod.selection(gt.view(), ir.col(0) % 3 == 0))
+        faulty = G.GroupQuery(gt, dfdb_mod.selection(gt.view(), ir.col(0) % ir.col(1) == 0))
+        other = G.GroupQuery(gt, dfdb_mod.selection(gt.view(), ir.col(0) > 100))
+        # (a) healthy count enqueued, then a collective that fails, then the read
+        healthy.count_async()
+        with pytest.raises(ZeroDivisionError):
+            faulty.count()
+        assert healthy.count() == n // 3
+        # (b) a faulty count enqueued (its local failure is reported at once), then healthy collectives, then the read: still the error
+        with pytest.raises(ZeroDivisionError):
+            faulty.count_async()
+        g.barrier()
+        assert g.allreduce([[1.0], [2.0], [3.0]])[0][0] == 6.0
+        assert other.count() == n - 100
+        with pytest.raises((ZeroDivisionError, RuntimeError)):
+            faulty.count()
+        # the raise invalidated that exchange on every rank alike: the next call enqueues again, and raises again
+        with pytest.raises(ZeroDivisionError):
+            faulty.count()
+        # Float64 MIN / MAX of caller scalars fold on the host with Julia's rules whatever the exchange
+        assert g.allreduce([[1.5], [-2.0], [3.0]], dfdb_mod.AGG_MIN)[2][0] == -2.0
+        for q in (healthy, faulty, other):
+            q.close()
+        gt.close()
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("order", [0, 1])
 def test_sharded_float_min_max_follow_julias_zero_and_nan_rules(dfdb_mod, ctx, order):
     """min(0.0, -0.0) is -0.0 and max is 0.0 in Julia whichever shard holds which zero; a NaN anywhere is the answer.  Both the

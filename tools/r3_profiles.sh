@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 # 1b. the same with nothing but the timed step in the process (no calibration, no config / decode legs): every k_scan_cmp launch is a warm-up or a timed step,
 #     so the trace's average and the line's roofline.avg_launch_ms are the same launches
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -o b -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-configs --no-decode-leg --no-placement > $O/bench_step_under_rocprof.json 2> $O/bench_step_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -o b -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-configs --no-decode-leg > $O/bench_step_under_rocprof.json 2> $O/bench_step_under_rocprof.err
 # 2. the default line (what the driver runs)
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 # 3. HBM traffic of K1 / K2 / K7: separate PMC passes (the TCC cannot hold FETCH_SIZE and WRITE_SIZE together)
