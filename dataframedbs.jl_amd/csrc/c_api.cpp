@@ -116,6 +116,7 @@ int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows
   return guard([&] { NEED(s); NEED(chunk); *chunk = nullptr; *chunk = stream_next(s, chunk_rows, first_row); });
 }
 int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats) { return guard([&] { NEED(s); NEED(stats); stream_stats(s, stats); }); }
+int32_t dfdb_stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* stats) { return guard([&] { NEED(s); NEED(stats); stream_read_stats(s, ordinal, stats); }); }
 int32_t dfdb_stream_close(dfdb_stream* s) { return guard([&] { stream_close(s); }); }
 
 int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx) { return guard([&] { NEED(ctx); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }

@@ -130,6 +130,12 @@ void table_load(dfdb_table* t, const int32_t* ordinals, int32_t ncols, int64_t b
 void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size_t nbytes, int64_t block_first, int64_t block_last,
                       dfdb_sizestats* stats);
 
+// one block of a chunk whose compressed body sits in the table's load staging buffer (stream.cpp -> table.cpp)
+struct StagedBlock { int32_t rows; int64_t origin, compressed, staged_off, row_pos; };
+void table_decode_staged_blocks(dfdb_table* t, int32_t ordinal, const StagedBlock* bl, int64_t n, int64_t total_rows, dfdb_sizestats* stats);
+// survivors of the query's current execution per block of `block_size` rows (query.cpp; synchronises)
+void query_block_counts(dfdb_query* q, int64_t block_size, std::vector<int64_t>& counts);
+
 void query_add_stage(dfdb_query* q, Stage&& s);   // composition rules of selection.jl:39-49
 void query_execute(dfdb_query* q, int nstages);   // evaluate stages [0, nstages) -> bitmap + counts + prefix
 int64_t query_count(dfdb_query* q, int nstages);
@@ -144,6 +150,7 @@ void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, 
 void query_return_mask(dfdb_query* q);            // give a borrowed calibrated bitmap back to its column
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread
+bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi);
 // stream.cpp: block-streamed execution over a non-resident table
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
@@ -152,6 +159,7 @@ void stream_drop_parked(dfdb_ctx* ctx);
 // K9: codes + dictionary for String column `ordinal` if it has at most max_entries distinct values; returns the number of entries (0: none built)
 int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries);   // dfdb_ctx_destroy: the parked stream dies with its context
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
+void stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* st);   // what the loaders have read so far of one column (-1: of every required column)
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp
 int64_t table_decode_status(dfdb_table* t, int32_t ordinal);   // table.cpp: blocks of the last resident decode whose status is not 0 (synchronises)

@@ -897,10 +897,10 @@ void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, con
 // One workgroup per block: values are copied to the column at the block's row offset; the bits are
 // re-packed at the block's global bit position (blocks need not start on a word boundary).
 __global__ __launch_bounds__(kBlock) void k_unpack_nullable(const uint8_t* __restrict__ bodies, const int64_t* __restrict__ body_off,
-                                                            const int64_t* __restrict__ row_off, int width, uint8_t* __restrict__ values,
-                                                            uint64_t* __restrict__ missing_bits) {
+                                                            const int64_t* __restrict__ row_off, const int64_t* __restrict__ rows_of, int width,
+                                                            uint8_t* __restrict__ values, uint64_t* __restrict__ missing_bits) {
   const int b = blockIdx.x;
-  const int64_t r0 = row_off[b], rows = row_off[b + 1] - r0;
+  const int64_t r0 = row_off[b], rows = rows_of[b];      // (the blocks need not be adjacent: a streamed chunk decodes only those with survivors)
   const uint8_t* body = bodies + body_off[b];
   const int64_t nchunks = (rows + 63) / 64;
   const uint64_t* chunks = (const uint64_t*)body;
@@ -925,19 +925,19 @@ __global__ __launch_bounds__(kBlock) void k_unpack_nullable(const uint8_t* __res
     }
   }
 }
-void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, int32_t nblocks, int width,
+void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* rows_of, int32_t nblocks, int width,
                             uint8_t* values, uint64_t* missing_bits) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(k_unpack_nullable, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, width, values, missing_bits);
+  hipLaunchKernelGGL(k_unpack_nullable, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, rows_of, width, values, missing_bits);
 }
 
 // ---------------------------------------------------------------- String bodies
 // body = Int32 datasize, rows x Int32 sizes, datasize bytes (blocks.jl:21-33,62-71)
 __global__ __launch_bounds__(kBlock) void k_unpack_strings(const uint8_t* __restrict__ bodies, const int64_t* __restrict__ body_off,
-                                                           const int64_t* __restrict__ row_off, const int64_t* __restrict__ byte_off,
+                                                           const int64_t* __restrict__ row_off, const int64_t* __restrict__ rows_of, const int64_t* __restrict__ byte_off,
                                                            int32_t* __restrict__ sizes, uint8_t* __restrict__ bytes) {
   const int b = blockIdx.x;
-  const int64_t r0 = row_off[b], rows = row_off[b + 1] - r0;
+  const int64_t r0 = row_off[b], rows = rows_of[b];
   const int64_t nb = byte_off[b + 1] - byte_off[b];
   const uint8_t* body = bodies + body_off[b];
   const int32_t* bs = (const int32_t*)(body + 4);
@@ -946,10 +946,10 @@ __global__ __launch_bounds__(kBlock) void k_unpack_strings(const uint8_t* __rest
   uint8_t* d = bytes + byte_off[b];
   for (int64_t k = threadIdx.x; k < nb; k += kBlock) d[k] = bd[k];
 }
-void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* byte_off,
+void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* rows_of, const int64_t* byte_off,
                            int32_t nblocks, int32_t* sizes, uint8_t* bytes) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(k_unpack_strings, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, byte_off, sizes, bytes);
+  hipLaunchKernelGGL(k_unpack_strings, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bodies, body_off, row_off, rows_of, byte_off, sizes, bytes);
 }
 
 }  // namespace dfdb

@@ -565,6 +565,43 @@ static int64_t selected_before(dfdb_query* q, int64_t row) {                 // 
   if (rem) c += __builtin_popcountll(w[words] & ((1ull << rem) - 1ull));
   return c;
 }
+// survivors of the current execution in every block of `block_size` rows.  Blocks that are a whole number of 1024-row tiles read one entry of the
+// prefix scan per block (a strided copy); other block sizes (the reference's tests use 50 and 100) count the bits of the mask on the host.
+void query_block_counts(dfdb_query* q, int64_t block_size, std::vector<int64_t>& counts) {
+  dfdb_table* t = q->t; hipStream_t s = t->ctx->stream;
+  const int64_t nrows = t->nrows < 0 ? 0 : t->nrows;
+  const int64_t nb = ceil_div(nrows, block_size);
+  counts.assign((size_t)nb, 0);
+  if (nb == 0) return;
+  if (!q->prefix_valid) scan_prefix(q);
+  const int64_t ntiles = ceil_div(nrows, kTileRows);
+  if (block_size % kTileRows == 0) {
+    const int64_t tpb = block_size / kTileRows;
+    std::vector<uint64_t> at((size_t)nb + 1, 0);
+    HIP_CHECK(hipMemcpy2DAsync(at.data(), 8, q->prefix.p, (size_t)tpb * 8, 8, (size_t)nb, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&at[(size_t)nb], q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t b = 0; b < nb; b++) counts[(size_t)b] = (int64_t)(at[(size_t)b + 1] - at[(size_t)b]);
+    return;
+  }
+  const size_t nw = (size_t)ceil_div(nrows, 64);
+  std::vector<uint64_t> bm(nw);
+  HIP_CHECK(hipMemcpyAsync(bm.data(), q->bitmap.p, nw * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  for (int64_t b = 0; b < nb; b++) {
+    const int64_t r0 = b * block_size, r1 = std::min(nrows, r0 + block_size);
+    int64_t c = 0;
+    for (int64_t r = r0; r < r1;) {
+      const int64_t wi = r >> 6, lo = r & 63, hi = std::min<int64_t>(64, r1 - (wi << 6));
+      uint64_t w = bm[(size_t)wi] >> lo;
+      if (hi - lo < 64) w &= (1ull << (hi - lo)) - 1ull;
+      c += __builtin_popcountll(w);
+      r = (wi << 6) + hi;
+    }
+    counts[(size_t)b] = c;
+  }
+}
+
 static bool error_is_reached(dfdb_query* q, uint64_t erow) {
   dfdb_table* t = q->t;
   const int64_t bs = t->block_size;

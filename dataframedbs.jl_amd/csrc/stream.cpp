@@ -10,6 +10,13 @@
 // used round-robin), so file I/O of one chunk overlaps PCIe + K7 of the other and the caller's scan/gather kernels.
 // HBM holds three chunks, never the table.
 //
+// Late materialization at BLOCK granularity (round 4; blocksiterator.jl:111-113 `if rows > 0 ... read_block!(projection-only columns)`, skip_block
+// BlockStreams.jl:74-78; quirk Q6): a loader first reads, copies and decodes only the columns the selection reads, evaluates the chunk's selection
+// on the slot's own stream — every stage up to the first range stage that numbers the survivors of earlier CHUNKS, whose base is not known yet:
+// the survivors of that prefix are a superset of the final ones — and then reads the projection-only columns ONLY for the blocks that kept a row:
+// their byte ranges are the only ones that leave the file, cross PCIe and go through K7.  A chunk without survivors never touches the projection
+// files.  dfdb_stream_read_stats reports what was really read per column.  ctx option "stream_late_materialize" = 0: every required column whole.
+//
 // The reference's per-stage running state carries over between chunks the same way it carries over between blocks:
 //   * a leading range stage numbers table rows            -> dfdb_table row_base = b0 * block_size
 //   * a range stage after a predicate numbers survivors    -> stage_base += survivors of the chunk (RangeToProcess.offset,
@@ -17,6 +24,7 @@
 //   * skip_if_can / is_finished (selection.jl:177-196)     -> chunks before the first requested row are never read, and the
 //     stream ends as soon as a range stage has passed its last element
 #include "engine.hpp"
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -65,6 +73,7 @@ struct Slot {
   bool has_chunk = false;          // tbl holds a decoded chunk the caller may be using
   int err_code = 0; std::string err_msg;
   uint8_t* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for the file bytes (DMA-able: the H2D copy is truly async)
+  bool pre_executed = false;       // the loader's evaluation of the selection IS the chunk's (no stage depends on earlier chunks, nothing raised): q keeps it
 };
 
 }  // namespace
@@ -89,6 +98,11 @@ struct dfdb_stream {
   int cur = -1;                    // slot handed to the caller (-1: none yet)
   bool done = false;
   int64_t compressed = 0, uncompressed = 0, rows = 0;
+  // late materialization: which required columns the loaders' evaluation of the selection reads (loaded whole, first), how many stages it covers
+  std::vector<char> sel_col;
+  int kprefix = 0;
+  bool late = true;
+  std::vector<dfdb_sizestats> read_stats;   // per required column: rows / compressed (+24 per block, quirk Q10) / uncompressed bytes the loaders have read (under mu)
   // the loader threads live as long as the stream (a fresh host thread pays the HIP runtime's per-thread set-up, ~45 ms,
   // on its first call): requests are slot numbers served first in first out, completion is signalled per slot
   std::thread loader[kLoaders];
@@ -104,51 +118,147 @@ namespace dfdb {
 
 namespace {
 
+void ensure_pin(Slot* sl, size_t need) {
+  if (need <= sl->pin_cap) return;
+  if (sl->pin) (void)hipHostFree(sl->pin);
+  sl->pin = nullptr; sl->pin_cap = 0;
+  HIP_CHECK(hipHostMalloc((void**)&sl->pin, need + need / 4, hipHostMallocDefault));
+  sl->pin_cap = need + need / 4;
+}
+void note_read(dfdb_stream* s, size_t k, const dfdb_sizestats& st) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->read_stats[k].rows += st.rows; s->read_stats[k].compressed += st.compressed; s->read_stats[k].uncompressed += st.uncompressed;
+}
+
+// every block of the chunk of required column k: file -> pinned -> HBM -> K7, the byte range read in 32-MB pieces (concurrent preads), each piece on
+// its way to HBM while the next is read — PCIe and the page-cache copy overlap inside the chunk, not only across the loaders (which fall into
+// lockstep: all reading, then all copying)
+void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
+  dfdb_table* tb = sl->tbl;
+  const dfdb_stream::ColSrc& c = s->colsrc[k];
+  const std::vector<BlockLoc>& ix = s->index[k];
+  const int64_t lo = ix[(size_t)sl->b0].off, hi = ix[(size_t)sl->b1 - 1].off + 20 + ix[(size_t)sl->b1 - 1].compressed;
+  const size_t need = c.data_off + (size_t)(hi - lo);
+  ensure_pin(sl, need);
+  const auto t0 = std::chrono::steady_clock::now();
+  // the column header (re-validated by the loader), then the blocks
+  if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+  const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
+  DevBuf& staged = tb->ld_staged;
+  staged.ensure(need - comp_lo + 64);
+  constexpr size_t kPiece = (size_t)32 << 20;
+  for (size_t a = c.data_off; a < need; a += kPiece) {
+    const size_t b = std::min(need, a + kPiece);
+    if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+    const size_t ca = std::max(a, comp_lo);
+    if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  dfdb_sizestats st{0, 0, 0};
+  tb->ld_prestaged = true;
+  try { table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st); } catch (...) { tb->ld_prestaged = false; throw; }
+  tb->ld_prestaged = false;
+  note_read(s, k, st);
+  if (getenv("DFDB_STREAM_DEBUG")) {
+    const auto t2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[stream] t=%.2f ms slot %d blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n",
+            dbg_ms() - std::chrono::duration<double, std::milli>(t2 - t0).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
+            std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)(hi - lo) / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
+}
+
+// only the blocks of the chunk with keep[b] != 0 (b relative to the chunk): every run of consecutive kept blocks is one byte range of the file
+void load_column_blocks(dfdb_stream* s, Slot* sl, size_t k, const std::vector<char>& keep, int64_t chunk_rows) {
+  dfdb_table* tb = sl->tbl;
+  const dfdb_stream::ColSrc& c = s->colsrc[k];
+  const std::vector<BlockLoc>& ix = s->index[k];
+  const int64_t nb = sl->b1 - sl->b0;
+  size_t need = 0;
+  for (int64_t b = 0; b < nb; b++) if (keep[(size_t)b]) need += 20 + (size_t)ix[(size_t)(sl->b0 + b)].compressed;
+  ensure_pin(sl, need + 64);
+  DevBuf& staged = tb->ld_staged;
+  staged.ensure(need + 64);
+  std::vector<StagedBlock> bl;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (need) {
+    const int fd = open(c.file.c_str(), O_RDONLY);
+    if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
+    struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
+    constexpr int64_t kPiece = 32ll << 20;
+    size_t poff = 0;
+    for (int64_t b = 0; b < nb;) {
+      if (!keep[(size_t)b]) { b++; continue; }
+      int64_t e = b;
+      while (e < nb && keep[(size_t)e]) e++;
+      const BlockLoc& first = ix[(size_t)(sl->b0 + b)]; const BlockLoc& last = ix[(size_t)(sl->b0 + e - 1)];
+      const int64_t lo = first.off, hi = last.off + 20 + last.compressed;
+      for (int64_t a = lo; a < hi; a += kPiece) {
+        const int64_t z = std::min(hi, a + kPiece);
+        if (!read_file_range_fd(fd, sl->pin + poff + (size_t)(a - lo), a, z)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+        HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + poff + (size_t)(a - lo), sl->pin + poff + (size_t)(a - lo), (size_t)(z - a), hipMemcpyHostToDevice, sl->ctx->stream));
+      }
+      for (int64_t j = b; j < e; j++) {
+        const BlockLoc& L = ix[(size_t)(sl->b0 + j)];
+        bl.push_back(StagedBlock{L.rows, L.origin, L.compressed, (int64_t)poff + (L.off - lo) + 20, j * s->block_size});
+      }
+      poff += (size_t)(hi - lo);
+      b = e;
+    }
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  dfdb_sizestats st{0, 0, 0};
+  table_decode_staged_blocks(tb, s->required[k], bl.data(), (int64_t)bl.size(), chunk_rows, &st);
+  st.rows = 0; for (const StagedBlock& x : bl) st.rows += x.rows;
+  note_read(s, k, st);
+  if (getenv("DFDB_STREAM_DEBUG")) {
+    const auto t2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[stream] t=%.2f ms slot %d blocks %lld-%lld col %s: %zu of %lld blocks kept, read %.2f ms (%.1f MB), load+decode %.2f ms\n",
+            dbg_ms() - std::chrono::duration<double, std::milli>(t2 - t0).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(), bl.size(), (long long)nb,
+            std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)need / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
+}
+
 // loader thread: column files -> HBM (decoded) for blocks [b0, b1), into the slot's persistent table (buffers are reused)
 void load_chunk(dfdb_stream* s, Slot* sl) {
   try {
     HIP_CHECK(hipSetDevice(sl->ctx->device));
     dfdb_table* tb = sl->tbl;
     tb->nrows = -1; tb->block_first = 0;
+    sl->pre_executed = false;
     for (Column& c : tb->cols) c.resident = false;
+    const int64_t nb = sl->b1 - sl->b0;
+    int64_t chunk_rows = 0;
+    for (int64_t b = sl->b0; b < sl->b1; b++) chunk_rows += s->index[0][(size_t)b].rows;
+    bool any_late = false;
     for (size_t k = 0; k < s->required.size(); k++) {
-      const dfdb_stream::ColSrc& c = s->colsrc[k];
-      const std::vector<BlockLoc>& ix = s->index[k];
-      const int64_t lo = ix[(size_t)sl->b0].off, hi = ix[(size_t)sl->b1 - 1].off + 20 + ix[(size_t)sl->b1 - 1].compressed;
-      const size_t need = c.data_off + (size_t)(hi - lo);
-      if (need > sl->pin_cap) {
-        if (sl->pin) (void)hipHostFree(sl->pin);
-        sl->pin = nullptr; sl->pin_cap = 0;
-        HIP_CHECK(hipHostMalloc((void**)&sl->pin, need + need / 4, hipHostMallocDefault));
-        sl->pin_cap = need + need / 4;
+      if (s->late && !s->sel_col[k]) { any_late = true; continue; }
+      load_column_whole(s, sl, k);
+    }
+    tb->block_first = 0;
+    tb->row_base = sl->b0 * s->block_size;                // (a leading range stage numbers table rows: known before the selection runs)
+    if (any_late) {
+      std::vector<char> keep((size_t)nb, 1);
+      dfdb_query* q = sl->q;
+      if (tb->nrows < 0) tb->nrows = chunk_rows;          // the selection reads no column at all (range stages only): the block headers say how many rows there are
+      if (s->kprefix > 0 && chunk_rows > 0) {
+        q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->bitmap_rows = -1;
+        for (Stage& st : q->stages) st.stage_base = 0;    // (no stage of the prefix numbers survivors of earlier chunks)
+        // nothing is raised here: whether a DivideError / InexactError of a predicate is reached is the caller's full execution's to say (query.cpp:
+        // error_is_reached); the erroring rows count as not selected meanwhile, and that execution raises or drops them for good
+        q->err_checking = true;
+        try { query_execute(q, s->kprefix); } catch (...) { q->err_checking = false; throw; }
+        q->err_checking = false;
+        std::vector<int64_t> counts;
+        query_block_counts(q, s->block_size, counts);
+        for (int64_t b = 0; b < nb && b < (int64_t)counts.size(); b++) keep[(size_t)b] = counts[(size_t)b] > 0;
+        sl->pre_executed = s->kprefix == (int)q->stages.size() && q->err_row[0] == ~0ull && q->err_row[1] == ~0ull;
+        if (!sl->pre_executed) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->err_row[0] = q->err_row[1] = ~0ull; }
       }
-      // the column header (re-validated by the loader), then the blocks: read in 32-MB pieces (concurrent preads), each piece on its way to
-      // HBM while the next is read — PCIe and the page-cache copy overlap inside the chunk, not only across the loaders (which fall into
-      // lockstep: all reading, then all copying)
-      const auto t0 = std::chrono::steady_clock::now();
-      if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-      const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
-      DevBuf& staged = tb->ld_staged;
-      staged.ensure(need - comp_lo + 64);
-      constexpr size_t kPiece = (size_t)32 << 20;
-      for (size_t a = c.data_off; a < need; a += kPiece) {
-        const size_t b = std::min(need, a + kPiece);
-        if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-        const size_t ca = std::max(a, comp_lo);
-        if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
-      }
-      const auto t1 = std::chrono::steady_clock::now();
-      dfdb_sizestats st{0, 0, 0};
-      tb->ld_prestaged = true;
-      try { table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st); } catch (...) { tb->ld_prestaged = false; throw; }
-      tb->ld_prestaged = false;
-      if (getenv("DFDB_STREAM_DEBUG")) {
-        const auto t2 = std::chrono::steady_clock::now();
-        static const auto epoch = std::chrono::steady_clock::now();
-        (void)epoch;
-        fprintf(stderr, "[stream] t=%.2f ms slot %d blocks %lld-%lld col %s: read %.2f ms (%.1f MB), load+decode %.2f ms\n",
-                dbg_ms() - std::chrono::duration<double, std::milli>(t2 - t0).count(), (int)(sl - s->slot), (long long)sl->b0, (long long)sl->b1, c.name.c_str(),
-                std::chrono::duration<double, std::milli>(t1 - t0).count(), (double)(hi - lo) / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
+      bool all = true;
+      for (char kp : keep) all = all && kp;
+      for (size_t k = 0; k < s->required.size(); k++) {
+        if (s->sel_col[k]) continue;
+        if (all) load_column_whole(s, sl, k); else load_column_blocks(s, sl, k, keep, chunk_rows);
       }
     }
     tb->block_first = 0;
@@ -223,10 +333,11 @@ static void stream_rearm(dfdb_stream* s) {
   s->stages.clear(); s->colsrc.clear(); s->required.clear(); s->index.clear(); s->base.clear();
   s->chunk_blocks = s->nblocks = s->next_block = 0; s->cur = -1; s->done = false;
   s->compressed = s->uncompressed = s->rows = 0;
+  s->sel_col.clear(); s->read_stats.clear(); s->kprefix = 0;
   s->requests.clear();
   for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
-    s->slot_done[i] = false; sl.loading = false; sl.has_chunk = false; sl.err_code = 0; sl.err_msg.clear(); sl.b0 = sl.b1 = 0;
+    s->slot_done[i] = false; sl.loading = false; sl.has_chunk = false; sl.pre_executed = false; sl.err_code = 0; sl.err_msg.clear(); sl.b0 = sl.b1 = 0;
     delete sl.q; sl.q = nullptr;
   }
 }
@@ -262,6 +373,16 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   if (req.empty() && !t->cols.empty()) req.push_back(0);
   std::sort(req.begin(), req.end()); req.erase(std::unique(req.begin(), req.end()), req.end());
   s->required = req;
+  // late materialization: the loaders evaluate stages [0, kprefix) — everything before the first range-like stage that follows another stage (its base is
+  // the survivors of earlier chunks) — and the columns those stages' predicates read are the ones loaded whole
+  s->late = ctx_option(t->ctx, "stream_late_materialize", 1) != 0;
+  s->kprefix = (int)q->stages.size();
+  for (size_t k = 1; k < q->stages.size(); k++) if (q->stages[k].kind != ST_PRED) { s->kprefix = (int)k; break; }
+  std::vector<int> selreq;
+  for (int k = 0; k < s->kprefix; k++) if (q->stages[(size_t)k].kind == ST_PRED) required_columns(*q->stages[(size_t)k].pred, selreq);
+  s->sel_col.assign(req.size(), 0);
+  for (size_t k = 0; k < req.size(); k++) s->sel_col[k] = std::find(selreq.begin(), selreq.end(), req[k]) != selreq.end();
+  s->read_stats.assign(req.size(), dfdb_sizestats{0, 0, 0});
   for (int o : req) {
     const Column& c = t->cols[(size_t)o];
     if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
@@ -356,7 +477,8 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
   if (!prefetch(s, &s->slot[(nxt + K - 1) % K])) { /* no chunk left to start */ }
   // 3. the slot's query, re-based for this chunk
   for (size_t k = 0; k < sl.q->stages.size(); k++) sl.q->stages[k].stage_base = s->base[k];
-  sl.q->executed_stages = -1; sl.q->count = -1; sl.q->prefix_valid = false; sl.q->bitmap_rows = -1;
+  // (a chunk whose selection the loader has already evaluated in full keeps that evaluation: nothing in it depends on the chunks before)
+  if (!sl.pre_executed) { sl.q->executed_stages = -1; sl.q->count = -1; sl.q->prefix_valid = false; sl.q->bitmap_rows = -1; }
   if (chunk_rows) *chunk_rows = sl.tbl->nrows < 0 ? 0 : sl.tbl->nrows;
   if (first_row) *first_row = sl.tbl->row_base;
   return sl.q;
@@ -409,5 +531,16 @@ void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st) {
 }
 
 void stream_stats(const dfdb_stream* s, dfdb_sizestats* st) { st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed; }
+
+// what the loaders have read so far of table column `ordinal` (-1: of every required column): the rows of the blocks read, their compressed bytes
+// (+ 24 per block: quirk Q10, like dfdb_stream_stats) and their decoded bytes.  A column the query does not need reads nothing.
+void stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* st) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  *st = dfdb_sizestats{0, 0, 0};
+  for (size_t k = 0; k < s->required.size() && k < s->read_stats.size(); k++) {
+    if (ordinal >= 0 && s->required[k] != ordinal) continue;
+    st->rows += s->read_stats[k].rows; st->compressed += s->read_stats[k].compressed; st->uncompressed += s->read_stats[k].uncompressed;
+  }
+}
 
 }  // namespace dfdb

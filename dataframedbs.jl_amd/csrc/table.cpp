@@ -228,17 +228,23 @@ static std::vector<BlockHdr> walk_blocks(const uint8_t* img, size_t n, size_t po
 }
 
 // K8 + block bodies on the device (k_decode.hip)
-void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, int32_t nblocks, int width,
+void launch_unpack_nullable(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* rows_of, int32_t nblocks, int width,
                             uint8_t* values, uint64_t* missing_bits);
-void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* byte_off,
+void launch_unpack_strings(hipStream_t s, const uint8_t* bodies, const int64_t* body_off, const int64_t* row_off, const int64_t* rows_of, const int64_t* byte_off,
                            int32_t nblocks, int32_t* sizes, uint8_t* bytes);
 
 // the blocks hs[0..nb) of column c — block ordinals block_first.. — whose compressed bodies already sit in t->ld_staged (the body of
 // hs[i] at staged + hs[i].body_off - comp_lo): K7 + K8 / string unpack into the column
-static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t nb, int64_t block_first, int64_t comp_lo, dfdb_sizestats* stats) {
+//
+// row_pos != nullptr (stream.cpp's late materialization): hs[] is a SUBSET of the blocks of a range that holds total_rows rows, block i starting at
+// row row_pos[i] of the column.  The rows of the blocks that were left out keep whatever the buffers held (no selected row points at them);
+// a String column gives them size 0, so that the tile byte offsets of the rows that ARE there come out of the same prefix scan.
+static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t nb, int64_t block_first, int64_t comp_lo, dfdb_sizestats* stats,
+                          const int64_t* row_pos = nullptr, int64_t total_rows = -1) {
   dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   int64_t nrows = 0;
   for (int64_t i = 0; i < nb; i++) nrows += hs[i].rows;
+  if (row_pos) nrows = total_rows;
   if (t->nrows >= 0 && t->nrows != nrows)
     fail(DFDB_ERR_ARGUMENT, "column %s would load %lld rows but the table holds %lld resident rows", c.name.c_str(), (long long)nrows, (long long)t->nrows);
   if (t->nrows >= 0 && t->block_first != block_first) fail(DFDB_ERR_ARGUMENT, "all columns of a table must load the same block range");
@@ -246,7 +252,7 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
   const bool is_str = dt_base(c.dtype) == DFDB_STRING, is_null = dt_nullable(c.dtype) && !is_str;
   DevBuf &staged = t->ld_staged, &bodies = t->ld_bodies, &dblocks = t->ld_blocks, &dstatus = t->ld_status, &d_aux = t->ld_aux;
   std::vector<Lz4Block> blocks((size_t)nb);
-  std::vector<int64_t> body_off((size_t)nb + 1), row_off((size_t)nb + 1), byte_off((size_t)nb + 1);
+  std::vector<int64_t> body_off((size_t)nb + 1), row_off((size_t)nb + 1), byte_off((size_t)nb + 1), rows_of((size_t)nb + 1, 0);
   int64_t bo = 0, ro = 0, so = 0;
   for (int64_t i = 0; i < nb; i++) {
     const BlockHdr& h = hs[i];
@@ -256,18 +262,18 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
       fail(DFDB_ERR_FORMAT, "block %lld of column %s has body of %lld bytes, expected %lld", (long long)(block_first + i), c.name.c_str(), (long long)h.origin, (long long)expect_min);
     blocks[i].src_off = (int64_t)h.body_off - comp_lo; blocks[i].src_len = (int32_t)h.compressed; blocks[i].dst_len = (int32_t)h.origin;
     blocks[i].dst_off = bo;
-    body_off[i] = bo; row_off[i] = ro; byte_off[i] = so;
+    if (row_pos) ro = row_pos[i];
+    body_off[i] = bo; row_off[i] = ro; byte_off[i] = so; rows_of[i] = h.rows;
     bo += round_up(h.origin, 16); ro += h.rows; if (is_str) so += h.origin - 4 - 4ll * h.rows;
   }
-  body_off[nb] = bo; row_off[nb] = ro; byte_off[nb] = so;
+  body_off[nb] = bo; row_off[nb] = row_pos ? nrows : ro; byte_off[nb] = so;
 
   c.nrows = nrows;
   uint8_t* decode_dst;
   if (!is_str && !is_null) {   // plain fixed width: decode straight into the column (no read!(io, v) copy: blocks.jl:43)
     c.data.ensure((size_t)nrows * w + 256);
     decode_dst = c.data.as<uint8_t>();
-    int64_t off = 0;
-    for (int64_t i = 0; i < nb; i++) { blocks[i].dst_off = off; off += (int64_t)w * hs[i].rows; }
+    for (int64_t i = 0; i < nb; i++) blocks[i].dst_off = (int64_t)w * row_off[i];
   } else {
     bodies.ensure((size_t)bo + 64);
     decode_dst = bodies.as<uint8_t>();
@@ -284,8 +290,9 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     for (int64_t i = 0; i < nb; i++) if (st[i] != 0) fail(DFDB_ERR_FORMAT, "decompression error in block %lld of column %s", (long long)(block_first + i), c.name.c_str());
   }
   if (is_str || is_null) {
-    d_aux.ensure(8 * 3 * ((size_t)nb + 1));
-    int64_t* d_body = d_aux.as<int64_t>(); int64_t* d_row = d_body + nb + 1; int64_t* d_byte = d_row + nb + 1;
+    d_aux.ensure(8 * 4 * ((size_t)nb + 1));
+    int64_t* d_body = d_aux.as<int64_t>(); int64_t* d_row = d_body + nb + 1; int64_t* d_byte = d_row + nb + 1; int64_t* d_rows = d_byte + nb + 1;
+    HIP_CHECK(hipMemcpyAsync(d_rows, rows_of.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d_body, body_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d_row, row_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d_byte, byte_off.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, s));
@@ -293,7 +300,8 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
       c.data.ensure((size_t)nrows * 4 + 256);
       c.nbytes = so; c.bytes.ensure((size_t)so + 64);
       HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + so, 0, 64, s));
-      if (nb) launch_unpack_strings(s, bodies.as<uint8_t>(), d_body, d_row, d_byte, (int32_t)nb, c.data.as<int32_t>(), c.bytes.as<uint8_t>());
+      if (row_pos && nrows) HIP_CHECK(hipMemsetAsync(c.data.p, 0, (size_t)nrows * 4, s));      // the blocks left out: empty strings
+      if (nb) launch_unpack_strings(s, bodies.as<uint8_t>(), d_body, d_row, d_rows, d_byte, (int32_t)nb, c.data.as<int32_t>(), c.bytes.as<uint8_t>());
       set_string_tile_offsets(ctx, c);
       // datasize must equal the sum of the positive sizes (unsafe_remake_offsets!: FlatStringsVectors.jl:69)
       uint64_t total = 0;
@@ -304,7 +312,7 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
       const size_t nw = padded_words(nrows);
       c.missing.ensure(nw * 8);
       HIP_CHECK(hipMemsetAsync(c.missing.p, 0, nw * 8, s));
-      if (nb) launch_unpack_nullable(s, bodies.as<uint8_t>(), d_body, d_row, (int32_t)nb, w, c.data.as<uint8_t>(), c.missing.as<uint64_t>());
+      if (nb) launch_unpack_nullable(s, bodies.as<uint8_t>(), d_body, d_row, d_rows, (int32_t)nb, w, c.data.as<uint8_t>(), c.missing.as<uint64_t>());
     }
     HIP_CHECK(hipStreamSynchronize(s));
   }
@@ -479,6 +487,23 @@ void table_load_image(dfdb_table* t, int32_t ordinal, const uint8_t* image, size
   if (dt_parse_ex(ty, &lg) != c.dtype || lg != c.logical) fail(DFDB_ERR_FORMAT, "column %s stored type is %s, but %s expected", c.name.c_str(), ty.c_str(), dt_type_string(c.dtype, c.logical).c_str());
   dfdb_sizestats st{0, 0, 0};
   load_from_image(t, c, image, nbytes, hr.pos, block_first, block_last, &st);
+  if (stats) *stats = st;
+}
+
+// stream.cpp, late materialization (blocksiterator.jl:111-113: a block without survivors never decompresses its projection-only columns): a SUBSET of
+// the blocks of a chunk, their compressed bodies already queued into t->ld_staged at staged_off, decoded to their own rows of the chunk's column
+void table_decode_staged_blocks(dfdb_table* t, int32_t ordinal, const StagedBlock* bl, int64_t n, int64_t total_rows, dfdb_sizestats* stats) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  std::vector<BlockHdr> hs((size_t)n);
+  std::vector<int64_t> pos((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; i++) {
+    hs[(size_t)i] = BlockHdr{bl[i].rows, bl[i].origin, bl[i].compressed, (size_t)bl[i].staged_off};
+    pos[(size_t)i] = bl[i].row_pos;
+    if (bl[i].row_pos < 0 || bl[i].row_pos + bl[i].rows > total_rows) fail(DFDB_ERR_FORMAT, "block %lld of column %s lies outside its chunk", (long long)i, c.name.c_str());
+  }
+  dfdb_sizestats st{0, 0, 0};
+  decode_staged(t, c, hs.data(), n, t->nrows >= 0 ? t->block_first : 0, 0, &st, pos.data(), total_rows);
   if (stats) *stats = st;
 }
 

@@ -805,6 +805,14 @@ class Stream:
         N.check(N.load().dfdb_stream_stats(self._h, C.byref(st)))
         return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
 
+    def read_stats(self, column: Optional[str] = None) -> dict:
+        """what the loaders have read so far of one column (None: of every required column): late materialization reads a projection-only
+        column only for the blocks whose selection kept a row (blocksiterator.jl:111-113)"""
+        st = N.SizeStats()
+        o = -1 if column is None else self.view.table.names().index(column)
+        N.check(N.load().dfdb_stream_read_stats(self._h, o, C.byref(st)))
+        return {"rows": st.rows, "compressed": st.compressed, "uncompressed": st.uncompressed}
+
     def __iter__(self):
         return self
 

@@ -125,6 +125,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     nontemporal is slower alone, but the scan that follows runs 4-7 % faster); 3 (default) / 4 = two ctiles per wave and nontemporal / plain
  *                     16-byte stores, one pair per wave; 5 / 6 = the same with 4 KB instead of 8 KB of LDS per wave.  "compact_grid_cap" bounds its workgroups
  *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
+ *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
+ *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
  *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
@@ -327,6 +329,13 @@ int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, dou
 int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row);
 int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats);   /* table_stats over the required columns (headers only) */
+/* Late materialization at block granularity (blocksiterator.jl:111-113: `if rows > 0` guards read_block! of the projection-only columns;
+ * skip_block, BlockStreams.jl:74-78): a loader reads, copies and decodes the columns the selection reads, evaluates the
+ * chunk's selection, and reads the projection-only columns ONLY for the blocks that kept a row — the other blocks' bytes never leave the file.
+ * This reports what the loaders have read so far of table column `ordinal` (-1: of every required column): rows of the blocks read, their
+ * compressed bytes (+ 24 per block like dfdb_stream_stats, quirk Q10) and their decoded bytes.  The loaders run ahead of the caller by up
+ * to three chunks; after the last dfdb_stream_next it is the whole scan's figure. */
+int32_t dfdb_stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* stats);
 int32_t dfdb_stream_close(dfdb_stream* s);
 
 /* ---- multi-GPU groups: ONE table block-range sharded over the GPUs of a node (§8b backend HIP_N) ----
