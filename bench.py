@@ -27,6 +27,9 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
                   `value` itself is the library-default configuration (no ctx option set)
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
+  cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
+                  (file bytes/s over PCIe against the pinned-copy rate measured in the run), and a clustered predicate showing late materialization
+                  (the projection column read only for the blocks with survivors: dfdb_stream_read_stats)
   cpu_baseline    N = 1: the oracle on the host cores
 Prints ONE JSON line on rank 0.
 """
@@ -238,6 +241,136 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
     t2.close()
     return res
 
+
+
+def cold_leg(dfdb, ctx, torch, dev, rows, peak, chunk_blocks=1024):
+    """The NON-resident path (every real DataFrameDBs table starts on disk): a three-column table written in the reference's block format to /dev/shm
+    (device LZ4 encoder), then — nothing resident — (1) open_table + load of one column, (2) block-streamed count, (3) block-streamed materialize with an
+    unclustered predicate (every block keeps rows: the projection column is read whole), (4) the same with a CLUSTERED predicate (i > 0.9 n over the
+    row-number column): late materialization (blocksiterator.jl:111-113) reads the projection column only for the blocks with survivors.  File bytes per
+    second are priced against the pinned host-to-device copy rate measured here.  Extra keys only: never part of `value`."""
+    import ctypes as C
+    import shutil
+    import tempfile
+    from dfdb import _native as N
+    need = rows * 16
+    base = next((d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d) and shutil.disk_usage(d).free > need + (4 << 30)), None)
+    if base is None:
+        return {"skipped": "no scratch directory with %d free bytes for the table files" % need}
+    lib = N.load()
+    res = {"rows": rows, "chunk_blocks": chunk_blocks, "files_in": base}
+    # the pinned-copy ceiling of this box: 1 GiB pinned -> device, best of 5
+    hp = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+    dp = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    best = None
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dp.copy_(hp, non_blocking=True); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    pcie = (1 << 30) / best / 1e9
+    res["pinned_copy_GBps"] = pcie
+    del hp, dp
+    d = tempfile.mkdtemp(prefix="dfdb_cold_", dir=base)
+    try:
+        path = os.path.join(d, "tb")
+        t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+        t.add_generated("i", dfdb.GEN_I64_IOTA, 0, rows)
+        t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows)
+        t.add_generated("b", dfdb.GEN_I64_MOD1M, seed_of(1), rows)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        st = t.save(path)
+        res["save"] = {"seconds": time.perf_counter() - t0, "file_GB": st["compressed"] / 1e9, "body_GB": st["uncompressed"] / 1e9,
+                       "encode_GBps_incl_file_write": st["uncompressed"] / (time.perf_counter() - t0) / 1e9}
+        want = t[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query().count()
+        t.close()
+        tb = dfdb.open_table(path, ctx=ctx, load=False)
+        cs = {}
+        for k, name in enumerate(("i", "x", "b")):
+            s_ = N.SizeStats()
+            N.check(lib.dfdb_table_column_stats(tb._h, k, C.byref(s_)))
+            cs[name] = {"compressed": s_.compressed, "uncompressed": s_.uncompressed}
+        res["columns"] = cs
+        # (1) open_table: file -> pinned -> HBM -> K7, one column
+        best = None
+        for _ in range(2):
+            t2 = dfdb.open_table(path, ctx=ctx, load=False)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            t2.load(["x"]); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            t2.close()
+        res["open_table"] = {"seconds": best, "rows_per_s": rows / best, "file_GBps": cs["x"]["compressed"] / best / 1e9, "decoded_GBps": rows * 8 / best / 1e9,
+                             "frac_of_pinned_copy": cs["x"]["compressed"] / best / 1e9 / pcie, "what": "dfdb_table_load of column x (file in page cache) until it is resident and decoded"}
+
+        def streamed(view, materialize_cols, reps=2):
+            """the whole stream consumed through the C ABI; per chunk count (+ materialize into device buffers)"""
+            q = view._query()
+            nrows_chunk = chunk_blocks * 65536
+            bufs = [torch.empty(nrows_chunk, dtype=torch.int64, device=dev) for _ in range(materialize_cols)]
+            outs = (N.OutCol * max(materialize_cols, 1))()
+            for k in range(materialize_cols):
+                outs[k].data, outs[k].memkind = bufs[k].data_ptr(), N.MEM_DEVICE
+            best, total, rd = None, 0, None
+            for _ in range(reps):
+                sh = C.c_void_p()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                N.check(lib.dfdb_stream_open(q._h, chunk_blocks, C.byref(sh)))
+                total = 0
+                try:
+                    while True:
+                        h, nr, fr = C.c_void_p(), C.c_int64(), C.c_int64()
+                        N.check(lib.dfdb_stream_next(sh, C.byref(h), C.byref(nr), C.byref(fr)))
+                        if not h:
+                            break
+                        if materialize_cols:
+                            N.check(lib.dfdb_query_hint_materialize(h, 1))
+                        c = C.c_int64()
+                        N.check(lib.dfdb_count(h, C.byref(c)))
+                        total += c.value
+                        if materialize_cols and c.value:
+                            N.check(lib.dfdb_materialize(h, outs, materialize_cols))
+                        rd = {}
+                        for k, name in enumerate(("i", "x", "b")):
+                            s_ = N.SizeStats()
+                            N.check(lib.dfdb_stream_read_stats(sh, k, C.byref(s_)))
+                            rd[name] = s_.compressed
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                finally:
+                    N.check(lib.dfdb_stream_close(sh))
+                best = dt if best is None else min(best, dt)
+            return best, total, rd
+
+        def rec(sec, total, rd, what):
+            file_b = sum(rd.values())
+            return {"seconds": sec, "rows_per_s": rows / sec, "selected": total, "file_bytes_read": rd, "file_GBps": file_b / sec / 1e9,
+                    "frac_of_pinned_copy": file_b / sec / 1e9 / pcie, "what": what}
+        v = tb[("x", lambda x: x > THRESHOLD), dfdb.ALL]
+        sec, total, rd = streamed(v[dfdb.ALL, ["x"]], 0)
+        res["stream_count"] = rec(sec, total, rd, "count(x > 899999), nothing resident: file -> pinned -> HBM -> K7 -> K1, chunks on four slots")
+        res["stream_count"]["count_ok"] = total == want
+        sec, total, rd = streamed(v[dfdb.ALL, ["x", "b"]], 2)
+        res["stream_materialize"] = rec(sec, total, rd, "materialize [x, b] of x > 899999 into device buffers chunk by chunk; every block keeps rows, so b is read whole")
+        thr = int(0.9 * rows)
+        vc = tb[("i", lambda i: i > thr), dfdb.ALL]
+        sec, total, rd = streamed(vc[dfdb.ALL, ["i", "b"]], 2)
+        r = rec(sec, total, rd, "materialize [i, b] of i > 0.9 n (clustered): b is read only for the blocks with survivors (late materialization)")
+        r["projection_bytes_read_frac"] = rd["b"] / cs["b"]["compressed"]
+        r["count_ok"] = total == rows - thr
+        res["stream_clustered"] = r
+        ctx.set_option("stream_late_materialize", 0)
+        try:
+            sec, total, rd = streamed(vc[dfdb.ALL, ["i", "b"]], 2, reps=1)
+        finally:
+            ctx.set_option("stream_late_materialize", 1)
+        r = rec(sec, total, rd, "the same with ctx option stream_late_materialize = 0: every required column of every chunk whole")
+        r["projection_bytes_read_frac"] = rd["b"] / cs["b"]["compressed"]
+        res["stream_clustered_eager"] = r
+        tb.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
 
 
 # ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 (extra keys, never part of `value`)
@@ -497,6 +630,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the non-resident (open_table / block-streamed) extra figures (N = 1 only)")
+    ap.add_argument("--cold-rows", type=int, default=500_000_000, help="rows of the three-column table the `cold` leg writes to /dev/shm and streams")
+    ap.add_argument("--cold-chunk-blocks", type=int, default=1024)
     ap.add_argument("--placement", action="store_true", help="also measure the step with the opt-in placement calibration (ctx option placement_calibrate = 1) and report it as the "
                     "extra key `calibrated_config`; `value` is always the library-default configuration")
     ap.add_argument("--no-placement", action="store_true", help="(accepted for older command lines: the calibration is off unless --placement asks for it)")
@@ -770,6 +906,12 @@ def main():
         watchdog.cancel()
         if res is not None:
             res["configs"] = legs
+    if res is not None and world == 1 and not lib and not args.no_cold:
+        try:
+            torch.cuda.empty_cache()
+            res["cold"] = cold_leg(dfdb, ctx, torch, dev, args.cold_rows, peak, args.cold_chunk_blocks)
+        except Exception as e:          # an extra figure: never fail the bench line for it
+            res["cold"] = {"error": f"{type(e).__name__}: {e}"}
     if res is not None:
         if not args.no_cpu and world == 1:      # the CPU baseline is an N=1, rank-0 figure
             res["cpu_baseline"] = cpu_baseline(args.cpu_rows, 3)

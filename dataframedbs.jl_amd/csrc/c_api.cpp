@@ -365,6 +365,51 @@ int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out) {
   return rc;
 }
 void ctx_destroy(dfdb_ctx* c) { (void)dfdb_ctx_destroy(c); }
+// "0-63,128-191" -> cpu_set_t
+static bool parse_cpulist(const std::string& txt, cpu_set_t* out) {
+  CPU_ZERO(out);
+  bool any = false;
+  size_t i = 0;
+  while (i < txt.size()) {
+    while (i < txt.size() && !isdigit((unsigned char)txt[i])) i++;
+    if (i >= txt.size()) break;
+    long a = 0; while (i < txt.size() && isdigit((unsigned char)txt[i])) a = a * 10 + (txt[i++] - '0');
+    long b = a;
+    if (i < txt.size() && txt[i] == '-') { i++; b = 0; while (i < txt.size() && isdigit((unsigned char)txt[i])) b = b * 10 + (txt[i++] - '0'); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, out); any = true; }
+  }
+  return any;
+}
+static std::string slurp_text(const std::string& path) {
+  std::string r;
+  if (FILE* f = fopen(path.c_str(), "r")) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) r.append(buf, n); fclose(f); }
+  return r;
+}
+static void lookup_node(dfdb_ctx* ctx) {
+  ctx->node_state = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::string id(bus);
+  for (char& ch : id) ch = (char)tolower((unsigned char)ch);
+  const std::string nn = slurp_text("/sys/bus/pci/devices/" + id + "/numa_node");
+  if (nn.empty()) return;
+  const int node = atoi(nn.c_str());
+  if (node < 0) return;
+  if (!parse_cpulist(slurp_text("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"), &ctx->node_cpus)) return;
+  ctx->node_state = 1;
+}
+NodeBind::NodeBind(dfdb_ctx* ctx) {
+  if (!ctx || ctx_option(ctx, "numa_bind", 1) == 0) return;
+  if (ctx->node_state == 0) lookup_node(ctx);
+  if (ctx->node_state != 1) return;
+  if (sched_getaffinity(0, sizeof old, &old) != 0) return;
+  cpu_set_t want;
+  CPU_AND(&want, &old, &ctx->node_cpus);
+  if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &old)) return;
+  if (sched_setaffinity(0, sizeof want, &want) == 0) active = true;
+}
+NodeBind::~NodeBind() { if (active) (void)sched_setaffinity(0, sizeof old, &old); }
+
 void ensure_pin_ring(dfdb_ctx* ctx, size_t bytes) {
   if (ctx->pin_ring_cap >= bytes) return;
   for (int i = 0; i < 2; i++) {

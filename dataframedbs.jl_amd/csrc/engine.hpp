@@ -2,8 +2,23 @@
 #pragma once
 #include "common.hpp"
 #include "expr.hpp"
+#include <memory>
+#include <mutex>
 
 namespace dfdb {
+
+// where the blocks of a column file lie (read_sizes without the bodies: BlockStreams.jl:68-78, header then skip(io, compressed)).  Walked lazily, a
+// chunk's worth of headers at a time, and kept with the table's column: a second stream over the same file finds it done.  30 000 headers are 30 000
+// preads (~20 ms), which a block-streamed scan of 2e9 rows used to pay before its first byte moved.
+struct BlockLoc { int64_t off; int32_t rows; int64_t origin, compressed; };
+struct BlockIndex {
+  std::string file; size_t data_off = 0;
+  int64_t file_size = -1, file_mtime_ns = 0;   // what the file looked like when the walk began (a rewritten file gets a fresh index)
+  std::mutex mu;
+  std::vector<BlockLoc> v;                     // guarded by mu: readers copy the slice they need
+  int64_t next_pos = -1;                       // where the next header lies (-1: not started)
+  bool complete = false;
+};
 
 // one column of a table, decoded and resident in HBM as ONE contiguous array over all resident blocks
 // (every block holds block_size rows except the last, so block b starts at row b*block_size)
@@ -38,6 +53,7 @@ struct Column {
   // on-disk source (tables opened from files)
   std::string file;
   size_t data_off = 0;  // first block inside the file
+  std::shared_ptr<BlockIndex> bix;   // block locations of `file`, as far as a stream or table_column_stats has walked them
 };
 
 enum StageKind { ST_RANGE = 0, ST_INTEGER = 1, ST_INDICES = 2, ST_PRED = 3 };
@@ -151,6 +167,7 @@ void query_return_mask(dfdb_query* q);            // give a borrowed calibrated 
 void set_string_tile_offsets(dfdb_ctx* ctx, Column& c);   // K4 over a resident string column
 bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t hi);   // table.cpp: parallel pread
 bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi);
+void set_io_threads(int64_t n);                  // table.cpp: concurrent preads per byte range (ctx option "io_threads")
 // stream.cpp: block-streamed execution over a non-resident table
 void stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row);
@@ -158,7 +175,7 @@ void stream_close(dfdb_stream* s);
 void stream_drop_parked(dfdb_ctx* ctx);
 // K9: codes + dictionary for String column `ordinal` if it has at most max_entries distinct values; returns the number of entries (0: none built)
 int64_t table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries);   // dfdb_ctx_destroy: the parked stream dies with its context
-void stream_stats(const dfdb_stream* s, dfdb_sizestats* st);
+void stream_stats(dfdb_stream* s, dfdb_sizestats* st);
 void stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* st);   // what the loaders have read so far of one column (-1: of every required column)
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp

@@ -29,9 +29,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <set>
 #include <thread>
 #include <unistd.h>
 #include <chrono>
@@ -43,25 +45,37 @@ void required_columns(const Node& n, std::vector<int>& out);
 
 namespace {
 
-struct BlockLoc { int64_t off; int32_t rows; int64_t origin, compressed; };
-
-// read_sizes over a column file without reading the bodies (BlockStreams.jl:68-78: read header, skip(io, compressed))
-std::vector<BlockLoc> index_blocks(const Column& c) {
-  std::vector<BlockLoc> v;
-  const int fd = open(c.file.c_str(), O_RDONLY);
-  if (fd < 0) fail(DFDB_ERR_IO, "column file '%s' for column %s don't exists", c.file.c_str(), c.name.c_str());
+// walk the headers of `bi`'s file until it holds at least `upto` blocks or the file ends (read_sizes / skip_block: BlockStreams.jl:68-78)
+void extend_index(BlockIndex& bi, int64_t upto) {
+  std::lock_guard<std::mutex> lk(bi.mu);
+  if (bi.complete || (int64_t)bi.v.size() >= upto) return;
+  const int fd = open(bi.file.c_str(), O_RDONLY);
+  if (fd < 0) fail(DFDB_ERR_IO, "column file '%s' don't exists", bi.file.c_str());
+  struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
   const off_t end = lseek(fd, 0, SEEK_END);
-  off_t pos = (off_t)c.data_off;
+  if (bi.next_pos < 0) bi.next_pos = (int64_t)bi.data_off;
+  off_t pos = (off_t)bi.next_pos;
   uint8_t h[20];
-  while (pos < end) {
-    if (pread(fd, h, 20, pos) != 20) { close(fd); fail(DFDB_ERR_FORMAT, "truncated block header in %s", c.file.c_str()); }
+  while (pos < end && (int64_t)bi.v.size() < upto) {
+    if (pread(fd, h, 20, pos) != 20) fail(DFDB_ERR_FORMAT, "truncated block header in %s", bi.file.c_str());
     BlockLoc b; b.off = pos; memcpy(&b.rows, h, 4); memcpy(&b.origin, h + 4, 8); memcpy(&b.compressed, h + 12, 8);
-    if (b.rows < 0 || b.origin < 0 || b.compressed < 0 || b.compressed > end - pos - 20) { close(fd); fail(DFDB_ERR_FORMAT, "corrupt block header in %s", c.file.c_str()); }
+    if (b.rows < 0 || b.origin < 0 || b.compressed < 0 || b.compressed > end - pos - 20) fail(DFDB_ERR_FORMAT, "corrupt block header in %s", bi.file.c_str());
     pos += 20 + b.compressed;
-    v.push_back(b);
+    bi.v.push_back(b);
   }
-  close(fd);
-  return v;
+  bi.next_pos = (int64_t)pos;
+  if (pos >= end) bi.complete = true;
+}
+// the index of a column file: the one its table column already holds if the file still looks the same, a fresh one otherwise
+std::shared_ptr<BlockIndex> index_of(Column& c) {
+  struct stat sb;
+  if (c.file.empty() || stat(c.file.c_str(), &sb) != 0) fail(DFDB_ERR_IO, "column file '%s' for column %s don't exists", c.file.c_str(), c.name.c_str());
+  const int64_t mt = (int64_t)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+  if (!c.bix || c.bix->file != c.file || c.bix->data_off != c.data_off || c.bix->file_size != (int64_t)sb.st_size || c.bix->file_mtime_ns != mt) {
+    c.bix = std::make_shared<BlockIndex>();
+    c.bix->file = c.file; c.bix->data_off = c.data_off; c.bix->file_size = (int64_t)sb.st_size; c.bix->file_mtime_ns = mt;
+  }
+  return c.bix;
 }
 
 struct Slot {
@@ -73,6 +87,7 @@ struct Slot {
   bool has_chunk = false;          // tbl holds a decoded chunk the caller may be using
   int err_code = 0; std::string err_msg;
   uint8_t* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for the file bytes (DMA-able: the H2D copy is truly async)
+  std::vector<std::vector<BlockLoc>> locs;   // per required column: the chunk's blocks [b0, b1) (copied out of the shared index when the load is requested)
   bool pre_executed = false;       // the loader's evaluation of the selection IS the chunk's (no stage depends on earlier chunks, nothing raised): q keeps it
 };
 
@@ -91,9 +106,12 @@ struct dfdb_stream {
   std::vector<ColSrc> colsrc;      // per required column
   int64_t chunk_blocks = 0, nblocks = 0, next_block = 0;
   std::vector<int> required;       // table ordinals the query touches
-  std::vector<std::vector<BlockLoc>> index;   // per required column
+  std::vector<std::shared_ptr<dfdb::BlockIndex>> index;   // per required column: walked lazily, a chunk ahead of the loaders (shared with the table's column)
+  int64_t checked_blocks = 0;      // blocks whose row counts have been checked across the columns
+  bool index_complete = false;     // every required column's file has been walked to its end: nblocks is final
   std::vector<int64_t> base;       // per stage: survivors of stages [0,k) in the chunks already consumed
-  static constexpr int kSlots = 4, kLoaders = 3;
+  static constexpr int kSlots = 8, kLoaders = 7;   // capacity; a stream uses nslots slots and nslots - 1 loaders (ctx option "stream_slots", default 8)
+  int nslots = 8;
   Slot slot[kSlots];
   int cur = -1;                    // slot handed to the caller (-1: none yet)
   bool done = false;
@@ -110,6 +128,11 @@ struct dfdb_stream {
   std::deque<int> requests;        // slots waiting for a loader
   bool quit = false;
   bool slot_done[kSlots] = {};
+  // At most `max_readers` loaders READ (page cache -> pinned, queueing the copies) at a time; the others are waiting for their copies and their decode.
+  // Without the limit the loaders run in lockstep — all reading (the host's memcpy bandwidth split five ways, PCIe waiting for pieces), then all
+  // waiting for PCIe and K7 at once while nobody reads — and the caller gets its chunks in bursts: 42 GB/s of file bytes on 8 slots, measured.
+  int max_readers = 3, readers = 0;
+  std::set<int64_t> waiting_readers;   // first blocks of the chunks whose loaders wait for a turn: the EARLIEST chunk reads first (the caller consumes in order)
   dfdb_ctx* parent = nullptr; std::weak_ptr<int> parent_alive;   // where a closed stream parks (if that context still exists)
 };
 
@@ -118,6 +141,24 @@ namespace dfdb {
 
 namespace {
 
+struct ReadTurn {                   // RAII: one of the stream's `max_readers` reading turns, granted in chunk order
+  dfdb_stream* s;
+  ReadTurn(dfdb_stream* st, int64_t first_block);
+  ~ReadTurn();
+};
+ReadTurn::ReadTurn(dfdb_stream* st, int64_t first_block) : s(st) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->waiting_readers.insert(first_block);
+  s->cv.wait(lk, [&] { return s->readers < s->max_readers && *s->waiting_readers.begin() == first_block; });
+  s->waiting_readers.erase(first_block);
+  s->readers++;
+  lk.unlock();
+  s->cv.notify_all();                 // (the next chunk in line may have a turn left to take)
+}
+ReadTurn::~ReadTurn() {
+  { std::lock_guard<std::mutex> lk(s->mu); s->readers--; }
+  s->cv.notify_all();
+}
 void ensure_pin(Slot* sl, size_t need) {
   if (need <= sl->pin_cap) return;
   if (sl->pin) (void)hipHostFree(sl->pin);
@@ -136,22 +177,26 @@ void note_read(dfdb_stream* s, size_t k, const dfdb_sizestats& st) {
 void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
   dfdb_table* tb = sl->tbl;
   const dfdb_stream::ColSrc& c = s->colsrc[k];
-  const std::vector<BlockLoc>& ix = s->index[k];
-  const int64_t lo = ix[(size_t)sl->b0].off, hi = ix[(size_t)sl->b1 - 1].off + 20 + ix[(size_t)sl->b1 - 1].compressed;
+  const std::vector<BlockLoc>& ix = sl->locs[k];              // the chunk's blocks, chunk-relative
+  const int64_t lo = ix.front().off, hi = ix.back().off + 20 + ix.back().compressed;
   const size_t need = c.data_off + (size_t)(hi - lo);
   ensure_pin(sl, need);
-  const auto t0 = std::chrono::steady_clock::now();
-  // the column header (re-validated by the loader), then the blocks
-  if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-  const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
-  DevBuf& staged = tb->ld_staged;
-  staged.ensure(need - comp_lo + 64);
-  constexpr size_t kPiece = (size_t)32 << 20;
-  for (size_t a = c.data_off; a < need; a += kPiece) {
-    const size_t b = std::min(need, a + kPiece);
-    if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-    const size_t ca = std::max(a, comp_lo);
-    if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
+  auto t0 = std::chrono::steady_clock::now();
+  {
+    ReadTurn turn(s, sl->b0);
+    t0 = std::chrono::steady_clock::now();
+    // the column header (re-validated by the loader), then the blocks
+    if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+    const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
+    DevBuf& staged = tb->ld_staged;
+    staged.ensure(need - comp_lo + 64);
+    constexpr size_t kPiece = (size_t)32 << 20;
+    for (size_t a = c.data_off; a < need; a += kPiece) {
+      const size_t b = std::min(need, a + kPiece);
+      if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      const size_t ca = std::max(a, comp_lo);
+      if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
+    }
   }
   const auto t1 = std::chrono::steady_clock::now();
   dfdb_sizestats st{0, 0, 0};
@@ -171,16 +216,17 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
 void load_column_blocks(dfdb_stream* s, Slot* sl, size_t k, const std::vector<char>& keep, int64_t chunk_rows) {
   dfdb_table* tb = sl->tbl;
   const dfdb_stream::ColSrc& c = s->colsrc[k];
-  const std::vector<BlockLoc>& ix = s->index[k];
+  const std::vector<BlockLoc>& ix = sl->locs[k];              // the chunk's blocks, chunk-relative
   const int64_t nb = sl->b1 - sl->b0;
   size_t need = 0;
-  for (int64_t b = 0; b < nb; b++) if (keep[(size_t)b]) need += 20 + (size_t)ix[(size_t)(sl->b0 + b)].compressed;
+  for (int64_t b = 0; b < nb; b++) if (keep[(size_t)b]) need += 20 + (size_t)ix[(size_t)b].compressed;
   ensure_pin(sl, need + 64);
   DevBuf& staged = tb->ld_staged;
   staged.ensure(need + 64);
   std::vector<StagedBlock> bl;
   const auto t0 = std::chrono::steady_clock::now();
   if (need) {
+    ReadTurn turn(s, sl->b0);
     const int fd = open(c.file.c_str(), O_RDONLY);
     if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
@@ -190,7 +236,7 @@ void load_column_blocks(dfdb_stream* s, Slot* sl, size_t k, const std::vector<ch
       if (!keep[(size_t)b]) { b++; continue; }
       int64_t e = b;
       while (e < nb && keep[(size_t)e]) e++;
-      const BlockLoc& first = ix[(size_t)(sl->b0 + b)]; const BlockLoc& last = ix[(size_t)(sl->b0 + e - 1)];
+      const BlockLoc& first = ix[(size_t)b]; const BlockLoc& last = ix[(size_t)(e - 1)];
       const int64_t lo = first.off, hi = last.off + 20 + last.compressed;
       for (int64_t a = lo; a < hi; a += kPiece) {
         const int64_t z = std::min(hi, a + kPiece);
@@ -198,7 +244,7 @@ void load_column_blocks(dfdb_stream* s, Slot* sl, size_t k, const std::vector<ch
         HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + poff + (size_t)(a - lo), sl->pin + poff + (size_t)(a - lo), (size_t)(z - a), hipMemcpyHostToDevice, sl->ctx->stream));
       }
       for (int64_t j = b; j < e; j++) {
-        const BlockLoc& L = ix[(size_t)(sl->b0 + j)];
+        const BlockLoc& L = ix[(size_t)j];
         bl.push_back(StagedBlock{L.rows, L.origin, L.compressed, (int64_t)poff + (L.off - lo) + 20, j * s->block_size});
       }
       poff += (size_t)(hi - lo);
@@ -228,7 +274,7 @@ void load_chunk(dfdb_stream* s, Slot* sl) {
     for (Column& c : tb->cols) c.resident = false;
     const int64_t nb = sl->b1 - sl->b0;
     int64_t chunk_rows = 0;
-    for (int64_t b = sl->b0; b < sl->b1; b++) chunk_rows += s->index[0][(size_t)b].rows;
+    for (const BlockLoc& L : sl->locs[0]) chunk_rows += L.rows;
     bool any_late = false;
     for (size_t k = 0; k < s->required.size(); k++) {
       if (s->late && !s->sel_col[k]) { any_late = true; continue; }
@@ -281,6 +327,7 @@ void release_slot(dfdb_stream* s, Slot& sl) {   // the caller is done with this 
   sl.has_chunk = false;
 }
 void loader_main(dfdb_stream* s) {
+  NodeBind bind(s->slot[0].ctx);          // for the thread's life: its preads (and the pread threads it starts), its slot's pinned buffer
   for (;;) {
     int idx;
     {
@@ -297,6 +344,40 @@ void loader_main(dfdb_stream* s) {
 
 bool range_like(const Stage& st) { return st.kind != ST_PRED; }
 
+// every required column's index walked to `upto` blocks (or its file's end), the new blocks checked against each other (all columns of a table share
+// their block boundaries: check_column_head, filesystem.jl:47-54).  Returns how many blocks are known for ALL columns.
+int64_t walk_index(dfdb_stream* s, int64_t upto) {
+  if (s->index.empty()) return 0;
+  if (s->index_complete) return s->nblocks;
+  const size_t nc = s->index.size();
+  std::vector<int64_t> have(nc);
+  std::vector<char> ended(nc);
+  std::vector<std::vector<int32_t>> rows(nc);              // row counts of the blocks not checked yet, copied out under each index's lock
+  for (size_t k = 0; k < nc; k++) {
+    extend_index(*s->index[k], upto);
+    std::lock_guard<std::mutex> lk(s->index[k]->mu);
+    const std::vector<BlockLoc>& v = s->index[k]->v;
+    have[k] = (int64_t)v.size(); ended[k] = s->index[k]->complete;
+    for (int64_t b = s->checked_blocks; b < have[k]; b++) rows[k].push_back(v[(size_t)b].rows);
+  }
+  const int64_t known = *std::min_element(have.begin(), have.end()), most = *std::max_element(have.begin(), have.end());
+  bool complete = true;
+  for (size_t k = 0; k < nc; k++) {
+    complete = complete && ended[k];
+    if (ended[k] && have[k] < most) fail(DFDB_ERR_FORMAT, "columns of %s have different block counts", s->path.c_str());
+  }
+  for (size_t k = 0; k < nc; k++)
+    for (int64_t b = s->checked_blocks; b < known; b++) {
+      const int32_t r = rows[k][(size_t)(b - s->checked_blocks)];
+      if (r != rows[0][(size_t)(b - s->checked_blocks)]) fail(DFDB_ERR_FORMAT, "columns of %s have different block boundaries", s->path.c_str());
+      const bool last_of_file = ended[k] && b + 1 == have[k];
+      if (!last_of_file && r != s->block_size) fail(DFDB_ERR_FORMAT, "block %lld holds %d rows, expected block_size %lld", (long long)b, r, (long long)s->block_size);
+    }
+  s->checked_blocks = known;
+  if (complete) { s->index_complete = true; s->nblocks = known; }
+  return known;
+}
+
 // start loading the next chunk that can still contribute rows into `sl`; false when the stream is exhausted
 bool prefetch(dfdb_stream* s, Slot* sl) {
   const int64_t B = s->block_size;
@@ -309,9 +390,16 @@ bool prefetch(dfdb_stream* s, Slot* sl) {
     if (first_block > s->next_block) s->next_block = (first_block / s->chunk_blocks) * s->chunk_blocks;   // keep chunk boundaries fixed
     if (st.last() <= s->next_block * B) return false;                                  // is_finished (:192-196)
   }
-  if (s->next_block >= s->nblocks) return false;
-  sl->b0 = s->next_block; sl->b1 = std::min(s->nblocks, s->next_block + s->chunk_blocks);
+  // the headers of the next chunk (and, after a skip, of everything before it: skip_block), walked now; the loaders get their own copy of the slice
+  const int64_t known = walk_index(s, s->next_block + s->chunk_blocks);
+  if (s->next_block >= known) return false;
+  sl->b0 = s->next_block; sl->b1 = std::min(known, s->next_block + s->chunk_blocks);
   s->next_block = sl->b1;
+  sl->locs.assign(s->index.size(), {});
+  for (size_t k = 0; k < s->index.size(); k++) {
+    std::lock_guard<std::mutex> lk(s->index[k]->mu);
+    sl->locs[k].assign(s->index[k]->v.begin() + sl->b0, s->index[k]->v.begin() + sl->b1);
+  }
   sl->err_code = 0; sl->err_msg.clear();
   sl->loading = true;
   {
@@ -333,11 +421,11 @@ static void stream_rearm(dfdb_stream* s) {
   s->stages.clear(); s->colsrc.clear(); s->required.clear(); s->index.clear(); s->base.clear();
   s->chunk_blocks = s->nblocks = s->next_block = 0; s->cur = -1; s->done = false;
   s->compressed = s->uncompressed = s->rows = 0;
-  s->sel_col.clear(); s->read_stats.clear(); s->kprefix = 0;
+  s->sel_col.clear(); s->read_stats.clear(); s->kprefix = 0; s->index_complete = false; s->checked_blocks = 0;
   s->requests.clear();
   for (int i = 0; i < dfdb_stream::kSlots; i++) {
     Slot& sl = s->slot[i];
-    s->slot_done[i] = false; sl.loading = false; sl.has_chunk = false; sl.pre_executed = false; sl.err_code = 0; sl.err_msg.clear(); sl.b0 = sl.b1 = 0;
+    s->slot_done[i] = false; sl.loading = false; sl.has_chunk = false; sl.pre_executed = false; sl.locs.clear(); sl.err_code = 0; sl.err_msg.clear(); sl.b0 = sl.b1 = 0;
     delete sl.q; sl.q = nullptr;
   }
 }
@@ -384,23 +472,18 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   for (size_t k = 0; k < req.size(); k++) s->sel_col[k] = std::find(selreq.begin(), selreq.end(), req[k]) != selreq.end();
   s->read_stats.assign(req.size(), dfdb_sizestats{0, 0, 0});
   for (int o : req) {
-    const Column& c = t->cols[(size_t)o];
+    Column& c = t->cols[(size_t)o];
     if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
-    s->index.push_back(index_blocks(c));
+    s->index.push_back(index_of(c));                     // (nothing is walked yet: prefetch walks a chunk's headers at a time)
     s->colsrc.push_back(dfdb_stream::ColSrc{c.name, c.file, c.data_off});
   }
-  s->nblocks = s->index.empty() ? 0 : (int64_t)s->index[0].size();
-  for (size_t k = 0; k < s->index.size(); k++) {
-    if ((int64_t)s->index[k].size() != s->nblocks) fail(DFDB_ERR_FORMAT, "columns of %s have different block counts", t->path.c_str());
-    for (int64_t b = 0; b < s->nblocks; b++) {
-      if (s->index[k][(size_t)b].rows != s->index[0][(size_t)b].rows) fail(DFDB_ERR_FORMAT, "columns of %s have different block boundaries", t->path.c_str());
-      if (b + 1 < s->nblocks && s->index[k][(size_t)b].rows != t->block_size) fail(DFDB_ERR_FORMAT, "block %lld holds %d rows, expected block_size %lld", (long long)b, s->index[k][(size_t)b].rows, (long long)t->block_size);
-      s->compressed += s->index[k][(size_t)b].compressed + 24; s->uncompressed += s->index[k][(size_t)b].origin;
-    }
-  }
-  for (int64_t b = 0; b < s->nblocks; b++) s->rows += s->index[0][(size_t)b].rows;
+  s->nblocks = 0; s->index_complete = false; s->checked_blocks = 0;
   s->base.assign(q->stages.size(), 0);
-  for (int i = 0; i < dfdb_stream::kSlots; i++) {
+  set_io_threads(ctx_option(t->ctx, "io_threads", 8));
+  s->max_readers = (int)std::min<int64_t>(dfdb_stream::kLoaders, std::max<int64_t>(1, ctx_option(t->ctx, "stream_readers", 3)));
+  s->readers = 0; s->waiting_readers.clear();
+  s->nslots = (int)std::min<int64_t>(dfdb_stream::kSlots, std::max<int64_t>(2, ctx_option(t->ctx, "stream_slots", 8)));
+  for (int i = 0; i < s->nslots; i++) {
     Slot& sl = s->slot[i];
     if (!sl.ctx) { if (ctx_create_like(t->ctx, &sl.ctx) != 0) fail(DFDB_ERR_DEVICE, "cannot create a stream context"); }
     else sl.ctx->options = t->ctx->options;                // a re-armed slot: same device (same parent context), today's options
@@ -438,10 +521,10 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     }
     sl.tbl = tb.release(); sl.q = cq.release();
   }
-  for (auto& th : s->loader) if (!th.joinable()) th = std::thread(loader_main, s);
+  for (int i = 0; i + 1 < s->nslots; i++) if (!s->loader[i].joinable()) s->loader[i] = std::thread(loader_main, s);
   if (nothing_to_read) { s->done = true; return; }
   if (!prefetch(s, &s->slot[0])) s->done = true;
-  else for (int i = 1; i + 1 < dfdb_stream::kSlots; i++) if (!prefetch(s, &s->slot[i])) break;
+  else for (int i = 1; i + 1 < s->nslots; i++) if (!prefetch(s, &s->slot[i])) break;
 }
 
 // the next chunk as a query (nullptr at the end).  The previous chunk's query dies here.
@@ -461,17 +544,19 @@ dfdb_query* stream_next(dfdb_stream* s, int64_t* chunk_rows, int64_t* first_row)
       }
     }
   }
-  constexpr int K = dfdb_stream::kSlots;
+  const int K = s->nslots;
   const int nxt = s->cur < 0 ? 0 : (s->cur + 1) % K;
   Slot& sl = s->slot[nxt];
   if (s->cur >= 0) release_slot(s, s->slot[s->cur]);
   if (s->done || !sl.loading) {          // nothing was prefetched: end of stream
-    for (Slot& o : s->slot) if (o.loading) release_slot(s, o);
+    for (int i = 0; i < s->nslots; i++) if (s->slot[i].loading) release_slot(s, s->slot[i]);
     s->done = true; s->cur = -1;
     return nullptr;
   }
   // 2. wait for the prefetched chunk, immediately start the one after it into the slot just retired
+  const double tw0 = getenv("DFDB_STREAM_DEBUG") ? dbg_ms() : 0;
   wait_loaded(s, sl);
+  if (tw0 != 0) fprintf(stderr, "[stream] t=%.2f ms next: slot %d blocks %lld-%lld handed out after waiting %.2f ms\n", dbg_ms(), nxt, (long long)sl.b0, (long long)sl.b1, dbg_ms() - tw0);
   if (sl.err_code) { const int c = sl.err_code; const std::string m = sl.err_msg; s->done = true; fail(c, "%s", m.c_str()); }
   s->cur = nxt;
   if (!prefetch(s, &s->slot[(nxt + K - 1) % K])) { /* no chunk left to start */ }
@@ -507,10 +592,10 @@ void stream_close(dfdb_stream* s) {
   bool park = false;
   if (!s->parent_alive.expired() && s->parent && !s->parent->parked_stream && ctx_option(s->parent, "stream_cache", 1) != 0) {
     park = true;
-    for (Slot& sl : s->slot) if (!sl.ctx || !sl.tbl) park = false;      // (an open that failed half-way)
+    for (int i = 0; i < s->nslots; i++) if (!s->slot[i].ctx || !s->slot[i].tbl) park = false;      // (an open that failed half-way)
   }
   if (park) {
-    for (Slot& sl : s->slot) release_slot(s, sl);         // loads in flight finish, the slots' streams drain
+    for (int i = 0; i < s->nslots; i++) release_slot(s, s->slot[i]);         // loads in flight finish, the slots' streams drain
     s->parent->parked_stream = s;
   } else stream_destroy(s);
   if (dbg) fprintf(stderr, "[stream] close ends at %.2f ms (%s)\n", dbg_ms(), park ? "parked" : "destroyed");
@@ -524,13 +609,26 @@ void stream_drop_parked(dfdb_ctx* ctx) {
 // table_stats (src/tables/misc.jl:6-43): skip_block over one column file — block headers only, nothing is decoded
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st) {
   if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
-  const Column& c = t->cols[(size_t)ordinal];
+  Column& c = t->cols[(size_t)ordinal];
   if (c.file.empty()) fail(DFDB_ERR_IO, "column %s has no backing file", c.name.c_str());
   st->rows = st->compressed = st->uncompressed = 0;
-  for (const BlockLoc& b : index_blocks(c)) { st->rows += b.rows; st->compressed += b.compressed + 24; st->uncompressed += b.origin; }   // +24: quirk Q10
+  std::shared_ptr<BlockIndex> bi = index_of(c);
+  extend_index(*bi, INT64_MAX);
+  std::lock_guard<std::mutex> lk(bi->mu);
+  for (const BlockLoc& b : bi->v) { st->rows += b.rows; st->compressed += b.compressed + 24; st->uncompressed += b.origin; }   // +24: quirk Q10
 }
 
-void stream_stats(const dfdb_stream* s, dfdb_sizestats* st) { st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed; }
+// table_stats over the required columns: asks for every header of their files (the scan itself only walks a chunk ahead of its loaders)
+void stream_stats(dfdb_stream* s, dfdb_sizestats* st) {
+  walk_index(s, INT64_MAX);
+  if (s->rows == 0 && s->compressed == 0) {
+    for (size_t k = 0; k < s->index.size(); k++) {
+      std::lock_guard<std::mutex> lk(s->index[k]->mu);
+      for (const BlockLoc& b : s->index[k]->v) { s->compressed += b.compressed + 24; s->uncompressed += b.origin; if (k == 0) s->rows += b.rows; }
+    }
+  }
+  st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed;
+}
 
 // what the loaders have read so far of table column `ordinal` (-1: of every required column): the rows of the blocks read, their compressed bytes
 // (+ 24 per block: quirk Q10, like dfdb_stream_stats) and their decoded bytes.  A column the query does not need reads nothing.

@@ -6,6 +6,7 @@
 // src/io/blocks.jl:37-71, which here becomes: stage the compressed file bytes in HBM once, LZ4-decode all
 // blocks of a column in ONE launch (K7, a wave per block), and leave the decoded column contiguous in HBM.
 #include "engine.hpp"
+#include <atomic>
 #include <algorithm>
 #include <cstdio>
 #include <fcntl.h>
@@ -46,9 +47,12 @@ bool read_file_range(const std::string& file, uint8_t* dst, int64_t lo, int64_t 
   close(fd);
   return ok;
 }
+// how many concurrent preads one range is split into (ctx option "io_threads", read when a table is loaded / a stream is opened; process-wide)
+static std::atomic<int> g_io_threads{8};
+void set_io_threads(int64_t n) { g_io_threads.store((int)std::min<int64_t>(64, std::max<int64_t>(1, n)), std::memory_order_relaxed); }
 bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi) {
   const int64_t n = hi - lo;
-  const int parts = (int)std::min<int64_t>(8, std::max<int64_t>(1, n / (4 << 20)));
+  const int parts = (int)std::min<int64_t>(g_io_threads.load(std::memory_order_relaxed), std::max<int64_t>(1, n / (2 << 20)));
   std::vector<std::thread> th;
   std::vector<char> ok((size_t)parts, 1);
   for (int k = 0; k < parts; k++) {
@@ -364,6 +368,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
 // blocks are decoded by ONE K7 launch once the last piece has been queued.
 static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {
   dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  NodeBind bind(ctx);                                                          // the preads and the bounce buffers on the GPU's NUMA node
   const int fd = open(c.file.c_str(), O_RDONLY);
   if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
   struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};

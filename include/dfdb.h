@@ -127,6 +127,14 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
  *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
  *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
+ *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one
+ *                     loader thread each (2e9 rows, 1024-block chunks, file bytes per second: 4 slots 36.6, 6 slots 40.9, 8 slots with three reading
+ *                     turns granted in chunk order and the loaders on the GPU's NUMA node 43-46 GB/s)
+ *   "io_threads"      concurrent preads a byte range of a column file is split into, 1 .. 64 (default 8; process-wide, read when a stream is opened)
+ *   "stream_readers"  loaders of a stream that may READ (page cache -> pinned memory, queueing the copies) at the same time, the others wait for their
+ *                     copies and their decode (default 3)
+ *   "numa_bind"       1 = the host threads that move file bytes (loads, streams, saves) run on the CPUs of the NUMA node the GPU hangs off, and the
+ *                     pinned bounce buffers are allocated from there (default 1; the calling thread's own affinity is restored on return)
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
  *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
  *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
