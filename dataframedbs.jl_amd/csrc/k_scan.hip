@@ -166,15 +166,124 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// single column x OP c for 1-, 2- and 4-byte types (round 4)
+// ------------------------------------------------------------------------------------------------
+// k_scan_cmp's lane loads ONE element per instruction whatever its width: an Int32 column moves in 256-byte wave requests and a Bool / Int8 column in
+// 64-byte ones, and the sixteen loads + sixteen ballots per 1024 rows that make an Int64 scan bandwidth-bound cap an Int32 scan at 0.4 and an Int8
+// scan at 0.1 of the HBM peak.  Here a lane loads 16 BYTES = E = 16 / sizeof(T) consecutive rows (every wave request is 1024 bytes: 256 / 512 / 1024
+// rows), compares them in registers into an E-bit piece of the mask, and the 64 / E lanes that share a 64-row word OR their pieces together with
+// log2(64 / E) xor-shuffles.  A load therefore yields E finished words, held by the lane groups in row order; one ds_bpermute moves word j of the tile
+// to lane l0 + j, where k_scan_cmp's ballots put it, and everything after that (four tiles per trip, one 512-byte bitmap store, tile counts, the
+// late-materialization tile skip) is k_scan_cmp's.
+template <typename T, int OP, bool AND_EXISTING>
+__global__ __launch_bounds__(kBlock) void k_scan_cmp_narrow(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
+                                                            int64_t nrows, int64_t ntiles, int wt_store) {
+  static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4, "narrow types only");
+  constexpr int E = 16 / (int)sizeof(T);        // rows per lane per load = words per load
+  constexpr int G = 64 / E;                     // lanes per word
+  constexpr int LOADS = kWordsPerTile / E;      // loads per tile: 4 / 2 / 1
+  constexpr int64_t kSpan = 64 * E;             // rows per wave load
+  // EIGHT 16-byte loads per lane are issued before the first is looked at (8 KB per wave in flight, what k_scan_cmp's sixteen 8-byte loads keep in
+  // flight): 2 tiles of a 4-byte column, 4 tiles (one group) of a 2-byte column, 8 tiles (two groups = two bitmap lines) of a 1-byte column
+  constexpr int GPT = sizeof(T) == 1 ? 2 : 1;   // four-tile groups per trip
+  constexpr int BATCH = 8;                      // loads per batch
+  constexpr int NB = GPT * 4 * LOADS / BATCH;   // batches per trip: 2 / 1 / 1
+  constexpr int TPB = BATCH / LOADS;            // tiles per batch: 2 / 4 / 8
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ngroups = (ntiles + 3) / 4;
+  const int64_t ntrips = (ngroups + GPT - 1) / GPT;
+  const int j16 = lane & 15;                    // the word of its tile this lane will hold
+  const int src_lane = G * (j16 % E);           // where that word sits after the group reduction of load j16 / E
+  const int my_load = j16 / E;
+  for (int64_t trip = wave; trip < ntrips; trip += nwaves) {
+    const int64_t g0 = trip * GPT;
+    uint64_t myword[GPT], existing[GPT], live[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+      myword[u] = 0; existing[u] = ~0ull; live[u] = ~0ull;
+      if (AND_EXISTING) {
+        existing[u] = g0 + u < ngroups ? bitmap[(g0 + u) * 64 + lane] : 0ull;
+        live[u] = __ballot(existing[u] != 0);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      // tiles [tb, tb + TPB) of the trip, all of one batch; tile x of the trip belongs to group x / 4, slot x % 4
+      const int tb = b * TPB;
+      u32x4 raw[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int x = tb + i / LOADS;                                          // tile of the trip
+        const int64_t tile = g0 * 4 + x;
+        const int64_t r0 = tile * kTile + (i % LOADS) * kSpan + (int64_t)E * lane;
+        const bool dead = AND_EXISTING && ((live[x / 4] >> (16 * (x % 4))) & 0xffffull) == 0;   // (wave-uniform: no earlier stage left a survivor in this tile)
+        const u32x4* p = (const u32x4*)(col + r0);
+        if (dead || r0 >= nrows) raw[i] = u32x4{0u, 0u, 0u, 0u};              // (a partly valid vector ends < 16 bytes past the column: inside its 256-byte pad)
+        else raw[i] = __builtin_nontemporal_load(p);
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        const int x = tb + i / LOADS;
+        const int64_t tile = g0 * 4 + x;
+        const int64_t r0 = tile * kTile + (i % LOADS) * kSpan + (int64_t)E * lane;
+        T v[E];
+        __builtin_memcpy(v, &raw[i], 16);
+        uint32_t piece = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) piece |= (cmp_op<OP, T>(v[e], c) ? 1u : 0u) << e;
+        const int64_t left = nrows - r0;                                       // rows of this lane's vector that exist
+        piece = left >= E ? piece : (left <= 0 ? 0u : piece & ((1u << left) - 1u));
+        uint64_t w = (uint64_t)piece << (E * (lane % G));
+#pragma unroll
+        for (int d = G / 2; d >= 1; d >>= 1) w |= __shfl_xor(w, d, 64);       // every lane of a G-lane group now holds the group's 64-row word
+        const uint64_t t = __shfl(w, src_lane, 64);
+        if (my_load == i % LOADS && (lane >> 4) == x % 4) myword[x / 4] = t;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+      const int64_t g = g0 + u;
+      if (g >= ngroups) break;
+      const int64_t t0 = g * 4;
+      uint64_t mw = myword[u];
+      if (AND_EXISTING) mw &= existing[u];
+      uint32_t cnt = (uint32_t)__popcll(mw);
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+      if (wt_store) __hip_atomic_store(&bitmap[g * 64 + lane], mw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else bitmap[g * 64 + lane] = mw;
+      if ((lane & 15) == 0 && t0 + (lane >> 4) < ntiles) tile_counts[t0 + (lane >> 4)] = cnt;
+    }
+  }
+}
+
 template <typename T, int OP>
 static void launch_cmp_t(hipStream_t s, const void* col, uint64_t cbits, uint64_t* bitmap, uint32_t* tc, int64_t nrows, bool and_existing, bool nt, void* cap, int wt_store) {
   const T c = from_bits<T>(cbits);
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   const int grid = grid_for_tiles((ntiles + 3) / 4);
+  const int narrow = (wt_store >> 1) & 3;        // ctx option "scan_narrow" rides in bits 1-2
+  wt_store &= 1;
   if constexpr (sizeof(T) == 8) {
     if (cap && !and_existing) { hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, true>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)cap, wt_store); return; }
   }
+  if constexpr (sizeof(T) < 8) {
+    // sixteen bytes per lane.  Measured at 1e9 rows (tools/diag_types.py, profiles/r4_types.txt): 1-byte columns 0.72-0.73 of the HBM peak against 0.51-0.52
+    // one element per lane; 2- and 4-byte columns 0.71-0.80 against 0.69-0.81 — no consistent difference, so by default only 1-byte columns take it
+    // (bits 1-2 of wt_store = ctx option "scan_narrow": 1 = 1-byte columns (default), 2 = every narrow column, 0 = never)
+    if ((narrow == 2 || (narrow == 1 && sizeof(T) == 1)) && ((uintptr_t)col & 15u) == 0) {
+      const int ngrid = grid_for_tiles(sizeof(T) == 1 ? (ntiles + 7) / 8 : (ntiles + 3) / 4);
+      if (and_existing) hipLaunchKernelGGL((k_scan_cmp_narrow<T, OP, true>), dim3(ngrid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, wt_store & 1);
+      else hipLaunchKernelGGL((k_scan_cmp_narrow<T, OP, false>), dim3(ngrid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, wt_store & 1);
+      return;
+    }
+  }
+  (void)narrow;
   if (and_existing) hipLaunchKernelGGL((k_scan_cmp<T, OP, true, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);
   else if (nt) hipLaunchKernelGGL((k_scan_cmp<T, OP, false, true, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);
   else hipLaunchKernelGGL((k_scan_cmp<T, OP, false, false, false>), dim3(grid), dim3(kBlock), 0, s, (const T*)col, c, bitmap, tc, nrows, ntiles, (T*)nullptr, wt_store);

@@ -37,7 +37,8 @@ struct ScanTerms {
 // single column `x OP c`; and_existing: bitmap &= result (a predicate stage after a range stage)
 void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint64_t cbits, uint64_t* bitmap,
                      uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr,
-                     int wt_store = 1 /* 1: the bitmap leaves with write-through stores (ctx option "scan_wt_store") */);
+                     int wt_store = 3 /* bit 0: the bitmap leaves with write-through stores (ctx option "scan_wt_store"); bits 1-2: ctx option "scan_narrow" — which
+                                         narrow columns take k_scan_cmp_narrow (16 bytes per lane): 1 = 1-byte (default), 2 = 1-, 2- and 4-byte, 0 = none */);
 // extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
 // extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,

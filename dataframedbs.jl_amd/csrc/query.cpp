@@ -460,7 +460,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // the launch that writes a fresh mask over the whole column: run it against the bitmap allocation this column pairs best with
     const ScanTerms tb0 = term_batches[0];
     const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
-    const int wt0 = (int)ctx_option(ctx, "scan_wt_store", 1);
+    const int wt0 = (ctx_option(ctx, "scan_wt_store", 1) ? 1 : 0) | (int)((ctx_option(ctx, "scan_narrow", 1) & 3) << 1);
     const void* const col_before = t->cols[(size_t)term_ords[0]].data.p;
     place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows, const void* colp) {
       ScanTerms tbx = tb0;                                          // the calibration may be trying another allocation of the first term's column
@@ -510,7 +510,8 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       LaunchTimer lt(ctx, "scan_cmp");
       prof_note(ctx, ctx_option(ctx, "scan_wt_store", 1) ? "scan_cmp.wt_store" : "scan_cmp.plain_store");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr, (int)ctx_option(ctx, "scan_wt_store", 1));
+                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr,
+                      (ctx_option(ctx, "scan_wt_store", 1) ? 1 : 0) | (int)((ctx_option(ctx, "scan_narrow", 1) & 3) << 1));
     } else {
       LaunchTimer lt(ctx, "scan_terms");
       const int pair = (int)ctx_option(ctx, "scan_pair", 1);
