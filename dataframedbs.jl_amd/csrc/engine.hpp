@@ -103,6 +103,8 @@ struct dfdb_query {
   // projection becomes a contiguous copy instead of a gather
   bool hint_materialize = false;
   int cap_col = -1;            // table ordinal captured by the last execution (-1: none)
+  int cap_col2 = -1;           // a second captured column (k_scan_terms EXTRA = 5: the term before the last), in cap_buf2
+  dfdb::DevBuf cap_buf2;
   int decoded_col = -1;        // table ordinal whose resident LZ4 blocks the last execution decoded on its way (decode_on_scan; -1: none)
   dfdb::DevBuf cap_buf;
   // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena

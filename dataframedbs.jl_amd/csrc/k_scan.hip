@@ -496,6 +496,32 @@ __device__ __forceinline__ uint64_t term_word_last(const void* colv, uint64_t cb
   return myword;
 }
 
+// A term whose column is captured although it is NOT the last one evaluated (EXTRA = 5: two projected predicate columns): its mask word like
+// term_word, and the tile's sixteen values per lane parked in LDS (stash[j * 64 + lane]) until the term after it has produced the final mask.
+// LDS as explicit spill space: held in registers across the last term the 32 VGPRs cost the two-term scan +0.75 ms per 1e9 rows (round 1).
+template <typename T>
+__device__ __forceinline__ uint64_t term_word_stash(const void* colv, uint64_t cbits, uint32_t sel, int64_t base, int64_t nrows, int lane, int l0,
+                                                    uint32_t sel2, uint64_t cbits2, uint64_t* stash) {
+  const T* p = (const T*)colv + base + lane;
+  const T c = from_bits<T>(cbits), c2 = from_bits<T>(cbits2);
+  uint64_t myword = 0;
+  const bool full = base + kTile <= nrows;
+  T v[kWordsPerTile];
+#pragma unroll
+  for (int j = 0; j < kWordsPerTile; j++) {
+    if (full) v[j] = __builtin_nontemporal_load(p + j * 64);
+    else v[j] = base + j * 64 + lane < nrows ? p[j * 64] : T(0);
+  }
+#pragma unroll
+  for (int j = 0; j < kWordsPerTile; j++) {
+    const bool inb = full || base + j * 64 + lane < nrows;
+    const uint64_t m = __ballot(inb && cmp_sel<T>(v[j], c, sel) && (sel2 == 0 || cmp_sel<T>(v[j], c2, sel2)));
+    if (lane == l0 + j) myword = m;
+    stash[j * 64 + lane] = bits_of(v[j]);
+  }
+  return myword;
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum_t(T v);
 template <> __device__ __forceinline__ double wave_sum_t<double>(double v) {
 #pragma unroll
@@ -507,16 +533,24 @@ template <> __device__ __forceinline__ uint64_t wave_sum_t<uint64_t>(uint64_t v)
 // EXTRA: 0 plain; 1 capture the values of the LAST term's 8-byte column at the finally selected rows -> extra_out[tile*1024 + rank];
 // 2 / 3 / 4 sum / min / max of them -> one partial per tile in extra_out (Float64 column: doubles; Int64 / UInt64 column: wrapping
 // 64-bit sums, as Julia's; an empty tile holds the identity)
+// 5 capture TWO columns: the last term's like EXTRA = 1 -> extra_out, and the term's before it -> extra_out2 (its tile parked in LDS while the last
+// term is evaluated: term_word_stash).  materialize(t[(a > c1) & (x < c2) & ..., [:a, :x]]) then gathers neither column (never
+// gather a column the scan already held; projection.jl:128-154 reads them per block for the same reason).
 template <bool AND_EXISTING, int EXTRA>
 __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts,
-                                                       int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out) {
-  uint64_t* stage = nullptr;      // EXTRA 1: the tile's slot in extra_out (see k_scan_cmp CAP)
-  __shared__ uint64_t cap_lds[EXTRA == 1 ? kWavesPerBlock * kCapBuf : 1];
-  uint64_t* const cap_mine = cap_lds + (EXTRA == 1 ? (threadIdx.x >> 6) * kCapBuf : 0);
+                                                       int64_t nrows, int64_t ntiles, uint64_t* __restrict__ extra_out, uint64_t* __restrict__ extra_out2) {
+  constexpr bool CAPQ = EXTRA == 1 || EXTRA == 5;      // a per-wave capture queue
+  constexpr bool AGG = EXTRA >= 2 && EXTRA <= 4;
+  constexpr int LASTX = EXTRA == 5 ? 1 : EXTRA;         // what the LAST term does with its values
+  uint64_t* stage = nullptr;      // capture: the tile's slot in extra_out (see k_scan_cmp CAP)
+  __shared__ uint64_t cap_lds[CAPQ ? kWavesPerBlock * kCapBuf : 1];
+  __shared__ uint64_t stash_lds[EXTRA == 5 ? kWavesPerBlock * kTile : 1];
+  uint64_t* const cap_mine = cap_lds + (CAPQ ? (threadIdx.x >> 6) * kCapBuf : 0);
+  uint64_t* const stash = stash_lds + (EXTRA == 5 ? (threadIdx.x >> 6) * kTile : 0);
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  const int nplain = EXTRA ? terms.n - 1 : terms.n;
+  const int nplain = EXTRA == 5 ? terms.n - 2 : (EXTRA ? terms.n - 1 : terms.n);
   // four consecutive tiles per trip, like k_scan_cmp: lane 16k + j holds word j of tile k, one 512-byte bitmap store per group
   const int64_t ngroups = (ntiles + 3) / 4;
   for (int64_t g = wave; g < ngroups; g += nwaves) {
@@ -527,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       existing = bitmap[g * 64 + lane];
       live = __ballot(existing != 0);
       if (live == 0) {
-        if ((lane & 15) == 0 && (lane >> 4) < nk) { tile_counts[t0 + (lane >> 4)] = 0; if (EXTRA >= 2) extra_out[t0 + (lane >> 4)] = agg_identity_bits<EXTRA>(terms.t[terms.n - 1].dtype); }
+        if ((lane & 15) == 0 && (lane >> 4) < nk) { tile_counts[t0 + (lane >> 4)] = 0; if (AGG) extra_out[t0 + (lane >> 4)] = agg_identity_bits<LASTX>(terms.t[terms.n - 1].dtype); }
         continue;
       }
     }
@@ -614,21 +648,47 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       for (int k = 0; k < nk; k++) {
         const int64_t tile = t0 + k, base = tile * kTile;
         const int l0 = 16 * k;
-        if (AND_EXISTING && ((live >> l0) & 0xffffull) == 0) { if (EXTRA >= 2 && lane == 0) extra_out[tile] = agg_identity_bits<EXTRA>(tm.dtype); continue; }
+        if (AND_EXISTING && ((live >> l0) & 0xffffull) == 0) { if (AGG && lane == 0) extra_out[tile] = agg_identity_bits<LASTX>(tm.dtype); continue; }
         uint32_t run = 0;
-        if (EXTRA == 1) stage = extra_out + base;   // straight to the tile's slot: a contiguous run per 64-row word, merged in L2
+        uint64_t bef = before;
+        if (EXTRA == 5) {           // the term before the last: its word of the mask, its values parked in LDS
+          const ScanTerm& ta = terms.t[terms.n - 2];
+          const uint32_t sa = op_sel(ta.op), sa2 = ta.op2 >= 0 ? op_sel(ta.op2) : 0u;
+          wave_lds_fence();         // (the previous tile's reads of the stash are done)
+          uint64_t wa;
+          if (ta.dtype == DFDB_F64) wa = term_word_stash<double>(ta.col, ta.cbits, sa, base, nrows, lane, l0, sa2, ta.cbits2, stash);
+          else if (ta.dtype == DFDB_I64) wa = term_word_stash<int64_t>(ta.col, ta.cbits, sa, base, nrows, lane, l0, sa2, ta.cbits2, stash);
+          else wa = term_word_stash<uint64_t>(ta.col, ta.cbits, sa, base, nrows, lane, l0, sa2, ta.cbits2, stash);
+          const bool mine16 = (lane >> 4) == k;            // the lanes that hold this tile's words
+          bef = mine16 ? (before & wa) : before;
+        }
+        if (CAPQ) stage = extra_out + base;   // straight to the tile's slot: a contiguous run per 64-row word, merged in L2
+        uint64_t ft;
         if (tm.dtype == DFDB_F64) {
-          double ls = agg_identity<double, EXTRA>();
-          fin |= term_word_last<double, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
-          if (EXTRA >= 2) { ls = wave_agg<double, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
+          double ls = agg_identity<double, LASTX>();
+          ft = term_word_last<double, LASTX>(tm.col, tm.cbits, sel, base, nrows, lane, bef, stage, run, ls, l0, sel2, cb2, cap_mine);
+          if (AGG) { ls = wave_agg<double, LASTX>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[tile] = b; } }
         } else if (tm.dtype == DFDB_I64) {
-          int64_t ls = agg_identity<int64_t, EXTRA>();
-          fin |= term_word_last<int64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
-          if (EXTRA >= 2) { ls = wave_agg<int64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = (uint64_t)ls; }
+          int64_t ls = agg_identity<int64_t, LASTX>();
+          ft = term_word_last<int64_t, LASTX>(tm.col, tm.cbits, sel, base, nrows, lane, bef, stage, run, ls, l0, sel2, cb2, cap_mine);
+          if (AGG) { ls = wave_agg<int64_t, LASTX>(ls); if (lane == 0) extra_out[tile] = (uint64_t)ls; }
         } else {
-          uint64_t ls = agg_identity<uint64_t, EXTRA>();
-          fin |= term_word_last<uint64_t, EXTRA>(tm.col, tm.cbits, sel, base, nrows, lane, before, stage, run, ls, l0, sel2, cb2, cap_mine);
-          if (EXTRA >= 2) { ls = wave_agg<uint64_t, EXTRA>(ls); if (lane == 0) extra_out[tile] = ls; }
+          uint64_t ls = agg_identity<uint64_t, LASTX>();
+          ft = term_word_last<uint64_t, LASTX>(tm.col, tm.cbits, sel, base, nrows, lane, bef, stage, run, ls, l0, sel2, cb2, cap_mine);
+          if (AGG) { ls = wave_agg<uint64_t, LASTX>(ls); if (lane == 0) extra_out[tile] = ls; }
+        }
+        fin |= ft;
+        if (EXTRA == 5) {           // the parked values of the rows that made it, in rank order, to the second capture buffer
+          wave_lds_fence();
+          CapQueue cq(cap_mine);
+          uint64_t* const stage2 = extra_out2 + base;
+#pragma unroll
+          for (int j = 0; j < kWordsPerTile; j++) {
+            const uint64_t mj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ft, l0 + j) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ft >> 32), l0 + j) << 32;
+            cap_push(cq, stage2, mj, stash[j * 64 + lane], lane);
+          }
+          cap_finish(cq, stage2, lane);
         }
       }
       acc = fin;
@@ -765,22 +825,24 @@ static bool launch_scan_pair(hipStream_t s, const ScanTerms& terms, uint64_t* bi
 }
 
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows, bool and_existing,
-                       int extra, void* extra_out, int pair) {
+                       int extra, void* extra_out, int pair, void* extra_out2) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   const dim3 g(grid_for_tiles((ntiles + 3) / 4)), b(kBlock);
-  uint64_t* eo = (uint64_t*)extra_out;
-  if (pair && launch_scan_pair(s, terms, bitmap, tile_counts, nrows, ntiles, and_existing, extra, eo)) return;
-  if (extra == 1 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 2 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 2) hipLaunchKernelGGL((k_scan_terms<true, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 3 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 3) hipLaunchKernelGGL((k_scan_terms<true, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 4 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (extra == 4) hipLaunchKernelGGL((k_scan_terms<true, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo);
-  else if (and_existing) hipLaunchKernelGGL((k_scan_terms<true, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
-  else hipLaunchKernelGGL((k_scan_terms<false, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr);
+  uint64_t* eo = (uint64_t*)extra_out; uint64_t* eo2 = (uint64_t*)extra_out2;
+  if (pair && extra != 5 && launch_scan_pair(s, terms, bitmap, tile_counts, nrows, ntiles, and_existing, extra, eo)) return;
+  if (extra == 1 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 1) hipLaunchKernelGGL((k_scan_terms<true, 1>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 5 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 5>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 5) hipLaunchKernelGGL((k_scan_terms<true, 5>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 2 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 2) hipLaunchKernelGGL((k_scan_terms<true, 2>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 3 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 3) hipLaunchKernelGGL((k_scan_terms<true, 3>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 4 && !and_existing) hipLaunchKernelGGL((k_scan_terms<false, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (extra == 4) hipLaunchKernelGGL((k_scan_terms<true, 4>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, eo, eo2);
+  else if (and_existing) hipLaunchKernelGGL((k_scan_terms<true, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr, (uint64_t*)nullptr);
+  else hipLaunchKernelGGL((k_scan_terms<false, 0>), g, b, 0, s, terms, bitmap, tile_counts, nrows, ntiles, (uint64_t*)nullptr, (uint64_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

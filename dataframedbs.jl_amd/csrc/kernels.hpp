@@ -41,9 +41,10 @@ void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint
                                          narrow columns take k_scan_cmp_narrow (16 bytes per lane): 1 = 1-byte (default), 2 = 1-, 2- and 4-byte, 0 = none */);
 // extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
 // extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
+// extra = 5 (capture two): the last term's column like extra = 1, and the 8-byte column of the term before it into extra_out2, same layout.
 void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
                        bool and_existing, int extra = 0, void* extra_out = nullptr,
-                       int pair = 1 /* ctx option "scan_pair": two plain 8-byte terms go to the pipelined k_scan_pair */);
+                       int pair = 1 /* ctx option "scan_pair": two plain 8-byte terms go to the pipelined k_scan_pair */, void* extra_out2 = nullptr);
 // whether launch_scan_terms hands these terms to k_scan_pair (pair != 0): an AND of exactly two plain comparisons / intervals on Int64 / Float64 columns, fresh mask
 bool scan_pair_applies(const ScanTerms& terms, bool and_existing);
 // captured values (per-tile compact) -> the output column: out[prefix[tile] + k] = cap[tile*1024 + k]

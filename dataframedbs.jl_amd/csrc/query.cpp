@@ -441,18 +441,31 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
           }
         }
     }
-    if (!extra && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && strs.empty() && term_batches.size() == 1) {
-      for (int k = 0; k < lb.n && special < 0; k++) {
+    // capture: the last batch of the LAST stage is the launch that produces the query's final mask, whatever ran before it in this stage (generic
+    // conjuncts, string and dictionary scans, missing masks, disjunctions all come first and only hand it a mask to AND with) or in earlier stages.
+    // Every projected plain 8-byte column among its terms — up to two — is kept by the scan instead of gathered afterwards (round 4; round 1-3 captured
+    // one column of a single-stage query whose only conjuncts were simple terms).
+    int special2 = -1;
+    if (!extra && q->hint_materialize && last_stage && ctx_option(ctx, "scan_capture", 2) > 0) {
+      const int maxcap = (int)std::min<int64_t>(2, ctx_option(ctx, "scan_capture", 2));
+      for (int k = 0; k < lb.n && (special < 0 || (special2 < 0 && maxcap >= 2)); k++) {
         const int dt = lb.t[k].dtype;
         if ((dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) || lb.t[k].pre) continue;
+        if (special >= 0 && term_ords[ord0 + (size_t)k] == term_ords[ord0 + (size_t)special]) continue;     // (two terms of one column that did not fold)
         for (const ProjCol& p : q->proj)
-          if (p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype)) { special = k; extra = 1; break; }
+          if (p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype)) { if (special < 0) { special = k; extra = 1; } else { special2 = k; extra = 5; } break; }
       }
     }
-    if (extra) {                                                     // the special term goes last
+    if (extra) {                                                     // the special term goes last (and the second captured one before it)
       std::swap(lb.t[special], lb.t[lb.n - 1]);
       std::swap(term_ords[ord0 + (size_t)special], term_ords[ord0 + (size_t)lb.n - 1]);
-      if (extra == 1) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
+      if (extra == 5) {
+        if (special2 == lb.n - 1) special2 = special;                // (it was sitting in the last place and has just been swapped away)
+        std::swap(lb.t[special2], lb.t[lb.n - 2]);
+        std::swap(term_ords[ord0 + (size_t)special2], term_ords[ord0 + (size_t)lb.n - 2]);
+        q->cap_buf2.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
+      }
+      if (extra == 1 || extra == 5) q->cap_buf.ensure((size_t)round_up(nrows, kTileRows) * 8 + 256);
       else q->agg_partials.ensure((size_t)(ceil_div(nrows, kTileRows) + 8) * 8);
     }
   }
@@ -506,7 +519,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
         }
       }
     }
-    if (tb.n == 1 && tb.t[0].op2 < 0 && tb.t[0].pre == 0 && ex < 2) {
+    if (tb.n == 1 && tb.t[0].op2 < 0 && tb.t[0].pre == 0 && ex < 2 && !(ex == 1 && have)) {      // (k_scan_cmp captures over a fresh mask only)
       LaunchTimer lt(ctx, "scan_cmp");
       prof_note(ctx, ctx_option(ctx, "scan_wt_store", 1) ? "scan_cmp.wt_store" : "scan_cmp.plain_store");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
@@ -516,12 +529,14 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       LaunchTimer lt(ctx, "scan_terms");
       const int pair = (int)ctx_option(ctx, "scan_pair", 1);
       if (pair && scan_pair_applies(tb, have)) prof_note(ctx, "scan_terms.pair");
-      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, ex == 1 ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr, pair);
+      launch_scan_terms(s, tb, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, ex, (ex == 1 || ex == 5) ? q->cap_buf.p : ex >= 2 ? q->agg_partials.p : nullptr, pair,
+                        ex == 5 ? q->cap_buf2.p : nullptr);
     }
     have = true;
   }
-  if (extra == 1) q->cap_col = term_ords.back();
-  if (extra >= 2) { q->agg_col = term_ords.back(); q->agg_dtype = term_batches.back().t[term_batches.back().n - 1].dtype; q->agg_op = q->hint_agg_op; }
+  if (extra == 1 || extra == 5) q->cap_col = term_ords.back();
+  if (extra == 5) q->cap_col2 = term_ords[term_ords.size() - 2];
+  if (extra >= 2 && extra <= 4) { q->agg_col = term_ords.back(); q->agg_dtype = term_batches.back().t[term_batches.back().n - 1].dtype; q->agg_op = q->hint_agg_op; }
 }
 
 static void run_range(dfdb_query* q, const Stage& st, bool first_stage) {
@@ -647,7 +662,7 @@ void query_execute(dfdb_query* q, int nstages) {
   ensure_state(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
-  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
   q->decoded_col = -1;
   q->gr_state = 0;             // a pending groupreduce belongs to the selection that is being replaced: its fetch must not restore the old one over this
   q->err_row[0] = q->err_row[1] = ~0ull;
@@ -869,9 +884,9 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
     }
     DevBuf stage; void* dst = o.data;
     if (!dev) { stage.ensure((size_t)cnt * w); dst = stage.p; }
-    if (q->cap_col == e.col && w == 8 && q->executed_stages == (int)q->stages.size()) {   // the scan kept these values: contiguous copy per tile
+    if ((q->cap_col == e.col || q->cap_col2 == e.col) && w == 8 && q->executed_stages == (int)q->stages.size()) {   // the scan kept these values: contiguous copy per tile
       LaunchTimer lt(ctx, "compact_captured");
-      launch_compact_captured(s, q->cap_buf.as<uint64_t>(), q->prefix.as<uint64_t>(), (uint64_t*)dst, t->nrows, cnt);
+      launch_compact_captured(s, (q->cap_col == e.col ? q->cap_buf : q->cap_buf2).as<uint64_t>(), q->prefix.as<uint64_t>(), (uint64_t*)dst, t->nrows, cnt);
     } else {
       LaunchTimer lt(ctx, "gather");
       launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt);
@@ -1007,7 +1022,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
   launch_set_rows(s, drows.as<uint64_t>(), (int)ng, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
   HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory
   return ng;
 }
@@ -1053,7 +1068,7 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
     if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
   }
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1; q->cap_str_col = -1; q->agg_col = -1;
+  q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1;
   HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here (or move to the caller: groupreduce looks rows up in them)
   if (keep) { keep->keys = std::move(keys); keep->rows = std::move(rows); keep->aux = std::move(aux); keep->rep_off = std::move(rep_off); keep->rep_len = std::move(rep_len);
               keep->cap = cap; keep->salt = used_salt; keep->is_str = is_str; }

@@ -125,6 +125,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     nontemporal is slower alone, but the scan that follows runs 4-7 % faster); 3 (default) / 4 = two ctiles per wave and nontemporal / plain
  *                     16-byte stores, one pair per wave; 5 / 6 = the same with 4 KB instead of 8 KB of LDS per wave.  "compact_grid_cap" bounds its workgroups
  *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
+ *   "scan_capture"    how many projected 8-byte predicate columns the scan that produces a query's final mask keeps for dfdb_materialize
+ *                     (dfdb_query_hint_materialize): 2 (default: the last two terms of the launch, the second parked in LDS), 1, or 0 = gather everything
  *   "scan_narrow"     which narrow columns `col OP const` scans with 16-byte loads per lane (k_scan_cmp_narrow): 1 = 1-byte columns — Bool, Int8, UInt8 —
  *                     (default: 0.72 of the HBM peak against 0.52), 2 = 2- and 4-byte columns too (no consistent gain measured), 0 = none
  *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
