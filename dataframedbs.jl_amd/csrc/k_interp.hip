@@ -22,54 +22,8 @@
 
 namespace dfdb {
 
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = 4;
-constexpr int64_t kTile = 1024;
-constexpr int kW = 4;            // 64-row words a wave carries through one instruction dispatch
-constexpr int kGroups = 16 / kW;
-constexpr int kMaxIns = 96;
-constexpr int kMaxCols = 32;     // (a queue of fused predicate stages is ONE program: eight columns was reached by three ordinary stages)
-constexpr int kMaxStr = 4;       // string columns whose bytes are read (need per-row byte offsets)
-constexpr int kMaxLds = 8;       // stack levels + offset arrays: 8 KB of dynamic LDS each per workgroup
+#include "k_interp_device.inc"
 
-enum Handler : uint8_t {
-  H_LOAD = 0,
-  H_FADD, H_FSUB, H_FMUL, H_FDIV, H_FREM, H_FMOD, H_FIDIV, H_FMIN, H_FMAX, H_FNEG, H_FABS, H_FROUND32,
-  H_IADD, H_ISUB, H_IMUL, H_IMIN_S, H_IMIN_U, H_IMAX_S, H_IMAX_U, H_IDIVOP, H_INEG, H_IABS, H_WRAP,
-  H_BAND1, H_BOR1, H_AND, H_OR, H_XOR, H_NOT,
-  H_CMP_FF, H_CMP_SS, H_CMP_UU, H_CMP_US, H_CMP_IF,
-  H_INSET, H_CAST,
-  // handlers that set the missing flag of their result themselves (everything above: flag = union of the operands' flags)
-  H_STRCMP, H_STRPRE, H_STRSUF, H_ISMISS, H_AND3, H_OR3, H_COALESCE, H_ISMISSA
-};
-constexpr int kFirstOwnFlag = H_STRCMP;
-enum BSrc : uint8_t { B_NONE = 0, B_IMM = 1, B_COL = 2, B_POP = 3 };
-enum Cvt : uint8_t { CV_NONE = 0, CV_S2D, CV_U2D, CV_S2F, CV_U2F, CV_D2F };
-enum : uint8_t { F_SWAP = 1,   // the fetched operand is the LEFT one: exchange A and B before the handler
-                 F_PUSH = 4,   // A is live: push it before this instruction produces a fresh value
-                 F_UNS = 8,    // unsigned compute type (integer division) / UInt64 integer side (H_CMP_IF)
-                 F_FLIP = 16 };// string comparison with the constant on the left
-
-struct IInstr {                // host-side form (the Compiler fills these fields)
-  uint8_t h, bsrc, cva, cvb, flags, cmp /* DFIR_EQ.. or DFIR_IDIV/REM/MOD */, wsh /* 64 - bits of the integer result type */, wsg;
-  int32_t slot;                // column slot (B_COL, string handlers, H_ISMISS)
-  int32_t len;                 // pattern / set length
-  uint64_t imm;                // immediate bits / pool offset
-  uint8_t ta, tb, rt, so;      // generic handlers (H_CAST, H_INSET): operand/result dtypes; so: offset-array index of the string column
-  int32_t aslot;               // 1 + column slot loaded into A before the operation (fused leaf load), 0 = A is the running value
-  uint64_t imm2;               // type_min of the compute type (typemin ÷ -1 check)
-};
-// device form: the same fields packed into dwords so that the whole instruction arrives with ONE scalar load
-// (sub-dword fields would be fetched with vector loads + s_waitcnt vmcnt(0): three exposed round trips per dispatch)
-struct DInstr {
-  uint32_t w0;                 // h | bsrc<<8 | cva<<16 | cvb<<24
-  uint32_t w1;                 // flags | cmp<<8 | wsh<<16 | wsg<<24
-  int32_t slot, len;
-  uint64_t imm;
-  uint32_t w2;                 // ta | tb<<8 | rt<<16 | so<<24
-  int32_t aslot;
-  uint64_t imm2;
-};
 static DInstr pack_instr(const IInstr& i) {
   DInstr d{};
   d.w0 = (uint32_t)i.h | (uint32_t)i.bsrc << 8 | (uint32_t)i.cva << 16 | (uint32_t)i.cvb << 24;
@@ -79,448 +33,6 @@ static DInstr pack_instr(const IInstr& i) {
   d.aslot = i.aslot; d.imm2 = i.imm2;
   return d;
 }
-struct IColDesc {
-  const void* data; const uint64_t* missing; const int64_t* tile_off; const uint8_t* bytes;
-  int32_t dtype; int32_t wide;     // wide: an 8-byte column (Int64 / UInt64 / Float64): loaded as it is, no dtype switch
-};
-struct IProgram {
-  int32_t n, ncols, result_dtype, nstr;
-  int32_t nullable_result, pad0;     // the value is Union{T,Missing}: flags are written beside it (projection)
-  const uint8_t* pool;               // string patterns and set elements
-  int32_t str_slot[kMaxStr];         // column slots of the string columns that need byte offsets
-  IColDesc cols[kMaxCols];
-  DInstr ins[kMaxIns];
-};
-
-// ---------------------------------------------------------------- scalar helpers
-__device__ __forceinline__ double bits_d(uint64_t x) { return __longlong_as_double((long long)x); }
-__device__ __forceinline__ uint64_t d_bits(double d) { return (uint64_t)__double_as_longlong(d); }
-__device__ __forceinline__ bool isf(int t) { return t == DFDB_F32 || t == DFDB_F64; }
-__device__ __forceinline__ bool issigned(int t) { return t >= DFDB_I8 && t <= DFDB_I64; }
-
-__device__ __forceinline__ int64_t wrap_to(int64_t x, int t) {
-  switch (t) {
-    case DFDB_I8: return (int8_t)x; case DFDB_I16: return (int16_t)x; case DFDB_I32: return (int32_t)x;
-    case DFDB_U8: return (uint8_t)x; case DFDB_U16: return (uint16_t)x; case DFDB_U32: return (uint32_t)x;
-    default: return x;
-  }
-}
-__device__ __forceinline__ int64_t type_min(int t) {
-  switch (t) { case DFDB_I8: return -128; case DFDB_I16: return -32768; case DFDB_I32: return -2147483648LL; case DFDB_I64: return INT64_MIN; }
-  return 0;
-}
-// operand (64-bit register image of type t) as a float of compute type ct, one rounding from the source
-__device__ __forceinline__ double as_float(uint64_t x, int t, int ct) {
-  if (isf(t)) { const double d = bits_d(x); return ct == DFDB_F32 ? (double)(float)d : d; }
-  if (ct == DFDB_F32) return t == DFDB_U64 ? (double)(float)x : (double)(float)(int64_t)x;
-  return t == DFDB_U64 ? (double)x : (double)(int64_t)x;
-}
-// exact three-way comparisons; 2 = unordered
-__device__ __forceinline__ int cmp_int_float(int64_t x, bool xu, double y) {
-  if (y != y) return 2;
-  if (xu) {
-    if (y >= 18446744073709551616.0) return -1;
-    if (y < 0.0) return 1;
-    const uint64_t yi = (uint64_t)y; const uint64_t ux = (uint64_t)x;
-    if (ux < yi) return -1;
-    if (ux > yi) return 1;
-    return (y - (double)yi) > 0.0 ? -1 : 0;
-  }
-  if (y >= 9223372036854775808.0) return -1;
-  if (y < -9223372036854775808.0) return 1;
-  const int64_t yi = (int64_t)y;
-  if (x < yi) return -1;
-  if (x > yi) return 1;
-  const double fr = y - (double)yi;
-  return fr > 0.0 ? -1 : (fr < 0.0 ? 1 : 0);
-}
-__device__ __forceinline__ int cmp3(uint64_t xa, int ta, uint64_t xb, int tb) {
-  const bool fa = isf(ta), fb = isf(tb);
-  if (fa && fb) { const double a = bits_d(xa), b = bits_d(xb); if (a != a || b != b) return 2; return a < b ? -1 : (a > b ? 1 : 0); }
-  if (fa) { const int r = cmp_int_float((int64_t)xb, tb == DFDB_U64, bits_d(xa)); return r == 2 ? 2 : -r; }
-  if (fb) return cmp_int_float((int64_t)xa, ta == DFDB_U64, bits_d(xb));
-  const bool ua = ta == DFDB_U64, ub = tb == DFDB_U64;
-  if (ua == ub) { if (ua) return xa < xb ? -1 : (xa > xb ? 1 : 0); const int64_t a = (int64_t)xa, b = (int64_t)xb; return a < b ? -1 : (a > b ? 1 : 0); }
-  if (ua) { if ((int64_t)xb < 0) return 1; return xa < xb ? -1 : (xa > xb ? 1 : 0); }
-  if ((int64_t)xa < 0) return -1;
-  return xa < xb ? -1 : (xa > xb ? 1 : 0);
-}
-__device__ __forceinline__ bool cmp_result(int op, int c) {
-  switch (op) {
-    case DFIR_EQ: return c == 0; case DFIR_NE: return c != 0; case DFIR_LT: return c == -1;
-    case DFIR_LE: return c == -1 || c == 0; case DFIR_GT: return c == 1; default: return c == 1 || c == 0;
-  }
-}
-__device__ __forceinline__ double jl_fmin(double x, double y) { const double r = (x < y || (x == y && __builtin_signbit(x))) ? x : y; return (x != x || y != y) ? __builtin_nan("") : r; }
-__device__ __forceinline__ double jl_fmax(double x, double y) { const double r = (x > y || (x == y && !__builtin_signbit(x))) ? x : y; return (x != x || y != y) ? __builtin_nan("") : r; }
-
-__device__ __forceinline__ int str_cmp_dev(const uint8_t* a, int la, const uint8_t* b, int lb) {
-  const int m = la < lb ? la : lb;
-  for (int k = 0; k < m; k++) { const int d = (int)a[k] - (int)b[k]; if (d) return d < 0 ? -1 : 1; }
-  return la < lb ? -1 : (la > lb ? 1 : 0);
-}
-
-// ---------------------------------------------------------------- out-of-line slow paths
-// Everything with lane-divergent control flow (loops over bytes, 64-bit division, fmod, error reporting) is a real
-// call: the dispatch loop then contains wave-uniform branches only, so LLVM's CFG structurizer leaves it alone and
-// the handler switch stays a plain scalar compare-and-branch tree instead of a flag-driven state machine.
-#define DFDB_SLOW __device__ __attribute__((noinline))
-DFDB_SLOW double slow_frem(double a, double b) { return fmod(a, b); }
-DFDB_SLOW double slow_fmod(double a, double b) {
-  double v = fmod(a, b);
-  if (v == 0.0) v = __builtin_copysign(v, b); else if ((v > 0.0) != (b > 0.0)) v += b;
-  return v;
-}
-// err[0]: flags (1 DivideError, 2 InexactError); the two 64-bit words at err + 2: the SMALLEST row each kind happened on (the host decides from it
-// whether the reference's block-by-block iteration would have reached that row at all: query.cpp error_is_reached)
-__device__ __forceinline__ void flag_error(int* err, int code, uint64_t row) {
-  atomicOr(err, code);
-  atomicMin((unsigned long long*)(err + 2) + (code == 1 ? 0 : 1), (unsigned long long)row);
-}
-DFDB_SLOW double slow_fidiv(double a, double b) { return __builtin_rint((a - fmod(a, b)) / b); }
-DFDB_SLOW uint64_t slow_idivop(int64_t a, int64_t b, int op, bool uns, int64_t tmin, bool alive, int* err, uint64_t row) {
-  int64_t v = 0;
-  if (b == 0) { if (alive) flag_error(err, 1, row); }
-  else if (uns) v = op == DFIR_IDIV ? (int64_t)((uint64_t)a / (uint64_t)b) : (int64_t)((uint64_t)a % (uint64_t)b);
-  else if (b == -1) { if (op == DFIR_IDIV) { if (a == tmin) { if (alive) flag_error(err, 1, row); } else v = -a; } }
-  else if (op == DFIR_IDIV) v = a / b;
-  else { v = a % b; if (op == DFIR_MOD && v != 0 && ((v < 0) != (b < 0))) v += b; }
-  return (uint64_t)v;
-}
-DFDB_SLOW int slow_cmp_int_float(int64_t x, bool xu, double y) { return cmp_int_float(x, xu, y); }
-DFDB_SLOW uint64_t slow_strop(int h_is_cmp, int suffix, const uint8_t* p, int len, const uint8_t* pat, int pl, int op, bool flip) {
-  if (h_is_cmp) { const int sc = str_cmp_dev(p, len, pat, pl); return cmp_result(op, flip ? -sc : sc); }
-  bool ok = len >= pl;
-  if (ok) { if (suffix) p += len - pl; for (int i = 0; i < pl && ok; i++) ok = p[i] == pat[i]; }
-  return ok;
-}
-DFDB_SLOW uint64_t slow_inset(uint64_t x, int ta, const uint64_t* set, int n, int tb) {
-  bool hit = false;
-  for (int i = 0; i < n && !hit; i++) hit = cmp3(x, ta, set[i], tb) == 0;
-  return hit;
-}
-// DFIR_CAST = Julia's T(x) / convert(T, x): exact or InexactError (Int8(300), Int8(300.0), UInt64(-1), UInt64(-1.0), Int64(typemax(UInt64)),
-// Bool(2) all throw; Float32(x) rounds).  The implicit promotions of arithmetic wrap instead (`a % T`, Base int.jl) and do not come here.
-__device__ __forceinline__ bool int_fits(uint64_t x, bool src_unsigned, int rt) {
-  int64_t lo, hi;                                   // [typemin, typemax] of the targets below 64 bits
-  switch (rt) {
-    case DFDB_I8: lo = -128; hi = 127; break;        case DFDB_I16: lo = -32768; hi = 32767; break;
-    case DFDB_I32: lo = -2147483648LL; hi = 2147483647LL; break;
-    case DFDB_U8: lo = 0; hi = 255; break;           case DFDB_U16: lo = 0; hi = 65535; break;
-    case DFDB_U32: lo = 0; hi = 4294967295LL; break;
-    case DFDB_I64: return !src_unsigned || (int64_t)x >= 0;      // a UInt64 above typemax(Int64)
-    case DFDB_U64: return src_unsigned || (int64_t)x >= 0;       // a negative signed value
-    default: return true;
-  }
-  if (src_unsigned) return x <= (uint64_t)hi;
-  return (int64_t)x >= lo && (int64_t)x <= hi;
-}
-DFDB_SLOW uint64_t slow_cast(uint64_t xa, int ta, int rt, bool alive, int* err, uint64_t row) {
-  if (isf(rt)) return d_bits(as_float(xa, ta, rt));
-  if (isf(ta)) {   // Float -> Int / Bool: InexactError unless integral and inside the TARGET's range
-    const double d = bits_d(xa);
-    bool okr = d == __builtin_trunc(d);
-    uint64_t v = 0;
-    if (rt == DFDB_U64) { okr = okr && d >= 0.0 && d < 18446744073709551616.0; if (okr) v = (uint64_t)d; }
-    else { okr = okr && d >= -9223372036854775808.0 && d < 9223372036854775808.0; if (okr) { v = (uint64_t)(int64_t)d; okr = rt == DFDB_BOOL || int_fits(v, false, rt); } }
-    if (!okr && alive) flag_error(err, 2, row);
-    if (!okr) v = 0;
-    if (rt == DFDB_BOOL) { if (v > 1 && alive) flag_error(err, 2, row); return v != 0; }
-    return (uint64_t)wrap_to((int64_t)v, rt);
-  }
-  if (rt == DFDB_BOOL) { if (xa > 1 && alive) flag_error(err, 2, row); return xa != 0; }
-  if (ta != DFDB_BOOL && !int_fits(xa, ta >= DFDB_U8 && ta <= DFDB_U64, rt) && alive) flag_error(err, 2, row);
-  return (uint64_t)wrap_to((int64_t)xa, rt);
-}
-
-// ---------------------------------------------------------------- the interpreter
-#define EACH for (int k = 0; k < kW; k++)
-
-// column reads: wave-uniform pointer to the tile's first row (SGPR pair) + a 32-bit byte offset per lane, so the
-// load uses the saddr addressing mode and no 64-bit vector address arithmetic
-template <typename T, bool FLT>
-__device__ __forceinline__ void load_words(const void* data, int64_t base, const uint32_t (&idx)[kW], uint64_t (&B)[kW]) {
-  // the pointer comes out of the program image (a generic pointer to the compiler): name the global address space,
-  // otherwise these become flat_load with 64-bit vector addresses
-  typedef const char __attribute__((address_space(1))) * gchar_p;
-  typedef const T __attribute__((address_space(1))) * gT_p;
-  gchar_p p = (gchar_p)((const T*)data + base);
-#pragma unroll
-  EACH {
-    // keep the 32-bit offset arithmetic HERE (the empty asm stops the compiler from hoisting 64-bit copies of idx*1,
-    // *2, *4, *8 out of the dispatch loop: 32 VGPRs) so that the load selects the SGPR-base + 32-bit-VGPR-offset form
-    uint32_t o = idx[k];
-    asm volatile("" : "+v"(o));
-    const T v = __builtin_nontemporal_load((gT_p)(p + (uint32_t)(o * (uint32_t)sizeof(T))));
-    if (FLT) B[k] = d_bits((double)v); else B[k] = (uint64_t)(int64_t)v;
-  }
-}
-__device__ __forceinline__ void load_col(const IColDesc& c, int64_t base, const uint32_t (&idx)[kW], uint64_t (&B)[kW]) {
-  if (c.wide) { load_words<uint64_t, false>(c.data, base, idx, B); return; }      // (one scalar test instead of a ten-way dtype tree)
-  switch (c.dtype & DFDB_DTYPE_MASK) {
-    case DFDB_I64: case DFDB_U64: case DFDB_F64: load_words<uint64_t, false>(c.data, base, idx, B); break;
-    case DFDB_I32: case DFDB_STRING: load_words<int32_t, false>(c.data, base, idx, B); break;   // String: the size
-    case DFDB_F32: load_words<float, true>(c.data, base, idx, B); break;
-    case DFDB_U32: load_words<uint32_t, false>(c.data, base, idx, B); break;
-    case DFDB_I16: load_words<int16_t, false>(c.data, base, idx, B); break;
-    case DFDB_U16: load_words<uint16_t, false>(c.data, base, idx, B); break;
-    case DFDB_I8:  load_words<int8_t, false>(c.data, base, idx, B); break;
-    case DFDB_U8:  load_words<uint8_t, false>(c.data, base, idx, B); break;
-    case DFDB_BOOL:
-#pragma unroll
-      EACH B[k] = ((const uint8_t*)c.data + base)[idx[k]] != 0;
-      break;
-  }
-}
-// missing flags of the rows just loaded from column c (1 = missing): one wave-uniform 64-bit word per 64 rows for a
-// fixed-width column, the sign of the size for a String
-__device__ __forceinline__ void load_missing(const IColDesc& c, int64_t base, int g, uint32_t lane, const uint64_t (&V)[kW], uint32_t (&M)[kW]) {
-  if (!(c.dtype & DFDB_NULLABLE)) {
-#pragma unroll
-    EACH M[k] = 0;
-  } else if ((c.dtype & DFDB_DTYPE_MASK) == DFDB_STRING) {
-#pragma unroll
-    EACH M[k] = (int64_t)V[k] < 0;
-  } else {
-#pragma unroll
-    EACH { const uint64_t w = c.missing ? c.missing[(base >> 6) + g * kW + k] : 0ull; M[k] = (uint32_t)(w >> lane) & 1u; }
-  }
-}
-__device__ __forceinline__ void convert(uint64_t (&X)[kW], int mode) {
-  switch (mode) {
-    case CV_S2D:
-#pragma unroll
-      EACH X[k] = d_bits((double)(int64_t)X[k]);
-      break;
-    case CV_U2D:
-#pragma unroll
-      EACH X[k] = d_bits((double)X[k]);
-      break;
-    case CV_S2F:
-#pragma unroll
-      EACH X[k] = d_bits((double)(float)(int64_t)X[k]);
-      break;
-    case CV_U2F:
-#pragma unroll
-      EACH X[k] = d_bits((double)(float)X[k]);
-      break;
-    case CV_D2F:
-#pragma unroll
-      EACH X[k] = d_bits((double)(float)bits_d(X[k]));
-      break;
-  }
-}
-// wrap a 64-bit image to the integer type of 64-sh bits (sh, sg wave-uniform)
-__device__ __forceinline__ uint64_t wrapv(uint64_t x, int sh, bool sg) {
-  return sg ? (uint64_t)((int64_t)(x << sh) >> sh) : ((x << sh) >> sh);
-}
-__device__ __forceinline__ bool cmp_pick(int op, bool lt, bool eq, bool un) {   // un: unordered (NaN)
-  switch (op) {
-    case DFIR_EQ: return eq; case DFIR_NE: return !eq; case DFIR_LT: return lt; case DFIR_LE: return lt || eq;
-    case DFIR_GT: return !lt && !eq && !un; default: return !lt && !un;
-  }
-}
-
-#define FLOAT_OP(EXPR)                                                        \
-  {                                                                           \
-    _Pragma("unroll") EACH {                                                  \
-      const double a = bits_d(A[k]), b = bits_d(B[k]); double v; (void)b;     \
-      EXPR;                                                                   \
-      A[k] = d_bits(v);                                                       \
-    }                                                                         \
-  } break
-#define INT_OP(EXPR)                                                          \
-  {                                                                           \
-    _Pragma("unroll") EACH {                                                  \
-      uint64_t a = A[k], b = B[k], v;                                         \
-      if (wsh) { a = wrapv(a, wsh, wsg); b = wrapv(b, wsh, wsg); }            \
-      EXPR;                                                                   \
-      A[k] = wsh ? wrapv(v, wsh, wsg) : v;                                    \
-    }                                                                         \
-  } break
-
-template <int MODE, bool STR, bool NUL>   // MODE 0: predicate -> bitmap ; 1: computed column at the selected rows -> compacted output; NUL: Union{T,Missing} flags
-__global__ __launch_bounds__(kBlock) void k_interp(const IProgram* __restrict__ prog, uint64_t* __restrict__ bitmap,
-                                                   uint32_t* __restrict__ tile_counts, const uint64_t* __restrict__ prefix, void* __restrict__ out,
-                                                   int64_t out_cap, int64_t nrows, int64_t ntiles, int and_existing, int* __restrict__ err,
-                                                   int stack_levels, uint8_t* __restrict__ out_missing) {
-  extern __shared__ uint64_t lds[];   // [stack level | offset array][k][thread]
-  const int tid = threadIdx.x, lane = lane_id();
-  // everything indexed by the tile is wave-uniform (SGPRs): say so, the compiler cannot see that tid>>6 is
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  const int nins = prog->n, rdt = prog->result_dtype, nstr = STR ? prog->nstr : 0;
-  const uint8_t* pool = prog->pool;
-  const bool masked = MODE == 1 || and_existing;
-  uint32_t* ldsf = (uint32_t*)(lds + (size_t)(stack_levels + nstr) * kW * kBlock);   // NUL: missing flags of the pushed values
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    const int64_t base = tile * kTile;
-    const uint32_t lastvalid = (uint32_t)(nrows - base < kTile ? nrows - base - 1 : kTile - 1);
-    int64_t srun[kMaxStr];
-#pragma unroll
-    for (int s = 0; s < kMaxStr; s++) srun[s] = (STR && s < nstr) ? prog->cols[prog->str_slot[s]].tile_off[tile] : 0;
-    uint32_t myword_lo = 0, myword_hi = 0, tile_cnt = 0;
-    uint32_t run_sel = 0;
-    // the tile's 16 incoming mask words: one coalesced load, handed out per word with v_readlane
-    uint32_t tm_lo = ~0u, tm_hi = ~0u;
-    if (masked && lane < 16) { const uint64_t w = bitmap[tile * 16 + lane]; tm_lo = (uint32_t)w; tm_hi = (uint32_t)(w >> 32); }
-    for (int g = 0; g < kGroups; g++) {
-      uint32_t idx[kW]; bool inb[kW]; uint64_t maskword[kW]; uint64_t anymask = 0;
-#pragma unroll
-      EACH {
-        const uint32_t r = (uint32_t)((g * kW + k) * 64 + lane);
-        inb[k] = r <= lastvalid;
-        idx[k] = inb[k] ? r : lastvalid;
-        maskword[k] = masked ? ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)tm_hi, g * kW + k) << 32 |
-                                (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, g * kW + k)) : ~0ull;
-        anymask |= maskword[k];
-      }
-      // byte offsets of these rows in the string columns whose bytes are read (wave prefix sum of the sizes)
-      if (STR) {
-#pragma unroll
-        for (int s = 0; s < kMaxStr; s++) {
-          if (s < nstr) {
-            const int32_t* sizes = (const int32_t*)prog->cols[prog->str_slot[s]].data;
-#pragma unroll
-            EACH {
-              const int32_t sz = inb[k] ? (sizes + base)[idx[k]] : 0;
-              const uint32_t c = sz > 0 ? (uint32_t)sz : 0u;
-              const uint32_t incl = wave_incl_scan(c);
-              lds[((stack_levels + s) * kW + k) * kBlock + tid] = (uint64_t)(srun[s] + (int64_t)(incl - c));
-              srun[s] += (int64_t)__shfl(incl, 63, 64);
-            }
-          }
-        }
-      }
-      if (masked && anymask == 0) {   // wave-uniform: nothing selected in these 256 rows
-        continue;
-      }
-      uint64_t A[kW], B[kW];
-      uint32_t Am[kW], Bm[kW];             // NUL: 1 = the value is missing
-#pragma unroll
-      EACH { A[k] = 0; B[k] = 0; Am[k] = 0; Bm[k] = 0; }
-      int sp = 0;
-      for (int pc = 0; pc < nins; pc++) {
-        const DInstr& in = prog->ins[pc];
-        const uint32_t w0 = in.w0, w1 = in.w1;
-        const int in_h = w0 & 0xff, in_bsrc = (w0 >> 8) & 0xff, in_cva = (w0 >> 16) & 0xff, in_cvb = w0 >> 24;
-        const int fl = w1 & 0xff, in_cmp = (w1 >> 8) & 0xff, wsh = (w1 >> 16) & 0xff; const bool wsg = (w1 >> 24) != 0;
-        if (fl & F_PUSH) {
-#pragma unroll
-          EACH lds[(sp * kW + k) * kBlock + tid] = A[k];
-          if (NUL) {
-#pragma unroll
-            EACH ldsf[(sp * kW + k) * kBlock + tid] = Am[k];
-          }
-          sp++;
-        }
-        if (in.aslot) {                                                   // fused leaf load: `col OP x` is one dispatch
-          load_col(prog->cols[in.aslot - 1], base, idx, A);
-          if (NUL) load_missing(prog->cols[in.aslot - 1], base, g, (uint32_t)lane, A, Am);
-        }
-        switch (in_bsrc) {
-          case B_IMM: {
-            const uint64_t v = in.imm;
-#pragma unroll
-            EACH { B[k] = v; Bm[k] = 0; }
-          } break;
-          case B_COL:
-            load_col(prog->cols[in.slot], base, idx, B);
-            if (NUL) load_missing(prog->cols[in.slot], base, g, (uint32_t)lane, B, Bm);
-            break;
-          case B_POP:
-            sp--;
-#pragma unroll
-            EACH B[k] = lds[(sp * kW + k) * kBlock + tid];
-            if (NUL) {
-#pragma unroll
-              EACH Bm[k] = ldsf[(sp * kW + k) * kBlock + tid];
-            }
-            break;
-          default:
-#pragma unroll
-            EACH Bm[k] = 0;
-            break;
-        }
-        if (fl & F_SWAP) {
-#pragma unroll
-          EACH { const uint64_t t = A[k]; A[k] = B[k]; B[k] = t; const uint32_t tm = Am[k]; Am[k] = Bm[k]; Bm[k] = tm; }
-        }
-        if (NUL && in_h != H_LOAD && in_h < kFirstOwnFlag) {              // Base methods propagate missing
-#pragma unroll
-          EACH Am[k] |= Bm[k];
-        }
-        if (w0 >> 16) {                                                     // (one test for the usual case: neither operand is converted)
-          if (in_cva) convert(A, in_cva);
-          if (in_cvb) convert(B, in_cvb);
-        }
-        // the handlers as a local function of the handler id: called with a CONSTANT id for the commonest ones (the switch folds to that one case), so that a compare or an
-        // add is found after one or two scalar compares instead of the six levels of a 43-way compare tree — the dispatch loop is bound by the CU's one scalar unit
-        if constexpr (NUL) {
-          // (the kernels that carry missing flags are register-bound: wrapped in the local function below they lose a wave per SIMD and run 13-16 % slower)
-          const int hh = in_h;
-          switch (hh) {
-#include "k_interp_handlers.inc"
-          }
-        } else {
-        auto handler = [&](const int hh) __attribute__((always_inline)) {
-        switch (hh) {
-#include "k_interp_handlers.inc"
-        }
-        };
-        if (in_h == H_CMP_SS) handler(H_CMP_SS);
-        else if (in_h == H_CMP_FF) handler(H_CMP_FF);
-        else if (in_h == H_IADD) handler(H_IADD);
-        else if (in_h == H_IMUL) handler(H_IMUL);
-        else if (in_h == H_ISUB) handler(H_ISUB);
-        else if (in_h == H_FMUL) handler(H_FMUL);
-        else if (in_h == H_FADD) handler(H_FADD);
-        else if (in_h == H_AND) handler(H_AND);
-        else if (in_h == H_OR) handler(H_OR);
-        else handler(in_h);
-        }
-      }
-#pragma unroll
-      EACH {
-        const int j = g * kW + k;
-        if (MODE == 0) {
-          uint64_t m = __ballot(inb[k] && (A[k] & 1ull));
-          if (and_existing) m &= maskword[k];
-          // m is wave-uniform: drop it into lane j of the tile's word vector, count it on the scalar unit
-          myword_lo = write_lane(myword_lo, (uint32_t)m, j);
-          myword_hi = write_lane(myword_hi, (uint32_t)(m >> 32), j);
-          tile_cnt += (uint32_t)__popcll(m);
-        } else {
-          const uint32_t rank = (uint32_t)__popcll(maskword[k] & ((1ull << lane) - 1ull));
-          const int64_t o = (int64_t)prefix[tile] + run_sel + rank;
-          const bool alive = inb[k] && ((maskword[k] >> lane) & 1ull);
-          const uint64_t res = A[k];
-          if (alive && o < out_cap) {
-            switch (rdt) {
-              case DFDB_I8: case DFDB_U8: ((uint8_t*)out)[o] = (uint8_t)res; break;
-              case DFDB_BOOL: ((uint8_t*)out)[o] = (uint8_t)(res & 1ull); break;
-              case DFDB_I16: case DFDB_U16: ((uint16_t*)out)[o] = (uint16_t)res; break;
-              case DFDB_I32: case DFDB_U32: ((uint32_t*)out)[o] = (uint32_t)res; break;
-              case DFDB_F32: ((float*)out)[o] = (float)bits_d(res); break;
-              default: ((uint64_t*)out)[o] = res; break;
-            }
-            if (NUL && out_missing) out_missing[o] = (uint8_t)Am[k];
-          }
-          run_sel += (uint32_t)__popcll(maskword[k]);
-        }
-      }
-    }
-    if (MODE == 0) {
-      if (lane < 16) __hip_atomic_store(&bitmap[tile * 16 + lane], (uint64_t)myword_hi << 32 | myword_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through: see k_scan_cmp
-      if (lane == 0) tile_counts[tile] = tile_cnt;
-    }
-  }
-}
-#undef EACH
-#undef CMP_CASES
-#undef FLOAT_OP
-#undef INT_OP
-
 // ---------------------------------------------------------------- host: typed tree -> accumulator program
 struct Compiler {
   const dfdb_table* t;
