@@ -25,6 +25,8 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
                   algorithmic_GB, rows_per_s (whole job) and roofline {achieved, peak, frac} in algorithmic bytes per GPU.
   calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
                   `value` itself is the library-default configuration (no ctx option set)
+                  Round 4 adds "3_computed" (config 3 with the computed x * 2 projection), "interp" (expressions outside the scan kernels: the device interpreter and
+                  the same program compiled at run time by hipRTC), "unique", "groupreduce", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
@@ -47,7 +49,7 @@ for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
 SEED = 0x9E3779B97F4A7C15
 THRESHOLD = 899_999          # x > c over h mod 1e6  ->  10 % selectivity
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable); the run reads it from dfdb_ctx_device_info
-KERNELS = ["scan_cmp", "scan_terms", "str_match", "dict_scan", "interp_predicate", "scan_counts", "compact_indices", "compact_captured", "gather",
+KERNELS = ["scan_cmp", "scan_terms", "str_match", "dict_scan", "interp_predicate", "jit_predicate", "interp_project", "jit_project", "scan_counts", "compact_indices", "compact_captured", "gather",
            "str_gather_sizes", "str_gather_bytes", "str_compact_captured", "dict_expand_sizes", "dict_expand_bytes", "fill_const_strings",
            "reduce", "reduce_partials", "range_stage"]
 
@@ -469,9 +471,123 @@ def config3_leg(L, dfdb, rows, rank):
         q.execute()
         N.check(lib.dfdb_materialize(q._h, outs, 2))
     sec, ks = L.timed(step)
-    res = L.record(rows, nsel, sec, ks, rows * 16 + nsel * 8 + nsel * 16,
-                   "a, b: Int64, x: Float64; (a > 683771) & (x < 632.456) -> materialize [b, x] into device buffers (x captured by the scan, b gathered)")
-    del ob, ox, q
+    res = {"3": L.record(rows, nsel, sec, ks, rows * 16 + nsel * 8 + nsel * 16,
+                         "a, b: Int64, x: Float64; (a > 683771) & (x < 632.456) -> materialize [b, x] into device buffers (x captured by the scan, b gathered)")}
+    # the computed `x * 2` variant of the projection (a BlockBroadcasting column: projection.jl:128-129)
+    q2 = t[(t.a > 683_771) & (t.x < 632.456), {"b": t.b, "x2": t.x * 2}]._query()
+    q2.hint_materialize(True)
+    assert q2.count() == nsel
+
+    def step2():
+        q2.execute()
+        N.check(lib.dfdb_materialize(q2._h, outs, 2))
+    sec, ks = L.timed(step2)
+    res["3_computed"] = L.record(rows, nsel, sec, ks, rows * 16 + nsel * 8 + nsel * 8 + nsel * 16,
+                                 "the same selection, projection [b, x * 2]: the computed column rides on a gather of x with the transform applied (k_gather_transform)")
+    del ob, ox, q, q2
+    t.close()
+    return res
+
+
+def interp_leg(L, dfdb, rows, rank):
+    """Expressions no specialised scan kernel takes (arbitrary closures are the reference's normal case: it JIT-fuses every broadcast, broadcast.jl:60-68):
+    the device interpreter (ctx option jit = 0) and the same program compiled at run time from the interpreter's own source by hipRTC (jit = 2: wait for
+    the compiler; csrc/jit.cpp), per launch, with algorithmic GB/s = (sum of the referenced column widths + 1/8 B for the bitmap) * rows / time."""
+    from dfdb import ir
+    ctx = L.ctx
+    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(0), rows, row_first=rank * rows)
+    t.add_generated("b", dfdb.GEN_I64_MOD1M, seed_of(1), rows, row_first=rank * rows)
+    t.add_generated("x", dfdb.GEN_F64_U2000, seed_of(2), rows, row_first=rank * rows)
+    a, b, x = ir.col(0), ir.col(1), ir.col(2)
+    cases = [("a*3 + b*2 - 7 > 4e6", a * 3 + b * 2 - 7 > 4_000_000, 16), ("(a > b) | (x*2 > a)", (a > b) | (x * 2 > a), 24), ("(a + b) * x > 3e9", (a + b) * x > 3e9, 24),
+             ("a + b > 1.8e6", a + b > 1_800_000, 16)]
+    res = {"rows_per_gpu": rows}
+    for name, pred, width in cases:
+        r = {"bytes_per_row": width + 0.125}
+        for jit, key, kern in ((0, "interpreter", "interp_predicate"), (2, "compiled", "jit_predicate")):
+            ctx.set_option("jit", jit)
+            try:
+                t0 = time.perf_counter()
+                q = t[pred, dfdb.ALL]._query()
+                r["selected"] = q.count()                                   # (jit = 2: the first execution waits for hipRTC)
+                first_s = time.perf_counter() - t0
+                ctx.profile(True)
+                for _ in range(L.steps):
+                    q.reset(); q.execute()
+                L.torch.cuda.synchronize()
+                n, ms = ctx.profile_get(kern)
+                ctx.profile(False)
+                if n:
+                    gbps = rows * r["bytes_per_row"] / (ms / n * 1e-3) / 1e9
+                    r[key] = {"ms": ms / n, "GBps": gbps, "frac_of_peak": gbps / L.peak, "launches": n, "first_execution_s": first_s}
+                else:
+                    r[key] = {"error": "the %s kernel did not run" % key}
+            finally:
+                ctx.set_option("jit", 1)
+        res[name] = r
+    t.close()
+    return res
+
+
+def f_rows_legs(L, dfdb, sc, rank):
+    """SURVEY.md section 8(f) rows as driver-visible figures: unique over 1e9 Int64 rows with 1e6 distinct values (column.jl:102-126, docs/src/index.md:171-182),
+    groupreduce by a 10-value String key (aggregate.jl:1-36), equality over a Union{String,Missing} column at config 4's size (the docs' real data set is all
+    Union{Missing,String}: index.md:264-272,326-328)."""
+    from dfdb import ir
+    torch, ctx = L.torch, L.ctx
+    res = {}
+    # ---- unique
+    n = int(1_000_000_000 * sc)
+    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+    t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, n, row_first=rank * n)
+    best, nd = None, 0
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        u = t.x.unique()
+        dt = time.perf_counter() - t0
+        nd = len(u); best = dt if best is None else min(best, dt)
+    res["unique"] = {"rows": n, "distinct": nd, "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
+                     "what": "unique(t.x) over Int64 h mod 1e6: hash table of first occurrences in HBM, distinct values fetched to the host in order of first appearance; best of 3"}
+    t.close()
+    # ---- groupreduce by a String key, flat and with the dictionary
+    n = int(500_000_000 * sc)
+    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+    t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(0), n, row_first=rank * n)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(1), n, row_first=rank * n)
+    for key in ("groupreduce", "groupreduce_dictionary"):
+        if key.endswith("dictionary"):
+            t.build_dictionary("s")
+        best, g = None, None
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            g = dfdb.groupreduce(t, "s", "a", "sum")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        byts = n * (4 + 5.4 + 8) if key == "groupreduce" else n * (2 + 8)
+        res[key] = {"rows": n, "groups": len(g), "seconds": best, "rows_per_s": n / best,
+                    "roofline": {"bound": "hbm", "achieved": byts / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": byts / best / 1e9 / L.peak},
+                    "what": "groupreduce(t, (:s,); out = :a => Sum()) by a 10-value String key over Int64 values; bytes = key column (flat sizes + bytes, or 2-byte codes) + value column"}
+    t.close()
+    # ---- Union{String,Missing} equality at config 4's size
+    t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+    t.add_generated("s", dfdb.GEN_STR_BRANDS10_MISSING, seed_of(0), n, row_first=rank * n)
+    t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(1), n, row_first=rank * n)
+    q = t[ir.coalesce(ir.col(0) == "sony", False), dfdb.ALL]._query()
+    nsel = q.count()
+    qm = t[ir.ismissing(ir.col(0)), dfdb.ALL]._query()
+    nmiss = qm.count()
+
+    def step():
+        q.reset(); q.execute()
+    ctx.set_option("jit", 2)                                   # steady state: the program's compiled kernel (the default compiles it in the background)
+    try:
+        sec, ks = L.timed(step)
+    finally:
+        ctx.set_option("jit", 1)
+    lbar = 5.4 * 7 / 8
+    res["nullable_string_eq"] = L.record(n, nsel, sec, ks, n * (4 + lbar + 0.125), 's: Union{String,Missing} (one row in eight missing), coalesce(s == "sony", false) -> mask; '
+                                         "three-valued comparison in the interpreter / its compiled kernel", missing_rows=nmiss)
     t.close()
     return res
 
@@ -610,9 +726,11 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
 
 def run_config_legs(L, dfdb, G, args, rank, local, stream, grp, out):
     sc = args.config_scale
-    legs = [("3", lambda: {"3": config3_leg(L, dfdb, int(1_000_000_000 * sc), rank)}),
+    legs = [("3", lambda: config3_leg(L, dfdb, int(1_000_000_000 * sc), rank)),
             ("4", lambda: config4_legs(L, dfdb, int(500_000_000 * sc), rank)),
-            ("5_shard", lambda: config5_legs(L, dfdb, G, int(1_250_000_000 * sc), rank, local, stream, grp, args.config5_host_shards))]
+            ("5_shard", lambda: config5_legs(L, dfdb, G, int(1_250_000_000 * sc), rank, local, stream, grp, args.config5_host_shards)),
+            ("interp", lambda: {"interp": interp_leg(L, dfdb, int(1_000_000_000 * sc), rank)}),
+            ("f_rows", lambda: f_rows_legs(L, dfdb, sc, rank))]
     for name, fn in legs:
         try:
             out.update(fn())
@@ -631,7 +749,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the decode-inclusive extra figure (N = 1 only)")
     ap.add_argument("--no-cold", action="store_true", help="skip the non-resident (open_table / block-streamed) extra figures (N = 1 only)")
-    ap.add_argument("--cold-rows", type=int, default=500_000_000, help="rows of the three-column table the `cold` leg writes to /dev/shm and streams")
+    ap.add_argument("--cold-rows", type=int, default=1_000_000_000, help="rows of the three-column table the `cold` leg writes to /dev/shm and streams")
     ap.add_argument("--cold-chunk-blocks", type=int, default=1024)
     ap.add_argument("--placement", action="store_true", help="also measure the step with the opt-in placement calibration (ctx option placement_calibrate = 1) and report it as the "
                     "extra key `calibrated_config`; `value` is always the library-default configuration")

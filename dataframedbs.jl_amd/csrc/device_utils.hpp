@@ -1,7 +1,9 @@
 // device_utils.hpp — wave64 helpers shared by the gfx950 kernels (no CUDA/other-arch paths).
 #pragma once
+#ifndef __HIPCC_RTC__            // (hipRTC brings the HIP device runtime and the fixed-width integer types itself: jit.cpp compiles this header at run time)
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#endif
 
 namespace dfdb {
 

@@ -154,6 +154,17 @@ void table_decode_staged_blocks(dfdb_table* t, int32_t ordinal, const StagedBloc
 // survivors of the query's current execution per block of `block_size` rows (query.cpp; synchronises)
 void query_block_counts(dfdb_query* q, int64_t block_size, std::vector<int64_t>& counts);
 
+// jit.cpp: the interpreter's source compiled by hipRTC for one program shape (everything below is a literal of the generated kernel = the cache key)
+struct JitShape {
+  int mode = 0, str = 0, nul = 0, and_existing = 0, stack_levels = 0, result_dtype = 0, nstr = 0;
+  std::vector<uint32_t> w0, w1, w2; std::vector<int32_t> slot, aslot, col_dtype;
+  int32_t str_slot[4] = {0, 0, 0, 0};
+};
+struct JitKernel;
+std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait);
+bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, void** args);
+void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending);
+
 void query_add_stage(dfdb_query* q, Stage&& s);   // composition rules of selection.jl:39-49
 void query_execute(dfdb_query* q, int nstages);   // evaluate stages [0, nstages) -> bitmap + counts + prefix
 int64_t query_count(dfdb_query* q, int nstages);

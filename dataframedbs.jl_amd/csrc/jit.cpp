@@ -1,0 +1,254 @@
+// jit.cpp — expression kernels compiled at run time by hipRTC: the second tier of the interpreter.
+//
+// The reference never interprets a predicate: `BlockBroadcasting` hands Julia's compiler a fused broadcast per (function, argument types) and runs the
+// machine code (src/tables/broadcast.jl:60-68; the block iterator even `precompile`s its executors, src/io/blocksiterator.jl:42).  Ahead-of-time HIP
+// cannot do that, so an expression outside the specialised scan kernels starts in the device interpreter (k_interp.hip): no waiting, ~0.5 of the HBM
+// peak for four or more instructions because every instruction is a wave-uniform decode + branch on the CU's one scalar unit.  Meanwhile this file
+// compiles THE SAME SOURCE (k_interp_device.inc + k_interp_step.inc + k_interp_handlers.inc, embedded in the library at build time) for that one
+// program shape — handler ids, operand sources, conversions, wrap widths, column slots and dtypes become literals, the dispatch loop becomes
+// straight-line code — on a background thread; executions of the same shape use the compiled kernel as soon as it exists.  Constants of the expression
+// (`x > 5` vs `x > 6`), pattern bytes and set members stay run-time data read from the program image, so they share one kernel.
+//   ctx option "jit": 0 = never, 1 = in the background (default), 2 = wait for the compiler (tests, benchmarks)
+//   ctx option "jit_min_rows": tables smaller than this are left to the interpreter (default 2^22 rows: below that a launch is microseconds either way)
+// hipRTC is loaded lazily (dlopen); without it — or if a compile fails — the interpreter simply stays in charge: same results, its speed.
+#include "engine.hpp"
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+namespace dfdb {
+
+// the interpreter's device source, as text (Makefile: build/jit_embed.inc from the four files themselves)
+#include "build/jit_embed.inc"
+
+namespace {
+struct Rtc {
+  void* h = nullptr;
+  hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+  hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char**) = nullptr;
+  hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+  hiprtcResult (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+  hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+  hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
+  hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+  bool ok = false;
+};
+Rtc& rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.h) break;
+    }
+    if (!r.h) return;
+    auto sym = [&](const char* n) { return dlsym(r.h, n); };
+    r.CreateProgram = (decltype(r.CreateProgram))sym("hiprtcCreateProgram");
+    r.CompileProgram = (decltype(r.CompileProgram))sym("hiprtcCompileProgram");
+    r.GetProgramLogSize = (decltype(r.GetProgramLogSize))sym("hiprtcGetProgramLogSize");
+    r.GetProgramLog = (decltype(r.GetProgramLog))sym("hiprtcGetProgramLog");
+    r.GetCodeSize = (decltype(r.GetCodeSize))sym("hiprtcGetCodeSize");
+    r.GetCode = (decltype(r.GetCode))sym("hiprtcGetCode");
+    r.DestroyProgram = (decltype(r.DestroyProgram))sym("hiprtcDestroyProgram");
+    r.ok = r.CreateProgram && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog && r.GetCodeSize && r.GetCode && r.DestroyProgram;
+  });
+  return r;
+}
+
+void table_fn(std::string& s, const char* type, const char* name, const std::vector<int64_t>& v, bool hex) {
+  char buf[96];
+  s += "__device__ constexpr "; s += type; s += " "; s += name; s += "(int i) {\n  switch (i) {\n";
+  for (size_t i = 0; i < v.size(); i++) {
+    if (hex) snprintf(buf, sizeof buf, "    case %zu: return 0x%llxu;\n", i, (unsigned long long)(uint32_t)v[i]);
+    else snprintf(buf, sizeof buf, "    case %zu: return %lld;\n", i, (long long)v[i]);
+    s += buf;
+  }
+  s += "  }\n  return 0;\n}\n";
+}
+}  // namespace
+
+struct JitKernel {
+  std::string key, source, log;
+  std::vector<char> code;
+  std::atomic<int> state{0};                   // 0: queued / compiling, 1: ready, -1: failed
+  double compile_ms = 0;
+  std::mutex mu;                               // guards `loaded`
+  std::unordered_map<int, hipFunction_t> loaded;   // device -> function (one module per device, kept for the life of the process)
+};
+
+namespace {
+struct JitCache {
+  std::mutex mu; std::condition_variable cv;
+  std::unordered_map<std::string, std::shared_ptr<JitKernel>> map;
+  std::deque<std::shared_ptr<JitKernel>> queue;
+  std::thread worker; bool started = false;
+  std::atomic<int64_t> compiled{0}, failed{0};
+};
+JitCache& cache() { static JitCache* c = new JitCache; return *c; }   // (leaked on purpose: the worker may outlive static destruction)
+
+void compile_one(JitKernel& k, const std::string& arch) {
+  Rtc& r = rtc();
+  const auto t0 = std::chrono::steady_clock::now();
+  hiprtcProgram prog = nullptr;
+  const char* headers[] = {src_device_utils_hpp, src_k_interp_handlers_inc, src_k_interp_step_inc, src_k_interp_device_inc, src_dfdb_ir_h, nullptr};
+  const char* names[] = {"device_utils.hpp", "k_interp_handlers.inc", "k_interp_step.inc", "k_interp_device.inc", "dfdb_ir.h", "jit_steps.inc"};
+  // the per-program include (`#define PC n / #include "k_interp_step.inc"` for every instruction) travels at the front of the source, up to a marker line
+  const size_t cut = k.source.find("//@@STEPS-END\n");
+  const std::string steps = k.source.substr(0, cut), main_src = k.source.substr(cut + 14);
+  headers[5] = steps.c_str();
+  if (r.CreateProgram(&prog, main_src.c_str(), "dfdb_jit.hip", 6, headers, names) != HIPRTC_SUCCESS) { k.log = "hiprtcCreateProgram failed"; k.state = -1; return; }
+  const std::string archopt = "--offload-arch=" + arch;
+  // -ffp-contract=off: the engine's floating-point results are Julia's, operation by operation (the library itself is built with it, see the Makefile)
+  const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed"};
+  const hiprtcResult rc = r.CompileProgram(prog, 5, opts);
+  size_t n = 0;
+  if (r.GetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { k.log.resize(n); r.GetProgramLog(prog, &k.log[0]); }
+  if (rc == HIPRTC_SUCCESS && r.GetCodeSize(prog, &n) == HIPRTC_SUCCESS && n > 0) {
+    k.code.resize(n);
+    if (r.GetCode(prog, k.code.data()) != HIPRTC_SUCCESS) k.code.clear();
+  }
+  r.DestroyProgram(&prog);
+  k.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (k.code.empty()) {
+    if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] compile FAILED (%.0f ms) for %s:\n%s\n", k.compile_ms, k.key.c_str(), k.log.c_str());
+    cache().failed++; k.state = -1; return;
+  }
+  if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] compiled %zu bytes in %.0f ms: %s\n", k.code.size(), k.compile_ms, k.key.c_str());
+  cache().compiled++; k.state = 1;
+}
+
+void worker_main(std::string arch) {
+  JitCache& c = cache();
+  for (;;) {
+    std::shared_ptr<JitKernel> k;
+    {
+      std::unique_lock<std::mutex> lk(c.mu);
+      c.cv.wait(lk, [&] { return !c.queue.empty(); });
+      k = c.queue.front(); c.queue.pop_front();
+    }
+    compile_one(*k, arch);
+    c.cv.notify_all();
+  }
+}
+}  // namespace
+
+// the kernel for this program shape: ready, or nullptr (still compiling, hipRTC missing, or the compile failed).  wait = true blocks until the compiler is done.
+std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait) {
+  if (!rtc().ok) return nullptr;
+  // ---- the key: every literal of the generated source
+  std::string key;
+  {
+    char b[64];
+    snprintf(b, sizeof b, "m%d s%d n%d a%d l%d r%d t%d|", sh.mode, sh.str, sh.nul, sh.and_existing, sh.stack_levels, sh.result_dtype, sh.nstr); key += b;
+    for (size_t i = 0; i < sh.w0.size(); i++) { snprintf(b, sizeof b, "%x.%x.%x.%d.%d;", sh.w0[i], sh.w1[i], sh.w2[i], sh.slot[i], sh.aslot[i]); key += b; }
+    key += "|";
+    for (int32_t d : sh.col_dtype) { snprintf(b, sizeof b, "%x,", d); key += b; }
+    key += "|";
+    for (int i = 0; i < sh.nstr; i++) { snprintf(b, sizeof b, "%d,", sh.str_slot[i]); key += b; }
+  }
+  JitCache& c = cache();
+  std::shared_ptr<JitKernel> k;
+  {
+    std::unique_lock<std::mutex> lk(c.mu);
+    auto it = c.map.find(key);
+    if (it != c.map.end()) k = it->second;
+    else {
+      k = std::make_shared<JitKernel>();
+      k->key = key;
+      // ---- the source
+      std::string s;
+      char b[160];
+      // a column slot that more than one instruction loads (as the fused A operand: aslot - 1, or as a B_COL operand: slot with bsrc == 2) is loaded once and
+      // kept: the first loader saves into jcN, the later ones copy from it.  String columns are read by their own handlers, not through these loads.
+      std::vector<int> uses(sh.col_dtype.size(), 0), seen(sh.col_dtype.size(), 0);
+      for (size_t i = 0; i < sh.w0.size(); i++) {
+        if (sh.aslot[i] > 0 && (size_t)(sh.aslot[i] - 1) < uses.size()) uses[(size_t)sh.aslot[i] - 1]++;
+        if (((sh.w0[i] >> 8) & 0xff) == 2 && sh.slot[i] >= 0 && (size_t)sh.slot[i] < uses.size()) uses[(size_t)sh.slot[i]]++;
+      }
+      std::string decls;
+      for (size_t c = 0; c < uses.size(); c++) if (uses[c] >= 2) { snprintf(b, sizeof b, "uint64_t jc%zu[kW]; ", c); decls += b; }
+      for (size_t i = 0; i < sh.w0.size(); i++) {
+        std::string pre, post;
+        auto mark = [&](int col, const char* which) {
+          if (col < 0 || (size_t)col >= uses.size() || uses[(size_t)col] < 2) return;
+          snprintf(b, sizeof b, "#define JIT_%s_%s jc%d\n", which, seen[(size_t)col] ? "FROM" : "SAVE", col); pre += b;
+          snprintf(b, sizeof b, "#undef JIT_%s_%s\n", which, seen[(size_t)col] ? "FROM" : "SAVE"); post += b;
+          seen[(size_t)col] = 1;
+        };
+        if (sh.aslot[i] > 0) mark(sh.aslot[i] - 1, "A");            // (the A load comes first inside a step)
+        if (((sh.w0[i] >> 8) & 0xff) == 2) mark(sh.slot[i], "B");
+        snprintf(b, sizeof b, "#define PC %zu\n{\n#include \"k_interp_step.inc\"\n}\n#undef PC\n", i);
+        s += pre; s += b; s += post;
+      }
+      s += "//@@STEPS-END\n";
+      s += "#define JIT_CACHE_DECLS " + decls + "\n";
+      snprintf(b, sizeof b, "#define DFDB_JIT 1\n#define DFDB_JIT_AND_EXISTING %d\n#define DFDB_JIT_STACK_LEVELS %d\n#define DFDB_JIT_RESULT_DTYPE %d\n#define DFDB_JIT_NSTR %d\n",
+               sh.and_existing, sh.stack_levels, sh.result_dtype, sh.nstr); s += b;
+      // hipRTC keeps the fixed-width integer types in a namespace of its own: name them as <cstdint> does on this ABI (int64_t is long)
+      s += "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t;\n"
+           "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
+           "typedef unsigned long uintptr_t;\n";
+      s += "#ifndef INT64_MIN\n#define INT64_MIN (-9223372036854775807L - 1)\n#endif\n";
+      s += "#include \"dfdb_ir.h\"\n#include \"device_utils.hpp\"\n";
+      std::vector<int64_t> v;
+      auto tab = [&](const char* type, const char* name, auto&& src, bool hex) { v.clear(); for (auto x : src) v.push_back((int64_t)x); table_fn(s, type, name, v, hex); };
+      tab("unsigned", "jit_w0", sh.w0, true); tab("unsigned", "jit_w1", sh.w1, true); tab("unsigned", "jit_w2", sh.w2, true);
+      tab("int", "jit_slot", sh.slot, false); tab("int", "jit_aslot", sh.aslot, false); tab("int", "jit_col_dtype", sh.col_dtype, false);
+      { std::vector<int32_t> ss(sh.str_slot, sh.str_slot + 4); tab("int", "jit_str_slot", ss, false); }
+      s += "namespace dfdb {\n#include \"k_interp_device.inc\"\n}\n";
+      snprintf(b, sizeof b, "  dfdb::interp_body<%d, %s, %s>(prog, bitmap, tile_counts, prefix, out, out_cap, nrows, ntiles, and_existing, err, stack_levels, out_missing);\n",
+               sh.mode, sh.str ? "true" : "false", sh.nul ? "true" : "false");
+      s += "extern \"C\" __global__ __launch_bounds__(256) void dfdb_jit_kernel(const dfdb::IProgram* __restrict__ prog, uint64_t* __restrict__ bitmap,\n"
+           "    uint32_t* __restrict__ tile_counts, const uint64_t* __restrict__ prefix, void* __restrict__ out, int64_t out_cap, int64_t nrows, int64_t ntiles,\n"
+           "    int and_existing, int* __restrict__ err, int stack_levels, uint8_t* __restrict__ out_missing) {\n";
+      s += b;
+      s += "}\n";
+      k->source = std::move(s);
+      c.map.emplace(key, k);
+      c.queue.push_back(k);
+      if (!c.started) { c.started = true; c.worker = std::thread(worker_main, std::string(ctx->prop.gcnArchName)); c.worker.detach(); }
+      c.cv.notify_all();
+    }
+    if (wait) c.cv.wait(lk, [&] { return k->state.load() != 0; });
+  }
+  return k->state.load() == 1 ? k : nullptr;
+}
+
+// launch on ctx's stream; the module is loaded on this device the first time the kernel is used there.  false: the module could not be loaded (the caller interprets)
+bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, void** args) {
+  hipFunction_t fn = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(k.mu);
+    auto it = k.loaded.find(ctx->device);
+    if (it != k.loaded.end()) fn = it->second;
+    else {
+      hipModule_t mod = nullptr;
+      if (hipModuleLoadData(&mod, k.code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "dfdb_jit_kernel") != hipSuccess) {
+        (void)hipGetLastError();
+        k.loaded.emplace(ctx->device, nullptr);
+        return false;
+      }
+      k.loaded.emplace(ctx->device, fn);
+    }
+  }
+  if (!fn) return false;
+  HIP_CHECK(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+  return true;
+}
+
+void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending) {
+  JitCache& c = cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (compiled) *compiled = c.compiled.load();
+  if (failed) *failed = c.failed.load();
+  if (pending) *pending = (int64_t)c.queue.size();
+}
+const char* jit_source_of(JitKernel& k) { return k.source.c_str(); }
+const char* jit_log_of(JitKernel& k) { return k.log.c_str(); }
+
+}  // namespace dfdb

@@ -28,9 +28,13 @@ __global__ __launch_bounds__(kBlock) void k_gen_f64_u2000(double* __restrict__ o
 __constant__ char k_brands[10][10] = {"apple", "samsung", "huawei", "microsoft", "dell", "xbox", "sony", "intel", "lenovo", "asus"};
 __constant__ int k_brand_len[10] = {5, 7, 6, 9, 4, 4, 4, 5, 6, 4};
 
-__global__ __launch_bounds__(kBlock) void k_gen_brand_sizes(int32_t* __restrict__ sizes, uint64_t seed, int64_t row_first, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    sizes[i] = k_brand_len[splitmix64(seed + (uint64_t)(row_first + i)) % 10ull];
+// with_missing: Union{String,Missing} — the row is missing (size -1, no bytes) when (h >> 32) mod 8 == 7: one row in eight, like the docs' real data set whose
+// columns are all Union{Missing,String} (docs/src/index.md:264-272)
+__global__ __launch_bounds__(kBlock) void k_gen_brand_sizes(int32_t* __restrict__ sizes, uint64_t seed, int64_t row_first, int64_t n, int with_missing) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint64_t h = splitmix64(seed + (uint64_t)(row_first + i));
+    sizes[i] = (with_missing && ((h >> 32) & 7ull) == 7ull) ? -1 : k_brand_len[h % 10ull];
+  }
 }
 
 // one wave per 1024-row string tile: running byte offset = tile_off[tile] + in-tile prefix of sizes
@@ -44,7 +48,8 @@ __global__ __launch_bounds__(kBlock) void k_gen_brand_bytes(const int32_t* __res
     int64_t run = tile_off[tile];
     for (int j = 0; j < 16; j++) {
       const int64_t i = tile * 1024 + j * 64 + lane;
-      const uint32_t sz = i < n ? (uint32_t)sizes[i] : 0u;
+      const int32_t raw = i < n ? sizes[i] : 0;
+      const uint32_t sz = raw > 0 ? (uint32_t)raw : 0u;                        // (-1 = missing: no bytes)
       const uint32_t incl = wave_incl_scan(sz);
       if (i < n) {
         const int b = (int)(splitmix64(seed + (uint64_t)(row_first + i)) % 10ull);
@@ -65,8 +70,8 @@ void launch_gen_i64_iota(hipStream_t s, int64_t* out, int64_t row_first, int64_t
 void launch_gen_f64_u2000(hipStream_t s, double* out, uint64_t seed, int64_t row_first, int64_t n) {
   if (n > 0) hipLaunchKernelGGL(k_gen_f64_u2000, dim3(gen_grid(n)), dim3(kBlock), 0, s, out, seed, row_first, n);
 }
-void launch_gen_brand_sizes(hipStream_t s, int32_t* sizes, uint64_t seed, int64_t row_first, int64_t n) {
-  if (n > 0) hipLaunchKernelGGL(k_gen_brand_sizes, dim3(gen_grid(n)), dim3(kBlock), 0, s, sizes, seed, row_first, n);
+void launch_gen_brand_sizes(hipStream_t s, int32_t* sizes, uint64_t seed, int64_t row_first, int64_t n, bool with_missing) {
+  if (n > 0) hipLaunchKernelGGL(k_gen_brand_sizes, dim3(gen_grid(n)), dim3(kBlock), 0, s, sizes, seed, row_first, n, with_missing ? 1 : 0);
 }
 void launch_gen_brand_bytes(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, uint8_t* bytes, uint64_t seed, int64_t row_first,
                             int64_t n) {

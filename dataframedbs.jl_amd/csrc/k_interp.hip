@@ -322,7 +322,31 @@ static void run_interp(dfdb_query* q, const Node& root, int mode, bool and_exist
   int64_t grid = ceil_div(ntiles, kWavesPerBlock); if (grid > 16384) grid = 16384;
   int* derr = (int*)(db.as<uint8_t>() + err_off);
   const size_t lds_bytes = (size_t)(c.max_sp + c.prog.nstr) * kW * kBlock * sizeof(uint64_t) + (c.nul ? (size_t)c.max_sp * kW * kBlock * sizeof(uint32_t) : 0);
-  {
+  // the second tier (jit.cpp): this program shape compiled by hipRTC from the interpreter's own source — used as soon as the compiler is done with it
+  std::shared_ptr<JitKernel> jk;
+  const int64_t jit_mode = ctx_option(ctx, "jit", 1);
+  if (jit_mode > 0 && t->nrows >= ctx_option(ctx, "jit_min_rows", (int64_t)1 << 22)) {
+    JitShape sh;
+    sh.mode = mode; sh.str = c.prog.nstr > 0; sh.nul = c.nul; sh.and_existing = mode == 0 ? (and_existing ? 1 : 0) : 1; sh.stack_levels = c.max_sp;
+    sh.result_dtype = c.prog.result_dtype; sh.nstr = c.prog.nstr;
+    for (int i = 0; i < c.prog.n; i++) {
+      const DInstr& d = c.prog.ins[i];
+      sh.w0.push_back(d.w0); sh.w1.push_back(d.w1); sh.w2.push_back(d.w2); sh.slot.push_back(d.slot); sh.aslot.push_back(d.aslot);
+    }
+    for (int i = 0; i < c.prog.ncols; i++) sh.col_dtype.push_back(c.prog.cols[i].dtype);
+    for (int i = 0; i < 4; i++) sh.str_slot[i] = c.prog.str_slot[i];
+    jk = jit_request(ctx, sh, jit_mode >= 2);
+  }
+  bool launched = false;
+  if (jk) {
+    const IProgram* a_prog = (const IProgram*)db.p; uint64_t* a_bm = q->bitmap.as<uint64_t>(); uint32_t* a_tc = q->tile_counts.as<uint32_t>();
+    const uint64_t* a_px = q->prefix.as<uint64_t>(); void* a_out = out; int64_t a_cap = cap, a_nrows = t->nrows, a_nt = ntiles;
+    int a_ae = mode == 0 ? (and_existing ? 1 : 0) : 1, a_sl = c.max_sp; int* a_err = derr; uint8_t* a_om = out_missing;
+    void* args[] = {&a_prog, &a_bm, &a_tc, &a_px, &a_out, &a_cap, &a_nrows, &a_nt, &a_ae, &a_err, &a_sl, &a_om};
+    LaunchTimer lt(ctx, mode == 0 ? "jit_predicate" : "jit_project");
+    launched = jit_launch(*jk, ctx, (unsigned)grid, lds_bytes, args);
+  }
+  if (!launched) {
     LaunchTimer lt(ctx, mode == 0 ? "interp_predicate" : "interp_project");
     const bool str = c.prog.nstr > 0;
 #define DFDB_INTERP_LAUNCH(M, S, NL, AE)                                                                                                        \

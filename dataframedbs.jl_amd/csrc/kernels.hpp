@@ -92,7 +92,7 @@ void launch_gather_bits(hipStream_t s, const uint64_t* bitmap, const uint64_t* p
 void launch_gen_i64_mod1m(hipStream_t s, int64_t* out, uint64_t seed, int64_t row_first, int64_t n);
 void launch_gen_i64_iota(hipStream_t s, int64_t* out, int64_t row_first, int64_t n);
 void launch_gen_f64_u2000(hipStream_t s, double* out, uint64_t seed, int64_t row_first, int64_t n);
-void launch_gen_brand_sizes(hipStream_t s, int32_t* sizes, uint64_t seed, int64_t row_first, int64_t n);
+void launch_gen_brand_sizes(hipStream_t s, int32_t* sizes, uint64_t seed, int64_t row_first, int64_t n, bool with_missing = false);
 void launch_gen_brand_bytes(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, uint8_t* bytes, uint64_t seed,
                             int64_t row_first, int64_t n);
 

@@ -173,7 +173,7 @@ void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t 
   if (nrows < 0) fail(DFDB_ERR_ARGUMENT, "negative row count");
   if (t->nrows >= 0 && t->nrows != nrows)
     fail(DFDB_ERR_ARGUMENT, "column has %lld rows but the table holds %lld resident rows", (long long)nrows, (long long)t->nrows);
-  if (gen < DFDB_GEN_I64_MOD1M || gen > DFDB_GEN_I64_IOTA) fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
+  if (gen < DFDB_GEN_I64_MOD1M || gen > DFDB_GEN_STR_BRANDS10_MISSING) fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);
   for (auto& c : t->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
   struct Rollback { dfdb_table* t; size_t n; int64_t rows; bool armed = true; ~Rollback() { if (armed) { t->cols.resize(n); t->nrows = rows; } } } rb{t, t->cols.size(), t->nrows};
   set_table_rows(t, nrows);
@@ -192,10 +192,11 @@ void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t 
       launch_gen_f64_u2000(s, c.data.as<double>(), seed, row_first, nrows);
       c.resident = true; break;
     }
-    case DFDB_GEN_STR_BRANDS10: {
-      Column& c = new_column(t, name, DFDB_STRING); c.nrows = nrows;
+    case DFDB_GEN_STR_BRANDS10: case DFDB_GEN_STR_BRANDS10_MISSING: {
+      const bool wm = gen == DFDB_GEN_STR_BRANDS10_MISSING;
+      Column& c = new_column(t, name, wm ? (DFDB_STRING | DFDB_NULLABLE) : DFDB_STRING); c.nrows = nrows;
       c.data.ensure((size_t)nrows * 4 + 256);
-      launch_gen_brand_sizes(s, c.data.as<int32_t>(), seed, row_first, nrows);
+      launch_gen_brand_sizes(s, c.data.as<int32_t>(), seed, row_first, nrows, wm);
       set_string_tile_offsets(t->ctx, c);
       const int64_t ntiles = ceil_div(nrows, kStrTileRows);
       uint64_t total = 0;
@@ -205,7 +206,7 @@ void table_add_generated(dfdb_table* t, const char* name, int32_t gen, uint64_t 
       HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + total, 0, 64, s));
       launch_gen_brand_bytes(s, c.data.as<int32_t>(), (const int64_t*)c.tile_off.p, c.bytes.as<uint8_t>(), seed, row_first, nrows);
       c.resident = true;
-      if (const int64_t dn = ctx_option(t->ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(t->cols.size() - 1), dn);
+      if (!wm) if (const int64_t dn = ctx_option(t->ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(t->cols.size() - 1), dn);
       break;
     }
     default: fail(DFDB_ERR_ARGUMENT, "unknown generator %d", gen);

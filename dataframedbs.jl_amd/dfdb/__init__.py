@@ -5,7 +5,7 @@ this package only mirrors the reference's lazy DFTable / DFView / DFColumn algeb
 expression IR.  Importing the package does not need a GPU; creating a Context does.
 """
 from . import ir
-from ._native import (AGG_COUNT, AGG_MAX, AGG_MIN, AGG_SUM, GEN_F64_U2000, GEN_I64_IOTA, GEN_I64_MOD1M, GEN_STR_BRANDS10,
+from ._native import (AGG_COUNT, AGG_MAX, AGG_MIN, AGG_SUM, GEN_F64_U2000, GEN_I64_IOTA, GEN_I64_MOD1M, GEN_STR_BRANDS10, GEN_STR_BRANDS10_MISSING,
                       LIB_PATH, MEM_DEVICE, MEM_HOST, SYMBOLS, DfdbError, load)
 from .api import (ALL, END, groupreduce, ColumnMeta, Context, DFColumn, DFTable, DFView, JRange, Projection, SelectionQueue, coalesce, col_equal,
                   create_table, default_context, endswith, float64, head, isin, ismissing, issameselection, jr, map_to_column, materialize,

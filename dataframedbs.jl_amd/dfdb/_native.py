@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_PKG), "libdfdb_hip.so")
 # status codes -> the Python exception standing in for the Julia one (include/dfdb.h)
 OK, ERR_ARGUMENT, ERR_IO, ERR_FORMAT, ERR_KEY, ERR_BOUNDS, ERR_DIVIDE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = range(10)
 MEM_HOST, MEM_DEVICE = 0, 1
-GEN_I64_MOD1M, GEN_F64_U2000, GEN_STR_BRANDS10, GEN_I64_IOTA = 1, 2, 3, 4
+GEN_I64_MOD1M, GEN_F64_U2000, GEN_STR_BRANDS10, GEN_I64_IOTA, GEN_STR_BRANDS10_MISSING = 1, 2, 3, 4, 5
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2, 3
 
 

@@ -51,7 +51,9 @@ enum {
   DFDB_GEN_I64_MOD1M = 1,   /* Int64   : h mod 1 000 000 */
   DFDB_GEN_F64_U2000 = 2,   /* Float64 : (h >> 11) * 2^-53 * 2000.0 */
   DFDB_GEN_STR_BRANDS10 = 3,/* String  : brands10[h mod 10] */
-  DFDB_GEN_I64_IOTA = 4     /* Int64   : i + 1  (the reference tests' 1:N columns) */
+  DFDB_GEN_I64_IOTA = 4,    /* Int64   : i + 1  (the reference tests' 1:N columns) */
+  DFDB_GEN_STR_BRANDS10_MISSING = 5 /* Union{String,Missing} : missing when (h >> 32) mod 8 == 7, else brands10[h mod 10] (docs/src/index.md:264-272: the
+                               docs' real data set is all Union{Missing,String}) */
 };
 
 /* aggregates over a filtered view (Base.iterate(::DFColumn) column.jl:102-126) */

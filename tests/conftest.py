@@ -32,4 +32,8 @@ def dfdb_mod():
 def ctx(dfdb_mod):
     """One engine context on cuda:0 for the whole GPU session.  Fails loudly without the HIP library / a GPU."""
     import torch  # noqa: F401  torch's bundled HIP runtime must be the one loaded first when both live in a process
-    return dfdb_mod.default_context(0)
+    c = dfdb_mod.default_context(0)
+    if os.environ.get("DFDB_TEST_JIT") == "1":       # soak: every interpreter program of every test runs as its hipRTC-compiled kernel (0.2-0.4 s per new shape)
+        c.set_option("jit", 2)
+        c.set_option("jit_min_rows", 0)
+    return c
