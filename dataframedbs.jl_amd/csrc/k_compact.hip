@@ -305,8 +305,12 @@ void launch_gather_transform(hipStream_t s, const uint64_t* bitmap, const uint64
 
 // projection of a predicate column whose selected values the scan already wrote per tile (k_scan_cmp / k_scan_terms CAP):
 // one wave per 4096-row ctile = 4 capture tiles; every lane finds its tile from the 5 prefix values and copies
+// XF: the captured values are those of an 8-byte column of type T and the output is a transform of them (transform_value: `x * 2` over a filtered view whose
+// predicate already read x — the computed projection rides on the capture instead of on a second gather of the column)
+template <bool XF, typename T>
 __global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __restrict__ cap, const uint64_t* __restrict__ prefix,
-                                                             uint64_t* __restrict__ out, int64_t nctiles, int64_t ntiles, int64_t out_cap) {
+                                                             uint64_t* __restrict__ out, int64_t nctiles, int64_t ntiles, int64_t out_cap,
+                                                             int pre, uint64_t magic, int shift, uint64_t dd) {
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -329,7 +333,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __r
       for (int u = 0; u < 4; u++) {
         const uint32_t k = k0 + (uint32_t)u * 64 + lane;
         const int64_t o = (int64_t)pf[0] + k;
-        if (k < total && o < out_cap) out[o] = v[u];
+        if (k < total && o < out_cap) {
+          if (XF) { T x; __builtin_memcpy(&x, &v[u], 8); out[o] = transform_value<T>(x, pre, magic, shift, dd); }
+          else out[o] = v[u];
+        }
       }
     }
   }
@@ -337,7 +344,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __r
 void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap) {
   const int64_t nct = (nrows + kCTile - 1) / kCTile, nt = (nrows + 1023) / 1024;
   if (nct == 0) return;
-  hipLaunchKernelGGL(k_compact_captured, dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, cap, prefix, out, nct, nt, out_cap);
+  hipLaunchKernelGGL((k_compact_captured<false, uint64_t>), dim3(grid_for_ctiles(nct)), dim3(kBlock), 0, s, cap, prefix, out, nct, nt, out_cap, 0, 0ull, 0, 0ull);
+}
+void launch_compact_captured_transform(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, int32_t src_dtype, const ScanTerm& tf, uint64_t* out, int64_t nrows, int64_t out_cap) {
+  const int64_t nct = (nrows + kCTile - 1) / kCTile, nt = (nrows + 1023) / 1024;
+  if (nct == 0) return;
+  const dim3 g(grid_for_ctiles(nct)), b(kBlock);
+  if (src_dtype == DFDB_F64) hipLaunchKernelGGL((k_compact_captured<true, double>), g, b, 0, s, cap, prefix, out, nct, nt, out_cap, (int)tf.pre, tf.pre_magic, (int)tf.pre_shift, tf.pre_d);
+  else if (src_dtype == DFDB_U64) hipLaunchKernelGGL((k_compact_captured<true, uint64_t>), g, b, 0, s, cap, prefix, out, nct, nt, out_cap, (int)tf.pre, tf.pre_magic, (int)tf.pre_shift, tf.pre_d);
+  else hipLaunchKernelGGL((k_compact_captured<true, int64_t>), g, b, 0, s, cap, prefix, out, nct, nt, out_cap, (int)tf.pre, tf.pre_magic, (int)tf.pre_shift, tf.pre_d);
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather_bits(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,

@@ -132,8 +132,17 @@ __device__ __forceinline__ T wave_incl_scan_max(T x, uint32_t lane) {
   return x;
 }
 
+// near_limit > 0 (ctx option "lz4_enc_near", e.g. 1984 = what K7 keeps on chip behind its read position; default 0 = off): a match whose source lies further
+// back than that costs the decoder a 128-byte line fetch from HBM for a few bytes (K7's far slots: 5.2 x the algorithmic traffic on the engine's own files,
+// VERDICT r3).  With the option a FAR hit is given up when one of the next two positions starts a NEAR match that ends at the same place or later: the sequence
+// gets one or two more literals and the decoder copies out of its LDS ring instead.  On 8-byte integer columns the far hits are the ones keyed by
+// (b1, b2, 0, 0) — 4096 keys, one recurrence per 32 KB — while the hit one byte later, keyed by (b2, 0, 0, 0), recurs every 128 bytes; NO nearer source exists
+// for the longer match, so the preference always costs a literal.  Measured on the 1e9-row benchmark column (profiles/r4_lz4_near.txt): ratio 1.761 -> 1.618
+// (- 8 %), indexed decode 628 -> 646 GB/s (+ 3 %), first decode 493 -> 478 GB/s (- 3 %: more compressed bytes to read).  A file travels over PCIe at 45 GB/s
+// before K7 sees it at 500-650, so 8 % more bytes for 3 % faster decoding is the wrong trade for every path that starts on disk: OFF by default, kept for
+// columns that live compressed in HBM and are decoded thousands of times.
 __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                        const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ out_len) {
+                                                        const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ out_len, uint32_t near_limit) {
   __shared__ uint32_t ht[1 << kHashBits];
   const uint32_t lane = (uint32_t)lane_id();
   for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
@@ -164,6 +173,14 @@ __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restric
           ml = capped ? 12u : 4u + ((uint32_t)__builtin_ctzll(x) >> 3);
           const uint32_t lim = matchlimit - p;    // >= 7
           if (ml >= lim) { ml = lim; capped = false; }
+        }
+        if (near_limit) {
+          const bool nearhit = ok && p - cand <= near_limit;
+          const uint32_t e = ok ? lane + ml + (capped ? 64u : 0u) : 0u;         // where the match ends (a capped one goes on: it always wins)
+          const uint32_t nearE = nearhit ? e : 0u;                                 // 0: no near match starts here
+          uint32_t n1 = (uint32_t)__shfl_down((int)nearE, 1, 64), n2 = (uint32_t)__shfl_down((int)nearE, 2, 64);
+          if (lane >= 63u) n1 = 0; if (lane >= 62u) n2 = 0;
+          if (ok && !nearhit && !capped && ((n1 && n1 >= e) || (n2 && n2 >= e))) ok = false;
         }
         const uint64_t M = __ballot(ok);
         if (M == 0) { wave_lds_fence(); if (inr) ht[h] = p; ip += 64; continue; }   // (after every lane has read; several lanes may share h, any of them may win)
@@ -259,12 +276,14 @@ __global__ __launch_bounds__(64) void k_lz4_compress_v2(const uint8_t* __restric
 }
 
 static int g_lz4_enc_variant = 1;
+static uint32_t g_lz4_enc_near = 0;
 void set_lz4_enc_variant(int v) { g_lz4_enc_variant = v; }
+void set_lz4_enc_near(int64_t v) { g_lz4_enc_near = v < 0 ? 0u : (v > 65535 ? 65535u : (uint32_t)v); }
 
 void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* out_len) {
   if (nblocks <= 0) return;
   if (g_lz4_enc_variant == 1) {
-    hipLaunchKernelGGL(k_lz4_compress_v2, dim3((unsigned)nblocks), dim3(64), 0, s, src, dst, blocks, nblocks, out_len);
+    hipLaunchKernelGGL(k_lz4_compress_v2, dim3((unsigned)nblocks), dim3(64), 0, s, src, dst, blocks, nblocks, out_len, g_lz4_enc_near);
     return;
   }
   int64_t grid = ((int64_t)nblocks + kEncWaves - 1) / kEncWaves;

@@ -49,6 +49,8 @@ void launch_scan_terms(hipStream_t s, const ScanTerms& terms, uint64_t* bitmap, 
 bool scan_pair_applies(const ScanTerms& terms, bool and_existing);
 // captured values (per-tile compact) -> the output column: out[prefix[tile] + k] = cap[tile*1024 + k]
 void launch_compact_captured(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, uint64_t* out, int64_t nrows, int64_t out_cap);
+// the same with the transform of launch_gather_transform applied to the captured values (their column's dtype: Int64 / UInt64 / Float64)
+void launch_compact_captured_transform(hipStream_t s, const uint64_t* cap, const uint64_t* prefix, int32_t src_dtype, const ScanTerm& tf, uint64_t* out, int64_t nrows, int64_t out_cap);
 
 // ---- tile-count scan: u32 counts[ntiles] -> u64 prefix[ntiles+1] (prefix[ntiles] = total) -------
 // scratch: >= (ceil(ntiles/4096)+1) * 8 bytes

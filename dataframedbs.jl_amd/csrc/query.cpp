@@ -452,8 +452,15 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
         const int dt = lb.t[k].dtype;
         if ((dt != DFDB_I64 && dt != DFDB_U64 && dt != DFDB_F64) || lb.t[k].pre) continue;
         if (special >= 0 && term_ords[ord0 + (size_t)k] == term_ords[ord0 + (size_t)special]) continue;     // (two terms of one column that did not fold)
-        for (const ProjCol& p : q->proj)
-          if (p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype)) { if (special < 0) { special = k; extra = 1; } else { special2 = k; extra = 5; } break; }
+        for (const ProjCol& p : q->proj) {
+          bool wanted = p.expr->op == DFIR_COL && p.expr->col == term_ords[ord0 + (size_t)k] && !dt_nullable(p.expr->dtype);
+          if (!wanted && p.expr->op != DFIR_COL && dt_width(p.expr->dtype) == 8 && !dt_nullable(p.expr->dtype)) {
+            // a computed column that is a transform of this one column (`x * 2`, `a % 7`, `a * 3 + 1`): it is made from the captured values too
+            ScanTerm tf; const Node* tcol = nullptr;
+            wanted = match_column_transform(p.expr.get(), tf, tcol) && tf.pre != 0 && tcol->col == term_ords[ord0 + (size_t)k] && !dt_nullable(tcol->dtype);
+          }
+          if (wanted) { if (special < 0) { special = k; extra = 1; } else { special2 = k; extra = 5; } break; }
+        }
       }
     }
     if (extra) {                                                     // the special term goes last (and the second captured one before it)
@@ -909,8 +916,13 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
     ScanTerm tf; const Node* tcol = nullptr;
     if (w == 8 && !dt_nullable(e.dtype) && match_column_transform(&e, tf, tcol) && tf.pre != 0 && !dt_nullable(tcol->dtype) && t->cols[(size_t)tcol->col].resident) {
       const Column& sc = t->cols[(size_t)tcol->col];
-      LaunchTimer lt(ctx, "gather");
-      launch_gather_transform(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), sc.data.p, dt_base(sc.dtype), tf, dst, t->nrows, cnt);
+      if ((q->cap_col == tcol->col || q->cap_col2 == tcol->col) && dt_width(sc.dtype) == 8 && q->executed_stages == (int)q->stages.size()) {
+        LaunchTimer lt(ctx, "compact_captured");                  // the scan kept the column's selected values: the transform rides on the copy
+        launch_compact_captured_transform(s, (q->cap_col == tcol->col ? q->cap_buf : q->cap_buf2).as<uint64_t>(), q->prefix.as<uint64_t>(), dt_base(sc.dtype), tf, (uint64_t*)dst, t->nrows, cnt);
+      } else {
+        LaunchTimer lt(ctx, "gather");
+        launch_gather_transform(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), sc.data.p, dt_base(sc.dtype), tf, dst, t->nrows, cnt);
+      }
     } else
     run_interp_project(q, e, dst, cnt, mdst);
     if (!dev) {

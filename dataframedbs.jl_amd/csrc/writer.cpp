@@ -21,6 +21,7 @@ namespace dfdb {
 void launch_lz4_compress(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* out_len);
 void launch_pack_file_image(hipStream_t s, const uint8_t* comp, const Lz4Block* blocks, const int32_t* lens, const int64_t* pos, const int32_t* rows,
                             int32_t nblocks, uint8_t* image);
+void set_lz4_enc_near(int64_t v);  // k_encode.hip: a far match is given up for a near one that ends as late (ctx option "lz4_enc_near": the near reach in bytes, 0 = off)
 void set_lz4_enc_variant(int v);   // 0 = v1 (one sequence per step), 1 = v2 (every match of a 64-byte window per step, default)
 void launch_pack_nullable(hipStream_t s, const uint8_t* values, const uint64_t* missing_bits, const int64_t* row_off, const int64_t* body_off,
                           int32_t nblocks, int width, uint8_t* bodies);
@@ -165,6 +166,7 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
     dlens.ensure(4 * (size_t)n);
     HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)n, hipMemcpyHostToDevice, s));
     set_lz4_enc_variant((int)ctx_option(ctx, "lz4_enc_variant", 1));
+    set_lz4_enc_near(ctx_option(ctx, "lz4_enc_near", 0));
     { LaunchTimer lt(ctx, "lz4_compress"); launch_lz4_compress(s, csrc, comp.as<uint8_t>(), dblocks.as<Lz4Block>(), (int32_t)n, dlens.as<int32_t>()); }
     std::vector<int32_t> lens((size_t)n);
     HIP_CHECK(hipMemcpyAsync(lens.data(), dlens.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s));

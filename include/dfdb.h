@@ -114,6 +114,10 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "scan_pair"       1 = an AND of exactly two plain comparisons / intervals on Int64 / Float64 columns runs in the pipelined two-column kernel (default 1;
  *                     0 = the generic multi-term kernel)
  *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
+ *   "lz4_enc_near"    > 0: the window-parallel compressor gives a match up whose source lies further back than this many bytes when one of the next two
+ *                     positions starts a match inside that reach that ends as late — K7 then copies out of its on-chip history instead of fetching a 128-byte
+ *                     line for a few bytes.  Measured at 1984 (K7's reach): ratio - 8 %, indexed decode + 3 %, first decode - 3 % (profiles/r4_lz4_near.txt):
+ *                     default 0 = off, since file bytes (PCIe) are what the cold path waits for
  *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself on a few fresh allocations of the column (device-to-device
  *                     copies: the fastest BECOMES the column, the others are released) and then against a few candidate bitmap allocations, and the column
  *                     keeps the fastest bitmap for the queries that scan it (query.cpp: place_mask; default 0: ~60 scans, copies of the column and 0.03-1.4 s of
