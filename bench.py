@@ -392,10 +392,14 @@ class Legs:
     def __init__(self, torch, dist, dev, ctx, world, rank, backend, steps, peak, calibrate=0):
         self.torch, self.dist, self.dev, self.ctx, self.world, self.rank, self.backend, self.steps, self.peak = torch, dist, dev, ctx, world, rank, backend, steps, peak
         self.calibrate = calibrate                          # ctx option placement_calibrate of the legs' contexts (the headline's setting)
+        self.shards = 1                                     # --mode threads: the GPUs this ONE process drives (rows_per_s counts every shard)
+        self.group, self.devices = None, None               # --mode threads: the library group whose streams a barrier must drain, its device ordinals
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
+        if self.group is not None:
+            self.group.synchronize()
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, sec):
@@ -435,7 +439,7 @@ class Legs:
         fraction of something the HBM delivered — and the flat-column figure is kept beside it as `frac_flat_equivalent`."""
         gbps = bytes_per_gpu / sec / 1e9
         r = {"what": what, "rows_per_gpu": rows, "selected_per_gpu": selected, "ms_per_step": sec * 1e3, "steps": self.steps, "kernels_avg_ms": ks,
-             "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world / sec, "placement_calibrate": self.calibrate,
+             "algorithmic_GB": bytes_per_gpu / 1e9, "rows_per_s": rows * self.world * self.shards / sec, "placement_calibrate": self.calibrate,
              "roofline": {"bound": "hbm", "achieved": gbps, "peak": self.peak, "unit": "GB/s", "frac": gbps / self.peak,
                           "what": "algorithmic bytes of the whole job per GPU (SURVEY.md section 8d) / step time"}}
         if bytes_read is not None:
@@ -644,7 +648,7 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
     from dfdb import _native as N
     torch, dist, world = L.torch, L.dist, L.world
     res = {}
-    total = rows * world
+    total = rows * (grp.world if (grp is not None and L.shards > 1) else world)
     bytes_row = 8 + 8 + 4 + 5.4                           # a, x, sizes + bytes of s
     own = None
     if host_shards > 1:                                   # functional: ONE process, host-exchange group of `host_shards` shards on this device
@@ -693,7 +697,8 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
         gm = G.GroupQuery(gt, v[dfdb.ALL, ["a", "x"]])
         N.check(N.load().dfdb_group_query_hint_materialize(gm._h, 1))
         cnts = gm.shard_counts()[grp.first_rank:grp.first_rank + grp.nlocal]
-        bufs = [[torch.empty(max(c, 1), dtype=torch.int64, device=L.dev), torch.empty(max(c, 1), dtype=torch.float64, device=L.dev)] for c in cnts]
+        devs = [torch.device("cuda", d) for d in L.devices] if L.devices else [L.dev] * len(cnts)      # (every shard's outputs in ITS OWN HBM)
+        bufs = [[torch.empty(max(c, 1), dtype=torch.int64, device=devs[l]), torch.empty(max(c, 1), dtype=torch.float64, device=devs[l])] for l, c in enumerate(cnts)]
         mouts = (N.OutCol * (2 * grp.nlocal))()
         for l in range(grp.nlocal):
             for p_ in range(2):
@@ -703,7 +708,7 @@ def config5_legs(L, dfdb, G, rows, rank, local, stream, grp, host_shards):
             gm.reset()
             N.check(N.load().dfdb_group_materialize_device(gm._h, mouts, 2))
         sec, ks = L.timed(step_m, gctx)
-        nsel_m = sum(cnts)
+        nsel_m = sum(cnts) // (grp.nlocal if L.shards > 1 else 1)          # per GPU
         res["5_shard_materialize"] = L.record(per_gpu_rows, nsel_m, sec, ks, per_gpu_rows * bytes_row + nsel_m * 32,
                                               "the same selection, materialize [a, x] into per-shard DEVICE buffers (dfdb_group_materialize_device): results stay sharded", exchange=exch)
         del bufs
@@ -739,6 +744,82 @@ def run_config_legs(L, dfdb, G, args, rank, local, stream, grp, out):
     return out
 
 
+def main_threads(args, out_fd):
+    """--mode threads: ONE process drives N GPUs through the library's own group (dfdb_group_create: a host worker thread per GPU issues that shard's launches,
+    ncclCommInitAll connects them, the count is one grouped RCCL all-reduce on the shards' engine streams) — what a Julia session calling the drop-in gets
+    (INTEGRATION.md), and the path torch.distributed.run never exercises.  --all-on-device0: every shard on device 0 with the host exchange (a 1-GPU box)."""
+    import torch
+    import dfdb
+    from dfdb import group as G, _native as N
+    n = args.gpus
+    devices = [0] * n if args.all_on_device0 else list(range(n))
+    grp = G.Group.create(devices, N.EXCHANGE_HOST if (args.all_on_device0 and n > 1) else N.EXCHANGE_AUTO)
+    rows = args.rows
+    total_rows = rows * n
+    gt = G.GroupTable.new(grp)
+    gt.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, total_rows)
+    gq = G.GroupQuery(gt, gt.view()[("x", lambda x: x > THRESHOLD), dfdb.ALL])
+    cnts = gq.shard_counts()
+    outs = [torch.empty(max(c, 1), dtype=torch.int64, device=torch.device("cuda", devices[l])) for l, c in enumerate(cnts)]
+    ptrs, caps = [o.data_ptr() for o in outs], list(cnts)
+    ctx0 = grp.ctx(0)
+    info = ctx0.device_info()
+    peak = float(info.get("peak_hbm_gbps") or HBM_PEAK_GBPS)
+
+    def step():
+        gq.reset()
+        gq.indices_device(ptrs, caps)                      # every shard: K1 scan -> bitmap + tile counts, count scan, K2 compaction (its own worker thread)
+        gq.count_async()                                   # one grouped all-reduce of the count on the engine streams, no host wait
+    for _ in range(args.warmup):
+        step()
+    ctx0.profile(True)
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    grp.synchronize()
+    elapsed = time.perf_counter() - t0
+    total_sel = gq.count()
+    kernels = {}
+    for k in ("scan_cmp", "scan_counts", "compact_indices"):
+        nl, ms = ctx0.profile_get(k)
+        if nl:
+            kernels[k] = dict(launches=nl, avg_ms=ms / nl)
+    ctx0.profile(False)
+    local_rows = gt.shard(0).view()._query().count()
+    scan_row_bytes = 8 + 1 / 8 + 4 / 1024
+    scan_ms = kernels.get("scan_cmp", {}).get("avg_ms")
+    achieved = local_rows * scan_row_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
+    sigma = cnts[0] / max(local_rows, 1)
+    res = {
+        "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
+        "value": total_rows * args.steps / elapsed, "unit": "rows/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "Int64 column, selection(x -> x > 899999) -> ascending 1-based Int64 row indices + count", "rows_per_gpu": rows, "selected_per_gpu": cnts[0],
+                   "selectivity": sigma, "block_size": 65536, "pipeline": "k_scan_cmp + count scan + k_compact_indices",
+                   "sharding": f"contiguous block ranges x{n}, ONE process: dfdb_group_create (a host thread per GPU), count all-reduced by " +
+                               ("libdfdb_hip's RCCL communicator (ncclCommInitAll)" if grp.exchange == N.EXCHANGE_RCCL else "the host exchange (shards share a device: functional)"),
+                   "launcher": "one process, a host thread per GPU (--mode threads)", "device": info["name"], "global_selected": total_sel,
+                   "options": "library defaults (no ctx option set; placement_calibrate = 0)", "placement_calibration": "off"},
+        "job_hbm_gbps": total_rows * (8 + 8 * sigma) / (elapsed / args.steps) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_scan_cmp<int64,GT>", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": (achieved / peak) if achieved else None,
+                     "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": local_rows * scan_row_bytes, "avg_launch_ms": scan_ms, "kernels": kernels,
+                     "what": "shard 0's kernel (every shard runs the same launch on its own GPU)"},
+    }
+    del outs
+    gq.close(); gt.close()
+    if not args.no_configs:
+        try:
+            L = Legs(torch, None, torch.device("cuda", devices[0]), ctx0, 1, 0, "none", args.config_steps or max(3, min(args.steps, 10)), peak, 0)
+            L.shards = n; L.group = grp; L.devices = devices
+            res["configs"] = config5_legs(L, dfdb, G, int(1_250_000_000 * args.config_scale), 0, devices[0], None, grp, 0)
+        except Exception as e:
+            res["configs"] = {"5_shard": {"error": f"{type(e).__name__}: {e}"}}
+    sys.stdout.flush()
+    os.write(out_fd, (json.dumps(res) + "\n").encode())
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -763,6 +844,8 @@ def main():
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
                     "or the library's own RCCL communicator behind the C ABI (dfdb_group_create_rank + dfdb_group_count)")
+    ap.add_argument("--mode", default="processes", choices=["processes", "threads"], help="processes: one process per GPU (torch.distributed.run or self-spawned ranks); "
+                    "threads: ONE process driving --gpus GPUs through dfdb_group_create (a host thread per GPU, ncclCommInitAll) — what a Julia session gets")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 legs (extra keys)")
     ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the config legs (functional runs; 1.0 = BASELINE.json's sizes)")
     ap.add_argument("--config-steps", type=int, default=None, help="timed steps per config leg (default: min(steps, 10), at least 3)")
@@ -771,6 +854,11 @@ def main():
                     "shards on the device (every path of csrc/group.cpp but the RCCL calls)")
     args = ap.parse_args()
 
+    if args.mode == "threads":
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            print("bench.py: --mode threads is one process; do not start it under torch.distributed.run", file=sys.stderr)
+            sys.exit(2)
+        return main_threads(args, claim_stdout())
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 

@@ -294,6 +294,77 @@ def test_bench_self_launches_ranks(ctx):
     assert "calibrated_config" not in r
 
 
+def _is_sony(sz, by):
+    """rows of a flat string column (sizes, bytes) that hold exactly "sony" """
+    off = np.concatenate([[0], np.cumsum(sz)])[:-1]
+    out = np.asarray(sz) == 4
+    idx = off[out]
+    ok = (by[idx] == ord("s")) & (by[idx + 1] == ord("o")) & (by[idx + 2] == ord("n")) & (by[idx + 3] == ord("y"))
+    out[np.nonzero(out)[0][~ok]] = False
+    return out
+
+
+@pytest.mark.parametrize("exchange", ["torch", "lib"])
+def test_bench_eight_ranks_on_one_device(oracle, ctx, exchange):
+    """what the driver's 8-GPU run will do, on the one GPU there is — `bench.py --gpus 8` spawns eight ranks (all on device 0, gloo), the
+    block count of the whole table is not divisible by 8, every config leg is present at every rank count, and the global counts equal the oracle's for the
+    same rows; with --exchange lib the headline's per-step all-reduce goes through the library's own group (its exchanges from the host's collectives here,
+    RCCL between eight devices on a real node)."""
+    rows = 20_000_000
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--all-on-device0", "--backend", "gloo", "--rows", str(rows), "--steps", "3", "--warmup", "1",
+           "--no-cpu", "--config-scale", "0.002"] + (["--exchange", "lib"] if exchange == "lib" else [])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 0
+    total = 8 * rows
+    assert (-(-total // 65536)) % 8 != 0                                       # the last rank's block range is shorter
+    want = int((oracle.gen_i64(0x9E3779B97F4A7C15, 0, total) > 899_999).sum())
+    assert r["config"]["global_selected"] == want
+    cf = r["configs"]
+    for k in ("3", "3_computed", "4", "4_dictionary", "5_shard", "5_shard_dictionary", "5_shard_materialize", "unique", "groupreduce", "nullable_string_eq"):
+        assert k in cf and "error" not in cf[k], (k, cf.get(k))
+    assert "error" not in cf["interp"], cf["interp"]
+    n5 = cf["5_shard"]["rows_per_gpu"]
+    a = oracle.gen_i64(0x9E3779B97F4A7C15, 0, 8 * n5); x = oracle.gen_f64((0x9E3779B97F4A7C15 * 2) & 0xFFFFFFFFFFFFFFFF, 0, 8 * n5)
+    sz, by = oracle.gen_str((0x9E3779B97F4A7C15 * 3) & 0xFFFFFFFFFFFFFFFF, 0, 8 * n5)
+    sony = _is_sony(sz, by)
+    sel = (a > 683_771) & (x < 632.456) & ~sony
+    assert cf["5_shard"]["total_rows"] == 8 * n5 and cf["5_shard"]["global_count"] == int(sel.sum())
+    assert abs(cf["5_shard"]["global_sum_x"] - float(x[sel].sum())) <= 64 * np.finfo(np.float64).eps * float(np.abs(x[sel]).sum())
+    if exchange == "lib":
+        assert "libdfdb_hip's group" in r["config"]["sharding"]
+
+
+def test_bench_threads_mode_one_process_drives_the_shards(oracle, ctx):
+    """`bench.py --mode threads` — ONE process, dfdb_group_create over N devices, a host worker thread per shard: what a Julia session gets
+    and what no torch.distributed launch exercises.  On a 1-GPU box the three shards share device 0 and exchange through the host; the global count and config
+    5's count / sum equal the oracle's."""
+    rows = 10_000_000
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "threads", "--gpus", "3", "--all-on-device0", "--rows", str(rows), "--steps", "3", "--warmup", "1",
+                        "--config-scale", "0.002"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 3 and r["value"] > 0 and "one process" in r["config"]["launcher"] and r["roofline"]["frac"] > 0
+    assert r["config"]["global_selected"] == int((oracle.gen_i64(0x9E3779B97F4A7C15, 0, 3 * rows) > 899_999).sum())
+    cf = r["configs"]
+    for k in ("5_shard", "5_shard_materialize", "5_shard_dictionary"):
+        assert "error" not in cf[k], cf[k]
+    n5 = cf["5_shard"]["rows_per_gpu"]
+    assert cf["5_shard"]["total_rows"] == 3 * n5
+    a = oracle.gen_i64(0x9E3779B97F4A7C15, 0, 3 * n5); x = oracle.gen_f64((0x9E3779B97F4A7C15 * 2) & 0xFFFFFFFFFFFFFFFF, 0, 3 * n5)
+    sz, by = oracle.gen_str((0x9E3779B97F4A7C15 * 3) & 0xFFFFFFFFFFFFFFFF, 0, 3 * n5)
+    sony = _is_sony(sz, by)
+    sel = (a > 683_771) & (x < 632.456) & ~sony
+    assert cf["5_shard"]["global_count"] == int(sel.sum())
+
+
 def test_bench_config_legs_through_the_library_group(oracle, ctx):
     """N = 1: the config legs at 0.4 % of BASELINE.json's sizes.  Config 5 runs twice through the library's own group path — a one-rank RCCL group
     (the RCCL all-reduce of {sum, count} issued for real) and, with --config5-host-shards 3, a one-process host-exchange group of three shards — and
