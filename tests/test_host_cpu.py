@@ -262,6 +262,9 @@ def test_julia_shim_ccalls_match_the_header():
         mod.JL = real
         os.unlink(f.name)
     assert len(bad) == 3 and "Int64(v)" in bad[0] and "pointer(buf)" in bad[1] and "dfdb_count" in bad[2], bad
+    # round 4: the closure-lowering rules (the walk over Base.code_lowered) are each pinned to a line of the shim and rendered into STATIC_REVIEW.md
+    wrows, wmissing = mod.walker_review()
+    assert not wmissing and len(wrows) >= 12 and all(at for _n, at, _w in wrows), wmissing
     syms = {r[1] for r in rows}
     # round 3: sharded unique / groupreduce go through the library's own merge
     for s in ("dfdb_group_query_unique", "dfdb_group_query_unique_fetch", "dfdb_group_query_groupreduce", "dfdb_group_query_groupreduce_fetch"):
@@ -271,6 +274,7 @@ def test_julia_shim_ccalls_match_the_header():
         assert s in syms, s
     review = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "STATIC_REVIEW.md")).read()
     assert f"**{len(rows)} ccall sites, 0 mismatches**" in review, "run tools/julia_static_review.py"
+    assert "## Closures with control flow: the walk over lowered code (round 4)" in review and "**MISSING**" not in review, "run tools/julia_static_review.py"
     jl = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "DataFrameDBsAMD.jl")).read()
     assert "Base.invoke_in_world(WORLD0[]" in jl and "invoke(DataFrameDBs._cpu" not in jl          # the fallback cannot re-enter an override
     for route in ("DataFrameDBs.materialize(c::DFColumn)", "Base.copyto!(dest::AbstractVector, src::DFColumn)", "Base.sum(c::DFColumn)",

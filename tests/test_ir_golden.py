@@ -204,3 +204,109 @@ def test_shim_constant_emitter_transcription():
     setfn = jl[jl.index("function emit_const(io, v::AbstractVector{T})"):]
     setfn = setfn[:setfn.index("\nend") + 4]
     assert "x > typemax(Int64)" in setfn and "throw(Unsupported(" in setfn and "convert(E, x)" in setfn
+
+
+# ---------------------------------------------------------------- the shim's walk over a closure's lowered code (round 4)
+def _shim_walk(code, args, ops):
+    """Python transcription of DataFrameDBsAMD.walk / select_bool over a miniature of Core.CodeInfo: statements are ("call", fname, operands...),
+    ("gotoifnot", cond, dest), ("goto", dest), ("return", value), ("assign", slot, stmt); operands are ("ssa", n), ("slot", n) or literals.  A traced value
+    is `bytes` (postfix IR), exactly the shim's Tr."""
+    G_ = G  # noqa: F841
+    from dfdb import ir
+
+    def const(v):
+        return ir.const(v).to_ir()
+
+    def tr(v):
+        return v if isinstance(v, bytes) else const(v)
+
+    def call(fn, av):
+        if fn == "!":
+            return av[0] + bytes([ops["!"]]) if isinstance(av[0], bytes) else (not av[0])
+        a, b = av
+        if not isinstance(a, bytes) and not isinstance(b, bytes):
+            return {">": a > b, "<": a < b, "==": a == b, "|": a | b, "&": a & b}[fn]
+        return tr(a) + tr(b) + bytes([ops[fn]])
+
+    def select_bool(c, t, e):
+        tb, eb = isinstance(t, bool), isinstance(e, bool)
+        if tb and eb:
+            return t if t == e else (c if t else call("!", [c]))
+        if not tb and eb:
+            return call("|", [call("!", [c]), t]) if e else call("&", [c, t])
+        if tb and not eb:
+            return call("|", [c, e]) if t else call("&", [call("!", [c]), e])
+        return call("|", [call("&", [c, t]), call("&", [call("!", [c]), e])])
+
+    def value(x, ssa, slots):
+        if isinstance(x, tuple) and x[0] == "ssa":
+            return ssa[x[1]]
+        if isinstance(x, tuple) and x[0] == "slot":
+            return slots[x[1]]
+        if isinstance(x, tuple) and x[0] == "call":
+            return call(x[1], [value(a, ssa, slots) for a in x[2:]])
+        return x
+
+    def walk(pc, ssa, slots):
+        while True:
+            st = code[pc - 1]
+            if st[0] == "return":
+                return value(st[1], ssa, slots)
+            if st[0] == "goto":
+                assert st[1] > pc
+                pc = st[1]
+            elif st[0] == "gotoifnot":
+                c = value(st[1], ssa, slots)
+                if isinstance(c, bool):
+                    pc = pc + 1 if c else st[2]
+                else:
+                    t = walk(pc + 1, dict(ssa), dict(slots))
+                    e = walk(st[2], dict(ssa), dict(slots))
+                    return select_bool(c, t, e)
+            elif st[0] == "assign":
+                slots[st[1]] = value(st[2], ssa, slots)
+                ssa[pc] = slots[st[1]]
+                pc += 1
+            else:
+                ssa[pc] = value(st, ssa, slots)
+                pc += 1
+    return walk(1, {}, {i + 2: a for i, a in enumerate(args)})
+
+
+def test_shim_lowered_code_walk_transcription():
+    """the tracer could not lower the reference's OWN test closure `(a)->65>a>34` (test/selection.jl:53): a chained comparison is
+    `&&`, which needs a real Bool out of a traced value.  The shim now walks the closure's lowered code (lower_closure / walk / select_bool).  No Julia here:
+    the walk is transcribed into Python above and run over the lowered code Julia produces for three closures; it must emit exactly the hand-assembled
+    golden bytes (which the oracle and the engine evaluate to Julia's answers), and the shim's source must hold the rules the transcription follows."""
+    from dfdb import ir
+    jl = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "DataFrameDBsAMD.jl")).read()
+    ops = {}
+    for name, key in ((">", "(>)"), ("<", "(<)"), ("==", "(==)"), ("&", "(&)"), ("|", "(|)"), ("!", "(!)")):
+        m = re.search(re.escape(key) + r"\s*=>\s*0x([0-9a-fA-F]{2})", jl)
+        assert m, key
+        ops[name] = int(m.group(1), 16)
+    by_name = {c["name"]: bytes.fromhex(c["hex"]) for c in G["cases"]}
+    a = ir.col(0).to_ir()
+    # a -> 3 > a > -2        %1 = 3 > a ; goto #5 if not %1 ; %3 = a > -2 ; return %3 ; return false
+    code = [("call", ">", 3, ("slot", 2)), ("gotoifnot", ("ssa", 1), 5), ("call", ">", ("slot", 2), -2), ("return", ("ssa", 3)), ("return", False)]
+    assert _shim_walk(code, [a], ops) == by_name["closure_chained_comparison"]
+    # a -> a < -2 || a > 5   %1 = a < -2 ; goto #4 if not %1 ; return true ; %4 = a > 5 ; return %4
+    code = [("call", "<", ("slot", 2), -2), ("gotoifnot", ("ssa", 1), 4), ("return", True), ("call", ">", ("slot", 2), 5), ("return", ("ssa", 4))]
+    assert _shim_walk(code, [a], ops) == by_name["closure_short_circuit_or"]
+    # a -> (a > -2 && a < 5) | (a == 10)
+    #   %1 = a > -2 ; goto #5 if not %1 ; @_3 = a < 5 ; goto #6 ; @_3 = false ; %6 = @_3 ; %7 = a == 10 ; %8 = %6 | %7 ; return %8
+    code = [("call", ">", ("slot", 2), -2), ("gotoifnot", ("ssa", 1), 5), ("assign", 3, ("call", "<", ("slot", 2), 5)), ("goto", 6), ("assign", 3, False),
+            ("slot", 3), ("call", "==", ("slot", 2), 10), ("call", "|", ("ssa", 6), ("ssa", 7)), ("return", ("ssa", 8))]
+    assert _shim_walk(code, [a], ops) == by_name["closure_and_then_or_through_a_join"]
+    # the reference's own closure: (a) -> 65 > a > 34
+    code = [("call", ">", 65, ("slot", 2)), ("gotoifnot", ("ssa", 1), 5), ("call", ">", ("slot", 2), 34), ("return", ("ssa", 3)), ("return", False)]
+    assert _shim_walk(code, [a], ops) == ((ir.const(65) > ir.col(0)) & (ir.col(0) > 34)).to_ir()
+    # the rules, in the shim's own text
+    for needle in ("function lower_closure(f, args::Vector{Any})", "Base.code_lowered(f)", "st isa Core.GotoIfNot", "select_bool(c::Tr, t::Tr, e::Bool) = e ? (!c | t) : (c & t)",
+                   "select_bool(c::Tr, t::Bool, e::Tr) = t ? (c | e) : (!c & e)", "select_bool(c::Tr, t::Tr, e::Tr) = (c & t) | (!c & e)",
+                   "const RAISING_OPS = (0x14, 0x15, 0x16, 0x50)", "(may_raise(t) || may_raise(e)) && throw(Unsupported(", "st.dest > pc || throw(Unsupported(",
+                   "return lower_closure(f, collect(Any, args))", "@warn \"DataFrameDBsAMD: $(f) falls back to the stock CPU path"):
+        assert needle in jl, needle
+    hdr = open(os.path.join(ROOT, "include", "dfdb_ir.h")).read()
+    for name, val in (("DFIR_IDIV", 0x14), ("DFIR_REM", 0x15), ("DFIR_MOD", 0x16), ("DFIR_CAST", 0x50)):      # what RAISING_OPS names
+        assert re.search(r"#define\s+" + name + r"\s+0x%02x" % val, hdr), name

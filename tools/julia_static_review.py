@@ -213,10 +213,42 @@ def lint():
     return findings
 
 
+WALKER_RULES = [
+    ("entry", "return lower_closure(f, collect(Any, args))", "a trace that dies (a `Tr` where Julia needs a real Bool) goes on to the lowered-code walk before anything is declared unsupported"),
+    ("source of the code", "cis = Base.code_lowered(f)", "the walk reads the closure's LOWERED code (before inference): `&&`, `||`, `?:` and chained comparisons are `goto #k if not %c` there"),
+    ("one method", "length(cis) == 1 || throw(Unsupported(", "only a closure with exactly one method is walked"),
+    ("captured variables", "slots[1] = f", "slot 1 is the closure itself: `getfield(#self#, :c)` runs as an ordinary call and yields the captured value"),
+    ("fork", "st isa Core.GotoIfNot", "a branch on a traced value forks the walk; a branch on a real Bool is decided while walking"),
+    ("no loops", "st.dest > pc || throw(Unsupported(\"the closure loops on a column value\"))", "a backward jump on a traced condition is refused (and every `goto` must go forward)"),
+    ("and", "select_bool(c::Tr, t::Tr, e::Bool) = e ? (!c | t) : (c & t)", "`c && t` (else arm is the literal false) becomes `c & t`"),
+    ("or", "select_bool(c::Tr, t::Bool, e::Tr) = t ? (c | e) : (!c & e)", "`c || e` (then arm is the literal true) becomes `c | e`"),
+    ("select", "select_bool(c::Tr, t::Tr, e::Tr) = (c & t) | (!c & e)", "two traced Bool arms: `(c & t) | (!c & e)`"),
+    ("Bool arms only", "select_bool(c, t, e) = throw(Unsupported(", "an arm that is not Bool-valued (`x > 0 ? x : -x`) stays on the CPU path: the IR has no select of numbers"),
+    ("no raising arms", "(may_raise(t) || may_raise(e)) && throw(Unsupported(", "an arm Julia evaluates conditionally must not be able to raise once `&` evaluates it for every row"),
+    ("what raises", "const RAISING_OPS = (0x14, 0x15, 0x16, 0x50)", "DFIR_IDIV, DFIR_REM, DFIR_MOD (DivideError) and DFIR_CAST (InexactError), by opcode"),
+    ("budget", "(w.steps += 1) > WALK_BUDGET && throw(Unsupported(", "the walk is bounded (4096 statements over all arms)"),
+    ("fallback is said", "@warn \"DataFrameDBsAMD: $(f) falls back to the stock CPU path: $(e.msg)\" maxlog = 1", "a view that falls back is logged once per reason"),
+]
+
+
+def walker_review():
+    """the closure-lowering rules of round 4, each pinned to the line of the shim that implements it"""
+    src = open(JL).read()
+    lines = src.split("\n")
+    rows, missing = [], []
+    for name, needle, what in WALKER_RULES:
+        at = next((i + 1 for i, ln in enumerate(lines) if needle in ln), None)
+        rows.append((name, at, what))
+        if at is None:
+            missing.append(f"closure lowering: the rule '{name}' is not in the shim (`{needle}`)")
+    return rows, missing
+
+
 def main():
     rows, errors = check()
     findings = lint()
-    errors = errors + findings
+    wrows, wmissing = walker_review()
+    errors = errors + findings + wmissing
     out = ["# Static review of the Julia shim's FFI (generated by tools/julia_static_review.py)", "",
            "Julia is not installed in the build image, so `dataframedbs.jl_amd/julia/DataFrameDBsAMD.jl` cannot be executed here.  This file walks every",
            "`ccall` of the shim against the prototype of the same symbol in `include/dfdb.h`: the symbol is declared, the arity matches, every argument",
@@ -236,13 +268,26 @@ def main():
             "", "The constant emitter itself is pinned dynamically: `tests/test_ir_golden.py::test_shim_constant_emitter_transcription` runs a Python transcription of",
             "`emit_const` (same branches, same wrapping) over UInt64 constants ≥ 2^63, negative Int8 … Int64, Bool and Float32 / Float64 and compares the bytes with `dfdb/ir.py`'s",
             "and with the hand-assembled golden bytes."]
+    out += ["", "## Closures with control flow: the walk over lowered code (round 4)", "",
+            "The tracer calls a closure on symbolic `Tr` values; `&&`, `||`, `?:` and chained comparisons need a real `Bool` and kill the trace — among them the",
+            "reference's own test closure `(a)->65>a>34` (`test/selection.jl:53`).  `lower_closure` walks `Base.code_lowered(f)` instead.  The rules, each at the",
+            "line of the shim that implements it (a rule that disappears from the source fails the CPU test suite):", "",
+            "| rule | shim line | what it guarantees |", "|---|---|---|"]
+    for name, at, what in wrows:
+        out.append(f"| {name} | {at if at else '**MISSING**'} | {what} |")
+    out += ["", "Pinned dynamically without a Julia: `tests/test_ir_golden.py::test_shim_lowered_code_walk_transcription` runs a Python transcription of `walk` /",
+            "`select_bool` over the lowered code of `a -> 3 > a > -2`, `a -> a < -2 || a > 5`, `a -> (a > -2 && a < 5) | (a == 10)` and `(a) -> 65 > a > 34` and compares",
+            "the bytes with the hand-assembled golden cases `closure_*` of `tests/golden/ir_golden.json`, which the oracle (CPU) and the engine (GPU) evaluate to the",
+            "answers Julia gives.  What the walk cannot know without running Julia: the exact shape `code_lowered` gives a closure in a given Julia version (the",
+            "statement kinds handled are `Core.GotoIfNot`, `Core.GotoNode`, `Core.ReturnNode`, `Core.NewvarNode`, slot assignment, `:call`; anything else is `Unsupported`)."]
     out += ["", "## Things a signature check cannot see (reviewed by reading)", "",
             "* **Fallback without recursion.** `enable!()` records `WORLD0 = Base.get_world_counter()` *before* it defines the overriding methods and every",
             "  fallback goes through `Base.invoke_in_world(WORLD0[], f, args...)`: in that world only the reference's own methods exist, including the `nrow(v)`",
             "  the stock `materialize(::DFView)` calls inside (`materialization.jl:29`), so an `Unsupported` can never re-enter an override (round 1's",
             "  `invoke(_cpu_materialize, …)` re-entered the replaced method).",
-            "* **Untraceable closures.** `65 > a > 34` lowers to `(65 > a) && (a > 34)`; `&&` on a `Tr` raises `TypeError` inside `lower`'s `try`, which rethrows it as",
-            "  `Unsupported` → stock path.  Lowering happens before any device call (`with_query` lowers all stages first), so a fallback leaves no device state behind.",
+            "* **Untraceable closures.** `65 > a > 34` lowers to `(65 > a) && (a > 34)`; `&&` on a `Tr` raises `TypeError` inside `lower`'s `try`: the lowered-code walk above",
+            "  takes over, and what it refuses is `Unsupported` → stock path, logged once.  Lowering happens before any device call (`with_query` lowers all stages first), so a",
+            "  fallback leaves no device state behind.",
             "* **GC safety.** Every buffer whose pointer crosses the ABI is rooted: IR byte vectors, index vectors, name / code pointer arrays and the output",
             "  vectors are under `GC.@preserve` for the duration of the call; the engine copies what it keeps (`parse_ir`, `Stage::idx`), so nothing outlives the call.",
             "* **Ownership.** `with_query` frees its query in `finally`; tables and the group live in `DEV[]` until `reset!()`; `dfdb_group_query_shard` returns a borrowed handle.",
