@@ -25,6 +25,8 @@ try:
     cfgs = ((4, 3, 8, 1024), (6, 5, 8, 1024), (6, 3, 8, 1024), (6, 2, 8, 1024), (8, 3, 8, 1024), (8, 2, 8, 1024), (8, 4, 8, 1024), (8, 3, 16, 1024), (8, 2, 16, 1024), (8, 3, 8, 512), (8, 2, 8, 512), (8, 3, 8, 256))
     if os.environ.get("SWEEP_SHORT"):
         cfgs = ((6, 5, 8, 1024), (8, 3, 8, 1024), (8, 2, 8, 512))
+    if os.environ.get("SWEEP_READERS"):
+        cfgs = ((8, 2, 8, 1024), (8, 3, 8, 1024), (8, 4, 8, 1024), (8, 5, 8, 1024), (8, 7, 8, 1024), (8, 3, 12, 1024), (8, 4, 12, 1024), (8, 4, 6, 1024), (8, 5, 6, 1024), (8, 3, 8, 512), (8, 4, 8, 512), (8, 4, 8, 2048))
     for slots, readers, io, chunk in cfgs:
         ctx.set_option("stream_slots", slots); ctx.set_option("io_threads", io); ctx.set_option("stream_readers", readers)
         ts = []
