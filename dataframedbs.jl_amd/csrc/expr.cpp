@@ -400,14 +400,15 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
   return false;
 }
 
-bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat) {
+// allow_nullable: the caller evaluates `coalesce(term, false)` — K5 gives exactly that over a Union{String,Missing} column (a missing row selects nothing)
+bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat, bool allow_nullable) {
   (void)t;
   if (!n.a || !n.b) return false;
   const Node *coln = nullptr, *cn = nullptr;
   if (n.a->op == DFIR_COL && n.b->op == DFIR_CONST_STR) { coln = n.a.get(); cn = n.b.get(); }
   else if (n.a->op == DFIR_CONST_STR && n.b->op == DFIR_COL && (n.op == DFIR_EQ || n.op == DFIR_NE)) { coln = n.b.get(); cn = n.a.get(); }
   else return false;
-  if (dt_base(coln->dtype) != DFDB_STRING || dt_nullable(coln->dtype)) return false;
+  if (dt_base(coln->dtype) != DFDB_STRING || (dt_nullable(coln->dtype) && !allow_nullable)) return false;
   switch (n.op) {
     case DFIR_EQ: mode = 0; break; case DFIR_NE: mode = 1; break;
     case DFIR_STARTSWITH: mode = 2; break; case DFIR_ENDSWITH: mode = 3; break;

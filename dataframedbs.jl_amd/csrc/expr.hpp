@@ -39,6 +39,6 @@ bool match_simple_term(const Node& n, const dfdb_table& t, ScanTerm& term, int& 
 bool match_column_transform(const Node* e, ScanTerm& out, const Node*& coln);   // the column itself / rem / col * k + d / col / k (ScanTerm::pre)
 
 // `strcol == "x"`, `!=`, startswith, endswith  -> mode 0..3 (launch_str_match)
-bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat);
+bool match_string_term(const Node& n, const dfdb_table& t, int& ordinal, int& mode, std::string& pat, bool allow_nullable = false);
 
 }  // namespace dfdb

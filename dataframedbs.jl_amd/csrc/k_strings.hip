@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match(const int32_t* __restrict_
       const uint32_t incl = wave_incl_scan(c);
       const int64_t off = run + (int64_t)(incl - c);
       run += (int64_t)__shfl(incl, 63, 64);
-      const bool inb = base + j * 64 + lane < nrows;
+      const bool inb = base + j * 64 + lane < nrows && sz[j] >= 0;          // (a missing row — size -1 — selects nothing under any of the four terms)
       bool r = false;
       const int len = (int)c;
       if (inb) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
       for (int j = 0; j < 8; j++) {                                   // B
         const int32_t s0 = sz[h * 8 + j];
         const int len = s0 > 0 ? s0 : 0;
-        cand[j] = s0 != -2 && (MODE <= 1 ? len == plen : len >= plen);
+        cand[j] = s0 >= 0 && (MODE <= 1 ? len == plen : len >= plen);          // (-2: past the last row; -1: missing — a comparison with missing selects nothing: coalesce(term, false))
         v[j] = 0; if (LONG) v2[j] = 0;
         if (cand[j] && plen > 0) {
           const uint8_t* p = tb + rel[j] + (MODE == 3 ? len - plen : 0);
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
           const uint8_t* p = tb + rel[j] + (MODE == 3 ? (s1 > 0 ? s1 : 0) - plen : 0);
           eq = bytes_equal_long(p + 16, pat_dev + 16, plen - 16);
         }
-        const bool r = MODE == 1 ? (sz[h * 8 + j] != -2 && !eq) : eq;
+        const bool r = MODE == 1 ? (sz[h * 8 + j] >= 0 && !eq) : eq;
         const uint64_t m = __ballot(r);
         if (lane == h * 8 + j) myword = m;
         if (CAP && m != 0) {

@@ -358,6 +358,9 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       if (terms.n == kMaxTerms) { term_batches.push_back(terms); terms.n = 0; }
       terms.t[terms.n++] = tm; term_ords.push_back(ord);
     } else if (match_string_term(*c, *t, ord, mode, pat)) strs.push_back(c);
+    else if (c->op == DFIR_COALESCE && c->a && c->b && c->b->op == DFIR_CONST && dt_base(c->b->dtype) == DFDB_BOOL && !dt_nullable(c->b->dtype) && c->b->cbits == 0 &&
+             match_string_term(*c->a, *t, ord, mode, pat, true))
+      strs.push_back(c->a.get());     // coalesce(s == "x", false) over a Union{String,Missing} column (the docs' real data set: index.md:264-272): K5's own answer, not the interpreter's
     else generic.push_back(c);
   }
   if (terms.n) term_batches.push_back(terms);
@@ -373,11 +376,12 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   }
   for (const DictLut& dl : dict_luts) { run_dict_scan(q, t->cols[(size_t)dl.ord], dl.lut, have); have = true; }
   for (const Node* c : strs) {
-    int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat);
+    int ord, mode; std::string pat; match_string_term(*c, *t, ord, mode, pat, true);
     const Column& col = need_resident(t, ord);
+    const bool str_nullable = dt_nullable(col.dtype);
     // `col == "const"` is an AND-ed conjunct of this stage, and later stages only remove rows: every row the query finally selects holds exactly
     // `const` in this column, so its projection needs neither the column nor a capture (materialize_col: launch_fill_const_strings)
-    if (mode == 0) { q->const_str_col = ord; q->const_str = pat; }
+    if (mode == 0 && !str_nullable) { q->const_str_col = ord; q->const_str = pat; }
     if (col.dict_n > 0) {
       // K9: the column has a dictionary — the term is decided once per distinct string on the host, the rows are a bit-table lookup of their codes
       std::vector<uint32_t> lut((size_t)(col.dict_n + 31) / 32, 0u);
@@ -392,7 +396,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
     StrCapture capture{nullptr, nullptr, nullptr};
     // (every other kind of conjunct runs AFTER this launch and narrows the mask: the capture would keep rows the query drops — found by tests/test_gpu_fuzz.py)
-    bool do_cap = mode != 0 && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && or_batches.empty() && miss.empty() &&
+    bool do_cap = mode != 0 && !str_nullable && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && or_batches.empty() && miss.empty() &&
                   dict_luts.empty() && strs.size() == 1 && pat.size() <= 64;
     if (do_cap) {
       do_cap = false;

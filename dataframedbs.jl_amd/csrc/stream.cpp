@@ -104,7 +104,7 @@ struct dfdb_stream {
   std::string path;
   struct ColSrc { std::string name, file; size_t data_off; };
   std::vector<ColSrc> colsrc;      // per required column
-  int64_t chunk_blocks = 0, nblocks = 0, next_block = 0;
+  int64_t chunk_blocks = 0, nblocks = 0, next_block = 0, chunks_issued = 0;
   std::vector<int> required;       // table ordinals the query touches
   std::vector<std::shared_ptr<dfdb::BlockIndex>> index;   // per required column: walked lazily, a chunk ahead of the loaders (shared with the table's column)
   int64_t checked_blocks = 0;      // blocks whose row counts have been checked across the columns
@@ -391,9 +391,14 @@ bool prefetch(dfdb_stream* s, Slot* sl) {
     if (st.last() <= s->next_block * B) return false;                                  // is_finished (:192-196)
   }
   // the headers of the next chunk (and, after a skip, of everything before it: skip_block), walked now; the loaders get their own copy of the slice
-  const int64_t known = walk_index(s, s->next_block + s->chunk_blocks);
+  // the first chunks of a scan with large chunks are shorter (a quarter, then half of chunk_blocks): the caller gets its first rows after a quarter of the
+  // read + copy + decode latency of a full chunk, and the loaders start out staggered instead of in step
+  int64_t want = s->chunk_blocks;
+  if (s->chunk_blocks >= 256 && s->chunks_issued < 2) want = s->chunk_blocks >> (2 - s->chunks_issued);
+  s->chunks_issued++;
+  const int64_t known = walk_index(s, s->next_block + want);
   if (s->next_block >= known) return false;
-  sl->b0 = s->next_block; sl->b1 = std::min(known, s->next_block + s->chunk_blocks);
+  sl->b0 = s->next_block; sl->b1 = std::min(known, s->next_block + want);
   s->next_block = sl->b1;
   sl->locs.assign(s->index.size(), {});
   for (size_t k = 0; k < s->index.size(); k++) {
@@ -419,7 +424,7 @@ static void stream_destroy(dfdb_stream* s);
 // pinned buffers, the slots' tables with their device buffers — stream_open_impl moves those into the new tables —, loader threads)
 static void stream_rearm(dfdb_stream* s) {
   s->stages.clear(); s->colsrc.clear(); s->required.clear(); s->index.clear(); s->base.clear();
-  s->chunk_blocks = s->nblocks = s->next_block = 0; s->cur = -1; s->done = false;
+  s->chunk_blocks = s->nblocks = s->next_block = s->chunks_issued = 0; s->cur = -1; s->done = false;
   s->compressed = s->uncompressed = s->rows = 0;
   s->sel_col.clear(); s->read_stats.clear(); s->kprefix = 0; s->index_complete = false; s->checked_blocks = 0;
   s->requests.clear();

@@ -343,7 +343,8 @@ int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, dou
  * contract of the NamedTuple an iteration of the reference yields.  *chunk == NULL marks the end.  While the caller works
  * on chunk i a loader thread reads, copies and LZ4-decodes chunk i+1 on its own HIP stream.  The per-stage running offsets
  * of RangeToProcess (selection.jl:68-75,107), skip_if_can and is_finished (:177-196) carry over between chunks, so
- * t[pred, :][1:100, :] or head(t) read only the chunks they need. */
+ * t[pred, :][1:100, :] or head(t) read only the chunks they need.  With chunk_blocks >= 256 the first two chunks are shorter (a quarter and half
+ * of chunk_blocks): the first rows arrive after a quarter of a full chunk's latency. */
 int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out);
 int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row);
 int32_t dfdb_stream_stats(dfdb_stream* s, dfdb_sizestats* stats);   /* table_stats over the required columns (headers only) */

@@ -24,6 +24,13 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def dfdb_mod():
+    # (see `ctx` below: where there is a GPU, torch's copy of the HIP runtime opens it before the engine's does — whichever fixture a test asks for first)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import dfdb
     return dfdb
 
@@ -31,7 +38,10 @@ def dfdb_mod():
 @pytest.fixture(scope="session")
 def ctx(dfdb_mod):
     """One engine context on cuda:0 for the whole GPU session.  Fails loudly without the HIP library / a GPU."""
-    import torch  # noqa: F401  torch's bundled HIP runtime must be the one loaded first when both live in a process
+    import torch  # torch brings its own copy of the HIP / HSA runtime (another soname than the system one libdfdb_hip.so links): both live in this process
+    # ... and the copy that opens the GPU SECOND must be the system one: torch's runtime finds "No HIP GPUs" once the system runtime holds /dev/kfd, the other
+    # order works.  Tests that use torch tensors (full-size buffers, bitmaps on the device) would otherwise depend on which test touched the GPU first.
+    torch.cuda.init()
     c = dfdb_mod.default_context(0)
     if os.environ.get("DFDB_TEST_JIT") == "1":       # soak: every interpreter program of every test runs as its hipRTC-compiled kernel (0.2-0.4 s per new shape)
         c.set_option("jit", 2)

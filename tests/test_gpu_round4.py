@@ -161,6 +161,17 @@ def test_nullable_string_generator_and_three_valued_equality(oracle, dfdb_mod, c
     assert_same(p, ov, dv)
     dq = t[pred, dfdb_mod.ALL]._query()
     assert np.array_equal(dq.indices(), ov.select_indices())
+    # coalesce(<string term>, false) over a nullable String column is K5's own answer (a missing row selects nothing), not an interpreter program: every
+    # term kind, the empty pattern (which every NON-missing row matches), a long pattern, and a conjunction with a numeric term
+    ctx.profile(True)
+    for term in (ir.col(0) != "sony", ir.startswith(ir.col(0), "s"), ir.endswith(ir.col(0), "y"), ir.col(0) == "", ir.col(0) != "", ir.startswith(ir.col(0), ""),
+                 ir.col(0) == "a-pattern-that-is-longer-than-sixteen-bytes", ir.col(0) != "a-pattern-that-is-longer-than-sixteen-bytes"):
+        ov, dv = apply_stages(p, [("pred", ir.coalesce(term, False))])
+        assert_same(p, ov, dv)
+        ov, dv = apply_stages(p, [("pred", ir.coalesce(term, False) & (ir.col(1) > 300_000))], proj=[("s", ir.col(0)), ("a", ir.col(1))])
+        assert_same(p, ov, dv)
+    assert ctx.profile_get("str_match")[0] >= 16 and ctx.profile_get("interp_predicate")[0] + ctx.profile_get("jit_predicate")[0] == 0
+    ctx.profile(False)
     # ismissing counts (docs/src/index.md:326-328)
     assert t[ir.ismissing(ir.col(0)), dfdb_mod.ALL]._query().count() == int(miss.sum())
     t.close()
