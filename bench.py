@@ -749,6 +749,7 @@ def main_threads(args, out_fd):
     ncclCommInitAll connects them, the count is one grouped RCCL all-reduce on the shards' engine streams) — what a Julia session calling the drop-in gets
     (INTEGRATION.md), and the path torch.distributed.run never exercises.  --all-on-device0: every shard on device 0 with the host exchange (a 1-GPU box)."""
     import torch
+    torch.cuda.init()                                      # torch's copy of the HIP runtime opens the GPUs before the engine's does (INTEGRATION.md section 3)
     import dfdb
     from dfdb import group as G, _native as N
     n = args.gpus
