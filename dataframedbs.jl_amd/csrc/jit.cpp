@@ -89,6 +89,7 @@ struct JitCache {
   std::thread worker; bool started = false;
   std::atomic<int64_t> compiled{0}, failed{0};
 };
+constexpr size_t kMaxShapes = 4096;                                   // ~10-20 KB of code object each
 JitCache& cache() { static JitCache* c = new JitCache; return *c; }   // (leaked on purpose: the worker may outlive static destruction)
 
 void compile_one(JitKernel& k, const std::string& arch) {
@@ -119,6 +120,7 @@ void compile_one(JitKernel& k, const std::string& arch) {
     cache().failed++; k.state = -1; return;
   }
   if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] compiled %zu bytes in %.0f ms: %s\n", k.code.size(), k.compile_ms, k.key.c_str());
+  else { std::string().swap(k.source); std::string().swap(k.log); }      // (60 KB of text per shape: only the code object is kept)
   cache().compiled++; k.state = 1;
 }
 
@@ -157,6 +159,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
     std::unique_lock<std::mutex> lk(c.mu);
     auto it = c.map.find(key);
     if (it != c.map.end()) k = it->second;
+    else if (c.map.size() >= kMaxShapes) return nullptr;            // a process that has seen this many different program shapes keeps interpreting new ones
     else {
       k = std::make_shared<JitKernel>();
       k->key = key;

@@ -255,6 +255,33 @@ CASES += [
 ]
 
 
+# ---- round 4: the routes this round added, pinned to Julia-typed answers rather than to the oracle's: narrow columns through k_scan_cmp_narrow (Int8 /
+# UInt8 / Bool against Int64 / Float64 constants: Julia compares the exact values, so an out-of-range constant decides the comparison by itself), Float32
+# against a Float64 constant (0.1f0 is 0.100000001490116...: not below 0.1), and `coalesce(<string comparison>, false)` over a Union{String,Missing} column,
+# which K5 now answers itself (`==` / `!=` with missing are missing in Julia: Base.:(==)(::Missing, ::Any); startswith / endswith have no Missing method
+# in Base, so they are not claimed here)
+CASES += [
+    ("nullable_string_ne_coalesced", 'coalesce.(ns .!= "a", false)', col(NS) + cs("a") + op("NE") + cb(False) + op("COALESCE"), "Bool", [F, F, T, F, T], 'ir.coalesce(Ns != "a", False)'),
+    ("nullable_string_eq_empty_coalesced", 'coalesce.(ns .== "", false)', col(NS) + cs("") + op("EQ") + cb(False) + op("COALESCE"), "Bool", [F, F, T, F, F], 'ir.coalesce(Ns == "", False)'),
+    ("nullable_string_ne_empty_coalesced", 'coalesce.(ns .!= "", false)', col(NS) + cs("") + op("NE") + cb(False) + op("COALESCE"), "Bool", [T, F, F, F, T], 'ir.coalesce(Ns != "", False)'),
+    ("int8_gt_minus1", "i8 .> -1", col(I8C) + ci(-1) + op("GT"), "Bool", [F, F, T, T, T], "I8c > -1"),
+    ("int8_le_typemin", "i8 .<= -128", col(I8C) + ci(-128) + op("LE"), "Bool", [T, F, F, F, F], "I8c <= -128"),
+    ("int8_lt_constant_above_its_range", "i8 .< 1000", col(I8C) + ci(1000) + op("LT"), "Bool", [T, T, T, T, T], "I8c < 1000"),
+    ("int8_eq_constant_above_its_range", "i8 .== 128", col(I8C) + ci(128) + op("EQ"), "Bool", [F, F, F, F, F], "I8c == 128"),
+    ("int8_ne_constant_below_its_range", "i8 .!= -129", col(I8C) + ci(-129) + op("NE"), "Bool", [T, T, T, T, T], "I8c != -129"),
+    ("int8_ge_fraction", "i8 .>= 0.5", col(I8C) + cf(0.5) + op("GE"), "Bool", [F, F, F, T, T], "I8c >= 0.5"),
+    ("uint8_gt_negative_constant", "u .> -1", col(U) + ci(-1) + op("GT"), "Bool", [T, T, T, T, T], "Uc > -1"),
+    ("uint8_eq_255", "u .== 255", col(U) + ci(255) + op("EQ"), "Bool", [F, F, F, F, T], "Uc == 255"),
+    ("uint8_ge_128", "u .>= 128", col(U) + ci(128) + op("GE"), "Bool", [F, F, F, T, T], "Uc >= 128"),
+    ("uint8_lt_fraction", "u .< 127.5", col(U) + cf(127.5) + op("LT"), "Bool", [T, T, T, F, F], "Uc < 127.5"),
+    ("uint8_le_constant_above_its_range", "u .<= 256", col(U) + ci(256) + op("LE"), "Bool", [T, T, T, T, T], "Uc <= 256"),
+    ("bool_eq_true", "b .== true", col(B) + cb(True) + op("EQ"), "Bool", [T, F, T, F, T], "Bc == True"),
+    ("bool_ne_true", "b .!= true", col(B) + cb(True) + op("NE"), "Bool", [F, T, F, T, F], "Bc != True"),
+    ("float32_tenth_is_not_below_the_float64_tenth", "f .< 0.1", col(FF) + cf(0.1) + op("LT"), "Bool", [F, T, F, F, F], "Ff < 0.1"),
+    ("float32_ge_integer_constant", "f .>= 3", col(FF) + ci(3) + op("GE"), "Bool", [F, F, T, F, T], "Ff >= 3"),
+    ("float32_ne_nan_row", "f .!= 3", col(FF) + ci(3) + op("NE"), "Bool", [T, T, T, T, F], "Ff != 3"),
+]
+
 def main():
     out = {"comment": "hand-assembled from include/dfdb_ir.h by tests/golden/make_ir_golden.py; expected = Julia semantics",
            "table": {"a": [-7, -1, 0, 3, 10], "x": [0.5, -2.0, 3.0, 1e10, "NaN"], "s": ["apple", "sony", "", "sonic", "xs"],
