@@ -134,6 +134,7 @@ void worker_main(std::string arch) {
       k = c.queue.front(); c.queue.pop_front();
     }
     compile_one(*k, arch);
+    { std::lock_guard<std::mutex> lk(c.mu); }      // (a waiter that has just found state == 0 is inside cv.wait by now: the notification cannot slip past it)
     c.cv.notify_all();
   }
 }
