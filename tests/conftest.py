@@ -24,7 +24,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def dfdb_mod():
-    # (see `ctx` below: where there is a GPU, torch's copy of the HIP runtime opens it before the engine's does — whichever fixture a test asks for first)
+    # (see `ctx` below: torch is imported — and its HIP runtime loaded — before libdfdb_hip.so, whichever fixture a test asks for first)
     try:
         import torch
         if torch.cuda.is_available():
@@ -38,9 +38,9 @@ def dfdb_mod():
 @pytest.fixture(scope="session")
 def ctx(dfdb_mod):
     """One engine context on cuda:0 for the whole GPU session.  Fails loudly without the HIP library / a GPU."""
-    import torch  # torch brings its own copy of the HIP / HSA runtime (another soname than the system one libdfdb_hip.so links): both live in this process
-    # ... and the copy that opens the GPU SECOND must be the system one: torch's runtime finds "No HIP GPUs" once the system runtime holds /dev/kfd, the other
-    # order works.  Tests that use torch tensors (full-size buffers, bitmaps on the device) would otherwise depend on which test touched the GPU first.
+    import torch  # torch bundles its own libamdhip64.so, with the soname libamdhip64.so.7 that libdfdb_hip.so asks for: loaded FIRST, the engine binds to that
+    # copy and the process holds ONE HIP runtime (streams, events and RCCL handles are shared: bench.py relies on it).  Loaded second, torch's libraries (which
+    # ask for "libamdhip64.so") bring a second copy that finds "No HIP GPUs" once the first holds /dev/kfd.  dfdb_mod above imports torch first for the same reason.
     torch.cuda.init()
     c = dfdb_mod.default_context(0)
     if os.environ.get("DFDB_TEST_JIT") == "1":       # soak: every interpreter program of every test runs as its hipRTC-compiled kernel (0.2-0.4 s per new shape)
