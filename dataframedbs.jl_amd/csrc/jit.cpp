@@ -15,6 +15,8 @@
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -87,6 +89,7 @@ struct JitCache {
   std::unordered_map<std::string, std::shared_ptr<JitKernel>> map;
   std::deque<std::shared_ptr<JitKernel>> queue;
   std::thread worker; bool started = false;
+  bool busy = false, stopping = false;          // the worker is inside hipRTC / the process is exiting (guarded by mu)
   std::atomic<int64_t> compiled{0}, failed{0};
 };
 constexpr size_t kMaxShapes = 4096;                                   // ~10-20 KB of code object each
@@ -130,13 +133,26 @@ void worker_main(std::string arch) {
     std::shared_ptr<JitKernel> k;
     {
       std::unique_lock<std::mutex> lk(c.mu);
-      c.cv.wait(lk, [&] { return !c.queue.empty(); });
+      c.cv.wait(lk, [&] { return !c.queue.empty() || c.stopping; });
+      if (c.stopping) return;
       k = c.queue.front(); c.queue.pop_front();
+      c.busy = true;
     }
     compile_one(*k, arch);
-    { std::lock_guard<std::mutex> lk(c.mu); }      // (a waiter that has just found state == 0 is inside cv.wait by now: the notification cannot slip past it)
+    { std::lock_guard<std::mutex> lk(c.mu); c.busy = false; }      // (a waiter that has just found state == 0 is inside cv.wait by now: the notification cannot slip past it)
     c.cv.notify_all();
   }
+}
+// exit(): the compiler thread must not be inside hipRTC / comgr while their static objects are destroyed.  Registered after hipRTC was loaded, so it runs before
+// their own exit handlers: pending shapes are dropped, a compile in flight is given ten seconds to finish.
+void jit_at_exit() {
+  JitCache& c = cache();
+  std::unique_lock<std::mutex> lk(c.mu);
+  c.stopping = true;
+  for (auto& k : c.queue) k->state = -1;
+  c.queue.clear();
+  c.cv.notify_all();
+  c.cv.wait_for(lk, std::chrono::seconds(10), [&] { return !c.busy; });
 }
 }  // namespace
 
@@ -160,7 +176,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
     std::unique_lock<std::mutex> lk(c.mu);
     auto it = c.map.find(key);
     if (it != c.map.end()) k = it->second;
-    else if (c.map.size() >= kMaxShapes) return nullptr;            // a process that has seen this many different program shapes keeps interpreting new ones
+    else if (c.map.size() >= kMaxShapes || c.stopping) return nullptr;            // a process that has seen this many different program shapes keeps interpreting new ones
     else {
       k = std::make_shared<JitKernel>();
       k->key = key;
@@ -215,7 +231,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
       k->source = std::move(s);
       c.map.emplace(key, k);
       c.queue.push_back(k);
-      if (!c.started) { c.started = true; c.worker = std::thread(worker_main, std::string(ctx->prop.gcnArchName)); c.worker.detach(); }
+      if (!c.started) { c.started = true; c.worker = std::thread(worker_main, std::string(ctx->prop.gcnArchName)); c.worker.detach(); std::atexit(jit_at_exit); }
       c.cv.notify_all();
     }
     if (wait) c.cv.wait(lk, [&] { return k->state.load() != 0; });

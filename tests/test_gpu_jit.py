@@ -132,3 +132,28 @@ def test_compiled_kernels_large_properties(dfdb_mod, ctx):
     for c0, c1 in zip(outs[0], outs[2]):
         assert np.array_equal(c0.view(np.uint8), c1.view(np.uint8))
     t.close()
+
+
+def test_exit_while_the_compiler_is_busy(ctx):
+    """a process that ends while the background compiler is inside hipRTC must end cleanly (exit status 0, no crash in comgr's static destructors): the
+    engine's exit handler drops pending shapes and waits for the compile in flight"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'dataframedbs.jl_amd')!r}]\n"
+        "import torch; torch.cuda.init()\n"
+        "import dfdb\n"
+        "from dfdb import ir\n"
+        "ctx = dfdb.default_context(0)\n"
+        "ctx.set_option('jit', 1); ctx.set_option('jit_min_rows', 0)\n"
+        "t = dfdb.DFTable.new(ctx=ctx)\n"
+        "t.add_generated('a', dfdb.GEN_I64_MOD1M, 1, 100000)\n"
+        "n = 0\n"
+        "for k in range(6):\n"                      # six new shapes queued: the first is being compiled when the process ends
+        "    n += t[abs(ir.col(0) * (k + 2)) % (k + 3) > k, dfdb.ALL]._query().count()\n"
+        "print('counted', n)\n")
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode(errors="replace")[-2000:])
+    assert b"counted" in p.stdout
