@@ -552,7 +552,21 @@ def f_rows_legs(L, dfdb, sc, rank):
         dt = time.perf_counter() - t0
         nd = len(u); best = dt if best is None else min(best, dt)
     res["unique"] = {"rows": n, "distinct": nd, "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
-                     "what": "unique(t.x) over Int64 h mod 1e6: hash table of first occurrences in HBM, distinct values fetched to the host in order of first appearance; best of 3"}
+                     "what": "unique(t.x) over Int64 h mod 1e6: the keys span < 1 277 952, so a presence bit per value in LDS (one pass over the column) + the first rows from row-ordered "
+                             "launches that stop once every value is found (k_unique.hip, dense form); distinct values fetched to the host in order of first appearance; best of 3"}
+    ctx.set_option("unique_dense", 0)                           # the same column through the general form: the hash table that grows with the distinct values met
+    try:
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            u = t.x.unique()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    finally:
+        ctx.set_option("unique_dense", 1)
+    res["unique_hash_table"] = {"rows": n, "distinct": len(u), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
+                                "what": "the same unique with ctx option unique_dense = 0: open-addressing table of {key, first row} sized by the distinct values as they turn up (what Float64 keys, "
+                                        "wide-ranged integers and String hashes take); best of 2"}
     t.close()
     # ---- groupreduce by a String key, flat and with the dictionary
     n = int(500_000_000 * sc)

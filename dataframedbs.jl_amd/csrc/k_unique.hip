@@ -3,14 +3,22 @@
 // Replaces Base.unique driven by Base.iterate(::DFColumn) (src/tables/column.jl:102-126; docs/src/index.md:171-182,
 // 479-486: "unique(t.brand[t.brand .!= ""])", 7-11 MRows/s in the reference).  Julia's unique keeps the FIRST occurrence
 // of every value in iteration order and compares with isequal (NaN == NaN, 0.0 != -0.0, missing == missing).  Here:
-//   pass 1  every selected row inserts (key, row) into an open-addressing table in HBM: 64-bit atomicCAS claims the slot of
-//           a key, 64-bit atomicMin keeps the smallest row that holds it;
-//   pass 2  every selected row looks its key up and keeps its bit iff it IS that smallest row -> the bitmap of first
-//           occurrences (+ per-tile counts), and the ordinary count / gather / materialize machinery returns the distinct
-//           values in order of first appearance.  No sort.
+//   insert  every selected row puts (key, row) into an open-addressing table of 16-byte {key, smallest row} entries in HBM:
+//           a 64-bit atomicCAS claims the slot of a key, a 64-bit atomicMin keeps the smallest row that holds it — both behind
+//           plain loads, so a row whose key is in place with a smaller row recorded touches one cache line and no atomic;
+//   mark    the bitmap of first occurrences (+ per-tile counts): SCATTERED out of the table when the distinct values are few
+//           beside the rows (one bit per occupied slot), else every selected row looks its key up and keeps its bit iff it IS
+//           that smallest row; the ordinary count / gather / materialize machinery then returns the distinct values in order
+//           of first appearance.  No sort.
+// The table is sized by the DISTINCT values, which nobody knows beforehand (round 4; it used to be sized by the selected rows:
+// 34 GB of table for 1e9 rows of 1e6 values, every probe a miss in every cache — 86 ms, this form 7x less): the host feeds the
+// rows in three chunks (1 M rows, 16 M, the rest), reads the number of claimed slots after each, estimates the distinct count
+// of the whole selection from it (query.cpp: unique_capacity_wanted) and MIGRATES the entries to a larger table when needed; a
+// probe sequence of kMaxProbe slots raises an abort flag, the host grows the table and repeats that chunk (inserts are idempotent).
 // Fixed-width values are their own keys.  A String's key is a salted 64-bit hash of its bytes; the slot remembers where one
-// holder's bytes start, pass 1b compares every selected row with that representative and reports a true hash collision
+// holder's bytes start, a verify pass compares every selected row with that representative and reports a true hash collision
 // (two different strings, one key), in which case the host repeats with another salt: the result is exact, not probabilistic.
+// Integer keys of a small range take the dense form at the end of this file instead (no hashing: a presence bit per value in LDS).
 #include "device_utils.hpp"
 #include "kernels.hpp"
 #include "../../include/dfdb_ir.h"
@@ -20,7 +28,11 @@ namespace dfdb {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = 4;
 constexpr int64_t kTile = 1024;
-constexpr uint64_t kEmpty = 0xFFFFFFFFFFFFFFFFull;    // never stored as a key: a value with this image uses special[0]
+constexpr uint64_t kEmpty = 0xFFFFFFFFFFFFFFFFull;    // never stored as a key: a value with this image uses aux[0]
+constexpr int kMaxProbe = 256;                        // a longer probe sequence means the table is too full: abort, the host grows it
+// aux (8 x u64 beside the table): 0 = smallest row whose key is kEmpty, 1 = smallest missing row, 2 = claimed slots, 3 = abort flag, 4 = (int) hash collision seen
+constexpr int kAuxClaims = 2, kAuxAbort = 3;
+constexpr uint64_t kNoSlot = 0xFFFFFFFFFFFFFFFFull;
 
 __device__ __forceinline__ uint64_t slot_of(uint64_t key, uint64_t mask) { return splitmix64(key) & mask; }
 
@@ -39,44 +51,79 @@ __device__ __forceinline__ uint64_t key_fixed(const void* col, int dtype, int64_
   }
 }
 
-__device__ __forceinline__ uint64_t table_insert(uint64_t* keys, uint64_t* rows, uint64_t mask, uint64_t key, uint64_t row) {
-  uint64_t h = slot_of(key, mask);
-  for (;;) {
-    // plain loads first: with few distinct values nearly every row finds its key in place and a smaller row recorded, and
-    // skips both atomics (5e8 rows of 10 distinct strings: 0.60 s with every row hammering the same 10 addresses, 0.023 s so)
-    uint64_t old = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
-    if (old == kEmpty) old = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)kEmpty, (unsigned long long)key);
+// -> the key's slot, bit 63 set when the key was already there (clear: this call claimed the slot), kNoSlot when the probe sequence got too long
+// (h: where the probe sequence starts — slot_of(key) for values that are their own keys, the low bits of a String's key, which is a hash already)
+__device__ __forceinline__ uint64_t table_insert(UniqueEntry* ent, uint64_t mask, uint64_t key, uint64_t row, uint64_t* aux, uint64_t h) {
+  for (int probes = 0; probes < kMaxProbe; probes++) {
+    // plain loads first (key and row of a slot share a line): with few distinct values nearly every row finds its key in place and a smaller row
+    // recorded, and skips both atomics (5e8 rows of 10 distinct strings: 0.60 s with every row hammering the same 10 addresses, 0.023 s so).  A
+    // stale line (the XCDs' L2s are not coherent) shows an emptier slot or a larger row than memory holds: an atomic too many, never one too few
+    uint64_t old = __atomic_load_n(&ent[h].key, __ATOMIC_RELAXED);
+    const uint64_t seen = __atomic_load_n(&ent[h].row, __ATOMIC_RELAXED);
+    if (old == kEmpty) old = atomicCAS((unsigned long long*)&ent[h].key, (unsigned long long)kEmpty, (unsigned long long)key);
     if (old == kEmpty || old == key) {
-      if (__atomic_load_n(&rows[h], __ATOMIC_RELAXED) > row) atomicMin((unsigned long long*)&rows[h], (unsigned long long)row);
+      if (seen > row) atomicMin((unsigned long long*)&ent[h].row, (unsigned long long)row);
       return old == kEmpty ? h : (h | (1ull << 63));
     }
     h = (h + 1) & mask;
   }
+  __atomic_store_n(&aux[kAuxAbort], 1ull, __ATOMIC_RELAXED);
+  return kNoSlot;
 }
-__device__ __forceinline__ uint64_t table_find(const uint64_t* keys, uint64_t mask, uint64_t key) {
-  uint64_t h = slot_of(key, mask);
-  while (keys[h] != key) h = (h + 1) & mask;     // present by construction (pass 1 inserted it)
+__device__ __forceinline__ uint64_t table_find(const UniqueEntry* ent, uint64_t mask, uint64_t key, uint64_t h) {
+  while (ent[h].key != key) h = (h + 1) & mask;     // present by construction (the insert pass put it there)
   return h;
+}
+// a workgroup's claimed slots -> aux[kAuxClaims] (one atomic per workgroup)
+__device__ __forceinline__ void add_claims(uint32_t mine, uint32_t* sh, uint64_t* aux) {
+  if (mine) atomicAdd(sh, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && *sh) atomicAdd((unsigned long long*)&aux[kAuxClaims], (unsigned long long)*sh);
 }
 
 // ---------------------------------------------------------------- fixed-width columns
 __global__ __launch_bounds__(kBlock) void k_unique_insert(const uint64_t* __restrict__ bitmap, const void* __restrict__ col, int dtype,
-                                                          const uint64_t* __restrict__ missing, int64_t nrows, uint64_t* keys, uint64_t* rows,
-                                                          uint64_t mask, uint64_t* special) {
+                                                          const uint64_t* __restrict__ missing, int64_t row0, int64_t row1, UniqueEntry* ent,
+                                                          uint64_t mask, uint64_t* aux) {
+  __shared__ uint32_t claims_sh;
+  if (threadIdx.x == 0) claims_sh = 0;
+  __syncthreads();
+  uint32_t mine = 0;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+  for (int64_t row = row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; row < row1; row += stride) {
     if (!((bitmap[row >> 6] >> (row & 63)) & 1ull)) continue;
-    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) { if (__atomic_load_n(&special[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&special[1], (unsigned long long)row); continue; }
+    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) { if (__atomic_load_n(&aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[1], (unsigned long long)row); continue; }
     const uint64_t key = key_fixed(col, dtype, row);
-    if (key == kEmpty) { if (__atomic_load_n(&special[0], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&special[0], (unsigned long long)row); continue; }
-    table_insert(keys, rows, mask, key, (uint64_t)row);
+    if (key == kEmpty) { if (__atomic_load_n(&aux[0], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[0], (unsigned long long)row); continue; }
+    const uint64_t r = table_insert(ent, mask, key, (uint64_t)row, aux, slot_of(key, mask));
+    if (r == kNoSlot) break;                          // the table is too full: the host grows it and repeats the chunk
+    mine += (uint32_t)!(r >> 63);
   }
+  add_claims(mine, &claims_sh, aux);
+}
+
+// the entries of a table that became too small, into its successor (strings: with their representatives)
+__global__ __launch_bounds__(kBlock) void k_unique_migrate(const UniqueEntry* __restrict__ from, const uint64_t* __restrict__ from_off, const uint32_t* __restrict__ from_len,
+                                                           uint64_t from_cap, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask, uint64_t* aux) {
+  __shared__ uint32_t claims_sh;
+  if (threadIdx.x == 0) claims_sh = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < from_cap; i += stride) {
+    const uint64_t key = from[i].key;
+    if (key == kEmpty) continue;
+    const uint64_t r = table_insert(ent, mask, key, from[i].row, aux, from_off ? (key & mask) : slot_of(key, mask));
+    if (r == kNoSlot) break;
+    mine += (uint32_t)!(r >> 63);
+    if (from_off && !(r >> 63)) { rep_off[r] = from_off[i]; rep_len[r] = from_len[i]; }
+  }
+  add_claims(mine, &claims_sh, aux);
 }
 
 __global__ __launch_bounds__(kBlock) void k_unique_mark(uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, const void* __restrict__ col,
                                                         int dtype, const uint64_t* __restrict__ missing, int64_t nrows, int64_t ntiles,
-                                                        const uint64_t* __restrict__ keys, const uint64_t* __restrict__ rows, uint64_t mask,
-                                                        const uint64_t* __restrict__ special) {
+                                                        const UniqueEntry* __restrict__ ent, uint64_t mask, const uint64_t* __restrict__ aux) {
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -90,10 +137,10 @@ __global__ __launch_bounds__(kBlock) void k_unique_mark(uint64_t* __restrict__ b
       if (w) {
         const int64_t row = tile * kTile + j * 64 + lane;
         if (row < nrows && ((w >> lane) & 1ull)) {
-          if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) first = special[1] == (uint64_t)row;
+          if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) first = aux[1] == (uint64_t)row;
           else {
             const uint64_t key = key_fixed(col, dtype, row);
-            first = key == kEmpty ? special[0] == (uint64_t)row : rows[table_find(keys, mask, key)] == (uint64_t)row;
+            first = key == kEmpty ? aux[0] == (uint64_t)row : ent[table_find(ent, mask, key, slot_of(key, mask))].row == (uint64_t)row;
           }
         }
       }
@@ -106,90 +153,226 @@ __global__ __launch_bounds__(kBlock) void k_unique_mark(uint64_t* __restrict__ b
   }
 }
 
-// ---------------------------------------------------------------- String columns (FlatStringsVector: sizes + arena, offsets per 1024-row tile)
-__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int32_t len, uint64_t salt) {
-  uint64_t h = splitmix64(salt ^ (uint64_t)(uint32_t)len);
-  int32_t k = 0;
-  for (; k + 8 <= len; k += 8) { uint64_t v; __builtin_memcpy(&v, p + k, 8); h = splitmix64(h ^ v); }
-  uint64_t tail = 0;
-  for (int b = 0; k < len; k++, b += 8) tail |= (uint64_t)p[k] << b;
-  return splitmix64(h ^ tail);
+// the first occurrences straight out of the table (few distinct values beside the rows): one bit + one tile count per occupied slot, into a
+// bitmap and tile counts the host has cleared
+__global__ __launch_bounds__(kBlock) void k_unique_scatter(const UniqueEntry* __restrict__ ent, uint64_t cap, const uint64_t* __restrict__ aux,
+                                                           uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < cap + 2; i += stride) {
+    uint64_t r;
+    if (i < cap) { if (ent[i].key == kEmpty) continue; r = ent[i].row; }
+    else { r = aux[i - cap]; if (r == kEmpty) continue; }
+    atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63));
+    atomicAdd(&tile_counts[r >> 10], 1u);
+  }
 }
 
-// MODE 0: insert (hash, row) and remember one holder's bytes; 1: verify every selected row against its slot's representative;
-// 2: mark first occurrences.  One wave per 1024-row tile: the rows' byte offsets are a wave prefix sum of the sizes.
+// ---------------------------------------------------------------- String columns (FlatStringsVector: sizes + arena, offsets per 1024-row tile)
+// A String's 64-bit key.  `head` = its first 8 bytes (as loaded: bytes past its end are masked here).  Two 32-bit lanes of state, one 32-bit multiply each per
+// 8 bytes and two to finish (64-bit multiplies are four quarter-rate instructions each on this chip: three rounds of splitmix64 per row were ~500 of the ~1000
+// cycles a wave spent per 64 rows, and the pass ran at the speed of the multiplier, not of memory).  Every step is a bijection of the state for a given chunk, so
+// two different strings of one length <= 8 never share a key; any others that do are found by the compare against the slot's representative, and the salt changes.
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
+__device__ __forceinline__ void hash_chunk(uint32_t& a, uint32_t& b, uint64_t v) {
+  a = (a ^ (uint32_t)v) * 0x85EBCA6Bu;
+  b = (b ^ (uint32_t)(v >> 32)) * 0xC2B2AE35u;
+  a = rotl32(a, 15) + b;
+  b = rotl32(b, 13) ^ a;
+}
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int32_t len, uint64_t salt, uint64_t head) {
+  uint32_t a = (uint32_t)salt ^ __umul24((uint32_t)len & 0xFFFFFFu, 0x9E3779u), b = (uint32_t)(salt >> 32) + ((uint32_t)len >> 24);
+  int32_t k = 0;
+  if (len >= 8) {
+    hash_chunk(a, b, head);
+    for (k = 8; k + 8 <= len; k += 8) { uint64_t v; __builtin_memcpy(&v, p + k, 8); hash_chunk(a, b, v); }
+  }
+  if (k < len) {
+    uint64_t tail = head;
+    if (k) __builtin_memcpy(&tail, p + k, 8);                       // (the arena ends in 16 bytes of padding: an 8-byte probe never faults)
+    hash_chunk(a, b, tail & (~0ull >> (64 - 8 * (len - k))));
+  }
+  a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13;
+  b ^= a; b *= 0xC2B2AE35u; b ^= b >> 16;
+  a ^= b;
+  return ((uint64_t)a << 32) | b;
+}
+// The strings of 256 rows of a 1024-row tile as a wave holds them: lane l has rows (4 g + k) * 64 + l, k = 0 .. 3 — sizes, byte offsets (a wave prefix sum of the
+// sizes per 64 rows, `run` carries on from group to group) and the first 8 bytes of every selected string, the four size loads and then the four byte loads
+// in flight together (one dependent load at a time per lane, as the loop over the sixteen words used to run, is 3.3 ms per pass over 5e8 short strings)
+constexpr int kStrGroup = 4;
+struct StrGroup { int32_t sz[kStrGroup]; int64_t off[kStrGroup]; uint64_t head[kStrGroup]; };
+__device__ __forceinline__ void load_str_group(StrGroup& T, const int32_t* __restrict__ sizes, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t tile, int g,
+                                               int lane, uint64_t mine, int64_t& run) {
+  const int64_t base = tile * kTile + (int64_t)g * kStrGroup * 64;
+  if (base + kStrGroup * 64 <= nrows) {
+#pragma unroll
+    for (int k = 0; k < kStrGroup; k++) T.sz[k] = sizes[base + k * 64 + lane];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kStrGroup; k++) { const int64_t row = base + k * 64 + lane; T.sz[k] = row < nrows ? sizes[row] : 0; }
+  }
+#pragma unroll
+  for (int k = 0; k < kStrGroup; k++) {
+    const uint32_t c = T.sz[k] > 0 ? (uint32_t)T.sz[k] : 0u;
+    const uint32_t incl = wave_incl_scan(c);
+    T.off[k] = run + (int64_t)(incl - c);
+    run += (int64_t)__shfl(incl, 63, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < kStrGroup; k++) {
+    const uint64_t w = __shfl(mine, g * kStrGroup + k, 64);
+    uint64_t v = 0;
+    if (((w >> lane) & 1ull) && T.sz[k] > 0) __builtin_memcpy(&v, bytes + T.off[k], 8);
+    T.head[k] = v;
+  }
+}
+
+// What a wave has already met: short strings (<= 8 bytes: length + bytes fit one entry and identify the string EXACTLY) in a direct-mapped cache in LDS, one per wave.
+// A wave walks its tiles, the words of a tile and the lanes of a word in increasing row order, so whatever it does for a string the first time it meets it — insert
+// its key with that row (smaller than any row it will meet later), compare it with its slot's representative, find its group — holds for every later meeting:
+// those rows touch neither the hash nor the table.  With few distinct values that is nearly every row (5e8 rows of ten brands: all of them hammered the same ten
+// cache lines of one L2 channel or two per XCD, 3.4 ms per pass).  An entry has ONE writer per instruction: lanes that want a slot write their lane number beside
+// it first, the one that reads its own number back writes the 16 bytes (two lanes storing different entries to one slot in the same instruction could tear it).
+constexpr int kMetSlots = 256;
+struct MetEntry { uint64_t head; uint32_t len, val; };
+struct MetCache {
+  MetEntry* e; uint32_t* claim;
+  __device__ __forceinline__ void init(MetEntry* entries, uint32_t* claims, int lane) {
+    e = entries; claim = claims;
+    for (int i = lane; i < kMetSlots; i += 64) e[i].len = 0xFFFFFFFFu;
+  }
+  static __device__ __forceinline__ uint32_t slot(uint64_t head, uint32_t len) {
+    uint32_t x = ((uint32_t)head ^ ((uint32_t)(head >> 32) * 0x9E3779B1u) ^ (len * 0x85EBCA6Bu)) * 0x9E3779B1u;
+    return x >> 24;
+  }
+  __device__ __forceinline__ bool find(uint64_t head, uint32_t len, uint32_t& val) const {
+    const MetEntry x = e[slot(head, len)];
+    val = x.val;
+    // the value is read HERE, with the tag: left to the compiler the load sinks into the caller's hit branch, which may run after the miss branch of other
+    // lanes of the same instruction has overwritten the slot (found by the forms test: rows counted for a neighbouring group)
+    asm volatile("" : "+v"(val));
+    return x.len == len && x.head == head;
+  }
+  __device__ __forceinline__ void put(uint64_t head, uint32_t len, uint32_t val, int lane) {
+    const uint32_t s = slot(head, len);
+    claim[s] = (uint32_t)lane;
+    asm volatile("" ::: "memory");                           // the read-back must be a read (of LDS, not of the register just stored): it decides which lane goes on
+    if (claim[s] == (uint32_t)lane) { MetEntry x; x.head = head; x.len = len; x.val = val; e[s] = x; }
+  }
+};
+__device__ __forceinline__ uint64_t head_of(uint64_t loaded, int32_t len) { return len >= 8 ? loaded : (len > 0 ? loaded & (~0ull >> (64 - 8 * len)) : 0ull); }
+
+// do the two strings hold the same bytes?  (8 at a time; both live in the padded arena)
+__device__ __forceinline__ bool same_bytes(const uint8_t* a, int32_t la, const uint8_t* b, uint32_t lb) {
+  if ((uint32_t)la != lb) return false;
+  int32_t k = 0;
+  for (; k + 8 <= la; k += 8) { uint64_t x, y; __builtin_memcpy(&x, a + k, 8); __builtin_memcpy(&y, b + k, 8); if (x != y) return false; }
+  if (k < la) { uint64_t x, y; __builtin_memcpy(&x, a + k, 8); __builtin_memcpy(&y, b + k, 8); if ((x ^ y) & (~0ull >> (64 - 8 * (la - k)))) return false; }
+  return true;
+}
+
+// MODE 0: insert (hash, row) for the tiles [tile0, tile1) and remember one holder's bytes; 1: verify every selected row against its slot's
+// representative; 2: mark first occurrences.  One wave per 1024-row tile: the rows' byte offsets are a wave prefix sum of the sizes.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_unique_str(uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, const int32_t* __restrict__ sizes,
-                                                       const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t ntiles,
-                                                       uint64_t* keys, uint64_t* rows, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
-                                                       uint64_t* special, uint64_t salt, int* __restrict__ collision) {
+                                                       const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t tile0, int64_t tile1,
+                                                       UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
+                                                       uint64_t* aux, uint64_t salt) {
+  __shared__ uint32_t claims_sh;
+  __shared__ MetEntry met_e[MODE == 2 ? 1 : kWavesPerBlock][MODE == 2 ? 1 : kMetSlots];
+  __shared__ uint32_t met_c[MODE == 2 ? 1 : kWavesPerBlock][MODE == 2 ? 1 : kMetSlots];
+  if (MODE == 0) { if (threadIdx.x == 0) claims_sh = 0; __syncthreads(); }
+  uint32_t claimed = 0;
+  int* collision = (int*)(aux + 4);
   const int lane = lane_id();
+  MetCache met;
+  if (MODE != 2) met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+  for (int64_t tile = tile0 + wave; tile < tile1; tile += nwaves) {
+    if (MODE == 0 && __atomic_load_n(&aux[kAuxAbort], __ATOMIC_RELAXED)) break;      // (wave-uniform) too full: the host grows the table and repeats the chunk
     const uint64_t mine = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
     if (__ballot(mine != 0) == 0) { if (MODE == 2 && lane == 0) tile_counts[tile] = 0; continue; }
-    int64_t run = tile_off[tile];
     uint64_t myword = 0; uint32_t cnt = 0;
-    for (int j = 0; j < 16; j++) {
+    int64_t run = tile_off[tile];
+#pragma unroll 1
+    for (int g = 0; g < 16 / kStrGroup; g++) {
+     StrGroup T;
+     load_str_group(T, sizes, bytes, nrows, tile, g, lane, mine, run);
+#pragma unroll
+     for (int k = 0; k < kStrGroup; k++) {
+      const int j = g * kStrGroup + k;
       const int64_t row = tile * kTile + j * 64 + lane;
-      const int32_t sz = row < nrows ? sizes[row] : 0;
-      const uint32_t c = sz > 0 ? (uint32_t)sz : 0u;
-      const uint32_t incl = wave_incl_scan(c);
-      const int64_t off = run + (int64_t)(incl - c);
-      run += (int64_t)__shfl(incl, 63, 64);
+      const int32_t sz = T.sz[k];
+      const int64_t off = T.off[k];
       const uint64_t w = __shfl(mine, j, 64);
       bool first = false;
       if (row < nrows && ((w >> lane) & 1ull)) {
         if (sz < 0) {                                                     // missing
-          if (MODE == 0) { if (__atomic_load_n(&special[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&special[1], (unsigned long long)row); }
-          else if (MODE == 2) first = special[1] == (uint64_t)row;
+          if (MODE == 0) { if (__atomic_load_n(&aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[1], (unsigned long long)row); }
+          else if (MODE == 2) first = aux[1] == (uint64_t)row;
         } else {
-          uint64_t key = hash_bytes(bytes + off, sz, salt);
-          if (key == kEmpty) key = 0x1234567ull;                         // (any fixed remap: equal strings still get equal keys)
-          if (MODE == 0) {
-            const uint64_t r = table_insert(keys, rows, mask, key, (uint64_t)row);
-            if (!(r >> 63)) { rep_off[r] = (uint64_t)off; rep_len[r] = (uint32_t)sz; }   // I claimed the slot: my bytes represent it
+          const uint64_t head = head_of(T.head[k], sz);
+          uint32_t unused;
+          if (MODE != 2 && sz <= 8 && met.find(head, (uint32_t)sz, unused)) {
+            // this wave has inserted / verified the very same string before, at a smaller row
           } else {
-            const uint64_t h = table_find(keys, mask, key);
-            if (MODE == 1) {
-              bool same = rep_len[h] == (uint32_t)sz;
-              const uint8_t* a = bytes + off; const uint8_t* b = bytes + rep_off[h];
-              for (int32_t k = 0; same && k < sz; k++) same = a[k] == b[k];
-              if (!same) atomicOr(collision, 1);
-            } else first = rows[h] == (uint64_t)row;
+            uint64_t key = hash_bytes(bytes + off, sz, salt, T.head[k]);
+            if (key == kEmpty) key = 0x1234567ull;                       // (any fixed remap: equal strings still get equal keys)
+            if (MODE == 0) {
+              const uint64_t r = table_insert(ent, mask, key, (uint64_t)row, aux, key & mask);
+              if (r != kNoSlot && !(r >> 63)) { rep_off[r] = (uint64_t)off; rep_len[r] = (uint32_t)sz; claimed++; }   // I claimed the slot: my bytes represent it
+              if (r != kNoSlot && sz <= 8) met.put(head, (uint32_t)sz, 1u, lane);
+            } else {
+              const uint64_t h = table_find(ent, mask, key, key & mask);
+              if (MODE == 1) {
+                if (!same_bytes(bytes + off, sz, bytes + rep_off[h], rep_len[h])) atomicOr(collision, 1);
+                else if (sz <= 8) met.put(head, (uint32_t)sz, 1u, lane);
+              } else first = ent[h].row == (uint64_t)row;
+            }
           }
         }
       }
       if (MODE == 2) { const uint64_t m = __ballot(first); if (lane == j) myword = m; cnt += (uint32_t)__popcll(m); }
+     }
     }
     if (MODE == 2) {
       if (lane < 16) bitmap[tile * 16 + lane] = myword;
       if (lane == 0) tile_counts[tile] = cnt;
     }
   }
+  if (MODE == 0) add_claims(claimed, &claims_sh, aux);
 }
 
 static int grid_rows(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 static int grid_tiles(int64_t nt) { int64_t b = (nt + kWavesPerBlock - 1) / kWavesPerBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 
-void launch_unique_fixed(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing,
-                         int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t mask, uint64_t* special) {
-  if (nrows <= 0) return;
-  const int64_t ntiles = (nrows + kTile - 1) / kTile;
-  if (pass == 0) hipLaunchKernelGGL(k_unique_insert, dim3(grid_rows(nrows)), dim3(kBlock), 0, s, bitmap, col, dtype, missing, nrows, keys, rows, mask, special);
-  else hipLaunchKernelGGL(k_unique_mark, dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, bitmap, tile_counts, col, dtype, missing, nrows, ntiles, keys, rows, mask, special);
+void launch_unique_insert(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1,
+                          UniqueEntry* ent, uint64_t mask, uint64_t* aux) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(k_unique_insert, dim3(grid_rows(row1 - row0)), dim3(kBlock), 0, s, bitmap, col, dtype, missing, row0, row1, ent, mask, aux);
 }
-
-void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
-                       const uint8_t* bytes, int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
-                       uint64_t* special, uint64_t salt, int* collision) {
+void launch_unique_mark(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing, int64_t nrows,
+                        const UniqueEntry* ent, uint64_t mask, const uint64_t* aux) {
   if (nrows <= 0) return;
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
-  const dim3 g(grid_tiles(ntiles)), b(kBlock);
-  if (pass == 0) hipLaunchKernelGGL((k_unique_str<0>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, ntiles, keys, rows, rep_off, rep_len, mask, special, salt, collision);
-  else if (pass == 1) hipLaunchKernelGGL((k_unique_str<1>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, ntiles, keys, rows, rep_off, rep_len, mask, special, salt, collision);
-  else hipLaunchKernelGGL((k_unique_str<2>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, ntiles, keys, rows, rep_off, rep_len, mask, special, salt, collision);
+  hipLaunchKernelGGL(k_unique_mark, dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, bitmap, tile_counts, col, dtype, missing, nrows, ntiles, ent, mask, aux);
+}
+void launch_unique_migrate(hipStream_t s, const UniqueEntry* from, const uint64_t* from_off, const uint32_t* from_len, uint64_t from_cap, UniqueEntry* ent,
+                           uint64_t* rep_off, uint32_t* rep_len, uint64_t mask, uint64_t* aux) {
+  hipLaunchKernelGGL(k_unique_migrate, dim3(grid_rows((int64_t)from_cap)), dim3(kBlock), 0, s, from, from_off, from_len, from_cap, ent, rep_off, rep_len, mask, aux);
+}
+void launch_unique_scatter(hipStream_t s, const UniqueEntry* ent, uint64_t cap, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts) {
+  hipLaunchKernelGGL(k_unique_scatter, dim3(grid_rows((int64_t)cap + 2)), dim3(kBlock), 0, s, ent, cap, aux, bitmap, tile_counts);
+}
+void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
+                       const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
+                       uint64_t* aux, uint64_t salt) {
+  if (tile1 <= tile0) return;
+  const dim3 g(grid_tiles(tile1 - tile0)), b(kBlock);
+  if (pass == 0) hipLaunchKernelGGL((k_unique_str<0>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
+  else if (pass == 1) hipLaunchKernelGGL((k_unique_str<1>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
+  else hipLaunchKernelGGL((k_unique_str<2>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
 }
 
 // ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
@@ -208,10 +391,10 @@ __device__ __forceinline__ uint64_t rank_of_row(const uint64_t* __restrict__ ubi
   for (uint64_t k = 0; k < w; k++) r += (uint64_t)__popcll(ubits[tile * 16 + k]);
   return r + (uint64_t)__popcll(ubits[tile * 16 + w] & ((1ull << (row & 63)) - 1ull));
 }
-__global__ __launch_bounds__(kBlock) void k_group_ids(const uint64_t* __restrict__ keys, uint64_t* __restrict__ rows, uint64_t cap, uint64_t* __restrict__ special,
+__global__ __launch_bounds__(kBlock) void k_group_ids(UniqueEntry* __restrict__ ent, uint64_t cap, uint64_t* __restrict__ special,
                                                       const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < cap && keys[i] != kEmpty) rows[i] = rank_of_row(ubits, uprefix, rows[i]);
+  if (i < cap && ent[i].key != kEmpty) ent[i].row = rank_of_row(ubits, uprefix, ent[i].row);
   if (i < 2 && special[i] != kEmpty) special[i] = rank_of_row(ubits, uprefix, special[i]);
 }
 
@@ -261,7 +444,7 @@ __device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
                                                              const void* __restrict__ valcol, int valdt, int op, int64_t nrows,
-                                                             const uint64_t* __restrict__ keys, const uint64_t* __restrict__ gids, uint64_t mask,
+                                                             const UniqueEntry* __restrict__ ent, uint64_t mask,
                                                              const uint64_t* __restrict__ special, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
   __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
   const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
@@ -272,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __r
     if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
     uint64_t gid;
     if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) gid = special[1];
-    else { const uint64_t key = key_fixed(keycol, keydt, row); gid = key == kEmpty ? special[0] : gids[table_find(keys, mask, key)]; }
+    else { const uint64_t key = key_fixed(keycol, keydt, row); gid = key == kEmpty ? special[0] : ent[table_find(ent, mask, key, slot_of(key, mask))].row; }
     int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
     val_kind = kind;
     if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
@@ -289,33 +472,54 @@ __global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __r
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_group_accumulate_str(const uint64_t* __restrict__ sel, const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
                                                                  const uint8_t* __restrict__ bytes, const void* __restrict__ valcol, int valdt, int op, int64_t nrows, int64_t ntiles,
-                                                                 const uint64_t* __restrict__ keys, const uint64_t* __restrict__ gids, uint64_t mask,
-                                                                 const uint64_t* __restrict__ special, uint64_t salt, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
+                                                                 const UniqueEntry* __restrict__ ent, const uint64_t* __restrict__ rep_off, const uint32_t* __restrict__ rep_len, uint64_t mask,
+                                                                 uint64_t* __restrict__ special, uint64_t salt, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
   __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
+  __shared__ MetEntry met_e[kWavesPerBlock][kMetSlots];
+  __shared__ uint32_t met_c[kWavesPerBlock][kMetSlots];
   const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
   if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
   const int lane = lane_id();
+  MetCache met;
+  met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const uint64_t mine = lane < 16 ? sel[tile * 16 + lane] : 0ull;
     if (__ballot(mine != 0) == 0) continue;
     int64_t run = tile_off[tile];
-    for (int j = 0; j < 16; j++) {
+#pragma unroll 1
+    for (int g = 0; g < 16 / kStrGroup; g++) {
+     StrGroup T;
+     load_str_group(T, sizes, bytes, nrows, tile, g, lane, mine, run);
+#pragma unroll
+     for (int k = 0; k < kStrGroup; k++) {
+      const int j = g * kStrGroup + k;
       const int64_t row = tile * kTile + j * 64 + lane;
-      const int32_t sz = row < nrows ? sizes[row] : 0;
-      const uint32_t c = sz > 0 ? (uint32_t)sz : 0u;
-      const uint32_t incl = wave_incl_scan(c);
-      const int64_t off = run + (int64_t)(incl - c);
-      run += (int64_t)__shfl(incl, 63, 64);
+      const int32_t sz = T.sz[k];
+      const int64_t off = T.off[k];
       const uint64_t w = __shfl(mine, j, 64);
       if (row < nrows && ((w >> lane) & 1ull)) {
         uint64_t gid;
         if (sz < 0) gid = special[1];
-        else { uint64_t key = hash_bytes(bytes + off, sz, salt); if (key == kEmpty) key = 0x1234567ull; gid = gids[table_find(keys, mask, key)]; }
+        else {
+          const uint64_t head = head_of(T.head[k], sz);
+          uint32_t g32;
+          if (sz <= 8 && met.find(head, (uint32_t)sz, g32)) gid = g32;          // the very same string, met by this wave before: its group, and it was compared then
+          else {
+            uint64_t key = hash_bytes(bytes + off, sz, salt, T.head[k]); if (key == kEmpty) key = 0x1234567ull;
+            const uint64_t h = table_find(ent, mask, key, key & mask);
+            gid = ent[h].row;
+            // unique's verify pass, folded into this one (every selected row against its slot's representative): a true hash collision makes the host repeat with another salt
+            const bool same = !rep_off || same_bytes(bytes + off, sz, bytes + rep_off[h], rep_len[h]);
+            if (!same) atomicOr((int*)(special + 4), 1);
+            else if (sz <= 8 && gid < 0xFFFFFFFFull) met.put(head, (uint32_t)sz, (uint32_t)gid, lane);
+          }
+        }
         int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
         if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
       }
+     }
     }
   }
   if (LDS) {
@@ -325,8 +529,8 @@ __global__ __launch_bounds__(kBlock) void k_group_accumulate_str(const uint64_t*
   }
 }
 
-void launch_group_ids(hipStream_t s, const uint64_t* keys, uint64_t* rows, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
-  hipLaunchKernelGGL(k_group_ids, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, rows, cap, special, ubits, uprefix);
+void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
+  hipLaunchKernelGGL(k_group_ids, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ent, cap, special, ubits, uprefix);
 }
 // ---- K9 fast path: the key is a String column with a dictionary (k_dict.hip) — its 16-bit codes ARE group labels.  What is left of `unique` is the
 // first selected row of every code (the reference numbers groups by first appearance), and `groupreduce` accumulates by rank_of_code[code]: no hash
@@ -399,20 +603,20 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
 
 int group_lds_limit() { return kGroupLds; }
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
-                             int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
+                             int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
                              int64_t ngroups, uint64_t val_init) {
   if (nrows <= 0) return;
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, keys, gids, mask, special, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, keys, gids, mask, special, cnt, val, (int)ngroups, val_init);
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
 }
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
-                                 int op, int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t salt,
+                                 int op, int64_t nrows, const UniqueEntry* ent, const uint64_t* rep_off, const uint32_t* rep_len, uint64_t mask, uint64_t* special, uint64_t salt,
                                  uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
   if (nrows <= 0) return;
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   const int g = grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles);
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_str<true>), dim3(g), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, keys, gids, mask, special, salt, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate_str<false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, keys, gids, mask, special, salt, cnt, val, (int)ngroups, val_init);
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_str<true>), dim3(g), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, ent, rep_off, rep_len, mask, special, salt, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate_str<false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, ent, rep_off, rep_len, mask, special, salt, cnt, val, (int)ngroups, val_init);
 }
 // accumulators -> results: min / max images back to values (in place)
 __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
@@ -429,6 +633,201 @@ __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
 void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int op) {
   if (ng <= 0) return;
   hipLaunchKernelGGL(k_group_finish, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, val, ng, kind, op);
+}
+
+// ---------------------------------------------------------------- integer keys of a small range: no hash table (round 4)
+// max - min of the selected keys (one pass at memory speed, k_dense_minmax) fits kDenseRange: the key IS its slot.
+//   presence  one 1024-thread workgroup per CU owns a bit per value in LDS (156 KB: 1 277 952 values); the column streams by once, every selected row
+//             sets its bit (ds_or, no return), the workgroups OR their bits into one global set at the end -> the distinct values and their number D;
+//   first     the row of every value's first occurrence: the rows again IN ORDER, a few million at a time (launches of 4 M, 16 M, 64 M ... rows), a
+//             guarded 64-bit atomicMin per row into first[value]; every launch starts by comparing the number of values whose first row is known with
+//             D and returns at once when they are equal, which for keys that are spread over the column happens after the first launch or two (1e9 rows
+//             of 1e6 uniform values: all met within 20 M rows) — in the worst case (a value that turns up late) the column is read a second time;
+//   mark      one bit + one tile count per value, scattered into a cleared bitmap.
+// unique over 1e9 Int64 rows of 1e6 values: 86 ms through the row-sized hash table of round 3, 2.9 ms so.
+constexpr int kDenseBlock = 1024;
+constexpr int kDenseWords = 39936;                                   // u32 words of LDS per workgroup (156 KB of the CU's 160)
+constexpr int64_t kDenseRange = (int64_t)kDenseWords * 32;
+constexpr int kAuxMissing = 1, kAuxOutside = 5, kAuxDistinct = 6, kAuxFound = 7, kAuxMin = 8, kAuxMax = 9;
+
+int64_t unique_dense_max_range() { return kDenseRange; }
+bool unique_dense_dtype(int dtype) {
+  switch (dtype) { case DFDB_I8: case DFDB_I16: case DFDB_I32: case DFDB_I64: case DFDB_U8: case DFDB_U16: case DFDB_U32: case DFDB_U64: case DFDB_BOOL: return true; default: return false; }
+}
+template <typename T> __device__ __forceinline__ uint64_t widen_key(T x) { return (T)-1 < (T)0 ? (uint64_t)(int64_t)x : (uint64_t)x; }
+
+// f(key image, row) for every selected, non-missing row of the tiles [tile0, tile1) this wave owns, sixteen loads in flight per lane;
+// g(row) for the smallest selected missing row of a 64-row word (lanes 0-15, one word each)
+template <typename T, typename F, typename G>
+__device__ __forceinline__ void walk_selected(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing, int64_t nrows,
+                                              int64_t tile0, int64_t tile1, int64_t wave, int64_t nwaves, F&& f, G&& g) {
+  const int lane = lane_id();
+  for (int64_t tile = tile0 + wave; tile < tile1; tile += nwaves) {
+    const uint64_t sel = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
+    const uint64_t ms = (missing && lane < 16) ? missing[tile * 16 + lane] : 0ull;
+    const int64_t base = tile * kTile;
+    if (sel & ms) { const int64_t row = base + lane * 64 + __builtin_ctzll(sel & ms); if (row < nrows) g(row); }
+    const uint64_t live = sel & ~ms;
+    if (__ballot(live != 0) == 0) continue;
+    T v[16];
+    if (base + kTile <= nrows) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = __builtin_nontemporal_load(col + base + j * 64 + lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int64_t row = base + j * 64 + lane; v[j] = row < nrows ? col[row] : (T)0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t w = __shfl(live, j, 64);
+      const int64_t row = base + j * 64 + lane;
+      if (((w >> lane) & 1ull) && row < nrows) f(widen_key(v[j]), row);
+    }
+  }
+}
+__device__ __forceinline__ void note_missing(uint64_t* aux, int64_t row) {
+  if (__atomic_load_n(&aux[kAuxMissing], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[kAuxMissing], (unsigned long long)row);
+}
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) { for (int d = 32; d; d >>= 1) { const uint64_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ uint64_t wave_max64(uint64_t v) { for (int d = 32; d; d >>= 1) { const uint64_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; } return v; }
+
+// smallest and largest selected key as order-preserving images (signed: sign bit flipped) -> aux[kAuxMin], aux[kAuxMax]
+// (every tile_step-th tile: a sample)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dense_minmax(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing,
+                                                         int64_t nrows, int64_t ntiles, int64_t tile_step, uint64_t* aux) {
+  const uint64_t flip = (T)-1 < (T)0 ? (1ull << 63) : 0ull;
+  uint64_t lo = ~0ull, hi = 0ull;
+  walk_selected<T>(bitmap, col, missing, nrows, 0, ntiles, ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * tile_step, (int64_t)gridDim.x * kWavesPerBlock * tile_step,
+                   [&](uint64_t key, int64_t) { const uint64_t im = key ^ flip; lo = im < lo ? im : lo; hi = im > hi ? im : hi; }, [&](int64_t) {});
+  lo = wave_min64(lo); hi = wave_max64(hi);
+  if (lane_id() == 0 && lo <= hi) { atomicMin((unsigned long long*)&aux[kAuxMin], (unsigned long long)lo); atomicMax((unsigned long long*)&aux[kAuxMax], (unsigned long long)hi); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kDenseBlock) void k_dense_presence(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing,
+                                                                int64_t nrows, int64_t ntiles, uint64_t lo, uint32_t range, uint32_t* __restrict__ present, uint64_t* aux) {
+  __shared__ uint32_t bits[kDenseWords];
+  const int words = (int)((range + 31u) >> 5);
+  for (int i = threadIdx.x; i < words; i += kDenseBlock) bits[i] = 0;
+  __syncthreads();
+  bool outside = false;
+  walk_selected<T>(bitmap, col, missing, nrows, 0, ntiles, (int64_t)blockIdx.x * (kDenseBlock / 64) + (threadIdx.x >> 6), (int64_t)gridDim.x * (kDenseBlock / 64),
+                   [&](uint64_t key, int64_t) { const uint64_t k = key - lo; if (k < range) atomicOr(&bits[k >> 5], 1u << (k & 31)); else outside = true; },
+                   [&](int64_t row) { note_missing(aux, row); });
+  if (outside) __atomic_store_n(&aux[kAuxOutside], 1ull, __ATOMIC_RELAXED);
+  __syncthreads();
+  for (int i = threadIdx.x; i < words; i += kDenseBlock) { const uint32_t b = bits[i]; if (b) atomicOr(&present[i], b); }
+}
+__global__ __launch_bounds__(kBlock) void k_dense_count(const uint32_t* __restrict__ present, int words, uint64_t* aux) {
+  uint32_t n = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < words; i += gridDim.x * kBlock) n += (uint32_t)__popc(present[i]);
+  for (int d = 32; d; d >>= 1) n += __shfl_xor(n, d, 64);
+  if (lane_id() == 0 && n) atomicAdd((unsigned long long*)&aux[kAuxDistinct], (unsigned long long)n);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dense_first(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing,
+                                                        int64_t nrows, int64_t tile0, int64_t tile1, uint64_t lo, uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux) {
+  // every value's first row lies in an earlier launch?  (`distinct` comes from the host, which read it after the presence pass; a stale view of the counter
+  // shows fewer values found than there are: one launch too many, never one too few)
+  if (__atomic_load_n(&aux[kAuxFound], __ATOMIC_RELAXED) >= distinct) return;
+  uint32_t fresh = 0;
+  walk_selected<T>(bitmap, col, missing, nrows, tile0, tile1, (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), (int64_t)gridDim.x * kWavesPerBlock,
+                   [&](uint64_t key, int64_t row) {
+                     const uint64_t k = key - lo;
+                     if (k < range && __atomic_load_n(&first[k], __ATOMIC_RELAXED) > (uint64_t)row)
+                       fresh += (uint32_t)(atomicMin((unsigned long long*)&first[k], (unsigned long long)row) == kEmpty);
+                   }, [&](int64_t) {});
+  for (int d = 32; d; d >>= 1) fresh += __shfl_xor(fresh, d, 64);
+  if (lane_id() == 0 && fresh) atomicAdd((unsigned long long*)&aux[kAuxFound], (unsigned long long)fresh);
+}
+
+__global__ __launch_bounds__(kBlock) void k_dense_scatter(const uint64_t* __restrict__ first, uint32_t range, const uint64_t* __restrict__ aux,
+                                                          uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > range) return;
+  const uint64_t r = i < range ? first[i] : aux[kAuxMissing];
+  if (r == kEmpty) return;
+  atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63));
+  atomicAdd(&tile_counts[r >> 10], 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_dense_group_ids(uint64_t* __restrict__ first, uint32_t range, uint64_t* __restrict__ aux,
+                                                            const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < range) { if (first[i] != kEmpty) first[i] = rank_of_row(ubits, uprefix, first[i]); }
+  else if (i == range && aux[kAuxMissing] != kEmpty) aux[kAuxMissing] = rank_of_row(ubits, uprefix, aux[kAuxMissing]);
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_group_accumulate_dense(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
+                                                                   const void* __restrict__ valcol, int valdt, int op, int64_t nrows, uint64_t lo,
+                                                                   const uint64_t* __restrict__ gids, const uint64_t* __restrict__ aux, uint64_t* cnt, uint64_t* val,
+                                                                   int ngroups, uint64_t val_init) {
+  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
+  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
+  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
+    uint64_t gid;
+    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) gid = aux[kAuxMissing];
+    else gid = gids[key_fixed(keycol, keydt, row) - lo];
+    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
+    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
+  }
+  if (LDS) {
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
+    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
+  }
+}
+
+#define DENSE_BY_DTYPE(CALL)                                                       \
+  switch (dtype) {                                                                 \
+    case DFDB_I8:  { using T = int8_t;   CALL; } break;                            \
+    case DFDB_I16: { using T = int16_t;  CALL; } break;                            \
+    case DFDB_I32: { using T = int32_t;  CALL; } break;                            \
+    case DFDB_I64: { using T = int64_t;  CALL; } break;                            \
+    case DFDB_U8: case DFDB_BOOL: { using T = uint8_t; CALL; } break;              \
+    case DFDB_U16: { using T = uint16_t; CALL; } break;                            \
+    case DFDB_U32: { using T = uint32_t; CALL; } break;                            \
+    default:       { using T = uint64_t; CALL; } break;                            \
+  }
+void launch_dense_minmax(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int64_t tile_step, uint64_t* aux) {
+  if (nrows <= 0) return;
+  const int64_t ntiles = (nrows + kTile - 1) / kTile, visited = (ntiles + tile_step - 1) / tile_step;
+  const dim3 g(grid_tiles(visited) > 2048 ? 2048 : grid_tiles(visited)), b(kBlock);
+  DENSE_BY_DTYPE(hipLaunchKernelGGL((k_dense_minmax<T>), g, b, 0, s, bitmap, (const T*)col, missing, nrows, ntiles, tile_step, aux))
+}
+void launch_dense_presence(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t nrows, uint64_t lo, uint32_t range,
+                           uint32_t* present, uint64_t* aux) {
+  if (nrows <= 0) return;
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  int64_t nb = (ntiles + kDenseBlock / 64 - 1) / (kDenseBlock / 64); if (nb > 256) nb = 256;      // one workgroup per CU: its LDS is the whole CU's
+  const dim3 g((unsigned)nb), b(kDenseBlock);
+  DENSE_BY_DTYPE(hipLaunchKernelGGL((k_dense_presence<T>), g, b, 0, s, bitmap, (const T*)col, missing, nrows, ntiles, lo, range, present, aux))
+  const int words = (int)((range + 31u) >> 5);
+  hipLaunchKernelGGL(k_dense_count, dim3((words + kBlock - 1) / kBlock > 64 ? 64 : (words + kBlock - 1) / kBlock), dim3(kBlock), 0, s, present, words, aux);
+}
+void launch_dense_first(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1, uint64_t lo,
+                        uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux) {
+  if (row1 <= row0) return;
+  const int64_t tile0 = row0 / kTile, tile1 = (row1 + kTile - 1) / kTile;
+  const dim3 g(grid_tiles(tile1 - tile0) > 2048 ? 2048 : grid_tiles(tile1 - tile0)), b(kBlock);
+  DENSE_BY_DTYPE(hipLaunchKernelGGL((k_dense_first<T>), g, b, 0, s, bitmap, (const T*)col, missing, row1, tile0, tile1, lo, range, distinct, first, aux))
+}
+void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts) {
+  hipLaunchKernelGGL(k_dense_scatter, dim3((range + 1 + kBlock) / kBlock), dim3(kBlock), 0, s, first, range, aux, bitmap, tile_counts);
+}
+void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint64_t* aux, const uint64_t* ubits, const uint64_t* uprefix) {
+  hipLaunchKernelGGL(k_dense_group_ids, dim3((range + 1 + kBlock) / kBlock), dim3(kBlock), 0, s, first, range, aux, ubits, uprefix);
+}
+void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+                                   int64_t nrows, uint64_t lo, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
+  if (nrows <= 0) return;
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_dense<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, lo, gids, aux, cnt, val, (int)ngroups, val_init);
+  else hipLaunchKernelGGL((k_group_accumulate_dense<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, lo, gids, aux, cnt, val, (int)ngroups, val_init);
 }
 
 }  // namespace dfdb

@@ -142,12 +142,31 @@ void launch_reduce(hipStream_t s, const uint64_t* bitmap, const void* col, int32
                    void* result /* 16 bytes: i64/u64 or f64 result + count */);
 size_t reduce_scratch_bytes();
 
-// ---- unique(col) as a selection of first occurrences (k_unique.hip).  pass 0: insert, 1: (strings) verify / (fixed) mark, 2: (strings) mark
-void launch_unique_fixed(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing,
-                         int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t mask, uint64_t* special);
+// ---- unique(col) as a selection of first occurrences (k_unique.hip: hash table of {key, smallest row}; k_unique_dense.hip: integer keys of a small range)
+struct UniqueEntry { uint64_t key, row; };
+void launch_unique_insert(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1,
+                          UniqueEntry* ent, uint64_t mask, uint64_t* aux);
+void launch_unique_mark(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing, int64_t nrows,
+                        const UniqueEntry* ent, uint64_t mask, const uint64_t* aux);
+void launch_unique_migrate(hipStream_t s, const UniqueEntry* from, const uint64_t* from_off, const uint32_t* from_len, uint64_t from_cap, UniqueEntry* ent,
+                           uint64_t* rep_off, uint32_t* rep_len, uint64_t mask, uint64_t* aux);
+void launch_unique_scatter(hipStream_t s, const UniqueEntry* ent, uint64_t cap, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts);
+// pass 0: insert the tiles [tile0, tile1), 1: verify, 2: mark
 void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
-                       const uint8_t* bytes, int64_t nrows, uint64_t* keys, uint64_t* rows, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
-                       uint64_t* special, uint64_t salt, int* collision);
+                       const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
+                       uint64_t* aux, uint64_t salt);
+// dense form.  aux words: 1 = smallest missing row, 5 = a key outside [lo, lo + range) was met, 6 = distinct keys, 7 = keys whose first row is known, 8 / 9 = min / max image
+int64_t unique_dense_max_range();
+bool unique_dense_dtype(int dtype);
+void launch_dense_minmax(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int64_t tile_step, uint64_t* aux);
+void launch_dense_presence(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t nrows, uint64_t lo, uint32_t range,
+                           uint32_t* present, uint64_t* aux);
+void launch_dense_first(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1, uint64_t lo,
+                        uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux);
+void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts);
+void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint64_t* aux, const uint64_t* ubits, const uint64_t* uprefix);
+void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+                                   int64_t nrows, uint64_t lo, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
 
 // ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------
 // (dst: the decoders may READ up to 32 bytes past the end of the last block's output — far-match sources are fetched 24 bytes at a time — so the

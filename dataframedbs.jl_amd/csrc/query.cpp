@@ -13,6 +13,7 @@
 #include "engine.hpp"
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <functional>
 
 namespace dfdb {
@@ -1011,7 +1012,14 @@ void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* 
 void launch_set_rows(hipStream_t s, const uint64_t* rows, int n, uint64_t* bitmap, uint32_t* tile_counts);
 void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uint16_t* codes, const uint32_t* rank_of_code, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
-struct UniqueTables { DevBuf keys, rows, aux, rep_off, rep_len; uint64_t cap = 0, salt = 0; bool is_str = false; };
+// what unique leaves behind for groupreduce: the hash table {key, first row} (Strings: + where one holder's bytes are), or — integer keys of a small
+// range — the first row per value; groupreduce turns the rows into group numbers in place
+struct UniqueTables {
+  DevBuf ent, aux, rep_off, rep_len, first, present;
+  uint64_t cap = 0, salt = 0, lo = 0; uint32_t range = 0; bool is_str = false, dense = false;
+  bool defer_verify = false;     // in: the caller's own pass over the rows compares every String with its slot's representative (groupreduce's accumulate pass)
+  int salt_skip = 0;             // in: salts already found colliding
+};
 // K9: unique over a String column that has a dictionary — the first selected row of every code, no hash table.  Leaves what unique_impl leaves (the
 // bitmap holds exactly the first occurrences, prefix scanned); rank_of_code (optional) maps a code to its group number in order of first appearance.
 static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_code) {
@@ -1042,9 +1050,195 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory
   return ng;
 }
+constexpr size_t kUniqueAuxBytes = 128;      // k_unique.hip: 0 first row of the key that cannot be stored, 1 first missing row, 2 claimed slots, 3 abort, 4 collision, 5-9 the dense form's
+static void unique_reset_aux(dfdb_ctx* ctx, DevBuf& aux) {
+  hipStream_t s = ctx->stream;
+  aux.ensure(kUniqueAuxBytes);
+  HIP_CHECK(hipMemsetAsync(aux.p, 0, kUniqueAuxBytes, s));
+  HIP_CHECK(hipMemsetAsync(aux.p, 0xFF, 16, s));                       // no such row yet
+  HIP_CHECK(hipMemsetAsync((char*)aux.p + 64, 0xFF, 8, s));            // the running minimum (k_dense_minmax)
+}
+static uint64_t pow2_at_least(uint64_t n) { uint64_t c = 1024; while (c < n) c <<= 1; return c; }
+
+// How many slots the table should have before the next chunk: `d` distinct keys met in the first `r` selected rows, `remaining` rows to come.
+// If the rows so far were nearly all different nothing can be said (every remaining row may bring a key).  Otherwise the distinct count D of the whole
+// selection is estimated as if keys were drawn uniformly — d = D (1 - exp(-r / D)), solved for D — and doubled: skewed data has more rare keys than that,
+// and an estimate that turns out too small costs one more migration (or an aborted chunk), never a wrong result.
+static uint64_t unique_capacity_wanted(uint64_t d, uint64_t r, uint64_t remaining, uint64_t cap, uint64_t capmax) {
+  if (remaining == 0 || r == 0) return cap;
+  double need;
+  if ((double)d > 0.95 * (double)r) need = (double)d + (double)remaining;
+  else {
+    double lo = (double)(d ? d : 1), hi = 20.0 * (double)r;
+    for (int it = 0; it < 64; it++) { const double D = 0.5 * (lo + hi); if (D * (1.0 - std::exp(-(double)r / D)) < (double)d) lo = D; else hi = D; }
+    need = std::min((double)d + (double)remaining, 2.0 * hi + 1024.0);
+  }
+  const uint64_t want = pow2_at_least((uint64_t)(2.0 * need));
+  return std::min(std::max(want, cap), capmax);
+}
+
+// integer keys whose selected values span less than the dense form's range (k_unique.hip, last section).  false: the span is too wide
+static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int dt = dt_base(col.dtype);
+  const int64_t limit = std::min<int64_t>(unique_dense_max_range(), ctx_option(ctx, "unique_dense_range", unique_dense_max_range()));
+  const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
+  const uint64_t flip = dt_issigned(dt) ? (1ull << 63) : 0ull;
+  uint64_t* aux = nullptr;
+  uint64_t distinct = 0;
+  auto minmax = [&](int64_t tile_step, uint64_t* mm) {                 // order-preserving images of the smallest / largest selected key (of every tile_step-th tile)
+    unique_reset_aux(ctx, T.aux);
+    { LaunchTimer lt(ctx, "unique_minmax"); launch_dense_minmax(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, tile_step, T.aux.as<uint64_t>()); }
+    HIP_CHECK(hipMemcpyAsync(mm, (char*)T.aux.p + 64, 16, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+  };
+  auto presence = [&](uint64_t lo_im, uint64_t span) -> bool {         // false: a selected key lies outside [lo, lo + span]
+    T.lo = lo_im ^ flip; T.range = (uint32_t)(span + 1);
+    const size_t words = ((size_t)T.range + 31) / 32;
+    T.first.ensure((size_t)T.range * 8 + 64); T.present.ensure(words * 4 + 64);
+    HIP_CHECK(hipMemsetAsync(T.first.p, 0xFF, (size_t)T.range * 8, s));
+    HIP_CHECK(hipMemsetAsync(T.present.p, 0, words * 4, s));
+    unique_reset_aux(ctx, T.aux);
+    aux = T.aux.as<uint64_t>();
+    { LaunchTimer lt(ctx, "unique_presence");
+      launch_dense_presence(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, T.lo, T.range, T.present.as<uint32_t>(), aux); }
+    uint64_t od[2] = {0, 0};                                            // a key outside?  distinct values
+    HIP_CHECK(hipMemcpyAsync(od, (char*)T.aux.p + 40, 16, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    distinct = od[1];
+    return od[0] == 0;
+  };
+  const int64_t nt = ceil_div(t->nrows, kTileRows);
+  bool placed = false;
+  if (dt_width(dt) <= 2) {                                             // the type's own range fits
+    const int bits = dt_width(dt) * 8;
+    if ((1ull << bits) > (uint64_t)limit) return false;
+    placed = presence(dt_issigned(dt) ? ((uint64_t)(-(int64_t)(1ull << (bits - 1))) ^ flip) : 0ull, (1ull << bits) - 1);
+  } else {
+    // where the keys lie is not known.  A SAMPLE (every nt/256-th tile) says where to expect them: the whole span the form can hold is laid around the sample's
+    // range and the presence pass reports any key outside it — then, and for a small table, the exact range costs a pass of its own (1.3 ms per 1e9 rows)
+    uint64_t mm[2];
+    const int64_t sample_step = nt / 256;
+    if (sample_step >= 16 && ctx_option(ctx, "unique_dense_sample", 1) != 0) {
+      minmax(sample_step, mm);
+      if (mm[0] <= mm[1]) {
+        if (mm[1] - mm[0] >= (uint64_t)limit) return false;
+        const uint64_t slack = ((uint64_t)limit - 1 - (mm[1] - mm[0])) / 2;
+        uint64_t lo_im = mm[0] > slack ? mm[0] - slack : 0ull;
+        if (lo_im > ~0ull - ((uint64_t)limit - 1)) lo_im = ~0ull - ((uint64_t)limit - 1);
+        placed = presence(lo_im, (uint64_t)limit - 1);
+      }
+    }
+    if (!placed) {
+      minmax(1, mm);
+      if (mm[0] > mm[1]) mm[0] = mm[1] = flip;                         // every selected key is missing
+      if (mm[1] - mm[0] >= (uint64_t)limit) return false;
+      placed = presence(mm[0], mm[1] - mm[0]);
+    }
+  }
+  if (!placed) fail(DFDB_ERR_DEVICE, "unique: a key outside the range of its column");
+  T.dense = true;
+  { LaunchTimer lt(ctx, "unique_first");
+    int64_t step = std::max<int64_t>(1, ctx_option(ctx, "unique_chunk_tiles", 4096));
+    for (int64_t t0 = 0; t0 < nt; t0 += step, step *= 4)
+      launch_dense_first(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(t->nrows, (t0 + step) * kTileRows), T.lo, T.range, distinct, T.first.as<uint64_t>(), aux);
+  }
+  HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
+  HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
+  { LaunchTimer lt(ctx, "unique_mark"); launch_dense_scatter(s, T.first.as<uint64_t>(), T.range, aux, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>()); }
+  uint64_t st[3];
+  HIP_CHECK(hipMemcpyAsync(st, (char*)T.aux.p + 40, 24, hipMemcpyDeviceToHost, s));      // outside flag, distinct values, values whose first row is known
+  stream_wait(ctx);
+  if (st[0] != 0 || st[1] != st[2]) fail(DFDB_ERR_DEVICE, "unique: the dense form lost a key (outside %llu, distinct %llu, found %llu)", (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2]);
+  return true;
+}
+
+// the general form: an open-addressing table of {key, first row} sized by the distinct values as they turn up (k_unique.hip)
+static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const bool is_str = T.is_str;
+  const int dt = dt_base(col.dtype);
+  const uint64_t* miss = (!is_str && dt_nullable(col.dtype)) ? col.missing.as<uint64_t>() : nullptr;
+  const int64_t nt = ceil_div(t->nrows, kTileRows);
+  const uint64_t capmax = pow2_at_least((uint64_t)cnt * 2);
+  const uint64_t cap0 = std::min(capmax, pow2_at_least(1ull << std::min<int64_t>(40, std::max<int64_t>(10, ctx_option(ctx, "unique_cap0_log2", 21)))));
+  const int64_t c0 = std::max<int64_t>(1, ctx_option(ctx, "unique_chunk_tiles", 1024));
+  const int64_t bounds[3] = {std::min(nt, c0), std::min(nt, c0 * 17), nt};
+  auto alloc = [&](UniqueTables& U, uint64_t cap) {
+    U.cap = cap;
+    U.ent.ensure(cap * sizeof(UniqueEntry));
+    HIP_CHECK(hipMemsetAsync(U.ent.p, 0xFF, cap * sizeof(UniqueEntry), s));
+    if (is_str) { U.rep_off.ensure(cap * 8); U.rep_len.ensure(cap * 4); }
+  };
+  auto insert = [&](int64_t t0, int64_t t1) {
+    LaunchTimer lt(ctx, "unique_insert");
+    if (is_str) launch_unique_str(s, 0, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                                  t->nrows, t0, t1, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, T.aux.as<uint64_t>(), T.salt);
+    else launch_unique_insert(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(t->nrows, t1 * kTileRows), T.ent.as<UniqueEntry>(), T.cap - 1, T.aux.as<uint64_t>());
+  };
+  uint64_t st[2] = {0, 0};                                             // claimed slots, abort flag
+  auto read_state = [&](uint64_t* selected_before, int64_t tile) {
+    HIP_CHECK(hipMemcpyAsync(st, (char*)T.aux.p + 16, 16, hipMemcpyDeviceToHost, s));
+    if (selected_before) HIP_CHECK(hipMemcpyAsync(selected_before, q->prefix.as<uint64_t>() + tile, 8, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+  };
+  auto grow = [&](uint64_t cap) {                                      // the entries move to a table of `cap` slots
+    LaunchTimer lt(ctx, "unique_migrate");
+    UniqueTables N; N.is_str = is_str;
+    alloc(N, cap);
+    HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 16, 0, 16, s));
+    launch_unique_migrate(s, T.ent.as<UniqueEntry>(), is_str ? T.rep_off.as<uint64_t>() : nullptr, is_str ? T.rep_len.as<uint32_t>() : nullptr, T.cap, N.ent.as<UniqueEntry>(),
+                          N.rep_off.as<uint64_t>(), N.rep_len.as<uint32_t>(), cap - 1, T.aux.as<uint64_t>());
+    read_state(nullptr, 0);
+    if (st[1]) fail(DFDB_ERR_DEVICE, "unique: %llu entries do not fit a table of %llu slots", (unsigned long long)st[0], (unsigned long long)cap);
+    T.ent = std::move(N.ent); T.rep_off = std::move(N.rep_off); T.rep_len = std::move(N.rep_len); T.cap = cap;
+  };
+  T.salt = 0x51ED270B27B4F3CFull;
+  for (int k = 0; k < T.salt_skip; k++) T.salt = splitmix64_host(T.salt);
+  for (int tries = T.salt_skip;; tries++, T.salt = splitmix64_host(T.salt)) {
+    if (!T.ent.p || T.cap != cap0) { T.ent.release(); alloc(T, cap0); } else HIP_CHECK(hipMemsetAsync(T.ent.p, 0xFF, T.cap * sizeof(UniqueEntry), s));
+    unique_reset_aux(ctx, T.aux);
+    int64_t t0 = 0;
+    for (int c = 0; c < 3; c++) {
+      const int64_t t1 = bounds[c];
+      if (t1 <= t0) continue;
+      uint64_t r = 0;
+      for (;;) {
+        insert(t0, t1);
+        read_state(&r, t1);
+        if (!st[1]) break;
+        if (T.cap >= capmax) fail(DFDB_ERR_DEVICE, "unique: probe sequences of a half-empty table got too long (%llu slots, %llu keys)", (unsigned long long)T.cap, (unsigned long long)st[0]);
+        grow(std::min(capmax, T.cap * 4));                             // (that clears the flag) and the chunk again: inserts are idempotent
+      }
+      const uint64_t want = unique_capacity_wanted(st[0], r, (uint64_t)cnt - std::min<uint64_t>(r, (uint64_t)cnt), T.cap, capmax);
+      if (want > T.cap) grow(want);
+      t0 = t1;
+    }
+    if (!is_str || T.defer_verify) break;
+    launch_unique_str(s, 1, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                      t->nrows, 0, nt, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, T.aux.as<uint64_t>(), T.salt);
+    int hit = 0;
+    HIP_CHECK(hipMemcpyAsync(&hit, (char*)T.aux.p + 32, 4, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    if (!hit) break;                                                   // no two different strings shared a key: the table is exact
+    if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
+  }
+  LaunchTimer lt(ctx, "unique_mark");
+  if (st[0] * 8 <= (uint64_t)cnt) {                                    // few distinct values beside the rows: the first rows straight out of the table
+    HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
+    HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)nt * 4, s));
+    launch_unique_scatter(s, T.ent.as<UniqueEntry>(), T.cap, T.aux.as<uint64_t>(), q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
+  } else if (is_str) {
+    launch_unique_str(s, 2, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+                      t->nrows, 0, nt, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, T.aux.as<uint64_t>(), T.salt);
+  } else {
+    launch_unique_mark(s, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.p, dt, miss, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, T.aux.as<uint64_t>());
+  }
+}
+
 static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   ensure_executed(q);
-  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
   const Node& e = *q->proj[(size_t)p].expr;
   if (e.op != DFIR_COL) fail(DFDB_ERR_UNSUPPORTED, "unique of a computed column: materialise it as a column first (dfdb_table_add_from_query)");
@@ -1052,54 +1246,29 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   const int64_t cnt = query_count(q, -1);
   if (cnt == 0 || t->nrows == 0) return;
   if (!keep && col.dict_n > 0) { dict_unique(q, col, nullptr); return; }
-  uint64_t cap = 1024; while (cap < (uint64_t)cnt * 2) cap <<= 1;
-  const bool is_str = dt_base(col.dtype) == DFDB_STRING;
-  DevBuf keys, rows, aux, rep_off, rep_len;
-  keys.ensure(cap * 8); rows.ensure(cap * 8); aux.ensure(64);
-  if (is_str) { rep_off.ensure(cap * 8); rep_len.ensure(cap * 4); }
-  uint64_t* special = aux.as<uint64_t>(); int* collision = (int*)(aux.as<uint8_t>() + 32);
-  LaunchTimer lt(ctx, "unique");
-  uint64_t used_salt = 0;
-  for (uint64_t salt = 0x51ED270B27B4F3CFull, tries = 0;; salt = splitmix64_host(salt), tries++) {
-    used_salt = salt;
-    HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, cap * 8, s));
-    HIP_CHECK(hipMemsetAsync(rows.p, 0xFF, cap * 8, s));
-    HIP_CHECK(hipMemsetAsync(aux.p, 0xFF, 16, s));
-    HIP_CHECK(hipMemsetAsync((char*)aux.p + 32, 0, 4, s));
-    if (!is_str) {
-      const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
-      launch_unique_fixed(s, 0, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.p, dt_base(col.dtype), miss, t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), cap - 1, special);
-      launch_unique_fixed(s, 1, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.p, dt_base(col.dtype), miss, t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), cap - 1, special);
-      break;
-    }
-    auto pass = [&](int k) {
-      launch_unique_str(s, k, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
-                        t->nrows, keys.as<uint64_t>(), rows.as<uint64_t>(), rep_off.as<uint64_t>(), rep_len.as<uint32_t>(), cap - 1, special, salt, collision);
-    };
-    pass(0); pass(1);
-    int hit = 0;
-    HIP_CHECK(hipMemcpyAsync(&hit, collision, 4, hipMemcpyDeviceToHost, s));
-    stream_wait(ctx);
-    if (!hit) { pass(2); break; }                          // no two different strings shared a key: the table is exact
-    if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
+  UniqueTables local;
+  UniqueTables& T = keep ? *keep : local;
+  T.is_str = dt_base(col.dtype) == DFDB_STRING; T.dense = false;
+  {
+    LaunchTimer lt(ctx, "unique");
+    const bool dense = !T.is_str && unique_dense_dtype(dt_base(col.dtype)) && ctx_option(ctx, "unique_dense", 1) != 0 && unique_dense(q, col, T);
+    if (!dense) unique_hashed(q, col, cnt, T);
   }
   scan_prefix(q);
   q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1;
-  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here (or move to the caller: groupreduce looks rows up in them)
-  if (keep) { keep->keys = std::move(keys); keep->rows = std::move(rows); keep->aux = std::move(aux); keep->rep_off = std::move(rep_off); keep->rep_len = std::move(rep_len);
-              keep->cap = cap; keep->salt = used_salt; keep->is_str = is_str; }
+  stream_wait(ctx);                                        // the tables die here (or stay with the caller: groupreduce looks rows up in them)
 }
 void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
 
 // groupreduce(view, (:key,); out = :val => Stat()) (src/tables/aggregate.jl:1-36; unfinished in the reference: it numbers the groups in order of
 // first appearance of the key and prints the map).  Completed to that intent: one group per distinct key (isequal), groups in order of first
 // appearance, count and one reduced value per group.  Device side: unique's table + k_group_ids + k_group_accumulate (k_unique.hip).
-void launch_group_ids(hipStream_t s, const uint64_t* keys, uint64_t* rows, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix);
+void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix);
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
-                             int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
+                             int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
                              int64_t ngroups, uint64_t val_init);
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
-                                 int op, int64_t nrows, const uint64_t* keys, const uint64_t* gids, uint64_t mask, const uint64_t* special, uint64_t salt,
+                                 int op, int64_t nrows, const UniqueEntry* ent, const uint64_t* rep_off, const uint32_t* rep_len, uint64_t mask, uint64_t* special, uint64_t salt,
                                  uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
 void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int op);
 
@@ -1145,25 +1314,45 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     return;
   }
   UniqueTables T;
-  unique_impl(q, key_p, &T);
-  const int64_t ng = query_count(q, -1);
-  uint64_t* special = T.aux.as<uint64_t>();
-  launch_group_ids(s, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap, special, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>());
-  q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
-  const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
-  HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
-  HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
-  { LaunchTimer lt(ctx, "group_accumulate");
-    if (T.is_str)
-      launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
-                                  vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap - 1, special, T.salt,
-                                  q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
-    else
-      launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr, vc ? vc->data.p : nullptr,
-                              vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.keys.as<uint64_t>(), T.rows.as<uint64_t>(), T.cap - 1, special,
-                              q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
+  int64_t ng = 0;
+  for (;;) {
+    // String keys: the pass that compares every row with its slot's representative (unique's verify pass) is folded into the accumulate pass below, which
+    // hashes every row and finds its slot anyway; should two different strings share a key the selection is put back and everything runs again under the next salt
+    T.defer_verify = true;
+    unique_impl(q, key_p, &T);
+    ng = query_count(q, -1);
+    uint64_t* special = T.aux.as<uint64_t>();
+    if (T.dense) launch_dense_group_ids(s, T.first.as<uint64_t>(), T.range, special, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>());
+    else launch_group_ids(s, T.ent.as<UniqueEntry>(), T.cap, special, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>());
+    q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
+    const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
+    HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
+    HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+    { LaunchTimer lt(ctx, "group_accumulate");
+      const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
+      if (T.dense)
+        launch_group_accumulate_dense(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.lo,
+                                      T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
+      else if (T.is_str)
+        launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
+                                    vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, special, T.salt,
+                                    q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
+      else
+        launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr,
+                                vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, special,
+                                q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
+    if (!T.is_str) break;
+    int hit = 0;
+    HIP_CHECK(hipMemcpyAsync(&hit, (char*)T.aux.p + 32, 4, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    if (!hit && ctx_option(ctx, "unique_test_collide", 0) <= T.salt_skip) break;
+    if (++T.salt_skip > 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
+    launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);     // the full selection again
+    scan_prefix(q);
+    q->count = -1;
+  }
   launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
-  HIP_CHECK(hipStreamSynchronize(s));                      // the tables die here
+  stream_wait(ctx);                                        // the tables die here
   q->gr_n = ng; q->gr_state = 2;
   if (ngroups) *ngroups = ng;
   if (key_bytes && dt_base(kc.dtype) == DFDB_STRING) *key_bytes = query_string_bytes(q, key_p);

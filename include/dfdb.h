@@ -135,6 +135,12 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     (dfdb_query_hint_materialize): 2 (default: the last two terms of the launch, the second parked in LDS), 1, or 0 = gather everything
  *   "scan_narrow"     which narrow columns `col OP const` scans with 16-byte loads per lane (k_scan_cmp_narrow): 1 = 1-byte columns — Bool, Int8, UInt8 —
  *                     (default: 0.72 of the HBM peak against 0.52), 2 = 2- and 4-byte columns too (no consistent gain measured), 0 = none
+ *   "unique_dense"    1 = dfdb_query_unique / _groupreduce over an integer key whose selected values span less than 1 277 952 take the form without a hash
+ *                     table (a presence bit per value in LDS; default 1); "unique_dense_range" lowers that span.  "unique_cap0_log2" = log2 of the slots the
+ *                     hash table starts with (default 21; it grows with the distinct values met), "unique_chunk_tiles" = 1024-row tiles of the first chunk
+ *                     either form feeds before it looks at what it found (defaults 1024 hashed / 4096 dense), "unique_dense_sample" = 0: the dense form reads the
+ *                     exact range of the keys first instead of laying its span around a sample's, "unique_test_collide" = N: groupreduce by a String key
+ *                     behaves as if the first N salts had produced a hash collision — test knobs, the results never depend on them
  *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
  *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
  *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one

@@ -175,3 +175,74 @@ def test_nullable_string_generator_and_three_valued_equality(oracle, dfdb_mod, c
     # ismissing counts (docs/src/index.md:326-328)
     assert t[ir.ismissing(ir.col(0)), dfdb_mod.ALL]._query().count() == int(miss.sum())
     t.close()
+
+
+# ------------------------------------------------------------------ unique / groupreduce: the table sized by the distinct values, and the dense form
+def _julia_unique(values, missing=None):
+    from test_gpu_parity import julia_unique
+    return julia_unique(values, missing)
+
+
+@pytest.mark.parametrize("form", ["dense", "dense_one_tile_chunks", "hashed", "hashed_tiny_table"])
+def test_unique_and_groupreduce_forms_agree_with_first_appearance(oracle, dfdb_mod, form):
+    """unique / groupreduce (column.jl:102-126, aggregate.jl:1-36) through every form of the round-4 rewrite: integer keys of a small range without a hash
+    table (presence bits in LDS, first rows found in row-ordered launches that stop early), and the hash table that starts small and MIGRATES as distinct
+    values turn up (a table of 1024 slots and one-tile chunks force aborts, repeated chunks and several migrations).  Keys: every integer width, a value
+    that first turns up in the very last rows (the early exit must not miss it), all-distinct keys, few keys, nullable keys, floats with NaN / -0.0,
+    Strings; over a filtered view; against Base.unique's order of first appearance."""
+    from test_gpu_parity import _np_group_ids, _np_groupreduce
+    ctx = dfdb_mod.Context(0)
+    opts = {"dense": {}, "dense_one_tile_chunks": {"unique_chunk_tiles": 1, "unique_dense_sample": 0}, "hashed": {"unique_dense": 0, "unique_test_collide": 2},
+            "hashed_tiny_table": {"unique_dense": 0, "unique_cap0_log2": 10, "unique_chunk_tiles": 1}}[form]
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    rng = np.random.default_rng(77)
+    n = 600_011                # (586 tiles: the dense form samples every second tile for the range of a wide key, and `late` puts two keys outside what it sees)
+    late = rng.integers(0, 900, n).astype(np.int64) + 5_000_000; late[-3] = 5_000_950; late[-1] = 4_999_990
+    f = rng.integers(-3, 4, n).astype(np.float64); f[::97] = np.nan; f[5::101] = -0.0
+    words = [f"w{k:05d}" for k in range(3000)]
+    cols = {"i8": rng.integers(-128, 128, n).astype(np.int8), "u8": rng.integers(0, 256, n).astype(np.uint8), "flag": rng.integers(0, 2, n).astype(bool),
+            "i16": rng.integers(-30000, 30000, n).astype(np.int16), "u16": rng.integers(0, 65536, n).astype(np.uint16),
+            "i32": rng.integers(-70_000, 70_000, n).astype(np.int32), "u32": (rng.integers(0, 1000, n) + 4_000_000_000).astype(np.uint32),
+            "late": late, "neg": rng.integers(-2**63, -2**63 + 5000, n, dtype=np.int64), "top": (rng.integers(0, 3000, n).astype(np.uint64) + np.uint64(2**64 - 3000)),
+            "wide": rng.integers(-2**62, 2**62, n).astype(np.int64), "distinct": rng.permutation(n).astype(np.int64) * 7,
+            "m": np.ma.masked_array(rng.integers(0, 5000, n).astype(np.int64), mask=rng.random(n) < 0.2), "f": f,
+            "s": [words[i] for i in rng.integers(0, len(words), n)], "c": rng.integers(-1000, 1000, n).astype(np.int64)}
+    t = dfdb_mod.DFTable.from_columns(cols, block_size=65536, ctx=ctx)
+    sel = cols["c"] > -700
+    v = t[t.c > -700, dfdb_mod.ALL]
+    for name, src in cols.items():
+        if name == "c":
+            continue
+        for view, keep in ((t, np.ones(n, bool)), (v, sel)):
+            got = getattr(view, name).unique()
+            if isinstance(src, np.ma.MaskedArray):
+                want = _julia_unique(src.data[keep].tolist(), np.ma.getmaskarray(src)[keep].tolist())
+                assert [None if mm else x for x, mm in zip(np.asarray(got.data).tolist(), np.ma.getmaskarray(got).tolist())] == want, (form, name)
+            elif isinstance(src, list):
+                assert list(got) == _julia_unique([x for x, k in zip(src, keep) if k]), (form, name)
+            elif src.dtype.kind == "f":
+                want = _julia_unique(src[keep].tolist())
+                assert len(got) == len(want) and all((x != x and y != y) or (x == y and np.signbit(x) == np.signbit(y)) for x, y in zip(got.tolist(), want)), (form, name)
+            else:
+                assert got.tolist() == _julia_unique(src[keep].tolist()), (form, name)
+    vals = cols["c"]
+    for by in ("i8", "u16", "i32", "late", "neg", "top", "wide", "m", "s"):
+        keys = cols[by] if not isinstance(cols[by], list) else np.array(cols[by], dtype=object)
+        ids = _np_group_ids([keys[i] for i in np.nonzero(sel)[0]])
+        for stat in ("sum", "min"):
+            got = dfdb_mod.groupreduce(v, by, "c", stat)
+            order, cnt, want = _np_groupreduce(ids, vals[sel], stat)
+            import pandas as pd
+            gk = [None if (not isinstance(k, str) and pd.isna(k)) else (k if isinstance(k, str) else int(k)) for k in got[by].tolist()]
+            wk = [None if (k is np.ma.masked or k is None) else (k if isinstance(k, str) else int(k)) for k in order]
+            assert gk == wk and got["count"].tolist() == cnt.tolist() and np.array_equal(got[stat].to_numpy().astype(np.int64), want.astype(np.int64)), (form, by, stat)
+    assert dfdb_mod.nrow(v) == int(sel.sum())
+    if form == "dense":          # which kernels ran: the dense form for the narrow ranges, the table for the wide ones
+        ctx.profile(True)
+        t.late.unique(); t.wide.unique()
+        ctx.synchronize()
+        assert ctx.profile_get("unique_presence")[0] == 1 and ctx.profile_get("unique_insert")[0] >= 1
+        ctx.profile(False)
+    t.close()
+    ctx.close()
