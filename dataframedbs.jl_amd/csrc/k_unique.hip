@@ -168,10 +168,10 @@ __global__ __launch_bounds__(kBlock) void k_unique_scatter(const UniqueEntry* __
 }
 
 // ---------------------------------------------------------------- String columns (FlatStringsVector: sizes + arena, offsets per 1024-row tile)
-// A String's 64-bit key.  `head` = its first 8 bytes (as loaded: bytes past its end are masked here).  Two 32-bit lanes of state, one 32-bit multiply each per
-// 8 bytes and two to finish (64-bit multiplies are four quarter-rate instructions each on this chip: three rounds of splitmix64 per row were ~500 of the ~1000
-// cycles a wave spent per 64 rows, and the pass ran at the speed of the multiplier, not of memory).  Every step is a bijection of the state for a given chunk, so
-// two different strings of one length <= 8 never share a key; any others that do are found by the compare against the slot's representative, and the salt changes.
+// A String's 64-bit key.  `head` / `head2` = its bytes 0..7 / 8..15 as loaded (bytes past its end are masked here; head2 only where len > 8).  Two 32-bit lanes of
+// state, one 32-bit multiply each per 8 bytes and two to finish (64-bit multiplies are four quarter-rate instructions each on this chip: three rounds of splitmix64 per
+// row were ~500 of the ~1000 cycles a wave spent per 64 rows).  Every step is a bijection of the state for a given chunk, so two different strings of one length
+// <= 8 never share a key; any others that do are found by the compare against the slot's representative, and the salt changes.
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
 __device__ __forceinline__ void hash_chunk(uint32_t& a, uint32_t& b, uint64_t v) {
   a = (a ^ (uint32_t)v) * 0x85EBCA6Bu;
@@ -179,225 +179,67 @@ __device__ __forceinline__ void hash_chunk(uint32_t& a, uint32_t& b, uint64_t v)
   a = rotl32(a, 15) + b;
   b = rotl32(b, 13) ^ a;
 }
-__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int32_t len, uint64_t salt, uint64_t head) {
+__device__ __forceinline__ uint64_t low_bytes(uint64_t v, int n) { return n >= 8 ? v : (n > 0 ? v & (~0ull >> (64 - 8 * n)) : 0ull); }
+__device__ __forceinline__ uint64_t load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }    // (the arena ends in 16 bytes of padding: an 8-byte probe never faults)
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int32_t len, uint64_t salt, uint64_t head, uint64_t head2) {
   uint32_t a = (uint32_t)salt ^ __umul24((uint32_t)len & 0xFFFFFFu, 0x9E3779u), b = (uint32_t)(salt >> 32) + ((uint32_t)len >> 24);
   int32_t k = 0;
   if (len >= 8) {
-    hash_chunk(a, b, head);
-    for (k = 8; k + 8 <= len; k += 8) { uint64_t v; __builtin_memcpy(&v, p + k, 8); hash_chunk(a, b, v); }
+    hash_chunk(a, b, head); k = 8;
+    if (len >= 16) { hash_chunk(a, b, head2); for (k = 16; k + 8 <= len; k += 8) hash_chunk(a, b, load8(p + k)); }
   }
-  if (k < len) {
-    uint64_t tail = head;
-    if (k) __builtin_memcpy(&tail, p + k, 8);                       // (the arena ends in 16 bytes of padding: an 8-byte probe never faults)
-    hash_chunk(a, b, tail & (~0ull >> (64 - 8 * (len - k))));
-  }
+  if (k < len) hash_chunk(a, b, low_bytes(k == 0 ? head : (k == 8 ? head2 : load8(p + k)), len - k));
   a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13;
   b ^= a; b *= 0xC2B2AE35u; b ^= b >> 16;
   a ^= b;
   return ((uint64_t)a << 32) | b;
 }
-// The strings of 256 rows of a 1024-row tile as a wave holds them: lane l has rows (4 g + k) * 64 + l, k = 0 .. 3 — sizes, byte offsets (a wave prefix sum of the
-// sizes per 64 rows, `run` carries on from group to group) and the first 8 bytes of every selected string, the four size loads and then the four byte loads
-// in flight together (one dependent load at a time per lane, as the loop over the sixteen words used to run, is 3.3 ms per pass over 5e8 short strings)
-constexpr int kStrGroup = 4;
-struct StrGroup { int32_t sz[kStrGroup]; int64_t off[kStrGroup]; uint64_t head[kStrGroup]; };
-__device__ __forceinline__ void load_str_group(StrGroup& T, const int32_t* __restrict__ sizes, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t tile, int g,
-                                               int lane, uint64_t mine, int64_t& run) {
-  const int64_t base = tile * kTile + (int64_t)g * kStrGroup * 64;
-  if (base + kStrGroup * 64 <= nrows) {
-#pragma unroll
-    for (int k = 0; k < kStrGroup; k++) T.sz[k] = sizes[base + k * 64 + lane];
-  } else {
-#pragma unroll
-    for (int k = 0; k < kStrGroup; k++) { const int64_t row = base + k * 64 + lane; T.sz[k] = row < nrows ? sizes[row] : 0; }
-  }
-#pragma unroll
-  for (int k = 0; k < kStrGroup; k++) {
-    const uint32_t c = T.sz[k] > 0 ? (uint32_t)T.sz[k] : 0u;
-    const uint32_t incl = wave_incl_scan(c);
-    T.off[k] = run + (int64_t)(incl - c);
-    run += (int64_t)__shfl(incl, 63, 64);
-  }
-#pragma unroll
-  for (int k = 0; k < kStrGroup; k++) {
-    const uint64_t w = __shfl(mine, g * kStrGroup + k, 64);
-    uint64_t v = 0;
-    if (((w >> lane) & 1ull) && T.sz[k] > 0) __builtin_memcpy(&v, bytes + T.off[k], 8);
-    T.head[k] = v;
-  }
-}
 
-// What a wave has already met: short strings (<= 8 bytes: length + bytes fit one entry and identify the string EXACTLY) in a direct-mapped cache in LDS, one per wave.
+// What a wave has already met: strings of up to 16 bytes (length + bytes fit one entry and identify the string EXACTLY) in a direct-mapped cache in LDS, one per wave.
 // A wave walks its tiles, the words of a tile and the lanes of a word in increasing row order, so whatever it does for a string the first time it meets it — insert
 // its key with that row (smaller than any row it will meet later), compare it with its slot's representative, find its group — holds for every later meeting:
-// those rows touch neither the hash nor the table.  With few distinct values that is nearly every row (5e8 rows of ten brands: all of them hammered the same ten
-// cache lines of one L2 channel or two per XCD, 3.4 ms per pass).  An entry has ONE writer per instruction: lanes that want a slot write their lane number beside
-// it first, the one that reads its own number back writes the 16 bytes (two lanes storing different entries to one slot in the same instruction could tear it).
+// those rows touch neither the hash nor the table.  An entry has ONE writer per instruction: lanes that want a slot write their lane number beside it first, the one
+// that reads its own number back writes the entry (two lanes storing different entries to one slot in the same instruction could tear it).
 constexpr int kMetSlots = 256;
-struct MetEntry { uint64_t head; uint32_t len, val; };
+struct MetEntry { uint64_t head, head2; uint32_t len, val; uint64_t pad; };
 struct MetCache {
   MetEntry* e; uint32_t* claim;
   __device__ __forceinline__ void init(MetEntry* entries, uint32_t* claims, int lane) {
     e = entries; claim = claims;
     for (int i = lane; i < kMetSlots; i += 64) e[i].len = 0xFFFFFFFFu;
   }
-  static __device__ __forceinline__ uint32_t slot(uint64_t head, uint32_t len) {
-    uint32_t x = ((uint32_t)head ^ ((uint32_t)(head >> 32) * 0x9E3779B1u) ^ (len * 0x85EBCA6Bu)) * 0x9E3779B1u;
-    return x >> 24;
+  static __device__ __forceinline__ uint32_t slot(uint64_t head, uint64_t head2, uint32_t len) {
+    const uint32_t x = (uint32_t)head ^ rotl32((uint32_t)(head >> 32), 7) ^ rotl32((uint32_t)head2, 13) ^ rotl32((uint32_t)(head2 >> 32), 19) ^ (len << 27);
+    return (x * 0x9E3779B1u) >> 24;
   }
-  __device__ __forceinline__ bool find(uint64_t head, uint32_t len, uint32_t& val) const {
-    const MetEntry x = e[slot(head, len)];
+  __device__ __forceinline__ bool find(uint64_t head, uint64_t head2, uint32_t len, uint32_t& val) const {
+    const MetEntry x = e[slot(head, head2, len)];
     val = x.val;
     // the value is read HERE, with the tag: left to the compiler the load sinks into the caller's hit branch, which may run after the miss branch of other
     // lanes of the same instruction has overwritten the slot (found by the forms test: rows counted for a neighbouring group)
     asm volatile("" : "+v"(val));
-    return x.len == len && x.head == head;
+    return x.len == len && x.head == head && x.head2 == head2;
   }
-  __device__ __forceinline__ void put(uint64_t head, uint32_t len, uint32_t val, int lane) {
-    const uint32_t s = slot(head, len);
+  __device__ __forceinline__ void put(uint64_t head, uint64_t head2, uint32_t len, uint32_t val, int lane) {
+    const uint32_t s = slot(head, head2, len);
     claim[s] = (uint32_t)lane;
     asm volatile("" ::: "memory");                           // the read-back must be a read (of LDS, not of the register just stored): it decides which lane goes on
-    if (claim[s] == (uint32_t)lane) { MetEntry x; x.head = head; x.len = len; x.val = val; e[s] = x; }
+    if (claim[s] == (uint32_t)lane) { MetEntry x; x.head = head; x.head2 = head2; x.len = len; x.val = val; x.pad = 0; e[s] = x; }
   }
 };
-__device__ __forceinline__ uint64_t head_of(uint64_t loaded, int32_t len) { return len >= 8 ? loaded : (len > 0 ? loaded & (~0ull >> (64 - 8 * len)) : 0ull); }
+constexpr int32_t kMetMaxLen = 16;
 
 // do the two strings hold the same bytes?  (8 at a time; both live in the padded arena)
 __device__ __forceinline__ bool same_bytes(const uint8_t* a, int32_t la, const uint8_t* b, uint32_t lb) {
   if ((uint32_t)la != lb) return false;
   int32_t k = 0;
-  for (; k + 8 <= la; k += 8) { uint64_t x, y; __builtin_memcpy(&x, a + k, 8); __builtin_memcpy(&y, b + k, 8); if (x != y) return false; }
-  if (k < la) { uint64_t x, y; __builtin_memcpy(&x, a + k, 8); __builtin_memcpy(&y, b + k, 8); if ((x ^ y) & (~0ull >> (64 - 8 * (la - k)))) return false; }
+  for (; k + 8 <= la; k += 8) if (load8(a + k) != load8(b + k)) return false;
+  if (k < la && ((load8(a + k) ^ load8(b + k)) & (~0ull >> (64 - 8 * (la - k))))) return false;
   return true;
 }
 
-// MODE 0: insert (hash, row) for the tiles [tile0, tile1) and remember one holder's bytes; 1: verify every selected row against its slot's
-// representative; 2: mark first occurrences.  One wave per 1024-row tile: the rows' byte offsets are a wave prefix sum of the sizes.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_unique_str(uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, const int32_t* __restrict__ sizes,
-                                                       const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t tile0, int64_t tile1,
-                                                       UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
-                                                       uint64_t* aux, uint64_t salt) {
-  __shared__ uint32_t claims_sh;
-  __shared__ MetEntry met_e[MODE == 2 ? 1 : kWavesPerBlock][MODE == 2 ? 1 : kMetSlots];
-  __shared__ uint32_t met_c[MODE == 2 ? 1 : kWavesPerBlock][MODE == 2 ? 1 : kMetSlots];
-  if (MODE == 0) { if (threadIdx.x == 0) claims_sh = 0; __syncthreads(); }
-  uint32_t claimed = 0;
-  int* collision = (int*)(aux + 4);
-  const int lane = lane_id();
-  MetCache met;
-  if (MODE != 2) met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t tile = tile0 + wave; tile < tile1; tile += nwaves) {
-    if (MODE == 0 && __atomic_load_n(&aux[kAuxAbort], __ATOMIC_RELAXED)) break;      // (wave-uniform) too full: the host grows the table and repeats the chunk
-    const uint64_t mine = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
-    if (__ballot(mine != 0) == 0) { if (MODE == 2 && lane == 0) tile_counts[tile] = 0; continue; }
-    uint64_t myword = 0; uint32_t cnt = 0;
-    int64_t run = tile_off[tile];
-#pragma unroll 1
-    for (int g = 0; g < 16 / kStrGroup; g++) {
-     StrGroup T;
-     load_str_group(T, sizes, bytes, nrows, tile, g, lane, mine, run);
-#pragma unroll
-     for (int k = 0; k < kStrGroup; k++) {
-      const int j = g * kStrGroup + k;
-      const int64_t row = tile * kTile + j * 64 + lane;
-      const int32_t sz = T.sz[k];
-      const int64_t off = T.off[k];
-      const uint64_t w = __shfl(mine, j, 64);
-      bool first = false;
-      if (row < nrows && ((w >> lane) & 1ull)) {
-        if (sz < 0) {                                                     // missing
-          if (MODE == 0) { if (__atomic_load_n(&aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[1], (unsigned long long)row); }
-          else if (MODE == 2) first = aux[1] == (uint64_t)row;
-        } else {
-          const uint64_t head = head_of(T.head[k], sz);
-          uint32_t unused;
-          if (MODE != 2 && sz <= 8 && met.find(head, (uint32_t)sz, unused)) {
-            // this wave has inserted / verified the very same string before, at a smaller row
-          } else {
-            uint64_t key = hash_bytes(bytes + off, sz, salt, T.head[k]);
-            if (key == kEmpty) key = 0x1234567ull;                       // (any fixed remap: equal strings still get equal keys)
-            if (MODE == 0) {
-              const uint64_t r = table_insert(ent, mask, key, (uint64_t)row, aux, key & mask);
-              if (r != kNoSlot && !(r >> 63)) { rep_off[r] = (uint64_t)off; rep_len[r] = (uint32_t)sz; claimed++; }   // I claimed the slot: my bytes represent it
-              if (r != kNoSlot && sz <= 8) met.put(head, (uint32_t)sz, 1u, lane);
-            } else {
-              const uint64_t h = table_find(ent, mask, key, key & mask);
-              if (MODE == 1) {
-                if (!same_bytes(bytes + off, sz, bytes + rep_off[h], rep_len[h])) atomicOr(collision, 1);
-                else if (sz <= 8) met.put(head, (uint32_t)sz, 1u, lane);
-              } else first = ent[h].row == (uint64_t)row;
-            }
-          }
-        }
-      }
-      if (MODE == 2) { const uint64_t m = __ballot(first); if (lane == j) myword = m; cnt += (uint32_t)__popcll(m); }
-     }
-    }
-    if (MODE == 2) {
-      if (lane < 16) bitmap[tile * 16 + lane] = myword;
-      if (lane == 0) tile_counts[tile] = cnt;
-    }
-  }
-  if (MODE == 0) add_claims(claimed, &claims_sh, aux);
-}
-
-static int grid_rows(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
-static int grid_tiles(int64_t nt) { int64_t b = (nt + kWavesPerBlock - 1) / kWavesPerBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
-
-void launch_unique_insert(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1,
-                          UniqueEntry* ent, uint64_t mask, uint64_t* aux) {
-  if (row1 <= row0) return;
-  hipLaunchKernelGGL(k_unique_insert, dim3(grid_rows(row1 - row0)), dim3(kBlock), 0, s, bitmap, col, dtype, missing, row0, row1, ent, mask, aux);
-}
-void launch_unique_mark(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing, int64_t nrows,
-                        const UniqueEntry* ent, uint64_t mask, const uint64_t* aux) {
-  if (nrows <= 0) return;
-  const int64_t ntiles = (nrows + kTile - 1) / kTile;
-  hipLaunchKernelGGL(k_unique_mark, dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, bitmap, tile_counts, col, dtype, missing, nrows, ntiles, ent, mask, aux);
-}
-void launch_unique_migrate(hipStream_t s, const UniqueEntry* from, const uint64_t* from_off, const uint32_t* from_len, uint64_t from_cap, UniqueEntry* ent,
-                           uint64_t* rep_off, uint32_t* rep_len, uint64_t mask, uint64_t* aux) {
-  hipLaunchKernelGGL(k_unique_migrate, dim3(grid_rows((int64_t)from_cap)), dim3(kBlock), 0, s, from, from_off, from_len, from_cap, ent, rep_off, rep_len, mask, aux);
-}
-void launch_unique_scatter(hipStream_t s, const UniqueEntry* ent, uint64_t cap, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts) {
-  hipLaunchKernelGGL(k_unique_scatter, dim3(grid_rows((int64_t)cap + 2)), dim3(kBlock), 0, s, ent, cap, aux, bitmap, tile_counts);
-}
-void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
-                       const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
-                       uint64_t* aux, uint64_t salt) {
-  if (tile1 <= tile0) return;
-  const dim3 g(grid_tiles(tile1 - tile0)), b(kBlock);
-  if (pass == 0) hipLaunchKernelGGL((k_unique_str<0>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
-  else if (pass == 1) hipLaunchKernelGGL((k_unique_str<1>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
-  else hipLaunchKernelGGL((k_unique_str<2>), g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile0, tile1, ent, rep_off, rep_len, mask, aux, salt);
-}
-
-// ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
-// The reference's groupreduce numbers the groups in order of first appearance of the key (group_map[elem] = length(group_map) + 1) and stops
-// there (it is unfinished: it prints the map).  Completed to that intent on top of unique's table: after the unique passes the table maps a
-// key to the row of its first occurrence and the bitmap holds exactly those rows, so a group's number is the RANK of its first row among them
-// (k_group_ids turns the table's row slots into group numbers, once per group); k_group_accumulate then sends every selected row's value to its
-// group's accumulator — privatised in LDS per workgroup when there are few groups (ten brands over 5e8 rows would otherwise be 5e8 atomics on ten
-// addresses), global atomics otherwise.  Accumulators are 64-bit: counts, wrapping integer sums (Julia's), double sums, and min / max through an
-// order-preserving image (a NaN wins both, like Julia's minimum / maximum).
+// ---- groupreduce's accumulators (the comment at `groupreduce` below says what they are for)
 constexpr int kGroupLds = 1024;                      // groups that fit the per-workgroup accumulators
-
-__device__ __forceinline__ uint64_t rank_of_row(const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix, uint64_t row) {
-  const uint64_t tile = row >> 10, w = (row & 1023) >> 6;
-  uint64_t r = uprefix[tile];
-  for (uint64_t k = 0; k < w; k++) r += (uint64_t)__popcll(ubits[tile * 16 + k]);
-  return r + (uint64_t)__popcll(ubits[tile * 16 + w] & ((1ull << (row & 63)) - 1ull));
-}
-__global__ __launch_bounds__(kBlock) void k_group_ids(UniqueEntry* __restrict__ ent, uint64_t cap, uint64_t* __restrict__ special,
-                                                      const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < cap && ent[i].key != kEmpty) ent[i].row = rank_of_row(ubits, uprefix, ent[i].row);
-  if (i < 2 && special[i] != kEmpty) special[i] = rank_of_row(ubits, uprefix, special[i]);
-}
-
 // the value of row `row` as the accumulator sees it: 0 = int64 (wrapping sum / signed order), 1 = uint64, 2 = double
 __device__ __forceinline__ uint64_t value_bits(const void* col, int dtype, int64_t row, int& kind) {
   switch (dtype) {
@@ -441,6 +283,235 @@ __device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t
   }
 }
 
+// ---- one pass over the selected rows of a String column, a wave per 1024-row tile, in two steps (round 4).
+// FAST: the sixteen sizes of a lane in flight together, then per half tile the byte offsets (a wave prefix sum of the sizes per 64 rows) and the first 8 (16) bytes
+//   of every selected string, again in flight together — a row whose string the wave has met before (MetCache) is DONE here: nothing to do (insert, verify) or its
+//   group is known (accumulate).  The other rows leave a bit in the word's miss mask.
+// SLOW: only the words with misses — sizes again, the word's own prefix sum from its recorded start, hash, table, representative, and the cache learns the string.
+// Few distinct values: after a wave's first tiles everything is FAST and the pass runs at what the loads allow; many: both steps run, the second as the whole pass did.
+// KIND 0: insert {key, row} for the tiles [tile0, tile1); 1: compare every selected row with its slot's representative; 2: groupreduce's accumulate pass (+ that compare)
+struct StrPassArgs {
+  const uint64_t* sel; const int32_t* sizes; const int64_t* tile_off; const uint8_t* bytes; int64_t nrows, tile0, tile1;
+  UniqueEntry* ent; uint64_t* rep_off; uint32_t* rep_len; uint64_t mask; uint64_t* aux; uint64_t salt;
+  const void* valcol; int valdt, op; uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;       // KIND 2
+};
+template <int KIND, bool LDS>
+__global__ __launch_bounds__(kBlock) void k_str_pass(const StrPassArgs A) {
+  __shared__ uint32_t claims_sh;
+  __shared__ uint64_t lcnt[(KIND == 2 && LDS) ? kGroupLds : 1], lval[(KIND == 2 && LDS) ? kGroupLds : 1];
+  __shared__ MetEntry met_e[kWavesPerBlock][kMetSlots];
+  __shared__ uint32_t met_c[kWavesPerBlock][kMetSlots];
+  const int lane = lane_id();
+  const bool has_val = KIND == 2 && A.valcol != nullptr && A.op != DFDB_AGG_COUNT;
+  if (KIND == 0 && threadIdx.x == 0) claims_sh = 0;
+  if (KIND == 2 && LDS) for (int g = threadIdx.x; g < A.ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; }
+  if (KIND == 0 || (KIND == 2 && LDS)) __syncthreads();
+  MetCache met;
+  met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
+  uint32_t claimed = 0;
+  int* collision = (int*)(A.aux + 4);
+  const uint64_t gid_missing = KIND == 2 ? A.aux[1] : 0ull;
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = A.tile0 + wave; tile < A.tile1; tile += nwaves) {
+    if (KIND == 0 && __atomic_load_n(&A.aux[kAuxAbort], __ATOMIC_RELAXED)) break;      // (wave-uniform) too full: the host grows the table and repeats the chunk
+    const uint64_t mine = lane < 16 ? A.sel[tile * 16 + lane] : 0ull;
+    if (__ballot(mine != 0) == 0) continue;
+    const int64_t base = tile * kTile;
+    const bool whole = base + kTile <= A.nrows;
+    const uint8_t* tb = A.bytes + A.tile_off[tile];
+    int32_t sz[16];
+    if (whole) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) sz[j] = __builtin_nontemporal_load(A.sizes + base + j * 64 + lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int64_t row = base + j * 64 + lane; sz[j] = row < A.nrows ? A.sizes[row] : 0; }
+    }
+    uint64_t missw = 0; uint32_t wordoff = 0, run = 0;        // lane j: the miss mask / the byte offset (inside the tile) of word j
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t rel[8]; uint64_t head[8], head2[8], bits[KIND == 2 ? 8 : 1]; bool on[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t c = sz[h * 8 + j] > 0 ? (uint32_t)sz[h * 8 + j] : 0u;
+        const uint32_t incl = wave_incl_scan(c);
+        rel[j] = run + incl - c;
+        if (lane == h * 8 + j) wordoff = run;
+        run += (uint32_t)__shfl(incl, 63, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint64_t w = __shfl(mine, h * 8 + j, 64);
+        on[j] = ((w >> lane) & 1ull) && (whole || base + (h * 8 + j) * 64 + lane < A.nrows);
+        const int32_t s0 = sz[h * 8 + j];
+        head[j] = (on[j] && s0 > 0) ? load8(tb + rel[j]) : 0ull;
+        head2[j] = (on[j] && s0 > 8) ? load8(tb + rel[j] + 8) : 0ull;
+        if (KIND == 2) { int kind = 0; bits[j] = (on[j] && has_val) ? value_bits(A.valcol, A.valdt, base + (h * 8 + j) * 64 + lane, kind) : 0ull; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int32_t s0 = sz[h * 8 + j];
+        const int64_t row = base + (h * 8 + j) * 64 + lane;
+        bool miss = false;
+        if (KIND == 0) {                                        // the word's smallest selected missing row
+          const uint64_t mm = __ballot(on[j] && s0 < 0);
+          if (mm && lane == __builtin_ctzll(mm) && __atomic_load_n(&A.aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&A.aux[1], (unsigned long long)row);
+        }
+        if (on[j]) {
+          uint32_t g32 = 0;
+          bool known = false;
+          uint64_t gid = gid_missing;
+          if (s0 >= 0) {
+            known = s0 <= kMetMaxLen && met.find(low_bytes(head[j], s0), low_bytes(head2[j], s0 - 8), (uint32_t)s0, g32);
+            gid = g32;
+            miss = !known;
+          }
+          if (KIND == 2 && !miss) {
+            int kind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, kind);       // (the value kind is a property of the column)
+            if (LDS) group_add(lcnt, lval, gid, bits[j], kind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits[j], kind, A.op, has_val);
+          }
+        }
+        const uint64_t m = __ballot(miss);
+        if (lane == h * 8 + j) missw = m;
+      }
+    }
+    if (__ballot(missw != 0) == 0) continue;
+#pragma unroll 1
+    for (int jj = 0; jj < 16; jj++) {
+      const uint64_t m = __shfl(missw, jj, 64);
+      if (m == 0) continue;                                     // (wave-uniform)
+      const int64_t row = base + jj * 64 + lane;
+      const int32_t s0 = row < A.nrows ? A.sizes[row] : 0;
+      const uint32_t c = s0 > 0 ? (uint32_t)s0 : 0u;
+      const uint32_t incl = wave_incl_scan(c);
+      const int64_t off = A.tile_off[tile] + (int64_t)((uint32_t)__shfl(wordoff, jj, 64) + incl - c);
+      if (!((m >> lane) & 1ull)) continue;
+      const uint8_t* p = A.bytes + off;
+      const uint64_t h1 = s0 > 0 ? load8(p) : 0ull, h2 = s0 > 8 ? load8(p + 8) : 0ull;
+      uint64_t key = hash_bytes(p, s0, A.salt, h1, h2);
+      if (key == kEmpty) key = 0x1234567ull;                    // (any fixed remap: equal strings still get equal keys)
+      const uint64_t c1 = low_bytes(h1, s0), c2 = low_bytes(h2, s0 - 8);
+      if (KIND == 0) {
+        const uint64_t r = table_insert(A.ent, A.mask, key, (uint64_t)row, A.aux, key & A.mask);
+        if (r != kNoSlot && !(r >> 63)) { A.rep_off[r] = (uint64_t)off; A.rep_len[r] = (uint32_t)s0; claimed++; }   // I claimed the slot: my bytes represent it
+        if (r != kNoSlot && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
+      } else {
+        const uint64_t hs = table_find(A.ent, A.mask, key, key & A.mask);
+        const bool same = !A.rep_off || same_bytes(p, s0, A.bytes + A.rep_off[hs], A.rep_len[hs]);
+        if (!same) atomicOr(collision, 1);                      // two different strings, one key: the host repeats with another salt
+        if (KIND == 2) {
+          const uint64_t gid = A.ent[hs].row;
+          if (same && s0 <= kMetMaxLen && gid < 0xFFFFFFFFull) met.put(c1, c2, (uint32_t)s0, (uint32_t)gid, lane);
+          int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
+          if (LDS) group_add(lcnt, lval, gid, bits, kind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits, kind, A.op, has_val);
+        } else if (same && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
+      }
+    }
+  }
+  if (KIND == 0) add_claims(claimed, &claims_sh, A.aux);
+  if (KIND == 2 && LDS) {
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);
+    group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, k2, has_val);
+  }
+}
+
+// mark the first occurrences row by row (many distinct values: the table's rows are compared with every selected row's own)
+__global__ __launch_bounds__(kBlock) void k_unique_str_mark(uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, const int32_t* __restrict__ sizes,
+                                                            const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes, int64_t nrows, int64_t ntiles,
+                                                            const UniqueEntry* __restrict__ ent, uint64_t mask, const uint64_t* __restrict__ aux, uint64_t salt) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const uint64_t mine = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
+    if (__ballot(mine != 0) == 0) { if (lane == 0) tile_counts[tile] = 0; continue; }
+    uint64_t myword = 0; uint32_t cnt = 0;
+    int64_t run = tile_off[tile];
+    for (int j = 0; j < 16; j++) {
+      const int64_t row = tile * kTile + j * 64 + lane;
+      const int32_t sz = row < nrows ? sizes[row] : 0;
+      const uint32_t c = sz > 0 ? (uint32_t)sz : 0u;
+      const uint32_t incl = wave_incl_scan(c);
+      const int64_t off = run + (int64_t)(incl - c);
+      run += (int64_t)__shfl(incl, 63, 64);
+      const uint64_t w = __shfl(mine, j, 64);
+      bool first = false;
+      if (row < nrows && ((w >> lane) & 1ull)) {
+        if (sz < 0) first = aux[1] == (uint64_t)row;
+        else {
+          const uint8_t* p = bytes + off;
+          uint64_t key = hash_bytes(p, sz, salt, sz > 0 ? load8(p) : 0ull, sz > 8 ? load8(p + 8) : 0ull);
+          if (key == kEmpty) key = 0x1234567ull;
+          first = ent[table_find(ent, mask, key, key & mask)].row == (uint64_t)row;
+        }
+      }
+      const uint64_t m = __ballot(first);
+      if (lane == j) myword = m;
+      cnt += (uint32_t)__popcll(m);
+    }
+    if (lane < 16) bitmap[tile * 16 + lane] = myword;
+    if (lane == 0) tile_counts[tile] = cnt;
+  }
+}
+
+static int grid_rows(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+static int grid_tiles(int64_t nt) { int64_t b = (nt + kWavesPerBlock - 1) / kWavesPerBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+void launch_unique_insert(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1,
+                          UniqueEntry* ent, uint64_t mask, uint64_t* aux) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(k_unique_insert, dim3(grid_rows(row1 - row0)), dim3(kBlock), 0, s, bitmap, col, dtype, missing, row0, row1, ent, mask, aux);
+}
+void launch_unique_mark(hipStream_t s, uint64_t* bitmap, uint32_t* tile_counts, const void* col, int dtype, const uint64_t* missing, int64_t nrows,
+                        const UniqueEntry* ent, uint64_t mask, const uint64_t* aux) {
+  if (nrows <= 0) return;
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  hipLaunchKernelGGL(k_unique_mark, dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, bitmap, tile_counts, col, dtype, missing, nrows, ntiles, ent, mask, aux);
+}
+void launch_unique_migrate(hipStream_t s, const UniqueEntry* from, const uint64_t* from_off, const uint32_t* from_len, uint64_t from_cap, UniqueEntry* ent,
+                           uint64_t* rep_off, uint32_t* rep_len, uint64_t mask, uint64_t* aux) {
+  hipLaunchKernelGGL(k_unique_migrate, dim3(grid_rows((int64_t)from_cap)), dim3(kBlock), 0, s, from, from_off, from_len, from_cap, ent, rep_off, rep_len, mask, aux);
+}
+void launch_unique_scatter(hipStream_t s, const UniqueEntry* ent, uint64_t cap, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts) {
+  hipLaunchKernelGGL(k_unique_scatter, dim3(grid_rows((int64_t)cap + 2)), dim3(kBlock), 0, s, ent, cap, aux, bitmap, tile_counts);
+}
+void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile_counts, const int32_t* sizes, const int64_t* tile_off,
+                       const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
+                       uint64_t* aux, uint64_t salt) {
+  if (tile1 <= tile0) return;
+  const dim3 g(grid_tiles(tile1 - tile0)), b(kBlock);
+  if (pass == 2) { hipLaunchKernelGGL(k_unique_str_mark, g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile1, ent, mask, aux, salt); return; }
+  StrPassArgs A{};
+  A.sel = bitmap; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = tile0; A.tile1 = tile1;
+  A.ent = ent; A.rep_off = rep_off; A.rep_len = rep_len; A.mask = mask; A.aux = aux; A.salt = salt;
+  if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, false>), g, b, 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<1, false>), g, b, 0, s, A);
+}
+
+// ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
+// The reference's groupreduce numbers the groups in order of first appearance of the key (group_map[elem] = length(group_map) + 1) and stops
+// there (it is unfinished: it prints the map).  Completed to that intent on top of unique's table: after the unique passes the table maps a
+// key to the row of its first occurrence and the bitmap holds exactly those rows, so a group's number is the RANK of its first row among them
+// (k_group_ids turns the table's row slots into group numbers, once per group); k_group_accumulate then sends every selected row's value to its
+// group's accumulator — privatised in LDS per workgroup when there are few groups (ten brands over 5e8 rows would otherwise be 5e8 atomics on ten
+// addresses), global atomics otherwise.  Accumulators are 64-bit: counts, wrapping integer sums (Julia's), double sums, and min / max through an
+// order-preserving image (a NaN wins both, like Julia's minimum / maximum).
+
+__device__ __forceinline__ uint64_t rank_of_row(const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix, uint64_t row) {
+  const uint64_t tile = row >> 10, w = (row & 1023) >> 6;
+  uint64_t r = uprefix[tile];
+  for (uint64_t k = 0; k < w; k++) r += (uint64_t)__popcll(ubits[tile * 16 + k]);
+  return r + (uint64_t)__popcll(ubits[tile * 16 + w] & ((1ull << (row & 63)) - 1ull));
+}
+__global__ __launch_bounds__(kBlock) void k_group_ids(UniqueEntry* __restrict__ ent, uint64_t cap, uint64_t* __restrict__ special,
+                                                      const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < cap && ent[i].key != kEmpty) ent[i].row = rank_of_row(ubits, uprefix, ent[i].row);
+  if (i < 2 && special[i] != kEmpty) special[i] = rank_of_row(ubits, uprefix, special[i]);
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
                                                              const void* __restrict__ valcol, int valdt, int op, int64_t nrows,
@@ -464,67 +535,6 @@ __global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __r
     __syncthreads();
     int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);      // (the value kind is a property of the column)
     (void)val_kind;
-    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
-  }
-}
-
-// String keys: one wave per 1024-row tile (byte offsets are a wave prefix sum of the sizes, as in k_unique_str)
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_group_accumulate_str(const uint64_t* __restrict__ sel, const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
-                                                                 const uint8_t* __restrict__ bytes, const void* __restrict__ valcol, int valdt, int op, int64_t nrows, int64_t ntiles,
-                                                                 const UniqueEntry* __restrict__ ent, const uint64_t* __restrict__ rep_off, const uint32_t* __restrict__ rep_len, uint64_t mask,
-                                                                 uint64_t* __restrict__ special, uint64_t salt, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
-  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
-  __shared__ MetEntry met_e[kWavesPerBlock][kMetSlots];
-  __shared__ uint32_t met_c[kWavesPerBlock][kMetSlots];
-  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
-  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
-  const int lane = lane_id();
-  MetCache met;
-  met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
-  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    const uint64_t mine = lane < 16 ? sel[tile * 16 + lane] : 0ull;
-    if (__ballot(mine != 0) == 0) continue;
-    int64_t run = tile_off[tile];
-#pragma unroll 1
-    for (int g = 0; g < 16 / kStrGroup; g++) {
-     StrGroup T;
-     load_str_group(T, sizes, bytes, nrows, tile, g, lane, mine, run);
-#pragma unroll
-     for (int k = 0; k < kStrGroup; k++) {
-      const int j = g * kStrGroup + k;
-      const int64_t row = tile * kTile + j * 64 + lane;
-      const int32_t sz = T.sz[k];
-      const int64_t off = T.off[k];
-      const uint64_t w = __shfl(mine, j, 64);
-      if (row < nrows && ((w >> lane) & 1ull)) {
-        uint64_t gid;
-        if (sz < 0) gid = special[1];
-        else {
-          const uint64_t head = head_of(T.head[k], sz);
-          uint32_t g32;
-          if (sz <= 8 && met.find(head, (uint32_t)sz, g32)) gid = g32;          // the very same string, met by this wave before: its group, and it was compared then
-          else {
-            uint64_t key = hash_bytes(bytes + off, sz, salt, T.head[k]); if (key == kEmpty) key = 0x1234567ull;
-            const uint64_t h = table_find(ent, mask, key, key & mask);
-            gid = ent[h].row;
-            // unique's verify pass, folded into this one (every selected row against its slot's representative): a true hash collision makes the host repeat with another salt
-            const bool same = !rep_off || same_bytes(bytes + off, sz, bytes + rep_off[h], rep_len[h]);
-            if (!same) atomicOr((int*)(special + 4), 1);
-            else if (sz <= 8 && gid < 0xFFFFFFFFull) met.put(head, (uint32_t)sz, (uint32_t)gid, lane);
-          }
-        }
-        int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
-        if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
-      }
-     }
-    }
-  }
-  if (LDS) {
-    __syncthreads();
-    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
     group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
   }
 }
@@ -609,14 +619,19 @@ void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* key
   if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
   else hipLaunchKernelGGL((k_group_accumulate<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
 }
+// String keys: k_str_pass, KIND 2
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
                                  int op, int64_t nrows, const UniqueEntry* ent, const uint64_t* rep_off, const uint32_t* rep_len, uint64_t mask, uint64_t* special, uint64_t salt,
                                  uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
   if (nrows <= 0) return;
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  StrPassArgs A{};
+  A.sel = sel; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = 0; A.tile1 = ntiles;
+  A.ent = const_cast<UniqueEntry*>(ent); A.rep_off = const_cast<uint64_t*>(rep_off); A.rep_len = const_cast<uint32_t*>(rep_len); A.mask = mask; A.aux = special; A.salt = salt;
+  A.valcol = valcol; A.valdt = valdt; A.op = op; A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
   const int g = grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles);
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_str<true>), dim3(g), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, ent, rep_off, rep_len, mask, special, salt, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate_str<false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, sizes, tile_off, bytes, valcol, valdt, op, nrows, ntiles, ent, rep_off, rep_len, mask, special, salt, cnt, val, (int)ngroups, val_init);
+  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_str_pass<2, true>), dim3(g), dim3(kBlock), 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<2, false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, A);
 }
 // accumulators -> results: min / max images back to values (in place)
 __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
