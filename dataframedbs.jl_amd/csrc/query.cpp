@@ -1139,7 +1139,7 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
   if (!placed) fail(DFDB_ERR_DEVICE, "unique: a key outside the range of its column");
   T.dense = true;
   { LaunchTimer lt(ctx, "unique_first");
-    int64_t step = std::max<int64_t>(1, ctx_option(ctx, "unique_chunk_tiles", 4096));
+    int64_t step = ctx_option(ctx, "unique_chunk_tiles", 0) > 0 ? ctx_option(ctx, "unique_chunk_tiles", 0) : 4096;
     for (int64_t t0 = 0; t0 < nt; t0 += step, step *= 4)
       launch_dense_first(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(t->nrows, (t0 + step) * kTileRows), T.lo, T.range, distinct, T.first.as<uint64_t>(), aux);
   }
@@ -1162,7 +1162,7 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
   const int64_t nt = ceil_div(t->nrows, kTileRows);
   const uint64_t capmax = pow2_at_least((uint64_t)cnt * 2);
   const uint64_t cap0 = std::min(capmax, pow2_at_least(1ull << std::min<int64_t>(40, std::max<int64_t>(10, ctx_option(ctx, "unique_cap0_log2", 21)))));
-  const int64_t c0 = std::max<int64_t>(1, ctx_option(ctx, "unique_chunk_tiles", 1024));
+  const int64_t c0 = ctx_option(ctx, "unique_chunk_tiles", 0) > 0 ? ctx_option(ctx, "unique_chunk_tiles", 0) : 1024;
   const int64_t bounds[3] = {std::min(nt, c0), std::min(nt, c0 * 17), nt};
   auto alloc = [&](UniqueTables& U, uint64_t cap) {
     U.cap = cap;

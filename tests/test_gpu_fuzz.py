@@ -330,9 +330,25 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
     from test_gpu_parity import _np_group_ids, _np_groupreduce
     g = Gen(ir, 90_000 + seed, risky=False)
     stages = g.stages()
-    key = g.pick(["a", "i8", "s", "m", "c"])
+    key = g.pick(["a", "i8", "s", "m", "c", "i32", "u64", "x"])
     val = g.pick([v for v in ["a", "b", "i32", "u16", "x", "c"] if v != key])      # (a projection cannot name a column twice)
     stat = g.pick(["count", "sum", "min", "max", "mean"])
+    # every form of unique's machinery in turn (round 4): the defaults; the hash table only; a 1024-slot table fed one tile at a time (aborted chunks, migrations);
+    # the dense form with a span of 100 values (keys outside the first placement, then the hash table for the wider columns), one-tile launches, the exact range
+    forms = [{}, {"unique_dense": 0}, {"unique_dense": 0, "unique_cap0_log2": 10, "unique_chunk_tiles": 1}, {"unique_dense_range": 100, "unique_chunk_tiles": 1, "unique_dense_sample": seed % 8 < 4}]
+    defaults = {"unique_dense": 1, "unique_cap0_log2": 21, "unique_chunk_tiles": 0, "unique_dense_range": 1 << 40, "unique_dense_sample": 1}
+    ctx0 = dfdb_mod.default_context(0)
+    for k, v in {**defaults, **forms[seed % 4]}.items():
+        ctx0.set_option(k, int(v))
+    try:
+        _groupreduce_and_unique_case(pair, dfdb_mod, g, stages, key, val, stat)
+    finally:
+        for k, v in defaults.items():
+            ctx0.set_option(k, v)
+
+
+def _groupreduce_and_unique_case(pair, dfdb_mod, g, stages, key, val, stat):
+    from test_gpu_parity import _np_group_ids, _np_groupreduce
     ov, dv = apply_stages_both(pair, stages)      # skips only when oracle AND engine refuse the queue with the same exception class; a one-sided refusal fails
     idx = ov.select_indices() - 1
     cols = full_columns(pair)
@@ -341,6 +357,8 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
         keys = [None if m else int(v) for v, m in zip(keys.data, np.ma.getmaskarray(keys))]
     elif not isinstance(keys, list):
         keys = keys.tolist()
+    if key == "x":                                          # isequal on Float64: one NaN, -0.0 apart from 0.0 (the keys come back as floats: compare images)
+        keys = [("nan",) if v != v else (v, bool(np.signbit(v))) for v in keys]
     vals = cols[val][idx]
     ids = _np_group_ids(keys)
     order, cnt, acc = _np_groupreduce(ids, vals, "sum" if stat in ("min", "max") else stat)
@@ -349,7 +367,10 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
         acc = np.array([(np.nan if (vals.dtype.kind == "f" and np.isnan(vals[gid == k]).any()) else (vals[gid == k].min() if stat == "min" else vals[gid == k].max()))
                         for k in range(len(order))], dtype=np.float64 if vals.dtype.kind == "f" else vals.dtype)
     got = dfdb_mod.groupreduce(dv, key, val, stat)
-    gk = [None if (k is None or k is np.ma.masked or (isinstance(k, float) and k != k)) else k for k in got[key].tolist()]
+    if key == "x":
+        gk = [("nan",) if v != v else (v, bool(np.signbit(v))) for v in got[key].tolist()]
+    else:
+        gk = [None if (k is None or k is np.ma.masked or (isinstance(k, float) and k != k)) else k for k in got[key].tolist()]
     assert gk == [None if k is None else k for k in order], (key, stages)
     assert got["count"].tolist() == cnt.tolist()
     if stat != "count" and len(order):
@@ -364,7 +385,10 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
             assert gv.astype(np.int64).tolist() == np.asarray(acc).astype(np.int64).tolist(), (stat, val)
     # unique of the key column over the same queue
     uk = dv[dfdb_mod.ALL, key].unique()
-    uk = [None if (k is None or k is np.ma.masked) else k for k in (uk.tolist() if hasattr(uk, "tolist") else list(uk))]
+    if key == "x":
+        uk = [("nan",) if v != v else (v, bool(np.signbit(v))) for v in uk.tolist()]
+    else:
+        uk = [None if (k is None or k is np.ma.masked) else k for k in (uk.tolist() if hasattr(uk, "tolist") else list(uk))]
     assert uk == [None if k is None else k for k in order]
 
 
