@@ -20,6 +20,7 @@
 // (two different strings, one key), in which case the host repeats with another salt: the result is exact, not probabilistic.
 // Integer keys of a small range take the dense form at the end of this file instead (no hashing: a presence bit per value in LDS).
 #include "device_utils.hpp"
+#include <algorithm>
 #include "kernels.hpp"
 #include "../../include/dfdb_ir.h"
 
@@ -271,8 +272,8 @@ __device__ __forceinline__ void group_add(uint64_t* cnt, uint64_t* val, uint64_t
   else if (op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, op));
 }
 // merge a workgroup's LDS accumulators into the global ones (val_kind: 2 = double sums)
-__device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t* lval, uint64_t* cnt, uint64_t* val, int ngroups, int op, int val_kind, bool has_val) {
-  for (int g = threadIdx.x; g < ngroups; g += kBlock) {
+__device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t* lval, uint64_t* cnt, uint64_t* val, int ngroups, int op, int val_kind, bool has_val, int nthreads = kBlock) {
+  for (int g = threadIdx.x; g < ngroups; g += nthreads) {
     const uint64_t c = lcnt[g];
     if (!c) continue;
     atomicAdd((unsigned long long*)&cnt[g], (unsigned long long)c);
@@ -512,31 +513,50 @@ __global__ __launch_bounds__(kBlock) void k_group_ids(UniqueEntry* __restrict__ 
   if (i < 2 && special[i] != kEmpty) special[i] = rank_of_row(ubits, uprefix, special[i]);
 }
 
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_group_accumulate(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
-                                                             const void* __restrict__ valcol, int valdt, int op, int64_t nrows,
-                                                             const UniqueEntry* __restrict__ ent, uint64_t mask,
-                                                             const uint64_t* __restrict__ special, uint64_t* cnt, uint64_t* val, int ngroups, uint64_t val_init) {
-  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
-  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
-  int val_kind = 0;
-  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
-    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
+// ---- groupreduce's accumulate pass for keys that are not flat Strings (those: k_str_pass).  SRC 0: the key's group number out of the hash table, 1: out of the
+// dictionary codes' rank table, 2: out of the dense form's table.  NG = how many groups the workgroup's own accumulators hold: 1024 (16 KB of LDS, 256 threads, several
+// workgroups per CU), 9216 (144 KB, one 1024-thread workgroup per CU: round 4 — 1e9 rows in 5 000 groups were 2e9 global atomics, 85 ms), 0 = global atomics
+constexpr int kGroupLdsBig = 9216;
+struct AccArgs {
+  const uint64_t* sel; const void* keycol; int keydt; const uint64_t* missing; const void* valcol; int valdt, op; int64_t nrows;
+  const UniqueEntry* ent; uint64_t mask; const uint64_t* special;       // SRC 0 (special: aux — the groups of the unstorable key and of missing)
+  const uint16_t* codes; const uint32_t* rank_of_code;                  // SRC 1
+  uint64_t lo; const uint64_t* gids;                                    // SRC 2 (special[1]: the group of missing)
+  uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;
+};
+template <int NG, int SRC>
+__global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(const AccArgs A) {
+  __shared__ uint64_t lcnt[NG ? NG : 1], lval[NG ? NG : 1];
+  const int nthreads = NG > kGroupLds ? 1024 : kBlock;
+  const bool has_val = A.valcol != nullptr && A.op != DFDB_AGG_COUNT;
+  if (NG) { for (int g = threadIdx.x; g < A.ngroups; g += nthreads) { lcnt[g] = 0; lval[g] = A.val_init; } __syncthreads(); }
+  const int64_t stride = (int64_t)gridDim.x * nthreads;
+  for (int64_t row = (int64_t)blockIdx.x * nthreads + threadIdx.x; row < A.nrows; row += stride) {
+    if (!((A.sel[row >> 6] >> (row & 63)) & 1ull)) continue;
     uint64_t gid;
-    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) gid = special[1];
-    else { const uint64_t key = key_fixed(keycol, keydt, row); gid = key == kEmpty ? special[0] : ent[table_find(ent, mask, key, slot_of(key, mask))].row; }
-    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
-    val_kind = kind;
-    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
+    if (SRC == 1) gid = A.rank_of_code[A.codes[row]];
+    else if (A.missing && ((A.missing[row >> 6] >> (row & 63)) & 1ull)) gid = A.special[1];
+    else {
+      const uint64_t key = key_fixed(A.keycol, A.keydt, row);
+      if (SRC == 2) gid = A.gids[key - A.lo];
+      else gid = key == kEmpty ? A.special[0] : A.ent[table_find(A.ent, A.mask, key, slot_of(key, A.mask))].row;
+    }
+    int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
+    if (NG) group_add(lcnt, lval, gid, bits, kind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits, kind, A.op, has_val);
   }
-  if (LDS) {
+  if (NG) {
     __syncthreads();
-    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);      // (the value kind is a property of the column)
-    (void)val_kind;
-    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
+    int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);      // (the value kind is a property of the column)
+    group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, k2, has_val, nthreads);
   }
+}
+template <int SRC>
+static void launch_group_acc(hipStream_t s, const AccArgs& A) {
+  if (A.nrows <= 0) return;
+  const int64_t b256 = (A.nrows + kBlock - 1) / kBlock;
+  if (A.ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_acc<kGroupLds, SRC>), dim3((unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
+  else if (A.ngroups <= kGroupLdsBig) hipLaunchKernelGGL((k_group_acc<kGroupLdsBig, SRC>), dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024))), dim3(1024), 0, s, A);
+  else hipLaunchKernelGGL((k_group_acc<0, SRC>), dim3((unsigned)std::min<int64_t>(8192, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
 }
 
 void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
@@ -584,40 +604,21 @@ __global__ void k_set_rows(const uint64_t* __restrict__ rows, int n, uint64_t* _
 void launch_set_rows(hipStream_t s, const uint64_t* rows, int n, uint64_t* bitmap, uint32_t* tile_counts) {
   if (n > 0) hipLaunchKernelGGL(k_set_rows, dim3((n + 255) / 256), dim3(256), 0, s, rows, n, bitmap, tile_counts);
 }
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_group_accumulate_codes(const uint64_t* __restrict__ sel, const uint16_t* __restrict__ codes, const uint32_t* __restrict__ rank_of_code,
-                                                                   const void* __restrict__ valcol, int valdt, int op, int64_t nrows, uint64_t* cnt, uint64_t* val,
-                                                                   int ngroups, uint64_t val_init) {
-  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
-  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
-  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
-    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
-    const uint64_t gid = rank_of_code[codes[row]];
-    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
-    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
-  }
-  if (LDS) {
-    __syncthreads();
-    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
-    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
-  }
-}
 void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uint16_t* codes, const uint32_t* rank_of_code, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
-  if (nrows <= 0) return;
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_codes<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, codes, rank_of_code, valcol, valdt, op, nrows, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate_codes<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, codes, rank_of_code, valcol, valdt, op, nrows, cnt, val, (int)ngroups, val_init);
+  AccArgs A{};
+  A.sel = sel; A.codes = codes; A.rank_of_code = rank_of_code; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
+  launch_group_acc<1>(s, A);
 }
 
 int group_lds_limit() { return kGroupLds; }
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                              int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
                              int64_t ngroups, uint64_t val_init) {
-  if (nrows <= 0) return;
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, ent, mask, special, cnt, val, (int)ngroups, val_init);
+  AccArgs A{};
+  A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.ent = ent; A.mask = mask; A.special = special;
+  A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
+  launch_group_acc<0>(s, A);
 }
 // String keys: k_str_pass, KIND 2
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
@@ -774,30 +775,6 @@ __global__ __launch_bounds__(kBlock) void k_dense_group_ids(uint64_t* __restrict
   else if (i == range && aux[kAuxMissing] != kEmpty) aux[kAuxMissing] = rank_of_row(ubits, uprefix, aux[kAuxMissing]);
 }
 
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_group_accumulate_dense(const uint64_t* __restrict__ sel, const void* __restrict__ keycol, int keydt, const uint64_t* __restrict__ missing,
-                                                                   const void* __restrict__ valcol, int valdt, int op, int64_t nrows, uint64_t lo,
-                                                                   const uint64_t* __restrict__ gids, const uint64_t* __restrict__ aux, uint64_t* cnt, uint64_t* val,
-                                                                   int ngroups, uint64_t val_init) {
-  __shared__ uint64_t lcnt[LDS ? kGroupLds : 1], lval[LDS ? kGroupLds : 1];
-  const bool has_val = valcol != nullptr && op != DFDB_AGG_COUNT;
-  if (LDS) { for (int g = threadIdx.x; g < ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = val_init; } __syncthreads(); }
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
-    if (!((sel[row >> 6] >> (row & 63)) & 1ull)) continue;
-    uint64_t gid;
-    if (missing && ((missing[row >> 6] >> (row & 63)) & 1ull)) gid = aux[kAuxMissing];
-    else gid = gids[key_fixed(keycol, keydt, row) - lo];
-    int kind = 0; const uint64_t bits = has_val ? value_bits(valcol, valdt, row, kind) : 0ull;
-    if (LDS) group_add(lcnt, lval, gid, bits, kind, op, has_val); else group_add(cnt, val, gid, bits, kind, op, has_val);
-  }
-  if (LDS) {
-    __syncthreads();
-    int k2 = 0; if (has_val) (void)value_bits(valcol, valdt, 0, k2);
-    group_flush(lcnt, lval, cnt, val, ngroups, op, k2, has_val);
-  }
-}
-
 #define DENSE_BY_DTYPE(CALL)                                                       \
   switch (dtype) {                                                                 \
     case DFDB_I8:  { using T = int8_t;   CALL; } break;                            \
@@ -840,9 +817,10 @@ void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint
 }
 void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t lo, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
-  if (nrows <= 0) return;
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_accumulate_dense<true>), dim3(grid_rows(nrows) > 2048 ? 2048 : grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, lo, gids, aux, cnt, val, (int)ngroups, val_init);
-  else hipLaunchKernelGGL((k_group_accumulate_dense<false>), dim3(grid_rows(nrows)), dim3(kBlock), 0, s, sel, keycol, keydt, missing, valcol, valdt, op, nrows, lo, gids, aux, cnt, val, (int)ngroups, val_init);
+  AccArgs A{};
+  A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.lo = lo; A.gids = gids; A.special = aux;
+  A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
+  launch_group_acc<2>(s, A);
 }
 
 }  // namespace dfdb

@@ -28,6 +28,10 @@ t.add_generated("x", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15, n)
 t.add_generated("v", dfdb.GEN_I64_MOD1M, 7, n)
 run("unique int64 mod 1e6, dense", lambda: t.x.unique())
 run("groupreduce by int64 mod 1e6 (sum of v), dense", lambda: dfdb.groupreduce(t, "x", "v", "sum"), 2)
+t.add_column_from("k5", t.x % 5000)
+t.add_column_from("k900", t.x % 900)
+run("groupreduce by x mod 5000 (sum of v): 144 KB of accumulators per CU", lambda: dfdb.groupreduce(t, "k5", "v", "sum"), 2)
+run("groupreduce by x mod 900 (sum of v): 16 KB of accumulators per workgroup", lambda: dfdb.groupreduce(t, "k900", "v", "sum"), 2)
 ctx.set_option("unique_dense", 0)
 run("unique int64 mod 1e6, hash table", lambda: t.x.unique())
 run("groupreduce by int64 mod 1e6 (sum of v), hash table", lambda: dfdb.groupreduce(t, "x", "v", "sum"), 2)
