@@ -695,7 +695,7 @@ void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int
 // max - min of the selected keys (one pass at memory speed, k_dense_minmax) fits kDenseRange: the key IS its slot.
 //   presence  one 1024-thread workgroup per CU owns a bit per value in LDS (156 KB: 1 277 952 values); the column streams by once, every selected row
 //             sets its bit (ds_or, no return), the workgroups OR their bits into one global set at the end -> the distinct values and their number D;
-//   first     the row of every value's first occurrence: the rows again IN ORDER, a few million at a time (launches of 4 M, 16 M, 64 M ... rows), a
+//   first     the row of every value's first occurrence: the rows again IN ORDER, a million or a few at a time (launches of 1 M, 1 M, 2 M, 4 M, 16 M, 64 M ... rows), a
 //             guarded 64-bit atomicMin per row into first[value]; every launch starts by comparing the number of values whose first row is known with
 //             D and returns at once when they are equal, which for keys that are spread over the column happens after the first launch or two (1e9 rows
 //             of 1e6 uniform values: all met within 20 M rows) — in the worst case (a value that turns up late) the column is read a second time;
@@ -782,21 +782,49 @@ __global__ __launch_bounds__(kBlock) void k_dense_count(const uint32_t* __restri
   if (lane_id() == 0 && n) atomicAdd((unsigned long long*)&aux[kAuxDistinct], (unsigned long long)n);
 }
 
+// (three round trips per tile — the keys, their table entries, the atomics — each sixteen deep: with a returning atomic inside the loop over the sixteen words
+// every one of them waited for the one before, ~30 us per tile, and the launches that find the first rows are a few tiles per wave)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dense_first(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing,
                                                         int64_t nrows, int64_t tile0, int64_t tile1, uint64_t lo, uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux) {
   // every value's first row lies in an earlier launch?  (`distinct` comes from the host, which read it after the presence pass; a stale view of the counter
   // shows fewer values found than there are: one launch too many, never one too few)
   if (__atomic_load_n(&aux[kAuxFound], __ATOMIC_RELAXED) >= distinct) return;
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   uint32_t fresh = 0;
-  walk_selected<T>(bitmap, col, missing, nrows, tile0, tile1, (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), (int64_t)gridDim.x * kWavesPerBlock,
-                   [&](uint64_t key, int64_t row) {
-                     const uint64_t k = key - lo;
-                     if (k < range && __atomic_load_n(&first[k], __ATOMIC_RELAXED) > (uint64_t)row)
-                       fresh += (uint32_t)(atomicMin((unsigned long long*)&first[k], (unsigned long long)row) == kEmpty);
-                   }, [&](int64_t) {});
+  for (int64_t tile = tile0 + wave; tile < tile1; tile += nwaves) {
+    const uint64_t sel = lane < 16 ? bitmap[tile * 16 + lane] : 0ull;
+    const uint64_t ms = (missing && lane < 16) ? missing[tile * 16 + lane] : 0ull;
+    const uint64_t live = sel & ~ms;
+    if (__ballot(live != 0) == 0) continue;
+    const int64_t base = tile * kTile;
+    T v[16];
+    if (base + kTile <= nrows) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = __builtin_nontemporal_load(col + base + j * 64 + lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int64_t row = base + j * 64 + lane; v[j] = row < nrows ? col[row] : (T)0; }
+    }
+    uint64_t seen[16], old[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t w = __shfl(live, j, 64);
+      const uint64_t k = widen_key(v[j]) - lo;
+      const bool on = ((w >> lane) & 1ull) && base + j * 64 + lane < nrows && k < range;
+      seen[j] = on ? __atomic_load_n(&first[k], __ATOMIC_RELAXED) : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t row = (uint64_t)(base + j * 64 + lane);
+      old[j] = seen[j] > row ? atomicMin((unsigned long long*)&first[widen_key(v[j]) - lo], (unsigned long long)row) : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) fresh += (uint32_t)(old[j] == kEmpty);
+  }
   for (int d = 32; d; d >>= 1) fresh += __shfl_xor(fresh, d, 64);
-  if (lane_id() == 0 && fresh) atomicAdd((unsigned long long*)&aux[kAuxFound], (unsigned long long)fresh);
+  if (lane == 0 && fresh) atomicAdd((unsigned long long*)&aux[kAuxFound], (unsigned long long)fresh);
 }
 
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const uint64_t* __restrict__ first, uint32_t range, const uint64_t* __restrict__ aux,

@@ -1139,8 +1139,11 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
   if (!placed) fail(DFDB_ERR_DEVICE, "unique: a key outside the range of its column");
   T.dense = true;
   { LaunchTimer lt(ctx, "unique_first");
-    int64_t step = ctx_option(ctx, "unique_chunk_tiles", 0) > 0 ? ctx_option(ctx, "unique_chunk_tiles", 0) : 4096;
-    for (int64_t t0 = 0; t0 < nt; t0 += step, step *= 4)
+    // launches of 1 M, 1 M, 2 M, 4 M rows, then four times the last: every row whose value has no first row yet costs an atomic, and rows that run side by side
+    // cannot see each other's — 1e6 values spread over the column are all met within 20 M rows, and met in small steps they cost 1.5 M atomics instead of 4 M
+    int64_t step = ctx_option(ctx, "unique_chunk_tiles", 0) > 0 ? ctx_option(ctx, "unique_chunk_tiles", 0) : 1024;
+    int launches = 0;
+    for (int64_t t0 = 0; t0 < nt; t0 += step, step *= (++launches < 2 ? 1 : (launches < 4 ? 2 : 4)))
       launch_dense_first(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(t->nrows, (t0 + step) * kTileRows), T.lo, T.range, distinct, T.first.as<uint64_t>(), aux);
   }
   HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
