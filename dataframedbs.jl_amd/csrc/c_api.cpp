@@ -1,6 +1,7 @@
 // c_api.cpp — the extern "C" boundary of libdfdb_hip.so (include/dfdb.h).  Every entry point converts
 // engine exceptions to status codes; nothing else crosses the ABI.
 #include "engine.hpp"
+#include <mutex>
 #include <cstdio>
 
 using namespace dfdb;
@@ -24,6 +25,54 @@ static hipEvent_t prof_event(dfdb_ctx* ctx) {
   if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
   hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
+// ---- DevPool / RecycleScope (common.hpp)
+namespace {
+struct PoolEntry { void* p; size_t cls; uint64_t age; };
+struct PoolState { std::mutex m; std::vector<PoolEntry> free[64]; size_t bytes[64] = {}; uint64_t clock = 0; };
+PoolState& pool_state() { static PoolState* s = new PoolState(); return *s; }    // (never destroyed: buffers may be released during static destruction)
+int pool_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return (d >= 0 && d < 64) ? d : 0; }
+thread_local bool tls_recycle = false;
+}  // namespace
+size_t DevPool::size_class(size_t n) {
+  if (n <= 4096) return 4096;
+  if (n > ((size_t)1 << 30)) return (n + 255) / 256 * 256;                   // columns and other giants: their own size, and (being no class) back to the driver when freed
+  int k = 63 - __builtin_clzll((unsigned long long)(n - 1));                 // 2^k <= n - 1 < 2^(k+1)
+  const size_t step = (size_t)1 << (k - 3);                                  // eight classes per octave
+  return (n + step - 1) / step * step;
+}
+void* DevPool::take(size_t cls) {
+  PoolState& S = pool_state();
+  const int d = pool_device();
+  std::lock_guard<std::mutex> g(S.m);
+  auto& v = S.free[d];
+  for (size_t i = v.size(); i-- > 0;)
+    if (v[i].cls == cls) { void* p = v[i].p; v.erase(v.begin() + (long)i); S.bytes[d] -= cls; return p; }
+  return nullptr;
+}
+void DevPool::give(void* p, size_t cls) {
+  if (cls > ((size_t)1 << 30)) { (void)hipFree(p); return; }
+  PoolState& S = pool_state();
+  const int d = pool_device();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(S.m);
+    auto& v = S.free[d];
+    v.push_back({p, cls, ++S.clock}); S.bytes[d] += cls;
+    while ((S.bytes[d] > kPoolBytes || v.size() > 512) && !v.empty()) { drop.push_back(v.front().p); S.bytes[d] -= v.front().cls; v.erase(v.begin()); }
+  }
+  for (void* q : drop) (void)hipFree(q);
+}
+void DevPool::flush() {
+  PoolState& S = pool_state();
+  const int d = pool_device();
+  std::vector<void*> drop;
+  { std::lock_guard<std::mutex> g(S.m); for (auto& e : S.free[d]) drop.push_back(e.p); S.free[d].clear(); S.bytes[d] = 0; }
+  for (void* q : drop) (void)hipFree(q);
+}
+RecycleScope::RecycleScope() : prev(tls_recycle) { tls_recycle = true; }
+RecycleScope::~RecycleScope() { tls_recycle = prev; }
+bool RecycleScope::active() { return tls_recycle; }
+
 LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n, hipStream_t on) : ctx(c), name(n), stream(on ? on : c->stream) {
   if (ctx->profiling) { e0 = prof_event(ctx); (void)hipEventRecord(e0, stream); }
 }
@@ -264,6 +313,7 @@ int32_t dfdb_query_free(dfdb_query* q) {
       auto& v = q->t->queries;
       for (size_t i = 0; i < v.size(); i++) if (v[i] == q) { v[i] = v.back(); v.pop_back(); break; }
     } else (void)hipDeviceSynchronize();
+    RecycleScope rs;                                   // (the stream is drained: the query's buffers go to the pool, not through hipFree)
     delete q;
   });
 }

@@ -54,6 +54,25 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 // ---- device buffer ------------------------------------------------------------------------------
+// Device buffers nothing in flight can touch any more, kept for the next allocation of their size class instead of going back to the driver (round 4: hipFree
+// drains the whole device and a fresh query over a 1e9-row table spent 1-2 ms in hipMalloc / hipFree — a fifth of a groupreduce).  A buffer enters ONLY through
+// DevBuf::release() inside a RecycleScope, which an owner opens after it has drained the stream its buffers were used on (dfdb_query_free, the end of unique /
+// groupreduce); everything else still goes through hipFree.  Sizes are rounded up to m * 2^k, m = 8 .. 15 (at most 12.5 % over), so a later request of about
+// the same size finds the buffer (requests above 1 GB — columns — are neither rounded nor kept); per device at most kPoolBytes stay (oldest out first) and a failed hipMalloc empties the pool and tries again.
+struct DevPool {
+  static constexpr size_t kPoolBytes = 8ull << 30;
+  static size_t size_class(size_t n);
+  static void* take(size_t cls);              // nullptr: none of that class on the current device
+  static void give(void* p, size_t cls);
+  static void flush();                        // the current device's buffers back to the driver
+};
+struct RecycleScope {
+  bool prev;
+  RecycleScope();
+  ~RecycleScope();
+  static bool active();
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -63,14 +82,22 @@ struct DevBuf {
   DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
   ~DevBuf() { release(); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  void release() {
+    if (p) { if (RecycleScope::active() && DevPool::size_class(bytes) == bytes) DevPool::give(p, bytes); else (void)hipFree(p); }
+    p = nullptr; bytes = 0;
+  }
   void ensure(size_t n) {  // grow-only
     if (n <= bytes && p) return;
     release();
     if (n == 0) n = 256;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) { p = nullptr; fail(DFDB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
-    bytes = n;
+    const size_t cls = DevPool::size_class(n);
+    p = DevPool::take(cls);
+    if (!p) {
+      hipError_t e = hipMalloc(&p, cls);
+      if (e != hipSuccess) { (void)hipGetLastError(); DevPool::flush(); e = hipMalloc(&p, cls); }
+      if (e != hipSuccess) { p = nullptr; fail(DFDB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", cls, hipGetErrorString(e)); }
+    }
+    bytes = cls;
   }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };

@@ -1031,7 +1031,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
     launch_dict_first_rows(s, q->bitmap.as<uint64_t>(), col.dict_codes.as<uint16_t>(), t->nrows, first.as<uint64_t>(), dn); }
   std::vector<uint64_t> fr((size_t)dn);
   HIP_CHECK(hipMemcpyAsync(fr.data(), first.p, (size_t)dn * 8, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  stream_wait(ctx);
   std::vector<std::pair<uint64_t, uint32_t>> present;
   for (int k = 0; k < dn; k++) if (fr[(size_t)k] != ~0ull) present.emplace_back(fr[(size_t)k], (uint32_t)k);
   std::sort(present.begin(), present.end());
@@ -1047,7 +1047,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   launch_set_rows(s, drows.as<uint64_t>(), (int)ng, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
   scan_prefix(q);
   q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
-  HIP_CHECK(hipStreamSynchronize(s));                      // rows / rank are pageable host memory
+  stream_wait(ctx);                                        // rows / rank are pageable host memory
   return ng;
 }
 constexpr size_t kUniqueAuxBytes = 128;      // k_unique.hip: 0 first row of the key that cannot be stored, 1 first missing row, 2 claimed slots, 3 abort, 4 collision, 5-9 the dense form's
@@ -1260,6 +1260,7 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   scan_prefix(q);
   q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1;
   stream_wait(ctx);                                        // the tables die here (or stay with the caller: groupreduce looks rows up in them)
+  if (!keep) { RecycleScope rs; local = UniqueTables(); }
 }
 void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
 
@@ -1310,7 +1311,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       launch_group_accumulate_codes(s, q->gr_sel.as<uint64_t>(), kc.dict_codes.as<uint16_t>(), rank.as<uint32_t>(), vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op,
                                     t->nrows, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
     launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
-    HIP_CHECK(hipStreamSynchronize(s));
+    stream_wait(ctx);
     q->gr_n = ng; q->gr_state = 2;
     if (ngroups) *ngroups = ng;
     if (key_bytes) *key_bytes = query_string_bytes(q, key_p);
@@ -1356,6 +1357,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   }
   launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
   stream_wait(ctx);                                        // the tables die here
+  { RecycleScope rs; T = UniqueTables(); }
   q->gr_n = ng; q->gr_state = 2;
   if (ngroups) *ngroups = ng;
   if (key_bytes && dt_base(kc.dtype) == DFDB_STRING) *key_bytes = query_string_bytes(q, key_p);
@@ -1373,7 +1375,7 @@ void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, 
     std::vector<uint64_t> c((size_t)ng), v((size_t)ng);
     HIP_CHECK(hipMemcpyAsync(c.data(), q->gr_cnt.p, (size_t)ng * 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(v.data(), q->gr_val.p, (size_t)ng * 8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    stream_wait(ctx);
     for (int64_t g = 0; g < ng; g++) {
       if (counts) counts[g] = (int64_t)c[(size_t)g];
       const uint64_t b = v[(size_t)g];
