@@ -11,7 +11,7 @@
 //           that smallest row; the ordinary count / gather / materialize machinery then returns the distinct values in order
 //           of first appearance.  No sort.
 // The table is sized by the DISTINCT values, which nobody knows beforehand (round 4; it used to be sized by the selected rows:
-// 34 GB of table for 1e9 rows of 1e6 values, every probe a miss in every cache — 86 ms, this form 7x less): the host feeds the
+// 34 GB of table for 1e9 rows of 1e6 values, every probe a miss in every cache — 86 ms, this form 20): the host feeds the
 // rows in three chunks (1 M rows, 16 M, the rest), reads the number of claimed slots after each, estimates the distinct count
 // of the whole selection from it (query.cpp: unique_capacity_wanted) and MIGRATES the entries to a larger table when needed; a
 // probe sequence of kMaxProbe slots raises an abort flag, the host grows the table and repeats that chunk (inserts are idempotent).
@@ -651,7 +651,6 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
   launch_group_acc<1>(s, A);
 }
 
-int group_lds_limit() { return kGroupLds; }
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                              int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
                              int64_t ngroups, uint64_t val_init) {
