@@ -200,6 +200,14 @@ int32_t dfdb_ctx_profile_enable(dfdb_ctx* ctx, int32_t on) { return guard([&] { 
 int32_t dfdb_ctx_profile_get(dfdb_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms) {
   return guard([&] {
     NEED(ctx); NEED(kernel);
+    if (!strncmp(kernel, "jit.", 4)) {               // the run-time compiler's process-wide counters: shapes compiled by hipRTC, read from the disk cache, failed
+      int64_t c = 0, f = 0, p = 0, d = 0;
+      jit_stats(&c, &f, &p, &d);
+      const std::string k = kernel + 4;
+      if (launches) *launches = k == "compiled" ? c : k == "from_disk" ? d : k == "failed" ? f : k == "pending" ? p : 0;
+      if (total_ms) *total_ms = 0.0;
+      return;
+    }
     profile_resolve(ctx);
     auto it = ctx->prof.find(kernel);
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;

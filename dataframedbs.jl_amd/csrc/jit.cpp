@@ -22,6 +22,8 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace dfdb {
 
@@ -90,14 +92,79 @@ struct JitCache {
   std::deque<std::shared_ptr<JitKernel>> queue;
   std::thread worker; bool started = false;
   bool busy = false, stopping = false;          // the worker is inside hipRTC / the process is exiting (guarded by mu)
-  std::atomic<int64_t> compiled{0}, failed{0};
+  std::atomic<int64_t> compiled{0}, failed{0}, from_disk{0};
 };
 constexpr size_t kMaxShapes = 4096;                                   // ~10-20 KB of code object each
 JitCache& cache() { static JitCache* c = new JitCache; return *c; }   // (leaked on purpose: the worker may outlive static destruction)
 
+// ---- the code objects on disk (round 4): a shape compiled once by any process of this user is read back by the next one (0.13-0.17 s of hipRTC per shape and
+// process otherwise).  File name = two 64-bit FNV-1a hashes over everything the code depends on (the generated source, the embedded interpreter source, the
+// target, the options); content = the code object followed by an 8-byte hash of it, written to a temporary name and renamed.  $DFDB_JIT_CACHE_DIR names the
+// directory (default $XDG_CACHE_HOME/dfdb-jit or ~/.cache/dfdb-jit), DFDB_JIT_CACHE=0 turns the cache off; every failure (no home, no space, a torn file) just
+// means compiling as before.
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; } return h; }
+std::string disk_dir() {
+  const char* off = getenv("DFDB_JIT_CACHE");
+  if (off && off[0] == '0') return "";
+  std::string d;
+  if (const char* e = getenv("DFDB_JIT_CACHE_DIR")) d = e;
+  else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/dfdb-jit";
+  else if (const char* h = getenv("HOME")) { d = std::string(h) + "/.cache"; (void)mkdir(d.c_str(), 0700); d += "/dfdb-jit"; }
+  if (d.empty()) return "";
+  (void)mkdir(d.c_str(), 0700);
+  struct stat st;
+  return (stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) ? d : "";
+}
+std::string disk_path(const JitKernel& k, const std::string& arch, const char* const* opts, int nopts) {
+  const std::string dir = disk_dir();
+  if (dir.empty()) return "";
+  uint64_t h1 = 0xCBF29CE484222325ull, h2 = 0x84222325CBF29CE4ull;
+  auto mix = [&](const void* p, size_t n) { h1 = fnv1a(p, n, h1); h2 = fnv1a(p, n, h2 ^ 0x9E3779B97F4A7C15ull); };
+  mix(k.source.data(), k.source.size());
+  for (const char* t : {src_device_utils_hpp, src_k_interp_handlers_inc, src_k_interp_step_inc, src_k_interp_device_inc, src_dfdb_ir_h}) mix(t, strlen(t));
+  mix(arch.data(), arch.size());
+  for (int i = 0; i < nopts; i++) mix(opts[i], strlen(opts[i]));
+  char name[64];
+  snprintf(name, sizeof name, "/%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
+  return dir + name;
+}
+bool disk_read(const std::string& path, std::vector<char>& code) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<char> buf;
+  char chunk[65536]; size_t n;
+  while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+  fclose(f);
+  if (buf.size() <= 8) return false;
+  uint64_t want; memcpy(&want, buf.data() + buf.size() - 8, 8);
+  buf.resize(buf.size() - 8);
+  if (fnv1a(buf.data(), buf.size(), 0xCBF29CE484222325ull) != want) { (void)unlink(path.c_str()); return false; }      // torn or foreign: out of the way
+  code.swap(buf);
+  return true;
+}
+void disk_write(const std::string& path, const std::vector<char>& code) {
+  char tmp[32]; snprintf(tmp, sizeof tmp, ".%d.tmp", (int)getpid());
+  const std::string t = path + tmp;
+  FILE* f = fopen(t.c_str(), "wb");
+  if (!f) return;
+  const uint64_t h = fnv1a(code.data(), code.size(), 0xCBF29CE484222325ull);
+  const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size() && fwrite(&h, 1, 8, f) == 8;
+  if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
+}
+
 void compile_one(JitKernel& k, const std::string& arch) {
   Rtc& r = rtc();
   const auto t0 = std::chrono::steady_clock::now();
+  const std::string archopt = "--offload-arch=" + arch;
+  // -ffp-contract=off: the engine's floating-point results are Julia's, operation by operation (the library itself is built with it, see the Makefile)
+  const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed"};
+  const std::string path = disk_path(k, arch, opts, 5);
+  if (!path.empty() && disk_read(path, k.code)) {
+    k.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] %zu bytes from %s in %.1f ms: %s\n", k.code.size(), path.c_str(), k.compile_ms, k.key.c_str());
+    else { std::string().swap(k.source); std::string().swap(k.log); }
+    cache().from_disk++; k.state = 1; return;
+  }
   hiprtcProgram prog = nullptr;
   const char* headers[] = {src_device_utils_hpp, src_k_interp_handlers_inc, src_k_interp_step_inc, src_k_interp_device_inc, src_dfdb_ir_h, nullptr};
   const char* names[] = {"device_utils.hpp", "k_interp_handlers.inc", "k_interp_step.inc", "k_interp_device.inc", "dfdb_ir.h", "jit_steps.inc"};
@@ -106,9 +173,6 @@ void compile_one(JitKernel& k, const std::string& arch) {
   const std::string steps = k.source.substr(0, cut), main_src = k.source.substr(cut + 14);
   headers[5] = steps.c_str();
   if (r.CreateProgram(&prog, main_src.c_str(), "dfdb_jit.hip", 6, headers, names) != HIPRTC_SUCCESS) { k.log = "hiprtcCreateProgram failed"; k.state = -1; return; }
-  const std::string archopt = "--offload-arch=" + arch;
-  // -ffp-contract=off: the engine's floating-point results are Julia's, operation by operation (the library itself is built with it, see the Makefile)
-  const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed"};
   const hiprtcResult rc = r.CompileProgram(prog, 5, opts);
   size_t n = 0;
   if (r.GetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { k.log.resize(n); r.GetProgramLog(prog, &k.log[0]); }
@@ -122,6 +186,7 @@ void compile_one(JitKernel& k, const std::string& arch) {
     if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] compile FAILED (%.0f ms) for %s:\n%s\n", k.compile_ms, k.key.c_str(), k.log.c_str());
     cache().failed++; k.state = -1; return;
   }
+  if (!path.empty()) disk_write(path, k.code);
   if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] compiled %zu bytes in %.0f ms: %s\n", k.code.size(), k.compile_ms, k.key.c_str());
   else { std::string().swap(k.source); std::string().swap(k.log); }      // (60 KB of text per shape: only the code object is kept)
   cache().compiled++; k.state = 1;
@@ -261,9 +326,10 @@ bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, vo
   return true;
 }
 
-void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending) {
+void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, int64_t* from_disk) {
   JitCache& c = cache();
   std::lock_guard<std::mutex> lk(c.mu);
+  if (from_disk) *from_disk = c.from_disk.load();
   if (compiled) *compiled = c.compiled.load();
   if (failed) *failed = c.failed.load();
   if (pending) *pending = (int64_t)c.queue.size();

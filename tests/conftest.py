@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the run-time compiler's disk cache stays out of the test session: what the JIT tests exercise is the compile itself (test_gpu_jit.py has the cache's own test)
+os.environ.setdefault("DFDB_JIT_CACHE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "dataframedbs.jl_amd")
 for p in (ROOT, PKG):

@@ -157,3 +157,42 @@ def test_exit_while_the_compiler_is_busy(ctx):
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stderr.decode(errors="replace")[-2000:])
     assert b"counted" in p.stdout
+
+
+def test_code_objects_come_back_from_the_disk_cache(tmp_path):
+    """a shape compiled by one process is read from $DFDB_JIT_CACHE_DIR by the next (no hipRTC call), gives the same answer, and a torn file in the cache is
+    discarded and compiled again"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'dataframedbs.jl_amd')!r}]\n"
+        "import torch; torch.cuda.init()\n"
+        "import dfdb\n"
+        "from dfdb import ir\n"
+        "ctx = dfdb.default_context(0)\n"
+        "ctx.set_option('jit', 2); ctx.set_option('jit_min_rows', 0)\n"
+        "t = dfdb.DFTable.new(ctx=ctx)\n"
+        "t.add_generated('a', dfdb.GEN_I64_MOD1M, 1, 300000)\n"
+        "t.add_generated('b', dfdb.GEN_I64_MOD1M, 2, 300000)\n"
+        "ctx.profile(True)\n"
+        "n = t[(abs(ir.col(0) * 3 - ir.col(1)) % 11 > 4) | (ir.col(1) * 2 < ir.col(0)), dfdb.ALL]._query().count()\n"
+        "print('RESULT', n, ctx.profile_get('jit.compiled')[0], ctx.profile_get('jit.from_disk')[0], ctx.profile_get('jit_predicate')[0])\n")
+    env = dict(os.environ, DFDB_JIT_CACHE="1", DFDB_JIT_CACHE_DIR=str(tmp_path))
+
+    def run():
+        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+        line = [l for l in p.stdout.decode().splitlines() if l.startswith("RESULT")][0].split()
+        return [int(x) for x in line[1:]]
+    n1, compiled1, disk1, ran1 = run()
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".co")]
+    assert compiled1 >= 1 and disk1 == 0 and ran1 >= 1 and len(files) == compiled1
+    n2, compiled2, disk2, ran2 = run()
+    assert n2 == n1 and compiled2 == 0 and disk2 == compiled1 and ran2 >= 1
+    victim = os.path.join(tmp_path, files[0])
+    with open(victim, "r+b") as f:
+        f.truncate(os.path.getsize(victim) // 2)
+    n3, compiled3, disk3, ran3 = run()
+    assert n3 == n1 and compiled3 == 1 and disk3 == compiled1 - 1 and ran3 >= 1
