@@ -71,7 +71,10 @@ void DevPool::flush() {
 }
 RecycleScope::RecycleScope() : prev(tls_recycle) { tls_recycle = true; }
 RecycleScope::~RecycleScope() { tls_recycle = prev; }
-bool RecycleScope::active() { return tls_recycle; }
+bool RecycleScope::active() {
+  static const bool enabled = [] { const char* e = getenv("DFDB_POOL"); return !(e && e[0] == '0'); }();      // DFDB_POOL=0: every buffer back to the driver at once
+  return enabled && tls_recycle;
+}
 
 LaunchTimer::LaunchTimer(dfdb_ctx* c, const char* n, hipStream_t on) : ctx(c), name(n), stream(on ? on : c->stream) {
   if (ctx->profiling) { e0 = prof_event(ctx); (void)hipEventRecord(e0, stream); }
@@ -110,6 +113,7 @@ int64_t ctx_option(const dfdb_ctx* ctx, const char* key, int64_t dflt) {
 extern "C" {
 
 int32_t dfdb_version(void) { return DFDB_ABI_VERSION; }
+int32_t dfdb_shutdown(void) { return guard([&] { jit_shutdown(); }); }
 int32_t dfdb_device_count(int32_t* n) {
   return guard([&] { NEED(n); int nd = 0; if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); nd = 0; } *n = nd; });
 }

@@ -33,6 +33,7 @@ struct Column {
   DevBuf bytes;      // String: byte arena (+16 B pad so 8-byte probes never fault)
   int64_t nbytes = 0;
   DevBuf tile_off;   // String: u64[nstrtiles+1] byte offset of each 1024-row tile (K4)
+  uint32_t max_tile_bytes = 0;   // String: the most bytes any 1024-row tile holds (K4; K5 stages a tile's bytes in LDS when every tile fits)
   DevBuf missing;    // nullable fixed width: bitmap, 1 = missing, padded like the selection bitmap
   // compressed-resident form (ctx option "keep_compressed" at load time; plain fixed-width columns): the column's LZ4 blocks as they
   // sit in the file stay in HBM with their descriptors, and dfdb_table_decode_resident re-runs K7 from them into `data`
@@ -163,6 +164,7 @@ struct JitShape {
 struct JitKernel;
 std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait);
 bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, void** args);
+void jit_shutdown();
 void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, int64_t* from_disk = nullptr);
 
 void query_add_stage(dfdb_query* q, Stage&& s);   // composition rules of selection.jl:39-49

@@ -85,7 +85,9 @@ struct JitKernel {
   std::unordered_map<int, hipFunction_t> loaded;   // device -> function (one module per device, kept for the life of the process)
 };
 
+void jit_shutdown();
 namespace {
+void jit_at_exit();
 struct JitCache {
   std::mutex mu; std::condition_variable cv;
   std::unordered_map<std::string, std::shared_ptr<JitKernel>> map;
@@ -204,13 +206,22 @@ void worker_main(std::string arch) {
       c.busy = true;
     }
     compile_one(*k, arch);
+    std::atexit(jit_at_exit);                                      // (again: newer than the statics this compile may have created; the handler is idempotent)
     { std::lock_guard<std::mutex> lk(c.mu); c.busy = false; }      // (a waiter that has just found state == 0 is inside cv.wait by now: the notification cannot slip past it)
     c.cv.notify_all();
   }
 }
 // exit(): the compiler thread must not be inside hipRTC / comgr while their static objects are destroyed.  Registered after hipRTC was loaded, so it runs before
 // their own exit handlers: pending shapes are dropped, a compile in flight is given ten seconds to finish.
-void jit_at_exit() {
+void jit_at_exit() { jit_shutdown(); }
+}  // namespace
+
+// No more compiles: pending shapes are dropped, a compile in flight is given ten seconds to finish, later requests are answered "interpret".  The host
+// binding calls this (dfdb_shutdown) from ITS exit hook — Python's atexit, Julia's atexit — which runs before the C runtime starts destroying static
+// objects.  The std::atexit handler below is only the second line: LLVM registers the destructors of its lazily built statics during the first compile,
+// i.e. AFTER this library could register anything, so at exit() they run BEFORE a handler of ours and the compiler thread dies in the rubble
+// ("LLVM ERROR: Invalid size request on a scalable vector", SIGSEGV: a third of the exits that caught the compiler busy on the boxes of round 4).
+void jit_shutdown() {
   JitCache& c = cache();
   std::unique_lock<std::mutex> lk(c.mu);
   c.stopping = true;
@@ -219,7 +230,6 @@ void jit_at_exit() {
   c.cv.notify_all();
   c.cv.wait_for(lk, std::chrono::seconds(10), [&] { return !c.busy; });
 }
-}  // namespace
 
 // the kernel for this program shape: ready, or nullptr (still compiling, hipRTC missing, or the compile failed).  wait = true blocks until the compiler is done.
 std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait) {

@@ -29,22 +29,25 @@ __device__ __forceinline__ uint32_t clamp_size(int32_t s) { return s > 0 ? (uint
 
 // ---------------------------------------------------------------- K4
 __global__ __launch_bounds__(kBlock) void k_str_tile_bytes(const int32_t* __restrict__ sizes, uint32_t* __restrict__ tile_bytes, int64_t nrows,
-                                                           int64_t ntiles) {
+                                                           int64_t ntiles, uint32_t* __restrict__ max_tile_bytes) {
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  uint32_t most = 0;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) { const int64_t i = tile * kTile + j * 64 + lane; if (i < nrows) s += clamp_size(sizes[i]); }
     s = wave_sum(s);
     if (lane == 0) tile_bytes[tile] = s;
+    most = s > most ? s : most;
   }
+  if (max_tile_bytes && lane == 0 && most) atomicMax(max_tile_bytes, most);      // (one per wave: K5 stages a tile's bytes in LDS when the largest tile fits)
 }
-void launch_str_tile_bytes(hipStream_t s, const int32_t* sizes, uint32_t* tile_bytes, int64_t nrows) {
+void launch_str_tile_bytes(hipStream_t s, const int32_t* sizes, uint32_t* tile_bytes, int64_t nrows, uint32_t* max_tile_bytes) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
-  hipLaunchKernelGGL(k_str_tile_bytes, dim3(grid_for(ntiles)), dim3(kBlock), 0, s, sizes, tile_bytes, nrows, ntiles);
+  hipLaunchKernelGGL(k_str_tile_bytes, dim3(grid_for(ntiles)), dim3(kBlock), 0, s, sizes, tile_bytes, nrows, ntiles, max_tile_bytes);
 }
 
 // ---------------------------------------------------------------- K5
@@ -155,12 +158,23 @@ __device__ __forceinline__ void store_small(uint8_t* d, uint64_t v, uint32_t len
   if (len & 1u) *d = (uint8_t)v;
 }
 
+// round 4: the tile's bytes arrive through LDS.  The probes of the candidate rows used to be the only readers of the arena — 8-byte loads at byte-granular
+// addresses, a few active lanes per instruction, every 128-byte line of the arena fetched anyway because a line holds ~20 strings — and the pass ran at 0.58-0.64
+// of the HBM peak.  Now the wave streams the tile's byte range [tile_off[t], tile_off[t+1]) with aligned 16-byte loads that are in flight together with the sixteen
+// size loads, parks it in 8 KB of LDS, and the probes read there.  A tile whose strings do not fit (mean length above ~7) keeps the direct probes.
+constexpr uint32_t kStageBytes = 8192;
+__device__ __forceinline__ uint64_t lds_probe(const uint32_t* st, uint32_t off) {     // 8 bytes at byte offset `off` of the staged range
+  const uint32_t i = off >> 2, sh = off & 3u;
+  const uint32_t w0 = st[i], w1 = st[i + 1], w2 = st[i + 2];
+  return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+}
+
 // CAP (dfdb_query_hint_materialize, the string column itself is projected): the pass that decides the rows also keeps them — the
 // size of every selected row at cap_sizes[tile * 1024 + rank], its bytes packed at the tile's own arena offset in cap_bytes, the
 // tile's selected byte total in sel_tile_bytes — so K6 does not read the column again: the projection is a contiguous copy per tile.
 // LONG: patterns of 9..64 bytes (a second probe rides along, the rest is compared where 16 bytes matched); !LONG keeps the one-probe kernel as it was
-template <bool AND_EXISTING, int MODE, bool CAP, bool LONG>
-__global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
+template <bool AND_EXISTING, int MODE, bool CAP, bool LONG, bool STAGE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CAP ? 2 : 4))) void k_str_match_short(const int32_t* __restrict__ sizes, const int64_t* __restrict__ tile_off,
                                                             const uint8_t* __restrict__ bytes, uint64_t patw, uint64_t patw1, int plen,
                                                             const uint8_t* __restrict__ pat_dev, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, int64_t nrows,
                                                             int64_t ntiles, int32_t* __restrict__ cap_sizes, uint8_t* __restrict__ cap_bytes,
@@ -173,6 +187,9 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
   const uint64_t want = patw & mask;
   const uint64_t mask2 = plen >= 16 ? ~0ull : (plen > 8 ? ((1ull << (8 * (plen - 8))) - 1ull) : 0ull);
   const uint64_t want2 = patw1 & mask2;
+  __shared__ __attribute__((aligned(16))) uint32_t stage_sh[STAGE ? kWavesPerBlock : 1][STAGE ? kStageBytes / 4 + 8 : 4];
+  uint32_t* const stage = stage_sh[STAGE ? (threadIdx.x >> 6) : 0];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     uint64_t existing = ~0ull;
     if (AND_EXISTING) {
@@ -184,6 +201,20 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
     int32_t sz[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) { const int64_t i = base + j * 64 + lane; sz[j] = i < nrows ? __builtin_nontemporal_load(sizes + i) : -2; }
+    // the tile's byte range (from the 16-byte boundary below it to 31 bytes past its end: a probe may read 15 bytes behind its string, and every arena is
+    // allocated with 64 bytes of slack), eight 1-KB pieces at most, all in flight with the size loads
+    const int64_t o0 = tile_off[tile], a0 = o0 & ~15ll;
+    const uint32_t lead = (uint32_t)(o0 - a0), need = (uint32_t)(tile_off[tile + 1] - a0) + 16u;
+    if (STAGE) {                                                       // (the launcher has checked that the column's largest tile fits)
+      // (a piece past the range's end is the range's last piece once more, loaded and stored by several lanes alike: no predication, no divergence)
+      const uint32_t lastc = (need - 1u) & ~15u;
+      u32x4 piece[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { uint32_t c = (uint32_t)i * 1024u + (uint32_t)lane * 16u; c = c < lastc ? c : lastc; piece[i] = __builtin_nontemporal_load((const u32x4*)(bytes + a0 + c)); }
+#pragma unroll
+      for (int i = 0; i < 8; i++) { uint32_t c = (uint32_t)i * 1024u + (uint32_t)lane * 16u; c = c < lastc ? c : lastc; *(u32x4*)(stage + (c >> 2)) = piece[i]; }
+      wave_lds_fence();
+    }
     uint64_t myword = 0;
     uint32_t run = 0;
     uint32_t cap_n = 0, cap_b = 0;                                    // CAP: selected rows / bytes of this tile so far
@@ -205,9 +236,14 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
         cand[j] = s0 >= 0 && (MODE <= 1 ? len == plen : len >= plen);          // (-2: past the last row; -1: missing — a comparison with missing selects nothing: coalesce(term, false))
         v[j] = 0; if (LONG) v2[j] = 0;
         if (cand[j] && plen > 0) {
-          const uint8_t* p = tb + rel[j] + (MODE == 3 ? len - plen : 0);
-          v[j] = load_u64_unaligned(p);
-          if (LONG) v2[j] = load_u64_unaligned(p + 8);                 // bytes 8..15 of the compared span ride along
+          const uint32_t po = rel[j] + (uint32_t)(MODE == 3 ? len - plen : 0);
+          if (STAGE) {
+            v[j] = lds_probe(stage, lead + po);
+            if (LONG) v2[j] = lds_probe(stage, lead + po + 8u);
+          } else {
+            v[j] = load_u64_unaligned(tb + po);
+            if (LONG) v2[j] = load_u64_unaligned(tb + po + 8);         // bytes 8..15 of the compared span ride along
+          }
         }
       }
 #pragma unroll
@@ -253,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_str_match_short(const int32_t* __res
   }
 }
 
-template <int MODE>
+template <int MODE, bool STAGE>
 static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const Pattern& pat,
                          const uint8_t* pat_dev, uint64_t* bitmap, uint32_t* tc, int64_t nrows, int64_t ntiles, const StrCapture* cap) {
   dim3 g(grid), b(kBlock);
@@ -264,36 +300,36 @@ static void launch_short(hipStream_t s, int grid, bool ae, const int32_t* sizes,
     static int resident = 0;
     if (resident == 0) {
       int per_cu = 0, dev = 0; hipDeviceProp_t pr;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_str_match_short<false, MODE, false, true>, kBlock, 0) == hipSuccess && per_cu > 0 &&
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_str_match_short<false, MODE, false, true, STAGE>, kBlock, 0) == hipSuccess && per_cu > 0 &&
           hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) resident = per_cu * pr.multiProcessorCount;
       else { (void)hipGetLastError(); resident = -1; }
     }
     if (resident > 0 && (int)g.x > resident) g.x = (unsigned)resident;
-    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
-    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
-    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, true>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, true, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, true, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, true, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
   } else {
-    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
-    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
-    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, false>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    if (cap) hipLaunchKernelGGL((k_str_match_short<false, MODE, true, false, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else if (ae) hipLaunchKernelGGL((k_str_match_short<true, MODE, false, false, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
+    else hipLaunchKernelGGL((k_str_match_short<false, MODE, false, false, STAGE>), g, b, 0, s, sizes, tile_off, bytes, pat.w[0], pat.w[1], (int)pat.len, pat_dev, bitmap, tc, nrows, ntiles, cs, cby, ctb);
   }
 }
 
 void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
                       const uint8_t* pat_dev, int32_t patlen, int mode, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
-                      bool and_existing, const StrCapture* cap) {
+                      bool and_existing, const StrCapture* cap, uint32_t max_tile_bytes) {
   const int64_t ntiles = (nrows + kTile - 1) / kTile;
   if (ntiles == 0) return;
   Pattern pat; memset(&pat, 0, sizeof pat); pat.len = patlen;
   if (patlen > 0 && patlen <= 64) memcpy(pat.w, pat_host, (size_t)patlen);   // short patterns ride in the kernel arguments
   const int grid = grid_for(ntiles, 2048);
   if (patlen <= 64) {
-    switch (mode) {
-      case 0: launch_short<0>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
-      case 1: launch_short<1>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
-      case 2: launch_short<2>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
-      default: launch_short<3>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); break;
-    }
+    // every tile of the column fits the 8 KB a wave stages (+ 15 bytes below the tile's first, + 16 behind its last): the bytes come through LDS
+    const bool stage = patlen > 0 && max_tile_bytes > 0 && max_tile_bytes + 48u <= kStageBytes;
+#define DFDB_SHORT(M) do { if (stage) launch_short<M, true>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); \
+                           else launch_short<M, false>(s, grid, and_existing, sizes, tile_off, bytes, pat, pat_dev, bitmap, tile_counts, nrows, ntiles, cap); } while (0)
+    switch (mode) { case 0: DFDB_SHORT(0); break; case 1: DFDB_SHORT(1); break; case 2: DFDB_SHORT(2); break; default: DFDB_SHORT(3); break; }
+#undef DFDB_SHORT
     return;
   }
   if (and_existing) hipLaunchKernelGGL((k_str_match<true>), dim3(grid), dim3(kBlock), 0, s, sizes, tile_off, bytes, pat, pat_dev, mode, bitmap, tile_counts, nrows, ntiles);

@@ -100,13 +100,13 @@ void launch_gen_brand_bytes(hipStream_t s, const int32_t* sizes, const int64_t* 
 
 // ---- strings (K4-K6) -------------------------------------------------------------------------------
 // per-1024-row byte totals of max(size,0)  (first half of unsafe_remake_offsets!)
-void launch_str_tile_bytes(hipStream_t s, const int32_t* sizes, uint32_t* tile_bytes, int64_t nrows);
+void launch_str_tile_bytes(hipStream_t s, const int32_t* sizes, uint32_t* tile_bytes, int64_t nrows, uint32_t* max_tile_bytes = nullptr);   // (max: one zeroed device word)
 // K5: s OP "const" (EQ / NE / STARTSWITH / ENDSWITH) -> bitmap + counts.  mode: 0 EQ, 1 NE, 2 STARTSWITH, 3 ENDSWITH
 // pat_host: the pattern in host memory (<= 64 bytes travel as kernel arguments); pat_dev: device copy for longer ones
 struct StrCapture { int32_t* sizes; uint8_t* bytes; uint32_t* tile_bytes; };   // K5 CAP outputs (see k_str_match_short)
 void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const uint8_t* pat_host,
                       const uint8_t* pat_dev, int32_t patlen, int mode, uint64_t* bitmap, uint32_t* tile_counts, int64_t nrows,
-                      bool and_existing, const StrCapture* cap = nullptr);
+                      bool and_existing, const StrCapture* cap = nullptr, uint32_t max_tile_bytes = 0);   // max_tile_bytes: Column::max_tile_bytes (0 = not known: probes straight from memory)
 void launch_str_compact_captured(hipStream_t s, const StrCapture& cap, const uint64_t* prefix, const int64_t* tile_off, const uint64_t* out_tile_off,
                                  int32_t* out_sizes, uint8_t* out_bytes, int64_t nrows, int64_t out_rows, int64_t out_bytes_cap);
 // K6: selected sizes -> out sizes (+ per-ctile selected byte totals); then bytes

@@ -413,7 +413,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     LaunchTimer lt(ctx, "str_match");
     launch_str_match(s, col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(), (const uint8_t*)pat.data(),
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                     do_cap ? &capture : nullptr);
+                     do_cap ? &capture : nullptr, ctx_option(ctx, "str_stage", 1) != 0 ? col.max_tile_bytes : 0u);
     if (do_cap) q->cap_str_col = ord;
     have = true;
   }

@@ -125,8 +125,12 @@ void set_string_tile_offsets(dfdb_ctx* ctx, Column& c) {
   tb.ensure((size_t)(ntiles + 1) * 4);
   scratch.ensure(scan_counts_scratch_bytes(ntiles));
   c.tile_off.ensure((size_t)(ntiles + 2) * 8);
-  launch_str_tile_bytes(ctx->stream, c.data.as<int32_t>(), tb.as<uint32_t>(), c.nrows);
+  uint32_t* dmax = tb.as<uint32_t>() + ntiles;    // (the spare word behind the per-tile sums)
+  HIP_CHECK(hipMemsetAsync(dmax, 0, 4, ctx->stream));
+  launch_str_tile_bytes(ctx->stream, c.data.as<int32_t>(), tb.as<uint32_t>(), c.nrows, dmax);
   launch_scan_counts(ctx->stream, tb.as<uint32_t>(), c.tile_off.as<uint64_t>(), ntiles, scratch.as<uint64_t>());
+  c.max_tile_bytes = 0;
+  HIP_CHECK(hipMemcpyAsync(&c.max_tile_bytes, dmax, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));   // tb/scratch die here
 }
 

@@ -46,7 +46,7 @@ class OutCol(C.Structure):
 
 # every exported symbol of include/dfdb.h: (restype is always int32 status)
 SYMBOLS = [
-    "dfdb_version", "dfdb_device_count", "dfdb_last_error",
+    "dfdb_version", "dfdb_shutdown", "dfdb_device_count", "dfdb_last_error",
     "dfdb_ctx_create", "dfdb_ctx_destroy", "dfdb_ctx_synchronize", "dfdb_ctx_device_info", "dfdb_ctx_timer_start",
     "dfdb_ctx_timer_stop", "dfdb_ctx_set_option", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
     "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(lib, s).restype = C.c_int32
+        import atexit
+        atexit.register(lib.dfdb_shutdown)          # before the C runtime's own exit processing: the background compiler must not be inside LLVM by then (dfdb.h)
         lib.dfdb_table_add_generated.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int64]
         lib.dfdb_table_add_column.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dfdb_table_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]

@@ -290,6 +290,8 @@ function device()
     if DEV[] === nothing
         ctx = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dfdb_ctx_create, LIB), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), 0, C_NULL, ctx))
+        # Julia's exit hooks run before the C runtime's: the engine's background compiler (hipRTC) must be idle by then (include/dfdb.h: dfdb_shutdown)
+        atexit(() -> check(ccall((:dfdb_shutdown, LIB), Int32, ())))
         # String columns with at most DFDB_STRING_DICTIONARY (default 4096) distinct values get 16-bit codes beside their flat form when they are
         # loaded: `t.brand .== "sony"` then scans 2 bytes per row (include/dfdb.h: dfdb_table_build_dictionary); 0 turns it off
         dictn = something(tryparse(Int, get(ENV, "DFDB_STRING_DICTIONARY", "")), 4096)

@@ -99,6 +99,10 @@ typedef struct dfdb_outcol {
 
 /* ------------------------------------------------------------------ misc */
 int32_t dfdb_version(void);
+/* Call from the host language's exit hook (Python atexit, Julia atexit: the shipped bindings do) before the process ends: stops the background compiler
+ * of run-time expression kernels (a compile in flight gets ten seconds), after which new expressions are interpreted.  Idempotent; handles stay valid.
+ * Without it a process that exits while hipRTC is compiling can crash inside LLVM's static destructors (there is no Julia method this replaces). */
+int32_t dfdb_shutdown(void);
 int32_t dfdb_device_count(int32_t* n);   /* visible HIP devices (0 without a GPU: no error); the Julia shim forms a group when n > 1 */
 int32_t dfdb_last_error(char* buf, size_t cap);
 
@@ -135,6 +139,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     (dfdb_query_hint_materialize): 2 (default: the last two terms of the launch, the second parked in LDS), 1, or 0 = gather everything
  *   "scan_narrow"     which narrow columns `col OP const` scans with 16-byte loads per lane (k_scan_cmp_narrow): 1 = 1-byte columns — Bool, Int8, UInt8 —
  *                     (default: 0.72 of the HBM peak against 0.52), 2 = 2- and 4-byte columns too (no consistent gain measured), 0 = none
+ *   "str_stage"       1 = a string comparison over a column whose 1024-row tiles hold at most 8 KB of bytes each streams a tile's bytes into LDS with aligned
+ *                     16-byte loads and probes there (default 1); 0 = 8-byte probes straight from memory, which longer strings always take
  *   "unique_dense"    1 = dfdb_query_unique / _groupreduce over an integer key whose selected values span less than 1 277 952 take the form without a hash
  *                     table (a presence bit per value in LDS; default 1); "unique_dense_range" lowers that span.  "unique_cap0_log2" = log2 of the slots the
  *                     hash table starts with (default 21; it grows with the distinct values met), "unique_chunk_tiles" = 1024-row tiles of the first chunk
