@@ -51,6 +51,9 @@ void* DevPool::take(size_t cls) {
 }
 void DevPool::give(void* p, size_t cls) {
   if (cls > ((size_t)1 << 30)) { (void)hipFree(p); return; }
+  // DFDB_POOL_POISON=1 (tests): a buffer comes back filled with 0xA5 — whoever reads memory it has not written gets garbage every time, not once in a while
+  static const bool poison = [] { const char* e = getenv("DFDB_POOL_POISON"); return e && e[0] == '1'; }();
+  if (poison) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0xA5, cls); (void)hipDeviceSynchronize(); }      // (the fill has landed before anyone can take the buffer)
   PoolState& S = pool_state();
   const int d = pool_device();
   std::vector<void*> drop;

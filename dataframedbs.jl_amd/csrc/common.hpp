@@ -59,6 +59,8 @@ inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 // DevBuf::release() inside a RecycleScope, which an owner opens after it has drained the stream its buffers were used on (dfdb_query_free, the end of unique /
 // groupreduce); everything else still goes through hipFree.  Sizes are rounded up to m * 2^k, m = 8 .. 15 (at most 12.5 % over), so a later request of about
 // the same size finds the buffer (requests above 1 GB — columns — are neither rounded nor kept); per device at most kPoolBytes stay (oldest out first) and a failed hipMalloc empties the pool and tries again.
+// Environment: DFDB_POOL=0 turns the pool off; DFDB_POOL_POISON=1 fills every buffer with 0xA5 (between two device synchronisations) as it enters — the GPU suite
+// passes with it, i.e. nothing reads a buffer it has not written.
 struct DevPool {
   static constexpr size_t kPoolBytes = 8ull << 30;
   static size_t size_class(size_t n);
