@@ -459,6 +459,17 @@ __global__ __launch_bounds__(kBlock) void k_unique_str_mark(uint64_t* __restrict
 
 static int grid_rows(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 static int grid_tiles(int64_t nt) { int64_t b = (nt + kWavesPerBlock - 1) / kWavesPerBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+// the String passes: a wave's met cache starts cold, so every wave's FIRST tile goes through the slow step whole — with one workgroup per four tiles (grid_tiles)
+// that was 10 % of the rows of a 5e8-row column (a tile or fourteen per wave, and all of a 16 M-row chunk).  At least 32 tiles per wave where the column has
+// them, never fewer workgroups than fill the chip once
+static int grid_str_pass(int64_t nt) {
+  int64_t b = nt / (32 * kWavesPerBlock);
+  const int64_t fill = 1280;                                          // ~ resident workgroups of these kernels (5 per CU x 256)
+  if (b < fill) b = std::min<int64_t>(fill, (nt + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 
 void launch_unique_insert(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t row0, int64_t row1,
                           UniqueEntry* ent, uint64_t mask, uint64_t* aux) {
@@ -482,8 +493,9 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
                        const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
                        uint64_t* aux, uint64_t salt) {
   if (tile1 <= tile0) return;
-  const dim3 g(grid_tiles(tile1 - tile0)), b(kBlock);
-  if (pass == 2) { hipLaunchKernelGGL(k_unique_str_mark, g, b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile1, ent, mask, aux, salt); return; }
+  const dim3 b(kBlock);
+  if (pass == 2) { hipLaunchKernelGGL(k_unique_str_mark, dim3(grid_tiles(tile1 - tile0)), b, 0, s, bitmap, tile_counts, sizes, tile_off, bytes, nrows, tile1, ent, mask, aux, salt); return; }
+  const dim3 g(grid_str_pass(tile1 - tile0));
   StrPassArgs A{};
   A.sel = bitmap; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = tile0; A.tile1 = tile1;
   A.ent = ent; A.rep_off = rep_off; A.rep_len = rep_len; A.mask = mask; A.aux = aux; A.salt = salt;
@@ -669,9 +681,9 @@ void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32
   A.sel = sel; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = 0; A.tile1 = ntiles;
   A.ent = const_cast<UniqueEntry*>(ent); A.rep_off = const_cast<uint64_t*>(rep_off); A.rep_len = const_cast<uint32_t*>(rep_len); A.mask = mask; A.aux = special; A.salt = salt;
   A.valcol = valcol; A.valdt = valdt; A.op = op; A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
-  const int g = grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles);
+  const int g = grid_str_pass(ntiles) > 2048 ? 2048 : grid_str_pass(ntiles);
   if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_str_pass<2, true>), dim3(g), dim3(kBlock), 0, s, A);
-  else hipLaunchKernelGGL((k_str_pass<2, false>), dim3(grid_tiles(ntiles)), dim3(kBlock), 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<2, false>), dim3(grid_str_pass(ntiles)), dim3(kBlock), 0, s, A);
 }
 // accumulators -> results: min / max images back to values (in place)
 __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
