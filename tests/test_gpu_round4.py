@@ -1,6 +1,7 @@
 """Round 4: k_scan_cmp_narrow (16 bytes per lane for 1-, 2- and 4-byte columns) against the oracle and numpy; see also tests/test_gpu_stream.py
 (late materialization) and tests/test_gpu_round3.py (group counts bound to their exchange)."""
 import operator
+import os
 
 import numpy as np
 import pytest
@@ -246,3 +247,17 @@ def test_unique_and_groupreduce_forms_agree_with_first_appearance(oracle, dfdb_m
         ctx.profile(False)
     t.close()
     ctx.close()
+
+
+def test_nothing_reads_a_recycled_buffer_it_has_not_written():
+    """DevPool (common.hpp) hands the device buffers of freed queries and of unique / groupreduce to the next allocation of their size class instead of to hipFree:
+    with DFDB_POOL_POISON=1 every buffer is filled with 0xA5 as it enters the pool, so a kernel that counts on fresh memory being zero — or on a neighbour's old
+    contents — gets garbage every time.  A second process runs the unique / groupreduce forms, the capture and the narrow-scan tests of this file that way."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFDB_POOL_POISON="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_round4.py"), os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "(unique or groupreduce or capture or narrow or dictionary) and not recycled"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, cwd=root)
+    tail = p.stdout.decode(errors="replace")[-1500:]
+    assert p.returncode == 0 and " passed" in tail and "failed" not in tail, tail
