@@ -919,6 +919,16 @@ def nrow(v: Union[DFView, DFTable, "DFColumn"]) -> int:      # view.jl:192-206
     return v._query().count()
 
 
+def _isequal_image(vals: np.ndarray) -> np.ndarray:
+    """the values as integers that are equal exactly when Julia's isequal says so: integers and Bool as they are, floats by bit pattern (0.0 and -0.0 apart)
+    with every NaN folded onto one"""
+    if vals.dtype.kind != "f":
+        return vals.astype(np.int64) if vals.dtype.kind in "ib" or vals.dtype.itemsize < 8 else vals.view(np.uint64)
+    u = np.ascontiguousarray(vals).view(np.uint32 if vals.dtype.itemsize == 4 else np.uint64).copy()
+    u[np.isnan(vals)] = (0x7fc00000 if vals.dtype.itemsize == 4 else 0x7ff8000000000000)
+    return u
+
+
 def _out_of_core(v: DFView) -> bool:
     """The view touches a column of a file-backed table that is not resident (open_table(path, load=False)): evaluate it
     block-streamed, the way the reference always does (blocksiterator.jl:98-145), instead of refusing."""
@@ -1044,13 +1054,26 @@ class DFColumn:
             return _to_user(q.materialize()[0], _logicals(self.view)[0])
         if _out_of_core(self.view):
             seen, out = set(), []
+            keys_seen, parts = None, []          # plain numeric chunks merge as arrays: their isequal images (bit patterns, one NaN) against the sorted images met so far
             with Stream(self.view) as s:
                 for part in s:
                     vals = one(part)
+                    if isinstance(vals, np.ndarray) and not isinstance(vals, np.ma.MaskedArray) and vals.dtype.kind in "iufb" and not out:
+                        img = _isequal_image(vals)
+                        new = np.ones(len(vals), bool) if keys_seen is None else ~np.isin(img, keys_seen, assume_unique=True)
+                        parts.append(vals[new])
+                        keys_seen = np.sort(img) if keys_seen is None else np.union1d(keys_seen, img[new])
+                        continue
+                    if parts:                    # (a chunk of another kind after numeric ones cannot happen for one column; kept safe: fold what was merged into the general form)
+                        for v in np.concatenate(parts).tolist():
+                            seen.add(("nan",) if isinstance(v, float) and v != v else v); out.append(v)
+                        parts = []
                     for v in (vals.tolist() if not isinstance(vals, np.ma.MaskedArray) else [None if m else x for x, m in zip(vals.data.tolist(), np.ma.getmaskarray(vals).tolist())]):
                         k = ("nan",) if isinstance(v, float) and v != v else v
                         if k not in seen:
                             seen.add(k); out.append(v)
+            if parts:
+                return np.concatenate(parts)
             return np.array(out, dtype=object) if out and isinstance(out[0], (str, type(None))) else np.array(out)
         return one(self.view._query())
 

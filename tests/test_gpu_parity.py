@@ -816,6 +816,14 @@ def test_unique_columns(oracle, dfdb_mod, ctx, tmp_path):
     t.save(path)
     tb = dfdb_mod.open_table(path, load=False)
     assert list(tb.s.unique()) == julia_unique(strs) and tb.a.unique().tolist() == julia_unique(cols["a"].tolist())
+    # (numeric chunks merge as arrays on the host, by isequal images: one NaN, -0.0 apart from 0.0, the column's own dtype)
+    for name in ("i8", "u", "flag", "b"):
+        got = getattr(tb, name).unique()
+        assert got.dtype == cols[name].dtype and got.tolist() == julia_unique(cols[name].tolist()), name
+    got, want = tb.f.unique(), julia_unique(cols["f"].tolist())
+    assert got.dtype == np.float64 and len(got) == len(want) and all((x != x and y != y) or (x == y and np.signbit(x) == np.signbit(y)) for x, y in zip(got.tolist(), want))
+    sm = tb.sm.unique()
+    assert list(sm) == julia_unique(cols["sm"], [x is None for x in cols["sm"]])
 
 
 # ------------------------------------------------------------------ groupreduce (aggregate.jl:1-36, completed to its intent)
