@@ -789,12 +789,16 @@ class _ChunkQuery(_Query):
         return out
 
 
+DEFAULT_CHUNK_BLOCKS = 512      # blocks per chunk of the block-streamed consumers that open their own Stream (unique, aggregates, groupreduce over a table that is not resident)
+
+
 class Stream:
     """Base.iterate(::BlocksIterator) in chunks of blocks (blocksiterator.jl:98-145) for a view over a table that was opened
     with load=False: `for part in dfdb.stream(v, chunk_blocks=256): part.count(), part.indices(), part.materialize()`.
     The next chunk is read, copied and LZ4-decoded on another HIP stream while the caller works on the current one."""
 
-    def __init__(self, v: Union[DFView, DFTable], chunk_blocks: int = 512):
+    def __init__(self, v: Union[DFView, DFTable], chunk_blocks: Optional[int] = None):
+        chunk_blocks = DEFAULT_CHUNK_BLOCKS if chunk_blocks is None else chunk_blocks
         self.view = v if isinstance(v, DFView) else DFView(v)
         self._q = _Query(self.view)
         self._h = C.c_void_p()
@@ -1309,4 +1313,58 @@ def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, s
     appearance (the reference's group_map numbering), with the group's row count and stat(col) — stat in count / sum / min / max / mean.
     Returns a pandas.DataFrame with columns [by, "count", stat]."""
     sub, with_value = _groupreduce_view(v, by, col, stat)
+    if _out_of_core(sub):
+        return _groupreduce_frame(by, stat, *_groupreduce_streamed(sub, with_value, stat))
     return _groupreduce_frame(by, stat, *_groupreduce_raw(_Query(sub), with_value, stat))
+
+
+def _groupreduce_streamed(sub: DFView, with_value: bool, stat: str):
+    """the same over a table that is not resident: every chunk of blocks is reduced on the device, the per-chunk groups (one record per distinct key) are
+    merged here in chunk order — a key keeps the place of its first appearance; counts and sums add (Int64 sums wrap like the device's), minimum / maximum
+    fold with a NaN winning, like Julia's."""
+    order: Dict[Any, int] = {}
+    keys_out: List[Any] = []
+    counts: List[int] = []
+    vis: List[int] = []
+    vfs: List[float] = []
+    vdt, kdt = None, None
+    M64 = (1 << 64) - 1
+    wrap = lambda x: ((int(x) + (1 << 63)) % (1 << 64)) - (1 << 63)
+    with Stream(sub) as s:
+        for part in s:
+            k, c, vi, vf, vdt = _groupreduce_raw(part, with_value, stat)
+            kdt = part.coltype(0)
+            if isinstance(k, np.ma.MaskedArray):
+                klist = [None if m else x for x, m in zip(k.data.tolist(), np.ma.getmaskarray(k).tolist())]
+            else:
+                klist = k.tolist() if isinstance(k, np.ndarray) else list(k)
+            for j, key in enumerate(klist):
+                canon = ("nan",) if isinstance(key, float) and key != key else ((key, bool(np.signbit(key))) if isinstance(key, float) else key)
+                at = order.get(canon)
+                if at is None:
+                    order[canon] = len(keys_out); keys_out.append(key); counts.append(int(c[j])); vis.append(int(vi[j])); vfs.append(float(vf[j]))
+                    continue
+                counts[at] += int(c[j])
+                if stat in ("sum", "mean", "count"):
+                    vis[at] = wrap(vis[at] + int(vi[j])); vfs[at] += float(vf[j])
+                else:
+                    lo = stat in ("min", "minimum")
+                    a, b = vfs[at], float(vf[j])
+                    if a != a or b != b:
+                        vfs[at] = float("nan")
+                    elif a == b:                                        # -0.0 orders below 0.0 (Base.min / Base.max)
+                        vfs[at] = (a if np.signbit(a) else b) if lo else (b if np.signbit(a) else a)
+                    else:
+                        vfs[at] = min(a, b) if lo else max(a, b)
+                    uns = vdt in (ir.U8, ir.U16, ir.U32, ir.U64)        # (UInt64 values travel as Int64 bits)
+                    x, y = (vis[at] & M64, int(vi[j]) & M64) if uns else (vis[at], int(vi[j]))
+                    z = min(x, y) if lo else max(x, y)
+                    vis[at] = wrap(z)
+    n = len(keys_out)
+    if kdt is not None and (kdt & ir.DTYPE_MASK) == ir.STRING:
+        keys = np.array(keys_out, dtype=object)
+    elif kdt is not None and kdt & ir.NULLABLE:
+        keys = np.ma.masked_array(np.array([0 if x is None else x for x in keys_out], ir.numpy_of_dtype(kdt)), mask=[x is None for x in keys_out])
+    else:
+        keys = np.array(keys_out, ir.numpy_of_dtype(kdt)) if kdt is not None else np.zeros(0, np.int64)
+    return keys, np.array(counts, np.int64).reshape(n), np.array(vis, np.int64).reshape(n), np.array(vfs, np.float64).reshape(n), vdt

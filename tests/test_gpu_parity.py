@@ -824,6 +824,30 @@ def test_unique_columns(oracle, dfdb_mod, ctx, tmp_path):
     assert got.dtype == np.float64 and len(got) == len(want) and all((x != x and y != y) or (x == y and np.signbit(x) == np.signbit(y)) for x, y in zip(got.tolist(), want))
     sm = tb.sm.unique()
     assert list(sm) == julia_unique(cols["sm"], [x is None for x in cols["sm"]])
+    # groupreduce over the table that is not resident: per-chunk groups merged on the host in chunk order == the resident table's answer
+    from dfdb import api as _api
+    keep = _api.DEFAULT_CHUNK_BLOCKS
+    _api.DEFAULT_CHUNK_BLOCKS = 1                     # four chunks
+    try:
+        vb, vt = tb[tb.a > 100, dfdb_mod.ALL], t[t.a > 100, dfdb_mod.ALL]
+        for by in ("a", "s", "sm", "m", "f", "i8"):
+            for col, stats in (("b", ("count", "sum", "min", "max")), ("u", ("sum", "max", "min")), ("f", ("sum", "min", "max", "mean"))):
+                if col == by:
+                    continue
+                for stat in stats:
+                    got, want = dfdb_mod.groupreduce(vb, by, col, stat), dfdb_mod.groupreduce(vt, by, col, stat)
+                    gk, wk = got[by].tolist(), want[by].tolist()
+                    assert len(gk) == len(wk) and all((x == y) or (x != x and y != y) or (x is None and y is None) for x, y in zip(gk, wk)), (by, col, stat)
+                    assert got["count"].tolist() == want["count"].tolist(), (by, col, stat)
+                    if stat != "count":
+                        g, w = got[stat].to_numpy(), want[stat].to_numpy()
+                        assert g.dtype == w.dtype, (by, col, stat, g.dtype, w.dtype)
+                        if g.dtype.kind == "f":
+                            assert np.allclose(g, w, rtol=1e-9, atol=1e-9, equal_nan=True), (by, col, stat)
+                        else:
+                            assert np.array_equal(g, w), (by, col, stat)
+    finally:
+        _api.DEFAULT_CHUNK_BLOCKS = keep
 
 
 # ------------------------------------------------------------------ groupreduce (aggregate.jl:1-36, completed to its intent)
