@@ -26,7 +26,7 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
   calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
                   `value` itself is the library-default configuration (no ctx option set)
                   Round 4 adds "3_computed" (config 3 with the computed x * 2 projection), "interp" (expressions outside the scan kernels: the device interpreter and
-                  the same program compiled at run time by hipRTC), "unique", "groupreduce", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
+                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "groupreduce", "groupreduce_int_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
@@ -567,6 +567,18 @@ def f_rows_legs(L, dfdb, sc, rank):
     res["unique_hash_table"] = {"rows": n, "distinct": len(u), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
                                 "what": "the same unique with ctx option unique_dense = 0: open-addressing table of {key, first row} sized by the distinct values as they turn up (what Float64 keys, "
                                         "wide-ranged integers and String hashes take); best of 2"}
+    # ---- groupreduce by an integer key: 5000 groups (x mod 5000, made on the device) over the same 1e9 rows, sum of x
+    t.add_column_from("k", t.x % 5000)
+    best, g = None, None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g = dfdb.groupreduce(t, "k", "x", "sum")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res["groupreduce_int_key"] = {"rows": n, "groups": len(g), "seconds": best, "rows_per_s": n / best,
+                                  "roofline": {"bound": "hbm", "achieved": n * 24 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 24 / best / 1e9 / L.peak},
+                                  "what": "groupreduce(t, (:k,); out = :x => Sum()), k = x mod 5000 (Int64): the keys' dense form (presence bits in LDS, no hash table) numbers the groups, the "
+                                          "accumulate pass adds into 144 KB of LDS accumulators per CU; bytes = the key column twice (presence pass, accumulate pass) + the value column; best of 3"}
     t.close()
     # ---- groupreduce by a String key, flat and with the dictionary
     n = int(500_000_000 * sc)

@@ -325,7 +325,7 @@ def test_bench_eight_ranks_on_one_device(oracle, ctx, exchange):
     want = int((oracle.gen_i64(0x9E3779B97F4A7C15, 0, total) > 899_999).sum())
     assert r["config"]["global_selected"] == want
     cf = r["configs"]
-    for k in ("3", "3_computed", "4", "4_dictionary", "5_shard", "5_shard_dictionary", "5_shard_materialize", "unique", "groupreduce", "nullable_string_eq"):
+    for k in ("3", "3_computed", "4", "4_dictionary", "5_shard", "5_shard_dictionary", "5_shard_materialize", "unique", "unique_hash_table", "groupreduce", "groupreduce_int_key", "nullable_string_eq"):
         assert k in cf and "error" not in cf[k], (k, cf.get(k), {n: v for n, v in cf.items() if isinstance(v, dict) and "error" in v})
     assert "error" not in cf["interp"], cf["interp"]
     n5 = cf["5_shard"]["rows_per_gpu"]
