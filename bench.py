@@ -375,6 +375,85 @@ def cold_leg(dfdb, ctx, torch, dev, rows, peak, chunk_blocks=1024):
     return res
 
 
+# ------------------------------------------------------------------ the line's last key: every leg in a few bytes
+def _r(x, nd=3):
+    return None if x is None else round(float(x), nd)
+
+
+def make_summary(res):
+    """`summary`, the LAST key of the line (the driver's record keeps the line's tail): per leg [ms per step or per launch, fraction of the 8 TB/s HBM peak] —
+    the BASELINE configs, the decode-inclusive steps, the expression / unique / groupreduce / nullable legs — and the cold path's file GB/s with its
+    fraction of the pinned-copy rate.  A leg that failed carries its error text; a leg that did not run is absent."""
+    s = {"fmt": "[ms, frac_of_8TBps_peak]", "2": [_r(res.get("ms_per_step")), _r((res.get("job_hbm_gbps") or 0) / HBM_PEAK_GBPS)]}
+    rf = res.get("roofline") or {}
+    s["2_k1"] = [_r(rf.get("avg_launch_ms")), _r(rf.get("frac"))]
+    if rf.get("box_read_ceiling_GBps"):
+        s["2_k1_box"] = {"read_ceiling_GBps": _r(rf["box_read_ceiling_GBps"], 0), "k1_frac_of_it": _r(rf.get("frac_of_box_ceiling"))}
+    cfg = res.get("configs") or {}
+    for k in ("3", "3_computed", "4", "4_dictionary", "5_shard", "5_shard_materialize", "5_shard_dictionary", "nullable_string_eq"):
+        v = cfg.get(k)
+        if isinstance(v, dict):
+            s[k] = v["error"][:80] if "error" in v else [_r(v.get("ms_per_step")), _r((v.get("roofline") or {}).get("frac"))]
+    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_dictionary"):
+        v = cfg.get(k)
+        if isinstance(v, dict):
+            s[k] = v["error"][:80] if "error" in v else [_r(v.get("seconds", 0) * 1e3), _r((v.get("roofline") or {}).get("frac"))]
+    it = cfg.get("interp")
+    if isinstance(it, dict):
+        d = {}
+        for name, v in it.items():
+            if isinstance(v, dict) and ("compiled" in v or "interpreter" in v):
+                d[name] = {t[:1]: [_r(v[t].get("ms")), _r(v[t].get("frac_of_peak"))] for t in ("interpreter", "compiled") if isinstance(v.get(t), dict) and "ms" in v[t]}
+        s["interp"] = d if d else str(it.get("error", ""))[:80]
+    for k in cfg:
+        if isinstance(cfg[k], dict) and "error" in cfg[k] and k not in s:
+            s[k] = cfg[k]["error"][:80]
+    ds = res.get("decode_scan")
+    if isinstance(ds, dict):
+        if "error" in ds or "skipped" in ds:
+            s["decode_scan"] = str(ds.get("error") or ds.get("skipped"))[:80]
+        else:
+            d = {"fmt": "[ms_per_step, K7_decoded_GBps]", "fused": [_r(ds.get("ms_per_step")), _r(ds.get("decoded_GBps"), 0)]}
+            for k in ("unfused", "without_index", "arena"):
+                if isinstance(ds.get(k), dict):
+                    d[k] = [_r(ds[k].get("ms_per_step")), _r(ds[k].get("decoded_GBps"), 0)]
+            if isinstance(ds.get("arena"), dict):
+                d["arena_resident_GB"] = _r(ds["arena"].get("resident_GB"))
+            s["decode_scan"] = d
+    cold = res.get("cold")
+    if isinstance(cold, dict):
+        if "error" in cold or "skipped" in cold:
+            s["cold"] = str(cold.get("error") or cold.get("skipped"))[:80]
+        else:
+            d = {"fmt": "[file_GBps, frac_of_pinned_copy]", "pinned_copy_GBps": _r(cold.get("pinned_copy_GBps"), 1)}
+            for k in ("open_table", "stream_count", "stream_materialize", "stream_clustered"):
+                if isinstance(cold.get(k), dict):
+                    d[k] = [_r(cold[k].get("file_GBps"), 1), _r(cold[k].get("frac_of_pinned_copy"))]
+            if isinstance(cold.get("stream_clustered"), dict):
+                d["clustered_projection_read_frac"] = _r(cold["stream_clustered"].get("projection_bytes_read_frac"))
+            s["cold"] = d
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("value"):
+        s["cpu_1core_rows_per_s"] = _r(cb["value"], 0)
+        if isinstance(ds, dict) and ds.get("rows_per_s"):
+            s["decode_scan_vs_cpu_1core"] = _r(ds["rows_per_s"] / cb["value"], 1)
+    return s
+
+
+def finish_line(res, keep_what):
+    """the line as printed: the legs' prose (`what`, `sample` stays) dropped unless --what asks for it — they were most of a 20-KB line — and `summary` LAST"""
+    def strip(x):
+        if isinstance(x, dict):
+            return {k: strip(v) for k, v in x.items() if k != "what"}
+        if isinstance(x, list):
+            return [strip(v) for v in x]
+        return x
+    out = res if keep_what else strip(res)
+    out.pop("summary", None)
+    out["summary"] = make_summary(out)
+    return out
+
+
 # ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 (extra keys, never part of `value`)
 def claim_stdout():
     """This script's stdout is ONE JSON line.  RCCL prints a version banner on stdout from C code the first time a communicator is used (sys.stdout
@@ -843,7 +922,7 @@ def main_threads(args, out_fd):
         except Exception as e:
             res["configs"] = {"5_shard": {"error": f"{type(e).__name__}: {e}"}}
     sys.stdout.flush()
-    os.write(out_fd, (json.dumps(res) + "\n").encode())
+    os.write(out_fd, (json.dumps(finish_line(res, args.what)) + "\n").encode())
     grp.close()
 
 
@@ -873,6 +952,7 @@ def main():
                     "or the library's own RCCL communicator behind the C ABI (dfdb_group_create_rank + dfdb_group_count)")
     ap.add_argument("--mode", default="processes", choices=["processes", "threads"], help="processes: one process per GPU (torch.distributed.run or self-spawned ranks); "
                     "threads: ONE process driving --gpus GPUs through dfdb_group_create (a host thread per GPU, ncclCommInitAll) — what a Julia session gets")
+    ap.add_argument("--what", action="store_true", help="keep every leg's prose description (`what`) in the line (off: the line stays small enough for a record that keeps its tail)")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 legs (extra keys)")
     ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the config legs (functional runs; 1.0 = BASELINE.json's sizes)")
     ap.add_argument("--config-steps", type=int, default=None, help="timed steps per config leg (default: min(steps, 10), at least 3)")
@@ -988,6 +1068,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # what this box / this allocation gives K1's read stream with nothing written beside it (dfdb_table_read_probe: the scan's load shape, no stores): the
+    # ceiling K1's own rate is read against — a slow box or an unlucky placement shows here, a slower kernel does not
+    probe_best_ms = probe_avg_ms = None
+    try:
+        probe_best_ms, probe_avg_ms = t.read_probe("x", 10)
+    except Exception as e:
+        print(f"bench.py: read probe failed: {e}", file=sys.stderr)
+    step()
     # roofline leg: HIP event pairs around every launch, recorded on the launch stream DURING the timed steps and resolved
     # after them (no host synchronisation inside the region: dfdb_ctx_profile_get folds them)
     ctx.profile(True)
@@ -1066,15 +1154,15 @@ def main():
         # HBM traffic of that kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command; FETCH_SIZE doubled per the gfx950 correction, calibrated on a known-byte read): profiles/
         traffic, traffic_src = None, None
-        for pmc_name in ("r3_pmc_scan_cmp.json", "r2_pmc_scan_cmp.json"):
-            pmc = os.path.join(ROOT, "profiles", pmc_name)
-            if not os.path.exists(pmc):
-                continue
+        import glob
+        import re
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_scan_cmp.json")), key=lambda f: -int(re.search(r"r(\d+)_pmc", f).group(1)))
+        for pmc in pmcs:                                   # the newest round's PMC passes first
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("rows"):
                 traffic = pj["hbm_bytes_per_launch_corrected"] * local_rows / pj["rows"]
-                traffic_src = f"profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
+                traffic_src = f"profiles/{os.path.basename(pmc)} (2*FETCH_SIZE + WRITE_SIZE, scaled to rows)"
                 break
         res = {
             "metric": "filtered-scan rows/sec + achieved HBM GB/s, 1e9-row Int64 col, 10% selectivity",
@@ -1100,6 +1188,11 @@ def main():
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "kernels": kernels},
         }
+        if probe_best_ms:
+            ceil = local_rows * 8 / (probe_best_ms * 1e-3) / 1e9
+            res["roofline"].update({"box_read_ceiling_GBps": ceil, "box_read_ceiling_avg_GBps": local_rows * 8 / (probe_avg_ms * 1e-3) / 1e9,
+                                    "frac_of_box_ceiling": (achieved / ceil) if achieved else None,
+                                    "box_read_ceiling_source": "dfdb_table_read_probe: K1's load shape over the same resident column, no stores, best / average of 10 launches before the timed steps"})
         res["config"]["options"] = "library defaults (no ctx option set; placement_calibrate = 0)" if not (lib and args.placement) else "placement_calibrate = 1"
         if calibrated_cfg is not None:
             res["calibrated_config"] = calibrated_cfg
@@ -1110,7 +1203,7 @@ def main():
                 res["decode_scan"] = {"error": f"{type(e).__name__}: {e}"}
     def emit(line):
         sys.stdout.flush()
-        os.write(out_fd, (json.dumps(line) + "\n").encode())
+        os.write(out_fd, (json.dumps(finish_line(line, args.what)) + "\n").encode())
 
     # ---- configs 3 / 4 / 5 on every rank (the column of config 2 goes first: the legs bring their own tables)
     if not args.no_configs:

@@ -55,7 +55,11 @@ void DevPool::give(void* p, size_t cls) {
   static const bool poison = [] { const char* e = getenv("DFDB_POOL_POISON"); return e && e[0] == '1'; }();
   if (poison) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0xA5, cls); (void)hipDeviceSynchronize(); }      // (the fill has landed before anyone can take the buffer)
   PoolState& S = pool_state();
-  const int d = pool_device();
+  // filed under the device that OWNS the buffer, not the one that happens to be current on the calling thread: a thread that holds contexts on two GPUs may
+  // free a device-1 query while device 0 is current, and the buffer must not be handed to a device-0 allocation later
+  int d = pool_device();
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) == hipSuccess) { if (at.device >= 0 && at.device < 64) d = at.device; } else (void)hipGetLastError();
   std::vector<void*> drop;
   {
     std::lock_guard<std::mutex> g(S.m);
@@ -117,6 +121,16 @@ extern "C" {
 
 int32_t dfdb_version(void) { return DFDB_ABI_VERSION; }
 int32_t dfdb_shutdown(void) { return guard([&] { jit_shutdown(); }); }
+int32_t dfdb_jit_cache_dir(char* buf, size_t cap) {
+  return guard([&] {
+    NEED(buf);
+    if (!cap) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_jit_cache_dir needs a buffer");
+    std::string why;
+    const std::string d = jit_cache_dir(&why);
+    snprintf(buf, cap, "%s", d.c_str());
+    if (d.empty()) set_last_error(("the run-time kernel cache on disk is off: " + why).c_str());   // (status stays 0: no cache is a state, not a failure)
+  });
+}
 int32_t dfdb_device_count(int32_t* n) {
   return guard([&] { NEED(n); int nd = 0; if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); nd = 0; } *n = nd; });
 }
@@ -289,6 +303,37 @@ int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_bl
     const int64_t bad = table_decode_status(t, ordinal);
     if (bad_blocks) *bad_blocks = bad;
     else if (bad > 0) fail(DFDB_ERR_FORMAT, "decompression error: %lld resident block(s) did not decode to their stored size", (long long)bad);
+  });
+}
+int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, double* best_ms, double* avg_ms) {
+  return guard([&] {
+    NEED(t);
+    if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
+    const Column& c = t->cols[(size_t)ordinal];
+    if (!c.resident || dt_width(c.dtype) != 8 || dt_base(c.dtype) == DFDB_STRING) fail(DFDB_ERR_ARGUMENT, "ArgumentError: the read probe takes a resident 8-byte column");
+    dfdb_ctx* ctx = t->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (repeats < 1) repeats = 1;
+    if (repeats > 64) repeats = 64;
+    DevBuf sink; sink.ensure(256);
+    std::vector<hipEvent_t> ev((size_t)repeats + 1);
+    for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    launch_read_probe(ctx->stream, c.data.p, c.nrows, sink.as<uint64_t>());      // (untimed: the first launch of a kernel loads its code object)
+    HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+    for (int r = 0; r < repeats; r++) {
+      LaunchTimer lt(ctx, "read_probe");
+      launch_read_probe(ctx->stream, c.data.p, c.nrows, sink.as<uint64_t>());
+      HIP_CHECK(hipEventRecord(ev[(size_t)r + 1], ctx->stream));
+    }
+    HIP_CHECK(hipEventSynchronize(ev[(size_t)repeats]));
+    double best = 0, sum = 0;
+    for (int r = 0; r < repeats; r++) {
+      float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev[(size_t)r], ev[(size_t)r + 1]));
+      sum += ms; if (r == 0 || ms < best) best = ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (best_ms) *best_ms = best;
+    if (avg_ms) *avg_ms = sum / repeats;
   });
 }
 int32_t dfdb_table_set_logical_type(dfdb_table* t, int32_t ordinal, const char* logical) {

@@ -165,6 +165,7 @@ struct JitKernel;
 std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait);
 bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, void** args);
 void jit_shutdown();
+std::string jit_cache_dir(std::string* why);   // "" = off or refused
 void jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, int64_t* from_disk = nullptr);
 
 void query_add_stage(dfdb_query* q, Stage&& s);   // composition rules of selection.jl:39-49

@@ -83,6 +83,31 @@ static Rccl& rccl() {
     if (_r != ncclSuccess) ::dfdb::fail(DFDB_ERR_DEVICE, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "rccl error"); \
   } while (0)
 
+// ncclGroupStart ... ncclGroupEnd around `body`, whatever happens in between.  A collective that fails inside the bracket used to throw with the group OPEN
+// (RCCL_CHECK between the two calls): the thread's next collective would then have nested inside the abandoned one.  Here GroupEnd always runs, and a failure
+// of anything inside the bracket (or of the bracket's own calls) marks the communicator dead: what the other ranks have enqueued by then is unknowable, so every
+// later collective of the group fails at once with ONE clear error instead of hanging or nesting.  `r` is a parameter so that a CPU self-test can drive
+// the bracket with a stub table (dfdb_selftest "rccl_bracket"); nothing in it touches a device.
+struct CommState { bool dead = false; std::string why; };
+template <class F>
+static void rccl_bracket(Rccl& r, CommState& cs, F&& body) {
+  if (cs.dead) fail(DFDB_ERR_DEVICE, "this group's RCCL communicator failed earlier (%s): destroy the group and create a new one", cs.why.c_str());
+  auto name_of = [&](ncclResult_t rc) { return std::string(r.GetErrorString ? r.GetErrorString(rc) : "rccl error"); };
+  ncclResult_t rc = r.GroupStart();
+  if (rc != ncclSuccess) { cs.dead = true; cs.why = "ncclGroupStart: " + name_of(rc); fail(DFDB_ERR_DEVICE, "ncclGroupStart failed: %s", name_of(rc).c_str()); }
+  try { body(); }
+  catch (const std::exception& e) { (void)r.GroupEnd(); cs.dead = true; cs.why = e.what(); throw; }
+  catch (...) { (void)r.GroupEnd(); cs.dead = true; cs.why = "unknown error inside a collective bracket"; throw; }
+  rc = r.GroupEnd();
+  if (rc != ncclSuccess) { cs.dead = true; cs.why = "ncclGroupEnd: " + name_of(rc); fail(DFDB_ERR_DEVICE, "ncclGroupEnd failed: %s", name_of(rc).c_str()); }
+}
+// the same check for a call inside a bracket, against the table the bracket was given
+#define RCCL_IN(r, expr)                                                                                          \
+  do {                                                                                                            \
+    ncclResult_t _r = (expr);                                                                                     \
+    if (_r != ncclSuccess) ::dfdb::fail(DFDB_ERR_DEVICE, "%s failed: %s", #expr, (r).GetErrorString ? (r).GetErrorString(_r) : "rccl error"); \
+  } while (0)
+
 // ---------------------------------------------------------------- one host thread per local shard
 struct Worker {
   std::thread th;
@@ -131,6 +156,7 @@ struct dfdb_group {
   // and the bare status otherwise — so that all ranks learn of the failure at the same point and raise the SAME error: the one of the
   // lowest table row, which is the one the reference's serial block iteration would have met first.
   int fault_code = 0; std::string fault_msg; uint64_t fault_key = ~0ull;
+  CommState comm_state;                  // RCCL: dead once anything failed inside a collective bracket (rccl_bracket)
   dfdb_exchange_fns fns{nullptr, nullptr, nullptr};   // DFDB_EXCHANGE_CALLBACK: the caller's collectives (host memory, blocking)
   int nlocal() const { return (int)ctx.size(); }
 };
@@ -292,13 +318,13 @@ static void exchange_reduce(dfdb_group* g, std::initializer_list<XSpec> specs_in
   if (!exchanges(g)) return;
   if (g->exchange == DFDB_EXCHANGE_RCCL) {
     Rccl& r = rccl();
-    RCCL_CHECK(r.GroupStart());
-    for (int l = 0; l < nl; l++)
-      for (const XSpec& x : specs) {
-        uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>() + x.slot;
-        RCCL_CHECK(r.AllReduce(p, p, (size_t)x.n, nccl_type(x.dt), nccl_op(x.op), g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
-      }
-    RCCL_CHECK(r.GroupEnd());
+    rccl_bracket(r, g->comm_state, [&] {
+      for (int l = 0; l < nl; l++)
+        for (const XSpec& x : specs) {
+          uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>() + x.slot;
+          RCCL_IN(r, r.AllReduce(p, p, (size_t)x.n, nccl_type(x.dt), nccl_op(x.op), g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+        }
+    });
     return;
   }
   if (g->exchange == DFDB_EXCHANGE_CALLBACK) {       // one shard per process: operands to pinned memory, the caller's all-reduce, results back
@@ -352,13 +378,13 @@ static std::vector<int64_t> exchange_gather(dfdb_group* g, int slot) {
   post_fault(g);
   if (g->exchange == DFDB_EXCHANGE_RCCL) {
     Rccl& r = rccl();
-    RCCL_CHECK(r.GroupStart());
-    for (int l = 0; l < nl; l++) {
-      uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>();
-      RCCL_CHECK(r.AllGather(p + slot, p + kXSlots, 1, ncclInt64, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
-      RCCL_CHECK(r.AllReduce(p + kFaultSlot, p + kFaultSlot, 1, ncclUint64, ncclMin, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
-    }
-    RCCL_CHECK(r.GroupEnd());
+    rccl_bracket(r, g->comm_state, [&] {
+      for (int l = 0; l < nl; l++) {
+        uint64_t* p = g->xbuf[(size_t)l].as<uint64_t>();
+        RCCL_IN(r, r.AllGather(p + slot, p + kXSlots, 1, ncclInt64, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+        RCCL_IN(r, r.AllReduce(p + kFaultSlot, p + kFaultSlot, 1, ncclUint64, ncclMin, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+      }
+    });
     HIP_CHECK(hipSetDevice(g->ctx[0]->device));
     HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kXSlots, g->xbuf[0].as<uint64_t>() + kXSlots, (size_t)g->world * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
     HIP_CHECK(hipMemcpyAsync(g->xpin[0] + kFaultSlot, g->xbuf[0].as<uint64_t>() + kFaultSlot, 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
@@ -1062,9 +1088,9 @@ static std::vector<GroupPart> all_parts(dfdb_group* g, std::vector<GroupPart>& l
     blobs[(size_t)l].resize((size_t)maxb, 0);
     HIP_CHECK(hipMemcpyAsync(send[(size_t)l].p, blobs[(size_t)l].data(), (size_t)maxb, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
   }
-  RCCL_CHECK(r.GroupStart());
-  for (int l = 0; l < nl; l++) RCCL_CHECK(r.AllGather(send[(size_t)l].p, recv[(size_t)l].p, (size_t)maxb, ncclInt8, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
-  RCCL_CHECK(r.GroupEnd());
+  rccl_bracket(r, g->comm_state, [&] {
+    for (int l = 0; l < nl; l++) RCCL_IN(r, r.AllGather(send[(size_t)l].p, recv[(size_t)l].p, (size_t)maxb, ncclInt8, g->comm[(size_t)l], g->ctx[(size_t)l]->stream));
+  });
   std::vector<uint8_t> all((size_t)maxb * (size_t)g->world);
   HIP_CHECK(hipSetDevice(g->ctx[0]->device));
   HIP_CHECK(hipMemcpyAsync(all.data(), recv[0].p, all.size(), hipMemcpyDeviceToHost, g->ctx[0]->stream));
@@ -1208,5 +1234,37 @@ int32_t dfdb_group_query_groupreduce(dfdb_gquery* gq, int32_t key_col, int32_t v
 }
 int32_t dfdb_group_query_groupreduce_fetch(dfdb_gquery* gq, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f) {
   return gguard([&] { GNEEDQ(gq); group_reduce_fetch(gq, keys, counts, values_i, values_f); gq->merged = GroupMerged{}; });
+}
+/* host-side self-tests that need neither a GPU nor RCCL (include/dfdb.h) */
+namespace {
+int st_starts, st_ends, st_calls, st_fail_at;
+ncclResult_t st_group_start() { st_starts++; return st_fail_at == -1 ? ncclInternalError : ncclSuccess; }
+ncclResult_t st_group_end() { st_ends++; return st_fail_at == -2 ? ncclInternalError : ncclSuccess; }
+ncclResult_t st_allreduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) { return ++st_calls == st_fail_at ? ncclInternalError : ncclSuccess; }
+const char* st_errstr(ncclResult_t) { return "stub failure"; }
+}  // namespace
+int32_t dfdb_selftest(const char* name, int64_t arg, int64_t* out, int32_t nout) {
+  return gguard([&] {
+    GNEED(name); GNEED(out);
+    if (!strcmp(name, "rccl_bracket")) {
+      // the collective bracket of every RCCL exchange, driven by a stub table: three all-reduces, number `arg` fails (1-based; 0 = none, -1 = ncclGroupStart,
+      // -2 = ncclGroupEnd); then a SECOND exchange on the same state.  out: [GroupStart calls, GroupEnd calls, collectives issued, first status, second status,
+      // communicator dead]
+      if (nout < 6) fail(DFDB_ERR_ARGUMENT, "ArgumentError: rccl_bracket fills 6 values");
+      Rccl r; r.GroupStart = st_group_start; r.GroupEnd = st_group_end; r.AllReduce = st_allreduce; r.GetErrorString = st_errstr;
+      st_starts = st_ends = st_calls = 0; st_fail_at = (int)arg;
+      CommState cs;
+      auto one = [&]() -> int64_t {
+        try { rccl_bracket(r, cs, [&] { for (int i = 0; i < 3; i++) RCCL_IN(r, r.AllReduce(nullptr, nullptr, 1, ncclInt64, ncclSum, nullptr, nullptr)); }); return 0; }
+        catch (const Error& e) { set_last_error(e.what()); return e.code; }
+      };
+      const int64_t first = one();
+      st_fail_at = 0;
+      const int64_t second = one();
+      out[0] = st_starts; out[1] = st_ends; out[2] = st_calls; out[3] = first; out[4] = second; out[5] = cs.dead ? 1 : 0;
+      return;
+    }
+    fail(DFDB_ERR_ARGUMENT, "ArgumentError: no self-test named %s", name);
+  });
 }
 }  // extern "C"

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -77,7 +78,7 @@ void table_fn(std::string& s, const char* type, const char* name, const std::vec
 }  // namespace
 
 struct JitKernel {
-  std::string key, source, log;
+  std::string key, source, log, arch;      // arch: the gcnArchName the code object is compiled for (part of the key: one kernel per shape AND target)
   std::vector<char> code;
   std::atomic<int> state{0};                   // 0: queued / compiling, 1: ready, -1: failed
   double compile_ms = 0;
@@ -105,17 +106,35 @@ JitCache& cache() { static JitCache* c = new JitCache; return *c; }   // (leaked
 // directory (default $XDG_CACHE_HOME/dfdb-jit or ~/.cache/dfdb-jit), DFDB_JIT_CACHE=0 turns the cache off; every failure (no home, no space, a torn file) just
 // means compiling as before.
 uint64_t fnv1a(const void* p, size_t n, uint64_t h) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; } return h; }
-std::string disk_dir() {
+// The cache directory is TRUSTED INPUT: a code object read from it runs inside this process's GPU context, and the FNV trailer only says the file is whole, not
+// who wrote it.  So the directory must be a real directory (no symlink) owned by the effective user with no group / other write permission — anything else
+// (a shared or world-writable $DFDB_JIT_CACHE_DIR, somebody else's directory) turns the cache off — and files are opened without following symlinks and must
+// be regular files of the same owner.  *why (optional) says what was refused.
+std::string disk_dir_checked(std::string* why) {
+  auto no = [&](const std::string& w) { if (why) *why = w; return std::string(); };
   const char* off = getenv("DFDB_JIT_CACHE");
-  if (off && off[0] == '0') return "";
+  if (off && off[0] == '0') return no("DFDB_JIT_CACHE=0");
   std::string d;
   if (const char* e = getenv("DFDB_JIT_CACHE_DIR")) d = e;
   else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/dfdb-jit";
   else if (const char* h = getenv("HOME")) { d = std::string(h) + "/.cache"; (void)mkdir(d.c_str(), 0700); d += "/dfdb-jit"; }
-  if (d.empty()) return "";
+  if (d.empty()) return no("no DFDB_JIT_CACHE_DIR, XDG_CACHE_HOME or HOME");
   (void)mkdir(d.c_str(), 0700);
   struct stat st;
-  return (stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) ? d : "";
+  if (lstat(d.c_str(), &st) != 0) return no(d + ": cannot be created or examined");
+  if (!S_ISDIR(st.st_mode)) return no(d + ": not a directory (a symbolic link is not followed)");
+  if (st.st_uid != geteuid()) return no(d + ": owned by another user");
+  if (st.st_mode & (S_IWGRP | S_IWOTH)) return no(d + ": writable by group or others");
+  return d;
+}
+std::string disk_dir() {
+  std::string why;
+  const std::string d = disk_dir_checked(&why);
+  if (d.empty() && getenv("DFDB_JIT_DEBUG")) {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "[jit] no disk cache: %s\n", why.c_str());
+  }
+  return d;
 }
 std::string disk_path(const JitKernel& k, const std::string& arch, const char* const* opts, int nopts) {
   const std::string dir = disk_dir();
@@ -131,30 +150,34 @@ std::string disk_path(const JitKernel& k, const std::string& arch, const char* c
   return dir + name;
 }
 bool disk_read(const std::string& path, std::vector<char>& code) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) { close(fd); return false; }   // not ours: never loaded, never touched
   std::vector<char> buf;
-  char chunk[65536]; size_t n;
-  while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) buf.insert(buf.end(), chunk, chunk + n);
-  fclose(f);
-  if (buf.size() <= 8) return false;
+  char chunk[65536]; ssize_t n;
+  while ((n = read(fd, chunk, sizeof chunk)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+  close(fd);
+  if (n < 0 || buf.size() <= 8) return false;
   uint64_t want; memcpy(&want, buf.data() + buf.size() - 8, 8);
   buf.resize(buf.size() - 8);
-  if (fnv1a(buf.data(), buf.size(), 0xCBF29CE484222325ull) != want) { (void)unlink(path.c_str()); return false; }      // torn or foreign: out of the way
+  if (fnv1a(buf.data(), buf.size(), 0xCBF29CE484222325ull) != want) { (void)unlink(path.c_str()); return false; }      // a torn file of ours: out of the way
   code.swap(buf);
   return true;
 }
 void disk_write(const std::string& path, const std::vector<char>& code) {
   char tmp[32]; snprintf(tmp, sizeof tmp, ".%d.tmp", (int)getpid());
   const std::string t = path + tmp;
-  FILE* f = fopen(t.c_str(), "wb");
-  if (!f) return;
+  const int fd = open(t.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return;
   const uint64_t h = fnv1a(code.data(), code.size(), 0xCBF29CE484222325ull);
-  const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size() && fwrite(&h, 1, 8, f) == 8;
-  if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
+  auto put = [&](const void* p, size_t n) { const char* b = (const char*)p; while (n) { const ssize_t w = write(fd, b, n); if (w <= 0) return false; b += w; n -= (size_t)w; } return true; };
+  const bool ok = put(code.data(), code.size()) && put(&h, 8);
+  if (close(fd) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
 }
 
-void compile_one(JitKernel& k, const std::string& arch) {
+void compile_one(JitKernel& k) {
+  const std::string& arch = k.arch;
   Rtc& r = rtc();
   const auto t0 = std::chrono::steady_clock::now();
   const std::string archopt = "--offload-arch=" + arch;
@@ -194,8 +217,9 @@ void compile_one(JitKernel& k, const std::string& arch) {
   cache().compiled++; k.state = 1;
 }
 
-void worker_main(std::string arch) {
+void worker_main() {
   JitCache& c = cache();
+  bool registered_after_compile = false;
   for (;;) {
     std::shared_ptr<JitKernel> k;
     {
@@ -205,8 +229,10 @@ void worker_main(std::string arch) {
       k = c.queue.front(); c.queue.pop_front();
       c.busy = true;
     }
-    compile_one(*k, arch);
-    std::atexit(jit_at_exit);                                      // (again: newer than the statics this compile may have created; the handler is idempotent)
+    compile_one(*k);
+    // ONE more registration, after the first compile: LLVM builds its statics (and registers their destructors) during that compile, so only a handler
+    // registered afterwards runs before them at exit().  Once: atexit slots are finite, and a process compiles up to kMaxShapes shapes.
+    if (!registered_after_compile) { registered_after_compile = true; std::atexit(jit_at_exit); }
     { std::lock_guard<std::mutex> lk(c.mu); c.busy = false; }      // (a waiter that has just found state == 0 is inside cv.wait by now: the notification cannot slip past it)
     c.cv.notify_all();
   }
@@ -228,8 +254,13 @@ void jit_shutdown() {
   for (auto& k : c.queue) k->state = -1;
   c.queue.clear();
   c.cv.notify_all();
-  c.cv.wait_for(lk, std::chrono::seconds(10), [&] { return !c.busy; });
+  // a compile in flight is waited for: 0.1-0.3 s as a rule.  The bound is only there so that a wedged compiler cannot keep a process from ending for ever;
+  // ten seconds (round 4) could run out on a loaded box and leave the worker inside LLVM while its statics were destroyed
+  c.cv.wait_for(lk, std::chrono::seconds(120), [&] { return !c.busy; });
 }
+
+// the directory the code-object cache uses, "" when it is off or was refused (*why then says which check failed): dfdb_jit_cache_dir
+std::string jit_cache_dir(std::string* why) { return disk_dir_checked(why); }
 
 // the kernel for this program shape: ready, or nullptr (still compiling, hipRTC missing, or the compile failed).  wait = true blocks until the compiler is done.
 std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool wait) {
@@ -238,6 +269,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
   std::string key;
   {
     char b[64];
+    key += ctx->prop.gcnArchName; key += "|";      // a code object is one target's: on a box with mixed parts every target compiles its own
     snprintf(b, sizeof b, "m%d s%d n%d a%d l%d r%d t%d|", sh.mode, sh.str, sh.nul, sh.and_existing, sh.stack_levels, sh.result_dtype, sh.nstr); key += b;
     for (size_t i = 0; i < sh.w0.size(); i++) { snprintf(b, sizeof b, "%x.%x.%x.%d.%d;", sh.w0[i], sh.w1[i], sh.w2[i], sh.slot[i], sh.aslot[i]); key += b; }
     key += "|";
@@ -255,6 +287,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
     else {
       k = std::make_shared<JitKernel>();
       k->key = key;
+      k->arch = ctx->prop.gcnArchName;
       // ---- the source
       std::string s;
       char b[160];
@@ -306,7 +339,7 @@ std::shared_ptr<JitKernel> jit_request(dfdb_ctx* ctx, const JitShape& sh, bool w
       k->source = std::move(s);
       c.map.emplace(key, k);
       c.queue.push_back(k);
-      if (!c.started) { c.started = true; c.worker = std::thread(worker_main, std::string(ctx->prop.gcnArchName)); c.worker.detach(); std::atexit(jit_at_exit); }
+      if (!c.started) { c.started = true; c.worker = std::thread(worker_main); c.worker.detach(); std::atexit(jit_at_exit); }
       c.cv.notify_all();
     }
     if (wait) c.cv.wait(lk, [&] { return k->state.load() != 0; });
@@ -325,6 +358,7 @@ bool jit_launch(JitKernel& k, dfdb_ctx* ctx, unsigned grid, size_t lds_bytes, vo
       hipModule_t mod = nullptr;
       if (hipModuleLoadData(&mod, k.code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "dfdb_jit_kernel") != hipSuccess) {
         (void)hipGetLastError();
+        if (getenv("DFDB_JIT_DEBUG")) fprintf(stderr, "[jit] device %d (%s) cannot load the code object compiled for %s: this shape stays interpreted there\n", ctx->device, ctx->prop.gcnArchName, k.arch.c_str());
         k.loaded.emplace(ctx->device, nullptr);
         return false;
       }

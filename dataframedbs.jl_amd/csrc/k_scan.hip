@@ -317,6 +317,45 @@ void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint
 }
 
 // ------------------------------------------------------------------------------------------------
+// read probe: what THIS box's HBM gives K1's load shape with nothing written beside it (dfdb_table_read_probe)
+// ------------------------------------------------------------------------------------------------
+// k_scan_cmp's trip — four consecutive tiles per wave, sixteen nontemporal 512-byte wave loads in flight per tile, the same grid — with the ballots, the bitmap
+// and the tile counts taken out: every loaded value is folded into one register and a store happens only if the fold hits a value the host picks so that it
+// cannot (the loads stay, nothing leaves).  bench.py prints the rate beside K1's: the distance between the two is the price of the 1/64 of bitmap written
+// into the read stream, and the ceiling itself is what tells a slow allocation / a slow box from a slower kernel.
+__global__ __launch_bounds__(kBlock) void k_read_probe(const uint64_t* __restrict__ col, int64_t nrows, int64_t ntiles, uint64_t never, uint64_t* __restrict__ sink) {
+  const int lane = lane_id();
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ngroups = (ntiles + 3) / 4;
+  uint64_t acc = 0;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    for (int k = 0; k < 4; k++) {
+      const int64_t tile = g * 4 + k;
+      if (tile >= ntiles) break;
+      const int64_t base = tile * kTile;
+      const uint64_t* p = col + base + lane;
+      if (base + kTile <= nrows) {
+        uint64_t v[kWordsPerTile];
+#pragma unroll
+        for (int j = 0; j < kWordsPerTile; j++) v[j] = __builtin_nontemporal_load(p + j * 64);
+#pragma unroll
+        for (int j = 0; j < kWordsPerTile; j++) acc += v[j] ^ (uint64_t)j;
+      } else {
+        for (int j = 0; j < kWordsPerTile; j++) if (base + j * 64 + lane < nrows) acc += p[j * 64];
+      }
+    }
+  }
+  if (acc == never) sink[0] = acc;
+}
+void launch_read_probe(hipStream_t s, const void* col, int64_t nrows, uint64_t* sink) {
+  const int64_t ntiles = (nrows + kTile - 1) / kTile;
+  if (ntiles == 0) return;
+  const int grid = grid_for_tiles((ntiles + 3) / 4);
+  hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(kBlock), 0, s, (const uint64_t*)col, nrows, ntiles, 0x9e3779b97f4a7c15ull, sink);
+}
+
+// ------------------------------------------------------------------------------------------------
 // conjunction / disjunction of simple terms over several columns (config 3: (a > c1) & (x < c2))
 // ------------------------------------------------------------------------------------------------
 // op -> which of {lt, eq, gt, unordered} satisfy it

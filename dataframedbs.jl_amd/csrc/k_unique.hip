@@ -715,7 +715,7 @@ void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int
 constexpr int kDenseBlock = 1024;
 constexpr int kDenseWords = 39936;                                   // u32 words of LDS per workgroup (156 KB of the CU's 160)
 constexpr int64_t kDenseRange = (int64_t)kDenseWords * 32;
-constexpr int kAuxMissing = 1, kAuxOutside = 5, kAuxDistinct = 6, kAuxFound = 7, kAuxMin = 8, kAuxMax = 9;
+constexpr int kAuxMissing = 1, kAuxOutside = 5, kAuxDistinct = 6, kAuxFound = 7, kAuxMin = 8, kAuxMax = 9, kAuxFoundBefore = 10;
 
 int64_t unique_dense_max_range() { return kDenseRange; }
 bool unique_dense_dtype(int dtype) {
@@ -798,9 +798,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_count(const uint32_t* __restri
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dense_first(const uint64_t* __restrict__ bitmap, const T* __restrict__ col, const uint64_t* __restrict__ missing,
                                                         int64_t nrows, int64_t tile0, int64_t tile1, uint64_t lo, uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux) {
-  // every value's first row lies in an earlier launch?  (`distinct` comes from the host, which read it after the presence pass; a stale view of the counter
-  // shows fewer values found than there are: one launch too many, never one too few)
-  if (__atomic_load_n(&aux[kAuxFound], __ATOMIC_RELAXED) >= distinct) return;
+  // every value's first row lies in an EARLIER launch?  The test reads kAuxFoundBefore — kAuxFound as the launches before this one left it (k_dense_snap copies it
+  // between two launches of the row-ordered series) — never the live counter: workgroups of THIS launch add to that as they finish, a workgroup that starts
+  // late could see found == distinct and skip its tiles although they hold an earlier row of a value a sibling has just found in a later tile (first[value]
+  // would then not be the smallest row, and unique's order with it).  `distinct` comes from the host, which read it after the presence pass.
+  if (aux[kAuxFoundBefore] >= distinct) return;
   const int lane = lane_id();
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   uint32_t fresh = 0;
@@ -837,6 +839,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_first(const uint64_t* __restri
   for (int d = 32; d; d >>= 1) fresh += __shfl_xor(fresh, d, 64);
   if (lane == 0 && fresh) atomicAdd((unsigned long long*)&aux[kAuxFound], (unsigned long long)fresh);
 }
+
+__global__ void k_dense_snap(uint64_t* aux) { aux[kAuxFoundBefore] = aux[kAuxFound]; }
 
 __global__ __launch_bounds__(kBlock) void k_dense_scatter(const uint64_t* __restrict__ first, uint32_t range, const uint64_t* __restrict__ aux,
                                                           uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts) {
@@ -886,6 +890,7 @@ void launch_dense_first(hipStream_t s, const uint64_t* bitmap, const void* col, 
   if (row1 <= row0) return;
   const int64_t tile0 = row0 / kTile, tile1 = (row1 + kTile - 1) / kTile;
   const dim3 g(grid_tiles(tile1 - tile0) > 2048 ? 2048 : grid_tiles(tile1 - tile0)), b(kBlock);
+  hipLaunchKernelGGL(k_dense_snap, dim3(1), dim3(1), 0, s, aux);      // what the launches before this one have found: the only count this launch may stop on
   DENSE_BY_DTYPE(hipLaunchKernelGGL((k_dense_first<T>), g, b, 0, s, bitmap, (const T*)col, missing, row1, tile0, tile1, lo, range, distinct, first, aux))
 }
 void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts) {

@@ -39,6 +39,8 @@ void launch_scan_cmp(hipStream_t s, const void* col, int32_t dtype, int op, uint
                      uint32_t* tile_counts, int64_t nrows, bool and_existing, bool nt = true, void* cap = nullptr,
                      int wt_store = 3 /* bit 0: the bitmap leaves with write-through stores (ctx option "scan_wt_store"); bits 1-2: ctx option "scan_narrow" — which
                                          narrow columns take k_scan_cmp_narrow (16 bytes per lane): 1 = 1-byte (default), 2 = 1-, 2- and 4-byte, 0 = none */);
+// K1's read stream alone (k_read_probe): an 8-byte column of nrows rows, nothing written (sink: one device word that is never stored to)
+void launch_read_probe(hipStream_t s, const void* col, int64_t nrows, uint64_t* sink);
 // extra = 1 (capture): the LAST term's 8-byte column at the finally selected rows, compacted per tile at extra_out[tile*1024 + rank];
 // extra = 2 (sum): one partial sum of that column per 1024-row tile in extra_out[tile] (double, or wrapping 64-bit integer).  AND only.
 // extra = 5 (capture two): the last term's column like extra = 1, and the 8-byte column of the term before it into extra_out2, same layout.

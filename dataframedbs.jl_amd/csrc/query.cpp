@@ -719,6 +719,17 @@ static void ensure_executed(dfdb_query* q) {
   if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
 }
 
+int64_t query_count(dfdb_query* q, int nstages);
+// ensure_executed for a consumer that hands results to the HOST (or builds on them: unique, groupreduce, a new column): an execution that decoded a column's
+// resident LZ4 blocks on its way (decode_on_scan) is only as good as that decode, and the blocks' statuses are read — and a failed decode repeated once
+// without the index — where query_count waits for the count (only dfdb_count did so).  Consumers that stay asynchronous on the device
+// (dfdb_select_indices / _bitmap into device memory without a count, the group layer's device aggregates) are covered by the caller's next dfdb_count or
+// dfdb_table_decode_status, as include/dfdb.h says.
+static void ensure_executed_checked(dfdb_query* q) {
+  ensure_executed(q);
+  if (q->decoded_col >= 0) (void)query_count(q, -1);
+}
+
 int64_t query_count(dfdb_query* q, int nstages) {
   if (nstages < 0) { ensure_executed(q); if (q->count >= 0) return q->count; }
   else query_execute(q, nstages);
@@ -747,7 +758,7 @@ int64_t query_count(dfdb_query* q, int nstages) {
 }
 
 void query_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
-  ensure_executed(q);
+  if (memkind == DFDB_MEM_DEVICE) ensure_executed(q); else ensure_executed_checked(q);
   hipStream_t s = q->t->ctx->stream;
   const size_t bytes = (size_t)ceil_div(q->t->nrows, 64) * 8;
   if (!bytes) return;
@@ -825,7 +836,7 @@ static int64_t string_out_offsets(dfdb_query* q, const Column& col, DevBuf& out_
 }
 
 int64_t query_string_bytes(dfdb_query* q, int i) {
-  ensure_executed(q);
+  ensure_executed_checked(q);
   if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
   const Node& e = *q->proj[(size_t)i].expr;
   if (dt_base(e.dtype) != DFDB_STRING) return 0;
@@ -966,7 +977,7 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
 // RESIDENT column of dst without leaving the device.  dst may be the view's own table (then every row must be selected).
 void launch_pack_flags(hipStream_t s, const uint8_t* flags, uint64_t* bits, int64_t n);
 void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p) {
-  ensure_executed(q);
+  ensure_executed_checked(q);
   if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
   if (dst->ctx != q->t->ctx) fail(DFDB_ERR_ARGUMENT, "the destination table lives on another context");
   for (auto& c : dst->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
@@ -1050,7 +1061,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   stream_wait(ctx);                                        // rows / rank are pageable host memory
   return ng;
 }
-constexpr size_t kUniqueAuxBytes = 128;      // k_unique.hip: 0 first row of the key that cannot be stored, 1 first missing row, 2 claimed slots, 3 abort, 4 collision, 5-9 the dense form's
+constexpr size_t kUniqueAuxBytes = 128;      // k_unique.hip: 0 first row of the key that cannot be stored, 1 first missing row, 2 claimed slots, 3 abort, 4 collision, 5-10 the dense form's (10: found-before snapshot)
 static void unique_reset_aux(dfdb_ctx* ctx, DevBuf& aux) {
   hipStream_t s = ctx->stream;
   aux.ensure(kUniqueAuxBytes);
@@ -1240,7 +1251,7 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
 }
 
 static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
-  ensure_executed(q);
+  ensure_executed_checked(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx;
   if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
   const Node& e = *q->proj[(size_t)p].expr;
@@ -1277,7 +1288,7 @@ void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32
 void launch_group_finish(hipStream_t s, uint64_t* val, int64_t ng, int kind, int op);
 
 void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, int64_t* ngroups, int64_t* key_bytes) {
-  ensure_executed(q);
+  ensure_executed_checked(q);
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   if (key_p < 0 || (size_t)key_p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", key_p);
   const Node& ke = *q->proj[(size_t)key_p].expr;
@@ -1440,6 +1451,7 @@ int query_aggregate_device(dfdb_query* q, int32_t op, int32_t i) {
 
 void query_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
   if (op == DFDB_AGG_COUNT) { const int64_t n = query_count(q, -1); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }
+  ensure_executed_checked(q);                       // (a host-facing result: a decode_on_scan execution answers for its decode first)
   const int dt = query_aggregate_device(q, op, i);
   dfdb_ctx* ctx = q->t->ctx;
   HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->red_result.p, 16, hipMemcpyDeviceToHost, ctx->stream));

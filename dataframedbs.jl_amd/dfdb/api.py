@@ -364,6 +364,12 @@ class DFTable:
         N.check(N.load().dfdb_table_decode_status(self._h, self.ordinal(column), C.byref(bad)))
         return bad.value
 
+    def read_probe(self, column: str, repeats: int = 5):
+        """(best_ms, avg_ms) of K1's read stream alone over a resident 8-byte column: dfdb_table_read_probe"""
+        best, avg = C.c_double(), C.c_double()
+        N.check(N.load().dfdb_table_read_probe(self._h, self.ordinal(column), repeats, C.byref(best), C.byref(avg)))
+        return best.value, avg.value
+
     def build_dictionary(self, column: str, max_entries: int = 4096) -> int:
         """K9: 16-bit codes + the distinct strings of a resident String column (kept beside its flat form); returns the number of distinct
         strings, 0 when none was built (more than max_entries, nullable, a string over 4 KB).  Results of every query stay the same."""

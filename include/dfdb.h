@@ -100,9 +100,21 @@ typedef struct dfdb_outcol {
 /* ------------------------------------------------------------------ misc */
 int32_t dfdb_version(void);
 /* Call from the host language's exit hook (Python atexit, Julia atexit: the shipped bindings do) before the process ends: stops the background compiler
- * of run-time expression kernels (a compile in flight gets ten seconds), after which new expressions are interpreted.  Idempotent; handles stay valid.
+ * of run-time expression kernels (a compile in flight is waited for: 0.1-0.3 s as a rule, two minutes at most), after which new expressions are interpreted.  Idempotent; handles stay valid.
  * Without it a process that exits while hipRTC is compiling can crash inside LLVM's static destructors (there is no Julia method this replaces). */
 int32_t dfdb_shutdown(void);
+/* Where the run-time compiler keeps its code objects between processes ($DFDB_JIT_CACHE_DIR, else $XDG_CACHE_HOME/dfdb-jit, else ~/.cache/dfdb-jit;
+ * DFDB_JIT_CACHE=0 turns it off), or "" when there is none.  The directory is TRUSTED INPUT — a code object read from it runs in this process's GPU
+ * context — so it is used only if it is a real directory (not a symbolic link) owned by the effective user and not writable by group or others; files in
+ * it are opened with O_NOFOLLOW and must be regular files of the same owner.  A directory that fails a check is never read or written: buf receives ""
+ * and dfdb_last_error says which check failed (the status is still 0: kernels are then compiled per process, as without a cache). */
+int32_t dfdb_jit_cache_dir(char* buf, size_t cap);
+/* Host-side self-tests of library internals that need neither a GPU nor RCCL (there is no Julia method this replaces; tests/test_host_cpu.py calls it).
+ *   "rccl_bracket": the ncclGroupStart / ncclGroupEnd bracket of every RCCL exchange (csrc/group.cpp) driven by a stub collective table: three all-reduces of
+ *   which number `arg` fails (0 = none, -1 = ncclGroupStart itself, -2 = ncclGroupEnd), then a second exchange on the same communicator state.
+ *   out[0..5] = GroupStart calls, GroupEnd calls, collectives issued, status of the first exchange, status of the second, communicator marked dead.
+ * An unknown name is ArgumentError. */
+int32_t dfdb_selftest(const char* name, int64_t arg, int64_t* out, int32_t nout);
 int32_t dfdb_device_count(int32_t* n);   /* visible HIP devices (0 without a GPU: no error); the Julia shim forms a group when n > 1 */
 int32_t dfdb_last_error(char* buf, size_t cap);
 
@@ -243,6 +255,11 @@ int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal);
  * were validated when the column was loaded, so anything but 0 means the resident copy (or the sequence-start index beside it) was damaged; the index is
  * dropped then, and the next decode parses the blocks for itself and records a new one. */
 int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_blocks);
+/* Measurement aid (there is no Julia method this replaces): K1's READ STREAM alone over a resident 8-byte column — the predicate scan's load shape (four
+ * 1024-row tiles per wave trip, sixteen nontemporal 512-byte wave loads in flight, the scan's grid) with no ballot, no bitmap and no tile count written.
+ * `repeats` (1 .. 64) launches back to back on the context's stream, each bracketed by HIP events: *best_ms / *avg_ms (either may be NULL).  bench.py prints
+ * rows * 8 / best as `roofline.box_read_ceiling_GBps`: what this box and this allocation give the scan before it writes anything. */
+int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, double* best_ms, double* avg_ms);
 /* Dictionary form of a resident, non-nullable String column with at most max_entries (<= 65535) distinct values: one 16-bit code per row and the
  * distinct strings once, kept BESIDE the FlatStringsVector form (the reference has no such form: docs/src/index.md lists dictionary encoding under
  * "Future plans").  From then on `col == / != / startswith / endswith "const"` is decided once per distinct string and becomes a bit-table lookup of

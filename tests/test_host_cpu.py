@@ -348,3 +348,73 @@ def test_every_context_option_the_engine_reads_is_documented_in_the_header():
     header = open(os.path.join(ROOT, "include", "dfdb.h")).read()
     missing = sorted(o for o in read if f'"{o}"' not in header)
     assert not missing, missing
+
+
+# ------------------------------------------------------------------ round 5: host-side hardening that needs no GPU
+def test_a_failed_collective_always_closes_its_rccl_group_and_marks_the_communicator_dead():
+    """csrc/group.cpp's ncclGroupStart / ncclGroupEnd bracket, driven by a stub collective table (dfdb_selftest "rccl_bracket"): whichever of
+    the three all-reduces fails — or the bracket's own calls — GroupEnd has run as often as GroupStart succeeded, the failing exchange returns an error,
+    and the NEXT exchange on that communicator fails at once without touching RCCL again (no nesting, no hang)."""
+    import ctypes as C
+    from dfdb import _native as N
+    lib = N.load()
+    out = (C.c_int64 * 6)()
+
+    def run(fail_at):
+        assert lib.dfdb_selftest(b"rccl_bracket", fail_at, out, 6) == 0
+        return list(out)
+    assert run(0) == [2, 2, 6, 0, 0, 0]                                    # two healthy exchanges: two brackets, six collectives
+    for k in (1, 2, 3):
+        starts, ends, calls, first, second, dead = run(k)
+        assert (starts, ends) == (1, 1), "GroupEnd must run for the bracket whose collective failed, and no second bracket may open"
+        assert calls == k and first == N.ERR_DEVICE and second == N.ERR_DEVICE and dead == 1
+    assert run(-1) == [1, 0, 0, N.ERR_DEVICE, N.ERR_DEVICE, 1]             # GroupStart itself failed: nothing to close
+    assert run(-2) == [1, 1, 3, N.ERR_DEVICE, N.ERR_DEVICE, 1]             # GroupEnd failed: still called exactly once
+    assert lib.dfdb_selftest(b"no_such_test", 0, out, 6) == N.ERR_ARGUMENT
+    assert lib.dfdb_selftest(b"rccl_bracket", 0, out, 2) == N.ERR_ARGUMENT
+
+
+def test_the_jit_disk_cache_refuses_directories_it_cannot_trust(tmp_path, monkeypatch):
+    """VERDICT r4 item 7 / ADVICE: a code object read from the cache runs in this process's GPU context, so the directory must be a real directory owned by the
+    user and writable by nobody else; anything else turns the cache off (dfdb_jit_cache_dir returns "" and says why)."""
+    import ctypes as C
+    from dfdb import _native as N
+    lib = N.load()
+    buf = C.create_string_buffer(4096)
+
+    def cache_dir():
+        assert lib.dfdb_jit_cache_dir(buf, len(buf)) == 0
+        return buf.value.decode()
+
+    def why():
+        e = C.create_string_buffer(1024)
+        lib.dfdb_last_error(e, len(e))
+        return e.value.decode()
+    monkeypatch.delenv("DFDB_JIT_CACHE", raising=False)
+    good = tmp_path / "good"
+    monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(good))
+    assert cache_dir() == str(good) and (good.stat().st_mode & 0o777) == 0o700           # created private
+    shared = tmp_path / "shared"
+    shared.mkdir(); shared.chmod(0o777)
+    monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(shared))
+    assert cache_dir() == "" and "writable by group or others" in why()
+    shared.chmod(0o770)
+    assert cache_dir() == "" and "writable by group or others" in why()
+    shared.chmod(0o755)
+    assert cache_dir() == str(shared)
+    link = tmp_path / "link"
+    link.symlink_to(good)
+    monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(link))
+    assert cache_dir() == "" and "symbolic link" in why()
+    afile = tmp_path / "afile"
+    afile.write_bytes(b"x")
+    monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(afile))
+    assert cache_dir() == "" and "not a directory" in why()
+    if os.geteuid() == 0:                                                              # (only root can make somebody else's directory)
+        other = tmp_path / "other"
+        other.mkdir(); other.chmod(0o755); os.chown(other, 12345, 12345)
+        monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(other))
+        assert cache_dir() == "" and "another user" in why()
+    monkeypatch.setenv("DFDB_JIT_CACHE", "0")
+    monkeypatch.setenv("DFDB_JIT_CACHE_DIR", str(good))
+    assert cache_dir() == "" and "DFDB_JIT_CACHE=0" in why()
