@@ -19,6 +19,8 @@ static int32_t guard(F&& f) noexcept {
 }
 #define NEED(p) do { if (!(p)) fail(DFDB_ERR_ARGUMENT, "null argument: " #p); } while (0)
 #define NEEDQ(q) do { NEED(q); if (!(q)->t) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); } while (0)
+// NEEDQ for an entry point that may have to decode a compressed-only column whole (keep_compressed = 2; table.cpp column_data): such a decode lives until this call returns
+#define NEEDQT(q) NEEDQ(q); ::dfdb::TransientScope transient_scope_((q)->t)
 
 namespace dfdb {
 static hipEvent_t prof_event(dfdb_ctx* ctx) {
@@ -181,7 +183,7 @@ int32_t dfdb_ctx_destroy(dfdb_ctx* ctx) {
 int32_t dfdb_table_build_dictionary(dfdb_table* t, int32_t ordinal, int64_t max_entries, int64_t* entries) {
   return guard([&] { NEED(t); const int64_t n = table_build_dictionary(t, ordinal, max_entries); if (entries) *entries = n; });
 }
-int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) { return guard([&] { NEEDQ(q); NEED(out); stream_open(q, chunk_blocks, out); }); }
+int32_t dfdb_stream_open(dfdb_query* q, int64_t chunk_blocks, dfdb_stream** out) { return guard([&] { NEEDQT(q); NEED(out); stream_open(q, chunk_blocks, out); }); }
 int32_t dfdb_stream_next(dfdb_stream* s, dfdb_query** chunk, int64_t* chunk_rows, int64_t* first_row) {
   return guard([&] { NEED(s); NEED(chunk); *chunk = nullptr; *chunk = stream_next(s, chunk_rows, first_row); });
 }
@@ -289,11 +291,14 @@ int32_t dfdb_table_add_generated(dfdb_table* t, const char* name, int32_t genera
   return guard([&] { NEED(t); NEED(name); table_add_generated(t, name, generator, seed, row_first, nrows); });
 }
 int32_t dfdb_table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t proj_col) {
-  return guard([&] { NEED(dst); NEED(name); NEEDQ(q); table_add_from_query(dst, name, q, proj_col); });
+  return guard([&] { NEED(dst); NEED(name); NEEDQT(q); table_add_from_query(dst, name, q, proj_col); });
 }
-int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(path); table_save(t, path, stats); }); }
+int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(path); TransientScope ts(t); table_save(t, path, stats); }); }
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
-  return guard([&] { NEED(t); NEED(file); table_save_column(t, ordinal, file, stats); });
+  return guard([&] { NEED(t); NEED(file); TransientScope ts(t); table_save_column(t, ordinal, file, stats); });
+}
+int32_t dfdb_table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed) {
+  return guard([&] { NEED(t); table_resident_bytes(t, ordinal, decoded, compressed); });
 }
 int32_t dfdb_table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* stats) { return guard([&] { NEED(t); NEED(stats); table_column_stats(t, ordinal, stats); }); }
 int32_t dfdb_table_decode_resident(dfdb_table* t, int32_t ordinal) { return guard([&] { NEED(t); table_decode_resident(t, ordinal); }); }
@@ -429,16 +434,16 @@ int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivor
     q->stages[(size_t)stage].stage_base = survivors_before; q->executed_stages = -1; q->count = -1;
   });
 }
-int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
+int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
 
 // ------------------------------------------------------------------ execution
-int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQ(q); query_execute(q, -1); }); }
-int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQ(q); query_unique(q, proj_col); }); }
+int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQT(q); query_execute(q, -1); }); }
+int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQT(q); query_unique(q, proj_col); }); }
 int32_t dfdb_query_groupreduce(dfdb_query* q, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes) {
-  return guard([&] { NEEDQ(q); query_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); });
+  return guard([&] { NEEDQT(q); query_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); });
 }
 int32_t dfdb_query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f) {
-  return guard([&] { NEEDQ(q); query_groupreduce_fetch(q, keys, counts, values_i, values_f); });
+  return guard([&] { NEEDQT(q); query_groupreduce_fetch(q, keys, counts, values_i, values_f); });
 }
 int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
   return guard([&] { NEEDQ(q); q->hint_agg_op = op; q->hint_agg_proj = proj_col; });   // (affects the NEXT execution only: an executed query keeps its results)
@@ -447,23 +452,23 @@ int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on) {
   return guard([&] { NEEDQ(q); if (q->hint_materialize != (on != 0)) { q->hint_materialize = on != 0; q->executed_stages = -1; q->count = -1; q->prefix_valid = false; } });
 }
 int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0; }); }
-int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = query_count(q, -1); }); }
+int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_count(q, -1); }); }
 int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind) {
   return guard([&] {
-    NEEDQ(q); NEED(out);
+    NEEDQT(q); NEED(out);
     if (memkind != DFDB_MEM_DEVICE) { *out = query_count(q, -1); return; }
     if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
     const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
     HIP_CHECK(hipMemcpyAsync(out, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
   });
 }
-int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEEDQ(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
+int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEEDQT(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
 int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
-  return guard([&] { NEEDQ(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
+  return guard([&] { NEEDQT(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
 }
-int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEEDQ(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
-int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEEDQ(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
-int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQ(q); query_aggregate(q, op, i, out_i, out_f); }); }
+int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEEDQT(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
+int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEEDQT(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
+int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQT(q); query_aggregate(q, op, i, out_i, out_f); }); }
 
 }  // extern "C"
 

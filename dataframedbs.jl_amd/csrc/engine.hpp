@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "expr.hpp"
+#include "kernels.hpp"
 #include <memory>
 #include <mutex>
 
@@ -41,6 +42,12 @@ struct Column {
   int64_t comp_nblocks = 0;
   DevBuf comp_index;            // one bit per byte of comp: where an LZ4 sequence starts (recorded by the first resident decode, read by the later ones)
   int comp_index_state = 0;     // 0: not recorded yet, 1: recorded
+  // COMPRESSED-ONLY form (ctx option "keep_compressed" = 2 at load time; round 5): the LZ4 blocks + the index are all the column holds —
+  // `data` is empty.  `col OP const` conjuncts are evaluated by the decoder itself (K7 HIST + SCAN: no decoded byte reaches a column array), gathers decode
+  // the blocks that kept a row into a per-query arena, and anything else gets a whole-column decode that lives for one ABI call (`transient`).
+  bool comp_only = false;
+  bool transient = false;       // `data` is such a whole-column decode: released when the ABI call that needed it returns (TransientScope)
+  std::vector<Lz4Block> comp_blocks_host;   // the descriptors of comp_blocks, for decoding subsets of the blocks
   // placement calibration (query.cpp: place_mask): the selection bitmap this column's scans run fastest against, found once by timing
   // the scan against a few candidate allocations; lent to one query at a time
   DevBuf mask_pref;
@@ -107,6 +114,11 @@ struct dfdb_query {
   int cap_col2 = -1;           // a second captured column (k_scan_terms EXTRA = 5: the term before the last), in cap_buf2
   dfdb::DevBuf cap_buf2;
   int decoded_col = -1;        // table ordinal whose resident LZ4 blocks the last execution decoded on its way (decode_on_scan; -1: none)
+  std::vector<int> comp_scanned;   // compressed-only columns whose blocks the last execution decoded inside its scan (their statuses are read with the count)
+  // compressed-only projection columns: the blocks that kept a row, decoded for THIS query's gathers at their natural offsets inside the span
+  // [first such block, last such block] — the iterator owns its decode buffers, like the reference's (blocksiterator.jl:98-121)
+  struct Arena { dfdb::DevBuf buf, blocks, status; int64_t first_row = 0; int64_t nblocks = 0; bool valid = false; };
+  std::map<int, Arena> arenas;
   dfdb::DevBuf cap_buf;
   // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena
   // offset, selected byte totals per tile
@@ -195,6 +207,13 @@ void stream_stats(dfdb_stream* s, dfdb_sizestats* st);
 void stream_read_stats(dfdb_stream* s, int32_t ordinal, dfdb_sizestats* st);   // what the loaders have read so far of one column (-1: of every required column)
 void table_column_stats(dfdb_table* t, int32_t ordinal, dfdb_sizestats* st);
 void table_decode_resident(dfdb_table* t, int32_t ordinal);   // table.cpp
+// compressed-only columns (table.cpp).  column_data: the decoded array of a fixed-width column — for a compressed-only one a whole-column decode made now
+// (asynchronously, on the context's stream) and kept until table_drop_transient; TransientScope drops them when the ABI call that made them returns.
+const void* column_data(dfdb_table* t, Column& c);
+void table_drop_transient(dfdb_table* t);
+struct TransientScope { dfdb_table* t; explicit TransientScope(dfdb_table* t_) : t(t_) {} ~TransientScope() { if (t) table_drop_transient(t); } };
+uint8_t* ctx_hist_scratch(dfdb_ctx* ctx, int* waves);       // the history rings of K7's HIST forms (one buffer per context, made on first use)
+void table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed);
 int64_t table_decode_status(dfdb_table* t, int32_t ordinal);   // table.cpp: blocks of the last resident decode whose status is not 0 (synchronises)
 int column_lz4_index(dfdb_ctx* ctx, Column& c, bool form_takes_index);   // table.cpp: 0 / 1 (record) / 2 (use) for launch_lz4_decode*
 int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp

@@ -96,11 +96,24 @@ __device__ __forceinline__ bool lz_cmp8(uint64_t v, uint64_t c, int dtype, int o
 // it: the start bits of the superbatch's windows come out of a 64-dword register window of the index (three v_readlane + a funnel shift per window)
 // instead of the candidate decode of every position, the next^2 / next^4 / next^8 tables, the chain walk and the fill-in (phases 1 and 2: 40 % of the
 // vector and a third of the LDS instructions of a superbatch); which sequences the batch takes is decided where their fields are decoded anyway (3b).
-template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE, int OCC = (PIPE ? 4 : 5), int FARMAX = 64, int INDEX = 0>
+// HIST = 1 (round 5, SURVEY.md §8f-2: "without writing decoded blocks to HBM"): the decoded bytes never become a column.  What leaves the LDS ring goes to a
+// per-WAVE history ring of 64 KB in a scratch buffer (`dst` + workgroup * kHistStride) instead of to the block's place in a decoded array: an LZ4 offset is at
+// most 65 535 and block-local (BlockStreams.jl:110: one LZ4_decompress_safe per block), so the last 64 KB of a block's output are all a match can ever reach.
+// Far sources (behind the LDS ring) are fetched from that history — a few hundred MB that thousands of waves keep rewriting, i.e. cache-resident lines rather
+// than 8 GB of column the decoder used to write and then read 24 bytes at a time —, the first 32 bytes of a lap are mirrored behind the ring so that a 24-byte
+// fetch near the lap's end stays contiguous, and blocks are handed to waves by a ticket counter (the grid is the resident waves, not the blocks: every
+// workgroup owns ONE ring for its whole life).  With SCAN the predicate still sees every byte on its way out (bitmap + tile counts are the only output:
+// the reference's loop body decodes into two reusable buffers and keeps nothing either, BlockStreams.jl:9-15,101-119, blocksiterator.jl:98-121); without
+// SCAN it is a validating decode (status only), which is how a compressed-only column is checked and its sequence-start index recorded at load time.
+constexpr uint32_t kHistBytes = 65536u, kHistStride = 65536u + 64u;
+template <int WAVES, int kRing, int kStage, int kBatchBytes, int W, int SCAN, int PIPE, int OCC = (PIPE ? 4 : 5), int FARMAX = 64, int INDEX = 0, int HIST = 0>
 __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                const Lz4Block* __restrict__ blocks, int32_t nblocks, int32_t* __restrict__ status,
                                                                LzScan sc, uint32_t* __restrict__ index) {
   static_assert(INDEX != 1 || !PIPE, "the two-wave pipeline does not record the index (it reads it: PIPE with INDEX = 2)");
+  static_assert(!HIST || (!PIPE && WAVES == 1), "the history-ring form is one wave per workgroup");
+  // where output position p of the current block lives behind `out`: its place in the decoded array, or its slot of the wave's history ring
+  auto HO = [](uint32_t p) -> uint32_t { return HIST ? (p & (kHistBytes - 1u)) : p; };
   // PIPE with INDEX = 2: with the index the parser wave is the short one, so it also fetches the superbatch's far sources (into a per-slot area): the
   // producer is left with byte production and the flush, and the two waves are balanced again
   constexpr bool kParserFar = PIPE && INDEX == 2;
@@ -153,10 +166,29 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
   constexpr int kChunk = kStage / 2;            // two chunks staged, a third in flight
   constexpr int kNF = kChunk / 512;             // 8-byte words per lane of the chunk in flight
   static_assert(kChunk >= 1024 && kChunk % 512 == 0, "the 512-byte register window plus one sequence's look-ahead must fit behind ip");
-  for (int64_t b = wave; b < nblocks; b += nwaves) {
+  // HIST: blocks by ticket (sc.ticket, a device word the launcher zeroes): whichever wave is free takes the next block, its ring goes with it
+  for (int64_t b = HIST ? -1 : wave; ; b += nwaves) {
+    if (HIST) {
+      // the next block that needs decoding.  A later conjunct / stage (and_existing = 1: the mask already holds survivors) does not decode a block none of
+      // whose tiles kept a row — the reference's late materialization at block granularity, blocksiterator.jl:111-113; its mask words and counts stay
+      // as they are: zero (and_existing = 2: AND without the skip, an A/B knob).  (An inner loop of its own, not a `continue` of the block loop: the compiler
+      // made an endless loop of that form — the ticket was taken once and block 0 decoded for ever.)
+      for (;;) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(sc.ticket, 1u);
+        b = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)tk, 0);
+        if (b >= nblocks || !(SCAN && sc.and_existing == 1)) break;
+        const int64_t tile0 = blocks[b].dst_off >> 13, nt = ((int64_t)blocks[b].dst_len / 8 + 1023) / 1024;      // (8-byte rows: 8192 bytes per 1024-row tile)
+        uint32_t any = 0;
+        for (int64_t k = lane; k < nt; k += 64) any |= sc.counts[tile0 + k];
+        if (__ballot(any != 0u) != 0) break;
+        if (lane == 0) status[b] = 0;
+      }
+    }
+    if (b >= nblocks) break;
     const Lz4Block blk = blocks[b];
     const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
+    uint8_t* out = HIST ? dst + (size_t)blockIdx.x * kHistStride : dst + blk.dst_off;
     const uint32_t in_len = (uint32_t)blk.src_len, out_len = (uint32_t)blk.dst_len;
     uint32_t ip = 0, op = 0, flushed = 0;
     uint32_t cb = 0;                   // staged: input bytes [cb, cb + 4096); invariant cb <= ip < cb + 2048
@@ -218,6 +250,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     // SCAN: mask words of this block so far, the current tile's words (word k of the tile in lane k) and its selected count
     uint32_t sc_words = 0, sc_tile_count = 0; uint64_t sc_myword = 0;
     const uint32_t sc_sel = SCAN ? lz_op_sel(sc.op) : 0u;
+    const uint32_t sc_sel2 = SCAN && sc.op2 >= 0 ? lz_op_sel(sc.op2) : 0u;      // an interval term: col OP c  &  col OP2 c2 (`65 > x > 34`, test/selection.jl:53)
     const int64_t sc_word0 = blk.dst_off / 512;                   // the block's first mask word (host: the block starts on a 1024-row tile)
     // ring -> HBM, bytes [flushed, upto)
     auto flush_to = [&](uint32_t upto) {
@@ -227,14 +260,26 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         for (uint32_t g = flushed; g < upto; g += 512u) {
           const bool have = g + lane * 8u + 8u <= upto;
           const uint64_t v = *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1)));      // (always inside the ring: only the ballot needs `have`)
-          if (g + 512u <= upto) *(uint64_t*)(out + g + lane * 8u) = v;                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
-          const uint64_t m = __ballot(have && lz_cmp8_sel(v, sc.cbits, sc.dtype, sc_sel));
+          if (g + 512u <= upto) {
+            *(uint64_t*)(out + HO(g) + lane * 8u) = v;                                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
+            if (HIST && HO(g) == 0u && lane < 4u) *(uint64_t*)(out + kHistBytes + lane * 8u) = v;   // the lap's first 32 bytes again, behind the ring
+          }
+          bool r = have && lz_cmp8_sel(v, sc.cbits, sc.dtype, sc_sel);
+          if (sc.op2 >= 0) r = r && lz_cmp8_sel(v, sc.cbits2, sc.dtype, sc_sel2);
+          const uint64_t m = __ballot(r);
           if (lane == (sc_words & 15u)) sc_myword = m;
           sc_tile_count += (uint32_t)__builtin_popcountll(m);
           sc_words++;
           if ((sc_words & 15u) == 0u) {                            // a 1024-row tile is complete: one 128-byte line of bitmap + its count
-            if (lane < 16u) sc.bitmap[sc_word0 + sc_words - 16u + lane] = sc_myword;
-            if (lane == 0u) sc.counts[(sc_word0 + sc_words - 16u) >> 4] = sc_tile_count;
+            const int64_t w0 = sc_word0 + sc_words - 16u;
+            if (sc.and_existing) {                                 // (wave-uniform) the words AND what the mask held; the count is theirs
+              if (lane < 16u) sc_myword &= sc.bitmap[w0 + lane];
+              uint32_t c = lane < 16u ? (uint32_t)__builtin_popcountll(sc_myword) : 0u;
+              for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+              sc_tile_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            }
+            if (lane < 16u) sc.bitmap[w0 + lane] = sc_myword;
+            if (lane == 0u) sc.counts[w0 >> 4] = sc_tile_count;
             sc_tile_count = 0;
           }
         }
@@ -246,7 +291,8 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         for (uint32_t o0 = 0; o0 < n512; o0 += 512) {
           const uint32_t o = o0 + lane * 8;
           const uint64_t v = *(const uint64_t*)(ring + ((flushed + o) & (kRing - 1)));
-          *(uint64_t*)(out + flushed + o) = v;
+          *(uint64_t*)(out + HO(flushed + o)) = v;
+          if (HIST && HO(flushed + o0) == 0u && lane < 4u) *(uint64_t*)(out + kHistBytes + lane * 8u) = v;
         }
         flushed += n512;
       }
@@ -256,15 +302,16 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
         for (uint32_t o0 = 0; o0 < n256; o0 += 256) {                    // whole 256-byte steps: every lane stores (a wave-uniform loop: no exec bookkeeping)
           const uint32_t o = o0 + lane * 4;
           const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1)));
-          *(uint32_t*)(out + flushed + o) = v;
+          *(uint32_t*)(out + HO(flushed + o)) = v;
+          if (HIST && HO(flushed + o0) == 0u && lane < 8u) *(uint32_t*)(out + kHistBytes + lane * 4u) = v;
         }
         if (n256 != n4) {                                                // (a block's last flush)
           const uint32_t o = n256 + lane * 4;
-          if (o < n4) { const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1))); *(uint32_t*)(out + flushed + o) = v; }
+          if (o < n4) { const uint32_t v = *(const uint32_t*)(ring + ((flushed + o) & (kRing - 1))); *(uint32_t*)(out + HO(flushed + o)) = v; }
         }
         flushed += n4;
       }
-      if (flushed != upto) { for (uint32_t o = flushed + lane; o < upto; o += 64) out[o] = ring[o & (kRing - 1)]; }
+      if (flushed != upto) { for (uint32_t o = flushed + lane; o < upto; o += 64) out[HO(o)] = ring[o & (kRing - 1)]; }
       flushed = upto;
     };
 
@@ -284,7 +331,8 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           uint64_t* d = (uint64_t*)(lds + kStage + kRing + lane * 24u);
           // (24 bytes whatever the match's length: near a block's end the last of them lie past its output — in the next block's, or in the >= 32 bytes
           //  of slack every caller leaves behind the last block (kernels.hpp) — and are never used: the bytes a sequence copies all precede `op`)
-          const uint64_t a = ld_u64_unaligned(out + so), b2 = ld_u64_unaligned(out + so + 8), c2 = ld_u64_unaligned(out + so + 16);
+          const uint8_t* sp = out + HO(so);          // (HIST: at most 24 bytes past the lap's end: the mirror)
+          const uint64_t a = ld_u64_unaligned(sp), b2 = ld_u64_unaligned(sp + 8), c2 = ld_u64_unaligned(sp + 16);
           d[0] = a; d[1] = b2; d[2] = c2;
         }
         wave_lds_fence();
@@ -793,14 +841,14 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
               op += n; done += n;
               if (op - flushed >= kFlush) flush_to(op & ~kFA);
             }
-          } else if (SCAN) {
+          } else if (SCAN || HIST) {
             // far match, SCAN form: the bytes must pass the ring (and the predicate) like all others, so they come back from HBM 64 at a
             // time (the source lies more than kRing - 64 bytes back: always flushed, never inside the step)
             uint32_t done = 0, fenced = 0xffffffffu;
             while (done < ml) {
               const uint32_t n = ml - done < 64u ? ml - done : 64u;
               if (fenced != flushed) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = flushed; }
-              if (lane < n) { const uint8_t v = __builtin_nontemporal_load(out + op - offset + lane); ring[(op + lane) & (kRing - 1)] = v; }
+              if (lane < n) { const uint8_t v = __builtin_nontemporal_load(out + HO(op - offset + lane)); ring[(op + lane) & (kRing - 1)] = v; }
               op += n; done += n;
               if (op - flushed >= kFlush) flush_to(op & ~kFA);
             }
@@ -835,7 +883,14 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     if (!err && op != out_len) err = 6;         // @assert size == sizes.origin "decompression error" (:112)
     if (!err) flush_to(op);
     if (SCAN && !err && (sc_words & 15u) != 0u) {                 // the column's last, shorter block: a partial tile
-      if (lane < (sc_words & 15u)) sc.bitmap[sc_word0 + (sc_words & ~15u) + lane] = sc_myword;
+      const bool mine = lane < (sc_words & 15u);
+      if (sc.and_existing) {
+        if (mine) sc_myword &= sc.bitmap[sc_word0 + (sc_words & ~15u) + lane];
+        uint32_t c = mine ? (uint32_t)__builtin_popcountll(sc_myword) : 0u;
+        for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        sc_tile_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      }
+      if (mine) sc.bitmap[sc_word0 + (sc_words & ~15u) + lane] = sc_myword;
       if (lane == 0u) sc.counts[(sc_word0 + sc_words) >> 4] = sc_tile_count;
     }
 #ifdef DFDB_LZ4_PROF
@@ -890,6 +945,31 @@ void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, con
   if (index && index_mode == 2) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
   else if (index && index_mode == 1) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
   else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, nullptr);
+}
+
+// the history-ring forms (HIST): one workgroup = one wave = one 64-KB ring for the life of the launch; blocks by ticket
+size_t lz4_hist_scratch_bytes(int waves) { return 256 + (size_t)waves * kHistStride + 256; }
+int lz4_hist_default_waves(int compute_units) { return compute_units * 4 * 6; }      // 4 SIMDs x the 6 waves this kernel's 79 VGPRs / 5.9 KB of LDS allow
+void launch_lz4_decode_hist(hipStream_t s, const uint8_t* src, uint8_t* scratch, int waves, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan* scp,
+                            uint32_t* index, int index_mode) {
+  if (nblocks <= 0) return;
+  if (waves > nblocks) waves = nblocks;
+  if (waves < 1) waves = 1;
+  (void)hipMemsetAsync(scratch, 0, 4, s);
+  LzScan sc = scp ? *scp : LzScan{};
+  sc.ticket = (uint32_t*)scratch;
+  uint8_t* rings = scratch + 256;
+  const dim3 g((unsigned)waves), b(64);
+  if (!index) index_mode = 0;
+  if (scp) {
+    if (index_mode == 2) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 2, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, index);
+    else if (index_mode == 1) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 1, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, index);
+    else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 0, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, nullptr);
+  } else {
+    if (index_mode == 2) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 2, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, index);
+    else if (index_mode == 1) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 1, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, index);
+    else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 0, 1>), g, b, 0, s, src, rings, blocks, nblocks, status, sc, nullptr);
+  }
 }
 
 // ---------------------------------------------------------------- K8: Union{T,Missing} bodies

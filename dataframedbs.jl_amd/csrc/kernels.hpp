@@ -184,8 +184,19 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
                        uint32_t* index = nullptr, int index_mode = 0 /* 1: record where the sequences start (one bit per byte of src, zeroed by the caller), 2: decode with it */);
 bool lz4_decode_takes_index(int32_t nblocks, int pipe);
 // K7 fused with the first predicate of a scan (decode -> scan fusion): 8-byte columns whose blocks start on 1024-row tiles
-struct LzScan { uint64_t* bitmap; uint32_t* counts; uint64_t cbits; int32_t dtype; int32_t op; };
+// op2 >= 0: the interval `col OP c & col OP2 c2`; and_existing: the mask already holds survivors — words are AND-ed into it and a block none of whose tiles
+// kept a row is not decoded at all; ticket: the history-ring form's block counter (set by its launcher)
+struct LzScan { uint64_t* bitmap; uint32_t* counts; uint64_t cbits; int32_t dtype; int32_t op; int32_t op2 = -1; int32_t and_existing = 0; uint64_t cbits2 = 0; uint32_t* ticket = nullptr; };
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc,
+                            uint32_t* index = nullptr, int index_mode = 0);
+
+// K7 without a decoded column (round 5): what leaves the decoder's LDS ring goes to a 64-KB history ring per resident wave inside `scratch`
+// (lz4_hist_scratch_bytes(waves) bytes: a ticket word, then the rings) — all an LZ4 match can reach — never to a column array.  sc != nullptr: the predicate
+// term is evaluated on the way (bitmap + tile counts are the only output; 8-byte columns whose blocks start on 1024-row tiles); sc == nullptr: a validating
+// decode (statuses, and the sequence-start index when index_mode = 1).  waves: workgroups launched = rings used (0: lz4_hist_default_waves(device CUs)).
+size_t lz4_hist_scratch_bytes(int waves);
+int lz4_hist_default_waves(int compute_units);
+void launch_lz4_decode_hist(hipStream_t s, const uint8_t* src, uint8_t* scratch, int waves, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan* sc,
                             uint32_t* index = nullptr, int index_mode = 0);
 
 }  // namespace dfdb

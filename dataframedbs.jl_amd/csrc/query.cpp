@@ -230,10 +230,19 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
 
 static uint64_t splitmix64_host(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
 
-static const Column& need_resident(const dfdb_table* t, int ordinal) {
-  const Column& c = t->cols[(size_t)ordinal];
+// (a compressed-only column — keep_compressed = 2 — that reaches a consumer through here gets a whole-column decode for the ABI call in progress:
+//  table.cpp column_data; the paths that need none — K7's fused scan, the survivors' arena of the gathers — do not come through here)
+static const Column& need_resident(dfdb_table* t, int ordinal) {
+  Column& c = t->cols[(size_t)ordinal];
   if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  if (c.comp_only) (void)column_data(t, c);
   return c;
+}
+// can K7 itself evaluate this simple term over a compressed-only column (HIST + SCAN: decode and compare in one pass, nothing decoded is kept)?
+static bool comp_scannable(const dfdb_table* t, const ScanTerm& tm, int ord) {
+  const Column& c = t->cols[(size_t)ord];
+  return c.resident && c.comp_only && !c.data.p && tm.pre == 0 && (tm.dtype == DFDB_I64 || tm.dtype == DFDB_U64 || tm.dtype == DFDB_F64) && !dt_nullable(c.dtype) &&
+         t->block_size % kTileRows == 0;
 }
 
 static void raise_reached_errors(dfdb_query* q, int nstages);
@@ -321,6 +330,8 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   };
   struct MissTerm { const uint64_t* bits; bool negate; };
   std::vector<MissTerm> miss;
+  struct CompTerm { ScanTerm tm; int ord; };
+  std::vector<CompTerm> comp_terms;
   auto match_missing = [&](const Node& n, MissTerm& out) {
     const Node* m = &n; bool neg = false;
     if (m->op == DFIR_NOT && m->a) { m = m->a.get(); neg = true; }
@@ -346,6 +357,13 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       }
     }
     if ((c->op == DFIR_OR || c->op == DFIR_IN_SET) && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
+    if (match_simple_term(*c, *t, tm, ord) && comp_scannable(t, tm, ord)) {
+      // a compressed-only column: the decoder evaluates the term (a second comparison of the same column folds into an interval there too)
+      bool folded = false;
+      for (CompTerm& ct : comp_terms) if (ct.ord == ord && ct.tm.op2 < 0 && ct.tm.dtype == tm.dtype) { ct.tm.op2 = tm.op; ct.tm.cbits2 = tm.cbits; folded = true; break; }
+      if (!folded) comp_terms.push_back(CompTerm{tm, ord});
+      continue;
+    }
     if (match_simple_term(*c, *t, tm, ord)) {
       tm.col = need_resident(t, ord).data.p;
       // a second comparison of a column the current batch already compares folds into that term as an interval: `65 > x > 34`
@@ -425,6 +443,22 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   for (const ScanTerms& ob : or_batches) {
     LaunchTimer lt(ctx, "scan_terms");
     launch_scan_terms(s, ob, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have, 0, nullptr);
+    have = true;
+  }
+  // compressed-only columns: one K7 launch per term — every block decoded into the waves' history rings, the comparison applied to the bytes as they leave
+  // the LDS ring, bitmap + tile counts the only output.  From the second mask on the words are AND-ed in and a block without a survivor
+  // is not decoded at all (blocksiterator.jl:111-113 at block granularity).
+  for (const CompTerm& ct : comp_terms) {
+    Column& fc = t->cols[(size_t)ct.ord];
+    LzScan sc{q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), ct.tm.cbits, ct.tm.dtype, ct.tm.op};
+    sc.op2 = ct.tm.op2; sc.cbits2 = ct.tm.cbits2; sc.and_existing = have ? (ctx_option(ctx, "lz4_hist_skip", 1) != 0 ? 1 : 2) : 0;
+    int waves = 0; uint8_t* scratch = ctx_hist_scratch(ctx, &waves);
+    const int imode = column_lz4_index(ctx, fc, true);
+    LaunchTimer lt(ctx, "lz4_decode_scan_hist");
+    prof_note(ctx, imode == 2 ? "lz4_decode_scan_hist.indexed" : imode == 1 ? "lz4_decode_scan_hist.recording" : "lz4_decode_scan_hist.plain");
+    launch_lz4_decode_hist(s, fc.comp.as<uint8_t>(), scratch, waves, fc.comp_blocks.as<Lz4Block>(), (int32_t)fc.comp_nblocks, fc.comp_status.as<int32_t>(), &sc,
+                           fc.comp_index.as<uint32_t>(), imode);
+    if (std::find(q->comp_scanned.begin(), q->comp_scanned.end(), ct.ord) == q->comp_scanned.end()) q->comp_scanned.push_back(ct.ord);
     have = true;
   }
   // The launch that produces the query's final mask can do more with its LAST term (k_scan_terms EXTRA):
@@ -676,6 +710,8 @@ void query_execute(dfdb_query* q, int nstages) {
   if (nstages < 0 || nstages > (int)q->stages.size()) nstages = (int)q->stages.size();
   q->count = -1; q->prefix_valid = false; q->executed_stages = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
   q->decoded_col = -1;
+  q->comp_scanned.clear();
+  for (auto& a : q->arenas) a.second.valid = false;      // the survivors' blocks of the previous selection
   q->gr_state = 0;             // a pending groupreduce belongs to the selection that is being replaced: its fetch must not restore the old one over this
   q->err_row[0] = q->err_row[1] = ~0ull;
   // A range-like stage that is EMPTY (an empty range, an empty index vector) finishes the reference's iteration before the first block is read:
@@ -727,7 +763,7 @@ int64_t query_count(dfdb_query* q, int nstages);
 // dfdb_table_decode_status, as include/dfdb.h says.
 static void ensure_executed_checked(dfdb_query* q) {
   ensure_executed(q);
-  if (q->decoded_col >= 0) (void)query_count(q, -1);
+  if (q->decoded_col >= 0 || !q->comp_scanned.empty()) (void)query_count(q, -1);
 }
 
 int64_t query_count(dfdb_query* q, int nstages) {
@@ -742,6 +778,22 @@ int64_t query_count(dfdb_query* q, int nstages) {
   // up on (a damaged copy, or err 9 — a sequence-start index that is not this stream's) leaves stale mask words, tile counts and column bytes
   // behind.  The statuses are read here, where the host waits for the count anyway.  A bad block drops the index
   // (table_decode_status); ONE more execution decodes by parsing and records a new one; bad again -> the blocks themselves are damaged.
+  if (!q->comp_scanned.empty()) {
+    // the same for the compressed-only columns this execution decoded inside its scan (several terms may have: each column's statuses are its last launch's)
+    const std::vector<int> cols = q->comp_scanned;
+    bool again = false;
+    for (int col : cols) again = table_decode_status(q->t, col) > 0 || again;
+    if (again) {
+      query_execute(q, nstages < 0 ? -1 : nstages);
+      for (int col : q->comp_scanned) {
+        const int64_t bad = table_decode_status(q->t, col);
+        if (bad > 0) { q->executed_stages = -1; fail(DFDB_ERR_FORMAT, "column %s: %lld of its resident LZ4 blocks do not decode", q->t->cols[(size_t)col].name.c_str(), (long long)bad); }
+      }
+      HIP_CHECK(hipMemcpyAsync(ctx->pinned_scalar, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+      stream_wait(ctx);
+      n = ctx->pinned_scalar[0];
+    }
+  }
   if (q->decoded_col >= 0) {
     const int col = q->decoded_col;
     if (table_decode_status(q->t, col) > 0) {
@@ -789,6 +841,60 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
     launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), q->tmp_b.as<int64_t>(), t->nrows, t->row_base, m, store, gcap); }
   HIP_CHECK(hipMemcpyAsync(out, q->tmp_b.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
   stream_wait(q->t->ctx);
+}
+
+// ---------------------------------------------------------------- compressed-only projection columns
+// The source pointer of a gather over a fixed-width column.  A compressed-only column (keep_compressed = 2) has no decoded array: the blocks of the current
+// selection that KEPT A ROW are decoded into an arena this query owns — at their natural offsets inside the span [first such block, last such block], so the
+// gather kernels address it like the column itself through a shifted base — and the others are never touched (blocksiterator.jl:111-113: a block with an
+// empty selection skips its projection columns).  Synchronises (the survivors per block are read on the host, like the reference's loop reads them).
+static const void* gather_source(dfdb_query* q, int ord) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  Column& c = t->cols[(size_t)ord];
+  if (!c.comp_only || c.data.p) return c.data.p;
+  const int w = dt_width(c.dtype);
+  dfdb_query::Arena& a = q->arenas[ord];
+  if (!a.valid) {
+    std::vector<int64_t> counts;
+    query_block_counts(q, t->block_size, counts);
+    int64_t first = -1, last = -1;
+    std::vector<Lz4Block> sub;
+    for (int64_t b = 0; b < (int64_t)counts.size() && b < c.comp_nblocks; b++) if (counts[(size_t)b] > 0) { if (first < 0) first = b; last = b; }
+    a.first_row = first < 0 ? 0 : first * t->block_size; a.nblocks = 0;
+    if (first >= 0) {
+      const int64_t base_off = c.comp_blocks_host[(size_t)first].dst_off;
+      for (int64_t b = first; b <= last; b++) if (counts[(size_t)b] > 0) { Lz4Block x = c.comp_blocks_host[(size_t)b]; x.dst_off -= base_off; sub.push_back(x); }
+      const Lz4Block& lb = c.comp_blocks_host[(size_t)last];
+      a.buf.ensure((size_t)(lb.dst_off - base_off) + (size_t)lb.dst_len + 256);
+      a.blocks.ensure(sub.size() * sizeof(Lz4Block)); a.status.ensure(sub.size() * 4);
+      HIP_CHECK(hipMemcpyAsync(a.blocks.p, sub.data(), sub.size() * sizeof(Lz4Block), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(a.status.p, 0, sub.size() * 4, s));
+      const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
+      const int mode = column_lz4_index(ctx, c, lz4_decode_takes_index((int32_t)sub.size(), pipe));
+      { LaunchTimer lt(ctx, "lz4_decode");
+        prof_note(ctx, "lz4_decode.survivors");
+        launch_lz4_decode(s, c.comp.as<uint8_t>(), a.buf.as<uint8_t>(), a.blocks.as<Lz4Block>(), (int32_t)sub.size(), a.status.as<int32_t>(), pipe, c.comp_index.as<uint32_t>(),
+                          mode == 1 ? 0 : mode); }      // (a subset of the blocks cannot RECORD the column's index)
+      if (mode == 1) c.comp_index_state = 0;
+      std::vector<int32_t> st(sub.size());
+      HIP_CHECK(hipMemcpyAsync(st.data(), a.status.p, st.size() * 4, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));            // (also: `sub` is pageable host memory)
+      int64_t bad = 0; for (int32_t v : st) bad += v != 0;
+      if (bad && mode == 2) {                        // the index may be what is damaged: once more by parsing
+        HIP_CHECK(hipMemsetAsync(a.status.p, 0, sub.size() * 4, s));
+        launch_lz4_decode(s, c.comp.as<uint8_t>(), a.buf.as<uint8_t>(), a.blocks.as<Lz4Block>(), (int32_t)sub.size(), a.status.as<int32_t>(), pipe, nullptr, 0);
+        HIP_CHECK(hipMemcpyAsync(st.data(), a.status.p, st.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        bad = 0; for (int32_t v : st) bad += v != 0;
+        if (!bad) { c.comp_index.release(); c.comp_index_state = 0; }
+      }
+      if (bad) fail(DFDB_ERR_FORMAT, "column %s: %lld of its resident LZ4 blocks do not decode", c.name.c_str(), (long long)bad);
+      a.nblocks = (int64_t)sub.size();
+    } else a.buf.ensure(256);
+    a.valid = true;
+  }
+  // row r of the column lives at arena byte (r - first_row) * w: hand the kernels the base that makes `src + r * w` land there (never dereferenced below first_row)
+  return (const void*)(a.buf.as<uint8_t>() - (intptr_t)a.first_row * w);
 }
 
 // ---------------------------------------------------------------- materialize
@@ -857,7 +963,13 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
   if (cnt == 0) return;
   if (!o.data) fail(DFDB_ERR_ARGUMENT, "output column %d has no data buffer", p);
   if (e.op == DFIR_COL) {   // ColProjExec: buffer .= data[name][range] (projection.jl:130-133)
-    const Column& col = need_resident(t, e.col);
+    const void* gsrc = nullptr;
+    if (t->cols[(size_t)e.col].comp_only && !dt_nullable(e.dtype) && dt_base(e.dtype) != DFDB_STRING) {
+      if (!t->cols[(size_t)e.col].resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", t->cols[(size_t)e.col].name.c_str());
+      gsrc = gather_source(q, e.col);        // compressed-only: the blocks with survivors, decoded for this query (no whole-column decode)
+    }
+    const Column& col = gsrc ? t->cols[(size_t)e.col] : need_resident(t, e.col);
+    if (!gsrc) gsrc = col.data.p;
     if (dt_base(e.dtype) == DFDB_STRING) {   // FlatStringsVector gather (FlatStringsVectors.jl:136-157)
       if (q->const_str_col == e.col && q->executed_stages == (int)q->stages.size()) {   // every selected row holds q->const_str (run_predicate)
         const int64_t plen = (int64_t)q->const_str.size(), total = cnt * plen;
@@ -912,7 +1024,7 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
       launch_compact_captured(s, (q->cap_col == e.col ? q->cap_buf : q->cap_buf2).as<uint64_t>(), q->prefix.as<uint64_t>(), (uint64_t*)dst, t->nrows, cnt);
     } else {
       LaunchTimer lt(ctx, "gather");
-      launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), col.data.p, dst, w, t->nrows, cnt);
+      launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), gsrc, dst, w, t->nrows, cnt);
     }
     if (!dev) HIP_CHECK(hipMemcpyAsync(o.data, dst, (size_t)cnt * w, hipMemcpyDeviceToHost, s));
     if (dt_nullable(e.dtype) && o.missing) {
@@ -937,7 +1049,7 @@ static void materialize_col(dfdb_query* q, int32_t p, dfdb_outcol& o, int64_t cn
         launch_compact_captured_transform(s, (q->cap_col == tcol->col ? q->cap_buf : q->cap_buf2).as<uint64_t>(), q->prefix.as<uint64_t>(), dt_base(sc.dtype), tf, (uint64_t*)dst, t->nrows, cnt);
       } else {
         LaunchTimer lt(ctx, "gather");
-        launch_gather_transform(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), sc.data.p, dt_base(sc.dtype), tf, dst, t->nrows, cnt);
+        launch_gather_transform(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), gather_source(q, tcol->col), dt_base(sc.dtype), tf, dst, t->nrows, cnt);
       }
     } else
     run_interp_project(q, e, dst, cnt, mdst);

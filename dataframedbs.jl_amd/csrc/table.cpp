@@ -279,9 +279,12 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
 
   c.nrows = nrows;
   uint8_t* decode_dst;
+  // ctx option keep_compressed = 2: a plain fixed-width column stays COMPRESSED-ONLY — its blocks are validated (and their sequence starts recorded) by a
+  // decode whose output goes to the per-wave history rings and nowhere else; there is no decoded array, now or later (k_decode.hip HIST)
+  const bool comp_only = !is_str && !is_null && nb && !row_pos && !t->keep_load_scratch && ctx_option(ctx, "keep_compressed", 0) == 2;
   if (!is_str && !is_null) {   // plain fixed width: decode straight into the column (no read!(io, v) copy: blocks.jl:43)
-    c.data.ensure((size_t)nrows * w + 256);
-    decode_dst = c.data.as<uint8_t>();
+    if (comp_only) { c.data.release(); decode_dst = nullptr; }
+    else { c.data.ensure((size_t)nrows * w + 256); decode_dst = c.data.as<uint8_t>(); }
     for (int64_t i = 0; i < nb; i++) blocks[i].dst_off = (int64_t)w * row_off[i];
   } else {
     bodies.ensure((size_t)bo + 64);
@@ -292,6 +295,20 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     dstatus.ensure(4 * (size_t)nb);
     HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)nb, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(dstatus.p, 0, 4 * (size_t)nb, s));
+    if (comp_only) {
+      // (the index this launch records is the column's: comp / comp_index are set up here, ahead of the move below)
+      if (c.comp.p || c.comp_index.p) { HIP_CHECK(hipStreamSynchronize(s)); c.comp_index.release(); }
+      c.comp_index_state = 0;
+      uint32_t* idx = nullptr;
+      if (ctx_option(ctx, "lz4_index", 1) != 0) {
+        try { c.comp_index.ensure((staged.bytes + 7) / 8 + 1024); idx = c.comp_index.as<uint32_t>(); HIP_CHECK(hipMemsetAsync(c.comp_index.p, 0, c.comp_index.bytes, s)); }
+        catch (const Error&) { (void)hipGetLastError(); idx = nullptr; }
+      }
+      int waves = 0; uint8_t* scratch = ctx_hist_scratch(ctx, &waves);
+      LaunchTimer lt(ctx, "lz4_decode_hist");
+      prof_note(ctx, idx ? "lz4_decode_hist.recording" : "lz4_decode_hist.plain");
+      launch_lz4_decode_hist(s, staged.as<uint8_t>(), scratch, waves, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>(), nullptr, idx, idx ? 1 : 0);
+    } else
     { LaunchTimer lt(ctx, "lz4_decode"); launch_lz4_decode(s, staged.as<uint8_t>(), decode_dst, dblocks.as<Lz4Block>(), (int32_t)nb, dstatus.as<int32_t>(), (int)ctx_option(ctx, "lz4_pipeline", -1)); }
     std::vector<int32_t> st((size_t)nb);
     HIP_CHECK(hipMemcpyAsync(st.data(), dstatus.p, 4 * (size_t)nb, hipMemcpyDeviceToHost, s));
@@ -332,13 +349,17 @@ static void decode_staged(dfdb_table* t, Column& c, const BlockHdr* hs, int64_t 
     if (const int64_t dn = ctx_option(ctx, "string_dictionary", 0)) table_build_dictionary(t, (int32_t)(&c - t->cols.data()), dn);
   // what an earlier load of this column kept is stale now, whatever this load keeps (a reload with keep_compressed = 0 left the old
   // descriptors behind and dfdb_table_decode_resident / decode_on_scan would have decoded them into the new array)
+  DevBuf fresh_index;
+  if (comp_only) fresh_index = std::move(c.comp_index);                        // (recorded by this very load: it stays)
   if (c.comp.p || c.comp_blocks.p || c.comp_status.p || c.comp_index.p) {      // (a stream slot, which never keeps anything, pays no drain here)
     HIP_CHECK(hipStreamSynchronize(s));
     c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release();
   }
-  c.comp_nblocks = 0; c.comp_index_state = 0;
+  c.comp_nblocks = 0; c.comp_index_state = 0; c.comp_only = false; c.transient = false; c.comp_blocks_host.clear();
   if (!is_str && !is_null && nb && ctx_option(ctx, "keep_compressed", 0) != 0) {   // the compressed blocks stay: dfdb_table_decode_resident
     c.comp = std::move(staged); c.comp_blocks = std::move(dblocks); c.comp_status = std::move(dstatus); c.comp_nblocks = nb;
+    c.comp_blocks_host = blocks;
+    if (comp_only) { c.comp_only = true; c.comp_index = std::move(fresh_index); c.comp_index_state = c.comp_index.p ? 1 : 0; }
   }
   if (!t->keep_load_scratch) { HIP_CHECK(hipStreamSynchronize(s)); staged.release(); bodies.release(); dblocks.release(); dstatus.release(); d_aux.release(); }
   if (stats) {   // SizeStats incl. the 24-byte header quirk (BlockStreams.jl:7,23)
@@ -447,6 +468,7 @@ void table_decode_resident(dfdb_table* t, int32_t ordinal) {
   if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
   Column& c = t->cols[(size_t)ordinal];
   if (!c.comp_nblocks) fail(DFDB_ERR_ARGUMENT, "column %s holds no compressed blocks (load it with option keep_compressed = 1)", c.name.c_str());
+  if (c.comp_only) fail(DFDB_ERR_ARGUMENT, "column %s is compressed-only (keep_compressed = 2): it has no decoded array to decode into", c.name.c_str());
   dfdb_ctx* ctx = t->ctx;
   for (dfdb_query* q : t->queries) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }
   const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
@@ -469,6 +491,55 @@ int64_t table_decode_status(dfdb_table* t, int32_t ordinal) {
   // a decode that went wrong may have been reading (or writing) the sequence-start index: drop it, the next decode parses for itself and records a new one
   if (bad > 0) { c.comp_index.release(); c.comp_index_state = 0; }
   return bad;
+}
+
+// ---- compressed-only columns (keep_compressed = 2)
+uint8_t* ctx_hist_scratch(dfdb_ctx* ctx, int* waves) {
+  int w = (int)ctx_option(ctx, "lz4_hist_waves", 0);
+  if (w <= 0) w = lz4_hist_default_waves(ctx->prop.multiProcessorCount);
+  if (w > 65536) w = 65536;
+  if (!ctx->hist.p || ctx->hist_waves != w) {
+    if (ctx->hist.p) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->hist.release();
+    ctx->hist.ensure(lz4_hist_scratch_bytes(w));
+    ctx->hist_waves = w;
+  }
+  if (waves) *waves = w;
+  return ctx->hist.as<uint8_t>();
+}
+// the decoded array of a fixed-width column; a compressed-only one is decoded whole, now, for the ABI call in progress (the statuses of that decode are
+// read by table_drop_transient, which every such call ends with)
+const void* column_data(dfdb_table* t, Column& c) {
+  if (!c.comp_only || c.data.p) return c.data.p;
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  c.data.ensure((size_t)c.nrows * (size_t)dt_width(c.dtype) + 256);
+  c.transient = true;
+  const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
+  const int mode = column_lz4_index(ctx, c, lz4_decode_takes_index((int32_t)c.comp_nblocks, pipe));
+  LaunchTimer lt(ctx, "lz4_decode");
+  prof_note(ctx, "lz4_decode.transient");
+  launch_lz4_decode(s, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), pipe,
+                    c.comp_index.as<uint32_t>(), mode);
+  return c.data.p;
+}
+void table_drop_transient(dfdb_table* t) {
+  bool any = false;
+  for (Column& c : t->cols) any = any || c.transient;
+  if (!any) return;
+  (void)hipStreamSynchronize(t->ctx->stream);                 // whatever the call launched over the transient arrays has to be done with them
+  for (Column& c : t->cols) if (c.transient) { c.data.release(); c.transient = false; }
+}
+void table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed) {
+  int64_t d = 0, k = 0;
+  auto one = [&](const Column& c) {
+    if (!c.transient) d += (int64_t)c.data.bytes;
+    d += (int64_t)c.bytes.bytes + (int64_t)c.tile_off.bytes + (int64_t)c.missing.bytes + (int64_t)c.dict_codes.bytes + (int64_t)c.dict_bytes.bytes;
+    k += (int64_t)c.comp.bytes + (int64_t)c.comp_blocks.bytes + (int64_t)c.comp_status.bytes + (int64_t)c.comp_index.bytes;
+  };
+  if (ordinal < 0) for (const Column& c : t->cols) one(c);
+  else { if ((size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal); one(t->cols[(size_t)ordinal]); }
+  if (decoded) *decoded = d;
+  if (compressed) *compressed = k;
 }
 
 // The sequence-start index of a column's resident LZ4 blocks (k_decode.hip INDEX): the first decode that can take it records it, the later ones decode with it.

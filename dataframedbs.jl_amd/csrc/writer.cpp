@@ -100,6 +100,7 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
   if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
   if (t->block_first != 0) fail(DFDB_ERR_UNSUPPORTED, "a block-range shard cannot be saved as a whole column");
   dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  if (c.comp_only) (void)column_data(t, c);             // a compressed-only column is decoded for the duration of the save (dropped by the caller's TransientScope)
   NodeBind bind(ctx);                                   // bounce buffers and the threads that fill the file mapping on the GPU's NUMA node
   const int64_t B = t->block_size, nrows = c.nrows, nb = ceil_div(nrows, B);
   const int w = dt_width(c.dtype);

@@ -364,6 +364,12 @@ class DFTable:
         N.check(N.load().dfdb_table_decode_status(self._h, self.ordinal(column), C.byref(bad)))
         return bad.value
 
+    def resident_bytes(self, column=None) -> dict:
+        """HBM bytes held right now by one column (or the whole table): {"decoded": ..., "compressed": ...} — dfdb_table_resident_bytes"""
+        d, k = C.c_int64(), C.c_int64()
+        N.check(N.load().dfdb_table_resident_bytes(self._h, -1 if column is None else self.ordinal(column), C.byref(d), C.byref(k)))
+        return {"decoded": d.value, "compressed": k.value}
+
     def read_probe(self, column: str, repeats: int = 5):
         """(best_ms, avg_ms) of K1's read stream alone over a resident 8-byte column: dfdb_table_read_probe"""
         best, avg = C.c_double(), C.c_double()

@@ -177,7 +177,16 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "decode_on_scan"  1 = a fresh-mask scan of one `col OP const` term over an 8-byte column that holds its LZ4 blocks (keep_compressed) decodes and
  *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array; with at most 2048 blocks
  *                     (the two-wave pipeline's range) it decodes with the pipeline and then scans the decoded array, which is shorter there (default 0)
- *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM (dfdb_table_decode_resident; default 0)
+ *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM beside the decoded array (dfdb_table_decode_resident; default 0).
+ *                     2 = COMPRESSED-ONLY: such a column holds its LZ4 blocks and their sequence-start index and NO decoded array — like the reference, whose
+ *                     iterator decodes every block into two reusable buffers and keeps nothing (BlockStreams.jl:9-15,101-119; "memory use is O(block)",
+ *                     docs/src/index.md:182,192).  At load the blocks are validated by a decode whose output goes to per-wave 64-KB history rings only
+ *                     (an LZ4 match reaches at most 65 535 bytes back inside its block).  Conjuncts `col OP const` (and intervals) over an 8-byte column are
+ *                     evaluated by the decoder itself, term by term — bitmap and tile counts are the only output; from the second mask on, blocks without a
+ *                     survivor are not decoded.  A projection gathers from the blocks that KEPT A ROW, decoded into an arena the query owns
+ *                     (blocksiterator.jl:111-113).  Every other consumer (interpreter programs, multi-column terms, aggregates, unique, save) gets a
+ *                     whole-column decode that lives for the one ABI call.  Nullable and String columns load as with 0.  dfdb_table_resident_bytes reports
+ *                     what a column holds.  "lz4_hist_waves" = history rings (= workgroups) of those decodes, 0 = 24 per compute unit (default)
  *   "group_force_exchange" 1 = a group's unique / groupreduce merge sends its records through the exchange (RCCL all-gather / the callbacks) even when one
  *                     process holds every shard and could merge them in place (default 0; what the one-GPU tests use to run the exchange code)
  *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
@@ -260,6 +269,10 @@ int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_bl
  * `repeats` (1 .. 64) launches back to back on the context's stream, each bracketed by HIP events: *best_ms / *avg_ms (either may be NULL).  bench.py prints
  * rows * 8 / best as `roofline.box_read_ceiling_GBps`: what this box and this allocation give the scan before it writes anything. */
 int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, double* best_ms, double* avg_ms);
+/* HBM bytes a column holds right now (ordinal < 0: the whole table): *decoded = its decoded arrays (values, string sizes / bytes / tile offsets, missing
+ * bitmap, dictionary codes), *compressed = its LZ4 blocks, their descriptors and statuses and the sequence-start index (ctx option "keep_compressed").
+ * A compressed-only column (keep_compressed = 2) reports decoded = 0.  Either pointer may be NULL.  (There is no Julia method this replaces.) */
+int32_t dfdb_table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed);
 /* Dictionary form of a resident, non-nullable String column with at most max_entries (<= 65535) distinct values: one 16-bit code per row and the
  * distinct strings once, kept BESIDE the FlatStringsVector form (the reference has no such form: docs/src/index.md lists dictionary encoding under
  * "Future plans").  From then on `col == / != / startswith / endswith "const"` is decided once per distinct string and becomes a bit-table lookup of
