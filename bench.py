@@ -240,7 +240,72 @@ def decode_scan_leg(dfdb, ctx, t, rows, steps, out_ptr, cap, cnt_ptr, sync):
                    "decoder) -> count scan -> K2 indices, per step; `unfused` = K7, then K1 over the decoded column.  The column's first resident decode recorded "
                    "where its LZ4 sequences start (one bit per compressed byte, ctx option lz4_index); these steps decode with that index, `without_index` without"}
     res["blocks_that_failed_to_decode"] = t2.decode_status("x")      # dfdb_table_decode_status: 0, or the figures above are not a decode
+    res["resident_GB"] = {k: v / 1e9 for k, v in t2.resident_bytes("x").items()}
     t2.close()
+    # ---- the same column COMPRESSED-ONLY (ctx option keep_compressed = 2; SURVEY.md section 8f-2 "without writing decoded blocks to HBM"): LZ4 blocks + the
+    # sequence-start index are all the column holds; the step decodes every block into the waves' 64-KB history rings with the predicate applied on the way
+    # (bitmap + tile counts the only output), then count scan + K2.  `materialize`: the same selection + [x] gathered out of the blocks that kept a row.
+    try:
+        d = tempfile.mkdtemp(prefix="dfdb_bench_", dir=base)
+        try:
+            t.save(os.path.join(d, "tb"))
+            ctx.set_option("keep_compressed", 2)
+            t3 = dfdb.open_table(os.path.join(d, "tb"), ctx=ctx, load=False)
+            t0 = time.perf_counter()
+            t3.load()
+            sync()
+            load_s = time.perf_counter() - t0
+        finally:
+            ctx.set_option("keep_compressed", 0)
+            shutil.rmtree(d, ignore_errors=True)
+        q3 = t3[("x", lambda x: x > THRESHOLD), dfdb.ALL]._query()
+        nsel4 = q3.count()
+
+        def step_arena():
+            q3.reset()
+            q3.indices_device(out_ptr, cap)
+            q3.count_device(cnt_ptr)
+        step_arena()
+        ctx.profile(True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_arena()
+        sync()
+        el_a = (time.perf_counter() - t0) / steps
+        nh, msh = ctx.profile_get("lz4_decode_scan_hist")
+        ctx.profile(False)
+        rb = t3.resident_bytes("x")
+        ms_h = msh / nh if nh else None
+        ar = {"rows_per_s": rows / el_a, "ms_per_step": el_a * 1e3, "selected": nsel4, "count_ok": nsel4 == nsel2, "lz4_decode_scan_hist_avg_ms": ms_h,
+              "decoded_GBps": rows * 8 / (ms_h * 1e-3) / 1e9 if ms_h else None, "resident_GB": (rb["decoded"] + rb["compressed"]) / 1e9,
+              "resident_decoded_GB": rb["decoded"] / 1e9, "load_seconds": load_s,
+              "history_rings_MB": ctx.device_info()["compute_units"] * 24 * 65600 / 1e6,
+              "what": "compressed-only column (keep_compressed = 2): K7 decodes every block into per-wave 64-KB history rings with the predicate applied on the way "
+                      "(no decoded column exists) -> count scan -> K2 indices, per step"}
+        import torch
+        ox = torch.empty(max(nsel4, 1), dtype=torch.int64, device="cuda")
+        from dfdb import _native as N
+        outs = (N.OutCol * 1)()
+        outs[0].data, outs[0].memkind = ox.data_ptr(), N.MEM_DEVICE
+        lib = N.load()
+
+        def step_mat():
+            q3.reset()
+            q3.execute()
+            N.check(lib.dfdb_materialize(q3._h, outs, 1))
+        step_mat()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(max(2, steps // 2)):
+            step_mat()
+        sync()
+        ar["materialize_x_ms_per_step"] = (time.perf_counter() - t0) / max(2, steps // 2) * 1e3
+        res["arena"] = ar
+        del ox
+        t3.close()
+    except Exception as e:
+        res["arena"] = {"error": f"{type(e).__name__}: {e}"}
     return res
 
 

@@ -297,6 +297,9 @@ int32_t dfdb_table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) 
 int32_t dfdb_table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats) {
   return guard([&] { NEED(t); NEED(file); TransientScope ts(t); table_save_column(t, ordinal, file, stats); });
 }
+int32_t dfdb_table_compress_column(dfdb_table* t, int32_t ordinal, int32_t mode, dfdb_sizestats* stats) {
+  return guard([&] { NEED(t); HIP_CHECK(hipSetDevice(t->ctx->device)); table_compress_column(t, ordinal, mode, stats); });
+}
 int32_t dfdb_table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed) {
   return guard([&] { NEED(t); table_resident_bytes(t, ordinal, decoded, compressed); });
 }

@@ -220,5 +220,6 @@ int32_t ctx_create_like(const dfdb_ctx* like, dfdb_ctx** out);   // c_api.cpp
 void ctx_destroy(dfdb_ctx* c);
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats);                       // writer.cpp
 void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_sizestats* stats);
+void table_compress_column(dfdb_table* t, int32_t ordinal, int32_t mode, dfdb_sizestats* stats);   // writer.cpp: resident -> compressed-resident (1) / compressed-only (2) in HBM
 void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p);       // add_column!(t, name, lazy column)
 }  // namespace dfdb

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           const bool have = g + lane * 8u + 8u <= upto;
           const uint64_t v = *(const uint64_t*)(ring + ((g + lane * 8u) & (kRing - 1)));      // (always inside the ring: only the ballot needs `have`)
           if (g + 512u <= upto) {
-            *(uint64_t*)(out + HO(g) + lane * 8u) = v;                                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
+            ((uint64_t*)(out + HO(g)))[lane] = v;                                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
             if (HIST && HO(g) == 0u && lane < 4u) *(uint64_t*)(out + kHistBytes + lane * 8u) = v;   // the lap's first 32 bytes again, behind the ring
           }
           bool r = have && lz_cmp8_sel(v, sc.cbits, sc.dtype, sc_sel);
@@ -273,12 +273,12 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           if ((sc_words & 15u) == 0u) {                            // a 1024-row tile is complete: one 128-byte line of bitmap + its count
             const int64_t w0 = sc_word0 + sc_words - 16u;
             if (sc.and_existing) {                                 // (wave-uniform) the words AND what the mask held; the count is theirs
-              if (lane < 16u) sc_myword &= sc.bitmap[w0 + lane];
+              if (lane < 16u) sc_myword &= (sc.bitmap + w0)[lane];
               uint32_t c = lane < 16u ? (uint32_t)__builtin_popcountll(sc_myword) : 0u;
               for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
               sc_tile_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             }
-            if (lane < 16u) sc.bitmap[w0 + lane] = sc_myword;
+            if (lane < 16u) (sc.bitmap + w0)[lane] = sc_myword;
             if (lane == 0u) sc.counts[w0 >> 4] = sc_tile_count;
             sc_tile_count = 0;
           }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
           // ---- phases 1-3a from the index: the start bits of the W windows, every start's position at its ordinal
           bits[lane & (kBatchBytes / 32 - 1)] = 0;
           const uint64_t gbit = (uint64_t)blk.src_off + ip;                 // the index bit of input position ip
-          if (gbit < ibase || gbit + 64u * W + 96u > ibase + 2048u) { ibase = gbit & ~31ull; iw = index[(ibase >> 5) + lane]; }
+          if (gbit < ibase || gbit + 64u * W + 96u > ibase + 2048u) { ibase = gbit & ~31ull; iw = (index + (ibase >> 5))[lane]; }
           const uint32_t o0 = (uint32_t)(gbit - ibase);
           // every lane fetches the dword that holds ITS bit (ds_bpermute out of the register window: no LDS memory, and the W fetches are in flight
           // together) — the scalar form (three v_readlane and a 64-bit funnel shift per window) cost ~25 scalar instructions and a VALU -> SGPR
@@ -909,6 +909,7 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
 // pipe: -1: by block count, 0: one wave per block, 1: two-wave pipeline (ctx option "lz4_pipeline", tools/bench_lz4)
 void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, int pipe, uint32_t* index, int index_mode) {
   if (nblocks <= 0) return;
+#ifndef DFDB_LZ4_HIST_ONLY      // (a build of the history-ring forms alone, for looking at their registers: not the library's)
   // latency-bound: give every block its own wave and let the CUs hold as many as they can
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
   // fewer blocks than the chip has wave slots: the two-wave pipeline shortens what matters then, a block's latency
@@ -934,6 +935,7 @@ void launch_lz4_decode(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz
     hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, index);
   else
     hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 0, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, LzScan{}, nullptr);
+#endif
 }
 // whether launch_lz4_decode would take (record or read) an index for this many blocks under this pipeline setting
 bool lz4_decode_takes_index(int32_t nblocks, int pipe) { (void)nblocks; return pipe != 10 && pipe != 15; }
@@ -941,10 +943,12 @@ bool lz4_decode_takes_index(int32_t nblocks, int pipe) { (void)nblocks; return p
 void launch_lz4_decode_scan(hipStream_t s, const uint8_t* src, uint8_t* dst, const Lz4Block* blocks, int32_t nblocks, int32_t* status, const LzScan& sc,
                             uint32_t* index, int index_mode) {
   if (nblocks <= 0) return;
+#ifndef DFDB_LZ4_HIST_ONLY
   int64_t g5 = nblocks; if (g5 > (1 << 20)) g5 = 1 << 20;
   if (index && index_mode == 2) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 2>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
   else if (index && index_mode == 1) hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32, 1>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, index);
   else hipLaunchKernelGGL((k_lz4_decode<1, 2048, 2048, 512, 4, 1, 0, 6, 32>), dim3((unsigned)g5), dim3(64), 0, s, src, dst, blocks, nblocks, status, sc, nullptr);
+#endif
 }
 
 // the history-ring forms (HIST): one workgroup = one wave = one 64-KB ring for the life of the launch; blocks by ticket

@@ -211,6 +211,84 @@ void table_save_column(dfdb_table* t, int32_t ordinal, const char* file, dfdb_si
   if (stats) *stats = st;
 }
 
+// A resident plain fixed-width column -> its COMPRESSED-ONLY (mode 2) or compressed-resident (mode 1) form without a file in between: the blocks are
+// encoded on the device exactly as table_save_column encodes them — the bytes a saved file would hold, 20-byte headers included — and stay in HBM
+// with their descriptors; mode 2 then releases the decoded array (what dfdb_table_load leaves behind under ctx option keep_compressed).
+void table_compress_column(dfdb_table* t, int32_t ordinal, int32_t mode, dfdb_sizestats* stats) {
+  if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", ordinal);
+  Column& c = t->cols[(size_t)ordinal];
+  if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
+  if (mode != 1 && mode != 2) fail(DFDB_ERR_ARGUMENT, "ArgumentError: mode 1 (keep the decoded array) or 2 (compressed-only)");
+  if (dt_base(c.dtype) == DFDB_STRING || dt_nullable(c.dtype)) fail(DFDB_ERR_UNSUPPORTED, "column %s: only plain fixed-width columns have a compressed-resident form", c.name.c_str());
+  if (c.comp_only && c.comp_nblocks) { if (stats) { stats->rows = c.nrows; stats->uncompressed = (int64_t)c.nrows * dt_width(c.dtype); stats->compressed = (int64_t)c.comp.bytes; } return; }
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int64_t B = t->block_size, nrows = c.nrows, nb = ceil_div(nrows, B);
+  const int w = dt_width(c.dtype);
+  if (nb == 0) fail(DFDB_ERR_ARGUMENT, "column %s has no rows", c.name.c_str());
+  HIP_CHECK(hipStreamSynchronize(s));
+  c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release();
+  c.comp_nblocks = 0; c.comp_index_state = 0; c.comp_blocks_host.clear();
+  DevBuf scratch, dblocks, dlens, dpos, image;
+  std::vector<Lz4Block> all((size_t)nb);
+  int64_t used = 0, b0 = 0;
+  set_lz4_enc_variant((int)ctx_option(ctx, "lz4_enc_variant", 1));
+  set_lz4_enc_near(ctx_option(ctx, "lz4_enc_near", 0));
+  while (b0 < nb) {
+    int64_t b1 = b0, co = 0;
+    std::vector<Lz4Block> blocks;
+    while (b1 < nb && (b1 == b0 || (b1 - b0) * B * w < kBatchBodyBytes)) {
+      const int64_t len = std::min(B, nrows - b1 * B) * w;
+      if (len > 0x7e000000LL) fail(DFDB_ERR_UNSUPPORTED, "block body larger than the LZ4 block limit");
+      Lz4Block x; x.src_off = b1 * B * w; x.src_len = (int32_t)len; x.dst_len = (int32_t)lz4_bound(len); x.dst_off = co;
+      co += round_up(lz4_bound(len), 16); blocks.push_back(x); b1++;
+    }
+    const int64_t n = b1 - b0;
+    scratch.ensure((size_t)co + 64); dblocks.ensure(sizeof(Lz4Block) * (size_t)n); dlens.ensure(4 * (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(dblocks.p, blocks.data(), sizeof(Lz4Block) * (size_t)n, hipMemcpyHostToDevice, s));
+    { LaunchTimer lt(ctx, "lz4_compress"); launch_lz4_compress(s, c.data.as<uint8_t>(), scratch.as<uint8_t>(), dblocks.as<Lz4Block>(), (int32_t)n, dlens.as<int32_t>()); }
+    std::vector<int32_t> lens((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(lens.data(), dlens.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int64_t> fpos((size_t)n + 1); std::vector<int32_t> brow((size_t)n);
+    int64_t fo = 0;
+    for (int64_t i = 0; i < n; i++) {
+      if (lens[(size_t)i] <= 0 || lens[(size_t)i] > blocks[(size_t)i].dst_len) fail(DFDB_ERR_DEVICE, "LZ4 compression failed in block %lld of column %s", (long long)(b0 + i), c.name.c_str());
+      fpos[(size_t)i] = fo; fo += 20 + lens[(size_t)i];
+      brow[(size_t)i] = (int32_t)std::min(B, nrows - (b0 + i) * B);
+      Lz4Block& a = all[(size_t)(b0 + i)];
+      a.src_off = used + fpos[(size_t)i] + 20; a.src_len = lens[(size_t)i]; a.dst_len = blocks[(size_t)i].src_len; a.dst_off = (b0 + i) * B * w;
+    }
+    fpos[(size_t)n] = fo;
+    // the column's image grows by this batch's piece (sized after the first batch's ratio, with room to spare; grown by copy if the guess was short)
+    if ((int64_t)image.bytes < used + fo + 64) {
+      const double done_frac = (double)b1 / (double)nb;
+      const int64_t guess = (int64_t)((double)(used + fo) / done_frac * 1.03) + (64 << 10);
+      DevBuf bigger; bigger.ensure((size_t)std::max<int64_t>(guess, used + fo + 64));
+      if (used) HIP_CHECK(hipMemcpyAsync(bigger.p, image.p, (size_t)used, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      image = std::move(bigger);
+    }
+    dpos.ensure(8 * ((size_t)n + 1) + 4 * (size_t)n);
+    int64_t* d_pos = dpos.as<int64_t>(); int32_t* d_rows = (int32_t*)(d_pos + n + 1);
+    HIP_CHECK(hipMemcpyAsync(d_pos, fpos.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_rows, brow.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    launch_pack_file_image(s, scratch.as<uint8_t>(), dblocks.as<Lz4Block>(), dlens.as<int32_t>(), d_pos, d_rows, (int32_t)n, image.as<uint8_t>() + used);
+    HIP_CHECK(hipStreamSynchronize(s));                 // (fpos / brow are pageable host memory)
+    used += fo; b0 = b1;
+  }
+  c.comp = std::move(image);
+  c.comp_blocks.ensure(sizeof(Lz4Block) * (size_t)nb); c.comp_status.ensure(4 * (size_t)nb);
+  HIP_CHECK(hipMemcpyAsync(c.comp_blocks.p, all.data(), sizeof(Lz4Block) * (size_t)nb, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemsetAsync(c.comp_status.p, 0, 4 * (size_t)nb, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  c.comp_nblocks = nb; c.comp_blocks_host = std::move(all);
+  if (mode == 2) {
+    for (dfdb_query* q : t->queries) { q->executed_stages = -1; q->count = -1; q->prefix_valid = false; }
+    c.data.release(); c.mask_pref.release(); c.mask_calibrated = false; c.comp_only = true; c.transient = false;
+  }
+  if (stats) { stats->rows = nrows; stats->uncompressed = nrows * w; stats->compressed = used; }
+}
+
 // make_table / create_table: meta.bin + one file per column (creators.jl:18-60, table_io.jl:9-19)
 void table_save(dfdb_table* t, const char* path, dfdb_sizestats* stats) {
   const std::string dir(path);

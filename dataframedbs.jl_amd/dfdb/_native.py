@@ -51,7 +51,7 @@ SYMBOLS = [
     "dfdb_ctx_timer_stop", "dfdb_ctx_set_option", "dfdb_ctx_profile_enable", "dfdb_ctx_profile_get",
     "dfdb_table_open", "dfdb_table_new", "dfdb_table_close", "dfdb_table_ncols", "dfdb_table_nrows", "dfdb_table_block_size",
     "dfdb_table_colinfo", "dfdb_table_find_column", "dfdb_table_load", "dfdb_table_load_image", "dfdb_table_add_column",
-    "dfdb_table_add_generated", "dfdb_table_decode_resident", "dfdb_table_decode_status", "dfdb_table_resident_bytes", "dfdb_table_read_probe", "dfdb_table_build_dictionary", "dfdb_table_set_row_base", "dfdb_table_set_logical_type", "dfdb_table_column_stats", "dfdb_table_add_from_query", "dfdb_table_save", "dfdb_table_save_column", "dfdb_query_hint_materialize", "dfdb_query_hint_aggregate", "dfdb_query_unique", "dfdb_query_groupreduce", "dfdb_query_groupreduce_fetch", "dfdb_stream_open", "dfdb_stream_next", "dfdb_stream_stats", "dfdb_stream_read_stats", "dfdb_stream_close",
+    "dfdb_table_add_generated", "dfdb_table_decode_resident", "dfdb_table_decode_status", "dfdb_table_resident_bytes", "dfdb_table_compress_column", "dfdb_table_read_probe", "dfdb_table_build_dictionary", "dfdb_table_set_row_base", "dfdb_table_set_logical_type", "dfdb_table_column_stats", "dfdb_table_add_from_query", "dfdb_table_save", "dfdb_table_save_column", "dfdb_query_hint_materialize", "dfdb_query_hint_aggregate", "dfdb_query_unique", "dfdb_query_groupreduce", "dfdb_query_groupreduce_fetch", "dfdb_stream_open", "dfdb_stream_next", "dfdb_stream_stats", "dfdb_stream_read_stats", "dfdb_stream_close",
     "dfdb_query_new", "dfdb_query_free", "dfdb_query_add_range", "dfdb_query_add_indices", "dfdb_query_add_integer",
     "dfdb_query_add_predicate", "dfdb_query_nstages", "dfdb_query_set_projection", "dfdb_query_ncols", "dfdb_query_coltype",
     "dfdb_expr_result_type", "dfdb_query_set_stage_base", "dfdb_query_count_prefix",
@@ -102,6 +102,7 @@ def load() -> C.CDLL:
         lib.dfdb_table_decode_status.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
         lib.dfdb_jit_cache_dir.argtypes = [C.c_char_p, C.c_size_t]
         lib.dfdb_selftest.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.c_int32]
+        lib.dfdb_table_compress_column.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SizeStats)]
         lib.dfdb_table_resident_bytes.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.dfdb_table_read_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.dfdb_table_build_dictionary.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]

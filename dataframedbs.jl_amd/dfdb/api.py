@@ -364,6 +364,12 @@ class DFTable:
         N.check(N.load().dfdb_table_decode_status(self._h, self.ordinal(column), C.byref(bad)))
         return bad.value
 
+    def compress_column(self, column: str, mode: int = 2) -> dict:
+        """a resident plain fixed-width column -> compressed-resident (mode 1) or compressed-only (mode 2) in HBM, encoded on the device: dfdb_table_compress_column"""
+        st = N.SizeStats()
+        N.check(N.load().dfdb_table_compress_column(self._h, self.ordinal(column), mode, C.byref(st)))
+        return dict(rows=st.rows, compressed=st.compressed, uncompressed=st.uncompressed)
+
     def resident_bytes(self, column=None) -> dict:
         """HBM bytes held right now by one column (or the whole table): {"decoded": ..., "compressed": ...} — dfdb_table_resident_bytes"""
         d, k = C.c_int64(), C.c_int64()

@@ -269,6 +269,12 @@ int32_t dfdb_table_decode_status(dfdb_table* t, int32_t ordinal, int64_t* bad_bl
  * `repeats` (1 .. 64) launches back to back on the context's stream, each bracketed by HIP events: *best_ms / *avg_ms (either may be NULL).  bench.py prints
  * rows * 8 / best as `roofline.box_read_ceiling_GBps`: what this box and this allocation give the scan before it writes anything. */
 int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, double* best_ms, double* avg_ms);
+/* A resident plain fixed-width column -> its compressed forms WITHOUT a file in between: every block of block_size rows is LZ4-encoded on the device
+ * (write_block_body + commit_block_write!, blocks.jl:2-7, BlockStreams.jl:36-60: the very bytes dfdb_table_save would write) and kept in HBM.
+ * mode 1 = beside the decoded array (what ctx option "keep_compressed" = 1 leaves after a load), mode 2 = COMPRESSED-ONLY: the decoded array is released and
+ * the column answers queries as described under "keep_compressed" = 2.  *stats (may be NULL): rows, body bytes, compressed bytes incl. the 20-byte headers.
+ * Nullable and String columns: DFDB_ERR_UNSUPPORTED.  A column that is compressed-only already is left as it is. */
+int32_t dfdb_table_compress_column(dfdb_table* t, int32_t ordinal, int32_t mode, dfdb_sizestats* stats);
 /* HBM bytes a column holds right now (ordinal < 0: the whole table): *decoded = its decoded arrays (values, string sizes / bytes / tile offsets, missing
  * bitmap, dictionary codes), *compressed = its LZ4 blocks, their descriptors and statuses and the sequence-start index (ctx option "keep_compressed").
  * A compressed-only column (keep_compressed = 2) reports decoded = 0.  Either pointer may be NULL.  (There is no Julia method this replaces.) */

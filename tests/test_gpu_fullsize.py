@@ -452,3 +452,51 @@ def test_writer_large_roundtrip(oracle, dfdb_mod, ctx, tmp_path):
     got = ov.materialize()[0]
     assert np.array_equal(got, oracle.gen_i64(SEED, n - 70_001, 70_001))
     t.close(); t2.close()
+
+
+def test_compressed_only_table_3e9_rows_answers_config3(oracle, dfdb_mod, ctx):
+    """SURVEY.md section 8f-2 at scale: a 3e9-row x 3-column table (72 GB decoded) held COMPRESSED-ONLY on one GPU — every column encoded on
+    the device into its LZ4 blocks, the decoded arrays released — answers config 3's query: the count, the projection [b, x] and the row indices equal the
+    oracle's on sampled 65 536-row blocks, every projected x satisfies the predicate, and no decoded column is resident before or after."""
+    import torch
+    from dfdb import _native as N
+    n = 3_000_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~150 GB of free HBM (one decoded column at a time beside 41 GB of blocks and 24 GB of results)")
+    dev = torch.device("cuda", 0)
+    t = dfdb_mod.DFTable.new()
+    comp = 0
+    for k, (name, gen) in enumerate((("a", dfdb_mod.GEN_I64_MOD1M), ("b", dfdb_mod.GEN_I64_MOD1M), ("x", dfdb_mod.GEN_F64_U2000))):
+        t.add_generated(name, gen, _seed(k), n)
+        st = t.compress_column(name, 2)                   # one decoded column at a time
+        assert st["rows"] == n
+        comp += st["compressed"]
+    rb = t.resident_bytes()
+    assert rb["decoded"] < 1 << 20 and comp <= rb["compressed"] < 0.8 * n * 24, rb
+    v = t[(t.a > 683_771) & (t.x < 632.456), ["b", "x"]]
+    q = v._query()
+    nsel = q.count()
+    assert abs(nsel / n - 0.1) < 2e-3
+    assert t.resident_bytes()["decoded"] < 1 << 20          # the two scans decoded into the history rings only
+    ob = torch.empty(nsel, dtype=torch.int64, device=dev)
+    ox = torch.empty(nsel, dtype=torch.float64, device=dev)
+    outs = (N.OutCol * 2)(_dev_outcol(N, ob), _dev_outcol(N, ox))
+    N.check(N.load().dfdb_materialize(q._h, outs, 2))
+    torch.cuda.synchronize()
+    assert bool((ox < 632.456).all())
+    didx = torch.empty(nsel, dtype=torch.int64, device=dev)
+    q.indices_device(didx.data_ptr(), nsel)
+    torch.cuda.synchronize()
+    assert bool((didx[1:] > didx[:-1]).all())
+    nb = -(-n // 65536)
+    for blk in (0, 1000, 17_123, nb // 2, nb - 2, nb - 1):   # sampled blocks vs the oracle's generators
+        r0 = blk * 65536
+        m_rows = min(65536, n - r0)
+        a = oracle.gen_i64(_seed(0), r0, m_rows); b = oracle.gen_i64(_seed(1), r0, m_rows); x = oracle.gen_f64(_seed(2), r0, m_rows)
+        m = (a > 683_771) & (x < 632.456)
+        lo = int(torch.searchsorted(didx, torch.tensor([r0 + 1], device=dev))[0]); hi = int(torch.searchsorted(didx, torch.tensor([r0 + m_rows + 1], device=dev))[0])
+        assert np.array_equal(didx[lo:hi].cpu().numpy(), np.nonzero(m)[0] + r0 + 1), blk
+        assert np.array_equal(ob[lo:hi].cpu().numpy(), b[m]) and np.array_equal(ox[lo:hi].cpu().numpy().view(np.uint64), x[m].view(np.uint64)), blk
+    del q
+    t.close()

@@ -192,3 +192,43 @@ def test_compressed_only_corrupt_resident_blocks_are_reported(oracle, dfdb_mod, 
             tb.close()
     open(f, "wb").write(bytes(raw))
     assert refused > 0 and refused + loaded == 40
+
+
+def test_compress_column_in_hbm_without_a_file(oracle, dfdb_mod, ctx):
+    """dfdb_table_compress_column: a resident column becomes compressed-resident (mode 1) or compressed-only (mode 2) on the device, with the bytes a saved file
+    would hold; every answer stays the oracle's, dfdb_table_decode_resident decodes them back (mode 1), nullable / String columns are refused."""
+    from dfdb import ir
+    dfdb = dfdb_mod
+    n = 150_001
+    cols = _cols(oracle, n, seed=9)
+    for bs in (4096, 65536):
+        ot = oracle.Table(block_size=bs)
+        for k, v in cols.items():
+            ot.add_column(k, v)
+        dt = dfdb.DFTable.new(block_size=bs, ctx=ctx)
+        for k, v in cols.items():
+            dt.add_column(k, v)
+        dt.add_column("s", ["a", "bb", None] * (n // 3) + ["z"] * (n - 3 * (n // 3)))
+        before = dt.resident_bytes()
+        st = dt.compress_column("a", 1)
+        assert st["rows"] == n and st["uncompressed"] == n * 8 and 0 < st["compressed"] < 1.1 * n * 8
+        assert dt.resident_bytes("a")["decoded"] >= n * 8 and dt.resident_bytes("a")["compressed"] >= st["compressed"]
+        dt.decode_resident("a")
+        assert dt.decode_status("a") == 0
+        assert np.array_equal(dfdb.materialize(dt[dfdb.ALL, ["a"]])["a"].to_numpy(), cols["a"])
+        for k in cols:
+            dt.compress_column(k, 2)
+        with pytest.raises(NotImplementedError):
+            dt.compress_column("s", 2)
+        after = dt.resident_bytes()
+        assert after["decoded"] < before["decoded"] - sum(v.nbytes for v in cols.values()) + 4096 * len(cols)
+        c = {k: i for i, k in enumerate(cols)}
+        for e in (ir.col(c["a"]) > 899_999, (ir.col(c["iota"]) > n // 2) & (ir.col(c["f"]) < 500.0), (ir.col(c["far"]) < 0) & (ir.col(c["i32"]) > 0),
+                  (ir.col(c["u"]) >= 2**63) & (ir.col(c["a"]) % 3 == 0)):
+            ov = ot.view().add_predicate(e.to_ir())
+            q = dfdb.selection(dt.view()[dfdb.ALL, list(cols)], e)._query()
+            assert q.count() == ov.nrow()
+            assert np.array_equal(q.indices(), ov.select_indices())
+            for g, w in zip(q.materialize(), ov.materialize()):
+                assert np.array_equal(g.view(np.uint8), w.view(np.uint8))
+        dt.close()
