@@ -186,7 +186,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     survivor are not decoded.  A projection gathers from the blocks that KEPT A ROW, decoded into an arena the query owns
  *                     (blocksiterator.jl:111-113).  Every other consumer (interpreter programs, multi-column terms, aggregates, unique, save) gets a
  *                     whole-column decode that lives for the one ABI call.  Nullable and String columns load as with 0.  dfdb_table_resident_bytes reports
- *                     what a column holds.  "lz4_hist_waves" = history rings (= workgroups) of those decodes, 0 = 24 per compute unit (default)
+ *                     what a column holds.  "lz4_hist_waves" = history rings (= workgroups) of those decodes, 0 = 24 per compute unit (default);
+ *                     "lz4_hist_skip" = 0: an AND-ed term decodes every block, also those no survivor is left in (default 1: skipped) — an A/B knob
  *   "group_force_exchange" 1 = a group's unique / groupreduce merge sends its records through the exchange (RCCL all-gather / the callbacks) even when one
  *                     process holds every shard and could merge them in place (default 0; what the one-GPU tests use to run the exchange code)
  *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
