@@ -49,7 +49,9 @@ struct Compiler {
     if ((int)col_ord.size() >= kMaxCols) fail(DFDB_ERR_UNSUPPORTED, "expression references more than %d columns", kMaxCols);
     const Column& c = t->cols[(size_t)ordinal];
     if (!c.resident) fail(DFDB_ERR_ARGUMENT, "column %s is not resident on the device (dfdb_table_load it first)", c.name.c_str());
-    IColDesc d{}; d.data = c.comp_only ? column_data(const_cast<dfdb_table*>(t), const_cast<Column&>(c)) : c.data.p;      // (compressed-only: a whole-column decode for this call) d.missing = c.missing.as<uint64_t>(); d.tile_off = (const int64_t*)c.tile_off.p; d.bytes = c.bytes.as<uint8_t>();
+    IColDesc d{};
+    d.data = c.comp_only ? column_data(const_cast<dfdb_table*>(t), const_cast<Column&>(c)) : c.data.p;      // (compressed-only: a whole-column decode for this call)
+    d.missing = c.missing.as<uint64_t>(); d.tile_off = (const int64_t*)c.tile_off.p; d.bytes = c.bytes.as<uint8_t>();
     d.dtype = c.dtype;
     { const int b = dt_base(c.dtype); d.wide = (b == DFDB_I64 || b == DFDB_U64 || b == DFDB_F64) ? 1 : 0; }
     prog.cols[col_ord.size()] = d;

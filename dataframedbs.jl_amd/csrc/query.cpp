@@ -357,14 +357,15 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       }
     }
     if ((c->op == DFIR_OR || c->op == DFIR_IN_SET) && match_or(*c, ob)) { or_batches.push_back(ob); continue; }
-    if (match_simple_term(*c, *t, tm, ord) && comp_scannable(t, tm, ord)) {
+    const bool simple = match_simple_term(*c, *t, tm, ord);      // (once: a failed match leaves `tm` half-written)
+    if (simple && comp_scannable(t, tm, ord)) {
       // a compressed-only column: the decoder evaluates the term (a second comparison of the same column folds into an interval there too)
       bool folded = false;
       for (CompTerm& ct : comp_terms) if (ct.ord == ord && ct.tm.op2 < 0 && ct.tm.dtype == tm.dtype) { ct.tm.op2 = tm.op; ct.tm.cbits2 = tm.cbits; folded = true; break; }
       if (!folded) comp_terms.push_back(CompTerm{tm, ord});
       continue;
     }
-    if (match_simple_term(*c, *t, tm, ord)) {
+    if (simple) {
       tm.col = need_resident(t, ord).data.p;
       // a second comparison of a column the current batch already compares folds into that term as an interval: `65 > x > 34`
       // (test/selection.jl:53) reads x once instead of twice

@@ -16,7 +16,7 @@ SCALE = int(os.environ.get("DFDB_FUZZ_SCALE", "1"))      # DFDB_FUZZ_SCALE=20 py
 SEED0 = int(os.environ.get("DFDB_FUZZ_SEED0", "0"))      # DFDB_FUZZ_SEED0=10000000: the same number of cases from fresh seeds (soaks)
 
 
-@pytest.fixture(scope="module", params=["flat strings", "string dictionary"])
+@pytest.fixture(scope="module", params=["flat strings", "string dictionary", "compressed-only"])
 def pair(oracle, dfdb_mod, request):
     rng = np.random.default_rng(2024)
     f64 = rng.normal(0, 50, N); f64[::101] = np.nan; f64[5::997] = np.inf; f64[7::991] = -0.0
@@ -41,9 +41,15 @@ def pair(oracle, dfdb_mod, request):
         # iteration gets that far (a later range stage that has seen its last element ends it: is_finished, selection.jl:192-196)
         "zl": np.where(np.arange(N) >= 2 * N // 3, rng.integers(0, 2, N), rng.integers(1, 5, N)).astype(np.int64),
     }
-    p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK)
+    # (the compressed-only variant takes blocks of whole 1024-row tiles, so that its simple 8-byte terms run inside the decoder: K7's history-ring scan)
+    p = Pair(oracle, dfdb_mod, cols, block_size=BLOCK if request.param != "compressed-only" or BLOCK % 1024 == 0 else 1024)
     if request.param == "string dictionary":             # K9: every string predicate and projection of `s` goes through the codes
         assert p.d.build_dictionary("s") == len(set(cols["s"]))
+    if request.param == "compressed-only":               # round 5: every plain fixed-width column holds its LZ4 blocks and nothing decoded (keep_compressed = 2's form,
+        for name, v in cols.items():                     # made in HBM by dfdb_table_compress_column): simple 8-byte terms run inside the decoder, gathers out of the
+            if isinstance(v, np.ndarray) and not isinstance(v, np.ma.MaskedArray):      # survivors' arena, everything else over a one-call decode
+                p.d.compress_column(name, 2)
+        assert p.d.resident_bytes("b")["decoded"] < 4096
     return p
 
 
