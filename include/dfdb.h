@@ -167,6 +167,11 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "io_threads"      concurrent preads a byte range of a column file is split into, 1 .. 64 (default 8; process-wide, read when a stream is opened)
  *   "stream_readers"  loaders of a stream that may READ (page cache -> pinned memory, queueing the copies) at the same time, the others wait for their
  *                     copies and their decode (default 3)
+ *   "load_progressive" 1 = dfdb_table_load decodes a plain fixed-width column batch by batch while the rest of its file is still being read and copied
+ *                     (K7 over the blocks that have arrived, behind their copies on the same stream; the 20-byte headers are walked on a side thread first so
+ *                     that the column array can be sized) instead of in one launch after the last byte (default 1); files under four pieces of "load_piece_kb"
+ *                     (default 65536 = 64 MB pieces through the pinned bounce buffers) load as before, "load_progressive_blocks" = blocks per batch (default 768)
+ *                     — the last two exist so that tests can drive the path with small files
  *   "numa_bind"       1 = the host threads that move file bytes (loads, streams, saves) run on the CPUs of the NUMA node the GPU hangs off, and the
  *                     pinned bounce buffers are allocated from there (default 1; the calling thread's own affinity is restored on return)
  *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next

@@ -232,3 +232,60 @@ def test_compress_column_in_hbm_without_a_file(oracle, dfdb_mod, ctx):
             for g, w in zip(q.materialize(), ov.materialize()):
                 assert np.array_equal(g.view(np.uint8), w.view(np.uint8))
         dt.close()
+
+
+def test_progressive_load_decodes_batches_behind_their_copies(oracle, dfdb_mod, ctx, tmp_path):
+    """dfdb_table_load of a plain fixed-width column decodes batch by batch on a side stream while the rest of the file is read (ctx option load_progressive):
+    same columns as one launch at the end — many small pieces and batches, a corrupt block in the middle, keep_compressed = 1 beside it, a second column
+    whose row count disagrees."""
+    dfdb = dfdb_mod
+    n, bs = 300_007, 4096
+    rng = np.random.default_rng(11)
+    cols = {"a": oracle.gen_i64(0x51, 0, n), "x": rng.random(n), "i32": rng.integers(-9, 9, n).astype(np.int32), "s": ["v%d" % (i % 13) for i in range(n)]}
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "t")
+    ot.save(path)
+    ctx.set_option("load_piece_kb", 64)                      # 64-KB pieces: the 1.2-MB files are ~20 pieces, batches of 5 blocks
+    ctx.set_option("load_progressive_blocks", 5)
+    ctx.profile(True)
+    try:
+        for keep in (0, 1):
+            ctx.set_option("keep_compressed", keep)
+            tb = dfdb.open_table(path)
+            for k in ("a", "x", "i32"):
+                assert np.array_equal(dfdb.materialize(tb[dfdb.ALL, [k]])[k].to_numpy().view(np.uint8), cols[k].view(np.uint8)), (keep, k)
+            assert list(dfdb.materialize(tb[dfdb.ALL, ["s"]])["s"]) == cols["s"]
+            if keep:
+                tb.decode_resident("a"); assert tb.decode_status("a") == 0
+                assert np.array_equal(dfdb.materialize(tb[dfdb.ALL, ["a"]])["a"].to_numpy(), cols["a"])
+            tb.close()
+        nprog, _ = ctx.profile_get("lz4_decode.progressive")
+        assert nprog >= 2 * 3 * 5, nprog                      # several batches per plain column and load
+        # a flipped byte inside a block body in the middle of the file: the load must fail like the one-launch form, not hand out a half-decoded column
+        f = os.path.join(path, [x for x in sorted(os.listdir(path)) if x.endswith(".bin") and x != "meta.bin"][0])
+        raw = open(f, "rb").read()
+        bad = bytearray(raw); pos = len(raw) // 2
+        outcomes = []
+        for prog in (1, 0):
+            ctx.set_option("load_progressive", prog)
+            res = []
+            for delta in range(0, 400, 37):
+                b2 = bytearray(raw); b2[pos + delta] ^= 0x5A
+                open(f, "wb").write(bytes(b2))
+                try:
+                    tb = dfdb.open_table(path)
+                    got = dfdb.materialize(tb[dfdb.ALL, ["a"]])["a"].to_numpy()
+                    res.append(("ok", bool(np.array_equal(got, cols["a"]))))
+                    tb.close()
+                except Exception as ex:
+                    res.append(("err", type(ex).__name__))
+            outcomes.append(res)
+        open(f, "wb").write(raw)
+        assert outcomes[0] == outcomes[1] and any(r[0] == "err" for r in outcomes[0]), outcomes
+        del bad
+    finally:
+        ctx.profile(False)
+        for k, v in (("load_piece_kb", 64 << 10), ("load_progressive_blocks", 768), ("load_progressive", 1), ("keep_compressed", 0)):
+            ctx.set_option(k, v)

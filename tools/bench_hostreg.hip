@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <thread>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,28 @@ int main(int argc, char** argv) {
     printf("T=%d threads register+copy+unregister 64-MB pieces: %.1f ms total (%.1f GB/s); per thread: register %.1f ms, unregister %.1f ms\n", T, t1 - t0, n / (t1 - t0) / 1e6, reg_ms[0], unreg_ms[0]);
     for (auto& s : st) (void)hipStreamDestroy(s);
     munmap(m, n);
+  }
+  // what a streamed scan's copies can reach: L loaders, each its own stream and its own pinned buffer, 32-MB pieces queued back to back (no host copy at all),
+  // then the same with R threads doing what the loaders' preads do (page cache -> another pinned buffer) beside the DMA
+  for (int cfg = 0; cfg < 9; cfg++) {
+    const int R = cfg < 3 ? (cfg == 0 ? 0 : cfg == 1 ? 8 : 24) : 0;
+    const int L = cfg < 3 ? 3 : (cfg == 3 ? 1 : cfg == 4 ? 2 : cfg == 5 ? 1 : cfg == 6 ? 3 : cfg == 7 ? 7 : 2);
+    const size_t piece = (cfg < 3 ? 32u : cfg == 3 ? 32u : cfg == 4 ? 32u : cfg == 5 ? 128u : cfg == 6 ? 128u : cfg == 7 ? 32u : 8u) << 20, per = n / L / piece * piece;
+    std::vector<void*> pb(L); std::vector<hipStream_t> st(L);
+    for (int k = 0; k < L; k++) { CK(hipHostMalloc(&pb[k], per, hipHostMallocDefault)); memset(pb[k], k + 1, per); CK(hipStreamCreate(&st[k])); }
+    std::atomic<bool> stop{false}; std::atomic<long> copied{0};
+    std::vector<std::thread> noise;
+    void* sink = nullptr; if (R) CK(hipHostMalloc(&sink, (size_t)R << 25, hipHostMallocDefault));
+    for (int r = 0; r < R; r++) noise.emplace_back([&, r] { char* d = (char*)sink + ((size_t)r << 25); size_t off = ((size_t)r << 25) % n; while (!stop) { ssize_t g = pread(fd, d, 1 << 25, off); if (g > 0) copied += g; off = (off + ((size_t)R << 25)) % (n - (1 << 25)); } });
+    double t0 = now();
+    for (int rep = 0; rep < 2; rep++)
+      for (size_t o = 0; o < per; o += piece) for (int k = 0; k < L; k++) (void)hipMemcpyAsync((char*)dev + k * per + o, (char*)pb[k] + o, piece, hipMemcpyHostToDevice, st[k]);
+    for (int k = 0; k < L; k++) (void)hipStreamSynchronize(st[k]);
+    double t1 = now();
+    stop = true; for (auto& t : noise) t.join();
+    printf("%d loaders x %zu-MB pieces on their own streams, %d pread threads beside them: %.1f GB/s of H2D (preads moved %.1f GB/s meanwhile)\n", L, piece >> 20, R, 2.0 * L * per / (t1 - t0) / 1e6, copied / (t1 - t0) / 1e6);
+    for (int k = 0; k < L; k++) { (void)hipHostFree(pb[k]); (void)hipStreamDestroy(st[k]); }
+    if (sink) (void)hipHostFree(sink);
   }
   // unregistered mapping straight into hipMemcpy (the runtime stages it)
   { void* m = mmap(nullptr, n, PROT_READ, MAP_SHARED, fd, 0); double t0 = now(); CK(hipMemcpy(dev, m, n, hipMemcpyHostToDevice)); double t1 = now(); printf("H2D from a plain mapping %.1f ms (%.1f GB/s)\n", t1 - t0, n / (t1 - t0) / 1e6); munmap(m, n); }
