@@ -87,6 +87,11 @@ struct Slot {
   bool has_chunk = false;          // tbl holds a decoded chunk the caller may be using
   int err_code = 0; std::string err_msg;
   uint8_t* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for the file bytes (DMA-able: the H2D copy is truly async)
+  // a whole-column chunk load goes through the first kRing pieces of `pin` in turn (round 5): a piece is read, queued for its copy, and reused once that copy
+  // has left — 96 MB that stay in the socket's last-level cache instead of a chunk-sized buffer the preads write to memory and the DMA reads back from there
+  static constexpr int kRing = 3;
+  hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr};
+  bool ring_used[kRing] = {false, false, false};
   std::vector<std::vector<BlockLoc>> locs;   // per required column: the chunk's blocks [b0, b1) (copied out of the shared index when the load is requested)
   bool pre_executed = false;       // the loader's evaluation of the selection IS the chunk's (no stage depends on earlier chunks, nothing raised): q keeps it
 };
@@ -131,6 +136,7 @@ struct dfdb_stream {
   // At most `max_readers` loaders READ (page cache -> pinned, queueing the copies) at a time; the others are waiting for their copies and their decode.
   // Without the limit the loaders run in lockstep — all reading (the host's memcpy bandwidth split five ways, PCIe waiting for pieces), then all
   // waiting for PCIe and K7 at once while nobody reads — and the caller gets its chunks in bursts: 42 GB/s of file bytes on 8 slots, measured.
+  int64_t piece_bytes = 64ll << 20;   // a whole-column chunk load reads and copies this much at a time (ctx option "stream_piece_mb")
   int max_readers = 3, readers = 0;
   std::set<int64_t> waiting_readers;   // first blocks of the chunks whose loaders wait for a turn: the EARLIEST chunk reads first (the caller consumes in order)
   dfdb_ctx* parent = nullptr; std::weak_ptr<int> parent_alive;   // where a closed stream parks (if that context still exists)
@@ -159,8 +165,10 @@ ReadTurn::~ReadTurn() {
   { std::lock_guard<std::mutex> lk(s->mu); s->readers--; }
   s->cv.notify_all();
 }
+void ring_drain(Slot* sl);
 void ensure_pin(Slot* sl, size_t need) {
   if (need <= sl->pin_cap) return;
+  ring_drain(sl);
   if (sl->pin) (void)hipHostFree(sl->pin);
   sl->pin = nullptr; sl->pin_cap = 0;
   HIP_CHECK(hipHostMalloc((void**)&sl->pin, need + need / 4, hipHostMallocDefault));
@@ -174,35 +182,44 @@ void note_read(dfdb_stream* s, size_t k, const dfdb_sizestats& st) {
 // every block of the chunk of required column k: file -> pinned -> HBM -> K7, the byte range read in 32-MB pieces (concurrent preads), each piece on
 // its way to HBM while the next is read — PCIe and the page-cache copy overlap inside the chunk, not only across the loaders (which fall into
 // lockstep: all reading, then all copying)
+void ring_drain(Slot* sl) {            // every copy out of the slot's pinned ring has left it (the buffer is about to be used differently)
+  for (int r = 0; r < Slot::kRing; r++) if (sl->ring_used[r]) { (void)hipEventSynchronize(sl->ring_ev[r]); sl->ring_used[r] = false; }
+}
 void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
   dfdb_table* tb = sl->tbl;
   const dfdb_stream::ColSrc& c = s->colsrc[k];
   const std::vector<BlockLoc>& ix = sl->locs[k];              // the chunk's blocks, chunk-relative
   const int64_t lo = ix.front().off, hi = ix.back().off + 20 + ix.back().compressed;
-  const size_t need = c.data_off + (size_t)(hi - lo);
-  ensure_pin(sl, need);
+  const int64_t kPiece = s->piece_bytes;
+  ensure_pin(sl, (size_t)(Slot::kRing * kPiece));
+  for (int r = 0; r < Slot::kRing; r++) if (!sl->ring_ev[r]) HIP_CHECK(hipEventCreateWithFlags(&sl->ring_ev[r], hipEventDisableTiming));
   auto t0 = std::chrono::steady_clock::now();
+  DevBuf& staged = tb->ld_staged;
+  staged.ensure((size_t)(hi - lo) + 64);
   {
     ReadTurn turn(s, sl->b0);
     t0 = std::chrono::steady_clock::now();
-    // the column header (re-validated by the loader), then the blocks
-    if (!read_file_range(c.file, sl->pin, 0, (int64_t)c.data_off)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-    const size_t comp_lo = c.data_off + 20;                    // the first block's body (load_from_image stages [comp_lo, need))
-    DevBuf& staged = tb->ld_staged;
-    staged.ensure(need - comp_lo + 64);
-    constexpr size_t kPiece = (size_t)32 << 20;
-    for (size_t a = c.data_off; a < need; a += kPiece) {
-      const size_t b = std::min(need, a + kPiece);
-      if (!read_file_range(c.file, sl->pin + a, lo + (int64_t)(a - c.data_off), lo + (int64_t)(b - c.data_off))) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
-      const size_t ca = std::max(a, comp_lo);
-      if (b > ca) HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (ca - comp_lo), sl->pin + ca, b - ca, hipMemcpyHostToDevice, sl->ctx->stream));
+    const int fd = open(c.file.c_str(), O_RDONLY);
+    if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
+    struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
+    int r = 0;
+    for (int64_t a = lo; a < hi; a += kPiece, r = (r + 1) % Slot::kRing) {
+      const int64_t e = std::min(hi, a + kPiece);
+      uint8_t* buf = sl->pin + (size_t)r * (size_t)kPiece;
+      if (sl->ring_used[r]) HIP_CHECK(hipEventSynchronize(sl->ring_ev[r]));   // its previous copy has left the buffer
+      if (!read_file_range_fd(fd, buf, a, e)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, sl->ctx->stream));
+      HIP_CHECK(hipEventRecord(sl->ring_ev[r], sl->ctx->stream)); sl->ring_used[r] = true;
     }
   }
   const auto t1 = std::chrono::steady_clock::now();
+  // the blocks as the index describes them (their headers were walked and checked against the other columns when the chunk was planned)
+  std::vector<StagedBlock> bl; bl.reserve(ix.size());
+  int64_t row = 0;
+  for (const BlockLoc& L : ix) { bl.push_back(StagedBlock{L.rows, L.origin, L.compressed, (L.off - lo) + 20, row}); row += L.rows; }
   dfdb_sizestats st{0, 0, 0};
-  tb->ld_prestaged = true;
-  try { table_load_image(tb, s->required[k], sl->pin, need, 0, -1, &st); } catch (...) { tb->ld_prestaged = false; throw; }
-  tb->ld_prestaged = false;
+  table_decode_staged_blocks(tb, s->required[k], bl.data(), (int64_t)bl.size(), row, &st);
+  st.rows = row;
   note_read(s, k, st);
   if (getenv("DFDB_STREAM_DEBUG")) {
     const auto t2 = std::chrono::steady_clock::now();
@@ -220,6 +237,7 @@ void load_column_blocks(dfdb_stream* s, Slot* sl, size_t k, const std::vector<ch
   const int64_t nb = sl->b1 - sl->b0;
   size_t need = 0;
   for (int64_t b = 0; b < nb; b++) if (keep[(size_t)b]) need += 20 + (size_t)ix[(size_t)b].compressed;
+  ring_drain(sl);                                            // (this path fills the pinned buffer from its start)
   ensure_pin(sl, need + 64);
   DevBuf& staged = tb->ld_staged;
   staged.ensure(need + 64);
@@ -487,6 +505,7 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   set_io_threads(ctx_option(t->ctx, "io_threads", 8));
   s->max_readers = (int)std::min<int64_t>(dfdb_stream::kLoaders, std::max<int64_t>(1, ctx_option(t->ctx, "stream_readers", 3)));
   s->readers = 0; s->waiting_readers.clear();
+  s->piece_bytes = std::min<int64_t>(512, std::max<int64_t>(1, ctx_option(t->ctx, "stream_piece_mb", 64))) << 20;
   s->nslots = (int)std::min<int64_t>(dfdb_stream::kSlots, std::max<int64_t>(2, ctx_option(t->ctx, "stream_slots", 8)));
   for (int i = 0; i < s->nslots; i++) {
     Slot& sl = s->slot[i];
@@ -584,6 +603,7 @@ static void stream_destroy(dfdb_stream* s) {
     if (sl.ctx) { release_slot(s, sl); }
     delete sl.q; sl.q = nullptr;
     delete sl.tbl; sl.tbl = nullptr;
+    for (int r = 0; r < Slot::kRing; r++) if (sl.ring_ev[r]) { (void)hipEventDestroy(sl.ring_ev[r]); sl.ring_ev[r] = nullptr; sl.ring_used[r] = false; }
     if (sl.pin) (void)hipHostFree(sl.pin);
     if (sl.ctx) ctx_destroy(sl.ctx);
   }
