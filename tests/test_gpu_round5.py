@@ -289,3 +289,43 @@ def test_progressive_load_decodes_batches_behind_their_copies(oracle, dfdb_mod, 
         ctx.profile(False)
         for k, v in (("load_piece_kb", 64 << 10), ("load_progressive_blocks", 768), ("load_progressive", 1), ("keep_compressed", 0)):
             ctx.set_option(k, v)
+
+
+def test_compressed_only_shards_of_a_group(oracle, dfdb_mod, ctx, tmp_path):
+    """block-range shards that are compressed-only (group option keep_compressed = 2 before the load): every answer of the sharded table — counts, indices,
+    materialised columns, sums, a range after a predicate (stage bases from the exchange) — equals the oracle's single table; nothing decoded stays resident"""
+    from dfdb import group as G, _native as N, ir
+    n, bs = 150_003, 4096
+    rng = np.random.default_rng(17)
+    cols = {"a": oracle.gen_i64(0xA1, 0, n), "x": rng.random(n) * 100.0, "i": np.arange(n, dtype=np.int64)}
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "t")
+    ot.save(path)
+    g = G.Group.create([0, 0, 0], N.EXCHANGE_HOST)
+    try:
+        g.set_option("keep_compressed", 2)
+        gt = G.GroupTable.open(g, path)
+        for l in range(3):
+            assert gt.shard(l).resident_bytes()["decoded"] < 4096 * 3
+        A, X, I = ir.col(0), ir.col(1), ir.col(2)
+        for stages in ([("pred", A > 700_000)], [("pred", (I > n // 3) & (X < 50.0))], [("pred", (A > 300_000) & (A < 600_000)), ("range", 5, 3, 20_000)],
+                       [("range", 100, 1, 140_000), ("pred", (X < 10.0) & (A % 2 == 0))]):
+            ov, gv = ot.view(), gt.view()
+            for st in stages:
+                if st[0] == "pred":
+                    ov.add_predicate(st[1].to_ir()); gv = dfdb_mod.selection(gv, st[1])
+                else:
+                    ov.add_range(st[1], st[2], st[3]); gv = dfdb_mod.selection(gv, dfdb_mod.jr(st[1], st[2], st[3]))
+            want = ov.select_indices()
+            assert G.gnrow(gv) == len(want) and np.array_equal(G.gindices(gv), want), stages
+            got, wm = G._gq(gv).materialize(), ov.materialize()
+            for a_, b_ in zip(got, wm):
+                assert np.array_equal(np.asarray(a_).view(np.uint8), np.asarray(b_).view(np.uint8)), stages
+            assert G.gaggregate(gv[dfdb_mod.ALL, "a"], N.AGG_SUM) == int(cols["a"][want - 1].sum())
+        for l in range(3):
+            assert gt.shard(l).resident_bytes()["decoded"] < 4096 * 3
+        gt.close()
+    finally:
+        g.close()
