@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""unique over 1e9 Int64 rows with 1e6 distinct values through the general hash table: the XCD-partitioned insert pass on / off"""
+"""unique over 1e9 Int64 rows with 1e6 distinct values through the general hash table: the XCD-partitioned insert pass on / off.
+(The record of an experiment: ctx option unique_xcd_parts and the kernel forms it selected were measured — 34-68 ms against 17.9 — and removed)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
