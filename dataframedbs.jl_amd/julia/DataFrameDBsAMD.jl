@@ -296,7 +296,9 @@ function device()
         # loaded: `t.brand .== "sony"` then scans 2 bytes per row (include/dfdb.h: dfdb_table_build_dictionary); 0 turns it off
         dictn = something(tryparse(Int, get(ENV, "DFDB_STRING_DICTIONARY", "")), 4096)
         check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "string_dictionary", dictn))
-        # DFDB_KEEP_COMPRESSED=1: plain fixed-width columns keep their LZ4 blocks in HBM beside the decoded array (gpu_redecode! below; include/dfdb.h: keep_compressed)
+        # DFDB_KEEP_COMPRESSED=1: plain fixed-width columns keep their LZ4 blocks in HBM beside the decoded array (gpu_redecode! below; include/dfdb.h: keep_compressed);
+        # DFDB_KEEP_COMPRESSED=2: COMPRESSED-ONLY — the blocks and nothing decoded (5.15 GB instead of 8 per 1e9 Int64 rows): predicates run inside the block decoder,
+        # projections decode the blocks that kept a row; every result is the same, scans cost ~10 x more (INTEGRATION.md section 6)
         keepc = something(tryparse(Int, get(ENV, "DFDB_KEEP_COMPRESSED", "")), 0)
         check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "keep_compressed", keepc))
         grp = Ref{Ptr{Cvoid}}(C_NULL)
@@ -306,6 +308,7 @@ function device()
             # exchange = 0 (DFDB_EXCHANGE_AUTO): RCCL over xGMI for distinct devices
             GC.@preserve ids check(ccall((:dfdb_group_create, LIB), Int32, (Ptr{Int32}, Int32, Int32, Ptr{Ptr{Cvoid}}), ids, n, 0, grp))
             check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "string_dictionary", dictn))
+            check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "keep_compressed", keepc))
         end
         DEV[] = Device(ctx[], grp[], Dict{String,Ptr{Cvoid}}(), Dict{String,Ptr{Cvoid}}())
     end
