@@ -164,6 +164,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one
  *                     loader thread each (2e9 rows, 1024-block chunks, file bytes per second: 4 slots 36.6, 6 slots 40.9, 8 slots with three reading
  *                     turns granted in chunk order and the loaders on the GPU's NUMA node 43-46 GB/s)
+ *   "stream_piece_mb" a loader reads and copies a chunk's bytes this many MB at a time through a three-piece pinned ring per slot, 1 .. 512 (default 64)
  *   "io_threads"      concurrent preads a byte range of a column file is split into, 1 .. 64 (default 8; process-wide, read when a stream is opened)
  *   "stream_readers"  loaders of a stream that may READ (page cache -> pinned memory, queueing the copies) at the same time, the others wait for their
  *                     copies and their decode (default 3)
