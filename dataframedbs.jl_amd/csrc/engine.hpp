@@ -117,7 +117,7 @@ struct dfdb_query {
   std::vector<int> comp_scanned;   // compressed-only columns whose blocks the last execution decoded inside its scan (their statuses are read with the count)
   // compressed-only projection columns: the blocks that kept a row, decoded for THIS query's gathers at their natural offsets inside the span
   // [first such block, last such block] — the iterator owns its decode buffers, like the reference's (blocksiterator.jl:98-121)
-  struct Arena { dfdb::DevBuf buf, blocks, status; int64_t first_row = 0; int64_t nblocks = 0; bool valid = false; };
+  struct Arena { dfdb::DevBuf buf, blocks, status; int64_t first_row = 0; int64_t nblocks = 0; bool valid = false; const void* from = nullptr; };   // from: the blocks (Column::comp) it was decoded out of
   std::map<int, Arena> arenas;
   dfdb::DevBuf cap_buf;
   // the same for a projected String column filtered by ONE short-pattern string term (K5 CAP): sizes per tile, bytes at the tile's arena

@@ -416,7 +416,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     // itself projected — the match pass then keeps the selected rows' sizes and bytes and K6 never reads the column again
     StrCapture capture{nullptr, nullptr, nullptr};
     // (every other kind of conjunct runs AFTER this launch and narrows the mask: the capture would keep rows the query drops — found by tests/test_gpu_fuzz.py)
-    bool do_cap = mode != 0 && !str_nullable && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && or_batches.empty() && miss.empty() &&
+    bool do_cap = mode != 0 && !str_nullable && q->hint_materialize && q->stages.size() == 1 && !have && generic.empty() && term_batches.empty() && or_batches.empty() && miss.empty() && comp_terms.empty() &&
                   dict_luts.empty() && strs.size() == 1 && pat.size() <= 64;
     if (do_cap) {
       do_cap = false;
@@ -855,7 +855,8 @@ static const void* gather_source(dfdb_query* q, int ord) {
   if (!c.comp_only || c.data.p) return c.data.p;
   const int w = dt_width(c.dtype);
   dfdb_query::Arena& a = q->arenas[ord];
-  if (!a.valid) {
+  if (!a.valid || a.from != c.comp.p) {                  // (a column that was loaded or compressed again since: other blocks)
+    a.from = c.comp.p;
     std::vector<int64_t> counts;
     query_block_counts(q, t->block_size, counts);
     int64_t first = -1, last = -1;

@@ -3,7 +3,7 @@
 fresh mask and AND-ed masks with / without the block skip.  Prints one JSON line per setting."""
 import json, os, shutil, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
+for p in (ROOT, os.path.join(ROOT, os.environ.get("DFDB_PKG", "dataframedbs.jl_amd"))):
     sys.path.insert(0, p)
 import torch
 torch.cuda.init()
