@@ -75,6 +75,16 @@ __device__ __forceinline__ uint64_t table_find(const UniqueEntry* ent, uint64_t 
   while (ent[h].key != key) h = (h + 1) & mask;     // present by construction (the insert pass put it there)
   return h;
 }
+// the same for a key that need not be there (groupreduce over an optimistically filled table): kNoSlot when its probe sequence reaches an empty slot
+__device__ __forceinline__ uint64_t table_find_maybe(const UniqueEntry* ent, uint64_t mask, uint64_t key, uint64_t h) {
+  for (int probes = 0; probes <= kMaxProbe; probes++) {
+    const uint64_t k = ent[h].key;
+    if (k == key) return h;
+    if (k == kEmpty) return kNoSlot;
+    h = (h + 1) & mask;
+  }
+  return kNoSlot;
+}
 // a workgroup's claimed slots -> aux[kAuxClaims] (one atomic per workgroup)
 __device__ __forceinline__ void add_claims(uint32_t mine, uint32_t* sh, uint64_t* aux) {
   if (mine) atomicAdd(sh, mine);
@@ -398,7 +408,8 @@ __global__ __launch_bounds__(kBlock) void k_str_pass(const StrPassArgs A) {
         if (r != kNoSlot && !(r >> 63)) { A.rep_off[r] = (uint64_t)off; A.rep_len[r] = (uint32_t)s0; claimed++; }   // I claimed the slot: my bytes represent it
         if (r != kNoSlot && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
       } else {
-        const uint64_t hs = table_find(A.ent, A.mask, key, key & A.mask);
+        const uint64_t hs = KIND == 2 ? table_find_maybe(A.ent, A.mask, key, key & A.mask) : table_find(A.ent, A.mask, key, key & A.mask);
+        if (KIND == 2 && hs == kNoSlot) { __atomic_store_n(&A.aux[kAuxAbort], 1ull, __ATOMIC_RELAXED); continue; }   // a string the (optimistically filled) table does not hold: the host runs everything again
         const bool same = !A.rep_off || same_bytes(p, s0, A.bytes + A.rep_off[hs], A.rep_len[hs]);
         if (!same) atomicOr(collision, 1);                      // two different strings, one key: the host repeats with another salt
         if (KIND == 2) {

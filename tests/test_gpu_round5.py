@@ -329,3 +329,50 @@ def test_compressed_only_shards_of_a_group(oracle, dfdb_mod, ctx, tmp_path):
         gt.close()
     finally:
         g.close()
+
+
+def test_groupreduce_by_a_string_key_skips_the_inserts_it_does_not_need(oracle, dfdb_mod, ctx):
+    """groupreduce by a String key (aggregate.jl:1-36): when the second chunk of rows brings no string the first had not, the remaining rows are not inserted into
+    the hash table — the accumulate pass meets every row anyway and says so if a string is missing, in which case everything runs again the slow way.  Same
+    groups, in order of first appearance, same counts and sums: with every key early (optimistic path taken), with a key that first turns up in the last rows
+    (found missing, redone), with the redo forced, with the option off."""
+    dfdb = dfdb_mod
+    n = 700_000
+    rng = np.random.default_rng(31)
+    brands = ["apple", "samsung", "huawei", "microsoft", "dell", "xbox", "sony", "intel", "lenovo", "asus", "a-rather-long-brand-name-over-16-bytes"]
+    k = rng.integers(0, len(brands), n)
+    early = [brands[i] for i in k]
+    late = list(early); late[-3] = "late-comer"; late[-1] = "zz"
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    ctx.set_option("unique_chunk_tiles", 8)                 # chunks of 8 K, 128 K, the rest: the rest is what the optimistic path skips
+    ctx.profile(True)
+    try:
+        for name, keys in (("early", early), ("late", late)):
+            t = dfdb.DFTable.from_columns({"s": keys, "a": a}, block_size=65536)
+            arr = np.array(keys, dtype=object)
+            first = {}
+            for i, v in enumerate(keys):
+                if v not in first:
+                    first[v] = i
+            order = sorted(first, key=first.get)
+            for opt in (1, 2, 0):
+                ctx.set_option("groupreduce_optimistic", opt)
+                before, _ = ctx.profile_get("unique_insert")
+                g = dfdb.groupreduce(t, "s", "a", "sum")
+                after, _ = ctx.profile_get("unique_insert")
+                assert list(g["s"]) == order, (name, opt)
+                for v, c_, s_ in zip(g["s"], g["count"].to_numpy(), g["sum"].to_numpy()):
+                    m = arr == v
+                    assert c_ == int(m.sum()) and s_ == int(a[m].sum()), (name, opt, v)
+                launches = after - before
+                if opt == 1 and name == "early":
+                    assert launches == 2, launches                # two prefix chunks, the rest skipped
+                elif opt == 0:
+                    assert launches == 3, launches
+                else:
+                    assert launches == 2 + 3, launches            # the optimistic attempt, then everything again
+            t.close()
+    finally:
+        ctx.profile(False)
+        ctx.set_option("groupreduce_optimistic", 1)
+        ctx.set_option("unique_chunk_tiles", 0)
