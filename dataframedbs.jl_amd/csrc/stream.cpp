@@ -137,6 +137,10 @@ struct dfdb_stream {
   // Without the limit the loaders run in lockstep — all reading (the host's memcpy bandwidth split five ways, PCIe waiting for pieces), then all
   // waiting for PCIe and K7 at once while nobody reads — and the caller gets its chunks in bursts: 42 GB/s of file bytes on 8 slots, measured.
   int64_t piece_bytes = 64ll << 20;   // a whole-column chunk load reads and copies this much at a time (ctx option "stream_piece_mb")
+  // the pinned rings of the whole-column loads belong to the READING TURNS, not to the slots: `max_readers` rings of three pieces are all the pinned memory
+  // the reads ever write (a few hundred MB that stay in the socket's last-level cache) however many slots the stream has; a ring goes with the turn
+  struct TurnRing { uint8_t* pin = nullptr; size_t cap = 0; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; bool used[3] = {false, false, false}; bool taken = false; };
+  TurnRing turn_ring[kLoaders];
   int max_readers = 3, readers = 0;
   std::set<int64_t> waiting_readers;   // first blocks of the chunks whose loaders wait for a turn: the EARLIEST chunk reads first (the caller consumes in order)
   dfdb_ctx* parent = nullptr; std::weak_ptr<int> parent_alive;   // where a closed stream parks (if that context still exists)
@@ -149,6 +153,7 @@ namespace {
 
 struct ReadTurn {                   // RAII: one of the stream's `max_readers` reading turns, granted in chunk order
   dfdb_stream* s;
+  int ring = 0;                     // which of the stream's turn rings this turn reads through
   ReadTurn(dfdb_stream* st, int64_t first_block);
   ~ReadTurn();
 };
@@ -158,11 +163,13 @@ ReadTurn::ReadTurn(dfdb_stream* st, int64_t first_block) : s(st) {
   s->cv.wait(lk, [&] { return s->readers < s->max_readers && *s->waiting_readers.begin() == first_block; });
   s->waiting_readers.erase(first_block);
   s->readers++;
+  for (int k = 0; k < s->max_readers; k++) if (!s->turn_ring[k].taken) { ring = k; break; }
+  s->turn_ring[ring].taken = true;
   lk.unlock();
   s->cv.notify_all();                 // (the next chunk in line may have a turn left to take)
 }
 ReadTurn::~ReadTurn() {
-  { std::lock_guard<std::mutex> lk(s->mu); s->readers--; }
+  { std::lock_guard<std::mutex> lk(s->mu); s->readers--; s->turn_ring[ring].taken = false; }
   s->cv.notify_all();
 }
 void ring_drain(Slot* sl);
@@ -191,25 +198,32 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
   const std::vector<BlockLoc>& ix = sl->locs[k];              // the chunk's blocks, chunk-relative
   const int64_t lo = ix.front().off, hi = ix.back().off + 20 + ix.back().compressed;
   const int64_t kPiece = s->piece_bytes;
-  ensure_pin(sl, (size_t)(Slot::kRing * kPiece));
-  for (int r = 0; r < Slot::kRing; r++) if (!sl->ring_ev[r]) HIP_CHECK(hipEventCreateWithFlags(&sl->ring_ev[r], hipEventDisableTiming));
   auto t0 = std::chrono::steady_clock::now();
   DevBuf& staged = tb->ld_staged;
   staged.ensure((size_t)(hi - lo) + 64);
   {
     ReadTurn turn(s, sl->b0);
+    dfdb_stream::TurnRing& R = s->turn_ring[turn.ring];        // (mine for the duration of the turn; its events may belong to copies another slot queued)
+    if (R.cap < (size_t)(3 * kPiece)) {
+      for (int r = 0; r < 3; r++) if (R.used[r]) { (void)hipEventSynchronize(R.ev[r]); R.used[r] = false; }
+      if (R.pin) (void)hipHostFree(R.pin);
+      R.pin = nullptr; R.cap = 0;
+      HIP_CHECK(hipHostMalloc((void**)&R.pin, (size_t)(3 * kPiece), hipHostMallocDefault));
+      R.cap = (size_t)(3 * kPiece);
+    }
+    for (int r = 0; r < 3; r++) if (!R.ev[r]) HIP_CHECK(hipEventCreateWithFlags(&R.ev[r], hipEventDisableTiming));
     t0 = std::chrono::steady_clock::now();
     const int fd = open(c.file.c_str(), O_RDONLY);
     if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
     int r = 0;
-    for (int64_t a = lo; a < hi; a += kPiece, r = (r + 1) % Slot::kRing) {
+    for (int64_t a = lo; a < hi; a += kPiece, r = (r + 1) % 3) {
       const int64_t e = std::min(hi, a + kPiece);
-      uint8_t* buf = sl->pin + (size_t)r * (size_t)kPiece;
-      if (sl->ring_used[r]) HIP_CHECK(hipEventSynchronize(sl->ring_ev[r]));   // its previous copy has left the buffer
+      uint8_t* buf = R.pin + (size_t)r * (size_t)kPiece;
+      if (R.used[r]) HIP_CHECK(hipEventSynchronize(R.ev[r]));                 // its previous copy (this chunk's or an earlier turn's) has left the buffer
       if (!read_file_range_fd(fd, buf, a, e)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
       HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, sl->ctx->stream));
-      HIP_CHECK(hipEventRecord(sl->ring_ev[r], sl->ctx->stream)); sl->ring_used[r] = true;
+      HIP_CHECK(hipEventRecord(R.ev[r], sl->ctx->stream)); R.used[r] = true;
     }
   }
   const auto t1 = std::chrono::steady_clock::now();
@@ -606,6 +620,10 @@ static void stream_destroy(dfdb_stream* s) {
     for (int r = 0; r < Slot::kRing; r++) if (sl.ring_ev[r]) { (void)hipEventDestroy(sl.ring_ev[r]); sl.ring_ev[r] = nullptr; sl.ring_used[r] = false; }
     if (sl.pin) (void)hipHostFree(sl.pin);
     if (sl.ctx) ctx_destroy(sl.ctx);
+  }
+  for (auto& R : s->turn_ring) {
+    for (int r = 0; r < 3; r++) if (R.ev[r]) { if (R.used[r]) (void)hipEventSynchronize(R.ev[r]); (void)hipEventDestroy(R.ev[r]); }
+    if (R.pin) (void)hipHostFree(R.pin);
   }
   delete s;
 }

@@ -7,6 +7,7 @@
 // blocks of a column in ONE launch (K7, a wave per block), and leave the decoded column contiguous in HBM.
 #include "engine.hpp"
 #include <atomic>
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <fcntl.h>
@@ -518,8 +519,13 @@ static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_
   for (int64_t a = lo; a < hi; a += kPiece, k ^= 1) {
     const int64_t e = std::min(hi, a + kPiece);
     uint8_t* buf = ctx->pin_ring[k];
+    const auto tw0 = std::chrono::steady_clock::now();
     if (used[k]) HIP_CHECK(hipEventSynchronize(ctx->pin_ev[k]));              // its previous copy has left the buffer
+    const auto tw1 = std::chrono::steady_clock::now();
     if (!read_file_range_fd(fd, buf, a, e)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+    if (getenv("DFDB_STREAM_DEBUG")) { const auto tw2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[load] piece at %lld: waited %.2f ms for its buffer, read %.1f MB in %.2f ms\n", (long long)(a - lo), std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
+              (double)(e - a) / 1e6, std::chrono::duration<double, std::milli>(tw2 - tw1).count()); }
     HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(ctx->pin_ev[k], s)); used[k] = true;
     if (walk) {

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=float, default=2e9)
 ap.add_argument("--slots", type=int, default=6)
 ap.add_argument("--chunk", type=int, default=1024)
+ap.add_argument("--readers", type=int, default=3)
 args = ap.parse_args()
 n = int(args.rows)
 ctx = dfdb.default_context(0)
@@ -21,7 +22,7 @@ try:
     t.close()
     tb = dfdb.open_table(os.path.join(d, "tb"), load=False)
     v = tb[("x", lambda x: x > 899_999), dfdb.ALL]
-    ctx.set_option("stream_slots", args.slots)
+    ctx.set_option("stream_slots", args.slots); ctx.set_option("stream_readers", args.readers)
     for rep in range(3):
         print(f"---- rep {rep}", file=sys.stderr, flush=True)
         t0 = time.perf_counter()
