@@ -249,8 +249,29 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
     };
     // SCAN: mask words of this block so far, the current tile's words (word k of the tile in lane k) and its selected count
     uint32_t sc_words = 0, sc_tile_count = 0; uint64_t sc_myword = 0;
-    const uint32_t sc_sel = SCAN ? lz_op_sel(sc.op) : 0u;
-    const uint32_t sc_sel2 = SCAN && sc.op2 >= 0 ? lz_op_sel(sc.op2) : 0u;      // an interval term: col OP c  &  col OP2 c2 (`65 > x > 34`, test/selection.jl:53)
+    // The comparison as MASK ARITHMETIC (round 5).  Written per value with the column's type and the operator as run-time selects, the compiler made uniform
+    // branches of every one of them: ~90 scalar instructions per 512 decoded bytes on the CU's one scalar unit — a third of all the kernel issues.  Instead every
+    // 8-byte value gets an order-preserving unsigned image (signed: sign bit flipped; Float64: -0.0 folded into +0.0, negatives complemented; the two forms blended
+    // with a mask VALUE, not a branch), the constant the same image once per block, and `less`, `greater` and `NaN` leave the vector unit as wave masks (the ballot
+    // is free); which of {less, equal, greater, unordered} the operator accepts is four more mask values.  An interval term ANDs a second such mask in.
+    struct ScKey { uint64_t ck, S_lt, S_eq, S_gt, S_un, CN; };
+    const uint64_t sc_FM = SCAN && sc.dtype == DFDB_F64 ? ~0ull : 0ull, sc_XM = SCAN && sc.dtype == DFDB_U64 ? 0ull : 0x8000000000000000ull;
+    auto sc_key_of = [&](uint64_t c, int op) -> ScKey {
+      const uint32_t sel = lz_op_sel(op);
+      ScKey k;
+      const bool cnan = sc_FM && (c & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+      const uint64_t cz = c == 0x8000000000000000ull ? 0ull : c;
+      k.ck = sc_FM ? (cz ^ ((uint64_t)((int64_t)cz >> 63) | 0x8000000000000000ull)) : (c ^ sc_XM);
+      k.S_lt = (sel & 1u) ? ~0ull : 0ull; k.S_eq = (sel & 2u) ? ~0ull : 0ull; k.S_gt = (sel & 4u) ? ~0ull : 0ull; k.S_un = (sel & 8u) ? ~0ull : 0ull;
+      k.CN = cnan ? ~0ull : 0ull;                                   // a NaN constant: every row compares unordered
+      return k;
+    };
+    const ScKey sc_k1 = SCAN ? sc_key_of(sc.cbits, sc.op) : ScKey{}, sc_k2 = SCAN && sc.op2 >= 0 ? sc_key_of(sc.cbits2, sc.op2) : ScKey{};
+    auto sc_mask = [&](uint64_t kimg, uint64_t mnan, const ScKey& k) -> uint64_t {      // the rows of this 64-row word the term accepts
+      const uint64_t mlt = __ballot(kimg < k.ck), mgt = __ballot(kimg > k.ck);
+      const uint64_t un = mnan | k.CN, ord = ~un;
+      return (mlt & ord & k.S_lt) | (mgt & ord & k.S_gt) | (~(mlt | mgt) & ord & k.S_eq) | (un & k.S_un);
+    };
     const int64_t sc_word0 = blk.dst_off / 512;                   // the block's first mask word (host: the block starts on a 1024-row tile)
     // ring -> HBM, bytes [flushed, upto)
     auto flush_to = [&](uint32_t upto) {
@@ -264,9 +285,12 @@ __global__ __launch_bounds__(PIPE ? 128 : WAVES * 64, OCC) void k_lz4_decode(con
             ((uint64_t*)(out + HO(g)))[lane] = v;                                          // a whole group leaves as one 512-byte store (8-byte columns: `out` is 8-aligned)
             if (HIST && HO(g) == 0u && lane < 4u) *(uint64_t*)(out + kHistBytes + lane * 8u) = v;   // the lap's first 32 bytes again, behind the ring
           }
-          bool r = have && lz_cmp8_sel(v, sc.cbits, sc.dtype, sc_sel);
-          if (sc.op2 >= 0) r = r && lz_cmp8_sel(v, sc.cbits2, sc.dtype, sc_sel2);
-          const uint64_t m = __ballot(r);
+          const uint64_t vz = v == 0x8000000000000000ull ? 0ull : v;
+          const uint64_t kimg = ((vz ^ ((uint64_t)((int64_t)vz >> 63) | 0x8000000000000000ull)) & sc_FM) | ((v ^ sc_XM) & ~sc_FM);
+          const uint64_t mnan = __ballot((v & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) & sc_FM;
+          uint64_t m = sc_mask(kimg, mnan, sc_k1);
+          if (sc.op2 >= 0) m &= sc_mask(kimg, mnan, sc_k2);
+          if (g + 512u > upto) m &= __ballot(have);                  // (a block's last, shorter group)
           if (lane == (sc_words & 15u)) sc_myword = m;
           sc_tile_count += (uint32_t)__builtin_popcountll(m);
           sc_words++;
