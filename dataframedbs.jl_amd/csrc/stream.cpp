@@ -220,8 +220,15 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
     for (int64_t a = lo; a < hi; a += kPiece, r = (r + 1) % 3) {
       const int64_t e = std::min(hi, a + kPiece);
       uint8_t* buf = R.pin + (size_t)r * (size_t)kPiece;
+      const auto tw0 = std::chrono::steady_clock::now();
       if (R.used[r]) HIP_CHECK(hipEventSynchronize(R.ev[r]));                 // its previous copy (this chunk's or an earlier turn's) has left the buffer
+      const auto tw1 = std::chrono::steady_clock::now();
       if (!read_file_range_fd(fd, buf, a, e)) fail(DFDB_ERR_IO, "short read from %s", c.file.c_str());
+      if (getenv("DFDB_STREAM_DEBUG")) { const auto tw2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[stream] slot %d piece at %lld: waited %.2f ms for its buffer, read %.1f MB in %.2f ms\n", (int)(sl - s->slot), (long long)(a - lo),
+                std::chrono::duration<double, std::milli>(tw1 - tw0).count(), (double)(e - a) / 1e6, std::chrono::duration<double, std::milli>(tw2 - tw1).count()); }
+      // (on the slot's own engine stream: one DMA queue per slot.  ONE queue for every slot's pieces, the slots waiting by event, was measured slower
+      // — 45 GB/s against 50 with two or three reading turns: copies of different queues overlap their starts and ends)
       HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, sl->ctx->stream));
       HIP_CHECK(hipEventRecord(R.ev[r], sl->ctx->stream)); R.used[r] = true;
     }

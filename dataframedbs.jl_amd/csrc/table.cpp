@@ -400,6 +400,7 @@ static void load_from_image(dfdb_table* t, Column& c, const uint8_t* img, size_t
 static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_t block_last, dfdb_sizestats* stats) {
   dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   NodeBind bind(ctx);                                                          // the preads and the bounce buffers on the GPU's NUMA node
+  set_io_threads(ctx_option(ctx, "io_threads", 8));                            // (process-wide: the last table loaded / stream opened decides)
   const int fd = open(c.file.c_str(), O_RDONLY);
   if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
   struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
