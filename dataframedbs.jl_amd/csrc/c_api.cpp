@@ -523,13 +523,14 @@ NodeBind::NodeBind(dfdb_ctx* ctx) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (ctx->node_state == 0) ctx->node_state = lookup_node(ctx);
-    if (ctx->node_state != 1) return;
+    if (ctx->node_state != 1) { if (getenv("DFDB_STREAM_DEBUG")) fprintf(stderr, "[numa] the device's node is unknown: nothing bound\n"); return; }
   }
   if (sched_getaffinity(0, sizeof old, &old) != 0) return;
   cpu_set_t want;
   CPU_AND(&want, &old, &ctx->node_cpus);
-  if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &old)) return;
+  if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &old)) { if (getenv("DFDB_STREAM_DEBUG")) fprintf(stderr, "[numa] thread on cpu %d: %d of its %d CPUs are on the device's node, nothing to narrow\n", sched_getcpu(), CPU_COUNT(&want), CPU_COUNT(&old)); return; }
   if (sched_setaffinity(0, sizeof want, &want) == 0) active = true;
+  if (getenv("DFDB_STREAM_DEBUG")) fprintf(stderr, "[numa] thread on cpu %d: %d of its %d CPUs are on the device's node, bound: %d\n", sched_getcpu(), CPU_COUNT(&want), CPU_COUNT(&old), (int)active);
 }
 NodeBind::~NodeBind() { if (active) (void)sched_setaffinity(0, sizeof old, &old); }
 

@@ -139,7 +139,7 @@ struct dfdb_stream {
   int64_t piece_bytes = 64ll << 20;   // a whole-column chunk load reads and copies this much at a time (ctx option "stream_piece_mb")
   // the pinned rings of the whole-column loads belong to the READING TURNS, not to the slots: `max_readers` rings of three pieces are all the pinned memory
   // the reads ever write (a few hundred MB that stay in the socket's last-level cache) however many slots the stream has; a ring goes with the turn
-  struct TurnRing { uint8_t* pin = nullptr; size_t cap = 0; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; bool used[3] = {false, false, false}; bool taken = false; };
+  struct TurnRing { uint8_t* pin = nullptr; size_t cap = 0; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; bool used[3] = {false, false, false}; bool taken = false; int next = 0; };
   TurnRing turn_ring[kLoaders];
   int max_readers = 3, readers = 0;
   std::set<int64_t> waiting_readers;   // first blocks of the chunks whose loaders wait for a turn: the EARLIEST chunk reads first (the caller consumes in order)
@@ -201,6 +201,8 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
   auto t0 = std::chrono::steady_clock::now();
   DevBuf& staged = tb->ld_staged;
   staged.ensure((size_t)(hi - lo) + 64);
+  const bool dbg_copy = getenv("DFDB_STREAM_DEBUG_COPIES") != nullptr;     // (timing events around every piece's copy: how long PCIe took, how long it sat idle before)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> dbg_ev; std::vector<double> dbg_mb;
   {
     ReadTurn turn(s, sl->b0);
     dfdb_stream::TurnRing& R = s->turn_ring[turn.ring];        // (mine for the duration of the turn; its events may belong to copies another slot queued)
@@ -216,7 +218,9 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
     const int fd = open(c.file.c_str(), O_RDONLY);
     if (fd < 0) fail(DFDB_ERR_IO, "cannot read %s", c.file.c_str());
     struct FdClose { int fd; ~FdClose() { close(fd); } } fdg{fd};
-    int r = 0;
+    // (the ring goes on where the previous turn left it: starting every chunk at piece 0 made its first read wait for the previous chunk's second-to-last
+    // copy — 0.6-1.6 ms per chunk — while the piece after it had been free for milliseconds)
+    int& r = R.next;
     for (int64_t a = lo; a < hi; a += kPiece, r = (r + 1) % 3) {
       const int64_t e = std::min(hi, a + kPiece);
       uint8_t* buf = R.pin + (size_t)r * (size_t)kPiece;
@@ -229,9 +233,21 @@ void load_column_whole(dfdb_stream* s, Slot* sl, size_t k) {
                 std::chrono::duration<double, std::milli>(tw1 - tw0).count(), (double)(e - a) / 1e6, std::chrono::duration<double, std::milli>(tw2 - tw1).count()); }
       // (on the slot's own engine stream: one DMA queue per slot.  ONE queue for every slot's pieces, the slots waiting by event, was measured slower
       // — 45 GB/s against 50 with two or three reading turns: copies of different queues overlap their starts and ends)
+      hipEvent_t d0 = nullptr, d1 = nullptr;
+      if (dbg_copy) { HIP_CHECK(hipEventCreate(&d0)); HIP_CHECK(hipEventCreate(&d1)); HIP_CHECK(hipEventRecord(d0, sl->ctx->stream)); }
       HIP_CHECK(hipMemcpyAsync(staged.as<uint8_t>() + (a - lo), buf, (size_t)(e - a), hipMemcpyHostToDevice, sl->ctx->stream));
+      if (dbg_copy) { HIP_CHECK(hipEventRecord(d1, sl->ctx->stream)); dbg_ev.push_back({d0, d1}); dbg_mb.push_back((double)(e - a) / 1e6); }
       HIP_CHECK(hipEventRecord(R.ev[r], sl->ctx->stream)); R.used[r] = true;
     }
+  }
+  if (dbg_copy) {
+    for (size_t i = 0; i < dbg_ev.size(); i++) {
+      (void)hipEventSynchronize(dbg_ev[i].second);
+      float ms = 0, gap = 0; (void)hipEventElapsedTime(&ms, dbg_ev[i].first, dbg_ev[i].second);
+      if (i) (void)hipEventElapsedTime(&gap, dbg_ev[i - 1].second, dbg_ev[i].first);
+      fprintf(stderr, "[stream] slot %d copy %zu: %.1f MB in %.2f ms (%.1f GB/s), %.2f ms after the previous one ended\n", (int)(sl - s->slot), i, dbg_mb[i], ms, dbg_mb[i] / ms, gap);
+    }
+    for (auto& pr : dbg_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   }
   const auto t1 = std::chrono::steady_clock::now();
   // the blocks as the index describes them (their headers were walked and checked against the other columns when the chunk was planned)

@@ -56,15 +56,19 @@ bool read_file_range_fd(int fd, uint8_t* dst, int64_t lo, int64_t hi) {
   const int parts = (int)std::min<int64_t>(g_io_threads.load(std::memory_order_relaxed), std::max<int64_t>(1, n / (2 << 20)));
   std::vector<std::thread> th;
   std::vector<char> ok((size_t)parts, 1);
+  static const bool dbg_cpus = getenv("DFDB_STREAM_DEBUG_CPUS") != nullptr;
+  int dbg_buf[64]; int* dbg = dbg_cpus ? dbg_buf : nullptr;
   for (int k = 0; k < parts; k++) {
     const int64_t a = lo + n * k / parts, b = lo + n * (k + 1) / parts;
-    auto work = [fd, dst, lo, a, b, k, &ok] {
+    auto work = [fd, dst, lo, a, b, k, &ok, dbg] {
+      if (dbg) dbg[k] = sched_getcpu();
       int64_t got = a;
       while (got < b) { const ssize_t r = pread(fd, dst + (got - lo), (size_t)(b - got), (off_t)got); if (r <= 0) { ok[(size_t)k] = 0; return; } got += r; }
     };
     if (k + 1 < parts) th.emplace_back(work); else work();
   }
   for (auto& t : th) t.join();
+  if (dbg) { std::string l; for (int k = 0; k < parts; k++) l += " " + std::to_string(dbg[k]); fprintf(stderr, "[pread] cpus:%s\n", l.c_str()); }
   for (char c : ok) if (!c) return false;
   return true;
 }
