@@ -206,36 +206,49 @@ __device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int32_t len, ui
   return ((uint64_t)a << 32) | b;
 }
 
-// What a wave has already met: strings of up to 16 bytes (length + bytes fit one entry and identify the string EXACTLY) in a direct-mapped cache in LDS, one per wave.
+// What a wave has already met: strings of up to 16 bytes (length + bytes fit one entry and identify the string EXACTLY) in a cache in LDS, one per wave.
 // A wave walks its tiles, the words of a tile and the lanes of a word in increasing row order, so whatever it does for a string the first time it meets it — insert
 // its key with that row (smaller than any row it will meet later), compare it with its slot's representative, find its group — holds for every later meeting:
 // those rows touch neither the hash nor the table.  An entry has ONE writer per instruction: lanes that want a slot write their lane number beside it first, the one
 // that reads its own number back writes the entry (two lanes storing different entries to one slot in the same instruction could tear it).
 constexpr int kMetSlots = 256;
 struct MetEntry { uint64_t head, head2; uint32_t len, val; uint64_t pad; };
-struct MetCache {
+template <int SLOTS>
+struct MetCacheT {
   MetEntry* e; uint32_t* claim;
   __device__ __forceinline__ void init(MetEntry* entries, uint32_t* claims, int lane) {
     e = entries; claim = claims;
-    for (int i = lane; i < kMetSlots; i += 64) e[i].len = 0xFFFFFFFFu;
+    for (int i = lane; i < SLOTS; i += 64) e[i].len = 0xFFFFFFFFu;
   }
-  static __device__ __forceinline__ uint32_t slot(uint64_t head, uint64_t head2, uint32_t len) {
+  // two places per string (the 32-bit mix gives both): direct-mapped, two of a column's FREQUENT strings that share a slot evict each other on every row — measured on the
+  // ten brands with 128 slots: the accumulate pass 3x slower.  A string goes to its first place if that is empty or already its own, to its second otherwise
+  static constexpr int kLog = SLOTS == 256 ? 8 : SLOTS == 128 ? 7 : 6;
+  static __device__ __forceinline__ uint32_t mix(uint64_t head, uint64_t head2, uint32_t len) {
     const uint32_t x = (uint32_t)head ^ rotl32((uint32_t)(head >> 32), 7) ^ rotl32((uint32_t)head2, 13) ^ rotl32((uint32_t)(head2 >> 32), 19) ^ (len << 27);
-    return (x * 0x9E3779B1u) >> 24;
+    return x * 0x9E3779B1u;
   }
-  __device__ __forceinline__ bool find(uint64_t head, uint64_t head2, uint32_t len, uint32_t& val) const {
-    const MetEntry x = e[slot(head, head2, len)];
+  static __device__ __forceinline__ uint32_t slot1(uint32_t m) { return m >> (32 - kLog); }
+  static __device__ __forceinline__ uint32_t slot2(uint32_t m) { const uint32_t a = m >> (32 - kLog), b = (m >> (32 - 2 * kLog)) & (uint32_t)(SLOTS - 1); return b == a ? (b ^ 1u) : b; }
+  static __device__ __forceinline__ bool is(const MetEntry& x, uint64_t head, uint64_t head2, uint32_t len) { return x.len == len && x.head == head && x.head2 == head2; }
+  // (called by every lane of the wave; `want`: this lane's answer matters — the second place is read by all lanes when one of those missed the first)
+  __device__ __forceinline__ bool find(uint64_t head, uint64_t head2, uint32_t len, uint32_t& val, bool want = true) const {
+    const uint32_t m = mix(head, head2, len);
+    const MetEntry x = e[slot1(m)];
+    bool hit = is(x, head, head2, len);
     val = x.val;
+    if (__ballot(want && !hit) != 0) { const MetEntry y = e[slot2(m)]; const bool hit2 = is(y, head, head2, len); val = hit ? val : y.val; hit = hit || hit2; }
     // the value is read HERE, with the tag: left to the compiler the load sinks into the caller's hit branch, which may run after the miss branch of other
     // lanes of the same instruction has overwritten the slot (found by the forms test: rows counted for a neighbouring group)
     asm volatile("" : "+v"(val));
-    return x.len == len && x.head == head && x.head2 == head2;
+    return hit;
   }
   __device__ __forceinline__ void put(uint64_t head, uint64_t head2, uint32_t len, uint32_t val, int lane) {
-    const uint32_t s = slot(head, head2, len);
+    const uint32_t m = mix(head, head2, len);
+    const MetEntry x = e[slot1(m)];
+    const uint32_t s = (x.len == 0xFFFFFFFFu || is(x, head, head2, len)) ? slot1(m) : slot2(m);
     claim[s] = (uint32_t)lane;
     asm volatile("" ::: "memory");                           // the read-back must be a read (of LDS, not of the register just stored): it decides which lane goes on
-    if (claim[s] == (uint32_t)lane) { MetEntry x; x.head = head; x.head2 = head2; x.len = len; x.val = val; x.pad = 0; e[s] = x; }
+    if (claim[s] == (uint32_t)lane) { MetEntry y; y.head = head; y.head2 = head2; y.len = len; y.val = val; y.pad = 0; e[s] = y; }
   }
 };
 constexpr int32_t kMetMaxLen = 16;
@@ -306,22 +319,28 @@ struct StrPassArgs {
   UniqueEntry* ent; uint64_t* rep_off; uint32_t* rep_len; uint64_t mask; uint64_t* aux; uint64_t salt;
   const void* valcol; int valdt, op; uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;       // KIND 2
 };
-template <int KIND, bool LDS>
-__global__ __launch_bounds__(kBlock) void k_str_pass(const StrPassArgs A) {
+template <int KIND, int NGL>                                   // NGL: groups the workgroup's LDS accumulators hold (0: global atomics)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_str_pass(const StrPassArgs A) {   // (four waves per SIMD: 128 VGPRs)
+  constexpr bool LDS = NGL > 0;
   __shared__ uint32_t claims_sh;
-  __shared__ uint64_t lcnt[(KIND == 2 && LDS) ? kGroupLds : 1], lval[(KIND == 2 && LDS) ? kGroupLds : 1];
-  __shared__ MetEntry met_e[kWavesPerBlock][kMetSlots];
-  __shared__ uint32_t met_c[kWavesPerBlock][kMetSlots];
+  __shared__ uint64_t lcnt[(KIND == 2 && LDS) ? NGL : 1], lval[(KIND == 2 && LDS) ? NGL : 1];
+  constexpr int kSlots = kMetSlots;
+  static_assert(kSlots == 256 || kSlots == 128 || kSlots == 64, "MetCacheT::slot shifts");
+  __shared__ MetEntry met_e[kWavesPerBlock][kSlots];
+  __shared__ uint32_t met_c[kWavesPerBlock][kSlots];
   const int lane = lane_id();
   const bool has_val = KIND == 2 && A.valcol != nullptr && A.op != DFDB_AGG_COUNT;
   if (KIND == 0 && threadIdx.x == 0) claims_sh = 0;
   if (KIND == 2 && LDS) for (int g = threadIdx.x; g < A.ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; }
   if (KIND == 0 || (KIND == 2 && LDS)) __syncthreads();
-  MetCache met;
+  MetCacheT<kSlots> met;
   met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
   uint32_t claimed = 0;
   int* collision = (int*)(A.aux + 4);
   const uint64_t gid_missing = KIND == 2 ? A.aux[1] : 0ull;
+  // (properties of the value column, looked at ONCE: inside the unrolled row loops the dtype switch was a chain of scalar compares per row)
+  int vkind = 0; if (KIND == 2 && has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);
+  const bool val8 = KIND == 2 && has_val && (A.valdt == DFDB_I64 || A.valdt == DFDB_U64 || A.valdt == DFDB_F64);
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t tile = A.tile0 + wave; tile < A.tile1; tile += nwaves) {
@@ -358,7 +377,11 @@ __global__ __launch_bounds__(kBlock) void k_str_pass(const StrPassArgs A) {
         const int32_t s0 = sz[h * 8 + j];
         head[j] = (on[j] && s0 > 0) ? load8(tb + rel[j]) : 0ull;
         head2[j] = (on[j] && s0 > 8) ? load8(tb + rel[j] + 8) : 0ull;
-        if (KIND == 2) { int kind = 0; bits[j] = (on[j] && has_val) ? value_bits(A.valcol, A.valdt, base + (h * 8 + j) * 64 + lane, kind) : 0ull; }
+        if (KIND == 2) {
+          const int64_t row = base + (h * 8 + j) * 64 + lane;
+          if (val8) bits[j] = on[j] ? ((const uint64_t*)A.valcol)[row] : 0ull;
+          else { int kind = 0; bits[j] = (on[j] && has_val) ? value_bits(A.valcol, A.valdt, row, kind) : 0ull; }
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -369,19 +392,17 @@ __global__ __launch_bounds__(kBlock) void k_str_pass(const StrPassArgs A) {
           const uint64_t mm = __ballot(on[j] && s0 < 0);
           if (mm && lane == __builtin_ctzll(mm) && __atomic_load_n(&A.aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&A.aux[1], (unsigned long long)row);
         }
-        if (on[j]) {
-          uint32_t g32 = 0;
-          bool known = false;
-          uint64_t gid = gid_missing;
-          if (s0 >= 0) {
-            known = s0 <= kMetMaxLen && met.find(low_bytes(head[j], s0), low_bytes(head2[j], s0 - 8), (uint32_t)s0, g32);
-            gid = g32;
-            miss = !known;
-          }
-          if (KIND == 2 && !miss) {
-            int kind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, kind);       // (the value kind is a property of the column)
-            if (LDS) group_add(lcnt, lval, gid, bits[j], kind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits[j], kind, A.op, has_val);
-          }
+        // (flat: every lane probes the cache — a lane that is off or holds a missing value probes with zeros and ignores the answer —, ONE predicated region does
+        // the accumulation; nested `if`s cost an exec-mask save / branch / restore each, 80 scalar instructions per 64 rows before)
+        const bool str = on[j] && s0 >= 0;
+        const int32_t sl = str ? s0 : 0;
+        uint32_t g32 = 0;
+        const bool hit = met.find(low_bytes(head[j], sl), low_bytes(head2[j], sl - 8), (uint32_t)sl, g32, str && s0 <= kMetMaxLen);
+        const bool known = str && s0 <= kMetMaxLen && hit;
+        miss = str && !known;
+        if (KIND == 2 && on[j] && !miss) {
+          const uint64_t gid = s0 >= 0 ? (uint64_t)g32 : gid_missing;
+          if (LDS) group_add(lcnt, lval, gid, bits[j], vkind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits[j], vkind, A.op, has_val);
         }
         const uint64_t m = __ballot(miss);
         if (lane == h * 8 + j) missw = m;
@@ -510,8 +531,8 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
   StrPassArgs A{};
   A.sel = bitmap; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = tile0; A.tile1 = tile1;
   A.ent = ent; A.rep_off = rep_off; A.rep_len = rep_len; A.mask = mask; A.aux = aux; A.salt = salt;
-  if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, false>), g, b, 0, s, A);
-  else hipLaunchKernelGGL((k_str_pass<1, false>), g, b, 0, s, A);
+  if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, 0>), g, b, 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<1, 0>), g, b, 0, s, A);
 }
 
 // ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
@@ -692,9 +713,19 @@ void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32
   A.sel = sel; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = 0; A.tile1 = ntiles;
   A.ent = const_cast<UniqueEntry*>(ent); A.rep_off = const_cast<uint64_t*>(rep_off); A.rep_len = const_cast<uint32_t*>(rep_len); A.mask = mask; A.aux = special; A.salt = salt;
   A.valcol = valcol; A.valdt = valdt; A.op = op; A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
-  const int g = grid_str_pass(ntiles) > 2048 ? 2048 : grid_str_pass(ntiles);
-  if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_str_pass<2, true>), dim3(g), dim3(kBlock), 0, s, A);
-  else hipLaunchKernelGGL((k_str_pass<2, false>), dim3(grid_str_pass(ntiles)), dim3(kBlock), 0, s, A);
+  // the LDS forms run ONE round of workgroups: as many as are resident at once (a workgroup's met caches warm up on its first tiles and its accumulators are
+  // flushed once, and 2048 workgroups over 768 resident places left a third of the chip idle in the last round)
+  auto one_round = [&](const void* fn) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 3; }
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int g = per_cu * cus;
+    if (const char* e = getenv("DFDB_XP_STRGRID")) g = atoi(e);
+    return (int)std::min<int64_t>(g, std::max<int64_t>(1, (ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
+  };
+  if (ngroups <= 64 && !getenv("DFDB_XP_NO64")) hipLaunchKernelGGL((k_str_pass<2, 64>), dim3(one_round((const void*)k_str_pass<2, 64>)), dim3(kBlock), 0, s, A);
+  else if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_str_pass<2, kGroupLds>), dim3(one_round((const void*)k_str_pass<2, kGroupLds>)), dim3(kBlock), 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<2, 0>), dim3(grid_str_pass(ntiles)), dim3(kBlock), 0, s, A);
 }
 // accumulators -> results: min / max images back to values (in place)
 __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
