@@ -21,6 +21,7 @@
 // Integer keys of a small range take the dense form at the end of this file instead (no hashing: a presence bit per value in LDS).
 #include "device_utils.hpp"
 #include <algorithm>
+#include <type_traits>
 #include "kernels.hpp"
 #include "../../include/dfdb_ir.h"
 
@@ -294,6 +295,23 @@ __device__ __forceinline__ void group_add(uint64_t* cnt, uint64_t* val, uint64_t
   else if (op == DFDB_AGG_MIN) atomicMin((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, op));
   else if (op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, op));
 }
+// the same with the operator fixed at compile time (OPK: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max): inside the unrolled row loops of the
+// String pass the runtime form was a tree of scalar compares and branches per row (a 10 000-line kernel; SGPRs spilled to lanes)
+template <int OPK>
+__device__ __forceinline__ void group_add_t(uint64_t* cnt, uint64_t* val, uint64_t gid, uint64_t bits, int kind) {
+  atomicAdd((unsigned long long*)&cnt[gid], 1ull);
+  if (OPK == 1) atomicAdd((unsigned long long*)&val[gid], (unsigned long long)bits);
+  if (OPK == 2) atomicAdd((double*)&val[gid], __longlong_as_double((long long)bits));
+  if (OPK == 3) atomicMin((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, DFDB_AGG_MIN));
+  if (OPK == 4) atomicMax((unsigned long long*)&val[gid], (unsigned long long)order_image(bits, kind, DFDB_AGG_MAX));
+}
+static int opk_of(int op, bool has_val, int kind) {
+  if (!has_val || op == DFDB_AGG_COUNT) return 0;
+  if (op == DFDB_AGG_SUM) return kind == 2 ? 2 : 1;
+  if (op == DFDB_AGG_MIN) return 3;
+  if (op == DFDB_AGG_MAX) return 4;
+  return 0;
+}
 // merge a workgroup's LDS accumulators into the global ones (val_kind: 2 = double sums)
 __device__ __forceinline__ void group_flush(const uint64_t* lcnt, const uint64_t* lval, uint64_t* cnt, uint64_t* val, int ngroups, int op, int val_kind, bool has_val, int nthreads = kBlock) {
   for (int g = threadIdx.x; g < ngroups; g += nthreads) {
@@ -319,7 +337,9 @@ struct StrPassArgs {
   UniqueEntry* ent; uint64_t* rep_off; uint32_t* rep_len; uint64_t mask; uint64_t* aux; uint64_t salt;
   const void* valcol; int valdt, op; uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;       // KIND 2
 };
-template <int KIND, int NGL>                                   // NGL: groups the workgroup's LDS accumulators hold (0: global atomics)
+// NGL: groups the workgroup's LDS accumulators hold (0: global atomics); OPK: group_add_t; V8: the value column is 8 bytes wide (loaded as is; the narrow types'
+// switch, sixteen copies of it in the unrolled loops, lives in the !V8 kernels only)
+template <int KIND, int NGL, int OPK, bool V8>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_str_pass(const StrPassArgs A) {   // (four waves per SIMD: 128 VGPRs)
   constexpr bool LDS = NGL > 0;
   __shared__ uint32_t claims_sh;
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
   __shared__ MetEntry met_e[kWavesPerBlock][kSlots];
   __shared__ uint32_t met_c[kWavesPerBlock][kSlots];
   const int lane = lane_id();
-  const bool has_val = KIND == 2 && A.valcol != nullptr && A.op != DFDB_AGG_COUNT;
+  constexpr bool has_val = KIND == 2 && OPK != 0;
   if (KIND == 0 && threadIdx.x == 0) claims_sh = 0;
   if (KIND == 2 && LDS) for (int g = threadIdx.x; g < A.ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; }
   if (KIND == 0 || (KIND == 2 && LDS)) __syncthreads();
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
   const uint64_t gid_missing = KIND == 2 ? A.aux[1] : 0ull;
   // (properties of the value column, looked at ONCE: inside the unrolled row loops the dtype switch was a chain of scalar compares per row)
   int vkind = 0; if (KIND == 2 && has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);
-  const bool val8 = KIND == 2 && has_val && (A.valdt == DFDB_I64 || A.valdt == DFDB_U64 || A.valdt == DFDB_F64);
+  constexpr bool val8 = KIND == 2 && has_val && V8;
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t tile = A.tile0 + wave; tile < A.tile1; tile += nwaves) {
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         miss = str && !known;
         if (KIND == 2 && on[j] && !miss) {
           const uint64_t gid = s0 >= 0 ? (uint64_t)g32 : gid_missing;
-          if (LDS) group_add(lcnt, lval, gid, bits[j], vkind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits[j], vkind, A.op, has_val);
+          if (LDS) group_add_t<OPK>(lcnt, lval, gid, bits[j], vkind); else group_add_t<OPK>(A.cnt, A.val, gid, bits[j], vkind);
         }
         const uint64_t m = __ballot(miss);
         if (lane == h * 8 + j) missw = m;
@@ -421,9 +441,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
       if (!((m >> lane) & 1ull)) continue;
       const uint8_t* p = A.bytes + off;
       const uint64_t h1 = s0 > 0 ? load8(p) : 0ull, h2 = s0 > 8 ? load8(p + 8) : 0ull;
+      const uint64_t c1 = low_bytes(h1, s0), c2 = low_bytes(h2, s0 - 8);
+      // the cache once more: the FAST step looked at the whole tile before any of its words came here, so on a wave's first tile every row of every word was a
+      // miss — but the words before this one have taught the cache since (a column of ten brands: 1024 hashes, table probes and hot-line atomics per wave became ~64)
+      if (s0 <= kMetMaxLen) {
+        uint32_t g32 = 0;
+        if (met.find(c1, c2, (uint32_t)s0, g32)) {
+          if (KIND == 2) {
+            int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
+            if (LDS) group_add_t<OPK>(lcnt, lval, (uint64_t)g32, bits, kind); else group_add_t<OPK>(A.cnt, A.val, (uint64_t)g32, bits, kind);
+          }
+          continue;
+        }
+      }
       uint64_t key = hash_bytes(p, s0, A.salt, h1, h2);
       if (key == kEmpty) key = 0x1234567ull;                    // (any fixed remap: equal strings still get equal keys)
-      const uint64_t c1 = low_bytes(h1, s0), c2 = low_bytes(h2, s0 - 8);
       if (KIND == 0) {
         const uint64_t r = table_insert(A.ent, A.mask, key, (uint64_t)row, A.aux, key & A.mask);
         if (r != kNoSlot && !(r >> 63)) { A.rep_off[r] = (uint64_t)off; A.rep_len[r] = (uint32_t)s0; claimed++; }   // I claimed the slot: my bytes represent it
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
           const uint64_t gid = A.ent[hs].row;
           if (same && s0 <= kMetMaxLen && gid < 0xFFFFFFFFull) met.put(c1, c2, (uint32_t)s0, (uint32_t)gid, lane);
           int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
-          if (LDS) group_add(lcnt, lval, gid, bits, kind, A.op, has_val); else group_add(A.cnt, A.val, gid, bits, kind, A.op, has_val);
+          if (LDS) group_add_t<OPK>(lcnt, lval, gid, bits, kind); else group_add_t<OPK>(A.cnt, A.val, gid, bits, kind);
         } else if (same && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
       }
     }
@@ -531,8 +563,8 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
   StrPassArgs A{};
   A.sel = bitmap; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = tile0; A.tile1 = tile1;
   A.ent = ent; A.rep_off = rep_off; A.rep_len = rep_len; A.mask = mask; A.aux = aux; A.salt = salt;
-  if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, 0>), g, b, 0, s, A);
-  else hipLaunchKernelGGL((k_str_pass<1, 0>), g, b, 0, s, A);
+  if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, 0, 0, false>), g, b, 0, s, A);
+  else hipLaunchKernelGGL((k_str_pass<1, 0, 0, false>), g, b, 0, s, A);
 }
 
 // ---------------------------------------------------------------- groupreduce (src/tables/aggregate.jl:1-36)
@@ -723,9 +755,35 @@ void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32
     if (const char* e = getenv("DFDB_XP_STRGRID")) g = atoi(e);
     return (int)std::min<int64_t>(g, std::max<int64_t>(1, (ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
   };
-  if (ngroups <= 64 && !getenv("DFDB_XP_NO64")) hipLaunchKernelGGL((k_str_pass<2, 64>), dim3(one_round((const void*)k_str_pass<2, 64>)), dim3(kBlock), 0, s, A);
-  else if (ngroups <= kGroupLds) hipLaunchKernelGGL((k_str_pass<2, kGroupLds>), dim3(one_round((const void*)k_str_pass<2, kGroupLds>)), dim3(kBlock), 0, s, A);
-  else hipLaunchKernelGGL((k_str_pass<2, 0>), dim3(grid_str_pass(ntiles)), dim3(kBlock), 0, s, A);
+  int vkind = 0;
+  switch (valdt) {                                             // (as value_bits sees the column)
+    case DFDB_I8: case DFDB_I16: case DFDB_I32: case DFDB_I64: vkind = 0; break;
+    case DFDB_U8: case DFDB_BOOL: case DFDB_U16: case DFDB_U32: case DFDB_U64: vkind = 1; break;
+    default: vkind = 2; break;
+  }
+  const int opk = opk_of(op, valcol != nullptr, vkind);
+  auto go = [&](auto ngl, auto opk_c) {
+    constexpr int NGL = decltype(ngl)::value, OPK = decltype(opk_c)::value;
+    if (OPK != 0 && (valdt == DFDB_I64 || valdt == DFDB_U64 || valdt == DFDB_F64)) {
+      const int g = NGL ? one_round((const void*)k_str_pass<2, NGL, OPK, true>) : grid_str_pass(ntiles);
+      hipLaunchKernelGGL((k_str_pass<2, NGL, OPK, true>), dim3(g), dim3(kBlock), 0, s, A);
+    } else {
+      const int g = NGL ? one_round((const void*)k_str_pass<2, NGL, OPK, false>) : grid_str_pass(ntiles);
+      hipLaunchKernelGGL((k_str_pass<2, NGL, OPK, false>), dim3(g), dim3(kBlock), 0, s, A);
+    }
+  };
+  auto by_op = [&](auto ngl) {
+    switch (opk) {
+      case 0: go(ngl, std::integral_constant<int, 0>{}); break;
+      case 1: go(ngl, std::integral_constant<int, 1>{}); break;
+      case 2: go(ngl, std::integral_constant<int, 2>{}); break;
+      case 3: go(ngl, std::integral_constant<int, 3>{}); break;
+      default: go(ngl, std::integral_constant<int, 4>{}); break;
+    }
+  };
+  if (ngroups <= 64) by_op(std::integral_constant<int, 64>{});
+  else if (ngroups <= kGroupLds) by_op(std::integral_constant<int, kGroupLds>{});
+  else by_op(std::integral_constant<int, 0>{});
 }
 // accumulators -> results: min / max images back to values (in place)
 __global__ void k_group_finish(uint64_t* val, int64_t ng, int kind, int op) {
