@@ -341,6 +341,8 @@ void launch_str_match(hipStream_t s, const int32_t* sizes, const int64_t* tile_o
 // (rows 16l..16l+15) and expands it into a 2-KB LDS list of selected in-tile positions (wave prefix-sum of
 // popcounts), so everything after that is proportional to the SELECTED rows.
 
+// tiles a wave looks at together (their emptiness decided by one load): as many as leave ~8192 waves busy — a dense selection of a small table keeps a wave per tile
+static int gather_group(int64_t nt) { int g = 1; while (g < 64 && nt / (g * 2) >= 8192) g *= 2; return g; }
 // stage the selected positions of `tile`; returns how many
 __device__ __forceinline__ uint32_t stage_tile_positions(const uint64_t* __restrict__ bitmap, int64_t tile, uint16_t* pos, int lane) {
   uint32_t w = (uint32_t)(bitmap[tile * 16 + (lane >> 2)] >> ((lane & 3) * 16)) & 0xffffu;
@@ -357,14 +359,22 @@ __device__ __forceinline__ uint32_t stage_tile_positions(const uint64_t* __restr
 // pass 1: selected sizes -> out_sizes at the tile's row offset, plus the selected byte total of the tile
 __global__ __launch_bounds__(kBlock) void k_str_gather_sizes(const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ prefix,
                                                              const int32_t* __restrict__ sizes, int32_t* __restrict__ out_sizes,
-                                                             uint32_t* __restrict__ sel_tile_bytes, int64_t ntiles, int64_t out_cap) {
+                                                             uint32_t* __restrict__ sel_tile_bytes, int64_t ntiles, int64_t out_cap, int group) {
   __shared__ uint16_t pos_sh[kWavesPerBlock][1024];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   uint16_t* pos = pos_sh[wib];
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+  // `group` (<= 64) tiles at a time: their selected-row counts come out of the prefix sums with one coalesced load, the empty ones get their zero and are never looked at (a
+  // sparse selection — ten first rows in 5e8 — used to pay one dependent bitmap load per tile: 60 us per pass)
+  for (int64_t c0 = wave * group; c0 < ntiles; c0 += nwaves * group) {
+   const int64_t tl = c0 + lane;
+   const bool mine = lane < group && tl < ntiles;
+   const bool some = mine && prefix[tl + 1] > prefix[tl];
+   if (mine && !some) sel_tile_bytes[tl] = 0;
+   for (uint64_t todo = __ballot(some); todo; todo &= todo - 1) {
+    const int64_t tile = c0 + __builtin_ctzll(todo);
     const uint32_t total = stage_tile_positions(bitmap, tile, pos, lane);
     const int64_t obase = (int64_t)prefix[tile];
     const int32_t* ts = sizes + tile * kTile;
@@ -377,13 +387,15 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_sizes(const uint64_t* __r
     bsum = wave_sum(bsum);
     if (lane == 0) sel_tile_bytes[tile] = bsum;
     wave_lds_fence();
+   }
   }
 }
 void launch_str_gather_sizes(hipStream_t s, const uint64_t* bitmap, const uint64_t* prefix, const int32_t* sizes, int32_t* out_sizes,
                              uint32_t* sel_tile_bytes, int64_t nrows, int64_t out_cap) {
   const int64_t nt = (nrows + kTile - 1) / kTile;
   if (nt == 0) return;
-  hipLaunchKernelGGL(k_str_gather_sizes, dim3(grid_for(nt)), dim3(kBlock), 0, s, bitmap, prefix, sizes, out_sizes, sel_tile_bytes, nt, out_cap);
+  const int group = gather_group(nt);
+  hipLaunchKernelGGL(k_str_gather_sizes, dim3(grid_for((nt + group - 1) / group)), dim3(kBlock), 0, s, bitmap, prefix, sizes, out_sizes, sel_tile_bytes, nt, out_cap, group);
 }
 
 // pass 2: bytes.  The tile's per-row source offsets (exclusive prefix of the sizes of ALL rows) go to LDS once
@@ -392,7 +404,7 @@ void launch_str_gather_sizes(hipStream_t s, const uint64_t* bitmap, const uint64
 __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __restrict__ bitmap, const int32_t* __restrict__ sizes,
                                                              const int64_t* __restrict__ tile_off, const uint8_t* __restrict__ bytes,
                                                              const uint64_t* __restrict__ out_tile_off, uint8_t* __restrict__ out_bytes,
-                                                             int64_t nrows, int64_t ntiles, int64_t out_cap) {
+                                                             int64_t nrows, int64_t ntiles, int64_t out_cap, int group) {
   __shared__ uint16_t pos_sh[kWavesPerBlock][1024];
   __shared__ uint32_t pre_sh[kWavesPerBlock][1024];
   const int lane = lane_id();
@@ -401,7 +413,11 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __r
   uint32_t* pre = pre_sh[wib];
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+  for (int64_t c0 = wave * group; c0 < ntiles; c0 += nwaves * group) {      // (`group` tiles at a time, as in pass 1: a tile without selected BYTES has nothing to copy)
+   const int64_t tl = c0 + lane;
+   const bool some = lane < group && tl < ntiles && out_tile_off[tl + 1] > out_tile_off[tl];
+   for (uint64_t todo = __ballot(some); todo; todo &= todo - 1) {
+    const int64_t tile = c0 + __builtin_ctzll(todo);
     const uint32_t total = stage_tile_positions(bitmap, tile, pos, lane);
     if (total == 0) { wave_lds_fence(); continue; }        // wave-uniform: late materialization of the arena
     const int64_t base = tile * kTile;
@@ -436,14 +452,16 @@ __global__ __launch_bounds__(kBlock) void k_str_gather_bytes(const uint64_t* __r
       drun += (int64_t)__shfl(incl, 63, 64);
     }
     wave_lds_fence();
+   }
   }
 }
 void launch_str_gather_bytes(hipStream_t s, const uint64_t* bitmap, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes,
                              const uint64_t* out_tile_off, uint8_t* out_bytes, int64_t nrows, int64_t out_bytes_cap) {
   const int64_t nt = (nrows + kTile - 1) / kTile;
   if (nt == 0) return;
-  hipLaunchKernelGGL(k_str_gather_bytes, dim3(grid_for(nt)), dim3(kBlock), 0, s, bitmap, sizes, tile_off, bytes, out_tile_off, out_bytes, nrows,
-                     nt, out_bytes_cap);
+  const int group = gather_group(nt);
+  hipLaunchKernelGGL(k_str_gather_bytes, dim3(grid_for((nt + group - 1) / group)), dim3(kBlock), 0, s, bitmap, sizes, tile_off, bytes, out_tile_off, out_bytes, nrows,
+                     nt, out_bytes_cap, group);
 }
 
 // projection of a String column whose selected rows K5 kept (CAP): per 1024-row tile a contiguous copy of its sizes and bytes
