@@ -711,6 +711,16 @@ def f_rows_legs(L, dfdb, sc, rank):
     res["unique_hash_table"] = {"rows": n, "distinct": len(u), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
                                 "what": "the same unique with ctx option unique_dense = 0: open-addressing table of {key, first row} sized by the distinct values as they turn up (what Float64 keys, "
                                         "wide-ranged integers and String hashes take); best of 2"}
+    # ---- unique over a Float64 key (x * 0.5, made on the device: 1e6 distinct values): floats always take the hash table
+    t.add_column_from("f", t.x * 0.5)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        uf = t.f.unique()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res["unique_float_key"] = {"rows": n, "distinct": len(uf), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
+                               "what": "unique(t.f), f = x * 0.5 (Float64, 1e6 distinct values): the hash table of isequal images; best of 2"}
     # ---- groupreduce by an integer key: 5000 groups (x mod 5000, made on the device) over the same 1e9 rows, sum of x
     t.add_column_from("k", t.x % 5000)
     best, g = None, None
@@ -729,6 +739,17 @@ def f_rows_legs(L, dfdb, sc, rank):
     t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
     t.add_generated("s", dfdb.GEN_STR_BRANDS10, seed_of(0), n, row_first=rank * n)
     t.add_generated("a", dfdb.GEN_I64_MOD1M, seed_of(1), n, row_first=rank * n)
+    best, us = None, None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        us = t.s.unique()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    byts = n * (4 + 5.4)
+    res["unique_string"] = {"rows": n, "distinct": len(us), "seconds": best, "rows_per_s": n / best,
+                            "roofline": {"bound": "hbm", "achieved": 2 * byts / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": 2 * byts / best / 1e9 / L.peak},
+                            "what": "unique(t.s) over a 10-value flat String column: insert pass (hash of every string a wave has not met, {key, first row} table) + the pass that compares "
+                                    "every row with its slot's representative; bytes = the key column (sizes + bytes) twice; best of 3"}
     for key in ("groupreduce", "groupreduce_dictionary"):
         if key.endswith("dictionary"):
             t.build_dictionary("s")

@@ -336,6 +336,7 @@ struct StrPassArgs {
   const uint64_t* sel; const int32_t* sizes; const int64_t* tile_off; const uint8_t* bytes; int64_t nrows, tile0, tile1;
   UniqueEntry* ent; uint64_t* rep_off; uint32_t* rep_len; uint64_t mask; uint64_t* aux; uint64_t salt;
   const void* valcol; int valdt, op; uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;       // KIND 2
+  int maybe;                                                   // KIND 1: the table may not hold every string (an optimistic unique): an unknown one raises aux[kAuxAbort]
 };
 // NGL: groups the workgroup's LDS accumulators hold (0: global atomics); OPK: group_add_t; V8: the value column is 8 bytes wide (loaded as is; the narrow types'
 // switch, sixteen copies of it in the unrolled loops, lives in the !V8 kernels only)
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         if (r != kNoSlot && !(r >> 63)) { A.rep_off[r] = (uint64_t)off; A.rep_len[r] = (uint32_t)s0; claimed++; }   // I claimed the slot: my bytes represent it
         if (r != kNoSlot && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
       } else {
-        const uint64_t hs = KIND == 2 ? table_find_maybe(A.ent, A.mask, key, key & A.mask) : table_find(A.ent, A.mask, key, key & A.mask);
-        if (KIND == 2 && hs == kNoSlot) { __atomic_store_n(&A.aux[kAuxAbort], 1ull, __ATOMIC_RELAXED); continue; }   // a string the (optimistically filled) table does not hold: the host runs everything again
+        const uint64_t hs = (KIND == 2 || A.maybe) ? table_find_maybe(A.ent, A.mask, key, key & A.mask) : table_find(A.ent, A.mask, key, key & A.mask);
+        if (hs == kNoSlot) { __atomic_store_n(&A.aux[kAuxAbort], 1ull, __ATOMIC_RELAXED); continue; }   // a string the (optimistically filled) table does not hold: the host runs everything again
         const bool same = !A.rep_off || same_bytes(p, s0, A.bytes + A.rep_off[hs], A.rep_len[hs]);
         if (!same) atomicOr(collision, 1);                      // two different strings, one key: the host repeats with another salt
         if (KIND == 2) {
@@ -563,6 +564,7 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
   StrPassArgs A{};
   A.sel = bitmap; A.sizes = sizes; A.tile_off = tile_off; A.bytes = bytes; A.nrows = nrows; A.tile0 = tile0; A.tile1 = tile1;
   A.ent = ent; A.rep_off = rep_off; A.rep_len = rep_len; A.mask = mask; A.aux = aux; A.salt = salt;
+  A.maybe = pass == 3 ? 1 : 0;
   if (pass == 0) hipLaunchKernelGGL((k_str_pass<0, 0, 0, false>), g, b, 0, s, A);
   else hipLaunchKernelGGL((k_str_pass<1, 0, 0, false>), g, b, 0, s, A);
 }

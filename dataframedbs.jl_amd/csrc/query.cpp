@@ -1337,7 +1337,7 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       const int64_t t1 = bounds[c];
       if (t1 <= t0) continue;
       uint64_t r = 0;
-      if (c == 2 && is_str && T.defer_verify && T.allow_optimistic && claims_c0 != ~0ull) { T.optimistic = true; break; }
+      if (c == 2 && is_str && T.allow_optimistic && claims_c0 != ~0ull) { T.optimistic = true; break; }
       for (;;) {
         insert(t0, t1);
         read_state(&r, t1);
@@ -1354,11 +1354,16 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       t0 = t1;
     }
     if (!is_str || T.defer_verify) break;
-    launch_unique_str(s, 1, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
+    // the pass that compares every selected row with its slot's representative.  After an optimistic insert it also meets the rows that were never inserted: a string
+    // the table does not hold raises the abort word and everything runs again with every row inserted (as groupreduce's accumulate pass does it)
+    if (T.optimistic) HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));
+    launch_unique_str(s, T.optimistic ? 3 : 1, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(),
                       t->nrows, 0, nt, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, T.aux.as<uint64_t>(), T.salt);
-    int hit = 0;
+    int hit = 0; uint64_t unknown = 0;
     HIP_CHECK(hipMemcpyAsync(&hit, (char*)T.aux.p + 32, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&unknown, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
+    if (T.optimistic && (unknown != 0 || ctx_option(ctx, "groupreduce_optimistic", 1) == 2)) { T.allow_optimistic = false; continue; }   // (2: the test knob, as in groupreduce)
     if (!hit) break;                                                   // no two different strings shared a key: the table is exact
     if (tries >= 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
   }
@@ -1388,6 +1393,7 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
   UniqueTables local;
   UniqueTables& T = keep ? *keep : local;
   T.is_str = dt_base(col.dtype) == DFDB_STRING; T.dense = false;
+  if (!keep) local.allow_optimistic = ctx_option(ctx, "groupreduce_optimistic", 1) != 0;      // (unique's own compare pass meets every row: the same bargain)
   {
     LaunchTimer lt(ctx, "unique");
     const bool dense = !T.is_str && unique_dense_dtype(dt_base(col.dtype)) && ctx_option(ctx, "unique_dense", 1) != 0 && unique_dense(q, col, T);

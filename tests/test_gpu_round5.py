@@ -365,6 +365,12 @@ def test_groupreduce_by_a_string_key_skips_the_inserts_it_does_not_need(oracle, 
                     m = arr == v
                     assert c_ == int(m.sum()) and s_ == int(a[m].sum()), (name, opt, v)
                 launches = after - before
+                # plain unique over the same column strikes the same bargain (its compare pass meets every row)
+                b2, _ = ctx.profile_get("unique_insert")
+                u = list(t.s.unique())
+                a2, _ = ctx.profile_get("unique_insert")
+                assert u == order, (name, opt)
+                assert a2 - b2 == launches, (name, opt, a2 - b2, launches)
                 if opt == 1 and name == "early":
                     assert launches == 2, launches                # two prefix chunks, the rest skipped
                 elif opt == 0:
