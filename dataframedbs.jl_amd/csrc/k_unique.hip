@@ -602,11 +602,13 @@ struct AccArgs {
   uint64_t lo; const uint64_t* gids;                                    // SRC 2 (special[1]: the group of missing)
   uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;
 };
-template <int NG, int SRC>
+// OPK: group_add_t's operator; W8: the value column AND (SRC 0 / 2) the key column are 8-byte integers or doubles, loaded as they are — the dtype switches of value_bits
+// and key_fixed, copied four times by the unrolled trip, stay in the !W8 kernels
+template <int NG, int SRC, int OPK, bool W8>
 __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(const AccArgs A) {
   __shared__ uint64_t lcnt[NG ? NG : 1], lval[NG ? NG : 1];
   const int nthreads = NG > kGroupLds ? 1024 : kBlock;
-  const bool has_val = A.valcol != nullptr && A.op != DFDB_AGG_COUNT;
+  const bool has_val = OPK < 0 ? (A.valcol != nullptr && A.op != DFDB_AGG_COUNT) : OPK != 0;      // (OPK -1: the operator at run time — the !W8 kernels)
   if (NG) { for (int g = threadIdx.x; g < A.ngroups; g += nthreads) { lcnt[g] = 0; lval[g] = A.val_init; } __syncthreads(); }
   // four rows per thread and trip, stage by stage (selection bits, keys, group numbers, values, adds): a row's loads depend on each other, the four rows' do not —
   // one row at a time the pass ran at the latency of three dependent loads per trip (5e8 rows by dictionary codes: 5 ms)
@@ -621,8 +623,11 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
     for (int k = 0; k < U; k++) {
       const int64_t row = row0 + k * stride;
       miss[k] = SRC != 1 && on[k] && A.missing && ((A.missing[row >> 6] >> (row & 63)) & 1ull);
-      key[k] = !on[k] ? 0ull : (SRC == 1 ? (uint64_t)A.codes[row] : key_fixed(A.keycol, A.keydt, row));
-      int kind = 0; bits[k] = (on[k] && has_val) ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
+      if (SRC == 1) key[k] = on[k] ? (uint64_t)A.codes[row] : 0ull;
+      else if (W8 && A.keydt != DFDB_F64) key[k] = on[k] ? ((const uint64_t*)A.keycol)[row] : 0ull;
+      else key[k] = on[k] ? key_fixed(A.keycol, A.keydt, row) : 0ull;
+      if (W8) bits[k] = (on[k] && has_val) ? ((const uint64_t*)A.valcol)[row] : 0ull;
+      else { int kind = 0; bits[k] = (on[k] && has_val) ? value_bits(A.valcol, A.valdt, row, kind) : 0ull; }
     }
 #pragma unroll
     for (int k = 0; k < U; k++) {
@@ -636,7 +641,8 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
 #pragma unroll
     for (int k = 0; k < U; k++) {
       if (!on[k]) continue;
-      if (NG) group_add(lcnt, lval, gid[k], bits[k], vkind, A.op, has_val); else group_add(A.cnt, A.val, gid[k], bits[k], vkind, A.op, has_val);
+      if (OPK < 0) { if (NG) group_add(lcnt, lval, gid[k], bits[k], vkind, A.op, has_val); else group_add(A.cnt, A.val, gid[k], bits[k], vkind, A.op, has_val); }
+      else if (NG) group_add_t<(OPK < 0 ? 0 : OPK)>(lcnt, lval, gid[k], bits[k], vkind); else group_add_t<(OPK < 0 ? 0 : OPK)>(A.cnt, A.val, gid[k], bits[k], vkind);
     }
   }
   if (NG) {
@@ -649,9 +655,30 @@ template <int SRC>
 static void launch_group_acc(hipStream_t s, const AccArgs& A) {
   if (A.nrows <= 0) return;
   const int64_t b256 = (A.nrows + kBlock - 1) / kBlock;
-  if (A.ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_acc<kGroupLds, SRC>), dim3((unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
-  else if (A.ngroups <= kGroupLdsBig) hipLaunchKernelGGL((k_group_acc<kGroupLdsBig, SRC>), dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024))), dim3(1024), 0, s, A);
-  else hipLaunchKernelGGL((k_group_acc<0, SRC>), dim3((unsigned)std::min<int64_t>(8192, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
+  int vkind = 0;
+  switch (A.valdt) {                                           // (as value_bits sees the column)
+    case DFDB_I8: case DFDB_I16: case DFDB_I32: case DFDB_I64: vkind = 0; break;
+    case DFDB_U8: case DFDB_BOOL: case DFDB_U16: case DFDB_U32: case DFDB_U64: vkind = 1; break;
+    default: vkind = 2; break;
+  }
+  const int opk = opk_of(A.op, A.valcol != nullptr, vkind);
+  const bool v8 = opk == 0 || A.valdt == DFDB_I64 || A.valdt == DFDB_U64 || A.valdt == DFDB_F64;
+  const bool k8 = SRC == 1 || A.keydt == DFDB_I64 || A.keydt == DFDB_U64 || A.keydt == DFDB_F64;
+  auto go = [&](auto opk_c, auto w8_c) {
+    constexpr int OPK = decltype(opk_c)::value; constexpr bool W8 = decltype(w8_c)::value;
+    if (A.ngroups <= kGroupLds) hipLaunchKernelGGL((k_group_acc<kGroupLds, SRC, OPK, W8>), dim3((unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
+    else if (A.ngroups <= kGroupLdsBig) hipLaunchKernelGGL((k_group_acc<kGroupLdsBig, SRC, OPK, W8>), dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024))), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((k_group_acc<0, SRC, OPK, W8>), dim3((unsigned)std::min<int64_t>(8192, std::max<int64_t>(1, b256))), dim3(kBlock), 0, s, A);
+  };
+  auto by_w = [&](auto opk_c) { go(opk_c, std::true_type{}); };
+  if (!(v8 && k8)) { go(std::integral_constant<int, -1>{}, std::false_type{}); return; }      // narrow keys or values: one kernel per (NG, SRC), operator at run time
+  switch (opk) {
+    case 0: by_w(std::integral_constant<int, 0>{}); break;
+    case 1: by_w(std::integral_constant<int, 1>{}); break;
+    case 2: by_w(std::integral_constant<int, 2>{}); break;
+    case 3: by_w(std::integral_constant<int, 3>{}); break;
+    default: by_w(std::integral_constant<int, 4>{}); break;
+  }
 }
 
 void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix) {
@@ -662,7 +689,7 @@ void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* s
 // table (the generic path sizes one by the number of selected rows: 30 GB for 5e8 rows of ten brands).
 // A wave walks its tiles and the rows of a tile in increasing order, so the first time it meets a code is its smallest row for that code: a per-wave
 // bit set in LDS keeps every later meeting away from the global atomicMin (ten brands over 5e8 rows: <= waves x 10 atomics, not 5e8).
-__global__ __launch_bounds__(kBlock) void k_dict_first_rows(const uint64_t* __restrict__ sel, const uint16_t* __restrict__ codes, int64_t nrows, int64_t ntiles,
+__global__ __launch_bounds__(kBlock) void k_dict_first_rows(const uint64_t* __restrict__ sel, const uint16_t* __restrict__ codes, int64_t nrows, int64_t tile0, int64_t ntiles,
                                                             unsigned long long* __restrict__ first, int lut_words) {
   __shared__ uint32_t seen_sh[kBlock / 64][2048];
   uint32_t* seen = seen_sh[threadIdx.x >> 6];
@@ -670,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_dict_first_rows(const uint64_t* __re
   for (int k = lane; k < lut_words; k += 64) seen[k] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (kBlock / 64);
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+  for (int64_t tile = tile0 + wave; tile < ntiles; tile += nwaves) {
     const uint64_t mine = lane < 16 ? sel[tile * 16 + lane] : 0ull;
     if (__ballot(mine != 0) == 0) continue;
     // a lane takes 8 CONSECUTIVE rows per half tile (one 16-byte load: 1 KB per wave instruction; 2-byte loads per lane were 128 B per instruction, 1.9 ms per
@@ -706,10 +733,15 @@ __global__ __launch_bounds__(kBlock) void k_dict_first_rows(const uint64_t* __re
     }
   }
 }
-void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* codes, int64_t nrows, uint64_t* first, int dict_n) {
-  const int64_t ntiles = (nrows + 1023) / 1024;
-  if (ntiles == 0) return;
-  hipLaunchKernelGGL(k_dict_first_rows, dim3(grid_tiles(ntiles) > 2048 ? 2048 : grid_tiles(ntiles)), dim3(kBlock), 0, s, sel, codes, nrows, ntiles, (unsigned long long*)first, (dict_n + 31) / 32);
+// (the tiles [tile0, tile1): a first row only ever gets smaller, so the column can be walked in pieces)
+void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* codes, int64_t nrows, uint64_t* first, int dict_n, int64_t tile0, int64_t tile1) {
+  const int64_t ntiles = std::min<int64_t>((nrows + 1023) / 1024, tile1);
+  if (ntiles <= tile0) return;
+  // every wave pays one global atomicMin per code it meets, all of them on the same few words: 8192 waves x 10 brands were 0.4 ms of serialised atomics whatever the
+  // rows.  A short range (the head that dict_unique walks first) goes to few waves with 32 tiles each — their later tiles are filtered by the wave's own seen-set
+  int g = grid_tiles(ntiles - tile0) > 2048 ? 2048 : grid_tiles(ntiles - tile0);
+  if (ntiles - tile0 <= 8192) g = (int)std::max<int64_t>(1, (ntiles - tile0 + 127) / 128);
+  hipLaunchKernelGGL(k_dict_first_rows, dim3(g), dim3(kBlock), 0, s, sel, codes, nrows, tile0, ntiles, (unsigned long long*)first, (dict_n + 31) / 32);
 }
 // the bitmap that holds exactly `rows` (ascending, n <= 65 535): what unique leaves behind
 __global__ void k_set_rows(const uint64_t* __restrict__ rows, int n, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts) {

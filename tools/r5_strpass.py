@@ -9,12 +9,16 @@ import dfdb
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 500_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = dfdb.default_context(0)
+use_dict = "dict" in sys.argv[3:]
 for k in sys.argv[3:]:
-    a, b = k.split("="); ctx.set_option(a, int(b))
+    if "=" in k:
+        a, b = k.split("="); ctx.set_option(a, int(b))
 t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
 t.add_generated("s", dfdb.GEN_STR_BRANDS10, 0x9E3779B97F4A7C15, n)
 t.add_generated("a", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C16, n)
 ctx.set_option("profile", 1) if "profile" in os.environ.get("DFDB_STRPASS", "") else None
+if use_dict:
+    t.build_dictionary("s")
 best = None
 for _ in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
