@@ -732,7 +732,8 @@ def f_rows_legs(L, dfdb, sc, rank):
     res["groupreduce_int_key"] = {"rows": n, "groups": len(g), "seconds": best, "rows_per_s": n / best,
                                   "roofline": {"bound": "hbm", "achieved": n * 24 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 24 / best / 1e9 / L.peak},
                                   "what": "groupreduce(t, (:k,); out = :x => Sum()), k = x mod 5000 (Int64): the keys' dense form (presence bits in LDS, no hash table) numbers the groups, the "
-                                          "accumulate pass adds into 144 KB of LDS accumulators per CU; bytes = the key column twice (presence pass, accumulate pass) + the value column; best of 3"}
+                                          "accumulate pass adds into LDS accumulators (one 1024-thread workgroup per CU) and looks the group numbers up in an LDS copy of the table's occupied span; "
+                                          "bytes = the key column twice (presence pass, accumulate pass) + the value column; best of 3"}
     t.close()
     # ---- groupreduce by a String key, flat and with the dictionary
     n = int(500_000_000 * sc)

@@ -616,19 +616,23 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
   const int64_t stride = (int64_t)gridDim.x * nthreads;
   int vkind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);      // (the value kind is a property of the column)
   for (int64_t row0 = (int64_t)blockIdx.x * nthreads + threadIdx.x; row0 < A.nrows; row0 += U * stride) {
-    bool on[U], miss[U]; uint64_t key[U], gid[U], bits[U];
-#pragma unroll
-    for (int k = 0; k < U; k++) { const int64_t row = row0 + k * stride; on[k] = row < A.nrows && ((A.sel[row >> 6] >> (row & 63)) & 1ull); }
+    bool on[U], miss[U]; uint64_t key[U], gid[U], bits[U], w[U], mw[U];
+    // every load of a trip is issued before any is looked at (round 5): the selection word, the key and the value of a row do not wait for each other — a key loaded only
+    // where its selection bit is set is a second dependent round trip per trip (rows that are off read a key nobody uses)
 #pragma unroll
     for (int k = 0; k < U; k++) {
       const int64_t row = row0 + k * stride;
-      miss[k] = SRC != 1 && on[k] && A.missing && ((A.missing[row >> 6] >> (row & 63)) & 1ull);
-      if (SRC == 1) key[k] = on[k] ? (uint64_t)A.codes[row] : 0ull;
-      else if (W8 && A.keydt != DFDB_F64) key[k] = on[k] ? ((const uint64_t*)A.keycol)[row] : 0ull;
-      else key[k] = on[k] ? key_fixed(A.keycol, A.keydt, row) : 0ull;
-      if (W8) bits[k] = (on[k] && has_val) ? ((const uint64_t*)A.valcol)[row] : 0ull;
-      else { int kind = 0; bits[k] = (on[k] && has_val) ? value_bits(A.valcol, A.valdt, row, kind) : 0ull; }
+      const bool inb = row < A.nrows;
+      w[k] = inb ? A.sel[row >> 6] : 0ull;
+      mw[k] = (SRC != 1 && inb && A.missing) ? A.missing[row >> 6] : 0ull;
+      if (SRC == 1) key[k] = inb ? (uint64_t)A.codes[row] : 0ull;
+      else if (W8 && A.keydt != DFDB_F64) key[k] = inb ? ((const uint64_t*)A.keycol)[row] : 0ull;
+      else key[k] = inb ? key_fixed(A.keycol, A.keydt, row) : 0ull;
+      if (W8) bits[k] = (inb && has_val) ? ((const uint64_t*)A.valcol)[row] : 0ull;
+      else { int kind = 0; bits[k] = (inb && has_val) ? value_bits(A.valcol, A.valdt, row, kind) : 0ull; }
     }
+#pragma unroll
+    for (int k = 0; k < U; k++) { const int64_t row = row0 + k * stride; on[k] = (w[k] >> (row & 63)) & 1ull; miss[k] = on[k] && ((mw[k] >> (row & 63)) & 1ull); }
 #pragma unroll
     for (int k = 0; k < U; k++) {
       gid[k] = 0;
@@ -850,6 +854,7 @@ constexpr int kDenseBlock = 1024;
 constexpr int kDenseWords = 39936;                                   // u32 words of LDS per workgroup (156 KB of the CU's 160)
 constexpr int64_t kDenseRange = (int64_t)kDenseWords * 32;
 constexpr int kAuxMissing = 1, kAuxOutside = 5, kAuxDistinct = 6, kAuxFound = 7, kAuxMin = 8, kAuxMax = 9, kAuxFoundBefore = 10;
+constexpr int kAuxSpanLo = 11, kAuxSpanHi = 12;            // smallest / largest value index with its presence bit set (k_dense_count): the span the keys really cover
 
 int64_t unique_dense_max_range() { return kDenseRange; }
 bool unique_dense_dtype(int dtype) {
@@ -921,10 +926,16 @@ __global__ __launch_bounds__(kDenseBlock) void k_dense_presence(const uint64_t* 
   for (int i = threadIdx.x; i < words; i += kDenseBlock) { const uint32_t b = bits[i]; if (b) atomicOr(&present[i], b); }
 }
 __global__ __launch_bounds__(kBlock) void k_dense_count(const uint32_t* __restrict__ present, int words, uint64_t* aux) {
-  uint32_t n = 0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < words; i += gridDim.x * kBlock) n += (uint32_t)__popc(present[i]);
-  for (int d = 32; d; d >>= 1) n += __shfl_xor(n, d, 64);
-  if (lane_id() == 0 && n) atomicAdd((unsigned long long*)&aux[kAuxDistinct], (unsigned long long)n);
+  uint32_t n = 0, lo = 0xFFFFFFFFu, hi = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < words; i += gridDim.x * kBlock) {
+    const uint32_t b = present[i];
+    if (b) { n += (uint32_t)__popc(b); lo = min(lo, (uint32_t)i * 32u + (uint32_t)__builtin_ctz(b)); hi = max(hi, (uint32_t)i * 32u + 31u - (uint32_t)__builtin_clz(b)); }
+  }
+  for (int d = 32; d; d >>= 1) { n += __shfl_xor(n, d, 64); lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64)); }
+  if (lane_id() == 0 && n) {
+    atomicAdd((unsigned long long*)&aux[kAuxDistinct], (unsigned long long)n);
+    atomicMin((unsigned long long*)&aux[kAuxSpanLo], (unsigned long long)lo); atomicMax((unsigned long long*)&aux[kAuxSpanHi], (unsigned long long)hi);
+  }
 }
 
 // (three round trips per tile — the keys, their table entries, the atomics — each sixteen deep: with a returning atomic inside the loop over the sixteen words
@@ -1033,11 +1044,87 @@ void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, 
 void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint64_t* aux, const uint64_t* ubits, const uint64_t* uprefix) {
   hipLaunchKernelGGL(k_dense_group_ids, dim3((range + 1 + kBlock) / kBlock), dim3(kBlock), 0, s, first, range, aux, ubits, uprefix);
 }
+// The dense form with its group-number table IN LDS (round 5): per row the pass looked its key's group up in `gids` — a random 8-byte load per lane, 64 different lines
+// per wave instruction (64 cycles of the CU's vector cache each, and a second dependent round trip per trip of rows): 1e9 rows by 5000 keys ran at 3.2 TB/s.  When the
+// table (4 bytes per value of the keys' range) fits beside the accumulators it is copied into LDS once per workgroup and the lookup is a ds_read.
+// Dynamic LDS: [ngroups] counts, [ngroups] values, [range + 1] group numbers (the last: missing).  8-byte integer keys and 8-byte values (or none).
+template <int OPK>
+__global__ __launch_bounds__(1024) void k_group_acc_dense_lds(const AccArgs A, uint32_t range, int ngp) {
+  extern __shared__ uint64_t dyn_sh[];
+  uint64_t* lcnt = dyn_sh; uint64_t* lval = dyn_sh + ngp; uint32_t* tbl = (uint32_t*)(dyn_sh + 2 * ngp);
+  constexpr bool has_val = OPK != 0;
+  for (int g = threadIdx.x; g < A.ngroups; g += 1024) { lcnt[g] = 0; lval[g] = A.val_init; }
+  for (uint32_t i = threadIdx.x; i < range; i += 1024) tbl[i] = (uint32_t)A.gids[i];
+  if (threadIdx.x == 0) tbl[range] = (uint32_t)A.special[1];
+  __syncthreads();
+  // every load of a trip is issued before any of them is looked at: the selection word, the key and the value of a row do not wait for each other (a key loaded only
+  // where the selection bit is set costs a second dependent round trip per trip: the counters showed waves waiting 89 % of their cycles with ~37 lines in flight per CU)
+  constexpr int U = 8;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  int vkind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);
+  for (int64_t row0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; row0 < A.nrows; row0 += U * stride) {
+    uint64_t w[U], mw[U], key[U], bits[U]; uint32_t gid[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const int64_t row = row0 + k * stride;
+      const bool inb = row < A.nrows;
+      w[k] = inb ? A.sel[row >> 6] : 0ull;
+      mw[k] = (inb && A.missing) ? A.missing[row >> 6] : 0ull;
+      key[k] = inb ? ((const uint64_t*)A.keycol)[row] : 0ull;
+      bits[k] = (inb && has_val) ? ((const uint64_t*)A.valcol)[row] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const int64_t row = row0 + k * stride;
+      const bool on = (w[k] >> (row & 63)) & 1ull, miss = (mw[k] >> (row & 63)) & 1ull;
+      const uint64_t idx = key[k] - A.lo;
+      gid[k] = tbl[(on && !miss && idx < (uint64_t)range) ? (uint32_t)idx : range];      // (missing, and rows that are off: the table's last entry)
+      w[k] = on ? 1ull : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) if (w[k]) group_add_t<OPK>(lcnt, lval, (uint64_t)gid[k], bits[k], vkind);
+  }
+  __syncthreads();
+  group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, vkind, has_val, 1024);
+}
+template <int OPK>
+static bool try_dense_lds(hipStream_t s, const AccArgs& A, uint32_t range) {
+  const int ngp = (A.ngroups + 1) & ~1;
+  const size_t lds = (size_t)ngp * 16 + ((size_t)range + 2) * 4;
+  if (lds > 156 * 1024) return false;
+  static bool raised[8] = {};                                  // (per operator: the attribute belongs to the function)
+  if (lds > 64 * 1024 && !raised[OPK]) {
+    if (hipFuncSetAttribute((const void*)k_group_acc_dense_lds<OPK>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+    raised[OPK] = true;
+  }
+  const unsigned g = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024));
+  hipLaunchKernelGGL((k_group_acc_dense_lds<OPK>), dim3(g), dim3(1024), lds, s, A, range, ngp);
+  return true;
+}
 void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
-                                   int64_t nrows, uint64_t lo, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init) {
+                                   int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val,
+                                   int64_t ngroups, uint64_t val_init) {
   AccArgs A{};
   A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.lo = lo; A.gids = gids; A.special = aux;
   A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
+  if (nrows > 0 && ngroups > kGroupLds && (keydt == DFDB_I64 || keydt == DFDB_U64) && span_lo <= span_hi && span_hi < range) {   // (few groups: the 256-thread kernels, several workgroups per CU)
+    // the table is laid out for the widest span the form can hold; the keys that are there cover [span_lo, span_hi] of it (k_dense_count) and only that goes to LDS
+    AccArgs B = A;
+    B.lo = lo + span_lo; B.gids = gids + span_lo;
+    const uint32_t brange = (uint32_t)(span_hi - span_lo + 1);
+    int vkind = (valdt == DFDB_F64) ? 2 : (valdt == DFDB_U64 ? 1 : 0);
+    const int opk = opk_of(op, valcol != nullptr, vkind);
+    const bool v8 = opk == 0 || valdt == DFDB_I64 || valdt == DFDB_U64 || valdt == DFDB_F64;
+    bool done = false;
+    if (v8) switch (opk) {
+      case 0: done = try_dense_lds<0>(s, B, brange); break;
+      case 1: done = try_dense_lds<1>(s, B, brange); break;
+      case 2: done = try_dense_lds<2>(s, B, brange); break;
+      case 3: done = try_dense_lds<3>(s, B, brange); break;
+      default: done = try_dense_lds<4>(s, B, brange); break;
+    }
+    if (done) return;
+  }
   launch_group_acc<2>(s, A);
 }
 

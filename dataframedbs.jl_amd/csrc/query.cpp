@@ -1142,6 +1142,7 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
 struct UniqueTables {
   DevBuf ent, aux, rep_off, rep_len, first, present;
   uint64_t cap = 0, salt = 0, lo = 0; uint32_t range = 0; bool is_str = false, dense = false;
+  uint64_t span_lo = ~0ull, span_hi = 0;   // dense form: the first / last value index that is present (the table is laid out for the widest span it can hold)
   bool defer_verify = false;     // in: the caller's own pass over the rows compares every String with its slot's representative (groupreduce's accumulate pass)
   int salt_skip = 0;             // in: salts already found colliding
   // in: String keys with defer_verify — if the second insert chunk (16 M rows) met no string the first (1 M rows) had not, the rest of the rows are NOT
@@ -1197,6 +1198,7 @@ static void unique_reset_aux(dfdb_ctx* ctx, DevBuf& aux) {
   HIP_CHECK(hipMemsetAsync(aux.p, 0, kUniqueAuxBytes, s));
   HIP_CHECK(hipMemsetAsync(aux.p, 0xFF, 16, s));                       // no such row yet
   HIP_CHECK(hipMemsetAsync((char*)aux.p + 64, 0xFF, 8, s));            // the running minimum (k_dense_minmax)
+  HIP_CHECK(hipMemsetAsync((char*)aux.p + 88, 0xFF, 8, s));            // the smallest present value index (k_dense_count)
 }
 static uint64_t pow2_at_least(uint64_t n) { uint64_t c = 1024; while (c < n) c <<= 1; return c; }
 
@@ -1242,10 +1244,11 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
     aux = T.aux.as<uint64_t>();
     { LaunchTimer lt(ctx, "unique_presence");
       launch_dense_presence(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, T.lo, T.range, T.present.as<uint32_t>(), aux); }
-    uint64_t od[2] = {0, 0};                                            // a key outside?  distinct values
-    HIP_CHECK(hipMemcpyAsync(od, (char*)T.aux.p + 40, 16, hipMemcpyDeviceToHost, s));
+    uint64_t od[8] = {0, 0, 0, 0, 0, 0, 0, 0};                          // [0] a key outside?  [1] distinct values ... [6], [7] the span of the present values
+    HIP_CHECK(hipMemcpyAsync(od, (char*)T.aux.p + 40, 64, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
     distinct = od[1];
+    T.span_lo = od[6]; T.span_hi = od[7];
     return od[0] == 0;
   };
   const int64_t nt = ceil_div(t->nrows, kTileRows);
@@ -1492,7 +1495,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
       if (T.dense)
         launch_group_accumulate_dense(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.lo,
-                                      T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
+                                      T.range, T.span_lo, T.span_hi, T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
       else if (T.is_str)
         launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
                                     vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, special, T.salt,
