@@ -14,7 +14,7 @@ try:
     t.add_generated("x", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15, 1_000_000_000)
     st = t.save(os.path.join(d, "tb")); t.close()
     for rep in range(5):
-        for what, readers, io, cq in (("load", 0, 8, 0), ("stream", 1, 8, 0), ("stream", 2, 8, 0), ("stream", 3, 8, 0), ("stream", 2, 12, 0), ("stream", 2, 6, 0), ("stream", 3, 6, 0), ("stream", 4, 4, 0)):
+        for what, readers, io, chunk in (("load", 0, 8, 1024), ("stream", 3, 8, 256), ("stream", 3, 8, 512), ("stream", 3, 8, 1024), ("stream", 3, 8, 2048), ("stream", 3, 8, 4096), ("stream", 2, 8, 2048)):
             ctx.set_option("io_threads", io)
             print(f"---- {what} readers={readers} io={io} rep={rep}", file=sys.stderr, flush=True)
             tb = dfdb.open_table(os.path.join(d, "tb"), load=False)
@@ -23,9 +23,9 @@ try:
                 tb.load(["x"]); torch.cuda.synchronize()
             else:
                 ctx.set_option("stream_slots", 8); ctx.set_option("stream_readers", readers)
-                dfdb.nrow_streamed(tb[("x", lambda x: x > 899_999), dfdb.ALL], 1024)
+                dfdb.nrow_streamed(tb[("x", lambda x: x > 899_999), dfdb.ALL], chunk)
             dt = time.perf_counter() - t0
-            print(json.dumps({"what": what, "readers": readers, "io_threads": io, "rep": rep, "seconds": round(dt, 4), "file_GBps": round(st["compressed"] / dt / 1e9, 1)}), flush=True)
+            print(json.dumps({"what": what, "readers": readers, "io_threads": io, "chunk_blocks": chunk, "rep": rep, "seconds": round(dt, 4), "file_GBps": round(st["compressed"] / dt / 1e9, 1)}), flush=True)
             tb.close()
 finally:
     shutil.rmtree(d, ignore_errors=True)
