@@ -21,6 +21,7 @@
 // Integer keys of a small range take the dense form at the end of this file instead (no hashing: a presence bit per value in LDS).
 #include "device_utils.hpp"
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include "kernels.hpp"
 #include "../../include/dfdb_ir.h"
@@ -1092,16 +1093,18 @@ static bool try_dense_lds(hipStream_t s, const AccArgs& A, uint32_t range) {
   const int ngp = (A.ngroups + 1) & ~1;
   const size_t lds = (size_t)ngp * 16 + ((size_t)range + 2) * 4;
   if (lds > 156 * 1024) return false;
-  static bool raised[8] = {};                                  // (per operator: the attribute belongs to the function)
-  if (lds > 64 * 1024 && !raised[OPK]) {
+  // (the attribute belongs to the function ON A DEVICE: a process that drives several GPUs raises it on each)
+  static std::atomic<bool> raised[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire))) {
     if (hipFuncSetAttribute((const void*)k_group_acc_dense_lds<OPK>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
-    raised[OPK] = true;
+    if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
   }
   const unsigned g = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024));
   hipLaunchKernelGGL((k_group_acc_dense_lds<OPK>), dim3(g), dim3(1024), lds, s, A, range, ngp);
   return true;
 }
-void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+int launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val,
                                    int64_t ngroups, uint64_t val_init) {
   AccArgs A{};
@@ -1123,9 +1126,10 @@ void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const voi
       case 3: done = try_dense_lds<3>(s, B, brange); break;
       default: done = try_dense_lds<4>(s, B, brange); break;
     }
-    if (done) return;
+    if (done) return 1;                                        // (1: the form with the group table in LDS)
   }
   launch_group_acc<2>(s, A);
+  return 0;
 }
 
 }  // namespace dfdb

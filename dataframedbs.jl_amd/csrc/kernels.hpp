@@ -167,7 +167,7 @@ void launch_dense_first(hipStream_t s, const uint64_t* bitmap, const void* col, 
                         uint32_t range, uint64_t distinct, uint64_t* first, uint64_t* aux);
 void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts);
 void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint64_t* aux, const uint64_t* ubits, const uint64_t* uprefix);
-void launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+int launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
 
 // ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------

@@ -1491,10 +1491,11 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
     HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
     HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+    int dense_lds = 0;
     { LaunchTimer lt(ctx, "group_accumulate");
       const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
       if (T.dense)
-        launch_group_accumulate_dense(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.lo,
+        dense_lds = launch_group_accumulate_dense(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.lo,
                                       T.range, T.span_lo, T.span_hi, T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
       else if (T.is_str)
         launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
@@ -1504,6 +1505,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
         launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr,
                                 vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, special,
                                 q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
+    if (dense_lds) prof_note(ctx, "group_accumulate.dense_lds");
     if (!T.is_str) break;
     int hit = 0; uint64_t unknown = 0;
     HIP_CHECK(hipMemcpyAsync(&hit, (char*)T.aux.p + 32, 4, hipMemcpyDeviceToHost, s));

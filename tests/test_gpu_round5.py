@@ -8,6 +8,7 @@
 import os
 
 import numpy as np
+import pandas as pd
 import pytest
 
 from helpers import Pair, assert_same
@@ -382,3 +383,45 @@ def test_groupreduce_by_a_string_key_skips_the_inserts_it_does_not_need(oracle, 
         ctx.profile(False)
         ctx.set_option("groupreduce_optimistic", 1)
         ctx.set_option("unique_chunk_tiles", 0)
+
+
+def test_groupreduce_by_an_integer_key_with_the_group_table_in_lds(oracle, dfdb_mod, ctx):
+    """groupreduce by an Int64 key of a few thousand values (aggregate.jl:1-36): the dense form's group-number table — the occupied span of it — is copied into LDS
+    beside the accumulators (k_group_acc_dense_lds).  Negative keys, a nullable key (missing is a group, the table's last entry), a filtered view, every
+    statistic over Int64 and Float64 values == a numpy restatement of first-appearance numbering; a narrow value column takes the general kernel."""
+    from test_gpu_parity import _np_group_ids, _np_groupreduce
+    dfdb = dfdb_mod
+    rng = np.random.default_rng(77)
+    n = 200_000
+    k = rng.integers(-1500, 1500, n).astype(np.int64) * 3 + 7            # ~3000 values spread over a span of 9000
+    km = np.ma.masked_array(k.copy(), mask=rng.random(n) < 0.2)
+    c = rng.integers(-1000, 1000, n).astype(np.int64)
+    x = rng.normal(size=n) * 100
+    u8 = rng.integers(0, 255, n).astype(np.uint8)
+    t = dfdb.DFTable.from_columns({"k": k, "km": km, "c": c, "x": x, "u8": u8}, block_size=4096)
+    ctx.profile(True)
+    try:
+        for view, sel in ((t[dfdb.ALL, dfdb.ALL], np.ones(n, bool)), (t[t.c > 0, dfdb.ALL], c > 0)):
+            for by, keys in (("k", k), ("km", km)):
+                ids = _np_group_ids([keys[i] for i in np.nonzero(sel)[0]])
+                for col, vals, stats in (("c", c, ("count", "sum", "min", "max")), ("x", x, ("sum", "min", "max")), ("u8", u8, ("sum",))):
+                    for stat in stats:
+                        before, _ = ctx.profile_get("group_accumulate.dense_lds")
+                        got = dfdb.groupreduce(view, by, col, stat)
+                        after, _ = ctx.profile_get("group_accumulate.dense_lds")
+                        assert after - before == (0 if col == "u8" else 1), (by, col, stat)      # (a narrow value column: the general kernel)
+                        order, cnt, want = _np_groupreduce(ids, vals[sel], stat)
+                        assert 1024 < len(order) <= 9216
+                        gk = [None if pd.isna(kk) else int(kk) for kk in got[by].tolist()]
+                        wk = [None if (kk is np.ma.masked or kk is None) else int(kk) for kk in order]
+                        assert gk == wk, (by, col, stat)
+                        assert got["count"].tolist() == cnt.tolist(), (by, col, stat)
+                        if stat != "count":
+                            g = got[stat].to_numpy()
+                            if col == "x" and stat == "sum":
+                                assert np.allclose(g, want, rtol=1e-9, atol=1e-6), (by, col, stat)
+                            else:
+                                assert np.array_equal(g.astype(np.float64), want.astype(np.float64)), (by, col, stat)
+    finally:
+        ctx.profile(False)
+    t.close()
