@@ -791,7 +791,6 @@ void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 3; }
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int g = per_cu * cus;
-    if (const char* e = getenv("DFDB_XP_STRGRID")) g = atoi(e);
     return (int)std::min<int64_t>(g, std::max<int64_t>(1, (ntiles + kWavesPerBlock - 1) / kWavesPerBlock));
   };
   int vkind = 0;
