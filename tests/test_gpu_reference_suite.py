@@ -164,3 +164,59 @@ def test_rows_and_errors(env):                          # test/rows.jl:20-29, te
     # (:c, :a) => f passes arguments in projection order (quirk Q13)
     v = tb[(("c", "a"), lambda x, y: (x == y) & (y < 3)), ["a"]]
     assert D.materialize(v)["a"].tolist() == [1, 2]
+
+
+def test_create_from_data(oracle, dfdb_mod, ctx, tmp_path):     # test/create_from_data.jl:5-41
+    """"from DataFrame": a = 1:5, b = string.(1:5) -> create_table(from = df) -> materialize == df, size == size(df).  "from rows": the rows of the
+    reference's own test/test.csv (kept as tests/golden/reference_test.csv), block_size = 10, the table the test ends with — those rows four times
+    (`repeat(df[:, n], 4)`; the reference gets there with three `insert`s, which rewrite the partial last block: this engine has no insert, the 28 rows
+    are written at once, 3 blocks, the last partial).  Both tables are also read back by the oracle's reader (liblz4)."""
+    import csv, os
+    D = dfdb_mod
+    df = pd.DataFrame({"a": np.arange(1, 6, dtype=np.int64), "b": np.array([str(i) for i in range(1, 6)], dtype=object)})
+    tb = D.create_table(str(tmp_path / "test_data"), from_={"a": df.a.to_numpy(), "b": list(df.b)})
+    assert eq(D.materialize(tb), df)
+    assert D.size(tb) == df.shape and D.nrow(tb) == 5 and D.ncol(tb) == 2
+    tb.close()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_test.csv")) as f:
+        rows = list(csv.DictReader(f))
+    assert [r["a"] for r in rows] == [str(i) for i in range(1, 8)] and [r["b"] for r in rows] == [str(i) for i in range(1, 8)]
+    four = {n: [r[n] for r in rows] * 4 for n in ("a", "b")}     # CSV.Rows yields strings for every column
+    path = str(tmp_path / "test_rows")
+    tb = D.create_table(path, from_=four, block_size=10)
+    dft = D.materialize(tb)
+    for n in ("a", "b"):
+        assert list(dft[n]) == four[n]
+    assert D.size(tb) == (28, 2)
+    ot = oracle.Table.open(path)
+    assert ot.block_size == 10 and [oracle.flat_to_strings(*c) for c in ot.view().materialize()] == [four["a"], four["b"]]
+    tb.close()
+
+
+def test_add_column(oracle, dfdb_mod, ctx, tmp_path):           # test/table_changes.jl:57-112 (the add_column! testset)
+    """add_column!(tb, :e, (1:1000) .+ 2000) -> materialize(tb) has e after c; a lazy column of the SAME table and of ANOTHER table of the same shape
+    (`tb[:, (c = :c => c -> c * 3,)][:, :c]`) -> materialize(tb[:, :e]) == df.c .* 3; a name that exists and a column of the wrong length are ArgumentErrors.
+    (`before = :a` — where the new column sits in meta.bin — is the control plane's: not mirrored.)"""
+    D = dfdb_mod
+    sz = 1000
+    a = np.arange(1, sz + 1, dtype=np.int64)
+    df = pd.DataFrame({"a": a, "b": np.array([str(i) for i in a], dtype=object), "c": a.astype(np.int16)})
+    cols = {"a": a, "b": list(df.b), "c": df.c.to_numpy()}
+    tb = D.create_table(str(tmp_path / "test_data"), from_=cols, block_size=100)
+    tb.load()
+    with pytest.raises(ValueError):
+        tb.add_column("c", np.zeros(sz, np.int64))        # the name exists
+    with pytest.raises(ValueError):
+        tb.add_column("e", np.zeros(0, np.int64))         # wrong length
+    tb.add_column("e", a + 2000)
+    want = df.copy(); want["e"] = a + 2000
+    assert eq(D.materialize(tb), want)
+    tb2 = D.create_table(str(tmp_path / "test_data2"), from_=cols, block_size=100)
+    tb2.load()
+    v1 = tb[D.ALL, {"c": ("c", lambda c: c * 3)}][D.ALL, "c"]
+    tb.add_column_from("f", v1)
+    assert np.array_equal(D.materialize(tb[D.ALL, "f"]), df.c.to_numpy() * 3)
+    v2 = tb2[D.ALL, {"c": ("c", lambda c: c * 3)}][D.ALL, "c"]
+    tb.add_column_from("g", v2)
+    assert np.array_equal(D.materialize(tb[D.ALL, "g"]), df.c.to_numpy() * 3)
+    tb.close(); tb2.close()

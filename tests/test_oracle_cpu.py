@@ -332,3 +332,65 @@ def test_oracle_raises_the_error_the_block_iteration_meets_first(oracle):
         for st in stages:
             v.add_predicate(st[1].to_ir()) if st[0] == "pred" else v.add_range(st[1], st[2], st[3])
         assert raised(v.nrow) == want, stages
+
+
+def _meta_type_strings(path):
+    """the type strings of a table's meta.bin as written (table_io.jl:9-19, common_io.jl:1-4: Int32 length + bytes)"""
+    import struct
+    raw = open(os.path.join(path, "meta.bin"), "rb").read()
+    _, _, ncols = struct.unpack_from("<qqq", raw, 0)
+    pos, out = 24, []
+    for _ in range(ncols):
+        pos += 8
+        (n,) = struct.unpack_from("<i", raw, pos); pos += 4 + n
+        (n,) = struct.unpack_from("<i", raw, pos); out.append(raw[pos + 4:pos + 4 + n].decode()); pos += 4 + n
+    return out
+
+
+def test_type_strings_are_the_reference_s(oracle, tmp_path):
+    """test/column_types.jl:31-43 (`deserialize("Int32") == Int32`, `deserialize("Missing(Int32)") == Union{Missing, Int32}`) and the names typestring writes
+    (columntypes/base.jl:108-126,163-168): a table written here carries exactly those strings in meta.bin and in every column header, and a file whose strings
+    were put there BY HAND (as the Julia package would write them) opens as the same types; a Tuple(...) column (column_types.jl:46-50) is refused by name."""
+    import struct
+    n = 5
+    cols = [("i8", np.arange(n, dtype=np.int8), "Int8"), ("i16", np.arange(n, dtype=np.int16), "Int16"), ("i32", np.arange(n, dtype=np.int32), "Int32"),
+            ("i64", np.arange(n, dtype=np.int64), "Int64"), ("u8", np.arange(n, dtype=np.uint8), "UInt8"), ("u16", np.arange(n, dtype=np.uint16), "UInt16"),
+            ("u32", np.arange(n, dtype=np.uint32), "UInt32"), ("u64", np.arange(n, dtype=np.uint64), "UInt64"), ("f32", np.arange(n, dtype=np.float32), "Float32"),
+            ("f64", np.arange(n, dtype=np.float64), "Float64"), ("b", np.array([True, False, True, True, False]), "Bool"), ("s", ["a", "bb", "", "d", "e"], "String"),
+            ("m", np.ma.masked_array(np.arange(n, dtype=np.int32), mask=[0, 1, 0, 0, 1]), "Missing(Int32)"), ("ms", ["a", None, "", "d", None], "Missing(String)")]
+    t = oracle.Table(block_size=3)
+    for name, v, _ in cols:
+        if isinstance(v, np.ma.MaskedArray):
+            t.add_column(name, v.filled(0), missing=np.ma.getmaskarray(v))
+        else:
+            t.add_column(name, v)
+    p = str(tmp_path / "types")
+    t.save(p)
+    assert _meta_type_strings(p) == [ts for _, _, ts in cols]
+    for k, (_, _, ts) in enumerate(cols):                 # column header: Int64 block size + the same string (filesystem.jl:14-23)
+        raw = open(os.path.join(p, f"{k + 1}.bin"), "rb").read(64)
+        bs, ln = struct.unpack_from("<qi", raw, 0)
+        assert bs == 3 and raw[12:12 + ln].decode() == ts
+    t2 = oracle.Table.open(p)
+    want = [oracle.I8, oracle.I16, oracle.I32, oracle.I64, oracle.U8, oracle.U16, oracle.U32, oracle.U64, oracle.F32, oracle.F64, oracle.BOOL, oracle.STRING,
+            oracle.I32 | oracle.NULLABLE, oracle.STRING | oracle.NULLABLE]
+    assert [t2.colinfo(i)[2] for i in range(len(cols))] == want
+    # a meta.bin / column header written by hand with the reference's strings: two columns, Int32 and Missing(Int32), one block of two rows each
+    import ctypes as C
+    hand = str(tmp_path / "hand"); os.mkdir(hand)
+
+    def jstr(s_):
+        return struct.pack("<i", len(s_)) + s_.encode()
+
+    def block(body):
+        return oracle.block_encode(body, 2)              # Int32 rows, Int64 origin, Int64 compressed, LZ4 block (BlockStreams.jl:50-53)
+    open(os.path.join(hand, "meta.bin"), "wb").write(struct.pack("<qqq", 1, 4, 2) + struct.pack("<q", 1) + jstr("x") + jstr("Int32") + struct.pack("<q", 2) + jstr("y") + jstr("Missing(Int32)"))
+    open(os.path.join(hand, "1.bin"), "wb").write(struct.pack("<q", 4) + jstr("Int32") + block(struct.pack("<ii", 7, -8)))
+    open(os.path.join(hand, "2.bin"), "wb").write(struct.pack("<q", 4) + jstr("Missing(Int32)") + block(struct.pack("<Q", 0b10) + struct.pack("<ii", 5, 99)))
+    th = oracle.Table.open(hand)
+    assert [th.colinfo(i)[2] for i in range(2)] == [oracle.I32, oracle.I32 | oracle.NULLABLE]
+    got = th.view().materialize()
+    assert got[0].tolist() == [7, -8] and got[1].tolist() == [5, None]
+    open(os.path.join(hand, "meta.bin"), "wb").write(struct.pack("<qqq", 1, 4, 1) + struct.pack("<q", 1) + jstr("x") + jstr("Tuple(Int32, UInt64)"))
+    with pytest.raises(NotImplementedError, match="Tuple"):
+        oracle.Table.open(hand)
