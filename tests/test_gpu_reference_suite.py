@@ -220,3 +220,25 @@ def test_add_column(oracle, dfdb_mod, ctx, tmp_path):           # test/table_cha
     tb.add_column_from("g", v2)
     assert np.array_equal(D.materialize(tb[D.ALL, "g"]), df.c.to_numpy() * 3)
     tb.close(); tb2.close()
+
+
+def test_type_strings_written_by_hand(oracle, dfdb_mod, ctx, tmp_path):   # test/column_types.jl:31-50
+    """a table directory whose type strings were typed here as the Julia package writes them — "Int32", "Missing(Int32)" (deserialize: column_types.jl:31-38) —
+    opens in the ENGINE as those types and decodes to the values put in; "Tuple(Int32, UInt64)" (:46-50) is refused by name, as the oracle refuses it"""
+    import os, struct
+    D = dfdb_mod
+    hand = str(tmp_path / "hand"); os.mkdir(hand)
+
+    def jstr(s_):
+        return struct.pack("<i", len(s_)) + s_.encode()
+    open(os.path.join(hand, "meta.bin"), "wb").write(struct.pack("<qqq", 1, 4, 2) + struct.pack("<q", 1) + jstr("x") + jstr("Int32") + struct.pack("<q", 2) + jstr("y") + jstr("Missing(Int32)"))
+    open(os.path.join(hand, "1.bin"), "wb").write(struct.pack("<q", 4) + jstr("Int32") + oracle.block_encode(struct.pack("<ii", 7, -8), 2))
+    open(os.path.join(hand, "2.bin"), "wb").write(struct.pack("<q", 4) + jstr("Missing(Int32)") + oracle.block_encode(struct.pack("<Q", 0b10) + struct.pack("<ii", 5, 99), 2))
+    tb = D.open_table(hand)
+    assert [c.dtype for c in tb.columns_meta()] == [D.ir.I32, D.ir.I32 | D.ir.NULLABLE]
+    got = D.materialize(tb)
+    assert got["x"].tolist() == [7, -8] and got["y"][0] == 5 and pd.isna(got["y"][1])
+    tb.close()
+    open(os.path.join(hand, "meta.bin"), "wb").write(struct.pack("<qqq", 1, 4, 1) + struct.pack("<q", 1) + jstr("x") + jstr("Tuple(Int32, UInt64)"))
+    with pytest.raises(Exception, match="Tuple"):
+        D.open_table(hand)
