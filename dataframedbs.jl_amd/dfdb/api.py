@@ -870,8 +870,24 @@ def stream(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> Stream:
 
 
 def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> int:
-    """nrow(v) without holding the table in HBM: sum of the per-chunk counts (BlockRowsIterator, view.jl:192-206)."""
-    with Stream(v, chunk_blocks) as s:
+    """nrow(v) without holding the table in HBM: sum of the per-chunk counts (BlockRowsIterator, view.jl:192-206).
+    Like the reference's row counter (blocksiterator.jl:46-66: the selection's columns, or the FIRST projection column when the queue holds no predicate) it
+    never reads a projection-only column: the stream is opened over the same selection with one of those columns as its projection (a count over a
+    three-column table used to read all three files)."""
+    view = v if isinstance(v, DFView) else DFView(v)
+    keep = None
+    for st in view.selection.queue:
+        if isinstance(st, ir.Expr) and st.columns():
+            keep = st.columns()[0]
+            break
+    if keep is None:
+        for e in view.projection.cols.values():
+            if e.columns():
+                keep = e.columns()[0]
+                break
+    if keep is not None:
+        view = DFView(view.table, Projection({view.table.names()[keep]: ir.col(keep)}), view.selection)
+    with Stream(view, chunk_blocks) as s:
         return sum(part.count() for part in s)
 
 

@@ -425,3 +425,30 @@ def test_groupreduce_by_an_integer_key_with_the_group_table_in_lds(oracle, dfdb_
     finally:
         ctx.profile(False)
     t.close()
+
+
+def test_a_streamed_count_never_reads_a_projection_only_column(oracle, dfdb_mod, ctx, tmp_path):
+    """nrow over a table that is not resident (BlockRowsIterator, blocksiterator.jl:46-66): only the selection's columns are read — the first projection column
+    when the queue holds no predicate.  The other columns' files are CUT SHORT after the table was opened: the counts are still the oracle's, while a streamed
+    materialize of the same views meets the damage."""
+    import os
+    dfdb = dfdb_mod
+    n = 50_000
+    rng = np.random.default_rng(5)
+    cols = {"a": rng.integers(0, 1000, n).astype(np.int64), "b": rng.integers(0, 1000, n).astype(np.int64), "s": [str(i % 97) for i in range(n)]}
+    ot = oracle.Table(block_size=1024)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    tb = dfdb.open_table(path, load=False)
+    for victim in ("2.bin", "3.bin"):                      # b and s: headers stay, the blocks go
+        with open(os.path.join(path, victim), "r+b") as f:
+            f.truncate(64)
+    v = tb[("a", lambda a: a > 899), dfdb.ALL]
+    assert dfdb.nrow_streamed(v, 8) == int((cols["a"] > 899).sum())
+    assert dfdb.nrow_streamed(tb[dfdb.jr(10, 40_000), dfdb.ALL], 8) == 39_991          # no predicate: the first projection column (a) — or no column at all
+    assert dfdb.nrow_streamed(tb[dfdb.ALL, ["a", "b"]], 8) == n
+    with pytest.raises(Exception):
+        dfdb.materialize_streamed(v, 8)
+    tb.close()
