@@ -304,7 +304,7 @@ void launch_gather_transform(hipStream_t s, const uint64_t* bitmap, const uint64
 }
 
 // projection of a predicate column whose selected values the scan already wrote per tile (k_scan_cmp / k_scan_terms CAP):
-// one wave per 4096-row ctile = 4 capture tiles; every lane finds its tile from the 5 prefix values and copies
+// one wave per 4096-row ctile = one capture group: a contiguous copy of its pf[4] - pf[0] values
 // XF: the captured values are those of an 8-byte column of type T and the output is a transform of them (transform_value: `x * 2` over a filtered view whose
 // predicate already read x — the computed projection rides on the capture instead of on a second gather of the column)
 template <bool XF, typename T>
@@ -316,18 +316,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_captured(const uint64_t* __r
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t ct = wave; ct < nctiles; ct += nwaves) {
     const int64_t t0 = ct * 4;
-    uint64_t pf[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) pf[i] = prefix[t0 + i < ntiles ? t0 + i : ntiles];
-    const uint32_t total = (uint32_t)(pf[4] - pf[0]);
+    const uint64_t pf[2] = {prefix[t0], prefix[t0 + 4 < ntiles ? t0 + 4 : ntiles]};
+    const uint32_t total = (uint32_t)(pf[1] - pf[0]);
     for (uint32_t k0 = 0; k0 < total; k0 += 256) {
       uint64_t v[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t k = k0 + (uint32_t)u * 64 + lane;
-        const uint64_t o = pf[0] + k;
-        const int ti = o >= pf[3] ? 3 : (o >= pf[2] ? 2 : (o >= pf[1] ? 1 : 0));
-        v[u] = k < total ? __builtin_nontemporal_load(cap + (t0 + ti) * 1024 + (int64_t)(o - pf[ti])) : 0ull;
+        v[u] = k < total ? __builtin_nontemporal_load(cap + t0 * 1024 + (int64_t)k) : 0ull;      // (a group's four runs lie back to back: k_scan.hip CAP)
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {

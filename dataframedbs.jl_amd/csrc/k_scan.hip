@@ -90,8 +90,10 @@ __device__ __forceinline__ void cap_push(CapQueue& cq, uint64_t* __restrict__ st
 __device__ __forceinline__ void cap_finish(CapQueue& cq, uint64_t* __restrict__ stage, int lane) { if (cq.run) cap_flush(cq, stage, lane); }
 template <typename T> __device__ __forceinline__ uint64_t bits_of(T v) { static_assert(sizeof(T) <= 8, ""); uint64_t b = 0; __builtin_memcpy(&b, &v, sizeof(T)); return b; }
 
-// CAP: the values of the selected rows are also written, compacted per 1024-row tile, to cap[tile*1024 + rank in tile]:
-// a projection of the predicate column itself is then a contiguous copy per tile (k_compact_captured) instead of a gather
+// CAP: the values of the selected rows are also written, compacted per GROUP of four 1024-row tiles (what a wave takes per trip), to cap[group*4096 + rank in group]
+// (round 5; per tile before: four 0.8-KB runs at 8-KB strides where there is now one 3.2-KB run — the scan's capture stores are what it pays for keeping the values,
+// 0.45 ms per 0.8 GB mixed into its read stream, not the instructions around them):
+// a projection of the predicate column itself is then a contiguous copy per group (k_compact_captured) instead of a gather
 // that re-reads ~81 % of the column's 128-B lines at 10 % selectivity (late materialization: the scan already holds the values)
 template <typename T, int OP, bool AND_EXISTING, bool NT, bool CAP>
 __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, T c, uint64_t* __restrict__ bitmap,
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
       live = __ballot(existing != 0);
       if (live == 0) { if ((lane & 15) == 0 && t0 + (lane >> 4) < ntiles) tile_counts[t0 + (lane >> 4)] = 0; continue; }
     }
+    uint32_t gout = 0;                                                         // CAP: values this GROUP of four tiles has kept so far (its tiles' runs lie back to back)
     for (int k = 0; k < 4; k++) {
       const int64_t tile = t0 + k;
       if (tile >= ntiles) break;                                               // (wave-uniform)
@@ -130,17 +133,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) v[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];   // 16 independent coalesced loads in flight; NT: streamed once
         CapQueue cq(cap_mine);
-        if (CAP) stage = (uint64_t*)(cap + base);
+        if (CAP) stage = (uint64_t*)cap + t0 * kTile + gout;
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) {
           uint64_t m = __ballot(cmp_op<OP, T>(v[j], c));
           if (lane == l0 + j) myword = m;
           if (CAP) cap_push(cq, stage, m, bits_of(v[j]), lane);
         }
-        if (CAP) cap_finish(cq, stage, lane);
+        if (CAP) { cap_finish(cq, stage, lane); gout += cq.out; }
       } else {
         CapQueue cq(cap_mine);
-        if (CAP) stage = (uint64_t*)(cap + base);
+        if (CAP) stage = (uint64_t*)cap + t0 * kTile + gout;
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) {
           const int64_t row = base + j * 64 + lane;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_cmp(const T* __restrict__ col, 
           if (lane == l0 + j) myword = m;
           if (CAP) cap_push(cq, stage, m, bits_of(x), lane);
         }
-        if (CAP) cap_finish(cq, stage, lane);
+        if (CAP) { cap_finish(cq, stage, lane); gout += cq.out; }
       }
     }
     if (AND_EXISTING) myword &= existing;
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
       const uint64_t cb2 = tm.cbits2;
       const uint64_t before = acc;
       uint64_t fin = 0;
+      uint32_t gout = 0, gout2 = 0;          // captured values of this group so far (first / second capture buffer): a group's four runs lie back to back
       for (int k = 0; k < nk; k++) {
         const int64_t tile = t0 + k, base = tile * kTile;
         const int l0 = 16 * k;
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
           const bool mine16 = (lane >> 4) == k;            // the lanes that hold this tile's words
           bef = mine16 ? (before & wa) : before;
         }
-        if (CAPQ) stage = extra_out + base;   // straight to the tile's slot: a contiguous run per 64-row word, merged in L2
+        if (CAPQ) stage = extra_out + t0 * kTile + gout;   // the group's slot, behind what its earlier tiles kept
         uint64_t ft;
         if (tm.dtype == DFDB_F64) {
           double ls = agg_identity<double, LASTX>();
@@ -717,10 +721,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
           if (AGG) { ls = wave_agg<uint64_t, LASTX>(ls); if (lane == 0) extra_out[tile] = ls; }
         }
         fin |= ft;
+        if (CAPQ) gout += run;
         if (EXTRA == 5) {           // the parked values of the rows that made it, in rank order, to the second capture buffer
           wave_lds_fence();
           CapQueue cq(cap_mine);
-          uint64_t* const stage2 = extra_out2 + base;
+          uint64_t* const stage2 = extra_out2 + t0 * kTile + gout2;
 #pragma unroll
           for (int j = 0; j < kWordsPerTile; j++) {
             const uint64_t mj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ft, l0 + j) |
@@ -728,6 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_terms(ScanTerms terms, uint64_t
             cap_push(cq, stage2, mj, stash[j * 64 + lane], lane);
           }
           cap_finish(cq, stage2, lane);
+          gout2 += cq.out;
         }
       }
       acc = fin;
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_pair(ScanTerms terms, uint64_t*
       const TA* pa = cola + t0 * kTile + lane;
       const TB* pb = colb + t0 * kTile + lane;
       TA va[kWordsPerTile]; TB vb[kWordsPerTile];
+      uint32_t gout = 0;                     // captured values of this group so far
 #pragma unroll
       for (int j = 0; j < kWordsPerTile; j++) va[j] = __builtin_nontemporal_load(pa + j * 64);
 #pragma unroll
@@ -791,7 +798,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_pair(ScanTerms terms, uint64_t*
         }
         CapQueue cq(cap_mine);
         TB ls = agg_identity<TB, EXTRA>();
-        uint64_t* stage = EXTRA == 1 ? extra_out + (t0 + k) * kTile : nullptr;
+        uint64_t* stage = EXTRA == 1 ? extra_out + t0 * kTile + gout : nullptr;
 #pragma unroll
         for (int j = 0; j < kWordsPerTile; j++) {
           uint64_t m = __ballot(cmp_sel<TB>(vb[j], cb, selb) && (selb2 == 0 || cmp_sel<TB>(vb[j], cb2, selb2)));
@@ -809,7 +816,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_pair(ScanTerms terms, uint64_t*
 #pragma unroll
           for (int j = 0; j < kWordsPerTile; j++) vb[j] = __builtin_nontemporal_load(pb + (k + 1) * kTile + j * 64);
         }
-        if (EXTRA == 1) cap_finish(cq, stage, lane);
+        if (EXTRA == 1) { cap_finish(cq, stage, lane); gout += cq.out; }
         if (EXTRA >= 2) { ls = wave_agg<TB, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[t0 + k] = b; } }
       }
     } else {
@@ -817,10 +824,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_pair(ScanTerms terms, uint64_t*
       uint64_t wa = 0;
       for (int k = 0; k < nk; k++) wa |= term_word<TA>(ta.col, ta.cbits, sela, (t0 + k) * kTile, nrows, lane, 16 * k, sela2, ta.cbits2);
       if (EXTRA) {
+        uint32_t gout = 0;
         for (int k = 0; k < nk; k++) {
           uint32_t run = 0;
           TB ls = agg_identity<TB, EXTRA>();
-          acc |= term_word_last<TB, EXTRA>(tb.col, tb.cbits, selb, (t0 + k) * kTile, nrows, lane, wa, EXTRA == 1 ? extra_out + (t0 + k) * kTile : nullptr, run, ls, 16 * k, selb2, tb.cbits2, cap_mine);
+          acc |= term_word_last<TB, EXTRA>(tb.col, tb.cbits, selb, (t0 + k) * kTile, nrows, lane, wa, EXTRA == 1 ? extra_out + t0 * kTile + gout : nullptr, run, ls, 16 * k, selb2, tb.cbits2, cap_mine);
+          gout += run;
           if (EXTRA >= 2) { ls = wave_agg<TB, EXTRA>(ls); if (lane == 0) { uint64_t b; __builtin_memcpy(&b, &ls, 8); extra_out[t0 + k] = b; } }
         }
       } else {
