@@ -602,6 +602,7 @@ struct AccArgs {
   const uint16_t* codes; const uint32_t* rank_of_code;                  // SRC 1
   uint64_t lo; const uint64_t* gids;                                    // SRC 2 (special[1]: the group of missing)
   uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;
+  uint64_t* unknown_flag;                                               // k_group_acc_dense_lds: raised by a selected row whose key has no group (an optimistic, head-only table)
 };
 // OPK: group_add_t's operator; W8: the value column AND (SRC 0 / 2) the key column are 8-byte integers or doubles, loaded as they are — the dtype switches of value_bits
 // and key_fixed, copied four times by the unrolled trip, stay in the !W8 kernels
@@ -1062,6 +1063,7 @@ __global__ __launch_bounds__(1024) void k_group_acc_dense_lds(const AccArgs A, u
   constexpr int U = 8;
   const int64_t stride = (int64_t)gridDim.x * 1024;
   int vkind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);
+  bool unknown = false;
   for (int64_t row0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; row0 < A.nrows; row0 += U * stride) {
     uint64_t w[U], mw[U], key[U], bits[U]; uint32_t gid[U];
 #pragma unroll
@@ -1078,12 +1080,17 @@ __global__ __launch_bounds__(1024) void k_group_acc_dense_lds(const AccArgs A, u
       const int64_t row = row0 + k * stride;
       const bool on = (w[k] >> (row & 63)) & 1ull, miss = (mw[k] >> (row & 63)) & 1ull;
       const uint64_t idx = key[k] - A.lo;
-      gid[k] = tbl[(on && !miss && idx < (uint64_t)range) ? (uint32_t)idx : range];      // (missing, and rows that are off: the table's last entry)
-      w[k] = on ? 1ull : 0ull;
+      const bool inr = idx < (uint64_t)range;
+      gid[k] = tbl[(on && !miss && inr) ? (uint32_t)idx : range];      // (missing, and rows that are off: the table's last entry)
+      // a selected row without a group: its key lies outside the span laid out, or it (or `missing`) never turned up among the rows the table was made from
+      const bool bad = on && (gid[k] == 0xFFFFFFFFu || (!miss && !inr));
+      unknown |= bad;
+      w[k] = (on && !bad) ? 1ull : 0ull;
     }
 #pragma unroll
     for (int k = 0; k < U; k++) if (w[k]) group_add_t<OPK>(lcnt, lval, (uint64_t)gid[k], bits[k], vkind);
   }
+  if (unknown && A.unknown_flag) __atomic_store_n(A.unknown_flag, 1ull, __ATOMIC_RELAXED);
   __syncthreads();
   group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, vkind, has_val, 1024);
 }
@@ -1105,11 +1112,14 @@ static bool try_dense_lds(hipStream_t s, const AccArgs& A, uint32_t range) {
 }
 int launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val,
-                                   int64_t ngroups, uint64_t val_init) {
+                                   int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag) {
+  // unknown_flag != nullptr: the table was made from the head of the column only — the pass must be the LDS form, which reports a key without a group; returns -1,
+  // nothing launched, when that form cannot take the job (the caller then makes the table from every row)
   AccArgs A{};
+  A.unknown_flag = unknown_flag;
   A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.lo = lo; A.gids = gids; A.special = aux;
   A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
-  if (nrows > 0 && ngroups > kGroupLds && (keydt == DFDB_I64 || keydt == DFDB_U64) && span_lo <= span_hi && span_hi < range) {   // (few groups: the 256-thread kernels, several workgroups per CU)
+  if (nrows > 0 && (ngroups > kGroupLds || unknown_flag) && (keydt == DFDB_I64 || keydt == DFDB_U64) && span_lo <= span_hi && span_hi < range) {   // (few groups: the 256-thread kernels, several workgroups per CU)
     // the table is laid out for the widest span the form can hold; the keys that are there cover [span_lo, span_hi] of it (k_dense_count) and only that goes to LDS
     AccArgs B = A;
     B.lo = lo + span_lo; B.gids = gids + span_lo;
@@ -1127,6 +1137,7 @@ int launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void
     }
     if (done) return 1;                                        // (1: the form with the group table in LDS)
   }
+  if (unknown_flag) return -1;
   launch_group_acc<2>(s, A);
   return 0;
 }

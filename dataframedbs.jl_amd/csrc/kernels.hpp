@@ -168,7 +168,7 @@ void launch_dense_first(hipStream_t s, const uint64_t* bitmap, const void* col, 
 void launch_dense_scatter(hipStream_t s, const uint64_t* first, uint32_t range, const uint64_t* aux, uint64_t* bitmap, uint32_t* tile_counts);
 void launch_dense_group_ids(hipStream_t s, uint64_t* first, uint32_t range, uint64_t* aux, const uint64_t* ubits, const uint64_t* uprefix);
 int launch_group_accumulate_dense(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
-                                   int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
+                                   int64_t nrows, uint64_t lo, uint32_t range, uint64_t span_lo, uint64_t span_hi, const uint64_t* gids, const uint64_t* aux, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag = nullptr);
 
 // ---- K7: LZ4 block decode, K8: missing bitmaps, block bodies ---------------------------------------
 // (dst: the decoders may READ up to 32 bytes past the end of the last block's output — far-match sources are fetched 24 bytes at a time — so the

@@ -1143,6 +1143,9 @@ struct UniqueTables {
   DevBuf ent, aux, rep_off, rep_len, first, present;
   uint64_t cap = 0, salt = 0, lo = 0; uint32_t range = 0; bool is_str = false, dense = false;
   uint64_t span_lo = ~0ull, span_hi = 0;   // dense form: the first / last value index that is present (the table is laid out for the widest span it can hold)
+  // in: the dense form may look at the HEAD of the column only (groupreduce over integer keys, round 5: its accumulate pass meets every row anyway and reports a key
+  // that has no group — one outside the span laid out, or one that first turns up behind the head —, in which case everything runs again over all rows); out: it did
+  bool allow_head = false, head_only = false;
   bool defer_verify = false;     // in: the caller's own pass over the rows compares every String with its slot's representative (groupreduce's accumulate pass)
   int salt_skip = 0;             // in: salts already found colliding
   // in: String keys with defer_verify — if the second insert chunk (16 M rows) met no string the first (1 M rows) had not, the rest of the rows are NOT
@@ -1228,6 +1231,9 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
   const uint64_t flip = dt_issigned(dt) ? (1ull << 63) : 0ull;
   uint64_t* aux = nullptr;
   uint64_t distinct = 0;
+  const int64_t nt_all = ceil_div(t->nrows, kTileRows), head_tiles = std::max<int64_t>(1, ctx_option(ctx, "dense_head_tiles", 4096));
+  T.head_only = T.allow_head && nt_all >= 8 * head_tiles;               // (the sample below still looks at the whole column: the span is laid around what IT saw)
+  auto prows = [&]() -> int64_t { return T.head_only ? head_tiles * kTileRows : t->nrows; };      // the rows the presence pass and the first-row launches walk
   auto minmax = [&](int64_t tile_step, uint64_t* mm) {                 // order-preserving images of the smallest / largest selected key (of every tile_step-th tile)
     unique_reset_aux(ctx, T.aux);
     { LaunchTimer lt(ctx, "unique_minmax"); launch_dense_minmax(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, tile_step, T.aux.as<uint64_t>()); }
@@ -1243,7 +1249,7 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
     unique_reset_aux(ctx, T.aux);
     aux = T.aux.as<uint64_t>();
     { LaunchTimer lt(ctx, "unique_presence");
-      launch_dense_presence(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, T.lo, T.range, T.present.as<uint32_t>(), aux); }
+      launch_dense_presence(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, prows(), T.lo, T.range, T.present.as<uint32_t>(), aux); }
     uint64_t od[8] = {0, 0, 0, 0, 0, 0, 0, 0};                          // [0] a key outside?  [1] distinct values ... [6], [7] the span of the present values
     HIP_CHECK(hipMemcpyAsync(od, (char*)T.aux.p + 40, 64, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
@@ -1261,8 +1267,9 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
     // where the keys lie is not known.  A SAMPLE (every nt/256-th tile) says where to expect them: the whole span the form can hold is laid around the sample's
     // range and the presence pass reports any key outside it — then, and for a small table, the exact range costs a pass of its own (1.3 ms per 1e9 rows)
     uint64_t mm[2];
-    const int64_t sample_step = nt / 256;
-    if (sample_step >= 16 && ctx_option(ctx, "unique_dense_sample", 1) != 0) {
+    const int64_t sample_opt = ctx_option(ctx, "unique_dense_sample", 1);
+    const int64_t sample_step = sample_opt == 2 ? std::max<int64_t>(2, nt / 256) : nt / 256;      // (2: a sample even of a small table, every other tile — tests of what follows a sample)
+    if ((sample_step >= 16 || sample_opt == 2) && sample_opt != 0) {
       minmax(sample_step, mm);
       if (mm[0] <= mm[1]) {
         if (mm[1] - mm[0] >= (uint64_t)limit) return false;
@@ -1273,6 +1280,7 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
       }
     }
     if (!placed) {
+      T.head_only = false;                                              // (no sample, or a key outside what it suggested: the exact range, every row)
       minmax(1, mm);
       if (mm[0] > mm[1]) mm[0] = mm[1] = flip;                         // every selected key is missing
       if (mm[1] - mm[0] >= (uint64_t)limit) return false;
@@ -1286,8 +1294,9 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
     // cannot see each other's — 1e6 values spread over the column are all met within 20 M rows, and met in small steps they cost 1.5 M atomics instead of 4 M
     int64_t step = ctx_option(ctx, "unique_chunk_tiles", 0) > 0 ? ctx_option(ctx, "unique_chunk_tiles", 0) : 1024;
     int launches = 0;
-    for (int64_t t0 = 0; t0 < nt; t0 += step, step *= (++launches < 2 ? 1 : (launches < 4 ? 2 : 4)))
-      launch_dense_first(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(t->nrows, (t0 + step) * kTileRows), T.lo, T.range, distinct, T.first.as<uint64_t>(), aux);
+    const int64_t nt_walk = T.head_only ? head_tiles : nt;
+    for (int64_t t0 = 0; t0 < nt_walk; t0 += step, step *= (++launches < 2 ? 1 : (launches < 4 ? 2 : 4)))
+      launch_dense_first(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t0 * kTileRows, std::min(prows(), (t0 + step) * kTileRows), T.lo, T.range, distinct, T.first.as<uint64_t>(), aux);
   }
   HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
   HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
@@ -1475,13 +1484,21 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   }
   UniqueTables T;
   int64_t ng = 0;
-  bool pessimistic = false;
+  bool pessimistic = false, whole_dense = false;
+  // integer keys, dense form: the table of first rows / group numbers is made from the HEAD of the column (4 M rows) when the accumulate pass can be the one with
+  // the table in LDS — that pass meets every row anyway and raises a flag for a key that has no group, after which everything runs again over every row
+  // (the presence pass over the whole key column was 1.3 of the 5.0 ms of 1e9 rows by 5000 keys)
+  const bool head_ok = ctx_option(ctx, "groupreduce_optimistic", 1) != 0 && (dt_base(kc.dtype) == DFDB_I64 || dt_base(kc.dtype) == DFDB_U64) &&
+                       (!vc || dt_width(vc->dtype) == 8);
   for (;;) {
     // String keys: the pass that compares every row with its slot's representative (unique's verify pass) is folded into the accumulate pass below, which
     // hashes every row and finds its slot anyway; should two different strings share a key the selection is put back and everything runs again under the next salt
     T.defer_verify = true;
     T.allow_optimistic = !pessimistic && ctx_option(ctx, "groupreduce_optimistic", 1) != 0;
+    T.allow_head = head_ok && !whole_dense;
     unique_impl(q, key_p, &T);
+    const bool head_table = T.dense && T.head_only;
+    if (head_table) HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));        // (the word the accumulate pass raises: aux[3])
     if (T.optimistic) HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));      // the accumulate pass raises this word when it meets a string the table does not hold
     ng = query_count(q, -1);
     uint64_t* special = T.aux.as<uint64_t>();
@@ -1496,7 +1513,8 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
       if (T.dense)
         dense_lds = launch_group_accumulate_dense(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr, vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.lo,
-                                      T.range, T.span_lo, T.span_hi, T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
+                                      T.range, T.span_lo, T.span_hi, T.first.as<uint64_t>(), special, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init,
+                                      head_table ? T.aux.as<uint64_t>() + 3 : nullptr);
       else if (T.is_str)
         launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
                                     vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, special, T.salt,
@@ -1505,7 +1523,23 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
         launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr,
                                 vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, special,
                                 q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init); }
-    if (dense_lds) prof_note(ctx, "group_accumulate.dense_lds");
+    if (dense_lds > 0) prof_note(ctx, "group_accumulate.dense_lds");
+    if (head_table) {
+      uint64_t unknown = dense_lds < 0 ? 1ull : 0ull;                  // (-1: the LDS form could not take the job and nothing ran)
+      if (!unknown) {
+        HIP_CHECK(hipMemcpyAsync(&unknown, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s));
+        stream_wait(ctx);
+      }
+      if (unknown || ctx_option(ctx, "groupreduce_optimistic", 1) == 2) {          // (2: the test knob — as if a key had been missing)
+        whole_dense = true;
+        prof_note(ctx, "group_accumulate.head_redo");
+        launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);     // the full selection again
+        scan_prefix(q);
+        q->count = -1;
+        continue;
+      }
+      prof_note(ctx, "group_accumulate.head_table");
+    }
     if (!T.is_str) break;
     int hit = 0; uint64_t unknown = 0;
     HIP_CHECK(hipMemcpyAsync(&hit, (char*)T.aux.p + 32, 4, hipMemcpyDeviceToHost, s));

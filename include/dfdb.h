@@ -156,8 +156,10 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "unique_dense"    1 = dfdb_query_unique / _groupreduce over an integer key whose selected values span less than 1 277 952 take the form without a hash
  *                     table (a presence bit per value in LDS; default 1); "unique_dense_range" lowers that span.  "unique_cap0_log2" = log2 of the slots the
  *                     hash table starts with (default 21; it grows with the distinct values met), "unique_chunk_tiles" = 1024-row tiles of the first chunk
- *                     either form feeds before it looks at what it found (default 1024), "dict_unique_head" = 0: unique / groupreduce over a dictionary-coded String column walk all of
- *                     the codes for their first rows at once (default 1: the first 4 M rows first, the rest only if a code has not turned up there), "unique_dense_sample" = 0: the dense form reads the
+ *                     either form feeds before it looks at what it found (default 1024), "dense_head_tiles" = 1024-row tiles of the head dfdb_query_groupreduce by an 8-byte integer key makes its group table from when "groupreduce_optimistic" is on (default 4096 =
+ *                     4 M rows, taken only for columns of at least eight times that; its accumulate pass reports a key the head did not hold and everything runs again over all rows),
+ *                     "dict_unique_head" = 0: unique / groupreduce over a dictionary-coded String column walk all of
+ *                     the codes for their first rows at once (default 1: the first 4 M rows first, the rest only if a code has not turned up there), "unique_dense_sample" = 0 (2 = sample even a small table: a test knob): the dense form reads the
  *                     exact range of the keys first instead of laying its span around a sample's, "groupreduce_optimistic" = 0: dfdb_query_groupreduce by a String key (and dfdb_query_unique over one) inserts every selected row into its hash table
  *                     (default 1: when the second chunk of rows — 16 M — brought no string the first — 1 M — had not, the rest are not inserted; the accumulate pass (unique: the
  *                     compare pass), which meets every row anyway, reports a string that is missing and everything runs again; 2 = behave as if one had been: a test knob),

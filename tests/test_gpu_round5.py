@@ -452,3 +452,51 @@ def test_a_streamed_count_never_reads_a_projection_only_column(oracle, dfdb_mod,
     with pytest.raises(Exception):
         dfdb.materialize_streamed(v, 8)
     tb.close()
+
+
+def test_groupreduce_by_an_integer_key_makes_its_groups_from_the_head_of_the_column(oracle, dfdb_mod, ctx):
+    """groupreduce by an Int64 key (aggregate.jl:1-36), dense form: the first rows / group numbers come from the head of the column, the accumulate pass — the one
+    with the table in LDS — meets every row and raises a flag for a key without a group, after which everything runs again over every row.  Same groups in order
+    of first appearance, same counts and sums: every key early (the head's table is used), a key / a missing value / a key outside the sampled span that first
+    turn up behind the head (found, redone), the redo forced, the option off; a narrow value column is not tried (the LDS form would not take it)."""
+    from test_gpu_parity import _np_group_ids, _np_groupreduce
+    dfdb = dfdb_mod
+    rng = np.random.default_rng(91)
+    n = 80_000
+    k_early = rng.integers(0, 40, n).astype(np.int64) * 5 - 60
+    k_late = k_early.copy(); k_late[-7] = 33                          # inside the span, never seen in the head
+    k_out = k_early.copy(); k_out[77 * 1024 + 5] = 10_000_019         # far outside what the sample saw (tile 77: the forced sample takes the even tiles)
+    km = np.ma.masked_array(k_early.copy(), mask=np.zeros(n, bool)); km.mask[-5] = True          # the only missing value sits behind the head
+    c = rng.integers(-1000, 1000, n).astype(np.int64)
+    u8 = rng.integers(0, 255, n).astype(np.uint8)
+    t = dfdb.DFTable.from_columns({"early": k_early, "late": k_late, "out": k_out, "km": km, "c": c, "u8": u8}, block_size=4096)
+    ctx.set_option("dense_head_tiles", 4)                            # a head of 4096 rows; the column has 79 tiles
+    ctx.set_option("unique_dense_sample", 2)                         # (a table this small is not sampled otherwise, and only a sampled span is trusted beyond the head)
+    ctx.profile(True)
+    try:
+        for by, keys, found_late in (("early", k_early, False), ("late", k_late, True), ("out", k_out, True), ("km", km, True)):
+            ids = _np_group_ids(list(keys))
+            for opt in (1, 2, 0):
+                ctx.set_option("groupreduce_optimistic", opt)
+                for col, vals, stat in (("c", c, "sum"), ("c", c, "min"), ("c", c, "count"), ("u8", u8, "sum")):
+                    h0, _ = ctx.profile_get("group_accumulate.head_table"); r0, _ = ctx.profile_get("group_accumulate.head_redo")
+                    got = dfdb.groupreduce(t, by, col, stat)
+                    h1, _ = ctx.profile_get("group_accumulate.head_table"); r1, _ = ctx.profile_get("group_accumulate.head_redo")
+                    order, cnt, want = _np_groupreduce(ids, vals, stat)
+                    gk = [None if pd.isna(kk) else int(kk) for kk in got[by].tolist()]
+                    wk = [None if (kk is np.ma.masked or kk is None) else int(kk) for kk in order]
+                    assert gk == wk and got["count"].tolist() == cnt.tolist(), (by, opt, col, stat)
+                    if stat != "count":
+                        assert np.array_equal(got[stat].to_numpy().astype(np.int64), want.astype(np.int64)), (by, opt, col, stat)
+                    if opt == 0 or col == "u8":                              # (a narrow value column: the LDS form would not take it, no head table is tried)
+                        assert (h1 - h0, r1 - r0) == (0, 0), (by, opt, col)
+                    elif opt == 2 or found_late:
+                        assert (h1 - h0, r1 - r0) == (0, 1), (by, opt, col, h1 - h0, r1 - r0)      # tried, redone over every row
+                    else:
+                        assert (h1 - h0, r1 - r0) == (1, 0), (by, opt, col, h1 - h0, r1 - r0)
+    finally:
+        ctx.profile(False)
+        ctx.set_option("groupreduce_optimistic", 1)
+        ctx.set_option("dense_head_tiles", 4096)
+        ctx.set_option("unique_dense_sample", 1)
+    t.close()
