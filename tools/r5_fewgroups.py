@@ -1,0 +1,19 @@
+import json, os, sys, time
+ROOT = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd()
+for p in (ROOT, os.path.join(ROOT, "dataframedbs.jl_amd")):
+    sys.path.insert(0, p)
+import torch, dfdb
+n = 1_000_000_000
+ctx = dfdb.default_context(0)
+t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+t.add_generated("x", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15, n)
+for m in (7, 300, 5000):
+    t.add_column_from("k%d" % m, t.x % m)
+for m in (7, 300, 5000):
+    for opt in (1, 0):
+        ctx.set_option("groupreduce_optimistic", opt)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = dfdb.groupreduce(t, "k%d" % m, "x", "sum"); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        print(json.dumps({"groups": m, "optimistic": opt, "best_ms": round(best * 1e3, 3), "n": len(r)}), flush=True)
