@@ -920,7 +920,13 @@ __global__ __launch_bounds__(kDenseBlock) void k_dense_presence(const uint64_t* 
   __syncthreads();
   bool outside = false;
   walk_selected<T>(bitmap, col, missing, nrows, 0, ntiles, (int64_t)blockIdx.x * (kDenseBlock / 64) + (threadIdx.x >> 6), (int64_t)gridDim.x * (kDenseBlock / 64),
-                   [&](uint64_t key, int64_t) { const uint64_t k = key - lo; if (k < range) atomicOr(&bits[k >> 5], 1u << (k & 31)); else outside = true; },
+                   // (the bit is looked at before it is set: a column of seven values sent 64 lanes' atomicOr to ONE word per instruction — 2.35 ms per 1e9 rows
+                   // against 1.24 for 300 or 5000 values; a plain read of one address is a broadcast)
+                   [&](uint64_t key, int64_t) {
+                     const uint64_t k = key - lo;
+                     if (k < range) { const uint32_t b = 1u << (k & 31); if (!(__atomic_load_n(&bits[k >> 5], __ATOMIC_RELAXED) & b)) atomicOr(&bits[k >> 5], b); }
+                     else outside = true;
+                   },
                    [&](int64_t row) { note_missing(aux, row); });
   if (outside) __atomic_store_n(&aux[kAuxOutside], 1ull, __ATOMIC_RELAXED);
   __syncthreads();
