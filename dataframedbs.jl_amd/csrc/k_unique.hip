@@ -87,6 +87,18 @@ __device__ __forceinline__ uint64_t table_find_maybe(const UniqueEntry* ent, uin
   }
   return kNoSlot;
 }
+// the group number (entry.row after k_group_ids) of a key that need not be there, the entry read ONCE as 16 bytes (key and row together: finding the slot and then
+// loading its row was a second dependent round trip per row of groupreduce's accumulate pass); kEmpty when the key has no slot
+__device__ __forceinline__ uint64_t table_row_maybe(const UniqueEntry* ent, uint64_t mask, uint64_t key, uint64_t h) {
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  for (int probes = 0; probes <= kMaxProbe; probes++) {
+    const u64x2 e = *(const u64x2*)&ent[h];
+    if (e.x == key) return e.y;
+    if (e.x == kEmpty) return kEmpty;
+    h = (h + 1) & mask;
+  }
+  return kEmpty;
+}
 // a workgroup's claimed slots -> aux[kAuxClaims] (one atomic per workgroup)
 __device__ __forceinline__ void add_claims(uint32_t mine, uint32_t* sh, uint64_t* aux) {
   if (mine) atomicAdd(sh, mine);
@@ -617,8 +629,10 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
   constexpr int U = 4;          // (eight: the same for integer keys, 1.6x slower on dictionary codes — measured)
   const int64_t stride = (int64_t)gridDim.x * nthreads;
   int vkind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);      // (the value kind is a property of the column)
+  bool unknown = false;
   for (int64_t row0 = (int64_t)blockIdx.x * nthreads + threadIdx.x; row0 < A.nrows; row0 += U * stride) {
     bool on[U], miss[U]; uint64_t key[U], gid[U], bits[U], w[U], mw[U];
+    (void)unknown;
     // every load of a trip is issued before any is looked at (round 5): the selection word, the key and the value of a row do not wait for each other — a key loaded only
     // where its selection bit is set is a second dependent round trip per trip (rows that are off read a key nobody uses)
 #pragma unroll
@@ -642,7 +656,10 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
       if (SRC == 1) gid[k] = A.rank_of_code[key[k]];
       else if (miss[k]) gid[k] = A.special[1];
       else if (SRC == 2) gid[k] = A.gids[key[k] - A.lo];
-      else gid[k] = key[k] == kEmpty ? A.special[0] : A.ent[table_find(A.ent, A.mask, key[k], slot_of(key[k], A.mask))].row;
+      else if (key[k] == kEmpty) gid[k] = A.special[0];
+      else gid[k] = table_row_maybe(A.ent, A.mask, key[k], slot_of(key[k], A.mask));      // (kEmpty: no slot — only an optimistically filled table can say that)
+      // (no group: the key, `missing` or the unstorable key never turned up among the rows the table was made from — the host runs everything again)
+      if (SRC == 0 && gid[k] >= (uint64_t)A.ngroups) { unknown = true; on[k] = false; }
     }
 #pragma unroll
     for (int k = 0; k < U; k++) {
@@ -651,6 +668,7 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
       else if (NG) group_add_t<(OPK < 0 ? 0 : OPK)>(lcnt, lval, gid[k], bits[k], vkind); else group_add_t<(OPK < 0 ? 0 : OPK)>(A.cnt, A.val, gid[k], bits[k], vkind);
     }
   }
+  if (SRC == 0 && unknown && A.unknown_flag) __atomic_store_n(A.unknown_flag, 1ull, __ATOMIC_RELAXED);
   if (NG) {
     __syncthreads();
     int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);      // (the value kind is a property of the column)
@@ -769,8 +787,9 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
 
 void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                              int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
-                             int64_t ngroups, uint64_t val_init) {
+                             int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag) {
   AccArgs A{};
+  A.unknown_flag = unknown_flag;                               // the table was filled from a prefix of the rows: a key without a slot raises this word
   A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.ent = ent; A.mask = mask; A.special = special;
   A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
   launch_group_acc<0>(s, A);

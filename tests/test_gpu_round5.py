@@ -366,6 +366,19 @@ def test_groupreduce_by_a_string_key_skips_the_inserts_it_does_not_need(oracle, 
                     m = arr == v
                     assert c_ == int(m.sum()) and s_ == int(a[m].sum()), (name, opt, v)
                 launches = after - before
+                # a Float64 key (floats always take the hash table) strikes it too: the accumulate pass probes every row's key anyway and reports one without a slot
+                fkeys = np.array([float(len(v)) * 0.25 if v != "late-comer" else -7.5 for v in keys])
+                if "f" not in t.names():
+                    t.add_column("f", fkeys)
+                b3, _ = ctx.profile_get("unique_insert")
+                gf = dfdb.groupreduce(t, "f", "a", "sum")
+                a3, _ = ctx.profile_get("unique_insert")
+                forder = list(dict.fromkeys(fkeys.tolist()))
+                assert gf["f"].tolist() == forder, (name, opt)
+                for v, c_, s_ in zip(gf["f"], gf["count"].to_numpy(), gf["sum"].to_numpy()):
+                    m = fkeys == v
+                    assert c_ == int(m.sum()) and s_ == int(a[m].sum()), (name, opt, v)
+                assert a3 - b3 == launches, (name, opt, a3 - b3, launches)
                 # plain unique over the same column strikes the same bargain (its compare pass meets every row)
                 b2, _ = ctx.profile_get("unique_insert")
                 u = list(t.s.unique())
