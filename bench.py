@@ -26,7 +26,7 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
   calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
                   `value` itself is the library-default configuration (no ctx option set)
                   Round 4 adds "3_computed" (config 3 with the computed x * 2 projection), "interp" (expressions outside the scan kernels: the device interpreter and
-                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "groupreduce", "groupreduce_int_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
+                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_float_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
@@ -459,7 +459,7 @@ def make_summary(res):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("ms_per_step")), _r((v.get("roofline") or {}).get("frac"))]
-    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_dictionary"):
+    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_float_key", "groupreduce_dictionary"):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("seconds", 0) * 1e3), _r((v.get("roofline") or {}).get("frac"))]
@@ -721,6 +721,18 @@ def f_rows_legs(L, dfdb, sc, rank):
         best = dt if best is None else min(best, dt)
     res["unique_float_key"] = {"rows": n, "distinct": len(uf), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
                                "what": "unique(t.f), f = x * 0.5 (Float64, 1e6 distinct values): the hash table of isequal images; best of 2"}
+    # ---- groupreduce by a Float64 key of 5000 values ((x mod 5000) * 0.5, made on the device) over the same 1e9 rows: floats always take the hash table
+    t.add_column_from("fk", (t.x % 5000) * 0.5)
+    best, g = None, None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g = dfdb.groupreduce(t, "fk", "x", "sum")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res["groupreduce_float_key"] = {"rows": n, "groups": len(g), "seconds": best, "rows_per_s": n / best,
+                                    "roofline": {"bound": "hbm", "achieved": n * 16 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 16 / best / 1e9 / L.peak},
+                                    "what": "groupreduce(t, (:fk,); out = :x => Sum()), fk = (x mod 5000) * 0.5 (Float64): the hash table is filled from the first 17 M rows (they stop bringing "
+                                            "new keys), the accumulate pass probes it with one 16-byte read per row and would report a key without a slot; bytes = key + value columns; best of 3"}
     # ---- groupreduce by an integer key: 5000 groups (x mod 5000, made on the device) over the same 1e9 rows, sum of x
     t.add_column_from("k", t.x % 5000)
     best, g = None, None
