@@ -732,7 +732,7 @@ def f_rows_legs(L, dfdb, sc, rank):
     res["groupreduce_float_key"] = {"rows": n, "groups": len(g), "seconds": best, "rows_per_s": n / best,
                                     "roofline": {"bound": "hbm", "achieved": n * 16 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 16 / best / 1e9 / L.peak},
                                     "what": "groupreduce(t, (:fk,); out = :x => Sum()), fk = (x mod 5000) * 0.5 (Float64): the hash table is filled from the first 17 M rows (they stop bringing "
-                                            "new keys), the accumulate pass probes it with one 16-byte read per row and would report a key without a slot; bytes = key + value columns; best of 3"}
+                                            "new keys), the accumulate pass looks a row's group up in a small table of the groups' keys in LDS and would report a key that is not among them; bytes = key + value columns; best of 3"}
     # ---- groupreduce by an integer key: 5000 groups (x mod 5000, made on the device) over the same 1e9 rows, sum of x
     t.add_column_from("k", t.x % 5000)
     best, g = None, None

@@ -141,7 +141,7 @@ struct dfdb_query {
   bool stream_owned = false;   // a chunk query handed out by dfdb_stream_next: owned by the stream
   dfdb::DevBuf dict_sel;       // K9: the selected rows' dictionary codes (materialize of a dictionary column)
   // dfdb_query_groupreduce: the full selection set aside, per-group counts / values, what the fetch needs
-  dfdb::DevBuf gr_sel, gr_cnt, gr_val;
+  dfdb::DevBuf gr_sel, gr_cnt, gr_val, gr_keys;     // (gr_keys: the key column's values at the groups' first rows, group order — k_group_acc_hash_lds)
   dfdb::DevBuf du_first, du_rows, du_rank;   // dict_unique's scratch (first row per code, the group rows, rank of every code)
   int64_t gr_n = 0; int gr_key = -1, gr_op = 0, gr_kind = 0, gr_state = 0;   // state 0: none, 1: empty result, 2: results + narrowed selection pending
   int mask_from = -1;          // table ordinal of the column whose calibrated bitmap this query has borrowed (-1: its own)

@@ -785,14 +785,123 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
   launch_group_acc<1>(s, A);
 }
 
-void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+// Keys that take the hash table (Float64, wide integers), a few thousand groups: the accumulate pass probed the GLOBAL table per row — a 64-bit mix, a 16-byte read
+// out of L2, a dependent round trip — and ran at 2 TB/s.  The groups' keys (the key column at the groups' first rows: `gkeys`, group order) are put into a small
+// open-addressing table IN LDS by every workgroup, beside its accumulators, and a row's group is a few ds_reads away (k_group_acc_dense_lds's shape otherwise).
+// Dynamic LDS: [ngp] counts, [ngp] values, [slots] 8-byte keys, [slots] 2-byte group numbers.  8-byte keys, 8-byte values (or none), at most 9216 groups.
+__device__ __forceinline__ uint32_t lds_slot_of(uint64_t key, uint32_t slots) {
+  uint32_t h = ((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u;
+  h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+  return (uint32_t)(((uint64_t)h * slots) >> 32);
+}
+template <int OPK>
+__global__ __launch_bounds__(1024) void k_group_acc_hash_lds(const AccArgs A, const void* __restrict__ gkeys, uint32_t slots, int ngp) {
+  extern __shared__ uint64_t dyn_sh[];
+  uint64_t* lcnt = dyn_sh; uint64_t* lval = dyn_sh + ngp; uint64_t* lkey = dyn_sh + 2 * ngp; uint16_t* lgid = (uint16_t*)(lkey + slots);
+  constexpr bool has_val = OPK != 0;
+  for (int g = threadIdx.x; g < A.ngroups; g += 1024) { lcnt[g] = 0; lval[g] = A.val_init; }
+  for (uint32_t i = threadIdx.x; i < slots; i += 1024) lkey[i] = kEmpty;
+  __syncthreads();
+  const uint64_t g_unstorable = A.special[0], g_missing = A.special[1];       // the groups of the key that cannot be stored / of `missing` (kEmpty: there is none)
+  for (int g = threadIdx.x; g < A.ngroups; g += 1024) {
+    if ((uint64_t)g == g_unstorable || (uint64_t)g == g_missing) continue;     // (their first rows hold no key of the table)
+    const uint64_t key = key_fixed(gkeys, A.keydt, g);
+    uint32_t h = lds_slot_of(key, slots);
+    for (;;) {
+      const uint64_t old = atomicCAS((unsigned long long*)&lkey[h], (unsigned long long)kEmpty, (unsigned long long)key);
+      if (old == kEmpty || old == key) { lgid[h] = (uint16_t)g; break; }
+      h = h + 1 == slots ? 0u : h + 1;
+    }
+  }
+  __syncthreads();
+  constexpr int U = 8;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  int vkind = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, vkind);
+  const bool fkey = A.keydt == DFDB_F64;
+  bool unknown = false;
+  for (int64_t row0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; row0 < A.nrows; row0 += U * stride) {
+    uint64_t w[U], mw[U], key[U], bits[U]; uint64_t gid[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {                              // every load of the trip before any is used
+      const int64_t row = row0 + k * stride;
+      const bool inb = row < A.nrows;
+      w[k] = inb ? A.sel[row >> 6] : 0ull;
+      mw[k] = (inb && A.missing) ? A.missing[row >> 6] : 0ull;
+      key[k] = inb ? ((const uint64_t*)A.keycol)[row] : 0ull;
+      bits[k] = (inb && has_val) ? ((const uint64_t*)A.valcol)[row] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const int64_t row = row0 + k * stride;
+      const bool on = (w[k] >> (row & 63)) & 1ull, miss = (mw[k] >> (row & 63)) & 1ull;
+      uint64_t kk = key[k];
+      if (fkey) { const double d = __longlong_as_double((long long)kk); if (d != d) kk = 0x7ff8000000000000ull; }      // (one NaN: key_fixed)
+      uint64_t g = kEmpty;
+      if (on) {
+        if (miss) g = g_missing;
+        else if (kk == kEmpty) g = g_unstorable;
+        else {
+          uint32_t h = lds_slot_of(kk, slots);
+          for (;;) {
+            const uint64_t t = lkey[h];
+            if (t == kk) { g = lgid[h]; break; }
+            if (t == kEmpty) break;                            // not among the groups: only a table made from a prefix of the rows can say that
+            h = h + 1 == slots ? 0u : h + 1;
+          }
+        }
+        if (g >= (uint64_t)A.ngroups) { unknown = true; g = kEmpty; }
+      }
+      gid[k] = g;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) if (gid[k] != kEmpty) group_add_t<OPK>(lcnt, lval, gid[k], bits[k], vkind);
+  }
+  if (unknown && A.unknown_flag) __atomic_store_n(A.unknown_flag, 1ull, __ATOMIC_RELAXED);
+  __syncthreads();
+  group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, vkind, has_val, 1024);
+}
+template <int OPK>
+static bool try_hash_lds(hipStream_t s, const AccArgs& A, const void* gkeys) {
+  const int ngp = (A.ngroups + 1) & ~1;
+  const size_t budget = 156 * 1024, acc = (size_t)ngp * 16;
+  if (acc + 64 * 10 > budget) return false;
+  size_t slots = std::min<size_t>((size_t)A.ngroups * 2 + 64, (budget - acc) / 10);
+  slots &= ~(size_t)3;                                         // (the 2-byte group numbers start on an 8-byte boundary)
+  if (slots < (size_t)A.ngroups + A.ngroups / 4 + 8) return false;             // (a load factor above 0.8: the probes get long)
+  const size_t lds = acc + slots * 10;
+  static std::atomic<bool> raised[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire))) {
+    if (hipFuncSetAttribute((const void*)k_group_acc_hash_lds<OPK>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+  }
+  const unsigned g = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (A.nrows + 1023) / 1024));
+  hipLaunchKernelGGL((k_group_acc_hash_lds<OPK>), dim3(g), dim3(1024), lds, s, A, gkeys, (uint32_t)slots, ngp);
+  return true;
+}
+int launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
                              int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
-                             int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag) {
+                             int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag, const void* gkeys) {
   AccArgs A{};
   A.unknown_flag = unknown_flag;                               // the table was filled from a prefix of the rows: a key without a slot raises this word
   A.sel = sel; A.keycol = keycol; A.keydt = keydt; A.missing = missing; A.valcol = valcol; A.valdt = valdt; A.op = op; A.nrows = nrows; A.ent = ent; A.mask = mask; A.special = special;
   A.cnt = cnt; A.val = val; A.ngroups = (int)ngroups; A.val_init = val_init;
+  if (gkeys && nrows > 0 && ngroups > 0 && (keydt == DFDB_I64 || keydt == DFDB_U64 || keydt == DFDB_F64)) {      // (1: the form with the groups' keys in an LDS table)
+    const int vkind = valdt == DFDB_F64 ? 2 : (valdt == DFDB_U64 ? 1 : 0);
+    const int opk = opk_of(op, valcol != nullptr, vkind);
+    const bool v8 = opk == 0 || valdt == DFDB_I64 || valdt == DFDB_U64 || valdt == DFDB_F64;
+    bool done = false;
+    if (v8) switch (opk) {
+      case 0: done = try_hash_lds<0>(s, A, gkeys); break;
+      case 1: done = try_hash_lds<1>(s, A, gkeys); break;
+      case 2: done = try_hash_lds<2>(s, A, gkeys); break;
+      case 3: done = try_hash_lds<3>(s, A, gkeys); break;
+      default: done = try_hash_lds<4>(s, A, gkeys); break;
+    }
+    if (done) return 1;
+  }
   launch_group_acc<0>(s, A);
+  return 0;
 }
 // String keys: k_str_pass, KIND 2
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,

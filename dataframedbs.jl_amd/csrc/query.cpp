@@ -1449,9 +1449,9 @@ void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
 // first appearance of the key and prints the map).  Completed to that intent: one group per distinct key (isequal), groups in order of first
 // appearance, count and one reduced value per group.  Device side: unique's table + k_group_ids + k_group_accumulate (k_unique.hip).
 void launch_group_ids(hipStream_t s, UniqueEntry* ent, uint64_t cap, uint64_t* special, const uint64_t* ubits, const uint64_t* uprefix);
-void launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
-                             int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
-                             int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag = nullptr);
+int launch_group_accumulate(hipStream_t s, const uint64_t* sel, const void* keycol, int keydt, const uint64_t* missing, const void* valcol, int valdt, int op,
+                            int64_t nrows, const UniqueEntry* ent, uint64_t mask, const uint64_t* special, uint64_t* cnt, uint64_t* val,
+                            int64_t ngroups, uint64_t val_init, uint64_t* unknown_flag = nullptr, const void* gkeys = nullptr);
 void launch_group_accumulate_str(hipStream_t s, const uint64_t* sel, const int32_t* sizes, const int64_t* tile_off, const uint8_t* bytes, const void* valcol, int valdt,
                                  int op, int64_t nrows, const UniqueEntry* ent, const uint64_t* rep_off, const uint32_t* rep_len, uint64_t mask, uint64_t* special, uint64_t salt,
                                  uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
@@ -1535,10 +1535,19 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
         launch_group_accumulate_str(s, q->gr_sel.as<uint64_t>(), kc.data.as<int32_t>(), (const int64_t*)kc.tile_off.p, kc.bytes.as<uint8_t>(), vc ? vc->data.p : nullptr,
                                     vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.rep_off.as<uint64_t>(), T.rep_len.as<uint32_t>(), T.cap - 1, special, T.salt,
                                     q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init);
-      else
-        launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr,
-                                vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, special,
-                                q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init, T.optimistic ? T.aux.as<uint64_t>() + 3 : nullptr); }
+      else {
+        // few groups of an 8-byte key: their keys (the key column at the first rows q's bitmap now holds, i.e. in group order) for the accumulate pass's LDS table
+        const void* gkeys = nullptr;
+        if (ng <= 9216 && dt_width(kc.dtype) == 8 && ctx_option(ctx, "groupreduce_lds_table", 1) != 0) {
+          q->gr_keys.ensure((size_t)ng * 8 + 64);
+          launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), kc.data.p, q->gr_keys.p, 8, t->nrows, ng);
+          gkeys = q->gr_keys.p;
+        }
+        if (launch_group_accumulate(s, q->gr_sel.as<uint64_t>(), kc.data.p, dt_base(kc.dtype), kmiss, vc ? vc->data.p : nullptr,
+                                    vc ? dt_base(vc->dtype) : 0, op, t->nrows, T.ent.as<UniqueEntry>(), T.cap - 1, special,
+                                    q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>(), ng, init, T.optimistic ? T.aux.as<uint64_t>() + 3 : nullptr, gkeys) > 0)
+          prof_note(ctx, "group_accumulate.hash_lds");
+      } }
     if (dense_lds > 0) prof_note(ctx, "group_accumulate.dense_lds");
     if (head_table) {
       uint64_t unknown = dense_lds < 0 ? 1ull : 0ull;                  // (-1: the LDS form could not take the job and nothing ran)

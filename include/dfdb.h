@@ -160,7 +160,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     4 M rows, taken only for columns of at least eight times that; its accumulate pass reports a key the head did not hold and everything runs again over all rows),
  *                     "dict_unique_head" = 0: unique / groupreduce over a dictionary-coded String column walk all of
  *                     the codes for their first rows at once (default 1: the first 4 M rows first, the rest only if a code has not turned up there), "unique_dense_sample" = 0 (2 = sample even a small table: a test knob): the dense form reads the
- *                     exact range of the keys first instead of laying its span around a sample's, "groupreduce_optimistic" = 0: dfdb_query_groupreduce by a String, Float or wide-integer key (and dfdb_query_unique over a String column) inserts every selected row into its hash table,
+ *                     exact range of the keys first instead of laying its span around a sample's, "groupreduce_lds_table" = 0: dfdb_query_groupreduce by a Float64 / wide-integer key of at most 9216 groups probes the global hash table per row
+ *                     (default 1: the groups' keys in a small table in LDS beside the accumulators), "groupreduce_optimistic" = 0: dfdb_query_groupreduce by a String, Float or wide-integer key (and dfdb_query_unique over a String column) inserts every selected row into its hash table,
  *                     and by a dense integer key walks every row for the first rows
  *                     (default 1: when the second chunk of rows — 16 M — brought no string the first — 1 M — had not, the rest are not inserted; the accumulate pass (unique: the
  *                     compare pass), which meets every row anyway, reports a string that is missing and everything runs again; 2 = behave as if one had been: a test knob),

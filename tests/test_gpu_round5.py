@@ -411,10 +411,33 @@ def test_groupreduce_by_an_integer_key_with_the_group_table_in_lds(oracle, dfdb_
     c = rng.integers(-1000, 1000, n).astype(np.int64)
     x = rng.normal(size=n) * 100
     u8 = rng.integers(0, 255, n).astype(np.uint8)
-    t = dfdb.DFTable.from_columns({"k": k, "km": km, "c": c, "x": x, "u8": u8}, block_size=4096)
+    fk = k * 0.5; fk[rng.random(n) < 0.01] = np.nan                   # Float64 keys take the hash table: the groups' keys go into an LDS table (k_group_acc_hash_lds)
+    fkm = np.ma.masked_array(k * 0.25, mask=rng.random(n) < 0.2)
+    t = dfdb.DFTable.from_columns({"k": k, "km": km, "fk": fk, "fkm": fkm, "c": c, "x": x, "u8": u8}, block_size=4096)
     ctx.profile(True)
     try:
         for view, sel in ((t[dfdb.ALL, dfdb.ALL], np.ones(n, bool)), (t[t.c > 0, dfdb.ALL], c > 0)):
+            for by, keys in (("fk", fk), ("fkm", fkm)):
+                ids = _np_group_ids([keys[i] for i in np.nonzero(sel)[0]])
+                for col, vals, stats in (("c", c, ("count", "sum", "min", "max")), ("x", x, ("sum", "max")), ("u8", u8, ("sum",))):
+                    for stat in stats:
+                        before, _ = ctx.profile_get("group_accumulate.hash_lds")
+                        got = dfdb.groupreduce(view, by, col, stat)
+                        after, _ = ctx.profile_get("group_accumulate.hash_lds")
+                        assert after - before == (0 if col == "u8" else 1), (by, col, stat)
+                        order, cnt, want = _np_groupreduce(ids, vals[sel], stat)
+                        gk = [None if kk is None or kk is pd.NA else ("nan" if kk != kk else float(kk)) for kk in [None if (isinstance(z, float) and False) else z for z in got[by].tolist()]]
+                        wk = [None if (kk is np.ma.masked or kk is None) else ("nan" if kk != kk else float(kk)) for kk in order]
+                        if by == "fkm":                                # (a masked value comes back as NaN in a float frame column: told apart by the masked order entry)
+                            gk = [None if (w_ is None) else g_ for g_, w_ in zip(gk, wk)]
+                        assert gk == wk, (by, col, stat)
+                        assert got["count"].tolist() == cnt.tolist(), (by, col, stat)
+                        if stat != "count":
+                            g = got[stat].to_numpy()
+                            if col == "x" and stat == "sum":
+                                assert np.allclose(g, want, rtol=1e-9, atol=1e-6), (by, col, stat)
+                            else:
+                                assert np.array_equal(g.astype(np.float64), want.astype(np.float64)), (by, col, stat)
             for by, keys in (("k", k), ("km", km)):
                 ids = _np_group_ids([keys[i] for i in np.nonzero(sel)[0]])
                 for col, vals, stats in (("c", c, ("count", "sum", "min", "max")), ("x", x, ("sum", "min", "max")), ("u8", u8, ("sum",))):
