@@ -797,7 +797,8 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint64_t key, uint32_t slots) {
 template <int OPK>
 __global__ __launch_bounds__(1024) void k_group_acc_hash_lds(const AccArgs A, const void* __restrict__ gkeys, uint32_t slots, int ngp) {
   extern __shared__ uint64_t dyn_sh[];
-  uint64_t* lcnt = dyn_sh; uint64_t* lval = dyn_sh + ngp; uint64_t* lkey = dyn_sh + 2 * ngp; uint16_t* lgid = (uint16_t*)(lkey + slots);
+  // (a workgroup meets fewer than 2^32 rows: its counts are 4 bytes, which leaves the key table more room — a lower load factor, shorter probe sequences)
+  uint64_t* lval = dyn_sh; uint64_t* lkey = dyn_sh + ngp; uint32_t* lcnt = (uint32_t*)(lkey + slots); uint16_t* lgid = (uint16_t*)(lcnt + ngp);
   constexpr bool has_val = OPK != 0;
   for (int g = threadIdx.x; g < A.ngroups; g += 1024) { lcnt[g] = 0; lval[g] = A.val_init; }
   for (uint32_t i = threadIdx.x; i < slots; i += 1024) lkey[i] = kEmpty;
@@ -854,19 +855,34 @@ __global__ __launch_bounds__(1024) void k_group_acc_hash_lds(const AccArgs A, co
       gid[k] = g;
     }
 #pragma unroll
-    for (int k = 0; k < U; k++) if (gid[k] != kEmpty) group_add_t<OPK>(lcnt, lval, gid[k], bits[k], vkind);
+    for (int k = 0; k < U; k++) if (gid[k] != kEmpty) {
+      atomicAdd(&lcnt[gid[k]], 1u);
+      if (OPK == 1) atomicAdd((unsigned long long*)&lval[gid[k]], (unsigned long long)bits[k]);
+      if (OPK == 2) atomicAdd((double*)&lval[gid[k]], __longlong_as_double((long long)bits[k]));
+      if (OPK == 3) atomicMin((unsigned long long*)&lval[gid[k]], (unsigned long long)order_image(bits[k], vkind, DFDB_AGG_MIN));
+      if (OPK == 4) atomicMax((unsigned long long*)&lval[gid[k]], (unsigned long long)order_image(bits[k], vkind, DFDB_AGG_MAX));
+    }
   }
   if (unknown && A.unknown_flag) __atomic_store_n(A.unknown_flag, 1ull, __ATOMIC_RELAXED);
   __syncthreads();
-  group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, vkind, has_val, 1024);
+  for (int g = threadIdx.x; g < A.ngroups; g += 1024) {         // (group_flush with 4-byte counts)
+    const uint32_t c = lcnt[g];
+    if (!c) continue;
+    atomicAdd((unsigned long long*)&A.cnt[g], (unsigned long long)c);
+    if (OPK == 1) atomicAdd((unsigned long long*)&A.val[g], (unsigned long long)lval[g]);
+    if (OPK == 2) atomicAdd((double*)&A.val[g], __longlong_as_double((long long)lval[g]));
+    if (OPK == 3) atomicMin((unsigned long long*)&A.val[g], (unsigned long long)lval[g]);
+    if (OPK == 4) atomicMax((unsigned long long*)&A.val[g], (unsigned long long)lval[g]);
+  }
 }
 template <int OPK>
 static bool try_hash_lds(hipStream_t s, const AccArgs& A, const void* gkeys) {
   const int ngp = (A.ngroups + 1) & ~1;
-  const size_t budget = 156 * 1024, acc = (size_t)ngp * 16;
+  // LDS: [ngp] 8-byte values, [slots] 8-byte keys, [ngp] 4-byte counts, [slots] 2-byte group numbers
+  const size_t budget = 156 * 1024, acc = (size_t)ngp * 12;
   if (acc + 64 * 10 > budget) return false;
-  size_t slots = std::min<size_t>((size_t)A.ngroups * 2 + 64, (budget - acc) / 10);
-  slots &= ~(size_t)3;                                         // (the 2-byte group numbers start on an 8-byte boundary)
+  size_t slots = std::min<size_t>((size_t)A.ngroups * 3 + 64, (budget - acc) / 10);
+  slots &= ~(size_t)3;
   if (slots < (size_t)A.ngroups + A.ngroups / 4 + 8) return false;             // (a load factor above 0.8: the probes get long)
   const size_t lds = acc + slots * 10;
   static std::atomic<bool> raised[64] = {};
