@@ -319,12 +319,15 @@ int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, d
     if (ordinal < 0 || (size_t)ordinal >= t->cols.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: column ordinal %d", ordinal);
     const Column& c = t->cols[(size_t)ordinal];
     if (!c.resident || dt_width(c.dtype) != 8 || dt_base(c.dtype) == DFDB_STRING) fail(DFDB_ERR_ARGUMENT, "ArgumentError: the read probe takes a resident 8-byte column");
+    if (c.comp_only || !c.data.p) fail(DFDB_ERR_ARGUMENT, "ArgumentError: column %s is compressed-only (keep_compressed = 2): there is no decoded array to probe", c.name.c_str());
     dfdb_ctx* ctx = t->ctx;
     HIP_CHECK(hipSetDevice(ctx->device));
     if (repeats < 1) repeats = 1;
     if (repeats > 64) repeats = 64;
     DevBuf sink; sink.ensure(256);
-    std::vector<hipEvent_t> ev((size_t)repeats + 1);
+    struct Events { std::vector<hipEvent_t> v; ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } evs;   // (released on every path: HIP_CHECK throws)
+    evs.v.assign((size_t)repeats + 1, nullptr);
+    std::vector<hipEvent_t>& ev = evs.v;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
     launch_read_probe(ctx->stream, c.data.p, c.nrows, sink.as<uint64_t>());      // (untimed: the first launch of a kernel loads its code object)
     HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
@@ -339,7 +342,6 @@ int32_t dfdb_table_read_probe(dfdb_table* t, int32_t ordinal, int32_t repeats, d
       float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev[(size_t)r], ev[(size_t)r + 1]));
       sum += ms; if (r == 0 || ms < best) best = ms;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (best_ms) *best_ms = best;
     if (avg_ms) *avg_ms = sum / repeats;
   });

@@ -535,7 +535,17 @@ static int32_t gguard(F&& f) noexcept {
   catch (...) { set_last_error("unknown error"); return DFDB_ERR_DEVICE; }
 }
 #define GNEED(p) do { if (!(p)) fail(DFDB_ERR_ARGUMENT, "null argument: " #p); } while (0)
-#define GNEEDQ(gq) do { GNEED(gq); if (!(gq)->gt) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); } while (0)
+// (the whole-column decodes of compressed-only columns a group entry point makes on its shards live until that entry point returns, like NEEDQT's in c_api.cpp:
+// without this they stayed in HBM — hidden from dfdb_table_resident_bytes — until some plain query call on the shard's table)
+struct GroupTransientScope {
+  dfdb_gquery* gq;
+  explicit GroupTransientScope(dfdb_gquery* q) : gq(q) {}
+  ~GroupTransientScope() {
+    if (!gq || !gq->gt) return;
+    for (dfdb_table* t : gq->gt->shard) if (t) { (void)hipSetDevice(t->ctx->device); dfdb::table_drop_transient(t); }
+  }
+};
+#define GNEEDQ(gq) GNEED(gq); if (!(gq)->gt) fail(DFDB_ERR_ARGUMENT, "the table of this query was closed"); GroupTransientScope group_transient_scope_(gq)
 
 extern "C" {
 

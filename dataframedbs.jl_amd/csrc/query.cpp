@@ -246,6 +246,13 @@ static bool comp_scannable(const dfdb_table* t, const ScanTerm& tm, int ord) {
 }
 
 static void raise_reached_errors(dfdb_query* q, int nstages);
+// The bitmap was changed outside query_execute (unique narrowed it to the first occurrences, groupreduce put the full selection back): everything derived
+// from the PREVIOUS bitmap goes — the host count, and the survivors' arenas of compressed-only projection columns, which hold only the blocks that kept a
+// row under the selection they were decoded for (a fetch restored the full selection and a later materialize gathered through the narrowed arena).
+static void selection_changed(dfdb_query* q) {
+  q->count = -1;
+  for (auto& a : q->arenas) a.second.valid = false;
+}
 static void scan_prefix(dfdb_query* q) {
   dfdb_ctx* ctx = q->t->ctx;
   LaunchTimer lt(ctx, "scan_counts");
@@ -1190,7 +1197,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
   HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
   launch_set_rows(s, drows.as<uint64_t>(), (int)ng, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>());
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
+  selection_changed(q); q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1; q->const_str_col = -1;
   stream_wait(ctx);                                        // rows / rank are pageable host memory
   return ng;
 }
@@ -1376,7 +1383,10 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       uint64_t r = 0;
       // (numeric keys: only for a caller whose own pass over the rows can report a key without a slot — groupreduce's accumulate pass, defer_verify —, and only when
       // the distinct keys are few beside the rows, so that the first rows come straight out of the table below)
-      if (c == 2 && (is_str || T.defer_verify) && T.allow_optimistic && claims_c0 != ~0ull && (is_str || st[0] * 8 <= (uint64_t)cnt)) { T.optimistic = true; break; }
+      // (String keys too.  After an optimistic break the mark step below must take the first rows straight out of the table — launch_unique_scatter,
+      // `st[0] * 8 <= cnt` — because the per-row mark pass looks every selected row up with an unbounded probe, and a row of the un-inserted tail whose
+      // string the table does not hold would never leave that loop: a GPU hang, which no host-side guard can catch.)
+      if (c == 2 && (is_str || T.defer_verify) && T.allow_optimistic && claims_c0 != ~0ull && st[0] * 8 <= (uint64_t)cnt) { T.optimistic = true; break; }
       for (;;) {
         insert(t0, t1);
         read_state(&r, t1);
@@ -1439,7 +1449,7 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
     if (!dense) unique_hashed(q, col, cnt, T);
   }
   scan_prefix(q);
-  q->count = -1; q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1;
+  selection_changed(q); q->cap_col = -1; q->cap_col2 = -1; q->cap_str_col = -1; q->agg_col = -1;
   stream_wait(ctx);                                        // the tables die here (or stay with the caller: groupreduce looks rows up in them)
   if (!keep) { RecycleScope rs; local = UniqueTables(); }
 }
@@ -1560,7 +1570,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
         prof_note(ctx, "group_accumulate.head_redo");
         launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);     // the full selection again
         scan_prefix(q);
-        q->count = -1;
+        selection_changed(q);
         continue;
       }
       prof_note(ctx, "group_accumulate.head_table");
@@ -1577,7 +1587,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     else if (++T.salt_skip > 8) fail(DFDB_ERR_DEVICE, "unique: hash collisions under 8 different salts");
     launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);     // the full selection again
     scan_prefix(q);
-    q->count = -1;
+    selection_changed(q);
   }
   launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
   stream_wait(ctx);                                        // the tables die here
@@ -1611,7 +1621,7 @@ void query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, 
   if (q->gr_state == 2) {                                  // back to the full selection: bitmap + tile counts + prefix
     launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
     scan_prefix(q);
-    q->count = -1;
+    selection_changed(q);
   }
   q->gr_state = 0;
 }

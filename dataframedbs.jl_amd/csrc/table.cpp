@@ -473,8 +473,10 @@ static void load_from_file(dfdb_table* t, Column& c, int64_t block_first, int64_
   // milliseconds) would hold up the copies queued behind it and PCIe would idle exactly as before (measured: 127 ms against 104)
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> prog_ev;
+  // (declared BEFORE the guard, so destroyed after it: these are the pageable sources of the side stream's asynchronous copies, and an exception that unwinds
+  // this frame must find them alive until SideGuard has synchronised that stream — ADVICE r5)
+  std::vector<std::vector<Lz4Block>> prog_desc;
   struct SideGuard { hipStream_t& st; std::vector<hipEvent_t>& ev; ~SideGuard() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } for (hipEvent_t e : ev) (void)hipEventDestroy(e); } } side_guard{side, prog_ev};
-  std::vector<std::vector<Lz4Block>> prog_desc;                                // (pageable sources of asynchronous copies: alive until the final synchronisation)
   auto progress = [&](bool last) {                                             // decode what has arrived since the last batch (blocks hs[predecoded ..) whose bodies end <= staged bytes)
     if (!progressive || pre.state.load() != 1) return;
     if (!prog_ready) {
@@ -600,19 +602,14 @@ uint8_t* ctx_hist_scratch(dfdb_ctx* ctx, int* waves) {
   if (waves) *waves = w;
   return ctx->hist.as<uint8_t>();
 }
+static void transient_decode_checked(dfdb_table* t, Column& c);
 // the decoded array of a fixed-width column; a compressed-only one is decoded whole, now, for the ABI call in progress (the statuses of that decode are
-// read by table_drop_transient, which every such call ends with)
+// read right behind the launch: transient_decode_checked)
 const void* column_data(dfdb_table* t, Column& c) {
   if (!c.comp_only || c.data.p) return c.data.p;
-  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   c.data.ensure((size_t)c.nrows * (size_t)dt_width(c.dtype) + 256);
   c.transient = true;
-  const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
-  const int mode = column_lz4_index(ctx, c, lz4_decode_takes_index((int32_t)c.comp_nblocks, pipe));
-  LaunchTimer lt(ctx, "lz4_decode");
-  prof_note(ctx, "lz4_decode.transient");
-  launch_lz4_decode(s, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), pipe,
-                    c.comp_index.as<uint32_t>(), mode);
+  transient_decode_checked(t, c);
   return c.data.p;
 }
 void table_drop_transient(dfdb_table* t) {
@@ -621,6 +618,28 @@ void table_drop_transient(dfdb_table* t) {
   if (!any) return;
   (void)hipStreamSynchronize(t->ctx->stream);                 // whatever the call launched over the transient arrays has to be done with them
   for (Column& c : t->cols) if (c.transient) { c.data.release(); c.transient = false; }
+}
+// A whole-column transient decode is only as good as its statuses (the reference's `@assert size == sizes.origin "decompression error"`, BlockStreams.jl:112):
+// they are read right behind the launch — a consumer that fed on garbage must never hand it to the caller.  A bad status with the sequence-start
+// index in use drops the index and decodes once more by parsing; bad again = the resident blocks are damaged.
+static void transient_decode_checked(dfdb_table* t, Column& c) {
+  dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int pipe = (int)ctx_option(ctx, "lz4_pipeline", -1);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const int mode = attempt == 0 ? column_lz4_index(ctx, c, lz4_decode_takes_index((int32_t)c.comp_nblocks, pipe)) : 0;
+    { LaunchTimer lt(ctx, "lz4_decode");
+      prof_note(ctx, "lz4_decode.transient");
+      launch_lz4_decode(s, c.comp.as<uint8_t>(), c.data.as<uint8_t>(), c.comp_blocks.as<Lz4Block>(), (int32_t)c.comp_nblocks, c.comp_status.as<int32_t>(), pipe,
+                        mode ? c.comp_index.as<uint32_t>() : nullptr, mode); }
+    std::vector<int32_t> st((size_t)c.comp_nblocks);
+    HIP_CHECK(hipMemcpyAsync(st.data(), c.comp_status.p, st.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    int64_t bad = 0; for (int32_t v : st) bad += v != 0;
+    if (!bad) return;
+    if (mode != 0) { c.comp_index.release(); c.comp_index_state = 0; HIP_CHECK(hipMemsetAsync(c.comp_status.p, 0, st.size() * 4, s)); continue; }   // the index may be what is damaged
+    c.data.release(); c.transient = false;
+    fail(DFDB_ERR_FORMAT, "column %s: %lld of its resident LZ4 blocks do not decode", c.name.c_str(), (long long)bad);
+  }
 }
 void table_resident_bytes(dfdb_table* t, int32_t ordinal, int64_t* decoded, int64_t* compressed) {
   int64_t d = 0, k = 0;

@@ -7,6 +7,5 @@ mkdir -p gpurun_out/r5
   cat /sys/devices/system/node/node*/cpulist
   nproc; taskset -p $$
 } > gpurun_out/r5/numa_box.txt 2>&1
-sed -i 's/range(5)/range(2)/' tools/r5_reader_ab.py
-DFDB_STREAM_DEBUG=1 DFDB_STREAM_DEBUG_CPUS=1 timeout 300 python tools/r5_reader_ab.py > gpurun_out/r5/numa_ab.out 2> gpurun_out/r5/numa_ab.err
+DFDB_AB_REPEATS=2 DFDB_STREAM_DEBUG=1 DFDB_STREAM_DEBUG_CPUS=1 timeout 300 python tools/r5_reader_ab.py > gpurun_out/r5/numa_ab.out 2> gpurun_out/r5/numa_ab.err
 cat gpurun_out/r5/numa_ab.out

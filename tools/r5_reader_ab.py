@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """the same 1e9-row Int64 column file on the same box, DFDB_STREAM_DEBUG=1: dfdb_table_load's reader against the block stream's (one reading turn, three turns,
 one turn with 16 pread threads) — per-piece read times go to stderr, one JSON line per run to stdout"""
@@ -17,7 +18,7 @@ try:
         t.add_generated("b", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C16, 1_000_000_000)
     st = t.save(os.path.join(d, "tb")); t.close()
     xbytes = os.path.getsize(os.path.join(d, "tb", "1.bin"))
-    for rep in range(5):
+    for rep in range(int(os.environ.get('DFDB_AB_REPEATS', '5'))):
         for what, readers, io, chunk in (("load", 0, 8, 1024), ("stream", 3, 8, 1024), ("stream", 2, 8, 1024), ("stream", 1, 8, 1024)):
             ctx.set_option("io_threads", io)
             print(f"---- {what} readers={readers} io={io} rep={rep}", file=sys.stderr, flush=True)
