@@ -1,6 +1,7 @@
 // c_api.cpp — the extern "C" boundary of libdfdb_hip.so (include/dfdb.h).  Every entry point converts
 // engine exceptions to status codes; nothing else crosses the ABI.
 #include "engine.hpp"
+#include "ooc.hpp"
 #include <mutex>
 #include <cstdio>
 
@@ -388,22 +389,24 @@ int32_t dfdb_query_free(dfdb_query* q) {
   });
 }
 int32_t dfdb_query_add_range(dfdb_query* q, int64_t start, int64_t step, int64_t stop) {
-  return guard([&] { NEEDQ(q); Stage s; s.kind = ST_RANGE; s.start = start; s.step = step; s.stop = stop; query_add_stage(q, std::move(s)); });
+  return guard([&] { NEEDQ(q); ooc_reset(q); Stage s; s.kind = ST_RANGE; s.start = start; s.step = step; s.stop = stop; query_add_stage(q, std::move(s)); });
 }
 int32_t dfdb_query_add_indices(dfdb_query* q, const int64_t* idx, int64_t n) {
   return guard([&] {
     NEEDQ(q); if (n > 0) NEED(idx);
+    ooc_reset(q);
     if (n < 0) fail(DFDB_ERR_ARGUMENT, "negative index count");
     Stage s; s.kind = ST_INDICES; s.idx.assign(idx, idx + n);
     query_add_stage(q, std::move(s));
   });
 }
 int32_t dfdb_query_add_integer(dfdb_query* q, int64_t i) {
-  return guard([&] { NEEDQ(q); Stage s; s.kind = ST_INTEGER; s.idx = {i}; query_add_stage(q, std::move(s)); });
+  return guard([&] { NEEDQ(q); ooc_reset(q); Stage s; s.kind = ST_INTEGER; s.idx = {i}; query_add_stage(q, std::move(s)); });
 }
 int32_t dfdb_query_add_predicate(dfdb_query* q, const uint8_t* ir, size_t len) {
   return guard([&] {
     NEEDQ(q); NEED(ir);
+    ooc_reset(q);
     Stage s; s.kind = ST_PRED; s.pred = parse_ir(*q->t, ir, len);
     if (s.pred->dtype != DFDB_BOOL) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Function for selection must have Bool result type");   // selection.jl:52-55
     query_add_stage(q, std::move(s));
@@ -419,6 +422,7 @@ int32_t dfdb_query_set_projection(dfdb_query* q, int32_t n, const char* const* n
       np.push_back(ProjCol{names[i], parse_ir(*q->t, irs[i], lens[i])});
     }
     q->proj = std::move(np);
+    ooc_reset(q);
   });
 }
 int32_t dfdb_query_ncols(dfdb_query* q, int32_t* n) { return guard([&] { NEEDQ(q); NEED(n); *n = (int32_t)q->proj.size(); }); }
@@ -442,13 +446,14 @@ int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivor
 int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }
 
 // ------------------------------------------------------------------ execution
-int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQT(q); query_execute(q, -1); }); }
-int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQT(q); query_unique(q, proj_col); }); }
+// (out of core there is nothing to leave in HBM: the consumers stream when they are asked)
+int32_t dfdb_query_execute(dfdb_query* q) { return guard([&] { NEEDQT(q); if (query_out_of_core(q)) { ooc_reset(q); return; } query_execute(q, -1); }); }
+int32_t dfdb_query_unique(dfdb_query* q, int32_t proj_col) { return guard([&] { NEEDQT(q); if (query_out_of_core(q)) { ooc_unique(q, proj_col); return; } query_unique(q, proj_col); }); }
 int32_t dfdb_query_groupreduce(dfdb_query* q, int32_t key_col, int32_t val_col, int32_t stat, int64_t* ngroups, int64_t* key_string_bytes) {
-  return guard([&] { NEEDQT(q); query_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); });
+  return guard([&] { NEEDQT(q); if (query_out_of_core(q)) { ooc_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); return; } query_groupreduce(q, key_col, val_col, stat, ngroups, key_string_bytes); });
 }
 int32_t dfdb_query_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* values_i, double* values_f) {
-  return guard([&] { NEEDQT(q); query_groupreduce_fetch(q, keys, counts, values_i, values_f); });
+  return guard([&] { NEEDQT(q); if (q->ooc && q->ooc->gr_pending) { ooc_groupreduce_fetch(q, keys, counts, values_i, values_f); return; } query_groupreduce_fetch(q, keys, counts, values_i, values_f); });
 }
 int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
   return guard([&] { NEEDQ(q); q->hint_agg_op = op; q->hint_agg_proj = proj_col; });   // (affects the NEXT execution only: an executed query keeps its results)
@@ -456,25 +461,68 @@ int32_t dfdb_query_hint_aggregate(dfdb_query* q, int32_t op, int32_t proj_col) {
 int32_t dfdb_query_hint_materialize(dfdb_query* q, int32_t on) {
   return guard([&] { NEEDQ(q); if (q->hint_materialize != (on != 0)) { q->hint_materialize = on != 0; q->executed_stages = -1; q->count = -1; q->prefix_valid = false; } });
 }
-int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0; }); }
-int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_count(q, -1); }); }
+int32_t dfdb_query_reset(dfdb_query* q) { return guard([&] { NEEDQ(q); ooc_reset(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0; }); }
+int32_t dfdb_count(dfdb_query* q, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_out_of_core(q) ? ooc_count(q) : query_count(q, -1); }); }
 int32_t dfdb_count_to(dfdb_query* q, int64_t* out, int32_t memkind) {
   return guard([&] {
     NEEDQT(q); NEED(out);
+    if (query_out_of_core(q)) {
+      const int64_t n = ooc_count(q);
+      if (memkind != DFDB_MEM_DEVICE) { *out = n; return; }
+      HIP_CHECK(hipMemcpyAsync(out, &n, 8, hipMemcpyHostToDevice, q->t->ctx->stream)); HIP_CHECK(hipStreamSynchronize(q->t->ctx->stream));
+      return;
+    }
     if (memkind != DFDB_MEM_DEVICE) { *out = query_count(q, -1); return; }
     if (q->executed_stages != (int)q->stages.size() || q->bitmap_rows != q->t->nrows) query_execute(q, -1);
     const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
     HIP_CHECK(hipMemcpyAsync(out, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
   });
 }
-int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) { return guard([&] { NEEDQT(q); NEED(out); query_select_bitmap(q, out, memkind); }); }
-int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
-  return guard([&] { NEEDQT(q); if (cap > 0) NEED(out); query_select_indices(q, out, cap, memkind, n); });
+int32_t dfdb_select_bitmap(dfdb_query* q, uint64_t* out, int32_t memkind) {
+  return guard([&] {
+    NEEDQT(q); NEED(out);
+    if (query_out_of_core(q)) fail(DFDB_ERR_UNSUPPORTED, "the selection bitmap of a view whose columns are not resident exists one chunk at a time: take it from the chunks of dfdb_stream_next");
+    query_select_bitmap(q, out, memkind);
+  });
 }
-int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEEDQT(q); NEED(nbytes); *nbytes = query_string_bytes(q, i); }); }
-int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEEDQT(q); if (ncols > 0) NEED(outs); query_materialize(q, outs, ncols); }); }
-int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQT(q); query_aggregate(q, op, i, out_i, out_f); }); }
+int32_t dfdb_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
+  return guard([&] { NEEDQT(q); if (cap > 0) NEED(out); if (query_out_of_core(q)) { ooc_select_indices(q, out, cap, memkind, n); return; } query_select_indices(q, out, cap, memkind, n); });
+}
+int32_t dfdb_result_string_bytes(dfdb_query* q, int32_t i, int64_t* nbytes) { return guard([&] { NEEDQT(q); NEED(nbytes); *nbytes = query_out_of_core(q) ? ooc_string_bytes(q, i) : query_string_bytes(q, i); }); }
+int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { return guard([&] { NEEDQT(q); if (ncols > 0) NEED(outs); if (query_out_of_core(q)) { ooc_materialize(q, outs, ncols); return; } query_materialize(q, outs, ncols); }); }
+int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) { return guard([&] { NEEDQT(q); if (query_out_of_core(q)) { ooc_aggregate(q, op, i, out_i, out_f); return; } query_aggregate(q, op, i, out_i, out_f); }); }
 
+
+/* ---- only what the view needs, resident only if it fits (view.jl:183-190, blocksiterator.jl:20-33) ---- */
+int32_t dfdb_query_prepare(dfdb_query* q, int32_t* how) {
+  return guard([&] { NEEDQ(q); const int32_t h = query_prepare(q); if (how) *how = h; });
+}
+int32_t dfdb_query_read_stats(dfdb_query* q, dfdb_sizestats* stats) {
+  return guard([&] { NEEDQ(q); NEED(stats); *stats = q->ooc ? q->ooc->read : dfdb_sizestats{0, 0, 0}; });
+}
+int32_t dfdb_table_unload(dfdb_table* t, const int32_t* ordinals, int32_t ncols) {
+  return guard([&] {
+    NEED(t); if (ncols > 0) NEED(ordinals);
+    HIP_CHECK(hipSetDevice(t->ctx->device));
+    HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+    for (dfdb_query* q : t->queries) { query_return_mask(q); q->executed_stages = -1; q->count = -1; q->prefix_valid = false; q->gr_state = 0; q->arenas.clear(); ooc_reset(q); }
+    std::vector<int32_t> all;
+    if (!ordinals) { for (size_t i = 0; i < t->cols.size(); i++) all.push_back((int32_t)i); ordinals = all.data(); ncols = (int32_t)all.size(); }
+    for (int32_t k = 0; k < ncols; k++) {
+      const int32_t o = ordinals[k];
+      if (o < 0 || (size_t)o >= t->cols.size()) fail(DFDB_ERR_KEY, "KeyError: column ordinal %d", o);
+      Column& c = t->cols[(size_t)o];
+      if (c.file.empty()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: column %s has no backing file: unloading it would lose it", c.name.c_str());
+      c.data.release(); c.bytes.release(); c.tile_off.release(); c.missing.release(); c.comp.release(); c.comp_blocks.release(); c.comp_status.release(); c.comp_index.release();
+      c.mask_pref.release(); c.mask_calibrated = false; c.mask_lent = false;
+      c.dict_codes.release(); c.dict_len.release(); c.dict_off.release(); c.dict_bytes.release(); c.dict_host.clear(); c.dict_n = 0;
+      c.comp_blocks_host.clear(); c.comp_nblocks = 0; c.comp_index_state = 0; c.comp_only = false; c.transient = false; c.resident = false; c.nrows = 0; c.nbytes = 0;
+    }
+    bool any = false;
+    for (const Column& c : t->cols) any = any || c.resident;
+    if (!any) { t->nrows = -1; t->block_first = 0; }
+  });
+}
 }  // extern "C"
 
 namespace dfdb {

@@ -81,6 +81,7 @@ struct ProjCol { std::string name; NodePtr expr; };
 
 }  // namespace dfdb
 
+namespace dfdb { struct OocState; }
 struct dfdb_query;
 struct dfdb_table {
   dfdb_ctx* ctx = nullptr;
@@ -149,6 +150,8 @@ struct dfdb_query {
   int executed_stages = -1;    // how many stages the current bitmap reflects (-1 = none)
   bool prefix_valid = false;
   int64_t count = -1;          // host copy of the total (valid when >= 0)
+  // what the query has learnt by block-streaming a table whose required columns are not resident (ooc.hpp; null until it does)
+  std::shared_ptr<dfdb::OocState> ooc;
 };
 
 namespace dfdb {

@@ -27,6 +27,7 @@
 // groupreduce over the whole table: per-shard device reduction, packed records all-gathered, merged by key in rank order (group_reduce_all);
 // (4) materialize with the result left sharded on the devices.
 #include "engine.hpp"
+#include "ooc.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
@@ -166,16 +167,7 @@ struct dfdb_gtable {
   int64_t total_rows = -1;               // rows of the whole table (all ranks); -1 until something is resident
   std::vector<dfdb_gquery*> queries;
 };
-// unique / groupreduce over every shard: one record per distinct key, merged in rank order (= table order), kept until fetched
-struct GroupMerged {
-  bool valid = false, with_stats = false;
-  int32_t key_dtype = 0; int kind = 0, op = 0;       // kind of the value column: 0 signed, 1 unsigned, 2 float (dfdb_query::gr_kind)
-  int64_t ng = 0;
-  std::vector<uint8_t> key_data;                     // fixed width: ng * width bytes; String: ng int32 sizes (-1 = missing)
-  std::vector<uint8_t> key_missing;                  // ng flags (1 = the key is missing)
-  std::vector<uint8_t> key_bytes;                    // String keys: their bytes, concatenated
-  std::vector<int64_t> counts; std::vector<uint64_t> vals;   // vals: Int64 / UInt64 / Float64 bits
-};
+// (GroupMerged — unique / groupreduce over every shard: one record per distinct key, merged in rank order = table order, kept until fetched — lives in ooc.hpp)
 struct dfdb_gquery {
   GroupMerged merged;
   dfdb_gtable* gt = nullptr;
@@ -278,24 +270,7 @@ static void group_alloc_exchange(dfdb_group* g) {
 static ncclDataType_t nccl_type(int dt) { return dt == DFDB_F64 ? ncclFloat64 : (dt == DFDB_U64 ? ncclUint64 : ncclInt64); }
 static ncclRedOp_t nccl_op(int op) { return op == DFDB_AGG_MIN ? ncclMin : (op == DFDB_AGG_MAX ? ncclMax : ncclSum); }
 
-template <class T> static T fold(T a, T b, int op) { return op == DFDB_AGG_MIN ? std::min(a, b) : (op == DFDB_AGG_MAX ? std::max(a, b) : (T)(a + b)); }
-// Julia's min / max over Float64: NaN propagates, and -0.0 orders below 0.0 (Base.min / Base.max; the device reductions compare an
-// order-preserving image and agree); std::min / std::max would keep whichever zero came first
-static double fold_f64(double x, double y, int op) {
-  if (op == DFDB_AGG_SUM) return x + y;
-  if (std::isnan(x) || std::isnan(y)) return NAN;
-  if (x == y) return op == DFDB_AGG_MIN ? (std::signbit(x) ? x : y) : (std::signbit(x) ? y : x);
-  return op == DFDB_AGG_MIN ? std::min(x, y) : std::max(x, y);
-}
-static uint64_t fold_bits(uint64_t a, uint64_t b, int dt, int op) {
-  if (dt == DFDB_F64) {
-    double x, y; memcpy(&x, &a, 8); memcpy(&y, &b, 8);
-    const double r = fold_f64(x, y, op);
-    uint64_t o; memcpy(&o, &r, 8); return o;
-  }
-  if (dt == DFDB_U64) return op == DFDB_AGG_SUM ? a + b : fold<uint64_t>(a, b, op);
-  return op == DFDB_AGG_SUM ? a + b : (uint64_t)fold<int64_t>((int64_t)a, (int64_t)b, op);
-}
+// (fold_f64 / fold_bits: ooc.cpp — Julia's NaN and signed-zero rules, wrapping Int sums; shared with the block-streamed merges)
 
 // stream-ordered host value -> slot of shard l
 static void put_slot(dfdb_group* g, int l, int slot, int64_t v) {
@@ -1034,11 +1009,6 @@ int32_t dfdb_group_materialize_device(dfdb_gquery* gq, dfdb_outcol* outs, int32_
 // ------------------------------------------------------------------ unique / groupreduce over the shards
 namespace dfdb {
 namespace {
-struct GroupPart {          // one shard's groups, in order of first appearance inside the shard
-  int64_t ng = 0;
-  std::vector<uint8_t> key_data, key_missing, key_bytes;
-  std::vector<int64_t> counts; std::vector<uint64_t> vals;
-};
 void put_i64(std::vector<uint8_t>& b, int64_t v) { const size_t o = b.size(); b.resize(o + 8); memcpy(b.data() + o, &v, 8); }
 void put_vec(std::vector<uint8_t>& b, const void* p, size_t n) { put_i64(b, (int64_t)n); const size_t o = b.size(); b.resize(o + n); if (n) memcpy(b.data() + o, p, n); }
 std::vector<uint8_t> pack_part(const GroupPart& p) {
@@ -1110,25 +1080,6 @@ static std::vector<GroupPart> all_parts(dfdb_group* g, std::vector<GroupPart>& l
   return parts;
 }
 
-// isequal as a byte string: the missing flag, then the value's bytes with every NaN folded onto one (isequal(NaN, -NaN); -0.0 and 0.0 stay apart)
-static std::string merge_key(int32_t kdt, const GroupPart& p, int64_t j, int64_t& byte_off) {
-  const bool miss = !p.key_missing.empty() && p.key_missing[(size_t)j];
-  std::string k(1, miss ? '\1' : '\0');
-  if (dt_base(kdt) == DFDB_STRING) {
-    int32_t sz; memcpy(&sz, p.key_data.data() + (size_t)j * 4, 4);
-    if (sz < 0) { k[0] = '\1'; return k; }
-    k.append((const char*)p.key_bytes.data() + byte_off, (size_t)sz); byte_off += sz;
-    return k;
-  }
-  if (miss) return k;                                    // (the bytes under a missing flag are garbage: quirk Q11)
-  const int w = dt_width(kdt);
-  const uint8_t* v = p.key_data.data() + (size_t)j * w;
-  if (dt_base(kdt) == DFDB_F64) { double d; memcpy(&d, v, 8); if (std::isnan(d)) { k.append("NaN"); return k; } }
-  if (dt_base(kdt) == DFDB_F32) { float f; memcpy(&f, v, 4); if (std::isnan(f)) { k.append("NaN"); return k; } }
-  k.append((const char*)v, (size_t)w);
-  return k;
-}
-
 static void group_reduce_all(dfdb_gquery* gq, int32_t key_p, int32_t val_p, int32_t op, bool with_stats) {
   dfdb_group* g = gq->gt->g;
   fresh(g);
@@ -1143,75 +1094,22 @@ static void group_reduce_all(dfdb_gquery* gq, int32_t key_p, int32_t val_p, int3
     int64_t ng = 0, kb = 0;
     query_groupreduce(q, key_p, val_p, op, &ng, &kb);     // the shard's own device reduction (k_unique.hip / k_dict.hip); the selection is the group's
     kinds[(size_t)l] = q->gr_kind;
-    const int32_t kdt = q->proj[(size_t)key_p].expr->dtype;
-    const bool is_str = dt_base(kdt) == DFDB_STRING;
-    part.ng = ng;
-    part.key_data.resize((size_t)ng * (size_t)(is_str ? 4 : dt_width(kdt)));
-    if (dt_nullable(kdt) && !is_str) part.key_missing.assign((size_t)ng, 0);
-    part.key_bytes.resize((size_t)kb);
-    part.counts.assign((size_t)ng, 0); part.vals.assign((size_t)ng, 0);
-    dfdb_outcol o{}; o.memkind = DFDB_MEM_HOST; o.data = part.key_data.data(); o.bytes = part.key_bytes.data(); o.bytes_cap = kb;
-    o.missing = part.key_missing.empty() ? nullptr : part.key_missing.data();
-    std::vector<int64_t> vi((size_t)ng); std::vector<double> vf((size_t)ng);
-    query_groupreduce_fetch(q, &o, part.counts.data(), vi.data(), vf.data());   // (puts the shard's full selection back)
-    for (int64_t j = 0; j < ng; j++) { if (q->gr_kind == 2) memcpy(&part.vals[(size_t)j], &vf[(size_t)j], 8); else part.vals[(size_t)j] = (uint64_t)vi[(size_t)j]; }
+    fetch_group_part(q, key_p, ng, kb, false, part);      // (puts the shard's full selection back)
   });
   const std::vector<GroupPart> parts = all_parts(g, local);
   const int32_t kdt = gq->shard[0]->proj[(size_t)key_p].expr->dtype;
-  const bool is_str = dt_base(kdt) == DFDB_STRING;
-  const int w = is_str ? 4 : dt_width(kdt);
   const int kind = kinds[0];
   GroupMerged& m = gq->merged;
   m.key_dtype = kdt; m.kind = kind; m.op = op; m.with_stats = with_stats;
-  std::unordered_map<std::string, int64_t> slot;
-  for (const GroupPart& p : parts) {                        // rank order = table order: a key keeps the place of its first appearance
-    int64_t boff = 0;
-    for (int64_t j = 0; j < p.ng; j++) {
-      const int64_t b0 = boff;
-      const std::string k = merge_key(kdt, p, j, boff);
-      auto it = slot.find(k);
-      if (it == slot.end()) {
-        slot.emplace(k, m.ng++);
-        m.key_data.insert(m.key_data.end(), p.key_data.begin() + j * w, p.key_data.begin() + (j + 1) * w);
-        m.key_missing.push_back(k[0] == '\1' ? 1 : 0);
-        if (is_str) m.key_bytes.insert(m.key_bytes.end(), p.key_bytes.begin() + b0, p.key_bytes.begin() + boff);
-        m.counts.push_back(p.counts[(size_t)j]); m.vals.push_back(p.vals[(size_t)j]);
-        continue;
-      }
-      const size_t s = (size_t)it->second;
-      m.counts[s] += p.counts[(size_t)j];
-      const uint64_t a = m.vals[s], b = p.vals[(size_t)j];
-      if (op == DFDB_AGG_COUNT) m.vals[s] = a + b;
-      else m.vals[s] = fold_bits(a, b, kind == 2 ? DFDB_F64 : (kind == 1 ? DFDB_U64 : DFDB_I64), op);   // wrapping Int sums, Float64 sums of the shards' sums, NaN-propagating min / max
-    }
-  }
+  GroupMerger mg;
+  for (const GroupPart& p : parts) mg.add(m, p);           // rank order = table order: a key keeps the place of its first appearance
   m.valid = true;
 }
 
 static void group_reduce_fetch(dfdb_gquery* gq, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f) {
   GroupMerged& m = gq->merged;
   if (!m.valid) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_group_query_unique / _groupreduce has not been called");
-  if (keys) {
-    if (keys->memkind != DFDB_MEM_HOST) fail(DFDB_ERR_ARGUMENT, "the merged keys of a group are written to host buffers");
-    const bool is_str = dt_base(m.key_dtype) == DFDB_STRING;
-    keys->dtype = m.key_dtype; keys->count = m.ng; keys->nbytes = (int64_t)m.key_bytes.size();
-    if (m.ng > 0) {
-      if (!keys->data) fail(DFDB_ERR_ARGUMENT, "the key column has no data buffer");
-      memcpy(keys->data, m.key_data.data(), m.key_data.size());
-      if (keys->missing) memcpy(keys->missing, m.key_missing.data(), (size_t)m.ng);
-      if (is_str && !m.key_bytes.empty()) {
-        if ((int64_t)m.key_bytes.size() > keys->bytes_cap || !keys->bytes) fail(DFDB_ERR_ARGUMENT, "the key column needs %zu string bytes, capacity is %lld", m.key_bytes.size(), (long long)keys->bytes_cap);
-        memcpy(keys->bytes, m.key_bytes.data(), m.key_bytes.size());
-      }
-    }
-  }
-  for (int64_t j = 0; j < m.ng; j++) {
-    if (counts) counts[j] = m.counts[(size_t)j];
-    const uint64_t b = m.vals[(size_t)j];
-    double d; memcpy(&d, &b, 8);
-    if (m.kind == 2) { if (vals_f) vals_f[j] = d; if (vals_i) vals_i[j] = (int64_t)d; }
-    else { if (vals_i) vals_i[j] = (int64_t)b; if (vals_f) vals_f[j] = m.kind == 1 ? (double)b : (double)(int64_t)b; }
-  }
+  merged_fetch(m, keys, counts, vals_i, vals_f);
 }
 }  // namespace dfdb
 

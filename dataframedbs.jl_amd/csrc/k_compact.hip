@@ -403,10 +403,13 @@ template <typename A> __device__ __forceinline__ A red_combine(A a, A b, int op)
   if (op == DFDB_AGG_MIN) return b < a ? b : a;
   return b > a ? b : a;
 }
-__device__ __forceinline__ double red_combine_f(double a, double b, int op) {   // Julia min/max propagate NaN
+__device__ __forceinline__ double red_combine_f(double a, double b, int op) {   // Julia min/max propagate NaN, and -0.0 orders below 0.0 (Base.min / Base.max)
   if (op == DFDB_AGG_SUM) return a + b;
   if (a != a) return a;
   if (b != b) return b;
+  // (a == b: equal values share their bits except the two zeros — OR keeps a sign bit either of them has, AND drops one either lacks.  `b < a ? b : a` kept
+  // whichever zero came first, so minimum() of a column holding 0.0 and -0.0 depended on the grid: found by the block-streamed aggregates, round 6)
+  if (a == b) { const unsigned long long x = __double_as_longlong(a), y = __double_as_longlong(b); return __longlong_as_double(op == DFDB_AGG_MIN ? (x | y) : (x & y)); }
   if (op == DFDB_AGG_MIN) return b < a ? b : a;
   return b > a ? b : a;
 }

@@ -490,7 +490,14 @@ template <typename T, int EXTRA> __device__ __forceinline__ T agg_identity() {
 }
 template <typename T, int EXTRA> __device__ __forceinline__ T agg_combine(T a, T b) {
   if (EXTRA == 2) return a + b;
-  if (std::is_same<T, double>::value) { if (a != a) return a; if (b != b) return b; }
+  if (std::is_same<T, double>::value) {
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a == b) {                       // the two zeros: -0.0 is the minimum, 0.0 the maximum, whichever came first (Base.min / Base.max; k_compact.hip red_combine_f)
+      const unsigned long long x = __double_as_longlong((double)a), y = __double_as_longlong((double)b);
+      return (T)__longlong_as_double(EXTRA == 3 ? (x | y) : (x & y));
+    }
+  }
   if (EXTRA == 3) return b < a ? b : a;
   return b > a ? b : a;
 }

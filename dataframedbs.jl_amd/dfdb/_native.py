@@ -56,7 +56,7 @@ SYMBOLS = [
     "dfdb_query_add_predicate", "dfdb_query_nstages", "dfdb_query_set_projection", "dfdb_query_ncols", "dfdb_query_coltype",
     "dfdb_expr_result_type", "dfdb_query_set_stage_base", "dfdb_query_count_prefix",
     "dfdb_query_execute", "dfdb_query_reset", "dfdb_count", "dfdb_count_to", "dfdb_select_bitmap", "dfdb_select_indices", "dfdb_result_string_bytes",
-    "dfdb_materialize", "dfdb_aggregate",
+    "dfdb_materialize", "dfdb_aggregate", "dfdb_query_prepare", "dfdb_table_unload", "dfdb_query_read_stats",
     # multi-GPU groups (block-range shards + RCCL)
     "dfdb_group_create", "dfdb_group_unique_id", "dfdb_group_create_rank", "dfdb_group_create_rank_callbacks", "dfdb_group_destroy", "dfdb_group_info", "dfdb_group_ctx",
     "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_set_option", "dfdb_group_allreduce_f64",
@@ -116,6 +116,9 @@ def load() -> C.CDLL:
         lib.dfdb_query_unique.argtypes = [C.c_void_p, C.c_int32]
         lib.dfdb_query_groupreduce.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         lib.dfdb_query_groupreduce_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dfdb_query_prepare.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        lib.dfdb_table_unload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.dfdb_query_read_stats.argtypes = [C.c_void_p, C.POINTER(SizeStats)]
         lib.dfdb_stream_open.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         lib.dfdb_stream_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.dfdb_stream_stats.argtypes = [C.c_void_p, C.POINTER(SizeStats)]

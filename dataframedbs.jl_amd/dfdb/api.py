@@ -869,45 +869,25 @@ def stream(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> Stream:
     return Stream(v, chunk_blocks)
 
 
-def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 512) -> int:
-    """nrow(v) without holding the table in HBM: sum of the per-chunk counts (BlockRowsIterator, view.jl:192-206).
-    Like the reference's row counter (blocksiterator.jl:46-66: the selection's columns, or the FIRST projection column when the queue holds no predicate) it
-    never reads a projection-only column: the stream is opened over the same selection with one of those columns as its projection (a count over a
-    three-column table used to read all three files)."""
-    view = v if isinstance(v, DFView) else DFView(v)
-    keep = None
-    for st in view.selection.queue:
-        if isinstance(st, ir.Expr) and st.columns():
-            keep = st.columns()[0]
-            break
-    if keep is None:
-        for e in view.projection.cols.values():
-            if e.columns():
-                keep = e.columns()[0]
-                break
-    if keep is not None:
-        view = DFView(view.table, Projection({view.table.names()[keep]: ir.col(keep)}), view.selection)
-    with Stream(view, chunk_blocks) as s:
-        return sum(part.count() for part in s)
+def _with_chunk_blocks(view: "DFView", chunk_blocks: Optional[int]):
+    if chunk_blocks is not None:
+        view.table.ctx.set_option("ooc_chunk_blocks", int(chunk_blocks))
 
 
-def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: int = 512):
-    """materialize(v) chunk by chunk: per-chunk buffers appended on the host like materialization.jl:33-37."""
-    import pandas as pd
+def nrow_streamed(v: Union[DFView, DFTable], chunk_blocks: Optional[int] = None) -> int:
+    """nrow(v) without holding the table in HBM (BlockRowsIterator, view.jl:192-206): ONE call — dfdb_count notices that the view's columns are not
+    resident and streams the selection's columns (the first projection column when there is no predicate) inside the library (csrc/ooc.cpp)."""
     view = v if isinstance(v, DFView) else DFView(v)
-    names = view.names()
-    lgs = _logicals(view)
-    parts = []
-    with Stream(view, chunk_blocks) as s:
-        for part in s:
-            parts.append([_to_user(c, lgs[i]) for i, c in enumerate(part.materialize())])
-    if not parts:                      # nothing streamed (empty table / exhausted range): typed empty columns of the plain path
-        return pd.DataFrame({n: [] for n in names})
-    cols = {}
-    for i, n in enumerate(names):
-        chunks = [p[i] for p in parts]
-        cols[n] = np.ma.concatenate(chunks) if isinstance(chunks[0], np.ma.MaskedArray) else np.concatenate(chunks)
-    return pd.DataFrame(cols)
+    _with_chunk_blocks(view, chunk_blocks)
+    return nrow(view)
+
+
+def materialize_streamed(v: Union[DFView, DFTable], chunk_blocks: Optional[int] = None):
+    """materialize(v) over a table that is not resident: dfdb_count + dfdb_materialize stream inside the library, every chunk's rows appended to the
+    caller's buffers (materialization.jl:33-37)."""
+    view = v if isinstance(v, DFView) else DFView(v)
+    _with_chunk_blocks(view, chunk_blocks)
+    return materialize(view)
 
 
 def _flat_to_strings(sizes: np.ndarray, data: np.ndarray) -> List[Optional[str]]:
@@ -952,24 +932,12 @@ def nrow(v: Union[DFView, DFTable, "DFColumn"]) -> int:      # view.jl:192-206
         v = v.view
     if len(v.projection) == 0:
         return 0      # isempty(it.streams): nothing to read, zero rows (blocksiterator.jl:101)
-    if _out_of_core(v):
-        return nrow_streamed(v)
-    return v._query().count()
-
-
-def _isequal_image(vals: np.ndarray) -> np.ndarray:
-    """the values as integers that are equal exactly when Julia's isequal says so: integers and Bool as they are, floats by bit pattern (0.0 and -0.0 apart)
-    with every NaN folded onto one"""
-    if vals.dtype.kind != "f":
-        return vals.astype(np.int64) if vals.dtype.kind in "ib" or vals.dtype.itemsize < 8 else vals.view(np.uint64)
-    u = np.ascontiguousarray(vals).view(np.uint32 if vals.dtype.itemsize == 4 else np.uint64).copy()
-    u[np.isnan(vals)] = (0x7fc00000 if vals.dtype.itemsize == 4 else 0x7ff8000000000000)
-    return u
+    return v._query().count()      # (a view over columns that are not resident is block-streamed inside dfdb_count: csrc/ooc.cpp)
 
 
 def _out_of_core(v: DFView) -> bool:
-    """The view touches a column of a file-backed table that is not resident (open_table(path, load=False)): evaluate it
-    block-streamed, the way the reference always does (blocksiterator.jl:98-145), instead of refusing."""
+    """The view touches a column of a file-backed table that is not resident (open_table(path, load=False)): the library evaluates it
+    block-streamed, the way the reference always does (blocksiterator.jl:98-145).  Informational: nothing here routes on it any more."""
     t = v.table
     if not t.path:
         return False
@@ -994,15 +962,11 @@ def size(v, dim: Optional[int] = None):
 def materialize(v: Union[DFView, DFTable, "DFColumn"]):
     """materialize(::DFView) -> pandas.DataFrame (stand-in for DataFrames.DataFrame); materialize(::DFColumn) -> array."""
     if isinstance(v, DFColumn):
-        if _out_of_core(v.view):
-            return materialize_streamed(v.view).iloc[:, 0].to_numpy()
         cols = v.view._query().materialize()
         return _to_user(cols[0], _logicals(v.view)[0])
     if isinstance(v, DFTable):
         v = DFView(v)
     import pandas as pd
-    if len(v.projection) and _out_of_core(v):
-        return materialize_streamed(v)
     cols = v._query().materialize() if len(v.projection) else []
     lg = _logicals(v)
     return pd.DataFrame({k: _to_user(c, lg[i]) for i, (k, c) in enumerate(zip(v.projection.keys(), cols))})
@@ -1083,76 +1047,28 @@ class DFColumn:
 
     def unique(self):
         """unique(col) (docs/src/index.md:171-182): the distinct values in order of first appearance.  On the device the
-        first occurrences are a selection (dfdb_query_unique); over a table that is not resident every chunk is reduced on the
-        device and the (small) per-chunk results are merged in order on the host."""
+        first occurrences are a selection (dfdb_query_unique); over a table that is not resident the same call reduces every chunk on the
+        device and merges the (small) per-chunk results in order inside the library (csrc/ooc.cpp)."""
         def one(q):
             q.hint_materialize(True)
             q.execute()
             N.check(N.load().dfdb_query_unique(q._h, 0))
             return _to_user(q.materialize()[0], _logicals(self.view)[0])
-        if _out_of_core(self.view):
-            seen, out = set(), []
-            keys_seen, parts = None, []          # plain numeric chunks merge as arrays: their isequal images (bit patterns, one NaN) against the sorted images met so far
-            with Stream(self.view) as s:
-                for part in s:
-                    vals = one(part)
-                    if isinstance(vals, np.ndarray) and not isinstance(vals, np.ma.MaskedArray) and vals.dtype.kind in "iufb" and not out:
-                        img = _isequal_image(vals)
-                        new = np.ones(len(vals), bool) if keys_seen is None else ~np.isin(img, keys_seen, assume_unique=True)
-                        parts.append(vals[new])
-                        keys_seen = np.sort(img) if keys_seen is None else np.union1d(keys_seen, img[new])
-                        continue
-                    if parts:                    # (a chunk of another kind after numeric ones cannot happen for one column; kept safe: fold what was merged into the general form)
-                        for v in np.concatenate(parts).tolist():
-                            seen.add(("nan",) if isinstance(v, float) and v != v else v); out.append(v)
-                        parts = []
-                    for v in (vals.tolist() if not isinstance(vals, np.ma.MaskedArray) else [None if m else x for x, m in zip(vals.data.tolist(), np.ma.getmaskarray(vals).tolist())]):
-                        k = ("nan",) if isinstance(v, float) and v != v else v
-                        if k not in seen:
-                            seen.add(k); out.append(v)
-            if parts:
-                return np.concatenate(parts)
-            return np.array(out, dtype=object) if out and isinstance(out[0], (str, type(None))) else np.array(out)
         return one(self.view._query())
 
     def _aggregate(self, op: int, with_count: bool = False):
         """sum / min / max driven by Base.iterate(::DFColumn) in the reference (column.jl:102-126).  Over a table that is not resident
-        every chunk is reduced on the device and the per-chunk results are combined here, block order = the reference's order."""
+        every chunk is reduced on the device and the per-chunk results are combined in block order — inside dfdb_aggregate (csrc/ooc.cpp)."""
         # sum(f.(cols)) of a computed Bool column — `sum(ismissing.(t.col))`, docs/src/index.md:326-328 — is the number of selected rows for
         # which it holds: one more predicate on the selection (routed to the scan kernels like any other) instead of a materialised
         # Bool per row and a reduction over it
         if op == N.AGG_SUM and self.eltype == ir.BOOL and self.expr.op != ir.COL:
             cnt = nrow(DFView(self.view.table, self.view.projection, self.view.selection.add(self.expr)))
             return (cnt, nrow(self.view)) if with_count else cnt
-        if not _out_of_core(self.view):
-            q = self.view._query()
-            q.hint_aggregate(op)                           # before anything executes the selection
-            r = q.aggregate(op)
-            return (r, q.count()) if with_count else r
-        isint = (self.eltype & ir.DTYPE_MASK) not in (ir.F32, ir.F64)
-        acc, total = None, 0
-        with Stream(self.view) as s:
-            for part in s:
-                c = part.count()
-                if c == 0:
-                    continue                              # (min / max of an empty chunk would raise)
-                total += c
-                r = part.aggregate(op)
-                if acc is None:
-                    acc = r
-                elif op == N.AGG_SUM:
-                    acc = acc + r
-                    if isint and (self.eltype & ir.DTYPE_MASK) in (ir.U8, ir.U16, ir.U32, ir.U64):
-                        acc %= 1 << 64                                     # UInt64 sums wrap
-                    elif isint:
-                        acc = (acc + (1 << 63)) % (1 << 64) - (1 << 63)    # Int64 sums wrap, like Julia's
-                else:
-                    acc = min(acc, r) if op == N.AGG_MIN else max(acc, r)
-        if acc is None:
-            if op != N.AGG_SUM:
-                raise ValueError("ArgumentError: reducing over an empty collection is not allowed")
-            acc = 0 if isint else 0.0
-        return (acc, total) if with_count else acc
+        q = self.view._query()
+        q.hint_aggregate(op)                           # before anything executes the selection
+        r = q.aggregate(op)                            # (not resident: per-chunk reductions folded in block order inside the library)
+        return (r, q.count()) if with_count else r
 
     def sum(self): return self._aggregate(N.AGG_SUM)
     def min(self): return self._aggregate(N.AGG_MIN)
@@ -1347,58 +1263,4 @@ def groupreduce(v: Union[DFView, DFTable], by: str, col: Optional[str] = None, s
     appearance (the reference's group_map numbering), with the group's row count and stat(col) — stat in count / sum / min / max / mean.
     Returns a pandas.DataFrame with columns [by, "count", stat]."""
     sub, with_value = _groupreduce_view(v, by, col, stat)
-    if _out_of_core(sub):
-        return _groupreduce_frame(by, stat, *_groupreduce_streamed(sub, with_value, stat))
     return _groupreduce_frame(by, stat, *_groupreduce_raw(_Query(sub), with_value, stat))
-
-
-def _groupreduce_streamed(sub: DFView, with_value: bool, stat: str):
-    """the same over a table that is not resident: every chunk of blocks is reduced on the device, the per-chunk groups (one record per distinct key) are
-    merged here in chunk order — a key keeps the place of its first appearance; counts and sums add (Int64 sums wrap like the device's), minimum / maximum
-    fold with a NaN winning, like Julia's."""
-    order: Dict[Any, int] = {}
-    keys_out: List[Any] = []
-    counts: List[int] = []
-    vis: List[int] = []
-    vfs: List[float] = []
-    vdt, kdt = None, None
-    M64 = (1 << 64) - 1
-    wrap = lambda x: ((int(x) + (1 << 63)) % (1 << 64)) - (1 << 63)
-    with Stream(sub) as s:
-        for part in s:
-            k, c, vi, vf, vdt = _groupreduce_raw(part, with_value, stat)
-            kdt = part.coltype(0)
-            if isinstance(k, np.ma.MaskedArray):
-                klist = [None if m else x for x, m in zip(k.data.tolist(), np.ma.getmaskarray(k).tolist())]
-            else:
-                klist = k.tolist() if isinstance(k, np.ndarray) else list(k)
-            for j, key in enumerate(klist):
-                canon = ("nan",) if isinstance(key, float) and key != key else ((key, bool(np.signbit(key))) if isinstance(key, float) else key)
-                at = order.get(canon)
-                if at is None:
-                    order[canon] = len(keys_out); keys_out.append(key); counts.append(int(c[j])); vis.append(int(vi[j])); vfs.append(float(vf[j]))
-                    continue
-                counts[at] += int(c[j])
-                if stat in ("sum", "mean", "count"):
-                    vis[at] = wrap(vis[at] + int(vi[j])); vfs[at] += float(vf[j])
-                else:
-                    lo = stat in ("min", "minimum")
-                    a, b = vfs[at], float(vf[j])
-                    if a != a or b != b:
-                        vfs[at] = float("nan")
-                    elif a == b:                                        # -0.0 orders below 0.0 (Base.min / Base.max)
-                        vfs[at] = (a if np.signbit(a) else b) if lo else (b if np.signbit(a) else a)
-                    else:
-                        vfs[at] = min(a, b) if lo else max(a, b)
-                    uns = vdt in (ir.U8, ir.U16, ir.U32, ir.U64)        # (UInt64 values travel as Int64 bits)
-                    x, y = (vis[at] & M64, int(vi[j]) & M64) if uns else (vis[at], int(vi[j]))
-                    z = min(x, y) if lo else max(x, y)
-                    vis[at] = wrap(z)
-    n = len(keys_out)
-    if kdt is not None and (kdt & ir.DTYPE_MASK) == ir.STRING:
-        keys = np.array(keys_out, dtype=object)
-    elif kdt is not None and kdt & ir.NULLABLE:
-        keys = np.ma.masked_array(np.array([0 if x is None else x for x in keys_out], ir.numpy_of_dtype(kdt)), mask=[x is None for x in keys_out])
-    else:
-        keys = np.array(keys_out, ir.numpy_of_dtype(kdt)) if kdt is not None else np.zeros(0, np.int64)
-    return keys, np.array(counts, np.int64).reshape(n), np.array(vis, np.int64).reshape(n), np.array(vfs, np.float64).reshape(n), vdt

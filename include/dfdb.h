@@ -398,6 +398,39 @@ int32_t dfdb_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols);
  * (tolerance documented in DESIGN.md), integer results exact */
 int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f);
 
+/* ---- out of core behind the ordinary entry points (round 6) ----
+ * The reference never holds more than one block per column (src/io/blocksiterator.jl:98-121, src/io/BlockStreams.jl:9-15; "memory use is O(block)",
+ * docs/src/index.md:182,192) and opens exactly required_columns(v) (src/tables/view.jl:183-190, blocksiterator.jl:20-33).  A query over a table opened
+ * with dfdb_table_open whose required columns are NOT all resident is answered the same way by the SAME entry points — dfdb_count, dfdb_count_to,
+ * dfdb_select_indices, dfdb_result_string_bytes, dfdb_materialize, dfdb_aggregate, dfdb_query_unique, dfdb_query_groupreduce (+ _fetch): each runs the
+ * block stream below internally, chunk by chunk (ctx option "ooc_chunk_blocks", default 512 blocks per chunk), and merges the chunks' results inside the
+ * library; HBM holds the stream's chunks, never the table.
+ *   dfdb_count            reads the selection's columns only — the FIRST projection column when the queue holds no predicate — like the reference's row
+ *                         counter (BlockRowsIterator, blocksiterator.jl:46-66); with dfdb_query_hint_materialize on it also sizes the projected String
+ *                         columns (for the blocks that kept a row), so count + materialize stay the reference's two passes (materialization.jl:29-37)
+ *   dfdb_materialize      appends every chunk's rows to the caller's buffers (append!(res, bl), materialization.jl:33-37); more rows than dfdb_count
+ *                         counted (the files changed in between) is BoundsError, nothing is written past the count
+ *   dfdb_aggregate        per-chunk reductions folded in chunk order: Int sums wrap, Float64 sums are sums of the chunks' sums (tolerance of DESIGN.md
+ *                         section 5), minimum / maximum with Julia's NaN and signed-zero rules; empty -> ArgumentError for minimum / maximum
+ *   dfdb_query_unique     per-chunk first occurrences merged by key (isequal) in chunk order = order of first appearance in the table; the query is
+ *                         then NARROWED to those rows: dfdb_count = the number of distinct values, dfdb_select_indices = their table rows,
+ *                         dfdb_materialize = the projection at those rows (the key column straight out of the merge), until dfdb_query_reset
+ *   dfdb_query_groupreduce  per-chunk groups merged by key in chunk order; counts and sums add, minimum / maximum fold (as dfdb_group_query_groupreduce)
+ *   dfdb_select_bitmap    DFDB_ERR_UNSUPPORTED (the bitmap exists one chunk at a time: dfdb_stream_next)
+ * dfdb_query_execute is a no-op there (nothing is left in HBM), dfdb_query_reset forgets what the passes learnt.
+ *
+ * dfdb_query_prepare(q, &how): "only the required columns are opened".  Brings the columns the view needs — and no others — into HBM when they fit
+ * ctx option "hbm_budget_mb" (0 = default: 80 % of the HBM that is free at the call; an explicit budget bounds what the TABLE holds): *how = 0 they were
+ * resident already, 1 loaded decoded (dfdb_table_load of exactly those ordinals), 2 loaded COMPRESSED-ONLY (as ctx option "keep_compressed" = 2: every
+ * missing column is a plain fixed-width one and the LZ4 blocks fit where the decoded arrays do not), 3 left on disk: the entry points above stream.
+ * DFDB_ERR_NOMEM inside a load falls through to the next form instead of failing.  A binding calls it once per view before it asks for results
+ * (julia/DataFrameDBsAMD.jl: device_query).  dfdb_table_unload releases resident columns of a file-backed table again (NULL = all). */
+int32_t dfdb_query_prepare(dfdb_query* q, int32_t* how);
+int32_t dfdb_table_unload(dfdb_table* t, const int32_t* ordinals, int32_t ncols);
+/* what the internal streams of this query have read so far: rows of the blocks read, their compressed bytes (+ 24 per block, quirk Q10), their decoded
+ * bytes — summed over the passes (a count reads one column; a materialize after it reads the projection's blocks that kept a row) */
+int32_t dfdb_query_read_stats(dfdb_query* q, dfdb_sizestats* stats);
+
 /* ---- block-streamed execution: Base.iterate(::BlocksIterator) (src/io/blocksiterator.jl:98-145) in chunks of blocks ----
  * For a query over a table opened with dfdb_table_open but NOT loaded (tables larger than HBM, one-off scans).  Each
  * dfdb_stream_next yields a query over the next chunk of `chunk_blocks` blocks of every required column, decoded in HBM:
