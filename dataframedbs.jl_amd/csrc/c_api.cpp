@@ -440,7 +440,7 @@ int32_t dfdb_query_set_stage_base(dfdb_query* q, int32_t stage, int64_t survivor
   return guard([&] {
     NEEDQ(q);
     if (stage < 0 || (size_t)stage >= q->stages.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: stage %d", stage);
-    q->stages[(size_t)stage].stage_base = survivors_before; q->executed_stages = -1; q->count = -1;
+    q->stages[(size_t)stage].stage_base = survivors_before; q->executed_stages = -1; q->count = -1; ooc_reset(q);
   });
 }
 int32_t dfdb_query_count_prefix(dfdb_query* q, int32_t nstages, int64_t* n) { return guard([&] { NEEDQT(q); NEED(n); *n = query_count(q, nstages); q->executed_stages = -1; }); }

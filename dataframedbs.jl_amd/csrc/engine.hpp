@@ -92,6 +92,9 @@ struct dfdb_table {
   int64_t nrows = -1;          // rows resident (all resident columns agree); -1 = nothing resident yet
   int64_t row_base = 0;        // global 0-based row of local row 0 (block-range shard)
   int64_t block_first = 0;     // first resident block
+  // block window of the table's out-of-core streams: a shard of a multi-GPU group that is NOT resident streams only ITS block range [win_first, win_last)
+  // of the column files (win_last < 0: to the end of the file); rows keep their table numbers (row_base of a chunk = its first block * block_size)
+  int64_t win_first = 0, win_last = -1;
   std::vector<dfdb_query*> queries;   // live queries over this table (orphaned, not dangling, when the table closes)
   // block-loading scratch (compressed bytes staged in HBM, packed bodies, block descriptors).  Freed after a load unless
   // the table is a stream slot that reloads a new block range every few milliseconds (hipMalloc/hipFree would dominate).

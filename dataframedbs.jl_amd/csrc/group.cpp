@@ -277,6 +277,14 @@ static void put_slot(dfdb_group* g, int l, int slot, int64_t v) {
   g->xpin[(size_t)l][slot] = v;
   HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + slot, g->xpin[(size_t)l] + slot, 8, hipMemcpyHostToDevice, g->ctx[(size_t)l]->stream));
 }
+// A shard whose required columns are NOT resident (dfdb_group_query_prepare left them on disk: they do not fit) answers by streaming ITS block window of the
+// column files (ooc.cpp; dfdb_table::win_first / win_last): the same per-shard values, taken from the stream instead of from HBM.
+static int64_t shard_count(dfdb_query* q) { return query_out_of_core(q) ? ooc_count(q) : query_count(q, -1); }
+static int64_t shard_string_bytes(dfdb_query* q, int32_t i) { return query_out_of_core(q) ? ooc_string_bytes(q, i) : query_string_bytes(q, i); }
+static void shard_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) { if (query_out_of_core(q)) ooc_materialize(q, outs, ncols); else query_materialize(q, outs, ncols); }
+static void shard_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memkind, int64_t* n) {
+  if (query_out_of_core(q)) ooc_select_indices(q, out, cap, memkind, n); else query_select_indices(q, out, cap, memkind, n);
+}
 // every local shard's fault slot := the local fault key (what this process knows so far)
 static void post_fault(dfdb_group* g) {
   for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); put_slot(g, l, kFaultSlot, (int64_t)g->fault_key); }
@@ -428,6 +436,7 @@ static void plan_stage_bases(dfdb_gquery* gq) {
       if (gq->shard[0]->stages[k].kind == ST_PRED) continue;
       for_shards_deferred(g, [&](int l) {
         dfdb_query* q = gq->shard[(size_t)l];
+        if (query_out_of_core(q)) { put_slot(g, l, 1, ooc_count_prefix(q, (int)k)); return; }
         // planning raises nothing: whether a DivideError / InexactError of a predicate is reached is decided by the full execution, once every
         // stage knows the survivors on the lower ranks (query.cpp: error_is_reached); the erroring rows count as not selected meanwhile
         q->err_checking = true;
@@ -442,7 +451,7 @@ static void plan_stage_bases(dfdb_gquery* gq) {
       for (int r = 0; r < g->first_rank; r++) base += counts[(size_t)r];
       for (int l = 0; l < g->nlocal(); l++) {
         dfdb_query* q = gq->shard[(size_t)l];
-        q->stages[k].stage_base = base; q->executed_stages = -1; q->count = -1;
+        q->stages[k].stage_base = base; q->executed_stages = -1; q->count = -1; ooc_reset(q);
         base += counts[(size_t)(g->first_rank + l)];
       }
     }
@@ -459,6 +468,7 @@ static void group_count_enqueue(dfdb_gquery* gq, bool wait) {
   plan_stage_bases(gq);
   for_shards_deferred(g, [&](int l) {
     dfdb_query* q = gq->shard[(size_t)l];
+    if (query_out_of_core(q)) { put_slot(g, l, 0, ooc_count(q)); return; }
     if (shard_needs_exec(q)) query_execute(q, -1);
     const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
     HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>(), q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
@@ -678,6 +688,19 @@ int32_t dfdb_group_table_open(dfdb_group* g, const char* path, dfdb_gtable** out
     GNEED(g); GNEED(path); GNEED(out);
     std::unique_ptr<dfdb_gtable, void (*)(dfdb_gtable*)> gt(new_gtable(g), gtable_free);
     for (int l = 0; l < g->nlocal(); l++) { HIP_CHECK(hipSetDevice(g->ctx[(size_t)l]->device)); table_open(g->ctx[(size_t)l], path, &gt->shard[(size_t)l]); }
+    // every shard's block window, from the headers of the first column (20 bytes per block: skip_block, BlockStreams.jl:74-78): a shard whose columns are never
+    // loaded streams ITS range of the files, not the table (ooc.cpp)
+    dfdb_table* t0 = gt->shard[0];
+    if (!t0->cols.empty()) {
+      dfdb_sizestats hs{0, 0, 0};
+      table_column_stats(t0, 0, &hs);
+      const int64_t nblocks = ceil_div(hs.rows, t0->block_size);
+      for (int l = 0; l < g->nlocal(); l++) {
+        int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+        gt->shard[(size_t)l]->win_first = b0; gt->shard[(size_t)l]->win_last = b1;
+      }
+      gt->total_rows = hs.rows;
+    }
     *out = gt.release();
   });
 }
@@ -800,6 +823,49 @@ int32_t dfdb_group_query_new(dfdb_gtable* gt, dfdb_gquery** out) {
   });
 }
 int32_t dfdb_group_query_free(dfdb_gquery* gq) { return gguard([&] { gquery_free(gq); }); }
+/* dfdb_query_prepare for a sharded table: only the columns the view needs are opened (view.jl:183-190, blocksiterator.jl:20-33).  Every shard loads ITS block
+ * range of exactly those columns when its share fits (*how = 1; 0: they were resident already); otherwise the shards keep nothing and every group entry point
+ * streams each shard's block range from the files (*how = 3; per-rank values meet in the same exchanges).  The decision is made ALIKE on every rank — from the
+ * files' headers, group option "hbm_budget_mb" (0: 80 % of the device's HBM) and what the shards hold —, never from a rank's momentary free memory. */
+int32_t dfdb_group_query_prepare(dfdb_gquery* gq, int32_t* how) {
+  return gguard([&] {
+    GNEEDQ(gq);
+    dfdb_gtable* gt = gq->gt; dfdb_group* g = gt->g;
+    dfdb_table* t0 = gt->shard[0];
+    if (how) *how = 0;
+    if (t0->path.empty() || t0->cols.empty()) return;
+    dfdb_query* q0 = gq->shard[0];
+    std::vector<int> req;
+    for (const Stage& st : q0->stages) if (st.kind == ST_PRED) required_columns(*st.pred, req);
+    for (const ProjCol& pc : q0->proj) required_columns(*pc.expr, req);
+    if (req.empty()) req.push_back(0);
+    std::vector<int32_t> need;
+    for (int o : req) if (!t0->cols[(size_t)o].resident) need.push_back(o);
+    if (need.empty()) return;
+    int64_t dec = 0, comp_max = 0; dfdb_sizestats hs{0, 0, 0};
+    for (int32_t o : need) { dfdb_sizestats st{0, 0, 0}; table_column_stats(t0, o, &st); dec += st.uncompressed; comp_max = std::max(comp_max, st.compressed); hs = st; }
+    const int64_t nblocks = ceil_div(hs.rows, t0->block_size);
+    int64_t budget = ctx_option(g->ctx[0], "hbm_budget_mb", 0) << 20;
+    int64_t held = 0;
+    { int64_t d = 0, k = 0; table_resident_bytes(t0, -1, &d, &k); held = d + k; }
+    if (budget <= 0) budget = (int64_t)((double)g->ctx[0]->prop.totalGlobalMem * 0.8);
+    const int64_t share = ceil_div(dec + comp_max, (int64_t)g->world) + (64 << 20);
+    if (share <= budget - held) {
+      std::vector<dfdb_sizestats> st((size_t)g->nlocal(), dfdb_sizestats{0, 0, 0});
+      for_shards(g, [&](int l) {
+        int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+        dfdb_table* t = gt->shard[(size_t)l];
+        table_load(t, need.data(), (int32_t)need.size(), b0, b1, &st[(size_t)l]);
+        t->row_base = b0 * t0->block_size;
+      });
+      gt->total_rows = hs.rows;
+      gtable_changed(gt);
+      if (how) *how = 1;
+      return;
+    }
+    if (how) *how = 3;                                     // (the shards' block windows were set when the table was opened)
+  });
+}
 int32_t dfdb_group_query_shard(dfdb_gquery* gq, int32_t local, dfdb_query** q) {
   return gguard([&] { GNEEDQ(gq); GNEED(q); if (local < 0 || (size_t)local >= gq->shard.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: local shard %d", local); *q = gq->shard[(size_t)local]; });
 }
@@ -844,6 +910,7 @@ int32_t dfdb_group_shard_counts(dfdb_gquery* gq, int64_t* counts) {
     group_count(gq);
     for_shards_deferred(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
+      if (query_out_of_core(q)) { put_slot(g, l, 1, ooc_count(q)); return; }
       const int64_t ntiles = ceil_div(q->t->nrows, kTileRows);
       HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 1, q->prefix.as<uint64_t>() + ntiles, 8, hipMemcpyDeviceToDevice, q->t->ctx->stream));
     });
@@ -865,6 +932,7 @@ int32_t dfdb_group_aggregate(dfdb_gquery* gq, int32_t op, int32_t i, int64_t* ou
     std::vector<int> dts((size_t)g->nlocal(), DFDB_I64);
     for_shards_deferred(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
+      if (query_out_of_core(q)) { uint64_t vb[2]; dts[(size_t)l] = ooc_aggregate_bits(q, op, i, vb); put_slot(g, l, 8, (int64_t)vb[0]); put_slot(g, l, 9, (int64_t)vb[1]); return; }
       dts[(size_t)l] = query_aggregate_device(q, op, i);          // {value, count} in q->red_result, identity when the shard selects nothing
       HIP_CHECK(hipMemcpyAsync(g->xbuf[(size_t)l].as<uint64_t>() + 8, q->red_result.p, 16, hipMemcpyDeviceToDevice, q->t->ctx->stream));
     });
@@ -901,7 +969,7 @@ int32_t dfdb_group_select_indices_device(dfdb_gquery* gq, int64_t* const* outs, 
   return gguard([&] {
     GNEEDQ(gq); GNEED(outs); GNEED(caps);
     plan_stage_bases(gq);
-    for_shards(gq->gt->g, [&](int l) { query_select_indices(gq->shard[(size_t)l], outs[l], caps[l], DFDB_MEM_DEVICE, nullptr); });
+    for_shards(gq->gt->g, [&](int l) { shard_select_indices(gq->shard[(size_t)l], outs[l], caps[l], DFDB_MEM_DEVICE, nullptr); });
   });
 }
 /* the same into ONE host buffer: the local shards' row numbers concatenated in rank order (= table order).  *n = rows written
@@ -912,12 +980,12 @@ int32_t dfdb_group_select_indices(dfdb_gquery* gq, int64_t* out, int64_t cap, in
     dfdb_group* g = gq->gt->g;
     plan_stage_bases(gq);
     std::vector<int64_t> cnt((size_t)g->nlocal(), 0), base((size_t)g->nlocal() + 1, 0);
-    for_shards(g, [&](int l) { cnt[(size_t)l] = query_count(gq->shard[(size_t)l], -1); });
+    for_shards(g, [&](int l) { cnt[(size_t)l] = shard_count(gq->shard[(size_t)l]); });
     for (int l = 0; l < g->nlocal(); l++) base[(size_t)l + 1] = base[(size_t)l] + cnt[(size_t)l];
     if (n) *n = base[(size_t)g->nlocal()];
     for_shards(g, [&](int l) {
       const int64_t room = std::max<int64_t>(0, std::min(cnt[(size_t)l], cap - base[(size_t)l]));
-      if (room > 0) query_select_indices(gq->shard[(size_t)l], out + base[(size_t)l], room, DFDB_MEM_HOST, nullptr);
+      if (room > 0) shard_select_indices(gq->shard[(size_t)l], out + base[(size_t)l], room, DFDB_MEM_HOST, nullptr);
     });
   });
 }
@@ -929,7 +997,7 @@ int32_t dfdb_group_result_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbyt
     dfdb_group* g = gq->gt->g;
     plan_stage_bases(gq);
     std::vector<int64_t> nb((size_t)g->nlocal(), 0);
-    for_shards(g, [&](int l) { nb[(size_t)l] = query_string_bytes(gq->shard[(size_t)l], i); });
+    for_shards(g, [&](int l) { nb[(size_t)l] = shard_string_bytes(gq->shard[(size_t)l], i); });
     *nbytes = 0; for (int64_t b : nb) *nbytes += b;
   });
 }
@@ -948,8 +1016,8 @@ int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols
     for_shards(g, [&](int l) {
       dfdb_query* q = gq->shard[(size_t)l];
       if (ncols != (int32_t)q->proj.size()) fail(DFDB_ERR_ARGUMENT, "ArgumentError: view has %zu columns, %d outputs given", q->proj.size(), ncols);
-      cnt[(size_t)l] = query_count(q, -1);
-      for (int32_t p = 0; p < ncols; p++) if (dt_base(q->proj[(size_t)p].expr->dtype) == DFDB_STRING) sb[(size_t)l][(size_t)p] = query_string_bytes(q, p);
+      cnt[(size_t)l] = shard_count(q);
+      for (int32_t p = 0; p < ncols; p++) if (dt_base(q->proj[(size_t)p].expr->dtype) == DFDB_STRING) sb[(size_t)l][(size_t)p] = shard_string_bytes(q, p);
     });
     for (int l = 0; l < nl; l++) base[(size_t)l + 1] = base[(size_t)l] + cnt[(size_t)l];
     std::vector<std::vector<int64_t>> boff((size_t)nl + 1, std::vector<int64_t>((size_t)ncols, 0));
@@ -969,7 +1037,7 @@ int32_t dfdb_group_materialize(dfdb_gquery* gq, dfdb_outcol* outs, int32_t ncols
         if (o.missing) o.missing += base[(size_t)l];
         so[(size_t)l][(size_t)p] = o;
       }
-      query_materialize(q, so[(size_t)l].data(), ncols);
+      shard_materialize(q, so[(size_t)l].data(), ncols);
     });
     for (int32_t p = 0; p < ncols; p++) {
       outs[p].dtype = so[0][(size_t)p].dtype; outs[p].count = base[(size_t)nl]; outs[p].nbytes = boff[(size_t)nl][(size_t)p];
@@ -985,7 +1053,7 @@ int32_t dfdb_group_shard_string_bytes(dfdb_gquery* gq, int32_t i, int64_t* nbyte
     GNEEDQ(gq); GNEED(nbytes);
     dfdb_group* g = gq->gt->g;
     plan_stage_bases(gq);
-    for_shards(g, [&](int l) { nbytes[l] = query_string_bytes(gq->shard[(size_t)l], i); });
+    for_shards(g, [&](int l) { nbytes[l] = shard_string_bytes(gq->shard[(size_t)l], i); });
   });
 }
 
@@ -1000,7 +1068,7 @@ int32_t dfdb_group_materialize_device(dfdb_gquery* gq, dfdb_outcol* outs, int32_
       for (int32_t p = 0; p < ncols; p++)
         if (outs[(size_t)l * ncols + p].memkind != DFDB_MEM_DEVICE) fail(DFDB_ERR_ARGUMENT, "dfdb_group_materialize_device writes device buffers (dfdb_group_materialize for host buffers)");
     plan_stage_bases(gq);
-    for_shards(g, [&](int l) { query_materialize(gq->shard[(size_t)l], outs + (size_t)l * ncols, ncols); });
+    for_shards(g, [&](int l) { shard_materialize(gq->shard[(size_t)l], outs + (size_t)l * ncols, ncols); });
   });
 }
 
@@ -1091,6 +1159,7 @@ static void group_reduce_all(dfdb_gquery* gq, int32_t key_p, int32_t val_p, int3
   for_shards_deferred(g, [&](int l) {
     dfdb_query* q = gq->shard[(size_t)l];
     GroupPart& part = local[(size_t)l];
+    if (query_out_of_core(q)) { kinds[(size_t)l] = ooc_group_part(q, key_p, val_p, op, part); return; }   // (its chunks merged in chunk order: one part)
     int64_t ng = 0, kb = 0;
     query_groupreduce(q, key_p, val_p, op, &ng, &kb);     // the shard's own device reduction (k_unique.hip / k_dict.hip); the selection is the group's
     kinds[(size_t)l] = q->gr_kind;

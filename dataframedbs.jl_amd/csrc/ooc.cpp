@@ -150,11 +150,12 @@ void ooc_reset(dfdb_query* q) { if (q->ooc) { const dfdb_sizestats keep = q->ooc
 // the caller's view re-stated with another projection (and, for a narrowed query, another selection): what a pass streams
 struct TempQuery {
   dfdb_query q;
-  TempQuery(const dfdb_query* src, bool with_stages) {
+  TempQuery(const dfdb_query* src, bool with_stages, int nstages = -1) {
     q.t = src->t;
     if (with_stages)
       for (const Stage& st : src->stages) {
-        Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx;
+        if (nstages >= 0 && (int)q.stages.size() >= nstages) break;
+        Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx; c.stage_base = st.stage_base;
         if (st.pred) c.pred = st.pred->clone();
         q.stages.push_back(std::move(c));
       }
@@ -449,6 +450,55 @@ void ooc_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, in
   if (!o.gr_pending || !o.merged.valid) fail(DFDB_ERR_ARGUMENT, "ArgumentError: dfdb_query_groupreduce has not been called (or the query was executed, reset or changed since)");
   merged_fetch(o.merged, keys, counts, vals_i, vals_f);
   o.merged = GroupMerged{}; o.gr_pending = false; o.merged_col = -1;
+}
+
+// ------------------------------------------------------------------ what a multi-GPU group asks of a shard that is not resident (group.cpp)
+// survivors of stages [0, nstages) over the shard's block window: the operand of the all-gather between a predicate stage and a range stage after it
+int64_t ooc_count_prefix(dfdb_query* q, int nstages) {
+  const dfdb_table* t = q->t;
+  TempQuery tq(q, true, nstages);
+  std::vector<int> sel, all;
+  view_columns(&tq.q, sel, all);
+  if (!sel.empty()) tq.project_column(t, sel[0]);
+  else { std::vector<int> s2, a2; view_columns(q, s2, a2); if (!a2.empty()) tq.project_column(t, a2[0]); }
+  int64_t total = 0;
+  StreamPass pass(q, &tq.q);
+  while (dfdb_query* c = pass.next()) total += query_count(c, -1);
+  return total;
+}
+// {value bits, selected rows} of sum / min / max over projection column i, the identity of `op` when nothing is selected (what query_aggregate_device
+// leaves in red_result); returns the accumulator dtype
+int ooc_aggregate_bits(dfdb_query* q, int32_t op, int32_t i, uint64_t out[2]) {
+  if (i < 0 || (size_t)i >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", i);
+  const Node& e = *q->proj[(size_t)i].expr;
+  if (!dt_isnum(e.dtype) || dt_nullable(e.dtype)) fail(DFDB_ERR_UNSUPPORTED, "aggregate over %s is not supported", dt_name(e.dtype).c_str());
+  const int b = dt_base(e.dtype);
+  const int adt = dt_isfloat(b) ? DFDB_F64 : (b == DFDB_U64 ? DFDB_U64 : DFDB_I64);
+  const int64_t n = ooc_count(q);
+  if (n == 0) {
+    uint64_t id = 0;
+    if (op == DFDB_AGG_MIN) { if (adt == DFDB_F64) { const double d = INFINITY; memcpy(&id, &d, 8); } else id = adt == DFDB_U64 ? ~0ull : (uint64_t)INT64_MAX; }
+    if (op == DFDB_AGG_MAX) { if (adt == DFDB_F64) { const double d = -INFINITY; memcpy(&id, &d, 8); } else id = adt == DFDB_U64 ? 0ull : (uint64_t)INT64_MIN; }
+    out[0] = id; out[1] = 0;
+    return adt;
+  }
+  int64_t vi = 0; double vf = 0;
+  ooc_aggregate(q, op, i, &vi, &vf);
+  if (adt == DFDB_F64) memcpy(&out[0], &vf, 8); else out[0] = (uint64_t)vi;
+  out[1] = (uint64_t)n;
+  return adt;
+}
+// the shard's groups as ONE part (its chunks merged in chunk order), for the merge across the ranks
+int ooc_group_part(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, GroupPart& part) {
+  stream_groupreduce(q, key_p, val_p, op, false);
+  OocState& o = state(q);
+  GroupMerged& m = o.merged;
+  part.ng = m.ng; part.key_data = std::move(m.key_data); part.key_bytes = std::move(m.key_bytes); part.counts = std::move(m.counts); part.vals = std::move(m.vals);
+  const int32_t kdt = m.key_dtype;
+  if (dt_nullable(kdt) && dt_base(kdt) != DFDB_STRING) part.key_missing = std::move(m.key_missing);
+  const int kind = m.kind;
+  o.merged = GroupMerged{}; o.merged_col = -1;
+  return kind;
 }
 
 // ------------------------------------------------------------------ dfdb_query_prepare

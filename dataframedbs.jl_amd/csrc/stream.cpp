@@ -110,6 +110,7 @@ struct dfdb_stream {
   struct ColSrc { std::string name, file; size_t data_off; };
   std::vector<ColSrc> colsrc;      // per required column
   int64_t chunk_blocks = 0, nblocks = 0, next_block = 0, chunks_issued = 0;
+  int64_t win_first = 0, win_last = -1;   // the table's block window (a group shard streams its own block range)
   std::vector<int> required;       // table ordinals the query touches
   std::vector<std::shared_ptr<dfdb::BlockIndex>> index;   // per required column: walked lazily, a chunk ahead of the loaders (shared with the table's column)
   int64_t checked_blocks = 0;      // blocks whose row counts have been checked across the columns
@@ -442,15 +443,17 @@ bool prefetch(dfdb_stream* s, Slot* sl) {
     const bool empty = (st.kind == ST_RANGE && st.n == 0) || (st.kind != ST_RANGE && st.idx.empty());
     if (empty) return false;
     const int64_t first_block = (st.first() - 1) / B;
-    if (first_block > s->next_block) s->next_block = (first_block / s->chunk_blocks) * s->chunk_blocks;   // keep chunk boundaries fixed
+    if (first_block > s->next_block) s->next_block = std::max(s->win_first, (first_block / s->chunk_blocks) * s->chunk_blocks);   // keep chunk boundaries fixed
     if (st.last() <= s->next_block * B) return false;                                  // is_finished (:192-196)
   }
+  if (s->win_last >= 0 && s->next_block >= s->win_last) return false;                  // the end of the table's block window
   // the headers of the next chunk (and, after a skip, of everything before it: skip_block), walked now; the loaders get their own copy of the slice
   // the first chunks of a scan with large chunks are shorter (a quarter, then half of chunk_blocks): the caller gets its first rows after a quarter of the
   // read + copy + decode latency of a full chunk, and the loaders start out staggered instead of in step
   int64_t want = s->chunk_blocks;
   if (s->chunk_blocks >= 256 && s->chunks_issued < 2) want = s->chunk_blocks >> (2 - s->chunks_issued);
   s->chunks_issued++;
+  if (s->win_last >= 0) want = std::min(want, s->win_last - s->next_block);
   const int64_t known = walk_index(s, s->next_block + want);
   if (s->next_block >= known) return false;
   sl->b0 = s->next_block; sl->b1 = std::min(known, s->next_block + want);
@@ -480,6 +483,7 @@ static void stream_destroy(dfdb_stream* s);
 static void stream_rearm(dfdb_stream* s) {
   s->stages.clear(); s->colsrc.clear(); s->required.clear(); s->index.clear(); s->base.clear();
   s->chunk_blocks = s->nblocks = s->next_block = s->chunks_issued = 0; s->cur = -1; s->done = false;
+  s->win_first = 0; s->win_last = -1;
   s->compressed = s->uncompressed = s->rows = 0;
   s->sel_col.clear(); s->read_stats.clear(); s->kprefix = 0; s->index_complete = false; s->checked_blocks = 0;
   s->requests.clear();
@@ -505,9 +509,11 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
   dfdb_table* t = q->t;
   s->block_size = t->block_size; s->path = t->path;
   for (const Stage& st : q->stages) {
-    Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx;   // (predicates live in the slots' queries)
+    Stage c; c.kind = st.kind; c.start = st.start; c.step = st.step; c.stop = st.stop; c.n = st.n; c.idx = st.idx; c.stage_base = st.stage_base;   // (predicates live in the slots' queries)
     s->stages.push_back(std::move(c));
   }
+  s->win_first = std::max<int64_t>(0, t->win_first); s->win_last = t->win_last;
+  s->next_block = s->win_first;
   // one block is decoded by one wave in ~5-8 ms (K7 is serial inside a block) and the chip holds ~5000 waves, so a chunk
   // should hold several hundred blocks: 512 blocks = 0.25 GB of Int64 per slot, four slots
   s->chunk_blocks = chunk_blocks > 0 ? chunk_blocks : 512;
@@ -538,7 +544,9 @@ static void stream_open_impl(dfdb_query* q, int64_t chunk_blocks, dfdb_stream* s
     s->colsrc.push_back(dfdb_stream::ColSrc{c.name, c.file, c.data_off});
   }
   s->nblocks = 0; s->index_complete = false; s->checked_blocks = 0;
+  // (a stage's base starts at the survivors on the LOWER RANKS of a group — dfdb_query_set_stage_base, group.cpp plan_stage_bases — and grows by every chunk's)
   s->base.assign(q->stages.size(), 0);
+  for (size_t k = 0; k < q->stages.size(); k++) s->base[k] = q->stages[k].stage_base;
   set_io_threads(ctx_option(t->ctx, "io_threads", 8));
   s->max_readers = (int)std::min<int64_t>(dfdb_stream::kLoaders, std::max<int64_t>(1, ctx_option(t->ctx, "stream_readers", 3)));
   s->readers = 0; s->waiting_readers.clear();
@@ -690,7 +698,9 @@ void stream_stats(dfdb_stream* s, dfdb_sizestats* st) {
   if (s->rows == 0 && s->compressed == 0) {
     for (size_t k = 0; k < s->index.size(); k++) {
       std::lock_guard<std::mutex> lk(s->index[k]->mu);
-      for (const BlockLoc& b : s->index[k]->v) { s->compressed += b.compressed + 24; s->uncompressed += b.origin; if (k == 0) s->rows += b.rows; }
+      const std::vector<BlockLoc>& v = s->index[k]->v;
+      const int64_t b1 = s->win_last >= 0 ? std::min<int64_t>(s->win_last, (int64_t)v.size()) : (int64_t)v.size();
+      for (int64_t bi = s->win_first; bi < b1; bi++) { const BlockLoc& b = v[(size_t)bi]; s->compressed += b.compressed + 24; s->uncompressed += b.origin; if (k == 0) s->rows += b.rows; }
     }
   }
   st->rows = s->rows; st->compressed = s->compressed; st->uncompressed = s->uncompressed;

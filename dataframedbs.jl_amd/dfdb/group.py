@@ -269,6 +269,13 @@ class GroupQuery:
 
     def reset(self): N.check(N.load().dfdb_group_query_reset(self._h))
 
+    def prepare(self) -> int:
+        """dfdb_group_query_prepare: every shard loads its block range of exactly the columns this view needs if that fits (1; 0 = resident already), else the
+        shards stay on disk and every call streams (3)"""
+        how = C.c_int32(-1)
+        N.check(N.load().dfdb_group_query_prepare(self._h, C.byref(how)))
+        return how.value
+
     def count(self) -> int:
         n = C.c_int64()
         N.check(N.load().dfdb_group_count(self._h, C.byref(n)))

@@ -167,6 +167,10 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     compare pass), which meets every row anyway, reports a string that is missing and everything runs again; 2 = behave as if one had been: a test knob),
  *                     "unique_test_collide" = N: groupreduce by a String key
  *                     behaves as if the first N salts had produced a hash collision — test knobs, the results never depend on them
+ *   "ooc_chunk_blocks"  blocks per chunk of the streams the query entry points run internally over columns that are not resident (default 512; see "out of core
+ *                     behind the ordinary entry points" below)
+ *   "hbm_budget_mb"   what dfdb_query_prepare / dfdb_group_query_prepare let a TABLE hold in HBM (per shard for a group), in MB; 0 (default) = no bound of its own —
+ *                     80 % of the HBM that is free at the call (a group: of the device's HBM) decides alone
  *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
  *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
  *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one
@@ -420,7 +424,7 @@ int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, dou
  * dfdb_query_execute is a no-op there (nothing is left in HBM), dfdb_query_reset forgets what the passes learnt.
  *
  * dfdb_query_prepare(q, &how): "only the required columns are opened".  Brings the columns the view needs — and no others — into HBM when they fit
- * ctx option "hbm_budget_mb" (0 = default: 80 % of the HBM that is free at the call; an explicit budget bounds what the TABLE holds): *how = 0 they were
+ * ctx option "hbm_budget_mb" (an explicit budget bounds what the TABLE holds; in any case at most 80 % of the HBM that is free at the call): *how = 0 they were
  * resident already, 1 loaded decoded (dfdb_table_load of exactly those ordinals), 2 loaded COMPRESSED-ONLY (as ctx option "keep_compressed" = 2: every
  * missing column is a plain fixed-width one and the LZ4 blocks fit where the decoded arrays do not), 3 left on disk: the entry points above stream.
  * DFDB_ERR_NOMEM inside a load falls through to the next form instead of failing.  A binding calls it once per view before it asks for results
@@ -517,6 +521,12 @@ int32_t dfdb_group_table_shard(dfdb_gtable* gt, int32_t local, dfdb_table** t); 
 
 int32_t dfdb_group_query_new(dfdb_gtable* gt, dfdb_gquery** out);                        /* DFView(table): view.jl:50 */
 int32_t dfdb_group_query_free(dfdb_gquery* gq);
+/* dfdb_query_prepare for a sharded table: every shard loads ITS block range of exactly the columns the view needs when its share fits (*how = 1; 0: they
+ * were resident already) — group option "hbm_budget_mb", 0 = 80 % of the device's HBM; decided alike on every rank from the files' headers, never from a
+ * rank's momentary free memory.  Otherwise (*how = 3) the shards keep nothing: every dfdb_group_* entry point then has each shard STREAM its block range of
+ * the column files (the block windows are laid out by dfdb_group_table_open) and the per-rank values meet in the same exchanges as resident shards' do.
+ * A sharded table that was opened and never loaded or prepared behaves like *how = 3. */
+int32_t dfdb_group_query_prepare(dfdb_gquery* gq, int32_t* how);
 int32_t dfdb_group_query_add_range(dfdb_gquery* gq, int64_t start, int64_t step, int64_t stop);   /* as dfdb_query_add_*, on every shard */
 int32_t dfdb_group_query_add_indices(dfdb_gquery* gq, const int64_t* idx, int64_t n);
 int32_t dfdb_group_query_add_integer(dfdb_gquery* gq, int64_t i);

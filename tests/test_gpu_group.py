@@ -592,3 +592,56 @@ def test_bench_exchange_lib_over_two_ranks(ctx):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and "libdfdb_hip's group" in r["config"]["sharding"]
     assert abs(r["config"]["global_selected"] / 2e7 - 0.1) < 0.002                       # both shards' survivors, reduced by the library
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_group_streams_its_block_ranges_when_the_shards_are_not_resident(oracle, dfdb_mod, ctx, tmp_path, world):
+    """Round 6: a sharded table whose columns do not fit (dfdb_group_query_prepare -> 3) — or that was simply never loaded — is answered by every shard
+    STREAMING its own block range of the column files (csrc/ooc.cpp behind group.cpp): count, indices, shard counts, materialize, aggregates, range
+    stages that number the survivors of the lower ranks, unique and groupreduce == the oracle / the single resident table.  Chunks of 4 blocks over 74."""
+    from dfdb import group as G, _native as N
+    n, bs = 300_007, 4096
+    cols = _columns(oracle, n)
+    ot = oracle.Table(block_size=bs)
+    for k, v in cols.items():
+        ot.add_column(k, v)
+    path = str(tmp_path / "tb")
+    ot.save(path)
+    g = G.Group.create([0] * world, N.EXCHANGE_HOST if world > 1 else N.EXCHANGE_AUTO)
+    try:
+        g.set_option("ooc_chunk_blocks", 4)
+        g.set_option("hbm_budget_mb", 1)                    # nothing fits
+        gt = G.GroupTable.open(g, path, load=False)
+        assert gt.nrows == n
+        gq = G._gq(gt[("a", lambda c: c > 700_000), dfdb_mod.ALL])
+        assert gq.prepare() == 3
+        for l in range(world):
+            assert gt.shard(l).resident_bytes() == {"decoded": 0, "compressed": 0}
+        _check_group_against_oracle(oracle, dfdb_mod, ot, gt, cols, n)
+        for l in range(world):
+            assert gt.shard(l).resident_bytes() == {"decoded": 0, "compressed": 0}, "a streamed shard keeps nothing"
+        # unique / groupreduce: the shards' chunk-merged parts merged in rank order
+        t1 = dfdb_mod.open_table(path, ctx=ctx)
+        try:
+            v1 = t1[("a", lambda c: c > 300_000), dfdb_mod.ALL]
+            gv = gt[("a", lambda c: c > 300_000), dfdb_mod.ALL]
+            want, got = v1.s.unique(), G.gunique(gv.s)
+            assert list(want) == list(got)
+            for col, stat in ((None, "count"), ("a", "sum"), ("x", "max"), ("a", "min")):
+                w, r = dfdb_mod.groupreduce(v1, "s", col, stat), G.ggroupreduce(gv, "s", col, stat)
+                assert list(w["s"]) == list(r["s"]) and np.array_equal(w["count"].to_numpy(), r["count"].to_numpy()), stat
+                if stat != "count":
+                    assert np.array_equal(w[stat].to_numpy(), r[stat].to_numpy()), stat
+        finally:
+            t1.close()
+        # with room, prepare loads every shard's block range of exactly the columns the view needs
+        g.set_option("hbm_budget_mb", 0)
+        gq2 = G._gq(gt[("a", lambda c: c > 700_000), ["a"]])
+        assert gq2.prepare() == 1 and gq2.prepare() == 0
+        for l in range(world):
+            sh = gt.shard(l)
+            assert sh.resident(0) and not sh.resident(1) and not sh.resident(2)
+        assert gq2.count() == int((cols["a"] > 700_000).sum())
+        gt.close()
+    finally:
+        g.close()
