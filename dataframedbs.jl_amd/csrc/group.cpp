@@ -713,6 +713,15 @@ int32_t dfdb_group_table_new(dfdb_group* g, int64_t block_size, dfdb_gtable** ou
   });
 }
 int32_t dfdb_group_table_close(dfdb_gtable* gt) { return gguard([&] { gtable_free(gt); }); }
+/* dfdb_table_unload on every shard: the listed columns (NULL = all) leave HBM; the files stay, and the group's entry points stream them from then on */
+int32_t dfdb_group_table_unload(dfdb_gtable* gt, const int32_t* ordinals, int32_t ncols) {
+  return gguard([&] {
+    GNEED(gt);
+    dfdb_group* g = gt->g;
+    for_shards(g, [&](int l) { rethrow_rc(dfdb_table_unload(gt->shard[(size_t)l], ordinals, ncols)); });
+    gtable_changed(gt);
+  });
+}
 int32_t dfdb_group_table_shard(dfdb_gtable* gt, int32_t local, dfdb_table** t) {
   return gguard([&] { GNEED(gt); GNEED(t); if (local < 0 || (size_t)local >= gt->shard.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: local shard %d", local); *t = gt->shard[(size_t)local]; });
 }

@@ -60,7 +60,7 @@ SYMBOLS = [
     # multi-GPU groups (block-range shards + RCCL)
     "dfdb_group_create", "dfdb_group_unique_id", "dfdb_group_create_rank", "dfdb_group_create_rank_callbacks", "dfdb_group_destroy", "dfdb_group_info", "dfdb_group_ctx",
     "dfdb_group_synchronize", "dfdb_group_barrier", "dfdb_group_set_option", "dfdb_group_allreduce_f64",
-    "dfdb_group_table_open", "dfdb_group_table_new", "dfdb_group_table_close", "dfdb_group_table_load", "dfdb_group_table_add_generated",
+    "dfdb_group_table_open", "dfdb_group_table_new", "dfdb_group_table_close", "dfdb_group_table_unload", "dfdb_group_table_load", "dfdb_group_table_add_generated",
     "dfdb_group_table_add_column", "dfdb_group_table_nrows", "dfdb_group_table_shard",
     "dfdb_group_query_new", "dfdb_group_query_free", "dfdb_group_query_prepare", "dfdb_group_query_add_range", "dfdb_group_query_add_indices", "dfdb_group_query_add_integer",
     "dfdb_group_query_add_predicate", "dfdb_group_query_set_projection", "dfdb_group_query_hint_aggregate", "dfdb_group_query_hint_materialize",
@@ -151,6 +151,7 @@ def load() -> C.CDLL:
         lib.dfdb_group_table_nrows.argtypes = [C.c_void_p, C.c_void_p]
         lib.dfdb_group_table_shard.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.dfdb_group_query_new.argtypes = [C.c_void_p, C.c_void_p]
+        lib.dfdb_group_table_unload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         lib.dfdb_group_query_prepare.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         lib.dfdb_group_query_add_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
         lib.dfdb_group_query_add_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]

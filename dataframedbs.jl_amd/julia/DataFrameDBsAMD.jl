@@ -58,7 +58,8 @@ function check(rc::Int32)
     rc == 5 && throw(BoundsError(msg))
     rc == 6 && throw(DivideError())
     rc == 7 && throw(Unsupported(msg))
-    error(msg)                       # IO / FORMAT / DEVICE / NOMEM -> ErrorException, like filesystem.jl:50-57
+    rc == 9 && throw(OutOfMemoryError())      # DFDB_ERR_NOMEM: with_query / with_gquery unload the table and answer block-streamed instead (below)
+    error(msg)                       # IO / FORMAT / DEVICE -> ErrorException, like filesystem.jl:50-57
 end
 
 # ---------------------------------------------------------------- dtypes (include/dfdb_ir.h)
@@ -301,6 +302,14 @@ function device()
         # projections decode the blocks that kept a row; every result is the same, scans cost ~10 x more (INTEGRATION.md section 6)
         keepc = something(tryparse(Int, get(ENV, "DFDB_KEEP_COMPRESSED", "")), 0)
         check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "keep_compressed", keepc))
+        # DFDB_HBM_BUDGET_MB: what ONE table may hold in HBM (per GPU when sharded); 0 / unset = whatever fits 80 % of the free HBM.  Only the columns a view
+        # needs are ever loaded (dfdb_query_prepare: required_columns, view.jl:183-190); a view whose columns do not fit is answered BLOCK-STREAMED inside the
+        # library, O(chunk) of HBM like the reference's O(block) (blocksiterator.jl:98-121; include/dfdb.h "out of core behind the ordinary entry points");
+        # DFDB_OOC_CHUNK_BLOCKS = blocks per chunk of those streams (default 512)
+        budget = something(tryparse(Int, get(ENV, "DFDB_HBM_BUDGET_MB", "")), 0)
+        chunkb = something(tryparse(Int, get(ENV, "DFDB_OOC_CHUNK_BLOCKS", "")), 512)
+        check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "hbm_budget_mb", budget))
+        check(ccall((:dfdb_ctx_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx[], "ooc_chunk_blocks", chunkb))
         grp = Ref{Ptr{Cvoid}}(C_NULL)
         n = ngpus()
         if n > 1
@@ -309,6 +318,8 @@ function device()
             GC.@preserve ids check(ccall((:dfdb_group_create, LIB), Int32, (Ptr{Int32}, Int32, Int32, Ptr{Ptr{Cvoid}}), ids, n, 0, grp))
             check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "string_dictionary", dictn))
             check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "keep_compressed", keepc))
+            check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "hbm_budget_mb", budget))
+            check(ccall((:dfdb_group_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), grp[], "ooc_chunk_blocks", chunkb))
         end
         DEV[] = Device(ctx[], grp[], Dict{String,Ptr{Cvoid}}(), Dict{String,Ptr{Cvoid}}())
     end
@@ -316,23 +327,22 @@ function device()
 end
 sharded() = device().group != C_NULL
 
-# open_table + read_block! of every block, once: decoded columns stay resident in HBM
+# open_table: the meta and the column headers only (creators.jl:7-16) — NO column is read here.  Which columns become resident is decided per view, by
+# dfdb_query_prepare in with_query below: exactly required_columns(v) (view.jl:183-190, blocksiterator.jl:20-33), and only when they fit.
 function device_table(t::DFTable)
     d = device()
     get!(d.tables, t.path) do
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dfdb_table_open, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Ptr{Cvoid}}), d.ctx, t.path, h))
-        check(ccall((:dfdb_table_load, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Int64, Int64, Ptr{Cvoid}), h[], C_NULL, 0, 0, -1, C_NULL))
         h[]
     end
 end
-# the same, every GPU loading only its block range
+# the same, sharded: the block ranges are laid out over the GPUs at open, nothing is read (dfdb_group_query_prepare loads per view)
 function device_gtable(t::DFTable)
     d = device()
     get!(d.gtables, t.path) do
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dfdb_group_table_open, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Ptr{Cvoid}}), d.group, t.path, h))
-        check(ccall((:dfdb_group_table_load, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Ptr{Cvoid}), h[], C_NULL, 0, C_NULL))
         h[]
     end
 end
@@ -344,11 +354,12 @@ end
 
 # ---------------------------------------------------------------- DFView -> dfdb_query / dfdb_gquery
 # One builder, generated twice: the group entry points take the same arguments as the single-GPU ones (include/dfdb.h).
-for (fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ) in (
+for (fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ, PREPARE, UNLOAD, RESET) in (
         (:with_query, :device_table, :dfdb_query_new, :dfdb_query_free, :dfdb_query_add_range, :dfdb_query_add_integer,
-         :dfdb_query_add_indices, :dfdb_query_add_predicate, :dfdb_query_set_projection),
+         :dfdb_query_add_indices, :dfdb_query_add_predicate, :dfdb_query_set_projection, :dfdb_query_prepare, :dfdb_table_unload, :dfdb_query_reset),
         (:with_gquery, :device_gtable, :dfdb_group_query_new, :dfdb_group_query_free, :dfdb_group_query_add_range, :dfdb_group_query_add_integer,
-         :dfdb_group_query_add_indices, :dfdb_group_query_add_predicate, :dfdb_group_query_set_projection))
+         :dfdb_group_query_add_indices, :dfdb_group_query_add_predicate, :dfdb_group_query_set_projection, :dfdb_group_query_prepare,
+         :dfdb_group_table_unload, :dfdb_group_query_reset))
     @eval function $fname(f, v::DFView)
         ord = ordinals(v.table)
         # lower everything BEFORE touching the device: an untraceable closure must fall back without side effects
@@ -378,7 +389,20 @@ for (fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ) in (
                 check(ccall(($(QuoteNode(PROJ)), LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Ptr{UInt8}}, Ptr{Csize_t}),
                             q[], length(names), np, cp, lens))
             end
-            return f(q[])
+            # required_columns(v) — and no others — into HBM if they fit the budget (decoded, else compressed-only); if not, nothing is loaded and every
+            # call f makes is answered block-streamed inside the library.  how: 0 resident already, 1 loaded, 2 compressed-only, 3 streamed.
+            how = Ref{Int32}(0)
+            check(ccall(($(QuoteNode(PREPARE)), LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), q[], how))
+            try
+                return f(q[])
+            catch e
+                # HBM ran out while answering (result buffers, a transient decode): give the table's columns back and answer once more, block-streamed —
+                # the reference's memory behaviour is O(block), an out-of-memory error is not among its outcomes (docs/src/index.md:182,192)
+                e isa OutOfMemoryError || rethrow()
+                check(ccall(($(QuoteNode(UNLOAD)), LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32), th, C_NULL, 0))
+                check(ccall(($(QuoteNode(RESET)), LIB), Int32, (Ptr{Cvoid},), q[]))
+                return f(q[])
+            end
         finally
             ccall(($(QuoteNode(FREE)), LIB), Int32, (Ptr{Cvoid},), q[])
         end

@@ -510,6 +510,8 @@ int32_t dfdb_group_allreduce_f64(dfdb_group* g, double* vals, int32_t n, int32_t
 int32_t dfdb_group_table_open(dfdb_group* g, const char* path, dfdb_gtable** out);       /* open_table: creators.jl:7-16 */
 int32_t dfdb_group_table_new(dfdb_group* g, int64_t block_size, dfdb_gtable** out);
 int32_t dfdb_group_table_close(dfdb_gtable* gt);
+/* dfdb_table_unload on every shard (NULL = all columns): the files stay, the group's entry points stream them from then on */
+int32_t dfdb_group_table_unload(dfdb_gtable* gt, const int32_t* ordinals, int32_t ncols);
 /* every shard loads ITS block range of the listed columns (NULL = all): dfdb_table_load(block range of rank) */
 int32_t dfdb_group_table_load(dfdb_gtable* gt, const int32_t* ordinals, int32_t ncols, dfdb_sizestats* stats);
 /* columns of the WHOLE table (nrows_total rows); every shard generates / uploads the rows of its block range */

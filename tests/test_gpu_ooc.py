@@ -338,3 +338,32 @@ def test_minimum_and_maximum_of_signed_zeros_do_not_depend_on_the_order(dfdb_mod
             assert mn == 0.0 and np.signbit(mn), (first, hinted, mn)
             assert mx == 0.0 and not np.signbit(mx), (first, hinted, mx)
         t.close()
+
+
+def test_julia_shim_routing_transcription(pair, dfdb_mod):
+    """The call sequence of julia/DataFrameDBsAMD.jl's with_query (round 6), transcribed: dfdb_table_open (NO load) -> dfdb_query_new + stages + projection ->
+    dfdb_query_prepare -> the consumer's calls; on OutOfMemoryError: dfdb_table_unload(all) + dfdb_query_reset + the consumer's calls again.  Both legs give
+    the oracle's answer, the first with exactly the required columns resident, the second with none."""
+    import dfdb._native as N
+    from dfdb import ir
+    L = N.load()
+    p = pair
+    ov, _ = apply_stages(p, [("pred", (ir.col(0) > 640_000) & (ir.col(2) == "sony"))], proj=[("x", ir.col(1)), ("s", ir.col(2))])
+    t = dfdb_mod.open_table(p.path, load=False)                                    # device_table(t): open only
+    try:
+        v = t[(("a", "s"), lambda a, s: (a > 640_000) & (s == "sony")), ["x", "s"]]
+        q = v._query()                                                             # dfdb_query_new, dfdb_query_add_predicate, dfdb_query_set_projection
+        how = C.c_int32(-1)
+        N.check(L.dfdb_query_prepare(q._h, C.byref(how)))                         # PREPARE
+        assert how.value == 1 and [t.resident(i) for i in range(3)] == [True, True, True] and not any(t.resident(i) for i in range(3, t.ncols))
+        def consumer():                                                            # gpu_materialize_columns: hint, count, coltype, string bytes, materialize
+            return q.materialize()
+        first = consumer()
+        same_cols(ov.materialize(), first)
+        N.check(L.dfdb_table_unload(t._h, None, 0))                                # the catch branch: UNLOAD, RESET, f again
+        q.reset()
+        assert not any(t.resident(i) for i in range(t.ncols))
+        same_cols(ov.materialize(), consumer())
+        assert not any(t.resident(i) for i in range(t.ncols)), "the retry streamed: nothing became resident"
+    finally:
+        t.close()

@@ -272,6 +272,21 @@ def test_julia_shim_ccalls_match_the_header():
     # the consumers VERDICT r1 asked for are bound: one-column routes, aggregates, unique, and the multi-GPU group
     for s in ("dfdb_materialize", "dfdb_aggregate", "dfdb_query_unique", "dfdb_group_create", "dfdb_group_count", "dfdb_group_aggregate", "dfdb_group_materialize"):
         assert s in syms, s
+    # round 6: nothing is loaded when a table is opened — the shim binds neither dfdb_table_load nor dfdb_group_table_load —, every view
+    # prepares exactly its required columns after its projection is set and before anything is asked of it, DFDB_ERR_NOMEM is OutOfMemoryError (not
+    # ErrorException) and is answered by unloading the table and asking once more, block-streamed
+    assert "dfdb_table_load" not in syms and "dfdb_group_table_load" not in syms
+    for s in ("dfdb_query_prepare", "dfdb_group_query_prepare", "dfdb_table_unload", "dfdb_group_table_unload", "dfdb_query_reset", "dfdb_group_query_reset"):
+        assert s in syms, s
+    jl = open(mod.JL).read()
+    assert "rc == 9 && throw(OutOfMemoryError())" in jl
+    builder = jl[jl.index("for (fname, tabfn, NEW, FREE"):jl.index("# struct dfdb_outcol")]
+    i_proj, i_prep, i_f = builder.index("QuoteNode(PROJ)"), builder.index("QuoteNode(PREPARE)"), builder.index("return f(q[])")
+    i_catch, i_unload, i_reset = builder.index("e isa OutOfMemoryError || rethrow()"), builder.index("QuoteNode(UNLOAD)"), builder.index("QuoteNode(RESET)")
+    assert i_proj < i_prep < i_f < i_catch < i_unload < i_reset < builder.rindex("return f(q[])")
+    assert builder.count("return f(q[])") == 2                      # the streamed retry happens once
+    for env in ("DFDB_HBM_BUDGET_MB", "DFDB_OOC_CHUNK_BLOCKS"):
+        assert env in jl
     review = open(os.path.join(ROOT, "dataframedbs.jl_amd", "julia", "STATIC_REVIEW.md")).read()
     assert f"**{len(rows)} ccall sites, 0 mismatches**" in review, "run tools/julia_static_review.py"
     assert "## Closures with control flow: the walk over lowered code (round 4)" in review and "**MISSING**" not in review, "run tools/julia_static_review.py"

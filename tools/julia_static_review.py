@@ -64,11 +64,15 @@ def jl_ccalls():
     src = open(JL).read()
     calls = []
     # the generated builders name their symbols through $(QuoteNode(X)): expand both instantiations
-    gen = re.search(r"for \(fname, tabfn, NEW, FREE, RANGE, INTEGER, INDICES, PRED, PROJ\) in \((.*?)\)\)\n", src, re.S)
+    gen = re.search(r"for \(([\w, ]+)\) in \((.*?)\)\)\n", src, re.S)
     maps = []
     if gen:
-        for tup in re.findall(r"\(:(\w+), :(\w+), :(\w+), :(\w+), :(\w+), :(\w+),\s*:(\w+), :(\w+), :(\w+)\)", gen.group(1) + ")"):
-            maps.append(dict(zip(["fname", "tabfn", "NEW", "FREE", "RANGE", "INTEGER", "INDICES", "PRED", "PROJ"], tup)))
+        names = [n.strip() for n in gen.group(1).split(",")]
+        for tup in re.findall(r"\(((?::\w+,?\s*)+)\)", gen.group(2) + ")"):
+            syms = re.findall(r":(\w+)", tup)
+            assert len(syms) == len(names), (names, syms)
+            maps.append(dict(zip(names, syms)))
+    assert maps, "the generated query builders were not found"
     for m in re.finditer(r"ccall\(\(", src):
         i = m.end()
         depth, j = 2, i
