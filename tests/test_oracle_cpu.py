@@ -394,3 +394,59 @@ def test_type_strings_are_the_reference_s(oracle, tmp_path):
     open(os.path.join(hand, "meta.bin"), "wb").write(struct.pack("<qqq", 1, 4, 1) + struct.pack("<q", 1) + jstr("x") + jstr("Tuple(Int32, UInt64)"))
     with pytest.raises(NotImplementedError, match="Tuple"):
         oracle.Table.open(hand)
+
+
+# ---------------------------------------------------------------- the file format pinned without either writer (round 6)
+def _format_golden():
+    import json
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = json.load(open(os.path.join(g, "format_v1.json")))
+    files = {n: open(os.path.join(g, "format_v1", n), "rb").read() for n in ("meta.bin", "1.bin", "2.bin")}
+    return spec, files, os.path.join(g, "format_v1")
+
+
+def test_hand_assembled_format_fixture_is_what_its_script_makes(tmp_path):
+    """tests/golden/format_v1 is the output of tests/golden/make_format_golden.py (struct.pack + system liblz4, one commented field per Julia line): the
+    committed bytes are current, and every field the script recorded lies where it says."""
+    import importlib.util
+    spec, files, _ = _format_golden()
+    assert sum(len(v) for v in files.values()) <= 4096
+    for f in spec["fields"]:
+        assert f["offset"] + f["length"] <= len(files[f["file"]]) and f["ref"], f
+    # re-run the assembly into a scratch directory (liblz4 is in the build image; the GPU box only reads the committed bytes)
+    try:
+        import ctypes
+        ctypes.CDLL("liblz4.so.1")
+    except OSError:
+        pytest.skip("no system liblz4 here: the committed bytes are checked by the other tests")
+    sp = importlib.util.spec_from_file_location("make_format_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_format_golden.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    mod.OUT = str(tmp_path / "fmt")
+    mod.HERE = str(tmp_path)
+    mod.main()
+    for n, want in files.items():
+        assert open(os.path.join(mod.OUT, n), "rb").read() == want, n
+
+
+def test_oracle_reads_and_rewrites_the_hand_assembled_format(oracle, tmp_path):
+    """The oracle's READER decodes the fixture to the values its script started from; the oracle's WRITER, given those values, reproduces meta.bin and both
+    column files byte for byte (it calls the same LZ4_compress_fast(…, 2) of liblz4 1.9.3 the script did)."""
+    spec, files, path = _format_golden()
+    t = oracle.Table.open(path)
+    assert t.block_size == spec["block_size"] and t.names() == ["a", "s"]
+    assert [t.colinfo(i)[0] for i in range(2)] == [1, 2]
+    assert t.colinfo(0)[2] == oracle.I64 and t.colinfo(1)[2] == (oracle.STRING | oracle.NULLABLE)
+    a, s = t.view().materialize()
+    assert a.tolist() == spec["a"] and oracle.flat_to_strings(*s) == spec["s"]
+    for i, n in ((0, "1.bin"), (1, "2.bin")):
+        assert t.image(i) == files[n]
+        st = t.column_stats(i)
+        assert (st["rows"], st["blocks"]) == (10, 3)
+    w = oracle.Table(block_size=spec["block_size"])
+    w.add_column("a", np.array(spec["a"], np.int64))
+    w.add_column("s", spec["s"], dtype=oracle.STRING | oracle.NULLABLE)
+    out = str(tmp_path / "rewritten")
+    w.save(out)
+    for n, want in files.items():
+        assert open(os.path.join(out, n), "rb").read() == want, n
