@@ -1326,6 +1326,77 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
   return true;
 }
 
+// The radix-partitioned form of the general unique (k_radix.hip, round 6): when the hash table would outgrow the L2s — `d0` distinct values among the first `r0`
+// selected rows say how many the whole selection holds, assuming they turn up evenly: d0 = D (1 - exp(-r0 / D)) — every selected row is written once as a
+// {key image, row} record into one of P partitions (by the top bits of the key's hash) and each partition is reduced through a table in LDS.  Streams instead
+// of one random line per row.  false = not taken (too few or too many distinct values, no room for the 12 bytes per selected row, a partition that outgrew
+// its table): the caller goes on with the hash table; the selection is as it was.
+static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  // MEASURED, 1e9 Int64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.4 + partition 9.8 + unique 3.8 ms = 18.4 ms end to end against the hash
+  // table's 20.0 — 8 % for 12 GB of scratch, not the 2 x the streams' byte count promised: the partition pass is not bandwidth-bound (3.4e9 vector instructions,
+  // 47 % of its wave cycles waiting at its five barriers with one 110-KB workgroup per CU).  So the form is built, tested and OFF by default (option = 1 turns it on).
+  const int64_t mode = ctx_option(ctx, "unique_radix", 0);
+  if (mode == 0 || t->nrows > (1ll << 32) || r0 == 0 || d0 == 0) return false;
+  if (mode < 2 && cnt < (32ll << 20)) return false;                      // (2: a test knob — any size)
+  double D = (double)cnt;
+  if (d0 < r0) {                                                         // solve d0 = D (1 - exp(-r0 / D)) for D by bisection
+    double lo = (double)d0, hi = (double)cnt;
+    for (int it = 0; it < 60 && hi - lo > 1.0; it++) { const double mid = 0.5 * (lo + hi); if (mid * (1.0 - std::exp(-(double)r0 / mid)) < (double)d0) lo = mid; else hi = mid; }
+    D = std::min((double)cnt, hi);
+  }
+  if (mode < 2 && D < 131072.0) return false;                            // the hash table stays in the L2s: nothing to gain
+  int kbits = 8;
+  while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;   // (fewer partitions = longer runs per 8192-row tile of the partition pass; more = emptier tables in the unique pass, whose linear probing has a long tail: 1e6 values -> 512; the partition pass's LDS holds at most 1024)
+  if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
+  const int P = 1 << kbits;
+  const int C = 4 * std::max(1, ctx->prop.multiProcessorCount);         // chunks = workgroups of the hist and partition passes
+  const int dt = dt_base(col.dtype);
+  const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
+  const int64_t nt = ceil_div(t->nrows, kTileRows);
+  const size_t nw = padded_words(t->nrows);
+  // the records' scratch (12 bytes per selected row) stays with the context between calls: hipMalloc / hipFree of 12 GB cost 3-4 ms of a 19-ms call (buffers
+  // above 1 GB never enter the pool); dfdb_ctx_destroy, or ctx option "unique_radix_scratch" = 0 at a later call, releases it
+  DevBuf counts_T, offsets_T, scratch, sel_keep, tc_keep;
+  DevBuf& keys = ctx->radix_keys; DevBuf& rows = ctx->radix_rows;
+  try {
+    counts_T.ensure((size_t)P * C * 4 + 64); offsets_T.ensure(((size_t)P * C + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes((int64_t)P * C));
+    keys.ensure((size_t)cnt * 8 + 256); rows.ensure((size_t)cnt * 4 + 256);
+    sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
+  } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  { LaunchTimer lt(ctx, "radix_hist");
+    if (!launch_radix_hist(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, counts_T.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
+  launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), (int64_t)P * C, scratch.as<uint64_t>());
+  { LaunchTimer lt(ctx, "radix_partition");
+    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), keys.as<uint64_t>(), rows.as<uint32_t>())) return false; }
+  // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
+  HIP_CHECK(hipMemcpyAsync(sel_keep.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(tc_keep.p, q->tile_counts.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, nw * 8, s));
+  HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)nt * 4, s));
+  uint64_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, offsets_T.as<uint64_t>() + (size_t)P * C, 8, hipMemcpyDeviceToHost, s));
+  stream_wait(ctx);
+  bool ok;
+  { LaunchTimer lt(ctx, "radix_unique");
+    ok = launch_radix_unique(s, keys.as<uint64_t>(), rows.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, C, total, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
+                             T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
+  uint64_t aborted = 0;
+  if (ok) { HIP_CHECK(hipMemcpyAsync(&aborted, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
+  if (!ok || aborted || ctx_option(ctx, "unique_radix", 0) == 3) {        // (3: a test knob — behave as if a partition had overflowed)
+    HIP_CHECK(hipMemcpyAsync(q->bitmap.p, sel_keep.p, nw * 8, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(q->tile_counts.p, tc_keep.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));
+    stream_wait(ctx);
+    prof_note(ctx, "unique_radix.fell_back");
+    return false;
+  }
+  prof_note(ctx, "unique_radix.taken");
+  stream_wait(ctx);                                                      // (the temporaries die with this frame)
+  if (ctx_option(ctx, "unique_radix_scratch", 1) == 0) { keys.release(); rows.release(); }
+  return true;
+}
+
 // the general form: an open-addressing table of {key, first row} sized by the distinct values as they turn up (k_unique.hip)
 static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
@@ -1396,6 +1467,7 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       }
       // (optimistic: chunk 1 must have fed at least 64 K selected rows and claimed nothing that chunk 0 had not)
       if (c == 0) { claims_c0 = st[0]; rows_c0 = r; }
+      if (c == 0 && !is_str && !T.defer_verify && unique_radix(q, col, cnt, T, st[0], r)) return;      // the radix-partitioned form took it: q's bitmap holds the first occurrences
       else if (c == 1 && !(st[0] == claims_c0 && r >= rows_c0 + 65536)) claims_c0 = ~0ull;
       if (c == 0 && bounds[1] <= bounds[0]) claims_c0 = ~0ull;
       const uint64_t want = unique_capacity_wanted(st[0], r, (uint64_t)cnt - std::min<uint64_t>(r, (uint64_t)cnt), T.cap, capmax);

@@ -171,6 +171,12 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                     behind the ordinary entry points" below)
  *   "hbm_budget_mb"   what dfdb_query_prepare / dfdb_group_query_prepare let a TABLE hold in HBM (per shard for a group), in MB; 0 (default) = no bound of its own —
  *                     80 % of the HBM that is free at the call (a group: of the device's HBM) decides alone
+ *   "unique_radix"    1 = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s (an estimated 131 072 .. ~2.5 M distinct values among
+ *                     at least 32 M selected rows) takes the radix-partitioned form (default 0: measured 18.4 ms against the hash table's 20.0 per 1e9 rows of 1e6
+ *                     values — profiles/r6_unique_radix.txt — which does not pay for 12 GB of scratch): every selected row is written once as a {key, row} record into one of 256 .. 2048
+ *                     partitions and each partition is reduced through a table in LDS (k_radix.hip; 12 bytes of scratch per selected row);
+ *                     0 = always the hash table; 2 = at any size, 3 = as if a partition had outgrown its table — test knobs, the results never depend on them.
+ *                     "unique_radix_scratch" = 0: the records' scratch goes back to the driver after every call (default 1: the context keeps it: allocating 12 GB costs 3-4 ms)
  *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
  *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
  *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one
