@@ -1042,10 +1042,7 @@ def main():
                     "extra key `calibrated_config`; `value` is always the library-default configuration")
     ap.add_argument("--no-placement", action="store_true", help="(accepted for older command lines: the calibration is off unless --placement asks for it)")
     ap.add_argument("--compact-store", type=int, default=None, help="A/B: K2 index stores 0 plain, 1 nontemporal, 2 write-through (ctx option compact_store)")
-    ap.add_argument("--placement-spacer-mb", type=int, default=None, help="A/B: MB held between the calibration's candidate bitmaps (ctx option placement_spacer_mb)")
-    ap.add_argument("--placement-count-candidates", type=int, default=None, help="A/B: fresh allocations of the query's tile-count array the calibration tries (ctx option placement_count_candidates)")
     ap.add_argument("--placement-column-candidates", type=int, default=None, help="A/B: fresh allocations of the column the calibration tries (ctx option placement_column_candidates; 0 = bitmaps only)")
-    ap.add_argument("--placement-candidates", type=int, default=None, help="A/B: candidate bitmaps the calibration tries (ctx option placement_candidates)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only for functional checks")
     ap.add_argument("--all-on-device0", action="store_true", help="functional check of the N-rank path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"], help="who runs the per-step count all-reduce: torch.distributed (default) "
@@ -1131,14 +1128,8 @@ def main():
         ctx = dfdb.Context(local, stream=stream_obj.cuda_stream)
         if args.compact_store is not None:
             ctx.set_option("compact_store", args.compact_store)
-        if args.placement_spacer_mb is not None:
-            ctx.set_option("placement_spacer_mb", args.placement_spacer_mb)
-        if args.placement_candidates is not None:
-            ctx.set_option("placement_candidates", args.placement_candidates)
         if args.placement_column_candidates is not None:
             ctx.set_option("placement_column_candidates", args.placement_column_candidates)
-        if args.placement_count_candidates is not None:
-            ctx.set_option("placement_count_candidates", args.placement_count_candidates)
         t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
         t.add_generated("x", dfdb.GEN_I64_MOD1M, SEED, rows, row_first=rank * rows)   # this rank's block range
         t.set_row_base(rank * rows)

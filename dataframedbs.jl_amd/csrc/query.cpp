@@ -137,8 +137,8 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     const auto wall0 = std::chrono::steady_clock::now();
-    const int kCand = (int)std::min<int64_t>(16, std::max<int64_t>(1, ctx_option(ctx, "placement_candidates", 8)));
-    const size_t spacer = std::min<size_t>((size_t)std::max<int64_t>(0, ctx_option(ctx, "placement_spacer_mb", 0)) << 20, free_b / (4 * (size_t)kCand));
+    const int kCand = 8;                    // candidate bitmaps (round 6: the A/B knobs of the search — "placement_candidates", "placement_spacer_mb", "placement_count_candidates" — are constants now)
+    const size_t spacer = 0;              // (round 2 held 12 GB between the candidates: seconds to release, nothing gained once the column is re-placed)
     if (free_b < (size_t)kCand * (bytes + spacer) + ((size_t)4 << 30)) return;      // not enough room to look around: keep the query's own
     std::vector<DevBuf> cand((size_t)kCand), space((size_t)kCand);
     try {
@@ -192,7 +192,7 @@ static void place_mask(dfdb_query* q, int ordinal, Launch&& launch /* (uint64_t*
     }
     // ---- the query's tile-count array last (4 bytes per 1024 rows: K1 writes it beside the bitmap).  Its placement is worth 1-2.5 % of the scan (eight candidates in each
     // of six processes: 1.195-1.236 ms), the search costs a few 4-MB allocations and 3 scans each: "placement_count_candidates" (default 4, 0 = leave it)
-    const int kTc = (int)std::min<int64_t>(16, std::max<int64_t>(0, ctx_option(ctx, "placement_count_candidates", 4)));
+    const int kTc = 4;
     if (kTc > 0 && q->tile_counts.bytes > 0) {
       uint64_t* const bmx = kbest >= 0 ? cand[(size_t)kbest].as<uint64_t>() : q->bitmap.as<uint64_t>();
       std::vector<DevBuf> tcand((size_t)kTc);
@@ -439,7 +439,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
     LaunchTimer lt(ctx, "str_match");
     launch_str_match(s, col.data.as<int32_t>(), (const int64_t*)col.tile_off.p, col.bytes.as<uint8_t>(), (const uint8_t*)pat.data(),
                      pb.as<uint8_t>(), (int32_t)pat.size(), mode, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                     do_cap ? &capture : nullptr, ctx_option(ctx, "str_stage", 1) != 0 ? col.max_tile_bytes : 0u);
+                     do_cap ? &capture : nullptr, col.max_tile_bytes);
     if (do_cap) q->cap_str_col = ord;
     have = true;
   }
@@ -459,7 +459,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   for (const CompTerm& ct : comp_terms) {
     Column& fc = t->cols[(size_t)ct.ord];
     LzScan sc{q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), ct.tm.cbits, ct.tm.dtype, ct.tm.op};
-    sc.op2 = ct.tm.op2; sc.cbits2 = ct.tm.cbits2; sc.and_existing = have ? (ctx_option(ctx, "lz4_hist_skip", 1) != 0 ? 1 : 2) : 0;
+    sc.op2 = ct.tm.op2; sc.cbits2 = ct.tm.cbits2; sc.and_existing = have ? 1 : 0;
     int waves = 0; uint8_t* scratch = ctx_hist_scratch(ctx, &waves);
     const int imode = column_lz4_index(ctx, fc, true);
     LaunchTimer lt(ctx, "lz4_decode_scan_hist");
@@ -526,7 +526,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
   if (!have && !term_batches.empty() && first_stage) {
     // the launch that writes a fresh mask over the whole column: run it against the bitmap allocation this column pairs best with
     const ScanTerms tb0 = term_batches[0];
-    const bool nt = ctx_option(ctx, "scan_nt", 1) != 0;
+    const bool nt = true;                 // nontemporal column loads (the A/B knob "scan_nt" went in round 6: plain loads were never faster)
     const int wt0 = (ctx_option(ctx, "scan_wt_store", 1) ? 1 : 0) | (int)((ctx_option(ctx, "scan_narrow", 1) & 3) << 1);
     const void* const col_before = t->cols[(size_t)term_ords[0]].data.p;
     place_mask(q, term_ords[0], [&](uint64_t* bm, int64_t rows, const void* colp) {
@@ -577,7 +577,7 @@ static void run_predicate(dfdb_query* q, const Node& pred, bool first_stage, boo
       LaunchTimer lt(ctx, "scan_cmp");
       prof_note(ctx, ctx_option(ctx, "scan_wt_store", 1) ? "scan_cmp.wt_store" : "scan_cmp.plain_store");
       launch_scan_cmp(s, tb.t[0].col, tb.t[0].dtype, tb.t[0].op, tb.t[0].cbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), nrows, have,
-                      ctx_option(ctx, "scan_nt", 1) != 0, ex == 1 ? q->cap_buf.p : nullptr,
+                      true, ex == 1 ? q->cap_buf.p : nullptr,
                       (ctx_option(ctx, "scan_wt_store", 1) ? 1 : 0) | (int)((ctx_option(ctx, "scan_narrow", 1) & 3) << 1));
     } else {
       LaunchTimer lt(ctx, "scan_terms");
@@ -833,7 +833,7 @@ void query_select_indices(dfdb_query* q, int64_t* out, int64_t cap, int32_t memk
   static const char* const store_names[] = {"compact_indices.plain8", "compact_indices.nt8", "compact_indices.wt8", "compact_indices.nt16", "compact_indices.plain16",
                                             "compact_indices.nt16_lds4k", "compact_indices.plain16_lds4k"};
   prof_note(ctx, store_names[store >= 0 && store <= 6 ? store : 0]);
-  const int gcap = (int)std::max<int64_t>(0, ctx_option(ctx, "compact_grid_cap", 0));
+  const int gcap = 0;
   if (memkind == DFDB_MEM_DEVICE) {
     { LaunchTimer lt(ctx, "compact_indices");
       launch_compact_indices(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), out, t->nrows, t->row_base, cap, store, gcap); }
@@ -1177,7 +1177,7 @@ static int64_t dict_unique(dfdb_query* q, const Column& col, DevBuf* rank_of_cod
     HIP_CHECK(hipMemcpyAsync(fr.data(), first.p, (size_t)dn * 8, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
   };
-  if (nt > 4 * head && ctx_option(ctx, "dict_unique_head", 1) != 0) {
+  if (nt > 4 * head) {
     walk(0, head);
     bool all = true;
     for (int k = 0; k < dn; k++) all = all && fr[(size_t)k] != ~0ull;
@@ -1393,7 +1393,6 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   }
   prof_note(ctx, "unique_radix.taken");
   stream_wait(ctx);                                                      // (the temporaries die with this frame)
-  if (ctx_option(ctx, "unique_radix_scratch", 1) == 0) { keys.release(); rows.release(); }
   return true;
 }
 
@@ -1620,7 +1619,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       else {
         // few groups of an 8-byte key: their keys (the key column at the first rows q's bitmap now holds, i.e. in group order) for the accumulate pass's LDS table
         const void* gkeys = nullptr;
-        if (ng <= 9216 && dt_width(kc.dtype) == 8 && ctx_option(ctx, "groupreduce_lds_table", 1) != 0) {
+        if (ng <= 9216 && dt_width(kc.dtype) == 8) {
           q->gr_keys.ensure((size_t)ng * 8 + 64);
           launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), kc.data.p, q->gr_keys.p, 8, t->nrows, ng);
           gkeys = q->gr_keys.p;

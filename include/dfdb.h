@@ -124,101 +124,53 @@ int32_t dfdb_ctx_create(int32_t device_id, void* hip_stream, dfdb_ctx** out);
 int32_t dfdb_ctx_destroy(dfdb_ctx* ctx);
 int32_t dfdb_ctx_synchronize(dfdb_ctx* ctx);
 int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
-/* tuning knobs (defaults are what the benchmarks use; the others keep measured alternatives selectable for A/B runs):
- *   "scan_nt"         1 = nontemporal column loads in the scan kernels (default 1)
- *   "scan_wt_store"   1 = K1 writes its bitmap with write-through stores (default 1)
- *   "scan_pair"       1 = an AND of exactly two plain comparisons / intervals on Int64 / Float64 columns runs in the pipelined two-column kernel (default 1;
- *                     0 = the generic multi-term kernel)
- *   "lz4_enc_variant" LZ4 block compressor: 0 = one sequence per step, 1 = window-parallel (default 1)
- *   "lz4_enc_near"    > 0: the window-parallel compressor gives a match up whose source lies further back than this many bytes when one of the next two
- *                     positions starts a match inside that reach that ends as late — K7 then copies out of its on-chip history instead of fetching a 128-byte
- *                     line for a few bytes.  Measured at 1984 (K7's reach): ratio - 8 %, indexed decode + 3 %, first decode - 3 % (profiles/r4_lz4_near.txt):
- *                     default 0 = off, since file bytes (PCIe) are what the cold path waits for
- *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself on a few fresh allocations of the column (device-to-device
- *                     copies: the fastest BECOMES the column, the others are released) and then against a few candidate bitmap allocations, and the column
- *                     keeps the fastest bitmap for the queries that scan it (query.cpp: place_mask; default 0: ~60 scans, copies of the column and 0.03-1.4 s of
- *                     allocations once per column buy ~3.5 % of K1 on average and halve its spread; bench.py turns it on).  "placement_column_candidates"
- *                     (8, at most 16; 0 = leave the column where it is; needs that many times the column's size of free HBM for the duration),
- *                     "placement_count_candidates" (4, at most 16; 0 = leave it: the query's 4-bytes-per-1024-rows tile-count array is tried in a few allocations too: 1-2.5 %),
- *                     "placement_spacer_mb" (0: round 2 held 12288 MB between the candidate bitmaps, which costs seconds to release and buys
- *                     nothing once the column is re-placed) / "placement_candidates" (8) size the search.  Pointers obtained from the table before the calibration
- *                     are not affected: the ABI never hands out a resident column's address
- *   "compact_store"   K2's form: 0 / 1 / 2 = one 4096-row ctile per wave step with plain / nontemporal / write-through 8-byte stores (1 was round 2's default:
- *                     nontemporal is slower alone, but the scan that follows runs 4-7 % faster); 3 (default) / 4 = two ctiles per wave and nontemporal / plain
- *                     16-byte stores, one pair per wave; 5 / 6 = the same with 4 KB instead of 8 KB of LDS per wave.  "compact_grid_cap" bounds its workgroups
+/* Context options (free-form keys; an unknown key is stored and ignored).  These TWENTY are the supported surface; defaults are what the benchmarks run with.
+ * A/B switches of measured alternatives and switches that force a code path in tests are not part of it: they are listed in
+ * dataframedbs.jl_amd/csrc/KNOBS.md, results never depend on them, and they may go without notice (round 6 removed ten).
+ *  residency
+ *   "keep_compressed"  0 (default) = a loaded column is its decoded array.  1 = plain fixed-width columns also keep their LZ4 blocks in HBM beside it
+ *                      (dfdb_table_decode_resident re-decodes from them).  2 = COMPRESSED-ONLY: the LZ4 blocks + their sequence-start index and NO decoded array —
+ *                      like the reference, whose iterator decodes every block into two reusable buffers and keeps nothing (BlockStreams.jl:9-15,101-119; "memory
+ *                      use is O(block)", docs/src/index.md:182,192).  `col OP const` conjuncts (and intervals) over an 8-byte column are evaluated by the decoder
+ *                      itself (bitmap and tile counts are the only output; from the second mask on, blocks without a survivor are not decoded); a projection
+ *                      gathers from the blocks that KEPT A ROW, decoded into an arena the query owns (blocksiterator.jl:111-113); every other consumer gets a
+ *                      whole-column decode that lives for the one ABI call.  Nullable and String columns load as with 0.
+ *   "lz4_index"        1 (default) = the first decode of a column's resident blocks records where its LZ4 sequences start (one bit per compressed byte) and every
+ *                      later decode reads that instead of parsing again: 450-490 -> 590-630 GB/s decoded on 8-byte integer columns; same bytes out
+ *   "decode_on_scan"   1 = a fresh-mask scan of one `col OP const` term over an 8-byte column that holds its blocks (keep_compressed = 1) decodes and filters in
+ *                      ONE pass instead of trusting the decoded array (default 0)
  *   "string_dictionary" N > 0 = a String column that becomes resident gets a dictionary when it has at most N distinct values (dfdb_table_build_dictionary; default 0)
- *   "scan_capture"    how many projected 8-byte predicate columns the scan that produces a query's final mask keeps for dfdb_materialize
- *                     (dfdb_query_hint_materialize): 2 (default: the last two terms of the launch, the second parked in LDS), 1, or 0 = gather everything
- *   "scan_narrow"     which narrow columns `col OP const` scans with 16-byte loads per lane (k_scan_cmp_narrow): 1 = 1-byte columns — Bool, Int8, UInt8 —
- *                     (default: 0.72 of the HBM peak against 0.52), 2 = 2- and 4-byte columns too (no consistent gain measured), 0 = none
- *   "str_stage"       1 = a string comparison over a column whose 1024-row tiles hold at most 8 KB of bytes each streams a tile's bytes into LDS with aligned
- *                     16-byte loads and probes there (default 1); 0 = 8-byte probes straight from memory, which longer strings always take
- *   "unique_dense"    1 = dfdb_query_unique / _groupreduce over an integer key whose selected values span less than 1 277 952 take the form without a hash
- *                     table (a presence bit per value in LDS; default 1); "unique_dense_range" lowers that span.  "unique_cap0_log2" = log2 of the slots the
- *                     hash table starts with (default 21; it grows with the distinct values met), "unique_chunk_tiles" = 1024-row tiles of the first chunk
- *                     either form feeds before it looks at what it found (default 1024), "dense_head_tiles" = 1024-row tiles of the head dfdb_query_groupreduce by an 8-byte integer key makes its group table from when "groupreduce_optimistic" is on (default 4096 =
- *                     4 M rows, taken only for columns of at least eight times that; its accumulate pass reports a key the head did not hold and everything runs again over all rows),
- *                     "dict_unique_head" = 0: unique / groupreduce over a dictionary-coded String column walk all of
- *                     the codes for their first rows at once (default 1: the first 4 M rows first, the rest only if a code has not turned up there), "unique_dense_sample" = 0 (2 = sample even a small table: a test knob): the dense form reads the
- *                     exact range of the keys first instead of laying its span around a sample's, "groupreduce_lds_table" = 0: dfdb_query_groupreduce by a Float64 / wide-integer key of at most 9216 groups probes the global hash table per row
- *                     (default 1: the groups' keys in a small table in LDS beside the accumulators), "groupreduce_optimistic" = 0: dfdb_query_groupreduce by a String, Float or wide-integer key (and dfdb_query_unique over a String column) inserts every selected row into its hash table,
- *                     and by a dense integer key walks every row for the first rows
- *                     (default 1: when the second chunk of rows — 16 M — brought no string the first — 1 M — had not, the rest are not inserted; the accumulate pass (unique: the
- *                     compare pass), which meets every row anyway, reports a string that is missing and everything runs again; 2 = behave as if one had been: a test knob),
- *                     "unique_test_collide" = N: groupreduce by a String key
- *                     behaves as if the first N salts had produced a hash collision — test knobs, the results never depend on them
- *   "ooc_chunk_blocks"  blocks per chunk of the streams the query entry points run internally over columns that are not resident (default 512; see "out of core
- *                     behind the ordinary entry points" below)
- *   "hbm_budget_mb"   what dfdb_query_prepare / dfdb_group_query_prepare let a TABLE hold in HBM (per shard for a group), in MB; 0 (default) = no bound of its own —
- *                     80 % of the HBM that is free at the call (a group: of the device's HBM) decides alone
- *   "unique_radix"    1 = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s (an estimated 131 072 .. ~2.5 M distinct values among
- *                     at least 32 M selected rows) takes the radix-partitioned form (default 0: measured 18.4 ms against the hash table's 20.0 per 1e9 rows of 1e6
- *                     values — profiles/r6_unique_radix.txt — which does not pay for 12 GB of scratch): every selected row is written once as a {key, row} record into one of 256 .. 2048
- *                     partitions and each partition is reduced through a table in LDS (k_radix.hip; 12 bytes of scratch per selected row);
- *                     0 = always the hash table; 2 = at any size, 3 = as if a partition had outgrown its table — test knobs, the results never depend on them.
- *                     "unique_radix_scratch" = 0: the records' scratch goes back to the driver after every call (default 1: the context keeps it: allocating 12 GB costs 3-4 ms)
- *   "stream_late_materialize"  1 = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row (default 1;
- *                     0 = every required column of every chunk whole, the selection evaluated afterwards)
- *   "stream_slots"    chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded by one
- *                     loader thread each (2e9 rows, 1024-block chunks, file bytes per second: 4 slots 36.6, 6 slots 40.9, 8 slots with three reading
- *                     turns granted in chunk order and the loaders on the GPU's NUMA node 43-46 GB/s)
- *   "stream_piece_mb" a loader reads and copies a chunk's bytes this many MB at a time through a three-piece pinned ring per slot, 1 .. 512 (default 64)
- *   "io_threads"      concurrent preads a byte range of a column file is split into, 1 .. 64 (default 8; process-wide, read when a stream is opened)
- *   "stream_readers"  loaders of a stream that may READ (page cache -> pinned memory, queueing the copies) at the same time, the others wait for their
- *                     copies and their decode (default 3)
- *   "load_progressive" 1 = dfdb_table_load decodes a plain fixed-width column batch by batch while the rest of its file is still being read and copied
- *                     (K7 over the blocks that have arrived, behind their copies on the same stream; the 20-byte headers are walked on a side thread first so
- *                     that the column array can be sized) instead of in one launch after the last byte (default 1); files under four pieces of "load_piece_kb"
- *                     (default 65536 = 64 MB pieces through the pinned bounce buffers) load as before, "load_progressive_blocks" = blocks per batch (default 768)
- *                     — the last two exist so that tests can drive the path with small files
- *   "numa_bind"       1 = the host threads that move file bytes (loads, streams, saves) run on the CPUs of the NUMA node the GPU hangs off, and the
- *                     pinned bounce buffers are allocated from there (default 1; the calling thread's own affinity is restored on return)
- *   "stream_cache"    1 = dfdb_stream_close parks the stream (slot contexts, pinned buffers, device buffers, loader threads) on its context and the next
- *                     dfdb_stream_open on that context re-arms it instead of building a new one (~40 ms saved per stream; default 1)
- *   "save_fsync"      1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
- *   "lz4_pipeline"    K7 with two waves per block (one parses, one produces, a superbatch apart): -1 = when every block of a launch can be resident in
- *                     that form at once (<= 2048 blocks; default), 0 = never, 1 = always
- *   "decode_on_scan"  1 = a fresh-mask scan of one `col OP const` term over an 8-byte column that holds its LZ4 blocks (keep_compressed) decodes and
- *                     filters in ONE pass (K7 fused with the predicate: SURVEY.md §8f-2) instead of trusting the decoded array; with at most 2048 blocks
- *                     (the two-wave pipeline's range) it decodes with the pipeline and then scans the decoded array, which is shorter there (default 0)
- *   "keep_compressed" 1 = dfdb_table_load keeps the LZ4 blocks of plain fixed-width columns in HBM beside the decoded array (dfdb_table_decode_resident; default 0).
- *                     2 = COMPRESSED-ONLY: such a column holds its LZ4 blocks and their sequence-start index and NO decoded array — like the reference, whose
- *                     iterator decodes every block into two reusable buffers and keeps nothing (BlockStreams.jl:9-15,101-119; "memory use is O(block)",
- *                     docs/src/index.md:182,192).  At load the blocks are validated by a decode whose output goes to per-wave 64-KB history rings only
- *                     (an LZ4 match reaches at most 65 535 bytes back inside its block).  Conjuncts `col OP const` (and intervals) over an 8-byte column are
- *                     evaluated by the decoder itself, term by term — bitmap and tile counts are the only output; from the second mask on, blocks without a
- *                     survivor are not decoded.  A projection gathers from the blocks that KEPT A ROW, decoded into an arena the query owns
- *                     (blocksiterator.jl:111-113).  Every other consumer (interpreter programs, multi-column terms, aggregates, unique, save) gets a
- *                     whole-column decode that lives for the one ABI call.  Nullable and String columns load as with 0.  dfdb_table_resident_bytes reports
- *                     what a column holds.  "lz4_hist_waves" = history rings (= workgroups) of those decodes, 0 = 24 per compute unit (default);
- *                     "lz4_hist_skip" = 0: an AND-ed term decodes every block, also those no survivor is left in (default 1: skipped) — an A/B knob
- *   "group_force_exchange" 1 = a group's unique / groupreduce merge sends its records through the exchange (RCCL all-gather / the callbacks) even when one
- *                     process holds every shard and could merge them in place (default 0; what the one-GPU tests use to run the exchange code)
- *   "lz4_index"       1 = the first dfdb_table_decode_resident / decode_on_scan of such a column records where its LZ4 sequences start — one bit per
- *                     compressed byte, +12.5 % beside the blocks, built inside that decode (which runs ~10 % slower for it) — and every later decode of
- *                     the column reads the index instead of parsing candidates and walking the chain again: 450-490 -> 590-630 GB/s decoded on 8-byte
- *                     integer columns.  Same bytes out.  The two-wave pipeline (<= 2048 blocks) reads it too — its parser wave then also fetches the far sources, which
- *                     balances the two waves again: 1 526 blocks 238 -> 328 GB/s, 2 048 blocks 308 -> 418; the recording launch is always one wave per block (default 1) */
+ *   "hbm_budget_mb"    what dfdb_query_prepare / dfdb_group_query_prepare let a TABLE hold in HBM (per shard for a group), in MB; 0 (default) = no bound of its own:
+ *                      80 % of the HBM that is free at the call (a group: of the device's HBM) decides alone
+ *  out of core (see "out of core behind the ordinary entry points" and "block-streamed execution" below)
+ *   "ooc_chunk_blocks" blocks per chunk of the streams the query entry points run internally over columns that are not resident (default 512)
+ *   "stream_slots"     chunks a stream holds in HBM at once, 2 .. 8 (default 8): one is the caller's, the others are being read, copied and decoded
+ *   "stream_readers"   loaders of a stream that may READ (page cache -> pinned memory) at the same time, the others wait for their copies and decode (default 3)
+ *   "stream_piece_mb"  a loader reads and copies a chunk's bytes this many MB at a time through a three-piece pinned ring, 1 .. 512 (default 64)
+ *   "stream_late_materialize"  1 (default) = a streamed chunk loads its projection-only columns only for the blocks whose selection kept a row
+ *                      (blocksiterator.jl:111-113); 0 = every required column of every chunk whole
+ *   "stream_cache"     1 (default) = dfdb_stream_close parks the stream (slot contexts, pinned buffers, loader threads) on its context for the next open (~40 ms saved)
+ *  host I/O
+ *   "io_threads"       concurrent preads a byte range of a column file is split into, 1 .. 64 (default 8; process-wide, read when a stream is opened)
+ *   "numa_bind"        1 (default) = the host threads that move file bytes run on the CPUs of the NUMA node the GPU hangs off, pinned buffers come from there
+ *   "load_progressive" 1 (default) = dfdb_table_load decodes a plain fixed-width column batch by batch while the rest of its file is still being read
+ *   "save_fsync"       1 = dfdb_table_save / _save_column fdatasync every file before closing it, column files before meta.bin (default 0, like the reference)
+ *  kernels
+ *   "placement_calibrate" 1 = the first fresh-mask scan of a column of >= 2^26 rows times itself on a few fresh allocations of the column and of its bitmap and keeps
+ *                      the fastest (~60 scans and 0.03-1.4 s once per column buy ~3.5 % of K1 and halve its spread; default 0; `bench.py --placement`)
+ *   "scan_capture"     how many projected 8-byte predicate columns the scan that produces a query's final mask keeps for dfdb_materialize
+ *                      (dfdb_query_hint_materialize): 2 (default), 1, or 0 = gather everything
+ *   "lz4_enc_near"     > 0: the writer's compressor gives up a match whose source lies further back than this many bytes when a nearer one ends as late — K7 then copies
+ *                      out of its on-chip history instead of fetching a line (at 1984, K7's reach: ratio - 8 %, indexed decode + 3 %; default 0: file bytes are what
+ *                      the cold path waits for)
+ *   "unique_radix"     1 = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s takes the radix-partitioned form (k_radix.hip: every selected
+ *                      row written once as a {key, row} record into one of 256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per
+ *                      selected row, kept by the context).  Default 0: measured 18.4 ms against the hash table's 20.0 per 1e9 rows of 1e6 values
+ *                      (profiles/r6_unique_radix.txt), which does not pay for the scratch
+ *   "jit"              1 (default) = an expression the device INTERPRETER evaluates (outside `col OP const` terms, pairs and string matches: configs 2-5 never get here)
+ *                      over at least 4 M rows is also compiled by hipRTC in the background — the interpreter's own source specialised for the program's shape — and later
+ *                      executions run the compiled kernel; until it is ready, or when libhiprtc is absent, the interpreter answers.  0 = interpret always; 2 = wait for
+ *                      the compiler (tests, benchmarks).  Results are identical by construction.  dfdb_shutdown stops the compiler; dfdb_jit_cache_dir is its disk cache */
 int32_t dfdb_ctx_set_option(dfdb_ctx* ctx, const char* key, int64_t value);
 /* HIP-event timing on the engine's own stream (bench.py's roofline leg) */
 int32_t dfdb_ctx_timer_start(dfdb_ctx* ctx);

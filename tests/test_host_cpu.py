@@ -354,15 +354,23 @@ def test_oracle_is_clean_under_address_and_ub_sanitizers():
 
 
 def test_every_context_option_the_engine_reads_is_documented_in_the_header():
-    """dfdb_ctx_set_option takes free-form keys: an option the engine reads but include/dfdb.h does not describe cannot be found by a caller"""
+    """dfdb_ctx_set_option takes free-form keys: an option the engine reads must be findable — the supported ones (at most twenty: VERDICT r5 weak 10) in
+    include/dfdb.h, the A/B and test knobs in csrc/KNOBS.md — and nothing is listed in either place that the engine no longer reads."""
     import glob
     import re
-    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "dataframedbs.jl_amd", "csrc", "*.[ch]pp")))
-    read = set(re.findall(r'ctx_option\([^,()]+,\s*"([a-z0-9_]+)"', src))
-    assert len(read) >= 15, read
+    files = glob.glob(os.path.join(ROOT, "dataframedbs.jl_amd", "csrc", "*.[ch]pp")) + glob.glob(os.path.join(ROOT, "dataframedbs.jl_amd", "csrc", "*.hip"))
+    src = "".join(open(f).read() for f in files)
+    read = set(re.findall(r'ctx_option\((?:[^,()]|\([^()]*\))+,\s*"([a-z0-9_]+)"', src))
+    assert len(read) >= 30, read
     header = open(os.path.join(ROOT, "include", "dfdb.h")).read()
-    missing = sorted(o for o in read if f'"{o}"' not in header)
-    assert not missing, missing
+    block = header[header.index("/* Context options (free-form keys"):header.index("int32_t dfdb_ctx_set_option(")]
+    public = set(re.findall(r'^ \*   "([a-z0-9_]+)"', block, re.M))
+    knobs_md = open(os.path.join(ROOT, "dataframedbs.jl_amd", "csrc", "KNOBS.md")).read()
+    knobs = set(re.findall(r'^\| `([a-z0-9_]+)`', knobs_md, re.M))
+    assert len(public) <= 20, sorted(public)
+    assert not (public & knobs), public & knobs
+    assert read - public - knobs == set(), sorted(read - public - knobs)
+    assert (public | knobs) - read == set(), sorted((public | knobs) - read)
 
 
 # ------------------------------------------------------------------ round 5: host-side hardening that needs no GPU
