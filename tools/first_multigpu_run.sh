@@ -21,10 +21,10 @@ rc_tests=${PIPESTATUS[0]}
 echo "== 3. bench.py"
 for n in 1 2 4 8; do
   [ "$n" -gt "$NDEV" ] && break
-  python3 bench.py --gpus $n --steps 20 --warmup 5 > "$OUT/bench_torch_n$n.json" 2> "$OUT/bench_torch_n$n.err"; echo "torch nccl  N=$n rc=$? $(python3 tools/r4_show_bench.py "$OUT/bench_torch_n$n.json" 2>/dev/null | head -1)"
+  python3 bench.py --gpus $n --steps 20 --warmup 5 > "$OUT/bench_torch_n$n.json" 2> "$OUT/bench_torch_n$n.err"; echo "torch nccl  N=$n rc=$? $(python3 tools/show_bench.py "$OUT/bench_torch_n$n.json" 2>/dev/null | head -1)"
   if [ "$n" -gt 1 ]; then
-    python3 bench.py --gpus $n --exchange lib --steps 20 --warmup 5 --no-cpu > "$OUT/bench_lib_n$n.json" 2> "$OUT/bench_lib_n$n.err"; echo "library RCCL N=$n rc=$? $(python3 tools/r4_show_bench.py "$OUT/bench_lib_n$n.json" 2>/dev/null | head -1)"
-    python3 bench.py --mode threads --gpus $n --steps 20 --warmup 5 > "$OUT/bench_threads_n$n.json" 2> "$OUT/bench_threads_n$n.err"; echo "one process  N=$n rc=$? $(python3 tools/r4_show_bench.py "$OUT/bench_threads_n$n.json" 2>/dev/null | head -1)"
+    python3 bench.py --gpus $n --exchange lib --steps 20 --warmup 5 --no-cpu > "$OUT/bench_lib_n$n.json" 2> "$OUT/bench_lib_n$n.err"; echo "library RCCL N=$n rc=$? $(python3 tools/show_bench.py "$OUT/bench_lib_n$n.json" 2>/dev/null | head -1)"
+    python3 bench.py --mode threads --gpus $n --steps 20 --warmup 5 > "$OUT/bench_threads_n$n.json" 2> "$OUT/bench_threads_n$n.err"; echo "one process  N=$n rc=$? $(python3 tools/show_bench.py "$OUT/bench_threads_n$n.json" 2>/dev/null | head -1)"
   fi
 done
 python3 - "$OUT" <<'PY'

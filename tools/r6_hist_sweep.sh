@@ -5,11 +5,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r6/hist
 mkdir -p $OUT
 WAVES=2048,3072,4096,0
 for v in 0 1 2; do
-  DFDB_LZ4_HIST_VARIANT=$v timeout 600 python3 $GRAFT_REPO_ROOT/tools/r5_hist_sweep.py 1e9 $WAVES > $OUT/ms_variant$v.txt 2>&1
+  DFDB_LZ4_HIST_VARIANT=$v timeout 600 python3 $GRAFT_REPO_ROOT/tools/hist_sweep.py 1e9 $WAVES > $OUT/ms_variant$v.txt 2>&1
 done
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o h -- python3 $GRAFT_REPO_ROOT/tools/r5_hist_sweep.py 1e9 $WAVES > $OUT/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o h -- python3 $GRAFT_REPO_ROOT/tools/hist_sweep.py 1e9 $WAVES > $OUT/pmc_$c.log 2>&1
 done
 cd $OUT && python3 - <<'PY' > $OUT/pmc_summary.txt
 import csv, glob
