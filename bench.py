@@ -434,6 +434,39 @@ def cold_leg(dfdb, ctx, torch, dev, rows, peak, chunk_blocks=1024):
         r = rec(sec, total, rd, "the same with ctx option stream_late_materialize = 0: every required column of every chunk whole")
         r["projection_bytes_read_frac"] = rd["b"] / cs["b"]["compressed"]
         res["stream_clustered_eager"] = r
+
+        # ---- round 6: the same table through the ORDINARY entry points (csrc/ooc.cpp): nothing is resident, dfdb_count / dfdb_materialize stream inside the library
+        def ooc(view, materialize_cols, reps=2):
+            ctx.set_option("ooc_chunk_blocks", chunk_blocks)
+            best, total, rd = None, 0, 0
+            for _ in range(reps):
+                q = dfdb.api._Query(view)                    # a fresh handle per repetition: nothing counted, nothing read yet
+                st0 = N.SizeStats()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                if materialize_cols:
+                    q.hint_materialize(True)
+                total = q.count()
+                if materialize_cols:
+                    bufs = [torch.empty(max(total, 1), dtype=torch.int64, device=dev) for _ in range(materialize_cols)]
+                    outs = (N.OutCol * materialize_cols)()
+                    for k in range(materialize_cols):
+                        outs[k].data, outs[k].memkind = bufs[k].data_ptr(), N.MEM_DEVICE
+                    N.check(lib.dfdb_materialize(q._h, outs, materialize_cols))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                N.check(lib.dfdb_query_read_stats(q._h, C.byref(st0)))
+                rd = st0.compressed
+                best = dt if best is None else min(best, dt)
+            return best, total, rd
+
+        def rec2(sec, total, rd, what):
+            return {"seconds": sec, "rows_per_s": rows / sec, "selected": total, "file_bytes_read": rd, "file_GBps": rd / sec / 1e9, "frac_of_pinned_copy": rd / sec / 1e9 / pcie, "what": what}
+        sec, total, rd = ooc(v[dfdb.ALL, ["x"]], 0, reps=3)
+        res["ooc_count"] = rec2(sec, total, rd, "dfdb_count(x > 899999) on the table that is not resident: ONE call, the library streams column x")
+        res["ooc_count"]["count_ok"] = total == want
+        sec, total, rd = ooc(v[dfdb.ALL, ["x", "b"]], 2)
+        res["ooc_materialize"] = rec2(sec, total, rd, "dfdb_count + dfdb_materialize [x, b] into device buffers sized by the count: two passes like the reference's (count pre-pass, then append); "
+                                                         "file bytes of both passes")
         tb.close()
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -491,7 +524,7 @@ def make_summary(res):
             s["cold"] = str(cold.get("error") or cold.get("skipped"))[:80]
         else:
             d = {"fmt": "[file_GBps, frac_of_pinned_copy]", "pinned_copy_GBps": _r(cold.get("pinned_copy_GBps"), 1)}
-            for k in ("open_table", "stream_count", "stream_materialize", "stream_clustered"):
+            for k in ("open_table", "stream_count", "stream_materialize", "stream_clustered", "ooc_count", "ooc_materialize"):
                 if isinstance(cold.get(k), dict):
                     d[k] = [_r(cold[k].get("file_GBps"), 1), _r(cold[k].get("frac_of_pinned_copy"))]
             if isinstance(cold.get("stream_clustered"), dict):
