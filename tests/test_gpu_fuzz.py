@@ -252,6 +252,27 @@ def test_random_queue_streamed_and_sharded(filed, dfdb_mod, seed):
     assert np.array_equal(np.asarray(got["a"], dtype=np.int64), want[0]) and np.array_equal(np.asarray(got["k"], dtype=np.int64), want[2])
     gx, wx = np.asarray(got["x"], dtype=np.float64), want[1]
     assert np.array_equal(np.isnan(gx), np.isnan(wx)) and np.array_equal(gx[~np.isnan(gx)], wx[~np.isnan(wx)])
+    # round 6: aggregates, unique and groupreduce over the table that is NOT resident — the ordinary calls, streamed inside the library (csrc/ooc.cpp): per-chunk
+    # device results merged in chunk order — against the same calls over the resident table (which the other fuzz tests hold to the oracle)
+    lazy.ctx.set_option("ooc_chunk_blocks", 1 + (seed // 7) % 5)
+    rsel = dfdb_mod.DFView(pair.d, None, dv.selection)
+    lsel = dfdb_mod.DFView(lazy, None, dv.selection)
+    for name in ("b", "u64", "i8"):
+        assert lsel[dfdb_mod.ALL, name].sum() == rsel[dfdb_mod.ALL, name].sum(), (name, stages)
+    if len(want_idx):
+        for name in ("a", "x", "f"):
+            lo, ro = lsel[dfdb_mod.ALL, name].min(), rsel[dfdb_mod.ALL, name].min()
+            assert (lo == ro and np.signbit(lo) == np.signbit(ro)) or (lo != lo and ro != ro), (name, lo, ro, stages)
+            lo, ro = lsel[dfdb_mod.ALL, name].max(), rsel[dfdb_mod.ALL, name].max()
+            assert (lo == ro and np.signbit(lo) == np.signbit(ro)) or (lo != lo and ro != ro), (name, lo, ro, stages)
+    key = ("c", "s", "i8", "a")[seed % 4]
+    lu, ru = lsel[dfdb_mod.ALL, key].unique(), rsel[dfdb_mod.ALL, key].unique()
+    assert list(lu) == list(ru), (key, stages)
+    stat, val = (("count", None), ("sum", "b"), ("min", "i32"), ("max", "u16"))[(seed // 4) % 4]
+    lg, rg = dfdb_mod.groupreduce(lsel, key, val, stat), dfdb_mod.groupreduce(rsel, key, val, stat)
+    assert list(lg[key]) == list(rg[key]) and np.array_equal(lg["count"].to_numpy(), rg["count"].to_numpy()), (key, stat, stages)
+    if stat != "count":
+        assert np.array_equal(lg[stat].to_numpy(), rg[stat].to_numpy()), (key, stat, stages)
     # three block-range shards
     gv = dfdb_mod.DFView(gt.view().table, dv.projection, dv.selection)
     assert G.gnrow(gv) == len(want_idx)
