@@ -24,6 +24,13 @@ constexpr int kRBlock = 1024;                 // threads per workgroup of all th
 constexpr int kRTile = 8192;                  // rows sorted at a time by the partition pass (8 per thread)
 constexpr int kRSlots = 8192;                 // slots of a partition's table in LDS
 constexpr uint64_t kREmpty = 0xFFFFFFFFFFFFFFFFull;
+// 32 bits of hash per key, three 32-bit multiplies (k_unique.hip lds_slot_of's mix; splitmix64's two 64-bit multiplies are eight quarter-rate instructions each and
+// the partition pass hashed every row twice: 3.4e9 vector instructions per 1e9 rows).  The partition is its TOP bits, a table slot its low bits.
+__device__ __forceinline__ uint32_t rhash(uint64_t key) {
+  uint32_t h = ((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u;
+  h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+  return h;
+}
 
 __device__ __forceinline__ uint64_t rkey_fixed(const void* col, int dtype, int64_t row) {      // = k_unique.hip key_fixed: the isequal image
   switch (dtype) {
@@ -86,8 +93,8 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 #pragma unroll
     for (int j = 0; j < 8; j++)
       if (radix_take<true>(rr[j], dtype, base + j * kRBlock + threadIdx.x, r1, aux)) {
-        if (xp & 1) { if (splitmix64(rr[j].key) == 12345ull) hist_sh[0] = 1; }       // (DFDB_RADIX_XP bit 0, timing only: the pass without its LDS atomics)
-        else atomicAdd(&hist_sh[splitmix64(rr[j].key) >> (64 - kbits)], 1u);
+        if (xp & 1) { if (rhash(rr[j].key) == 12345u) hist_sh[0] = 1; }              // (DFDB_RADIX_XP bit 0, timing only: the pass without its LDS atomics)
+        else atomicAdd(&hist_sh[rhash(rr[j].key) >> (32 - kbits)], 1u);
       }
   }
   __syncthreads();
@@ -95,104 +102,83 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 }
 
 // ---- pass 2: the records of chunk c, sorted by partition 8192 rows at a time, to their places
+// (Tried and dropped, profiles/r6_unique_radix.txt: ranks by ballots instead of LDS atomics that return a value — slower at 9-10 partition bits; whole 16-record
+// units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3.)
 __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
                                                              uint64_t* __restrict__ keys_out, uint32_t* __restrict__ rows_out, int xp) {
   extern __shared__ uint64_t part_sh[];
   const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x;
-  constexpr int NWV = kRBlock / 64;
-  static_assert(NWV == 16, "the (partition, wave) scan shifts by 4");
   uint64_t* skey = part_sh;                                   // [kRTile]
   uint64_t* cursor = skey + kRTile;                           // [P]   where the chunk's next record of partition p goes
-  uint32_t* srow = (uint32_t*)(cursor + P);                   // [kRTile]
-  uint32_t* lstart = srow + kRTile;                           // [P]   first slot of the tile's run of partition p in skey / srow
+  uint32_t* srow = (uint32_t*)(cursor + P);                   // [kRTile]  partition << 13 | row's offset inside the tile (the partition is not hashed again on the way out)
+  uint32_t* hist2 = srow + kRTile;                            // [P]   this tile's records per partition
+  uint32_t* lstart = hist2 + P;                               // [P]   their first slot in skey / srow
   uint32_t* wsum = lstart + P;                                // [16]  scan scratch: one total per wave
-  uint16_t* wcount = (uint16_t*)(wsum + 16);                  // [NWV][P]  records of partition p this tile, per wave (wave-major: a wave's lanes, each with its own
-                                                              //           partition, then spread over the LDS banks); after the scan: that wave's first slot of the partition's run
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int p = tid; p < P; p += kRBlock) cursor[p] = offsets_T[(size_t)p * C + c];
-  for (int i = tid; i < P * NWV; i += kRBlock) wcount[i] = 0;
+  for (int p = tid; p < P; p += kRBlock) { cursor[p] = offsets_T[(size_t)p * C + c]; hist2[p] = 0; }
   __syncthreads();
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   RadixRow nx[8];                                             // the NEXT tile's rows: loaded while this tile is sorted and written
 #pragma unroll
   for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, r0 + j * kRBlock + tid, r1);
   for (int64_t base = r0; base < r1; base += kRTile) {
-    // 1. keys, partitions, and every record's rank among its WAVE's records of the same partition — by ballots, not by LDS atomics that return a value
-    //    (one such atomic per record took 3.8 ms of the pass's 7.0 per 1e9 rows): the lanes that share a partition are the AND over the partition's bits of
-    //    {ballot(bit) or its complement}; the lowest of them adds the group's size to the wave's count of that partition (a plain read-modify-write: the
-    //    wave owns wcount[p][wave], and its eight rounds run one after the other)
-    uint64_t key[8]; uint32_t pr[8];                          // pr: partition << 13 | rank inside the wave's run, ~0 = no record
+    // 1. keys, partitions, rank inside the tile's partition (an LDS atomic that returns a value: 0.8 ms of the pass per 1e9 rows)
+    uint64_t key[8]; uint32_t pr[8];                          // pr: partition << 13 | rank  (rank < 8192), ~0 = no record
+    bool tk[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int64_t row = base + j * kRBlock + tid;
-      const bool take = radix_take<false>(nx[j], dtype, row, r1, nullptr);
+      tk[j] = radix_take<false>(nx[j], dtype, base + j * kRBlock + tid, r1, nullptr);
       key[j] = nx[j].key;
-      const uint32_t p = take ? (uint32_t)(splitmix64(key[j]) >> (64 - kbits)) : 0u;
-      uint64_t peers = __ballot(take);
+    }
 #pragma unroll
-      for (int b = 0; b < 10; b++) {                           // (kbits <= 10 here; the bits above a partition number are zero in every lane: their round changes nothing)
-        if (b >= kbits) break;
-        const uint64_t m = __ballot((p >> b) & 1u); peers &= ((p >> b) & 1u) ? m : ~m;
-      }
+    for (int j = 0; j < 8; j++) {
       pr[j] = ~0u;
-      if (take) {
-        const uint32_t below = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
-        const uint32_t sofar = wcount[wv * P + p];          // (every peer reads the same word before the lowest one updates it: the update is below, after this read)
-        pr[j] = p << 13 | (sofar + below);
-        if (below == 0) wcount[wv * P + p] = (uint16_t)(sofar + (uint32_t)__builtin_popcountll(peers));
+      if (tk[j]) {
+        const uint32_t p = rhash(key[j]) >> (32 - kbits);
+        pr[j] = p << 13 | ((xp & 2) ? (uint32_t)(j * kRBlock + tid) / (uint32_t)P : atomicAdd(&hist2[p], 1u));     // (DFDB_RADIX_XP bit 1, timing only: no rank atomics — and with them no stores)
       }
-      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, base + kRTile + j * kRBlock + tid, r1);
     __syncthreads();
-    // 2. exclusive scan over (partition, wave): wcount becomes each wave's first slot of each partition's run; lstart[p] = the run's first slot
-    {
-      const int per = (P * NWV) / kRBlock;                    // entries per thread (P >= 64: a whole number; at most 32)
-      // (logical entry e = p * NWV + w, partition-major: that is the order of the slots; it lives at wcount[w * P + p])
-      uint32_t sum = 0;
-      for (int i = 0; i < per; i++) { const int e = tid * per + i; sum += wcount[(e & (NWV - 1)) * P + (e >> 4)]; }
-      uint32_t incl = sum;
+    // 2. exclusive scan of hist2 over the partitions (P <= 2048: at most two per thread)
+    uint32_t h0 = tid < P ? hist2[tid] : 0u, h1 = tid + kRBlock < P ? hist2[tid + kRBlock] : 0u;
+    uint32_t mine = h0 + h1, incl = mine;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-      if (lane == 63) wsum[wv] = incl;
-      __syncthreads();
-      uint32_t run = incl - sum;
-      for (int w = 0; w < wv; w++) run += wsum[w];
-      for (int i = 0; i < per; i++) {
-        const int e = tid * per + i, at = (e & (NWV - 1)) * P + (e >> 4);
-        const uint32_t cnt = wcount[at];
-        if ((e & (NWV - 1)) == 0) lstart[e >> 4] = run;
-        wcount[at] = (uint16_t)run;
-        run += cnt;
-      }
-    }
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    // 3. the tile's records into LDS, sorted by partition (and by wave inside a partition)
+    uint32_t before = 0;
+    for (int w = 0; w < wv; w++) before += wsum[w];
+    // (thread t scans partitions t and t + 1024 as one element: their slots are adjacent, t's first)
+    const uint32_t ex = before + incl - mine;
+    if (tid < P) lstart[tid] = ex;
+    if (tid + kRBlock < P) lstart[tid + kRBlock] = ex + h0;
+    __syncthreads();
+    // 3. the tile's records into LDS, sorted by partition
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (pr[j] == ~0u) continue;
-      const uint32_t p = pr[j] >> 13, slot = (uint32_t)wcount[wv * P + p] + (pr[j] & 8191u);
+      const uint32_t p = pr[j] >> 13, slot = lstart[p] + (pr[j] & 8191u);
       skey[slot] = key[j];
-      srow[slot] = (uint32_t)(base + j * kRBlock + tid);
+      srow[slot] = p << 13 | (uint32_t)(j * kRBlock + tid);
     }
     __syncthreads();
-    // 4. out: slot s belongs to the partition of its key; its place is the partition's cursor + its rank in the tile's run
+    // 4. out: slot s's place is its partition's cursor + its rank in the tile's run
     uint32_t total = 0;
-    for (int w = 0; w < NWV; w++) total += wsum[w];
+    for (int w = 0; w < kRBlock / 64; w++) total += wsum[w];
     for (uint32_t s = (uint32_t)tid; s < total; s += kRBlock) {
       const uint64_t k = skey[s];
-      const uint32_t p = (uint32_t)(splitmix64(k) >> (64 - kbits));
+      const uint32_t pw = srow[s], p = pw >> 13;
       const uint64_t dst = cursor[p] + (s - lstart[p]);
       if (xp & 4) { if (k == 12345ull) keys_out[dst] = k; continue; }                 // (DFDB_RADIX_XP bit 2, timing only: no stores)
       keys_out[dst] = k;
-      rows_out[dst] = srow[s];
+      rows_out[dst] = (uint32_t)base + (pw & 8191u);
     }
     __syncthreads();
-    // 5. the cursors move on by the partitions' runs (run length = next run's start - this one's; the last run ends at `total`), the counts start over
-    for (int p = tid; p < P; p += kRBlock) cursor[p] += (p + 1 < P ? lstart[p + 1] : total) - lstart[p];
-    for (int i = tid; i < P * NWV; i += kRBlock) wcount[i] = 0;
+    // 5. the cursors move on
+    for (int p = tid; p < P; p += kRBlock) { cursor[p] += hist2[p]; hist2[p] = 0; }
     __syncthreads();
   }
 }
@@ -214,7 +200,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint64_t* __rest
 #pragma unroll
       for (int j = 0; j < 4; j++) { const uint64_t i = i0 + (uint64_t)j * kRBlock + threadIdx.x; kk[j] = i < b ? keys[i] : kREmpty; rw[j] = i < b ? rows[i] : 0u; }
 #pragma unroll
-      for (int j = 0; j < 4; j++) hh[j] = (uint32_t)(splitmix64(kk[j]) & (kRSlots - 1));                 // (the partition is the hash's TOP bits)
+      for (int j = 0; j < 4; j++) hh[j] = rhash(kk[j]) & (uint32_t)(kRSlots - 1);                        // (the partition is the hash's TOP bits)
       // every lane walks ITS four records at its own pace: one probe per trip, the next record as soon as this one is placed — a wave waits for the lane
       // with the most probes over four records, not for the slowest lane of every record (linear probing at 25-50 % load has a long tail)
       int j = 0; uint32_t probes = 0;
@@ -260,7 +246,7 @@ int64_t radix_rows_per_chunk(int64_t nrows, int chunks) {
   return (per + kRTile - 1) / kRTile * kRTile;              // whole tiles of the partition pass (and whole bitmap words)
 }
 static int radix_xp() { static const int v = [] { const char* e = getenv("DFDB_RADIX_XP"); return e ? atoi(e) : 0; }(); return v; }   // timing experiments only: results are WRONG with any bit set
-size_t radix_partition_lds_bytes(int kbits) { const size_t P = (size_t)1 << kbits; return (size_t)kRTile * 12 + P * (8 + 4 + 2 * (kRBlock / 64)) + 64 + 64; }
+size_t radix_partition_lds_bytes(int kbits) { const size_t P = (size_t)1 << kbits; return (size_t)kRTile * 12 + P * 16 + 64 + 64; }
 
 bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                        uint32_t* counts_T, uint64_t* aux) {

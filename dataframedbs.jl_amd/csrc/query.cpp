@@ -1333,10 +1333,10 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // its table): the caller goes on with the hash table; the selection is as it was.
 static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  // MEASURED, 1e9 Int64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.4 + partition 9.8 + unique 3.8 ms = 18.4 ms end to end against the hash
-  // table's 20.0 — 8 % for 12 GB of scratch, not the 2 x the streams' byte count promised: the partition pass is not bandwidth-bound (3.4e9 vector instructions,
-  // 47 % of its wave cycles waiting at its five barriers with one 110-KB workgroup per CU).  So the form is built, tested and OFF by default (option = 1 turns it on).
-  const int64_t mode = ctx_option(ctx, "unique_radix", 0);
+  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.1 + partition 7.3 + unique 3.6 ms = 15.5 ms end to end against the
+  // hash table's 20.0 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass is bound by its STORES (5 of its
+  // 7.3 ms: 16-record runs that start wherever the previous tile's ended: partial 128-byte lines), not by its rank atomics (0.8 ms).  On by default; option = 0: the hash table.
+  const int64_t mode = ctx_option(ctx, "unique_radix", 1);
   if (mode == 0 || t->nrows > (1ll << 32) || r0 == 0 || d0 == 0) return false;
   if (mode < 2 && cnt < (32ll << 20)) return false;                      // (2: a test knob — any size)
   double D = (double)cnt;
@@ -1347,7 +1347,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   }
   if (mode < 2 && D < 131072.0) return false;                            // the hash table stays in the L2s: nothing to gain
   int kbits = 8;
-  while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;   // (fewer partitions = longer runs per 8192-row tile of the partition pass; more = emptier tables in the unique pass, whose linear probing has a long tail: 1e6 values -> 512; the partition pass's LDS holds at most 1024)
+  while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;       // (fewer partitions = longer runs per tile of the partition pass; more = emptier tables in the unique pass: 1e6 values -> 512)
   if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
   const int P = 1 << kbits;
   const int C = 4 * std::max(1, ctx->prop.multiProcessorCount);         // chunks = workgroups of the hist and partition passes
@@ -1383,7 +1383,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
                              T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
   uint64_t aborted = 0;
   if (ok) { HIP_CHECK(hipMemcpyAsync(&aborted, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
-  if (!ok || aborted || ctx_option(ctx, "unique_radix", 0) == 3) {        // (3: a test knob — behave as if a partition had overflowed)
+  if (!ok || aborted || ctx_option(ctx, "unique_radix", 1) == 3) {        // (3: a test knob — behave as if a partition had overflowed)
     HIP_CHECK(hipMemcpyAsync(q->bitmap.p, sel_keep.p, nw * 8, hipMemcpyDeviceToDevice, s));
     HIP_CHECK(hipMemcpyAsync(q->tile_counts.p, tc_keep.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
     HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));

@@ -163,10 +163,11 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "lz4_enc_near"     > 0: the writer's compressor gives up a match whose source lies further back than this many bytes when a nearer one ends as late — K7 then copies
  *                      out of its on-chip history instead of fetching a line (at 1984, K7's reach: ratio - 8 %, indexed decode + 3 %; default 0: file bytes are what
  *                      the cold path waits for)
- *   "unique_radix"     1 = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s takes the radix-partitioned form (k_radix.hip: every selected
- *                      row written once as a {key, row} record into one of 256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per
- *                      selected row, kept by the context).  Default 0: measured 18.4 ms against the hash table's 20.0 per 1e9 rows of 1e6 values
- *                      (profiles/r6_unique_radix.txt), which does not pay for the scratch
+ *   "unique_radix"     1 (default) = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s (an estimated 131 072 .. ~5 M distinct values among
+ *                      at least 32 M selected rows) takes the radix-partitioned form (k_radix.hip: every selected row written once as a {key, row} record into one of
+ *                      256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per selected row, kept by the context; no room for it, or a
+ *                      partition that outgrows its table: the hash table answers).  15.5 ms against the hash table's 20.0 per 1e9 rows of 1e6 values
+ *                      (profiles/r6_unique_radix.txt).  0 = always the hash table
  *   "jit"              1 (default) = an expression the device INTERPRETER evaluates (outside `col OP const` terms, pairs and string matches: configs 2-5 never get here)
  *                      over at least 4 M rows is also compiled by hipRTC in the background — the interpreter's own source specialised for the program's shape — and later
  *                      executions run the compiled kernel; until it is ready, or when libhiprtc is absent, the interpreter answers.  0 = interpret always; 2 = wait for

@@ -43,7 +43,7 @@ def run_unique(dfdb, t, view, radix):
     finally:
         t.ctx.profile(False)
         t.ctx.set_option("unique_dense", 1)
-        t.ctx.set_option("unique_radix", 0)
+        t.ctx.set_option("unique_radix", 1)
     return rows, taken, fell
 
 
@@ -82,7 +82,7 @@ def test_radix_unique_is_first_appearance(dfdb_mod, ctx, kind):
         try:
             vals = t.k.unique()
         finally:
-            ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 0)
+            ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 1)
         want_rows = first_rows(img, np.ones(n, bool))
         if kind == "nullable":
             gm = np.ma.getmaskarray(vals)

@@ -11,6 +11,7 @@ ctx = dfdb.default_context(0)
 t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
 t.add_generated("x", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15, n)
 ctx.set_option("unique_dense", 0)
+ctx.set_option("unique_radix", 1)
 for rep in range(2):
     ctx.profile(True)
     try:
