@@ -742,8 +742,17 @@ def f_rows_legs(L, dfdb, sc, rank):
     finally:
         ctx.set_option("unique_dense", 1)
     res["unique_hash_table"] = {"rows": n, "distinct": len(u), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
-                                "what": "the same unique with ctx option unique_dense = 0: open-addressing table of {key, first row} sized by the distinct values as they turn up (what Float64 keys, "
-                                        "wide-ranged integers and String hashes take); best of 2"}
+                                "what": "the same unique with ctx option unique_dense = 0: the GENERAL form (what Float64 keys and wide-ranged integers take).  Round 6: for 131 K .. ~5 M distinct "
+                                        "values it partitions the {key, row} records by radix and reduces each partition through a table in LDS (k_radix.hip); `hash_table_only_seconds` is the "
+                                        "open-addressing table of {key, first row} in HBM it replaces there (ctx option unique_radix = 0); best of 2"}
+    ctx.set_option("unique_dense", 0); ctx.set_option("unique_radix", 0)
+    try:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        uh = t.x.unique()
+        res["unique_hash_table"]["hash_table_only_seconds"] = time.perf_counter() - t0
+        res["unique_hash_table"]["hash_table_only_distinct"] = len(uh)
+    finally:
+        ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 1)
     # ---- unique over a Float64 key (x * 0.5, made on the device: 1e6 distinct values): floats always take the hash table
     t.add_column_from("f", t.x * 0.5)
     best = None
@@ -753,7 +762,7 @@ def f_rows_legs(L, dfdb, sc, rank):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     res["unique_float_key"] = {"rows": n, "distinct": len(uf), "seconds": best, "rows_per_s": n / best, "roofline": {"bound": "hbm", "achieved": n * 8 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 8 / best / 1e9 / L.peak},
-                               "what": "unique(t.f), f = x * 0.5 (Float64, 1e6 distinct values): the hash table of isequal images; best of 2"}
+                               "what": "unique(t.f), f = x * 0.5 (Float64, 1e6 distinct values): isequal images through the general form (radix partition + LDS tables since round 6); best of 2"}
     # ---- groupreduce by a Float64 key of 5000 values ((x mod 5000) * 0.5, made on the device) over the same 1e9 rows: floats always take the hash table
     t.add_column_from("fk", (t.x % 5000) * 0.5)
     best, g = None, None
