@@ -367,3 +367,77 @@ def test_julia_shim_routing_transcription(pair, dfdb_mod):
         assert not any(t.resident(i) for i in range(t.ncols)), "the retry streamed: nothing became resident"
     finally:
         t.close()
+
+
+def test_errors_surface_through_the_ordinary_entry_points_and_leave_the_handles_usable(oracle, dfdb_mod, tmp_path):
+    """The reference's errors met while iterating blocks — DivideError inside a predicate, "decompression error" (BlockStreams.jl:112) — come out of dfdb_count /
+    dfdb_materialize / dfdb_aggregate / dfdb_query_unique over a table that is not resident exactly as they do out of the explicit stream; the internal stream is
+    closed (parked) behind the failure, and the same context answers the next query, streamed again."""
+    import struct
+    import dfdb._native as N
+    n, bs = 40_000, 4096
+    t = oracle.Table(block_size=bs)
+    t.add_column("a", np.arange(1, n + 1, dtype=np.int64))
+    t.add_column("z", (np.arange(n) < 30_000).astype(np.int64))       # zeros from row 30 001 on
+    path = str(tmp_path / "tb")
+    t.save(path)
+    tb = dfdb_mod.open_table(path, load=False)
+    tb.ctx.set_option("ooc_chunk_blocks", 2)
+    try:
+        bad = tb[(tb.a % tb.z) == 0, ["a"]]
+        for call in (lambda q: q.count(), lambda q: q.indices(), lambda q: q.materialize(), lambda q: q.aggregate(N.AGG_SUM, 0),
+                     lambda q: N.check(N.load().dfdb_query_unique(q._h, 0))):
+            with pytest.raises(ZeroDivisionError):
+                call(dfdb_mod.api._Query(bad))
+        # rows before the first zero divisor only: no error, and the answer is the oracle's arithmetic
+        ok = tb[dfdb_mod.jr(1, 30_000), ["a", "z"]]
+        ok2 = dfdb_mod.selection(ok, (ok.a % ok.z) == 0)
+        assert dfdb_mod.api._Query(ok2).count() == 30_000             # a % 1 == 0 everywhere there
+        # a corrupt LZ4 payload in block 5 of column a
+        f = tmp_path / "tb" / "1.bin"
+        raw = bytearray(f.read_bytes())
+        pos = 8 + 4 + len("Int64")
+        for _ in range(5):
+            rows, origin, comp = struct.unpack_from("<iqq", raw, pos)
+            pos += 20 + comp
+        raw[pos + 20: pos + 24] = b"\xff\xff\xff\xff"
+        f.write_bytes(bytes(raw))
+        tb2 = dfdb_mod.open_table(path, load=False)
+        try:
+            for call in (lambda q: q.count(), lambda q: q.materialize(), lambda q: q.aggregate(N.AGG_MAX, 0)):
+                with pytest.raises(dfdb_mod.DfdbError, match="decompression error"):
+                    call(dfdb_mod.api._Query(tb2[dfdb_mod.ALL, ["a"]]))
+            # column z is intact: a view that needs only z is answered (only the required columns are ever read)
+            assert dfdb_mod.api._Query(tb2[("z", lambda z: z == 0), ["z"]]).count() == 10_000
+            # a leading range that ends before the damaged block never reads it (skip_if_can / is_finished, selection.jl:177-196)
+            early = tb2[dfdb_mod.jr(1, 4 * bs), ["a"]]
+            assert np.array_equal(dfdb_mod.api._Query(early).materialize()[0], np.arange(1, 4 * bs + 1))
+        finally:
+            tb2.close()
+    finally:
+        tb.close()
+
+
+def test_empty_and_tiny_tables_out_of_core(oracle, dfdb_mod, tmp_path):
+    """zero rows, one row, one short block: the streamed entry points agree with the resident ones"""
+    import dfdb._native as N
+    for n in (0, 1, 999):
+        t = oracle.Table(block_size=1000)
+        t.add_column("a", np.arange(n, dtype=np.int64) * 3)
+        t.add_column("s", ["s%d" % (i % 5) for i in range(n)])
+        path = str(tmp_path / ("t%d" % n))
+        t.save(path)
+        lazy, res = dfdb_mod.open_table(path, load=False), dfdb_mod.open_table(path)
+        try:
+            for tb in (lazy, res):
+                v = tb[("a", lambda c: c % 2 == 0), dfdb_mod.ALL]
+                q = dfdb_mod.api._Query(v)
+                want = (np.arange(n) * 3) % 2 == 0
+                assert q.count() == int(want.sum()) and np.array_equal(q.indices(), np.flatnonzero(want) + 1)
+                got = q.materialize()
+                assert np.array_equal(got[0], (np.arange(n) * 3)[want])
+                assert dfdb_mod.api._Query(v).aggregate(N.AGG_SUM, 0) == int((np.arange(n) * 3)[want].sum())
+                assert list(tb.s.unique()) == ["s%d" % i for i in range(min(n, 5))]
+            assert not lazy.resident(0)
+        finally:
+            lazy.close(); res.close()
