@@ -861,16 +861,21 @@ int32_t dfdb_group_query_prepare(dfdb_gquery* gq, int32_t* how) {
     const int64_t share = ceil_div(dec + comp_max, (int64_t)g->world) + (64 << 20);
     if (share <= budget - held) {
       std::vector<dfdb_sizestats> st((size_t)g->nlocal(), dfdb_sizestats{0, 0, 0});
-      for_shards(g, [&](int l) {
-        int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
-        dfdb_table* t = gt->shard[(size_t)l];
-        table_load(t, need.data(), (int32_t)need.size(), b0, b1, &st[(size_t)l]);
-        t->row_base = b0 * t0->block_size;
-      });
+      bool nomem = false;
+      try {
+        for_shards(g, [&](int l) {
+          int64_t b0, b1; block_range(nblocks, g->first_rank + l, g->world, b0, b1);
+          dfdb_table* t = gt->shard[(size_t)l];
+          table_load(t, need.data(), (int32_t)need.size(), b0, b1, &st[(size_t)l]);
+          t->row_base = b0 * t0->block_size;
+        });
+      } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; nomem = true; }
       gt->total_rows = hs.rows;
+      if (!nomem) { gtable_changed(gt); if (how) *how = 1; return; }
+      // HBM ran out inside a load after all (other tables, fragmentation): the view's columns leave every local shard again and the shards stream.  (Ranks of other
+      // processes may have loaded theirs: every shard answers for itself, from HBM or from its files, and the exchanges are the same either way.)
+      for_shards(g, [&](int l) { (void)hipGetLastError(); rethrow_rc(dfdb_table_unload(gt->shard[(size_t)l], need.data(), (int32_t)need.size())); });
       gtable_changed(gt);
-      if (how) *how = 1;
-      return;
     }
     if (how) *how = 3;                                     // (the shards' block windows were set when the table was opened)
   });
