@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
       const uint64_t dst = cursor[p] + (s - lstart[p]);
       if (xp & 4) { if (k == 12345ull) keys_out[dst] = k; continue; }                 // (DFDB_RADIX_XP bit 2, timing only: no stores)
       keys_out[dst] = k;
-      rows_out[dst] = (uint32_t)base + (pw & 8191u);
+      if (!(xp & 16)) rows_out[dst] = (uint32_t)base + (pw & 8191u);                   // (DFDB_RADIX_XP bit 4, timing only: keys without their rows)
     }
     __syncthreads();
     // 5. the cursors move on
