@@ -104,31 +104,33 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 // ---- pass 2: the records of chunk c, sorted by partition 8192 rows at a time, to their places
 // (Tried and dropped, profiles/r6_unique_radix.txt: ranks by ballots instead of LDS atomics that return a value — slower at 9-10 partition bits; whole 16-record
 // units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3.)
-__global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
                                                              uint64_t* __restrict__ keys_out, uint32_t* __restrict__ rows_out, int xp) {
   extern __shared__ uint64_t part_sh[];
+  constexpr int TILE = 8 * BLOCK;                            // rows sorted at a time (8 per thread)
   const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x;
-  uint64_t* skey = part_sh;                                   // [kRTile]
-  uint64_t* cursor = skey + kRTile;                           // [P]   where the chunk's next record of partition p goes
-  uint32_t* srow = (uint32_t*)(cursor + P);                   // [kRTile]  partition << 13 | row's offset inside the tile (the partition is not hashed again on the way out)
-  uint32_t* hist2 = srow + kRTile;                            // [P]   this tile's records per partition
+  uint64_t* skey = part_sh;                                   // [TILE]
+  uint64_t* cursor = skey + TILE;                           // [P]   where the chunk's next record of partition p goes
+  uint32_t* srow = (uint32_t*)(cursor + P);                   // [TILE]  partition << 13 | row's offset inside the tile (the partition is not hashed again on the way out)
+  uint32_t* hist2 = srow + TILE;                            // [P]   this tile's records per partition
   uint32_t* lstart = hist2 + P;                               // [P]   their first slot in skey / srow
   uint32_t* wsum = lstart + P;                                // [16]  scan scratch: one total per wave
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int p = tid; p < P; p += kRBlock) { cursor[p] = offsets_T[(size_t)p * C + c]; hist2[p] = 0; }
+  for (int p = tid; p < P; p += BLOCK) { cursor[p] = offsets_T[(size_t)p * C + c]; hist2[p] = 0; }
   __syncthreads();
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   RadixRow nx[8];                                             // the NEXT tile's rows: loaded while this tile is sorted and written
 #pragma unroll
-  for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, r0 + j * kRBlock + tid, r1);
-  for (int64_t base = r0; base < r1; base += kRTile) {
+  for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, r0 + j * BLOCK + tid, r1);
+  for (int64_t base = r0; base < r1; base += TILE) {
     // 1. keys, partitions, rank inside the tile's partition (an LDS atomic that returns a value: 0.8 ms of the pass per 1e9 rows)
     uint64_t key[8]; uint32_t pr[8];                          // pr: partition << 13 | rank  (rank < 8192), ~0 = no record
     bool tk[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      tk[j] = radix_take<false>(nx[j], dtype, base + j * kRBlock + tid, r1, nullptr);
+      tk[j] = radix_take<false>(nx[j], dtype, base + j * BLOCK + tid, r1, nullptr);
       key[j] = nx[j].key;
     }
 #pragma unroll
@@ -136,14 +138,14 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
       pr[j] = ~0u;
       if (tk[j]) {
         const uint32_t p = rhash(key[j]) >> (32 - kbits);
-        pr[j] = p << 13 | ((xp & 2) ? (uint32_t)(j * kRBlock + tid) / (uint32_t)P : atomicAdd(&hist2[p], 1u));     // (DFDB_RADIX_XP bit 1, timing only: no rank atomics — and with them no stores)
+        pr[j] = p << 13 | ((xp & 2) ? (uint32_t)(j * BLOCK + tid) / (uint32_t)P : atomicAdd(&hist2[p], 1u));     // (DFDB_RADIX_XP bit 1, timing only: no rank atomics — and with them no stores)
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, base + kRTile + j * kRBlock + tid, r1);
+    for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, base + TILE + j * BLOCK + tid, r1);
     __syncthreads();
     // 2. exclusive scan of hist2 over the partitions (P <= 2048: at most two per thread)
-    uint32_t h0 = tid < P ? hist2[tid] : 0u, h1 = tid + kRBlock < P ? hist2[tid + kRBlock] : 0u;
+    uint32_t h0 = tid < P ? hist2[tid] : 0u, h1 = tid + BLOCK < P ? hist2[tid + BLOCK] : 0u;
     uint32_t mine = h0 + h1, incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     // (thread t scans partitions t and t + 1024 as one element: their slots are adjacent, t's first)
     const uint32_t ex = before + incl - mine;
     if (tid < P) lstart[tid] = ex;
-    if (tid + kRBlock < P) lstart[tid + kRBlock] = ex + h0;
+    if (tid + BLOCK < P) lstart[tid + BLOCK] = ex + h0;
     __syncthreads();
     // 3. the tile's records into LDS, sorted by partition
 #pragma unroll
@@ -162,13 +164,13 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
       if (pr[j] == ~0u) continue;
       const uint32_t p = pr[j] >> 13, slot = lstart[p] + (pr[j] & 8191u);
       skey[slot] = key[j];
-      srow[slot] = p << 13 | (uint32_t)(j * kRBlock + tid);
+      srow[slot] = p << 13 | (uint32_t)(j * BLOCK + tid);
     }
     __syncthreads();
     // 4. out: slot s's place is its partition's cursor + its rank in the tile's run
     uint32_t total = 0;
-    for (int w = 0; w < kRBlock / 64; w++) total += wsum[w];
-    for (uint32_t s = (uint32_t)tid; s < total; s += kRBlock) {
+    for (int w = 0; w < BLOCK / 64; w++) total += wsum[w];
+    for (uint32_t s = (uint32_t)tid; s < total; s += BLOCK) {
       const uint64_t k = skey[s];
       const uint32_t pw = srow[s], p = pw >> 13;
       const uint64_t dst = cursor[p] + (s - lstart[p]);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     }
     __syncthreads();
     // 5. the cursors move on
-    for (int p = tid; p < P; p += kRBlock) { cursor[p] += hist2[p]; hist2[p] = 0; }
+    for (int p = tid; p < P; p += BLOCK) { cursor[p] += hist2[p]; hist2[p] = 0; }
     __syncthreads();
   }
 }
@@ -256,10 +258,16 @@ bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int 
 }
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                             const uint64_t* offsets_T, uint64_t* keys_out, uint32_t* rows_out) {
-  const size_t lds = radix_partition_lds_bytes(kbits);
-  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
-  if (!ok || lds > 156 * 1024) { (void)hipGetLastError(); return false; }
-  hipLaunchKernelGGL(k_radix_partition, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, radix_rows_per_chunk(nrows, chunks), kbits, offsets_T, keys_out, rows_out, radix_xp());
+  // DFDB_RADIX_BLOCK (an A/B switch, read once): 1024-thread workgroups sorting 8192 rows at a time, one per CU (default), or 512-thread ones sorting 4096, two per CU
+  static const int block = [] { const char* e = getenv("DFDB_RADIX_BLOCK"); return e && atoi(e) == 512 ? 512 : 1024; }();
+  const size_t P = (size_t)1 << kbits;
+  const size_t lds = (size_t)(8 * block) * 12 + P * 16 + 64 + 64;
+  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+                               hipFuncSetAttribute((const void*)k_radix_partition<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
+  if (!ok || lds > 156 * 1024 || P > (size_t)2 * block) { (void)hipGetLastError(); return false; }
+  const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
+  if (block == 512) hipLaunchKernelGGL(k_radix_partition<512>, dim3(chunks), dim3(512), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, keys_out, rows_out, radix_xp());
+  else hipLaunchKernelGGL(k_radix_partition<1024>, dim3(chunks), dim3(1024), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, keys_out, rows_out, radix_xp());
   return true;
 }
 bool launch_radix_unique(hipStream_t s, const uint64_t* keys, const uint32_t* rows, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,

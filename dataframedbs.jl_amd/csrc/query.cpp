@@ -1348,6 +1348,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   if (mode < 2 && D < 131072.0) return false;                            // the hash table stays in the L2s: nothing to gain
   int kbits = 8;
   while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;       // (fewer partitions = longer runs per tile of the partition pass; more = emptier tables in the unique pass: 1e6 values -> 512)
+  if (const char* e = getenv("DFDB_RADIX_KBITS")) kbits = std::min(10, std::max(6, atoi(e)));      // (an A/B switch for measurements)
   if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
   const int P = 1 << kbits;
   const int C = 4 * std::max(1, ctx->prop.multiProcessorCount);         // chunks = workgroups of the hist and partition passes
