@@ -356,6 +356,19 @@ void ooc_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
   stream_materialize(q, &tq.q, outs, ncols, o.count);
 }
 
+void ooc_materialize_column(dfdb_query* q, int32_t p, dfdb_outcol* o) {
+  if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
+  OocState& st = state(q);
+  TempQuery tq(q, !st.narrowed);
+  if (st.narrowed) narrowed_view(q, tq);
+  tq.project(q->proj[(size_t)p]);
+  const int64_t cap = st.narrowed ? st.merged.ng : st.count;
+  // (stream_materialize keeps what it learns under the projection index of the query it streams: a one-column pass must not overwrite column 0's string bytes)
+  const std::vector<int64_t> keep = st.str_bytes;
+  stream_materialize(q, &tq.q, o, 1, cap);
+  state(q).str_bytes = keep;
+}
+
 // ------------------------------------------------------------------ aggregates
 void ooc_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, double* out_f) {
   if (op == DFDB_AGG_COUNT) { const int64_t n = ooc_count(q); if (out_i) *out_i = n; if (out_f) *out_f = (double)n; return; }

@@ -67,6 +67,8 @@ void ooc_unique(dfdb_query* q, int32_t p);
 void ooc_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, int64_t* ngroups, int64_t* key_bytes);
 void ooc_groupreduce_fetch(dfdb_query* q, dfdb_outcol* keys, int64_t* counts, int64_t* vals_i, double* vals_f);
 void ooc_reset(dfdb_query* q);
+// projection column p alone into ONE caller buffer (dfdb_table_add_from_query over a view whose columns are not resident)
+void ooc_materialize_column(dfdb_query* q, int32_t p, dfdb_outcol* o);
 // what a multi-GPU group asks of a shard whose columns are not resident (group.cpp): the shard streams its own block window (dfdb_table::win_first / win_last)
 int64_t ooc_count_prefix(dfdb_query* q, int nstages);
 int ooc_aggregate_bits(dfdb_query* q, int32_t op, int32_t i, uint64_t out[2]);

@@ -11,6 +11,7 @@
 // an exclusive scan of per-tile popcounts.  The selection is evaluated once (no count pre-pass, quirk Q8):
 // dfdb_count reads the scan total, dfdb_materialize reuses the same bitmap.
 #include "engine.hpp"
+#include "ooc.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1098,12 +1099,13 @@ void query_materialize(dfdb_query* q, dfdb_outcol* outs, int32_t ncols) {
 // RESIDENT column of dst without leaving the device.  dst may be the view's own table (then every row must be selected).
 void launch_pack_flags(hipStream_t s, const uint8_t* flags, uint64_t* bits, int64_t n);
 void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int32_t p) {
-  ensure_executed_checked(q);
+  const bool ooc = query_out_of_core(q);      // the view's columns are not resident: the new column is made from the block stream (csrc/ooc.cpp), chunk by chunk
+  if (!ooc) ensure_executed_checked(q);
   if (p < 0 || (size_t)p >= q->proj.size()) fail(DFDB_ERR_BOUNDS, "BoundsError: projection column %d", p);
   if (dst->ctx != q->t->ctx) fail(DFDB_ERR_ARGUMENT, "the destination table lives on another context");
   for (auto& c : dst->cols) if (c.name == name) fail(DFDB_ERR_ARGUMENT, "ArgumentError: Duplicated column %s", name);
   const Node& e = *q->proj[(size_t)p].expr;
-  const int64_t cnt = query_count(q, -1);
+  const int64_t cnt = ooc ? ooc_count(q) : query_count(q, -1);
   if (dst->nrows >= 0 && dst->nrows != cnt)
     fail(DFDB_ERR_ARGUMENT, "ArgumentError: column has %lld rows but the table has %lld", (long long)cnt, (long long)dst->nrows);
   dfdb_ctx* ctx = dst->ctx; hipStream_t s = ctx->stream;
@@ -1113,7 +1115,7 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
   dfdb_outcol o{}; o.memkind = DFDB_MEM_DEVICE;
   DevBuf flags;
   if (dt_base(e.dtype) == DFDB_STRING) {
-    const int64_t total = query_string_bytes(q, p);
+    const int64_t total = ooc ? ooc_string_bytes(q, p) : query_string_bytes(q, p);
     c.data.ensure((size_t)cnt * 4 + 256);
     c.nbytes = total; c.bytes.ensure((size_t)total + 64);
     HIP_CHECK(hipMemsetAsync((char*)c.bytes.p + total, 0, 64, s));
@@ -1123,7 +1125,7 @@ void table_add_from_query(dfdb_table* dst, const char* name, dfdb_query* q, int3
     o.data = c.data.p;
     if (dt_nullable(e.dtype)) { flags.ensure((size_t)cnt + 64); HIP_CHECK(hipMemsetAsync(flags.p, 0, (size_t)cnt + 64, s)); o.missing = flags.as<uint8_t>(); }
   }
-  materialize_col(q, p, o, cnt);
+  if (ooc) ooc_materialize_column(q, p, &o); else materialize_col(q, p, o, cnt);
   if (dt_base(e.dtype) == DFDB_STRING) set_string_tile_offsets(ctx, c);
   else if (dt_nullable(e.dtype)) {
     const size_t nw = (size_t)(round_up(cnt > 0 ? cnt : 1, kCTileRows) / 64 + 64);

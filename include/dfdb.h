@@ -380,6 +380,8 @@ int32_t dfdb_aggregate(dfdb_query* q, int32_t op, int32_t i, int64_t* out_i, dou
  *                         dfdb_materialize = the projection at those rows (the key column straight out of the merge), until dfdb_query_reset
  *   dfdb_query_groupreduce  per-chunk groups merged by key in chunk order; counts and sums add, minimum / maximum fold (as dfdb_group_query_groupreduce)
  *   dfdb_select_bitmap    DFDB_ERR_UNSUPPORTED (the bitmap exists one chunk at a time: dfdb_stream_next)
+ *   dfdb_table_add_from_query  the new resident column is filled from the stream, chunk by chunk (add_column!(t, name, lazy_col) / create_table(path; from = view)
+ *                         over a view of a table that does not fit: table.jl:96-124, creators.jl:18-60)
  * dfdb_query_execute is a no-op there (nothing is left in HBM), dfdb_query_reset forgets what the passes learnt.
  *
  * dfdb_query_prepare(q, &how): "only the required columns are opened".  Brings the columns the view needs — and no others — into HBM when they fit

@@ -441,3 +441,30 @@ def test_empty_and_tiny_tables_out_of_core(oracle, dfdb_mod, tmp_path):
             assert not lazy.resident(0)
         finally:
             lazy.close(); res.close()
+
+
+def test_a_new_table_made_from_a_view_that_is_not_resident(pair, oracle, dfdb_mod, tmp_path):
+    """create_table(path; from = view) / add_column!(t, name, lazy_col) (creators.jl:18-60, table.jl:96-124) over a view whose columns are NOT resident:
+    dfdb_table_add_from_query fills the new resident columns from the block stream (plain, computed, String and nullable columns), the saved table reads back
+    through the oracle's reader as what numpy says."""
+    p = pair
+    p.d.ctx.set_option("ooc_chunk_blocks", 5)
+    a, x, s, m = p.cols["a"], p.cols["x"], p.cols["s"], p.cols["m"]
+    sel = a > 600_000
+    v = p.d[("a", lambda c: c > 600_000), dfdb_mod.ALL]
+    dst = dfdb_mod.DFTable.new(block_size=1000, ctx=p.d.ctx)
+    try:
+        dst.add_column_from("a", v.a)
+        dst.add_column_from("x2", v.x * 2.0)
+        dst.add_column_from("s", v.s)
+        dst.add_column_from("m", v.m)
+        assert not any(p.d.resident(i) for i in range(p.d.ncols))
+        out = str(tmp_path / "copy")
+        dst.save(out)
+        back = oracle.Table.open(out)
+        ba, bx2, bs, bm = back.view().materialize()
+        assert np.array_equal(ba, a[sel]) and np.array_equal(bx2, x[sel] * 2.0)
+        assert oracle.flat_to_strings(*bs) == [s[i] for i in np.flatnonzero(sel)]
+        assert np.array_equal(np.ma.getmaskarray(bm), np.ma.getmaskarray(m)[sel]) and np.array_equal(bm.compressed(), m[sel].compressed())
+    finally:
+        dst.close()
