@@ -1335,7 +1335,7 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // its table): the caller goes on with the hash table; the selection is as it was.
 static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.1 + partition 7.3 + unique 3.6 ms = 15.5 ms end to end against the
+  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.1 + partition 7.2 + unique 3.6 ms = 14.2 ms end to end against the
   // hash table's 20.0 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass is bound by its STORES (5 of its
   // 7.3 ms: 16-record runs that start wherever the previous tile's ended: partial 128-byte lines), not by its rank atomics (0.8 ms).  On by default; option = 0: the hash table.
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
@@ -1360,7 +1360,13 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   const size_t nw = padded_words(t->nrows);
   // the records' scratch (12 bytes per selected row) stays with the context between calls: hipMalloc / hipFree of 12 GB cost 3-4 ms of a 19-ms call (buffers
   // above 1 GB never enter the pool); dfdb_ctx_destroy, or ctx option "unique_radix_scratch" = 0 at a later call, releases it
-  DevBuf counts_T, offsets_T, scratch, sel_keep, tc_keep;
+  // (the call's temporaries go back to the buffer pool, not through hipFree — which drains the device and took ~1.5 ms of a 16-ms call for the 125-MB copy of the
+  // selection alone; the stream is drained first: nothing in flight may still touch them)
+  struct Temps {
+    dfdb_ctx* ctx; DevBuf counts_T, offsets_T, scratch, sel_keep, tc_keep;
+    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; counts_T.release(); offsets_T.release(); scratch.release(); sel_keep.release(); tc_keep.release(); }
+  } tmp{ctx, {}, {}, {}, {}, {}};
+  DevBuf &counts_T = tmp.counts_T, &offsets_T = tmp.offsets_T, &scratch = tmp.scratch, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
   DevBuf& keys = ctx->radix_keys; DevBuf& rows = ctx->radix_rows;
   try {
     counts_T.ensure((size_t)P * C * 4 + 64); offsets_T.ensure(((size_t)P * C + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes((int64_t)P * C));
