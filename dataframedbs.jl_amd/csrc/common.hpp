@@ -124,7 +124,7 @@ struct dfdb_ctx {
   int64_t* pinned_scalar = nullptr;          // 64 B of pinned host memory for small readbacks
   hipEvent_t sync_ev = nullptr;              // stream_wait()
   std::map<std::string, int64_t> options;    // dfdb_ctx_set_option
-  dfdb::DevBuf radix_keys, radix_rows;       // unique by radix partition (k_radix.hip): the {key, row} records' scratch, kept between calls
+  dfdb::DevBuf radix_recs;                   // unique by radix partition (k_radix.hip): the 12-byte {key image, row} records' scratch, kept between calls
   dfdb::DevBuf hist;                         // K7 HIST forms: a ticket word + one 64-KB history ring per resident wave (k_decode.hip), made on first use
   int hist_waves = 0;
   // two pinned bounce buffers for dfdb_table_load: the file is read piece by piece into one while the other is in flight to HBM

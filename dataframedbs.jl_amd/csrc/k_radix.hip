@@ -45,197 +45,307 @@ __device__ __forceinline__ uint64_t rkey_fixed(const void* col, int dtype, int64
     default: return ((const uint64_t*)col)[row];
   }
 }
-// A row takes part when it is selected, not missing and its image can be stored (the special rows go to aux, once, in the hist pass).  In two steps, so that
-// a thread can have several rows' loads in flight before it looks at any of them: `radix_load` issues the (unconditional) loads
-// of a row — its selection word, its missing word, its value —, `radix_take` decides.  (One row at a time — bitmap word, then the value, then the atomics — kept
-// ~8 KB in flight per CU: the hist pass read its 8 GB at 2.8 TB/s.)
-struct RadixRow { uint64_t selw, missw, key; };
-// (no control flow and no use of a loaded value in here: a branch around a row's loads, or the NaN select on its value, made the compiler wait for that row before it
-// issued the next one's — the hist pass read its 8 GB at 2.2 TB/s with or without its atomics.  A row past the end loads the last row again and is masked in radix_take.)
-__device__ __forceinline__ RadixRow radix_load(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
-                                               int64_t row, int64_t nrows) {
-  const int64_t rc = row < nrows ? row : nrows - 1;            // (nrows >= 1: the launchers never run over an empty table)
-  RadixRow r;
-  r.selw = sel[rc >> 6];
-  r.missw = missing ? missing[rc >> 6] : 0ull;
-  if (dtype == DFDB_I64 || dtype == DFDB_U64 || dtype == DFDB_F64) r.key = __builtin_nontemporal_load((const uint64_t*)col + rc);   // (wave-uniform: 8-byte keys, raw)
-  else r.key = rkey_fixed(col, dtype, rc);
-  return r;
+struct __attribute__((packed, aligned(4))) Rec12 { uint32_t lo, hi, row; };
+enum { kKindRaw8 = 0, kKindF64 = 1, kKindAny = 2 };       // what a key load is: 8 raw bytes (Int64 / UInt64), 8 bytes + isequal's one NaN (Float64), anything narrower (rkey_fixed)
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {     // a value every lane of the wave holds, into scalar registers
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
 }
-template <bool SPECIALS>
-__device__ __forceinline__ bool radix_take(RadixRow& r, int dtype, int64_t row, int64_t nrows, uint64_t* aux) {
-  if (dtype == DFDB_F64 && (r.key & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) r.key = 0x7ff8000000000000ull;      // isequal: one NaN
-  if (row >= nrows) return false;
-  if (!((r.selw >> (row & 63)) & 1ull)) return false;
-  if ((r.missw >> (row & 63)) & 1ull) {
-    if (SPECIALS && __atomic_load_n(&aux[1], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[1], (unsigned long long)row);
-    return false;
+__device__ __forceinline__ void aux_min(uint64_t* a, uint64_t row) {
+  if (__atomic_load_n(a, __ATOMIC_RELAXED) > row) atomicMin((unsigned long long*)a, (unsigned long long)row);
+}
+
+// ---- one 8192-row tile, as the hist and partition passes read it -----------------------------------------------------------------------------------------
+// Wave w of the 16 takes the tile's rows [512 w, 512 w + 512): EIGHT WHOLE WORDS of the selection (and of the missing bits) — wave-uniform, scalar loads —, and
+// lane l's j-th row is 512 w + 64 j + l: bit l of word j.  Who takes part is decided on the scalar unit (word & ~missing word, handed to the lanes as an execution
+// mask: __builtin_amdgcn_inverse_ballot_w64); the eight key loads of a lane are one address and eight immediate offsets.  The first form of these passes did the
+// same per row on the vector unit — a 64-bit row number, its clamp, the word's address, a 64-bit shift, per row — and ran at 46 (hist) / 215 (partition) vector
+// instructions per 64 rows: at 2.5-4.3 cycles per wave-instruction (tools/ubench/valu_rate.hip) that, not HBM, was what both passes waited for.
+// FULL = every row of the tile exists (base + 8192 <= nrows); the one partial tile of a table clamps its word and row numbers instead.
+// A row takes part when it is selected, not missing and its image can be stored; the special rows go to aux, once, in the hist pass (SPECIALS): a missing key's
+// smallest row to aux[1] here, the unstorable image's (all ones) to aux[0] where the keys are looked at.
+template <int KIND, bool FULL>
+__device__ __forceinline__ uint64_t tile_load(uint64_t (&key)[8], uint64_t (&in)[8], const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype,
+                                              const uint64_t* __restrict__ missing, int64_t base, int64_t nrows, int wv, int lane) {
+  const int64_t w0 = (base >> 6) + wv * 8;
+  uint64_t mw[8];
+  if (FULL) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) in[j] = sel[w0 + j];
+    if (missing) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) mw[j] = missing[w0 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) mw[j] = 0;
+    }
+  } else {
+    const int64_t wl = (nrows - 1) >> 6;                        // the last word that holds a row
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int64_t w = w0 + j, wc = w < wl ? w : wl;
+      uint64_t sw = sel[wc];
+      mw[j] = missing ? missing[wc] : 0ull;
+      if (w > wl) sw = 0; else if (w == wl && (nrows & 63)) sw &= (1ull << (nrows & 63)) - 1ull;
+      in[j] = sw;
+    }
   }
-  if (r.key == kREmpty) {
-    if (SPECIALS && __atomic_load_n(&aux[0], __ATOMIC_RELAXED) > (uint64_t)row) atomicMin((unsigned long long*)&aux[0], (unsigned long long)row);
-    return false;
+  const uint32_t lo = (uint32_t)(wv * 512 + lane);              // the lane's first row of the tile; a row past the table's end reads the last row again (its bit is clear)
+  const uint32_t last = FULL ? 8191u : (uint32_t)(nrows - 1 - base < 8191 ? nrows - 1 - base : 8191);
+  if (KIND != kKindAny) {
+    const uint64_t* kp = (const uint64_t*)col + base;           // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint32_t o = lo + (uint32_t)(j * 64); key[j] = __builtin_nontemporal_load(kp + (FULL || o < last ? o : last)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint32_t o = lo + (uint32_t)(j * 64); key[j] = rkey_fixed(col, dtype, base + (FULL || o < last ? o : last)); }
   }
-  return true;
+  uint64_t selected_missing = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint64_t sw = wave_uniform(in[j]), m = wave_uniform(mw[j]);
+    selected_missing |= sw & m;
+    in[j] = sw & ~m;
+  }
+  return selected_missing;                                      // (wave-uniform: nonzero = the hist pass looks for the tile's first missing row, tile_first_missing)
+}
+// the rare side of the hist pass: the smallest selected row of the wave's 512 whose key is missing, to aux[1]
+__device__ __forceinline__ void tile_first_missing(const uint64_t* __restrict__ sel, const uint64_t* __restrict__ missing, int64_t base, int64_t nrows, int wv, int lane, uint64_t* aux) {
+  const int64_t w0 = (base >> 6) + wv * 8, wl = (nrows - 1) >> 6;
+  for (int j = 0; j < 8; j++) {
+    const int64_t w = w0 + j;
+    if (w > wl) break;
+    uint64_t m = wave_uniform(sel[w] & missing[w]);
+    if (w == wl && (nrows & 63)) m &= (1ull << (nrows & 63)) - 1ull;
+    if (m) { if (lane == 0) aux_min(&aux[1], (uint64_t)(w * 64 + __builtin_ctzll(m))); break; }
+  }
+}
+// the lanes of the wave whose key can be stored, as a mask (all ones is the table's "empty"); Float64 keys become their isequal image first: one NaN — and all
+// ones is a NaN
+template <int KIND> __device__ __forceinline__ uint64_t keys_storable(uint64_t& k) {
+  if (KIND == kKindF64) { if ((k << 1) > 0xFFE0000000000000ull) k = 0x7ff8000000000000ull; return ~0ull; }
+  return __ballot(k != kREmpty);                                // (called with every lane active: the compare's result as it stands)
 }
 
 // ---- pass 1: counts_T[p * C + c] = selected rows of chunk c whose key falls into partition p
+template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
-                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, uint64_t* aux, int xp) {
+                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, uint64_t* aux) {
   extern __shared__ uint32_t hist_sh[];
   const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x;
   for (int p = threadIdx.x; p < P; p += kRBlock) hist_sh[p] = 0;
   __syncthreads();
+  const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), sh = 32 - kbits;
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
-  for (int64_t base = r0; base < r1; base += 8 * kRBlock) {                // eight rows per thread, their loads issued together
-    RadixRow rr[8];
+  for (int64_t base = r0; base < r1; base += kRTile) {
+    uint64_t key[8], in[8];
+    const uint64_t sm = base + kRTile <= nrows ? tile_load<KIND, true>(key, in, sel, col, dtype, missing, base, nrows, wv, lane)
+                                               : tile_load<KIND, false>(key, in, sel, col, dtype, missing, base, nrows, wv, lane);
+    if (sm) tile_first_missing(sel, missing, base, nrows, wv, lane, aux);
+    uint64_t unstorable = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) rr[j] = radix_load(sel, col, dtype, missing, base + j * kRBlock + threadIdx.x, r1);
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (radix_take<true>(rr[j], dtype, base + j * kRBlock + threadIdx.x, r1, aux)) {
-        if (xp & 1) { if (rhash(rr[j].key) == 12345u) hist_sh[0] = 1; }              // (DFDB_RADIX_XP bit 0, timing only: the pass without its LDS atomics)
-        else atomicAdd(&hist_sh[rhash(rr[j].key) >> (32 - kbits)], 1u);
+    for (int j = 0; j < 8; j++) {
+      const uint64_t ok = keys_storable<KIND>(key[j]);
+      unstorable |= in[j] & ~ok;
+      if (__builtin_amdgcn_inverse_ballot_w64(in[j] & ok)) atomicAdd(&hist_sh[rhash(key[j]) >> sh], 1u);
+    }
+    if (unstorable) {                                             // (rare — but -1 in an Int64 column is this image: one lane of the wave reports the first such row)
+      for (int j = 0; j < 8; j++) {
+        const uint64_t bad = in[j] & ~keys_storable<KIND>(key[j]);
+        if (bad) { if (lane == 0) aux_min(&aux[0], (uint64_t)(base + wv * 512 + j * 64 + __builtin_ctzll(bad))); break; }
       }
+    }
   }
   __syncthreads();
   for (int p = threadIdx.x; p < P; p += kRBlock) counts_T[(size_t)p * C + c] = hist_sh[p];
 }
 
 // ---- pass 2: the records of chunk c, sorted by partition 8192 rows at a time, to their places
+// Per tile: (1) every row's partition and its rank among the tile's rows of that partition (an LDS atomic that returns a value), the NEXT tile's loads issued;
+// (2) thread p < P scans the tile's counts: where partition p's run starts in the sorted tile (lstart) and how far the run's slots are from their places in the
+// chunk's share of partition p (delta = the running position, kept in thread p's register, minus lstart); (3) the records into LDS, sorted by partition;
+// (4) slot s to delta[its partition] + s — each partition's run a contiguous store.  Four barriers per tile.
 // (Tried and dropped, profiles/r6_unique_radix.txt: ranks by ballots instead of LDS atomics that return a value — slower at 9-10 partition bits; whole 16-record
-// units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3.)
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
+// units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3;
+// 512-thread workgroups sorting 4096 rows, two per CU — shorter runs store slower than the overlap gains.)
+constexpr int kPartLdsWords = 3 * 1024 + 32 + kRTile;           // hist2, lstart, delta (1024 each: P <= 1024), wave sums, srow — in 4-byte words; skey follows
+template <int KIND>
+__global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
-                                                             uint64_t* __restrict__ keys_out, uint32_t* __restrict__ rows_out, int xp) {
+                                                             uint32_t* __restrict__ recs_out, int xp) {
   extern __shared__ uint64_t part_sh[];
-  constexpr int TILE = 8 * BLOCK;                            // rows sorted at a time (8 per thread)
-  const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x;
-  uint64_t* skey = part_sh;                                   // [TILE]
-  uint64_t* cursor = skey + TILE;                           // [P]   where the chunk's next record of partition p goes
-  uint32_t* srow = (uint32_t*)(cursor + P);                   // [TILE]  partition << 13 | row's offset inside the tile (the partition is not hashed again on the way out)
-  uint32_t* hist2 = srow + TILE;                            // [P]   this tile's records per partition
-  uint32_t* lstart = hist2 + P;                               // [P]   their first slot in skey / srow
-  uint32_t* wsum = lstart + P;                                // [16]  scan scratch: one total per wave
-  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int p = tid; p < P; p += BLOCK) { cursor[p] = offsets_T[(size_t)p * C + c]; hist2[p] = 0; }
-  __syncthreads();
+  uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
+  uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
+  uint32_t* delta = lstart + 1024;                              // [1024] a slot's place in the output minus the slot (mod 2^32: fewer than 2^32 records)
+  uint32_t* wsum = delta + 1024;                                // [16]   scan scratch: one total per wave
+  uint32_t* srow = wsum + 32;                                   // [8192] partition << 13 | the row's offset inside the tile
+  uint64_t* skey = (uint64_t*)(srow + kRTile);                  // [8192]
+  const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x, sh = 32 - kbits;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
-  RadixRow nx[8];                                             // the NEXT tile's rows: loaded while this tile is sorted and written
+  if (r0 >= r1) return;
+  uint32_t cur = tid < P ? (uint32_t)offsets_T[(size_t)tid * C + c] : 0u;       // where the chunk's next record of partition `tid` goes
+  hist2[tid] = 0;
+  __syncthreads();
+  uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
+  if (r0 + kRTile <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
+  else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
 #pragma unroll
-  for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, r0 + j * BLOCK + tid, r1);
-  for (int64_t base = r0; base < r1; base += TILE) {
-    // 1. keys, partitions, rank inside the tile's partition (an LDS atomic that returns a value: 0.8 ms of the pass per 1e9 rows)
-    uint64_t key[8]; uint32_t pr[8];                          // pr: partition << 13 | rank  (rank < 8192), ~0 = no record
-    bool tk[8];
+  for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));      // (arrived before the loop is entered — see step 4: no wait for them may sit at the loop's top)
+  for (int64_t base = r0; base < r1; base += kRTile) {
+    uint64_t key[8]; uint32_t pr[8];                            // pr: partition << 13 | rank among the tile's records of that partition; ~0 = the row takes no part
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      tk[j] = radix_take<false>(nx[j], dtype, base + j * BLOCK + tid, r1, nullptr);
-      key[j] = nx[j].key;
+      key[j] = nkey[j]; pr[j] = ~0u;
+      const uint64_t ok = keys_storable<KIND>(key[j]);
+      if (__builtin_amdgcn_inverse_ballot_w64(nin[j] & ok)) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      pr[j] = ~0u;
-      if (tk[j]) {
-        const uint32_t p = rhash(key[j]) >> (32 - kbits);
-        pr[j] = p << 13 | ((xp & 2) ? (uint32_t)(j * BLOCK + tid) / (uint32_t)P : atomicAdd(&hist2[p], 1u));     // (DFDB_RADIX_XP bit 1, timing only: no rank atomics — and with them no stores)
-      }
+    const int64_t nb = base + kRTile;
+    if (nb < r1) {
+      if (nb + kRTile <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
+      else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++) nx[j] = radix_load(sel, col, dtype, missing, base + TILE + j * BLOCK + tid, r1);
     __syncthreads();
-    // 2. exclusive scan of hist2 over the partitions (P <= 2048: at most two per thread)
-    uint32_t h0 = tid < P ? hist2[tid] : 0u, h1 = tid + BLOCK < P ? hist2[tid + BLOCK] : 0u;
-    uint32_t mine = h0 + h1, incl = mine;
+    if (xp & 8) continue;                                       // (bit 3, timing only: loads and ranks only)
+    // 2. exclusive scan of the tile's counts (thread p owns partition p; its count is cleared for the next tile as it is read)
+    uint32_t h = 0;
+    if (tid < P) { h = hist2[tid]; hist2[tid] = 0; }
+    uint32_t incl = h;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < wv; w++) before += wsum[w];
-    // (thread t scans partitions t and t + 1024 as one element: their slots are adjacent, t's first)
-    const uint32_t ex = before + incl - mine;
-    if (tid < P) lstart[tid] = ex;
-    if (tid + BLOCK < P) lstart[tid + BLOCK] = ex + h0;
-    __syncthreads();
-    // 3. the tile's records into LDS, sorted by partition
+    uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (pr[j] == ~0u) continue;
-      const uint32_t p = pr[j] >> 13, slot = lstart[p] + (pr[j] & 8191u);
-      skey[slot] = key[j];
-      srow[slot] = p << 13 | (uint32_t)(j * BLOCK + tid);
+    for (int w = 0; w < kRBlock / 64; w++) { const uint32_t t = wsum[w]; total += t; if (w < wv) before += t; }
+    if (tid < P) { const uint32_t ex = before + incl - h; lstart[tid] = ex; delta[tid] = cur - ex; cur += h; }
+    __syncthreads();
+    if (xp & 4) continue;                                       // (bit 2, timing only: ranks and scan only)
+    // 3. the tile's records into LDS, sorted by partition (the eight reads of lstart first, unconditionally: a branch per row made each wait for its own)
+    uint32_t ls[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ls[j] = lstart[(pr[j] >> 13) & 1023u];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (pr[j] != ~0u) {
+        const uint32_t slot = ls[j] + (pr[j] & 8191u);
+        skey[slot] = key[j];
+        srow[slot] = (pr[j] & ~8191u) | (uint32_t)(wv * 512 + j * 64 + lane);
+      }
+    __syncthreads();
+    if (xp & 2) continue;                                       // (bit 1, timing only: nothing after the sort)
+    // 4. out: all the LDS reads, then the stores
+    uint64_t ok[8]; uint32_t ow[8], od[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ok[k] = skey[k * kRBlock + tid]; ow[k] = srow[k * kRBlock + tid]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) od[k] = delta[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
+    // the next tile's keys are waited for HERE, before the first store is issued: loads and stores share one in-order counter (vmcnt), and a wait for the loads at
+    // the top of the next step would also be a wait for the sixteen stores issued after them — a tile's store latency, every tile
+#pragma unroll
+    for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));
+    const uint32_t base32 = (uint32_t)base;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t s = (uint32_t)(k * kRBlock + tid);
+      if (s < total) {
+        const uint32_t dst = od[k] + s;
+        if (xp & 1) { if (ok[k] == 12345ull) recs_out[dst] = 1; continue; }              // (DFDB_RADIX_XP bit 0, timing only: no stores)
+        // one 12-byte record {key image, row}: a partition's run of a tile is ONE piece of 192 bytes, not 128 + 64 in two arrays (the pass waits for its
+        // stores, and what they cost goes by the number of pieces: tools/ubench/scatter_runs.hip)
+        Rec12 r; r.lo = (uint32_t)ok[k]; r.hi = (uint32_t)(ok[k] >> 32); r.row = base32 | (ow[k] & 8191u);
+        *(Rec12*)(recs_out + (size_t)dst * 3) = r;
+      }
     }
-    __syncthreads();
-    // 4. out: slot s's place is its partition's cursor + its rank in the tile's run
-    uint32_t total = 0;
-    for (int w = 0; w < BLOCK / 64; w++) total += wsum[w];
-    for (uint32_t s = (uint32_t)tid; s < total; s += BLOCK) {
-      const uint64_t k = skey[s];
-      const uint32_t pw = srow[s], p = pw >> 13;
-      const uint64_t dst = cursor[p] + (s - lstart[p]);
-      if (xp & 4) { if (k == 12345ull) keys_out[dst] = k; continue; }                 // (DFDB_RADIX_XP bit 2, timing only: no stores)
-      keys_out[dst] = k;
-      if (!(xp & 16)) rows_out[dst] = (uint32_t)base + (pw & 8191u);                   // (DFDB_RADIX_XP bit 4, timing only: keys without their rows)
-    }
-    __syncthreads();
-    // 5. the cursors move on
-    for (int p = tid; p < P; p += BLOCK) { cursor[p] += hist2[p]; hist2[p] = 0; }
-    __syncthreads();
+    // (no barrier here: the next tile writes hist2 — cleared above — before its first barrier, and nothing this step still reads before its third)
   }
 }
 
 // ---- pass 3: one workgroup per partition (grid-strided): first occurrences out of a table in LDS
-__global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ rows, const uint64_t* __restrict__ offsets_T,
+// Linear probing from an EVEN slot; a record first looks at the two slots its probing starts with in one 16-byte read (the slot is the top 13 bits of the
+// hash's first product — the partition is the top bits of the mixed hash —: four vector instructions): nearly every record of a partition is a key the table
+// already holds, and at 24 % load all but a few per cent of the keys sit in one of those two slots.  What is left — a key's first record, the displaced keys'
+// records — goes through the claiming loop, lane by lane.
+// four records of a thread: FULL = all four exist; otherwise a record past the partition's end reads the last one again and is made the empty image afterwards
+template <bool FULL>
+__device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], const uint32_t* __restrict__ rp, int64_t i0, int64_t n, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int64_t i = i0 + j * kRBlock + tid;
+    const Rec12 r = *(const Rec12*)(rp + (FULL || i < n ? i : n - 1) * 3);
+    kk[j] = (uint64_t)r.hi << 32 | r.lo; rw[j] = r.row;
+  }
+}
+__global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __restrict__ recs, const uint64_t* __restrict__ offsets_T,
                                                           int P, int C, uint64_t total, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kRSlots]
   uint32_t* trow = (uint32_t*)(tkey + kRSlots);               // [kRSlots]
   __shared__ uint32_t claims_sh, abort_sh;
+  const int tid = (int)threadIdx.x;
   for (int p = (int)blockIdx.x; p < P; p += (int)gridDim.x) {
-    for (int i = threadIdx.x; i < kRSlots; i += kRBlock) { tkey[i] = kREmpty; trow[i] = 0xFFFFFFFFu; }
-    if (threadIdx.x == 0) { claims_sh = 0; abort_sh = 0; }
+    for (int i = tid; i < kRSlots; i += kRBlock) { tkey[i] = kREmpty; trow[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { claims_sh = 0; abort_sh = 0; }
     __syncthreads();
     const uint64_t a = offsets_T[(size_t)p * C], b = p + 1 < P ? offsets_T[(size_t)(p + 1) * C] : total;
-    for (uint64_t i0 = a; i0 < b; i0 += 4 * kRBlock) {
-      uint64_t kk[4]; uint32_t rw[4], hh[4];
+    const int64_t n = (int64_t)(b - a);
+    const uint32_t* rp = recs + a * 3;
+    uint64_t nk[4]; uint32_t nr[4];                           // the NEXT four records: loaded while these four go through the table
+    if (n > 0) { if (4 * kRBlock <= n) recs_load<true>(nk, nr, rp, 0, n, tid); else recs_load<false>(nk, nr, rp, 0, n, tid); }
+    for (int64_t i0 = 0; i0 < n; i0 += 4 * kRBlock) {
+      uint64_t kk[4]; uint32_t rw[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) { const uint64_t i = i0 + (uint64_t)j * kRBlock + threadIdx.x; kk[j] = i < b ? keys[i] : kREmpty; rw[j] = i < b ? rows[i] : 0u; }
+      for (int j = 0; j < 4; j++) { kk[j] = nk[j]; rw[j] = nr[j]; }
+      if (i0 + 4 * kRBlock > n) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) hh[j] = rhash(kk[j]) & (uint32_t)(kRSlots - 1);                        // (the partition is the hash's TOP bits)
-      // every lane walks ITS four records at its own pace: one probe per trip, the next record as soon as this one is placed — a wave waits for the lane
-      // with the most probes over four records, not for the slowest lane of every record (linear probing at 25-50 % load has a long tail)
-      int j = 0; uint32_t probes = 0;
-      uint64_t key = kk[0]; uint32_t row = rw[0], h = hh[0];
-      while (j < 4) {
-        bool placed = key == kREmpty;                                            // (past the partition's end: no record holds this image)
-        if (!placed) {
+        for (int j = 0; j < 4; j++) if (i0 + j * kRBlock + tid >= n) { kk[j] = kREmpty; rw[j] = 0xFFFFFFFFu; }       // (no record holds the empty image)
+      }
+      const int64_t i1 = i0 + 4 * kRBlock;
+      if (i1 < n) { if (i1 + 4 * kRBlock <= n) recs_load<true>(nk, nr, rp, i1, n, tid); else recs_load<false>(nk, nr, rp, i1, n, tid); }
+      uint32_t hb[4]; uint64_t t0[4], t1[4]; uint32_t q0[4], q1[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) hb[j] = ((((uint32_t)kk[j] ^ (uint32_t)(kk[j] >> 32) * 0x85EBCA77u) * 0x9E3779B1u) >> 19) & ~1u;       // (rhash's first product)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const ulonglong2 tt = *(const ulonglong2*)&tkey[hb[j]]; t0[j] = tt.x; t1[j] = tt.y;
+        const uint2 qq = *(const uint2*)&trow[hb[j]]; q0[j] = qq.x; q1[j] = qq.y;
+      }
+      uint32_t pend = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool e0 = t0[j] == kk[j], e1 = t1[j] == kk[j];
+        if (e0 | e1) { const uint32_t slot = hb[j] + (e0 ? 0u : 1u); if ((e0 ? q0[j] : q1[j]) > rw[j]) atomicMin(&trow[slot], rw[j]); }
+        else if (kk[j] != kREmpty) pend |= 1u << j;           // (an absent record compares equal to an empty slot — its row, all ones, changes nothing — or is skipped here)
+      }
+      while (pend) {
+        const int j = __builtin_ctz(pend);
+        pend &= pend - 1;
+        const uint64_t key = j == 0 ? kk[0] : (j == 1 ? kk[1] : (j == 2 ? kk[2] : kk[3]));
+        const uint32_t row = j == 0 ? rw[0] : (j == 1 ? rw[1] : (j == 2 ? rw[2] : rw[3]));
+        uint32_t h = j == 0 ? hb[0] : (j == 1 ? hb[1] : (j == 2 ? hb[2] : hb[3]));
+        for (uint32_t probes = 0;; probes++) {
           uint64_t old = tkey[h];
           if (old == kREmpty) {
             old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)kREmpty, (unsigned long long)key);
             if (old == kREmpty) atomicAdd(&claims_sh, 1u);
           }
-          if (old == kREmpty || old == key) { if (trow[h] > row) atomicMin(&trow[h], row); placed = true; }
-          else { h = (h + 1) & (kRSlots - 1); if (++probes >= (uint32_t)kRSlots) { abort_sh = 1; placed = true; } }
-        }
-        if (placed) {
-          j++; probes = 0;
-          key = j == 1 ? kk[1] : (j == 2 ? kk[2] : kk[3]); row = j == 1 ? rw[1] : (j == 2 ? rw[2] : rw[3]); h = j == 1 ? hh[1] : (j == 2 ? hh[2] : hh[3]);
+          if (old == kREmpty || old == key) { if (trow[h] > row) atomicMin(&trow[h], row); break; }
+          h = (h + 1) & (kRSlots - 1);
+          if (probes >= (uint32_t)kRSlots) { abort_sh = 1; break; }
         }
       }
       // (the claims are read without a barrier: a late view only delays the stop — the flag is what the host looks at)
       if (claims_sh > (kRSlots * 7) / 8) { abort_sh = 1; break; }
     }
     __syncthreads();
-    if (abort_sh) { if (threadIdx.x == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }      // aux[kAuxAbort]: this column needs the hash-table form
-    for (int i = threadIdx.x; i < kRSlots; i += kRBlock) {
+    if (abort_sh) { if (tid == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }      // aux[kAuxAbort]: this column needs the hash-table form
+    for (int i = tid; i < kRSlots; i += kRBlock) {
       if (tkey[i] == kREmpty) continue;
       const uint64_t r = trow[i];
       atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63));
       atomicAdd(&tile_counts[r >> 10], 1u);
     }
-    if (p == 0 && threadIdx.x < 2) {                          // the two keys kept aside: the unstorable image, missing
-      const uint64_t r = aux[threadIdx.x];
+    if (p == 0 && tid < 2) {                                  // the two keys kept aside: the unstorable image, missing
+      const uint64_t r = aux[tid];
       if (r != kREmpty) { atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63)); atomicAdd(&tile_counts[r >> 10], 1u); }
     }
     __syncthreads();
@@ -248,36 +358,44 @@ int64_t radix_rows_per_chunk(int64_t nrows, int chunks) {
   return (per + kRTile - 1) / kRTile * kRTile;              // whole tiles of the partition pass (and whole bitmap words)
 }
 static int radix_xp() { static const int v = [] { const char* e = getenv("DFDB_RADIX_XP"); return e ? atoi(e) : 0; }(); return v; }   // timing experiments only: results are WRONG with any bit set
-size_t radix_partition_lds_bytes(int kbits) { const size_t P = (size_t)1 << kbits; return (size_t)kRTile * 12 + P * 16 + 64 + 64; }
+size_t radix_partition_lds_bytes(int) { return (size_t)kPartLdsWords * 4 + (size_t)kRTile * 8; }
+static int radix_kind(int dtype) { return dtype == DFDB_F64 ? kKindF64 : (dtype == DFDB_I64 || dtype == DFDB_U64 ? kKindRaw8 : kKindAny); }
 
 bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                        uint32_t* counts_T, uint64_t* aux) {
-  if (kbits < 6 || kbits > 11) return false;
-  hipLaunchKernelGGL(k_radix_hist, dim3(chunks), dim3(kRBlock), ((size_t)1 << kbits) * 4, s, sel, col, dtype, missing, nrows, radix_rows_per_chunk(nrows, chunks), kbits, counts_T, aux, radix_xp());
+  if (kbits < 6 || kbits > 10 || nrows < 1) return false;
+  const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
+  const size_t lds = ((size_t)1 << kbits) * 4;
+  switch (radix_kind(dtype)) {
+    case kKindRaw8: hipLaunchKernelGGL(k_radix_hist<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
+    case kKindF64: hipLaunchKernelGGL(k_radix_hist<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
+    default: hipLaunchKernelGGL(k_radix_hist<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
+  }
   return true;
 }
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint64_t* keys_out, uint32_t* rows_out) {
-  // DFDB_RADIX_BLOCK (an A/B switch, read once): 1024-thread workgroups sorting 8192 rows at a time, one per CU (default), or 512-thread ones sorting 4096, two per CU
-  static const int block = [] { const char* e = getenv("DFDB_RADIX_BLOCK"); return e && atoi(e) == 512 ? 512 : 1024; }();
-  const size_t P = (size_t)1 << kbits;
-  const size_t lds = (size_t)(8 * block) * 12 + P * 16 + 64 + 64;
-  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
-                               hipFuncSetAttribute((const void*)k_radix_partition<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
-  if (!ok || lds > 156 * 1024 || P > (size_t)2 * block) { (void)hipGetLastError(); return false; }
+                            const uint64_t* offsets_T, uint32_t* recs_out) {
+  const size_t lds = radix_partition_lds_bytes(kbits);
+  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition<kKindRaw8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+                               hipFuncSetAttribute((const void*)k_radix_partition<kKindF64>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+                               hipFuncSetAttribute((const void*)k_radix_partition<kKindAny>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
+  if (!ok || kbits < 6 || kbits > 10 || nrows < 1) { (void)hipGetLastError(); return false; }
   const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
-  if (block == 512) hipLaunchKernelGGL(k_radix_partition<512>, dim3(chunks), dim3(512), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, keys_out, rows_out, radix_xp());
-  else hipLaunchKernelGGL(k_radix_partition<1024>, dim3(chunks), dim3(1024), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, keys_out, rows_out, radix_xp());
+  switch (radix_kind(dtype)) {
+    case kKindRaw8: hipLaunchKernelGGL(k_radix_partition<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
+    case kKindF64: hipLaunchKernelGGL(k_radix_partition<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
+    default: hipLaunchKernelGGL(k_radix_partition<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
+  }
   return true;
 }
-bool launch_radix_unique(hipStream_t s, const uint64_t* keys, const uint32_t* rows, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
                          uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus) {
   const size_t lds = (size_t)kRSlots * 12;
   static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_unique, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   const int grid = P < cus ? P : cus;                       // one 96-KB table per CU at a time
-  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, keys, rows, offsets_T, P, chunks, total, bitmap, tile_counts, aux);
+  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, offsets_T, P, chunks, total, bitmap, tile_counts, aux);
   return true;
 }
 

@@ -164,8 +164,8 @@ int64_t radix_rows_per_chunk(int64_t nrows, int chunks);
 bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                        uint32_t* counts_T, uint64_t* aux);
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint64_t* keys_out, uint32_t* rows_out);
-bool launch_radix_unique(hipStream_t s, const uint64_t* keys, const uint32_t* rows, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
+                            const uint64_t* offsets_T, uint32_t* recs_out /* 12 bytes per record: key image, row */);
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
                          uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus);
 int64_t unique_dense_max_range();
 bool unique_dense_dtype(int dtype);

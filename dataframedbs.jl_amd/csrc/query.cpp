@@ -1359,7 +1359,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   const int64_t nt = ceil_div(t->nrows, kTileRows);
   const size_t nw = padded_words(t->nrows);
   // the records' scratch (12 bytes per selected row) stays with the context between calls: hipMalloc / hipFree of 12 GB cost 3-4 ms of a 19-ms call (buffers
-  // above 1 GB never enter the pool); dfdb_ctx_destroy, or ctx option "unique_radix_scratch" = 0 at a later call, releases it
+  // above 1 GB never enter the pool); dfdb_ctx_destroy releases it
   // (the call's temporaries go back to the buffer pool, not through hipFree — which drains the device and took ~1.5 ms of a 16-ms call for the 125-MB copy of the
   // selection alone; the stream is drained first: nothing in flight may still touch them)
   struct Temps {
@@ -1367,17 +1367,17 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
     ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; counts_T.release(); offsets_T.release(); scratch.release(); sel_keep.release(); tc_keep.release(); }
   } tmp{ctx, {}, {}, {}, {}, {}};
   DevBuf &counts_T = tmp.counts_T, &offsets_T = tmp.offsets_T, &scratch = tmp.scratch, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
-  DevBuf& keys = ctx->radix_keys; DevBuf& rows = ctx->radix_rows;
+  DevBuf& recs = ctx->radix_recs;
   try {
     counts_T.ensure((size_t)P * C * 4 + 64); offsets_T.ensure(((size_t)P * C + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes((int64_t)P * C));
-    keys.ensure((size_t)cnt * 8 + 256); rows.ensure((size_t)cnt * 4 + 256);
+    recs.ensure((size_t)cnt * 12 + 256);
     sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
   { LaunchTimer lt(ctx, "radix_hist");
     if (!launch_radix_hist(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, counts_T.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
   launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), (int64_t)P * C, scratch.as<uint64_t>());
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), keys.as<uint64_t>(), rows.as<uint32_t>())) return false; }
+    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), recs.as<uint32_t>())) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
   HIP_CHECK(hipMemcpyAsync(sel_keep.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(tc_keep.p, q->tile_counts.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
@@ -1388,7 +1388,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   stream_wait(ctx);
   bool ok;
   { LaunchTimer lt(ctx, "radix_unique");
-    ok = launch_radix_unique(s, keys.as<uint64_t>(), rows.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, C, total, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
+    ok = launch_radix_unique(s, recs.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, C, total, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
                              T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
   uint64_t aborted = 0;
   if (ok) { HIP_CHECK(hipMemcpyAsync(&aborted, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
