@@ -24,6 +24,7 @@ constexpr int kRBlock = 1024;                 // threads per workgroup of all th
 constexpr int kRTile = 8192;                  // rows sorted at a time by the partition pass (8 per thread)
 constexpr int kRSlots = 8192;                 // slots of a partition's table in LDS
 constexpr uint64_t kREmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kRShare = 8;                    // the workgroups whose number is equal mod 8 — one XCD's, as the dispatcher deals them out — share their running positions
 // 32 bits of hash per key, three 32-bit multiplies (k_unique.hip lds_slot_of's mix; splitmix64's two 64-bit multiplies are eight quarter-rate instructions each and
 // the partition pass hashed every row twice: 3.4e9 vector instructions per 1e9 rows).  The partition is its TOP bits, a table slot its low bits.
 __device__ __forceinline__ uint32_t rhash(uint64_t key) {
@@ -126,12 +127,12 @@ template <int KIND> __device__ __forceinline__ uint64_t keys_storable(uint64_t& 
   return __ballot(k != kREmpty);                                // (called with every lane active: the compare's result as it stands)
 }
 
-// ---- pass 1: counts_T[p * C + c] = selected rows of chunk c whose key falls into partition p
+// ---- pass 1: counts[p * 8 + x] = selected rows whose key falls into partition p, over the chunks c with c mod 8 = x (kRShare = 8: see the partition pass)
 template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                         int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, uint64_t* aux) {
   extern __shared__ uint32_t hist_sh[];
-  const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x;
+  const int P = 1 << kbits, c = (int)blockIdx.x;
   for (int p = threadIdx.x; p < P; p += kRBlock) hist_sh[p] = 0;
   __syncthreads();
   const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), sh = 32 - kbits;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
     }
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < P; p += kRBlock) counts_T[(size_t)p * C + c] = hist_sh[p];
+  for (int p = threadIdx.x; p < P; p += kRBlock) { const uint32_t h = hist_sh[p]; if (h) atomicAdd(&counts_T[p * kRShare + (c & (kRShare - 1))], h); }
 }
 
 // ---- pass 2: the records of chunk c, sorted by partition 8192 rows at a time, to their places
@@ -171,7 +172,7 @@ constexpr int kPartLdsWords = 3 * 1024 + 32 + kRTile;           // hist2, lstart
 template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
-                                                             uint32_t* __restrict__ recs_out, int xp) {
+                                                             uint32_t* __restrict__ front, uint32_t* __restrict__ recs_out, int xp) {
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
@@ -179,11 +180,12 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
   uint32_t* wsum = delta + 1024;                                // [16]   scan scratch: one total per wave
   uint32_t* srow = wsum + 32;                                   // [8192] partition << 13 | the row's offset inside the tile
   uint64_t* skey = (uint64_t*)(srow + kRTile);                  // [8192]
-  const int P = 1 << kbits, C = (int)gridDim.x, c = (int)blockIdx.x, sh = 32 - kbits;
+  const int P = 1 << kbits, c = (int)blockIdx.x, sh = 32 - kbits;
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
-  uint32_t cur = tid < P ? (uint32_t)offsets_T[(size_t)tid * C + c] : 0u;       // where the chunk's next record of partition `tid` goes
+  const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the running position of (partition p, this workgroup's share)
+  const uint32_t obase = tid < P ? (uint32_t)offsets_T[fx] : 0u;  // ... and where that share of the partition starts
   hist2[tid] = 0;
   __syncthreads();
   uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     uint32_t before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kRBlock / 64; w++) { const uint32_t t = wsum[w]; total += t; if (w < wv) before += t; }
-    if (tid < P) { const uint32_t ex = before + incl - h; lstart[tid] = ex; delta[tid] = cur - ex; cur += h; }
+    const uint32_t ex = before + incl - h;
+    uint32_t got = 0;
+    if (tid < P) { lstart[tid] = ex; if (h) got = atomicAdd(&front[fx], h); }      // the tile's run of partition `tid`: reserved behind whatever the XCD's other workgroups reserved last
     __syncthreads();
     if (xp & 4) continue;                                       // (bit 2, timing only: ranks and scan only)
     // 3. the tile's records into LDS, sorted by partition (the eight reads of lstart first, unconditionally: a branch per row made each wait for its own)
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
         skey[slot] = key[j];
         srow[slot] = (pr[j] & ~8191u) | (uint32_t)(wv * 512 + j * 64 + lane);
       }
+    if (tid < P) delta[tid] = obase + got - ex;                 // (the atomic's answer is waited for here, behind the sort)
     __syncthreads();
     if (xp & 2) continue;                                       // (bit 1, timing only: nothing after the sort)
     // 4. out: all the LDS reads, then the stores
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
         const uint32_t dst = od[k] + s;
         if (xp & 1) { if (ok[k] == 12345ull) recs_out[dst] = 1; continue; }              // (DFDB_RADIX_XP bit 0, timing only: no stores)
         // one 12-byte record {key image, row}: a partition's run of a tile is ONE piece of 192 bytes, not 128 + 64 in two arrays (the pass waits for its
-        // stores, and what they cost goes by the number of pieces: tools/ubench/scatter_runs.hip)
+        // stores, and what they cost goes by the number of pieces: tools/ubench/scatter_runs.hip; as nontemporal stores: 7.4 ms instead of 6.15)
         Rec12 r; r.lo = (uint32_t)ok[k]; r.hi = (uint32_t)(ok[k] >> 32); r.row = base32 | (ow[k] & 8191u);
         *(Rec12*)(recs_out + (size_t)dst * 3) = r;
       }
@@ -261,10 +266,28 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
 }
 
 // ---- pass 3: one workgroup per partition (grid-strided): first occurrences out of a table in LDS
-// Linear probing from an EVEN slot; a record first looks at the two slots its probing starts with in one 16-byte read (the slot is the top 13 bits of the
-// hash's first product — the partition is the top bits of the mixed hash —: four vector instructions): nearly every record of a partition is a key the table
-// already holds, and at 24 % load all but a few per cent of the keys sit in one of those two slots.  What is left — a key's first record, the displaced keys'
-// records — goes through the claiming loop, lane by lane.
+// Linear probing from an EVEN slot; a record first looks at the two slots its probing starts with (one 16-byte read of keys, one 8-byte read of rows): nearly
+// every record of a partition is a key the table already holds, and at 24 % load all but a few per cent of the keys sit in one of those two.  What is left — a
+// key's first record, the displaced keys' records — is claimed later, 64 at a time (the wave's list).  (FOUR slots per look — 48 bytes of LDS per record instead
+// of 24 — left 0.5 % of the records for the list and took 5.7 ms instead of 3.0: the pass is bound by LDS reads at random addresses.)
+constexpr int kRQueue = 128;                                  // records a wave's list holds (it is emptied by 64 whenever it holds 64: at most 63 + 64)
+// where a key's probing starts: an EVEN slot, from the top bits of the hash's first product (the partition is the top bits of the MIXED
+// hash): four vector instructions
+__device__ __forceinline__ uint32_t table_home(uint64_t key) { return ((((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u) >> 19) & ~1u; }
+// one record per lane through the partition's table: linear probing from the key's home slot; the smallest row stays
+__device__ __forceinline__ void table_claim(uint64_t* tkey, uint32_t* trow, uint64_t key, uint32_t row, uint32_t* claims, uint32_t* abort_flag) {
+  uint32_t h = table_home(key);
+  for (uint32_t probes = 0;; probes++) {
+    uint64_t old = tkey[h];
+    if (old == kREmpty) {
+      old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)kREmpty, (unsigned long long)key);
+      if (old == kREmpty) atomicAdd(claims, 1u);
+    }
+    if (old == kREmpty || old == key) { if (trow[h] > row) atomicMin(&trow[h], row); break; }
+    h = (h + 1) & (kRSlots - 1);
+    if (probes >= (uint32_t)kRSlots) { *abort_flag = 1; break; }
+  }
+}
 // four records of a thread: FULL = all four exist; otherwise a record past the partition's end reads the last one again and is made the empty image afterwards
 template <bool FULL>
 __device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], const uint32_t* __restrict__ rp, int64_t i0, int64_t n, int tid) {
@@ -276,17 +299,20 @@ __device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], 
   }
 }
 __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __restrict__ recs, const uint64_t* __restrict__ offsets_T,
-                                                          int P, int C, uint64_t total, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux) {
+                                                          int P, int C, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux, int xp) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kRSlots]
   uint32_t* trow = (uint32_t*)(tkey + kRSlots);               // [kRSlots]
   __shared__ uint32_t claims_sh, abort_sh;
-  const int tid = (int)threadIdx.x;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t* qk = (uint64_t*)(trow + kRSlots) + wv * kRQueue;                     // the wave's list of records still to be claimed: [kRQueue] keys ...
+  uint32_t* qr = (uint32_t*)((uint64_t*)(trow + kRSlots) + (kRBlock / 64) * kRQueue) + wv * kRQueue;    // ... and their rows
   for (int p = (int)blockIdx.x; p < P; p += (int)gridDim.x) {
+    uint32_t qn = 0;                                          // (wave-uniform)
     for (int i = tid; i < kRSlots; i += kRBlock) { tkey[i] = kREmpty; trow[i] = 0xFFFFFFFFu; }
     if (tid == 0) { claims_sh = 0; abort_sh = 0; }
     __syncthreads();
-    const uint64_t a = offsets_T[(size_t)p * C], b = p + 1 < P ? offsets_T[(size_t)(p + 1) * C] : total;
+    const uint64_t a = offsets_T[(size_t)p * C], b = offsets_T[(size_t)(p + 1) * C];      // (offsets_T[P * C] = all the records: the scan's total)
     const int64_t n = (int64_t)(b - a);
     const uint32_t* rp = recs + a * 3;
     uint64_t nk[4]; uint32_t nr[4];                           // the NEXT four records: loaded while these four go through the table
@@ -301,41 +327,33 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __rest
       }
       const int64_t i1 = i0 + 4 * kRBlock;
       if (i1 < n) { if (i1 + 4 * kRBlock <= n) recs_load<true>(nk, nr, rp, i1, n, tid); else recs_load<false>(nk, nr, rp, i1, n, tid); }
-      uint32_t hb[4]; uint64_t t0[4], t1[4]; uint32_t q0[4], q1[4];
+      if (xp & 32) { if ((kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) == 12345ull && (rw[0] ^ rw[1] ^ rw[2] ^ rw[3]) == 77u) abort_sh = 1; continue; }   // (DFDB_RADIX_XP bit 5, timing only: the loads alone)
+      uint32_t hb[4]; ulonglong2 tt[4]; uint2 qq[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) hb[j] = ((((uint32_t)kk[j] ^ (uint32_t)(kk[j] >> 32) * 0x85EBCA77u) * 0x9E3779B1u) >> 19) & ~1u;       // (rhash's first product)
+      for (int j = 0; j < 4; j++) hb[j] = table_home(kk[j]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { tt[j] = *(const ulonglong2*)&tkey[hb[j]]; qq[j] = *(const uint2*)&trow[hb[j]]; }
+      // a record that is not in its two slots — its key's first record, a displaced key's every record — does not go through the claiming loop here, where it
+      // would hold its 63 neighbours up for a handful of dependent LDS round trips (1.4 of the pass's 3.6 ms when it did): it is put on the WAVE's own list in
+      // LDS, and the wave claims 64 at a time, one per lane, whenever the list holds that many
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const ulonglong2 tt = *(const ulonglong2*)&tkey[hb[j]]; t0[j] = tt.x; t1[j] = tt.y;
-        const uint2 qq = *(const uint2*)&trow[hb[j]]; q0[j] = qq.x; q1[j] = qq.y;
-      }
-      uint32_t pend = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const bool e0 = t0[j] == kk[j], e1 = t1[j] == kk[j];
-        if (e0 | e1) { const uint32_t slot = hb[j] + (e0 ? 0u : 1u); if ((e0 ? q0[j] : q1[j]) > rw[j]) atomicMin(&trow[slot], rw[j]); }
-        else if (kk[j] != kREmpty) pend |= 1u << j;           // (an absent record compares equal to an empty slot — its row, all ones, changes nothing — or is skipped here)
-      }
-      while (pend) {
-        const int j = __builtin_ctz(pend);
-        pend &= pend - 1;
-        const uint64_t key = j == 0 ? kk[0] : (j == 1 ? kk[1] : (j == 2 ? kk[2] : kk[3]));
-        const uint32_t row = j == 0 ? rw[0] : (j == 1 ? rw[1] : (j == 2 ? rw[2] : rw[3]));
-        uint32_t h = j == 0 ? hb[0] : (j == 1 ? hb[1] : (j == 2 ? hb[2] : hb[3]));
-        for (uint32_t probes = 0;; probes++) {
-          uint64_t old = tkey[h];
-          if (old == kREmpty) {
-            old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)kREmpty, (unsigned long long)key);
-            if (old == kREmpty) atomicAdd(&claims_sh, 1u);
-          }
-          if (old == kREmpty || old == key) { if (trow[h] > row) atomicMin(&trow[h], row); break; }
-          h = (h + 1) & (kRSlots - 1);
-          if (probes >= (uint32_t)kRSlots) { abort_sh = 1; break; }
+        const bool e0 = tt[j].x == kk[j], e1 = tt[j].y == kk[j];
+        bool pending = false;
+        if (e0 | e1) { if ((e0 ? qq[j].x : qq[j].y) > rw[j]) atomicMin(&trow[hb[j] + (e0 ? 0u : 1u)], rw[j]); }
+        else pending = kk[j] != kREmpty;                      // (an absent record compares equal to an empty slot — its row, all ones, changes nothing — or is skipped here)
+        if (xp & 64) pending = false;                         // (DFDB_RADIX_XP bit 6, timing only: nothing is claimed)
+        const uint64_t pm = __ballot(pending);
+        if (pm) {
+          if (pending) { const uint32_t e = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u)); qk[e] = kk[j]; qr[e] = rw[j]; }
+          qn += (uint32_t)__builtin_popcountll(pm);
+          if (qn >= 64u) { qn -= 64u; table_claim(tkey, trow, qk[qn + lane], qr[qn + lane], &claims_sh, &abort_sh); }
         }
       }
       // (the claims are read without a barrier: a late view only delays the stop — the flag is what the host looks at)
       if (claims_sh > (kRSlots * 7) / 8) { abort_sh = 1; break; }
     }
+    if (qn && !abort_sh) { if (lane < (int)qn) table_claim(tkey, trow, qk[lane], qr[lane], &claims_sh, &abort_sh); }      // what is left on the wave's list
     __syncthreads();
     if (abort_sh) { if (tid == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }      // aux[kAuxAbort]: this column needs the hash-table form
     for (int i = tid; i < kRSlots; i += kRBlock) {
@@ -374,28 +392,29 @@ bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int 
   return true;
 }
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint32_t* recs_out) {
+                            const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out) {
   const size_t lds = radix_partition_lds_bytes(kbits);
   static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition<kKindRaw8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
                                hipFuncSetAttribute((const void*)k_radix_partition<kKindF64>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
                                hipFuncSetAttribute((const void*)k_radix_partition<kKindAny>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
-  if (!ok || kbits < 6 || kbits > 10 || nrows < 1) { (void)hipGetLastError(); return false; }
+  if (!ok || kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) { (void)hipGetLastError(); return false; }
   const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
   switch (radix_kind(dtype)) {
-    case kKindRaw8: hipLaunchKernelGGL(k_radix_partition<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
-    case kKindF64: hipLaunchKernelGGL(k_radix_partition<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
-    default: hipLaunchKernelGGL(k_radix_partition<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, recs_out, radix_xp()); break;
+    case kKindRaw8: hipLaunchKernelGGL(k_radix_partition<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
+    case kKindF64: hipLaunchKernelGGL(k_radix_partition<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
+    default: hipLaunchKernelGGL(k_radix_partition<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
   }
   return true;
 }
-bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
+int radix_share() { return kRShare; }
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits,
                          uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus) {
-  const size_t lds = (size_t)kRSlots * 12;
+  const size_t lds = (size_t)kRSlots * 12 + (size_t)(kRBlock / 64) * kRQueue * 12;
   static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_unique, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   const int grid = P < cus ? P : cus;                       // one 96-KB table per CU at a time
-  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, offsets_T, P, chunks, total, bitmap, tile_counts, aux);
+  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, offsets_T, P, kRShare, bitmap, tile_counts, aux, radix_xp());
   return true;
 }
 

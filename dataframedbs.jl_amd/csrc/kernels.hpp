@@ -159,13 +159,15 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
                        uint64_t* aux, uint64_t salt);
 // dense form.  aux words: 1 = smallest missing row, 5 = a key outside [lo, lo + range) was met, 6 = distinct keys, 7 = keys whose first row is known, 8 / 9 = min / max image
 // radix-partitioned form of the hash-table unique (k_radix.hip): hist -> scan -> partition -> one LDS table per partition.  false: the launch is not possible
-// (LDS attribute refused, too many partition bits): the caller stays with the hash table.  counts_T / offsets_T are [2^kbits][chunks] (+ 1), partition-major.
+// (LDS attribute refused, too many partition bits): the caller stays with the hash table.  counts / offsets are [2^kbits][radix_share()] (+ 1), partition-major:
+// the workgroups (chunks) whose number is equal mod radix_share() fill one share of every partition together (`front`: their running positions, zero before the pass).
 int64_t radix_rows_per_chunk(int64_t nrows, int chunks);
 bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                        uint32_t* counts_T, uint64_t* aux);
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint32_t* recs_out /* 12 bytes per record: key image, row */);
-bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits, int chunks, uint64_t total,
+                            const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out /* 12 bytes per record: key image, row */);
+int radix_share();
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits,
                          uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus);
 int64_t unique_dense_max_range();
 bool unique_dense_dtype(int dtype);

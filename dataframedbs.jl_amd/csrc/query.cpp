@@ -1353,7 +1353,8 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   if (const char* e = getenv("DFDB_RADIX_KBITS")) kbits = std::min(10, std::max(6, atoi(e)));      // (an A/B switch for measurements)
   if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
   const int P = 1 << kbits;
-  const int C = 4 * std::max(1, ctx->prop.multiProcessorCount);         // chunks = workgroups of the hist and partition passes
+  const int C = round_up(4 * std::max(1, ctx->prop.multiProcessorCount), radix_share());      // chunks = workgroups of the hist and partition passes
+  const int64_t PS = (int64_t)P * radix_share();                        // (partition, share) pairs: what the counts, their scan and the running positions are kept by
   const int dt = dt_base(col.dtype);
   const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
   const int64_t nt = ceil_div(t->nrows, kTileRows);
@@ -1369,26 +1370,24 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   DevBuf &counts_T = tmp.counts_T, &offsets_T = tmp.offsets_T, &scratch = tmp.scratch, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
   DevBuf& recs = ctx->radix_recs;
   try {
-    counts_T.ensure((size_t)P * C * 4 + 64); offsets_T.ensure(((size_t)P * C + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes((int64_t)P * C));
+    counts_T.ensure((size_t)PS * 8 + 64); offsets_T.ensure(((size_t)PS + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes(PS));     // (counts_T: the counts, then the running positions)
     recs.ensure((size_t)cnt * 12 + 256);
     sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  HIP_CHECK(hipMemsetAsync(counts_T.p, 0, (size_t)PS * 8, s));
   { LaunchTimer lt(ctx, "radix_hist");
     if (!launch_radix_hist(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, counts_T.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
-  launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), (int64_t)P * C, scratch.as<uint64_t>());
+  launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), PS, scratch.as<uint64_t>());
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), recs.as<uint32_t>())) return false; }
+    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), counts_T.as<uint32_t>() + PS, recs.as<uint32_t>())) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
   HIP_CHECK(hipMemcpyAsync(sel_keep.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(tc_keep.p, q->tile_counts.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, nw * 8, s));
   HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)nt * 4, s));
-  uint64_t total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, offsets_T.as<uint64_t>() + (size_t)P * C, 8, hipMemcpyDeviceToHost, s));
-  stream_wait(ctx);
   bool ok;
   { LaunchTimer lt(ctx, "radix_unique");
-    ok = launch_radix_unique(s, recs.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, C, total, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
+    ok = launch_radix_unique(s, recs.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
                              T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
   uint64_t aborted = 0;
   if (ok) { HIP_CHECK(hipMemcpyAsync(&aborted, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }

@@ -6,7 +6,7 @@
 //   P         partitions (runs per tile); P = 0: the tile's 8192 records in row order (one fully coalesced run)
 //   chunk-major  the (partition, chunk) regions laid out [chunk][partition] — a workgroup's 512 running positions inside ~12 MB — instead of [partition][chunk]
 //             (512 positions ~20 MB apart: as many 2-MB pages as partitions, per array)
-//   shared    1 = ONE running position per partition for all workgroups (a global atomicAdd per tile and partition reserves the run) instead of one per
+//   shared    2 = one running position per (XCD, partition), XCD = workgroup number mod 8;  1 = ONE running position per partition for all workgroups (a global atomicAdd per tile and partition reserves the run) instead of one per
 //             (partition, workgroup): 512 write streams instead of 131 072
 //   hipcc -O3 --offload-arch=gfx950 scatter_runs.hip -o scatter_runs && ./scatter_runs
 #include <hip/hip_runtime.h>
@@ -18,7 +18,7 @@ constexpr int kTile = 8192, kBlock = 1024;
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
 __global__ __launch_bounds__(kBlock) void k_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ keys, uint32_t* __restrict__ rows, int P, int layout, int align,
-                                                    int tiles_per_chunk, uint32_t cap /* records per (partition, chunk) */, int do_read, int chunk_major, uint32_t* gfront /* shared mode: one running position per partition, all workgroups */) {
+                                                    int tiles_per_chunk, uint32_t cap /* records per (partition, chunk) */, int do_read, int chunk_major, int shared_mode, uint32_t* gfront /* shared mode: one running position per partition, all workgroups */) {
   __shared__ uint32_t lens[1024], lstart[1024], frontier[1024], wsum[16];
   __shared__ uint16_t owner[kTile];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = blockIdx.x, C = gridDim.x;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const uint64_t* __restrict__
       __syncthreads();
       uint32_t before = 0; for (int w = 0; w < wv; w++) before += wsum[w];
       if (tid < P) { const uint32_t ex = before + incl - h; lstart[tid] = ex; for (uint32_t i = 0; i < h; i++) owner[ex + i] = (uint16_t)tid;
-                     if (gfront) frontier[tid] = atomicAdd(&gfront[tid], (h + align - 1) / align * align); }
+                     if (gfront) frontier[tid] = atomicAdd(&gfront[(shared_mode == 2 ? (c & 7) * P : 0) + tid], (h + align - 1) / align * align); }
       __syncthreads();
     }
     for (int k = 0; k < 8; k++) {
@@ -68,11 +68,10 @@ int main(int argc, char** argv) {
   CK(hipMemset(in, 1, n * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct Cfg { int P, layout, align, read, shared, cm; };
-  uint32_t* gfront; CK(hipMalloc(&gfront, 4096)); uint32_t hfront[1024];
-  const Cfg cfgs[] = {{0, 0, 1, 1, 0, 0}, {0, 0, 1, 0, 0, 0},
-                      {512, 0, 1, 1, 0, 0}, {512, 1, 1, 1, 0, 0}, {512, 0, 1, 1, 1, 0}, {256, 0, 1, 1, 0, 0}, {1024, 0, 1, 1, 0, 0},
-                      {512, 0, 1, 1, 0, 1}, {512, 0, 4, 1, 0, 1}, {512, 0, 16, 1, 0, 1}, {512, 1, 1, 1, 0, 1}, {512, 1, 8, 1, 0, 1}, {512, 2, 8, 1, 0, 1}, {256, 0, 1, 1, 0, 1}, {1024, 0, 1, 1, 0, 1}, {1024, 1, 1, 1, 0, 1},
-                      {2048 / 2, 0, 4, 1, 0, 1}, {512, 0, 1, 0, 0, 1}};
+  uint32_t* gfront; CK(hipMalloc(&gfront, 8 * 4096)); static uint32_t hfront[8 * 1024];
+  const Cfg cfgs[] = {{0, 0, 1, 1, 0, 0}, {0, 1, 1, 1, 0, 0},
+                      {512, 0, 1, 1, 0, 0}, {512, 1, 1, 1, 0, 0}, {512, 0, 1, 1, 1, 0}, {512, 1, 1, 1, 1, 0}, {512, 0, 1, 1, 2, 0}, {512, 1, 1, 1, 2, 0},
+                      {256, 1, 1, 1, 0, 0}, {256, 1, 1, 1, 2, 0}, {1024, 1, 1, 1, 0, 0}, {1024, 1, 1, 1, 2, 0}, {1024, 0, 1, 1, 2, 0}, {512, 1, 1, 1, 0, 0}, {512, 1, 1, 1, 2, 0}};
   printf("%zu records; ms are per pass (best of 3); 'alg GB' = records x (8 read + 12 written)\n", n);
   printf("%6s %7s %6s %5s %7s %9s %12s\n", "P", "layout", "align", "read", "shared", "ms", "written GB/s  (last column: 1 = a chunk's runs side by side, [chunk][partition])");
   for (const Cfg& g : cfgs) {
@@ -81,9 +80,11 @@ int main(int argc, char** argv) {
     if (g.P && (size_t)g.P * C * cap > n * slack) { printf("%6d %7d %6d: no room\n", g.P, g.layout, g.align); continue; }
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
-      if (g.shared) { for (int p = 0; p < g.P; p++) hfront[p] = (uint32_t)p * C * cap; CK(hipMemcpy(gfront, hfront, 4096, hipMemcpyHostToDevice)); }
+      if (g.shared == 1) for (int p = 0; p < g.P; p++) hfront[p] = (uint32_t)p * C * cap;
+      if (g.shared == 2) for (int x = 0; x < 8; x++) for (int p = 0; p < g.P; p++) hfront[x * g.P + p] = ((uint32_t)p * 8 + x) * (C / 8) * cap;
+      if (g.shared) CK(hipMemcpy(gfront, hfront, 8 * 4096, hipMemcpyHostToDevice));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(k_scatter, dim3(C), dim3(kBlock), 0, 0, in, keys, rows, g.P, g.layout, g.align, tiles_per_chunk, cap, g.read, g.cm, g.shared ? gfront : nullptr);
+      hipLaunchKernelGGL(k_scatter, dim3(C), dim3(kBlock), 0, 0, in, keys, rows, g.P, g.layout, g.align, tiles_per_chunk, cap, g.read, g.cm, g.shared, g.shared ? gfront : nullptr);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
