@@ -3,15 +3,18 @@
 // Replaces Base.unique driven by Base.iterate(::DFColumn) (src/tables/column.jl:102-126; docs/src/index.md:479-487), like k_unique.hip.  The open-addressing
 // table of {key, smallest row} in HBM costs one random 128-byte line per selected row once it outgrows the L2s (1e6 distinct Int64 / Float64 values: 32 MB of
 // table, 1e9 probes, 19.8 ms per 1e9 rows = 0.05 of the HBM roofline on the 8 bytes per row it needs).  Here every byte moves in STREAMS:
-//   hist       one pass over the key column: how many selected rows of each of C contiguous chunks fall into each of P = 2^k partitions (the top k bits of
-//              splitmix64(key image)); an exclusive scan of the P x C counts (partition-major) is every chunk's write position in every partition
-//   partition  the same pass again: a workgroup sorts 8192 rows at a time by partition in LDS and writes each partition's run — {key image 8 B} and
-//              {row 4 B} in two arrays — at its running position: no global atomic, every store a contiguous run
-//   unique     one workgroup per partition: its keys go through a table that lives in LDS (8192 slots: 64-bit compare-and-swap claims a slot, a 32-bit
+//   hist       one pass over the key column: how many selected rows fall into each of P = 2^k partitions (the top k bits of a 32-bit hash of the key image),
+//              kept per SHARE — the chunks (= workgroups) whose number is equal mod 8, one XCD's as the dispatcher deals them out; an exclusive scan of the
+//              P x 8 counts (partition-major) is where every share of every partition starts
+//   partition  the same pass again: a workgroup sorts 8192 rows at a time by partition in LDS, reserves each partition's run behind its share's running position
+//              (one global atomicAdd per tile and partition: the workgroups of an XCD append to the SAME 512 places, so their runs follow each other and
+//              complete their 128-byte lines in that XCD's L2) and writes it: 12-byte records {key image, row}, every run one contiguous piece
+//   unique     one workgroup per partition: its records go through a table that lives in LDS (8192 slots: 64-bit compare-and-swap claims a slot, a 32-bit
 //              atomic minimum keeps the smallest row), and the occupied slots leave one bit each in the bitmap of first occurrences (+ per-tile counts)
-// 8 + (8 + 12) + 12 bytes per selected row, all sequential.  A partition that holds more distinct keys than its table takes raises a flag and the host
-// runs the hash-table form instead (query.cpp: unique_hashed); keys are isequal images (one NaN, -0.0 apart from 0.0), a missing key and the one image that
-// cannot be stored (all ones) are kept aside in aux[1] / aux[0] exactly as k_unique_insert keeps them.
+// 8 + (8 + 12) + 12 bytes per selected row, all sequential.  The order of a partition's records depends on timing; the result (smallest row per key) does not.
+// A partition that holds more distinct keys than its table takes raises a flag and the host runs the hash-table form instead (query.cpp: unique_hashed); keys
+// are isequal images (one NaN, -0.0 apart from 0.0), a missing key and the one image that cannot be stored (all ones) are kept aside in aux[1] / aux[0]
+// exactly as k_unique_insert keeps them.  Measured history: profiles/r6_unique_radix.txt; what the instruction and store choices rest on: tools/ubench/.
 #include <cstdlib>
 #include "device_utils.hpp"
 #include "kernels.hpp"
@@ -168,9 +171,9 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 // (Tried and dropped, profiles/r6_unique_radix.txt: ranks by ballots instead of LDS atomics that return a value — slower at 9-10 partition bits; whole 16-record
 // units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3;
 // 512-thread workgroups sorting 4096 rows, two per CU — shorter runs store slower than the overlap gains.)
-constexpr int kPartLdsWords = 3 * 1024 + 32 + kRTile;           // hist2, lstart, delta (1024 each: P <= 1024), wave sums, srow — in 4-byte words; skey follows
-template <int KIND>
-__global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
+constexpr int part_lds_words(int block) { return 3 * 1024 + 32 + 8 * block; }      // hist2, lstart, delta (1024 each), wave sums, srow — in 4-byte words; skey follows
+template <int KIND, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
                                                              uint32_t* __restrict__ front, uint32_t* __restrict__ recs_out, int xp) {
   extern __shared__ uint64_t part_sh[];
@@ -178,22 +181,23 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
   uint32_t* delta = lstart + 1024;                              // [1024] a slot's place in the output minus the slot (mod 2^32: fewer than 2^32 records)
   uint32_t* wsum = delta + 1024;                                // [16]   scan scratch: one total per wave
-  uint32_t* srow = wsum + 32;                                   // [8192] partition << 13 | the row's offset inside the tile
-  uint64_t* skey = (uint64_t*)(srow + kRTile);                  // [8192]
+  constexpr int TILE = 8 * BLOCK;                               // rows sorted at a time: 8192 (one workgroup per CU) or 4096 (two)
+  uint32_t* srow = wsum + 32;                                   // [TILE] partition << 13 | the row's offset inside the tile
+  uint64_t* skey = (uint64_t*)(srow + TILE);                    // [TILE]
   const int P = 1 << kbits, c = (int)blockIdx.x, sh = 32 - kbits;
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
   const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the running position of (partition p, this workgroup's share)
   const uint32_t obase = tid < P ? (uint32_t)offsets_T[fx] : 0u;  // ... and where that share of the partition starts
-  hist2[tid] = 0;
+  for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
   uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
-  if (r0 + kRTile <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
+  if (r0 + TILE <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
   else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
 #pragma unroll
   for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));      // (arrived before the loop is entered — see step 4: no wait for them may sit at the loop's top)
-  for (int64_t base = r0; base < r1; base += kRTile) {
+  for (int64_t base = r0; base < r1; base += TILE) {
     uint64_t key[8]; uint32_t pr[8];                            // pr: partition << 13 | rank among the tile's records of that partition; ~0 = the row takes no part
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -201,9 +205,9 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
       const uint64_t ok = keys_storable<KIND>(key[j]);
       if (__builtin_amdgcn_inverse_ballot_w64(nin[j] & ok)) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
     }
-    const int64_t nb = base + kRTile;
+    const int64_t nb = base + TILE;
     if (nb < r1) {
-      if (nb + kRTile <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
+      if (nb + TILE <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
       else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
     }
     __syncthreads();
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     __syncthreads();
     uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kRBlock / 64; w++) { const uint32_t t = wsum[w]; total += t; if (w < wv) before += t; }
+    for (int w = 0; w < BLOCK / 64; w++) { const uint32_t t = wsum[w]; total += t; if (w < wv) before += t; }
     const uint32_t ex = before + incl - h;
     uint32_t got = 0;
     if (tid < P) { lstart[tid] = ex; if (h) got = atomicAdd(&front[fx], h); }      // the tile's run of partition `tid`: reserved behind whatever the XCD's other workgroups reserved last
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     // 4. out: all the LDS reads, then the stores
     uint64_t ok[8]; uint32_t ow[8], od[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { ok[k] = skey[k * kRBlock + tid]; ow[k] = srow[k * kRBlock + tid]; }
+    for (int k = 0; k < 8; k++) { ok[k] = skey[k * BLOCK + tid]; ow[k] = srow[k * BLOCK + tid]; }
 #pragma unroll
     for (int k = 0; k < 8; k++) od[k] = delta[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
     // the next tile's keys are waited for HERE, before the first store is issued: loads and stores share one in-order counter (vmcnt), and a wait for the loads at
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_partition(const uint64_t* __r
     const uint32_t base32 = (uint32_t)base;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const uint32_t s = (uint32_t)(k * kRBlock + tid);
+      const uint32_t s = (uint32_t)(k * BLOCK + tid);
       if (s < total) {
         const uint32_t dst = od[k] + s;
         if (xp & 1) { if (ok[k] == 12345ull) recs_out[dst] = 1; continue; }              // (DFDB_RADIX_XP bit 0, timing only: no stores)
@@ -376,7 +380,7 @@ int64_t radix_rows_per_chunk(int64_t nrows, int chunks) {
   return (per + kRTile - 1) / kRTile * kRTile;              // whole tiles of the partition pass (and whole bitmap words)
 }
 static int radix_xp() { static const int v = [] { const char* e = getenv("DFDB_RADIX_XP"); return e ? atoi(e) : 0; }(); return v; }   // timing experiments only: results are WRONG with any bit set
-size_t radix_partition_lds_bytes(int) { return (size_t)kPartLdsWords * 4 + (size_t)kRTile * 8; }
+static size_t radix_partition_lds_bytes(int block) { return (size_t)part_lds_words(block) * 4 + (size_t)block * 8 * 8; }
 static int radix_kind(int dtype) { return dtype == DFDB_F64 ? kKindF64 : (dtype == DFDB_I64 || dtype == DFDB_U64 ? kKindRaw8 : kKindAny); }
 
 bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
@@ -391,20 +395,24 @@ bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int 
   }
   return true;
 }
+template <int KIND>
+static bool radix_partition_go(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
+                               const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out) {
+  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); return false; }
+  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
+                     radix_rows_per_chunk(nrows, chunks), kbits, offsets_T, front, recs_out, radix_xp());
+  return true;
+}
+// (512-thread workgroups sorting 4096 rows, two per CU, instead of one of 1024 sorting 8192: 5.36-5.43 ms against 5.32-5.33 — the pass waits for its stores either way)
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                             const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out) {
-  const size_t lds = radix_partition_lds_bytes(kbits);
-  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_partition<kKindRaw8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
-                               hipFuncSetAttribute((const void*)k_radix_partition<kKindF64>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
-                               hipFuncSetAttribute((const void*)k_radix_partition<kKindAny>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
-  if (!ok || kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) { (void)hipGetLastError(); return false; }
-  const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
+  if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
   switch (radix_kind(dtype)) {
-    case kKindRaw8: hipLaunchKernelGGL(k_radix_partition<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
-    case kKindF64: hipLaunchKernelGGL(k_radix_partition<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
-    default: hipLaunchKernelGGL(k_radix_partition<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, offsets_T, front, recs_out, radix_xp()); break;
+    case kKindRaw8: return radix_partition_go<kKindRaw8>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
+    case kKindF64: return radix_partition_go<kKindF64>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
+    default: return radix_partition_go<kKindAny>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
   }
-  return true;
 }
 int radix_share() { return kRShare; }
 bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits,

@@ -1335,9 +1335,9 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // its table): the caller goes on with the hash table; the selection is as it was.
 static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 2.1 + partition 7.2 + unique 3.6 ms = 14.2 ms end to end against the
-  // hash table's 20.0 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass is bound by its STORES (5 of its
-  // 7.3 ms: 16-record runs that start wherever the previous tile's ended: partial 128-byte lines), not by its rank atomics (0.8 ms).  On by default; option = 0: the hash table.
+  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 1.3 + partition 5.0-5.3 + unique 3.0 ms = 10.7-10.9 ms end to end against the
+  // hash table's 19.9 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass waits for its STORES (2.8 ms without
+  // them): 192-byte runs behind running positions that one XCD's workgroups share, so that whole lines leave that XCD's L2.  On by default; option = 0: the hash table.
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
   if (mode == 0 || t->nrows > (1ll << 32) || r0 == 0 || d0 == 0) return false;
   if (mode < 2 && cnt < (32ll << 20)) return false;                      // (2: a test knob — any size)

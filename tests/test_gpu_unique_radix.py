@@ -96,6 +96,36 @@ def test_radix_unique_is_first_appearance(dfdb_mod, ctx, kind):
         t.close()
 
 
+@pytest.mark.parametrize("dt", ["int8", "int16", "int32", "uint8", "uint16", "uint32", "float32", "uint64"])
+def test_radix_unique_narrow_and_unsigned_keys(dfdb_mod, ctx, dt):
+    """the keys that are not eight raw bytes (k_radix.hip kKindAny: rkey_fixed makes the image) and UInt64, over a table whose last tile is partial"""
+    rng = np.random.default_rng(11)
+    n = 1_300_007
+    if dt == "float32":
+        k = (rng.integers(0, 90_000, n).astype(np.float32) / np.float32(4.0))
+        k[rng.random(n) < 0.01] = np.nan
+        k[rng.random(n) < 0.01] = -0.0
+        u = k.view(np.uint32).astype(np.uint64); u[np.isnan(k)] = 0x7fc00000
+        img = u
+    elif dt == "uint64":
+        k = (rng.integers(0, 250_000, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        k[rng.random(n) < 0.001] = np.uint64(0xFFFFFFFFFFFFFFFF)          # the image the table cannot store
+        img = k.copy()
+    else:
+        info = np.iinfo(dt)
+        k = rng.integers(max(info.min, -60_000), min(info.max, 60_000) + 1, n).astype(dt)   # (-1 of a signed type is the unstorable image too)
+        img = k.astype(np.int64).view(np.uint64).copy()
+    a = rng.integers(0, 100, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "k": k}, block_size=65536, ctx=ctx)
+    try:
+        for view, sel in ((t[dfdb_mod.ALL, ["k"]], np.ones(n, bool)), (t[("a", lambda c: c < 37), ["k"]], a < 37)):
+            got, taken, fell = run_unique(dfdb_mod, t, view, 2)
+            assert taken == 1 and fell == 0, (dt, taken, fell)
+            assert np.array_equal(got, first_rows(img, sel)), dt
+    finally:
+        t.close()
+
+
 def test_radix_unique_small_tables_and_one_tile_partitions(dfdb_mod, ctx):
     for n in (1, 63, 1024, 8191, 8193, 70_001):
         k = (np.arange(n, dtype=np.int64) * 2_654_435_761) % max(1, n // 3 + 1)
