@@ -1378,6 +1378,19 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   { LaunchTimer lt(ctx, "radix_hist");
     if (!launch_radix_hist(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, counts_T.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
   launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), PS, scratch.as<uint64_t>());
+  // SKEW: one workgroup reduces one partition, so a partition that holds a large part of all the rows (a value that a third of the column has) would be one CU's
+  // work while 255 wait — 1.5 ms per average partition, i.e. 8 average partitions' worth of records already costs what the whole pass does.  The hash table takes such
+  // a column (the hot key's probes hit one cached line): the offsets come back (4 K words) and the largest partition is looked at before anything is written.
+  {
+    std::vector<uint64_t> off((size_t)PS + 1);
+    HIP_CHECK(hipMemcpyAsync(off.data(), offsets_T.p, ((size_t)PS + 1) * 8, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    const int S = radix_share();
+    uint64_t maxp = 0;
+    for (int p = 0; p < P; p++) maxp = std::max(maxp, off[(size_t)(p + 1) * S] - off[(size_t)p * S]);
+    const uint64_t total = off[(size_t)PS];
+    if (maxp > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "unique_radix.skewed"); return false; }
+  }
   { LaunchTimer lt(ctx, "radix_partition");
     if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), counts_T.as<uint32_t>() + PS, recs.as<uint32_t>())) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)

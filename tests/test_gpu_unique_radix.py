@@ -138,6 +138,30 @@ def test_radix_unique_small_tables_and_one_tile_partitions(dfdb_mod, ctx):
             t.close()
 
 
+def test_radix_unique_leaves_a_skewed_column_to_the_hash_table(dfdb_mod, ctx):
+    """a value that 40 % of the rows hold would make one partition — one workgroup's work — of 40 % of the records: the sizes are looked at after the hist pass and
+    the hash table answers (nothing was written: the selection is as it was)"""
+    rng = np.random.default_rng(5)
+    n = 3_000_011
+    k = (rng.integers(0, 400_000, n) * 7 + 11).astype(np.int64)
+    k[rng.random(n) < 0.4] = 123_456_789
+    t = dfdb_mod.DFTable.from_columns({"k": k}, block_size=65536, ctx=ctx)
+    try:
+        import dfdb._native as N
+        ctx.set_option("unique_dense", 0); ctx.set_option("unique_radix", 2); ctx.profile(True)
+        try:
+            q = t[dfdb_mod.ALL, ["k"]]._query()
+            N.check(N.load().dfdb_query_unique(q._h, 0))
+            rows = q.indices() - 1
+            skewed, taken = ctx.profile_get("unique_radix.skewed")[0], ctx.profile_get("unique_radix.taken")[0]
+        finally:
+            ctx.profile(False); ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 1)
+        assert (skewed, taken) == (1, 0)
+        assert np.array_equal(rows, first_rows(image(k), np.ones(n, bool)))
+    finally:
+        t.close()
+
+
 def test_radix_unique_partition_overflow_falls_back(dfdb_mod, ctx):
     """20 M distinct keys over 2048 partitions = ~9 800 per 8192-slot table: the unique pass raises its flag, the selection is put back and the hash table answers."""
     n = 20_000_000
