@@ -362,10 +362,12 @@ def test_random_groupreduce_and_unique(pair, dfdb_mod, seed):
     stat = g.pick(["count", "sum", "min", "max", "mean"])
     # every form of unique's machinery in turn (round 4): the defaults; the hash table only; a 1024-slot table fed one tile at a time (aborted chunks, migrations);
     # the dense form with a span of 100 values (keys outside the first placement, then the hash table for the wider columns), one-tile launches, the exact range
-    forms = [{}, {"unique_dense": 0}, {"unique_dense": 0, "unique_cap0_log2": 10, "unique_chunk_tiles": 1}, {"unique_dense_range": 100, "unique_chunk_tiles": 1, "unique_dense_sample": seed % 8 < 4}]
-    defaults = {"unique_dense": 1, "unique_cap0_log2": 21, "unique_chunk_tiles": 0, "unique_dense_range": 1 << 40, "unique_dense_sample": 1}
+    # (round 6) the radix-partitioned form at any size (k_radix.hip: fixed-width keys; the others go on to the hash table)
+    forms = [{}, {"unique_dense": 0}, {"unique_dense": 0, "unique_cap0_log2": 10, "unique_chunk_tiles": 1}, {"unique_dense_range": 100, "unique_chunk_tiles": 1, "unique_dense_sample": seed % 8 < 4},
+             {"unique_dense": 0, "unique_radix": 2}]
+    defaults = {"unique_dense": 1, "unique_cap0_log2": 21, "unique_chunk_tiles": 0, "unique_dense_range": 1 << 40, "unique_dense_sample": 1, "unique_radix": 1}
     ctx0 = dfdb_mod.default_context(0)
-    for k, v in {**defaults, **forms[seed % 4]}.items():
+    for k, v in {**defaults, **forms[seed % 5]}.items():
         ctx0.set_option(k, int(v))
     try:
         _groupreduce_and_unique_case(pair, dfdb_mod, g, stages, key, val, stat)

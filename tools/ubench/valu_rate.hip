@@ -9,7 +9,7 @@ constexpr int kIters = 2048;
 #define BODY8(ASM32) \
   for (int i = 0; i < kIters; i++) { \
     asm volatile(ASM32(0) ASM32(1) ASM32(2) ASM32(3) ASM32(4) ASM32(5) ASM32(6) ASM32(7) \
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(k), "s"(sk)); }
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(k), "s"(sk) : "vcc", "s20", "s21", "s22"); }
 #define KERNEL32(NAME, ASM32) \
   __global__ __launch_bounds__(512) void NAME(unsigned* out, unsigned k, unsigned sk) { \
     unsigned a[8]; for (int j = 0; j < 8; j++) a[j] = threadIdx.x * 8 + j + k; \
@@ -30,10 +30,26 @@ constexpr int kIters = 2048;
 #define A_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 3, 9\n"
 #define A_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %" #n ", 13\n"
 #define A_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CNDS(n) "v_cndmask_b32 %" #n ", %" #n ", %8, s[20:21]\n"
+#define A_CMPCND(n) "v_cmp_gt_u32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CMPCND2(n) "v_cmp_gt_u32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\nv_cndmask_b32 %" #n ", %8, %" #n ", vcc\n"
+#define A_CMPCND4(n) "v_cmp_gt_u32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\nv_cndmask_b32 %" #n ", %8, %" #n ", vcc\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\nv_cndmask_b32 %" #n ", %8, %" #n ", vcc\n"
+#define A_CMPSCND2(n) "v_cmp_gt_u32 s[20:21], %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %8, s[20:21]\nv_cndmask_b32 %" #n ", %8, %" #n ", s[20:21]\n"
+#define A_MIN(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define A_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define A_LSHR(n) "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
+#define A_LSHRV(n) "v_lshrrev_b32 %" #n ", %8, %" #n "\n"
+#define A_SUB(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define A_ADDCO(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %8\n"
+#define A_BFI(n) "v_bfi_b32 %" #n ", %" #n ", %8, %8\n"
+#define A_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define A_READLANE(n) "v_readlane_b32 s22, %" #n ", 5\n"
 #define A_MADU32(n) "v_mad_u64_u32 v[40:41], vcc, %" #n ", %8, v[40:41]\n"
 KERNEL32(k_add, A_ADD) KERNEL32(k_mul, A_MUL) KERNEL32(k_muls, A_MULS) KERNEL32(k_mulhi, A_MULHI) KERNEL32(k_mul24, A_MUL24) KERNEL32(k_mad24, A_MAD24)
 KERNEL32(k_xor, A_XOR) KERNEL32(k_lshladd, A_LSHLADD) KERNEL32(k_lshlor, A_LSHLOR) KERNEL32(k_andor, A_ANDOR) KERNEL32(k_add3, A_ADD3) KERNEL32(k_xad, A_XAD)
-KERNEL32(k_bfe, A_BFE) KERNEL32(k_alignbit, A_ALIGNBIT) KERNEL32(k_cndmask, A_CNDMASK)
+KERNEL32(k_bfe, A_BFE) KERNEL32(k_alignbit, A_ALIGNBIT) KERNEL32(k_cndmask, A_CNDMASK) KERNEL32(k_cnds, A_CNDS) KERNEL32(k_cmpcnd, A_CMPCND) KERNEL32(k_cmpcnd2, A_CMPCND2) KERNEL32(k_cmpcnd4, A_CMPCND4) KERNEL32(k_cmpscnd2, A_CMPSCND2) KERNEL32(k_min, A_MIN) KERNEL32(k_and, A_AND)
+KERNEL32(k_lshr, A_LSHR) KERNEL32(k_lshrv, A_LSHRV) KERNEL32(k_sub, A_SUB) KERNEL32(k_addco, A_ADDCO) KERNEL32(k_perm, A_PERM) KERNEL32(k_bfi, A_BFI) KERNEL32(k_mov, A_MOV) KERNEL32(k_readlane, A_READLANE)
 // 64-bit kinds: four chains of register pairs
 #define KERNEL64(NAME, ASM) \
   __global__ __launch_bounds__(512) void NAME(unsigned* out, unsigned k, unsigned sk) { \
@@ -59,7 +75,9 @@ int main() {
   struct K { const char* name; void (*f)(unsigned*, unsigned, unsigned); int per_trip; };
   std::vector<K> ks = {{"v_add_u32", k_add, 8}, {"v_mul_lo_u32", k_mul, 8}, {"v_mul_lo_u32 (sgpr operand)", k_muls, 8}, {"v_mul_hi_u32", k_mulhi, 8}, {"v_mul_u32_u24", k_mul24, 8}, {"v_mad_u32_u24", k_mad24, 8},
                        {"v_xor_b32", k_xor, 8}, {"v_lshl_add_u32", k_lshladd, 8}, {"v_lshl_or_b32", k_lshlor, 8}, {"v_and_or_b32", k_andor, 8}, {"v_add3_u32", k_add3, 8}, {"v_xad_u32", k_xad, 8},
-                       {"v_bfe_u32", k_bfe, 8}, {"v_alignbit_b32", k_alignbit, 8}, {"v_cndmask_b32", k_cndmask, 8},
+                       {"v_bfe_u32", k_bfe, 8}, {"v_alignbit_b32", k_alignbit, 8}, {"v_cndmask_b32 (vcc)", k_cndmask, 8}, {"v_cndmask_b32 (sgpr pair)", k_cnds, 8}, {"v_cmp_gt_u32 + v_cndmask", k_cmpcnd, 16}, {"v_cmp + 2 v_cndmask (vcc)", k_cmpcnd2, 24}, {"v_cmp + 4 v_cndmask (vcc)", k_cmpcnd4, 40}, {"v_cmp + 2 v_cndmask (sgpr pair)", k_cmpscnd2, 24},
+                       {"v_min_u32", k_min, 8}, {"v_and_b32", k_and, 8}, {"v_lshrrev_b32 (imm)", k_lshr, 8}, {"v_lshrrev_b32 (vgpr)", k_lshrv, 8}, {"v_sub_u32", k_sub, 8}, {"v_add_co_u32", k_addco, 8},
+                       {"v_perm_b32", k_perm, 8}, {"v_bfi_b32", k_bfi, 8}, {"v_mov_b32", k_mov, 8}, {"v_readlane_b32", k_readlane, 8},
                        {"v_lshl_add_u64", k_lshladd64, 8}, {"v_lshrrev_b64", k_lshr64, 8}, {"v_lshlrev_b64", k_lshl64, 8}, {"v_cmp_eq_u64", k_cmp64, 8}, {"v_cmp_gt_u64", k_cmpgt64, 8}, {"v_cmp_eq_u32", k_cmp32, 8},
                        {"v_mad_u64_u32", k_mad64, 8}};
   for (auto& k : ks) {
