@@ -27,6 +27,7 @@ constexpr int kRBlock = 1024;                 // threads per workgroup of all th
 constexpr int kRTile = 8192;                  // rows sorted at a time by the partition pass (8 per thread)
 constexpr int kRSlots = 8192;                 // slots of a partition's table in LDS
 constexpr uint64_t kREmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kRPage = 8192;                   // records per page of the record pool (a tile's run of a partition — at most 8192 records — lies in at most two)
 constexpr int kRShare = 8;                    // the workgroups whose number is equal mod 8 — one XCD's, as the dispatcher deals them out — share their running positions
 // 32 bits of hash per key, three 32-bit multiplies (k_unique.hip lds_slot_of's mix; splitmix64's two 64-bit multiplies are eight quarter-rate instructions each and
 // the partition pass hashed every row twice: 3.4e9 vector instructions per 1e9 rows).  The partition is its TOP bits, a table slot its low bits.
@@ -130,57 +131,54 @@ template <int KIND> __device__ __forceinline__ uint64_t keys_storable(uint64_t& 
   return __ballot(k != kREmpty);                                // (called with every lane active: the compare's result as it stands)
 }
 
-// ---- pass 1: counts[p * 8 + x] = selected rows whose key falls into partition p, over the chunks c with c mod 8 = x (kRShare = 8: see the partition pass)
+// ---- the SAMPLE: counts[p] = selected rows whose key falls into partition p among every `step`-th tile (query.cpp looks at the largest partition before anything
+// is written: a skewed column is the hash table's).  The partition pass needs no counts: it takes pages from a pool as it goes.
 template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
-                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, uint64_t* aux) {
+                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, int step) {
   extern __shared__ uint32_t hist_sh[];
   const int P = 1 << kbits, c = (int)blockIdx.x;
   for (int p = threadIdx.x; p < P; p += kRBlock) hist_sh[p] = 0;
   __syncthreads();
   const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), sh = 32 - kbits;
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
-  for (int64_t base = r0; base < r1; base += kRTile) {
+  for (int64_t base = r0 + (int64_t)(c % step) * kRTile; base < r1; base += (int64_t)kRTile * step) {
     uint64_t key[8], in[8];
-    const uint64_t sm = base + kRTile <= nrows ? tile_load<KIND, true>(key, in, sel, col, dtype, missing, base, nrows, wv, lane)
-                                               : tile_load<KIND, false>(key, in, sel, col, dtype, missing, base, nrows, wv, lane);
-    if (sm) tile_first_missing(sel, missing, base, nrows, wv, lane, aux);
-    uint64_t unstorable = 0;
+    if (base + kRTile <= nrows) tile_load<KIND, true>(key, in, sel, col, dtype, missing, base, nrows, wv, lane);
+    else tile_load<KIND, false>(key, in, sel, col, dtype, missing, base, nrows, wv, lane);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const uint64_t ok = keys_storable<KIND>(key[j]);
-      unstorable |= in[j] & ~ok;
       if (__builtin_amdgcn_inverse_ballot_w64(in[j] & ok)) atomicAdd(&hist_sh[rhash(key[j]) >> sh], 1u);
-    }
-    if (unstorable) {                                             // (rare — but -1 in an Int64 column is this image: one lane of the wave reports the first such row)
-      for (int j = 0; j < 8; j++) {
-        const uint64_t bad = in[j] & ~keys_storable<KIND>(key[j]);
-        if (bad) { if (lane == 0) aux_min(&aux[0], (uint64_t)(base + wv * 512 + j * 64 + __builtin_ctzll(bad))); break; }
-      }
     }
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < P; p += kRBlock) { const uint32_t h = hist_sh[p]; if (h) atomicAdd(&counts_T[p * kRShare + (c & (kRShare - 1))], h); }
+  for (int p = threadIdx.x; p < P; p += kRBlock) { const uint32_t h = hist_sh[p]; if (h) atomicAdd(&counts_T[p], h); }
 }
 
-// ---- pass 2: the records of chunk c, sorted by partition 8192 rows at a time, to their places
+// ---- pass 1: the records of chunk c, sorted by partition 8192 rows at a time, to their places
 // Per tile: (1) every row's partition and its rank among the tile's rows of that partition (an LDS atomic that returns a value), the NEXT tile's loads issued;
-// (2) thread p < P scans the tile's counts: where partition p's run starts in the sorted tile (lstart) and how far the run's slots are from their places in the
-// chunk's share of partition p (delta = the running position, kept in thread p's register, minus lstart); (3) the records into LDS, sorted by partition;
-// (4) slot s to delta[its partition] + s — each partition's run a contiguous store.  Four barriers per tile.
+// (2) thread p < P scans the tile's counts: where partition p's run starts in the sorted tile (lstart), and reserves the run behind the running position of its
+// STREAM (partition p, the workgroup's share) with one global atomicAdd; (3) the records into LDS, sorted by partition; thread p turns the reserved position
+// into places in the record pool; (4) slot s to its place — each partition's run a contiguous store.  Four barriers per tile.
+// The pool (no counting pass: the first build read the column once more, 1.3 ms, only to size the partitions): a stream's records are numbered 0, 1, 2 … by the
+// reservations, every 8192 of them are a PAGE, and pt[stream][k] is where the stream's k-th page lies in the pool.  The thread whose run holds a page's first
+// record takes the page (an atomicAdd on the pool's counter) and publishes it; a thread whose run lies in a page somebody else's run began waits for that
+// entry.  All the taking is done before any of the waiting (the thread that has to publish never waits for anybody first), so nothing can wait in a circle.
+// A stream that needs more pages than the table has columns (a value that a large part of the column holds) raises the abort flag: the hash table answers.
 // (Tried and dropped, profiles/r6_unique_radix.txt: ranks by ballots instead of LDS atomics that return a value — slower at 9-10 partition bits; whole 16-record
 // units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3;
 // 512-thread workgroups sorting 4096 rows, two per CU — shorter runs store slower than the overlap gains.)
-constexpr int part_lds_words(int block) { return 3 * 1024 + 32 + 8 * block; }      // hist2, lstart, delta (1024 each), wave sums, srow — in 4-byte words; skey follows
+constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }      // hist2, lstart (1024 each), place (1024 x 16 bytes), wave sums, srow — in 4-byte words; skey follows
 template <int KIND, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
-                                                             int64_t nrows, int64_t rows_per_chunk, int kbits, const uint64_t* __restrict__ offsets_T,
-                                                             uint32_t* __restrict__ front, uint32_t* __restrict__ recs_out, int xp) {
+                                                             int64_t nrows, int64_t rows_per_chunk, int kbits, RadixPool pool,
+                                                             uint32_t* __restrict__ recs_out, uint64_t* aux, int xp) {
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
-  uint32_t* delta = lstart + 1024;                              // [1024] a slot's place in the output minus the slot (mod 2^32: fewer than 2^32 records)
-  uint32_t* wsum = delta + 1024;                                // [16]   scan scratch: one total per wave
+  uint4* place = (uint4*)(lstart + 1024);                       // [1024] {d0, d1, slim}: sorted slot s of the partition goes to pool record s + (s < slim ? d0 : d1)
+  uint32_t* wsum = (uint32_t*)(place + 1024);                   // [16]   scan scratch: one total per wave
   constexpr int TILE = 8 * BLOCK;                               // rows sorted at a time: 8192 (one workgroup per CU) or 4096 (two)
   uint32_t* srow = wsum + 32;                                   // [TILE] partition << 13 | the row's offset inside the tile
   uint64_t* skey = (uint64_t*)(srow + TILE);                    // [TILE]
@@ -188,27 +186,37 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
-  const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the running position of (partition p, this workgroup's share)
-  const uint32_t obase = tid < P ? (uint32_t)offsets_T[fx] : 0u;  // ... and where that share of the partition starts
+  const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the stream (partition p, this workgroup's share)
   for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
   uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
-  if (r0 + TILE <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
-  else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
+  uint32_t pk = 0xFFFFFFFFu, pb = 0;                            // thread p < P: the page of its stream its last run ended in, and where that page lies
+  uint64_t nmiss;                                               // (wave-uniform) selected rows of the next tile whose key is missing
+  if (r0 + TILE <= nrows) nmiss = tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
+  else nmiss = tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
 #pragma unroll
   for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));      // (arrived before the loop is entered — see step 4: no wait for them may sit at the loop's top)
   for (int64_t base = r0; base < r1; base += TILE) {
     uint64_t key[8]; uint32_t pr[8];                            // pr: partition << 13 | rank among the tile's records of that partition; ~0 = the row takes no part
+    uint64_t unstorable = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       key[j] = nkey[j]; pr[j] = ~0u;
       const uint64_t ok = keys_storable<KIND>(key[j]);
+      unstorable |= nin[j] & ~ok;
       if (__builtin_amdgcn_inverse_ballot_w64(nin[j] & ok)) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
+    }
+    if (nmiss) tile_first_missing(sel, missing, base, nrows, wv, lane, aux);       // (rare: the two keys kept aside — a missing key's first row, aux[1]; ...
+    if (unstorable) {                                           // ... the unstorable image's, aux[0]: -1 in an Int64 column is that image; one lane of the wave reports)
+      for (int j = 0; j < 8; j++) {
+        const uint64_t bad = nin[j] & ~keys_storable<KIND>(key[j]);
+        if (bad) { if (lane == 0) aux_min(&aux[0], (uint64_t)(base + wv * 512 + j * 64 + __builtin_ctzll(bad))); break; }
+      }
     }
     const int64_t nb = base + TILE;
     if (nb < r1) {
-      if (nb + TILE <= nrows) tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
-      else tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
+      if (nb + TILE <= nrows) nmiss = tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
+      else nmiss = tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, nb, nrows, wv, lane);
     }
     __syncthreads();
     if (xp & 8) continue;                                       // (bit 3, timing only: loads and ranks only)
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     for (int w = 0; w < BLOCK / 64; w++) { const uint32_t t = wsum[w]; total += t; if (w < wv) before += t; }
     const uint32_t ex = before + incl - h;
     uint32_t got = 0;
-    if (tid < P) { lstart[tid] = ex; if (h) got = atomicAdd(&front[fx], h); }      // the tile's run of partition `tid`: reserved behind whatever the XCD's other workgroups reserved last
+    if (tid < P) { lstart[tid] = ex; if (h) got = atomicAdd(&pool.front[fx], h); } // the tile's run of partition `tid`: reserved behind whatever the XCD's other workgroups reserved last
     __syncthreads();
     if (xp & 4) continue;                                       // (bit 2, timing only: ranks and scan only)
     // 3. the tile's records into LDS, sorted by partition (the eight reads of lstart first, unconditionally: a branch per row made each wait for its own)
@@ -239,15 +247,47 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
         skey[slot] = key[j];
         srow[slot] = (pr[j] & ~8191u) | (uint32_t)(wv * 512 + j * 64 + lane);
       }
-    if (tid < P) delta[tid] = obase + got - ex;                 // (the atomic's answer is waited for here, behind the sort)
+    // the reserved positions [got, got + h) of the stream as places in the pool (the atomic's answer is waited for here, behind the sort)
+    if (tid < P && h) {
+      const uint32_t k0 = got >> 13, k1 = (got + h - 1u) >> 13;                 // the stream's pages the run lies in (k1 = k0 or k0 + 1)
+      uint32_t* e0 = pool.pt + (size_t)fx * pool.maxv + k0;
+      uint32_t b0 = pool.dump_page, b1 = pool.dump_page;
+      const bool over = k1 >= pool.maxv;
+      if (over) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED);             // aux[kAuxAbort]: this column needs the hash-table form (the records go to the spare page)
+      // first the taking ...  (publishing and reading the page table are read-modify-write atomics — exchanged, OR-ed with zero —: they are performed where the
+      // other XCDs' are; an acquiring LOAD per thread and tile invalidated the CU's caches 512 times a tile and the pass took 19 ms)
+      if (!over && k1 != k0) { b1 = atomicAdd(pool.next_page, 1u); atomicExch(e0 + 1, b1); }
+      const bool mine = (got & 8191u) == 0u;
+      if (!over && mine) { b0 = atomicAdd(pool.next_page, 1u); atomicExch(e0, b0); }
+      // ... then the waiting (the page of the thread's last run is remembered: a stream's page takes 512 runs, a sixteenth of them this workgroup's)
+      if (!over && !mine) {
+        if (k0 == pk) b0 = pb;
+        else {
+          uint32_t spins = 0;                                                   // (bounded: a page that never comes — it cannot — would end in the abort flag, not in a hang)
+          while ((b0 = atomicOr(e0, 0u)) == 0xFFFFFFFFu) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); b0 = pool.dump_page; break; }
+          }
+        }
+      }
+      if (k1 == k0) b1 = b0;
+      pk = k1; pb = b1;
+      // sorted slot s (ex <= s < ex + h) is the stream's record got + (s - ex): in page k0 while that is below (k0 + 1) * 8192
+      uint4 pl;
+      pl.x = (b0 << 13) + (got & 8191u) - ex;                                   // s + d0: its place in page k0
+      pl.y = (b1 << 13) + got - ex - (k1 << 13);                                // s + d1: in page k1
+      pl.z = ex + ((k0 + 1u) << 13) - got;                                      // slim: the first slot that lies in page k1
+      pl.w = 0;
+      place[tid] = pl;
+    }
     __syncthreads();
     if (xp & 2) continue;                                       // (bit 1, timing only: nothing after the sort)
     // 4. out: all the LDS reads, then the stores
-    uint64_t ok[8]; uint32_t ow[8], od[8];
+    uint64_t ok[8]; uint32_t ow[8]; uint4 od[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { ok[k] = skey[k * BLOCK + tid]; ow[k] = srow[k * BLOCK + tid]; }
 #pragma unroll
-    for (int k = 0; k < 8; k++) od[k] = delta[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
+    for (int k = 0; k < 8; k++) od[k] = place[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
     // the next tile's keys are waited for HERE, before the first store is issued: loads and stores share one in-order counter (vmcnt), and a wait for the loads at
     // the top of the next step would also be a wait for the sixteen stores issued after them — a tile's store latency, every tile
 #pragma unroll
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     for (int k = 0; k < 8; k++) {
       const uint32_t s = (uint32_t)(k * BLOCK + tid);
       if (s < total) {
-        const uint32_t dst = od[k] + s;
+        const uint32_t dst = s + (s < od[k].z ? od[k].x : od[k].y);
         if (xp & 1) { if (ok[k] == 12345ull) recs_out[dst] = 1; continue; }              // (DFDB_RADIX_XP bit 0, timing only: no stores)
         // one 12-byte record {key image, row}: a partition's run of a tile is ONE piece of 192 bytes, not 128 + 64 in two arrays (the pass waits for its
         // stores, and what they cost goes by the number of pieces: tools/ubench/scatter_runs.hip; as nontemporal stores: 7.4 ms instead of 6.15)
@@ -294,16 +334,16 @@ __device__ __forceinline__ void table_claim(uint64_t* tkey, uint32_t* trow, uint
 }
 // four records of a thread: FULL = all four exist; otherwise a record past the partition's end reads the last one again and is made the empty image afterwards
 template <bool FULL>
-__device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], const uint32_t* __restrict__ rp, int64_t i0, int64_t n, int tid) {
+__device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], const uint32_t* __restrict__ rp, uint32_t n, int tid) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int64_t i = i0 + j * kRBlock + tid;
-    const Rec12 r = *(const Rec12*)(rp + (FULL || i < n ? i : n - 1) * 3);
+    const uint32_t i = (uint32_t)(j * kRBlock + tid);
+    const Rec12 r = *(const Rec12*)(rp + (size_t)(FULL || i < n ? i : n - 1u) * 3);
     kk[j] = (uint64_t)r.hi << 32 | r.lo; rw[j] = r.row;
   }
 }
-__global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __restrict__ recs, const uint64_t* __restrict__ offsets_T,
-                                                          int P, int C, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux, int xp) {
+__global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __restrict__ recs, RadixPool pool,
+                                                          int P, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux, int xp) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kRSlots]
   uint32_t* trow = (uint32_t*)(tkey + kRSlots);               // [kRSlots]
@@ -314,23 +354,37 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __rest
   for (int p = (int)blockIdx.x; p < P; p += (int)gridDim.x) {
     uint32_t qn = 0;                                          // (wave-uniform)
     for (int i = tid; i < kRSlots; i += kRBlock) { tkey[i] = kREmpty; trow[i] = 0xFFFFFFFFu; }
-    if (tid == 0) { claims_sh = 0; abort_sh = 0; }
+    if (tid == 0) { claims_sh = 0; abort_sh = __atomic_load_n(&aux[3], __ATOMIC_RELAXED) != 0; }
     __syncthreads();
-    const uint64_t a = offsets_T[(size_t)p * C], b = offsets_T[(size_t)(p + 1) * C];      // (offsets_T[P * C] = all the records: the scan's total)
-    const int64_t n = (int64_t)(b - a);
-    const uint32_t* rp = recs + a * 3;
+    if (abort_sh) return;                                     // (the partition pass gave up on a stream: the hash table answers)
+    // the partition's records: its kRShare streams one after the other, a stream page by page, a page in two blocks of 4096 records (all wave-uniform)
+    int sx = -1; uint32_t soff = 0, sn = 0;                   // the stream being read, where its next block starts, its records
+    auto next_block = [&](const uint32_t*& bp, uint32_t& bc) {
+      while (sx < kRShare && soff >= sn) {
+        sx++; soff = 0;
+        sn = sx < kRShare ? pool.front[p * kRShare + sx] : 0u;
+        if ((uint64_t)sn > (uint64_t)pool.maxv * kRPage) sn = 0;                 // (the partition pass raised the flag for this stream)
+      }
+      if (sx >= kRShare) { bc = 0; return; }
+      const uint32_t pg = pool.pt[(size_t)(p * kRShare + sx) * pool.maxv + (soff >> 13)];
+      bp = recs + ((size_t)pg * kRPage + (soff & (uint32_t)(kRPage - 1))) * 3;
+      bc = sn - soff < 4u * kRBlock ? sn - soff : 4u * kRBlock;
+      soff += 4u * kRBlock;
+    };
+    const uint32_t* cp = recs; uint32_t cc = 0;
+    next_block(cp, cc);
     uint64_t nk[4]; uint32_t nr[4];                           // the NEXT four records: loaded while these four go through the table
-    if (n > 0) { if (4 * kRBlock <= n) recs_load<true>(nk, nr, rp, 0, n, tid); else recs_load<false>(nk, nr, rp, 0, n, tid); }
-    for (int64_t i0 = 0; i0 < n; i0 += 4 * kRBlock) {
+    if (cc) { if (cc == 4u * kRBlock) recs_load<true>(nk, nr, cp, cc, tid); else recs_load<false>(nk, nr, cp, cc, tid); }
+    while (cc) {
       uint64_t kk[4]; uint32_t rw[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) { kk[j] = nk[j]; rw[j] = nr[j]; }
-      if (i0 + 4 * kRBlock > n) {
+      if (cc != 4u * kRBlock) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (i0 + j * kRBlock + tid >= n) { kk[j] = kREmpty; rw[j] = 0xFFFFFFFFu; }       // (no record holds the empty image)
+        for (int j = 0; j < 4; j++) if ((uint32_t)(j * kRBlock + tid) >= cc) { kk[j] = kREmpty; rw[j] = 0xFFFFFFFFu; }       // (no record holds the empty image)
       }
-      const int64_t i1 = i0 + 4 * kRBlock;
-      if (i1 < n) { if (i1 + 4 * kRBlock <= n) recs_load<true>(nk, nr, rp, i1, n, tid); else recs_load<false>(nk, nr, rp, i1, n, tid); }
+      next_block(cp, cc);
+      if (cc) { if (cc == 4u * kRBlock) recs_load<true>(nk, nr, cp, cc, tid); else recs_load<false>(nk, nr, cp, cc, tid); }
       if (xp & 32) { if ((kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) == 12345ull && (rw[0] ^ rw[1] ^ rw[2] ^ rw[3]) == 77u) abort_sh = 1; continue; }   // (DFDB_RADIX_XP bit 5, timing only: the loads alone)
       uint32_t hb[4]; ulonglong2 tt[4]; uint2 qq[4];
 #pragma unroll
@@ -382,47 +436,51 @@ int64_t radix_rows_per_chunk(int64_t nrows, int chunks) {
 static int radix_xp() { static const int v = [] { const char* e = getenv("DFDB_RADIX_XP"); return e ? atoi(e) : 0; }(); return v; }   // timing experiments only: results are WRONG with any bit set
 static size_t radix_partition_lds_bytes(int block) { return (size_t)part_lds_words(block) * 4 + (size_t)block * 8 * 8; }
 static int radix_kind(int dtype) { return dtype == DFDB_F64 ? kKindF64 : (dtype == DFDB_I64 || dtype == DFDB_U64 ? kKindRaw8 : kKindAny); }
+int radix_share() { return kRShare; }
+// the record pool for `cnt` selected rows in 2^kbits partitions: every stream (partition, share) ends in a page that is not full, one page is nobody's
+// (where a stream that gave up puts its records); a stream may take `maxv` pages: 16 times its even share — the sample already turned skewed columns away
+int64_t radix_pool_pages(int64_t cnt, int kbits) { return (cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) + 1; }
+int64_t radix_pool_record_bytes(int64_t cnt, int kbits) { return radix_pool_pages(cnt, kbits) * kRPage * 12; }
+uint32_t radix_pool_maxv(int64_t cnt, int kbits) { const int64_t even = ((cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) - 1) / ((int64_t)kRShare << kbits); return (uint32_t)(16 * even + 16); }
 
-bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                       uint32_t* counts_T, uint64_t* aux) {
-  if (kbits < 6 || kbits > 10 || nrows < 1) return false;
+bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks, int step,
+                         uint32_t* counts) {
+  if (kbits < 6 || kbits > 10 || nrows < 1 || step < 1) return false;
   const int64_t rpc = radix_rows_per_chunk(nrows, chunks);
   const size_t lds = ((size_t)1 << kbits) * 4;
   switch (radix_kind(dtype)) {
-    case kKindRaw8: hipLaunchKernelGGL(k_radix_hist<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
-    case kKindF64: hipLaunchKernelGGL(k_radix_hist<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
-    default: hipLaunchKernelGGL(k_radix_hist<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts_T, aux); break;
+    case kKindRaw8: hipLaunchKernelGGL(k_radix_hist<kKindRaw8>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts, step); break;
+    case kKindF64: hipLaunchKernelGGL(k_radix_hist<kKindF64>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts, step); break;
+    default: hipLaunchKernelGGL(k_radix_hist<kKindAny>, dim3(chunks), dim3(kRBlock), lds, s, sel, col, dtype, missing, nrows, rpc, kbits, counts, step); break;
   }
   return true;
 }
 template <int KIND>
 static bool radix_partition_go(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                               const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out) {
+                               const RadixPool& pool, uint32_t* recs_out, uint64_t* aux) {
   static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); return false; }
   hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
-                     radix_rows_per_chunk(nrows, chunks), kbits, offsets_T, front, recs_out, radix_xp());
+                     radix_rows_per_chunk(nrows, chunks), kbits, pool, recs_out, aux, radix_xp());
   return true;
 }
 // (512-thread workgroups sorting 4096 rows, two per CU, instead of one of 1024 sorting 8192: 5.36-5.43 ms against 5.32-5.33 — the pass waits for its stores either way)
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out) {
+                            const RadixPool& pool, uint32_t* recs_out, uint64_t* aux) {
   if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
   switch (radix_kind(dtype)) {
-    case kKindRaw8: return radix_partition_go<kKindRaw8>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
-    case kKindF64: return radix_partition_go<kKindF64>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
-    default: return radix_partition_go<kKindAny>(s, sel, col, dtype, missing, nrows, kbits, chunks, offsets_T, front, recs_out);
+    case kKindRaw8: return radix_partition_go<kKindRaw8>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
+    case kKindF64: return radix_partition_go<kKindF64>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
+    default: return radix_partition_go<kKindAny>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
   }
 }
-int radix_share() { return kRShare; }
-bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits,
-                         uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus) {
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus) {
   const size_t lds = (size_t)kRSlots * 12 + (size_t)(kRBlock / 64) * kRQueue * 12;
   static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_unique, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   const int grid = P < cus ? P : cus;                       // one 96-KB table per CU at a time
-  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, offsets_T, P, kRShare, bitmap, tile_counts, aux, radix_xp());
+  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, pool, P, bitmap, tile_counts, aux, radix_xp());
   return true;
 }
 

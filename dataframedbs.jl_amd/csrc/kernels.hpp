@@ -158,17 +158,21 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
                        const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
                        uint64_t* aux, uint64_t salt);
 // dense form.  aux words: 1 = smallest missing row, 5 = a key outside [lo, lo + range) was met, 6 = distinct keys, 7 = keys whose first row is known, 8 / 9 = min / max image
-// radix-partitioned form of the hash-table unique (k_radix.hip): hist -> scan -> partition -> one LDS table per partition.  false: the launch is not possible
-// (LDS attribute refused, too many partition bits): the caller stays with the hash table.  counts / offsets are [2^kbits][radix_share()] (+ 1), partition-major:
-// the workgroups (chunks) whose number is equal mod radix_share() fill one share of every partition together (`front`: their running positions, zero before the pass).
+// radix-partitioned form of the hash-table unique (k_radix.hip): sample -> partition into a pool of pages -> one LDS table per partition.  false: the launch is
+// not possible (LDS attribute refused, too many partition bits): the caller stays with the hash table.  The pool: `front` [2^kbits x radix_share()] running
+// positions of the streams (zero before the pass), `pt` [2^kbits x radix_share()][maxv] the streams' pages (all ones before the pass), `next_page` the pool's
+// counter (zero), `dump_page` the page nobody owns (radix_pool_pages() - 1); the records' buffer holds radix_pool_record_bytes().
+struct RadixPool { uint32_t* front; uint32_t* pt; uint32_t* next_page; uint32_t maxv; uint32_t dump_page; };
 int64_t radix_rows_per_chunk(int64_t nrows, int chunks);
-bool launch_radix_hist(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                       uint32_t* counts_T, uint64_t* aux);
-bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const uint64_t* offsets_T, uint32_t* front, uint32_t* recs_out /* 12 bytes per record: key image, row */);
 int radix_share();
-bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const uint64_t* offsets_T, int kbits,
-                         uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus);
+int64_t radix_pool_pages(int64_t cnt, int kbits);
+int64_t radix_pool_record_bytes(int64_t cnt, int kbits);
+uint32_t radix_pool_maxv(int64_t cnt, int kbits);
+bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks, int step,
+                         uint32_t* counts /* [2^kbits], zero before */);
+bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
+                            const RadixPool& pool, uint32_t* recs_out /* 12 bytes per record: key image, row */, uint64_t* aux);
+bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus);
 int64_t unique_dense_max_range();
 bool unique_dense_dtype(int dtype);
 void launch_dense_minmax(hipStream_t s, const uint64_t* bitmap, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int64_t tile_step, uint64_t* aux);

@@ -1354,7 +1354,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
   const int P = 1 << kbits;
   const int C = round_up(4 * std::max(1, ctx->prop.multiProcessorCount), radix_share());      // chunks = workgroups of the hist and partition passes
-  const int64_t PS = (int64_t)P * radix_share();                        // (partition, share) pairs: what the counts, their scan and the running positions are kept by
+  const int64_t PS = (int64_t)P * radix_share();                        // streams: (partition, share) pairs — the workgroups whose number is equal mod radix_share() fill one share together
   const int dt = dt_base(col.dtype);
   const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
   const int64_t nt = ceil_div(t->nrows, kTileRows);
@@ -1364,35 +1364,41 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   // (the call's temporaries go back to the buffer pool, not through hipFree — which drains the device and took ~1.5 ms of a 16-ms call for the 125-MB copy of the
   // selection alone; the stream is drained first: nothing in flight may still touch them)
   struct Temps {
-    dfdb_ctx* ctx; DevBuf counts_T, offsets_T, scratch, sel_keep, tc_keep;
-    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; counts_T.release(); offsets_T.release(); scratch.release(); sel_keep.release(); tc_keep.release(); }
-  } tmp{ctx, {}, {}, {}, {}, {}};
-  DevBuf &counts_T = tmp.counts_T, &offsets_T = tmp.offsets_T, &scratch = tmp.scratch, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
+    dfdb_ctx* ctx; DevBuf ctl, pt, sel_keep, tc_keep;
+    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); sel_keep.release(); tc_keep.release(); }
+  } tmp{ctx, {}, {}, {}, {}};
+  DevBuf &ctl = tmp.ctl, &pt = tmp.pt, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
   DevBuf& recs = ctx->radix_recs;
+  // the record pool (k_radix.hip): pages of 8192 records taken as the partition pass goes — no counting pass over the column
+  RadixPool pool{};
+  pool.maxv = radix_pool_maxv(cnt, kbits);
+  pool.dump_page = (uint32_t)(radix_pool_pages(cnt, kbits) - 1);
+  const size_t ctl_words = (size_t)P + (size_t)PS + 16;                  // the sample's counts [P], the streams' running positions [PS], the pool's counter
   try {
-    counts_T.ensure((size_t)PS * 8 + 64); offsets_T.ensure(((size_t)PS + 1) * 8 + 64); scratch.ensure(scan_counts_scratch_bytes(PS));     // (counts_T: the counts, then the running positions)
-    recs.ensure((size_t)cnt * 12 + 256);
+    ctl.ensure(ctl_words * 4); pt.ensure((size_t)PS * pool.maxv * 4 + 64);
+    recs.ensure((size_t)radix_pool_record_bytes(cnt, kbits) + 256);
     sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
-  HIP_CHECK(hipMemsetAsync(counts_T.p, 0, (size_t)PS * 8, s));
-  { LaunchTimer lt(ctx, "radix_hist");
-    if (!launch_radix_hist(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, counts_T.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
-  launch_scan_counts(s, counts_T.as<uint32_t>(), offsets_T.as<uint64_t>(), PS, scratch.as<uint64_t>());
+  pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.pt = pt.as<uint32_t>();
+  HIP_CHECK(hipMemsetAsync(ctl.p, 0, ctl_words * 4, s));
+  HIP_CHECK(hipMemsetAsync(pt.p, 0xFF, (size_t)PS * pool.maxv * 4, s));
   // SKEW: one workgroup reduces one partition, so a partition that holds a large part of all the rows (a value that a third of the column has) would be one CU's
   // work while 255 wait — 1.5 ms per average partition, i.e. 8 average partitions' worth of records already costs what the whole pass does.  The hash table takes such
-  // a column (the hot key's probes hit one cached line): the offsets come back (4 K words) and the largest partition is looked at before anything is written.
+  // a column (the hot key's probes hit one cached line).  Every 16th tile is counted (all of them in a small table: 0.1 ms per 1e9 rows), the counts come back and
+  // the largest partition is looked at before anything is written.
   {
-    std::vector<uint64_t> off((size_t)PS + 1);
-    HIP_CHECK(hipMemcpyAsync(off.data(), offsets_T.p, ((size_t)PS + 1) * 8, hipMemcpyDeviceToHost, s));
+    const int step = radix_rows_per_chunk(t->nrows, C) / 8192 >= 32 ? 16 : 1;
+    { LaunchTimer lt(ctx, "radix_sample");
+      if (!launch_radix_sample(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, step, ctl.as<uint32_t>())) return false; }
+    std::vector<uint32_t> cn((size_t)P);
+    HIP_CHECK(hipMemcpyAsync(cn.data(), ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
-    const int S = radix_share();
-    uint64_t maxp = 0;
-    for (int p = 0; p < P; p++) maxp = std::max(maxp, off[(size_t)(p + 1) * S] - off[(size_t)p * S]);
-    const uint64_t total = off[(size_t)PS];
-    if (maxp > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "unique_radix.skewed"); return false; }
+    uint64_t maxp = 0, total = 0;
+    for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
+    if (maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "unique_radix.skewed"); return false; }
   }
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, offsets_T.as<uint64_t>(), counts_T.as<uint32_t>() + PS, recs.as<uint32_t>())) return false; }
+    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
   HIP_CHECK(hipMemcpyAsync(sel_keep.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(tc_keep.p, q->tile_counts.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
@@ -1400,8 +1406,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)nt * 4, s));
   bool ok;
   { LaunchTimer lt(ctx, "radix_unique");
-    ok = launch_radix_unique(s, recs.as<uint32_t>(), offsets_T.as<uint64_t>(), kbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(),
-                             T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
+    ok = launch_radix_unique(s, recs.as<uint32_t>(), pool, kbits, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), T.aux.as<uint64_t>(), ctx->prop.multiProcessorCount); }
   uint64_t aborted = 0;
   if (ok) { HIP_CHECK(hipMemcpyAsync(&aborted, (char*)T.aux.p + 24, 8, hipMemcpyDeviceToHost, s)); stream_wait(ctx); }
   if (!ok || aborted || ctx_option(ctx, "unique_radix", 1) == 3) {        // (3: a test knob — behave as if a partition had overflowed)
