@@ -3,15 +3,17 @@
 // Replaces Base.unique driven by Base.iterate(::DFColumn) (src/tables/column.jl:102-126; docs/src/index.md:479-487), like k_unique.hip.  The open-addressing
 // table of {key, smallest row} in HBM costs one random 128-byte line per selected row once it outgrows the L2s (1e6 distinct Int64 / Float64 values: 32 MB of
 // table, 1e9 probes, 19.8 ms per 1e9 rows = 0.05 of the HBM roofline on the 8 bytes per row it needs).  Here every byte moves in STREAMS:
-//   hist       one pass over the key column: how many selected rows fall into each of P = 2^k partitions (the top k bits of a 32-bit hash of the key image),
-//              kept per SHARE — the chunks (= workgroups) whose number is equal mod 8, one XCD's as the dispatcher deals them out; an exclusive scan of the
-//              P x 8 counts (partition-major) is where every share of every partition starts
-//   partition  the same pass again: a workgroup sorts 8192 rows at a time by partition in LDS, reserves each partition's run behind its share's running position
-//              (one global atomicAdd per tile and partition: the workgroups of an XCD append to the SAME 512 places, so their runs follow each other and
-//              complete their 128-byte lines in that XCD's L2) and writes it: 12-byte records {key image, row}, every run one contiguous piece
-//   unique     one workgroup per partition: its records go through a table that lives in LDS (8192 slots: 64-bit compare-and-swap claims a slot, a 32-bit
-//              atomic minimum keeps the smallest row), and the occupied slots leave one bit each in the bitmap of first occurrences (+ per-tile counts)
-// 8 + (8 + 12) + 12 bytes per selected row, all sequential.  The order of a partition's records depends on timing; the result (smallest row per key) does not.
+//   partition  ONE pass over the key column: a workgroup sorts 8192 rows at a time by partition (the top k bits of a 32-bit hash of the key image) in LDS,
+//              reserves each partition's run behind the running position of its STREAM — (partition, share), a share being the chunks (= workgroups) whose
+//              number is equal mod 8: one XCD's, as the dispatcher deals them out — with one global atomicAdd per tile and partition, and writes it: 12-byte
+//              records {key image, row}, every run one contiguous piece.  The workgroups of an XCD append to the SAME 512 places, so their runs follow each
+//              other and complete their 128-byte lines in that XCD's L2.  A stream's records live in PAGES of 8192 taken from a pool as the pass goes (the
+//              thread whose run holds a page's first record takes it and publishes it in the stream's page table): nothing has to be counted first
+//   unique     one workgroup per partition: the records of its streams' pages go through a table that lives in LDS (8192 slots: 64-bit compare-and-swap
+//              claims a slot, a 32-bit atomic minimum keeps the smallest row), and the occupied slots leave one bit each in the bitmap of first occurrences
+//              (+ per-tile counts)
+// 8 + 12 + 12 bytes per selected row, all streams.  The order of a partition's records depends on timing; the result (smallest row per key) does not.
+// Before anything is written a SAMPLE (every 16th tile counted per partition) turns skewed columns away: one workgroup reduces one partition.
 // A partition that holds more distinct keys than its table takes raises a flag and the host runs the hash-table form instead (query.cpp: unique_hashed); keys
 // are isequal images (one NaN, -0.0 apart from 0.0), a missing key and the one image that cannot be stored (all ones) are kept aside in aux[1] / aux[0]
 // exactly as k_unique_insert keeps them.  Measured history: profiles/r6_unique_radix.txt; what the instruction and store choices rest on: tools/ubench/.
@@ -332,6 +334,7 @@ __device__ __forceinline__ void table_claim(uint64_t* tkey, uint32_t* trow, uint
     if (probes >= (uint32_t)kRSlots) { *abort_flag = 1; break; }
   }
 }
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 // four records of a thread: FULL = all four exist; otherwise a record past the partition's end reads the last one again and is made the empty image afterwards
 template <bool FULL>
 __device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], const uint32_t* __restrict__ rp, uint32_t n, int tid) {
@@ -357,16 +360,27 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __rest
     if (tid == 0) { claims_sh = 0; abort_sh = __atomic_load_n(&aux[3], __ATOMIC_RELAXED) != 0; }
     __syncthreads();
     if (abort_sh) return;                                     // (the partition pass gave up on a stream: the hash table answers)
-    // the partition's records: its kRShare streams one after the other, a stream page by page, a page in two blocks of 4096 records (all wave-uniform)
+    // the partition's records: its kRShare streams one after the other, a stream page by page, a page in two blocks of 4096 records (all wave-uniform).
+    // What says where a block lies comes through VECTOR loads — the streams' record counts in lanes 0 .. 7 of one register, 64 entries of the current stream's
+    // page table in another, read with v_readlane: a scalar load per block shares its counter with the LDS reads (returns out of order: every wait is a wait
+    // for everything) and cost 0.4 of the pass's 3.5 ms
+    const uint32_t vfront = pool.front[p * kRShare + (lane & (kRShare - 1))];
+    uint32_t wnext = pool.pt[(size_t)(p * kRShare) * pool.maxv + lane], wcur = 0, wbase = 0;      // (the table has 64 entries of slack behind its last row)
     int sx = -1; uint32_t soff = 0, sn = 0;                   // the stream being read, where its next block starts, its records
     auto next_block = [&](const uint32_t*& bp, uint32_t& bc) {
       while (sx < kRShare && soff >= sn) {
-        sx++; soff = 0;
-        sn = sx < kRShare ? pool.front[p * kRShare + sx] : 0u;
-        if ((uint64_t)sn > (uint64_t)pool.maxv * kRPage) sn = 0;                 // (the partition pass raised the flag for this stream)
+        sx++; soff = 0; sn = 0;
+        if (sx < kRShare) {
+          sn = rl32(vfront, (uint32_t)sx);
+          if ((uint64_t)sn > (uint64_t)pool.maxv * kRPage) sn = 0;               // (the partition pass raised the flag for this stream)
+          wcur = wnext; wbase = 0;
+          if (sx + 1 < kRShare) wnext = pool.pt[(size_t)(p * kRShare + sx + 1) * pool.maxv + lane];
+        }
       }
       if (sx >= kRShare) { bc = 0; return; }
-      const uint32_t pg = pool.pt[(size_t)(p * kRShare + sx) * pool.maxv + (soff >> 13)];
+      const uint32_t k = soff >> 13;
+      if (k - wbase >= 64u) { wbase = k & ~63u; wcur = pool.pt[(size_t)(p * kRShare + sx) * pool.maxv + wbase + lane]; }      // (a stream of more than 64 pages: twice its even share)
+      const uint32_t pg = rl32(wcur, k - wbase);
       bp = recs + ((size_t)pg * kRPage + (soff & (uint32_t)(kRPage - 1))) * 3;
       bc = sn - soff < 4u * kRBlock ? sn - soff : 4u * kRBlock;
       soff += 4u * kRBlock;

@@ -1375,7 +1375,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   pool.dump_page = (uint32_t)(radix_pool_pages(cnt, kbits) - 1);
   const size_t ctl_words = (size_t)P + (size_t)PS + 16;                  // the sample's counts [P], the streams' running positions [PS], the pool's counter
   try {
-    ctl.ensure(ctl_words * 4); pt.ensure((size_t)PS * pool.maxv * 4 + 64);
+    ctl.ensure(ctl_words * 4); pt.ensure((size_t)PS * pool.maxv * 4 + 512);        // (+ 64 entries nobody owns: the unique pass reads 64 at a time)
     recs.ensure((size_t)radix_pool_record_bytes(cnt, kbits) + 256);
     sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }

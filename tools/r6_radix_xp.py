@@ -18,6 +18,6 @@ for rep in range(2):
         u = t.x.unique()
     except Exception as e:
         print("raised", type(e).__name__, str(e)[:80])
-    p = {k: ctx.profile_get(k) for k in ("radix_hist", "radix_partition", "radix_unique")}
+    p = {k: ctx.profile_get(k) for k in ("radix_sample", "radix_partition", "radix_unique")}
     ctx.profile(False)
 print("XP", os.environ.get("DFDB_RADIX_XP"), {k: round(v[1] / max(v[0], 1), 3) for k, v in p.items()}, flush=True)

@@ -28,7 +28,7 @@ for col in ("x", "f"):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             u = getattr(t, col).unique()
             dt = time.perf_counter() - t0
-            p = {k: ctx.profile_get(k) for k in ("radix_hist", "radix_partition", "radix_unique", "unique_insert", "unique_mark", "unique_migrate", "unique", "unique_radix.taken", "unique_radix.fell_back", "gather", "scan_counts")}
+            p = {k: ctx.profile_get(k) for k in ("radix_sample", "radix_partition", "radix_unique", "unique_insert", "unique_mark", "unique_migrate", "unique", "unique_radix.taken", "unique_radix.fell_back", "gather", "scan_counts")}
             ctx.profile(False)
             if best is None or dt < best:
                 best, prof = dt, {k: [v[0], round(v[1], 3)] for k, v in p.items() if v[0]}
