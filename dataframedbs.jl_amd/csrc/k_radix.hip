@@ -96,22 +96,32 @@ __device__ __forceinline__ uint64_t tile_load(uint64_t (&key)[8], uint64_t (&in)
       in[j] = sw;
     }
   }
-  const uint32_t lo = (uint32_t)(wv * 512 + lane);              // the lane's first row of the tile; a row past the table's end reads the last row again (its bit is clear)
-  const uint32_t last = FULL ? 8191u : (uint32_t)(nrows - 1 - base < 8191 ? nrows - 1 - base : 8191);
-  if (KIND != kKindAny) {
-    const uint64_t* kp = (const uint64_t*)col + base;           // (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const uint32_t o = lo + (uint32_t)(j * 64); key[j] = __builtin_nontemporal_load(kp + (FULL || o < last ? o : last)); }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const uint32_t o = lo + (uint32_t)(j * 64); key[j] = rkey_fixed(col, dtype, base + (FULL || o < last ? o : last)); }
-  }
   uint64_t selected_missing = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint64_t sw = wave_uniform(in[j]), m = wave_uniform(mw[j]);
     selected_missing |= sw & m;
     in[j] = sw & ~m;
+  }
+  // the keys of the rows that take part only: under a selective predicate most 128-byte lines of the column hold no such row and are never fetched (the words
+  // are needed first — but the partition pass asks for a tile's keys a whole tile ahead)
+  const uint32_t lo = (uint32_t)(wv * 512 + lane);              // the lane's first row of the tile
+  const uint32_t last = FULL ? 8191u : (uint32_t)(nrows - 1 - base < 8191 ? nrows - 1 - base : 8191);
+  if (KIND != kKindAny) {
+    const uint64_t* kp = (const uint64_t*)col + base;           // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t o = lo + (uint32_t)(j * 64);
+      key[j] = 0;
+      if (__builtin_amdgcn_inverse_ballot_w64(in[j])) key[j] = __builtin_nontemporal_load(kp + (FULL || o < last ? o : last));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t o = lo + (uint32_t)(j * 64);
+      key[j] = 0;
+      if (__builtin_amdgcn_inverse_ballot_w64(in[j])) key[j] = rkey_fixed(col, dtype, base + (FULL || o < last ? o : last));
+    }
   }
   return selected_missing;                                      // (wave-uniform: nonzero = the hist pass looks for the tile's first missing row, tile_first_missing)
 }

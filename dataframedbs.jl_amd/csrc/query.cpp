@@ -1340,7 +1340,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   // them): 192-byte runs behind running positions that one XCD's workgroups share, so that whole lines leave that XCD's L2.  On by default; option = 0: the hash table.
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
   if (mode == 0 || t->nrows > (1ll << 32) || r0 == 0 || d0 == 0) return false;
-  if (mode < 2 && cnt < (32ll << 20)) return false;                      // (2: a test knob — any size)
+  if (mode < 2 && cnt < (4ll << 20)) return false;                       // (2: a test knob — any size; measured against the hash table down to 3 M selected rows of 1e9: tools/r6_radix_selective.py)
   double D = (double)cnt;
   if (d0 < r0) {                                                         // solve d0 = D (1 - exp(-r0 / D)) for D by bisection
     double lo = (double)d0, hi = (double)cnt;

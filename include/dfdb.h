@@ -164,7 +164,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                      out of its on-chip history instead of fetching a line (at 1984, K7's reach: ratio - 8 %, indexed decode + 3 %; default 0: file bytes are what
  *                      the cold path waits for)
  *   "unique_radix"     1 (default) = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s (an estimated 131 072 .. ~5 M distinct values among
- *                      at least 32 M selected rows) takes the radix-partitioned form (k_radix.hip: every selected row written once as a {key, row} record into one of
+ *                      at least 4 M selected rows) takes the radix-partitioned form (k_radix.hip: every selected row written once as a {key, row} record into one of
  *                      256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per selected row + 0.4-0.8 GB of part-filled pages, kept by the context; no room for it, a
  *                      partition that outgrows its table, or one that holds more than eight average partitions' rows — a value a large part of the column has
  *                      —: the hash table answers).  8.8 ms against the hash table's 19.8 per 1e9 rows of 1e6 values
