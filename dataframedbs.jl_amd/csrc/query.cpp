@@ -1339,7 +1339,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   // hash table's 19.9 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass waits for its STORES (2.8 ms without
   // them): 192-byte runs behind running positions that one XCD's workgroups share, so that whole lines leave that XCD's L2.  On by default; option = 0: the hash table.
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
-  if (mode == 0 || t->nrows > (1ll << 32) || r0 == 0 || d0 == 0) return false;
+  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || r0 == 0 || d0 == 0) return false;      // (rows and pool positions are 32-bit; all ones is "no row")
   if (mode < 2 && cnt < (4ll << 20)) return false;                       // (2: a test knob — any size; measured against the hash table down to 3 M selected rows of 1e9: tools/r6_radix_selective.py)
   double D = (double)cnt;
   if (d0 < r0) {                                                         // solve d0 = D (1 - exp(-r0 / D)) for D by bisection
@@ -1370,6 +1370,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   DevBuf &ctl = tmp.ctl, &pt = tmp.pt, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
   DevBuf& recs = ctx->radix_recs;
   // the record pool (k_radix.hip): pages of 8192 records taken as the partition pass goes — no counting pass over the column
+  if (radix_pool_pages(cnt, kbits) * 8192 >= (1ll << 32)) return false;   // (a record's place in the pool is a 32-bit number)
   RadixPool pool{};
   pool.maxv = radix_pool_maxv(cnt, kbits);
   pool.dump_page = (uint32_t)(radix_pool_pages(cnt, kbits) - 1);

@@ -500,3 +500,44 @@ def test_compressed_only_table_3e9_rows_answers_config3(oracle, dfdb_mod, ctx):
         assert np.array_equal(ob[lo:hi].cpu().numpy(), b[m]) and np.array_equal(ox[lo:hi].cpu().numpy().view(np.uint64), x[m].view(np.uint64)), blk
     del q
     t.close()
+
+
+def test_unique_by_radix_at_full_size(dfdb_mod, ctx):
+    """unique(col) over 1e9 rows of 1e6 distinct values (round 6: csrc/k_radix.hip — the partition pass's page pool, the LDS tables): the first occurrences it
+    marks are the hash-table form's, row for row, for the Int64 column, for a Float64 image of it and under a predicate; every value of the range is there once;
+    a second call gives the same rows (the order of a partition's records depends on timing, the answer must not)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs ~45 GB of HBM")
+    import dfdb._native as N
+    n = 1_000_000_000
+    t = dfdb_mod.DFTable.new(ctx=ctx)
+    t.add_generated("x", dfdb_mod.GEN_I64_MOD1M, SEED, n)
+    t.add_generated("a", dfdb_mod.GEN_I64_MOD1M, SEED * 2, n)
+    t.add_column_from("f", t.x * 0.5)
+
+    def first_rows(view, radix):
+        ctx.set_option("unique_dense", 0); ctx.set_option("unique_radix", radix); ctx.profile(True)
+        try:
+            q = view._query()
+            N.check(N.load().dfdb_query_unique(q._h, 0))
+            rows = q.indices()
+            taken = ctx.profile_get("unique_radix.taken")[0]
+        finally:
+            ctx.profile(False); ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 1)
+        return rows, taken
+
+    try:
+        for label, view in (("x", t[dfdb_mod.ALL, ["x"]]), ("f", t[dfdb_mod.ALL, ["f"]]), ("x where a > 499999", t[("a", lambda c: c > 499_999), ["x"]])):
+            r1, taken = first_rows(view, 1)
+            assert taken == 1, label
+            r2, _ = first_rows(view, 1)
+            h, taken_h = first_rows(view, 0)
+            assert taken_h == 0
+            assert np.array_equal(r1, h) and np.array_equal(r1, r2), label
+            assert len(r1) == 1_000_000 and bool(np.all(r1[1:] > r1[:-1])), label
+        vals = t.x.unique()                                                  # (the dense form: a third opinion on the values)
+        assert len(vals) == 1_000_000 and np.array_equal(np.sort(vals), np.arange(1_000_000))
+    finally:
+        t.close()
