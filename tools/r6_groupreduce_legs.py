@@ -22,3 +22,21 @@ for label, key in (("Float64 key, 5000 groups", "fk"), ("Int64 key, 5000 groups"
         p = {k: ctx.profile_get(k) for k in keys}
         ctx.profile(False)
         print(label, "ms %.3f" % (dt * 1e3), len(g), {k: (v2[0], round(v2[1], 3)) for k, v2 in p.items() if v2[0]}, flush=True)
+t.close()
+# by a 10-value String key, flat and with the dictionary (5e8 rows)
+n = 500_000_000
+t = dfdb.DFTable.new(block_size=65536, ctx=ctx)
+t.add_generated("s", dfdb.GEN_STR_BRANDS10, 0x9E3779B97F4A7C15, n)
+t.add_generated("a", dfdb.GEN_I64_MOD1M, 0x9E3779B97F4A7C15 * 2, n)
+keys = keys + ("dict_scan", "str_match")
+for label in ("String key (flat), 10 groups", "String key (dictionary), 10 groups"):
+    if "dictionary" in label:
+        t.build_dictionary("s")
+    for rep in range(3):
+        ctx.profile(True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g = dfdb.groupreduce(t, "s", "a", "sum")
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        p = {k: ctx.profile_get(k) for k in keys}
+        ctx.profile(False)
+        print(label, "ms %.3f" % (dt * 1e3), len(g), {k: (v2[0], round(v2[1], 3)) for k, v2 in p.items() if v2[0]}, flush=True)
