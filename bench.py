@@ -26,7 +26,7 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
   calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
                   `value` itself is the library-default configuration (no ctx option set)
                   Round 4 adds "3_computed" (config 3 with the computed x * 2 projection), "interp" (expressions outside the scan kernels: the device interpreter and
-                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_float_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
+                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_float_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
@@ -492,7 +492,7 @@ def make_summary(res):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("ms_per_step")), _r((v.get("roofline") or {}).get("frac"))]
-    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_float_key", "groupreduce_dictionary"):
+    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_float_key", "groupreduce_dictionary"):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("seconds", 0) * 1e3), _r((v.get("roofline") or {}).get("frac"))]
@@ -789,6 +789,28 @@ def f_rows_legs(L, dfdb, sc, rank):
                                           "accumulate pass adds into LDS accumulators (one 1024-thread workgroup per CU) and looks the group numbers up in an LDS copy of the table's occupied span; "
                                           "and reports a key the head did not hold (everything would then run again over every row); bytes = the key column + the value column, once each "
                                           "(24 B/row — the key column twice — while the presence pass still walked every row: 7.0 ms = 0.43 then); best of 3"}
+    # ---- groupreduce over MORE groups than a workgroup's LDS accumulators hold (9216): 50 000 groups (x mod 50000), by radix since round 6 (csrc/k_radix.hip:
+    # {key, row, value} records partitioned by the key's hash, a table with accumulators per partition in LDS); `atomics_seconds` is the form it replaced there
+    # (every row's value to its group through a global atomic: ctx option unique_radix = 0)
+    t.add_column_from("k50", t.x % 50000)
+    both = {}
+    for radix in (1, 0):
+        ctx.set_option("unique_radix", radix)
+        best, g = None, None
+        try:
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                g = dfdb.groupreduce(t, "k50", "x", "sum")
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+        finally:
+            ctx.set_option("unique_radix", 1)
+        both[radix] = (best, len(g))
+    best, ng50 = both[1]
+    res["groupreduce_50k_groups"] = {"rows": n, "groups": ng50, "seconds": best, "rows_per_s": n / best, "atomics_seconds": both[0][0],
+                                     "roofline": {"bound": "hbm", "achieved": n * 16 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 16 / best / 1e9 / L.peak},
+                                     "what": "groupreduce(t, (:k50,); out = :x => Sum()), k50 = x mod 50000 (Int64): more groups than LDS accumulators hold — partitioned by radix "
+                                             "(20-byte records) and reduced per partition in LDS; bytes = the key column + the value column, once each; best of 2"}
     t.close()
     # ---- groupreduce by a String key, flat and with the dictionary
     n = int(500_000_000 * sc)

@@ -53,6 +53,7 @@ __device__ __forceinline__ uint64_t rkey_fixed(const void* col, int dtype, int64
   }
 }
 struct __attribute__((packed, aligned(4))) Rec12 { uint32_t lo, hi, row; };
+struct __attribute__((packed, aligned(4))) Rec20 { uint32_t lo, hi, row, vlo, vhi; };
 enum { kKindRaw8 = 0, kKindF64 = 1, kKindAny = 2 };       // what a key load is: 8 raw bytes (Int64 / UInt64), 8 bytes + isequal's one NaN (Float64), anything narrower (rkey_fixed)
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {     // a value every lane of the wave holds, into scalar registers
   return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
@@ -182,10 +183,29 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 // units at 16-aligned positions with the remainders carried over in LDS, 4096-row tiles — every store a full line, and the pass took 11.7 ms instead of 7.3;
 // 512-thread workgroups sorting 4096 rows, two per CU — shorter runs store slower than the overlap gains.)
 constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }      // hist2, lstart (1024 each), place (1024 x 16 bytes), wave sums, srow — in 4-byte words; skey follows
-template <int KIND, int BLOCK>
+// HASVAL (groupreduce by radix, below): a record carries the row's 8-byte VALUE too — 20 bytes {key image, row, value}; the value is fetched from its column where
+// the record is written (the tile's 64 KB of values: one gathered read per record, behind the sort), and the rows whose key cannot be stored are counted and reduced
+// here, in a workgroup-wide accumulator that is flushed to gspec {count, value} once per workgroup (GOP: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
+// of order images; vkind: how a value's image is made — k_unique.hip's order_image).
+struct RadixVals { const uint64_t* col; uint64_t* gspec; int gop; int vkind; };
+__device__ __forceinline__ uint64_t order_image(uint64_t bits, int kind, bool is_min) {         // (= k_unique.hip's: unsigned compare; a NaN wins either reduction)
+  if (kind == 1) return bits;
+  if (kind == 0) return bits ^ (1ull << 63);
+  const double d = __longlong_as_double((long long)bits);
+  if (d != d) return is_min ? 0ull : ~0ull;
+  return (bits >> 63) ? ~bits : (bits | (1ull << 63));
+}
+__device__ __forceinline__ void acc_value(uint64_t* slot, uint64_t v, int gop, int vkind) {      // (LDS or global: one atomic)
+  if (gop == 1) atomicAdd((unsigned long long*)slot, (unsigned long long)v);
+  else if (gop == 2) atomicAdd((double*)slot, __longlong_as_double((long long)v));
+  else if (gop == 3) atomicMin((unsigned long long*)slot, (unsigned long long)order_image(v, vkind, true));
+  else if (gop == 4) atomicMax((unsigned long long*)slot, (unsigned long long)order_image(v, vkind, false));
+}
+template <int KIND, int BLOCK, bool HASVAL>
 __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, RadixPool pool,
-                                                             uint32_t* __restrict__ recs_out, uint64_t* aux, int xp) {
+                                                             uint32_t* __restrict__ recs_out, uint64_t* aux, RadixVals vals, int xp) {
+  __shared__ uint64_t spec_sh[2];                               // HASVAL: {rows, reduced value} of the rows whose key is the unstorable image, this workgroup's
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
@@ -198,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
+  if (HASVAL && tid == 0) { spec_sh[0] = 0; spec_sh[1] = vals.gop == 3 ? ~0ull : 0ull; }
   const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the stream (partition p, this workgroup's share)
   for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
@@ -220,9 +241,15 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     }
     if (nmiss) tile_first_missing(sel, missing, base, nrows, wv, lane, aux);       // (rare: the two keys kept aside — a missing key's first row, aux[1]; ...
     if (unstorable) {                                           // ... the unstorable image's, aux[0]: -1 in an Int64 column is that image; one lane of the wave reports)
+      bool first = true;
       for (int j = 0; j < 8; j++) {
         const uint64_t bad = nin[j] & ~keys_storable<KIND>(key[j]);
-        if (bad) { if (lane == 0) aux_min(&aux[0], (uint64_t)(base + wv * 512 + j * 64 + __builtin_ctzll(bad))); break; }
+        if (!bad) continue;
+        if (first && lane == 0) aux_min(&aux[0], (uint64_t)(base + wv * 512 + j * 64 + __builtin_ctzll(bad)));
+        first = false;
+        if (!HASVAL) break;
+        if (lane == 0) atomicAdd((unsigned long long*)&spec_sh[0], (unsigned long long)__builtin_popcountll(bad));
+        if (vals.col && ((bad >> lane) & 1ull)) acc_value(&spec_sh[1], vals.col[base + wv * 512 + j * 64 + lane], vals.gop, vals.vkind);
       }
     }
     const int64_t nb = base + TILE;
@@ -302,6 +329,11 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     for (int k = 0; k < 8; k++) od[k] = place[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
     // the next tile's keys are waited for HERE, before the first store is issued: loads and stores share one in-order counter (vmcnt), and a wait for the loads at
     // the top of the next step would also be a wait for the sixteen stores issued after them — a tile's store latency, every tile
+    uint64_t ov[8];                                             // HASVAL: the records' values, gathered out of the tile's rows
+    if (HASVAL) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) ov[k] = vals.col && !(xp & 256) && (uint32_t)(k * BLOCK + tid) < total ? vals.col[base + (ow[k] & 8191u)] : 0ull;      // (bit 8, timing only: no values)
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));
     const uint32_t base32 = (uint32_t)base;
@@ -313,11 +345,26 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
         if (xp & 1) { if (ok[k] == 12345ull) recs_out[dst] = 1; continue; }              // (DFDB_RADIX_XP bit 0, timing only: no stores)
         // one 12-byte record {key image, row}: a partition's run of a tile is ONE piece of 192 bytes, not 128 + 64 in two arrays (the pass waits for its
         // stores, and what they cost goes by the number of pieces: tools/ubench/scatter_runs.hip; as nontemporal stores: 7.4 ms instead of 6.15)
+        if (HASVAL) {
+          Rec20 r; r.lo = (uint32_t)ok[k]; r.hi = (uint32_t)(ok[k] >> 32); r.row = base32 | (ow[k] & 8191u); r.vlo = (uint32_t)ov[k]; r.vhi = (uint32_t)(ov[k] >> 32);
+          *(Rec20*)(recs_out + (size_t)dst * 5) = r;
+          continue;
+        }
         Rec12 r; r.lo = (uint32_t)ok[k]; r.hi = (uint32_t)(ok[k] >> 32); r.row = base32 | (ow[k] & 8191u);
         *(Rec12*)(recs_out + (size_t)dst * 3) = r;
       }
     }
     // (no barrier here: the next tile writes hist2 — cleared above — before its first barrier, and nothing this step still reads before its third)
+  }
+  if (HASVAL) {                                                 // the workgroup's rows of the unstorable key -> the launch's
+    __syncthreads();
+    if (tid == 0 && spec_sh[0]) {
+      atomicAdd((unsigned long long*)&vals.gspec[0], (unsigned long long)spec_sh[0]);
+      if (vals.gop == 1) atomicAdd((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
+      else if (vals.gop == 2) atomicAdd((double*)&vals.gspec[1], __longlong_as_double((long long)spec_sh[1]));
+      else if (vals.gop == 3) atomicMin((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
+      else if (vals.gop == 4) atomicMax((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
+    }
   }
 }
 
@@ -451,6 +498,153 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __rest
     __syncthreads();
   }
 }
+
+// ---- groupreduce by radix: the LDS-table pass with accumulators -------------------------------------------------------------------------------------------
+// dfdb_query_groupreduce over more groups than a workgroup's LDS accumulators hold (9216) sent every selected row's value to its group through a global atomic:
+// 85-90 ms per 1e9 rows whether the groups were 5e4 or 1e6.  Here the partition pass writes {key, row, value} records and one workgroup per partition reduces them
+// through a table in LDS that holds, per key, its smallest row, the number of its rows and their reduced value; every occupied slot leaves one result {first row,
+// rows, value} — a key lives in exactly one partition, so nothing is merged —, the first rows are marked in the bitmap as unique marks them (`mark`), and once the
+// bitmap's prefix exists k_radix_group_finish sends every result to the place its first row's rank names: groups in order of first appearance.
+constexpr int kGSlots = 4096;                                   // slots of a partition's table (24 bytes each + the waves' lists: 136 KB of LDS)
+__device__ __forceinline__ uint32_t gtable_home(uint64_t key) { return ((((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u) >> 20) & ~1u; }
+__device__ __forceinline__ void gtable_add(uint32_t* trow, uint32_t* tcnt, uint64_t* tval, uint32_t slot, uint32_t seen_row, uint32_t row, uint64_t v, int gop, int vkind) {
+  if (seen_row > row) atomicMin(&trow[slot], row);
+  atomicAdd(&tcnt[slot], 1u);
+  if (gop) acc_value(&tval[slot], v, gop, vkind);
+}
+__device__ __forceinline__ void gtable_claim(uint64_t* tkey, uint32_t* trow, uint32_t* tcnt, uint64_t* tval, uint64_t key, uint32_t row, uint64_t v, int gop, int vkind,
+                                             uint32_t* claims, uint32_t* abort_flag) {
+  uint32_t h = gtable_home(key);
+  for (uint32_t probes = 0;; probes++) {
+    uint64_t old = tkey[h];
+    if (old == kREmpty) {
+      old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)kREmpty, (unsigned long long)key);
+      if (old == kREmpty) atomicAdd(claims, 1u);
+    }
+    if (old == kREmpty || old == key) { gtable_add(trow, tcnt, tval, h, trow[h], row, v, gop, vkind); break; }
+    h = (h + 1) & (kGSlots - 1);
+    if (probes >= (uint32_t)kGSlots) { *abort_flag = 1; break; }
+  }
+}
+template <bool FULL>
+__device__ __forceinline__ void recs20_load(uint64_t (&kk)[4], uint32_t (&rw)[4], uint64_t (&vv)[4], const uint32_t* __restrict__ rp, uint32_t n, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = (uint32_t)(j * kRBlock + tid);
+    const Rec20 r = *(const Rec20*)(rp + (size_t)(FULL || i < n ? i : n - 1u) * 5);
+    kk[j] = (uint64_t)r.hi << 32 | r.lo; rw[j] = r.row; vv[j] = (uint64_t)r.vhi << 32 | r.vlo;
+  }
+}
+__global__ __launch_bounds__(kRBlock) void k_radix_group(const uint32_t* __restrict__ recs, RadixPool pool, int P, int mark, uint64_t* __restrict__ bitmap,
+                                                         uint32_t* __restrict__ tile_counts, uint64_t* aux, uint4* __restrict__ results, uint32_t* __restrict__ nres,
+                                                         int gop, int vkind) {
+  extern __shared__ uint64_t tab_sh[];
+  uint64_t* tkey = tab_sh;                                    // [kGSlots]
+  uint64_t* tval = tkey + kGSlots;                            // [kGSlots] the key's reduced value (min / max: of order images)
+  uint32_t* trow = (uint32_t*)(tval + kGSlots);               // [kGSlots] its smallest row
+  uint32_t* tcnt = trow + kGSlots;                            // [kGSlots] its rows
+  __shared__ uint32_t claims_sh, abort_sh;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint64_t* qbase = (uint64_t*)(tcnt + kGSlots);
+  uint64_t* qk = qbase + wv * kRQueue;                                                   // the wave's list of records still to be claimed: keys ...
+  uint64_t* qv = qbase + (kRBlock / 64) * kRQueue + wv * kRQueue;                        // ... values ...
+  uint32_t* qr = (uint32_t*)(qbase + 2 * (kRBlock / 64) * kRQueue) + wv * kRQueue;       // ... rows
+  const uint64_t vinit = gop == 3 ? ~0ull : 0ull;
+  for (int p = (int)blockIdx.x; p < P; p += (int)gridDim.x) {
+    uint32_t qn = 0;
+    for (int i = tid; i < kGSlots; i += kRBlock) { tkey[i] = kREmpty; trow[i] = 0xFFFFFFFFu; tcnt[i] = 0; tval[i] = vinit; }
+    if (tid == 0) { claims_sh = 0; abort_sh = __atomic_load_n(&aux[3], __ATOMIC_RELAXED) != 0; }
+    __syncthreads();
+    if (abort_sh) return;
+    const uint32_t vfront = pool.front[p * kRShare + (lane & (kRShare - 1))];
+    uint32_t wnext = pool.pt[(size_t)(p * kRShare) * pool.maxv + lane], wcur = 0, wbase = 0;
+    int sx = -1; uint32_t soff = 0, sn = 0;
+    auto next_block = [&](const uint32_t*& bp, uint32_t& bc) {
+      while (sx < kRShare && soff >= sn) {
+        sx++; soff = 0; sn = 0;
+        if (sx < kRShare) {
+          sn = rl32(vfront, (uint32_t)sx);
+          if ((uint64_t)sn > (uint64_t)pool.maxv * kRPage) sn = 0;
+          wcur = wnext; wbase = 0;
+          if (sx + 1 < kRShare) wnext = pool.pt[(size_t)(p * kRShare + sx + 1) * pool.maxv + lane];
+        }
+      }
+      if (sx >= kRShare) { bc = 0; return; }
+      const uint32_t k = soff >> 13;
+      if (k - wbase >= 64u) { wbase = k & ~63u; wcur = pool.pt[(size_t)(p * kRShare + sx) * pool.maxv + wbase + lane]; }
+      const uint32_t pg = rl32(wcur, k - wbase);
+      bp = recs + ((size_t)pg * kRPage + (soff & (uint32_t)(kRPage - 1))) * 5;
+      bc = sn - soff < 4u * kRBlock ? sn - soff : 4u * kRBlock;
+      soff += 4u * kRBlock;
+    };
+    const uint32_t* cp = recs; uint32_t cc = 0;
+    next_block(cp, cc);
+    uint64_t nk[4], nv[4]; uint32_t nr[4];
+    if (cc) { if (cc == 4u * kRBlock) recs20_load<true>(nk, nr, nv, cp, cc, tid); else recs20_load<false>(nk, nr, nv, cp, cc, tid); }
+    while (cc) {
+      uint64_t kk[4], vv[4]; uint32_t rw[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { kk[j] = nk[j]; rw[j] = nr[j]; vv[j] = nv[j]; }
+      if (cc != 4u * kRBlock) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if ((uint32_t)(j * kRBlock + tid) >= cc) { kk[j] = kREmpty; rw[j] = 0xFFFFFFFFu; }
+      }
+      next_block(cp, cc);
+      if (cc) { if (cc == 4u * kRBlock) recs20_load<true>(nk, nr, nv, cp, cc, tid); else recs20_load<false>(nk, nr, nv, cp, cc, tid); }
+      uint32_t hb[4]; ulonglong2 tt[4]; uint2 qq[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) hb[j] = gtable_home(kk[j]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { tt[j] = *(const ulonglong2*)&tkey[hb[j]]; qq[j] = *(const uint2*)&trow[hb[j]]; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool real = kk[j] != kREmpty;                   // (a slot past the block's end: no record)
+        const bool e0 = tt[j].x == kk[j], e1 = tt[j].y == kk[j];
+        const bool hit = real && (e0 | e1), pending = real && !hit;
+        if (hit) gtable_add(trow, tcnt, tval, hb[j] + (e0 ? 0u : 1u), e0 ? qq[j].x : qq[j].y, rw[j], vv[j], gop, vkind);
+        const uint64_t pm = __ballot(pending);
+        if (pm) {
+          if (pending) { const uint32_t e = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u)); qk[e] = kk[j]; qv[e] = vv[j]; qr[e] = rw[j]; }
+          qn += (uint32_t)__builtin_popcountll(pm);
+          if (qn >= 64u) { qn -= 64u; gtable_claim(tkey, trow, tcnt, tval, qk[qn + lane], qr[qn + lane], qv[qn + lane], gop, vkind, &claims_sh, &abort_sh); }
+        }
+      }
+      if (claims_sh > (kGSlots * 7) / 8) { abort_sh = 1; break; }
+    }
+    if (qn && !abort_sh) { if (lane < (int)qn) gtable_claim(tkey, trow, tcnt, tval, qk[lane], qr[lane], qv[lane], gop, vkind, &claims_sh, &abort_sh); }
+    __syncthreads();
+    if (abort_sh) { if (tid == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }
+    for (int i = tid; i < kGSlots; i += kRBlock) {
+      if (tkey[i] == kREmpty) continue;
+      const uint64_t r = trow[i], v = tval[i];
+      results[atomicAdd(nres, 1u)] = make_uint4((uint32_t)r, tcnt[i], (uint32_t)v, (uint32_t)(v >> 32));
+      if (mark) { atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63)); atomicAdd(&tile_counts[r >> 10], 1u); }
+    }
+    if (mark && p == 0 && tid < 2) {                          // the two keys kept aside: the unstorable image, missing
+      const uint64_t r = aux[tid];
+      if (r != kREmpty) { atomicOr((unsigned long long*)&bitmap[r >> 6], 1ull << (r & 63)); atomicAdd(&tile_counts[r >> 10], 1u); }
+    }
+    __syncthreads();
+  }
+}
+// results -> the groups' places: a result's group is the rank of its first row among the first rows (the bitmap's set bits, `prefix` = set bits before every
+// 1024-row tile); the unstorable key's group takes the partition pass's own accumulator
+__global__ void k_radix_group_finish(const uint4* __restrict__ results, const uint32_t* __restrict__ nres, const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ uprefix,
+                                     const uint64_t* aux, const uint64_t* gspec, uint64_t* __restrict__ cnt, uint64_t* __restrict__ val) {
+  auto rank_of = [&](uint64_t row) -> uint64_t {
+    const uint64_t tile = row >> 10, w = (row & 1023) >> 6;
+    uint64_t r = uprefix[tile];
+    for (uint64_t k = 0; k < w; k++) r += (uint64_t)__popcll(ubits[tile * 16 + k]);
+    return r + (uint64_t)__popcll(ubits[tile * 16 + w] & ((1ull << (row & 63)) - 1ull));
+  };
+  const uint32_t n = *nres;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4 r = results[i];
+    const uint64_t g = rank_of(r.x);
+    cnt[g] = r.y; val[g] = (uint64_t)r.w << 32 | r.z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && aux[0] != kREmpty) { const uint64_t g = rank_of(aux[0]); cnt[g] = gspec[0]; val[g] = gspec[1]; }
+}
 }  // namespace
 
 int64_t radix_rows_per_chunk(int64_t nrows, int chunks) {
@@ -464,7 +658,8 @@ int radix_share() { return kRShare; }
 // the record pool for `cnt` selected rows in 2^kbits partitions: every stream (partition, share) ends in a page that is not full, one page is nobody's
 // (where a stream that gave up puts its records); a stream may take `maxv` pages: 16 times its even share — the sample already turned skewed columns away
 int64_t radix_pool_pages(int64_t cnt, int kbits) { return (cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) + 1; }
-int64_t radix_pool_record_bytes(int64_t cnt, int kbits) { return radix_pool_pages(cnt, kbits) * kRPage * 12; }
+int64_t radix_pool_record_bytes(int64_t cnt, int kbits, bool with_values) { return radix_pool_pages(cnt, kbits) * kRPage * (with_values ? 20 : 12); }
+int radix_group_slots() { return kGSlots; }
 uint32_t radix_pool_maxv(int64_t cnt, int kbits) { const int64_t even = ((cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) - 1) / ((int64_t)kRShare << kbits); return (uint32_t)(16 * even + 16); }
 
 bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks, int step,
@@ -479,24 +674,43 @@ bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, in
   }
   return true;
 }
-template <int KIND>
+template <int KIND, bool HASVAL>
 static bool radix_partition_go(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                               const RadixPool& pool, uint32_t* recs_out, uint64_t* aux) {
-  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+                               const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixVals& vals) {
+  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock, HASVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); return false; }
-  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
-                     radix_rows_per_chunk(nrows, chunks), kbits, pool, recs_out, aux, radix_xp());
+  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock, HASVAL>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
+                     radix_rows_per_chunk(nrows, chunks), kbits, pool, recs_out, aux, vals, radix_xp());
   return true;
 }
 // (512-thread workgroups sorting 4096 rows, two per CU, instead of one of 1024 sorting 8192: 5.36-5.43 ms against 5.32-5.33 — the pass waits for its stores either way)
+// group = nullptr: 12-byte records for unique; otherwise 20-byte records {key, row, value} for groupreduce (group->valcol may be null: count only)
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const RadixPool& pool, uint32_t* recs_out, uint64_t* aux) {
+                            const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixGroup* group) {
   if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
+  RadixVals v{};
+  if (group) { v.col = (const uint64_t*)group->valcol; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; }
+#define DFDB_RP(K) (group ? radix_partition_go<K, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
+                          : radix_partition_go<K, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v))
   switch (radix_kind(dtype)) {
-    case kKindRaw8: return radix_partition_go<kKindRaw8>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
-    case kKindF64: return radix_partition_go<kKindF64>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
-    default: return radix_partition_go<kKindAny>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux);
+    case kKindRaw8: return DFDB_RP(kKindRaw8);
+    case kKindF64: return DFDB_RP(kKindF64);
+    default: return DFDB_RP(kKindAny);
   }
+#undef DFDB_RP
+}
+bool launch_radix_group(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, bool mark, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux,
+                        const RadixGroup& group, int cus) {
+  const size_t lds = (size_t)kGSlots * 24 + (size_t)(kRBlock / 64) * kRQueue * 20;
+  static bool ok = [] { return hipFuncSetAttribute((const void*)k_radix_group, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess; }();
+  if (!ok) { (void)hipGetLastError(); return false; }
+  const int P = 1 << kbits;
+  hipLaunchKernelGGL(k_radix_group, dim3(P < cus ? P : cus), dim3(kRBlock), lds, s, recs, pool, P, mark ? 1 : 0, bitmap, tile_counts, aux, (uint4*)group.results, group.nres,
+                     group.gop, group.vkind);
+  return true;
+}
+void launch_radix_group_finish(hipStream_t s, const RadixGroup& group, const uint64_t* ubits, const uint64_t* uprefix, const uint64_t* aux, uint64_t* cnt, uint64_t* val) {
+  hipLaunchKernelGGL(k_radix_group_finish, dim3(1024), dim3(256), 0, s, (const uint4*)group.results, group.nres, ubits, uprefix, aux, group.gspec, cnt, val);
 }
 bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus) {
   const size_t lds = (size_t)kRSlots * 12 + (size_t)(kRBlock / 64) * kRQueue * 12;

@@ -166,12 +166,20 @@ struct RadixPool { uint32_t* front; uint32_t* pt; uint32_t* next_page; uint32_t 
 int64_t radix_rows_per_chunk(int64_t nrows, int chunks);
 int radix_share();
 int64_t radix_pool_pages(int64_t cnt, int kbits);
-int64_t radix_pool_record_bytes(int64_t cnt, int kbits);
+int64_t radix_pool_record_bytes(int64_t cnt, int kbits, bool with_values);
+int radix_group_slots();
 uint32_t radix_pool_maxv(int64_t cnt, int kbits);
 bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks, int step,
                          uint32_t* counts /* [2^kbits], zero before */);
+// groupreduce by radix: the records carry the row's 8-byte value (valcol; null: count only); gop 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
+// (of order images: vkind 0 signed, 1 unsigned, 2 double); results [<= groups] {first row, rows, value} + their count nres; gspec {rows, value} of the unstorable key
+struct RadixGroup { const void* valcol; int gop; int vkind; void* results; uint32_t* nres; uint64_t* gspec; };
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const RadixPool& pool, uint32_t* recs_out /* 12 bytes per record: key image, row */, uint64_t* aux);
+                            const RadixPool& pool, uint32_t* recs_out /* 12 bytes per record: key image, row; with a group: 20, + the value */, uint64_t* aux,
+                            const RadixGroup* group = nullptr);
+bool launch_radix_group(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, bool mark, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux,
+                        const RadixGroup& group, int cus);
+void launch_radix_group_finish(hipStream_t s, const RadixGroup& group, const uint64_t* ubits, const uint64_t* uprefix, const uint64_t* aux, uint64_t* cnt, uint64_t* val);
 bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux, int cus);
 int64_t unique_dense_max_range();
 bool unique_dense_dtype(int dtype);

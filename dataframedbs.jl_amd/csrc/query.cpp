@@ -1161,6 +1161,9 @@ struct UniqueTables {
   // inserted: the caller's pass meets every row anyway and reports a string that is not in the table (`optimistic` comes back true; the caller then
   // runs everything again with allow_optimistic = false).  Ten brands over 5e8 rows: the insert pass 2.2 -> 0.1 ms.
   bool allow_optimistic = false, optimistic = false;
+  // in: the caller can reduce by radix (group_radix: more groups than LDS accumulators hold) and wants to know EARLY whether that is the case; out: the number of
+  // distinct keys the first chunk's rows promise when it is more than 9216 — and then nothing else was done: the selection is as it was, no table was finished
+  bool group_probe = false; int64_t group_estimate = 0;
 };
 // K9: unique over a String column that has a dictionary — the first selected row of every code, no hash table.  Leaves what unique_impl leaves (the
 // bitmap holds exactly the first occurrences, prefix scanned); rank_of_code (optional) maps a code to its group number in order of first appearance.
@@ -1333,6 +1336,16 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // {key image, row} record into one of P partitions (by the top bits of the key's hash) and each partition is reduced through a table in LDS.  Streams instead
 // of one random line per row.  false = not taken (too few or too many distinct values, no room for the 12 bytes per selected row, a partition that outgrew
 // its table): the caller goes on with the hash table; the selection is as it was.
+// how many distinct values `cnt` selected rows hold when the first r0 of them held d0, assuming they turn up evenly: d0 = D (1 - exp(-r0 / D)), by bisection
+static double estimate_distinct(uint64_t d0, uint64_t r0, int64_t cnt) {
+  double D = (double)cnt;
+  if (d0 < r0) {
+    double lo = (double)d0, hi = (double)cnt;
+    for (int it = 0; it < 60 && hi - lo > 1.0; it++) { const double mid = 0.5 * (lo + hi); if (mid * (1.0 - std::exp(-(double)r0 / mid)) < (double)d0) lo = mid; else hi = mid; }
+    D = std::min((double)cnt, hi);
+  }
+  return D;
+}
 static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 1.3 + partition 5.0-5.3 + unique 3.0 ms = 10.7-10.9 ms end to end against the
@@ -1341,12 +1354,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
   if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || r0 == 0 || d0 == 0) return false;      // (rows and pool positions are 32-bit; all ones is "no row")
   if (mode < 2 && cnt < (4ll << 20)) return false;                       // (2: a test knob — any size; measured against the hash table down to 3 M selected rows of 1e9: tools/r6_radix_selective.py)
-  double D = (double)cnt;
-  if (d0 < r0) {                                                         // solve d0 = D (1 - exp(-r0 / D)) for D by bisection
-    double lo = (double)d0, hi = (double)cnt;
-    for (int it = 0; it < 60 && hi - lo > 1.0; it++) { const double mid = 0.5 * (lo + hi); if (mid * (1.0 - std::exp(-(double)r0 / mid)) < (double)d0) lo = mid; else hi = mid; }
-    D = std::min((double)cnt, hi);
-  }
+  const double D = estimate_distinct(d0, r0, cnt);
   if (mode < 2 && D < 131072.0) return false;                            // the hash table stays in the L2s: nothing to gain
   int kbits = 8;
   while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;       // (fewer partitions = longer runs per tile of the partition pass; more = emptier tables in the unique pass: 1e6 values -> 512)
@@ -1377,7 +1385,7 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   const size_t ctl_words = (size_t)P + (size_t)PS + 16;                  // the sample's counts [P], the streams' running positions [PS], the pool's counter
   try {
     ctl.ensure(ctl_words * 4); pt.ensure((size_t)PS * pool.maxv * 4 + 512);        // (+ 64 entries nobody owns: the unique pass reads 64 at a time)
-    recs.ensure((size_t)radix_pool_record_bytes(cnt, kbits) + 256);
+    recs.ensure((size_t)radix_pool_record_bytes(cnt, kbits, false) + 256);
     sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
   pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.pt = pt.as<uint32_t>();
@@ -1493,6 +1501,10 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       }
       // (optimistic: chunk 1 must have fed at least 64 K selected rows and claimed nothing that chunk 0 had not)
       if (c == 0) { claims_c0 = st[0]; rows_c0 = r; }
+      if (c == 0 && !is_str && T.group_probe && r > 0) {               // groupreduce asks: more groups than LDS accumulators hold?  Then it reduces by radix, first rows included
+        const double D = estimate_distinct(st[0], r, cnt);
+        if (D > 9216.0) { T.group_estimate = (int64_t)D; return; }
+      }
       if (c == 0 && !is_str && !T.defer_verify && unique_radix(q, col, cnt, T, st[0], r)) return;      // the radix-partitioned form took it: q's bitmap holds the first occurrences
       else if (c == 1 && !(st[0] == claims_c0 && r >= rows_c0 + 65536)) claims_c0 = ~0ull;
       if (c == 0 && bounds[1] <= bounds[0]) claims_c0 = ~0ull;
@@ -1553,6 +1565,90 @@ static void unique_impl(dfdb_query* q, int32_t p, UniqueTables* keep) {
 }
 void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
 
+// groupreduce over MORE groups than a workgroup's LDS accumulators hold, by radix (k_radix.hip, round 6): with the first occurrences already in q's bitmap (unique
+// made them: `ng` groups, q->prefix scanned) every selected row of `sel` is written as a {key, row, value} record into one of P partitions, each partition is reduced
+// through a table in LDS, and a key's result goes to the place its first row's rank names.  false = not taken (nothing was written to the outputs): too many groups
+// for the tables, a skewed column, no room — the caller's accumulate pass (global atomics) runs.  85-135 ms -> see profiles/r6_groupreduce_radix.txt.
+// mark: q's bitmap does NOT hold every group's first row yet (unique looked at the head of the column only): the table pass marks them itself — the bitmap is
+// cleared first, scanned afterwards, and *ng_io becomes the number of groups; on false the bitmap is whatever the pass left (the caller restores the selection).
+static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int op, int64_t nsel, int64_t* ng_io, const uint64_t* sel, bool mark) {
+  int64_t ng = mark ? *ng_io + *ng_io / 4 + 1024 : *ng_io;                // (marking: an estimate from the head — the tables are sized with room to spare)
+  dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
+  const int64_t mode = ctx_option(ctx, "unique_radix", 1);
+  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || dt_nullable(kc.dtype) || dt_base(kc.dtype) == DFDB_STRING) return false;
+  if (vc && dt_width(vc->dtype) != 8) return false;
+  int kbits = 9;                                                         // (512 partitions at least: one workgroup reduces one partition, and there are 256 CUs)
+  while (kbits < 10 && ng / (1ll << kbits) > 1200) kbits++;              // (a 4096-slot table at 30 % load)
+  if (ng / (1ll << kbits) > 1800) return false;
+  const int P = 1 << kbits;
+  const int C = round_up(4 * std::max(1, ctx->prop.multiProcessorCount), radix_share());
+  const int64_t PS = (int64_t)P * radix_share();
+  const int dt = dt_base(kc.dtype);
+  if (radix_pool_pages(nsel, kbits) * 8192 >= (1ll << 32)) return false;
+  struct Temps {
+    dfdb_ctx* ctx; DevBuf ctl, pt, res;
+    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); res.release(); }
+  } tmp{ctx, {}, {}, {}};
+  DevBuf& recs = ctx->radix_recs;
+  RadixPool pool{};
+  pool.maxv = radix_pool_maxv(nsel, kbits);
+  pool.dump_page = (uint32_t)(radix_pool_pages(nsel, kbits) - 1);
+  // ctl: the sample's counts [P], the streams' running positions [PS], the pool's counter, then (8-byte words) aux [4], gspec [2], nres
+  const size_t ctl_words = (size_t)P + (size_t)PS + 16, tail = (ctl_words * 4 + 63) / 64 * 64;
+  try {
+    tmp.ctl.ensure(tail + 128); tmp.pt.ensure((size_t)PS * pool.maxv * 4 + 512); tmp.res.ensure((size_t)(mark ? (int64_t)P * radix_group_slots() : ng) * 16 + 256);
+    recs.ensure((size_t)radix_pool_record_bytes(nsel, kbits, true) + 256);
+  } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  pool.front = tmp.ctl.as<uint32_t>() + P; pool.next_page = tmp.ctl.as<uint32_t>() + P + PS; pool.pt = tmp.pt.as<uint32_t>();
+  uint64_t* aux = (uint64_t*)((char*)tmp.ctl.p + tail);                  // [0] the unstorable key's first row, [1] unused (no missing keys here), [3] abort
+  RadixGroup g{};
+  g.valcol = vc ? vc->data.p : nullptr;
+  g.gop = op == DFDB_AGG_SUM ? (q->gr_kind == 2 ? 2 : 1) : (op == DFDB_AGG_MIN ? 3 : (op == DFDB_AGG_MAX ? 4 : 0));
+  if (!vc) g.gop = 0;
+  g.vkind = q->gr_kind; g.results = tmp.res.p; g.gspec = aux + 4; g.nres = (uint32_t*)(aux + 6);
+  HIP_CHECK(hipMemsetAsync(tmp.ctl.p, 0, tail + 128, s));
+  HIP_CHECK(hipMemsetAsync(aux, 0xFF, 16, s));                           // aux[0], aux[1] = none
+  if (g.gop == 3) HIP_CHECK(hipMemsetAsync(aux + 5, 0xFF, 8, s));        // gspec[1]: a minimum starts at all ones
+  HIP_CHECK(hipMemsetAsync(tmp.pt.p, 0xFF, (size_t)PS * pool.maxv * 4, s));
+  {
+    const int step = radix_rows_per_chunk(t->nrows, C) / 8192 >= 32 ? 16 : 1;
+    { LaunchTimer lt(ctx, "radix_sample");
+      if (!launch_radix_sample(s, sel, kc.data.p, dt, nullptr, t->nrows, kbits, C, step, tmp.ctl.as<uint32_t>())) return false; }
+    std::vector<uint32_t> cn((size_t)P);
+    HIP_CHECK(hipMemcpyAsync(cn.data(), tmp.ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    stream_wait(ctx);
+    uint64_t maxp = 0, total = 0;
+    for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
+    if (maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "group_radix.skewed"); return false; }
+  }
+  { LaunchTimer lt(ctx, "radix_partition");
+    if (!launch_radix_partition(s, sel, kc.data.p, dt, nullptr, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g)) return false; }
+  if (mark) {
+    HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
+    HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
+  }
+  { LaunchTimer lt(ctx, "radix_group");
+    if (!launch_radix_group(s, recs.as<uint32_t>(), pool, kbits, mark, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), aux, g, ctx->prop.multiProcessorCount)) return false; }
+  uint64_t tailw[8] = {};
+  HIP_CHECK(hipMemcpyAsync(tailw, aux, 56, hipMemcpyDeviceToHost, s));
+  stream_wait(ctx);
+  const uint32_t nres = (uint32_t)tailw[6];
+  if (tailw[3] != 0) { prof_note(ctx, "group_radix.fell_back"); return false; }
+  if (mark) {
+    scan_prefix(q);
+    selection_changed(q);
+    ng = query_count(q, -1);
+    *ng_io = ng;
+  }
+  if ((int64_t)nres + (tailw[0] != ~0ull ? 1 : 0) != ng) { prof_note(ctx, "group_radix.mismatch"); return false; }     // (cannot happen: the table pass saw every key unique saw)
+  q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
+  HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
+  HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+  launch_radix_group_finish(s, g, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), aux, q->gr_cnt.as<uint64_t>(), q->gr_val.as<uint64_t>());
+  prof_note(ctx, "group_radix.taken");
+  return true;                                                           // (the temporaries' destructor drains the stream)
+}
+
 // groupreduce(view, (:key,); out = :val => Stat()) (src/tables/aggregate.jl:1-36; unfinished in the reference: it numbers the groups in order of
 // first appearance of the key and prints the map).  Completed to that intent: one group per distinct key (isequal), groups in order of first
 // appearance, count and one reduced value per group.  Device side: unique's table + k_group_ids + k_group_accumulate (k_unique.hip).
@@ -1584,7 +1680,8 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   if (vc) { const int b = dt_base(vc->dtype); q->gr_kind = dt_isfloat(b) ? 2 : (dt_issigned(b) ? 0 : 1); }
   if (ngroups) *ngroups = 0;
   if (key_bytes) *key_bytes = 0;
-  if (query_count(q, -1) == 0 || t->nrows == 0) { q->gr_state = 1; return; }
+  const int64_t nsel = query_count(q, -1);
+  if (nsel == 0 || t->nrows == 0) { q->gr_state = 1; return; }
   // the full selection is kept aside: unique narrows q's bitmap to the first occurrences (= the groups, in order)
   const size_t nw = padded_words(t->nrows);
   q->gr_sel.ensure(nw * 8);
@@ -1608,7 +1705,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   }
   UniqueTables T;
   int64_t ng = 0;
-  bool pessimistic = false, whole_dense = false;
+  bool pessimistic = false, whole_dense = false, radix_failed = false;
   // integer keys, dense form: the table of first rows / group numbers is made from the HEAD of the column (4 M rows) when the accumulate pass can be the one with
   // the table in LDS — that pass meets every row anyway and raises a flag for a key that has no group, after which everything runs again over every row
   // (the presence pass over the whole key column was 1.3 of the 5.0 ms of 1e9 rows by 5000 keys)
@@ -1620,7 +1717,18 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     T.defer_verify = true;
     T.allow_optimistic = !pessimistic && ctx_option(ctx, "groupreduce_optimistic", 1) != 0;
     T.allow_head = head_ok && !whole_dense;
+    T.group_probe = !radix_failed && ctx_option(ctx, "unique_radix", 1) != 0 && !dt_nullable(kc.dtype) && dt_base(kc.dtype) != DFDB_STRING && (!vc || dt_width(vc->dtype) == 8);
+    T.group_estimate = 0;
     unique_impl(q, key_p, &T);
+    if (T.group_estimate > 0) {                                  // the first chunk of rows promises more groups than any accumulate pass's LDS holds: by radix, first rows and all
+      ng = T.group_estimate;
+      if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), true)) break;
+      radix_failed = true;                                       // (skewed, too many groups, no room: the bitmap may have been cleared — everything again, the old way)
+      launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
+      scan_prefix(q);
+      selection_changed(q);
+      continue;
+    }
     const bool head_table = T.dense && T.head_only;
     if (head_table) HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));        // (the word the accumulate pass raises: aux[3])
     if (T.optimistic) HIP_CHECK(hipMemsetAsync((char*)T.aux.p + 24, 0, 8, s));      // the accumulate pass raises this word when it meets a string the table does not hold
@@ -1632,6 +1740,20 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
     HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
     HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
+    // more groups than the LDS accumulators of any accumulate pass hold: by radix (group_radix) — which needs EVERY group's first row in the bitmap: a table made
+    // from the head of the column / a prefix of the rows is made again from all of them first
+    if (!radix_failed && !T.is_str && ng > 9216 && !dt_nullable(kc.dtype) && (!vc || dt_width(vc->dtype) == 8) && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 1800 * 1024) {
+      const bool partial = head_table || T.optimistic;          // unique looked at the head of the column / a prefix of the rows: not every group's first row is marked
+      if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
+      radix_failed = true;
+      if (partial) {                                             // not taken, and the bitmap may have been cleared: everything again, every row looked at
+        whole_dense = true; pessimistic = true;
+        launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);     // the full selection again
+        scan_prefix(q);
+        selection_changed(q);
+        continue;
+      }
+    }
     int dense_lds = 0;
     { LaunchTimer lt(ctx, "group_accumulate");
       const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;

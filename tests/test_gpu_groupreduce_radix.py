@@ -1,0 +1,117 @@
+"""groupreduce over MORE groups than a workgroup's LDS accumulators hold (9216), by radix (csrc/k_radix.hip: 20-byte {key, row, value} records, a table with
+accumulators per partition in LDS, results placed by the rank of a group's first row; csrc/query.cpp group_radix).  The reference's groupreduce numbers the groups
+in order of first appearance and stops (src/tables/aggregate.jl:1-36: it prints the map); counts and one statistic per group are this repository's completion.
+Checked against a numpy restatement: groups in order of first appearance, exact counts, integer sums / extrema exact, Float64 sums within n * eps * sum|x| (the
+order of the additions is not fixed), isequal keys (one NaN, -0.0 apart from 0.0), the key whose image cannot be stored (-1), a predicate, and the same answers
+from the form it replaces (global atomics: ctx option unique_radix = 0)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def expect(keys_img, sel, vals, stat):
+    rows = np.flatnonzero(sel)
+    uniq, first, inv = np.unique(keys_img[rows], return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                    # groups in order of first appearance
+    rank = np.empty(len(uniq), np.int64); rank[order] = np.arange(len(uniq))
+    gid = rank[inv]
+    ng = len(uniq)
+    cnt = np.bincount(gid, minlength=ng)
+    first_rows = rows[first[order]]
+    if stat == "count":
+        return first_rows, cnt, None
+    v = vals[rows]
+    if stat == "sum":
+        acc = np.zeros(ng, np.float64 if v.dtype.kind == "f" else np.int64)
+        np.add.at(acc, gid, v)
+        return first_rows, cnt, acc
+    acc = np.full(ng, v.max() if stat == "min" else v.min(), v.dtype)
+    (np.minimum if stat == "min" else np.maximum).at(acc, gid, v)
+    return first_rows, cnt, acc
+
+
+def image(k):
+    if k.dtype.kind == "f":
+        u = k.astype(np.float64).view(np.uint64).copy(); u[np.isnan(k)] = 0x7ff8000000000000
+        return u
+    return k.astype(np.int64).view(np.uint64)
+
+
+def run(dfdb, ctx, view, by, col, stat, radix):
+    ctx.set_option("unique_radix", radix); ctx.profile(True)
+    try:
+        df = dfdb.groupreduce(view, by, col, stat)
+        taken = ctx.profile_get("group_radix.taken")[0]
+    finally:
+        ctx.profile(False); ctx.set_option("unique_radix", 1)
+    return df, taken
+
+
+@pytest.mark.parametrize("kind", ["int64", "float64", "int32", "dense"])
+@pytest.mark.parametrize("stat", ["count", "sum", "min", "max"])
+def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
+    rng = np.random.default_rng(hash((kind, stat)) % 1000)
+    n = 1_200_007
+    if kind == "int64":
+        k = (rng.integers(0, 150_000, n) * 40_503 - 3_000_000_000).astype(np.int64)
+        k[rng.random(n) < 0.002] = -1                                    # the image the tables cannot store: counted and reduced by the partition pass itself
+    elif kind == "float64":
+        k = rng.integers(0, 120_000, n).astype(np.float64) / 8.0
+        k[rng.random(n) < 0.005] = np.nan
+        k[rng.random(n) < 0.005] = -0.0
+    elif kind == "int32":
+        k = rng.integers(-60_000, 60_000, n).astype(np.int32)
+    else:
+        k = rng.integers(0, 300_000, n).astype(np.int64)                 # a small span: unique takes its dense form, from the head of the column first
+    vi = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    vf = rng.normal(size=n) * 1e3
+    a = rng.integers(0, 100, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "k": k, "vi": vi, "vf": vf}, block_size=65536, ctx=ctx)
+    try:
+        for col, vals in (("vi", vi), ("vf", vf)):
+            if stat == "count" and col == "vf":
+                continue
+            for view, sel in ((t, np.ones(n, bool)), (t[("a", lambda c: c < 61), dfdb_mod.ALL], a < 61)):
+                first_rows, cnt, acc = expect(image(k), sel, vals, stat)
+                df, taken = run(dfdb_mod, ctx, view, "k", None if stat == "count" else col, stat, 1)
+                assert taken == 1, (kind, stat, col)
+                keys = df["k"].to_numpy()
+                want_keys = k[first_rows]
+                assert len(df) == len(cnt)
+                assert np.array_equal(image(np.asarray(keys, dtype=k.dtype)), image(want_keys)), (kind, stat, col)
+                assert np.array_equal(df["count"].to_numpy(), cnt), (kind, stat, col)
+                if stat != "count":
+                    got = df[stat].to_numpy()
+                    if vals.dtype.kind == "f" and stat == "sum":
+                        absum = expect(image(k), sel, np.abs(vals), "sum")[2]
+                        assert np.all(np.abs(got - acc) <= cnt * np.finfo(np.float64).eps * absum + 1e-300), (kind, col)
+                    else:
+                        assert np.array_equal(got, acc), (kind, stat, col)
+                # the form it replaces gives the same table
+                df0, taken0 = run(dfdb_mod, ctx, view, "k", None if stat == "count" else col, stat, 0)
+                assert taken0 == 0
+                assert np.array_equal(image(np.asarray(df0["k"].to_numpy(), dtype=k.dtype)), image(want_keys)) and np.array_equal(df0["count"].to_numpy(), cnt)
+    finally:
+        t.close()
+
+
+def test_groupreduce_by_radix_leaves_a_skewed_column_alone(dfdb_mod, ctx):
+    rng = np.random.default_rng(3)
+    n = 2_000_003
+    k = (rng.integers(0, 100_000, n) * 3).astype(np.int64) + (1 << 40)
+    k[rng.random(n) < 0.45] = 7
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"k": k, "v": v}, block_size=65536, ctx=ctx)
+    try:
+        ctx.profile(True)
+        try:
+            df = dfdb_mod.groupreduce(t, "k", "v", "sum")
+            skewed, taken = ctx.profile_get("group_radix.skewed")[0], ctx.profile_get("group_radix.taken")[0]
+        finally:
+            ctx.profile(False)
+        assert skewed >= 1 and taken == 0
+        first_rows, cnt, acc = expect(image(k), np.ones(n, bool), v, "sum")
+        assert np.array_equal(df["k"].to_numpy(), k[first_rows]) and np.array_equal(df["count"].to_numpy(), cnt) and np.array_equal(df["sum"].to_numpy(), acc)
+    finally:
+        t.close()
