@@ -187,7 +187,20 @@ constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }   
 // the record is written (the tile's 64 KB of values: one gathered read per record, behind the sort), and the rows whose key cannot be stored are counted and reduced
 // here, in a workgroup-wide accumulator that is flushed to gspec {count, value} once per workgroup (GOP: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // of order images; vkind: how a value's image is made — k_unique.hip's order_image).
-struct RadixVals { const uint64_t* col; uint64_t* gspec; int gop; int vkind; };
+struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; };
+// a value as the 64 bits the accumulators work on (= k_unique.hip's value_bits: integers widened, Float32 as the double it converts to)
+__device__ __forceinline__ uint64_t rvalue_bits(const void* col, int dtype, int64_t row) {
+  switch (dtype) {
+    case DFDB_I8:  return (uint64_t)(int64_t)((const int8_t*)col)[row];
+    case DFDB_I16: return (uint64_t)(int64_t)((const int16_t*)col)[row];
+    case DFDB_I32: return (uint64_t)(int64_t)((const int32_t*)col)[row];
+    case DFDB_U8: case DFDB_BOOL: return ((const uint8_t*)col)[row];
+    case DFDB_U16: return ((const uint16_t*)col)[row];
+    case DFDB_U32: return ((const uint32_t*)col)[row];
+    case DFDB_F32: return (uint64_t)__double_as_longlong((double)((const float*)col)[row]);
+    default: return ((const uint64_t*)col)[row];
+  }
+}
 __device__ __forceinline__ uint64_t order_image(uint64_t bits, int kind, bool is_min) {         // (= k_unique.hip's: unsigned compare; a NaN wins either reduction)
   if (kind == 1) return bits;
   if (kind == 0) return bits ^ (1ull << 63);
@@ -205,7 +218,7 @@ template <int KIND, int BLOCK, bool HASVAL>
 __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, RadixPool pool,
                                                              uint32_t* __restrict__ recs_out, uint64_t* aux, RadixVals vals, int xp) {
-  __shared__ uint64_t spec_sh[2];                               // HASVAL: {rows, reduced value} of the rows whose key is the unstorable image, this workgroup's
+  __shared__ uint64_t spec_sh[4];                               // HASVAL: {rows, reduced value} of the rows whose key is the unstorable image, then of the rows whose key is missing: this workgroup's
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
@@ -218,7 +231,8 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
-  if (HASVAL && tid == 0) { spec_sh[0] = 0; spec_sh[1] = vals.gop == 3 ? ~0ull : 0ull; }
+  if (HASVAL && tid == 0) { spec_sh[0] = spec_sh[2] = 0; spec_sh[1] = spec_sh[3] = vals.gop == 3 ? ~0ull : 0ull; }
+  const bool v8 = vals.vdt == DFDB_I64 || vals.vdt == DFDB_U64 || vals.vdt == DFDB_F64;
   const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the stream (partition p, this workgroup's share)
   for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
@@ -239,7 +253,19 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
       unstorable |= nin[j] & ~ok;
       if (__builtin_amdgcn_inverse_ballot_w64(nin[j] & ok)) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
     }
-    if (nmiss) tile_first_missing(sel, missing, base, nrows, wv, lane, aux);       // (rare: the two keys kept aside — a missing key's first row, aux[1]; ...
+    if (nmiss) {                                                // (rare: the two keys kept aside — a missing key's first row, aux[1] — and, HASVAL, its rows and their values; ...
+      tile_first_missing(sel, missing, base, nrows, wv, lane, aux);
+      if (HASVAL) {
+        const int64_t w0 = (base >> 6) + wv * 8, wl = (nrows - 1) >> 6;
+        for (int j = 0; j < 8 && w0 + j <= wl; j++) {
+          uint64_t m = wave_uniform(sel[w0 + j] & missing[w0 + j]);
+          if (w0 + j == wl && (nrows & 63)) m &= (1ull << (nrows & 63)) - 1ull;
+          if (!m) continue;
+          if (lane == 0) atomicAdd((unsigned long long*)&spec_sh[2], (unsigned long long)__builtin_popcountll(m));
+          if (vals.col && ((m >> lane) & 1ull)) acc_value(&spec_sh[3], rvalue_bits(vals.col, vals.vdt, (w0 + j) * 64 + lane), vals.gop, vals.vkind);
+        }
+      }
+    }
     if (unstorable) {                                           // ... the unstorable image's, aux[0]: -1 in an Int64 column is that image; one lane of the wave reports)
       bool first = true;
       for (int j = 0; j < 8; j++) {
@@ -249,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
         first = false;
         if (!HASVAL) break;
         if (lane == 0) atomicAdd((unsigned long long*)&spec_sh[0], (unsigned long long)__builtin_popcountll(bad));
-        if (vals.col && ((bad >> lane) & 1ull)) acc_value(&spec_sh[1], vals.col[base + wv * 512 + j * 64 + lane], vals.gop, vals.vkind);
+        if (vals.col && ((bad >> lane) & 1ull)) acc_value(&spec_sh[1], rvalue_bits(vals.col, vals.vdt, base + wv * 512 + j * 64 + lane), vals.gop, vals.vkind);
       }
     }
     const int64_t nb = base + TILE;
@@ -332,7 +358,11 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     uint64_t ov[8];                                             // HASVAL: the records' values, gathered out of the tile's rows
     if (HASVAL) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) ov[k] = vals.col && !(xp & 256) && (uint32_t)(k * BLOCK + tid) < total ? vals.col[base + (ow[k] & 8191u)] : 0ull;      // (bit 8, timing only: no values)
+      for (int k = 0; k < 8; k++) {
+        ov[k] = 0;
+        if (vals.col && !(xp & 256) && (uint32_t)(k * BLOCK + tid) < total)                      // (bit 8, timing only: no values)
+          ov[k] = v8 ? ((const uint64_t*)vals.col)[base + (ow[k] & 8191u)] : rvalue_bits(vals.col, vals.vdt, base + (ow[k] & 8191u));
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));
@@ -358,12 +388,13 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   }
   if (HASVAL) {                                                 // the workgroup's rows of the unstorable key -> the launch's
     __syncthreads();
-    if (tid == 0 && spec_sh[0]) {
-      atomicAdd((unsigned long long*)&vals.gspec[0], (unsigned long long)spec_sh[0]);
-      if (vals.gop == 1) atomicAdd((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
-      else if (vals.gop == 2) atomicAdd((double*)&vals.gspec[1], __longlong_as_double((long long)spec_sh[1]));
-      else if (vals.gop == 3) atomicMin((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
-      else if (vals.gop == 4) atomicMax((unsigned long long*)&vals.gspec[1], (unsigned long long)spec_sh[1]);
+    if (tid < 2 && spec_sh[2 * tid]) {
+      atomicAdd((unsigned long long*)&vals.gspec[2 * tid], (unsigned long long)spec_sh[2 * tid]);
+      const uint64_t v = spec_sh[2 * tid + 1];
+      if (vals.gop == 1) atomicAdd((unsigned long long*)&vals.gspec[2 * tid + 1], (unsigned long long)v);
+      else if (vals.gop == 2) atomicAdd((double*)&vals.gspec[2 * tid + 1], __longlong_as_double((long long)v));
+      else if (vals.gop == 3) atomicMin((unsigned long long*)&vals.gspec[2 * tid + 1], (unsigned long long)v);
+      else if (vals.gop == 4) atomicMax((unsigned long long*)&vals.gspec[2 * tid + 1], (unsigned long long)v);
     }
   }
 }
@@ -643,7 +674,7 @@ __global__ void k_radix_group_finish(const uint4* __restrict__ results, const ui
     const uint64_t g = rank_of(r.x);
     cnt[g] = r.y; val[g] = (uint64_t)r.w << 32 | r.z;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && aux[0] != kREmpty) { const uint64_t g = rank_of(aux[0]); cnt[g] = gspec[0]; val[g] = gspec[1]; }
+  if (blockIdx.x == 0 && threadIdx.x < 2 && aux[threadIdx.x] != kREmpty) { const uint64_t g = rank_of(aux[threadIdx.x]); cnt[g] = gspec[2 * threadIdx.x]; val[g] = gspec[2 * threadIdx.x + 1]; }
 }
 }  // namespace
 
@@ -689,7 +720,7 @@ bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col,
                             const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixGroup* group) {
   if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
   RadixVals v{};
-  if (group) { v.col = (const uint64_t*)group->valcol; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; }
+  if (group) { v.col = group->valcol; v.vdt = group->valdt; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; }
 #define DFDB_RP(K) (group ? radix_partition_go<K, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
                           : radix_partition_go<K, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v))
   switch (radix_kind(dtype)) {

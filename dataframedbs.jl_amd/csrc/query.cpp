@@ -1575,8 +1575,8 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   int64_t ng = mark ? *ng_io + *ng_io / 4 + 1024 : *ng_io;                // (marking: an estimate from the head — the tables are sized with room to spare)
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
-  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || dt_nullable(kc.dtype) || dt_base(kc.dtype) == DFDB_STRING) return false;
-  if (vc && dt_width(vc->dtype) != 8) return false;
+  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || dt_base(kc.dtype) == DFDB_STRING) return false;
+  const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
   int kbits = 9;                                                         // (512 partitions at least: one workgroup reduces one partition, and there are 256 CUs)
   while (kbits < 10 && ng / (1ll << kbits) > 1200) kbits++;              // (a 4096-slot table at 30 % load)
   if (ng / (1ll << kbits) > 1800) return false;
@@ -1600,20 +1600,20 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
     recs.ensure((size_t)radix_pool_record_bytes(nsel, kbits, true) + 256);
   } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
   pool.front = tmp.ctl.as<uint32_t>() + P; pool.next_page = tmp.ctl.as<uint32_t>() + P + PS; pool.pt = tmp.pt.as<uint32_t>();
-  uint64_t* aux = (uint64_t*)((char*)tmp.ctl.p + tail);                  // [0] the unstorable key's first row, [1] unused (no missing keys here), [3] abort
+  uint64_t* aux = (uint64_t*)((char*)tmp.ctl.p + tail);                  // [0] the unstorable key's first row, [1] the missing key's, [3] abort; [4..7] gspec; [8] nres
   RadixGroup g{};
-  g.valcol = vc ? vc->data.p : nullptr;
+  g.valcol = vc ? vc->data.p : nullptr; g.valdt = vc ? dt_base(vc->dtype) : 0;
   g.gop = op == DFDB_AGG_SUM ? (q->gr_kind == 2 ? 2 : 1) : (op == DFDB_AGG_MIN ? 3 : (op == DFDB_AGG_MAX ? 4 : 0));
   if (!vc) g.gop = 0;
-  g.vkind = q->gr_kind; g.results = tmp.res.p; g.gspec = aux + 4; g.nres = (uint32_t*)(aux + 6);
+  g.vkind = q->gr_kind; g.results = tmp.res.p; g.gspec = aux + 4; g.nres = (uint32_t*)(aux + 8);
   HIP_CHECK(hipMemsetAsync(tmp.ctl.p, 0, tail + 128, s));
   HIP_CHECK(hipMemsetAsync(aux, 0xFF, 16, s));                           // aux[0], aux[1] = none
-  if (g.gop == 3) HIP_CHECK(hipMemsetAsync(aux + 5, 0xFF, 8, s));        // gspec[1]: a minimum starts at all ones
+  if (g.gop == 3) { HIP_CHECK(hipMemsetAsync(aux + 5, 0xFF, 8, s)); HIP_CHECK(hipMemsetAsync(aux + 7, 0xFF, 8, s)); }      // gspec[1], [3]: a minimum starts at all ones
   HIP_CHECK(hipMemsetAsync(tmp.pt.p, 0xFF, (size_t)PS * pool.maxv * 4, s));
   {
     const int step = radix_rows_per_chunk(t->nrows, C) / 8192 >= 32 ? 16 : 1;
     { LaunchTimer lt(ctx, "radix_sample");
-      if (!launch_radix_sample(s, sel, kc.data.p, dt, nullptr, t->nrows, kbits, C, step, tmp.ctl.as<uint32_t>())) return false; }
+      if (!launch_radix_sample(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, step, tmp.ctl.as<uint32_t>())) return false; }
     std::vector<uint32_t> cn((size_t)P);
     HIP_CHECK(hipMemcpyAsync(cn.data(), tmp.ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, s));
     stream_wait(ctx);
@@ -1622,17 +1622,17 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
     if (maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "group_radix.skewed"); return false; }
   }
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, sel, kc.data.p, dt, nullptr, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g)) return false; }
+    if (!launch_radix_partition(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g)) return false; }
   if (mark) {
     HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
     HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
   }
   { LaunchTimer lt(ctx, "radix_group");
     if (!launch_radix_group(s, recs.as<uint32_t>(), pool, kbits, mark, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), aux, g, ctx->prop.multiProcessorCount)) return false; }
-  uint64_t tailw[8] = {};
-  HIP_CHECK(hipMemcpyAsync(tailw, aux, 56, hipMemcpyDeviceToHost, s));
+  uint64_t tailw[9] = {};
+  HIP_CHECK(hipMemcpyAsync(tailw, aux, 72, hipMemcpyDeviceToHost, s));
   stream_wait(ctx);
-  const uint32_t nres = (uint32_t)tailw[6];
+  const uint32_t nres = (uint32_t)tailw[8];
   if (tailw[3] != 0) { prof_note(ctx, "group_radix.fell_back"); return false; }
   if (mark) {
     scan_prefix(q);
@@ -1640,7 +1640,7 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
     ng = query_count(q, -1);
     *ng_io = ng;
   }
-  if ((int64_t)nres + (tailw[0] != ~0ull ? 1 : 0) != ng) { prof_note(ctx, "group_radix.mismatch"); return false; }     // (cannot happen: the table pass saw every key unique saw)
+  if ((int64_t)nres + (tailw[0] != ~0ull ? 1 : 0) + (tailw[1] != ~0ull ? 1 : 0) != ng) { prof_note(ctx, "group_radix.mismatch"); return false; }     // (cannot happen: the table pass saw every key unique saw)
   q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
   HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
   HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
@@ -1717,7 +1717,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     T.defer_verify = true;
     T.allow_optimistic = !pessimistic && ctx_option(ctx, "groupreduce_optimistic", 1) != 0;
     T.allow_head = head_ok && !whole_dense;
-    T.group_probe = !radix_failed && ctx_option(ctx, "unique_radix", 1) != 0 && !dt_nullable(kc.dtype) && dt_base(kc.dtype) != DFDB_STRING && (!vc || dt_width(vc->dtype) == 8);
+    T.group_probe = !radix_failed && ctx_option(ctx, "unique_radix", 1) != 0 && dt_base(kc.dtype) != DFDB_STRING;
     T.group_estimate = 0;
     unique_impl(q, key_p, &T);
     if (T.group_estimate > 0) {                                  // the first chunk of rows promises more groups than any accumulate pass's LDS holds: by radix, first rows and all
@@ -1742,7 +1742,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
     // more groups than the LDS accumulators of any accumulate pass hold: by radix (group_radix) — which needs EVERY group's first row in the bitmap: a table made
     // from the head of the column / a prefix of the rows is made again from all of them first
-    if (!radix_failed && !T.is_str && ng > 9216 && !dt_nullable(kc.dtype) && (!vc || dt_width(vc->dtype) == 8) && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 1800 * 1024) {
+    if (!radix_failed && !T.is_str && ng > 9216 && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 1800 * 1024) {
       const bool partial = head_table || T.optimistic;          // unique looked at the head of the column / a prefix of the rows: not every group's first row is marked
       if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
       radix_failed = true;

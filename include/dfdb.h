@@ -168,8 +168,8 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                      256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per selected row + 0.4-0.8 GB of part-filled pages, kept by the context; no room for it, a
  *                      partition that outgrows its table, or one that holds more than eight average partitions' rows — a value a large part of the column has
  *                      —: the hash table answers).  8.8 ms against the hash table's 19.8 per 1e9 rows of 1e6 values
- *                      (profiles/r6_unique_radix.txt).  dfdb_query_groupreduce over more groups than a workgroup's LDS accumulators hold (9216; a fixed-width key that is
- *                      not nullable, an 8-byte value or none) goes the same way: 15.7 ms where global atomics took 88.8 per 1e9 rows in 50 000 groups
+ *                      (profiles/r6_unique_radix.txt).  dfdb_query_groupreduce over more groups than a workgroup's LDS accumulators hold (9216; a fixed-width key,
+ *                      nullable or not) goes the same way: 15.7 ms where global atomics took 88.8 per 1e9 rows in 50 000 groups
  *                      (profiles/r6_groupreduce_radix.txt).  0 = always the hash table / the global atomics
  *   "jit"              1 (default) = an expression the device INTERPRETER evaluates (outside `col OP const` terms, pairs and string matches: configs 2-5 never get here)
  *                      over at least 4 M rows is also compiled by hipRTC in the background — the interpreter's own source specialised for the program's shape — and later

@@ -48,7 +48,7 @@ def run(dfdb, ctx, view, by, col, stat, radix):
     return df, taken
 
 
-@pytest.mark.parametrize("kind", ["int64", "float64", "int32", "dense"])
+@pytest.mark.parametrize("kind", ["int64", "float64", "int32", "dense", "nullable"])
 @pytest.mark.parametrize("stat", ["count", "sum", "min", "max"])
 def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
     rng = np.random.default_rng(hash((kind, stat)) % 1000)
@@ -62,36 +62,51 @@ def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
         k[rng.random(n) < 0.005] = -0.0
     elif kind == "int32":
         k = rng.integers(-60_000, 60_000, n).astype(np.int32)
-    else:
+    elif kind == "dense":
         k = rng.integers(0, 300_000, n).astype(np.int64)                 # a small span: unique takes its dense form, from the head of the column first
+    else:
+        k = (rng.integers(0, 90_000, n) * 7_919 + (1 << 41)).astype(np.int64)      # Union{Int64, Missing}: missing is a group of its own
+    miss = rng.random(n) < 0.03 if kind == "nullable" else None
+    kcol = np.ma.masked_array(k, mask=miss) if miss is not None else k
+    kimg = image(k)
+    if miss is not None:
+        kimg = kimg.copy(); kimg[miss] = np.uint64(0x0123456789ABCDEF)   # (an image no key has)
     vi = rng.integers(-10**12, 10**12, n).astype(np.int64)
     vf = rng.normal(size=n) * 1e3
+    v32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)            # a value that is not eight bytes wide: widened where the record is written
     a = rng.integers(0, 100, n).astype(np.int64)
-    t = dfdb_mod.DFTable.from_columns({"a": a, "k": k, "vi": vi, "vf": vf}, block_size=65536, ctx=ctx)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "k": kcol, "vi": vi, "vf": vf, "v32": v32}, block_size=65536, ctx=ctx)
     try:
-        for col, vals in (("vi", vi), ("vf", vf)):
-            if stat == "count" and col == "vf":
+        for col, vals in (("vi", vi), ("vf", vf), ("v32", v32.astype(np.int64))):
+            if stat == "count" and col != "vi":
                 continue
             for view, sel in ((t, np.ones(n, bool)), (t[("a", lambda c: c < 61), dfdb_mod.ALL], a < 61)):
-                first_rows, cnt, acc = expect(image(k), sel, vals, stat)
+                first_rows, cnt, acc = expect(kimg, sel, vals, stat)
                 df, taken = run(dfdb_mod, ctx, view, "k", None if stat == "count" else col, stat, 1)
                 assert taken == 1, (kind, stat, col)
-                keys = df["k"].to_numpy()
                 want_keys = k[first_rows]
                 assert len(df) == len(cnt)
-                assert np.array_equal(image(np.asarray(keys, dtype=k.dtype)), image(want_keys)), (kind, stat, col)
+
+                def same_keys(frame):
+                    got_k = frame["k"]
+                    if miss is None:
+                        return np.array_equal(image(np.asarray(got_k.to_numpy(), dtype=k.dtype)), image(want_keys))
+                    gm = got_k.isna().to_numpy() if hasattr(got_k, "isna") else np.ma.getmaskarray(got_k)
+                    wm = miss[first_rows]
+                    return np.array_equal(gm, wm) and np.array_equal(np.asarray(got_k.to_numpy()[~gm], dtype=np.int64), want_keys[~wm])
+                assert same_keys(df), (kind, stat, col)
                 assert np.array_equal(df["count"].to_numpy(), cnt), (kind, stat, col)
                 if stat != "count":
                     got = df[stat].to_numpy()
                     if vals.dtype.kind == "f" and stat == "sum":
-                        absum = expect(image(k), sel, np.abs(vals), "sum")[2]
+                        absum = expect(kimg, sel, np.abs(vals), "sum")[2]
                         assert np.all(np.abs(got - acc) <= cnt * np.finfo(np.float64).eps * absum + 1e-300), (kind, col)
                     else:
                         assert np.array_equal(got, acc), (kind, stat, col)
                 # the form it replaces gives the same table
                 df0, taken0 = run(dfdb_mod, ctx, view, "k", None if stat == "count" else col, stat, 0)
                 assert taken0 == 0
-                assert np.array_equal(image(np.asarray(df0["k"].to_numpy(), dtype=k.dtype)), image(want_keys)) and np.array_equal(df0["count"].to_numpy(), cnt)
+                assert same_keys(df0) and np.array_equal(df0["count"].to_numpy(), cnt)
     finally:
         t.close()
 
