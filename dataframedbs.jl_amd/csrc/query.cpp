@@ -1336,6 +1336,48 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // {key image, row} record into one of P partitions (by the top bits of the key's hash) and each partition is reduced through a table in LDS.  Streams instead
 // of one random line per row.  false = not taken (too few or too many distinct values, no room for the 12 bytes per selected row, a partition that outgrew
 // its table): the caller goes on with the hash table; the selection is as it was.
+// What the two radix forms (unique, groupreduce) share on the host: the pool of pages for `nsel` records in 2^kbits partitions (k_radix.hip), its control words —
+// the sample's counts [P], the streams' running positions [P x share], the pool's counter, then `extra` bytes the caller lays out (64-byte aligned) — and the
+// SAMPLE: one workgroup reduces one partition, so a partition that holds a large part of all the rows (a value that a third of the column has) would be one CU's
+// work while 255 wait — 1.5 ms per average partition, i.e. 8 average partitions' worth of records already costs what the whole pass does.  Every 16th tile is
+// counted (all of them in a small table: 0.1 ms per 1e9 rows), the counts come back and the largest partition is looked at before anything is written.
+// The temporaries go back to the buffer pool (not through hipFree, which drains the device: 1.5 ms of a 16-ms call once), the stream drained first; the records'
+// scratch stays with the context between calls (hipMalloc / hipFree of 12 GB cost 3-4 ms; buffers above 1 GB never enter the pool; dfdb_ctx_destroy releases it).
+struct RadixRun {
+  dfdb_ctx* ctx; int kbits, P, C; int64_t PS; RadixPool pool{}; DevBuf ctl, pt; size_t tail = 0;
+  RadixRun(dfdb_ctx* c, int kb) : ctx(c), kbits(kb), P(1 << kb), C((int)round_up(4 * std::max(1, c->prop.multiProcessorCount), radix_share())), PS((int64_t)(1 << kb) * radix_share()) {}
+  ~RadixRun() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); }
+  uint32_t* counts() const { return ctl.as<uint32_t>(); }
+  char* extra() const { return (char*)ctl.p + tail; }
+  // false: no room, or more records than a 32-bit place in the pool can name
+  bool prepare(int64_t nsel, bool with_values, size_t extra_bytes) {
+    if (radix_pool_pages(nsel, kbits) * 8192 >= (1ll << 32)) return false;
+    pool.maxv = radix_pool_maxv(nsel, kbits);
+    pool.dump_page = (uint32_t)(radix_pool_pages(nsel, kbits) - 1);
+    const size_t ctl_words = (size_t)P + (size_t)PS + 16;
+    tail = (ctl_words * 4 + 63) / 64 * 64;
+    try {
+      ctl.ensure(tail + extra_bytes + 64); pt.ensure((size_t)PS * pool.maxv * 4 + 512);      // (+ 64 entries nobody owns: the table passes read 64 at a time)
+      ctx->radix_recs.ensure((size_t)radix_pool_record_bytes(nsel, kbits, with_values) + 256);
+    } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+    pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.pt = pt.as<uint32_t>();
+    HIP_CHECK(hipMemsetAsync(ctl.p, 0, tail + extra_bytes, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(pt.p, 0xFF, (size_t)PS * pool.maxv * 4, ctx->stream));
+    return true;
+  }
+  // 1 = skewed, 0 = not, -1 = the sample could not be launched
+  int skewed(const uint64_t* sel, const void* col, int dt, const uint64_t* miss, int64_t nrows) {
+    const int step = radix_rows_per_chunk(nrows, C) / 8192 >= 32 ? 16 : 1;
+    { LaunchTimer lt(ctx, "radix_sample");
+      if (!launch_radix_sample(ctx->stream, sel, col, dt, miss, nrows, kbits, C, step, counts())) return -1; }
+    std::vector<uint32_t> cn((size_t)P);
+    HIP_CHECK(hipMemcpyAsync(cn.data(), ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    stream_wait(ctx);
+    uint64_t maxp = 0, total = 0;
+    for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
+    return maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total ? 1 : 0;
+  }
+};
 // how many distinct values `cnt` selected rows hold when the first r0 of them held d0, assuming they turn up evenly: d0 = D (1 - exp(-r0 / D)), by bisection
 static double estimate_distinct(uint64_t d0, uint64_t r0, int64_t cnt) {
   double D = (double)cnt;
@@ -1348,9 +1390,9 @@ static double estimate_distinct(uint64_t d0, uint64_t r0, int64_t cnt) {
 }
 static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTables& T, uint64_t d0, uint64_t r0) {
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
-  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): hist 1.3 + partition 5.0-5.3 + unique 3.0 ms = 10.7-10.9 ms end to end against the
-  // hash table's 19.9 (the first build, with splitmix64 and the partition re-hashed on the way out, was 18.4).  The partition pass waits for its STORES (2.8 ms without
-  // them): 192-byte runs behind running positions that one XCD's workgroups share, so that whole lines leave that XCD's L2.  On by default; option = 0: the hash table.
+  // MEASURED, 1e9 Int64 / Float64 rows of 1e6 distinct values (profiles/r6_unique_radix.txt): sample 0.1 + partition 4.5 + LDS tables 3.2 ms = 8.8-9.3 ms end to end against the
+  // hash table's 19.8 (the first build, with splitmix64, a counting pass and the partition re-hashed on the way out, was 18.4).  The partition pass waits for its STORES
+  // (2.8 ms without them): 192-byte runs behind running positions that one XCD's workgroups share, so that whole lines leave that XCD's L2.  On by default; option = 0: the hash table.
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
   if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || r0 == 0 || d0 == 0) return false;      // (rows and pool positions are 32-bit; all ones is "no row")
   if (mode < 2 && cnt < (4ll << 20)) return false;                       // (2: a test knob — any size; measured against the hash table down to 3 M selected rows of 1e9: tools/r6_radix_selective.py)
@@ -1360,52 +1402,23 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   while (kbits < 10 && D / (double)(1 << kbits) > 2500.0) kbits++;       // (fewer partitions = longer runs per tile of the partition pass; more = emptier tables in the unique pass: 1e6 values -> 512)
   if (const char* e = getenv("DFDB_RADIX_KBITS")) kbits = std::min(10, std::max(6, atoi(e)));      // (an A/B switch for measurements)
   if (mode < 2 && D / (double)(1 << kbits) > 5500.0) return false;       // the partitions' tables (8192 slots) would overflow
-  const int P = 1 << kbits;
-  const int C = round_up(4 * std::max(1, ctx->prop.multiProcessorCount), radix_share());      // chunks = workgroups of the hist and partition passes
-  const int64_t PS = (int64_t)P * radix_share();                        // streams: (partition, share) pairs — the workgroups whose number is equal mod radix_share() fill one share together
   const int dt = dt_base(col.dtype);
   const uint64_t* miss = dt_nullable(col.dtype) ? col.missing.as<uint64_t>() : nullptr;
   const int64_t nt = ceil_div(t->nrows, kTileRows);
   const size_t nw = padded_words(t->nrows);
-  // the records' scratch (12 bytes per selected row) stays with the context between calls: hipMalloc / hipFree of 12 GB cost 3-4 ms of a 19-ms call (buffers
-  // above 1 GB never enter the pool); dfdb_ctx_destroy releases it
-  // (the call's temporaries go back to the buffer pool, not through hipFree — which drains the device and took ~1.5 ms of a 16-ms call for the 125-MB copy of the
-  // selection alone; the stream is drained first: nothing in flight may still touch them)
-  struct Temps {
-    dfdb_ctx* ctx; DevBuf ctl, pt, sel_keep, tc_keep;
-    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); sel_keep.release(); tc_keep.release(); }
-  } tmp{ctx, {}, {}, {}, {}};
-  DevBuf &ctl = tmp.ctl, &pt = tmp.pt, &sel_keep = tmp.sel_keep, &tc_keep = tmp.tc_keep;
+  struct Keep {                                                          // the selection, set aside (pooled like RadixRun's temporaries)
+    dfdb_ctx* ctx; DevBuf sel, tc;
+    ~Keep() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; sel.release(); tc.release(); }
+  } keep{ctx, {}, {}};
+  DevBuf &sel_keep = keep.sel, &tc_keep = keep.tc;
+  RadixRun run(ctx, kbits);
+  if (!run.prepare(cnt, false, 0)) return false;
+  try { sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64); } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  const RadixPool& pool = run.pool; const int C = run.C;
   DevBuf& recs = ctx->radix_recs;
-  // the record pool (k_radix.hip): pages of 8192 records taken as the partition pass goes — no counting pass over the column
-  if (radix_pool_pages(cnt, kbits) * 8192 >= (1ll << 32)) return false;   // (a record's place in the pool is a 32-bit number)
-  RadixPool pool{};
-  pool.maxv = radix_pool_maxv(cnt, kbits);
-  pool.dump_page = (uint32_t)(radix_pool_pages(cnt, kbits) - 1);
-  const size_t ctl_words = (size_t)P + (size_t)PS + 16;                  // the sample's counts [P], the streams' running positions [PS], the pool's counter
-  try {
-    ctl.ensure(ctl_words * 4); pt.ensure((size_t)PS * pool.maxv * 4 + 512);        // (+ 64 entries nobody owns: the unique pass reads 64 at a time)
-    recs.ensure((size_t)radix_pool_record_bytes(cnt, kbits, false) + 256);
-    sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64);
-  } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
-  pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.pt = pt.as<uint32_t>();
-  HIP_CHECK(hipMemsetAsync(ctl.p, 0, ctl_words * 4, s));
-  HIP_CHECK(hipMemsetAsync(pt.p, 0xFF, (size_t)PS * pool.maxv * 4, s));
-  // SKEW: one workgroup reduces one partition, so a partition that holds a large part of all the rows (a value that a third of the column has) would be one CU's
-  // work while 255 wait — 1.5 ms per average partition, i.e. 8 average partitions' worth of records already costs what the whole pass does.  The hash table takes such
-  // a column (the hot key's probes hit one cached line).  Every 16th tile is counted (all of them in a small table: 0.1 ms per 1e9 rows), the counts come back and
-  // the largest partition is looked at before anything is written.
-  {
-    const int step = radix_rows_per_chunk(t->nrows, C) / 8192 >= 32 ? 16 : 1;
-    { LaunchTimer lt(ctx, "radix_sample");
-      if (!launch_radix_sample(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, step, ctl.as<uint32_t>())) return false; }
-    std::vector<uint32_t> cn((size_t)P);
-    HIP_CHECK(hipMemcpyAsync(cn.data(), ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-    stream_wait(ctx);
-    uint64_t maxp = 0, total = 0;
-    for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
-    if (maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "unique_radix.skewed"); return false; }
-  }
+  { const int sk = run.skewed(q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows);
+    if (sk < 0) return false;
+    if (sk) { prof_note(ctx, "unique_radix.skewed"); return false; } }   // (the hash table takes such a column: the hot key's probes hit one cached line)
   { LaunchTimer lt(ctx, "radix_partition");
     if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
@@ -1581,46 +1594,24 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   while (kbits < 10 && ng / (1ll << kbits) > 1200) kbits++;              // (a 4096-slot table at 30 % load)
   if (ng / (1ll << kbits) > 1800) return false;
   const int P = 1 << kbits;
-  const int C = round_up(4 * std::max(1, ctx->prop.multiProcessorCount), radix_share());
-  const int64_t PS = (int64_t)P * radix_share();
   const int dt = dt_base(kc.dtype);
-  if (radix_pool_pages(nsel, kbits) * 8192 >= (1ll << 32)) return false;
-  struct Temps {
-    dfdb_ctx* ctx; DevBuf ctl, pt, res;
-    ~Temps() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); res.release(); }
-  } tmp{ctx, {}, {}, {}};
+  struct Res { dfdb_ctx* ctx; DevBuf res; ~Res() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; res.release(); } } tmp{ctx, {}};
+  RadixRun run(ctx, kbits);
+  if (!run.prepare(nsel, true, 128)) return false;
+  try { tmp.res.ensure((size_t)(mark ? (int64_t)P * radix_group_slots() : ng) * 16 + 256); } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  const RadixPool& pool = run.pool; const int C = run.C;
   DevBuf& recs = ctx->radix_recs;
-  RadixPool pool{};
-  pool.maxv = radix_pool_maxv(nsel, kbits);
-  pool.dump_page = (uint32_t)(radix_pool_pages(nsel, kbits) - 1);
-  // ctl: the sample's counts [P], the streams' running positions [PS], the pool's counter, then (8-byte words) aux [4], gspec [2], nres
-  const size_t ctl_words = (size_t)P + (size_t)PS + 16, tail = (ctl_words * 4 + 63) / 64 * 64;
-  try {
-    tmp.ctl.ensure(tail + 128); tmp.pt.ensure((size_t)PS * pool.maxv * 4 + 512); tmp.res.ensure((size_t)(mark ? (int64_t)P * radix_group_slots() : ng) * 16 + 256);
-    recs.ensure((size_t)radix_pool_record_bytes(nsel, kbits, true) + 256);
-  } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
-  pool.front = tmp.ctl.as<uint32_t>() + P; pool.next_page = tmp.ctl.as<uint32_t>() + P + PS; pool.pt = tmp.pt.as<uint32_t>();
-  uint64_t* aux = (uint64_t*)((char*)tmp.ctl.p + tail);                  // [0] the unstorable key's first row, [1] the missing key's, [3] abort; [4..7] gspec; [8] nres
+  uint64_t* aux = (uint64_t*)run.extra();                                // [0] the unstorable key's first row, [1] the missing key's, [3] abort; [4..7] gspec; [8] nres
   RadixGroup g{};
   g.valcol = vc ? vc->data.p : nullptr; g.valdt = vc ? dt_base(vc->dtype) : 0;
   g.gop = op == DFDB_AGG_SUM ? (q->gr_kind == 2 ? 2 : 1) : (op == DFDB_AGG_MIN ? 3 : (op == DFDB_AGG_MAX ? 4 : 0));
   if (!vc) g.gop = 0;
   g.vkind = q->gr_kind; g.results = tmp.res.p; g.gspec = aux + 4; g.nres = (uint32_t*)(aux + 8);
-  HIP_CHECK(hipMemsetAsync(tmp.ctl.p, 0, tail + 128, s));
   HIP_CHECK(hipMemsetAsync(aux, 0xFF, 16, s));                           // aux[0], aux[1] = none
   if (g.gop == 3) { HIP_CHECK(hipMemsetAsync(aux + 5, 0xFF, 8, s)); HIP_CHECK(hipMemsetAsync(aux + 7, 0xFF, 8, s)); }      // gspec[1], [3]: a minimum starts at all ones
-  HIP_CHECK(hipMemsetAsync(tmp.pt.p, 0xFF, (size_t)PS * pool.maxv * 4, s));
-  {
-    const int step = radix_rows_per_chunk(t->nrows, C) / 8192 >= 32 ? 16 : 1;
-    { LaunchTimer lt(ctx, "radix_sample");
-      if (!launch_radix_sample(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, step, tmp.ctl.as<uint32_t>())) return false; }
-    std::vector<uint32_t> cn((size_t)P);
-    HIP_CHECK(hipMemcpyAsync(cn.data(), tmp.ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-    stream_wait(ctx);
-    uint64_t maxp = 0, total = 0;
-    for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
-    if (maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total) { prof_note(ctx, "group_radix.skewed"); return false; }
-  }
+  { const int sk = run.skewed(sel, kc.data.p, dt, kmiss, t->nrows);
+    if (sk < 0) return false;
+    if (sk) { prof_note(ctx, "group_radix.skewed"); return false; } }
   { LaunchTimer lt(ctx, "radix_partition");
     if (!launch_radix_partition(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g)) return false; }
   if (mark) {
