@@ -184,7 +184,8 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
 // 512-thread workgroups sorting 4096 rows, two per CU — shorter runs store slower than the overlap gains.)
 constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }      // hist2, lstart (1024 each), place (1024 x 16 bytes), wave sums, srow — in 4-byte words; skey follows
 // HASVAL (groupreduce by radix, below): a record carries the row's 8-byte VALUE too — 20 bytes {key image, row, value}; the value is fetched from its column where
-// the record is written (the tile's 64 KB of values: one gathered read per record, behind the sort), and the rows whose key cannot be stored are counted and reduced
+// the record is written (the tile's values are read in row order behind the sort and laid down in LDS where the sorted keys were), and the rows whose key cannot be
+// stored are counted and reduced
 // here, in a workgroup-wide accumulator that is flushed to gspec {count, value} once per workgroup (GOP: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // of order images; vkind: how a value's image is made — k_unique.hip's order_image).
 struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; };
@@ -312,6 +313,17 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
         skey[slot] = key[j];
         srow[slot] = (pr[j] & ~8191u) | (uint32_t)(wv * 512 + j * 64 + lane);
       }
+    // HASVAL: the rows' values, asked for now in row order (coalesced: the registers of the keys are free) — they go through LDS behind the keys (step 4)
+    uint64_t val[8];
+    if (HASVAL) {
+      const uint32_t lo = (uint32_t)(wv * 512 + lane);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        val[j] = 0;
+        if (vals.col && !(xp & 256) && pr[j] != ~0u)                                           // (bit 8, timing only: no values)
+          val[j] = v8 ? __builtin_nontemporal_load((const uint64_t*)vals.col + base + lo + (uint32_t)(j * 64)) : rvalue_bits(vals.col, vals.vdt, base + lo + (uint32_t)(j * 64));
+      }
+    }
     // the reserved positions [got, got + h) of the stream as places in the pool (the atomic's answer is waited for here, behind the sort)
     if (tid < P && h) {
       const uint32_t k0 = got >> 13, k1 = (got + h - 1u) >> 13;                 // the stream's pages the run lies in (k1 = k0 or k0 + 1)
@@ -355,14 +367,14 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     for (int k = 0; k < 8; k++) od[k] = place[(ow[k] >> 13) & 1023u];            // (a slot past `total` holds an older tile's record: read, not written)
     // the next tile's keys are waited for HERE, before the first store is issued: loads and stores share one in-order counter (vmcnt), and a wait for the loads at
     // the top of the next step would also be a wait for the sixteen stores issued after them — a tile's store latency, every tile
-    uint64_t ov[8];                                             // HASVAL: the records' values, gathered out of the tile's rows
-    if (HASVAL) {
+    uint64_t ov[8];                                             // HASVAL: the records' values: the rows' values laid down in row order where the sorted keys were
+    if (HASVAL) {                                               // (LDS has no room for a third array beside keys and rows; a gathered read from the column per record: 2.6 ms)
+      __syncthreads();                                          // every thread has its sorted keys and rows in registers
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        ov[k] = 0;
-        if (vals.col && !(xp & 256) && (uint32_t)(k * BLOCK + tid) < total)                      // (bit 8, timing only: no values)
-          ov[k] = v8 ? ((const uint64_t*)vals.col)[base + (ow[k] & 8191u)] : rvalue_bits(vals.col, vals.vdt, base + (ow[k] & 8191u));
-      }
+      for (int j = 0; j < 8; j++) skey[wv * 512 + j * 64 + lane] = val[j];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; k++) ov[k] = skey[ow[k] & 8191u];
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));
