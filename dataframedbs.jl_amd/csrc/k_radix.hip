@@ -188,7 +188,17 @@ constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }   
 // stored are counted and reduced
 // here, in a workgroup-wide accumulator that is flushed to gspec {count, value} once per workgroup (GOP: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // of order images; vkind: how a value's image is made — k_unique.hip's order_image).
-struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; };
+struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; uint64_t* hot; uint32_t* hot_n; uint32_t hot_cap; };
+// HOT KEYS.  A key that a large part of the rows hold would make one partition — one workgroup's work — of all those rows, every one an atomic on the same LDS
+// word (and through the form this replaces, 3e8 global atomics on ONE address: 3.6 s per 1e9 rows).  A workgroup of the partition pass keeps kHotSlots keys in LDS
+// with their own accumulators: a key that turns up three times among the 64 rows of a selection word is given a slot (if its slot is free), and from the next tile
+// on a row whose key has a slot is counted and reduced THERE and never becomes a record.  When the workgroup ends its slots go to a list {key, value, rows, first
+// row}; the table pass merges the entries of its partition into its table like records that stand for many rows.
+constexpr int kHotSlots = 256;
+__device__ __forceinline__ uint32_t hot_slot(uint64_t key) { return (((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u) >> 24; }
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32;
+}
 // a value as the 64 bits the accumulators work on (= k_unique.hip's value_bits: integers widened, Float32 as the double it converts to)
 __device__ __forceinline__ uint64_t rvalue_bits(const void* col, int dtype, int64_t row) {
   switch (dtype) {
@@ -202,6 +212,7 @@ __device__ __forceinline__ uint64_t rvalue_bits(const void* col, int dtype, int6
     default: return ((const uint64_t*)col)[row];
   }
 }
+template <bool V8> __device__ __forceinline__ uint64_t rvalue_of(const void* col, int dtype, int64_t row) { return V8 ? ((const uint64_t*)col)[row] : rvalue_bits(col, dtype, row); }
 __device__ __forceinline__ uint64_t order_image(uint64_t bits, int kind, bool is_min) {         // (= k_unique.hip's: unsigned compare; a NaN wins either reduction)
   if (kind == 1) return bits;
   if (kind == 0) return bits ^ (1ull << 63);
@@ -215,11 +226,14 @@ __device__ __forceinline__ void acc_value(uint64_t* slot, uint64_t v, int gop, i
   else if (gop == 3) atomicMin((unsigned long long*)slot, (unsigned long long)order_image(v, vkind, true));
   else if (gop == 4) atomicMax((unsigned long long*)slot, (unsigned long long)order_image(v, vkind, false));
 }
-template <int KIND, int BLOCK, bool HASVAL>
+// V8: the value column is eight bytes wide (loaded as it is; the narrow types' switch — seventeen copies of it — lives in the !V8 kernels only)
+template <int KIND, int BLOCK, bool HASVAL, bool V8>
 __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, RadixPool pool,
                                                              uint32_t* __restrict__ recs_out, uint64_t* aux, RadixVals vals, int xp) {
   __shared__ uint64_t spec_sh[4];                               // HASVAL: {rows, reduced value} of the rows whose key is the unstorable image, then of the rows whose key is missing: this workgroup's
+  __shared__ uint64_t hc_key[HASVAL ? kHotSlots : 1], hc_val[HASVAL ? kHotSlots : 1];      // HASVAL: the hot keys' slots: key, reduced value, ...
+  __shared__ uint32_t hc_cnt[HASVAL ? kHotSlots : 1], hc_row[HASVAL ? kHotSlots : 1], hc_any;   // ... rows, smallest row; whether any slot is taken
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
@@ -232,13 +246,14 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
-  if (HASVAL && tid == 0) { spec_sh[0] = spec_sh[2] = 0; spec_sh[1] = spec_sh[3] = vals.gop == 3 ? ~0ull : 0ull; }
-  const bool v8 = vals.vdt == DFDB_I64 || vals.vdt == DFDB_U64 || vals.vdt == DFDB_F64;
+  if (HASVAL && tid == 0) { spec_sh[0] = spec_sh[2] = 0; spec_sh[1] = spec_sh[3] = vals.gop == 3 ? ~0ull : 0ull; hc_any = 0; }
+  if (HASVAL && tid < kHotSlots) { hc_key[tid] = kREmpty; hc_val[tid] = vals.gop == 3 ? ~0ull : 0ull; hc_cnt[tid] = 0; hc_row[tid] = 0xFFFFFFFFu; }
   const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the stream (partition p, this workgroup's share)
   for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
   uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
   uint32_t pk = 0xFFFFFFFFu, pb = 0;                            // thread p < P: the page of its stream its last run ended in, and where that page lies
+  bool hot_on = false;                                          // HASVAL: some hot key has a slot (wave-uniform)
   uint64_t nmiss;                                               // (wave-uniform) selected rows of the next tile whose key is missing
   if (r0 + TILE <= nrows) nmiss = tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
   else nmiss = tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
@@ -246,14 +261,48 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   for (int j = 0; j < 8; j++) asm volatile("" : "+v"(nkey[j]));      // (arrived before the loop is entered — see step 4: no wait for them may sit at the loop's top)
   for (int64_t base = r0; base < r1; base += TILE) {
     uint64_t key[8]; uint32_t pr[8];                            // pr: partition << 13 | rank among the tile's records of that partition; ~0 = the row takes no part
-    uint64_t unstorable = 0;
+    uint64_t unstorable = 0, take[8];                           // take: the rows that become records (wave-uniform masks)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       key[j] = nkey[j]; pr[j] = ~0u;
       const uint64_t ok = keys_storable<KIND>(key[j]);
       unstorable |= nin[j] & ~ok;
-      if (__builtin_amdgcn_inverse_ballot_w64(nin[j] & ok)) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
+      take[j] = nin[j] & ok;
     }
+    if (HASVAL) {                                               // hot keys (see RadixVals)
+      if (!hot_on) hot_on = __builtin_amdgcn_readfirstlane((int)hc_any) != 0;      // (as the tile begins: a slot taken during it counts from the next tile on)
+      if (hot_on) {
+        uint64_t ck[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) ck[j] = hc_key[hot_slot(key[j])];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint64_t hit = take[j] & __ballot(ck[j] == key[j]);
+          if (!hit) continue;
+          if ((hit >> lane) & 1ull) {
+            const uint32_t sl = hot_slot(key[j]);
+            const int64_t row = base + wv * 512 + j * 64 + lane;
+            atomicAdd(&hc_cnt[sl], 1u);
+            if (hc_row[sl] > (uint32_t)row) atomicMin(&hc_row[sl], (uint32_t)row);
+            if (vals.col && vals.gop) acc_value(&hc_val[sl], rvalue_of<V8>(vals.col, vals.vdt, row), vals.gop, vals.vkind);
+          }
+          take[j] &= ~hit;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j += 4) {                          // a key that holds three of a word's 64 rows gets a slot (two of a wave's eight words are looked at)
+        if (!take[j]) continue;
+        const uint64_t fk = readlane64(key[j], __builtin_ctzll(take[j]));
+        if (__builtin_popcountll(take[j] & __ballot(key[j] == fk)) < 3) continue;
+        if (lane == 0) {
+          const uint32_t sl = hot_slot(fk);
+          if (hc_key[sl] == kREmpty) { atomicCAS((unsigned long long*)&hc_key[sl], (unsigned long long)kREmpty, (unsigned long long)fk); hc_any = 1; }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (__builtin_amdgcn_inverse_ballot_w64(take[j])) { const uint32_t p = rhash(key[j]) >> sh; pr[j] = p << 13 | atomicAdd(&hist2[p], 1u); }
     if (nmiss) {                                                // (rare: the two keys kept aside — a missing key's first row, aux[1] — and, HASVAL, its rows and their values; ...
       tile_first_missing(sel, missing, base, nrows, wv, lane, aux);
       if (HASVAL) {
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
           if (w0 + j == wl && (nrows & 63)) m &= (1ull << (nrows & 63)) - 1ull;
           if (!m) continue;
           if (lane == 0) atomicAdd((unsigned long long*)&spec_sh[2], (unsigned long long)__builtin_popcountll(m));
-          if (vals.col && ((m >> lane) & 1ull)) acc_value(&spec_sh[3], rvalue_bits(vals.col, vals.vdt, (w0 + j) * 64 + lane), vals.gop, vals.vkind);
+          if (vals.col && ((m >> lane) & 1ull)) acc_value(&spec_sh[3], rvalue_of<V8>(vals.col, vals.vdt, (w0 + j) * 64 + lane), vals.gop, vals.vkind);
         }
       }
     }
@@ -276,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
         first = false;
         if (!HASVAL) break;
         if (lane == 0) atomicAdd((unsigned long long*)&spec_sh[0], (unsigned long long)__builtin_popcountll(bad));
-        if (vals.col && ((bad >> lane) & 1ull)) acc_value(&spec_sh[1], rvalue_bits(vals.col, vals.vdt, base + wv * 512 + j * 64 + lane), vals.gop, vals.vkind);
+        if (vals.col && ((bad >> lane) & 1ull)) acc_value(&spec_sh[1], rvalue_of<V8>(vals.col, vals.vdt, base + wv * 512 + j * 64 + lane), vals.gop, vals.vkind);
       }
     }
     const int64_t nb = base + TILE;
@@ -321,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
       for (int j = 0; j < 8; j++) {
         val[j] = 0;
         if (vals.col && !(xp & 256) && pr[j] != ~0u)                                           // (bit 8, timing only: no values)
-          val[j] = v8 ? __builtin_nontemporal_load((const uint64_t*)vals.col + base + lo + (uint32_t)(j * 64)) : rvalue_bits(vals.col, vals.vdt, base + lo + (uint32_t)(j * 64));
+          val[j] = rvalue_of<V8>(vals.col, vals.vdt, base + lo + (uint32_t)(j * 64));
       }
     }
     // the reserved positions [got, got + h) of the stream as places in the pool (the atomic's answer is waited for here, behind the sort)
@@ -400,6 +449,11 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   }
   if (HASVAL) {                                                 // the workgroup's rows of the unstorable key -> the launch's
     __syncthreads();
+    if (tid < kHotSlots && hc_key[tid] != kREmpty && hc_cnt[tid]) {          // the hot keys' slots -> the launch's list
+      const uint32_t i = atomicAdd(vals.hot_n, 1u);
+      if (i < vals.hot_cap) { vals.hot[3 * (size_t)i] = hc_key[tid]; vals.hot[3 * (size_t)i + 1] = hc_val[tid]; vals.hot[3 * (size_t)i + 2] = (uint64_t)hc_cnt[tid] << 32 | hc_row[tid]; }
+      else __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED);              // (cannot happen: the list holds every workgroup's every slot)
+    }
     if (tid < 2 && spec_sh[2 * tid]) {
       atomicAdd((unsigned long long*)&vals.gspec[2 * tid], (unsigned long long)spec_sh[2 * tid]);
       const uint64_t v = spec_sh[2 * tid + 1];
@@ -569,6 +623,29 @@ __device__ __forceinline__ void gtable_claim(uint64_t* tkey, uint32_t* trow, uin
     if (probes >= (uint32_t)kGSlots) { *abort_flag = 1; break; }
   }
 }
+// an entry of the hot keys' list into the partition's table: it stands for `cnt` rows whose values are already reduced to `v` (min / max: an order image)
+__device__ __forceinline__ void gtable_merge(uint64_t* tkey, uint32_t* trow, uint32_t* tcnt, uint64_t* tval, uint64_t key, uint32_t row, uint32_t cnt, uint64_t v, int gop,
+                                             uint32_t* claims, uint32_t* abort_flag) {
+  uint32_t h = gtable_home(key);
+  for (uint32_t probes = 0;; probes++) {
+    uint64_t old = tkey[h];
+    if (old == kREmpty) {
+      old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)kREmpty, (unsigned long long)key);
+      if (old == kREmpty) atomicAdd(claims, 1u);
+    }
+    if (old == kREmpty || old == key) {
+      atomicMin(&trow[h], row);
+      atomicAdd(&tcnt[h], cnt);
+      if (gop == 1) atomicAdd((unsigned long long*)&tval[h], (unsigned long long)v);
+      else if (gop == 2) atomicAdd((double*)&tval[h], __longlong_as_double((long long)v));
+      else if (gop == 3) atomicMin((unsigned long long*)&tval[h], (unsigned long long)v);
+      else if (gop == 4) atomicMax((unsigned long long*)&tval[h], (unsigned long long)v);
+      break;
+    }
+    h = (h + 1) & (kGSlots - 1);
+    if (probes >= (uint32_t)kGSlots) { *abort_flag = 1; break; }
+  }
+}
 template <bool FULL>
 __device__ __forceinline__ void recs20_load(uint64_t (&kk)[4], uint32_t (&rw)[4], uint64_t (&vv)[4], const uint32_t* __restrict__ rp, uint32_t n, int tid) {
 #pragma unroll
@@ -580,7 +657,7 @@ __device__ __forceinline__ void recs20_load(uint64_t (&kk)[4], uint32_t (&rw)[4]
 }
 __global__ __launch_bounds__(kRBlock) void k_radix_group(const uint32_t* __restrict__ recs, RadixPool pool, int P, int mark, uint64_t* __restrict__ bitmap,
                                                          uint32_t* __restrict__ tile_counts, uint64_t* aux, uint4* __restrict__ results, uint32_t* __restrict__ nres,
-                                                         int gop, int vkind) {
+                                                         int gop, int vkind, const uint64_t* __restrict__ hot, const uint32_t* __restrict__ hot_n, int kbits) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kGSlots]
   uint64_t* tval = tkey + kGSlots;                            // [kGSlots] the key's reduced value (min / max: of order images)
@@ -655,6 +732,14 @@ __global__ __launch_bounds__(kRBlock) void k_radix_group(const uint32_t* __restr
       if (claims_sh > (kGSlots * 7) / 8) { abort_sh = 1; break; }
     }
     if (qn && !abort_sh) { if (lane < (int)qn) gtable_claim(tkey, trow, tcnt, tval, qk[lane], qr[lane], qv[lane], gop, vkind, &claims_sh, &abort_sh); }
+    // the hot keys the partition pass reduced on its own (one entry per workgroup and key): those of this partition
+    const uint32_t nhot = *hot_n;
+    for (uint32_t i = (uint32_t)tid; i < nhot && !abort_sh; i += kRBlock) {
+      const uint64_t key = hot[3 * (size_t)i];
+      if ((int)(rhash(key) >> (32 - kbits)) != p) continue;
+      const uint64_t cr = hot[3 * (size_t)i + 2];
+      gtable_merge(tkey, trow, tcnt, tval, key, (uint32_t)cr, (uint32_t)(cr >> 32), hot[3 * (size_t)i + 1], gop, &claims_sh, &abort_sh);
+    }
     __syncthreads();
     if (abort_sh) { if (tid == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }
     for (int i = tid; i < kGSlots; i += kRBlock) {
@@ -703,6 +788,7 @@ int radix_share() { return kRShare; }
 int64_t radix_pool_pages(int64_t cnt, int kbits) { return (cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) + 1; }
 int64_t radix_pool_record_bytes(int64_t cnt, int kbits, bool with_values) { return radix_pool_pages(cnt, kbits) * kRPage * (with_values ? 20 : 12); }
 int radix_group_slots() { return kGSlots; }
+int radix_hot_slots() { return kHotSlots; }
 uint32_t radix_pool_maxv(int64_t cnt, int kbits) { const int64_t even = ((cnt + kRPage - 1) / kRPage + ((int64_t)kRShare << kbits) - 1) / ((int64_t)kRShare << kbits); return (uint32_t)(16 * even + 16); }
 
 bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks, int step,
@@ -717,12 +803,12 @@ bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, in
   }
   return true;
 }
-template <int KIND, bool HASVAL>
+template <int KIND, bool HASVAL, bool V8>
 static bool radix_partition_go(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                                const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixVals& vals) {
-  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock, HASVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock, HASVAL, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)radix_partition_lds_bytes(kRBlock)) == hipSuccess;      // (+ the static arrays: under 160 KB)
   if (!ok) { (void)hipGetLastError(); return false; }
-  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock, HASVAL>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
+  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock, HASVAL, V8>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
                      radix_rows_per_chunk(nrows, chunks), kbits, pool, recs_out, aux, vals, radix_xp());
   return true;
 }
@@ -732,9 +818,11 @@ bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col,
                             const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixGroup* group) {
   if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
   RadixVals v{};
-  if (group) { v.col = group->valcol; v.vdt = group->valdt; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; }
-#define DFDB_RP(K) (group ? radix_partition_go<K, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
-                          : radix_partition_go<K, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v))
+  if (group) { v.col = group->valcol; v.vdt = group->valdt; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; v.hot = group->hot; v.hot_n = group->hot_n; v.hot_cap = group->hot_cap; }
+  const bool v8 = !group || !group->valcol || group->valdt == DFDB_I64 || group->valdt == DFDB_U64 || group->valdt == DFDB_F64;
+#define DFDB_RP(K) (group ? (v8 ? radix_partition_go<K, true, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
+                                : radix_partition_go<K, true, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v)) \
+                          : radix_partition_go<K, false, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v))
   switch (radix_kind(dtype)) {
     case kKindRaw8: return DFDB_RP(kKindRaw8);
     case kKindF64: return DFDB_RP(kKindF64);
@@ -749,7 +837,7 @@ bool launch_radix_group(hipStream_t s, const uint32_t* recs, const RadixPool& po
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   hipLaunchKernelGGL(k_radix_group, dim3(P < cus ? P : cus), dim3(kRBlock), lds, s, recs, pool, P, mark ? 1 : 0, bitmap, tile_counts, aux, (uint4*)group.results, group.nres,
-                     group.gop, group.vkind);
+                     group.gop, group.vkind, group.hot, group.hot_n, kbits);
   return true;
 }
 void launch_radix_group_finish(hipStream_t s, const RadixGroup& group, const uint64_t* ubits, const uint64_t* uprefix, const uint64_t* aux, uint64_t* cnt, uint64_t* val) {

@@ -174,7 +174,9 @@ bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, in
 // groupreduce by radix: the records carry the row's 8-byte value (valcol; null: count only); gop 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // (of order images: vkind 0 signed, 1 unsigned, 2 double); results [<= groups] {first row, rows, value} + their count nres; gspec {rows, value} of the unstorable key
 // and of the missing key (their first rows: aux[0], aux[1])
-struct RadixGroup { const void* valcol; int valdt; int gop; int vkind; void* results; uint32_t* nres; uint64_t* gspec /* [4]: the unstorable key's, the missing key's */; };
+struct RadixGroup { const void* valcol; int valdt; int gop; int vkind; void* results; uint32_t* nres; uint64_t* gspec /* [4]: the unstorable key's, the missing key's */;
+                    uint64_t* hot /* [hot_cap x 3]: the hot keys' list (chunks x radix_hot_slots() entries) */; uint32_t* hot_n /* zero before */; uint32_t hot_cap; };
+int radix_hot_slots();
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                             const RadixPool& pool, uint32_t* recs_out /* 12 bytes per record: key image, row; with a group: 20, + the value */, uint64_t* aux,
                             const RadixGroup* group = nullptr);
