@@ -26,7 +26,7 @@ Beside `value` (config 2, never anything else) the same JSON line carries, as ex
   calibrated_config  only with --placement: config 2 after the engine's opt-in placement calibration (ctx option placement_calibrate = 1), measured AFTER `value`;
                   `value` itself is the library-default configuration (no ctx option set)
                   Round 4 adds "3_computed" (config 3 with the computed x * 2 projection), "interp" (expressions outside the scan kernels: the device interpreter and
-                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_float_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
+                  the same program compiled at run time by hipRTC), "unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_hot_key", "groupreduce_float_key", "groupreduce_dictionary", "nullable_string_eq" (SURVEY 8f rows).
   decode_scan     N = 1: the decode-inclusive figure (K7 over the column's LZ4 blocks, fused with the predicate; `unfused`: K7 then K1; both decode with the
                   sequence-start index the column's first resident decode recorded — ctx option lz4_index — and `without_index` is the unfused step without it)
   cold            N = 1: the non-resident path — a table written to /dev/shm in the reference's format, open_table rows/s, block-streamed count and materialize
@@ -492,7 +492,7 @@ def make_summary(res):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("ms_per_step")), _r((v.get("roofline") or {}).get("frac"))]
-    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_float_key", "groupreduce_dictionary"):
+    for k in ("unique", "unique_hash_table", "unique_float_key", "unique_string", "groupreduce", "groupreduce_int_key", "groupreduce_50k_groups", "groupreduce_hot_key", "groupreduce_float_key", "groupreduce_dictionary"):
         v = cfg.get(k)
         if isinstance(v, dict):
             s[k] = v["error"][:80] if "error" in v else [_r(v.get("seconds", 0) * 1e3), _r((v.get("roofline") or {}).get("frac"))]
@@ -811,6 +811,19 @@ def f_rows_legs(L, dfdb, sc, rank):
                                      "roofline": {"bound": "hbm", "achieved": n * 16 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 16 / best / 1e9 / L.peak},
                                      "what": "groupreduce(t, (:k50,); out = :x => Sum()), k50 = x mod 50000 (Int64): more groups than LDS accumulators hold — partitioned by radix "
                                              "(20-byte records) and reduced per partition in LDS; bytes = the key column + the value column, once each; best of 2"}
+    # ---- the same with a HOT key: 30 % of the rows hold one key, the rest 1e5 keys evenly (through the form round 6 replaced every third row was a global atomic
+    # on ONE address: 3.63 s per call, profiles/r6_groupreduce_radix.txt — not run here)
+    t.add_column_from("khot", (t.x % 100000) * (t.x > 299999) + (1 << 40))
+    best, g = None, None
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g = dfdb.groupreduce(t, "khot", "x", "sum")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res["groupreduce_hot_key"] = {"rows": n, "groups": len(g), "largest_group_rows": int(g["count"].max()), "seconds": best, "rows_per_s": n / best,
+                                  "roofline": {"bound": "hbm", "achieved": n * 16 / best / 1e9, "peak": L.peak, "unit": "GB/s", "frac": n * 16 / best / 1e9 / L.peak},
+                                  "what": "groupreduce by a key that 30 % of the rows hold among 1e5 others: the partition pass reduces a hot key's rows in its own LDS slots "
+                                          "(csrc/k_radix.hip); the form it replaced took 3.63 s here (global atomics on one address); best of 2"}
     t.close()
     # ---- groupreduce by a String key, flat and with the dictionary
     n = int(500_000_000 * sc)

@@ -169,7 +169,7 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *                      partition that outgrows its table, or one that holds more than eight average partitions' rows — a value a large part of the column has
  *                      —: the hash table answers).  8.8 ms against the hash table's 19.8 per 1e9 rows of 1e6 values
  *                      (profiles/r6_unique_radix.txt).  dfdb_query_groupreduce over more groups than a workgroup's LDS accumulators hold (9216; a fixed-width key,
- *                      nullable or not) goes the same way: 15.7 ms where global atomics took 88.8 per 1e9 rows in 50 000 groups
+ *                      nullable or not) goes the same way: 14.5 ms where global atomics took 89 per 1e9 rows in 50 000 groups (19.6 ms against 3.6 s when one key holds 30 % of the rows)
  *                      (profiles/r6_groupreduce_radix.txt).  0 = always the hash table / the global atomics
  *   "jit"              1 (default) = an expression the device INTERPRETER evaluates (outside `col OP const` terms, pairs and string matches: configs 2-5 never get here)
  *                      over at least 4 M rows is also compiled by hipRTC in the background — the interpreter's own source specialised for the program's shape — and later
