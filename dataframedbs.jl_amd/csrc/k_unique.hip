@@ -618,9 +618,18 @@ struct AccArgs {
 };
 // OPK: group_add_t's operator; W8: the value column AND (SRC 0 / 2) the key column are 8-byte integers or doubles, loaded as they are — the dtype switches of value_bits
 // and key_fixed, copied four times by the unrolled trip, stay in the !W8 kernels
+// NG = 0 (more groups than any LDS holds: every row's value through a global atomic) keeps kHotGroups slots in LDS for HOT groups (round 6): a group that a
+// large part of the rows belong to was 3e8 atomics on one address — 3.6 s per 1e9 rows.  A group that holds three of the 64 rows a wave looks at is given a slot
+// (if its slot is free); from the next trip on a row of a group with a slot is added THERE, and the slots are flushed with one global atomic each when the
+// workgroup ends.  (groupreduce by radix — k_radix.hip — does the same in its partition pass; this is for what it does not take: String keys, > 1.8 M groups.)
+constexpr int kHotGroups = 256;
 template <int NG, int SRC, int OPK, bool W8>
 __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(const AccArgs A) {
-  __shared__ uint64_t lcnt[NG ? NG : 1], lval[NG ? NG : 1];
+  __shared__ uint64_t lcnt[NG ? NG : (int)kHotGroups], lval[NG ? NG : (int)kHotGroups];      // (NG = 0: the hot groups' slots)
+  __shared__ uint64_t hg_gid[NG ? 1 : (int)kHotGroups];
+  __shared__ uint32_t hg_any;
+  if (!NG) { for (int g = threadIdx.x; g < kHotGroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; hg_gid[g] = kEmpty; } if (threadIdx.x == 0) hg_any = 0; __syncthreads(); }
+  bool hot_on = false;
   const int nthreads = NG > kGroupLds ? 1024 : kBlock;
   const bool has_val = OPK < 0 ? (A.valcol != nullptr && A.op != DFDB_AGG_COUNT) : OPK != 0;      // (OPK -1: the operator at run time — the !W8 kernels)
   if (NG) { for (int g = threadIdx.x; g < A.ngroups; g += nthreads) { lcnt[g] = 0; lval[g] = A.val_init; } __syncthreads(); }
@@ -661,6 +670,27 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
       // (no group: the key, `missing` or the unstorable key never turned up among the rows the table was made from — the host runs everything again)
       if (SRC == 0 && gid[k] >= (uint64_t)A.ngroups) { unknown = true; on[k] = false; }
     }
+    if (!NG) {                                                 // hot groups: rows of a group that has a slot are added in LDS
+      // (volatile: there is no barrier in this loop, and a plain read of what another wave sets was hoisted out of it — only the wave that gave a slot away ever used it)
+      if (!hot_on) hot_on = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&hg_any) != 0;
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        if (hot_on && on[k] && ((volatile uint64_t*)hg_gid)[gid[k] & (kHotGroups - 1)] == gid[k]) {
+          const uint64_t sl = gid[k] & (kHotGroups - 1);
+          if (OPK < 0) group_add(lcnt, lval, sl, bits[k], vkind, A.op, has_val); else group_add_t<(OPK < 0 ? 0 : OPK)>(lcnt, lval, sl, bits[k], vkind);
+          on[k] = false;
+        }
+        const uint64_t m = __ballot(on[k]);
+        if (k == 0 && m) {                                       // (one of the trip's four rows is looked at)
+          const int fl = __builtin_ctzll(m);
+          const uint64_t fg = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gid[k], fl) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gid[k] >> 32), fl) << 32;
+          if (__builtin_popcountll(m & __ballot(on[k] && gid[k] == fg)) >= 3 && (threadIdx.x & 63) == 0) {
+            const uint64_t sl = fg & (kHotGroups - 1);
+            if (((volatile uint64_t*)hg_gid)[sl] == kEmpty) { atomicCAS((unsigned long long*)&hg_gid[sl], (unsigned long long)kEmpty, (unsigned long long)fg); *(volatile uint32_t*)&hg_any = 1; }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < U; k++) {
       if (!on[k]) continue;
@@ -673,6 +703,18 @@ __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(co
     __syncthreads();
     int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);      // (the value kind is a property of the column)
     group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, k2, has_val, nthreads);
+  } else {                                                     // the hot groups' slots -> their groups (group_flush, a slot's group from hg_gid)
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);
+    for (int sl = threadIdx.x; sl < kHotGroups; sl += nthreads) {
+      const uint64_t c = lcnt[sl], g = hg_gid[sl];
+      if (!c || g == kEmpty) continue;
+      atomicAdd((unsigned long long*)&A.cnt[g], (unsigned long long)c);
+      if (!has_val) continue;
+      if (A.op == DFDB_AGG_SUM) { if (k2 == 2) atomicAdd((double*)&A.val[g], __longlong_as_double((long long)lval[sl])); else atomicAdd((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]); }
+      else if (A.op == DFDB_AGG_MIN) atomicMin((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]);
+      else if (A.op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]);
+    }
   }
 }
 template <int SRC>

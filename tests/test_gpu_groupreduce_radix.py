@@ -142,5 +142,10 @@ def test_groupreduce_by_radix_with_hot_keys(dfdb_mod, ctx, stat):
                         assert np.all(np.abs(got - acc) <= cnt * np.finfo(np.float64).eps * absum + 1e-300)
                     else:
                         assert np.array_equal(got, acc), (stat, col)
+                # the form it replaces — every row's value through a global atomic, the hot groups' through LDS slots of their own (k_unique.hip k_group_acc<0>)
+                df0, taken0 = run(dfdb_mod, ctx, view, "k", None if stat == "count" else col, stat, 0)
+                assert taken0 == 0 and np.array_equal(df0["k"].to_numpy(), k[first_rows]) and np.array_equal(df0["count"].to_numpy(), cnt), (stat, col)
+                if stat != "count" and not (vals.dtype.kind == "f" and stat == "sum"):
+                    assert np.array_equal(df0[stat].to_numpy(), acc), (stat, col)
     finally:
         t.close()
