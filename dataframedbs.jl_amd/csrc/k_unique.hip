@@ -351,13 +351,16 @@ struct StrPassArgs {
   const void* valcol; int valdt, op; uint64_t* cnt; uint64_t* val; int ngroups; uint64_t val_init;       // KIND 2
   int maybe;                                                   // KIND 1: the table may not hold every string (an optimistic unique): an unknown one raises aux[kAuxAbort]
 };
-// NGL: groups the workgroup's LDS accumulators hold (0: global atomics); OPK: group_add_t; V8: the value column is 8 bytes wide (loaded as is; the narrow types'
+constexpr int kHotGroups = 256;                      // LDS slots for hot groups where every row's value goes through a global atomic (k_group_acc<0>, k_str_pass<2, 0>)
+// NGL: groups the workgroup's LDS accumulators hold (0: global atomics — and kHotGroups slots for hot groups, as in k_group_acc<0>); OPK: group_add_t; V8: the value column is 8 bytes wide (loaded as is; the narrow types'
 // switch, sixteen copies of it in the unrolled loops, lives in the !V8 kernels only)
 template <int KIND, int NGL, int OPK, bool V8>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_str_pass(const StrPassArgs A) {   // (four waves per SIMD: 128 VGPRs)
   constexpr bool LDS = NGL > 0;
   __shared__ uint32_t claims_sh;
-  __shared__ uint64_t lcnt[(KIND == 2 && LDS) ? NGL : 1], lval[(KIND == 2 && LDS) ? NGL : 1];
+  constexpr bool HOT = KIND == 2 && !LDS;
+  __shared__ uint64_t lcnt[KIND == 2 ? (LDS ? NGL : (int)kHotGroups) : 1], lval[KIND == 2 ? (LDS ? NGL : (int)kHotGroups) : 1], hg_gid[HOT ? (int)kHotGroups : 1];
+  __shared__ uint32_t hg_any;
   constexpr int kSlots = kMetSlots;
   static_assert(kSlots == 256 || kSlots == 128 || kSlots == 64, "MetCacheT::slot shifts");
   __shared__ MetEntry met_e[kWavesPerBlock][kSlots];
@@ -366,7 +369,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
   constexpr bool has_val = KIND == 2 && OPK != 0;
   if (KIND == 0 && threadIdx.x == 0) claims_sh = 0;
   if (KIND == 2 && LDS) for (int g = threadIdx.x; g < A.ngroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; }
-  if (KIND == 0 || (KIND == 2 && LDS)) __syncthreads();
+  if (HOT) { for (int g = threadIdx.x; g < kHotGroups; g += kBlock) { lcnt[g] = 0; lval[g] = A.val_init; hg_gid[g] = kEmpty; } if (threadIdx.x == 0) hg_any = 0; }
+  if (KIND == 0 || KIND == 2) __syncthreads();
+  bool hot_on = false;
+  // a row of a hot group into the group's LDS slot (true), or not (k_group_acc<0> describes the scheme; volatile: no barrier in these loops)
+  auto hot_add = [&](uint64_t gid, uint64_t bits, int kind) -> bool {
+    if (!HOT || !hot_on || ((volatile uint64_t*)hg_gid)[gid & (kHotGroups - 1)] != gid) return false;
+    group_add_t<OPK>(lcnt, lval, gid & (kHotGroups - 1), bits, kind);
+    return true;
+  };
   MetCacheT<kSlots> met;
   met.init(met_e[threadIdx.x >> 6], met_c[threadIdx.x >> 6], lane);
   uint32_t claimed = 0;
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     if (KIND == 0 && __atomic_load_n(&A.aux[kAuxAbort], __ATOMIC_RELAXED)) break;      // (wave-uniform) too full: the host grows the table and repeats the chunk
     const uint64_t mine = lane < 16 ? A.sel[tile * 16 + lane] : 0ull;
     if (__ballot(mine != 0) == 0) continue;
+    if (HOT && !hot_on) hot_on = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&hg_any) != 0;
     const int64_t base = tile * kTile;
     const bool whole = base + kTile <= A.nrows;
     const uint8_t* tb = A.bytes + A.tile_off[tile];
@@ -434,9 +446,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         const bool hit = met.find(low_bytes(head[j], sl), low_bytes(head2[j], sl - 8), (uint32_t)sl, g32, str && s0 <= kMetMaxLen);
         const bool known = str && s0 <= kMetMaxLen && hit;
         miss = str && !known;
-        if (KIND == 2 && on[j] && !miss) {
-          const uint64_t gid = s0 >= 0 ? (uint64_t)g32 : gid_missing;
-          if (LDS) group_add_t<OPK>(lcnt, lval, gid, bits[j], vkind); else group_add_t<OPK>(A.cnt, A.val, gid, bits[j], vkind);
+        const bool acc = KIND == 2 && on[j] && !miss;
+        const uint64_t gidv = s0 >= 0 ? (uint64_t)g32 : gid_missing;
+        if (acc) {
+          if (LDS) group_add_t<OPK>(lcnt, lval, gidv, bits[j], vkind); else if (!hot_add(gidv, bits[j], vkind)) group_add_t<OPK>(A.cnt, A.val, gidv, bits[j], vkind);
+        }
+        if (HOT && j == 0) {                                    // a group that holds three of these 64 rows gets a slot (one word in eight is looked at)
+          const uint64_t am = __ballot(acc);
+          if (am) {
+            const int fl = __builtin_ctzll(am);
+            const uint64_t fg = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gidv, fl) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gidv >> 32), fl) << 32;
+            if (__builtin_popcountll(am & __ballot(acc && gidv == fg)) >= 3 && lane == 0) {
+              const uint64_t sl2 = fg & (kHotGroups - 1);
+              if (((volatile uint64_t*)hg_gid)[sl2] == kEmpty) { atomicCAS((unsigned long long*)&hg_gid[sl2], (unsigned long long)kEmpty, (unsigned long long)fg); *(volatile uint32_t*)&hg_any = 1; }
+            }
+          }
         }
         const uint64_t m = __ballot(miss);
         if (lane == h * 8 + j) missw = m;
@@ -463,7 +487,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         if (met.find(c1, c2, (uint32_t)s0, g32)) {
           if (KIND == 2) {
             int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
-            if (LDS) group_add_t<OPK>(lcnt, lval, (uint64_t)g32, bits, kind); else group_add_t<OPK>(A.cnt, A.val, (uint64_t)g32, bits, kind);
+            if (LDS) group_add_t<OPK>(lcnt, lval, (uint64_t)g32, bits, kind); else if (!hot_add((uint64_t)g32, bits, kind)) group_add_t<OPK>(A.cnt, A.val, (uint64_t)g32, bits, kind);
           }
           continue;
         }
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
           const uint64_t gid = A.ent[hs].row;
           if (same && s0 <= kMetMaxLen && gid < 0xFFFFFFFFull) met.put(c1, c2, (uint32_t)s0, (uint32_t)gid, lane);
           int kind = 0; const uint64_t bits = has_val ? value_bits(A.valcol, A.valdt, row, kind) : 0ull;
-          if (LDS) group_add_t<OPK>(lcnt, lval, gid, bits, kind); else group_add_t<OPK>(A.cnt, A.val, gid, bits, kind);
+          if (LDS) group_add_t<OPK>(lcnt, lval, gid, bits, kind); else if (!hot_add(gid, bits, kind)) group_add_t<OPK>(A.cnt, A.val, gid, bits, kind);
         } else if (same && s0 <= kMetMaxLen) met.put(c1, c2, (uint32_t)s0, 1u, lane);
       }
     }
@@ -493,6 +517,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     __syncthreads();
     int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);
     group_flush(lcnt, lval, A.cnt, A.val, A.ngroups, A.op, k2, has_val);
+  }
+  if (HOT) {                                                   // the hot groups' slots -> their groups
+    __syncthreads();
+    int k2 = 0; if (has_val) (void)value_bits(A.valcol, A.valdt, 0, k2);
+    for (int sl = threadIdx.x; sl < kHotGroups; sl += kBlock) {
+      const uint64_t c = lcnt[sl], g = hg_gid[sl];
+      if (!c || g == kEmpty) continue;
+      atomicAdd((unsigned long long*)&A.cnt[g], (unsigned long long)c);
+      if (!has_val) continue;
+      if (A.op == DFDB_AGG_SUM) { if (k2 == 2) atomicAdd((double*)&A.val[g], __longlong_as_double((long long)lval[sl])); else atomicAdd((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]); }
+      else if (A.op == DFDB_AGG_MIN) atomicMin((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]);
+      else if (A.op == DFDB_AGG_MAX) atomicMax((unsigned long long*)&A.val[g], (unsigned long long)lval[sl]);
+    }
   }
 }
 
@@ -622,7 +659,6 @@ struct AccArgs {
 // large part of the rows belong to was 3e8 atomics on one address — 3.6 s per 1e9 rows.  A group that holds three of the 64 rows a wave looks at is given a slot
 // (if its slot is free); from the next trip on a row of a group with a slot is added THERE, and the slots are flushed with one global atomic each when the
 // workgroup ends.  (groupreduce by radix — k_radix.hip — does the same in its partition pass; this is for what it does not take: String keys, > 1.8 M groups.)
-constexpr int kHotGroups = 256;
 template <int NG, int SRC, int OPK, bool W8>
 __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(const AccArgs A) {
   __shared__ uint64_t lcnt[NG ? NG : (int)kHotGroups], lval[NG ? NG : (int)kHotGroups];      // (NG = 0: the hot groups' slots)

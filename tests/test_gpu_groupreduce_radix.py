@@ -149,3 +149,26 @@ def test_groupreduce_by_radix_with_hot_keys(dfdb_mod, ctx, stat):
                     assert np.array_equal(df0[stat].to_numpy(), acc), (stat, col)
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("stat", ["count", "sum", "min"])
+def test_groupreduce_by_a_string_key_with_a_hot_group(dfdb_mod, ctx, stat):
+    """String keys take neither the radix form nor (above 1024 groups) LDS accumulators: every row's value goes through a global atomic — and a string that 40 % of
+    the rows hold made that one address.  k_str_pass<2, 0> keeps LDS slots for hot groups like k_group_acc<0>; the answers must be everybody else's."""
+    rng = np.random.default_rng(9)
+    n = 600_011
+    ids = rng.integers(0, 3000, n)
+    ids[rng.random(n) < 0.4] = 4242
+    words = np.array([f"k{v:05d}" for v in range(5000)], dtype=object)
+    s = words[ids]
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"s": list(s), "v": v}, block_size=65536, ctx=ctx)
+    try:
+        df = dfdb_mod.groupreduce(t, "s", None if stat == "count" else "v", stat)
+        first_rows, cnt, acc = expect(ids.astype(np.int64).view(np.uint64), np.ones(n, bool), v, stat)
+        assert list(df["s"]) == list(s[first_rows])
+        assert np.array_equal(df["count"].to_numpy(), cnt)
+        if stat != "count":
+            assert np.array_equal(df[stat].to_numpy(), acc)
+    finally:
+        t.close()
