@@ -1346,7 +1346,11 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 struct RadixRun {
   dfdb_ctx* ctx; int kbits, P, C; int64_t PS; RadixPool pool{}; DevBuf ctl, pt; size_t tail = 0;
   RadixRun(dfdb_ctx* c, int kb) : ctx(c), kbits(kb), P(1 << kb), C((int)round_up(4 * std::max(1, c->prop.multiProcessorCount), radix_share())), PS((int64_t)(1 << kb) * radix_share()) {}
-  ~RadixRun() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; ctl.release(); pt.release(); }
+  ~RadixRun() {
+    (void)hipStreamSynchronize(ctx->stream);
+    { RecycleScope rs; ctl.release(); pt.release(); }
+    if (ctx->radix_recs.bytes > ctx->prop.totalGlobalMem / 4) ctx->radix_recs.release();      // (a scratch of more than a quarter of the device's memory is not kept between calls)
+  }
   uint32_t* counts() const { return ctl.as<uint32_t>(); }
   char* extra() const { return (char*)ctl.p + tail; }
   // false: no room, or more records than a 32-bit place in the pool can name
