@@ -62,14 +62,14 @@ __device__ __forceinline__ void aux_min(uint64_t* a, uint64_t row) {
   if (__atomic_load_n(a, __ATOMIC_RELAXED) > row) atomicMin((unsigned long long*)a, (unsigned long long)row);
 }
 
-// ---- one 8192-row tile, as the hist and partition passes read it -----------------------------------------------------------------------------------------
+// ---- one 8192-row tile, as the sample and the partition pass read it -----------------------------------------------------------------------------------------
 // Wave w of the 16 takes the tile's rows [512 w, 512 w + 512): EIGHT WHOLE WORDS of the selection (and of the missing bits) — wave-uniform, scalar loads —, and
 // lane l's j-th row is 512 w + 64 j + l: bit l of word j.  Who takes part is decided on the scalar unit (word & ~missing word, handed to the lanes as an execution
 // mask: __builtin_amdgcn_inverse_ballot_w64); the eight key loads of a lane are one address and eight immediate offsets.  The first form of these passes did the
 // same per row on the vector unit — a 64-bit row number, its clamp, the word's address, a 64-bit shift, per row — and ran at 46 (hist) / 215 (partition) vector
 // instructions per 64 rows: at 2.5-4.3 cycles per wave-instruction (tools/ubench/valu_rate.hip) that, not HBM, was what both passes waited for.
 // FULL = every row of the tile exists (base + 8192 <= nrows); the one partial tile of a table clamps its word and row numbers instead.
-// A row takes part when it is selected, not missing and its image can be stored; the special rows go to aux, once, in the hist pass (SPECIALS): a missing key's
+// A row takes part when it is selected, not missing and its image can be stored; the special rows go to aux in the partition pass: a missing key's
 // smallest row to aux[1] here, the unstorable image's (all ones) to aux[0] where the keys are looked at.
 template <int KIND, bool FULL>
 __device__ __forceinline__ uint64_t tile_load(uint64_t (&key)[8], uint64_t (&in)[8], const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype,
@@ -124,9 +124,9 @@ __device__ __forceinline__ uint64_t tile_load(uint64_t (&key)[8], uint64_t (&in)
       if (__builtin_amdgcn_inverse_ballot_w64(in[j])) key[j] = rkey_fixed(col, dtype, base + (FULL || o < last ? o : last));
     }
   }
-  return selected_missing;                                      // (wave-uniform: nonzero = the hist pass looks for the tile's first missing row, tile_first_missing)
+  return selected_missing;                                      // (wave-uniform: nonzero = the partition pass looks for the tile's first missing row, tile_first_missing)
 }
-// the rare side of the hist pass: the smallest selected row of the wave's 512 whose key is missing, to aux[1]
+// the rare side of the partition pass: the smallest selected row of the wave's 512 whose key is missing, to aux[1]
 __device__ __forceinline__ void tile_first_missing(const uint64_t* __restrict__ sel, const uint64_t* __restrict__ missing, int64_t base, int64_t nrows, int wv, int lane, uint64_t* aux) {
   const int64_t w0 = (base >> 6) + wv * 8, wl = (nrows - 1) >> 6;
   for (int j = 0; j < 8; j++) {
@@ -148,7 +148,7 @@ template <int KIND> __device__ __forceinline__ uint64_t keys_storable(uint64_t& 
 // is written: a skewed column is the hash table's).  The partition pass needs no counts: it takes pages from a pool as it goes.
 template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
-                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts_T, int step) {
+                                                        int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts, int step) {
   extern __shared__ uint32_t hist_sh[];
   const int P = 1 << kbits, c = (int)blockIdx.x;
   for (int p = threadIdx.x; p < P; p += kRBlock) hist_sh[p] = 0;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restri
     }
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < P; p += kRBlock) { const uint32_t h = hist_sh[p]; if (h) atomicAdd(&counts_T[p], h); }
+  for (int p = threadIdx.x; p < P; p += kRBlock) { const uint32_t h = hist_sh[p]; if (h) atomicAdd(&counts[p], h); }
 }
 
 // ---- pass 1: the records of chunk c, sorted by partition 8192 rows at a time, to their places
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   }
 }
 
-// ---- pass 3: one workgroup per partition (grid-strided): first occurrences out of a table in LDS
+// ---- pass 2: one workgroup per partition (grid-strided): first occurrences out of a table in LDS
 // Linear probing from an EVEN slot; a record first looks at the two slots its probing starts with (one 16-byte read of keys, one 8-byte read of rows): nearly
 // every record of a partition is a key the table already holds, and at 24 % load all but a few per cent of the keys sit in one of those two.  What is left — a
 // key's first record, the displaced keys' records — is claimed later, 64 at a time (the wave's list).  (FOUR slots per look — 48 bytes of LDS per record instead
