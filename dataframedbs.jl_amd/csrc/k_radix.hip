@@ -13,7 +13,8 @@
 //              claims a slot, a 32-bit atomic minimum keeps the smallest row), and the occupied slots leave one bit each in the bitmap of first occurrences
 //              (+ per-tile counts)
 // 8 + 12 + 12 bytes per selected row, all streams.  The order of a partition's records depends on timing; the result (smallest row per key) does not.
-// Before anything is written a SAMPLE (every 16th tile counted per partition) turns skewed columns away: one workgroup reduces one partition.
+// A key that a large part of the rows hold (one partition = one workgroup's work) is kept out of the records: the partition pass gives it one of a workgroup's
+// 256 LDS slots (HOT KEYS, below) and the table pass gets one list entry per workgroup and key instead.
 // A partition that holds more distinct keys than its table takes raises a flag and the host runs the hash-table form instead (query.cpp: unique_hashed); keys
 // are isequal images (one NaN, -0.0 apart from 0.0), a missing key and the one image that cannot be stored (all ones) are kept aside in aux[1] / aux[0]
 // exactly as k_unique_insert keeps them.  Measured history: profiles/r6_unique_radix.txt; what the instruction and store choices rest on: tools/ubench/.
@@ -145,7 +146,7 @@ template <int KIND> __device__ __forceinline__ uint64_t keys_storable(uint64_t& 
 }
 
 // ---- the SAMPLE: counts[p] = selected rows whose key falls into partition p among every `step`-th tile (query.cpp looks at the largest partition before anything
-// is written: a skewed column is the hash table's).  The partition pass needs no counts: it takes pages from a pool as it goes.
+// is written: a skewed column gets the partition kernels that look for hot keys).  The partition pass needs no counts: it takes pages from a pool as it goes.
 template <int KIND>
 __global__ __launch_bounds__(kRBlock) void k_radix_hist(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                         int64_t nrows, int64_t rows_per_chunk, int kbits, uint32_t* __restrict__ counts, int step) {
@@ -188,7 +189,7 @@ constexpr int part_lds_words(int block) { return 6 * 1024 + 32 + 8 * block; }   
 // stored are counted and reduced
 // here, in a workgroup-wide accumulator that is flushed to gspec {count, value} once per workgroup (GOP: 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // of order images; vkind: how a value's image is made — k_unique.hip's order_image).
-struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; uint64_t* hot; uint32_t* hot_n; uint32_t hot_cap; };
+struct RadixVals { const void* col; int vdt; uint64_t* gspec; int gop; int vkind; };
 // HOT KEYS.  A key that a large part of the rows hold would make one partition — one workgroup's work — of all those rows, every one an atomic on the same LDS
 // word (and through the form this replaces, 3e8 global atomics on ONE address: 3.6 s per 1e9 rows).  A workgroup of the partition pass keeps kHotSlots keys in LDS
 // with their own accumulators: a key that turns up three times among the 64 rows of a selection word is given a slot (if its slot is free), and from the next tile
@@ -227,13 +228,14 @@ __device__ __forceinline__ void acc_value(uint64_t* slot, uint64_t v, int gop, i
   else if (gop == 4) atomicMax((unsigned long long*)slot, (unsigned long long)order_image(v, vkind, false));
 }
 // V8: the value column is eight bytes wide (loaded as it is; the narrow types' switch — seventeen copies of it — lives in the !V8 kernels only)
-template <int KIND, int BLOCK, bool HASVAL, bool V8>
+// HOT: the hot keys' slots are compiled in (groupreduce always; unique only for a column its sample calls skewed: the code beside the sort costs the pass 1.1 of its 4.6 ms)
+template <int KIND, int BLOCK, bool HASVAL, bool V8, bool HOT>
 __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __restrict__ sel, const void* __restrict__ col, int dtype, const uint64_t* __restrict__ missing,
                                                              int64_t nrows, int64_t rows_per_chunk, int kbits, RadixPool pool,
                                                              uint32_t* __restrict__ recs_out, uint64_t* aux, RadixVals vals, int xp) {
   __shared__ uint64_t spec_sh[4];                               // HASVAL: {rows, reduced value} of the rows whose key is the unstorable image, then of the rows whose key is missing: this workgroup's
-  __shared__ uint64_t hc_key[HASVAL ? kHotSlots : 1], hc_val[HASVAL ? kHotSlots : 1];      // HASVAL: the hot keys' slots: key, reduced value, ...
-  __shared__ uint32_t hc_cnt[HASVAL ? kHotSlots : 1], hc_row[HASVAL ? kHotSlots : 1], hc_any;   // ... rows, smallest row; whether any slot is taken
+  __shared__ uint64_t hc_key[HOT ? kHotSlots : 1], hc_val[HOT && HASVAL ? kHotSlots : 1];      // the hot keys' slots: key, (HASVAL) reduced value, ...
+  __shared__ uint32_t hc_cnt[HOT ? kHotSlots : 1], hc_row[HOT ? kHotSlots : 1], hc_any;         // ... rows, smallest row; whether any slot is taken
   extern __shared__ uint64_t part_sh[];
   uint32_t* hist2 = (uint32_t*)part_sh;                         // [1024] this tile's records per partition
   uint32_t* lstart = hist2 + 1024;                              // [1024] their first slot in the sorted tile
@@ -246,14 +248,14 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)c * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
   if (r0 >= r1) return;
-  if (HASVAL && tid == 0) { spec_sh[0] = spec_sh[2] = 0; spec_sh[1] = spec_sh[3] = vals.gop == 3 ? ~0ull : 0ull; hc_any = 0; }
-  if (HASVAL && tid < kHotSlots) { hc_key[tid] = kREmpty; hc_val[tid] = vals.gop == 3 ? ~0ull : 0ull; hc_cnt[tid] = 0; hc_row[tid] = 0xFFFFFFFFu; }
+  if (tid == 0) { hc_any = 0; if (HASVAL) { spec_sh[0] = spec_sh[2] = 0; spec_sh[1] = spec_sh[3] = vals.gop == 3 ? ~0ull : 0ull; } }
+  if (HOT && tid < kHotSlots) { hc_key[tid] = kREmpty; hc_cnt[tid] = 0; hc_row[tid] = 0xFFFFFFFFu; if (HASVAL) hc_val[tid] = vals.gop == 3 ? ~0ull : 0ull; }
   const int fx = tid * kRShare + (c & (kRShare - 1));          // thread p < P: the stream (partition p, this workgroup's share)
   for (int p = tid; p < 1024; p += BLOCK) hist2[p] = 0;
   __syncthreads();
   uint64_t nkey[8], nin[8];                                     // the NEXT tile: loaded while this one is sorted and written
   uint32_t pk = 0xFFFFFFFFu, pb = 0;                            // thread p < P: the page of its stream its last run ended in, and where that page lies
-  bool hot_on = false;                                          // HASVAL: some hot key has a slot (wave-uniform)
+  bool hot_on = false;                                          // some hot key has a slot (wave-uniform)
   uint64_t nmiss;                                               // (wave-uniform) selected rows of the next tile whose key is missing
   if (r0 + TILE <= nrows) nmiss = tile_load<KIND, true>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
   else nmiss = tile_load<KIND, false>(nkey, nin, sel, col, dtype, missing, r0, nrows, wv, lane);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
       unstorable |= nin[j] & ~ok;
       take[j] = nin[j] & ok;
     }
-    if (HASVAL) {                                               // hot keys (see RadixVals)
+    if (HOT) {                                                  // hot keys (see RadixVals)
       if (!hot_on) hot_on = __builtin_amdgcn_readfirstlane((int)hc_any) != 0;      // (as the tile begins: a slot taken during it counts from the next tile on)
       if (hot_on) {
         uint64_t ck[8];
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
             const int64_t row = base + wv * 512 + j * 64 + lane;
             atomicAdd(&hc_cnt[sl], 1u);
             if (hc_row[sl] > (uint32_t)row) atomicMin(&hc_row[sl], (uint32_t)row);
-            if (vals.col && vals.gop) acc_value(&hc_val[sl], rvalue_of<V8>(vals.col, vals.vdt, row), vals.gop, vals.vkind);
+            if (HASVAL && vals.col && vals.gop) acc_value(&hc_val[sl], rvalue_of<V8>(vals.col, vals.vdt, row), vals.gop, vals.vkind);
           }
           take[j] &= ~hit;
         }
@@ -447,13 +449,13 @@ __global__ __launch_bounds__(BLOCK) void k_radix_partition(const uint64_t* __res
     }
     // (no barrier here: the next tile writes hist2 — cleared above — before its first barrier, and nothing this step still reads before its third)
   }
-  if (HASVAL) {                                                 // the workgroup's rows of the unstorable key -> the launch's
-    __syncthreads();
-    if (tid < kHotSlots && hc_key[tid] != kREmpty && hc_cnt[tid]) {          // the hot keys' slots -> the launch's list
-      const uint32_t i = atomicAdd(vals.hot_n, 1u);
-      if (i < vals.hot_cap) { vals.hot[3 * (size_t)i] = hc_key[tid]; vals.hot[3 * (size_t)i + 1] = hc_val[tid]; vals.hot[3 * (size_t)i + 2] = (uint64_t)hc_cnt[tid] << 32 | hc_row[tid]; }
-      else __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED);              // (cannot happen: the list holds every workgroup's every slot)
-    }
+  if (HOT || HASVAL) __syncthreads();
+  if (HOT && tid < kHotSlots && hc_key[tid] != kREmpty && hc_cnt[tid]) {     // the hot keys' slots -> the launch's list
+    const uint32_t i = atomicAdd(pool.hot_n, 1u);
+    if (i < pool.hot_cap) { pool.hot[3 * (size_t)i] = hc_key[tid]; pool.hot[3 * (size_t)i + 1] = HASVAL ? hc_val[tid] : 0ull; pool.hot[3 * (size_t)i + 2] = (uint64_t)hc_cnt[tid] << 32 | hc_row[tid]; }
+    else __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED);                // (cannot happen: the list holds every workgroup's every slot)
+  }
+  if (HASVAL) {                                                 // the workgroup's rows of the unstorable key / the missing key -> the launch's
     if (tid < 2 && spec_sh[2 * tid]) {
       atomicAdd((unsigned long long*)&vals.gspec[2 * tid], (unsigned long long)spec_sh[2 * tid]);
       const uint64_t v = spec_sh[2 * tid + 1];
@@ -500,7 +502,7 @@ __device__ __forceinline__ void recs_load(uint64_t (&kk)[4], uint32_t (&rw)[4], 
   }
 }
 __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __restrict__ recs, RadixPool pool,
-                                                          int P, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux, int xp) {
+                                                          int P, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ tile_counts, uint64_t* aux, int kbits, int xp) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kRSlots]
   uint32_t* trow = (uint32_t*)(tkey + kRSlots);               // [kRSlots]
@@ -580,6 +582,12 @@ __global__ __launch_bounds__(kRBlock) void k_radix_unique(const uint32_t* __rest
       if (claims_sh > (kRSlots * 7) / 8) { abort_sh = 1; break; }
     }
     if (qn && !abort_sh) { if (lane < (int)qn) table_claim(tkey, trow, qk[lane], qr[lane], &claims_sh, &abort_sh); }      // what is left on the wave's list
+    // the hot keys the partition pass kept to itself (one entry per workgroup and key, the smallest of its rows): those of this partition
+    { const uint32_t nhot = *pool.hot_n;
+      for (uint32_t i = (uint32_t)tid; i < nhot && !abort_sh; i += kRBlock) {
+        const uint64_t key = pool.hot[3 * (size_t)i];
+        if ((int)(rhash(key) >> (32 - kbits)) == p) table_claim(tkey, trow, key, (uint32_t)pool.hot[3 * (size_t)i + 2], &claims_sh, &abort_sh);
+      } }
     __syncthreads();
     if (abort_sh) { if (tid == 0) __atomic_store_n(&aux[3], 1ull, __ATOMIC_RELAXED); return; }      // aux[kAuxAbort]: this column needs the hash-table form
     for (int i = tid; i < kRSlots; i += kRBlock) {
@@ -657,7 +665,7 @@ __device__ __forceinline__ void recs20_load(uint64_t (&kk)[4], uint32_t (&rw)[4]
 }
 __global__ __launch_bounds__(kRBlock) void k_radix_group(const uint32_t* __restrict__ recs, RadixPool pool, int P, int mark, uint64_t* __restrict__ bitmap,
                                                          uint32_t* __restrict__ tile_counts, uint64_t* aux, uint4* __restrict__ results, uint32_t* __restrict__ nres,
-                                                         int gop, int vkind, const uint64_t* __restrict__ hot, const uint32_t* __restrict__ hot_n, int kbits) {
+                                                         int gop, int vkind, int kbits) {
   extern __shared__ uint64_t tab_sh[];
   uint64_t* tkey = tab_sh;                                    // [kGSlots]
   uint64_t* tval = tkey + kGSlots;                            // [kGSlots] the key's reduced value (min / max: of order images)
@@ -733,7 +741,8 @@ __global__ __launch_bounds__(kRBlock) void k_radix_group(const uint32_t* __restr
     }
     if (qn && !abort_sh) { if (lane < (int)qn) gtable_claim(tkey, trow, tcnt, tval, qk[lane], qr[lane], qv[lane], gop, vkind, &claims_sh, &abort_sh); }
     // the hot keys the partition pass reduced on its own (one entry per workgroup and key): those of this partition
-    const uint32_t nhot = *hot_n;
+    const uint64_t* hot = pool.hot;
+    const uint32_t nhot = *pool.hot_n;
     for (uint32_t i = (uint32_t)tid; i < nhot && !abort_sh; i += kRBlock) {
       const uint64_t key = hot[3 * (size_t)i];
       if ((int)(rhash(key) >> (32 - kbits)) != p) continue;
@@ -803,26 +812,28 @@ bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, in
   }
   return true;
 }
-template <int KIND, bool HASVAL, bool V8>
+template <int KIND, bool HASVAL, bool V8, bool HOT>
 static bool radix_partition_go(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                                const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixVals& vals) {
-  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock, HASVAL, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)radix_partition_lds_bytes(kRBlock)) == hipSuccess;      // (+ the static arrays: under 160 KB)
+  static const bool ok = hipFuncSetAttribute((const void*)k_radix_partition<KIND, kRBlock, HASVAL, V8, HOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)radix_partition_lds_bytes(kRBlock)) == hipSuccess;      // (+ the static arrays: under 160 KB)
   if (!ok) { (void)hipGetLastError(); return false; }
-  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock, HASVAL, V8>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
+  hipLaunchKernelGGL((k_radix_partition<KIND, kRBlock, HASVAL, V8, HOT>), dim3(chunks), dim3(kRBlock), radix_partition_lds_bytes(kRBlock), s, sel, col, dtype, missing, nrows,
                      radix_rows_per_chunk(nrows, chunks), kbits, pool, recs_out, aux, vals, radix_xp());
   return true;
 }
 // (512-thread workgroups sorting 4096 rows, two per CU, instead of one of 1024 sorting 8192: 5.36-5.43 ms against 5.32-5.33 — the pass waits for its stores either way)
 // group = nullptr: 12-byte records for unique; otherwise 20-byte records {key, row, value} for groupreduce (group->valcol may be null: count only)
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
-                            const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixGroup* group) {
+                            const RadixPool& pool, uint32_t* recs_out, uint64_t* aux, const RadixGroup* group, bool hot) {
   if (kbits < 6 || kbits > 10 || nrows < 1 || chunks % kRShare) return false;
   RadixVals v{};
-  if (group) { v.col = group->valcol; v.vdt = group->valdt; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; v.hot = group->hot; v.hot_n = group->hot_n; v.hot_cap = group->hot_cap; }
+  if (group) { v.col = group->valcol; v.vdt = group->valdt; v.gspec = group->gspec; v.gop = group->gop; v.vkind = group->vkind; }
   const bool v8 = !group || !group->valcol || group->valdt == DFDB_I64 || group->valdt == DFDB_U64 || group->valdt == DFDB_F64;
-#define DFDB_RP(K) (group ? (v8 ? radix_partition_go<K, true, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
-                                : radix_partition_go<K, true, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v)) \
-                          : radix_partition_go<K, false, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v))
+#define DFDB_RP(K) (group ? (!v8 ? radix_partition_go<K, true, false, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
+                                 : hot ? radix_partition_go<K, true, true, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
+                                       : radix_partition_go<K, true, true, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v)) \
+                          : (hot ? radix_partition_go<K, false, true, true>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v) \
+                                 : radix_partition_go<K, false, true, false>(s, sel, col, dtype, missing, nrows, kbits, chunks, pool, recs_out, aux, v)))
   switch (radix_kind(dtype)) {
     case kKindRaw8: return DFDB_RP(kKindRaw8);
     case kKindF64: return DFDB_RP(kKindF64);
@@ -837,7 +848,7 @@ bool launch_radix_group(hipStream_t s, const uint32_t* recs, const RadixPool& po
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   hipLaunchKernelGGL(k_radix_group, dim3(P < cus ? P : cus), dim3(kRBlock), lds, s, recs, pool, P, mark ? 1 : 0, bitmap, tile_counts, aux, (uint4*)group.results, group.nres,
-                     group.gop, group.vkind, group.hot, group.hot_n, kbits);
+                     group.gop, group.vkind, kbits);
   return true;
 }
 void launch_radix_group_finish(hipStream_t s, const RadixGroup& group, const uint64_t* ubits, const uint64_t* uprefix, const uint64_t* aux, uint64_t* cnt, uint64_t* val) {
@@ -849,7 +860,7 @@ bool launch_radix_unique(hipStream_t s, const uint32_t* recs, const RadixPool& p
   if (!ok) { (void)hipGetLastError(); return false; }
   const int P = 1 << kbits;
   const int grid = P < cus ? P : cus;                       // one 96-KB table per CU at a time
-  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, pool, P, bitmap, tile_counts, aux, radix_xp());
+  hipLaunchKernelGGL(k_radix_unique, dim3(grid), dim3(kRBlock), lds, s, recs, pool, P, bitmap, tile_counts, aux, kbits, radix_xp());
   return true;
 }
 

@@ -158,11 +158,12 @@ void launch_unique_str(hipStream_t s, int pass, uint64_t* bitmap, uint32_t* tile
                        const uint8_t* bytes, int64_t nrows, int64_t tile0, int64_t tile1, UniqueEntry* ent, uint64_t* rep_off, uint32_t* rep_len, uint64_t mask,
                        uint64_t* aux, uint64_t salt);
 // dense form.  aux words: 1 = smallest missing row, 5 = a key outside [lo, lo + range) was met, 6 = distinct keys, 7 = keys whose first row is known, 8 / 9 = min / max image
-// radix-partitioned form of the hash-table unique (k_radix.hip): sample -> partition into a pool of pages -> one LDS table per partition.  false: the launch is
+// radix-partitioned form of the hash-table unique (k_radix.hip): partition into a pool of pages -> one LDS table per partition.  false: the launch is
 // not possible (LDS attribute refused, too many partition bits): the caller stays with the hash table.  The pool: `front` [2^kbits x radix_share()] running
 // positions of the streams (zero before the pass), `pt` [2^kbits x radix_share()][maxv] the streams' pages (all ones before the pass), `next_page` the pool's
 // counter (zero), `dump_page` the page nobody owns (radix_pool_pages() - 1); the records' buffer holds radix_pool_record_bytes().
-struct RadixPool { uint32_t* front; uint32_t* pt; uint32_t* next_page; uint32_t maxv; uint32_t dump_page; };
+struct RadixPool { uint32_t* front; uint32_t* pt; uint32_t* next_page; uint32_t maxv; uint32_t dump_page;
+                   uint64_t* hot /* [hot_cap x 3]: the hot keys' list {key, value, rows << 32 | first row}: chunks x radix_hot_slots() entries */; uint32_t* hot_n /* zero before */; uint32_t hot_cap; };
 int64_t radix_rows_per_chunk(int64_t nrows, int chunks);
 int radix_share();
 int64_t radix_pool_pages(int64_t cnt, int kbits);
@@ -174,12 +175,11 @@ bool launch_radix_sample(hipStream_t s, const uint64_t* sel, const void* col, in
 // groupreduce by radix: the records carry the row's 8-byte value (valcol; null: count only); gop 0 count only, 1 wrapping integer sum, 2 double sum, 3 min, 4 max
 // (of order images: vkind 0 signed, 1 unsigned, 2 double); results [<= groups] {first row, rows, value} + their count nres; gspec {rows, value} of the unstorable key
 // and of the missing key (their first rows: aux[0], aux[1])
-struct RadixGroup { const void* valcol; int valdt; int gop; int vkind; void* results; uint32_t* nres; uint64_t* gspec /* [4]: the unstorable key's, the missing key's */;
-                    uint64_t* hot /* [hot_cap x 3]: the hot keys' list (chunks x radix_hot_slots() entries) */; uint32_t* hot_n /* zero before */; uint32_t hot_cap; };
+struct RadixGroup { const void* valcol; int valdt; int gop; int vkind; void* results; uint32_t* nres; uint64_t* gspec /* [4]: the unstorable key's, the missing key's */; };
 int radix_hot_slots();
 bool launch_radix_partition(hipStream_t s, const uint64_t* sel, const void* col, int dtype, const uint64_t* missing, int64_t nrows, int kbits, int chunks,
                             const RadixPool& pool, uint32_t* recs_out /* 12 bytes per record: key image, row; with a group: 20, + the value */, uint64_t* aux,
-                            const RadixGroup* group = nullptr);
+                            const RadixGroup* group = nullptr, bool hot = false /* the kernels that keep hot keys out of the records (values narrower than 8 bytes: always) */);
 bool launch_radix_group(hipStream_t s, const uint32_t* recs, const RadixPool& pool, int kbits, bool mark, uint64_t* bitmap, uint32_t* tile_counts, uint64_t* aux,
                         const RadixGroup& group, int cus);
 void launch_radix_group_finish(hipStream_t s, const RadixGroup& group, const uint64_t* ubits, const uint64_t* uprefix, const uint64_t* aux, uint64_t* cnt, uint64_t* val);

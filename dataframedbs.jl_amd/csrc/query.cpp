@@ -1337,49 +1337,49 @@ static bool unique_dense(dfdb_query* q, const Column& col, UniqueTables& T) {
 // of one random line per row.  false = not taken (too few or too many distinct values, no room for the 12 bytes per selected row, a partition that outgrew
 // its table): the caller goes on with the hash table; the selection is as it was.
 // What the two radix forms (unique, groupreduce) share on the host: the pool of pages for `nsel` records in 2^kbits partitions (k_radix.hip), its control words —
-// the sample's counts [P], the streams' running positions [P x share], the pool's counter, then `extra` bytes the caller lays out (64-byte aligned) — and the
-// SAMPLE: one workgroup reduces one partition, so a partition that holds a large part of all the rows (a value that a third of the column has) would be one CU's
-// work while 255 wait — 1.5 ms per average partition, i.e. 8 average partitions' worth of records already costs what the whole pass does.  Every 16th tile is
-// counted (all of them in a small table: 0.1 ms per 1e9 rows), the counts come back and the largest partition is looked at before anything is written.
-// The temporaries go back to the buffer pool (not through hipFree, which drains the device: 1.5 ms of a 16-ms call once), the stream drained first; the records'
-// scratch stays with the context between calls (hipMalloc / hipFree of 12 GB cost 3-4 ms; buffers above 1 GB never enter the pool; dfdb_ctx_destroy releases it).
+// the sample's counts [P], the streams' running positions [P x share], the pool's counter, the hot keys' count, then `extra` bytes the caller lays out (64-byte aligned) — and the hot keys'
+// list.  The temporaries go back to the buffer pool (not through hipFree, which drains the device: 1.5 ms of a 16-ms call once), the stream drained first; the
+// records' scratch stays with the context between calls (hipMalloc / hipFree of 12 GB cost 3-4 ms; buffers above 1 GB never enter the pool; dfdb_ctx_destroy
+// releases it) unless it is more than a quarter of the device's memory.
 struct RadixRun {
-  dfdb_ctx* ctx; int kbits, P, C; int64_t PS; RadixPool pool{}; DevBuf ctl, pt; size_t tail = 0;
+  dfdb_ctx* ctx; int kbits, P, C; int64_t PS; RadixPool pool{}; DevBuf ctl, pt, hot; size_t tail = 0;
   RadixRun(dfdb_ctx* c, int kb) : ctx(c), kbits(kb), P(1 << kb), C((int)round_up(4 * std::max(1, c->prop.multiProcessorCount), radix_share())), PS((int64_t)(1 << kb) * radix_share()) {}
   ~RadixRun() {
     (void)hipStreamSynchronize(ctx->stream);
-    { RecycleScope rs; ctl.release(); pt.release(); }
-    if (ctx->radix_recs.bytes > ctx->prop.totalGlobalMem / 4) ctx->radix_recs.release();      // (a scratch of more than a quarter of the device's memory is not kept between calls)
+    { RecycleScope rs; ctl.release(); pt.release(); hot.release(); }
+    if (ctx->radix_recs.bytes > ctx->prop.totalGlobalMem / 4) ctx->radix_recs.release();
   }
-  uint32_t* counts() const { return ctl.as<uint32_t>(); }
   char* extra() const { return (char*)ctl.p + tail; }
   // false: no room, or more records than a 32-bit place in the pool can name
   bool prepare(int64_t nsel, bool with_values, size_t extra_bytes) {
     if (radix_pool_pages(nsel, kbits) * 8192 >= (1ll << 32)) return false;
     pool.maxv = radix_pool_maxv(nsel, kbits);
     pool.dump_page = (uint32_t)(radix_pool_pages(nsel, kbits) - 1);
-    const size_t ctl_words = (size_t)P + (size_t)PS + 16;
+    pool.hot_cap = (uint32_t)C * (uint32_t)radix_hot_slots();
+    const size_t ctl_words = (size_t)P + (size_t)PS + 16;                 // the sample's counts [P], the streams' running positions [PS], the pool's counter, the hot keys' count
     tail = (ctl_words * 4 + 63) / 64 * 64;
     try {
       ctl.ensure(tail + extra_bytes + 64); pt.ensure((size_t)PS * pool.maxv * 4 + 512);      // (+ 64 entries nobody owns: the table passes read 64 at a time)
+      hot.ensure((size_t)pool.hot_cap * 24 + 64);
       ctx->radix_recs.ensure((size_t)radix_pool_record_bytes(nsel, kbits, with_values) + 256);
     } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
-    pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.pt = pt.as<uint32_t>();
+    pool.front = ctl.as<uint32_t>() + P; pool.next_page = ctl.as<uint32_t>() + P + PS; pool.hot_n = ctl.as<uint32_t>() + P + PS + 1; pool.pt = pt.as<uint32_t>(); pool.hot = hot.as<uint64_t>();
     HIP_CHECK(hipMemsetAsync(ctl.p, 0, tail + extra_bytes, ctx->stream));
     HIP_CHECK(hipMemsetAsync(pt.p, 0xFF, (size_t)PS * pool.maxv * 4, ctx->stream));
     return true;
   }
-  // 1 = skewed, 0 = not, -1 = the sample could not be launched
-  int skewed(const uint64_t* sel, const void* col, int dt, const uint64_t* miss, int64_t nrows) {
+  // unique: does some partition hold a large part of all the rows (a value that a third of the column has)?  Every 16th tile is counted (all of them in a small
+  // table: 0.1 ms per 1e9 rows) and the counts come back.  1 = skewed, 0 = not, -1 = the sample could not be launched
+  int skewed(const uint64_t* sel, const void* col, int dt, const uint64_t* miss, int64_t nrows, int times) {      // times: "large" = more than this many average partitions
     const int step = radix_rows_per_chunk(nrows, C) / 8192 >= 32 ? 16 : 1;
     { LaunchTimer lt(ctx, "radix_sample");
-      if (!launch_radix_sample(ctx->stream, sel, col, dt, miss, nrows, kbits, C, step, counts())) return -1; }
+      if (!launch_radix_sample(ctx->stream, sel, col, dt, miss, nrows, kbits, C, step, ctl.as<uint32_t>())) return -1; }
     std::vector<uint32_t> cn((size_t)P);
     HIP_CHECK(hipMemcpyAsync(cn.data(), ctl.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
     stream_wait(ctx);
     uint64_t maxp = 0, total = 0;
     for (int p = 0; p < P; p++) { maxp = std::max<uint64_t>(maxp, cn[(size_t)p]); total += cn[(size_t)p]; }
-    return maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > 8 * total ? 1 : 0;
+    return maxp * (uint64_t)step > 65536 && maxp * (uint64_t)P > (uint64_t)times * total ? 1 : 0;
   }
 };
 // how many distinct values `cnt` selected rows hold when the first r0 of them held d0, assuming they turn up evenly: d0 = D (1 - exp(-r0 / D)), by bisection
@@ -1420,11 +1420,14 @@ static bool unique_radix(dfdb_query* q, const Column& col, int64_t cnt, UniqueTa
   try { sel_keep.ensure(nw * 8); tc_keep.ensure((size_t)nt * 4 + 64); } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
   const RadixPool& pool = run.pool; const int C = run.C;
   DevBuf& recs = ctx->radix_recs;
-  { const int sk = run.skewed(q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows);
-    if (sk < 0) return false;
-    if (sk) { prof_note(ctx, "unique_radix.skewed"); return false; } }   // (the hash table takes such a column: the hot key's probes hit one cached line)
+  // SKEW: one workgroup reduces one partition, so a value that a large part of the rows hold would be one CU's work while 255 wait.  The sample says whether some
+  // partition holds more than eight average ones; then the partition kernels that keep hot keys out of the records run (k_radix.hip, hot keys: 1.1 ms slower where
+  // nothing is hot, which is why they are not the only ones)
+  const int sk = run.skewed(q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, 8);
+  if (sk < 0) return false;
+  if (sk) prof_note(ctx, "unique_radix.skewed");
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), T.aux.as<uint64_t>())) return false; }
+    if (!launch_radix_partition(s, q->bitmap.as<uint64_t>(), col.data.p, dt, miss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), T.aux.as<uint64_t>(), nullptr, sk != 0)) return false; }
   // the selection is set aside (a partition that outgrows its table means: back to the hash table, over the same selection)
   HIP_CHECK(hipMemcpyAsync(sel_keep.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(tc_keep.p, q->tile_counts.p, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
@@ -1599,11 +1602,10 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   if (ng / (1ll << kbits) > 1800) return false;
   const int P = 1 << kbits;
   const int dt = dt_base(kc.dtype);
-  struct Res { dfdb_ctx* ctx; DevBuf res, hot; ~Res() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; res.release(); hot.release(); } } tmp{ctx, {}, {}};
+  struct Res { dfdb_ctx* ctx; DevBuf res; ~Res() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; res.release(); } } tmp{ctx, {}};
   RadixRun run(ctx, kbits);
   if (!run.prepare(nsel, true, 128)) return false;
-  const uint32_t hot_cap = (uint32_t)run.C * (uint32_t)radix_hot_slots();
-  try { tmp.res.ensure((size_t)(mark ? (int64_t)P * radix_group_slots() : ng) * 16 + 256); tmp.hot.ensure((size_t)hot_cap * 24 + 64); } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
+  try { tmp.res.ensure((size_t)(mark ? (int64_t)P * radix_group_slots() : ng) * 16 + 256); } catch (const Error& e) { if (e.code != DFDB_ERR_NOMEM) throw; (void)hipGetLastError(); return false; }
   const RadixPool& pool = run.pool; const int C = run.C;
   DevBuf& recs = ctx->radix_recs;
   uint64_t* aux = (uint64_t*)run.extra();                                // [0] the unstorable key's first row, [1] the missing key's, [3] abort; [4..7] gspec; [8] nres
@@ -1612,13 +1614,16 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   g.gop = op == DFDB_AGG_SUM ? (q->gr_kind == 2 ? 2 : 1) : (op == DFDB_AGG_MIN ? 3 : (op == DFDB_AGG_MAX ? 4 : 0));
   if (!vc) g.gop = 0;
   g.vkind = q->gr_kind; g.results = tmp.res.p; g.gspec = aux + 4; g.nres = (uint32_t*)(aux + 8);
-  g.hot = tmp.hot.as<uint64_t>(); g.hot_n = (uint32_t*)(aux + 9); g.hot_cap = hot_cap;
   HIP_CHECK(hipMemsetAsync(aux, 0xFF, 16, s));                           // aux[0], aux[1] = none
   if (g.gop == 3) { HIP_CHECK(hipMemsetAsync(aux + 5, 0xFF, 8, s)); HIP_CHECK(hipMemsetAsync(aux + 7, 0xFF, 8, s)); }      // gspec[1], [3]: a minimum starts at all ones
-  // (no sample here: a key that a large part of the rows hold is reduced by the partition pass itself — k_radix.hip, hot keys —, and the form this replaces would
-  // send every one of its rows through a global atomic on ONE address: 3.6 s per 1e9 rows with a key that 30 % of them hold)
+  // a key that a large part of the rows hold is reduced by the partition pass itself (k_radix.hip, hot keys: the form this replaces sent every one of its rows
+  // through a global atomic on ONE address — 3.6 s per 1e9 rows with a key that 30 % of them hold); the kernels that do so are 0.8-1.1 ms slower where nothing is
+  // hot, so the sample picks: some partition above THREE average ones, and they run
+  const int sk = run.skewed(sel, kc.data.p, dt, kmiss, t->nrows, 3);
+  if (sk < 0) return false;
+  if (sk) prof_note(ctx, "group_radix.skewed");
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g)) return false; }
+    if (!launch_radix_partition(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g, sk != 0)) return false; }
   if (mark) {
     HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
     HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));

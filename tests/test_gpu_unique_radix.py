@@ -138,26 +138,22 @@ def test_radix_unique_small_tables_and_one_tile_partitions(dfdb_mod, ctx):
             t.close()
 
 
-def test_radix_unique_leaves_a_skewed_column_to_the_hash_table(dfdb_mod, ctx):
-    """a value that 40 % of the rows hold would make one partition — one workgroup's work — of 40 % of the records: the sizes are looked at after the hist pass and
-    the hash table answers (nothing was written: the selection is as it was)"""
+@pytest.mark.parametrize("share", [0.4, 0.05, 0.004])
+def test_radix_unique_with_a_hot_value(dfdb_mod, ctx, share):
+    """a value that a large part of the rows hold would make one partition — one workgroup's work — of all those rows: the partition pass keeps such a value in one of
+    a workgroup's LDS slots (its rows never become records) and the table pass gets one list entry per workgroup (k_radix.hip, hot keys); the first occurrences are
+    everybody else's, under a predicate too"""
     rng = np.random.default_rng(5)
     n = 3_000_011
     k = (rng.integers(0, 400_000, n) * 7 + 11).astype(np.int64)
-    k[rng.random(n) < 0.4] = 123_456_789
-    t = dfdb_mod.DFTable.from_columns({"k": k}, block_size=65536, ctx=ctx)
+    k[rng.random(n) < share] = 123_456_789
+    a = rng.integers(0, 10, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "k": k}, block_size=65536, ctx=ctx)
     try:
-        import dfdb._native as N
-        ctx.set_option("unique_dense", 0); ctx.set_option("unique_radix", 2); ctx.profile(True)
-        try:
-            q = t[dfdb_mod.ALL, ["k"]]._query()
-            N.check(N.load().dfdb_query_unique(q._h, 0))
-            rows = q.indices() - 1
-            skewed, taken = ctx.profile_get("unique_radix.skewed")[0], ctx.profile_get("unique_radix.taken")[0]
-        finally:
-            ctx.profile(False); ctx.set_option("unique_dense", 1); ctx.set_option("unique_radix", 1)
-        assert (skewed, taken) == (1, 0)
-        assert np.array_equal(rows, first_rows(image(k), np.ones(n, bool)))
+        for view, sel in ((t[dfdb_mod.ALL, ["k"]], np.ones(n, bool)), (t[("a", lambda c: c > 3), ["k"]], a > 3)):
+            got, taken, fell = run_unique(dfdb_mod, t, view, 2)
+            assert (taken, fell) == (1, 0)                           # (0.4 and 0.05: the sample calls the column skewed and the kernels with the hot keys' slots run; 0.004: the plain ones)
+            assert np.array_equal(got, first_rows(image(k), sel)), share
     finally:
         t.close()
 
