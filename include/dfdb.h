@@ -166,9 +166,9 @@ int32_t dfdb_ctx_device_info(dfdb_ctx* ctx, dfdb_device_info* out);
  *   "unique_radix"     1 (default) = dfdb_query_unique over a fixed-width key whose hash table would outgrow the L2s (an estimated 131 072 .. ~5 M distinct values among
  *                      at least 4 M selected rows) takes the radix-partitioned form (k_radix.hip: every selected row written once as a {key, row} record into one of
  *                      256 .. 1024 partitions, each reduced through a table in LDS; 12 bytes of scratch per selected row (20 for groupreduce) + 0.4-0.8 GB of part-filled pages, kept by the context between calls
- *                      unless it is more than a quarter of the device's memory; no room for it, a
- *                      partition that outgrows its table, or one that holds more than eight average partitions' rows — a value a large part of the column has
- *                      —: the hash table answers).  8.8 ms against the hash table's 19.8 per 1e9 rows of 1e6 values
+ *                      unless it is more than a quarter of the device's memory; no room for it, or a
+ *                      partition that outgrows its table: the hash table answers; a value that a large part of the column holds is kept out of the records by the
+ *                      partition pass itself — LDS slots for hot keys).  8.8 ms against the hash table's 19.8 per 1e9 rows of 1e6 values
  *                      (profiles/r6_unique_radix.txt).  dfdb_query_groupreduce over more groups than a workgroup's LDS accumulators hold (9216; a fixed-width key,
  *                      nullable or not) goes the same way: 14.5 ms where global atomics took 89 per 1e9 rows in 50 000 groups (19.6 ms against 3.6 s when one key holds 30 % of the rows)
  *                      (profiles/r6_groupreduce_radix.txt).  0 = always the hash table / the global atomics
