@@ -658,7 +658,7 @@ struct AccArgs {
 // NG = 0 (more groups than any LDS holds: every row's value through a global atomic) keeps kHotGroups slots in LDS for HOT groups (round 6): a group that a
 // large part of the rows belong to was 3e8 atomics on one address — 3.6 s per 1e9 rows.  A group that holds three of the 64 rows a wave looks at is given a slot
 // (if its slot is free); from the next trip on a row of a group with a slot is added THERE, and the slots are flushed with one global atomic each when the
-// workgroup ends.  (groupreduce by radix — k_radix.hip — does the same in its partition pass; this is for what it does not take: String keys, > 1.8 M groups.)
+// workgroup ends.  (groupreduce by radix — k_radix.hip — does the same in its partition pass; this is for what it does not take: String keys, > 2.4 M groups.)
 template <int NG, int SRC, int OPK, bool W8>
 __global__ __launch_bounds__(NG > kGroupLds ? 1024 : kBlock) void k_group_acc(const AccArgs A) {
   __shared__ uint64_t lcnt[NG ? NG : (int)kHotGroups], lval[NG ? NG : (int)kHotGroups];      // (NG = 0: the hot groups' slots)

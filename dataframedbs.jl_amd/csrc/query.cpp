@@ -1599,7 +1599,7 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
   int kbits = 9;                                                         // (512 partitions at least: one workgroup reduces one partition, and there are 256 CUs)
   while (kbits < 10 && ng / (1ll << kbits) > 1200) kbits++;              // (a 4096-slot table at 30 % load)
-  if (ng / (1ll << kbits) > 1800) return false;
+  if ((mark ? *ng_io : ng) / (1ll << kbits) > 2400) return false;        // (59 % load: the claims stop a table at 7/8, and that raises the abort word)
   const int P = 1 << kbits;
   const int dt = dt_base(kc.dtype);
   struct Res { dfdb_ctx* ctx; DevBuf res; ~Res() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; res.release(); } } tmp{ctx, {}};
@@ -1743,7 +1743,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
     // more groups than the LDS accumulators of any accumulate pass hold: by radix (group_radix) — which needs EVERY group's first row in the bitmap: a table made
     // from the head of the column / a prefix of the rows is made again from all of them first
-    if (!radix_failed && !T.is_str && ng > 9216 && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 1800 * 1024) {
+    if (!radix_failed && !T.is_str && ng > 9216 && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 2400 * 1024) {
       const bool partial = head_table || T.optimistic;          // unique looked at the head of the column / a prefix of the rows: not every group's first row is marked
       if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
       radix_failed = true;
