@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of the three radix passes of unique (k_radix.hip) at 1e9 rows / 1e6 distinct values: separate --pmc passes, kernel trace only.
-# $1 = "mem" collects only the HBM traffic counters (one counter per pass, as the guide's HBM section prescribes)
+# $1 = "mem" collects only the HBM traffic counters (one counter per pass, as the guide's HBM section prescribes); $2 = "group": groupreduce over 5e4 groups instead of unique
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r6/radix_pmc
 rm -rf $OUT; mkdir -p $OUT
@@ -9,7 +9,8 @@ else SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_A
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o r -- python3 $GRAFT_REPO_ROOT/tools/r6_radix_xp.py > $OUT/p$i.log 2>&1
+  PROG=$GRAFT_REPO_ROOT/tools/r6_radix_xp.py; if [ "$2" = "group" ]; then PROG=$GRAFT_REPO_ROOT/tools/r6_groupreduce_many.py; export DFDB_ONE_LEG=1; fi
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o r -- python3 $PROG > $OUT/p$i.log 2>&1
   echo "pass $i ($set): exit $?" >> $OUT/passes.txt
 done
 cd $OUT && python3 - <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/r6/radix_pmc.txt
