@@ -1591,17 +1591,16 @@ void query_unique(dfdb_query* q, int32_t p) { unique_impl(q, p, nullptr); }
 // for the tables, a skewed column, no room — the caller's accumulate pass (global atomics) runs.  85-135 ms -> see profiles/r6_groupreduce_radix.txt.
 // mark: q's bitmap does NOT hold every group's first row yet (unique looked at the head of the column only): the table pass marks them itself — the bitmap is
 // cleared first, scanned afterwards, and *ng_io becomes the number of groups; on false the bitmap is whatever the pass left (the caller restores the selection).
-static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int op, int64_t nsel, int64_t* ng_io, const uint64_t* sel, bool mark) {
+// (keys: the key column's values, their base dtype and missing bits — or a dictionary's 16-bit codes)
+static bool group_radix(dfdb_query* q, const void* keys, int dt, const uint64_t* kmiss, const Column* vc, int op, int64_t nsel, int64_t* ng_io, const uint64_t* sel, bool mark) {
   int64_t ng = mark ? *ng_io + *ng_io / 4 + 1024 : *ng_io;                // (marking: an estimate from the head — the tables are sized with room to spare)
   dfdb_table* t = q->t; dfdb_ctx* ctx = t->ctx; hipStream_t s = ctx->stream;
   const int64_t mode = ctx_option(ctx, "unique_radix", 1);
-  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || dt_base(kc.dtype) == DFDB_STRING) return false;
-  const uint64_t* kmiss = dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr;
+  if (mode == 0 || t->nrows >= (1ll << 32) - 8192 || dt == DFDB_STRING) return false;
   int kbits = 9;                                                         // (512 partitions at least: one workgroup reduces one partition, and there are 256 CUs)
   while (kbits < 10 && ng / (1ll << kbits) > 1200) kbits++;              // (a 4096-slot table at 30 % load)
   if ((mark ? *ng_io : ng) / (1ll << kbits) > 2400) return false;        // (59 % load: the claims stop a table at 7/8, and that raises the abort word)
   const int P = 1 << kbits;
-  const int dt = dt_base(kc.dtype);
   struct Res { dfdb_ctx* ctx; DevBuf res; ~Res() { (void)hipStreamSynchronize(ctx->stream); RecycleScope rs; res.release(); } } tmp{ctx, {}};
   RadixRun run(ctx, kbits);
   if (!run.prepare(nsel, true, 128)) return false;
@@ -1619,11 +1618,11 @@ static bool group_radix(dfdb_query* q, const Column& kc, const Column* vc, int o
   // a key that a large part of the rows hold is reduced by the partition pass itself (k_radix.hip, hot keys: the form this replaces sent every one of its rows
   // through a global atomic on ONE address — 3.6 s per 1e9 rows with a key that 30 % of them hold); the kernels that do so are 0.8-1.1 ms slower where nothing is
   // hot, so the sample picks: some partition above THREE average ones, and they run
-  const int sk = run.skewed(sel, kc.data.p, dt, kmiss, t->nrows, 3);
+  const int sk = run.skewed(sel, keys, dt, kmiss, t->nrows, 3);
   if (sk < 0) return false;
   if (sk) prof_note(ctx, "group_radix.skewed");
   { LaunchTimer lt(ctx, "radix_partition");
-    if (!launch_radix_partition(s, sel, kc.data.p, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g, sk != 0)) return false; }
+    if (!launch_radix_partition(s, sel, keys, dt, kmiss, t->nrows, kbits, C, pool, recs.as<uint32_t>(), aux, &g, sk != 0)) return false; }
   if (mark) {
     HIP_CHECK(hipMemsetAsync(q->bitmap.p, 0, padded_words(t->nrows) * 8, s));
     HIP_CHECK(hipMemsetAsync(q->tile_counts.p, 0, (size_t)ceil_div(t->nrows, kTileRows) * 4, s));
@@ -1689,7 +1688,16 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
   HIP_CHECK(hipMemcpyAsync(q->gr_sel.p, q->bitmap.p, nw * 8, hipMemcpyDeviceToDevice, s));
   if (kc.dict_n > 0) {                                       // K9: group by the dictionary codes
     DevBuf& rank = q->du_rank;
-    const int64_t ng = dict_unique(q, kc, &rank);
+    int64_t ng = dict_unique(q, kc, &rank);
+    // more codes in use than LDS accumulators hold: the codes are the keys of the radix form (the first occurrences are in the bitmap already)
+    if (ng > 9216 && group_radix(q, kc.dict_codes.p, DFDB_U16, nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), false)) {
+      launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
+      stream_wait(ctx);
+      q->gr_n = ng; q->gr_state = 2;
+      if (ngroups) *ngroups = ng;
+      if (key_bytes) *key_bytes = query_string_bytes(q, key_p);
+      return;
+    }
     q->gr_cnt.ensure((size_t)ng * 8 + 64); q->gr_val.ensure((size_t)ng * 8 + 64);
     const uint64_t init = op == DFDB_AGG_MIN ? ~0ull : 0ull;
     HIP_CHECK(hipMemsetAsync(q->gr_cnt.p, 0, (size_t)ng * 8 + 64, s));
@@ -1723,7 +1731,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     unique_impl(q, key_p, &T);
     if (T.group_estimate > 0) {                                  // the first chunk of rows promises more groups than any accumulate pass's LDS holds: by radix, first rows and all
       ng = T.group_estimate;
-      if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), true)) break;
+      if (group_radix(q, kc.data.p, dt_base(kc.dtype), dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), true)) break;
       radix_failed = true;                                       // (skewed, too many groups, no room: the bitmap may have been cleared — everything again, the old way)
       launch_missing_mask(s, q->gr_sel.as<uint64_t>(), false, false, q->bitmap.as<uint64_t>(), q->tile_counts.as<uint32_t>(), t->nrows);
       scan_prefix(q);
@@ -1745,7 +1753,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     // from the head of the column / a prefix of the rows is made again from all of them first
     if (!radix_failed && !T.is_str && ng > 9216 && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 2400 * 1024) {
       const bool partial = head_table || T.optimistic;          // unique looked at the head of the column / a prefix of the rows: not every group's first row is marked
-      if (group_radix(q, kc, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
+      if (group_radix(q, kc.data.p, dt_base(kc.dtype), dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
       radix_failed = true;
       if (partial) {                                             // not taken, and the bitmap may have been cleared: everything again, every row looked at
         whole_dense = true; pessimistic = true;

@@ -172,3 +172,28 @@ def test_groupreduce_by_a_string_key_with_a_hot_group(dfdb_mod, ctx, stat):
             assert np.array_equal(df[stat].to_numpy(), acc)
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("stat", ["count", "sum", "max"])
+def test_groupreduce_by_a_dictionary_of_many_strings(dfdb_mod, ctx, stat):
+    """a String column with a dictionary of more than 9216 entries: its 16-bit codes are the keys of the radix form (the first occurrences come from the
+    dictionary's own pass); one string holds 35 % of the rows"""
+    rng = np.random.default_rng(13)
+    n = 900_017
+    ids = rng.integers(0, 20_000, n)
+    ids[rng.random(n) < 0.35] = 777
+    words = np.array([f"w{v:06d}" for v in range(20_000)], dtype=object)
+    s = words[ids]
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"s": list(s), "v": v}, block_size=65536, ctx=ctx)
+    try:
+        assert t.build_dictionary("s", max_entries=65535) == len(np.unique(ids))
+        df, taken = run(dfdb_mod, ctx, t, "s", None if stat == "count" else "v", stat, 1)
+        assert taken == 1
+        first_rows, cnt, acc = expect(ids.astype(np.int64).view(np.uint64), np.ones(n, bool), v, stat)
+        assert list(df["s"]) == list(s[first_rows])
+        assert np.array_equal(df["count"].to_numpy(), cnt)
+        if stat != "count":
+            assert np.array_equal(df[stat].to_numpy(), acc)
+    finally:
+        t.close()
