@@ -32,6 +32,8 @@ def expect(keys_img, sel, vals, stat):
 
 
 def image(k):
+    if k.dtype == np.float32:
+        k = k.astype(np.float64)
     if k.dtype.kind == "f":
         u = k.astype(np.float64).view(np.uint64).copy(); u[np.isnan(k)] = 0x7ff8000000000000
         return u
@@ -48,7 +50,7 @@ def run(dfdb, ctx, view, by, col, stat, radix):
     return df, taken
 
 
-@pytest.mark.parametrize("kind", ["int64", "float64", "int32", "dense", "nullable"])
+@pytest.mark.parametrize("kind", ["int64", "float64", "int32", "dense", "nullable", "int16", "float32"])
 @pytest.mark.parametrize("stat", ["count", "sum", "min", "max"])
 def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
     rng = np.random.default_rng(hash((kind, stat)) % 1000)
@@ -62,6 +64,11 @@ def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
         k[rng.random(n) < 0.005] = -0.0
     elif kind == "int32":
         k = rng.integers(-60_000, 60_000, n).astype(np.int32)
+    elif kind == "int16":
+        k = rng.integers(-16_000, 16_000, n).astype(np.int16)            # (-1 is the unstorable image of a narrow signed key too)
+    elif kind == "float32":
+        k = (rng.integers(0, 40_000, n).astype(np.float32) / np.float32(4.0))
+        k[rng.random(n) < 0.004] = np.nan
     elif kind == "dense":
         k = rng.integers(0, 300_000, n).astype(np.int64)                 # a small span: unique takes its dense form, from the head of the column first
     else:
@@ -74,10 +81,13 @@ def test_groupreduce_by_radix(dfdb_mod, ctx, kind, stat):
     vi = rng.integers(-10**12, 10**12, n).astype(np.int64)
     vf = rng.normal(size=n) * 1e3
     v32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)            # a value that is not eight bytes wide: widened where the record is written
+    vf32 = (rng.normal(size=n) * 100).astype(np.float32)                 # ... Float32: reduced as the Float64 it converts to
+    vu8 = rng.integers(0, 256, n).astype(np.uint8)
     a = rng.integers(0, 100, n).astype(np.int64)
-    t = dfdb_mod.DFTable.from_columns({"a": a, "k": kcol, "vi": vi, "vf": vf, "v32": v32}, block_size=65536, ctx=ctx)
+    t = dfdb_mod.DFTable.from_columns({"a": a, "k": kcol, "vi": vi, "vf": vf, "v32": v32, "vf32": vf32, "vu8": vu8}, block_size=65536, ctx=ctx)
     try:
-        for col, vals in (("vi", vi), ("vf", vf), ("v32", v32.astype(np.int64))):
+        narrow = (("vf32", vf32.astype(np.float64)), ("vu8", vu8.astype(np.int64))) if kind in ("int16", "float32") else ()
+        for col, vals in (("vi", vi), ("vf", vf), ("v32", v32.astype(np.int64))) + narrow:
             if stat == "count" and col != "vi":
                 continue
             for view, sel in ((t, np.ones(n, bool)), (t[("a", lambda c: c < 61), dfdb_mod.ALL], a < 61)):
