@@ -207,3 +207,28 @@ def test_groupreduce_by_a_dictionary_of_many_strings(dfdb_mod, ctx, stat):
             assert np.array_equal(df[stat].to_numpy(), acc)
     finally:
         t.close()
+
+
+def test_groupreduce_by_radix_gives_up_when_the_estimate_was_far_too_low(dfdb_mod, ctx):
+    """the first chunk of rows promises 20 000 groups, the rest of the column brings three million more: the partitions' LDS tables fill up, the table pass raises
+    the abort word, the selection is put back and the form the radix form replaces answers — the same table as always"""
+    rng = np.random.default_rng(21)
+    n = 4_200_000
+    k = np.empty(n, np.int64)
+    head = 1_100_000
+    k[:head] = rng.integers(0, 20_000, head) * 5 + 3
+    k[head:] = np.arange(n - head, dtype=np.int64) * 7 + (1 << 45)
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    t = dfdb_mod.DFTable.from_columns({"k": k, "v": v}, block_size=65536, ctx=ctx)
+    try:
+        ctx.profile(True)
+        try:
+            df = dfdb_mod.groupreduce(t, "k", "v", "sum")
+            taken, fell = ctx.profile_get("group_radix.taken")[0], ctx.profile_get("group_radix.fell_back")[0]
+        finally:
+            ctx.profile(False)
+        assert taken == 0 and fell >= 1
+        first_rows, cnt, acc = expect(image(k), np.ones(n, bool), v, "sum")
+        assert np.array_equal(df["k"].to_numpy(), k[first_rows]) and np.array_equal(df["count"].to_numpy(), cnt) and np.array_equal(df["sum"].to_numpy(), acc)
+    finally:
+        t.close()
