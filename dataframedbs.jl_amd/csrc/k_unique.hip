@@ -870,7 +870,7 @@ void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uin
 __device__ __forceinline__ uint32_t lds_slot_of(uint64_t key, uint32_t slots) {
   uint32_t h = ((uint32_t)key ^ (uint32_t)(key >> 32) * 0x85EBCA77u) * 0x9E3779B1u;
   h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
-  return (uint32_t)(((uint64_t)h * slots) >> 32);
+  return (uint32_t)(((uint64_t)h * slots) >> 32) & ~1u;      // (an EVEN slot: a probe of the accumulate pass reads two slots at a time; slots is a multiple of 4)
 }
 template <int OPK>
 __global__ __launch_bounds__(1024) void k_group_acc_hash_lds(const AccArgs A, const void* __restrict__ gkeys, uint32_t slots, int ngp) {
@@ -921,11 +921,13 @@ __global__ __launch_bounds__(1024) void k_group_acc_hash_lds(const AccArgs A, co
         else if (kk == kEmpty) g = g_unstorable;
         else {
           uint32_t h = lds_slot_of(kk, slots);
-          for (;;) {
-            const uint64_t t = lkey[h];
-            if (t == kk) { g = lgid[h]; break; }
-            if (t == kEmpty) break;                            // not among the groups: only a table made from a prefix of the rows can say that
-            h = h + 1 == slots ? 0u : h + 1;
+          for (;;) {                                             // two slots per probe (one 16-byte read): half the trips of a loop the wave leaves with its slowest lane
+            const ulonglong2 t = *(const ulonglong2*)&lkey[h];
+            if (t.x == kk) { g = lgid[h]; break; }
+            if (t.x == kEmpty) break;                          // not among the groups: only a table made from a prefix of the rows can say that
+            if (t.y == kk) { g = lgid[h + 1]; break; }
+            if (t.y == kEmpty) break;
+            h = h + 2 >= slots ? 0u : h + 2;
           }
         }
         if (g >= (uint64_t)A.ngroups) { unknown = true; g = kEmpty; }
