@@ -1146,6 +1146,7 @@ void launch_dict_first_rows(hipStream_t s, const uint64_t* sel, const uint16_t* 
 void launch_set_rows(hipStream_t s, const uint64_t* rows, int n, uint64_t* bitmap, uint32_t* tile_counts);
 void launch_group_accumulate_codes(hipStream_t s, const uint64_t* sel, const uint16_t* codes, const uint32_t* rank_of_code, const void* valcol, int valdt, int op,
                                    int64_t nrows, uint64_t* cnt, uint64_t* val, int64_t ngroups, uint64_t val_init);
+constexpr int64_t kGroupsInLds = 9216;      // groups a workgroup's LDS accumulators hold (k_unique.hip kGroupLdsBig): above it groupreduce goes by radix
 // what unique leaves behind for groupreduce: the hash table {key, first row} (Strings: + where one holder's bytes are), or — integer keys of a small
 // range — the first row per value; groupreduce turns the rows into group numbers in place
 struct UniqueTables {
@@ -1523,7 +1524,7 @@ static void unique_hashed(dfdb_query* q, const Column& col, int64_t cnt, UniqueT
       if (c == 0) { claims_c0 = st[0]; rows_c0 = r; }
       if (c == 0 && !is_str && T.group_probe && r > 0) {               // groupreduce asks: more groups than LDS accumulators hold?  Then it reduces by radix, first rows included
         const double D = estimate_distinct(st[0], r, cnt);
-        if (D > 9216.0) { T.group_estimate = (int64_t)D; return; }
+        if (D > (double)kGroupsInLds) { T.group_estimate = (int64_t)D; return; }
       }
       if (c == 0 && !is_str && !T.defer_verify && unique_radix(q, col, cnt, T, st[0], r)) return;      // the radix-partitioned form took it: q's bitmap holds the first occurrences
       else if (c == 1 && !(st[0] == claims_c0 && r >= rows_c0 + 65536)) claims_c0 = ~0ull;
@@ -1690,7 +1691,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     DevBuf& rank = q->du_rank;
     int64_t ng = dict_unique(q, kc, &rank);
     // more codes in use than LDS accumulators hold: the codes are the keys of the radix form (the first occurrences are in the bitmap already)
-    if (ng > 9216 && group_radix(q, kc.dict_codes.p, DFDB_U16, nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), false)) {
+    if (ng > kGroupsInLds && group_radix(q, kc.dict_codes.p, DFDB_U16, nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), false)) {
       launch_group_finish(s, q->gr_val.as<uint64_t>(), ng, q->gr_kind, op);
       stream_wait(ctx);
       q->gr_n = ng; q->gr_state = 2;
@@ -1751,7 +1752,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
     HIP_CHECK(hipMemsetAsync(q->gr_val.p, op == DFDB_AGG_MIN ? 0xFF : 0, (size_t)ng * 8 + 64, s));
     // more groups than the LDS accumulators of any accumulate pass hold: by radix (group_radix) — which needs EVERY group's first row in the bitmap: a table made
     // from the head of the column / a prefix of the rows is made again from all of them first
-    if (!radix_failed && !T.is_str && ng > 9216 && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 2400 * 1024) {
+    if (!radix_failed && !T.is_str && ng > kGroupsInLds && ctx_option(ctx, "unique_radix", 1) != 0 && ng <= 2400 * 1024) {
       const bool partial = head_table || T.optimistic;          // unique looked at the head of the column / a prefix of the rows: not every group's first row is marked
       if (group_radix(q, kc.data.p, dt_base(kc.dtype), dt_nullable(kc.dtype) ? kc.missing.as<uint64_t>() : nullptr, vc, op, nsel, &ng, q->gr_sel.as<uint64_t>(), partial)) break;
       radix_failed = true;
@@ -1777,7 +1778,7 @@ void query_groupreduce(dfdb_query* q, int32_t key_p, int32_t val_p, int32_t op, 
       else {
         // few groups of an 8-byte key: their keys (the key column at the first rows q's bitmap now holds, i.e. in group order) for the accumulate pass's LDS table
         const void* gkeys = nullptr;
-        if (ng <= 9216 && dt_width(kc.dtype) == 8) {
+        if (ng <= kGroupsInLds && dt_width(kc.dtype) == 8) {
           q->gr_keys.ensure((size_t)ng * 8 + 64);
           launch_gather(s, q->bitmap.as<uint64_t>(), q->prefix.as<uint64_t>(), kc.data.p, q->gr_keys.p, 8, t->nrows, ng);
           gkeys = q->gr_keys.p;
